@@ -1,0 +1,255 @@
+"""ctypes binding of the CPU oracle (oracle/ndb_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package (neurondb_amd/).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+TID_DTYPE = np.dtype([("bi_hi", "<u2"), ("bi_lo", "<u2"), ("posid", "<u2")])
+
+
+class NdboTid(C.Structure):
+    _fields_ = [("bi_hi", C.c_uint16), ("bi_lo", C.c_uint16), ("posid", C.c_uint16)]
+
+
+class NdboIvf(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int), ("nlists", C.c_int), ("maxoff", C.c_int),
+        ("centroids", C.c_void_p), ("centroid_dim", C.c_void_p),
+        ("list_off", C.c_void_p), ("vecs", C.c_void_p), ("tids", C.c_void_p),
+        ("live", C.c_void_p),
+    ]
+
+
+class NdboHnsw(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int), ("m", C.c_int), ("ef_construction", C.c_int),
+        ("entry_point", C.c_uint32), ("entry_level", C.c_int), ("max_level", C.c_int),
+        ("inserted", C.c_int64), ("nblocks", C.c_uint32), ("cap_blocks", C.c_uint32),
+        ("vecs", C.POINTER(C.c_float)), ("heap_tids", C.POINTER(NdboTid)),
+        ("levels", C.POINTER(C.c_int)), ("ncount", C.POINTER(C.c_int16)),
+        ("nbrs", C.POINTER(C.c_uint32)),
+    ]
+
+
+def build(native: bool = False) -> str:
+    """Compile the oracle with oracle/Makefile; returns the .so path."""
+    target = "libndboracle_native.so" if native else "libndboracle.so"
+    path = os.path.join(_BUILD, target)
+    src = os.path.join(_HERE, "ndb_oracle.c")
+    hdr = os.path.join(_HERE, "ndb_oracle.h")
+    stale = (not os.path.exists(path)) or any(
+        os.path.getmtime(s) > os.path.getmtime(path) for s in (src, hdr))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, os.path.join("_build", target)],
+                              stdout=subprocess.DEVNULL)
+    return path
+
+
+_LIBS: dict = {}
+
+
+def lib(native: bool = False):
+    key = bool(native)
+    if key in _LIBS:
+        return _LIBS[key]
+    L = C.CDLL(build(native))
+    f, i, p = C.c_float, C.c_int, C.c_void_p
+    sig = {
+        "ndbo_ivf_distance": (f, [f32p, f32p, i, i]),
+        "ndbo_ivf_l2sq": (f, [f32p, f32p, i]),
+        "ndbo_hnsw_distance": (f, [f32p, f32p, i, i, C.POINTER(C.c_int)]),
+        "ndbo_op_l2_scalar": (f, [f32p, f32p, i]),
+        "ndbo_op_ip_scalar": (f, [f32p, f32p, i]),
+        "ndbo_op_cosine_scalar": (f, [f32p, f32p, i]),
+        "ndbo_op_l2_simd": (f, [f32p, f32p, i, i]),
+        "ndbo_op_ip_simd": (f, [f32p, f32p, i, i]),
+        "ndbo_op_cosine_simd": (f, [f32p, f32p, i, i]),
+        "ndbo_op_l2": (f, [f32p, f32p, i, i]),
+        "ndbo_op_ip": (f, [f32p, f32p, i, i]),
+        "ndbo_op_cosine": (f, [f32p, f32p, i, i]),
+        "ndbo_float4_to_fp16": (C.c_uint16, [f]),
+        "ndbo_fp16_to_float": (f, [C.c_uint16]),
+        "ndbo_halfvec_l2": (f, [u16p, u16p, i]),
+        "ndbo_halfvec_cosine": (f, [u16p, u16p, i]),
+        "ndbo_halfvec_ip": (f, [u16p, u16p, i]),
+        "ndbo_ivf_select_clusters": (i, [C.POINTER(NdboIvf), f32p, i, i32p]),
+        "ndbo_ivf_collect_candidates": (i, [C.POINTER(NdboIvf), f32p, i, i32p, i, i, C.c_int64,
+                                             p, f32p, C.POINTER(C.c_int64)]),
+        "ndbo_ivf_search": (i, [C.POINTER(NdboIvf), f32p, i, i, i, C.c_int64, p, f32p,
+                                 C.POINTER(C.c_int64)]),
+        "ndbo_kmeans": (i, [f32p, i, i, i, i, f, f32p, i32p, i32p, C.POINTER(f)]),
+        "ndbo_kmeans_assign": (None, [f32p, i, i, f32p, i, i32p, i32p]),
+        "ndbo_kmeans_update": (None, [f32p, i, i, i32p, i32p, i, f32p]),
+        "ndbo_kmeans_cost": (f, [f32p, i, i, i32p, f32p]),
+        "ndbo_ivf_assign": (i, [f32p, p, i, i, i, f32p, C.POINTER(f)]),
+        "ndbo_hnsw_create": (C.POINTER(NdboHnsw), [i, i, i, C.c_uint32]),
+        "ndbo_hnsw_free": (None, [C.POINTER(NdboHnsw)]),
+        "ndbo_hnsw_search": (i, [C.POINTER(NdboHnsw), f32p, i, i, i, u32p, f32p,
+                                  C.POINTER(C.c_int64)]),
+        "ndbo_hnsw_insert": (C.c_uint32, [C.POINTER(NdboHnsw), f32p, NdboTid, i]),
+        "ndbo_hnsw_level_from_uniform": (i, [C.c_double, f]),
+        "ndbo_selection_topk": (i, [f32p, C.c_int64, i, i64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIBS[key] = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class IvfImage:
+    """Flat IVF image handed to the oracle (see ndbo_ivf in ndb_oracle.h)."""
+
+    def __init__(self, centroids, list_off, vecs, tids, nlists=None, live=None, centroid_dim=None):
+        self.centroids = _f32(centroids)
+        self.vecs = _f32(vecs)
+        self.dim = int(self.centroids.shape[1])
+        self.maxoff = int(self.centroids.shape[0])
+        self.nlists = int(nlists if nlists is not None else self.maxoff)
+        self.list_off = np.ascontiguousarray(list_off, dtype=np.int64)
+        self.tids = np.ascontiguousarray(tids, dtype=TID_DTYPE)
+        self.live = None if live is None else np.ascontiguousarray(live, dtype=np.uint8)
+        self.centroid_dim = None if centroid_dim is None else np.ascontiguousarray(centroid_dim, np.int32)
+        s = NdboIvf()
+        s.dim, s.nlists, s.maxoff = self.dim, self.nlists, self.maxoff
+        s.centroids = self.centroids.ctypes.data
+        s.centroid_dim = None if self.centroid_dim is None else self.centroid_dim.ctypes.data
+        s.list_off = self.list_off.ctypes.data
+        s.vecs = self.vecs.ctypes.data if self.vecs.size else None
+        s.tids = self.tids.ctypes.data if self.tids.size else None
+        s.live = None if self.live is None else self.live.ctypes.data
+        self.c = s
+
+    def select_clusters(self, query, nprobe, native=False):
+        sel = np.zeros(max(nprobe, 1), dtype=np.int32)
+        lib(native).ndbo_ivf_select_clusters(C.byref(self.c), _f32(query), nprobe, sel)
+        return sel[:nprobe]
+
+    def search(self, query, strategy=1, nprobe=10, k=10, max_candidates=0, native=False):
+        """Returns (tids[k] structured, dist[k], n_scored)."""
+        out_t = np.zeros(max(k, 1), dtype=TID_DTYPE)
+        out_d = np.zeros(max(k, 1), dtype=np.float32)
+        ns = C.c_int64(0)
+        n = lib(native).ndbo_ivf_search(C.byref(self.c), _f32(query), strategy, nprobe, k,
+                                        int(max_candidates), out_t.ctypes.data, out_d, C.byref(ns))
+        return out_t[:n], out_d[:n], ns.value
+
+
+def tids_from_rows(rows):
+    """Synthetic heap TIDs for row numbers: block = row // 64, offset = row % 64 + 1."""
+    rows = np.asarray(rows, dtype=np.int64)
+    t = np.zeros(rows.shape, dtype=TID_DTYPE)
+    blk = rows // 64
+    t["bi_hi"] = (blk >> 16) & 0xFFFF
+    t["bi_lo"] = blk & 0xFFFF
+    t["posid"] = rows % 64 + 1
+    return t
+
+
+def tids_to_u64(t):
+    """Pack structured TIDs into uint64 (bi_hi<<32 | bi_lo<<16 | posid) for comparisons."""
+    t = np.asarray(t)
+    return (t["bi_hi"].astype(np.uint64) << np.uint64(32)) | \
+           (t["bi_lo"].astype(np.uint64) << np.uint64(16)) | t["posid"].astype(np.uint64)
+
+
+def kmeans(data, k, max_iter=50, threshold=0.001, native=False):
+    data = _f32(data)
+    n, dim = data.shape
+    cent = np.zeros((k, dim), dtype=np.float32)
+    asg = np.zeros(n, dtype=np.int32)
+    cnt = np.zeros(k, dtype=np.int32)
+    cost = C.c_float(0)
+    iters = lib(native).ndbo_kmeans(data, n, dim, k, max_iter, np.float32(threshold), cent, asg, cnt,
+                                    C.byref(cost))
+    return cent, asg, cnt, iters, cost.value
+
+
+def ivf_assign_all(centroids, vecs, native=False):
+    """Insert-time assignment (ivf_am.c:905-935) of every row; returns list ids."""
+    centroids = _f32(centroids)
+    vecs = _f32(vecs)
+    L = lib(native)
+    nl, dim = centroids.shape
+    out = np.empty(len(vecs), dtype=np.int32)
+    for r in range(len(vecs)):
+        out[r] = L.ndbo_ivf_assign(centroids, None, nl, nl, dim, vecs[r], None)
+    return out
+
+
+def build_ivf_image(base, nlists, max_iter=50, native=False):
+    """Intended-mode IVF build: sample first min(10000, 100*nlists) rows,
+    k-means, assign every row with the insert-time rule, lists in insertion order."""
+    base = _f32(base)
+    n = len(base)
+    ns = min(10000, nlists * 100, n)
+    cent, _, _, iters, cost = kmeans(base[:ns], nlists, max_iter=max_iter, native=native)
+    asg = ivf_assign_all(cent, base, native=native)
+    order = np.argsort(asg, kind="stable")
+    counts = np.bincount(asg, minlength=nlists)
+    off = np.zeros(nlists + 1, dtype=np.int64)
+    off[1:] = np.cumsum(counts)
+    return IvfImage(cent, off, base[order], tids_from_rows(order)), asg, iters
+
+
+class HnswGraph:
+    def __init__(self, dim, m=16, ef_construction=200, cap_nodes=1024, native=False):
+        self.L = lib(native)
+        self.g = self.L.ndbo_hnsw_create(dim, m, ef_construction, cap_nodes)
+        self.dim, self.m, self.cap = dim, m, cap_nodes
+
+    def __del__(self):
+        try:
+            self.L.ndbo_hnsw_free(self.g)
+        except Exception:
+            pass
+
+    def insert(self, vec, row, level):
+        t = tids_from_rows(np.array([row]))[0]
+        return self.L.ndbo_hnsw_insert(self.g, _f32(vec), NdboTid(int(t["bi_hi"]), int(t["bi_lo"]),
+                                                                   int(t["posid"])), int(level))
+
+    def search(self, query, strategy=1, ef=64, k=10):
+        ob = np.zeros(max(k, 1), dtype=np.uint32)
+        od = np.zeros(max(k, 1), dtype=np.float32)
+        ns = C.c_int64(0)
+        n = self.L.ndbo_hnsw_search(self.g, _f32(query), strategy, ef, k, ob, od, C.byref(ns))
+        return ob[:n], od[:n], ns.value
+
+    # views of the graph arrays (for loading the device mirror)
+    def arrays(self):
+        g = self.g.contents
+        nb = g.nblocks
+        dim, m = g.dim, g.m
+        vecs = np.ctypeslib.as_array(g.vecs, shape=(g.cap_blocks * dim,))[: nb * dim].reshape(nb, dim).copy()
+        levels = np.ctypeslib.as_array(g.levels, shape=(g.cap_blocks,))[:nb].copy()
+        ncount = np.ctypeslib.as_array(g.ncount, shape=(g.cap_blocks * 16,))[: nb * 16].reshape(nb, 16).copy()
+        nbrs = np.ctypeslib.as_array(g.nbrs, shape=(g.cap_blocks * 16 * 2 * m,))[: nb * 16 * 2 * m] \
+            .reshape(nb, 16, 2 * m).copy()
+        tids = np.ctypeslib.as_array(C.cast(g.heap_tids, C.POINTER(C.c_uint16)),
+                                     shape=(g.cap_blocks * 3,))[: nb * 3].reshape(nb, 3).copy()
+        return dict(vecs=vecs, levels=levels, ncount=ncount, nbrs=nbrs, tids=tids,
+                    entry_point=int(g.entry_point), entry_level=int(g.entry_level), nblocks=int(nb),
+                    m=int(m), dim=int(dim))
