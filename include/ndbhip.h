@@ -1,0 +1,235 @@
+/*
+ * ndbhip.h — C ABI of the MI355X (gfx950) vector-distance engine that sits
+ * behind NeuronDB's index access methods.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, int status
+ * codes, no PostgreSQL and no torch types.  Each entry point names the
+ * reference interface it replaces (paths relative to NeuronDB/ in the
+ * reference tree).  The reference-side binding a maintainer would add
+ * (ivf_am.c / hnsw_am.c calling these) is shown in INTEGRATION.md.
+ *
+ * Conventions (same as the reference's GPU vtable,
+ * include/neurondb_gpu_backend.h:24-26 and src/gpu/common/gpu_distance.c:50-51):
+ *   - every function returns 0 on success and a negative NDBHIP_ERR_* code on
+ *     failure; nothing longjmps or throws across this boundary;
+ *   - ndbhip_last_error() returns a thread-local message for the last failure;
+ *   - inputs are copied (or consumed) before a function returns: the library
+ *     never keeps a pointer into palloc'd or buffer-page memory;
+ *   - there is NO CPU fallback inside the library: without a usable HIP device
+ *     every compute entry point fails with NDBHIP_ERR_NODEVICE and the caller
+ *     decides (neurondb.compute_mode, src/gpu/common/gpu_core.c:268-284).
+ *   - HIP is initialised lazily by ndbhip_init() in the calling process, never
+ *     at library load (PostgreSQL loads the library pre-fork:
+ *     src/worker/worker_init.c:77-84).
+ *
+ * Heap TIDs cross the boundary as PostgreSQL ItemPointerData images
+ * (6 bytes: bi_hi, bi_lo, ip_posid, each little-endian uint16).  On the device
+ * they are held as uint64 = bi_hi | bi_lo << 16 | ip_posid << 32.
+ */
+#ifndef NDBHIP_H
+#define NDBHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDBHIP_ABI_VERSION 1
+
+/* status codes */
+#define NDBHIP_OK               0
+#define NDBHIP_ERR_INVALID     (-1)	/* bad argument (reference: ereport(ERROR) on bad params) */
+#define NDBHIP_ERR_NODEVICE    (-2)	/* no HIP device / not initialised */
+#define NDBHIP_ERR_HIP         (-3)	/* a HIP runtime call failed */
+#define NDBHIP_ERR_NOMEM       (-4)
+#define NDBHIP_ERR_STATE       (-5)	/* index not loaded / wrong lifecycle order */
+#define NDBHIP_ERR_UNSUPPORTED (-6)	/* e.g. hnsw strategy not in {1,2,3}: hnsw_am.c:1339-1343 */
+
+/* ordering-operator strategy numbers as the AMs switch on them
+ * (src/index/ivf_am.c:1559-1591, src/index/hnsw_am.c:1310-1344) */
+#define NDBHIP_STRATEGY_L2      1
+#define NDBHIP_STRATEGY_COSINE  2
+#define NDBHIP_STRATEGY_IP      3	/* hnsw: in the reference; ivf: new surface (quirk Q2) */
+
+#define NDBHIP_INVALID_BLOCK 0xFFFFFFFFu
+#define NDBHIP_HNSW_MAX_LEVEL 16	/* src/index/hnsw_am.c:85 */
+#define NDBHIP_MAX_K       1024		/* neurondb.hnsw_k upper bound is 1000: src/util/neurondb_guc.c:174 */
+#define NDBHIP_MAX_NPROBE  1024		/* neurondb.ivf_probes upper bound is 1000: src/util/neurondb_guc.c:187 */
+#define NDBHIP_MAX_EF      1024
+
+typedef struct ndbhip_ivf ndbhip_ivf;	/* device-resident mirror of one ivf index */
+typedef struct ndbhip_hnsw ndbhip_hnsw;	/* device-resident mirror of one hnsw index */
+
+/* ------------------------------------------------------------------ */
+/* Runtime (replaces ndb_gpu_backend.init/shutdown/device_count/set_device/
+ * stream_*: include/neurondb_gpu_backend.h:28-65; lazy init pattern of
+ * ndb_gpu_init_if_needed: src/gpu/common/gpu_core.c:240-310)           */
+/* ------------------------------------------------------------------ */
+int			ndbhip_abi_version(void);
+int			ndbhip_device_count(void);		/* >= 0, or NDBHIP_ERR_NODEVICE; does not create a context */
+int			ndbhip_init(int device);		/* idempotent per process */
+int			ndbhip_shutdown(void);
+const char *ndbhip_last_error(void);
+/* Run all work on this hipStream_t (NULL = the library's own stream). */
+int			ndbhip_set_stream(void *hip_stream);
+int			ndbhip_synchronize(void);
+
+/* Per-process counters (replaces GPUStats, include/neurondb_gpu.h:34-42). */
+typedef struct ndbhip_stats
+{
+	uint64_t	queries;			/* queries searched */
+	uint64_t	rows_scored;		/* distance evaluations on the device */
+	uint64_t	bytes_scored;		/* algorithmic bytes = rows_scored * dim * elem size */
+	uint64_t	scan_launches;		/* launches of the dominant kernel (list scan / hnsw walk) */
+	double		scan_kernel_ms;		/* HIP-event time of those launches (only while profiling is on) */
+}			ndbhip_stats;
+int			ndbhip_stats_get(ndbhip_stats *out);
+int			ndbhip_stats_reset(void);
+int			ndbhip_profile(int on);			/* bracket the dominant kernel with HIP events */
+
+/* ------------------------------------------------------------------ */
+/* IVF mirror lifecycle.  Replaces the page walk of ivfSelectClusters /
+ * ivfCollectCandidates (src/index/ivf_am.c:1597-1909): centroids page →
+ * `centroids`, list page chains → one packed row block per list, in chain
+ * order, dead / dim-mismatched items already dropped by the packer.       */
+/* ------------------------------------------------------------------ */
+int			ndbhip_ivf_create(int dim, int nlists, ndbhip_ivf **out);
+int			ndbhip_ivf_destroy(ndbhip_ivf *ix);
+
+/* centroids: host, row-major [ncentroids * dim] (ncentroids = items on the
+ * centroid page(s), "maxoff" in ivf_am.c:1646-1652; may be < nlists). */
+int			ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncentroids);
+
+/*
+ * Load every list in one call (host pointers).
+ *   list_len[ncentroids]  GLOBAL number of live entries of each list
+ *   owned[ncentroids]     nullable; owned[L]==0 → this process holds no rows of
+ *                         list L (multi-GPU sharding, one process per GPU)
+ *   rows                  the owned lists' vectors, list-major, chain order
+ *   tids6                 matching ItemPointerData images, 6 bytes per row
+ *   nrows                 number of rows in `rows`/`tids6` (= sum of owned list_len)
+ */
+int			ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
+							const float *rows, const uint8_t *tids6, int64_t nrows);
+/* Same, rows/tids already in HBM (d_tids as uint64 device format). The arrays
+ * are adopted without a copy and must outlive the index. */
+int			ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
+								   const float *d_rows, const uint64_t *d_tids, int64_t nrows);
+/* aminsert: append one entry to the tail of list `list_id`
+ * (src/index/ivf_am.c:954-1157) — see ndbhip_ivf_assign for the list choice. */
+int			ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6);
+
+int64_t		ndbhip_ivf_nrows(const ndbhip_ivf *ix);			/* rows resident on this device */
+int64_t		ndbhip_ivf_max_candidates(const ndbhip_ivf *ix, int nprobe);	/* sum of the nprobe longest lists */
+
+/* ------------------------------------------------------------------ */
+/* IVF search = ivfgettuple's first-call work (src/index/ivf_am.c:1976-1999:
+ * ivfSelectClusters + ivfCollectCandidates) for nq queries at once.
+ *   strategy        1 L2, 2 cosine, 3 -IP (new), anything else L2 (:1583)
+ *   nprobe          so->nprobe (the reference pins it to 10: quirk Q4)
+ *   k               so->k (the reference pins it to 10: quirk Q3)
+ *   max_candidates  k*10 reproduces the reference's cap (:1743); <= 0 = no cap
+ * Results per query q: out_count[q] <= k entries at out_*[q*k ...], in the
+ * exact order the reference's selection sort returns them.                 */
+/* ------------------------------------------------------------------ */
+int			ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy,
+							  int nprobe, int k, int64_t max_candidates,
+							  uint8_t *out_tids6, float *out_dist, int *out_count);
+/* Device-pointer form (inputs and outputs in HBM, asynchronous on the stream). */
+int			ndbhip_ivf_search_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy,
+									 int nprobe, int k, int64_t max_candidates,
+									 uint64_t *d_out_tids, float *d_out_dist, int *d_out_count);
+
+/* Centroid selection only (ivfSelectClusters, :1597-1717): out_probes[nq*nprobe]. */
+int			ndbhip_ivf_select_clusters(ndbhip_ivf *ix, const float *queries, int nq, int nprobe,
+									   int *out_probes);
+
+/*
+ * Sharded search (one process per GPU).  Each rank scans only the lists it
+ * owns and emits, per query, the candidates that can still reach the global
+ * top-k: fixed-size records {key, pos, tid}, NDBHIP_PARTIAL_CAP(k) per query.
+ * After an all-gather of the records, ndbhip_merge_topk_* replays the
+ * reference's selection sort on the union, so the merged result equals the
+ * single-process result entry for entry.
+ */
+typedef struct ndbhip_cand
+{
+	uint32_t	key;			/* order-preserving image of the float4 distance */
+	uint32_t	pos;			/* index in the reference's candidates[] array */
+	uint64_t	tid;
+}			ndbhip_cand;
+#define NDBHIP_PARTIAL_CAP(k) (3 * (k))
+int			ndbhip_ivf_search_partial_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy,
+											 int nprobe, int k, int64_t max_candidates,
+											 ndbhip_cand *d_out_cand, int *d_out_ncand, int64_t *d_out_total);
+/* d_cand: [world][nq][cap] records, d_ncand: [world][nq], d_total: [nq]
+ * (number of candidates over all ranks, identical on every rank). */
+int			ndbhip_merge_topk_device(const ndbhip_cand *d_cand, const int *d_ncand, const int64_t *d_total,
+									 int world, int nq, int k, int cap,
+									 uint64_t *d_out_tids, float *d_out_dist, int *d_out_count);
+/* Host form of the same merge (results already on the host, e.g. gathered by
+ * the PostgreSQL backend from several device-owner processes). Pure C, needs
+ * no device. */
+int			ndbhip_merge_topk_host(const ndbhip_cand *cand, const int *ncand, const int64_t *total,
+								   int world, int nq, int k, int cap,
+								   uint64_t *out_tids, float *out_dist, int *out_count);
+
+/* ------------------------------------------------------------------ */
+/* IVF build (src/index/ivf_am.c:501-745, 2070-2294) and insert-time
+ * assignment (:905-935).                                               */
+/* ------------------------------------------------------------------ */
+/* kmeans_init + kmeans_run on the first n sample rows. d_samples in HBM,
+ * centroids out (device) [k*dim]; returns iterations in *out_iters. */
+int			ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter,
+								 float threshold, float *d_centroids, int *d_assign, int *d_counts,
+								 int *out_iters, float *out_cost);
+/* Nearest centroid by sqrtf(fp32 L2), strict <, first wins (:915-934). */
+int			ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim,
+									 const float *d_rows, int64_t nrows, int *d_out_list);
+/* Whole build in HBM: sample first min(10000, 100*nlists) rows, k-means,
+ * assign all nrows, pack lists in insertion (heap) order, adopt into ix. */
+int			ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids,
+									int64_t nrows, int max_iter, int *out_iters);
+
+/* ------------------------------------------------------------------ */
+/* HNSW mirror and search (src/index/hnsw_am.c:1545-2080).  Node b = block
+ * number b (block 0 is the meta page and is never a node).
+ *   vecs       [nblocks * dim], row b = node b's vector
+ *   levels     [nblocks]
+ *   ncount     [nblocks * 16]  neighborCount[level]
+ *   nbr_off    [nblocks + 1]   start of node b's neighbour slots in `nbrs`
+ *   nbrs       node b holds (levels[b]+1) * 2m slots, level-major, unused = 0xFFFFFFFF
+ *   tids6      [nblocks * 6]   heapPtr of each node                     */
+/* ------------------------------------------------------------------ */
+int			ndbhip_hnsw_create(int dim, int m, ndbhip_hnsw **out);
+int			ndbhip_hnsw_destroy(ndbhip_hnsw *g);
+int			ndbhip_hnsw_load(ndbhip_hnsw *g, uint32_t nblocks, const float *vecs, const int32_t *levels,
+							 const int16_t *ncount, const int64_t *nbr_off, const uint32_t *nbrs,
+							 const uint8_t *tids6, uint32_t entry_point, int entry_level);
+/* hnswSearch for nq queries: strategy in {1,2,3}; ef = neurondb.hnsw_ef_search;
+ * k = neurondb.hnsw_k.  out_blocks/out_dist [nq*k]; out_tids6 nullable
+ * (hnswgettuple's node->heapPtr lookup, :1009-1053); out_scored nullable
+ * [nq] = hnswComputeDistance calls per query. */
+int			ndbhip_hnsw_search(ndbhip_hnsw *g, const float *queries, int nq, int strategy, int ef, int k,
+							   uint32_t *out_blocks, float *out_dist, int *out_count,
+							   uint8_t *out_tids6, int64_t *out_scored);
+int			ndbhip_hnsw_search_device(ndbhip_hnsw *g, const float *d_queries, int nq, int strategy, int ef,
+									  int k, uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
+									  uint64_t *d_out_tids, int64_t *d_out_scored);
+
+/* ------------------------------------------------------------------ */
+/* Batch distance (replaces neurondb_gpu_batch_l2_distance & co:
+ * include/neurondb_gpu.h:94-106, src/gpu/common/gpu_batch.c:27-83, whose
+ * body is a CPU loop).  recipe selects the rounding:
+ *   0 ivf (fp32 sequential), 1 hnsw (fp64 accumulate).
+ * results[q*nv + v], host pointers.                                     */
+/* ------------------------------------------------------------------ */
+int			ndbhip_batch_distance(const float *queries, const float *vectors, float *results,
+								  int nq, int nv, int dim, int strategy, int recipe);
+
+#ifdef __cplusplus
+}
+#endif
+#endif							/* NDBHIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of include/ndbhip.h.  Fails loudly when the HIP library has
+not been built — there is no CPU fallback in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB = os.path.join(_HERE, "lib", "libndbhip.so")
+_HDR = os.path.join(_ROOT, "include", "ndbhip.h")
+
+OK = 0
+ERR_INVALID, ERR_NODEVICE, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+STRATEGY_L2, STRATEGY_COSINE, STRATEGY_IP = 1, 2, 3
+
+
+class NdbHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ndbhip error {code}: {msg}")
+        self.code = code
+
+
+class Cand(C.Structure):
+    _fields_ = [("key", C.c_uint32), ("pos", C.c_uint32), ("tid", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("rows_scored", C.c_uint64), ("bytes_scored", C.c_uint64),
+                ("scan_launches", C.c_uint64), ("scan_kernel_ms", C.c_double)]
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+def declared_symbols() -> list:
+    """Every function include/ndbhip.h declares."""
+    with open(_HDR) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ndbhip_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise NdbHipError(ERR_NODEVICE,
+                          f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(_LIB)
+    vp, i, i64, f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    sig = {
+        "ndbhip_abi_version": (i, []),
+        "ndbhip_device_count": (i, []),
+        "ndbhip_init": (i, [i]),
+        "ndbhip_shutdown": (i, []),
+        "ndbhip_last_error": (C.c_char_p, []),
+        "ndbhip_set_stream": (i, [vp]),
+        "ndbhip_synchronize": (i, []),
+        "ndbhip_stats_get": (i, [C.POINTER(Stats)]),
+        "ndbhip_stats_reset": (i, []),
+        "ndbhip_profile": (i, [i]),
+        "ndbhip_ivf_create": (i, [i, i, C.POINTER(vp)]),
+        "ndbhip_ivf_destroy": (i, [vp]),
+        "ndbhip_ivf_set_centroids": (i, [vp, vp, i]),
+        "ndbhip_ivf_load": (i, [vp, vp, vp, vp, vp, i64]),
+        "ndbhip_ivf_load_device": (i, [vp, vp, vp, vp, vp, i64]),
+        "ndbhip_ivf_append": (i, [vp, i, vp, vp]),
+        "ndbhip_ivf_nrows": (i64, [vp]),
+        "ndbhip_ivf_max_candidates": (i64, [vp, i]),
+        "ndbhip_ivf_search": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),
+        "ndbhip_ivf_search_device": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),
+        "ndbhip_ivf_select_clusters": (i, [vp, vp, i, i, vp]),
+        "ndbhip_ivf_search_partial_device": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),
+        "ndbhip_merge_topk_device": (i, [vp, vp, vp, i, i, i, i, vp, vp, vp]),
+        "ndbhip_merge_topk_host": (i, [vp, vp, vp, i, i, i, i, vp, vp, vp]),
+        "ndbhip_kmeans_device": (i, [vp, i, i, i, i, f, vp, vp, vp, C.POINTER(i), C.POINTER(f)]),
+        "ndbhip_ivf_assign_device": (i, [vp, i, i, vp, i64, vp]),
+        "ndbhip_ivf_build_device": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
+        "ndbhip_hnsw_create": (i, [i, i, C.POINTER(vp)]),
+        "ndbhip_hnsw_destroy": (i, [vp]),
+        "ndbhip_hnsw_load": (i, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i]),
+        "ndbhip_hnsw_search": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
+        "ndbhip_hnsw_search_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
+        "ndbhip_batch_distance": (i, [vp, vp, vp, i, i, i, i, i]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().ndbhip_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int):
+    if rc != OK:
+        raise NdbHipError(rc, last_error())
+
+
+_inited = False
+
+
+def ensure_init(device: int | None = None):
+    """Lazy per-process device init (the reference's ndb_gpu_init_if_needed pattern)."""
+    global _inited
+    if _inited:
+        return
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        n = lib().ndbhip_device_count()
+        if n > 0:
+            device %= n
+    check(lib().ndbhip_init(int(device)))
+    _inited = True
+
+
+def stats() -> dict:
+    s = Stats()
+    check(lib().ndbhip_stats_get(C.byref(s)))
+    return {k: getattr(s, k) for k, _ in Stats._fields_}

@@ -1,0 +1,1691 @@
+/*
+ * ndbhip.hip — MI355X (gfx950) implementation of include/ndbhip.h.
+ *
+ * Kernel pipeline of one IVF search batch (reference call stack:
+ * ivfgettuple -> ivfSelectClusters -> ivfCollectCandidates,
+ * NeuronDB/src/index/ivf_am.c:1911-2027, 1597-1717, 1722-1909):
+ *
+ *   k_rows_scan      query x every centroid        (HOT LOOP 1, :1660-1681)
+ *   k_probe_select   nprobe first-min selection     (:1686-1714) + candidate offsets
+ *   k_ivf_scan       query x every probed entry     (HOT LOOP 2, :1810-1834)  <- dominant, HBM-bound
+ *   k_ivf_topk       k-th value, tie-complete subset, selection-sort replay (:1856-1899)
+ *
+ * Written for wave64 / CDNA4 only.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <vector>
+#include <algorithm>
+#include <mutex>
+
+#include "../../include/ndbhip.h"
+#include "ndbhip_kernels.h"
+
+#pragma clang fp contract(off)
+
+/* ================================================================== */
+/* context / errors                                                    */
+/* ================================================================== */
+
+static thread_local char g_err[512];
+
+static int
+fail(int code, const char *fmt, ...)
+{
+	va_list		ap;
+
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+	do {                                                                           \
+		hipError_t _e = (expr);                                                    \
+		if (_e != hipSuccess)                                                      \
+			return fail(NDBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+						hipGetErrorString(_e), __FILE__, __LINE__);                \
+	} while (0)
+
+struct Ctx
+{
+	bool		inited = false;
+	int			device = -1;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	bool		profile = false;
+	ndbhip_stats stats = {};
+	unsigned long long *d_counters = nullptr;	/* [0] candidate rows scored (all ranks' view), [1] rows scored here */
+	uint64_t	host_rows = 0, host_bytes = 0;	/* counted on the host (batch distance) */
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;	/* profiling events not yet read */
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+static Ctx	g;
+
+static int
+need_init()
+{
+	if (!g.inited)
+		return fail(NDBHIP_ERR_NODEVICE, "ndbhip_init() has not succeeded in this process");
+	return 0;
+}
+
+static int	set_kernel_attributes();
+
+extern "C" int
+ndbhip_abi_version(void)
+{
+	return NDBHIP_ABI_VERSION;
+}
+
+extern "C" const char *
+ndbhip_last_error(void)
+{
+	return g_err;
+}
+
+extern "C" int
+ndbhip_device_count(void)
+{
+	int			n = 0;
+	hipError_t	e = hipGetDeviceCount(&n);
+
+	if (e != hipSuccess)
+	{
+		(void) hipGetLastError();
+		return fail(NDBHIP_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+	}
+	return n;
+}
+
+extern "C" int
+ndbhip_init(int device)
+{
+	int			n;
+
+	if (g.inited)
+	{
+		if (device == g.device)
+			return NDBHIP_OK;
+		return fail(NDBHIP_ERR_STATE, "already initialised on device %d", g.device);
+	}
+	n = ndbhip_device_count();
+	if (n <= 0)
+		return fail(NDBHIP_ERR_NODEVICE, "no HIP device visible");
+	if (device < 0 || device >= n)
+		return fail(NDBHIP_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+	HIP_TRY(hipSetDevice(device));
+	{
+		hipDeviceProp_t prop;
+
+		HIP_TRY(hipGetDeviceProperties(&prop, device));
+		if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+			return fail(NDBHIP_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only",
+						device, prop.gcnArchName);
+	}
+	HIP_TRY(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
+	g.stream = g.own_stream;
+	HIP_TRY(hipMalloc((void **) &g.d_counters, 4 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemset(g.d_counters, 0, 4 * sizeof(unsigned long long)));
+	g.device = device;
+	g.inited = true;
+	return set_kernel_attributes();
+}
+
+extern "C" int
+ndbhip_shutdown(void)
+{
+	if (!g.inited)
+		return NDBHIP_OK;
+	(void) hipStreamSynchronize(g.stream);
+	for (auto &p : g.pending) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+	for (auto &p : g.pool) { (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second); }
+	g.pending.clear();
+	g.pool.clear();
+	if (g.own_stream)
+		(void) hipStreamDestroy(g.own_stream);
+	if (g.d_counters)
+		(void) hipFree(g.d_counters);
+	g = Ctx();
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_set_stream(void *s)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	g.stream = s ? (hipStream_t) s : g.own_stream;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_synchronize(void)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return NDBHIP_OK;
+}
+
+static int
+drain_profile_events()
+{
+	for (auto &p : g.pending)
+	{
+		float		ms = 0.f;
+
+		HIP_TRY(hipEventSynchronize(p.second));
+		HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+		g.stats.scan_kernel_ms += ms;
+		g.pool.push_back(p);
+	}
+	g.pending.clear();
+	return 0;
+}
+
+extern "C" int
+ndbhip_stats_get(ndbhip_stats *out)
+{
+	if (!out)
+		return fail(NDBHIP_ERR_INVALID, "out is NULL");
+	if (g.inited)
+	{
+		unsigned long long c[4];
+
+		if (drain_profile_events())
+			return NDBHIP_ERR_HIP;
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		HIP_TRY(hipMemcpy(c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost));
+		g.stats.rows_scored = g.host_rows + c[1];
+		g.stats.bytes_scored = g.host_bytes + c[2];
+	}
+	*out = g.stats;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_stats_reset(void)
+{
+	if (g.inited)
+	{
+		if (drain_profile_events())
+			return NDBHIP_ERR_HIP;
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		HIP_TRY(hipMemset(g.d_counters, 0, 4 * sizeof(unsigned long long)));
+	}
+	g.host_rows = g.host_bytes = 0;
+	g.stats = ndbhip_stats();
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_profile(int on)
+{
+	g.profile = on != 0;
+	return NDBHIP_OK;
+}
+
+/* bracket the dominant kernel with events when profiling */
+struct ScanTimer
+{
+	std::pair<hipEvent_t, hipEvent_t> ev{};
+	bool		on = false;
+	int start()
+	{
+		g.stats.scan_launches++;
+		if (!g.profile)
+			return 0;
+		if (!g.pool.empty()) { ev = g.pool.back(); g.pool.pop_back(); }
+		else
+		{
+			HIP_TRY(hipEventCreate(&ev.first));
+			HIP_TRY(hipEventCreate(&ev.second));
+		}
+		HIP_TRY(hipEventRecord(ev.first, g.stream));
+		on = true;
+		return 0;
+	}
+	int stop()
+	{
+		if (!on)
+			return 0;
+		HIP_TRY(hipEventRecord(ev.second, g.stream));
+		g.pending.push_back(ev);
+		return 0;
+	}
+};
+
+/* ================================================================== */
+/* device-side index views                                             */
+/* ================================================================== */
+
+struct IvfDev
+{
+	const float *vecs;			/* [nrows_local * dim] */
+	const uint64_t *tids;		/* [nrows_local] */
+	const float *centroids;		/* [ncent * dim] */
+	const int64_t *loc_off;		/* [ncent + 1] local row offsets */
+	const uint32_t *glob_len;	/* [ncent] global live entries per list */
+	const uint8_t *owned;		/* [ncent] */
+	int			dim;
+	int			ncent;			/* centroid items present ("maxoff") */
+	int			nlists;			/* meta->nlists */
+};
+
+/* ================================================================== */
+/* block-level primitives                                              */
+/* ================================================================== */
+
+/*
+ * Radix select over the order-preserving keys of the valid elements of a
+ * sequence.  f(i, bits) -> valid.  On return (all threads):
+ *   kk      = min(k_want, number of valid elements)
+ *   T       = key of the kk-th smallest valid element (undefined if kk == 0)
+ *   m_less  = number of valid elements with key < T
+ *   cnt_eq  = number of valid elements with key == T
+ * hist: 256 words of LDS; sh: 8 words of LDS.  Ends with a barrier.
+ */
+template <class F>
+__device__ void
+block_radix_select(F f, uint32_t n, uint32_t k_want, uint32_t *hist, uint32_t *sh,
+				   uint32_t &T, uint32_t &m_less, uint32_t &kk, uint32_t &cnt_eq)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t nthr = blockDim.x;
+	uint32_t	prefix = 0,
+				mask = 0;
+
+	kk = 0;
+	m_less = 0;
+	cnt_eq = 0;
+	T = 0;
+	for (int pass = 0; pass < 4; pass++)
+	{
+		const int	shift = 24 - 8 * pass;
+
+		for (uint32_t b = tid; b < 256; b += nthr)
+			hist[b] = 0;
+		__syncthreads();
+		for (uint32_t i = tid; i < n; i += nthr)
+		{
+			uint32_t	bits;
+
+			if (f(i, bits))
+			{
+				const uint32_t key = ndb_key_from_bits(bits);
+
+				if ((key & mask) == prefix)
+					atomicAdd(&hist[(key >> shift) & 255u], 1u);
+			}
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			uint32_t	rem;
+			uint32_t	cum = 0;
+
+			if (pass == 0)
+			{
+				uint32_t	nv = 0;
+
+				for (int b = 0; b < 256; b++)
+					nv += hist[b];
+				sh[3] = (k_want < nv) ? k_want : nv;	/* kk */
+				rem = sh[3];
+			}
+			else
+				rem = sh[1];
+			sh[0] = 0;
+			sh[2] = 0;
+			if (rem > 0)
+			{
+				for (int b = 0; b < 256; b++)
+				{
+					const uint32_t c = hist[b];
+
+					if (cum + c >= rem)
+					{
+						sh[0] = (uint32_t) b;
+						sh[1] = rem - cum;	/* rank inside this bin, 1-based */
+						sh[2] = c;
+						break;
+					}
+					cum += c;
+				}
+			}
+			else
+				sh[1] = 0;
+		}
+		__syncthreads();
+		prefix |= sh[0] << shift;
+		mask |= 0xFFu << shift;
+		kk = sh[3];
+		if (pass == 3)
+		{
+			cnt_eq = sh[2];
+			m_less = kk - sh[1];
+		}
+		__syncthreads();
+		if (kk == 0)
+			return;
+	}
+	T = prefix;
+}
+
+/*
+ * In-order compaction of the elements with key < T (class 0, all of them) and
+ * key == T (class 1, the first eq_cap by index).  emit(cls, rank, i, bits).
+ * sh: 16 words of LDS.  Block size must be a multiple of 64, at most 512.
+ */
+template <class F, class E>
+__device__ void
+block_ordered_gather(F f, uint32_t n, uint32_t T, uint32_t eq_cap, uint32_t *sh, E emit)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t nthr = blockDim.x;
+	const uint32_t lane = tid & 63u;
+	const uint32_t wave = tid >> 6;
+	const uint32_t nwave = nthr >> 6;
+	uint32_t	base_lt = 0,
+				base_eq = 0;
+
+	for (uint32_t start = 0; start < n; start += nthr)
+	{
+		const uint32_t i = start + tid;
+		uint32_t	bits = 0;
+		bool		valid = (i < n) && f(i, bits);
+		const uint32_t key = ndb_key_from_bits(bits);
+		const bool	is_lt = valid && key < T;
+		const bool	is_eq = valid && key == T;
+		const unsigned long long m_lt = __ballot(is_lt);
+		const unsigned long long m_eq = __ballot(is_eq);
+		const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+		const uint32_t r_lt = __popcll(m_lt & below);
+		const uint32_t r_eq = __popcll(m_eq & below);
+
+		if (lane == 0)
+		{
+			sh[wave * 2 + 0] = __popcll(m_lt);
+			sh[wave * 2 + 1] = __popcll(m_eq);
+		}
+		__syncthreads();
+		uint32_t	w_lt = 0, w_eq = 0, t_lt = 0, t_eq = 0;
+
+		for (uint32_t w = 0; w < nwave; w++)
+		{
+			if (w < wave)
+			{
+				w_lt += sh[w * 2 + 0];
+				w_eq += sh[w * 2 + 1];
+			}
+			t_lt += sh[w * 2 + 0];
+			t_eq += sh[w * 2 + 1];
+		}
+		if (is_lt)
+			emit(0, base_lt + w_lt + r_lt, i, bits);
+		if (is_eq && base_eq + w_eq + r_eq < eq_cap)
+			emit(1, base_eq + w_eq + r_eq, i, bits);
+		base_lt += t_lt;
+		base_eq += t_eq;
+		__syncthreads();
+	}
+}
+
+/* Bitonic sort of npad (power of two) 64-bit keys with a 32-bit payload, in LDS. */
+__device__ void
+block_bitonic_sort(uint64_t *comp, uint32_t *payload, uint32_t npad)
+{
+	for (uint32_t size = 2; size <= npad; size <<= 1)
+	{
+		for (uint32_t stride = size >> 1; stride > 0; stride >>= 1)
+		{
+			__syncthreads();
+			for (uint32_t t = threadIdx.x; t < (npad >> 1); t += blockDim.x)
+			{
+				const uint32_t lo = 2 * t - (t & (stride - 1));
+				const uint32_t hi = lo + stride;
+				const bool	up = ((lo & size) == 0);
+				const uint64_t a = comp[lo], b = comp[hi];
+
+				if ((a > b) == up)
+				{
+					const uint32_t pa = payload[lo], pb = payload[hi];
+
+					comp[lo] = b;
+					comp[hi] = a;
+					payload[lo] = pb;
+					payload[hi] = pa;
+				}
+			}
+		}
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ uint64_t
+wave_min_u64(uint64_t v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const uint32_t lo = __shfl_xor((uint32_t) v, off, 64);
+		const uint32_t hi = __shfl_xor((uint32_t) (v >> 32), off, 64);
+		const uint64_t o = ((uint64_t) hi << 32) | lo;
+
+		v = (o < v) ? o : v;
+	}
+	return v;
+}
+
+/*
+ * Final stage shared by IVF top-k, the shard merge and HNSW: given n entries
+ * (dist bits, position in the reference's candidates[] array, payload id) in
+ * LDS, replay the reference's selection sort (ivf_am.c:1856-1881) and write the
+ * first kk = min(k, total) results.
+ *
+ * LDS scratch (npad = next pow2 >= n): comp[npad] u64, perm[npad] u32,
+ * curpos[npad] u32, taken[npad] u8, order[k] u32.
+ */
+struct FinalizeScratch
+{
+	uint64_t   *comp;
+	uint32_t   *perm;
+	uint32_t   *curpos;
+	uint8_t    *taken;
+	uint32_t   *order;
+};
+
+__device__ void
+block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_t *e_id, uint32_t n,
+					uint32_t npad, uint32_t k, uint64_t total, FinalizeScratch s,
+					uint64_t *out_id, float *out_dist, int *out_count)
+{
+	const uint32_t tid = threadIdx.x;
+	uint32_t	kk = (uint32_t) ((uint64_t) k < total ? (uint64_t) k : total);
+
+	if (kk > n)
+		kk = n;
+	for (uint32_t j = tid; j < npad; j += blockDim.x)
+	{
+		if (j < n)
+		{
+			s.comp[j] = ((uint64_t) ndb_key_from_bits(e_bits[j]) << 32) | e_pos[j];
+			s.perm[j] = j;
+		}
+		else
+		{
+			s.comp[j] = ~0ull;
+			s.perm[j] = 0xFFFFFFFFu;
+		}
+	}
+	block_bitonic_sort(s.comp, s.perm, npad);
+
+	/* tie-complete prefix: everything below T plus the first 2k entries equal to T */
+	uint32_t	ns = n;
+
+	if (kk > 0)
+	{
+		const uint32_t Tkey = (uint32_t) (s.comp[kk - 1] >> 32);
+		/* first index whose key >= T: binary search, every thread redundantly */
+		uint32_t	lo = 0, hi = kk - 1;
+
+		while (lo < hi)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if ((uint32_t) (s.comp[mid] >> 32) < Tkey)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		uint32_t	lim = lo + 2 * k;
+
+		if (lim < ns)
+			ns = lim;
+		/* (entries with key > T inside [kk, ns) are harmless: they lose to every tie) */
+	}
+	for (uint32_t j = tid; j < ns; j += blockDim.x)
+	{
+		s.curpos[j] = (uint32_t) s.comp[j];
+		s.taken[j] = 0;
+	}
+	__syncthreads();
+
+	if (tid < 64)
+	{
+		for (uint32_t i = 0; i < kk; i++)
+		{
+			uint64_t	best = ~0ull;
+
+			for (uint32_t j = tid; j < ns; j += 64)
+				if (!s.taken[j])
+				{
+					const uint64_t c = (s.comp[j] & 0xFFFFFFFF00000000ull) | s.curpos[j];
+
+					best = (c < best) ? c : best;
+				}
+			best = wave_min_u64(best);
+			const uint32_t bpos = (uint32_t) best;
+
+			for (uint32_t j = tid; j < ns; j += 64)
+				if (!s.taken[j])
+				{
+					const uint64_t c = (s.comp[j] & 0xFFFFFFFF00000000ull) | s.curpos[j];
+
+					if (c == best)
+					{
+						s.taken[j] = 1;
+						s.order[i] = j;
+					}
+					else if (s.curpos[j] == i)
+						s.curpos[j] = bpos;	/* the loser parked in slot i moves to the winner's slot */
+				}
+			wave_lds_sync();
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < kk; i += blockDim.x)
+	{
+		const uint32_t e = s.perm[s.order[i]];
+
+		out_id[i] = e_id[e];
+		out_dist[i] = ndb_u2f(e_bits[e]);
+	}
+	if (tid == 0)
+		*out_count = (int) kk;
+}
+
+/* ================================================================== */
+/* kernels                                                             */
+/* ================================================================== */
+
+/* out[q * out_stride + r] = dist(query q, base row r), r < nrows.
+ * grid = (ceil(nrows / 256), nq), block = 256 (4 independent waves). */
+template <int R>
+__global__ __launch_bounds__(256) void
+k_rows_scan(const float *__restrict__ base, uint32_t nrows, int dim,
+			const float *__restrict__ queries, float *__restrict__ out, uint32_t out_stride)
+{
+	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t q = blockIdx.y;
+	const uint32_t r0 = (blockIdx.x * 4 + wave) * 64;
+
+	if (r0 >= nrows)
+		return;
+	const uint32_t r = r0 + lane;
+	const uint32_t row = (r < nrows) ? r : (nrows - 1);
+	const float d = score_rows<R>(queries + (size_t) q * dim, base, row, dim,
+								  tiles + wave * NDB_TILE_FLOATS);
+
+	if (r < nrows)
+		out[(size_t) q * out_stride + r] = d;
+}
+
+/*
+ * ivfSelectClusters selection + candidate offsets.  One block per query.
+ *   cdist[q * cstride + c], c < ncmp (= min(nlists, ncent))
+ *   probes[q * npr + i]:  i < nsel: i-th nearest centroid (first-min ties);
+ *                         nsel <= i < npr_eff: -1 (bestIdx stays -1);
+ *                         npr_eff <= i < npr: 0 (palloc0 slots never written: ivf_am.c:1978)
+ *   cand_off[q * (npr+1) + i]: start of probe i's entries in candidates[],
+ *                         capped at `cap` (ivf_am.c:1743) when cap > 0.
+ */
+__global__ __launch_bounds__(256) void
+k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int ncent, int npr,
+			   const uint32_t *__restrict__ glob_len, const uint8_t *__restrict__ owned, uint64_t cap,
+			   int dim, int *__restrict__ probes, uint32_t *__restrict__ cand_off,
+			   unsigned long long *__restrict__ counters)
+{
+	__shared__ uint32_t hist[256];
+	__shared__ uint32_t sh[16];
+	__shared__ uint64_t comp[NDBHIP_MAX_NPROBE];
+	__shared__ uint32_t perm[NDBHIP_MAX_NPROBE];
+	__shared__ uint32_t lens[NDBHIP_MAX_NPROBE];
+	__shared__ int selc[NDBHIP_MAX_NPROBE];
+	const uint32_t q = blockIdx.x;
+	const uint32_t tid = threadIdx.x;
+	const float *d = cdist + (size_t) q * cstride;
+	int			npr_eff = npr < ncmp ? npr : ncmp;
+	uint32_t	T, m_less, kk, cnt_eq;
+
+	if (npr_eff < 0)
+		npr_eff = 0;
+	/* valid = strictly below FLT_MAX (bestDist starts at FLT_MAX: ivf_am.c:1689, 1706) */
+	auto		ld = [&](uint32_t i, uint32_t &bits) -> bool {
+		const float v = d[i];
+
+		bits = __float_as_uint(v);
+		return v < FLT_MAX;
+	};
+
+	block_radix_select(ld, (uint32_t) ncmp, (uint32_t) npr_eff, hist, sh, T, m_less, kk, cnt_eq);
+
+	uint32_t	npad = 1;
+
+	while (npad < kk)
+		npad <<= 1;
+	for (uint32_t j = tid; j < npad; j += blockDim.x)
+	{
+		comp[j] = ~0ull;
+		perm[j] = 0;
+	}
+	__syncthreads();
+	if (kk > 0)
+	{
+		auto		emit = [&](int cls, uint32_t rank, uint32_t i, uint32_t bits) {
+			const uint32_t slot = cls ? (m_less + rank) : rank;
+
+			comp[slot] = ((uint64_t) ndb_key_from_bits(bits) << 32) | i;
+			perm[slot] = i;
+		};
+		block_ordered_gather(ld, (uint32_t) ncmp, T, kk - m_less, sh, emit);
+		block_bitonic_sort(comp, perm, npad);
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < (uint32_t) npr; i += blockDim.x)
+	{
+		int			c;
+
+		if (i < kk)
+			c = (int) perm[i];
+		else if (i < (uint32_t) npr_eff)
+			c = -1;
+		else
+			c = 0;
+		probes[(size_t) q * npr + i] = c;
+		selc[i] = c;
+		lens[i] = (c >= 0 && c < ncent) ? glob_len[c] : 0u;	/* ivf_am.c:1768-1779 */
+	}
+	__syncthreads();
+	if (tid == 0)
+	{
+		uint64_t	acc = 0, mine = 0;
+		uint32_t   *co = cand_off + (size_t) q * (npr + 1);
+
+		co[0] = 0;
+		for (int i = 0; i < npr; i++)
+		{
+			uint64_t	l = lens[i];
+
+			if (cap > 0 && acc + l > cap)
+				l = cap - acc;	/* candidateCount < maxCandidates guards: ivf_am.c:1764, 1793, 1811 */
+			acc += l;
+			if (l > 0 && owned[selc[i]])
+				mine += l;
+			co[i + 1] = (uint32_t) acc;
+		}
+		if (counters)
+		{
+			atomicAdd(&counters[0], (unsigned long long) acc);
+			atomicAdd(&counters[1], (unsigned long long) mine);
+			atomicAdd(&counters[2], (unsigned long long) mine * (unsigned long long) dim * 4ull);
+		}
+	}
+}
+
+/* position -> (probe index) : largest p with co[p] <= pos */
+__device__ __forceinline__ uint32_t
+find_probe(const uint32_t *__restrict__ co, int npr, uint32_t pos)
+{
+	uint32_t	lo = 0, hi = (uint32_t) npr;	/* invariant: co[lo] <= pos < co[hi] */
+
+	while (hi - lo > 1)
+	{
+		const uint32_t mid = (lo + hi) >> 1;
+
+		if (co[mid] <= pos)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+/*
+ * HOT LOOP 2: score every entry of every probed list (ivf_am.c:1810-1834).
+ * candidates[] position pos = cand_off[p] + index inside list probes[p].
+ * grid = (ceil(stride / 256), nq), block = 256 = 4 independent 64-row tiles.
+ * Writes dist[q * stride + pos]; rows of lists this rank does not hold get
+ * NDB_ABSENT_BITS.
+ */
+template <int R>
+__global__ __launch_bounds__(256) void
+k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
+		   const uint32_t *__restrict__ cand_off, int npr, float *__restrict__ dist, uint32_t stride)
+{
+	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t q = blockIdx.y;
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t total = co[npr];
+	const uint32_t pos0 = (blockIdx.x * 4 + wave) * 64;
+
+	if (pos0 >= total)
+		return;
+	const uint32_t pos = pos0 + lane;
+	const bool	valid = pos < total;
+	const uint32_t spos = valid ? pos : (total - 1);
+	const uint32_t p = find_probe(co, npr, spos);
+	const int	L = probes[(size_t) q * npr + p];
+	const bool	own = ix.owned[L] != 0;
+	const uint32_t row = own ? (uint32_t) (ix.loc_off[L] + (spos - co[p])) : 0u;
+
+	if (__ballot(valid && own) == 0ull)
+	{
+		if (valid)
+			dist[(size_t) q * stride + pos] = __uint_as_float(NDB_ABSENT_BITS);
+		return;
+	}
+	const float d = score_rows<R>(queries + (size_t) q * ix.dim, ix.vecs, row, ix.dim,
+								  tiles + wave * NDB_TILE_FLOATS);
+
+	if (valid)
+		dist[(size_t) q * stride + pos] = own ? d : __uint_as_float(NDB_ABSENT_BITS);
+}
+
+/* dynamic LDS layout of k_ivf_topk / k_merge_topk */
+struct TopkSmem
+{
+	uint32_t   *hist;			/* 256 */
+	uint32_t   *sh;				/* 16 */
+	uint32_t   *e_bits;			/* cap */
+	uint32_t   *e_pos;			/* cap */
+	uint64_t   *e_id;			/* cap */
+	FinalizeScratch fs;
+};
+
+__host__ __device__ static inline uint32_t
+next_pow2(uint32_t v)
+{
+	uint32_t	p = 1;
+
+	while (p < v)
+		p <<= 1;
+	return p;
+}
+
+__host__ __device__ static inline size_t
+topk_smem_bytes(uint32_t cap, uint32_t k)
+{
+	const uint32_t npad = next_pow2(cap);
+
+	return (size_t) (256 + 16) * 4 + (size_t) cap * (4 + 4 + 8) + (size_t) npad * (8 + 4 + 4 + 1) +
+		(size_t) k * 4 + 64;
+}
+
+__device__ static inline TopkSmem
+carve_topk_smem(unsigned char *base, uint32_t cap, uint32_t k)
+{
+	TopkSmem	s;
+	const uint32_t npad = next_pow2(cap);
+	unsigned char *p = base;
+
+	s.e_id = (uint64_t *) p;			p += (size_t) cap * 8;
+	s.fs.comp = (uint64_t *) p;			p += (size_t) npad * 8;
+	s.hist = (uint32_t *) p;			p += 256 * 4;
+	s.sh = (uint32_t *) p;				p += 16 * 4;
+	s.e_bits = (uint32_t *) p;			p += (size_t) cap * 4;
+	s.e_pos = (uint32_t *) p;			p += (size_t) cap * 4;
+	s.fs.perm = (uint32_t *) p;			p += (size_t) npad * 4;
+	s.fs.curpos = (uint32_t *) p;		p += (size_t) npad * 4;
+	s.fs.order = (uint32_t *) p;		p += (size_t) k * 4;
+	s.fs.taken = (uint8_t *) p;
+	return s;
+}
+
+/*
+ * Top-k of one query's candidate distances, reproducing ivf_am.c:1856-1899.
+ * One block per query.  partial != 0: emit the tie-complete subset for the
+ * shard merge instead of final results.
+ */
+__global__ __launch_bounds__(256) void
+k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr,
+		   const float *__restrict__ dist, uint32_t stride, uint32_t k, int partial,
+		   ndbhip_cand *__restrict__ out_cand, int *__restrict__ out_ncand, int64_t *__restrict__ out_total,
+		   uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	const uint32_t cap = 3 * k;
+	TopkSmem	s = carve_topk_smem(smem_raw, cap, k);
+	const uint32_t q = blockIdx.x;
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t total = co[npr];
+	const float *d = dist + (size_t) q * stride;
+	uint32_t	T, m_less, kk, cnt_eq;
+
+	auto		ld = [&](uint32_t i, uint32_t &bits) -> bool {
+		bits = __float_as_uint(d[i]);
+		return bits != NDB_ABSENT_BITS;
+	};
+
+	block_radix_select(ld, total, k, s.hist, s.sh, T, m_less, kk, cnt_eq);
+
+	uint32_t	n_eq = cnt_eq < 2 * k ? cnt_eq : 2 * k;
+	uint32_t	ns = (kk > 0) ? (m_less + n_eq) : 0;
+
+	if (kk > 0)
+	{
+		auto		emit = [&](int cls, uint32_t rank, uint32_t i, uint32_t bits) {
+			const uint32_t slot = cls ? (m_less + rank) : rank;
+			const uint32_t p = find_probe(co, npr, i);
+			const int	L = probes[(size_t) q * npr + p];
+
+			s.e_bits[slot] = bits;
+			s.e_pos[slot] = i;
+			s.e_id[slot] = ix.tids[ix.loc_off[L] + (i - co[p])];
+		};
+		block_ordered_gather(ld, total, T, n_eq, s.sh, emit);
+	}
+	__syncthreads();
+
+	if (partial)
+	{
+		for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x)
+		{
+			ndbhip_cand c;
+
+			c.key = s.e_bits[j];	/* raw float4 bits; the merge derives the order key */
+			c.pos = s.e_pos[j];
+			c.tid = s.e_id[j];
+			out_cand[(size_t) q * cap + j] = c;
+		}
+		if (threadIdx.x == 0)
+		{
+			out_ncand[q] = (int) ns;
+			out_total[q] = (int64_t) total;
+		}
+		return;
+	}
+	block_finalize_topk(s.e_bits, s.e_pos, s.e_id, ns, next_pow2(ns > 0 ? ns : 1), k, total, s.fs,
+						out_tids + (size_t) q * k, out_dist + (size_t) q * k, out_count + q);
+}
+
+/*
+ * Shard merge: union of the ranks' partial records for one query, then the
+ * same replay.  cand[(w * nq + q) * cap + j], ncand[w * nq + q].
+ */
+__global__ __launch_bounds__(256) void
+k_merge_topk(const ndbhip_cand *__restrict__ cand, const int *__restrict__ ncand,
+			 const int64_t *__restrict__ total, int world, int nq, uint32_t k, uint32_t cap,
+			 uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	const uint32_t capall = cap * (uint32_t) world;
+	TopkSmem	s = carve_topk_smem(smem_raw, capall, k);
+	const uint32_t q = blockIdx.x;
+	__shared__ uint32_t woff[65];
+
+	if (threadIdx.x == 0)
+	{
+		uint32_t	acc = 0;
+
+		for (int w = 0; w < world; w++)
+		{
+			woff[w] = acc;
+			acc += (uint32_t) ncand[(size_t) w * nq + q];
+		}
+		woff[world] = acc;
+	}
+	__syncthreads();
+	const uint32_t n = woff[world];
+
+	for (int w = 0; w < world; w++)
+	{
+		const uint32_t cnt = woff[w + 1] - woff[w];
+		const ndbhip_cand *src = cand + ((size_t) w * nq + q) * cap;
+
+		for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x)
+		{
+			const ndbhip_cand c = src[j];
+
+			s.e_bits[woff[w] + j] = c.key;
+			s.e_pos[woff[w] + j] = c.pos;
+			s.e_id[woff[w] + j] = c.tid;
+		}
+	}
+	__syncthreads();
+	block_finalize_topk(s.e_bits, s.e_pos, s.e_id, n, next_pow2(n > 0 ? n : 1), k,
+						(uint64_t) total[q], s.fs,
+						out_tids + (size_t) q * k, out_dist + (size_t) q * k, out_count + q);
+}
+
+#define NDB_TOPK_MAX_SMEM (150 * 1024)
+
+static int
+set_kernel_attributes()
+{
+	HIP_TRY(hipFuncSetAttribute((const void *) k_ivf_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
+								NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
+								NDB_TOPK_MAX_SMEM));
+	return NDBHIP_OK;
+}
+
+/* ================================================================== */
+/* host side: IVF mirror                                               */
+/* ================================================================== */
+
+struct ndbhip_ivf
+{
+	int			dim = 0;
+	int			nlists = 0;
+	int			ncent = 0;
+	float	   *d_centroids = nullptr;
+	float	   *d_vecs = nullptr;
+	uint64_t   *d_tids = nullptr;
+	bool		own_rows = false;
+	int64_t		nrows = 0;
+	int64_t		cap_rows = 0;
+	int64_t    *d_loc_off = nullptr;
+	uint32_t   *d_glob_len = nullptr;
+	uint8_t    *d_owned = nullptr;
+	std::vector<int64_t> glob_len;
+	std::vector<int64_t> loc_off;
+	std::vector<uint8_t> owned;
+	bool		loaded = false;
+	/* workspace (grown on demand) */
+	float	   *w_cdist = nullptr;	size_t w_cdist_n = 0;
+	int		   *w_probes = nullptr;	size_t w_probes_n = 0;
+	uint32_t   *w_candoff = nullptr; size_t w_candoff_n = 0;
+	float	   *w_dist = nullptr;	size_t w_dist_n = 0;
+	float	   *w_q = nullptr;		size_t w_q_n = 0;
+	uint64_t   *w_otid = nullptr;	size_t w_otid_n = 0;
+	float	   *w_odist = nullptr;	size_t w_odist_n = 0;
+	int		   *w_ocnt = nullptr;	size_t w_ocnt_n = 0;
+};
+
+template <class T>
+static int
+grow(T *&p, size_t &have, size_t want)
+{
+	if (want <= have)
+		return 0;
+	if (p)
+		HIP_TRY(hipFree(p));
+	p = nullptr;
+	have = 0;
+	HIP_TRY(hipMalloc((void **) &p, want * sizeof(T)));
+	have = want;
+	return 0;
+}
+
+extern "C" int
+ndbhip_ivf_create(int dim, int nlists, ndbhip_ivf **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!out)
+		return fail(NDBHIP_ERR_INVALID, "out is NULL");
+	if (dim < 1 || dim > 32767)
+		return fail(NDBHIP_ERR_INVALID, "dim %d out of range 1..32767", dim);
+	if (nlists < 1)
+		return fail(NDBHIP_ERR_INVALID, "nlists %d must be >= 1", nlists);
+	ndbhip_ivf *ix = new (std::nothrow) ndbhip_ivf();
+
+	if (!ix)
+		return fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	ix->dim = dim;
+	ix->nlists = nlists;
+	*out = ix;
+	return NDBHIP_OK;
+}
+
+static void
+ivf_free_rows(ndbhip_ivf *ix)
+{
+	if (ix->own_rows)
+	{
+		if (ix->d_vecs) (void) hipFree(ix->d_vecs);
+		if (ix->d_tids) (void) hipFree(ix->d_tids);
+	}
+	ix->d_vecs = nullptr;
+	ix->d_tids = nullptr;
+	ix->own_rows = false;
+	ix->nrows = 0;
+	ix->cap_rows = 0;
+}
+
+extern "C" int
+ndbhip_ivf_destroy(ndbhip_ivf *ix)
+{
+	if (!ix)
+		return NDBHIP_OK;
+	if (g.inited)
+	{
+		(void) hipStreamSynchronize(g.stream);
+		ivf_free_rows(ix);
+		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
+			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt};
+
+		for (void *p : ptrs)
+			if (p) (void) hipFree(p);
+	}
+	delete ix;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncent)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !centroids || ncent < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ix->d_centroids)
+		HIP_TRY(hipFree(ix->d_centroids));
+	ix->d_centroids = nullptr;
+	HIP_TRY(hipMalloc((void **) &ix->d_centroids, (size_t) ncent * ix->dim * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(ix->d_centroids, centroids, (size_t) ncent * ix->dim * sizeof(float),
+						   hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));	/* caller's buffer may be palloc'd: copy before return */
+	ix->ncent = ncent;
+	ix->loaded = false;
+	return NDBHIP_OK;
+}
+
+static int
+ivf_set_layout(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned, int64_t nrows)
+{
+	const int	nc = ix->ncent;
+	int64_t		acc = 0;
+
+	if (nc < 1)
+		return fail(NDBHIP_ERR_STATE, "set centroids before loading lists");
+	ix->glob_len.assign(list_len, list_len + nc);
+	ix->owned.resize(nc);
+	ix->loc_off.resize(nc + 1);
+	std::vector<uint32_t> gl32(nc);
+
+	for (int c = 0; c < nc; c++)
+	{
+		if (list_len[c] < 0 || list_len[c] > 0xFFFFFFFFll)
+			return fail(NDBHIP_ERR_INVALID, "list_len[%d] out of range", c);
+		ix->owned[c] = owned ? (owned[c] != 0) : 1;
+		ix->loc_off[c] = acc;
+		if (ix->owned[c])
+			acc += list_len[c];
+		gl32[c] = (uint32_t) list_len[c];
+	}
+	ix->loc_off[nc] = acc;
+	if (acc != nrows)
+		return fail(NDBHIP_ERR_INVALID, "nrows %lld does not match the owned lists' total %lld",
+					(long long) nrows, (long long) acc);
+	if (acc > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 rows on one device");
+	void	  **ptrs[] = {(void **) &ix->d_loc_off, (void **) &ix->d_glob_len, (void **) &ix->d_owned};
+
+	for (void **p : ptrs)
+		if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
+	HIP_TRY(hipMalloc((void **) &ix->d_loc_off, (size_t) (nc + 1) * sizeof(int64_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_glob_len, (size_t) nc * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_owned, (size_t) nc));
+	HIP_TRY(hipMemcpyAsync(ix->d_loc_off, ix->loc_off.data(), (size_t) (nc + 1) * sizeof(int64_t),
+						   hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_glob_len, gl32.data(), (size_t) nc * sizeof(uint32_t),
+						   hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_owned, ix->owned.data(), (size_t) nc, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+extern "C" int
+ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
+				const float *rows, const uint8_t *tids6, int64_t nrows)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !list_len || nrows < 0 || (nrows > 0 && (!rows || !tids6)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	int			rc = ivf_set_layout(ix, list_len, owned, nrows);
+
+	if (rc)
+		return rc;
+	ivf_free_rows(ix);
+	const int64_t cap = nrows > 0 ? nrows : 1;
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
+	ix->own_rows = true;
+	ix->cap_rows = cap;
+	if (nrows > 0)
+	{
+		std::vector<uint64_t> t64((size_t) nrows);
+
+		for (int64_t r = 0; r < nrows; r++)
+			t64[(size_t) r] = ndb_tid_pack(tids6 + 6 * r);
+		HIP_TRY(hipMemcpyAsync(ix->d_vecs, rows, (size_t) nrows * ix->dim * sizeof(float),
+							   hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_tids, t64.data(), (size_t) nrows * sizeof(uint64_t),
+							   hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	ix->nrows = nrows;
+	ix->loaded = true;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
+					   const float *d_rows, const uint64_t *d_tids, int64_t nrows)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !list_len || nrows < 0 || (nrows > 0 && (!d_rows || !d_tids)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (((uintptr_t) d_rows & 15) != 0)
+		return fail(NDBHIP_ERR_INVALID, "d_rows must be 16-byte aligned");
+	int			rc = ivf_set_layout(ix, list_len, owned, nrows);
+
+	if (rc)
+		return rc;
+	ivf_free_rows(ix);
+	ix->d_vecs = const_cast<float *>(d_rows);
+	ix->d_tids = const_cast<uint64_t *>(d_tids);
+	ix->own_rows = false;
+	ix->nrows = nrows;
+	ix->cap_rows = nrows;
+	ix->loaded = true;
+	return NDBHIP_OK;
+}
+
+extern "C" int64_t
+ndbhip_ivf_nrows(const ndbhip_ivf *ix)
+{
+	return ix ? ix->nrows : -1;
+}
+
+extern "C" int64_t
+ndbhip_ivf_max_candidates(const ndbhip_ivf *ix, int nprobe)
+{
+	if (!ix || nprobe < 1)
+		return 0;
+	std::vector<int64_t> v(ix->glob_len);
+	int			n = std::min<int>(nprobe, (int) v.size());
+
+	std::partial_sort(v.begin(), v.begin() + n, v.end(), std::greater<int64_t>());
+	int64_t		s = 0;
+
+	for (int i = 0; i < n; i++)
+		s += v[i];
+	/* nprobe > nlists: the never-written probe slots re-scan list 0 (ivf_am.c:1978, 1990-1999) */
+	if (nprobe > n && !ix->glob_len.empty())
+		s += (int64_t) (nprobe - n) * ix->glob_len[0];
+	return s;
+}
+
+static IvfDev
+ivf_dev(const ndbhip_ivf *ix)
+{
+	IvfDev		d;
+
+	d.vecs = ix->d_vecs;
+	d.tids = ix->d_tids;
+	d.centroids = ix->d_centroids;
+	d.loc_off = ix->d_loc_off;
+	d.glob_len = ix->d_glob_len;
+	d.owned = ix->d_owned;
+	d.dim = ix->dim;
+	d.ncent = ix->ncent;
+	d.nlists = ix->nlists;
+	return d;
+}
+
+static int
+ivf_recipe(int strategy)
+{
+	switch (strategy)
+	{
+		case NDBHIP_STRATEGY_COSINE: return R_IVF_COS;
+		case NDBHIP_STRATEGY_IP: return R_IVF_IP;
+		default: return R_IVF_L2;	/* ivf_am.c:1561, 1583 */
+	}
+}
+
+#define LAUNCH_BY_RECIPE(R, KERNEL, GRID, BLOCK, ...)                                            \
+	do {                                                                                         \
+		switch (R) {                                                                             \
+			case R_IVF_L2: hipLaunchKernelGGL(KERNEL<R_IVF_L2>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+			case R_IVF_COS: hipLaunchKernelGGL(KERNEL<R_IVF_COS>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+			case R_IVF_IP: hipLaunchKernelGGL(KERNEL<R_IVF_IP>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+			case R_IVF_L2SQ: hipLaunchKernelGGL(KERNEL<R_IVF_L2SQ>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+			case R_HNSW_L2: hipLaunchKernelGGL(KERNEL<R_HNSW_L2>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+			case R_HNSW_COS: hipLaunchKernelGGL(KERNEL<R_HNSW_COS>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+			default: hipLaunchKernelGGL(KERNEL<R_HNSW_IP>, GRID, BLOCK, 0, g.stream, __VA_ARGS__); break; \
+		}                                                                                        \
+	} while (0)
+
+/* queries already on the device; runs select (+ scan + topk when `full`) for one sub-batch */
+static int
+ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr, int k,
+				 int64_t max_candidates, uint32_t stride, bool full, int partial,
+				 ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
+				 uint64_t *d_otid, float *d_odist, int *d_ocnt)
+{
+	const IvfDev d = ivf_dev(ix);
+	const int	ncmp = std::min(ix->nlists, ix->ncent);
+	const uint32_t cstride = (uint32_t) ((ncmp + 63) & ~63);
+
+	/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680) */
+	{
+		dim3		grid((ncmp + 255) / 256, nq);
+
+		hipLaunchKernelGGL(k_rows_scan<R_IVF_L2>, grid, dim3(256), 0, g.stream, (const float *) d.centroids,
+						   (uint32_t) ncmp, ix->dim, d_q, ix->w_cdist, cstride);
+	}
+	hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
+					   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
+					   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim, ix->w_probes,
+					   ix->w_candoff, full ? g.d_counters : (unsigned long long *) nullptr);
+	HIP_TRY(hipGetLastError());
+	if (!full)
+		return 0;
+
+	/* HOT LOOP 2 */
+	{
+		dim3		grid((stride + 255) / 256, nq);
+		const int	R = ivf_recipe(strategy);
+		ScanTimer	t;
+
+		if (t.start()) return NDBHIP_ERR_HIP;
+		LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) ix->w_probes,
+						 (const uint32_t *) ix->w_candoff, npr, ix->w_dist, stride);
+		if (t.stop()) return NDBHIP_ERR_HIP;
+	}
+	{
+		const size_t smem = topk_smem_bytes(3u * (uint32_t) k, (uint32_t) k);
+
+		hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) ix->w_probes,
+						   (const uint32_t *) ix->w_candoff, npr, (const float *) ix->w_dist, stride,
+						   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+static int
+ivf_check_search_args(ndbhip_ivf *ix, int nq, int nprobe, int k)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix)
+		return fail(NDBHIP_ERR_INVALID, "index is NULL");
+	if (!ix->loaded || ix->ncent < 1)
+		return fail(NDBHIP_ERR_STATE, "index has no centroids/lists loaded");
+	if (nq < 0)
+		return fail(NDBHIP_ERR_INVALID, "nq < 0");
+	if (nprobe < 1 || nprobe > NDBHIP_MAX_NPROBE)
+		return fail(NDBHIP_ERR_INVALID, "nprobe %d out of range 1..%d", nprobe, NDBHIP_MAX_NPROBE);
+	if (k < 1 || k > NDBHIP_MAX_K)
+		return fail(NDBHIP_ERR_INVALID, "k %d out of range 1..%d", k, NDBHIP_MAX_K);
+	return 0;
+}
+
+/* per-sub-batch budget for the candidate-distance buffer */
+static size_t g_dist_budget_bytes = (size_t) 2 << 30;
+
+static int
+ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe, int k,
+					   int64_t max_candidates, int partial, ndbhip_cand *d_cand, int *d_ncand,
+					   int64_t *d_total, uint64_t *d_otid, float *d_odist, int *d_ocnt)
+{
+	int			rc = ivf_check_search_args(ix, nq, nprobe, k);
+
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (topk_smem_bytes(3u * k, k) > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "k too large for the LDS top-k stage");
+
+	int64_t		maxc = ndbhip_ivf_max_candidates(ix, nprobe);
+
+	if (max_candidates > 0 && maxc > max_candidates)
+		maxc = max_candidates;
+	if (maxc > 0xFFFFFF00ll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 candidates per query");
+	const uint32_t stride = (uint32_t) std::max<int64_t>(64, (maxc + 63) & ~63ll);
+	int			qb = (int) std::max<size_t>(1, g_dist_budget_bytes / ((size_t) stride * 4));
+
+	qb = std::min(qb, std::min(nq, 65535));
+	const int	ncmp = std::min(ix->nlists, ix->ncent);
+	const size_t cstride = (size_t) ((ncmp + 63) & ~63);
+
+	if (grow(ix->w_cdist, ix->w_cdist_n, (size_t) qb * cstride)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_probes, ix->w_probes_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
+
+	const uint32_t cap = 3u * (uint32_t) k;
+
+	for (int q0 = 0; q0 < nq; q0 += qb)
+	{
+		const int	n = std::min(qb, nq - q0);
+
+		rc = ivf_search_chunk(ix, d_queries + (size_t) q0 * ix->dim, n, strategy, nprobe, k, max_candidates,
+							  stride, true, partial,
+							  d_cand ? d_cand + (size_t) q0 * cap : nullptr,
+							  d_ncand ? d_ncand + q0 : nullptr, d_total ? d_total + q0 : nullptr,
+							  d_otid ? d_otid + (size_t) q0 * k : nullptr,
+							  d_odist ? d_odist + (size_t) q0 * k : nullptr, d_ocnt ? d_ocnt + q0 : nullptr);
+		if (rc)
+			return rc;
+	}
+	g.stats.queries += (uint64_t) nq;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_search_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe, int k,
+						 int64_t max_candidates, uint64_t *d_out_tids, float *d_out_dist, int *d_out_count)
+{
+	if (nq > 0 && (!d_queries || !d_out_tids || !d_out_dist || !d_out_count))
+		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	return ivf_search_device_impl(ix, d_queries, nq, strategy, nprobe, k, max_candidates, 0, nullptr, nullptr,
+								  nullptr, d_out_tids, d_out_dist, d_out_count);
+}
+
+extern "C" int
+ndbhip_ivf_search_partial_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe,
+								 int k, int64_t max_candidates, ndbhip_cand *d_out_cand, int *d_out_ncand,
+								 int64_t *d_out_total)
+{
+	if (nq > 0 && (!d_queries || !d_out_cand || !d_out_ncand || !d_out_total))
+		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	return ivf_search_device_impl(ix, d_queries, nq, strategy, nprobe, k, max_candidates, 1, d_out_cand,
+								  d_out_ncand, d_out_total, nullptr, nullptr, nullptr);
+}
+
+extern "C" int
+ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, int nprobe, int k,
+				  int64_t max_candidates, uint8_t *out_tids6, float *out_dist, int *out_count)
+{
+	int			rc = ivf_check_search_args(ix, nq, nprobe, k);
+
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (!queries || !out_tids6 || !out_dist || !out_count)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	if (grow(ix->w_q, ix->w_q_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_otid, ix->w_otid_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_odist, ix->w_odist_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_ocnt, ix->w_ocnt_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(ix->w_q, queries, (size_t) nq * ix->dim * sizeof(float), hipMemcpyHostToDevice,
+						   g.stream));
+	rc = ivf_search_device_impl(ix, ix->w_q, nq, strategy, nprobe, k, max_candidates, 0, nullptr, nullptr,
+								nullptr, ix->w_otid, ix->w_odist, ix->w_ocnt);
+	if (rc)
+		return rc;
+	std::vector<uint64_t> t64((size_t) nq * k);
+
+	HIP_TRY(hipMemcpyAsync(t64.data(), ix->w_otid, t64.size() * 8, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(out_dist, ix->w_odist, (size_t) nq * k * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(out_count, ix->w_ocnt, (size_t) nq * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	for (int q = 0; q < nq; q++)
+		for (int i = 0; i < k; i++)
+		{
+			if (i < out_count[q])
+				ndb_tid_unpack(t64[(size_t) q * k + i], out_tids6 + ((size_t) q * k + i) * 6);
+			else
+			{
+				memset(out_tids6 + ((size_t) q * k + i) * 6, 0, 6);
+				out_dist[(size_t) q * k + i] = 0.0f;
+			}
+		}
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_select_clusters(ndbhip_ivf *ix, const float *queries, int nq, int nprobe, int *out_probes)
+{
+	int			rc = ivf_check_search_args(ix, nq, nprobe, 1);
+
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (!queries || !out_probes)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	const int	ncmp = std::min(ix->nlists, ix->ncent);
+	const size_t cstride = (size_t) ((ncmp + 63) & ~63);
+	const int	qb = 4096;
+
+	if (grow(ix->w_q, ix->w_q_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_cdist, ix->w_cdist_n, (size_t) std::min(qb, nq) * cstride)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_probes, ix->w_probes_n, (size_t) std::min(qb, nq) * nprobe)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) std::min(qb, nq) * (nprobe + 1))) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(ix->w_q, queries, (size_t) nq * ix->dim * sizeof(float), hipMemcpyHostToDevice,
+						   g.stream));
+	for (int q0 = 0; q0 < nq; q0 += qb)
+	{
+		const int	n = std::min(qb, nq - q0);
+
+		rc = ivf_search_chunk(ix, ix->w_q + (size_t) q0 * ix->dim, n, 1, nprobe, 1, 0, 0, false, 0, nullptr,
+							  nullptr, nullptr, nullptr, nullptr, nullptr);
+		if (rc)
+			return rc;
+		HIP_TRY(hipMemcpyAsync(out_probes + (size_t) q0 * nprobe, ix->w_probes, (size_t) n * nprobe * 4,
+							   hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	return NDBHIP_OK;
+}
+
+/* ================================================================== */
+/* shard merge                                                         */
+/* ================================================================== */
+
+extern "C" int
+ndbhip_merge_topk_device(const ndbhip_cand *d_cand, const int *d_ncand, const int64_t *d_total, int world,
+						 int nq, int k, int cap, uint64_t *d_out_tids, float *d_out_dist, int *d_out_count)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (world < 1 || world > 64 || nq < 0 || k < 1 || cap < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nq == 0)
+		return NDBHIP_OK;
+	const size_t smem = topk_smem_bytes((uint32_t) cap * world, (uint32_t) k);
+
+	if (smem > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "world*cap=%d records do not fit the LDS merge stage", cap * world);
+	hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(256), smem, g.stream, d_cand, d_ncand, d_total, world, nq,
+					   (uint32_t) k, (uint32_t) cap, d_out_tids, d_out_dist, d_out_count);
+	HIP_TRY(hipGetLastError());
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_merge_topk_host(const ndbhip_cand *cand, const int *ncand, const int64_t *total, int world, int nq,
+					   int k, int cap, uint64_t *out_tids, float *out_dist, int *out_count)
+{
+	if (!cand || !ncand || !total || !out_tids || !out_dist || !out_count || world < 1 || nq < 0 || k < 1 ||
+		cap < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	std::vector<uint32_t> key, pos;
+	std::vector<uint64_t> comp;
+	std::vector<uint32_t> idx;
+	std::vector<uint8_t> taken;
+	std::vector<int> order((size_t) k);
+	std::vector<const ndbhip_cand *> ent;
+
+	for (int q = 0; q < nq; q++)
+	{
+		ent.clear();
+		for (int w = 0; w < world; w++)
+		{
+			const int	n = ncand[(size_t) w * nq + q];
+
+			if (n < 0 || n > cap)
+				return fail(NDBHIP_ERR_INVALID, "ncand out of range");
+			for (int j = 0; j < n; j++)
+				ent.push_back(cand + ((size_t) w * nq + q) * cap + j);
+		}
+		const int	n = (int) ent.size();
+		int64_t		kk64 = std::min<int64_t>(k, total[q]);
+		int			kk = (int) std::min<int64_t>(kk64, n);
+
+		/* sort by (order key, position), keep the tie-complete prefix, replay */
+		idx.resize(n);
+		for (int j = 0; j < n; j++)
+			idx[j] = j;
+		std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+			const uint64_t ca = ((uint64_t) ndb_key_from_bits(ent[a]->key) << 32) | ent[a]->pos;
+			const uint64_t cb = ((uint64_t) ndb_key_from_bits(ent[b]->key) << 32) | ent[b]->pos;
+
+			return ca < cb;
+		});
+		int			ns = n;
+
+		if (kk > 0)
+		{
+			const uint32_t Tkey = ndb_key_from_bits(ent[idx[kk - 1]]->key);
+			int			first = 0;
+
+			while (first < kk && ndb_key_from_bits(ent[idx[first]]->key) < Tkey)
+				first++;
+			ns = std::min(n, first + 2 * k);
+		}
+		key.resize(ns);
+		pos.resize(ns);
+		taken.resize(ns ? ns : 1);
+		for (int j = 0; j < ns; j++)
+		{
+			key[j] = ndb_key_from_bits(ent[idx[j]]->key);
+			pos[j] = ent[idx[j]]->pos;
+		}
+		const int	got = ndb_replay_selection_host(key.data(), pos.data(), taken.data(), ns, k, total[q],
+													order.data());
+
+		for (int i = 0; i < k; i++)
+		{
+			if (i < got)
+			{
+				const ndbhip_cand *c = ent[idx[order[i]]];
+
+				out_tids[(size_t) q * k + i] = c->tid;
+				out_dist[(size_t) q * k + i] = ndb_u2f(c->key);
+			}
+			else
+			{
+				out_tids[(size_t) q * k + i] = 0;
+				out_dist[(size_t) q * k + i] = 0.0f;
+			}
+		}
+		out_count[q] = got;
+	}
+	return NDBHIP_OK;
+}
+
+/* ================================================================== */
+/* batch distance                                                      */
+/* ================================================================== */
+
+extern "C" int
+ndbhip_batch_distance(const float *queries, const float *vectors, float *results, int nq, int nv, int dim,
+					  int strategy, int recipe)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (nq < 0 || nv < 0 || dim < 1 || dim > 32767)
+		return fail(NDBHIP_ERR_INVALID, "bad sizes");
+	if (nq == 0 || nv == 0)
+		return NDBHIP_OK;
+	if (!queries || !vectors || !results)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	int			R;
+
+	if (recipe == 0)
+		R = (strategy == 4) ? R_IVF_L2SQ : ivf_recipe(strategy);
+	else if (recipe == 1)
+	{
+		if (strategy < 1 || strategy > 3)
+			return fail(NDBHIP_ERR_UNSUPPORTED, "hnsw: unsupported distance strategy %d", strategy);
+		R = R_HNSW_L2 + (strategy - 1);
+	}
+	else
+		return fail(NDBHIP_ERR_INVALID, "recipe must be 0 (ivf) or 1 (hnsw)");
+
+	float	   *d_q = nullptr, *d_v = nullptr, *d_o = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_q, (size_t) nq * dim * 4));
+	HIP_TRY(hipMalloc((void **) &d_v, (size_t) nv * dim * 4));
+	HIP_TRY(hipMalloc((void **) &d_o, (size_t) nq * nv * 4));
+	HIP_TRY(hipMemcpyAsync(d_q, queries, (size_t) nq * dim * 4, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_v, vectors, (size_t) nv * dim * 4, hipMemcpyHostToDevice, g.stream));
+	for (int q0 = 0; q0 < nq; q0 += 65535)
+	{
+		const int	n = std::min(65535, nq - q0);
+		dim3		grid((nv + 255) / 256, n);
+
+		LAUNCH_BY_RECIPE(R, k_rows_scan, grid, dim3(256), (const float *) d_v, (uint32_t) nv, dim,
+						 (const float *) (d_q + (size_t) q0 * dim), d_o + (size_t) q0 * nv, (uint32_t) nv);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(results, d_o, (size_t) nq * nv * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_q));
+	HIP_TRY(hipFree(d_v));
+	HIP_TRY(hipFree(d_o));
+	g.host_rows += (uint64_t) nq * nv;
+	g.host_bytes += (uint64_t) nq * nv * dim * 4;
+	return NDBHIP_OK;
+}
+
+/* ================================================================== */
+/* entry points implemented in later sections of this file            */
+/* ================================================================== */
+#ifndef NDB_HAVE_BUILD
+extern "C" int
+ndbhip_ivf_append(ndbhip_ivf *, int, const float *, const uint8_t *)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_append: not implemented in this build");
+}
+extern "C" int
+ndbhip_kmeans_device(const float *, int, int, int, int, float, float *, int *, int *, int *, float *)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_kmeans_device: not implemented in this build");
+}
+extern "C" int
+ndbhip_ivf_assign_device(const float *, int, int, const float *, int64_t, int *)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_assign_device: not implemented in this build");
+}
+extern "C" int
+ndbhip_ivf_build_device(ndbhip_ivf *, const float *, const uint64_t *, int64_t, int, int *)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_build_device: not implemented in this build");
+}
+#endif
+#ifndef NDB_HAVE_HNSW
+extern "C" int
+ndbhip_hnsw_create(int, int, ndbhip_hnsw **)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
+}
+extern "C" int
+ndbhip_hnsw_destroy(ndbhip_hnsw *)
+{
+	return NDBHIP_OK;
+}
+extern "C" int
+ndbhip_hnsw_load(ndbhip_hnsw *, uint32_t, const float *, const int32_t *, const int16_t *, const int64_t *,
+				 const uint32_t *, const uint8_t *, uint32_t, int)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
+}
+extern "C" int
+ndbhip_hnsw_search(ndbhip_hnsw *, const float *, int, int, int, int, uint32_t *, float *, int *, uint8_t *,
+				   int64_t *)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
+}
+extern "C" int
+ndbhip_hnsw_search_device(ndbhip_hnsw *, const float *, int, int, int, int, uint32_t *, float *, int *,
+						  uint64_t *, int64_t *)
+{
+	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
+}
+#endif

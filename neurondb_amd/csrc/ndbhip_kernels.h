@@ -1,0 +1,262 @@
+/*
+ * ndbhip_kernels.h — device code of the MI355X (gfx950, wave64) distance engine.
+ *
+ * Design (DESIGN.md has the long form):
+ *
+ *  * Exact arithmetic.  The reference scores a candidate with a strictly
+ *    sequential loop (`sum += diff*diff`, src/index/ivf_am.c:1562-1568; fp64
+ *    accumulate in src/index/hnsw_am.c:1312-1337).  A lane-parallel reduction
+ *    rounds differently and can flip neighbour ranks, so here ONE LANE OWNS ONE
+ *    ROW and walks its dimensions in order with the same operand types and the
+ *    same unfused multiply/add — distances come out bit-identical, not merely
+ *    the ids.  Parallelism is across rows (64 rows per wave), never inside one.
+ *
+ *  * HBM-bound by construction.  A lane reading its own row would touch a new
+ *    3 KB-strided line per lane.  Instead a wave stages a 64-row x 256-byte
+ *    chunk through a wave-private 16 KiB LDS tile: 16 lanes fetch one row's
+ *    256 contiguous bytes (4 rows = 1 KiB per load instruction, fully
+ *    coalesced), the tile is written with a 16-byte-slot XOR swizzle
+ *    (slot ^= row & 15) and each lane then reads its row back with
+ *    conflict-free ds_read_b128.  Waves never synchronise with each other
+ *    (no s_barrier): each is an independent streaming engine, latency is
+ *    hidden by 8+ waves per CU.
+ *
+ *  * The query is wave-uniform: it is read through the scalar cache into SGPRs
+ *    and used as the scalar operand of v_sub/v_mul — no LDS traffic for it.
+ */
+#ifndef NDBHIP_KERNELS_H
+#define NDBHIP_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ndbhip_common.h"
+
+#pragma clang fp contract(off)
+
+#define NDB_WAVE 64
+#define NDB_CHUNK 64						/* floats of each row staged per step (256 B) */
+#define NDB_TILE_FLOATS (NDB_WAVE * NDB_CHUNK)	/* 16 KiB per wave */
+
+/* rounding recipes */
+enum
+{
+	R_IVF_L2 = 0,				/* ivf_am.c:1561-1568 */
+	R_IVF_COS = 1,				/* ivf_am.c:1570-1581 */
+	R_IVF_IP = 2,				/* new (quirk Q2): -dot, fp32 sequential */
+	R_IVF_L2SQ = 3,				/* ivf_am.c:2255-2269 (k-means) */
+	R_HNSW_L2 = 4,				/* hnsw_am.c:1312-1319 */
+	R_HNSW_COS = 5,				/* hnsw_am.c:1321-1332 */
+	R_HNSW_IP = 6,				/* hnsw_am.c:1334-1337 */
+	R_COUNT = 7
+};
+
+template <int R> struct Acc;
+
+template <> struct Acc<R_IVF_L2>
+{
+	float		s = 0.0f;
+	__device__ __forceinline__ void step(float q, float x)
+	{
+		float		d = q - x;
+
+		s = s + d * d;
+	}
+	__device__ __forceinline__ float fin() const { return __builtin_sqrtf(s); }
+};
+
+template <> struct Acc<R_IVF_L2SQ>
+{
+	float		s = 0.0f;
+	__device__ __forceinline__ void step(float q, float x)
+	{
+		float		d = q - x;
+
+		s = s + d * d;
+	}
+	__device__ __forceinline__ float fin() const { return s; }
+};
+
+template <> struct Acc<R_IVF_COS>
+{
+	float		dot = 0.0f, n1 = 0.0f, n2 = 0.0f;
+	__device__ __forceinline__ void step(float q, float x)
+	{
+		dot = dot + q * x;
+		n1 = n1 + q * q;
+		n2 = n2 + x * x;
+	}
+	__device__ __forceinline__ float fin() const
+	{
+		float		a = __builtin_sqrtf(n1);
+		float		b = __builtin_sqrtf(n2);
+
+		if (a == 0.0f || b == 0.0f)
+			return 1.0f;
+		return 1.0f - (dot / (a * b));
+	}
+};
+
+template <> struct Acc<R_IVF_IP>
+{
+	float		dot = 0.0f;
+	__device__ __forceinline__ void step(float q, float x) { dot = dot + q * x; }
+	__device__ __forceinline__ float fin() const { return -dot; }
+};
+
+template <> struct Acc<R_HNSW_L2>
+{
+	double		s = 0.0;
+	__device__ __forceinline__ void step(float q, float x)
+	{
+		double		d = (double) (q - x);	/* fp32 subtract, then widened */
+
+		s = s + d * d;
+	}
+	__device__ __forceinline__ float fin() const { return (float) __builtin_sqrt(s); }
+};
+
+template <> struct Acc<R_HNSW_COS>
+{
+	double		dot = 0.0, n1 = 0.0, n2 = 0.0;
+	__device__ __forceinline__ void step(float q, float x)
+	{
+		dot = dot + (double) (q * x);	/* fp32 products, widened */
+		n1 = n1 + (double) (q * q);
+		n2 = n2 + (double) (x * x);
+	}
+	__device__ __forceinline__ float fin() const
+	{
+		double		a = __builtin_sqrt(n1);
+		double		b = __builtin_sqrt(n2);
+
+		if (a == 0.0 || b == 0.0)
+			return 2.0f;
+		return (float) (1.0 - (dot / (a * b)));
+	}
+};
+
+template <> struct Acc<R_HNSW_IP>
+{
+	double		dot = 0.0;
+	__device__ __forceinline__ void step(float q, float x) { dot = dot + (double) (q * x); }
+	__device__ __forceinline__ float fin() const { return (float) (-dot); }
+};
+
+/* Order LDS writes before the same wave's later LDS reads (different lanes).
+ * LDS instructions of one wave execute in issue order; this only pins the
+ * compiler's ordering. No instruction is emitted. */
+__device__ __forceinline__ void
+wave_lds_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/*
+ * Score 64 rows (one per lane) against the wave-uniform query q.
+ *   base   row-major [* x dim] fp32, 16-byte aligned, dim % 4 == 0
+ *   row    this lane's row number (any valid row for idle lanes)
+ *   tile   this wave's private 16 KiB LDS tile
+ * Returns this lane's distance, bit-identical to the CPU recipe R.
+ */
+/* One 64-row x 64-float step: stage through LDS, then every lane walks its row.
+ * FULL = the chunk lies completely inside the row (no per-piece bounds checks). */
+template <int R, bool FULL>
+__device__ __forceinline__ void
+score_chunk(Acc<R> &acc, const float *__restrict__ q, const float *__restrict__ base,
+			const uint32_t (&rows16)[16], int dim, int c, float *tile, int lane, int grp, int slot)
+{
+	float4		v[16];
+
+	/* global -> registers: instruction i covers rows 4i..4i+3, 256 B each */
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		const int	r = 4 * i + grp;
+		const int	piece = slot ^ (r & 15);
+		const int	col = c + piece * 4;
+		const float *src = base + (size_t) rows16[i] * (size_t) dim + col;
+
+		if (FULL || col < dim)
+			v[i] = *reinterpret_cast<const float4 *>(src);
+		else
+			v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+	/* registers -> LDS, linear in (row, slot): piece p of row r sits in slot p ^ (r & 15) */
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		const int	r = 4 * i + grp;
+
+		*reinterpret_cast<float4 *>(tile + r * NDB_CHUNK + slot * 4) = v[i];
+	}
+	wave_lds_sync();
+
+	/* each lane walks ITS row's chunk in dimension order */
+	const int	npieces = FULL ? 16 : ((dim - c) >> 2);
+#pragma unroll
+	for (int p = 0; p < 16; p++)
+	{
+		if (FULL || p < npieces)
+		{
+			const float4 x = *reinterpret_cast<const float4 *>(
+				tile + lane * NDB_CHUNK + ((p ^ (lane & 15)) * 4));
+			const float4 qq = *reinterpret_cast<const float4 *>(q + c + p * 4);
+
+			acc.step(qq.x, x.x);
+			acc.step(qq.y, x.y);
+			acc.step(qq.z, x.z);
+			acc.step(qq.w, x.w);
+		}
+	}
+	wave_lds_sync();
+}
+
+template <int R>
+__device__ __forceinline__ float
+score_rows_tiled(const float *__restrict__ q, const float *__restrict__ base,
+				 uint32_t row, int dim, float *tile)
+{
+	const int	lane = threadIdx.x & (NDB_WAVE - 1);
+	const int	grp = lane >> 4;	/* which of the 4 rows of a load instruction */
+	const int	slot = lane & 15;	/* 16-byte slot inside the 256-byte row chunk */
+	uint32_t	rows16[16];
+	Acc<R>		acc;
+	int			c = 0;
+
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		rows16[i] = __shfl(row, 4 * i + grp, NDB_WAVE);
+
+	for (; c + NDB_CHUNK <= dim; c += NDB_CHUNK)
+		score_chunk<R, true>(acc, q, base, rows16, dim, c, tile, lane, grp, slot);
+	if (c < dim)
+		score_chunk<R, false>(acc, q, base, rows16, dim, c, tile, lane, grp, slot);
+	return acc.fin();
+}
+
+/* Any dimension, no alignment requirement: the lane reads its row directly.
+ * Used only when dim % 4 != 0 (tiny test shapes). */
+template <int R>
+__device__ __forceinline__ float
+score_row_direct(const float *__restrict__ q, const float *__restrict__ rowp, int dim)
+{
+	Acc<R>		acc;
+
+	for (int i = 0; i < dim; i++)
+		acc.step(q[i], rowp[i]);
+	return acc.fin();
+}
+
+template <int R>
+__device__ __forceinline__ float
+score_rows(const float *__restrict__ q, const float *__restrict__ base, uint32_t row, int dim,
+		   float *tile)
+{
+	if ((dim & 3) == 0)
+		return score_rows_tiled<R>(q, base, row, dim, tile);
+	return score_row_direct<R>(q, base + (size_t) row * (size_t) dim, dim);
+}
+
+#endif							/* NDBHIP_KERNELS_H */

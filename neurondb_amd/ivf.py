@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's IVF access-method interface
+(NeuronDB/src/index/ivf_am.c) over the C ABI.
+
+IvfIndex  ~ the index relation: centroids + inverted lists, resident in HBM.
+IvfScan   ~ IndexScanDesc + IvfScanOpaqueData: rescan(query) / gettuple(),
+            same state machine as ivfrescan / ivfgettuple (ivf_am.c:1439-1545,
+            1911-2027): the first gettuple() call does all the work, later
+            calls stream the buffered (tid, distance) pairs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ensure_init, lib
+
+IVF_DEFAULT_NPROBE = 10   # ivf_am.c:55
+IVF_DEFAULT_K = 10        # ivf_am.c:1543
+
+TID_DTYPE = np.dtype([("bi_hi", "<u2"), ("bi_lo", "<u2"), ("posid", "<u2")])
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class IvfIndex:
+    def __init__(self, dim: int, nlists: int, device: int | None = None):
+        ensure_init(device)
+        self.dim, self.nlists = int(dim), int(nlists)
+        h = C.c_void_p()
+        check(lib().ndbhip_ivf_create(self.dim, self.nlists, C.byref(h)))
+        self._h = h
+        self._keep = []          # device tensors adopted by load_device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ndbhip_ivf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- loading ---------------------------------------------------------
+    def set_centroids(self, centroids):
+        c = np.ascontiguousarray(centroids, dtype=np.float32)
+        assert c.ndim == 2 and c.shape[1] == self.dim
+        check(lib().ndbhip_ivf_set_centroids(self._h, _ptr(c), c.shape[0]))
+        self.ncent = c.shape[0]
+
+    def load(self, list_len, rows, tids, owned=None):
+        """rows: [n, dim] float32 of the OWNED lists, list-major; tids: structured TID array or [n,6] uint8."""
+        ll = np.ascontiguousarray(list_len, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.dim)
+        t = np.ascontiguousarray(tids)
+        t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
+        t6 = np.ascontiguousarray(t6)
+        ow = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
+        check(lib().ndbhip_ivf_load(self._h, _ptr(ll), _ptr(ow), _ptr(rows), _ptr(t6), rows.shape[0]))
+
+    def load_device(self, list_len, d_rows, d_tids, owned=None):
+        """d_rows: torch float32 [n, dim] on the device, d_tids: torch int64 [n] (device TID format)."""
+        ll = np.ascontiguousarray(list_len, dtype=np.int64)
+        ow = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
+        assert d_rows.is_contiguous() and d_tids.is_contiguous()
+        check(lib().ndbhip_ivf_load_device(self._h, _ptr(ll), _ptr(ow), C.c_void_p(d_rows.data_ptr()),
+                                           C.c_void_p(d_tids.data_ptr()), d_rows.shape[0]))
+        self._keep = [d_rows, d_tids]
+
+    @property
+    def nrows(self):
+        return lib().ndbhip_ivf_nrows(self._h)
+
+    def max_candidates(self, nprobe):
+        return lib().ndbhip_ivf_max_candidates(self._h, nprobe)
+
+    # -- search ----------------------------------------------------------
+    def search(self, queries, strategy=1, nprobe=IVF_DEFAULT_NPROBE, k=IVF_DEFAULT_K, max_candidates=0):
+        """Host arrays in/out. Returns (tids [nq,k] structured, dist [nq,k], count [nq])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        t6 = np.zeros((nq, k, 6), dtype=np.uint8)
+        d = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.int32)
+        check(lib().ndbhip_ivf_search(self._h, _ptr(q), nq, strategy, nprobe, k, int(max_candidates),
+                                      _ptr(t6), _ptr(d), _ptr(cnt)))
+        return t6.view(TID_DTYPE).reshape(nq, k), d, cnt
+
+    def search_device(self, d_queries, out_tids, out_dist, out_count, strategy=1, nprobe=IVF_DEFAULT_NPROBE,
+                      k=IVF_DEFAULT_K, max_candidates=0):
+        """torch device tensors in/out; asynchronous on the current ndbhip stream."""
+        nq = d_queries.shape[0]
+        check(lib().ndbhip_ivf_search_device(self._h, C.c_void_p(d_queries.data_ptr()), nq, strategy, nprobe, k,
+                                             int(max_candidates), C.c_void_p(out_tids.data_ptr()),
+                                             C.c_void_p(out_dist.data_ptr()), C.c_void_p(out_count.data_ptr())))
+
+    def search_partial_device(self, d_queries, out_cand, out_ncand, out_total, strategy=1,
+                              nprobe=IVF_DEFAULT_NPROBE, k=IVF_DEFAULT_K, max_candidates=0):
+        nq = d_queries.shape[0]
+        check(lib().ndbhip_ivf_search_partial_device(
+            self._h, C.c_void_p(d_queries.data_ptr()), nq, strategy, nprobe, k, int(max_candidates),
+            C.c_void_p(out_cand.data_ptr()), C.c_void_p(out_ncand.data_ptr()), C.c_void_p(out_total.data_ptr())))
+
+    def select_clusters(self, queries, nprobe=IVF_DEFAULT_NPROBE):
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        out = np.zeros((q.shape[0], nprobe), dtype=np.int32)
+        check(lib().ndbhip_ivf_select_clusters(self._h, _ptr(q), q.shape[0], nprobe, _ptr(out)))
+        return out
+
+
+class IvfScan:
+    """ivfbeginscan / ivfrescan / ivfgettuple / ivfendscan over an IvfIndex."""
+
+    def __init__(self, index: IvfIndex, ref_compat: bool = False):
+        # ivfbeginscan: ivf_am.c:1412-1437
+        self.index = index
+        self.ref_compat = ref_compat
+        self.query = None
+        self.strategy = 1
+        self.nprobe = IVF_DEFAULT_NPROBE
+        self.k = IVF_DEFAULT_K
+        self.first_call = True
+        self.result_count = 0
+        self.results = None
+        self.distances = None
+        self.current = 0
+        self.xs_heaptid = None
+        self.xs_orderbyval = None
+
+    def rescan(self, query, strategy=1, nprobe=None, k=None):
+        # ivfrescan: ivf_am.c:1439-1545 — resets state, copies the query
+        self.first_call = True
+        self.result_count = 0
+        self.current = 0
+        self.results = self.distances = None
+        self.query = None if query is None else np.array(query, dtype=np.float32, copy=True)
+        if self.ref_compat:
+            # Q1: every opclass registers strategy 1; Q4: nprobe pinned; Q3: k pinned
+            self.strategy, self.nprobe, self.k = 1, IVF_DEFAULT_NPROBE, IVF_DEFAULT_K
+        else:
+            self.strategy = strategy
+            self.nprobe = IVF_DEFAULT_NPROBE if nprobe is None else int(nprobe)
+            self.k = IVF_DEFAULT_K if k is None else int(k)
+
+    def gettuple(self) -> bool:
+        # ivfgettuple: ivf_am.c:1911-2027
+        if self.query is None:
+            return False
+        if self.first_call:
+            if self.query.shape[0] != self.index.dim:       # :1961-1972
+                self.first_call = False
+                self.result_count = 0
+                return False
+            cap = self.k * 10 if self.ref_compat else 0     # :1743
+            t, d, c = self.index.search(self.query[None, :], self.strategy, self.nprobe, self.k, cap)
+            self.result_count = int(c[0])
+            self.results, self.distances = t[0], d[0]
+            self.first_call = False
+            self.current = 0
+        if self.current < self.result_count:                # :2011-2024
+            self.xs_heaptid = self.results[self.current]
+            self.xs_orderbyval = self.distances[self.current]
+            self.current += 1
+            return True
+        return False
+
+    def endscan(self):
+        self.query = self.results = self.distances = None

@@ -1,0 +1,221 @@
+"""Parity of the HIP IVF path (through the C ABI) against the CPU oracle:
+neighbour ids, ranks AND float4 distances bit-identical.  Runs on the MI355X."""
+import numpy as np
+import pytest
+
+from tests.util import assert_same_results, make_ivf_arrays, oracle_image, oracle_search_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(a, nlists=None):
+    from neurondb_amd import IvfIndex
+    ix = IvfIndex(a["centroids"].shape[1], nlists if nlists is not None else len(a["list_len"]))
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    return ix
+
+
+def _queries(a, nq, seed):
+    rng = np.random.default_rng(seed)
+    dim = a["base"].shape[1]
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[: nq // 4] = a["base"][rng.integers(0, len(a["base"]), nq // 4)]   # exact hits (distance 0)
+    return q
+
+
+def test_batch_distance_all_recipes_bitexact():
+    """hot loops 1/2 in isolation: every rounding recipe, several dims (tiled, tail chunk, direct)."""
+    import ctypes as C
+    from neurondb_amd import _lib
+    from oracle import ndbo
+    _lib.ensure_init()
+    L = ndbo.lib()
+    rng = np.random.default_rng(3)
+    for dim in (4, 28, 64, 100, 128, 768, 3, 130, 1536):
+        nq, nv = 3, 200
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        v = rng.standard_normal((nv, dim)).astype(np.float32)
+        v[5] = 0.0
+        v[7] = q[0]
+        for recipe, strategies in ((0, (1, 2, 3, 4)), (1, (1, 2, 3))):
+            for s in strategies:
+                out = np.zeros((nq, nv), np.float32)
+                _lib.check(_lib.lib().ndbhip_batch_distance(q.ctypes.data, v.ctypes.data, out.ctypes.data,
+                                                            nq, nv, dim, s, recipe))
+                exp = np.zeros_like(out)
+                for i in range(nq):
+                    for j in range(nv):
+                        if recipe == 0 and s == 4:
+                            exp[i, j] = L.ndbo_ivf_l2sq(q[i], v[j], dim)
+                        elif recipe == 0:
+                            exp[i, j] = L.ndbo_ivf_distance(q[i], v[j], dim, s)
+                        else:
+                            exp[i, j] = L.ndbo_hnsw_distance(q[i], v[j], dim, s, None)
+                assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), (dim, recipe, s)
+
+
+@pytest.mark.parametrize("dim,n,nlists", [(4, 100, 10), (28, 1000, 10), (128, 10000, 100), (768, 4000, 64),
+                                           (3, 300, 7), (100, 2000, 20)])
+@pytest.mark.parametrize("strategy", [1, 2, 3])
+def test_ivf_search_matches_oracle(dim, n, nlists, strategy):
+    a = make_ivf_arrays(n, dim, nlists, seed=dim * 7 + nlists, dup_frac=0.05, zero_rows=2)
+    ix = _index(a)
+    img = oracle_image(a)
+    q = _queries(a, 24, seed=dim)
+    for nprobe, k in ((10, 10), (3, 5), (nlists, 10), (1, 1)):
+        nprobe = min(nprobe, 64)
+        t, d, c = ix.search(q, strategy, nprobe, k)
+        et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k)
+        assert_same_results(t, d, c, et, ed, ec)
+
+
+def test_c1_config_oracle_built_index_ref_compat_and_intended():
+    """BASELINE configs[0]: 10k x 128, lists=100, k=10 L2, index built by the oracle's k-means
+    (reference build rule), searched in ref_compat (cap k*10, nprobe 10) and intended mode."""
+    from oracle import ndbo
+    rng = np.random.default_rng(2024)
+    base = rng.standard_normal((10000, 128)).astype(np.float32)
+    img, asg, iters = ndbo.build_ivf_image(base, 100, max_iter=8)
+    a = dict(centroids=img.centroids, list_len=np.diff(img.list_off), rows=img.vecs, tids=img.tids, base=base)
+    ix = _index(a)
+    q = _queries(a, 32, seed=9)
+    for cap in (100, 0):
+        t, d, c = ix.search(q, 1, 10, 10, cap)
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, 10, 10, cap)
+        assert_same_results(t, d, c, et, ed, ec)
+    # centroid selection alone
+    sel = ix.select_clusters(q, 10)
+    for i in range(len(q)):
+        assert np.array_equal(sel[i], img.select_clusters(q[i], 10))
+
+
+def test_integer_data_massive_ties():
+    """small integer coordinates => many equal distances, incl. inside the first k slots."""
+    a = make_ivf_arrays(3000, 8, 12, seed=5, integer=True)
+    ix = _index(a)
+    img = oracle_image(a)
+    rng = np.random.default_rng(1)
+    q = rng.integers(-3, 4, size=(40, 8)).astype(np.float32)
+    for strategy in (1, 2, 3):
+        for k in (1, 10, 37):
+            t, d, c = ix.search(q, strategy, 6, k)
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, 6, k)
+            assert_same_results(t, d, c, et, ed, ec)
+
+
+def test_all_rows_identical():
+    n, dim = 700, 16
+    a = make_ivf_arrays(n, dim, 5, seed=1)
+    a["rows"][:] = a["rows"][0]
+    ix = _index(a)
+    img = oracle_image(a)
+    q = np.stack([a["rows"][0], a["rows"][0] + 1.0]).astype(np.float32)
+    t, d, c = ix.search(q, 1, 5, 10)
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, 5, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+
+
+def test_edge_cases_empty_lists_small_index_and_nprobe_quirk():
+    # empty lists among the probed ones
+    a = make_ivf_arrays(500, 16, 8, seed=3, empty_lists=(0, 3, 7))
+    assert a["list_len"][0] == 0
+    ix = _index(a)
+    img = oracle_image(a)
+    q = _queries(a, 8, seed=4)
+    t, d, c = ix.search(q, 1, 8, 10)
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, 8, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+    # fewer candidates than k
+    t, d, c = ix.search(q, 1, 1, 400)
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, 1, 400)
+    assert_same_results(t, d, c, et, ed, ec)
+    # nprobe > nlists: never-written probe slots re-scan list 0 (palloc0: ivf_am.c:1978)
+    a2 = make_ivf_arrays(300, 8, 4, seed=8)
+    ix2 = _index(a2)
+    img2 = oracle_image(a2)
+    q2 = _queries(a2, 6, seed=2)
+    t, d, c = ix2.search(q2, 1, 7, 10)
+    et, ed, ec, _ = oracle_search_batch(img2, q2, 1, 7, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+    # completely empty index
+    a3 = make_ivf_arrays(50, 8, 4, seed=8)
+    from neurondb_amd import IvfIndex
+    ix3 = IvfIndex(8, 4)
+    ix3.set_centroids(a3["centroids"])
+    ix3.load(np.zeros(4, np.int64), np.zeros((0, 8), np.float32), np.zeros((0, 6), np.uint8))
+    t, d, c = ix3.search(q2, 1, 4, 10)
+    assert (c == 0).all()
+
+
+def test_scan_state_machine_mirrors_ivfgettuple():
+    from neurondb_amd import IvfScan
+    a = make_ivf_arrays(2000, 32, 20, seed=11)
+    ix = _index(a)
+    img = oracle_image(a)
+    q = _queries(a, 3, seed=12)
+    for ref_compat in (True, False):
+        scan = IvfScan(ix, ref_compat=ref_compat)
+        for qq in q:
+            scan.rescan(qq, strategy=2, nprobe=4, k=7)
+            got = []
+            while scan.gettuple():
+                got.append((scan.xs_heaptid.copy(), scan.xs_orderbyval))
+            if ref_compat:
+                et, ed, _ = img.search(qq, 1, 10, 10, 100)
+            else:
+                et, ed, _ = img.search(qq, 2, 4, 7, 0)
+            assert len(got) == len(et)
+            for (t, d), t2, d2 in zip(got, et, ed):
+                assert t == t2 and np.float32(d).tobytes() == np.float32(d2).tobytes()
+        scan.endscan()
+        # wrong-dimension query: no rows, no error (ivf_am.c:1961-1972)
+        scan.rescan(np.zeros(5, np.float32))
+        assert scan.gettuple() is False
+
+
+def test_sharded_partial_plus_merge_equals_single_device():
+    """8-way list sharding emulated on one GPU: per-shard partial records -> merge == unsharded."""
+    import torch
+    from neurondb_amd import IvfIndex, _lib
+    a = make_ivf_arrays(6000, 64, 32, seed=21, dup_frac=0.1)
+    img = oracle_image(a)
+    q = _queries(a, 16, seed=22)
+    k, nprobe, world = 10, 8, 8
+    cap = 3 * k
+    off = np.zeros(33, np.int64)
+    off[1:] = np.cumsum(a["list_len"])
+    dq = torch.from_numpy(q).cuda()
+    cand = torch.zeros((world, len(q), cap, 2), dtype=torch.int64, device="cuda")   # 16-byte records
+    ncand = torch.zeros((world, len(q)), dtype=torch.int32, device="cuda")
+    total = torch.zeros((world, len(q)), dtype=torch.int64, device="cuda")
+    keep = []
+    for w in range(world):
+        owned = (np.arange(32) % world == w).astype(np.uint8)
+        sel = np.concatenate([np.arange(off[l], off[l + 1]) for l in range(32) if owned[l]] or
+                             [np.zeros(0, np.int64)]).astype(np.int64)
+        ix = IvfIndex(64, 32)
+        ix.set_centroids(a["centroids"])
+        ix.load(a["list_len"], a["rows"][sel], a["tids"][sel], owned=owned)
+        ix.search_partial_device(dq, cand[w], ncand[w], total[w], 1, nprobe, k)
+        keep.append(ix)
+    ot = torch.zeros((len(q), k), dtype=torch.int64, device="cuda")
+    od = torch.zeros((len(q), k), dtype=torch.float32, device="cuda")
+    oc = torch.zeros(len(q), dtype=torch.int32, device="cuda")
+    import ctypes as C
+    _lib.check(_lib.lib().ndbhip_merge_topk_device(cand.data_ptr(), ncand.data_ptr(), total[0].data_ptr(),
+                                                   world, len(q), k, cap, ot.data_ptr(), od.data_ptr(),
+                                                   oc.data_ptr()))
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+    assert np.array_equal(oc.cpu().numpy(), ec)
+    assert np.array_equal(ot.cpu().numpy().astype(np.uint64), et)
+    assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+    # the host merge agrees too
+    hc, hn, ht = cand.cpu().numpy(), ncand.cpu().numpy(), total[0].cpu().numpy()
+    ot2 = np.zeros((len(q), k), np.uint64)
+    od2 = np.zeros((len(q), k), np.float32)
+    oc2 = np.zeros(len(q), np.int32)
+    _lib.check(_lib.lib().ndbhip_merge_topk_host(hc.ctypes.data, hn.ctypes.data, ht.ctypes.data, world, len(q),
+                                                 k, cap, ot2.ctypes.data, od2.ctypes.data, oc2.ctypes.data))
+    assert np.array_equal(ot2, et) and np.array_equal(oc2, ec)
