@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""bench.py — kNN queries/sec on the IVFFlat list-scan hot path (BASELINE.json configs[1]:
+1M x 768 fp32, lists=1024, probes=32, k=10, L2) on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (centroid scan -> probe select -> list scan -> top-k)
+over one batch of --batch synthetic queries, inputs resident in HBM.  N > 1: the inverted
+lists are sharded over the ranks (size-balanced), every rank scans its own lists for the
+whole batch, the per-rank candidate records are all-gathered over RCCL and merged (strong
+scaling: the index and the query stream are the same as at N = 1).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nvec", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--lists", type=int, default=1024)
+    ap.add_argument("--probes", type=int, default=32)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="queries per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--recall-queries", type=int, default=200)
+    ap.add_argument("--setup-build", choices=["hip", "torch"], default="hip",
+                    help="hip: ndbhip_ivf_build_device (reference k-means rule); torch: approximate setup")
+    return ap.parse_args()
+
+
+def pack_tids(rows: torch.Tensor) -> torch.Tensor:
+    """row number -> device TID format (uint64 image of ItemPointerData): block = row // 64, offset = row % 64 + 1."""
+    blk = rows // 64
+    bi_hi = (blk >> 16) & 0xFFFF
+    bi_lo = blk & 0xFFFF
+    pos = rows % 64 + 1
+    return (bi_hi | (bi_lo << 16) | (pos << 32)).to(torch.int64)
+
+
+def unpack_tids(t: torch.Tensor) -> torch.Tensor:
+    bi_hi = t & 0xFFFF
+    bi_lo = (t >> 16) & 0xFFFF
+    pos = (t >> 32) & 0xFFFF
+    return ((bi_hi << 16) | bi_lo) * 64 + pos - 1
+
+
+def torch_setup_build(base, nlists, iters=8):
+    """Approximate IVF build with torch ops — SETUP ONLY (not timed, not the product's build path)."""
+    n, dim = base.shape
+    ns = min(10000, nlists * 100, n)
+    smp = base[:ns]
+    cent = smp[:nlists].clone()
+    for _ in range(iters):
+        a = torch.cdist(smp, cent).argmin(1)
+        for_sum = torch.zeros_like(cent).index_add_(0, a, smp)
+        cnt = torch.bincount(a, minlength=nlists).clamp(min=1).unsqueeze(1)
+        cent = for_sum / cnt
+    asg = torch.empty(n, dtype=torch.int64, device=base.device)
+    cc = (cent * cent).sum(1)
+    for s in range(0, n, 131072):
+        x = base[s:s + 131072]
+        asg[s:s + 131072] = (cc[None, :] - 2.0 * (x @ cent.T)).argmin(1)
+    return cent, asg
+
+
+def lpt_partition(list_len, world):
+    """Size-balanced list -> rank map (longest processing time first)."""
+    order = np.argsort(-list_len, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.zeros(len(list_len), dtype=np.int32)
+    for l in order:
+        r = int(load.argmin())
+        owner[l] = r
+        load[r] += list_len[l]
+    return owner
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import check, lib
+    _lib.ensure_init(local_rank)
+    stream = torch.cuda.current_stream()
+    check(lib().ndbhip_set_stream(stream.cuda_stream))
+
+    n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
+
+    # ---------------- synthetic data (identical on every rank) ----------------
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0001)
+    base = torch.randn((n, dim), generator=gen, device=dev, dtype=torch.float32)
+    gen.manual_seed(0x5EED0002)
+    nq_total = nq * (args.steps + args.warmup)
+    queries = torch.randn((max(nq_total, args.recall_queries), dim), generator=gen, device=dev,
+                          dtype=torch.float32)
+
+    # ---------------- index build ----------------
+    build_vps = None
+    build_kind = args.setup_build
+    ix_full = None
+    tids_all = pack_tids(torch.arange(n, device=dev))
+    t_build = None
+    if build_kind == "hip":
+        import ctypes as C
+        ix_full = IvfIndex(dim, nlists, device=local_rank)
+        iters = C.c_int(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = lib().ndbhip_ivf_build_device(ix_full._h, base.data_ptr(), tids_all.data_ptr(), n, 50, C.byref(iters))
+        if rc == 0:
+            check(lib().ndbhip_synchronize())
+            t_build = time.perf_counter() - t0
+            build_vps = n / t_build
+        else:
+            if rank == 0:
+                print(f"[bench] ndbhip_ivf_build_device unavailable ({_lib.last_error()}); torch setup build",
+                      file=sys.stderr)
+            build_kind = "torch"
+            ix_full.close()
+            ix_full = None
+    if build_kind == "torch":
+        cent, asg = torch_setup_build(base, nlists)
+        order = torch.argsort(asg, stable=True)
+        list_len = torch.bincount(asg, minlength=nlists).cpu().numpy().astype(np.int64)
+        rows_sorted = base[order].contiguous()
+        tids_sorted = tids_all[order].contiguous()
+        del base
+        cent_h = cent.cpu().numpy()
+    else:
+        raise SystemExit("hip build path: export not wired yet")  # replaced once the build kernels land
+
+    # ---------------- shard lists over ranks ----------------
+    owner = lpt_partition(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
+    owned = (owner == rank).astype(np.uint8)
+    off = np.zeros(nlists + 1, dtype=np.int64)
+    off[1:] = np.cumsum(list_len)
+    if world > 1:
+        keep = torch.cat([torch.arange(off[l], off[l + 1], device=dev) for l in range(nlists) if owned[l]])
+        my_rows = rows_sorted[keep].contiguous()
+        my_tids = tids_sorted[keep].contiguous()
+    else:
+        my_rows, my_tids = rows_sorted, tids_sorted
+    ix = IvfIndex(dim, nlists, device=local_rank)
+    ix.set_centroids(cent_h)
+    ix.load_device(list_len, my_rows, my_tids, owned=owned)
+
+    # ---------------- one step ----------------
+    cap = 3 * k
+    out_t = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    out_d = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    out_c = torch.zeros(nq, dtype=torch.int32, device=dev)
+    if world > 1:
+        cand = torch.zeros((nq, cap, 2), dtype=torch.int64, device=dev)
+        ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+        total = torch.zeros(nq, dtype=torch.int64, device=dev)
+        cand_all = torch.zeros((world, nq, cap, 2), dtype=torch.int64, device=dev)
+        ncand_all = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+
+    def step(qs):
+        if world == 1:
+            ix.search_device(qs, out_t, out_d, out_c, 1, nprobe, k, 0)
+        else:
+            ix.search_partial_device(qs, cand, ncand, total, 1, nprobe, k, 0)
+            dist.all_gather_into_tensor(cand_all, cand)
+            dist.all_gather_into_tensor(ncand_all, ncand)
+            check(lib().ndbhip_merge_topk_device(cand_all.data_ptr(), ncand_all.data_ptr(), total.data_ptr(),
+                                                 world, nq, k, cap, out_t.data_ptr(), out_d.data_ptr(),
+                                                 out_c.data_ptr()))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(queries[w * nq:(w + 1) * nq])
+    barrier()
+    check(lib().ndbhip_stats_reset())
+    check(lib().ndbhip_profile(1))
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        i = args.warmup + s
+        step(queries[i * nq:(i + 1) * nq])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    check(lib().ndbhip_profile(0))
+    st = _lib.stats()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    qps = nq * args.steps / elapsed
+
+    # ---------------- roofline of the dominant kernel (k_ivf_scan) ----------------
+    launches = max(1, st["scan_launches"])
+    bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B
+    ms_per_launch = st["scan_kernel_ms"] / launches
+    achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_ivf_scan<R_IVF_L2>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None, "bytes_per_launch": int(bytes_per_launch),
+                "avg_launch_ms": round(ms_per_launch, 4), "launches": int(launches)}
+
+    # ---------------- recall@10 vs exact float64 brute force ----------------
+    recall = None
+    cpu_baseline = None
+    if rank == 0 and world == 1:
+        rq = min(args.recall_queries, nq)
+        qs = queries[args.warmup * nq: args.warmup * nq + nq]
+        step(qs)
+        torch.cuda.synchronize()
+        got = unpack_tids(out_t[:rq]).cpu().numpy()
+        gt = []
+        q64 = qs[:rq].double()
+        best_d = torch.full((rq, k), float("inf"), dtype=torch.float64, device=dev)
+        best_i = torch.zeros((rq, k), dtype=torch.int64, device=dev)
+        orig_rows = unpack_tids(tids_sorted)
+        for s in range(0, n, 65536):
+            x = rows_sorted[s:s + 65536].double()
+            d2 = (q64 * q64).sum(1)[:, None] + (x * x).sum(1)[None, :] - 2.0 * (q64 @ x.T)
+            dd = torch.cat([best_d, d2], 1)
+            ii = torch.cat([best_i, orig_rows[s:s + 65536][None, :].expand(rq, -1)], 1)
+            sel = torch.topk(dd, k, dim=1, largest=False)
+            best_d, best_i = sel.values, torch.gather(ii, 1, sel.indices)
+        gt = best_i.cpu().numpy()
+        recall = float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(rq)]))
+
+        # ---------------- CPU baseline: the oracle on the host cores (bounded sample) ----------------
+        if args.cpu_seconds > 0:
+            cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_sorted, tids_sorted, qs, out_t, out_d, out_c)
+
+    if rank == 0:
+        line = {
+            "metric": "kNN queries/sec @ recall@10, 1M x 768 fp32 (IVFFlat lists=1024 probes=32 k=10 L2)",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic N(0,1) (torch.randn, seeds 0x5EED0001/0x5EED0002)",
+            "config": {"workload": f"IVFFlat {n}x{dim} fp32 lists={nlists} probes={nprobe} k={k} L2, "
+                                   f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
+                       "sharding": "none" if world == 1 else f"lists over {world} ranks (LPT), RCCL all-gather + merge",
+                       "index_build": build_kind},
+            "recall_at_10": None if recall is None else round(recall, 4),
+            "build_vectors_per_s": None if build_vps is None else round(build_vps, 1),
+            "bytes_per_query": int(st["bytes_scored"] / max(1, nq * args.steps)) + nlists * dim * 4,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, cent_h, list_len, rows_sorted, tids_sorted, qs, out_t, out_d, out_c):
+    """Times the CPU oracle (oracle/, kind 'port') on the host cores for a bounded sample of the
+    same workload, and checks the GPU results of those queries against it (ids + distances)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import ndbo
+    cores = os.cpu_count() or 1
+    rows_h = rows_sorted.cpu().numpy()
+    t = tids_sorted.cpu().numpy().astype(np.uint64)
+    tid_h = np.zeros(len(t), dtype=ndbo.TID_DTYPE)
+    tid_h["bi_hi"], tid_h["bi_lo"], tid_h["posid"] = t & 0xFFFF, (t >> 16) & 0xFFFF, (t >> 32) & 0xFFFF
+    off = np.zeros(len(list_len) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(list_len)
+    img = ndbo.IvfImage(cent_h, off, rows_h, tid_h)
+    q_h = qs.cpu().numpy()
+    ndbo.lib()                                    # build/load outside the timed region
+    t0 = time.perf_counter()
+    img.search(q_h[0], 1, args.probes, args.k, 0)
+    one = time.perf_counter() - t0
+    nsample = int(max(cores, min(len(q_h), args.cpu_seconds * cores / max(one, 1e-4))))
+    nsample = min(nsample, len(q_h))
+
+    def work(i):
+        return img.search(q_h[i], 1, args.probes, args.k, 0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:      # ctypes calls release the GIL
+        res = list(ex.map(work, range(nsample)))
+    wall = time.perf_counter() - t0
+    # parity of the GPU results on the sample
+    gt = ndbo.tids_from_device_u64(out_t[:nsample].cpu().numpy())
+    gd = out_d[:nsample].cpu().numpy()
+    gc = out_c[:nsample].cpu().numpy()
+    bad = 0
+    for i, (et, ed, _) in enumerate(res):
+        ok = gc[i] == len(et) and np.array_equal(gt[i, :len(et)], ndbo.tids_to_u64(et)) and \
+            np.array_equal(gd[i, :len(et)].view(np.uint32), ed.view(np.uint32))
+        bad += (not ok)
+    return {"value": round(nsample / wall, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{nsample} queries of the same workload, oracle/ndb_oracle.c (gcc -O2, -ffp-contract=off), "
+                      f"one thread per core; single-thread latency {one * 1e3:.1f} ms/query",
+            "gpu_parity_on_sample": {"queries": nsample, "mismatches": int(bad)}}
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,12 @@ def lib():
         raise NdbHipError(ERR_NODEVICE,
                           f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; load it first so that this library binds to the SAME
+    # HIP runtime (one runtime per process: streams and events can then be shared with torch).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB)
     vp, i, i64, f = C.c_void_p, C.c_int, C.c_int64, C.c_float
     sig = {

@@ -175,6 +175,14 @@ def tids_to_u64(t):
            (t["bi_lo"].astype(np.uint64) << np.uint64(16)) | t["posid"].astype(np.uint64)
 
 
+def tids_from_device_u64(x):
+    """Device TID format (uint64 = little-endian ItemPointerData image) -> comparable uint64."""
+    x = np.ascontiguousarray(x).astype(np.uint64)
+    b = x.view(np.uint8).reshape(x.shape + (8,))[..., :6]
+    t = np.ascontiguousarray(b).view(TID_DTYPE).reshape(x.shape)
+    return tids_to_u64(t)
+
+
 def kmeans(data, k, max_iter=50, threshold=0.001, native=False):
     data = _f32(data)
     n, dim = data.shape

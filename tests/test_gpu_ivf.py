@@ -209,7 +209,8 @@ def test_sharded_partial_plus_merge_equals_single_device():
     _lib.check(_lib.lib().ndbhip_synchronize())
     et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
     assert np.array_equal(oc.cpu().numpy(), ec)
-    assert np.array_equal(ot.cpu().numpy().astype(np.uint64), et)
+    from oracle import ndbo
+    assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
     assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
     # the host merge agrees too
     hc, hn, ht = cand.cpu().numpy(), ncand.cpu().numpy(), total[0].cpu().numpy()
@@ -218,4 +219,4 @@ def test_sharded_partial_plus_merge_equals_single_device():
     oc2 = np.zeros(len(q), np.int32)
     _lib.check(_lib.lib().ndbhip_merge_topk_host(hc.ctypes.data, hn.ctypes.data, ht.ctypes.data, world, len(q),
                                                  k, cap, ot2.ctypes.data, od2.ctypes.data, oc2.ctypes.data))
-    assert np.array_equal(ot2, et) and np.array_equal(oc2, ec)
+    assert np.array_equal(ndbo.tids_from_device_u64(ot2), et) and np.array_equal(oc2, ec)
