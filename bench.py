@@ -43,8 +43,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=200)
-    ap.add_argument("--setup-build", choices=["hip", "torch"], default="hip",
-                    help="hip: ndbhip_ivf_build_device (reference k-means rule); torch: approximate setup")
+    ap.add_argument("--data", choices=["clustered", "gauss"], default="clustered",
+                    help="clustered: mixture of --components Gaussians (sigma --sigma); gauss: i.i.d. N(0,1)")
+    ap.add_argument("--components", type=int, default=1024)
+    ap.add_argument("--sigma", type=float, default=0.1)
     return ap.parse_args()
 
 
@@ -64,23 +66,22 @@ def unpack_tids(t: torch.Tensor) -> torch.Tensor:
     return ((bi_hi << 16) | bi_lo) * 64 + pos - 1
 
 
-def torch_setup_build(base, nlists, iters=8):
-    """Approximate IVF build with torch ops — SETUP ONLY (not timed, not the product's build path)."""
-    n, dim = base.shape
-    ns = min(10000, nlists * 100, n)
-    smp = base[:ns]
-    cent = smp[:nlists].clone()
-    for _ in range(iters):
-        a = torch.cdist(smp, cent).argmin(1)
-        for_sum = torch.zeros_like(cent).index_add_(0, a, smp)
-        cnt = torch.bincount(a, minlength=nlists).clamp(min=1).unsqueeze(1)
-        cent = for_sum / cnt
-    asg = torch.empty(n, dtype=torch.int64, device=base.device)
-    cc = (cent * cent).sum(1)
-    for s in range(0, n, 131072):
-        x = base[s:s + 131072]
-        asg[s:s + 131072] = (cc[None, :] - 2.0 * (x @ cent.T)).argmin(1)
-    return cent, asg
+def make_data(n, dim, kind, components, sigma, seed, center_seed, dev):
+    """Synthetic vectors, identical on every rank.  clustered: x = center[c] + sigma * N(0,1) with
+    centers ~ N(0,1) shared by base and queries (SURVEY 8d 'clustered variant'); gauss: i.i.d. N(0,1)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    if kind == "gauss":
+        return torch.randn((n, dim), generator=gen, device=dev, dtype=torch.float32)
+    cg = torch.Generator(device=dev)
+    cg.manual_seed(center_seed)
+    centers = torch.randn((components, dim), generator=cg, device=dev, dtype=torch.float32)
+    comp = torch.randint(0, components, (n,), generator=gen, device=dev)
+    x = torch.randn((n, dim), generator=gen, device=dev, dtype=torch.float32)
+    x.mul_(sigma)
+    for s in range(0, n, 1 << 18):
+        x[s:s + (1 << 18)] += centers[comp[s:s + (1 << 18)]]
+    return x
 
 
 def lpt_partition(list_len, world):
@@ -117,63 +118,34 @@ def main():
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
 
     # ---------------- synthetic data (identical on every rank) ----------------
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0001)
-    base = torch.randn((n, dim), generator=gen, device=dev, dtype=torch.float32)
-    gen.manual_seed(0x5EED0002)
+    base = make_data(n, dim, args.data, args.components, args.sigma, 0x5EED0001, 0x5EEDC0DE, dev)
     nq_total = nq * (args.steps + args.warmup)
-    queries = torch.randn((max(nq_total, args.recall_queries), dim), generator=gen, device=dev,
-                          dtype=torch.float32)
+    queries = make_data(max(nq_total, args.recall_queries), dim, args.data, args.components, args.sigma,
+                        0x5EED0002, 0x5EEDC0DE, dev)
 
-    # ---------------- index build ----------------
-    build_vps = None
-    build_kind = args.setup_build
-    ix_full = None
+    # ---------------- index build: the product's build path, timed ----------------
+    # sample first min(10000, 100*lists) rows + k-means (reference rule) + assign all rows + pack lists
     tids_all = pack_tids(torch.arange(n, device=dev))
-    t_build = None
-    if build_kind == "hip":
-        import ctypes as C
-        ix_full = IvfIndex(dim, nlists, device=local_rank)
-        iters = C.c_int(0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rc = lib().ndbhip_ivf_build_device(ix_full._h, base.data_ptr(), tids_all.data_ptr(), n, 50, C.byref(iters))
-        if rc == 0:
-            check(lib().ndbhip_synchronize())
-            t_build = time.perf_counter() - t0
-            build_vps = n / t_build
-        else:
-            if rank == 0:
-                print(f"[bench] ndbhip_ivf_build_device unavailable ({_lib.last_error()}); torch setup build",
-                      file=sys.stderr)
-            build_kind = "torch"
-            ix_full.close()
-            ix_full = None
-    if build_kind == "torch":
-        cent, asg = torch_setup_build(base, nlists)
-        order = torch.argsort(asg, stable=True)
-        list_len = torch.bincount(asg, minlength=nlists).cpu().numpy().astype(np.int64)
-        rows_sorted = base[order].contiguous()
-        tids_sorted = tids_all[order].contiguous()
-        del base
-        cent_h = cent.cpu().numpy()
-    else:
-        raise SystemExit("hip build path: export not wired yet")  # replaced once the build kernels land
+    ix_full = IvfIndex(dim, nlists, device=local_rank)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kmeans_iters = ix_full.build_device(base, tids_all, 50)
+    check(lib().ndbhip_synchronize())
+    t_build = time.perf_counter() - t0
+    build_vps = n / t_build
+    cent_h, list_len, _, _ = ix_full.export(rows=False)
+    del base
 
     # ---------------- shard lists over ranks ----------------
     owner = lpt_partition(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
     owned = (owner == rank).astype(np.uint8)
-    off = np.zeros(nlists + 1, dtype=np.int64)
-    off[1:] = np.cumsum(list_len)
     if world > 1:
-        keep = torch.cat([torch.arange(off[l], off[l + 1], device=dev) for l in range(nlists) if owned[l]])
-        my_rows = rows_sorted[keep].contiguous()
-        my_tids = tids_sorted[keep].contiguous()
+        ix = ix_full.shard(owned)
+        ix_full.close()
+        ix_full = None
+        torch.cuda.empty_cache()
     else:
-        my_rows, my_tids = rows_sorted, tids_sorted
-    ix = IvfIndex(dim, nlists, device=local_rank)
-    ix.set_centroids(cent_h)
-    ix.load_device(list_len, my_rows, my_tids, owned=owned)
+        ix = ix_full
 
     # ---------------- one step ----------------
     cap = 3 * k
@@ -241,13 +213,14 @@ def main():
         step(qs)
         torch.cuda.synchronize()
         got = unpack_tids(out_t[:rq]).cpu().numpy()
-        gt = []
+        _, _, rows_h, tids_h = ix.export(rows=True)          # index image, list-major (host)
+        orig_rows_h = (((tids_h["bi_hi"].astype(np.int64) << 16) | tids_h["bi_lo"]) * 64 + tids_h["posid"] - 1)
+        orig_rows = torch.from_numpy(orig_rows_h).to(dev)
         q64 = qs[:rq].double()
         best_d = torch.full((rq, k), float("inf"), dtype=torch.float64, device=dev)
         best_i = torch.zeros((rq, k), dtype=torch.int64, device=dev)
-        orig_rows = unpack_tids(tids_sorted)
         for s in range(0, n, 65536):
-            x = rows_sorted[s:s + 65536].double()
+            x = torch.from_numpy(rows_h[s:s + 65536]).to(dev).double()
             d2 = (q64 * q64).sum(1)[:, None] + (x * x).sum(1)[None, :] - 2.0 * (q64 @ x.T)
             dd = torch.cat([best_d, d2], 1)
             ii = torch.cat([best_i, orig_rows[s:s + 65536][None, :].expand(rq, -1)], 1)
@@ -258,7 +231,7 @@ def main():
 
         # ---------------- CPU baseline: the oracle on the host cores (bounded sample) ----------------
         if args.cpu_seconds > 0:
-            cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_sorted, tids_sorted, qs, out_t, out_d, out_c)
+            cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_h, tids_h, qs, out_t, out_d, out_c)
 
     if rank == 0:
         line = {
@@ -266,11 +239,15 @@ def main():
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic N(0,1) (torch.randn, seeds 0x5EED0001/0x5EED0002)",
+            "data": "synthetic (torch generator, seeds 0x5EED0001 base / 0x5EED0002 queries)",
             "config": {"workload": f"IVFFlat {n}x{dim} fp32 lists={nlists} probes={nprobe} k={k} L2, "
                                    f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
                        "sharding": "none" if world == 1 else f"lists over {world} ranks (LPT), RCCL all-gather + merge",
-                       "index_build": build_kind},
+                       "data": (f"mixture of {args.components} Gaussians, sigma={args.sigma}" if args.data == "clustered"
+                                else "i.i.d. N(0,1)"),
+                       "index_build": f"ndbhip_ivf_build_device: first-10000-row sample, {kmeans_iters} Lloyd iterations "
+                                      f"(reference k-means rule), all rows assigned, {t_build:.3f} s",
+                       "list_len_min_mean_max": [int(list_len.min()), float(list_len.mean()), int(list_len.max())]},
             "recall_at_10": None if recall is None else round(recall, 4),
             "build_vectors_per_s": None if build_vps is None else round(build_vps, 1),
             "bytes_per_query": int(st["bytes_scored"] / max(1, nq * args.steps)) + nlists * dim * 4,
@@ -282,16 +259,13 @@ def main():
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(args, cent_h, list_len, rows_sorted, tids_sorted, qs, out_t, out_d, out_c):
+def run_cpu_baseline(args, cent_h, list_len, rows_h, tid_h, qs, out_t, out_d, out_c):
     """Times the CPU oracle (oracle/, kind 'port') on the host cores for a bounded sample of the
     same workload, and checks the GPU results of those queries against it (ids + distances)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ndbo
     cores = os.cpu_count() or 1
-    rows_h = rows_sorted.cpu().numpy()
-    t = tids_sorted.cpu().numpy().astype(np.uint64)
-    tid_h = np.zeros(len(t), dtype=ndbo.TID_DTYPE)
-    tid_h["bi_hi"], tid_h["bi_lo"], tid_h["posid"] = t & 0xFFFF, (t >> 16) & 0xFFFF, (t >> 32) & 0xFFFF
+    tid_h = np.ascontiguousarray(tid_h).view(ndbo.TID_DTYPE).reshape(-1)
     off = np.zeros(len(list_len) + 1, dtype=np.int64)
     off[1:] = np.cumsum(list_len)
     img = ndbo.IvfImage(cent_h, off, rows_h, tid_h)

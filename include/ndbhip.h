@@ -121,6 +121,16 @@ int			ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint
  * (src/index/ivf_am.c:954-1157) — see ndbhip_ivf_assign for the list choice. */
 int			ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6);
 
+/* Read the mirror back to the host (any pointer may be NULL): centroids
+ * [ncentroids*dim], list_len [ncentroids] (owned lists only), rows/tids6 of
+ * the resident rows.  Used by the page writer of ambuild and by tests. */
+int			ndbhip_ivf_export(const ndbhip_ivf *ix, float *centroids, int64_t *list_len, float *rows,
+							  uint8_t *tids6);
+int			ndbhip_ivf_ncentroids(const ndbhip_ivf *ix);
+/* Multi-GPU: a new mirror holding only the lists with owned[L] != 0 (one process
+ * per GPU keeps its share); list lengths stay global, so candidate positions —
+ * and therefore the merged result — are identical to the unsharded index. */
+int			ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out);
 int64_t		ndbhip_ivf_nrows(const ndbhip_ivf *ix);			/* rows resident on this device */
 int64_t		ndbhip_ivf_max_candidates(const ndbhip_ivf *ix, int nprobe);	/* sum of the nprobe longest lists */
 

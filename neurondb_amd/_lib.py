@@ -79,6 +79,9 @@ def lib():
         "ndbhip_ivf_load": (i, [vp, vp, vp, vp, vp, i64]),
         "ndbhip_ivf_load_device": (i, [vp, vp, vp, vp, vp, i64]),
         "ndbhip_ivf_append": (i, [vp, i, vp, vp]),
+        "ndbhip_ivf_export": (i, [vp, vp, vp, vp, vp]),
+        "ndbhip_ivf_ncentroids": (i, [vp]),
+        "ndbhip_ivf_shard": (i, [vp, vp, C.POINTER(vp)]),
         "ndbhip_ivf_nrows": (i64, [vp]),
         "ndbhip_ivf_max_candidates": (i64, [vp, i]),
         "ndbhip_ivf_search": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),

@@ -1634,29 +1634,614 @@ ndbhip_batch_distance(const float *queries, const float *vectors, float *results
 	return NDBHIP_OK;
 }
 
+
+/* ================================================================== */
+/* IVF build: k-means (ivf_am.c:2070-2294), insert-time assignment     */
+/* (:905-935), list packing                                            */
+/* ================================================================== */
+#define NDB_HAVE_BUILD 1
+#define NDB_CGROUP 64			/* centroids handled by one wave */
+
+/*
+ * Nearest-centroid search for 64 rows x one group of NDB_CGROUP centroids.
+ * The row tile is staged ONCE per 64-float chunk and every centroid of the
+ * group is accumulated against it: acc[c] lives in LDS ([c][lane], conflict
+ * free), the centroid chunk arrives through the scalar cache.  Each
+ * (row, centroid) sum is still the reference's sequential fp32 chain
+ * (vector_distance_l2 / the accum loop of ivfinsert).
+ * SQRT = false: compare squared sums (find_nearest_centroid, :2274-2294)
+ * SQRT = true : compare sqrtf(sum)     (ivfinsert, :915-934)
+ * grid = (ceil(nrows/64), ngroups), block = 64.
+ */
+template <bool SQRT>
+__global__ __launch_bounds__(64) void
+k_assign_partial(const float *__restrict__ rows, uint32_t nrows, int dim,
+				 const float *__restrict__ cents, int ncent,
+				 float *__restrict__ part_dist, int *__restrict__ part_idx)
+{
+	__shared__ __attribute__((aligned(16))) float tile[NDB_TILE_FLOATS];
+	__shared__ float accs[NDB_CGROUP * 64];
+	const int	lane = threadIdx.x;
+	const int	grp = lane >> 4;
+	const int	slot = lane & 15;
+	const uint32_t r = blockIdx.x * 64 + lane;
+	const uint32_t row = (r < nrows) ? r : (nrows - 1);
+	const int	c0 = blockIdx.y * NDB_CGROUP;
+	const int	gc = (ncent - c0 < NDB_CGROUP) ? (ncent - c0) : NDB_CGROUP;
+	uint32_t	rows16[16];
+
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		rows16[i] = __shfl(row, 4 * i + grp, 64);
+	for (int cl = 0; cl < gc; cl++)
+		accs[cl * 64 + lane] = 0.0f;
+
+	for (int c = 0; c < dim; c += NDB_CHUNK)
+	{
+		const bool	full = (dim - c) >= NDB_CHUNK;
+		const int	npieces = full ? 16 : ((dim - c) >> 2);
+		float4		x[16];
+
+		if (full)
+			stage_chunk<true>(x, rows, rows16, dim, c, tile, lane, grp, slot);
+		else
+			stage_chunk<false>(x, rows, rows16, dim, c, tile, lane, grp, slot);
+
+		for (int cl = 0; cl < gc; cl++)
+		{
+			const float *__restrict__ q = cents + (size_t) (c0 + cl) * (size_t) dim + c;
+			float		a = accs[cl * 64 + lane];
+
+			if (full)
+			{
+#pragma unroll
+				for (int p = 0; p < 16; p++)
+				{
+					const float4 qq = *reinterpret_cast<const float4 *>(q + p * 4);
+					float		d;
+
+					d = x[p].x - qq.x; a = a + d * d;
+					d = x[p].y - qq.y; a = a + d * d;
+					d = x[p].z - qq.z; a = a + d * d;
+					d = x[p].w - qq.w; a = a + d * d;
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int p = 0; p < 16; p++)
+					if (p < npieces)
+					{
+						const float4 qq = *reinterpret_cast<const float4 *>(q + p * 4);
+						float		d;
+
+						d = x[p].x - qq.x; a = a + d * d;
+						d = x[p].y - qq.y; a = a + d * d;
+						d = x[p].z - qq.z; a = a + d * d;
+						d = x[p].w - qq.w; a = a + d * d;
+					}
+			}
+			accs[cl * 64 + lane] = a;
+		}
+	}
+	float		best = FLT_MAX;
+	int			bidx = -1;
+
+	for (int cl = 0; cl < gc; cl++)
+	{
+		float		d = accs[cl * 64 + lane];
+
+		if (SQRT)
+			d = __builtin_sqrtf(d);
+		if (d < best)
+		{
+			best = d;
+			bidx = c0 + cl;
+		}
+	}
+	if (r < nrows)
+	{
+		part_dist[(size_t) blockIdx.y * nrows + r] = best;
+		part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
+	}
+}
+
+/* dim % 4 != 0: one lane walks its row against every centroid of the group directly */
+template <bool SQRT>
+__global__ __launch_bounds__(64) void
+k_assign_partial_direct(const float *__restrict__ rows, uint32_t nrows, int dim,
+						const float *__restrict__ cents, int ncent,
+						float *__restrict__ part_dist, int *__restrict__ part_idx)
+{
+	const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+	const int	c0 = blockIdx.y * NDB_CGROUP;
+	const int	gc = (ncent - c0 < NDB_CGROUP) ? (ncent - c0) : NDB_CGROUP;
+
+	if (r >= nrows)
+		return;
+	float		best = FLT_MAX;
+	int			bidx = -1;
+
+	for (int cl = 0; cl < gc; cl++)
+	{
+		const float *q = cents + (size_t) (c0 + cl) * dim;
+		const float *x = rows + (size_t) r * dim;
+		float		a = 0.0f;
+
+		for (int i = 0; i < dim; i++)
+		{
+			const float d = x[i] - q[i];
+
+			a = a + d * d;
+		}
+		if (SQRT)
+			a = __builtin_sqrtf(a);
+		if (a < best)
+		{
+			best = a;
+			bidx = c0 + cl;
+		}
+	}
+	part_dist[(size_t) blockIdx.y * nrows + r] = best;
+	part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
+}
+
+/* first strict minimum over the groups, in centroid order; none below FLT_MAX -> 0
+ * (best = 0 / min_idx = 0 initialisers: ivf_am.c:2277, 812) */
+__global__ void
+k_assign_combine(const float *__restrict__ part_dist, const int *__restrict__ part_idx, int ngroups,
+				 uint32_t nrows, int *__restrict__ out_list, int *__restrict__ counts)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (r >= nrows)
+		return;
+	float		best = FLT_MAX;
+	int			bidx = 0;
+
+	for (int g2 = 0; g2 < ngroups; g2++)
+	{
+		const float d = part_dist[(size_t) g2 * nrows + r];
+		const int	i = part_idx[(size_t) g2 * nrows + r];
+
+		if (i >= 0 && d < best)
+		{
+			best = d;
+			bidx = i;
+		}
+	}
+	out_list[r] = bidx;
+	if (counts)
+		atomicAdd(&counts[bidx], 1);
+}
+
+/* kmeans_update_centroids (:2182-2213): block = centroid, thread = coordinate;
+ * members are summed in sample order, then divided by (float) count. */
+__global__ void
+k_kmeans_update(const float *__restrict__ data, int n, int dim, const int *__restrict__ assign,
+				const int *__restrict__ counts, float *__restrict__ cents)
+{
+	const int	c = blockIdx.x;
+
+	for (int j = threadIdx.x; j < dim; j += blockDim.x)
+	{
+		float		s = 0.0f;
+
+		for (int i = 0; i < n; i++)
+			if (assign[i] == c)
+				s = s + data[(size_t) i * dim + j];
+		if (counts[c] > 0)
+			s = s / (float) counts[c];
+		cents[(size_t) c * dim + j] = s;
+	}
+}
+
+/* per-sample squared distance to its own centroid (:2225-2230) */
+__global__ void
+k_kmeans_point_cost(const float *__restrict__ data, int n, int dim, const int *__restrict__ assign,
+					const float *__restrict__ cents, float *__restrict__ pc)
+{
+	const int	i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= n)
+		return;
+	const float *x = data + (size_t) i * dim;
+	const float *q = cents + (size_t) assign[i] * dim;
+	float		s = 0.0f;
+
+	for (int j = 0; j < dim; j++)
+	{
+		const float d = x[j] - q[j];
+
+		s = s + d * d;
+	}
+	pc[i] = s;
+}
+
+/* cost += d_i strictly in sample order, in fp32 (:2221-2232) */
+__global__ void
+k_seq_sum(const float *__restrict__ pc, int n, float *__restrict__ out)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+	{
+		float		s = 0.0f;
+
+		for (int i = 0; i < n; i++)
+			s = s + pc[i];
+		*out = s;
+	}
+}
+
+/* kmeans_init (:2092-2104): first k samples, zeros beyond n */
+__global__ void
+k_kmeans_init(const float *__restrict__ data, int n, int dim, int k, float *__restrict__ cents)
+{
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= (size_t) k * dim)
+		return;
+	const int	c = (int) (i / dim);
+
+	cents[i] = (c < n) ? data[i] : 0.0f;
+}
+
+static int
+assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int ncent, bool use_sqrt,
+			int *d_out_list, int *d_counts)
+{
+	const int	ngroups = (ncent + NDB_CGROUP - 1) / NDB_CGROUP;
+	const int64_t chunk = 1 << 18;
+	float	   *pd = nullptr;
+	int		   *pi = nullptr;
+	const int64_t cmax = std::min<int64_t>(chunk, nrows);
+
+	if (nrows <= 0)
+		return 0;
+	HIP_TRY(hipMalloc((void **) &pd, (size_t) ngroups * cmax * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &pi, (size_t) ngroups * cmax * sizeof(int)));
+	for (int64_t r0 = 0; r0 < nrows; r0 += chunk)
+	{
+		const uint32_t n = (uint32_t) std::min<int64_t>(chunk, nrows - r0);
+		dim3		grid((n + 63) / 64, ngroups);
+		const float *rows = d_rows + (size_t) r0 * dim;
+
+		if ((dim & 3) == 0)
+		{
+			if (use_sqrt)
+				hipLaunchKernelGGL(k_assign_partial<true>, grid, dim3(64), 0, g.stream, rows, n, dim, d_cents,
+								   ncent, pd, pi);
+			else
+				hipLaunchKernelGGL(k_assign_partial<false>, grid, dim3(64), 0, g.stream, rows, n, dim, d_cents,
+								   ncent, pd, pi);
+		}
+		else
+		{
+			if (use_sqrt)
+				hipLaunchKernelGGL(k_assign_partial_direct<true>, grid, dim3(64), 0, g.stream, rows, n, dim,
+								   d_cents, ncent, pd, pi);
+			else
+				hipLaunchKernelGGL(k_assign_partial_direct<false>, grid, dim3(64), 0, g.stream, rows, n, dim,
+								   d_cents, ncent, pd, pi);
+		}
+		hipLaunchKernelGGL(k_assign_combine, dim3((n + 255) / 256), dim3(256), 0, g.stream, (const float *) pd,
+						   (const int *) pi, ngroups, n, d_out_list + r0, d_counts);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(pd));
+	HIP_TRY(hipFree(pi));
+	return 0;
+}
+
+extern "C" int
+ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, const float *d_rows,
+						 int64_t nrows, int *d_out_list)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!d_centroids || ncentroids < 1 || dim < 1 || nrows < 0 || (nrows > 0 && (!d_rows || !d_out_list)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nrows > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "too many rows");
+	return assign_rows(d_rows, nrows, dim, d_centroids, ncentroids, true, d_out_list, nullptr);
+}
+
+extern "C" int
+ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter, float threshold,
+					 float *d_centroids, int *d_assign, int *d_counts, int *out_iters, float *out_cost)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!d_samples || !d_centroids || !d_assign || !d_counts || n < 1 || dim < 1 || k < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_pc = nullptr, *d_cost = nullptr;
+	float		prevCost = FLT_MAX, cost = 0.0f;
+	int			iters = 0;
+
+	HIP_TRY(hipMalloc((void **) &d_pc, (size_t) n * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_cost, sizeof(float)));
+	hipLaunchKernelGGL(k_kmeans_init, dim3((unsigned) (((size_t) k * dim + 255) / 256)), dim3(256), 0, g.stream,
+					   d_samples, n, dim, k, d_centroids);
+	for (int iter = 0; iter < max_iter; iter++)
+	{
+		int			rc;
+
+		HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t) k * sizeof(int), g.stream));
+		rc = assign_rows(d_samples, n, dim, d_centroids, k, false, d_assign, d_counts);
+		if (rc)
+			return rc;
+		hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), 0, g.stream, d_samples, n, dim,
+						   (const int *) d_assign, (const int *) d_counts, d_centroids);
+		hipLaunchKernelGGL(k_kmeans_point_cost, dim3((n + 255) / 256), dim3(256), 0, g.stream, d_samples, n, dim,
+						   (const int *) d_assign, (const float *) d_centroids, d_pc);
+		hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(64), 0, g.stream, (const float *) d_pc, n, d_cost);
+		HIP_TRY(hipMemcpyAsync(&cost, d_cost, sizeof(float), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		iters = iter + 1;
+		/* fabs(prevCost - cost) < threshold, float difference widened (ivf_am.c:2141) */
+		if (fabs((double) (float) (prevCost - cost)) < (double) threshold)
+			break;
+		prevCost = cost;
+	}
+	HIP_TRY(hipFree(d_pc));
+	HIP_TRY(hipFree(d_cost));
+	if (out_iters)
+		*out_iters = iters;
+	if (out_cost)
+		*out_cost = cost;
+	return NDBHIP_OK;
+}
+
+/* ---- list packing: stable counting sort of rows by list id (heap order kept inside a list) ---- */
+
+#define NDB_PACK_BLOCK 256
+
+/* per-block histogram: hist[list * nblocks + block] */
+__global__ __launch_bounds__(NDB_PACK_BLOCK) void
+k_pack_hist(const int *__restrict__ lists, int64_t nrows, int nlists, uint32_t nblocks,
+			uint32_t *__restrict__ hist)
+{
+	const int64_t r = (int64_t) blockIdx.x * NDB_PACK_BLOCK + threadIdx.x;
+
+	if (r < nrows)
+		atomicAdd(&hist[(size_t) lists[r] * nblocks + blockIdx.x], 1u);
+}
+
+/* dest = scanned[list][block] + rank of the row among earlier same-list rows of its block; copies the row */
+__global__ __launch_bounds__(NDB_PACK_BLOCK) void
+k_pack_scatter(const int *__restrict__ lists, int64_t nrows, int dim, uint32_t nblocks,
+			   const int64_t *__restrict__ scanned, const float *__restrict__ rows,
+			   const uint64_t *__restrict__ tids, float *__restrict__ out_rows, uint64_t *__restrict__ out_tids)
+{
+	__shared__ int sl[NDB_PACK_BLOCK];
+	__shared__ int64_t sdest[NDB_PACK_BLOCK];
+	const int	t = threadIdx.x;
+	const int64_t r0 = (int64_t) blockIdx.x * NDB_PACK_BLOCK;
+	const int64_t r = r0 + t;
+	const int	L = (r < nrows) ? lists[r] : -1;
+
+	sl[t] = L;
+	__syncthreads();
+	if (r < nrows)
+	{
+		int			rank = 0;
+
+		for (int u = 0; u < t; u++)
+			rank += (sl[u] == L);
+		sdest[t] = scanned[(size_t) L * nblocks + blockIdx.x] + rank;
+		out_tids[sdest[t]] = tids[r];
+	}
+	__syncthreads();
+	const int	nb = (int) ((nrows - r0 < NDB_PACK_BLOCK) ? (nrows - r0) : NDB_PACK_BLOCK);
+
+	if ((dim & 3) == 0)
+	{
+		const int	d4 = dim >> 2;
+
+		for (int rr = 0; rr < nb; rr++)
+		{
+			const float4 *src = reinterpret_cast<const float4 *>(rows + (size_t) (r0 + rr) * dim);
+			float4	   *dst = reinterpret_cast<float4 *>(out_rows + (size_t) sdest[rr] * dim);
+
+			for (int j = t; j < d4; j += NDB_PACK_BLOCK)
+				dst[j] = src[j];
+		}
+	}
+	else
+	{
+		for (int rr = 0; rr < nb; rr++)
+			for (int j = t; j < dim; j += NDB_PACK_BLOCK)
+				out_rows[(size_t) sdest[rr] * dim + j] = rows[(size_t) (r0 + rr) * dim + j];
+	}
+}
+
+extern "C" int
+ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
+						int max_iter, int *out_iters)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !d_rows || !d_tids || nrows < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nrows > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "too many rows");
+	const int	dim = ix->dim;
+	const int	k = ix->nlists;
+	/* maxSamples = Min(10000, nlists * 100): the FIRST rows in heap order (ivf_am.c:580, 486-495) */
+	const int	ns = (int) std::min<int64_t>(std::min<int64_t>(10000, (int64_t) k * 100), nrows);
+
+	if (ns < k)					/* ivf_am.c:596-601 */
+		return fail(NDBHIP_ERR_INVALID, "ivf: not enough sample vectors (%d < %d)", ns, k);
+
+	float	   *d_cent = nullptr;
+	int		   *d_sasg = nullptr, *d_scnt = nullptr, *d_list = nullptr;
+	int			iters = 0, rc;
+
+	HIP_TRY(hipMalloc((void **) &d_cent, (size_t) k * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_sasg, (size_t) ns * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &d_scnt, (size_t) k * sizeof(int)));
+	rc = ndbhip_kmeans_device(d_rows, ns, dim, k, max_iter, 0.001f, d_cent, d_sasg, d_scnt, &iters, nullptr);
+	if (rc)
+		return rc;
+	HIP_TRY(hipFree(d_sasg));
+	HIP_TRY(hipFree(d_scnt));
+
+	/* every row goes to the list ivfinsert would choose (Q5: the reference leaves this to later INSERTs) */
+	HIP_TRY(hipMalloc((void **) &d_list, (size_t) nrows * sizeof(int)));
+	rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr);
+	if (rc)
+		return rc;
+
+	const uint32_t nblocks = (uint32_t) ((nrows + NDB_PACK_BLOCK - 1) / NDB_PACK_BLOCK);
+	const size_t nh = (size_t) k * nblocks;
+	uint32_t   *d_hist = nullptr;
+	int64_t    *d_scan = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_hist, nh * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &d_scan, nh * sizeof(int64_t)));
+	HIP_TRY(hipMemsetAsync(d_hist, 0, nh * sizeof(uint32_t), g.stream));
+	hipLaunchKernelGGL(k_pack_hist, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list, nrows,
+					   k, nblocks, d_hist);
+	std::vector<uint32_t> h(nh);
+	std::vector<int64_t> sc(nh);
+	std::vector<int64_t> list_len((size_t) k, 0);
+
+	HIP_TRY(hipMemcpyAsync(h.data(), d_hist, nh * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	{
+		int64_t		acc = 0;
+
+		for (size_t i = 0; i < nh; i++)
+		{
+			sc[i] = acc;
+			acc += h[i];
+			list_len[i / nblocks] += h[i];
+		}
+	}
+	HIP_TRY(hipMemcpyAsync(d_scan, sc.data(), nh * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+
+	float	   *d_prow = nullptr;
+	uint64_t   *d_ptid = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+	hipLaunchKernelGGL(k_pack_scatter, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list,
+					   nrows, dim, nblocks, (const int64_t *) d_scan, d_rows, d_tids, d_prow, d_ptid);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_hist));
+	HIP_TRY(hipFree(d_scan));
+	HIP_TRY(hipFree(d_list));
+
+	/* adopt: centroids + packed lists become the index */
+	if (ix->d_centroids)
+		HIP_TRY(hipFree(ix->d_centroids));
+	ix->d_centroids = d_cent;
+	ix->ncent = k;
+	rc = ivf_set_layout(ix, list_len.data(), nullptr, nrows);
+	if (rc)
+		return rc;
+	ivf_free_rows(ix);
+	ix->d_vecs = d_prow;
+	ix->d_tids = d_ptid;
+	ix->own_rows = true;
+	ix->nrows = nrows;
+	ix->cap_rows = nrows;
+	ix->loaded = true;
+	if (out_iters)
+		*out_iters = iters;
+	return NDBHIP_OK;
+}
+
+/* read the index image back (tests, bench cpu baseline, PostgreSQL page writer) */
+extern "C" int
+ndbhip_ivf_export(const ndbhip_ivf *ix, float *centroids, int64_t *list_len, float *rows, uint8_t *tids6)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !ix->loaded)
+		return fail(NDBHIP_ERR_STATE, "index not loaded");
+	if (centroids)
+		HIP_TRY(hipMemcpy(centroids, ix->d_centroids, (size_t) ix->ncent * ix->dim * 4, hipMemcpyDeviceToHost));
+	if (list_len)
+		for (int c = 0; c < ix->ncent; c++)
+			list_len[c] = ix->owned[c] ? ix->glob_len[c] : 0;
+	if (rows && ix->nrows > 0)
+		HIP_TRY(hipMemcpy(rows, ix->d_vecs, (size_t) ix->nrows * ix->dim * 4, hipMemcpyDeviceToHost));
+	if (tids6 && ix->nrows > 0)
+	{
+		std::vector<uint64_t> t((size_t) ix->nrows);
+
+		HIP_TRY(hipMemcpy(t.data(), ix->d_tids, t.size() * 8, hipMemcpyDeviceToHost));
+		for (int64_t r = 0; r < ix->nrows; r++)
+			ndb_tid_unpack(t[(size_t) r], tids6 + 6 * r);
+	}
+	return NDBHIP_OK;
+}
+
+/* New index holding only the lists with owned[L] != 0 (device-to-device copy);
+ * list lengths stay global so candidate positions are identical on every rank. */
+extern "C" int
+ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!src || !src->loaded || !owned || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	for (int c = 0; c < src->ncent; c++)
+		if (owned[c] && !src->owned[c])
+			return fail(NDBHIP_ERR_INVALID, "list %d is not resident in the source index", c);
+	ndbhip_ivf *ix = nullptr;
+	int			rc = ndbhip_ivf_create(src->dim, src->nlists, &ix);
+
+	if (rc)
+		return rc;
+	HIP_TRY(hipMalloc((void **) &ix->d_centroids, (size_t) src->ncent * src->dim * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(ix->d_centroids, src->d_centroids, (size_t) src->ncent * src->dim * sizeof(float),
+						   hipMemcpyDeviceToDevice, g.stream));
+	ix->ncent = src->ncent;
+	int64_t		nrows = 0;
+
+	for (int c = 0; c < src->ncent; c++)
+		if (owned[c])
+			nrows += src->glob_len[c];
+	rc = ivf_set_layout(ix, src->glob_len.data(), owned, nrows);
+	if (rc)
+		return rc;
+	const int64_t cap = nrows > 0 ? nrows : 1;
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
+	ix->own_rows = true;
+	ix->cap_rows = cap;
+	for (int c = 0; c < src->ncent; c++)
+	{
+		const int64_t n = src->glob_len[c];
+
+		if (!owned[c] || n == 0)
+			continue;
+		HIP_TRY(hipMemcpyAsync(ix->d_vecs + (size_t) ix->loc_off[c] * ix->dim,
+							   src->d_vecs + (size_t) src->loc_off[c] * src->dim,
+							   (size_t) n * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_tids + ix->loc_off[c], src->d_tids + src->loc_off[c],
+							   (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	ix->nrows = nrows;
+	ix->loaded = true;
+	*out = ix;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_ncentroids(const ndbhip_ivf *ix)
+{
+	return ix ? ix->ncent : -1;
+}
+
 /* ================================================================== */
 /* entry points implemented in later sections of this file            */
 /* ================================================================== */
-#ifndef NDB_HAVE_BUILD
+#ifndef NDB_HAVE_APPEND
 extern "C" int
 ndbhip_ivf_append(ndbhip_ivf *, int, const float *, const uint8_t *)
 {
 	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_append: not implemented in this build");
-}
-extern "C" int
-ndbhip_kmeans_device(const float *, int, int, int, int, float, float *, int *, int *, int *, float *)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_kmeans_device: not implemented in this build");
-}
-extern "C" int
-ndbhip_ivf_assign_device(const float *, int, int, const float *, int64_t, int *)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_assign_device: not implemented in this build");
-}
-extern "C" int
-ndbhip_ivf_build_device(ndbhip_ivf *, const float *, const uint64_t *, int64_t, int, int *)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_build_device: not implemented in this build");
 }
 #endif
 #ifndef NDB_HAVE_HNSW

@@ -160,6 +160,37 @@ wave_lds_sync()
  *   tile   this wave's private 16 KiB LDS tile
  * Returns this lane's distance, bit-identical to the CPU recipe R.
  */
+/* Stage one 64-row x 64-float chunk through the wave's LDS tile and hand every
+ * lane ITS row's 64 floats back in x[0..15] (x[p] = dims c+4p .. c+4p+3).
+ * FULL = the chunk lies completely inside the row. */
+template <bool FULL>
+__device__ __forceinline__ void
+stage_chunk(float4 (&x)[16], const float *__restrict__ base, const uint32_t (&rows16)[16],
+			int dim, int c, float *tile, int lane, int grp, int slot)
+{
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		const int	r = 4 * i + grp;
+		const int	piece = slot ^ (r & 15);
+		const int	col = c + piece * 4;
+		const float *src = base + (size_t) rows16[i] * (size_t) dim + col;
+
+		if (FULL || col < dim)
+			x[i] = *reinterpret_cast<const float4 *>(src);
+		else
+			x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		*reinterpret_cast<float4 *>(tile + (4 * i + grp) * NDB_CHUNK + slot * 4) = x[i];
+	wave_lds_sync();
+#pragma unroll
+	for (int p = 0; p < 16; p++)
+		x[p] = *reinterpret_cast<const float4 *>(tile + lane * NDB_CHUNK + ((p ^ (lane & 15)) * 4));
+	wave_lds_sync();
+}
+
 /* One 64-row x 64-float step: stage through LDS, then every lane walks its row.
  * FULL = the chunk lies completely inside the row (no per-piece bounds checks). */
 template <int R, bool FULL>

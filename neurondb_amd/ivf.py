@@ -72,6 +72,51 @@ class IvfIndex:
                                            C.c_void_p(d_tids.data_ptr()), d_rows.shape[0]))
         self._keep = [d_rows, d_tids]
 
+    def build_device(self, d_rows, d_tids, max_iter=50):
+        """ambuild on data already in HBM: sample the first min(10000, 100*nlists) rows, k-means
+        (ivf_am.c:2070-2294), assign every row (ivf_am.c:905-935), pack lists in heap order.
+        d_rows torch float32 [n, dim], d_tids torch int64 [n]. Returns Lloyd iterations run."""
+        iters = C.c_int(0)
+        assert d_rows.is_contiguous() and d_tids.is_contiguous()
+        check(lib().ndbhip_ivf_build_device(self._h, C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_tids.data_ptr()),
+                                            d_rows.shape[0], max_iter, C.byref(iters)))
+        self.ncent = self.nlists
+        return iters.value
+
+    def build(self, rows, tids, max_iter=50):
+        """Host-array form of build_device (stages through torch device tensors)."""
+        import torch
+        r = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
+        t = np.ascontiguousarray(tids)
+        t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
+        t8 = np.zeros((t6.shape[0], 8), dtype=np.uint8)
+        t8[:, :6] = t6
+        tt = torch.from_numpy(t8.view(np.int64).reshape(-1)).cuda()
+        it = self.build_device(r, tt, max_iter)
+        check(lib().ndbhip_synchronize())
+        return it
+
+    def shard(self, owned):
+        """New IvfIndex holding only the lists with owned[L] != 0 (multi-GPU: one process per GPU)."""
+        ow = np.ascontiguousarray(owned, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().ndbhip_ivf_shard(self._h, _ptr(ow), C.byref(h)))
+        sub = IvfIndex.__new__(IvfIndex)
+        sub.dim, sub.nlists, sub._h, sub._keep = self.dim, self.nlists, h, []
+        sub.ncent = getattr(self, "ncent", self.nlists)
+        return sub
+
+    def export(self, rows=True):
+        """Read the mirror back: (centroids, list_len, rows, tids structured)."""
+        nc = lib().ndbhip_ivf_ncentroids(self._h)
+        n = self.nrows
+        cent = np.zeros((nc, self.dim), dtype=np.float32)
+        ll = np.zeros(nc, dtype=np.int64)
+        r = np.zeros((n, self.dim), dtype=np.float32) if rows else None
+        t6 = np.zeros((n, 6), dtype=np.uint8) if rows else None
+        check(lib().ndbhip_ivf_export(self._h, _ptr(cent), _ptr(ll), _ptr(r), _ptr(t6)))
+        return cent, ll, r, (None if t6 is None else t6.view(TID_DTYPE).reshape(n))
+
     @property
     def nrows(self):
         return lib().ndbhip_ivf_nrows(self._h)
