@@ -84,18 +84,6 @@ def make_data(n, dim, kind, components, sigma, seed, center_seed, dev):
     return x
 
 
-def lpt_partition(list_len, world):
-    """Size-balanced list -> rank map (longest processing time first)."""
-    order = np.argsort(-list_len, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
-    owner = np.zeros(len(list_len), dtype=np.int32)
-    for l in order:
-        r = int(load.argmin())
-        owner[l] = r
-        load[r] += list_len[l]
-    return owner
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +98,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, sharded_search
     from neurondb_amd._lib import check, lib
     _lib.ensure_init(local_rank)
     stream = torch.cuda.current_stream()
@@ -137,7 +126,7 @@ def main():
     del base
 
     # ---------------- shard lists over ranks ----------------
-    owner = lpt_partition(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
+    owner = partition_lists(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
     owned = (owner == rank).astype(np.uint8)
     if world > 1:
         ix = ix_full.shard(owned)
@@ -148,27 +137,14 @@ def main():
         ix = ix_full
 
     # ---------------- one step ----------------
-    cap = 3 * k
-    out_t = torch.zeros((nq, k), dtype=torch.int64, device=dev)
-    out_d = torch.zeros((nq, k), dtype=torch.float32, device=dev)
-    out_c = torch.zeros(nq, dtype=torch.int32, device=dev)
-    if world > 1:
-        cand = torch.zeros((nq, cap, 2), dtype=torch.int64, device=dev)
-        ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
-        total = torch.zeros(nq, dtype=torch.int64, device=dev)
-        cand_all = torch.zeros((world, nq, cap, 2), dtype=torch.int64, device=dev)
-        ncand_all = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+    buf = ShardedSearchBuffers(nq, k, world, dev)
+    out_t, out_d, out_c = buf.out_tids, buf.out_dist, buf.out_count
 
     def step(qs):
         if world == 1:
             ix.search_device(qs, out_t, out_d, out_c, 1, nprobe, k, 0)
         else:
-            ix.search_partial_device(qs, cand, ncand, total, 1, nprobe, k, 0)
-            dist.all_gather_into_tensor(cand_all, cand)
-            dist.all_gather_into_tensor(ncand_all, ncand)
-            check(lib().ndbhip_merge_topk_device(cand_all.data_ptr(), ncand_all.data_ptr(), total.data_ptr(),
-                                                 world, nq, k, cap, out_t.data_ptr(), out_d.data_ptr(),
-                                                 out_c.data_ptr()))
+            sharded_search(ix, qs, buf, 1, nprobe, k, 0)
 
     def barrier():
         if world > 1:

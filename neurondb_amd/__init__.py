@@ -8,5 +8,6 @@ and raises if the library is missing.
 """
 from ._lib import NdbHipError, lib, lib_path, last_error  # noqa: F401
 from .ivf import IvfIndex, IvfScan  # noqa: F401
+from .hnsw import HnswIndex, HnswScan  # noqa: F401
 
-__all__ = ["NdbHipError", "lib", "lib_path", "last_error", "IvfIndex", "IvfScan"]
+__all__ = ["NdbHipError", "lib", "lib_path", "last_error", "IvfIndex", "IvfScan", "HnswIndex", "HnswScan"]

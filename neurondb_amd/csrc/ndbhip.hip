@@ -592,7 +592,8 @@ block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_
 	{
 		const uint32_t e = s.perm[s.order[i]];
 
-		out_id[i] = e_id[e];
+		if (out_id)
+			out_id[i] = e_id[e];
 		out_dist[i] = ndb_u2f(e_bits[e]);
 	}
 	if (tid == 0)
@@ -920,7 +921,7 @@ k_merge_topk(const ndbhip_cand *__restrict__ cand, const int *__restrict__ ncand
 	const uint32_t capall = cap * (uint32_t) world;
 	TopkSmem	s = carve_topk_smem(smem_raw, capall, k);
 	const uint32_t q = blockIdx.x;
-	__shared__ uint32_t woff[65];
+	uint32_t   *woff = s.hist;		/* 65 words: the histogram area is unused in the merge */
 
 	if (threadIdx.x == 0)
 	{
@@ -2232,6 +2233,525 @@ extern "C" int
 ndbhip_ivf_ncentroids(const ndbhip_ivf *ix)
 {
 	return ix ? ix->ncent : -1;
+}
+
+
+/* ================================================================== */
+/* HNSW: hnswSearch (src/index/hnsw_am.c:1545-2080)                    */
+/* ================================================================== */
+#define NDB_HAVE_HNSW 1
+
+struct HnswDev
+{
+	const float *vecs;			/* [nblocks * dim], row b = node b (row 0 = meta page, unused) */
+	const int  *levels;			/* [nblocks] */
+	const int16_t *ncount;		/* [nblocks * 16] */
+	const int64_t *nbr_off;		/* [nblocks + 1] */
+	const uint32_t *nbrs;
+	const uint64_t *tids;		/* [nblocks] */
+	uint32_t	nblocks;
+	int			dim;
+	int			m;
+	uint32_t	entry_point;
+	int			entry_level;
+};
+
+/* hnswValidateBlockNumber (:1228-1241) + "the meta page holds no node" (PageIsEmpty checks) */
+__device__ __forceinline__ bool
+hnsw_valid(const HnswDev &g, uint32_t b)
+{
+	return b != NDBHIP_INVALID_BLOCK && b < g.nblocks && b != 0;
+}
+
+__device__ __forceinline__ int
+hnsw_clamp(int c, int m)
+{
+	return c < 0 ? 0 : (c > 2 * m ? 2 * m : c);
+}
+
+__host__ __device__ static inline size_t
+hnsw_smem_bytes(uint32_t ef, uint32_t k, uint32_t m)
+{
+	const uint32_t npad = next_pow2(ef < 4 ? 4 : ef);
+
+	return (size_t) NDB_TILE_FLOATS * 4 + (size_t) ef * (4 + 4 + 4 + 8) + (size_t) (ef + 2 * m + 64) * 4 +
+		(size_t) npad * (8 + 4 + 4 + 1) + (size_t) k * 4 + 128;
+}
+
+/*
+ * One wave per query.  The walk is the reference's, statement for statement;
+ * only the distance evaluations of one neighbour list are batched (one lane per
+ * neighbour) — they do not depend on the sequential state — and the sequential
+ * bookkeeping (visited marks, append / replace-worst, first-min ties) is then
+ * replayed in neighbour order.
+ */
+template <int R>
+__global__ __launch_bounds__(64) void
+k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_t k,
+			  uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
+			  uint64_t *__restrict__ out_tids, long long *__restrict__ out_scored)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	unsigned char *sp = smem_raw;
+	float	   *tile = (float *) sp;			sp += (size_t) NDB_TILE_FLOATS * 4;
+	uint64_t   *e_id = (uint64_t *) sp;			sp += (size_t) ef * 8;
+	const uint32_t npad = next_pow2(ef < 4 ? 4 : ef);
+	FinalizeScratch fs;
+
+	fs.comp = (uint64_t *) sp;					sp += (size_t) npad * 8;
+	uint32_t   *cand = (uint32_t *) sp;			sp += (size_t) ef * 4;
+	uint32_t   *cdist = (uint32_t *) sp;		sp += (size_t) ef * 4;	/* float bits */
+	uint32_t   *e_pos = (uint32_t *) sp;		sp += (size_t) ef * 4;
+	uint32_t   *visited = (uint32_t *) sp;		sp += (size_t) (ef + 2 * g.m + 64) * 4;
+	fs.perm = (uint32_t *) sp;					sp += (size_t) npad * 4;
+	fs.curpos = (uint32_t *) sp;				sp += (size_t) npad * 4;
+	fs.order = (uint32_t *) sp;					sp += (size_t) k * 4;
+	fs.taken = (uint8_t *) sp;					/* npad bytes (npad >= 4: multiple of 4), then one int */
+
+	const uint32_t lane = threadIdx.x;
+	const uint32_t qi = blockIdx.x;
+	const float *q = queries + (size_t) qi * g.dim;
+	const int	m2 = 2 * g.m;
+	long long	scored = 0;
+	uint32_t	cur = g.entry_point;
+	int			curLevel = g.entry_level;
+
+	if (cur == NDBHIP_INVALID_BLOCK)	/* :1593-1599 */
+	{
+		if (lane == 0)
+		{
+			out_count[qi] = 0;
+			if (out_scored) out_scored[qi] = 0;
+		}
+		return;
+	}
+	if (curLevel < 0 || curLevel >= NDBHIP_HNSW_MAX_LEVEL)	/* :1609-1613 */
+		curLevel = 0;
+
+	/* ---- greedy descent (:1638-1750) ---- */
+	for (int level = curLevel; level > 0; level--)
+	{
+		bool		found;
+
+		do
+		{
+			found = false;
+			if (!hnsw_valid(g, cur))
+				break;
+			const int	nc = (g.levels[cur] >= level)
+				? hnsw_clamp(g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level], g.m) : 0;
+			const uint32_t *nb = g.nbrs + g.nbr_off[cur] + (size_t) level * m2;
+			const uint32_t node = cur;
+			float		currentDist = 0.0f;
+
+			/* batch 0: lane 0 = the node itself (currentDist, :1683), lanes 1.. = neighbours */
+			for (int j0 = -1; j0 < nc; j0 += 64)
+			{
+				const int	j = j0 + (int) lane;
+				uint32_t	my = (j < 0) ? node : ((j < nc) ? nb[j] : NDBHIP_INVALID_BLOCK);
+				const bool	act = hnsw_valid(g, my);
+				const float d = score_rows<R>(q, g.vecs, act ? my : node, g.dim, tile);
+				const unsigned long long am = __ballot(act);
+
+				scored += __popcll(am);
+				if (j0 < 0)
+					currentDist = __shfl(d, 0, 64);
+				/* sequential `if (neighborDist < currentDist)` over the batch = first strict minimum */
+				const bool	isnb = act && j >= 0;
+				uint64_t	key = isnb ? (((uint64_t) ndb_key_from_bits(__float_as_uint(d)) << 32) | lane)
+					: ~0ull;
+				const uint64_t best = wave_min_u64(key);
+
+				if (best != ~0ull)
+				{
+					const uint32_t bl = (uint32_t) best & 63u;
+					const float bd = __shfl(d, bl, 64);
+
+					if (bd < currentDist)
+					{
+						cur = __shfl(my, bl, 64);
+						currentDist = bd;
+						found = true;
+					}
+				}
+			}
+		} while (found);
+	}
+
+	if (!hnsw_valid(g, cur))	/* :1752-1763 */
+	{
+		if (lane == 0)
+		{
+			out_count[qi] = 0;
+			if (out_scored) out_scored[qi] = scored;
+		}
+		return;
+	}
+
+	/* ---- level 0 (:1765-1975) ---- */
+	uint32_t	cc = 1, vc = 1;
+	{
+		const float d0 = score_rows<R>(q, g.vecs, cur, g.dim, tile);
+
+		scored += 1;
+		if (lane == 0)
+		{
+			cand[0] = cur;
+			cdist[0] = __float_as_uint(d0);
+			visited[0] = cur;
+		}
+		wave_lds_sync();
+	}
+	for (uint32_t i = 0; i < cc && cc < ef; i++)
+	{
+		const uint32_t c = cand[i];
+
+		if (!hnsw_valid(g, c))
+			continue;
+		const int	nc = hnsw_clamp(g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + 0], g.m);
+		const uint32_t *nb = g.nbrs + g.nbr_off[c];
+
+		for (int j0 = 0; j0 < nc; j0 += 64)
+		{
+			const int	j = j0 + (int) lane;
+			const uint32_t my = (j < nc) ? nb[j] : NDBHIP_INVALID_BLOCK;
+			bool		ok = hnsw_valid(g, my);
+
+			/* visitedSet test (:1891) against everything scored so far */
+			if (ok)
+				for (uint32_t v = 0; v < vc; v++)
+					if (visited[v] == my)
+					{
+						ok = false;
+						break;
+					}
+			/* a block repeated inside this batch is visited by the time its 2nd copy is met */
+			for (uint32_t l = 0; l < 63; l++)
+			{
+				const uint32_t other = __shfl(my, l, 64);
+				const int	ook = __shfl((int) ok, l, 64);
+
+				if (l < lane && ook && other == my)
+					ok = false;
+			}
+			const unsigned long long mask0 = __ballot(ok);
+
+			if (mask0 == 0ull)
+				continue;
+			const float d = score_rows<R>(q, g.vecs, ok ? my : c, g.dim, tile);
+			unsigned long long mask = mask0;
+
+			scored += __popcll(mask0);
+			while (mask)
+			{
+				const int	l = __ffsll((long long) mask) - 1;
+
+				mask &= mask - 1;
+				const uint32_t nbk = __shfl(my, l, 64);
+				const float nd = __shfl(d, l, 64);
+
+				if (lane == 0)
+					visited[vc] = nbk;
+				vc++;
+				if (cc < ef)		/* :1948-1953 */
+				{
+					if (lane == 0)
+					{
+						cand[cc] = nbk;
+						cdist[cc] = __float_as_uint(nd);
+					}
+					cc++;
+				}
+				else				/* :1954-1972: first maximum, strict > */
+				{
+					uint64_t	wk = 0;
+
+					for (uint32_t t = lane; t < cc; t += 64)
+					{
+						const uint64_t kk2 = ((uint64_t) ndb_key_from_bits(cdist[t]) << 32) | (0xFFFFFFFFu - t);
+
+						wk = kk2 > wk ? kk2 : wk;
+					}
+#pragma unroll
+					for (int off = 32; off > 0; off >>= 1)
+					{
+						const uint32_t lo = __shfl_xor((uint32_t) wk, off, 64);
+						const uint32_t hi = __shfl_xor((uint32_t) (wk >> 32), off, 64);
+						const uint64_t o = ((uint64_t) hi << 32) | lo;
+
+						wk = o > wk ? o : wk;
+					}
+					const uint32_t widx = 0xFFFFFFFFu - (uint32_t) wk;
+					const float wd = __uint_as_float(cdist[widx]);
+
+					if (nd < wd && lane == 0)
+					{
+						cand[widx] = nbk;
+						cdist[widx] = __float_as_uint(nd);
+					}
+				}
+				wave_lds_sync();
+			}
+		}
+	}
+	wave_lds_sync();
+
+	/* ---- top-k by the reference's selection sort (:1977-2013) ---- */
+	for (uint32_t t = lane; t < cc; t += 64)
+	{
+		e_pos[t] = t;
+		e_id[t] = cand[t];
+	}
+	__syncthreads();
+	int		   *s_count = (int *) (fs.taken + npad);	/* last word of the dynamic LDS block */
+
+	block_finalize_topk(cdist, e_pos, e_id, cc, next_pow2(cc), k, (uint64_t) cc, fs,
+						(uint64_t *) nullptr, out_dist + (size_t) qi * k, s_count);
+	__syncthreads();
+	const uint32_t kk = (uint32_t) *s_count;
+
+	for (uint32_t i2 = lane; i2 < kk; i2 += 64)
+	{
+		const uint32_t e = fs.perm[fs.order[i2]];
+		const uint32_t b = cand[e];
+
+		out_blocks[(size_t) qi * k + i2] = b;
+		if (out_tids)
+			out_tids[(size_t) qi * k + i2] = g.tids[b];
+	}
+	if (lane == 0)
+	{
+		out_count[qi] = (int) kk;
+		if (out_scored) out_scored[qi] = scored;
+	}
+}
+
+struct ndbhip_hnsw
+{
+	int			dim = 0, m = 0;
+	uint32_t	nblocks = 0;
+	uint32_t	entry_point = NDBHIP_INVALID_BLOCK;
+	int			entry_level = -1;
+	float	   *d_vecs = nullptr;
+	int		   *d_levels = nullptr;
+	int16_t    *d_ncount = nullptr;
+	int64_t    *d_nbr_off = nullptr;
+	uint32_t   *d_nbrs = nullptr;
+	uint64_t   *d_tids = nullptr;
+	bool		loaded = false;
+	/* host-call workspace */
+	float	   *w_q = nullptr;		size_t w_q_n = 0;
+	uint32_t   *w_ob = nullptr;		size_t w_ob_n = 0;
+	float	   *w_od = nullptr;		size_t w_od_n = 0;
+	int		   *w_oc = nullptr;		size_t w_oc_n = 0;
+	uint64_t   *w_ot = nullptr;		size_t w_ot_n = 0;
+	long long  *w_os = nullptr;		size_t w_os_n = 0;
+};
+
+extern "C" int
+ndbhip_hnsw_create(int dim, int m, ndbhip_hnsw **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!out || dim < 1 || dim > 32767)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (m < 2 || m > 128)		/* HNSW_MIN_M / HNSW_MAX_M: hnsw_am.c:90-91 */
+		return fail(NDBHIP_ERR_INVALID, "m %d out of range 2..128", m);
+	ndbhip_hnsw *g2 = new (std::nothrow) ndbhip_hnsw();
+
+	if (!g2)
+		return fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	g2->dim = dim;
+	g2->m = m;
+	*out = g2;
+	return NDBHIP_OK;
+}
+
+static void
+hnsw_free_dev(ndbhip_hnsw *h)
+{
+	void	   *ptrs[] = {h->d_vecs, h->d_levels, h->d_ncount, h->d_nbr_off, h->d_nbrs, h->d_tids};
+
+	for (void *p : ptrs)
+		if (p) (void) hipFree(p);
+	h->d_vecs = nullptr; h->d_levels = nullptr; h->d_ncount = nullptr;
+	h->d_nbr_off = nullptr; h->d_nbrs = nullptr; h->d_tids = nullptr;
+	h->loaded = false;
+}
+
+extern "C" int
+ndbhip_hnsw_destroy(ndbhip_hnsw *h)
+{
+	if (!h)
+		return NDBHIP_OK;
+	if (g.inited)
+	{
+		(void) hipStreamSynchronize(g.stream);
+		hnsw_free_dev(h);
+		void	   *ptrs[] = {h->w_q, h->w_ob, h->w_od, h->w_oc, h->w_ot, h->w_os};
+
+		for (void *p : ptrs)
+			if (p) (void) hipFree(p);
+	}
+	delete h;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_load(ndbhip_hnsw *h, uint32_t nblocks, const float *vecs, const int32_t *levels,
+				 const int16_t *ncount, const int64_t *nbr_off, const uint32_t *nbrs, const uint8_t *tids6,
+				 uint32_t entry_point, int entry_level)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || nblocks < 1 || !vecs || !levels || !ncount || !nbr_off || !tids6)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	const int64_t nn = nbr_off[nblocks];
+
+	if (nn < 0 || (nn > 0 && !nbrs))
+		return fail(NDBHIP_ERR_INVALID, "bad neighbour arrays");
+	for (uint32_t b = 1; b < nblocks; b++)
+	{
+		if (levels[b] < 0 || levels[b] >= NDBHIP_HNSW_MAX_LEVEL)
+			return fail(NDBHIP_ERR_INVALID, "node %u: level %d out of range", b, levels[b]);
+		if (nbr_off[b + 1] - nbr_off[b] != (int64_t) (levels[b] + 1) * 2 * h->m)
+			return fail(NDBHIP_ERR_INVALID, "node %u: neighbour slots do not match (level+1)*2m", b);
+	}
+	hnsw_free_dev(h);
+	std::vector<uint64_t> t64(nblocks);
+
+	for (uint32_t b = 0; b < nblocks; b++)
+		t64[b] = ndb_tid_pack(tids6 + 6 * (size_t) b);
+	HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nblocks * h->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nblocks * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nblocks * 16 * sizeof(int16_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_nbr_off, (size_t) (nblocks + 1) * sizeof(int64_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) std::max<int64_t>(nn, 1) * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nblocks * sizeof(uint64_t)));
+	HIP_TRY(hipMemcpyAsync(h->d_vecs, vecs, (size_t) nblocks * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_levels, levels, (size_t) nblocks * sizeof(int), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_ncount, ncount, (size_t) nblocks * 16 * sizeof(int16_t), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_nbr_off, nbr_off, (size_t) (nblocks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+	if (nn > 0)
+		HIP_TRY(hipMemcpyAsync(h->d_nbrs, nbrs, (size_t) nn * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_tids, t64.data(), (size_t) nblocks * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	h->nblocks = nblocks;
+	h->entry_point = entry_point;
+	h->entry_level = entry_level;
+	h->loaded = true;
+	return NDBHIP_OK;
+}
+
+static int
+hnsw_check(ndbhip_hnsw *h, int nq, int strategy, int ef, int k)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !h->loaded)
+		return fail(NDBHIP_ERR_STATE, "hnsw mirror not loaded");
+	if (strategy < 1 || strategy > 3)	/* hnsw_am.c:1339-1343 */
+		return fail(NDBHIP_ERR_UNSUPPORTED, "hnsw: unsupported distance strategy %d", strategy);
+	if (nq < 0 || ef < 1 || ef > NDBHIP_MAX_EF || k < 1 || k > NDBHIP_MAX_K)
+		return fail(NDBHIP_ERR_INVALID, "nq/ef/k out of range (ef <= %d, k <= %d)", NDBHIP_MAX_EF, NDBHIP_MAX_K);
+	return 0;
+}
+
+extern "C" int
+ndbhip_hnsw_search_device(ndbhip_hnsw *h, const float *d_queries, int nq, int strategy, int ef, int k,
+						  uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count, uint64_t *d_out_tids,
+						  int64_t *d_out_scored)
+{
+	int			rc = hnsw_check(h, nq, strategy, ef, k);
+
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (!d_queries || !d_out_blocks || !d_out_dist || !d_out_count)
+		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	HnswDev		d;
+
+	d.vecs = h->d_vecs; d.levels = h->d_levels; d.ncount = h->d_ncount; d.nbr_off = h->d_nbr_off;
+	d.nbrs = h->d_nbrs; d.tids = h->d_tids; d.nblocks = h->nblocks; d.dim = h->dim; d.m = h->m;
+	d.entry_point = h->entry_point; d.entry_level = h->entry_level;
+	const size_t smem = hnsw_smem_bytes((uint32_t) ef, (uint32_t) k, (uint32_t) h->m);
+
+	if (smem > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "ef/k too large for the LDS-resident candidate set");
+	ScanTimer	t;
+
+	if (t.start()) return NDBHIP_ERR_HIP;
+	switch (strategy)
+	{
+		case 1:
+			hipLaunchKernelGGL(k_hnsw_search<R_HNSW_L2>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,
+							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,
+							   (long long *) d_out_scored);
+			break;
+		case 2:
+			hipLaunchKernelGGL(k_hnsw_search<R_HNSW_COS>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,
+							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,
+							   (long long *) d_out_scored);
+			break;
+		default:
+			hipLaunchKernelGGL(k_hnsw_search<R_HNSW_IP>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,
+							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,
+							   (long long *) d_out_scored);
+			break;
+	}
+	if (t.stop()) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipGetLastError());
+	g.stats.queries += (uint64_t) nq;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, int ef, int k,
+				   uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_scored)
+{
+	int			rc = hnsw_check(h, nq, strategy, ef, k);
+
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (!queries || !out_blocks || !out_dist || !out_count)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	if (grow(h->w_q, h->w_q_n, (size_t) nq * h->dim)) return NDBHIP_ERR_HIP;
+	if (grow(h->w_ob, h->w_ob_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+	if (grow(h->w_od, h->w_od_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+	if (grow(h->w_oc, h->w_oc_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	if (grow(h->w_ot, h->w_ot_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+	if (grow(h->w_os, h->w_os_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(h->w_q, queries, (size_t) nq * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(h->w_ob, 0, (size_t) nq * k * 4, g.stream));
+	HIP_TRY(hipMemsetAsync(h->w_od, 0, (size_t) nq * k * 4, g.stream));
+	HIP_TRY(hipMemsetAsync(h->w_ot, 0, (size_t) nq * k * 8, g.stream));
+	rc = ndbhip_hnsw_search_device(h, h->w_q, nq, strategy, ef, k, h->w_ob, h->w_od, h->w_oc, h->w_ot,
+								   (int64_t *) h->w_os);
+	if (rc)
+		return rc;
+	std::vector<uint64_t> t64((size_t) nq * k);
+	std::vector<long long> sc((size_t) nq);
+
+	HIP_TRY(hipMemcpyAsync(out_blocks, h->w_ob, (size_t) nq * k * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(out_dist, h->w_od, (size_t) nq * k * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(out_count, h->w_oc, (size_t) nq * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(t64.data(), h->w_ot, t64.size() * 8, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(sc.data(), h->w_os, sc.size() * 8, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	uint64_t	tot = 0;
+
+	for (int q2 = 0; q2 < nq; q2++)
+	{
+		tot += (uint64_t) sc[q2];
+		if (out_scored)
+			out_scored[q2] = sc[q2];
+		if (out_tids6)
+			for (int i = 0; i < k; i++)
+				ndb_tid_unpack(i < out_count[q2] ? t64[(size_t) q2 * k + i] : 0, out_tids6 + ((size_t) q2 * k + i) * 6);
+	}
+	g.host_rows += tot;
+	g.host_bytes += tot * (uint64_t) h->dim * 4;
+	return NDBHIP_OK;
 }
 
 /* ================================================================== */

@@ -1,0 +1,73 @@
+"""Multi-GPU driver for sharded IVF search: one process per GPU, lists partitioned
+over the ranks, per-rank candidate records all-gathered (RCCL over xGMI when the
+tensors live on the GPU, gloo on CPU tensors in the tests) and merged by replaying
+the reference's selection sort on the union (ndbhip_merge_topk_*).
+
+The only collective the path needs is this all-gather of nq x 3k x 16 B per rank
+(SURVEY 8e); there is no reduction and no all-to-all."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import check, lib
+
+CAND_WORDS = 2          # one ndbhip_cand = 16 bytes = 2 x int64
+
+
+def partition_lists(list_len, world: int) -> np.ndarray:
+    """Size-balanced list -> rank map (longest-processing-time first). Deterministic:
+    every rank computes the same map from the replicated list lengths."""
+    list_len = np.asarray(list_len, dtype=np.int64)
+    order = np.argsort(-list_len, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.zeros(len(list_len), dtype=np.int32)
+    for l in order:
+        r = int(load.argmin())
+        owner[l] = r
+        load[r] += list_len[l]
+    return owner
+
+
+def partial_cap(k: int) -> int:
+    return 3 * k            # NDBHIP_PARTIAL_CAP
+
+
+class ShardedSearchBuffers:
+    """Pre-allocated exchange buffers for batches of nq queries."""
+
+    def __init__(self, nq: int, k: int, world: int, device):
+        cap = partial_cap(k)
+        self.nq, self.k, self.world, self.cap = nq, k, world, cap
+        self.cand = torch.zeros((nq, cap, CAND_WORDS), dtype=torch.int64, device=device)
+        self.ncand = torch.zeros(nq, dtype=torch.int32, device=device)
+        self.total = torch.zeros(nq, dtype=torch.int64, device=device)
+        self.cand_all = torch.zeros((world, nq, cap, CAND_WORDS), dtype=torch.int64, device=device)
+        self.ncand_all = torch.zeros((world, nq), dtype=torch.int32, device=device)
+        self.out_tids = torch.zeros((nq, k), dtype=torch.int64, device=device)
+        self.out_dist = torch.zeros((nq, k), dtype=torch.float32, device=device)
+        self.out_count = torch.zeros(nq, dtype=torch.int32, device=device)
+
+
+def gather_and_merge(buf: ShardedSearchBuffers, group=None):
+    """all-gather the ranks' records, then merge.  Device tensors: RCCL + the HIP merge kernel
+    (asynchronous on the current stream).  CPU tensors: gloo + ndbhip_merge_topk_host."""
+    if buf.world > 1:
+        # output = ranks concatenated along dim 0 (the layout both RCCL and gloo accept)
+        dist.all_gather_into_tensor(buf.cand_all.view(buf.world * buf.nq, buf.cap, CAND_WORDS), buf.cand, group=group)
+        dist.all_gather_into_tensor(buf.ncand_all.view(buf.world * buf.nq), buf.ncand, group=group)
+    else:
+        buf.cand_all[0].copy_(buf.cand)
+        buf.ncand_all[0].copy_(buf.ncand)
+    fn = lib().ndbhip_merge_topk_device if buf.cand.is_cuda else lib().ndbhip_merge_topk_host
+    check(fn(buf.cand_all.data_ptr(), buf.ncand_all.data_ptr(), buf.total.data_ptr(), buf.world, buf.nq, buf.k,
+             buf.cap, buf.out_tids.data_ptr(), buf.out_dist.data_ptr(), buf.out_count.data_ptr()))
+    return buf.out_tids, buf.out_dist, buf.out_count
+
+
+def sharded_search(index, d_queries, buf: ShardedSearchBuffers, strategy=1, nprobe=10, k=10, max_candidates=0,
+                   group=None):
+    """One batch on this rank's shard (`index` = IvfIndex.shard(owned)) + exchange + merge."""
+    index.search_partial_device(d_queries, buf.cand, buf.ncand, buf.total, strategy, nprobe, k, max_candidates)
+    return gather_and_merge(buf, group)

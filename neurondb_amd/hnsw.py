@@ -1,0 +1,112 @@
+"""Host-side mirror of the reference's HNSW access-method scan interface
+(NeuronDB/src/index/hnsw_am.c: hnswbeginscan/hnswrescan/hnswgettuple) over the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, ensure_init, lib
+
+HNSW_DEFAULT_EF_SEARCH = 64   # GUC neurondb.hnsw_ef_search (src/util/neurondb_guc.c:161)
+HNSW_DEFAULT_K = 10           # GUC neurondb.hnsw_k (src/util/neurondb_guc.c:174)
+TID_DTYPE = np.dtype([("bi_hi", "<u2"), ("bi_lo", "<u2"), ("posid", "<u2")])
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HnswIndex:
+    """Device mirror of an hnsw index: node b = block number b (block 0 = meta page)."""
+
+    def __init__(self, dim: int, m: int = 16, device: int | None = None):
+        ensure_init(device)
+        self.dim, self.m = int(dim), int(m)
+        h = C.c_void_p()
+        check(lib().ndbhip_hnsw_create(self.dim, self.m, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ndbhip_hnsw_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, vecs, levels, ncount, nbrs_full, tids, entry_point, entry_level):
+        """vecs [nb, dim]; levels [nb]; ncount [nb,16]; nbrs_full [nb,16,2m] (only levels <= level[b] are kept);
+        tids [nb] structured or [nb,6] uint8."""
+        nb = int(vecs.shape[0])
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        levels = np.ascontiguousarray(levels, dtype=np.int32)
+        ncount = np.ascontiguousarray(ncount, dtype=np.int16)
+        slots = (levels.astype(np.int64) + 1) * 2 * self.m
+        slots[0] = 0
+        off = np.zeros(nb + 1, dtype=np.int64)
+        off[1:] = np.cumsum(slots)
+        packed = np.full(int(off[-1]), 0xFFFFFFFF, dtype=np.uint32)
+        nf = np.asarray(nbrs_full, dtype=np.uint32)
+        for b in range(1, nb):
+            packed[off[b]:off[b + 1]] = nf[b, : levels[b] + 1].reshape(-1)
+        t = np.ascontiguousarray(tids)
+        t6 = np.ascontiguousarray(t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6))
+        check(lib().ndbhip_hnsw_load(self._h, nb, _ptr(vecs), _ptr(levels), _ptr(ncount), _ptr(off), _ptr(packed),
+                                     _ptr(t6), int(entry_point) & 0xFFFFFFFF, int(entry_level)))
+        self.nblocks = nb
+
+    def search(self, queries, strategy=1, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K):
+        """Returns (blocks [nq,k] uint32, dist [nq,k], count [nq], tids [nq,k], scored [nq])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ob = np.zeros((nq, k), dtype=np.uint32)
+        od = np.zeros((nq, k), dtype=np.float32)
+        oc = np.zeros(nq, dtype=np.int32)
+        t6 = np.zeros((nq, k, 6), dtype=np.uint8)
+        sc = np.zeros(nq, dtype=np.int64)
+        check(lib().ndbhip_hnsw_search(self._h, _ptr(q), nq, strategy, ef, k, _ptr(ob), _ptr(od), _ptr(oc),
+                                       _ptr(t6), _ptr(sc)))
+        return ob, od, oc, t6.view(TID_DTYPE).reshape(nq, k), sc
+
+
+class HnswScan:
+    """hnswbeginscan / hnswrescan / hnswgettuple / hnswendscan (hnsw_am.c:880-1084)."""
+
+    def __init__(self, index: HnswIndex, ef_search=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K):
+        self.index = index
+        self.ef_search, self.k = ef_search, k     # the two GUCs read in hnswrescan (:923-936, 974)
+        self.query = None
+        self.strategy = 1
+        self.first_call = True
+        self.results = self.distances = self.tids = None
+        self.result_count = 0
+        self.current = 0
+        self.xs_heaptid = None
+
+    def rescan(self, query, strategy=1):
+        self.query = None if query is None else np.array(query, dtype=np.float32, copy=True)
+        self.strategy = strategy                    # orderbys[0].sk_strategy (:918-921)
+        self.first_call = True
+        self.result_count = self.current = 0
+
+    def gettuple(self) -> bool:
+        if self.query is None:
+            return False
+        if self.first_call:                          # :978-1007
+            b, d, c, t, _ = self.index.search(self.query[None, :], self.strategy, self.ef_search, self.k)
+            self.results, self.distances, self.tids = b[0], d[0], t[0]
+            self.result_count = int(c[0])
+            self.first_call = False
+            self.current = 0
+        if self.current < self.result_count:         # :1009-1053: node->heapPtr -> xs_heaptid (no orderbyvals: Q13)
+            self.xs_heaptid = self.tids[self.current]
+            self.current += 1
+            return True
+        return False
+
+    def endscan(self):
+        self.query = self.results = self.distances = self.tids = None

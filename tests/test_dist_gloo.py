@@ -1,0 +1,97 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the product's exchange + merge
+(neurondb_amd.dist.gather_and_merge -> ndbhip_merge_topk_host) on per-rank candidate
+records; the merged result must equal the oracle's single-process search."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ndbo
+from tests.test_merge_host import key_of, partial_records
+from tests.util import make_ivf_arrays, oracle_image
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_records(a, img, owner, rank, q, nprobe, k):
+    """What ndbhip_ivf_search_partial_device emits on `rank` (restated with the oracle's distances)."""
+    sel = img.select_clusters(q, nprobe)
+    ll = a["list_len"]
+    off = np.zeros(len(ll) + 1, np.int64)
+    off[1:] = np.cumsum(ll)
+    dist_l, pos_l, tid_l = [], [], []
+    pos = 0
+    L = ndbo.lib()
+    t64 = (a["tids"]["bi_hi"].astype(np.uint64) | (a["tids"]["bi_lo"].astype(np.uint64) << np.uint64(16)) |
+           (a["tids"]["posid"].astype(np.uint64) << np.uint64(32)))
+    for c in sel:
+        if c < 0:
+            continue
+        for r in range(off[c], off[c + 1]):
+            if owner[c] == rank:
+                dist_l.append(L.ndbo_ivf_distance(q, a["rows"][r], a["rows"].shape[1], 1))
+                pos_l.append(pos)
+                tid_l.append(t64[r])
+            pos += 1
+    rec = partial_records(np.array(dist_l, np.float32), np.array(pos_l, np.uint32), np.array(tid_l, np.uint64), k)
+    return rec, pos
+
+
+def _worker(rank, world, port, seed, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neurondb_amd.dist import ShardedSearchBuffers, gather_and_merge, partition_lists
+    a = make_ivf_arrays(1500, 16, 12, seed=seed, dup_frac=0.2, integer=True)
+    img = oracle_image(a)
+    owner = partition_lists(a["list_len"], world)
+    rng = np.random.default_rng(seed + 1)
+    queries = rng.integers(-3, 4, size=(6, 16)).astype(np.float32)
+    k, nprobe = 10, 5
+    buf = ShardedSearchBuffers(len(queries), k, world, "cpu")
+    for i, q in enumerate(queries):
+        rec, total = _rank_records(a, img, owner, rank, q, nprobe, k)
+        raw = np.zeros((buf.cap,), dtype=rec.dtype)
+        raw[:len(rec)] = rec
+        buf.cand[i] = torch.from_numpy(raw.view(np.int64).reshape(buf.cap, 2))
+        buf.ncand[i] = len(rec)
+        buf.total[i] = total
+    ot, od, oc = gather_and_merge(buf)
+    ok = True
+    for i, q in enumerate(queries):
+        et, ed, _ = img.search(q, 1, nprobe, k, 0)
+        got = ndbo.tids_from_device_u64(ot[i, :len(et)].numpy())
+        ok &= int(oc[i]) == len(et)
+        ok &= bool(np.array_equal(got, ndbo.tids_to_u64(et)))
+        ok &= bool(np.array_equal(od[i, :len(et)].numpy().view(np.uint32), ed.view(np.uint32)))
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gloo_world2_exchange_and_merge_equals_oracle(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, 77, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_partition_is_balanced_and_deterministic():
+    from neurondb_amd.dist import partition_lists
+    rng = np.random.default_rng(0)
+    ll = rng.integers(0, 5000, 1024)
+    o1, o2 = partition_lists(ll, 8), partition_lists(ll, 8)
+    assert np.array_equal(o1, o2)
+    loads = np.bincount(o1, weights=ll, minlength=8)
+    assert loads.max() - loads.min() <= ll.max()
