@@ -177,7 +177,7 @@ def main():
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "k_ivf_scan<R_IVF_L2>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None, "bytes_per_launch": int(bytes_per_launch),
+                "traffic": pmc_traffic(args, world), "bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(ms_per_launch, 4), "launches": int(launches)}
 
     # ---------------- recall@10 vs exact float64 brute force ----------------
@@ -233,6 +233,26 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, world):
+    """HBM-side bytes per launch of k_ivf_scan from the committed PMC passes (profiles/*_pmc_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied), or None when this run's workload differs
+    from the profiled one (counters cannot be read from inside the process being timed)."""
+    import glob
+    if world != 1:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get("k_ivf_scan", {}).get(args.data)
+    if not k:
+        return None
+    w = k["workload"]
+    same = (w["nvec"], w["dim"], w["lists"], w["probes"], w["batch"]) == \
+        (args.nvec, args.dim, args.lists, args.probes, args.batch) and args.k == 10
+    return int(k["traffic_bytes_per_launch"]) if same else None
 
 
 def run_cpu_baseline(args, cent_h, list_len, rows_h, tid_h, qs, out_t, out_d, out_c):
