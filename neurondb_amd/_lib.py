@@ -73,6 +73,7 @@ def lib():
         "ndbhip_stats_get": (i, [C.POINTER(Stats)]),
         "ndbhip_stats_reset": (i, []),
         "ndbhip_profile": (i, [i]),
+        "ndbhip_set_scan_mode": (i, [i]),
         "ndbhip_ivf_create": (i, [i, i, C.POINTER(vp)]),
         "ndbhip_ivf_destroy": (i, [vp]),
         "ndbhip_ivf_set_centroids": (i, [vp, vp, i]),

@@ -52,6 +52,10 @@ fail(int code, const char *fmt, ...)
 						hipGetErrorString(_e), __FILE__, __LINE__);                \
 	} while (0)
 
+/* list-scan kernel choice: 0 auto (grouped for batches >= 64 queries and dim % 64 == 0),
+ * 1 always per-query (k_ivf_scan), 2 always grouped (k_ivf_scan_grouped) */
+static int	g_scan_mode = 0;
+
 struct Ctx
 {
 	bool		inited = false;
@@ -59,6 +63,7 @@ struct Ctx
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;
 	bool		profile = false;
+	int			num_cus = 256;
 	ndbhip_stats stats = {};
 	unsigned long long *d_counters = nullptr;	/* [0] candidate rows scored (all ranks' view), [1] rows scored here */
 	uint64_t	host_rows = 0, host_bytes = 0;	/* counted on the host (batch distance) */
@@ -127,6 +132,7 @@ ndbhip_init(int device)
 		if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
 			return fail(NDBHIP_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only",
 						device, prop.gcnArchName);
+		g.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
 	g.stream = g.own_stream;
@@ -219,6 +225,15 @@ ndbhip_stats_reset(void)
 	}
 	g.host_rows = g.host_bytes = 0;
 	g.stats = ndbhip_stats();
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_set_scan_mode(int mode)
+{
+	if (mode < 0 || mode > 2)
+		return fail(NDBHIP_ERR_INVALID, "scan mode must be 0 (auto), 1 (per-query) or 2 (grouped)");
+	g_scan_mode = mode;
 	return NDBHIP_OK;
 }
 
@@ -791,6 +806,357 @@ k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 		dist[(size_t) q * stride + pos] = own ? d : __uint_as_float(NDB_ABSENT_BITS);
 }
 
+/* ------------------------------------------------------------------ */
+/* Query-grouped list scan.  In a batch many queries probe the same list
+ * (nq * nprobe / nlists on average), so the (query, probe) pairs are bucketed
+ * by list and one work item = (list, 64-row tile, group of <= NDB_QG queries):
+ * the row chunk is staged ONCE into registers and every query of the group is
+ * accumulated against it with its own register accumulator.  Each (row, query)
+ * sum is still the reference's sequential chain, so the distances are the same
+ * bits as k_ivf_scan's; HBM/fabric traffic drops by the group size and the
+ * kernel becomes bound by the fp32 vector ALU instead of HBM.
+ * Requires dim % 64 == 0 (otherwise the per-query kernel is used).          */
+/* ------------------------------------------------------------------ */
+#define NDB_QG 16
+
+struct PairRec
+{
+	uint32_t	q;				/* query index inside the sub-batch */
+	uint32_t	p;				/* probe index */
+};
+
+/* pass 1: how many (query, probe) pairs hit each owned list */
+__global__ void
+k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr, uint32_t nq,
+			 const uint8_t *__restrict__ owned, uint32_t *__restrict__ cnt)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= nq * (uint32_t) npr)
+		return;
+	const uint32_t q = i / npr, p = i % npr;
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+
+	if (co[p + 1] == co[p])
+		return;
+	const int	L = probes[(size_t) q * npr + p];
+
+	if (owned[L])
+		atomicAdd(&cnt[L], 1u);
+}
+
+/* pass 2 (one block of 1024 threads): per-list pair / work-item / group offsets */
+__global__ __launch_bounds__(1024) void
+k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
+			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
+			   uint32_t *__restrict__ grp_off)
+{
+	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
+	const int	t = threadIdx.x;
+	const int	per = (ncent + 1023) / 1024;
+	const int	l0 = t * per, l1 = min(ncent, l0 + per);
+	uint32_t	a = 0, b = 0, c2 = 0;
+
+	for (int L = l0; L < l1; L++)
+	{
+		const uint32_t c = cnt[L];
+		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
+
+		a += c;
+		b += ((glob_len[L] + 63u) >> 6) * ng;
+		c2 += ng;
+	}
+	sa[t] = a;
+	sb[t] = b;
+	sc[t] = c2;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1)
+	{
+		const uint32_t va = (t >= off) ? sa[t - off] : 0u;
+		const uint32_t vb = (t >= off) ? sb[t - off] : 0u;
+		const uint32_t vc = (t >= off) ? sc[t - off] : 0u;
+
+		__syncthreads();
+		sa[t] += va;
+		sb[t] += vb;
+		sc[t] += vc;
+		__syncthreads();
+	}
+	a = sa[t] - a;				/* exclusive prefix of this thread's first list */
+	b = sb[t] - b;
+	c2 = sc[t] - c2;
+	for (int L = l0; L < l1; L++)
+	{
+		const uint32_t c = cnt[L];
+		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
+
+		pair_off[L] = a;
+		item_off[L] = b;
+		grp_off[L] = c2;
+		a += c;
+		b += ((glob_len[L] + 63u) >> 6) * ng;
+		c2 += ng;
+	}
+	if (t == 1023)
+	{
+		pair_off[ncent] = sa[1023];
+		item_off[ncent] = sb[1023];
+		grp_off[ncent] = sc[1023];
+	}
+}
+
+/* pass 3: bucket the pairs */
+__global__ void
+k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr, uint32_t nq,
+			const uint8_t *__restrict__ owned, const uint32_t *__restrict__ pair_off,
+			uint32_t *__restrict__ fill, PairRec *__restrict__ pairs)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= nq * (uint32_t) npr)
+		return;
+	const uint32_t q = i / npr, p = i % npr;
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+
+	if (co[p + 1] == co[p])
+		return;
+	const int	L = probes[(size_t) q * npr + p];
+
+	if (!owned[L])
+		return;
+	const uint32_t slot = pair_off[L] + atomicAdd(&fill[L], 1u);
+	PairRec		r;
+
+	r.q = q;
+	r.p = p;
+	pairs[slot] = r;
+}
+
+/*
+ * pass 4: interleave every group's queries per dimension:
+ *   qblock[group][d][j] = queries[member j][d]   (j < 16; short groups are padded with member 0)
+ * so that ONE s_load_dwordx16 brings the 16 queries' values of a dimension and the
+ * arithmetic runs on query pairs with packed fp32 instructions.
+ * thread = (group, d): 16 coalesced reads (one per member), one 64-byte write.
+ */
+__global__ void
+k_group_pack(const float *__restrict__ queries, int dim, int ncent, const uint32_t *__restrict__ cnt,
+			 const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ grp_off,
+			 const PairRec *__restrict__ pairs, float *__restrict__ qblock)
+{
+	const uint32_t grp = blockIdx.y;
+	const uint32_t ngroups = grp_off[ncent];
+
+	if (grp >= ngroups)
+		return;
+	uint32_t	lo = 0, hi = (uint32_t) ncent;
+
+	while (hi - lo > 1)
+	{
+		const uint32_t mid = (lo + hi) >> 1;
+
+		if (grp_off[mid] <= grp)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	/* lists without pairs share their offset with the next one: skip forward to the owner */
+	while (lo + 1 < (uint32_t) ncent && grp_off[lo + 1] <= grp)
+		lo++;
+	const uint32_t L = lo;
+	const uint32_t g0 = (grp - grp_off[L]) * NDB_QG;
+	const uint32_t nmem = min((uint32_t) NDB_QG, cnt[L] - g0);
+	const PairRec *mem = pairs + pair_off[L] + g0;
+	const int	d = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (d >= dim)
+		return;
+	float		v[NDB_QG];
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG; j++)
+	{
+		const uint32_t qid = mem[(uint32_t) j < nmem ? j : 0].q;
+
+		v[j] = queries[(size_t) qid * dim + d];
+	}
+	float4	   *dst = reinterpret_cast<float4 *>(qblock + ((size_t) grp * dim + d) * NDB_QG);
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG / 4; j++)
+		dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+/* positions of lists this rank does not hold: mark absent (sharded search only) */
+__global__ void
+k_mark_absent(const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr, uint32_t nq,
+			  const uint8_t *__restrict__ owned, float *__restrict__ dist, uint32_t stride)
+{
+	const uint32_t q = blockIdx.y;
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+
+	for (int p = 0; p < npr; p++)
+	{
+		const uint32_t a = co[p], b = co[p + 1];
+
+		if (a == b || owned[probes[(size_t) q * npr + p]])
+			continue;
+		for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x)
+			dist[(size_t) q * stride + i] = __uint_as_float(NDB_ABSENT_BITS);
+	}
+}
+
+typedef float ndb_f2 __attribute__((ext_vector_type(2)));
+
+/* accumulators of 16 queries as 8 packed pairs; STEP = one dimension for all 16 queries */
+template <int R> struct GAcc;
+
+template <> struct GAcc<R_IVF_L2>
+{
+	ndb_f2		s[NDB_QG / 2];
+	__device__ __forceinline__ void init()
+	{
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+			s[i] = (ndb_f2) (0.0f);
+	}
+	__device__ __forceinline__ void step(const ndb_f2 *__restrict__ q, float x)
+	{
+		const ndb_f2 xx = (ndb_f2) (x);
+
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+		{
+			const ndb_f2 d = q[i] - xx;
+
+			s[i] = s[i] + d * d;
+		}
+	}
+	__device__ __forceinline__ float fin(int j) const
+	{
+		return __builtin_sqrtf((j & 1) ? s[j >> 1].y : s[j >> 1].x);
+	}
+};
+
+template <> struct GAcc<R_IVF_IP>
+{
+	ndb_f2		s[NDB_QG / 2];
+	__device__ __forceinline__ void init()
+	{
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+			s[i] = (ndb_f2) (0.0f);
+	}
+	__device__ __forceinline__ void step(const ndb_f2 *__restrict__ q, float x)
+	{
+		const ndb_f2 xx = (ndb_f2) (x);
+
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+			s[i] = s[i] + q[i] * xx;
+	}
+	__device__ __forceinline__ float fin(int j) const
+	{
+		return -((j & 1) ? s[j >> 1].y : s[j >> 1].x);
+	}
+};
+
+/*
+ * Persistent kernel: every wave pulls work items (list, 64-row tile, query group)
+ * from a global counter.  block = 256 (4 independent waves, 16 KiB LDS tile each).
+ */
+template <int R>
+__global__ __launch_bounds__(256) void
+k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ cand_off,
+				   int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
+				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
+				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
+				   float *__restrict__ dist, uint32_t stride)
+{
+	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
+	const int	lane = threadIdx.x & 63;
+	const int	wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int	grp = lane >> 4;
+	const int	slot = lane & 15;
+	float	   *tile = tiles + wave * NDB_TILE_FLOATS;
+	const int	dim = ix.dim;
+	const uint32_t nitems = item_off[ix.ncent];
+
+	for (;;)
+	{
+		uint32_t	item = 0;
+
+		if (lane == 0)
+			item = atomicAdd(next_item, 1u);
+		item = __builtin_amdgcn_readfirstlane(item);
+		if (item >= nitems)
+			break;
+		/* list of this item: the L with item_off[L] <= item < item_off[L+1] */
+		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;
+
+		while (hi - lo > 1)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if (item_off[mid] <= item)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (lo + 1 < (uint32_t) ix.ncent && item_off[lo + 1] <= item)
+			lo++;
+		const uint32_t L = lo;
+		const uint32_t len = ix.glob_len[L];
+		const uint32_t ntile = (len + 63u) >> 6;
+		const uint32_t local = item - item_off[L];
+		const uint32_t t = local % ntile;
+		const uint32_t gi = local / ntile;
+		const uint32_t g0 = gi * NDB_QG;
+		const uint32_t nmem = min((uint32_t) NDB_QG, cnt[L] - g0);
+		const PairRec *mem = pairs + pair_off[L] + g0;
+		const float *__restrict__ qb = qblock + (size_t) (grp_off[L] + gi) * (size_t) dim * NDB_QG;
+		const uint32_t ridx = t * 64 + lane;
+		const uint32_t row = (uint32_t) ix.loc_off[L] + (ridx < len ? ridx : len - 1);
+		uint32_t	rows16[16];
+		GAcc<R>		acc;
+
+		acc.init();
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			rows16[i] = __shfl(row, 4 * i + grp, 64);
+
+		for (int c = 0; c < dim; c += NDB_CHUNK)
+		{
+			float4		x[16];
+			const float *__restrict__ qc = qb + (size_t) c * NDB_QG;
+
+			stage_chunk<true>(x, ix.vecs, rows16, dim, c, tile, lane, grp, slot);
+#pragma unroll
+			for (int p = 0; p < 16; p++)
+			{
+				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 0) * NDB_QG), x[p].x);
+				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 1) * NDB_QG), x[p].y);
+				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 2) * NDB_QG), x[p].z);
+				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 3) * NDB_QG), x[p].w);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < NDB_QG; j++)
+		{
+			if ((uint32_t) j < nmem)
+			{
+				const uint32_t qid = mem[j].q;
+				const uint32_t pp = mem[j].p;
+				const uint32_t *co = cand_off + (size_t) qid * (npr + 1);
+				const uint32_t a = co[pp], nrow = co[pp + 1] - a;	/* may be capped below len (ivf_am.c:1743) */
+
+				if (ridx < nrow)
+					dist[(size_t) qid * stride + a + ridx] = acc.fin(j);
+			}
+		}
+	}
+}
+
 /* dynamic LDS layout of k_ivf_topk / k_merge_topk */
 struct TopkSmem
 {
@@ -991,6 +1357,7 @@ struct ndbhip_ivf
 	std::vector<int64_t> loc_off;
 	std::vector<uint8_t> owned;
 	bool		loaded = false;
+	bool		sharded = false;		/* some list is not held here */
 	/* workspace (grown on demand) */
 	float	   *w_cdist = nullptr;	size_t w_cdist_n = 0;
 	int		   *w_probes = nullptr;	size_t w_probes_n = 0;
@@ -1000,6 +1367,10 @@ struct ndbhip_ivf
 	uint64_t   *w_otid = nullptr;	size_t w_otid_n = 0;
 	float	   *w_odist = nullptr;	size_t w_odist_n = 0;
 	int		   *w_ocnt = nullptr;	size_t w_ocnt_n = 0;
+	uint32_t   *w_gcnt = nullptr;	size_t w_gcnt_n = 0;	/* [3*ncent + 3]: cnt, fill, + next_item */
+	uint32_t   *w_goff = nullptr;	size_t w_goff_n = 0;	/* [2*(ncent+1)]: pair_off, item_off */
+	PairRec    *w_pairs = nullptr;	size_t w_pairs_n = 0;
+	float	   *w_qblock = nullptr;	size_t w_qblock_n = 0;	/* [groups][dim][16] interleaved queries */
 };
 
 template <class T>
@@ -1062,7 +1433,8 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		(void) hipStreamSynchronize(g.stream);
 		ivf_free_rows(ix);
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
-			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt};
+			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
+			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -1113,6 +1485,10 @@ ivf_set_layout(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned, in
 		gl32[c] = (uint32_t) list_len[c];
 	}
 	ix->loc_off[nc] = acc;
+	ix->sharded = false;
+	for (int c = 0; c < nc; c++)
+		if (!ix->owned[c])
+			ix->sharded = true;
 	if (acc != nrows)
 		return fail(NDBHIP_ERR_INVALID, "nrows %lld does not match the owned lists' total %lld",
 					(long long) nrows, (long long) acc);
@@ -1285,9 +1661,56 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		return 0;
 
 	/* HOT LOOP 2 */
+	const int	R = ivf_recipe(strategy);
+	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 && R != R_IVF_COS &&
+		(g_scan_mode == 2 || (g_scan_mode == 0 && nq >= 64));
+
+	if (grouped)
+	{
+		const int	nc = ix->ncent;
+		uint32_t   *cnt = ix->w_gcnt, *fill = ix->w_gcnt + nc;
+		unsigned int *next_item = ix->w_gcnt + 2 * nc;
+		uint32_t   *pair_off = ix->w_goff, *item_off = ix->w_goff + (nc + 1), *grp_off = ix->w_goff + 2 * (nc + 1);
+		const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
+		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
+		ScanTimer	t;
+
+		if (t.start()) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 1) * sizeof(uint32_t), g.stream));
+		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
+						   (const int *) ix->w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
+						   (const uint8_t *) d.owned, cnt);
+		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
+						   (const uint32_t *) d.glob_len, nc, pair_off, item_off, grp_off);
+		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
+						   (const int *) ix->w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
+						   (const uint8_t *) d.owned, (const uint32_t *) pair_off, fill, ix->w_pairs);
+		hipLaunchKernelGGL(k_group_pack, dim3((ix->dim + 255) / 256, maxgroups), dim3(256), 0, g.stream, d_q,
+						   ix->dim, nc, (const uint32_t *) cnt, (const uint32_t *) pair_off,
+						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, ix->w_qblock);
+		if (ix->sharded)
+			hipLaunchKernelGGL(k_mark_absent, dim3(8, nq), dim3(256), 0, g.stream, (const int *) ix->w_probes,
+							   (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq, (const uint8_t *) d.owned,
+							   ix->w_dist, stride);
+		const dim3	pgrid(g.num_cus * 2);
+
+		if (R == R_IVF_IP)
+			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_IP>, pgrid, dim3(256), 0, g.stream, d,
+							   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,
+							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
+							   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,
+							   stride);
+		else
+			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_L2>, pgrid, dim3(256), 0, g.stream, d,
+							   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,
+							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
+							   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,
+							   stride);
+		if (t.stop()) return NDBHIP_ERR_HIP;
+	}
+	else
 	{
 		dim3		grid((stride + 255) / 256, nq);
-		const int	R = ivf_recipe(strategy);
 		ScanTimer	t;
 
 		if (t.start()) return NDBHIP_ERR_HIP;
@@ -1324,6 +1747,7 @@ ivf_check_search_args(ndbhip_ivf *ix, int nq, int nprobe, int k)
 }
 
 /* per-sub-batch budget for the candidate-distance buffer */
+#define NDB_DIST_BUDGET_DECLARED 1
 static size_t g_dist_budget_bytes = (size_t) 2 << 30;
 
 static int
@@ -1357,6 +1781,13 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (grow(ix->w_probes, ix->w_probes_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 4)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1))) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
+	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= 64 || g_scan_mode == 2))
+		if (grow(ix->w_qblock, ix->w_qblock_n,
+				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))
+			return NDBHIP_ERR_HIP;
 
 	const uint32_t cap = 3u * (uint32_t) k;
 

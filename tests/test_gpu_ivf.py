@@ -220,3 +220,66 @@ def test_sharded_partial_plus_merge_equals_single_device():
     _lib.check(_lib.lib().ndbhip_merge_topk_host(hc.ctypes.data, hn.ctypes.data, ht.ctypes.data, world, len(q),
                                                  k, cap, ot2.ctypes.data, od2.ctypes.data, oc2.ctypes.data))
     assert np.array_equal(ndbo.tids_from_device_u64(ot2), et) and np.array_equal(oc2, ec)
+
+
+@pytest.fixture
+def scan_mode():
+    from neurondb_amd import _lib
+    _lib.ensure_init()
+
+    def set_mode(m):
+        _lib.check(_lib.lib().ndbhip_set_scan_mode(m))
+    yield set_mode
+    set_mode(0)
+
+
+@pytest.mark.parametrize("dim,n,nlists", [(64, 3000, 12), (128, 6000, 40), (768, 3000, 24)])
+def test_grouped_scan_is_bit_identical_to_per_query_scan_and_oracle(dim, n, nlists, scan_mode):
+    """k_ivf_scan_grouped (query-grouped, packed fp32 pairs) vs k_ivf_scan vs the oracle."""
+    a = make_ivf_arrays(n, dim, nlists, seed=dim + 1, dup_frac=0.05, zero_rows=1)
+    ix = _index(a)
+    img = oracle_image(a)
+    q = _queries(a, 150, seed=dim + 2)          # > 64 queries: several groups per list, short tails
+    for strategy in (1, 3, 2):                  # cosine falls back to the per-query kernel
+        for nprobe, k, cap in ((8, 10, 0), (3, 7, 0), (10, 10, 100)):
+            res = {}
+            for mode in (1, 2):
+                scan_mode(mode)
+                res[mode] = ix.search(q, strategy, nprobe, k, cap)
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
+            for mode in (1, 2):
+                assert_same_results(*res[mode], et, ed, ec)
+
+
+def test_grouped_scan_sharded(scan_mode):
+    import torch
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd.dist import ShardedSearchBuffers, gather_and_merge
+    a = make_ivf_arrays(5000, 64, 16, seed=31, dup_frac=0.1)
+    img = oracle_image(a)
+    q = _queries(a, 100, seed=32)
+    k, nprobe, world = 10, 6, 4
+    full = _index(a)
+    dq = torch.from_numpy(q).cuda()
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+    for mode in (1, 2):
+        scan_mode(mode)
+        bufs = [ShardedSearchBuffers(len(q), k, world, "cuda") for _ in range(world)]
+        for w in range(world):
+            owned = (np.arange(16) % world == w).astype(np.uint8)
+            sh = full.shard(owned)
+            sh.search_partial_device(dq, bufs[w].cand, bufs[w].ncand, bufs[w].total, 1, nprobe, k)
+            _lib.check(_lib.lib().ndbhip_synchronize())
+            bufs[0].cand_all[w].copy_(bufs[w].cand)
+            bufs[0].ncand_all[w].copy_(bufs[w].ncand)
+            sh.close()
+        b = bufs[0]
+        _lib.check(_lib.lib().ndbhip_merge_topk_device(b.cand_all.data_ptr(), b.ncand_all.data_ptr(),
+                                                       b.total.data_ptr(), world, len(q), k, b.cap,
+                                                       b.out_tids.data_ptr(), b.out_dist.data_ptr(),
+                                                       b.out_count.data_ptr()))
+        _lib.check(_lib.lib().ndbhip_synchronize())
+        from oracle import ndbo
+        assert np.array_equal(b.out_count.cpu().numpy(), ec)
+        assert np.array_equal(ndbo.tids_from_device_u64(b.out_tids.cpu().numpy()), et)
+        assert np.array_equal(b.out_dist.cpu().numpy().view(np.uint32), ed.view(np.uint32))
