@@ -1007,6 +1007,28 @@ k_mark_absent(const int *__restrict__ probes, const uint32_t *__restrict__ cand_
 }
 
 typedef float ndb_f2 __attribute__((ext_vector_type(2)));
+typedef float ndb_f16 __attribute__((ext_vector_type(16)));
+
+/*
+ * Scalar (SMEM) loads the compiler does not schedule: hipcc sinks every s_load next to its
+ * first use and then waits lgkmcnt(0) — the full scalar-cache latency once per dimension.
+ * These helpers issue the loads early and wait late (cdna_hip_programming.md 5.7 form ii:
+ * "=s" loads, one wait statement that names every destination "+s").  SMEM returns out of
+ * order, so the only legal wait is lgkmcnt(0): the pipeline is "wait current -> issue next ->
+ * compute current".
+ */
+__device__ __forceinline__ void
+sload2x16(ndb_f16 &a, ndb_f16 &b, const float *p)
+{
+	asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
+				 : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+
+__device__ __forceinline__ void
+swait2(ndb_f16 &a, ndb_f16 &b)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) :: "memory");
+}
 
 /* accumulators of 16 queries as 8 packed pairs; STEP = one dimension for all 16 queries */
 template <int R> struct GAcc;
@@ -1020,14 +1042,18 @@ template <> struct GAcc<R_IVF_L2>
 		for (int i = 0; i < NDB_QG / 2; i++)
 			s[i] = (ndb_f2) (0.0f);
 	}
-	__device__ __forceinline__ void step(const ndb_f2 *__restrict__ q, float x)
+	__device__ __forceinline__ void step(const ndb_f16 &q, float x)
 	{
 		const ndb_f2 xx = (ndb_f2) (x);
 
 #pragma unroll
 		for (int i = 0; i < NDB_QG / 2; i++)
 		{
-			const ndb_f2 d = q[i] - xx;
+			ndb_f2		qp;
+
+			qp.x = q[2 * i];
+			qp.y = q[2 * i + 1];
+			const ndb_f2 d = qp - xx;
 
 			s[i] = s[i] + d * d;
 		}
@@ -1047,13 +1073,19 @@ template <> struct GAcc<R_IVF_IP>
 		for (int i = 0; i < NDB_QG / 2; i++)
 			s[i] = (ndb_f2) (0.0f);
 	}
-	__device__ __forceinline__ void step(const ndb_f2 *__restrict__ q, float x)
+	__device__ __forceinline__ void step(const ndb_f16 &q, float x)
 	{
 		const ndb_f2 xx = (ndb_f2) (x);
 
 #pragma unroll
 		for (int i = 0; i < NDB_QG / 2; i++)
-			s[i] = s[i] + q[i] * xx;
+		{
+			ndb_f2		qp;
+
+			qp.x = q[2 * i];
+			qp.y = q[2 * i + 1];
+			s[i] = s[i] + qp * xx;
+		}
 	}
 	__device__ __forceinline__ float fin(int j) const
 	{
@@ -1125,21 +1157,35 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 		for (int i = 0; i < 16; i++)
 			rows16[i] = __shfl(row, 4 * i + grp, 64);
 
+		/* query stream of this group: [dim][16] floats, consumed 2 dimensions (128 B) per batch,
+		 * double buffered in SGPRs: A = even batch, B = odd batch */
+		const float *qs = qb;
+		ndb_f16		qa0, qa1, qb0, qb1;
+
+		asm volatile("s_nop 4" ::: "memory");	/* the base pointer may come from v_readfirstlane */
+		sload2x16(qa0, qa1, qs);
 		for (int c = 0; c < dim; c += NDB_CHUNK)
 		{
 			float4		x[16];
-			const float *__restrict__ qc = qb + (size_t) c * NDB_QG;
 
 			stage_chunk<true>(x, ix.vecs, rows16, dim, c, tile, lane, grp, slot);
 #pragma unroll
 			for (int p = 0; p < 16; p++)
 			{
-				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 0) * NDB_QG), x[p].x);
-				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 1) * NDB_QG), x[p].y);
-				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 2) * NDB_QG), x[p].z);
-				acc.step(reinterpret_cast<const ndb_f2 *>(qc + (4 * p + 3) * NDB_QG), x[p].w);
+				/* dims 4p, 4p+1 from A; 4p+2, 4p+3 from B */
+				swait2(qa0, qa1);
+				sload2x16(qb0, qb1, qs + 2 * NDB_QG);
+				acc.step(qa0, x[p].x);
+				acc.step(qa1, x[p].y);
+				swait2(qb0, qb1);
+				qs += 4 * NDB_QG;
+				/* the last batch of the last chunk re-reads the final 128 B of this group's block */
+				sload2x16(qa0, qa1, (c + NDB_CHUNK >= dim && p == 15) ? qs - 2 * NDB_QG : qs);
+				acc.step(qb0, x[p].z);
+				acc.step(qb1, x[p].w);
 			}
 		}
+		swait2(qa0, qa1);
 #pragma unroll
 		for (int j = 0; j < NDB_QG; j++)
 		{
