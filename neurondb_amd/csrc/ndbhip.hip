@@ -514,10 +514,12 @@ struct FinalizeScratch
 	uint32_t   *order;
 };
 
-__device__ void
-block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_t *e_id, uint32_t n,
-					uint32_t npad, uint32_t k, uint64_t total, FinalizeScratch s,
-					uint64_t *out_id, float *out_dist, int *out_count)
+/* Sort the n entries by (order key, position) and cut to the tie-complete prefix:
+ * everything below T (= k-th smallest) plus the first 2k entries equal to T.
+ * Returns (all threads) ns = prefix length; fills s.comp / s.perm. Ends with a barrier. */
+__device__ uint32_t
+block_sort_cut(const uint32_t *e_bits, const uint32_t *e_pos, uint32_t n, uint32_t npad, uint32_t k,
+			   uint64_t total, FinalizeScratch s, uint32_t &kk_out)
 {
 	const uint32_t tid = threadIdx.x;
 	uint32_t	kk = (uint32_t) ((uint64_t) k < total ? (uint64_t) k : total);
@@ -539,7 +541,6 @@ block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_
 	}
 	block_bitonic_sort(s.comp, s.perm, npad);
 
-	/* tie-complete prefix: everything below T plus the first 2k entries equal to T */
 	uint32_t	ns = n;
 
 	if (kk > 0)
@@ -557,12 +558,22 @@ block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_
 			else
 				hi = mid;
 		}
-		uint32_t	lim = lo + 2 * k;
-
-		if (lim < ns)
-			ns = lim;
 		/* (entries with key > T inside [kk, ns) are harmless: they lose to every tie) */
+		if (lo + 2 * k < ns)
+			ns = lo + 2 * k;
 	}
+	kk_out = kk;
+	__syncthreads();
+	return ns;
+}
+
+/* Replay the reference's selection sort on the sorted prefix [0, ns) and write kk results. */
+__device__ void
+block_replay_emit(const uint32_t *e_bits, const uint64_t *e_id, uint32_t ns, uint32_t kk, FinalizeScratch s,
+				  uint64_t *out_id, float *out_dist, int *out_count)
+{
+	const uint32_t tid = threadIdx.x;
+
 	for (uint32_t j = tid; j < ns; j += blockDim.x)
 	{
 		s.curpos[j] = (uint32_t) s.comp[j];
@@ -613,6 +624,17 @@ block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_
 	}
 	if (tid == 0)
 		*out_count = (int) kk;
+}
+
+__device__ void
+block_finalize_topk(const uint32_t *e_bits, const uint32_t *e_pos, const uint64_t *e_id, uint32_t n,
+					uint32_t npad, uint32_t k, uint64_t total, FinalizeScratch s,
+					uint64_t *out_id, float *out_dist, int *out_count)
+{
+	uint32_t	kk;
+	const uint32_t ns = block_sort_cut(e_bits, e_pos, n, npad, k, total, s, kk);
+
+	block_replay_emit(e_bits, e_id, ns, kk, s, out_id, out_dist, out_count);
 }
 
 /* ================================================================== */
@@ -1253,10 +1275,30 @@ carve_topk_smem(unsigned char *base, uint32_t cap, uint32_t k)
 	return s;
 }
 
+#define NDB_TOPK_FAST_MAXK 64		/* fast path: k <= 64 (256 thread minima bound the k-th value) */
+#define NDB_TOPK_FAST_CAP 1024		/* candidates <= U the fast path can hold before falling back */
+
+__host__ __device__ static inline uint32_t
+topk_entry_cap(uint32_t k)
+{
+	return (k <= NDB_TOPK_FAST_MAXK && 3 * k < NDB_TOPK_FAST_CAP) ? NDB_TOPK_FAST_CAP : 3 * k;
+}
+
 /*
  * Top-k of one query's candidate distances, reproducing ivf_am.c:1856-1899.
- * One block per query.  partial != 0: emit the tie-complete subset for the
- * shard merge instead of final results.
+ * One block (256 threads) per query.
+ *
+ * Fast path (k <= 64), two streaming passes and no histogram:
+ *   1. every thread keeps the minimum key of its strided share; the k-th smallest of
+ *      the 256 thread minima is an upper bound U of the k-th smallest candidate
+ *      (the k smallest minima are k distinct candidates <= U);
+ *   2. every candidate with key <= U is gathered (a superset of "everything <= T");
+ *      block_sort_cut trims it to the tie-complete subset and the replay finishes.
+ *   If more than NDB_TOPK_FAST_CAP candidates are <= U (massive ties) the radix
+ *   path below is used instead.
+ * Radix path: 4-pass LDS-histogram select + ordered compaction (any k, any ties).
+ *
+ * partial != 0: emit the tie-complete subset for the shard merge instead of results.
  */
 __global__ __launch_bounds__(256) void
 k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr,
@@ -1265,59 +1307,143 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		   uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	const uint32_t cap = 3 * k;
-	TopkSmem	s = carve_topk_smem(smem_raw, cap, k);
+	const uint32_t ecap = topk_entry_cap(k);
+	TopkSmem	s = carve_topk_smem(smem_raw, ecap, k);
 	const uint32_t q = blockIdx.x;
+	const uint32_t tid = threadIdx.x;
 	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
 	const uint32_t total = co[npr];
 	const float *d = dist + (size_t) q * stride;
-	uint32_t	T, m_less, kk, cnt_eq;
+	uint32_t	ns = 0;
+	bool		have = false;
 
 	auto		ld = [&](uint32_t i, uint32_t &bits) -> bool {
 		bits = __float_as_uint(d[i]);
 		return bits != NDB_ABSENT_BITS;
 	};
+	auto		tid_of = [&](uint32_t i) -> uint64_t {
+		const uint32_t p = find_probe(co, npr, i);
+		const int	L = probes[(size_t) q * npr + p];
 
-	block_radix_select(ld, total, k, s.hist, s.sh, T, m_less, kk, cnt_eq);
+		return ix.tids[ix.loc_off[L] + (i - co[p])];
+	};
 
-	uint32_t	n_eq = cnt_eq < 2 * k ? cnt_eq : 2 * k;
-	uint32_t	ns = (kk > 0) ? (m_less + n_eq) : 0;
-
-	if (kk > 0)
+	if (k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
 	{
-		auto		emit = [&](int cls, uint32_t rank, uint32_t i, uint32_t bits) {
-			const uint32_t slot = cls ? (m_less + rank) : rank;
-			const uint32_t p = find_probe(co, npr, i);
-			const int	L = probes[(size_t) q * npr + p];
+		/* pass 1: thread minima (4 independent loads in flight per thread) */
+		uint32_t	mn = 0xFFFFFFFFu;
+		uint32_t	nvalid = 0;
+		uint32_t	i = tid;
 
-			s.e_bits[slot] = bits;
-			s.e_pos[slot] = i;
-			s.e_id[slot] = ix.tids[ix.loc_off[L] + (i - co[p])];
-		};
-		block_ordered_gather(ld, total, T, n_eq, s.sh, emit);
+		for (; i + 3 * 256 < total; i += 4 * 256)
+		{
+			const uint32_t b0 = __float_as_uint(d[i]), b1 = __float_as_uint(d[i + 256]);
+			const uint32_t b2 = __float_as_uint(d[i + 512]), b3 = __float_as_uint(d[i + 768]);
+
+			if (b0 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b0)); nvalid++; }
+			if (b1 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b1)); nvalid++; }
+			if (b2 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b2)); nvalid++; }
+			if (b3 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b3)); nvalid++; }
+		}
+		for (; i < total; i += 256)
+		{
+			const uint32_t b0 = __float_as_uint(d[i]);
+
+			if (b0 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b0)); nvalid++; }
+		}
+		/* sort the 256 minima; threads without a candidate carry 0xFFFFFFFF and sort last */
+		const uint32_t nth = (uint32_t) __syncthreads_count(nvalid > 0);
+
+		s.fs.comp[tid] = ((uint64_t) mn << 32) | tid;
+		s.fs.perm[tid] = tid;
+		block_bitonic_sort(s.fs.comp, s.fs.perm, 256);
+		/* U: the k-th smallest thread minimum bounds the k-th smallest candidate (the k smallest
+		 * minima are k distinct candidates <= U); with fewer than k non-empty threads gather all */
+		const uint32_t U = (nth >= k) ? (uint32_t) (s.fs.comp[k - 1] >> 32) : 0xFFFFFFFFu;
+		__syncthreads();
+
+		/* pass 2: gather every candidate with key <= U */
+		if (tid == 0)
+			s.sh[0] = 0;
+		__syncthreads();
+		for (i = tid; i < total; i += 256)
+		{
+			const uint32_t b0 = __float_as_uint(d[i]);
+
+			if (b0 != NDB_ABSENT_BITS && ndb_key_from_bits(b0) <= U)
+			{
+				const uint32_t slot = atomicAdd(&s.sh[0], 1u);
+
+				if (slot < NDB_TOPK_FAST_CAP)
+				{
+					s.e_bits[slot] = b0;
+					s.e_pos[slot] = i;
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t got = s.sh[0];
+
+		__syncthreads();
+		if (got <= NDB_TOPK_FAST_CAP)
+		{
+			ns = got;
+			have = true;
+			for (uint32_t j = tid; j < ns; j += 256)
+				s.e_id[j] = tid_of(s.e_pos[j]);
+			__syncthreads();
+		}
 	}
-	__syncthreads();
+
+	if (!have)
+	{
+		uint32_t	T, m_less, kk0, cnt_eq;
+
+		block_radix_select(ld, total, k, s.hist, s.sh, T, m_less, kk0, cnt_eq);
+		const uint32_t n_eq = cnt_eq < 2 * k ? cnt_eq : 2 * k;
+
+		ns = (kk0 > 0) ? (m_less + n_eq) : 0;
+		if (kk0 > 0)
+		{
+			auto		emit = [&](int cls, uint32_t rank, uint32_t i, uint32_t bits) {
+				const uint32_t slot = cls ? (m_less + rank) : rank;
+
+				s.e_bits[slot] = bits;
+				s.e_pos[slot] = i;
+				s.e_id[slot] = tid_of(i);
+			};
+			block_ordered_gather(ld, total, T, n_eq, s.sh, emit);
+		}
+		__syncthreads();
+	}
+
+	/* number of candidates this rank holds = what bounds kk locally; globally `total` */
+	uint32_t	kk;
+	const uint32_t npad = next_pow2(ns > 0 ? ns : 1);
+	const uint32_t cut = block_sort_cut(s.e_bits, s.e_pos, ns, npad, k, partial ? (uint64_t) ns : (uint64_t) total,
+										s.fs, kk);
 
 	if (partial)
 	{
-		for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x)
+		for (uint32_t j = tid; j < cut; j += blockDim.x)
 		{
+			const uint32_t e = s.fs.perm[j];
 			ndbhip_cand c;
 
-			c.key = s.e_bits[j];	/* raw float4 bits; the merge derives the order key */
-			c.pos = s.e_pos[j];
-			c.tid = s.e_id[j];
-			out_cand[(size_t) q * cap + j] = c;
+			c.key = s.e_bits[e];	/* raw float4 bits; the merge derives the order key */
+			c.pos = s.e_pos[e];
+			c.tid = s.e_id[e];
+			out_cand[(size_t) q * (3 * k) + j] = c;
 		}
-		if (threadIdx.x == 0)
+		if (tid == 0)
 		{
-			out_ncand[q] = (int) ns;
+			out_ncand[q] = (int) cut;
 			out_total[q] = (int64_t) total;
 		}
 		return;
 	}
-	block_finalize_topk(s.e_bits, s.e_pos, s.e_id, ns, next_pow2(ns > 0 ? ns : 1), k, total, s.fs,
-						out_tids + (size_t) q * k, out_dist + (size_t) q * k, out_count + q);
+	block_replay_emit(s.e_bits, s.e_id, cut, kk, s.fs, out_tids + (size_t) q * k, out_dist + (size_t) q * k,
+					  out_count + q);
 }
 
 /*
@@ -1765,7 +1891,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (t.stop()) return NDBHIP_ERR_HIP;
 	}
 	{
-		const size_t smem = topk_smem_bytes(3u * (uint32_t) k, (uint32_t) k);
+		const size_t smem = topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k);
 
 		hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) ix->w_probes,
 						   (const uint32_t *) ix->w_candoff, npr, (const float *) ix->w_dist, stride,
@@ -1807,7 +1933,7 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 		return rc;
 	if (nq == 0)
 		return NDBHIP_OK;
-	if (topk_smem_bytes(3u * k, k) > NDB_TOPK_MAX_SMEM)
+	if (topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k) > NDB_TOPK_MAX_SMEM)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "k too large for the LDS top-k stage");
 
 	int64_t		maxc = ndbhip_ivf_max_candidates(ix, nprobe);
