@@ -28,6 +28,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+# fp32 vector peak is 157.3 TFLOP/s with FMA (64 FLOP/clk/SIMD); the reference's recipe needs separately
+# rounded subtract, multiply and add (no FMA), i.e. 32 FLOP/clk/SIMD = 78.6 TFLOP/s
+UNFUSED_FP32_PEAK_TFLOPS = 78.6
 
 
 def parse():
@@ -170,15 +173,25 @@ def main():
         elapsed = float(tt.item())
     qps = nq * args.steps / elapsed
 
-    # ---------------- roofline of the dominant kernel (k_ivf_scan) ----------------
+    # ---------------- roofline of the dominant kernel ----------------
+    grouped = (nq >= 64 and dim % 64 == 0)
+    kernel = "k_ivf_scan_grouped<R_IVF_L2>" if grouped else "k_ivf_scan<R_IVF_L2>"
     launches = max(1, st["scan_launches"])
-    bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B
+    bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B per query
     ms_per_launch = st["scan_kernel_ms"] / launches
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_ivf_scan<R_IVF_L2>", "achieved": round(achieved, 1),
+    # every scored (row element, query) pair costs one subtract, one multiply, one add, unfused
+    flops_per_launch = 3.0 * bytes_per_launch / 4.0
+    valu_tflops = flops_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(args, world), "bytes_per_launch": int(bytes_per_launch),
-                "avg_launch_ms": round(ms_per_launch, 4), "launches": int(launches)}
+                "traffic": pmc_traffic(args, world, kernel.split("<")[0]), "bytes_per_launch": int(bytes_per_launch),
+                "avg_launch_ms": round(ms_per_launch, 4), "launches": int(launches),
+                "note": ("algorithmic bytes = rows scored x 3072 B per query; the grouped kernel stages each row tile once "
+                         "for up to 16 queries, so HBM traffic is ~1/16 of that and the limiter is the fp32 vector ALU"
+                         if grouped else "one pass over the probed rows per query"),
+                "valu": {"achieved": round(valu_tflops, 2), "peak": UNFUSED_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(valu_tflops / UNFUSED_FP32_PEAK_TFLOPS, 4)}}
 
     # ---------------- recall@10 vs exact float64 brute force ----------------
     recall = None
@@ -235,7 +248,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, world):
+def pmc_traffic(args, world, kernel="k_ivf_scan"):
     """HBM-side bytes per launch of k_ivf_scan from the committed PMC passes (profiles/*_pmc_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied), or None when this run's workload differs
     from the profiled one (counters cannot be read from inside the process being timed)."""
@@ -246,7 +259,7 @@ def pmc_traffic(args, world):
     if not files:
         return None
     with open(files[-1]) as f:
-        k = json.load(f)["kernels"].get("k_ivf_scan", {}).get(args.data)
+        k = json.load(f)["kernels"].get(kernel, {}).get(args.data)
     if not k:
         return None
     w = k["workload"]

@@ -840,6 +840,9 @@ k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
  * Requires dim % 64 == 0 (otherwise the per-query kernel is used).          */
 /* ------------------------------------------------------------------ */
 #define NDB_QG 16
+#ifndef NDB_GROUPED_WAVES_PER_SIMD
+#define NDB_GROUPED_WAVES_PER_SIMD 3		/* caps the kernel at 168 VGPRs; LDS (16 KiB/wave) allows 10 waves/CU */
+#endif
 
 struct PairRec
 {
@@ -1120,19 +1123,17 @@ template <> struct GAcc<R_IVF_IP>
  * from a global counter.  block = 256 (4 independent waves, 16 KiB LDS tile each).
  */
 template <int R>
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(64, NDB_GROUPED_WAVES_PER_SIMD) void
 k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ cand_off,
 				   int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 				   float *__restrict__ dist, uint32_t stride)
 {
-	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
+	__shared__ __attribute__((aligned(16))) float tile[NDB_TILE_FLOATS];
 	const int	lane = threadIdx.x & 63;
-	const int	wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int	grp = lane >> 4;
 	const int	slot = lane & 15;
-	float	   *tile = tiles + wave * NDB_TILE_FLOATS;
 	const int	dim = ix.dim;
 	const uint32_t nitems = item_off[ix.ncent];
 
@@ -1847,7 +1848,6 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
 		ScanTimer	t;
 
-		if (t.start()) return NDBHIP_ERR_HIP;
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 1) * sizeof(uint32_t), g.stream));
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) ix->w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
@@ -1864,16 +1864,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			hipLaunchKernelGGL(k_mark_absent, dim3(8, nq), dim3(256), 0, g.stream, (const int *) ix->w_probes,
 							   (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq, (const uint8_t *) d.owned,
 							   ix->w_dist, stride);
-		const dim3	pgrid(g.num_cus * 2);
+		const dim3	pgrid(g.num_cus * 10);	/* one wave per block; LDS admits 10 per CU */
+
+		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
 		if (R == R_IVF_IP)
-			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_IP>, pgrid, dim3(256), 0, g.stream, d,
+			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_IP>, pgrid, dim3(64), 0, g.stream, d,
 							   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,
 							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
 							   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,
 							   stride);
 		else
-			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_L2>, pgrid, dim3(256), 0, g.stream, d,
+			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_L2>, pgrid, dim3(64), 0, g.stream, d,
 							   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,
 							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
 							   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,
