@@ -2392,6 +2392,104 @@ k_assign_partial_direct(const float *__restrict__ rows, uint32_t nrows, int dim,
 	part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
 }
 
+/* cblock[g][d][j] = cents[16 g + j][d] (j beyond the last centroid repeats centroid 0 and is ignored) */
+__global__ void
+k_interleave16(const float *__restrict__ cents, int ncent, int dim, float *__restrict__ cblock)
+{
+	const int	g16 = blockIdx.y;
+	const int	d = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (d >= dim)
+		return;
+	float		v[NDB_QG];
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG; j++)
+	{
+		const int	c = g16 * NDB_QG + j;
+
+		v[j] = cents[(size_t) (c < ncent ? c : 0) * dim + d];
+	}
+	float4	   *dst = reinterpret_cast<float4 *>(cblock + ((size_t) g16 * dim + d) * NDB_QG);
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG / 4; j++)
+		dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+/*
+ * Nearest centroid, fast form (dim % 64 == 0): one wave = 64 rows x 16 centroids, the row chunk
+ * staged once per chunk, the 16 centroids' values of a dimension arriving as ONE scalar load and
+ * the arithmetic running on centroid pairs (v_pk_*_f32) — the same engine as k_ivf_scan_grouped.
+ * Every (row, centroid) sum is still the sequential fp32 chain of vector_distance_l2 / ivfinsert
+ * ((x-c)^2 == (c-x)^2 exactly).  grid = (row tiles, centroid groups of 16), block = 64.
+ */
+template <bool SQRT>
+__global__ __launch_bounds__(64, NDB_GROUPED_WAVES_PER_SIMD) void
+k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const float *__restrict__ cblock,
+				 int ncent, float *__restrict__ part_dist, int *__restrict__ part_idx)
+{
+	__shared__ __attribute__((aligned(16))) float tile[NDB_TILE_FLOATS];
+	const int	lane = threadIdx.x;
+	const int	grp = lane >> 4;
+	const int	slot = lane & 15;
+	const uint32_t r = blockIdx.x * 64 + lane;
+	const uint32_t row = (r < nrows) ? r : (nrows - 1);
+	const int	c0 = blockIdx.y * NDB_QG;
+	const int	gc = (ncent - c0 < NDB_QG) ? (ncent - c0) : NDB_QG;
+	uint32_t	rows16[16];
+	GAcc<R_IVF_L2> acc;
+	const float *qs = cblock + (size_t) blockIdx.y * (size_t) dim * NDB_QG;
+	ndb_f16		qa0, qa1, qb0, qb1;
+
+	acc.init();
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		rows16[i] = __shfl(row, 4 * i + grp, 64);
+	sload2x16(qa0, qa1, qs);
+	for (int c = 0; c < dim; c += NDB_CHUNK)
+	{
+		float4		x[16];
+
+		stage_chunk<true>(x, rows, rows16, dim, c, tile, lane, grp, slot);
+#pragma unroll
+		for (int p = 0; p < 16; p++)
+		{
+			swait2(qa0, qa1);
+			sload2x16(qb0, qb1, qs + 2 * NDB_QG);
+			acc.step(qa0, x[p].x);
+			acc.step(qa1, x[p].y);
+			swait2(qb0, qb1);
+			qs += 4 * NDB_QG;
+			sload2x16(qa0, qa1, (c + NDB_CHUNK >= dim && p == 15) ? qs - 2 * NDB_QG : qs);
+			acc.step(qb0, x[p].z);
+			acc.step(qb1, x[p].w);
+		}
+	}
+	swait2(qa0, qa1);
+	float		best = FLT_MAX;
+	int			bidx = -1;
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG; j++)
+	{
+		float		d = (j & 1) ? acc.s[j >> 1].y : acc.s[j >> 1].x;
+
+		if (SQRT)
+			d = __builtin_sqrtf(d);
+		if (j < gc && d < best)
+		{
+			best = d;
+			bidx = c0 + j;
+		}
+	}
+	if (r < nrows)
+	{
+		part_dist[(size_t) blockIdx.y * nrows + r] = best;
+		part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
+	}
+}
+
 /* first strict minimum over the groups, in centroid order; none below FLT_MAX -> 0
  * (best = 0 / min_idx = 0 initialisers: ivf_am.c:2277, 812) */
 __global__ void
@@ -2495,9 +2593,11 @@ static int
 assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int ncent, bool use_sqrt,
 			int *d_out_list, int *d_counts)
 {
-	const int	ngroups = (ncent + NDB_CGROUP - 1) / NDB_CGROUP;
+	const bool	fast = (dim % NDB_CHUNK) == 0;
+	const int	gsize = fast ? NDB_QG : NDB_CGROUP;
+	const int	ngroups = (ncent + gsize - 1) / gsize;
 	const int64_t chunk = 1 << 18;
-	float	   *pd = nullptr;
+	float	   *pd = nullptr, *cblock = nullptr;
 	int		   *pi = nullptr;
 	const int64_t cmax = std::min<int64_t>(chunk, nrows);
 
@@ -2505,13 +2605,28 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 		return 0;
 	HIP_TRY(hipMalloc((void **) &pd, (size_t) ngroups * cmax * sizeof(float)));
 	HIP_TRY(hipMalloc((void **) &pi, (size_t) ngroups * cmax * sizeof(int)));
+	if (fast)
+	{
+		HIP_TRY(hipMalloc((void **) &cblock, (size_t) ngroups * dim * NDB_QG * sizeof(float)));
+		hipLaunchKernelGGL(k_interleave16, dim3((dim + 255) / 256, ngroups), dim3(256), 0, g.stream, d_cents,
+						   ncent, dim, cblock);
+	}
 	for (int64_t r0 = 0; r0 < nrows; r0 += chunk)
 	{
 		const uint32_t n = (uint32_t) std::min<int64_t>(chunk, nrows - r0);
 		dim3		grid((n + 63) / 64, ngroups);
 		const float *rows = d_rows + (size_t) r0 * dim;
 
-		if ((dim & 3) == 0)
+		if (fast)
+		{
+			if (use_sqrt)
+				hipLaunchKernelGGL(k_assign_grouped<true>, grid, dim3(64), 0, g.stream, rows, n, dim,
+								   (const float *) cblock, ncent, pd, pi);
+			else
+				hipLaunchKernelGGL(k_assign_grouped<false>, grid, dim3(64), 0, g.stream, rows, n, dim,
+								   (const float *) cblock, ncent, pd, pi);
+		}
+		else if ((dim & 3) == 0)
 		{
 			if (use_sqrt)
 				hipLaunchKernelGGL(k_assign_partial<true>, grid, dim3(64), 0, g.stream, rows, n, dim, d_cents,
@@ -2536,6 +2651,8 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	HIP_TRY(hipFree(pd));
 	HIP_TRY(hipFree(pi));
+	if (cblock)
+		HIP_TRY(hipFree(cblock));
 	return 0;
 }
 
