@@ -234,6 +234,22 @@ int			ndbhip_hnsw_search_device(ndbhip_hnsw *g, const float *d_queries, int nq, 
 									  uint64_t *d_out_tids, int64_t *d_out_scored);
 
 /* ------------------------------------------------------------------ */
+/* Datum -> dense float4[] (replaces ivfExtractVectorData, src/index/ivf_am.c:117-218,
+ * and hnswExtractVectorData, src/index/hnsw_am.c:1402-1519).  `datum` is the
+ * DETOASTED varlena image of the indexed value (vector / halfvec / sparsevec /
+ * bit), `kind` says which.  Pure host code; needs no device.  halfvec elements
+ * decode exactly like the reference's fp16_to_float (src/types/quantization.c:
+ * 170-218), sparsevec scatters into zeros dropping out-of-range indices, bit
+ * maps 1 -> +1.0f and 0 -> -1.0f.  out may be NULL to query the dimension.   */
+/* ------------------------------------------------------------------ */
+#define NDBHIP_TYPE_VECTOR    0
+#define NDBHIP_TYPE_HALFVEC   1
+#define NDBHIP_TYPE_SPARSEVEC 2
+#define NDBHIP_TYPE_BIT       3
+int			ndbhip_extract_vector(int kind, const void *datum, size_t datum_len, float *out, int out_cap,
+								  int *out_dim);
+
+/* ------------------------------------------------------------------ */
 /* Batch distance (replaces neurondb_gpu_batch_l2_distance & co:
  * include/neurondb_gpu.h:94-106, src/gpu/common/gpu_batch.c:27-83, whose
  * body is a CPU loop).  recipe selects the rounding:

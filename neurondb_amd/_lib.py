@@ -100,6 +100,7 @@ def lib():
         "ndbhip_hnsw_search": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_hnsw_search_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_batch_distance": (i, [vp, vp, vp, i, i, i, i, i]),
+        "ndbhip_extract_vector": (i, [i, vp, C.c_size_t, vp, i, C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly

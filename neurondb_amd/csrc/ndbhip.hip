@@ -1531,6 +1531,10 @@ struct ndbhip_ivf
 	std::vector<uint8_t> owned;
 	bool		loaded = false;
 	bool		sharded = false;		/* some list is not held here */
+	/* aminsert: entries appended since the last repack (flushed before the next search) */
+	std::vector<int> pend_list;
+	std::vector<float> pend_rows;
+	std::vector<uint64_t> pend_tids;
 	/* workspace (grown on demand) */
 	float	   *w_cdist = nullptr;	size_t w_cdist_n = 0;
 	int		   *w_probes = nullptr;	size_t w_probes_n = 0;
@@ -1744,7 +1748,14 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 extern "C" int64_t
 ndbhip_ivf_nrows(const ndbhip_ivf *ix)
 {
-	return ix ? ix->nrows : -1;
+	if (!ix)
+		return -1;
+	int64_t		n = ix->nrows;
+
+	for (int c : ix->pend_list)
+		if (ix->owned[c])
+			n++;
+	return n;
 }
 
 extern "C" int64_t
@@ -1765,6 +1776,132 @@ ndbhip_ivf_max_candidates(const ndbhip_ivf *ix, int nprobe)
 		s += (int64_t) (nprobe - n) * ix->glob_len[0];
 	return s;
 }
+
+/*
+ * Fold the pending aminsert entries into the packed layout: every list keeps its
+ * old rows in place order and gains its new entries at the tail, in arrival order —
+ * exactly where ivfinsert's PageAddItem on the tail page puts them
+ * (src/index/ivf_am.c:985-1157).  Cost O(nlists) copies per flush, amortised over
+ * all inserts since the previous search.
+ */
+static int
+ivf_flush(ndbhip_ivf *ix)
+{
+	const size_t P = ix->pend_list.size();
+
+	if (P == 0)
+		return 0;
+	const int	nc = ix->ncent;
+	const int	dim = ix->dim;
+	std::vector<int64_t> add((size_t) nc, 0), new_len(ix->glob_len);
+	std::vector<int64_t> new_off((size_t) nc + 1, 0);
+	int64_t		nown = 0;
+
+	for (size_t i = 0; i < P; i++)
+	{
+		add[ix->pend_list[i]]++;
+		new_len[ix->pend_list[i]]++;
+	}
+	for (int c = 0; c < nc; c++)
+	{
+		new_off[c] = nown;
+		if (ix->owned[c])
+			nown += new_len[c];
+	}
+	new_off[nc] = nown;
+	if (nown > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 rows on one device");
+
+	/* pending rows of owned lists, grouped by list (stable) */
+	std::vector<int64_t> stage_off((size_t) nc + 1, 0);
+
+	for (int c = 0; c < nc; c++)
+		stage_off[c + 1] = stage_off[c] + (ix->owned[c] ? add[c] : 0);
+	const int64_t nstage = stage_off[nc];
+	std::vector<float> srows((size_t) std::max<int64_t>(nstage, 1) * dim);
+	std::vector<uint64_t> stids((size_t) std::max<int64_t>(nstage, 1));
+	std::vector<int64_t> cur(stage_off.begin(), stage_off.end() - 1);
+
+	for (size_t i = 0; i < P; i++)
+	{
+		const int	c = ix->pend_list[i];
+
+		if (!ix->owned[c])
+			continue;
+		memcpy(&srows[(size_t) cur[c] * dim], &ix->pend_rows[i * dim], (size_t) dim * sizeof(float));
+		stids[(size_t) cur[c]] = ix->pend_tids[i];
+		cur[c]++;
+	}
+	float	   *nrows_d = nullptr, *stage_d = nullptr;
+	uint64_t   *ntids_d = nullptr, *stids_d = nullptr;
+	const int64_t cap = std::max<int64_t>(nown, 1);
+
+	HIP_TRY(hipMalloc((void **) &nrows_d, (size_t) cap * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &ntids_d, (size_t) cap * sizeof(uint64_t)));
+	if (nstage > 0)
+	{
+		HIP_TRY(hipMalloc((void **) &stage_d, (size_t) nstage * dim * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &stids_d, (size_t) nstage * sizeof(uint64_t)));
+		HIP_TRY(hipMemcpyAsync(stage_d, srows.data(), (size_t) nstage * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(stids_d, stids.data(), (size_t) nstage * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	}
+	for (int c = 0; c < nc; c++)
+	{
+		if (!ix->owned[c])
+			continue;
+		const int64_t oldn = ix->glob_len[c];
+
+		if (oldn > 0)
+		{
+			HIP_TRY(hipMemcpyAsync(nrows_d + (size_t) new_off[c] * dim, ix->d_vecs + (size_t) ix->loc_off[c] * dim,
+								   (size_t) oldn * dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(ntids_d + new_off[c], ix->d_tids + ix->loc_off[c], (size_t) oldn * sizeof(uint64_t),
+								   hipMemcpyDeviceToDevice, g.stream));
+		}
+		if (add[c] > 0)
+		{
+			HIP_TRY(hipMemcpyAsync(nrows_d + (size_t) (new_off[c] + oldn) * dim, stage_d + (size_t) stage_off[c] * dim,
+								   (size_t) add[c] * dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(ntids_d + new_off[c] + oldn, stids_d + stage_off[c],
+								   (size_t) add[c] * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (stage_d) HIP_TRY(hipFree(stage_d));
+	if (stids_d) HIP_TRY(hipFree(stids_d));
+	std::vector<uint8_t> owned(ix->owned);
+	int			rc = ivf_set_layout(ix, new_len.data(), owned.data(), nown);
+
+	if (rc)
+		return rc;
+	ivf_free_rows(ix);
+	ix->d_vecs = nrows_d;
+	ix->d_tids = ntids_d;
+	ix->own_rows = true;
+	ix->nrows = nown;
+	ix->cap_rows = cap;
+	ix->pend_list.clear();
+	ix->pend_rows.clear();
+	ix->pend_tids.clear();
+	return 0;
+}
+
+extern "C" int
+ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !vec || !tid6)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!ix->loaded)
+		return fail(NDBHIP_ERR_STATE, "index has no lists loaded");
+	if (list_id < 0 || list_id >= ix->ncent)
+		return fail(NDBHIP_ERR_INVALID, "list %d out of range 0..%d", list_id, ix->ncent - 1);
+	ix->pend_list.push_back(list_id);
+	ix->pend_rows.insert(ix->pend_rows.end(), vec, vec + ix->dim);	/* copied: caller's memory may be palloc'd */
+	ix->pend_tids.push_back(ndb_tid_pack(tid6));
+	return NDBHIP_OK;
+}
+#define NDB_HAVE_APPEND 1
 
 static IvfDev
 ivf_dev(const ndbhip_ivf *ix)
@@ -1933,6 +2070,9 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 
 	if (rc)
 		return rc;
+	rc = ivf_flush(ix);
+	if (rc)
+		return rc;
 	if (nq == 0)
 		return NDBHIP_OK;
 	if (topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k) > NDB_TOPK_MAX_SMEM)
@@ -2056,6 +2196,9 @@ ndbhip_ivf_select_clusters(ndbhip_ivf *ix, const float *queries, int nq, int npr
 		return NDBHIP_OK;
 	if (!queries || !out_probes)
 		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	rc = ivf_flush(ix);
+	if (rc)
+		return rc;
 	const int	ncmp = std::min(ix->nlists, ix->ncent);
 	const size_t cstride = (size_t) ((ncmp + 63) & ~63);
 	const int	qb = 4096;
@@ -2875,11 +3018,15 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 
 /* read the index image back (tests, bench cpu baseline, PostgreSQL page writer) */
 extern "C" int
-ndbhip_ivf_export(const ndbhip_ivf *ix, float *centroids, int64_t *list_len, float *rows, uint8_t *tids6)
+ndbhip_ivf_export(const ndbhip_ivf *cix, float *centroids, int64_t *list_len, float *rows, uint8_t *tids6)
 {
+	ndbhip_ivf *ix = const_cast<ndbhip_ivf *>(cix);
+
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!ix || !ix->loaded)
 		return fail(NDBHIP_ERR_STATE, "index not loaded");
+	if (ivf_flush(ix))
+		return NDBHIP_ERR_HIP;
 	if (centroids)
 		HIP_TRY(hipMemcpy(centroids, ix->d_centroids, (size_t) ix->ncent * ix->dim * 4, hipMemcpyDeviceToHost));
 	if (list_len)
@@ -3474,6 +3621,144 @@ ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, i
 	g.host_rows += tot;
 	g.host_bytes += tot * (uint64_t) h->dim * 4;
 	return NDBHIP_OK;
+}
+
+
+/* ================================================================== */
+/* Datum -> dense float4[] (ivfExtractVectorData ivf_am.c:117-218,      */
+/* hnswExtractVectorData hnsw_am.c:1402-1519).  Host-side staging of    */
+/* queries and inserted rows; operates on detoasted datum images.       */
+/* ================================================================== */
+
+/* fp16 -> fp32 exactly as the reference's fp16_to_float (quantization.c:170-218), including its
+ * subnormal exponent arithmetic (quirk Q20), so halfvec columns index the same values */
+static float
+fp16_image_to_float(uint16_t h)
+{
+	const uint32_t sign = (uint32_t) (h & 0x8000u) << 16;
+	uint32_t	exp = (h & 0x7c00u) >> 10;
+	const uint32_t mant = h & 0x03ffu;
+	uint32_t	f;
+	float		out;
+
+	if (exp == 0)
+	{
+		if (mant == 0)
+			f = sign;
+		else
+		{
+			uint32_t	m = mant;
+
+			exp = 1;
+			while ((m & 0x0400u) == 0)
+			{
+				m <<= 1;
+				exp--;
+			}
+			m &= 0x03ffu;
+			f = sign | ((127u - 15u - (10u - exp)) << 23) | (m << 13);
+		}
+	}
+	else if (exp == 0x1f)
+		f = sign | 0x7f800000u | (mant << 13);
+	else
+		f = sign | ((exp + 127u - 15u) << 23) | (mant << 13);
+	memcpy(&out, &f, 4);
+	return out;
+}
+
+extern "C" int
+ndbhip_extract_vector(int kind, const void *datum, size_t datum_len, float *out, int out_cap, int *out_dim)
+{
+	const uint8_t *p = (const uint8_t *) datum;
+
+	if (!datum || !out_dim)
+		return fail(NDBHIP_ERR_INVALID, "ivf: out_dim cannot be NULL");
+	switch (kind)
+	{
+		case NDBHIP_TYPE_VECTOR:	/* Vector {int32 vl_len_; int16 dim; int16 unused; float4 data[]} */
+		{
+			int16_t		dim;
+
+			if (datum_len < 8)
+				return fail(NDBHIP_ERR_INVALID, "vector datum too short");
+			memcpy(&dim, p + 4, 2);
+			if (dim < 0 || datum_len < 8 + (size_t) dim * 4)
+				return fail(NDBHIP_ERR_INVALID, "vector datum truncated");
+			*out_dim = dim;
+			if (out && out_cap >= dim)
+				memcpy(out, p + 8, (size_t) dim * 4);
+			else if (out)
+				return fail(NDBHIP_ERR_INVALID, "output buffer too small for %d dimensions", (int) dim);
+			return NDBHIP_OK;
+		}
+		case NDBHIP_TYPE_HALFVEC:	/* VectorF16 {int32 vl_len_; int16 dim; int16 data[]} */
+		{
+			int16_t		dim;
+
+			if (datum_len < 6)
+				return fail(NDBHIP_ERR_INVALID, "halfvec datum too short");
+			memcpy(&dim, p + 4, 2);
+			if (dim < 0 || datum_len < 6 + (size_t) dim * 2)
+				return fail(NDBHIP_ERR_INVALID, "halfvec datum truncated");
+			*out_dim = dim;
+			if (out && out_cap < dim)
+				return fail(NDBHIP_ERR_INVALID, "output buffer too small for %d dimensions", (int) dim);
+			for (int i = 0; out && i < dim; i++)
+			{
+				uint16_t	h;
+
+				memcpy(&h, p + 6 + 2 * (size_t) i, 2);
+				out[i] = fp16_image_to_float(h);
+			}
+			return NDBHIP_OK;
+		}
+		case NDBHIP_TYPE_SPARSEVEC:	/* VectorMap {int32 vl_len_; int32 total_dim; int32 nnz; int32 idx[]; float4 val[]} */
+		{
+			int32_t		total_dim, nnz;
+
+			if (datum_len < 12)
+				return fail(NDBHIP_ERR_INVALID, "sparsevec datum too short");
+			memcpy(&total_dim, p + 4, 4);
+			memcpy(&nnz, p + 8, 4);
+			if (total_dim < 0 || nnz < 0 || datum_len < 12 + (size_t) nnz * 8)
+				return fail(NDBHIP_ERR_INVALID, "sparsevec datum truncated");
+			*out_dim = total_dim;
+			if (out && out_cap < total_dim)
+				return fail(NDBHIP_ERR_INVALID, "output buffer too small for %d dimensions", total_dim);
+			if (out)
+			{
+				memset(out, 0, (size_t) total_dim * 4);
+				for (int i = 0; i < nnz; i++)
+				{
+					int32_t		ix;
+
+					memcpy(&ix, p + 12 + 4 * (size_t) i, 4);
+					if (ix >= 0 && ix < total_dim)	/* out-of-range indices are dropped (ivf_am.c:187-188) */
+						memcpy(&out[ix], p + 12 + 4 * (size_t) nnz + 4 * (size_t) i, 4);
+				}
+			}
+			return NDBHIP_OK;
+		}
+		case NDBHIP_TYPE_BIT:		/* VarBit {int32 vl_len_; int32 bit_len; bits8 bit_dat[]}: 1 -> +1.0, 0 -> -1.0 */
+		{
+			int32_t		nbits;
+
+			if (datum_len < 8)
+				return fail(NDBHIP_ERR_INVALID, "bit datum too short");
+			memcpy(&nbits, p + 4, 4);
+			if (nbits < 0 || datum_len < 8 + ((size_t) nbits + 7) / 8)
+				return fail(NDBHIP_ERR_INVALID, "bit datum truncated");
+			*out_dim = nbits;
+			if (out && out_cap < nbits)
+				return fail(NDBHIP_ERR_INVALID, "output buffer too small for %d dimensions", nbits);
+			for (int i = 0; out && i < nbits; i++)
+				out[i] = ((p[8 + i / 8] >> (7 - (i % 8))) & 1) ? 1.0f : -1.0f;
+			return NDBHIP_OK;
+		}
+		default:				/* ereport(ERROR, "ivf: unsupported type OID"): ivf_am.c:208-214 */
+			return fail(NDBHIP_ERR_UNSUPPORTED, "ivf: unsupported type kind %d", kind);
+	}
 }
 
 /* ================================================================== */

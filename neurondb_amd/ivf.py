@@ -72,6 +72,12 @@ class IvfIndex:
                                            C.c_void_p(d_tids.data_ptr()), d_rows.shape[0]))
         self._keep = [d_rows, d_tids]
 
+    def append(self, list_id, vec, tid):
+        """aminsert: add one entry at the tail of list `list_id` (ivf_am.c:954-1157)."""
+        v = np.ascontiguousarray(vec, dtype=np.float32)
+        t = np.ascontiguousarray(np.asarray(tid).reshape(1)).view(np.uint8).reshape(-1)[:6].copy()
+        check(lib().ndbhip_ivf_append(self._h, int(list_id), _ptr(v), _ptr(t)))
+
     def build_device(self, d_rows, d_tids, max_iter=50):
         """ambuild on data already in HBM: sample the first min(10000, 100*nlists) rows, k-means
         (ivf_am.c:2070-2294), assign every row (ivf_am.c:905-935), pack lists in heap order.

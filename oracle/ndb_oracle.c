@@ -473,6 +473,84 @@ ndbo_halfvec_ip(const uint16_t *a, const uint16_t *b, int dim)
 }
 
 /* ================================================================== */
+/* ivfExtractVectorData: src/index/ivf_am.c:117-218 (datum images)      */
+/* ================================================================== */
+int
+ndbo_extract_vector(int kind, const unsigned char *datum, float *out, int *out_dim)
+{
+	int			i;
+
+	switch (kind)
+	{
+		case 0:					/* vector: :158-167 */
+		{
+			int16_t		dim;
+
+			memcpy(&dim, datum + 4, 2);
+			*out_dim = dim;
+			for (i = 0; i < dim; i++)
+				memcpy(&out[i], datum + 8 + 4 * (size_t) i, 4);
+			return 0;
+		}
+		case 1:					/* halfvec: :168-177 */
+		{
+			int16_t		dim;
+
+			memcpy(&dim, datum + 4, 2);
+			*out_dim = dim;
+			for (i = 0; i < dim; i++)
+			{
+				uint16_t	h;
+
+				memcpy(&h, datum + 6 + 2 * (size_t) i, 2);
+				out[i] = ndbo_fp16_to_float(h);
+			}
+			return 0;
+		}
+		case 2:					/* sparsevec: :178-194 */
+		{
+			int32_t		total_dim, nnz;
+			const unsigned char *indices = datum + 12;
+			const unsigned char *values;
+
+			memcpy(&total_dim, datum + 4, 4);
+			memcpy(&nnz, datum + 8, 4);
+			values = indices + 4 * (size_t) nnz;
+			*out_dim = total_dim;
+			memset(out, 0, (size_t) total_dim * sizeof(float));
+			for (i = 0; i < nnz; i++)
+			{
+				int32_t		ix;
+
+				memcpy(&ix, indices + 4 * (size_t) i, 4);
+				if (ix >= 0 && ix < total_dim)
+					memcpy(&out[ix], values + 4 * (size_t) i, 4);
+			}
+			return 0;
+		}
+		case 3:					/* bit: :195-212 */
+		{
+			int32_t		nbits;
+			const unsigned char *bit_data = datum + 8;
+
+			memcpy(&nbits, datum + 4, 4);
+			*out_dim = nbits;
+			for (i = 0; i < nbits; i++)
+			{
+				int			byte_idx = i / 8;
+				int			bit_idx = i % 8;
+				int			bit_val = (bit_data[byte_idx] >> (8 - 1 - bit_idx)) & 1;
+
+				out[i] = bit_val ? 1.0f : -1.0f;
+			}
+			return 0;
+		}
+		default:				/* :213-220 ereport(ERROR) */
+			return -1;
+	}
+}
+
+/* ================================================================== */
 /* Top-k by selection sort with index swaps                            */
 /* src/index/ivf_am.c:1856-1881 ; src/index/hnsw_am.c:1977-2004        */
 /* ================================================================== */

@@ -85,6 +85,10 @@ float		ndbo_halfvec_l2(const uint16_t *a, const uint16_t *b, int dim);
 float		ndbo_halfvec_cosine(const uint16_t *a, const uint16_t *b, int dim);
 float		ndbo_halfvec_ip(const uint16_t *a, const uint16_t *b, int dim);	/* -sum */
 
+/* src/index/ivf_am.c:117-218 on detoasted datum images: kind 0 vector, 1 halfvec,
+ * 2 sparsevec, 3 bit; returns -1 for an unsupported kind (reference: ERROR) */
+int			ndbo_extract_vector(int kind, const unsigned char *datum, float *out, int *out_dim);
+
 /* ------------------------------------------------------------------ */
 /* IVF                                                                 */
 /* ------------------------------------------------------------------ */

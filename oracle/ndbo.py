@@ -106,6 +106,7 @@ def lib(native: bool = False):
         "ndbo_hnsw_insert": (C.c_uint32, [C.POINTER(NdboHnsw), f32p, NdboTid, i]),
         "ndbo_hnsw_level_from_uniform": (i, [C.c_double, f]),
         "ndbo_selection_topk": (i, [f32p, C.c_int64, i, i64p]),
+        "ndbo_extract_vector": (i, [i, u8p, f32p, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -96,3 +96,37 @@ def test_assign_device_matches_insert_rule():
     _lib.check(_lib.lib().ndbhip_ivf_assign_device(dc.data_ptr(), 130, 64, dr.data_ptr(), 700, out.data_ptr()))
     _lib.check(_lib.lib().ndbhip_synchronize())
     assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_append_keeps_lists_in_insertion_order_and_matches_oracle():
+    """aminsert path: 70 % of the rows loaded, 30 % appended one by one to the list ivfinsert
+    would choose; the result must equal the oracle image holding all rows."""
+    from neurondb_amd import IvfIndex
+    from tests.util import assert_same_results, oracle_search_batch
+    rng = np.random.default_rng(5)
+    n, dim, nlists = 2000, 32, 9
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    cent = base[rng.choice(n, nlists, replace=False)].copy()
+    asg = ndbo.ivf_assign_all(cent, base)
+    n0 = 1400
+    tids = ndbo.tids_from_rows(np.arange(n))
+    order0 = np.argsort(asg[:n0], kind="stable")
+    ll0 = np.bincount(asg[:n0], minlength=nlists).astype(np.int64)
+    ix = IvfIndex(dim, nlists)
+    ix.set_centroids(cent)
+    ix.load(ll0, base[:n0][order0], tids[:n0][order0])
+    for r in range(n0, n):
+        ix.append(asg[r], base[r], tids[r])
+    assert ix.nrows == n
+    order = np.argsort(asg, kind="stable")
+    off = np.zeros(nlists + 1, np.int64)
+    off[1:] = np.cumsum(np.bincount(asg, minlength=nlists))
+    img = ndbo.IvfImage(cent, off, base[order], tids[order])
+    q = rng.standard_normal((10, dim)).astype(np.float32)
+    t, d, c = ix.search(q, 1, 4, 10)
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, 4, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+    _, ll, rows, tt = ix.export()
+    assert np.array_equal(ll, np.diff(off))
+    assert np.array_equal(rows.view(np.uint32), img.vecs.view(np.uint32))
+    assert np.array_equal(ndbo.tids_to_u64(tt), ndbo.tids_to_u64(img.tids))
