@@ -131,6 +131,33 @@ int			ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uin
 int			ndbhip_ivf_export(const ndbhip_ivf *ix, float *centroids, int64_t *list_len, float *rows,
 							  uint8_t *tids6);
 int			ndbhip_ivf_ncentroids(const ndbhip_ivf *ix);
+int			ndbhip_ivf_shape(const ndbhip_ivf *ix, int *dim, int *nlists);
+
+/* ------------------------------------------------------------------ */
+/* Index pages <-> mirror.  PostgreSQL-free codec of the ivf
+ * relation's 8 KB pages, layouts as in src/index/ivf_am.c:62-106, 241-256,
+ * 640-711, 954-1157 (meta page, centroid items, list page chains).  `pages` is
+ * the relation image, block b at pages + b*8192.  The reader follows exactly the
+ * walk of ivfSelectClusters / ivfCollectCandidates: centroid items in offset
+ * order, each list's chain via IvfListPageHeader.nextBlock, dead line pointers
+ * and entries with a foreign dim skipped.  Format version 2 chains several
+ * centroid pages (the reference fits only 2 centroids at dim 768 on its single
+ * page: quirk Q6); single-page indexes are written as version 1.  Host code.  */
+/* ------------------------------------------------------------------ */
+int			ndbhip_ivf_pages_info(const uint8_t *pages, uint32_t nblocks, int *dim, int *nlists,
+								  int *ncentroids, int64_t *live_rows, int *version);
+int			ndbhip_ivf_pages_unpack(const uint8_t *pages, uint32_t nblocks, float *centroids,
+									int64_t *list_len, float *rows, uint8_t *tids6);
+/* pages -> new device mirror (the packer behind ambeginscan's mirror cache) */
+int			ndbhip_ivf_load_pages(ndbhip_ivf **out, const uint8_t *pages, uint32_t nblocks);
+int64_t		ndbhip_ivf_pages_needed(int dim, int ncentroids, const int64_t *list_len);
+int			ndbhip_ivf_pages_pack(int dim, int nlists, int nprobe, int ncentroids, const float *centroids,
+								  const int64_t *list_len, const float *rows, const uint8_t *tids6,
+								  uint8_t *pages, uint32_t nblocks_cap, uint32_t *nblocks_out);
+/* device mirror -> pages (ambuild after ndbhip_ivf_build_device) */
+int			ndbhip_ivf_write_pages(const ndbhip_ivf *ix, int nprobe, uint8_t *pages, uint32_t nblocks_cap,
+								   uint32_t *nblocks_out);
+
 /* Multi-GPU: a new mirror holding only the lists with owned[L] != 0 (one process
  * per GPU keeps its share); list lengths stay global, so candidate positions —
  * and therefore the merged result — are identical to the unsharded index. */

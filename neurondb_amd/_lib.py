@@ -83,6 +83,14 @@ def lib():
         "ndbhip_ivf_export": (i, [vp, vp, vp, vp, vp]),
         "ndbhip_ivf_ncentroids": (i, [vp]),
         "ndbhip_ivf_shard": (i, [vp, vp, C.POINTER(vp)]),
+        "ndbhip_ivf_shape": (i, [vp, C.POINTER(i), C.POINTER(i)]),
+        "ndbhip_ivf_pages_info": (i, [vp, C.c_uint32, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i64),
+                                      C.POINTER(i)]),
+        "ndbhip_ivf_pages_unpack": (i, [vp, C.c_uint32, vp, vp, vp, vp]),
+        "ndbhip_ivf_load_pages": (i, [C.POINTER(vp), vp, C.c_uint32]),
+        "ndbhip_ivf_pages_needed": (i64, [i, i, vp]),
+        "ndbhip_ivf_pages_pack": (i, [i, i, i, i, vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "ndbhip_ivf_write_pages": (i, [vp, i, vp, C.c_uint32, C.POINTER(C.c_uint32)]),
         "ndbhip_ivf_nrows": (i64, [vp]),
         "ndbhip_ivf_max_candidates": (i64, [vp, i]),
         "ndbhip_ivf_search": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),

@@ -3099,6 +3099,23 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 }
 
 extern "C" int
+ndbhip_ivf_shape(const ndbhip_ivf *ix, int *dim, int *nlists)
+{
+	if (!ix)
+		return fail(NDBHIP_ERR_INVALID, "index is NULL");
+	if (dim) *dim = ix->dim;
+	if (nlists) *nlists = ix->nlists;
+	return NDBHIP_OK;
+}
+
+/* error text for the PostgreSQL-free page codec (ndbhip_pages.cpp) */
+int
+ndbhip_pages_fail(int code, const char *msg)
+{
+	return fail(code, "%s", msg);
+}
+
+extern "C" int
 ndbhip_ivf_ncentroids(const ndbhip_ivf *ix)
 {
 	return ix ? ix->ncent : -1;

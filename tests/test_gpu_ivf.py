@@ -283,3 +283,54 @@ def test_grouped_scan_sharded(scan_mode):
         assert np.array_equal(b.out_count.cpu().numpy(), ec)
         assert np.array_equal(ndbo.tids_from_device_u64(b.out_tids.cpu().numpy()), et)
         assert np.array_equal(b.out_dist.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+
+
+def test_mirror_from_reference_format_pages_and_back():
+    """pages (reference on-disk format, with dead entries) -> device mirror -> search == oracle on the
+    live rows; mirror -> pages -> unpack round trip."""
+    import ctypes as C
+    from neurondb_amd import IvfIndex, _lib
+    from oracle import ndbo
+    from tests import pgpages
+    rng = np.random.default_rng(42)
+    dim, nl = 28, 9
+    cents = rng.standard_normal((nl, dim)).astype(np.float32)
+    sizes = [50, 0, 120, 33, 7, 260, 1, 90, 14]
+    lists, r = [], 0
+    for L in range(nl):
+        ent = []
+        for _ in range(sizes[L]):
+            t = ndbo.tids_from_rows(np.array([r]))[0]
+            ent.append((rng.standard_normal(dim).astype(np.float32), t.tobytes()))
+            r += 1
+        lists.append(ent)
+    dead = {(5, 0), (5, 100), (2, 119), (0, 10)}
+    img = pgpages.write_reference_format(cents, lists, dead=dead)
+    a = np.frombuffer(img, np.uint8).copy()
+    h = C.c_void_p()
+    _lib.ensure_init()
+    _lib.check(_lib.lib().ndbhip_ivf_load_pages(C.byref(h), a.ctypes.data, len(a) // 8192))
+    ix = IvfIndex.__new__(IvfIndex)
+    ix.dim, ix.nlists, ix._h, ix._keep, ix.ncent = dim, nl, h, [], nl
+    # oracle image of the live rows
+    rows, tids, ll = [], [], []
+    for L in range(nl):
+        keep = [(v, t) for i, (v, t) in enumerate(lists[L]) if (L, i) not in dead]
+        ll.append(len(keep))
+        rows += [v for v, _ in keep]
+        tids += [np.frombuffer(t, ndbo.TID_DTYPE)[0] for _, t in keep]
+    off = np.zeros(nl + 1, np.int64)
+    off[1:] = np.cumsum(ll)
+    oimg = ndbo.IvfImage(cents, off, np.array(rows, np.float32), np.array(tids, ndbo.TID_DTYPE))
+    q = rng.standard_normal((12, dim)).astype(np.float32)
+    t, d, c = ix.search(q, 1, 4, 10)
+    et, ed, ec, _ = oracle_search_batch(oimg, q, 1, 4, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+    # back to pages
+    need = _lib.lib().ndbhip_ivf_pages_needed(dim, nl, np.array(ll, np.int64).ctypes.data)
+    out = np.zeros(need * 8192, np.uint8)
+    nb = C.c_uint32()
+    _lib.check(_lib.lib().ndbhip_ivf_write_pages(ix._h, 10, out.ctypes.data, need, C.byref(nb)))
+    d2, c2, ll2, rows2, t62, ver = pgpages.read_image(out[: nb.value * 8192].tobytes())
+    assert ver == 1 and list(ll2) == ll
+    assert np.array_equal(rows2.view(np.uint32), np.array(rows, np.float32).view(np.uint32))
