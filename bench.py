@@ -50,6 +50,8 @@ def parse():
                     help="clustered: mixture of --components Gaussians (sigma --sigma); gauss: i.i.d. N(0,1)")
     ap.add_argument("--components", type=int, default=1024)
     ap.add_argument("--sigma", type=float, default=0.1)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the sharded path (process group, partial search, all-gather, merge) even at N=1")
     return ap.parse_args()
 
 
@@ -96,8 +98,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from neurondb_amd import IvfIndex, _lib
@@ -131,7 +137,7 @@ def main():
     # ---------------- shard lists over ranks ----------------
     owner = partition_lists(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
     owned = (owner == rank).astype(np.uint8)
-    if world > 1:
+    if use_dist:
         ix = ix_full.shard(owned)
         ix_full.close()
         ix_full = None
@@ -144,13 +150,13 @@ def main():
     out_t, out_d, out_c = buf.out_tids, buf.out_dist, buf.out_count
 
     def step(qs):
-        if world == 1:
+        if not use_dist:
             ix.search_device(qs, out_t, out_d, out_c, 1, nprobe, k, 0)
         else:
             sharded_search(ix, qs, buf, 1, nprobe, k, 0)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +173,7 @@ def main():
     elapsed = time.perf_counter() - t0
     check(lib().ndbhip_profile(0))
     st = _lib.stats()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -244,7 +250,7 @@ def main():
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -53,7 +53,7 @@ class ShardedSearchBuffers:
 def gather_and_merge(buf: ShardedSearchBuffers, group=None):
     """all-gather the ranks' records, then merge.  Device tensors: RCCL + the HIP merge kernel
     (asynchronous on the current stream).  CPU tensors: gloo + ndbhip_merge_topk_host."""
-    if buf.world > 1:
+    if buf.world > 1 or (dist.is_available() and dist.is_initialized()):
         # output = ranks concatenated along dim 0 (the layout both RCCL and gloo accept)
         dist.all_gather_into_tensor(buf.cand_all.view(buf.world * buf.nq, buf.cap, CAND_WORDS), buf.cand, group=group)
         dist.all_gather_into_tensor(buf.ncand_all.view(buf.world * buf.nq), buf.ncand, group=group)
