@@ -91,6 +91,11 @@ def make_data(n, dim, kind, components, sigma, seed, center_seed, dev):
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: RCCL / HIP runtime banners written by C libraries to fd 1
+    # (some are flushed at exit, after Python's own output) are sent to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -249,7 +254,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
