@@ -55,6 +55,9 @@ fail(int code, const char *fmt, ...)
 /* list-scan kernel choice: 0 auto (grouped for batches >= 64 queries and dim % 64 == 0),
  * 1 always per-query (k_ivf_scan), 2 always grouped (k_ivf_scan_grouped) */
 static int	g_scan_mode = 0;
+/* rows staged per step by the grouped kernels: 64 floats (16 KiB tile, 3 waves/SIMD) or 32 (8 KiB, 4 waves/SIMD);
+ * NDBHIP_GCHUNK overrides for experiments */
+static int	g_gchunk = 32;
 
 struct Ctx
 {
@@ -140,6 +143,14 @@ ndbhip_init(int device)
 	HIP_TRY(hipMemset(g.d_counters, 0, 4 * sizeof(unsigned long long)));
 	g.device = device;
 	g.inited = true;
+	{
+		const char *e = getenv("NDBHIP_GCHUNK");
+
+		if (e && atoi(e) == 32)
+			g_gchunk = 32;
+		else if (e && atoi(e) == 64)
+			g_gchunk = 64;
+	}
 	return set_kernel_attributes();
 }
 
@@ -840,6 +851,9 @@ k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
  * Requires dim % 64 == 0 (otherwise the per-query kernel is used).          */
 /* ------------------------------------------------------------------ */
 #define NDB_QG 16
+#ifndef NDB_G32_WAVES
+#define NDB_G32_WAVES 5
+#endif
 #ifndef NDB_GROUPED_WAVES_PER_SIMD
 #define NDB_GROUPED_WAVES_PER_SIMD 3		/* caps the kernel at 168 VGPRs; LDS (16 KiB/wave) allows 10 waves/CU */
 #endif
@@ -1122,18 +1136,16 @@ template <> struct GAcc<R_IVF_IP>
  * Persistent kernel: every wave pulls work items (list, 64-row tile, query group)
  * from a global counter.  block = 256 (4 independent waves, 16 KiB LDS tile each).
  */
-template <int R>
-__global__ __launch_bounds__(64, NDB_GROUPED_WAVES_PER_SIMD) void
+template <int R, int CH>
+__global__ __launch_bounds__(64, (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD)) void
 k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ cand_off,
 				   int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 				   float *__restrict__ dist, uint32_t stride)
 {
-	__shared__ __attribute__((aligned(16))) float tile[NDB_TILE_FLOATS];
+	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x & 63;
-	const int	grp = lane >> 4;
-	const int	slot = lane & 15;
 	const int	dim = ix.dim;
 	const uint32_t nitems = item_off[ix.ncent];
 
@@ -1172,13 +1184,11 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 		const float *__restrict__ qb = qblock + (size_t) (grp_off[L] + gi) * (size_t) dim * NDB_QG;
 		const uint32_t ridx = t * 64 + lane;
 		const uint32_t row = (uint32_t) ix.loc_off[L] + (ridx < len ? ridx : len - 1);
-		uint32_t	rows16[16];
+		uint32_t	rowsN[CH / 4];
 		GAcc<R>		acc;
 
 		acc.init();
-#pragma unroll
-		for (int i = 0; i < 16; i++)
-			rows16[i] = __shfl(row, 4 * i + grp, 64);
+		rows_for_loads<CH>(rowsN, row, lane);
 
 		/* query stream of this group: [dim][16] floats, consumed 2 dimensions (128 B) per batch,
 		 * double buffered in SGPRs: A = even batch, B = odd batch */
@@ -1187,13 +1197,13 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 
 		asm volatile("s_nop 4" ::: "memory");	/* the base pointer may come from v_readfirstlane */
 		sload2x16(qa0, qa1, qs);
-		for (int c = 0; c < dim; c += NDB_CHUNK)
+		for (int c = 0; c < dim; c += CH)
 		{
-			float4		x[16];
+			float4		x[CH / 4];
 
-			stage_chunk<true>(x, ix.vecs, rows16, dim, c, tile, lane, grp, slot);
+			stage_chunk_w<CH>(x, ix.vecs, rowsN, dim, c, tile, lane);
 #pragma unroll
-			for (int p = 0; p < 16; p++)
+			for (int p = 0; p < CH / 4; p++)
 			{
 				/* dims 4p, 4p+1 from A; 4p+2, 4p+3 from B */
 				swait2(qa0, qa1);
@@ -1203,7 +1213,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				swait2(qb0, qb1);
 				qs += 4 * NDB_QG;
 				/* the last batch of the last chunk re-reads the final 128 B of this group's block */
-				sload2x16(qa0, qa1, (c + NDB_CHUNK >= dim && p == 15) ? qs - 2 * NDB_QG : qs);
+				sload2x16(qa0, qa1, (c + CH >= dim && p == CH / 4 - 1) ? qs - 2 * NDB_QG : qs);
 				acc.step(qb0, x[p].z);
 				acc.step(qb1, x[p].w);
 			}
@@ -2005,18 +2015,28 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
-		if (R == R_IVF_IP)
-			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_IP>, pgrid, dim3(64), 0, g.stream, d,
-							   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,
-							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
-							   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,
-							   stride);
+#define LAUNCH_GROUPED(RR, CC, GRID)                                                                       \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_scan_grouped<RR, CC>), GRID, dim3(64), 0, g.stream, d,        \
+						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,                \
+						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
+						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,   \
+						   stride)
+		if (g_gchunk == 32)
+		{
+			const dim3	g32(g.num_cus * 4 * NDB_G32_WAVES);	/* 8 KiB LDS per wave, VGPRs capped for NDB_G32_WAVES per SIMD */
+
+			if (R == R_IVF_IP)
+				LAUNCH_GROUPED(R_IVF_IP, 32, g32);
+			else
+				LAUNCH_GROUPED(R_IVF_L2, 32, g32);
+		}
 		else
-			hipLaunchKernelGGL(k_ivf_scan_grouped<R_IVF_L2>, pgrid, dim3(64), 0, g.stream, d,
-							   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,
-							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
-							   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,
-							   stride);
+		{
+			if (R == R_IVF_IP)
+				LAUNCH_GROUPED(R_IVF_IP, 64, pgrid);
+			else
+				LAUNCH_GROUPED(R_IVF_L2, 64, pgrid);
+		}
 		if (t.stop()) return NDBHIP_ERR_HIP;
 	}
 	else

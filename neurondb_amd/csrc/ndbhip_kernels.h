@@ -191,6 +191,65 @@ stage_chunk(float4 (&x)[16], const float *__restrict__ base, const uint32_t (&ro
 	wave_lds_sync();
 }
 
+/*
+ * Generic-width staging (CH = 64 or 32 floats of every row per step).  CH = 32 halves the LDS tile
+ * (8 KiB per wave) and the row registers, so more waves fit per SIMD — the grouped kernels, which are
+ * bound by the vector ALU and by scalar-load waits rather than by HBM, use it.
+ *   lanes per row PP = CH/4, rows per load instruction 64/PP, load instructions per chunk PP.
+ *   tile is linear in (row, slot); piece p of row r sits in slot p ^ swz(r):
+ *     CH = 64: swz = r & 15          (row stride 256 B = one bank row)
+ *     CH = 32: swz = (r >> 1) & 7    (two rows per 256-B bank row: the row parity picks the half)
+ *   Either way the 16 lanes of every ds_read_b128 lane group land on 16 distinct 16-B slots of the
+ *   bank row, and every ds_write_b128 8-lane group writes 128 contiguous bytes: conflict-free.
+ */
+template <int CH>
+__device__ __forceinline__ int
+tile_swz(int r)
+{
+	return CH == 64 ? (r & 15) : ((r >> 1) & 7);
+}
+
+template <int CH>
+__device__ __forceinline__ void
+stage_chunk_w(float4 (&x)[CH / 4], const float *__restrict__ base, const uint32_t (&rowsN)[CH / 4],
+			  int dim, int c, float *tile, int lane)
+{
+	constexpr int PP = CH / 4;			/* pieces (= lanes) per row chunk, load instructions per chunk */
+	constexpr int RPI = 64 / PP;		/* rows per load instruction */
+	const int	grp = lane / PP;
+	const int	slot = lane % PP;
+
+#pragma unroll
+	for (int i = 0; i < PP; i++)
+	{
+		const int	r = RPI * i + grp;
+		const int	piece = slot ^ tile_swz<CH>(r);
+
+		x[i] = *reinterpret_cast<const float4 *>(base + (size_t) rowsN[i] * (size_t) dim + c + piece * 4);
+	}
+#pragma unroll
+	for (int i = 0; i < PP; i++)
+		*reinterpret_cast<float4 *>(tile + (RPI * i + grp) * CH + slot * 4) = x[i];
+	wave_lds_sync();
+#pragma unroll
+	for (int p = 0; p < PP; p++)
+		x[p] = *reinterpret_cast<const float4 *>(tile + lane * CH + ((p ^ tile_swz<CH>(lane)) * 4));
+	wave_lds_sync();
+}
+
+/* rowsN[i] = row handled by this lane's i-th load instruction */
+template <int CH>
+__device__ __forceinline__ void
+rows_for_loads(uint32_t (&rowsN)[CH / 4], uint32_t row, int lane)
+{
+	constexpr int PP = CH / 4;
+	constexpr int RPI = 64 / PP;
+
+#pragma unroll
+	for (int i = 0; i < PP; i++)
+		rowsN[i] = __shfl(row, RPI * i + lane / PP, 64);
+}
+
 /* Split form of stage_chunk for software pipelining: issue the 16 global loads of a chunk early
  * (load_chunk), and pass them through the LDS tile later (commit_chunk). */
 __device__ __forceinline__ void
