@@ -2587,36 +2587,32 @@ k_interleave16(const float *__restrict__ cents, int ncent, int dim, float *__res
  * Every (row, centroid) sum is still the sequential fp32 chain of vector_distance_l2 / ivfinsert
  * ((x-c)^2 == (c-x)^2 exactly).  grid = (row tiles, centroid groups of 16), block = 64.
  */
-template <bool SQRT>
-__global__ __launch_bounds__(64, NDB_GROUPED_WAVES_PER_SIMD) void
+template <bool SQRT, int CH>
+__global__ __launch_bounds__(64, (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD)) void
 k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const float *__restrict__ cblock,
 				 int ncent, float *__restrict__ part_dist, int *__restrict__ part_idx)
 {
-	__shared__ __attribute__((aligned(16))) float tile[NDB_TILE_FLOATS];
+	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x;
-	const int	grp = lane >> 4;
-	const int	slot = lane & 15;
 	const uint32_t r = blockIdx.x * 64 + lane;
 	const uint32_t row = (r < nrows) ? r : (nrows - 1);
 	const int	c0 = blockIdx.y * NDB_QG;
 	const int	gc = (ncent - c0 < NDB_QG) ? (ncent - c0) : NDB_QG;
-	uint32_t	rows16[16];
+	uint32_t	rowsN[CH / 4];
 	GAcc<R_IVF_L2> acc;
 	const float *qs = cblock + (size_t) blockIdx.y * (size_t) dim * NDB_QG;
 	ndb_f16		qa0, qa1, qb0, qb1;
 
 	acc.init();
-#pragma unroll
-	for (int i = 0; i < 16; i++)
-		rows16[i] = __shfl(row, 4 * i + grp, 64);
+	rows_for_loads<CH>(rowsN, row, lane);
 	sload2x16(qa0, qa1, qs);
-	for (int c = 0; c < dim; c += NDB_CHUNK)
+	for (int c = 0; c < dim; c += CH)
 	{
-		float4		x[16];
+		float4		x[CH / 4];
 
-		stage_chunk<true>(x, rows, rows16, dim, c, tile, lane, grp, slot);
+		stage_chunk_w<CH>(x, rows, rowsN, dim, c, tile, lane);
 #pragma unroll
-		for (int p = 0; p < 16; p++)
+		for (int p = 0; p < CH / 4; p++)
 		{
 			swait2(qa0, qa1);
 			sload2x16(qb0, qb1, qs + 2 * NDB_QG);
@@ -2624,7 +2620,7 @@ k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const 
 			acc.step(qa1, x[p].y);
 			swait2(qb0, qb1);
 			qs += 4 * NDB_QG;
-			sload2x16(qa0, qa1, (c + NDB_CHUNK >= dim && p == 15) ? qs - 2 * NDB_QG : qs);
+			sload2x16(qa0, qa1, (c + CH >= dim && p == CH / 4 - 1) ? qs - 2 * NDB_QG : qs);
 			acc.step(qb0, x[p].z);
 			acc.step(qb1, x[p].w);
 		}
@@ -2783,10 +2779,10 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 		if (fast)
 		{
 			if (use_sqrt)
-				hipLaunchKernelGGL(k_assign_grouped<true>, grid, dim3(64), 0, g.stream, rows, n, dim,
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), grid, dim3(64), 0, g.stream, rows, n, dim,
 								   (const float *) cblock, ncent, pd, pi);
 			else
-				hipLaunchKernelGGL(k_assign_grouped<false>, grid, dim3(64), 0, g.stream, rows, n, dim,
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<false, 32>), grid, dim3(64), 0, g.stream, rows, n, dim,
 								   (const float *) cblock, ncent, pd, pi);
 		}
 		else if ((dim & 3) == 0)
