@@ -84,6 +84,7 @@ need_init()
 }
 
 static int	set_kernel_attributes();
+static int	set_kernel_attributes_build();
 
 extern "C" int
 ndbhip_abi_version(void)
@@ -1515,6 +1516,7 @@ set_kernel_attributes()
 								NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_merge_topk, hipFuncAttributeMaxDynamicSharedMemorySize,
 								NDB_TOPK_MAX_SMEM));
+	return set_kernel_attributes_build();
 	return NDBHIP_OK;
 }
 
@@ -2678,21 +2680,52 @@ k_assign_combine(const float *__restrict__ part_dist, const int *__restrict__ pa
 		atomicAdd(&counts[bidx], 1);
 }
 
-/* kmeans_update_centroids (:2182-2213): block = centroid, thread = coordinate;
- * members are summed in sample order, then divided by (float) count. */
-__global__ void
+/* kmeans_update_centroids (:2182-2213): block = centroid.  The members are first compacted IN SAMPLE
+ * ORDER into LDS (ballot + popcount prefix), then thread = coordinate adds them in that order and
+ * divides by (float) count — the reference's summation order, without scanning all n samples per
+ * coordinate.  Dynamic LDS: n uint32. */
+__global__ __launch_bounds__(256) void
 k_kmeans_update(const float *__restrict__ data, int n, int dim, const int *__restrict__ assign,
 				const int *__restrict__ counts, float *__restrict__ cents)
 {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	uint32_t   *members = (uint32_t *) smem_raw;
+	uint32_t   *sh = members + n;		/* 8 words */
 	const int	c = blockIdx.x;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	uint32_t	base = 0;
 
-	for (int j = threadIdx.x; j < dim; j += blockDim.x)
+	for (int start = 0; start < n; start += 256)
+	{
+		const int	i = start + (int) tid;
+		const bool	mine = i < n && assign[i] == c;
+		const unsigned long long m = __ballot(mine);
+		const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+		if (lane == 0)
+			sh[wave] = __popcll(m);
+		__syncthreads();
+		uint32_t	woff = 0, tot = 0;
+
+		for (uint32_t w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				woff += sh[w];
+			tot += sh[w];
+		}
+		if (mine)
+			members[base + woff + __popcll(m & below)] = (uint32_t) i;
+		base += tot;
+		__syncthreads();
+	}
+	const uint32_t cnt = base;		/* == counts[c] */
+
+	for (int j = tid; j < dim; j += 256)
 	{
 		float		s = 0.0f;
 
-		for (int i = 0; i < n; i++)
-			if (assign[i] == c)
-				s = s + data[(size_t) i * dim + j];
+		for (uint32_t k2 = 0; k2 < cnt; k2++)
+			s = s + data[(size_t) members[k2] * dim + j];
 		if (counts[c] > 0)
 			s = s / (float) counts[c];
 		cents[(size_t) c * dim + j] = s;
@@ -2721,16 +2754,23 @@ k_kmeans_point_cost(const float *__restrict__ data, int n, int dim, const int *_
 	pc[i] = s;
 }
 
-/* cost += d_i strictly in sample order, in fp32 (:2221-2232) */
-__global__ void
+/* cost += d_i strictly in sample order, in fp32 (:2221-2232): the block stages the terms in LDS,
+ * one lane then adds them in order (the sum is order-dependent and decides the stopping iteration) */
+__global__ __launch_bounds__(256) void
 k_seq_sum(const float *__restrict__ pc, int n, float *__restrict__ out)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0)
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	float	   *v = (float *) smem_raw;
+
+	for (int i = threadIdx.x; i < n; i += 256)
+		v[i] = pc[i];
+	__syncthreads();
+	if (threadIdx.x == 0)
 	{
 		float		s = 0.0f;
 
 		for (int i = 0; i < n; i++)
-			s = s + pc[i];
+			s = s + v[i];
 		*out = s;
 	}
 }
@@ -2749,24 +2789,69 @@ k_kmeans_init(const float *__restrict__ data, int n, int dim, int k, float *__re
 }
 
 static int
-assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int ncent, bool use_sqrt,
-			int *d_out_list, int *d_counts)
+set_kernel_attributes_build()
 {
+	HIP_TRY(hipFuncSetAttribute((const void *) k_kmeans_update, hipFuncAttributeMaxDynamicSharedMemorySize,
+								NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_seq_sum, hipFuncAttributeMaxDynamicSharedMemorySize,
+								NDB_TOPK_MAX_SMEM));
+	return NDBHIP_OK;
+}
+
+/* scratch of assign_rows, reusable across calls (the k-means loop calls it once per iteration) */
+struct AssignWs
+{
+	float	   *pd = nullptr;
+	int		   *pi = nullptr;
+	float	   *cblock = nullptr;
+	size_t		pn = 0, cn = 0;
+	int release()
+	{
+		if (pd) HIP_TRY(hipFree(pd));
+		if (pi) HIP_TRY(hipFree(pi));
+		if (cblock) HIP_TRY(hipFree(cblock));
+		pd = nullptr; pi = nullptr; cblock = nullptr; pn = cn = 0;
+		return 0;
+	}
+};
+
+static int
+assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int ncent, bool use_sqrt,
+			int *d_out_list, int *d_counts, AssignWs *ws = nullptr)
+{
+	AssignWs	local;
+
+	if (!ws)
+		ws = &local;
 	const bool	fast = (dim % NDB_CHUNK) == 0;
 	const int	gsize = fast ? NDB_QG : NDB_CGROUP;
 	const int	ngroups = (ncent + gsize - 1) / gsize;
 	const int64_t chunk = 1 << 18;
-	float	   *pd = nullptr, *cblock = nullptr;
-	int		   *pi = nullptr;
 	const int64_t cmax = std::min<int64_t>(chunk, nrows);
 
 	if (nrows <= 0)
 		return 0;
-	HIP_TRY(hipMalloc((void **) &pd, (size_t) ngroups * cmax * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &pi, (size_t) ngroups * cmax * sizeof(int)));
+	if (ws->pn < (size_t) ngroups * cmax)
+	{
+		if (ws->pd) HIP_TRY(hipFree(ws->pd));
+		if (ws->pi) HIP_TRY(hipFree(ws->pi));
+		ws->pd = nullptr; ws->pi = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->pd, (size_t) ngroups * cmax * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &ws->pi, (size_t) ngroups * cmax * sizeof(int)));
+		ws->pn = (size_t) ngroups * cmax;
+	}
+	if (fast && ws->cn < (size_t) ngroups * dim * NDB_QG)
+	{
+		if (ws->cblock) HIP_TRY(hipFree(ws->cblock));
+		ws->cblock = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->cblock, (size_t) ngroups * dim * NDB_QG * sizeof(float)));
+		ws->cn = (size_t) ngroups * dim * NDB_QG;
+	}
+	float	   *pd = ws->pd, *cblock = ws->cblock;
+	int		   *pi = ws->pi;
+
 	if (fast)
 	{
-		HIP_TRY(hipMalloc((void **) &cblock, (size_t) ngroups * dim * NDB_QG * sizeof(float)));
 		hipLaunchKernelGGL(k_interleave16, dim3((dim + 255) / 256, ngroups), dim3(256), 0, g.stream, d_cents,
 						   ncent, dim, cblock);
 	}
@@ -2807,11 +2892,11 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 						   (const int *) pi, ngroups, n, d_out_list + r0, d_counts);
 	}
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(g.stream));
-	HIP_TRY(hipFree(pd));
-	HIP_TRY(hipFree(pi));
-	if (cblock)
-		HIP_TRY(hipFree(cblock));
+	if (ws == &local)
+	{
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		return local.release();
+	}
 	return 0;
 }
 
@@ -2834,9 +2919,12 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!d_samples || !d_centroids || !d_assign || !d_counts || n < 1 || dim < 1 || k < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if ((size_t) n * 4 + 64 > NDB_TOPK_MAX_SMEM)	/* the reference samples at most 10000 rows (ivf_am.c:580) */
+		return fail(NDBHIP_ERR_UNSUPPORTED, "k-means sample of %d rows exceeds the LDS-resident limit", n);
 	float	   *d_pc = nullptr, *d_cost = nullptr;
 	float		prevCost = FLT_MAX, cost = 0.0f;
 	int			iters = 0;
+	AssignWs	ws;
 
 	HIP_TRY(hipMalloc((void **) &d_pc, (size_t) n * sizeof(float)));
 	HIP_TRY(hipMalloc((void **) &d_cost, sizeof(float)));
@@ -2847,14 +2935,14 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 		int			rc;
 
 		HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t) k * sizeof(int), g.stream));
-		rc = assign_rows(d_samples, n, dim, d_centroids, k, false, d_assign, d_counts);
+		rc = assign_rows(d_samples, n, dim, d_centroids, k, false, d_assign, d_counts, &ws);
 		if (rc)
 			return rc;
-		hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), 0, g.stream, d_samples, n, dim,
+		hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), (size_t) n * 4 + 64, g.stream, d_samples, n, dim,
 						   (const int *) d_assign, (const int *) d_counts, d_centroids);
 		hipLaunchKernelGGL(k_kmeans_point_cost, dim3((n + 255) / 256), dim3(256), 0, g.stream, d_samples, n, dim,
 						   (const int *) d_assign, (const float *) d_centroids, d_pc);
-		hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(64), 0, g.stream, (const float *) d_pc, n, d_cost);
+		hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(256), (size_t) n * 4, g.stream, (const float *) d_pc, n, d_cost);
 		HIP_TRY(hipMemcpyAsync(&cost, d_cost, sizeof(float), hipMemcpyDeviceToHost, g.stream));
 		HIP_TRY(hipStreamSynchronize(g.stream));
 		iters = iter + 1;
@@ -2865,6 +2953,8 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 	}
 	HIP_TRY(hipFree(d_pc));
 	HIP_TRY(hipFree(d_cost));
+	if (ws.release())
+		return NDBHIP_ERR_HIP;
 	if (out_iters)
 		*out_iters = iters;
 	if (out_cost)
@@ -2885,6 +2975,51 @@ k_pack_hist(const int *__restrict__ lists, int64_t nrows, int nlists, uint32_t n
 
 	if (r < nrows)
 		atomicAdd(&hist[(size_t) lists[r] * nblocks + blockIdx.x], 1u);
+}
+
+/* exclusive scan of hist[list][block] in (list-major, block) order, on the device:
+ * pass A: one thread per list adds up its blocks -> list_len; pass B (single thread): list bases;
+ * pass C: one thread per list walks its blocks again writing the running offsets */
+__global__ void
+k_pack_list_totals(const uint32_t *__restrict__ hist, int nlists, uint32_t nblocks, int64_t *__restrict__ list_len)
+{
+	const int	L = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (L >= nlists)
+		return;
+	int64_t		t = 0;
+
+	for (uint32_t b = 0; b < nblocks; b++)
+		t += hist[(size_t) L * nblocks + b];
+	list_len[L] = t;
+}
+
+__global__ void
+k_pack_offsets(const uint32_t *__restrict__ hist, int nlists, uint32_t nblocks,
+			   const int64_t *__restrict__ list_len, int64_t *__restrict__ scanned)
+{
+	__shared__ int64_t base_sh;
+	const int	L = blockIdx.x;
+
+	if (threadIdx.x == 0)
+	{
+		int64_t		b0 = 0;
+
+		for (int l2 = 0; l2 < L; l2++)
+			b0 += list_len[l2];
+		base_sh = b0;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		int64_t		acc = base_sh;
+
+		for (uint32_t b = 0; b < nblocks; b++)
+		{
+			scanned[(size_t) L * nblocks + b] = acc;
+			acc += hist[(size_t) L * nblocks + b];
+		}
+	}
 }
 
 /* dest = scanned[list][block] + rank of the row among earlier same-list rows of its block; copies the row */
@@ -2981,23 +3116,15 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	HIP_TRY(hipMemsetAsync(d_hist, 0, nh * sizeof(uint32_t), g.stream));
 	hipLaunchKernelGGL(k_pack_hist, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list, nrows,
 					   k, nblocks, d_hist);
-	std::vector<uint32_t> h(nh);
-	std::vector<int64_t> sc(nh);
 	std::vector<int64_t> list_len((size_t) k, 0);
+	int64_t    *d_llen = nullptr;
 
-	HIP_TRY(hipMemcpyAsync(h.data(), d_hist, nh * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipStreamSynchronize(g.stream));
-	{
-		int64_t		acc = 0;
-
-		for (size_t i = 0; i < nh; i++)
-		{
-			sc[i] = acc;
-			acc += h[i];
-			list_len[i / nblocks] += h[i];
-		}
-	}
-	HIP_TRY(hipMemcpyAsync(d_scan, sc.data(), nh * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMalloc((void **) &d_llen, (size_t) k * sizeof(int64_t)));
+	hipLaunchKernelGGL(k_pack_list_totals, dim3((k + 63) / 64), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k,
+					   nblocks, d_llen);
+	hipLaunchKernelGGL(k_pack_offsets, dim3(k), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k, nblocks,
+					   (const int64_t *) d_llen, d_scan);
+	HIP_TRY(hipMemcpyAsync(list_len.data(), d_llen, (size_t) k * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
 
 	float	   *d_prow = nullptr;
 	uint64_t   *d_ptid = nullptr;
@@ -3011,6 +3138,7 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	HIP_TRY(hipFree(d_hist));
 	HIP_TRY(hipFree(d_scan));
 	HIP_TRY(hipFree(d_list));
+	HIP_TRY(hipFree(d_llen));
 
 	/* adopt: centroids + packed lists become the index */
 	if (ix->d_centroids)
