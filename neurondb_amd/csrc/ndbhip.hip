@@ -1098,7 +1098,7 @@ template <> struct GAcc<R_IVF_L2>
 			s[i] = s[i] + d * d;
 		}
 	}
-	__device__ __forceinline__ float fin(int j) const
+	__device__ __forceinline__ float fin(int j, float) const
 	{
 		return __builtin_sqrtf((j & 1) ? s[j >> 1].y : s[j >> 1].x);
 	}
@@ -1127,11 +1127,68 @@ template <> struct GAcc<R_IVF_IP>
 			s[i] = s[i] + qp * xx;
 		}
 	}
-	__device__ __forceinline__ float fin(int j) const
+	__device__ __forceinline__ float fin(int j, float) const
 	{
 		return -((j & 1) ? s[j >> 1].y : s[j >> 1].x);
 	}
 };
+
+/* cosine (ivf_am.c:1570-1581): dot per (row, query) as packed pairs, the row's own norm chain in the
+ * lane, the query's norm chain precomputed once per query (k_query_norms) — three independent
+ * sequential fp32 chains, exactly the reference's */
+template <> struct GAcc<R_IVF_COS>
+{
+	ndb_f2		s[NDB_QG / 2];
+	float		n2;
+	__device__ __forceinline__ void init()
+	{
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+			s[i] = (ndb_f2) (0.0f);
+		n2 = 0.0f;
+	}
+	__device__ __forceinline__ void step(const ndb_f16 &q, float x)
+	{
+		const ndb_f2 xx = (ndb_f2) (x);
+
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+		{
+			ndb_f2		qp;
+
+			qp.x = q[2 * i];
+			qp.y = q[2 * i + 1];
+			s[i] = s[i] + qp * xx;
+		}
+		n2 = n2 + x * x;
+	}
+	__device__ __forceinline__ float fin(int j, float n1) const
+	{
+		const float dot = (j & 1) ? s[j >> 1].y : s[j >> 1].x;
+		const float a = __builtin_sqrtf(n1);
+		const float b = __builtin_sqrtf(n2);
+
+		if (a == 0.0f || b == 0.0f)
+			return 1.0f;
+		return 1.0f - (dot / (a * b));
+	}
+};
+
+/* norm1 of every query: `norm1 += vec1[i] * vec1[i]` in dimension order (ivf_am.c:1574) */
+__global__ void
+k_query_norms(const float *__restrict__ queries, uint32_t nq, int dim, float *__restrict__ out)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (q >= nq)
+		return;
+	const float *v = queries + (size_t) q * dim;
+	float		n1 = 0.0f;
+
+	for (int i = 0; i < dim; i++)
+		n1 = n1 + v[i] * v[i];
+	out[q] = n1;
+}
 
 /*
  * Persistent kernel: every wave pulls work items (list, 64-row tile, query group)
@@ -1143,7 +1200,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				   int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
-				   float *__restrict__ dist, uint32_t stride)
+				   float *__restrict__ dist, uint32_t stride, const float *__restrict__ qnorm)
 {
 	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x & 63;
@@ -1231,7 +1288,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				const uint32_t a = co[pp], nrow = co[pp + 1] - a;	/* may be capped below len (ivf_am.c:1743) */
 
 				if (ridx < nrow)
-					dist[(size_t) qid * stride + a + ridx] = acc.fin(j);
+					dist[(size_t) qid * stride + a + ridx] = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
 			}
 		}
 	}
@@ -1560,6 +1617,7 @@ struct ndbhip_ivf
 	uint32_t   *w_goff = nullptr;	size_t w_goff_n = 0;	/* [2*(ncent+1)]: pair_off, item_off */
 	PairRec    *w_pairs = nullptr;	size_t w_pairs_n = 0;
 	float	   *w_qblock = nullptr;	size_t w_qblock_n = 0;	/* [groups][dim][16] interleaved queries */
+	float	   *w_qnorm = nullptr;	size_t w_qnorm_n = 0;	/* [nq] sum of squares of every query (cosine) */
 };
 
 template <class T>
@@ -1623,7 +1681,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		ivf_free_rows(ix);
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
-			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock};
+			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -1984,7 +2042,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 	/* HOT LOOP 2 */
 	const int	R = ivf_recipe(strategy);
-	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 && R != R_IVF_COS &&
+	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
 		(g_scan_mode == 2 || (g_scan_mode == 0 && nq >= 64));
 
 	if (grouped)
@@ -2015,6 +2073,9 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 							   ix->w_dist, stride);
 		const dim3	pgrid(g.num_cus * 10);	/* one wave per block; LDS admits 10 per CU */
 
+		if (R == R_IVF_COS)
+			hipLaunchKernelGGL(k_query_norms, dim3((nq + 63) / 64), dim3(64), 0, g.stream, d_q, (uint32_t) nq,
+							   ix->dim, ix->w_qnorm);
 		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
 #define LAUNCH_GROUPED(RR, CC, GRID)                                                                       \
@@ -2022,13 +2083,15 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,                \
 						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,   \
-						   stride)
+						   stride, (const float *) ix->w_qnorm)
 		if (g_gchunk == 32)
 		{
 			const dim3	g32(g.num_cus * 4 * NDB_G32_WAVES);	/* 8 KiB LDS per wave, VGPRs capped for NDB_G32_WAVES per SIMD */
 
 			if (R == R_IVF_IP)
 				LAUNCH_GROUPED(R_IVF_IP, 32, g32);
+			else if (R == R_IVF_COS)
+				LAUNCH_GROUPED(R_IVF_COS, 32, g32);
 			else
 				LAUNCH_GROUPED(R_IVF_L2, 32, g32);
 		}
@@ -2036,6 +2099,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		{
 			if (R == R_IVF_IP)
 				LAUNCH_GROUPED(R_IVF_IP, 64, pgrid);
+			else if (R == R_IVF_COS)
+				LAUNCH_GROUPED(R_IVF_COS, 64, pgrid);
 			else
 				LAUNCH_GROUPED(R_IVF_L2, 64, pgrid);
 		}
@@ -2120,6 +2185,7 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 4)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) qb)) return NDBHIP_ERR_HIP;
 	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= 64 || g_scan_mode == 2))
 		if (grow(ix->w_qblock, ix->w_qblock_n,
 				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))

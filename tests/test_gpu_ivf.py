@@ -334,3 +334,20 @@ def test_mirror_from_reference_format_pages_and_back():
     d2, c2, ll2, rows2, t62, ver = pgpages.read_image(out[: nb.value * 8192].tobytes())
     assert ver == 1 and list(ll2) == ll
     assert np.array_equal(rows2.view(np.uint32), np.array(rows, np.float32).view(np.uint32))
+
+
+def test_large_k_and_nprobe_limits():
+    """k and nprobe up to the GUC maxima (hnsw_k / ivf_probes: 1000) take the radix path and the big LDS carve."""
+    a = make_ivf_arrays(9000, 16, 300, seed=77, dup_frac=0.05)
+    ix = _index(a)
+    img = oracle_image(a)
+    q = _queries(a, 6, seed=78)
+    for nprobe, k in ((300, 10), (64, 200), (250, 1000), (1000, 65)):
+        t, d, c = ix.search(q, 1, nprobe, k)
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+        assert_same_results(t, d, c, et, ed, ec)
+    from neurondb_amd import NdbHipError
+    with pytest.raises(NdbHipError):
+        ix.search(q, 1, 10, 2000)
+    with pytest.raises(NdbHipError):
+        ix.search(q, 1, 0, 10)
