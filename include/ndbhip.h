@@ -249,6 +249,16 @@ int			ndbhip_hnsw_destroy(ndbhip_hnsw *g);
 int			ndbhip_hnsw_load(ndbhip_hnsw *g, uint32_t nblocks, const float *vecs, const int32_t *levels,
 							 const int16_t *ncount, const int64_t *nbr_off, const uint32_t *nbrs,
 							 const uint8_t *tids6, uint32_t entry_point, int entry_level);
+/* hnswbuild (src/index/hnsw_am.c:343-415): hnswInsertNode (:2091-2670) for rows 0..n-1 in order, on
+ * rows already in HBM; node i+1 = row i.  levels[i] (host) = the level hnswGetRandomLevel (:1143-1161)
+ * drew for row i — injected, because the reference draws it from random().  Links are always built with
+ * L2 and ef = k = ef_construction, as the reference does (quirk Q12). */
+int			ndbhip_hnsw_build_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+									 const int32_t *levels, int ef_construction);
+/* Read the graph back in the dense 16-level layout (any pointer may be NULL):
+ * levels [nblocks], ncount [nblocks*16], nbrs [nblocks*16*2m]. */
+int			ndbhip_hnsw_export(const ndbhip_hnsw *g, uint32_t *nblocks, int32_t *levels, int16_t *ncount,
+							   uint32_t *nbrs, uint32_t *entry_point, int *entry_level);
 /* hnswSearch for nq queries: strategy in {1,2,3}; ef = neurondb.hnsw_ef_search;
  * k = neurondb.hnsw_k.  out_blocks/out_dist [nq*k]; out_tids6 nullable
  * (hnswgettuple's node->heapPtr lookup, :1009-1053); out_scored nullable

@@ -2855,13 +2855,16 @@ k_kmeans_init(const float *__restrict__ data, int n, int dim, int k, float *__re
 }
 
 static int
+set_kernel_attributes_hnsw();
+
+static int
 set_kernel_attributes_build()
 {
 	HIP_TRY(hipFuncSetAttribute((const void *) k_kmeans_update, hipFuncAttributeMaxDynamicSharedMemorySize,
 								NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_seq_sum, hipFuncAttributeMaxDynamicSharedMemorySize,
 								NDB_TOPK_MAX_SMEM));
-	return NDBHIP_OK;
+	return set_kernel_attributes_hnsw();
 }
 
 /* scratch of assign_rows, reusable across calls (the k-means loop calls it once per iteration) */
@@ -3342,9 +3345,10 @@ struct HnswDev
 	const float *vecs;			/* [nblocks * dim], row b = node b (row 0 = meta page, unused) */
 	const int  *levels;			/* [nblocks] */
 	const int16_t *ncount;		/* [nblocks * 16] */
-	const int64_t *nbr_off;		/* [nblocks + 1] */
+	const int64_t *nbr_off;		/* [nblocks + 1] (packed layout) */
 	const uint32_t *nbrs;
 	const uint64_t *tids;		/* [nblocks] */
+	int64_t		dense_stride;	/* != 0: node b's slots start at b * dense_stride (16 levels x 2m each) */
 	uint32_t	nblocks;
 	int			dim;
 	int			m;
@@ -3354,9 +3358,9 @@ struct HnswDev
 
 /* hnswValidateBlockNumber (:1228-1241) + "the meta page holds no node" (PageIsEmpty checks) */
 __device__ __forceinline__ bool
-hnsw_valid(const HnswDev &g, uint32_t b)
+hnsw_valid(uint32_t nblocks, uint32_t b)
 {
-	return b != NDBHIP_INVALID_BLOCK && b < g.nblocks && b != 0;
+	return b != NDBHIP_INVALID_BLOCK && b < nblocks && b != 0;
 }
 
 __device__ __forceinline__ int
@@ -3364,6 +3368,33 @@ hnsw_clamp(int c, int m)
 {
 	return c < 0 ? 0 : (c > 2 * m ? 2 * m : c);
 }
+
+/* Graph metadata read.  MUT = the graph is being modified by this kernel (build): go through an
+ * agent-scope load so that neither the scalar cache nor the CU's L1 can serve a stale value. */
+template <bool MUT, class T>
+__device__ __forceinline__ T
+gload(const T *p)
+{
+	if (MUT)
+		return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
+}
+
+__device__ __forceinline__ const uint32_t *
+hnsw_nbr_base(const HnswDev &g, uint32_t b)
+{
+	return g.nbrs + (g.dense_stride ? (int64_t) b * g.dense_stride : g.nbr_off[b]);
+}
+
+struct HnswLds
+{
+	float	   *tile;
+	uint64_t   *e_id;
+	FinalizeScratch fs;
+	uint32_t   *cand, *cdist, *e_pos, *visited;
+	int		   *s_count;
+	uint32_t	npad;
+};
 
 __host__ __device__ static inline size_t
 hnsw_smem_bytes(uint32_t ef, uint32_t k, uint32_t m)
@@ -3374,53 +3405,51 @@ hnsw_smem_bytes(uint32_t ef, uint32_t k, uint32_t m)
 		(size_t) npad * (8 + 4 + 4 + 1) + (size_t) k * 4 + 128;
 }
 
-/*
- * One wave per query.  The walk is the reference's, statement for statement;
- * only the distance evaluations of one neighbour list are batched (one lane per
- * neighbour) — they do not depend on the sequential state — and the sequential
- * bookkeeping (visited marks, append / replace-worst, first-min ties) is then
- * replayed in neighbour order.
- */
-template <int R>
-__global__ __launch_bounds__(64) void
-k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_t k,
-			  uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
-			  uint64_t *__restrict__ out_tids, long long *__restrict__ out_scored)
+__device__ static inline HnswLds
+carve_hnsw_lds(unsigned char *sp, uint32_t ef, uint32_t k, uint32_t m)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	unsigned char *sp = smem_raw;
-	float	   *tile = (float *) sp;			sp += (size_t) NDB_TILE_FLOATS * 4;
-	uint64_t   *e_id = (uint64_t *) sp;			sp += (size_t) ef * 8;
-	const uint32_t npad = next_pow2(ef < 4 ? 4 : ef);
-	FinalizeScratch fs;
+	HnswLds		L;
 
-	fs.comp = (uint64_t *) sp;					sp += (size_t) npad * 8;
-	uint32_t   *cand = (uint32_t *) sp;			sp += (size_t) ef * 4;
-	uint32_t   *cdist = (uint32_t *) sp;		sp += (size_t) ef * 4;	/* float bits */
-	uint32_t   *e_pos = (uint32_t *) sp;		sp += (size_t) ef * 4;
-	uint32_t   *visited = (uint32_t *) sp;		sp += (size_t) (ef + 2 * g.m + 64) * 4;
-	fs.perm = (uint32_t *) sp;					sp += (size_t) npad * 4;
-	fs.curpos = (uint32_t *) sp;				sp += (size_t) npad * 4;
-	fs.order = (uint32_t *) sp;					sp += (size_t) k * 4;
-	fs.taken = (uint8_t *) sp;					/* npad bytes (npad >= 4: multiple of 4), then one int */
+	L.npad = next_pow2(ef < 4 ? 4 : ef);
+	L.tile = (float *) sp;				sp += (size_t) NDB_TILE_FLOATS * 4;
+	L.e_id = (uint64_t *) sp;			sp += (size_t) ef * 8;
+	L.fs.comp = (uint64_t *) sp;		sp += (size_t) L.npad * 8;
+	L.cand = (uint32_t *) sp;			sp += (size_t) ef * 4;
+	L.cdist = (uint32_t *) sp;			sp += (size_t) ef * 4;	/* float bits */
+	L.e_pos = (uint32_t *) sp;			sp += (size_t) ef * 4;
+	L.visited = (uint32_t *) sp;		sp += (size_t) (ef + 2 * m + 64) * 4;
+	L.fs.perm = (uint32_t *) sp;		sp += (size_t) L.npad * 4;
+	L.fs.curpos = (uint32_t *) sp;		sp += (size_t) L.npad * 4;
+	L.fs.order = (uint32_t *) sp;		sp += (size_t) k * 4;
+	L.fs.taken = (uint8_t *) sp;		/* npad bytes (multiple of 4), then one int */
+	L.s_count = (int *) (L.fs.taken + L.npad);
+	return L;
+}
 
+/*
+ * hnswSearch's walk for ONE query by ONE wave (hnsw_am.c:1593-1975): greedy descent, then the level-0
+ * "BFS until ef candidates" loop.  The walk is the reference's, statement for statement; only the
+ * distance evaluations of one neighbour list are batched (one lane per neighbour) — they do not depend on
+ * the sequential state — and the sequential bookkeeping (visited marks, append / replace-worst, first-min
+ * ties) is then replayed in neighbour order.  Leaves candidates[0..cc) / their distances in L.cand /
+ * L.cdist.  Returns false when the reference returns "no results" before level 0.
+ */
+template <int R, bool MUT>
+__device__ bool
+hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L, uint32_t &cc_out,
+		  long long &scored)
+{
 	const uint32_t lane = threadIdx.x;
-	const uint32_t qi = blockIdx.x;
-	const float *q = queries + (size_t) qi * g.dim;
 	const int	m2 = 2 * g.m;
-	long long	scored = 0;
+	const uint32_t nblocks = g.nblocks;
 	uint32_t	cur = g.entry_point;
 	int			curLevel = g.entry_level;
+	float	   *tile = L.tile;
+	uint32_t   *cand = L.cand, *cdist = L.cdist, *visited = L.visited;
 
+	cc_out = 0;
 	if (cur == NDBHIP_INVALID_BLOCK)	/* :1593-1599 */
-	{
-		if (lane == 0)
-		{
-			out_count[qi] = 0;
-			if (out_scored) out_scored[qi] = 0;
-		}
-		return;
-	}
+		return false;
 	if (curLevel < 0 || curLevel >= NDBHIP_HNSW_MAX_LEVEL)	/* :1609-1613 */
 		curLevel = 0;
 
@@ -3432,11 +3461,11 @@ k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_
 		do
 		{
 			found = false;
-			if (!hnsw_valid(g, cur))
+			if (!hnsw_valid(nblocks, cur))
 				break;
-			const int	nc = (g.levels[cur] >= level)
-				? hnsw_clamp(g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level], g.m) : 0;
-			const uint32_t *nb = g.nbrs + g.nbr_off[cur] + (size_t) level * m2;
+			const int	nc = (gload<MUT>(&g.levels[cur]) >= level)
+				? hnsw_clamp(gload<MUT>(&g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level]), g.m) : 0;
+			const uint32_t *nb = hnsw_nbr_base(g, cur) + (size_t) level * m2;
 			const uint32_t node = cur;
 			float		currentDist = 0.0f;
 
@@ -3444,8 +3473,8 @@ k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_
 			for (int j0 = -1; j0 < nc; j0 += 64)
 			{
 				const int	j = j0 + (int) lane;
-				uint32_t	my = (j < 0) ? node : ((j < nc) ? nb[j] : NDBHIP_INVALID_BLOCK);
-				const bool	act = hnsw_valid(g, my);
+				uint32_t	my = (j < 0) ? node : ((j < nc) ? gload<MUT>(&nb[j]) : NDBHIP_INVALID_BLOCK);
+				const bool	act = hnsw_valid(nblocks, my);
 				const float d = score_rows<R>(q, g.vecs, act ? my : node, g.dim, tile);
 				const unsigned long long am = __ballot(act);
 
@@ -3474,15 +3503,8 @@ k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_
 		} while (found);
 	}
 
-	if (!hnsw_valid(g, cur))	/* :1752-1763 */
-	{
-		if (lane == 0)
-		{
-			out_count[qi] = 0;
-			if (out_scored) out_scored[qi] = scored;
-		}
-		return;
-	}
+	if (!hnsw_valid(nblocks, cur))	/* :1752-1763 */
+		return false;
 
 	/* ---- level 0 (:1765-1975) ---- */
 	uint32_t	cc = 1, vc = 1;
@@ -3502,16 +3524,16 @@ k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_
 	{
 		const uint32_t c = cand[i];
 
-		if (!hnsw_valid(g, c))
+		if (!hnsw_valid(nblocks, c))
 			continue;
-		const int	nc = hnsw_clamp(g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + 0], g.m);
-		const uint32_t *nb = g.nbrs + g.nbr_off[c];
+		const int	nc = hnsw_clamp(gload<MUT>(&g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + 0]), g.m);
+		const uint32_t *nb = hnsw_nbr_base(g, c);
 
 		for (int j0 = 0; j0 < nc; j0 += 64)
 		{
 			const int	j = j0 + (int) lane;
-			const uint32_t my = (j < nc) ? nb[j] : NDBHIP_INVALID_BLOCK;
-			bool		ok = hnsw_valid(g, my);
+			const uint32_t my = (j < nc) ? gload<MUT>(&nb[j]) : NDBHIP_INVALID_BLOCK;
+			bool		ok = hnsw_valid(nblocks, my);
 
 			/* visitedSet test (:1891) against everything scored so far */
 			if (ok)
@@ -3591,35 +3613,193 @@ k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_
 		}
 	}
 	wave_lds_sync();
+	cc_out = cc;
+	return true;
+}
 
-	/* ---- top-k by the reference's selection sort (:1977-2013) ---- */
-	for (uint32_t t = lane; t < cc; t += 64)
+/* top-k of the walk's candidates by the reference's selection sort (:1977-2013); returns kk,
+ * result i = candidate L.fs.perm[L.fs.order[i]] */
+__device__ uint32_t
+hnsw_topk(HnswLds &L, uint32_t cc, uint32_t k, float *out_dist)
+{
+	for (uint32_t t = threadIdx.x; t < cc; t += 64)
 	{
-		e_pos[t] = t;
-		e_id[t] = cand[t];
+		L.e_pos[t] = t;
+		L.e_id[t] = L.cand[t];
 	}
 	__syncthreads();
-	int		   *s_count = (int *) (fs.taken + npad);	/* last word of the dynamic LDS block */
-
-	block_finalize_topk(cdist, e_pos, e_id, cc, next_pow2(cc), k, (uint64_t) cc, fs,
-						(uint64_t *) nullptr, out_dist + (size_t) qi * k, s_count);
+	block_finalize_topk(L.cdist, L.e_pos, L.e_id, cc, next_pow2(cc > 0 ? cc : 1), k, (uint64_t) cc, L.fs,
+						(uint64_t *) nullptr, out_dist, L.s_count);
 	__syncthreads();
-	const uint32_t kk = (uint32_t) *s_count;
+	return (uint32_t) *L.s_count;
+}
 
-	for (uint32_t i2 = lane; i2 < kk; i2 += 64)
+/* One wave per query. */
+template <int R>
+__global__ __launch_bounds__(64) void
+k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_t k,
+			  uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
+			  uint64_t *__restrict__ out_tids, long long *__restrict__ out_scored)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	HnswLds		L = carve_hnsw_lds(smem_raw, ef, k, (uint32_t) g.m);
+	const uint32_t lane = threadIdx.x;
+	const uint32_t qi = blockIdx.x;
+	long long	scored = 0;
+	uint32_t	cc = 0;
+	const bool	ok = hnsw_walk<R, false>(g, queries + (size_t) qi * g.dim, ef, L, cc, scored);
+	uint32_t	kk = 0;
+
+	if (ok)
 	{
-		const uint32_t e = fs.perm[fs.order[i2]];
-		const uint32_t b = cand[e];
+		kk = hnsw_topk(L, cc, k, out_dist + (size_t) qi * k);
+		for (uint32_t i2 = lane; i2 < kk; i2 += 64)
+		{
+			const uint32_t b = L.cand[L.fs.perm[L.fs.order[i2]]];
 
-		out_blocks[(size_t) qi * k + i2] = b;
-		if (out_tids)
-			out_tids[(size_t) qi * k + i2] = g.tids[b];
+			out_blocks[(size_t) qi * k + i2] = b;
+			if (out_tids)
+				out_tids[(size_t) qi * k + i2] = g.tids[b];
+		}
 	}
 	if (lane == 0)
 	{
 		out_count[qi] = (int) kk;
 		if (out_scored) out_scored[qi] = scored;
 	}
+}
+
+/*
+ * hnswbuild (hnsw_am.c:343-415) = hnswInsertNode for every heap row in order (:2091-2670).  The inserts
+ * depend on each other (each one searches the graph the previous ones left), so ONE wave walks them in
+ * order inside ONE launch; the graph lives in the dense 16-level layout so that the reference's writes
+ * at `currentLevel` into nodes allocated with fewer levels (Q12 / Q21) land in a defined slot, exactly
+ * like the oracle's model.  levels[i] = the level drawn for row i (hnswGetRandomLevel uses random():
+ * injected by the caller).
+ */
+__global__ __launch_bounds__(64) void
+k_hnsw_build(float *vecs, int *levels_out, int16_t *ncount, uint32_t *nbrs, uint64_t *tids_out,
+			 const float *__restrict__ rows, const uint64_t *__restrict__ tids_in,
+			 const int *__restrict__ levels_in, uint32_t n, int dim, int m, uint32_t efc,
+			 uint32_t *entry_io /* [0] entry point, [1] entry level (as int) */)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	const uint32_t ksel = (uint32_t) m < efc ? (uint32_t) m : efc;
+	HnswLds		L = carve_hnsw_lds(smem_raw, efc, efc, (uint32_t) m);
+	const uint32_t lane = threadIdx.x;
+	const int	m2 = 2 * m;
+	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+	uint32_t	entry = entry_io[0];
+	int			entry_level = (int) entry_io[1];
+	long long	scored = 0;
+
+	for (uint32_t i = 0; i < n; i++)
+	{
+		const uint32_t blk = i + 1;
+		int			level = levels_in[i];
+
+		if (level >= NDBHIP_HNSW_MAX_LEVEL) level = NDBHIP_HNSW_MAX_LEVEL - 1;
+		if (level < 0) level = 0;
+		/* Step 4 (:2288-2332): the node's page */
+		for (int j = lane; j < dim; j += 64)
+			vecs[(size_t) blk * dim + j] = rows[(size_t) i * dim + j];
+		for (int j = lane; j < NDBHIP_HNSW_MAX_LEVEL; j += 64)
+			ncount[(size_t) blk * NDBHIP_HNSW_MAX_LEVEL + j] = 0;
+		for (int64_t j = lane; j < stride; j += 64)
+			nbrs[(size_t) blk * stride + j] = NDBHIP_INVALID_BLOCK;
+		if (lane == 0)
+		{
+			levels_out[blk] = level;
+			tids_out[blk] = tids_in[i];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+		/* Step 5 (:2334-2640) */
+		if (entry != NDBHIP_INVALID_BLOCK && entry_level >= 0)
+		{
+			HnswDev		g;
+
+			g.vecs = vecs; g.levels = levels_out; g.ncount = ncount; g.nbr_off = nullptr; g.nbrs = nbrs;
+			g.tids = tids_out; g.dense_stride = stride; g.nblocks = blk + 1; g.dim = dim; g.m = m;
+			g.entry_point = entry; g.entry_level = entry_level;
+			const int	maxLevel = level < entry_level ? level : entry_level;
+
+			for (int cl = maxLevel; cl >= 0; cl--)
+			{
+				uint32_t	cc = 0;
+				/* always L2, ef = k = efConstruction (:2369-2378); only the first m results are used,
+				 * and the second selection sort (:2391-2414) over already sorted results is the identity */
+				const bool	ok = hnsw_walk<R_HNSW_L2, true>(g, rows + (size_t) i * dim, efc, L, cc, scored);
+				uint32_t	kk = 0;
+
+				if (ok)
+					kk = hnsw_topk(L, cc, ksel, (float *) L.fs.curpos /* scratch: distances not needed */);
+				const uint32_t nsel = kk;	/* = Min(m, candidateCount) */
+
+				for (uint32_t idx = 0; idx < nsel; idx++)
+				{
+					const uint32_t nbk = L.cand[L.fs.perm[L.fs.order[idx]]];
+					uint32_t   *newn = nbrs + (size_t) blk * stride + (size_t) cl * m2;
+					uint32_t   *nn = nbrs + (size_t) nbk * stride + (size_t) cl * m2;
+					int16_t    *ncp = &ncount[(size_t) nbk * NDBHIP_HNSW_MAX_LEVEL + cl];
+
+					if (lane == 0)
+					{
+						newn[idx] = nbk;		/* :2452-2456 */
+						ncount[(size_t) blk * NDBHIP_HNSW_MAX_LEVEL + cl] = (int16_t) (idx + 1);
+					}
+					/* back-link (:2487-2511): first InvalidBlockNumber slot among the first count, else count */
+					const int	cnt = hnsw_clamp(gload<true>(ncp), m);
+					int			pos = cnt;
+
+					for (int j0 = 0; j0 < cnt; j0 += 64)
+					{
+						const int	j = j0 + (int) lane;
+						const bool	inv = j < cnt && gload<true>(&nn[j]) == NDBHIP_INVALID_BLOCK;
+						const unsigned long long mk = __ballot(inv);
+
+						if (mk)
+						{
+							pos = j0 + __ffsll((long long) mk) - 1;
+							break;
+						}
+					}
+					if (lane == 0 && pos < m2)
+					{
+						nn[pos] = blk;
+						if (pos >= cnt)
+							*ncp = (int16_t) (pos + 1);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				}
+			}
+		}
+		/* Step 6 (:2642-2663) */
+		if (entry == NDBHIP_INVALID_BLOCK || level > entry_level)
+		{
+			entry = blk;
+			entry_level = level;
+		}
+	}
+	if (lane == 0)
+	{
+		entry_io[0] = entry;
+		entry_io[1] = (uint32_t) entry_level;
+	}
+}
+
+static int
+set_kernel_attributes_hnsw()
+{
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_COS>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_build, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	return NDBHIP_OK;
 }
 
 struct ndbhip_hnsw
@@ -3635,6 +3815,7 @@ struct ndbhip_hnsw
 	uint32_t   *d_nbrs = nullptr;
 	uint64_t   *d_tids = nullptr;
 	bool		loaded = false;
+	bool		dense = false;			/* neighbour slots in the 16-level dense layout (device-built graphs) */
 	/* host-call workspace */
 	float	   *w_q = nullptr;		size_t w_q_n = 0;
 	uint32_t   *w_ob = nullptr;		size_t w_ob_n = 0;
@@ -3734,6 +3915,102 @@ ndbhip_hnsw_load(ndbhip_hnsw *h, uint32_t nblocks, const float *vecs, const int3
 	h->entry_point = entry_point;
 	h->entry_level = entry_level;
 	h->loaded = true;
+	h->dense = false;
+	return NDBHIP_OK;
+}
+
+/* hnswbuild on rows already in HBM: node i+1 = row i, levels[i] = its drawn level (host array). */
+extern "C" int
+ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+						 const int32_t *levels, int ef_construction)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !d_rows || !d_tids || !levels || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ef_construction < 4 || ef_construction > NDBHIP_MAX_EF)	/* HNSW_MIN_EF_CONSTRUCTION: hnsw_am.c:92 */
+		return fail(NDBHIP_ERR_INVALID, "ef_construction %d out of range 4..%d", ef_construction, NDBHIP_MAX_EF);
+	const size_t smem = hnsw_smem_bytes((uint32_t) ef_construction, (uint32_t) ef_construction, (uint32_t) h->m);
+
+	if (smem > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "ef_construction too large for the LDS-resident candidate set");
+	hnsw_free_dev(h);
+	const uint32_t nb = n + 1;
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
+	int		   *d_lv_in = nullptr;
+	uint32_t   *d_entry = nullptr;
+	uint32_t	entry[2] = {NDBHIP_INVALID_BLOCK, (uint32_t) -1};
+
+	HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
+	HIP_TRY(hipMalloc((void **) &d_lv_in, (size_t) n * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &d_entry, 2 * sizeof(uint32_t)));
+	HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));	/* row 0 = meta page */
+	HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
+	HIP_TRY(hipMemcpyAsync(d_lv_in, levels, (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_entry, entry, sizeof(entry), hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_hnsw_build, dim3(1), dim3(64), smem, g.stream, h->d_vecs, h->d_levels, h->d_ncount,
+					   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, h->m,
+					   (uint32_t) ef_construction, d_entry);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(entry, d_entry, sizeof(entry), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_lv_in));
+	HIP_TRY(hipFree(d_entry));
+	h->nblocks = nb;
+	h->entry_point = entry[0];
+	h->entry_level = (int) entry[1];
+	h->loaded = true;
+	h->dense = true;
+	return NDBHIP_OK;
+}
+
+/* Read a graph back in the dense layout: levels [nblocks], ncount [nblocks*16],
+ * nbrs [nblocks*16*2m] (slots a packed graph does not hold come back as 0xFFFFFFFF). */
+extern "C" int
+ndbhip_hnsw_export(const ndbhip_hnsw *h, uint32_t *nblocks, int32_t *levels, int16_t *ncount, uint32_t *nbrs,
+				   uint32_t *entry_point, int *entry_level)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !h->loaded)
+		return fail(NDBHIP_ERR_STATE, "hnsw mirror not loaded");
+	const uint32_t nb = h->nblocks;
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
+
+	if (nblocks) *nblocks = nb;
+	if (entry_point) *entry_point = h->entry_point;
+	if (entry_level) *entry_level = h->entry_level;
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	std::vector<int32_t> lv(nb);
+
+	HIP_TRY(hipMemcpy(lv.data(), h->d_levels, (size_t) nb * sizeof(int), hipMemcpyDeviceToHost));
+	if (levels)
+		memcpy(levels, lv.data(), (size_t) nb * sizeof(int));
+	if (ncount)
+		HIP_TRY(hipMemcpy(ncount, h->d_ncount, (size_t) nb * 16 * sizeof(int16_t), hipMemcpyDeviceToHost));
+	if (nbrs)
+	{
+		if (h->dense)
+			HIP_TRY(hipMemcpy(nbrs, h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		else
+		{
+			std::vector<int64_t> off((size_t) nb + 1);
+
+			HIP_TRY(hipMemcpy(off.data(), h->d_nbr_off, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+			std::vector<uint32_t> packed((size_t) std::max<int64_t>(off[nb], 1));
+
+			if (off[nb] > 0)
+				HIP_TRY(hipMemcpy(packed.data(), h->d_nbrs, (size_t) off[nb] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+			memset(nbrs, 0xFF, (size_t) nb * stride * sizeof(uint32_t));
+			for (uint32_t b = 1; b < nb; b++)
+				memcpy(nbrs + (size_t) b * stride, packed.data() + off[b], (size_t) (off[b + 1] - off[b]) * sizeof(uint32_t));
+		}
+	}
 	return NDBHIP_OK;
 }
 
@@ -3767,6 +4044,7 @@ ndbhip_hnsw_search_device(ndbhip_hnsw *h, const float *d_queries, int nq, int st
 
 	d.vecs = h->d_vecs; d.levels = h->d_levels; d.ncount = h->d_ncount; d.nbr_off = h->d_nbr_off;
 	d.nbrs = h->d_nbrs; d.tids = h->d_tids; d.nblocks = h->nblocks; d.dim = h->dim; d.m = h->m;
+	d.dense_stride = h->dense ? (int64_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m : 0;
 	d.entry_point = h->entry_point; d.entry_level = h->entry_level;
 	const size_t smem = hnsw_smem_bytes((uint32_t) ef, (uint32_t) k, (uint32_t) h->m);
 

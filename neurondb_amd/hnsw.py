@@ -59,6 +59,32 @@ class HnswIndex:
                                      _ptr(t6), int(entry_point) & 0xFFFFFFFF, int(entry_level)))
         self.nblocks = nb
 
+    def build(self, rows, tids, levels, ef_construction=200):
+        """hnswbuild on the device: inserts rows in order (node i+1 = row i) with the given level draws."""
+        import torch
+        r = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
+        t = np.ascontiguousarray(tids)
+        t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
+        t8 = np.zeros((t6.shape[0], 8), dtype=np.uint8)
+        t8[:, :6] = t6
+        tt = torch.from_numpy(t8.view(np.int64).reshape(-1)).cuda()
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        check(lib().ndbhip_hnsw_build_device(self._h, C.c_void_p(r.data_ptr()), C.c_void_p(tt.data_ptr()), len(lv),
+                                             _ptr(lv), int(ef_construction)))
+        self.nblocks = len(lv) + 1
+
+    def export(self):
+        nb = C.c_uint32()
+        ep = C.c_uint32()
+        el = C.c_int()
+        check(lib().ndbhip_hnsw_export(self._h, C.byref(nb), None, None, None, C.byref(ep), C.byref(el)))
+        n = nb.value
+        levels = np.zeros(n, np.int32)
+        ncount = np.zeros((n, 16), np.int16)
+        nbrs = np.zeros((n, 16, 2 * self.m), np.uint32)
+        check(lib().ndbhip_hnsw_export(self._h, None, _ptr(levels), _ptr(ncount), _ptr(nbrs), None, None))
+        return dict(levels=levels, ncount=ncount, nbrs=nbrs, entry_point=ep.value, entry_level=el.value, nblocks=n)
+
     def search(self, queries, strategy=1, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K):
         """Returns (blocks [nq,k] uint32, dist [nq,k], count [nq], tids [nq,k], scored [nq])."""
         q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)

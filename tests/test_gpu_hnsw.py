@@ -94,3 +94,33 @@ def test_hnsw_scan_state_machine():
     eb, ed, _ = g.search(vecs[7], 1, 32, 5)
     exp = [tuple(a["tids"][b]) for b in eb]
     assert [tuple(int(x) for x in t.tolist()) for t in got] == [tuple(int(x) for x in e) for e in exp]
+
+
+@pytest.mark.parametrize("n,dim,m,efc", [(500, 16, 4, 20), (700, 64, 8, 40), (300, 768, 16, 64), (200, 6, 5, 16)])
+def test_hnsw_device_build_matches_oracle_graph(n, dim, m, efc):
+    """hnswbuild on the device (k_hnsw_build) vs the oracle's literal hnswInsertNode: identical neighbour
+    arrays (all 16 levels, incl. the out-of-node back-links of Q12/Q21), counts, entry point."""
+    from neurondb_amd import HnswIndex
+    rng = np.random.default_rng(n * 3 + dim)
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    vecs[n // 2] = vecs[3]                                   # duplicate vector
+    L = ndbo.lib()
+    levels = np.array([L.ndbo_hnsw_level_from_uniform(float(r), np.float32(0.36))
+                       for r in rng.uniform(1e-9, 1.0, n)], np.int32)
+    levels[7] = 3                                            # make sure upper levels (and self-links) occur
+    g = ndbo.HnswGraph(dim, m=m, ef_construction=efc, cap_nodes=n + 2)
+    for i in range(n):
+        g.insert(vecs[i], i, int(levels[i]))
+    a = g.arrays()
+    ix = HnswIndex(dim, m)
+    ix.build(vecs, ndbo.tids_from_rows(np.arange(n)), levels, efc)
+    e = ix.export()
+    assert e["nblocks"] == a["nblocks"]
+    assert (e["entry_point"], e["entry_level"]) == (a["entry_point"], a["entry_level"])
+    assert np.array_equal(e["levels"][1:], a["levels"][1:])
+    assert np.array_equal(e["ncount"][1:], a["ncount"][1:])
+    assert np.array_equal(e["nbrs"][1:], a["nbrs"][1:])
+    # and the device-built (dense) graph answers queries like the oracle
+    q = rng.standard_normal((8, dim)).astype(np.float32)
+    for strategy in (1, 2, 3):
+        check(g, ix, q, strategy, 32, 10)
