@@ -235,6 +235,25 @@ class HnswGraph:
         except Exception:
             pass
 
+    @classmethod
+    def from_arrays(cls, vecs, levels, ncount, nbrs, tids, entry_point, entry_level, m, ef_construction=200,
+                    native=False):
+        """Oracle graph image filled from dense arrays (node b = row b of vecs, row 0 unused)."""
+        nb, dim = vecs.shape
+        g = cls(dim, m=m, ef_construction=ef_construction, cap_nodes=nb, native=native)
+        s = g.g.contents
+        C.memmove(s.vecs, np.ascontiguousarray(vecs, np.float32).ctypes.data, nb * dim * 4)
+        C.memmove(s.levels, np.ascontiguousarray(levels, np.int32).ctypes.data, nb * 4)
+        C.memmove(s.ncount, np.ascontiguousarray(ncount, np.int16).ctypes.data, nb * 16 * 2)
+        C.memmove(s.nbrs, np.ascontiguousarray(nbrs, np.uint32).ctypes.data, nb * 16 * 2 * m * 4)
+        if tids is not None:
+            C.memmove(s.heap_tids, np.ascontiguousarray(tids).ctypes.data, nb * 6)
+        s.nblocks = nb
+        s.entry_point = int(entry_point) & 0xFFFFFFFF
+        s.entry_level = int(entry_level)
+        s.inserted = nb - 1
+        return g
+
     def insert(self, vec, row, level):
         t = tids_from_rows(np.array([row]))[0]
         return self.L.ndbo_hnsw_insert(self.g, _f32(vec), NdboTid(int(t["bi_hi"]), int(t["bi_lo"]),
