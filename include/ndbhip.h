@@ -117,6 +117,13 @@ int			ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncent
  */
 int			ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 							const float *rows, const uint8_t *tids6, int64_t nrows);
+/* halfvec column (src/types/quantization.c, VectorF16): the rows as IEEE fp16 images, kept as fp16 in
+ * HBM (half the bytes per row) and decoded on the fly exactly like the reference's fp16_to_float
+ * (quantization.c:170-218, incl. its subnormal quirk) — results are bit-identical to indexing the expanded
+ * float4 values, which is what the reference stores (hnsw_am.c:1436-1451 / ivf_am.c:168-177).
+ * Needs dim % 64 == 0.  Queries stay float4 (ndbhip_extract_vector expands a halfvec query). */
+int			ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
+								const uint16_t *rows_f16, const uint8_t *tids6, int64_t nrows);
 /* Same, rows/tids already in HBM (d_tids as uint64 device format). The arrays
  * are adopted without a copy and must outlive the index. */
 int			ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,

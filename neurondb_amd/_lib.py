@@ -79,6 +79,7 @@ def lib():
         "ndbhip_ivf_set_centroids": (i, [vp, vp, i]),
         "ndbhip_ivf_load": (i, [vp, vp, vp, vp, vp, i64]),
         "ndbhip_ivf_load_device": (i, [vp, vp, vp, vp, vp, i64]),
+        "ndbhip_ivf_load_f16": (i, [vp, vp, vp, vp, vp, i64]),
         "ndbhip_ivf_append": (i, [vp, i, vp, vp]),
         "ndbhip_ivf_export": (i, [vp, vp, vp, vp, vp]),
         "ndbhip_ivf_ncentroids": (i, [vp]),

@@ -301,6 +301,7 @@ struct IvfDev
 	int			dim;
 	int			ncent;			/* centroid items present ("maxoff") */
 	int			nlists;			/* meta->nlists */
+	int			f16;			/* rows are fp16 (vecs points at them; dim % 64 == 0) */
 };
 
 /* ================================================================== */
@@ -774,7 +775,7 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 		{
 			atomicAdd(&counters[0], (unsigned long long) acc);
 			atomicAdd(&counters[1], (unsigned long long) mine);
-			atomicAdd(&counters[2], (unsigned long long) mine * (unsigned long long) dim * 4ull);
+			atomicAdd(&counters[2], (unsigned long long) mine * (unsigned long long) dim);
 		}
 	}
 }
@@ -835,6 +836,43 @@ k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 	}
 	const float d = score_rows<R>(queries + (size_t) q * ix.dim, ix.vecs, row, ix.dim,
 								  tiles + wave * NDB_TILE_FLOATS);
+
+	if (valid)
+		dist[(size_t) q * stride + pos] = own ? d : __uint_as_float(NDB_ABSENT_BITS);
+}
+
+/* the same for fp16 rows (halfvec columns) */
+template <int R>
+__global__ __launch_bounds__(256) void
+k_ivf_scan_h(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
+		   const uint32_t *__restrict__ cand_off, int npr, float *__restrict__ dist, uint32_t stride)
+{
+	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t q = blockIdx.y;
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t total = co[npr];
+	const uint32_t pos0 = (blockIdx.x * 4 + wave) * 64;
+
+	if (pos0 >= total)
+		return;
+	const uint32_t pos = pos0 + lane;
+	const bool	valid = pos < total;
+	const uint32_t spos = valid ? pos : (total - 1);
+	const uint32_t p = find_probe(co, npr, spos);
+	const int	L = probes[(size_t) q * npr + p];
+	const bool	own = ix.owned[L] != 0;
+	const uint32_t row = own ? (uint32_t) (ix.loc_off[L] + (spos - co[p])) : 0u;
+
+	if (__ballot(valid && own) == 0ull)
+	{
+		if (valid)
+			dist[(size_t) q * stride + pos] = __uint_as_float(NDB_ABSENT_BITS);
+		return;
+	}
+	const float d = score_rows_f16<R>(queries + (size_t) q * ix.dim, ix.vecs, row, ix.dim,
+									  tiles + wave * NDB_TILE_FLOATS);
 
 	if (valid)
 		dist[(size_t) q * stride + pos] = own ? d : __uint_as_float(NDB_ABSENT_BITS);
@@ -1194,8 +1232,8 @@ k_query_norms(const float *__restrict__ queries, uint32_t nq, int dim, float *__
  * Persistent kernel: every wave pulls work items (list, 64-row tile, query group)
  * from a global counter.  block = 256 (4 independent waves, 16 KiB LDS tile each).
  */
-template <int R, int CH>
-__global__ __launch_bounds__(64, (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD)) void
+template <int R, int CH, bool H16>
+__global__ __launch_bounds__(64, (H16 ? 4 : (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD))) void
 k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ cand_off,
 				   int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
@@ -1255,6 +1293,42 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 
 		asm volatile("s_nop 4" ::: "memory");	/* the base pointer may come from v_readfirstlane */
 		sload2x16(qa0, qa1, qs);
+		if constexpr (H16)
+		{
+			/* fp16 rows: 64 dimensions (128 raw bytes per row) per step */
+			for (int c = 0; c < dim; c += 64)
+			{
+				float4		raw[8];
+
+				stage_chunk_w<32>(raw, ix.vecs, rowsN, dim >> 1, c >> 1, tile, lane);
+#pragma unroll
+				for (int p = 0; p < 8; p++)
+				{
+					float		x[8];
+
+					decode8(raw[p], x);
+					swait2(qa0, qa1);
+					sload2x16(qb0, qb1, qs + 2 * NDB_QG);
+					acc.step(qa0, x[0]);
+					acc.step(qa1, x[1]);
+					swait2(qb0, qb1);
+					sload2x16(qa0, qa1, qs + 4 * NDB_QG);
+					acc.step(qb0, x[2]);
+					acc.step(qb1, x[3]);
+					swait2(qa0, qa1);
+					sload2x16(qb0, qb1, qs + 6 * NDB_QG);
+					acc.step(qa0, x[4]);
+					acc.step(qa1, x[5]);
+					swait2(qb0, qb1);
+					qs += 8 * NDB_QG;
+					sload2x16(qa0, qa1, (c + 64 >= dim && p == 7) ? qs - 2 * NDB_QG : qs);
+					acc.step(qb0, x[6]);
+					acc.step(qb1, x[7]);
+				}
+			}
+		}
+		else
+		{
 		for (int c = 0; c < dim; c += CH)
 		{
 			float4		x[CH / 4];
@@ -1275,6 +1349,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				acc.step(qb0, x[p].z);
 				acc.step(qb1, x[p].w);
 			}
+		}
 		}
 		swait2(qa0, qa1);
 #pragma unroll
@@ -1600,6 +1675,7 @@ struct ndbhip_ivf
 	std::vector<uint8_t> owned;
 	bool		loaded = false;
 	bool		sharded = false;		/* some list is not held here */
+	bool		f16 = false;			/* rows held as fp16 (halfvec column): d_vecs points at uint16 data */
 	/* aminsert: entries appended since the last repack (flushed before the next search) */
 	std::vector<int> pend_list;
 	std::vector<float> pend_rows;
@@ -1775,6 +1851,7 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
 	ix->own_rows = true;
 	ix->cap_rows = cap;
+	ix->f16 = false;
 	if (nrows > 0)
 	{
 		std::vector<uint64_t> t64((size_t) nrows);
@@ -1788,6 +1865,45 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
+	ix->loaded = true;
+	return NDBHIP_OK;
+}
+
+/* halfvec column: rows as IEEE fp16 images (uint16), decoded on the fly exactly like fp16_to_float */
+extern "C" int
+ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
+					const uint16_t *rows_f16, const uint8_t *tids6, int64_t nrows)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !list_len || nrows < 0 || (nrows > 0 && (!rows_f16 || !tids6)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ix->dim % 64 != 0)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "fp16 rows need dim %% 64 == 0 (dim = %d)", ix->dim);
+	int			rc = ivf_set_layout(ix, list_len, owned, nrows);
+
+	if (rc)
+		return rc;
+	ivf_free_rows(ix);
+	const int64_t cap = nrows > 0 ? nrows : 1;
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * sizeof(uint16_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
+	ix->own_rows = true;
+	ix->cap_rows = cap;
+	if (nrows > 0)
+	{
+		std::vector<uint64_t> t64((size_t) nrows);
+
+		for (int64_t r = 0; r < nrows; r++)
+			t64[(size_t) r] = ndb_tid_pack(tids6 + 6 * r);
+		HIP_TRY(hipMemcpyAsync(ix->d_vecs, rows_f16, (size_t) nrows * ix->dim * sizeof(uint16_t),
+							   hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_tids, t64.data(), (size_t) nrows * sizeof(uint64_t), hipMemcpyHostToDevice,
+							   g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	ix->nrows = nrows;
+	ix->f16 = true;
 	ix->loaded = true;
 	return NDBHIP_OK;
 }
@@ -1809,6 +1925,7 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 	ix->d_vecs = const_cast<float *>(d_rows);
 	ix->d_tids = const_cast<uint64_t *>(d_tids);
 	ix->own_rows = false;
+	ix->f16 = false;
 	ix->nrows = nrows;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
@@ -1966,6 +2083,8 @@ ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *
 		return fail(NDBHIP_ERR_STATE, "index has no lists loaded");
 	if (list_id < 0 || list_id >= ix->ncent)
 		return fail(NDBHIP_ERR_INVALID, "list %d out of range 0..%d", list_id, ix->ncent - 1);
+	if (ix->f16)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "append to an fp16 mirror is not implemented: reload the list");
 	ix->pend_list.push_back(list_id);
 	ix->pend_rows.insert(ix->pend_rows.end(), vec, vec + ix->dim);	/* copied: caller's memory may be palloc'd */
 	ix->pend_tids.push_back(ndb_tid_pack(tid6));
@@ -1987,6 +2106,7 @@ ivf_dev(const ndbhip_ivf *ix)
 	d.dim = ix->dim;
 	d.ncent = ix->ncent;
 	d.nlists = ix->nlists;
+	d.f16 = ix->f16 ? 1 : 0;
 	return d;
 }
 
@@ -2034,7 +2154,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	}
 	hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
 					   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
-					   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim, ix->w_probes,
+					   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4), ix->w_probes,
 					   ix->w_candoff, full ? g.d_counters : (unsigned long long *) nullptr);
 	HIP_TRY(hipGetLastError());
 	if (!full)
@@ -2078,13 +2198,25 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 							   ix->dim, ix->w_qnorm);
 		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
-#define LAUNCH_GROUPED(RR, CC, GRID)                                                                       \
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_scan_grouped<RR, CC>), GRID, dim3(64), 0, g.stream, d,        \
+#define LAUNCH_GROUPED(RR, CC, GRID) LAUNCH_GROUPED_H(RR, CC, false, GRID)
+#define LAUNCH_GROUPED_H(RR, CC, HH, GRID)                                                                       \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_scan_grouped<RR, CC, HH>), GRID, dim3(64), 0, g.stream, d,    \
 						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,                \
 						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,   \
 						   stride, (const float *) ix->w_qnorm)
-		if (g_gchunk == 32)
+		if (ix->f16)
+		{
+			const dim3	g16(g.num_cus * 16);	/* 8 KiB tile, 4 waves per SIMD */
+
+			if (R == R_IVF_IP)
+				LAUNCH_GROUPED_H(R_IVF_IP, 32, true, g16);
+			else if (R == R_IVF_COS)
+				LAUNCH_GROUPED_H(R_IVF_COS, 32, true, g16);
+			else
+				LAUNCH_GROUPED_H(R_IVF_L2, 32, true, g16);
+		}
+		else if (g_gchunk == 32)
 		{
 			const dim3	g32(g.num_cus * 4 * NDB_G32_WAVES);	/* 8 KiB LDS per wave, VGPRs capped for NDB_G32_WAVES per SIMD */
 
@@ -2112,8 +2244,12 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		ScanTimer	t;
 
 		if (t.start()) return NDBHIP_ERR_HIP;
-		LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) ix->w_probes,
-						 (const uint32_t *) ix->w_candoff, npr, ix->w_dist, stride);
+		if (ix->f16)
+			LAUNCH_BY_RECIPE(R, k_ivf_scan_h, grid, dim3(256), d, d_q, (const int *) ix->w_probes,
+							 (const uint32_t *) ix->w_candoff, npr, ix->w_dist, stride);
+		else
+			LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) ix->w_probes,
+							 (const uint32_t *) ix->w_candoff, npr, ix->w_dist, stride);
 		if (t.stop()) return NDBHIP_ERR_HIP;
 	}
 	{
@@ -3245,6 +3381,8 @@ ndbhip_ivf_export(const ndbhip_ivf *cix, float *centroids, int64_t *list_len, fl
 	if (list_len)
 		for (int c = 0; c < ix->ncent; c++)
 			list_len[c] = ix->owned[c] ? ix->glob_len[c] : 0;
+	if (rows && ix->f16)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "fp16 mirror: rows are not exported as float4");
 	if (rows && ix->nrows > 0)
 		HIP_TRY(hipMemcpy(rows, ix->d_vecs, (size_t) ix->nrows * ix->dim * 4, hipMemcpyDeviceToHost));
 	if (tids6 && ix->nrows > 0)
@@ -3269,6 +3407,10 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 	for (int c = 0; c < src->ncent; c++)
 		if (owned[c] && !src->owned[c])
 			return fail(NDBHIP_ERR_INVALID, "list %d is not resident in the source index", c);
+	if (src->f16)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "sharding an fp16 mirror is not implemented: load each shard with ndbhip_ivf_load_f16");
+	if (!src->pend_list.empty())
+		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
 	ndbhip_ivf *ix = nullptr;
 	int			rc = ndbhip_ivf_create(src->dim, src->nlists, &ix);
 

@@ -28,6 +28,7 @@
 #define NDBHIP_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "ndbhip_common.h"
 
@@ -248,6 +249,74 @@ rows_for_loads(uint32_t (&rowsN)[CH / 4], uint32_t row, int lane)
 #pragma unroll
 	for (int i = 0; i < PP; i++)
 		rowsN[i] = __shfl(row, RPI * i + lane / PP, 64);
+}
+
+/*
+ * fp16 rows (halfvec columns: the indexed values ARE half precision, so keeping them as fp16 in HBM
+ * is lossless and halves bytes and capacity per row).  Decode = the reference's fp16_to_float
+ * (src/types/quantization.c:170-218): normals, zeros and infinities are IEEE; SUBNORMALS come out
+ * 2^-10 too small in the reference (quirk Q20: exponent = 127-15-(10-exp)), reproduced here by an
+ * exact power-of-two scaling of the hardware conversion.
+ */
+__device__ __forceinline__ float
+h2f_ref(uint32_t h16)
+{
+	const float f = __half2float(__ushort_as_half((unsigned short) h16));
+
+	return ((h16 & 0x7c00u) == 0u && (h16 & 0x03ffu) != 0u) ? f * 0x1p-10f : f;
+}
+
+/* 8 halves (one 16-byte piece) -> 8 floats, element order preserved */
+__device__ __forceinline__ void
+decode8(const float4 &raw, float (&out)[8])
+{
+	const uint32_t w[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z),
+		__float_as_uint(raw.w)};
+
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+	{
+		out[2 * i] = h2f_ref(w[i] & 0xFFFFu);
+		out[2 * i + 1] = h2f_ref(w[i] >> 16);
+	}
+}
+
+/* 64 fp16 rows x 64 dimensions per step: the 128 raw bytes of every row pass through the 8 KiB
+ * tile exactly like a 32-float chunk; rows are addressed in units of floats (dim/2 per row). */
+template <int R>
+__device__ __forceinline__ float
+score_rows_f16(const float *__restrict__ q, const float *__restrict__ base16, uint32_t row, int dim,
+			   float *tile)
+{
+	const int	lane = threadIdx.x & (NDB_WAVE - 1);
+	uint32_t	rowsN[8];
+	Acc<R>		acc;
+
+	rows_for_loads<32>(rowsN, row, lane);
+	for (int c = 0; c < dim; c += 64)
+	{
+		float4		raw[8];
+
+		stage_chunk_w<32>(raw, base16, rowsN, dim >> 1, c >> 1, tile, lane);
+#pragma unroll
+		for (int p = 0; p < 8; p++)
+		{
+			float		x[8];
+			const float4 q0 = *reinterpret_cast<const float4 *>(q + c + p * 8);
+			const float4 q1 = *reinterpret_cast<const float4 *>(q + c + p * 8 + 4);
+
+			decode8(raw[p], x);
+			acc.step(q0.x, x[0]);
+			acc.step(q0.y, x[1]);
+			acc.step(q0.z, x[2]);
+			acc.step(q0.w, x[3]);
+			acc.step(q1.x, x[4]);
+			acc.step(q1.y, x[5]);
+			acc.step(q1.z, x[6]);
+			acc.step(q1.w, x[7]);
+		}
+	}
+	return acc.fin();
 }
 
 /* Split form of stage_chunk for software pipelining: issue the 16 global loads of a chunk early

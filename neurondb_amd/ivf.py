@@ -63,6 +63,15 @@ class IvfIndex:
         ow = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
         check(lib().ndbhip_ivf_load(self._h, _ptr(ll), _ptr(ow), _ptr(rows), _ptr(t6), rows.shape[0]))
 
+    def load_f16(self, list_len, rows_f16, tids, owned=None):
+        """halfvec column: rows as uint16 fp16 images [n, dim] of the OWNED lists, list-major."""
+        ll = np.ascontiguousarray(list_len, dtype=np.int64)
+        rows = np.ascontiguousarray(rows_f16, dtype=np.uint16).reshape(-1, self.dim)
+        t = np.ascontiguousarray(tids)
+        t6 = np.ascontiguousarray(t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6))
+        ow = None if owned is None else np.ascontiguousarray(owned, dtype=np.uint8)
+        check(lib().ndbhip_ivf_load_f16(self._h, _ptr(ll), _ptr(ow), _ptr(rows), _ptr(t6), rows.shape[0]))
+
     def load_device(self, list_len, d_rows, d_tids, owned=None):
         """d_rows: torch float32 [n, dim] on the device, d_tids: torch int64 [n] (device TID format)."""
         ll = np.ascontiguousarray(list_len, dtype=np.int64)

@@ -351,3 +351,29 @@ def test_large_k_and_nprobe_limits():
         ix.search(q, 1, 10, 2000)
     with pytest.raises(NdbHipError):
         ix.search(q, 1, 0, 10)
+
+
+@pytest.mark.parametrize("dim,n,nlists", [(64, 3000, 10), (128, 5000, 20), (1536, 1200, 8)])
+def test_fp16_rows_are_bit_identical_to_expanded_float4_rows(dim, n, nlists, scan_mode):
+    """halfvec column kept as fp16 in HBM: decode on the fly == the reference's fp16_to_float (incl. the
+    subnormal quirk Q20), so every result equals the search over the expanded float4 rows."""
+    from neurondb_amd import IvfIndex
+    from oracle import ndbo
+    L = ndbo.lib()
+    a = make_ivf_arrays(n, dim, nlists, seed=dim + 5, dup_frac=0.05)
+    h = (a["rows"] * 0.25).astype(np.float16).view(np.uint16).copy()
+    h[3, :8] = [0x0001, 0x0200, 0x03FF, 0x8001, 0x83FF, 0x0000, 0x8000, 0x0400]     # subnormals, signed zeros
+    lut = np.array([L.ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+    rows32 = lut[h]                                   # what the reference indexes for these halfvec values
+    img = oracle_image(dict(a, rows=rows32))
+    ix = IvfIndex(dim, nlists)
+    ix.set_centroids(a["centroids"])
+    ix.load_f16(a["list_len"], h, a["tids"])
+    q = _queries(a, 100, seed=dim)
+    q[0] = rows32[3]
+    for mode in (1, 2):
+        scan_mode(mode)
+        for strategy in (3, 1, 2):                    # config 5 is inner product
+            t, d, c = ix.search(q, strategy, 5, 10)
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, 5, 10)
+            assert_same_results(t, d, c, et, ed, ec)
