@@ -2090,7 +2090,6 @@ ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *
 	ix->pend_tids.push_back(ndb_tid_pack(tid6));
 	return NDBHIP_OK;
 }
-#define NDB_HAVE_APPEND 1
 
 static IvfDev
 ivf_dev(const ndbhip_ivf *ix)
@@ -2281,7 +2280,6 @@ ivf_check_search_args(ndbhip_ivf *ix, int nq, int nprobe, int k)
 }
 
 /* per-sub-batch budget for the candidate-distance buffer */
-#define NDB_DIST_BUDGET_DECLARED 1
 static size_t g_dist_budget_bytes = (size_t) 2 << 30;
 
 static int
@@ -2612,7 +2610,6 @@ ndbhip_batch_distance(const float *queries, const float *vectors, float *results
 /* IVF build: k-means (ivf_am.c:2070-2294), insert-time assignment     */
 /* (:905-935), list packing                                            */
 /* ================================================================== */
-#define NDB_HAVE_BUILD 1
 #define NDB_CGROUP 64			/* centroids handled by one wave */
 
 /*
@@ -3480,7 +3477,6 @@ ndbhip_ivf_ncentroids(const ndbhip_ivf *ix)
 /* ================================================================== */
 /* HNSW: hnswSearch (src/index/hnsw_am.c:1545-2080)                    */
 /* ================================================================== */
-#define NDB_HAVE_HNSW 1
 
 struct HnswDev
 {
@@ -4407,44 +4403,3 @@ ndbhip_extract_vector(int kind, const void *datum, size_t datum_len, float *out,
 			return fail(NDBHIP_ERR_UNSUPPORTED, "ivf: unsupported type kind %d", kind);
 	}
 }
-
-/* ================================================================== */
-/* entry points implemented in later sections of this file            */
-/* ================================================================== */
-#ifndef NDB_HAVE_APPEND
-extern "C" int
-ndbhip_ivf_append(ndbhip_ivf *, int, const float *, const uint8_t *)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_ivf_append: not implemented in this build");
-}
-#endif
-#ifndef NDB_HAVE_HNSW
-extern "C" int
-ndbhip_hnsw_create(int, int, ndbhip_hnsw **)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
-}
-extern "C" int
-ndbhip_hnsw_destroy(ndbhip_hnsw *)
-{
-	return NDBHIP_OK;
-}
-extern "C" int
-ndbhip_hnsw_load(ndbhip_hnsw *, uint32_t, const float *, const int32_t *, const int16_t *, const int64_t *,
-				 const uint32_t *, const uint8_t *, uint32_t, int)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
-}
-extern "C" int
-ndbhip_hnsw_search(ndbhip_hnsw *, const float *, int, int, int, int, uint32_t *, float *, int *, uint8_t *,
-				   int64_t *)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
-}
-extern "C" int
-ndbhip_hnsw_search_device(ndbhip_hnsw *, const float *, int, int, int, int, uint32_t *, float *, int *,
-						  uint64_t *, int64_t *)
-{
-	return fail(NDBHIP_ERR_UNSUPPORTED, "ndbhip_hnsw_*: not implemented in this build");
-}
-#endif

@@ -319,35 +319,6 @@ score_rows_f16(const float *__restrict__ q, const float *__restrict__ base16, ui
 	return acc.fin();
 }
 
-/* Split form of stage_chunk for software pipelining: issue the 16 global loads of a chunk early
- * (load_chunk), and pass them through the LDS tile later (commit_chunk). */
-__device__ __forceinline__ void
-load_chunk(float4 (&v)[16], const float *__restrict__ base, const uint32_t (&rows16)[16],
-		   int dim, int c, int grp, int slot)
-{
-#pragma unroll
-	for (int i = 0; i < 16; i++)
-	{
-		const int	r = 4 * i + grp;
-		const int	piece = slot ^ (r & 15);
-
-		v[i] = *reinterpret_cast<const float4 *>(base + (size_t) rows16[i] * (size_t) dim + c + piece * 4);
-	}
-}
-
-__device__ __forceinline__ void
-commit_chunk(float4 (&x)[16], const float4 (&v)[16], float *tile, int lane, int grp, int slot)
-{
-#pragma unroll
-	for (int i = 0; i < 16; i++)
-		*reinterpret_cast<float4 *>(tile + (4 * i + grp) * NDB_CHUNK + slot * 4) = v[i];
-	wave_lds_sync();
-#pragma unroll
-	for (int p = 0; p < 16; p++)
-		x[p] = *reinterpret_cast<const float4 *>(tile + lane * NDB_CHUNK + ((p ^ (lane & 15)) * 4));
-	wave_lds_sync();
-}
-
 /* One 64-row x 64-float step: stage through LDS, then every lane walks its row.
  * FULL = the chunk lies completely inside the row (no per-piece bounds checks). */
 template <int R, bool FULL>
