@@ -185,7 +185,7 @@ def main():
     qps = nq * args.steps / elapsed
 
     # ---------------- roofline of the dominant kernel ----------------
-    grouped = (nq >= 64 and dim % 64 == 0)
+    grouped = (nq >= 8 and dim % 64 == 0)
     kernel = "k_ivf_scan_grouped<R_IVF_L2>" if grouped else "k_ivf_scan<R_IVF_L2>"
     launches = max(1, st["scan_launches"])
     bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B per query

@@ -89,7 +89,7 @@ int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);
 int			ndbhip_profile(int on);			/* bracket the dominant kernel with HIP events */
 /* List-scan kernel choice (results are bit-identical either way): 0 = auto
- * (query-grouped scan for batches of >= 64 queries when dim % 64 == 0, per-query
+ * (query-grouped scan for batches of >= 8 queries when dim % 64 == 0, per-query
  * scan otherwise), 1 = always per-query, 2 = always grouped. */
 int			ndbhip_set_scan_mode(int mode);
 

@@ -52,9 +52,11 @@ fail(int code, const char *fmt, ...)
 						hipGetErrorString(_e), __FILE__, __LINE__);                \
 	} while (0)
 
-/* list-scan kernel choice: 0 auto (grouped for batches >= 64 queries and dim % 64 == 0),
+/* list-scan kernel choice: 0 auto (grouped for batches >= NDB_GROUPED_MIN_NQ queries and dim % 64 == 0),
  * 1 always per-query (k_ivf_scan), 2 always grouped (k_ivf_scan_grouped) */
 static int	g_scan_mode = 0;
+/* measured crossover on MI355X (tools/batch_sweep.py, 1M x 768, probes 32): per-query wins only below 8 queries */
+#define NDB_GROUPED_MIN_NQ 8
 /* rows staged per step by the grouped kernels: 64 floats (16 KiB tile, 3 waves/SIMD) or 32 (8 KiB, 4 waves/SIMD);
  * NDBHIP_GCHUNK overrides for experiments */
 static int	g_gchunk = 32;
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(256) void
 k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int ncent, int npr,
 			   const uint32_t *__restrict__ glob_len, const uint8_t *__restrict__ owned, uint64_t cap,
 			   int dim, int *__restrict__ probes, uint32_t *__restrict__ cand_off,
-			   unsigned long long *__restrict__ counters)
+			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters)
 {
 	__shared__ uint32_t hist[256];
 	__shared__ uint32_t sh[16];
@@ -758,8 +760,11 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 	{
 		uint64_t	acc = 0, mine = 0;
 		uint32_t   *co = cand_off + (size_t) q * (npr + 1);
+		uint32_t   *lco = loc_cand_off ? loc_cand_off + (size_t) q * (npr + 1) : nullptr;
 
 		co[0] = 0;
+		if (lco)
+			lco[0] = 0;
 		for (int i = 0; i < npr; i++)
 		{
 			uint64_t	l = lens[i];
@@ -770,6 +775,8 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			if (l > 0 && owned[selc[i]])
 				mine += l;
 			co[i + 1] = (uint32_t) acc;
+			if (lco)			/* positions of the rows THIS rank holds (sharded mirrors) */
+				lco[i + 1] = (uint32_t) mine;
 		}
 		if (counters)
 		{
@@ -802,19 +809,19 @@ find_probe(const uint32_t *__restrict__ co, int npr, uint32_t pos)
  * HOT LOOP 2: score every entry of every probed list (ivf_am.c:1810-1834).
  * candidates[] position pos = cand_off[p] + index inside list probes[p].
  * grid = (ceil(stride / 256), nq), block = 256 = 4 independent 64-row tiles.
- * Writes dist[q * stride + pos]; rows of lists this rank does not hold get
- * NDB_ABSENT_BITS.
+ * Writes dist[q * stride + local pos]; on a sharded mirror the positions count only
+ * the rows held here (loc_cand_off), so a rank's scan and top-k cost what its lists cost.
  */
 template <int R>
 __global__ __launch_bounds__(256) void
 k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
-		   const uint32_t *__restrict__ cand_off, int npr, float *__restrict__ dist, uint32_t stride)
+		   const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride)
 {
 	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t q = blockIdx.y;
-	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);	/* rows held here, in candidates[] order */
 	const uint32_t total = co[npr];
 	const uint32_t pos0 = (blockIdx.x * 4 + wave) * 64;
 
@@ -825,33 +832,25 @@ k_ivf_scan(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 	const uint32_t spos = valid ? pos : (total - 1);
 	const uint32_t p = find_probe(co, npr, spos);
 	const int	L = probes[(size_t) q * npr + p];
-	const bool	own = ix.owned[L] != 0;
-	const uint32_t row = own ? (uint32_t) (ix.loc_off[L] + (spos - co[p])) : 0u;
-
-	if (__ballot(valid && own) == 0ull)
-	{
-		if (valid)
-			dist[(size_t) q * stride + pos] = __uint_as_float(NDB_ABSENT_BITS);
-		return;
-	}
+	const uint32_t row = (uint32_t) (ix.loc_off[L] + (spos - co[p]));
 	const float d = score_rows<R>(queries + (size_t) q * ix.dim, ix.vecs, row, ix.dim,
 								  tiles + wave * NDB_TILE_FLOATS);
 
 	if (valid)
-		dist[(size_t) q * stride + pos] = own ? d : __uint_as_float(NDB_ABSENT_BITS);
+		dist[(size_t) q * stride + pos] = d;
 }
 
 /* the same for fp16 rows (halfvec columns) */
 template <int R>
 __global__ __launch_bounds__(256) void
 k_ivf_scan_h(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
-		   const uint32_t *__restrict__ cand_off, int npr, float *__restrict__ dist, uint32_t stride)
+		   const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride)
 {
 	__shared__ __attribute__((aligned(16))) float tiles[4 * NDB_TILE_FLOATS];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t q = blockIdx.y;
-	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);	/* rows held here, in candidates[] order */
 	const uint32_t total = co[npr];
 	const uint32_t pos0 = (blockIdx.x * 4 + wave) * 64;
 
@@ -862,20 +861,12 @@ k_ivf_scan_h(IvfDev ix, const float *__restrict__ queries, const int *__restrict
 	const uint32_t spos = valid ? pos : (total - 1);
 	const uint32_t p = find_probe(co, npr, spos);
 	const int	L = probes[(size_t) q * npr + p];
-	const bool	own = ix.owned[L] != 0;
-	const uint32_t row = own ? (uint32_t) (ix.loc_off[L] + (spos - co[p])) : 0u;
-
-	if (__ballot(valid && own) == 0ull)
-	{
-		if (valid)
-			dist[(size_t) q * stride + pos] = __uint_as_float(NDB_ABSENT_BITS);
-		return;
-	}
+	const uint32_t row = (uint32_t) (ix.loc_off[L] + (spos - co[p]));
 	const float d = score_rows_f16<R>(queries + (size_t) q * ix.dim, ix.vecs, row, ix.dim,
-									  tiles + wave * NDB_TILE_FLOATS);
+								  tiles + wave * NDB_TILE_FLOATS);
 
 	if (valid)
-		dist[(size_t) q * stride + pos] = own ? d : __uint_as_float(NDB_ABSENT_BITS);
+		dist[(size_t) q * stride + pos] = d;
 }
 
 /* ------------------------------------------------------------------ */
@@ -1065,25 +1056,6 @@ k_group_pack(const float *__restrict__ queries, int dim, int ncent, const uint32
 		dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
-/* positions of lists this rank does not hold: mark absent (sharded search only) */
-__global__ void
-k_mark_absent(const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr, uint32_t nq,
-			  const uint8_t *__restrict__ owned, float *__restrict__ dist, uint32_t stride)
-{
-	const uint32_t q = blockIdx.y;
-	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
-
-	for (int p = 0; p < npr; p++)
-	{
-		const uint32_t a = co[p], b = co[p + 1];
-
-		if (a == b || owned[probes[(size_t) q * npr + p]])
-			continue;
-		for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x)
-			dist[(size_t) q * stride + i] = __uint_as_float(NDB_ABSENT_BITS);
-	}
-}
-
 typedef float ndb_f2 __attribute__((ext_vector_type(2)));
 typedef float ndb_f16 __attribute__((ext_vector_type(16)));
 
@@ -1235,7 +1207,7 @@ k_query_norms(const float *__restrict__ queries, uint32_t nq, int dim, float *__
 template <int R, int CH, bool H16>
 __global__ __launch_bounds__(64, (H16 ? 4 : (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD))) void
 k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ cand_off,
-				   int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
+				   const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 				   float *__restrict__ dist, uint32_t stride, const float *__restrict__ qnorm)
@@ -1360,10 +1332,11 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				const uint32_t qid = mem[j].q;
 				const uint32_t pp = mem[j].p;
 				const uint32_t *co = cand_off + (size_t) qid * (npr + 1);
-				const uint32_t a = co[pp], nrow = co[pp + 1] - a;	/* may be capped below len (ivf_am.c:1743) */
+				const uint32_t nrow = co[pp + 1] - co[pp];	/* may be capped below len (ivf_am.c:1743) */
+				const uint32_t la = loc_cand_off[(size_t) qid * (npr + 1) + pp];
 
 				if (ridx < nrow)
-					dist[(size_t) qid * stride + a + ridx] = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
+					dist[(size_t) qid * stride + la + ridx] = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
 			}
 		}
 	}
@@ -1445,8 +1418,8 @@ topk_entry_cap(uint32_t k)
  * partial != 0: emit the tie-complete subset for the shard merge instead of results.
  */
 __global__ __launch_bounds__(256) void
-k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr,
-		   const float *__restrict__ dist, uint32_t stride, uint32_t k, int partial,
+k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict__ cand_off,
+		   const uint32_t *__restrict__ loc_cand_off, int npr, const float *__restrict__ dist, uint32_t stride, uint32_t k, int partial,
 		   ndbhip_cand *__restrict__ out_cand, int *__restrict__ out_ncand, int64_t *__restrict__ out_total,
 		   uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count)
 {
@@ -1455,21 +1428,25 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 	TopkSmem	s = carve_topk_smem(smem_raw, ecap, k);
 	const uint32_t q = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
-	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
-	const uint32_t total = co[npr];
+	const uint32_t *co = cand_off + (size_t) q * (npr + 1);		/* positions in the reference's candidates[] */
+	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);	/* positions among the rows held here */
+	const uint32_t gtotal = co[npr];
+	const uint32_t total = lco[npr];
 	const float *d = dist + (size_t) q * stride;
 	uint32_t	ns = 0;
 	bool		have = false;
 
 	auto		ld = [&](uint32_t i, uint32_t &bits) -> bool {
 		bits = __float_as_uint(d[i]);
-		return bits != NDB_ABSENT_BITS;
+		return true;
 	};
-	auto		tid_of = [&](uint32_t i) -> uint64_t {
-		const uint32_t p = find_probe(co, npr, i);
+	/* local position -> (TID, position in candidates[]) */
+	auto		tid_of = [&](uint32_t i, uint32_t &gpos) -> uint64_t {
+		const uint32_t p = find_probe(lco, npr, i);
 		const int	L = probes[(size_t) q * npr + p];
 
-		return ix.tids[ix.loc_off[L] + (i - co[p])];
+		gpos = co[p] + (i - lco[p]);
+		return ix.tids[ix.loc_off[L] + (i - lco[p])];
 	};
 
 	if (k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
@@ -1484,16 +1461,15 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 			const uint32_t b0 = __float_as_uint(d[i]), b1 = __float_as_uint(d[i + 256]);
 			const uint32_t b2 = __float_as_uint(d[i + 512]), b3 = __float_as_uint(d[i + 768]);
 
-			if (b0 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b0)); nvalid++; }
-			if (b1 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b1)); nvalid++; }
-			if (b2 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b2)); nvalid++; }
-			if (b3 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b3)); nvalid++; }
+			mn = min(min(mn, ndb_key_from_bits(b0)), min(ndb_key_from_bits(b1), min(ndb_key_from_bits(b2), ndb_key_from_bits(b3))));
+			nvalid += 4;
 		}
 		for (; i < total; i += 256)
 		{
 			const uint32_t b0 = __float_as_uint(d[i]);
 
-			if (b0 != NDB_ABSENT_BITS) { mn = min(mn, ndb_key_from_bits(b0)); nvalid++; }
+			mn = min(mn, ndb_key_from_bits(b0));
+			nvalid++;
 		}
 		/* sort the 256 minima; threads without a candidate carry 0xFFFFFFFF and sort last */
 		const uint32_t nth = (uint32_t) __syncthreads_count(nvalid > 0);
@@ -1514,7 +1490,7 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		{
 			const uint32_t b0 = __float_as_uint(d[i]);
 
-			if (b0 != NDB_ABSENT_BITS && ndb_key_from_bits(b0) <= U)
+			if (ndb_key_from_bits(b0) <= U)
 			{
 				const uint32_t slot = atomicAdd(&s.sh[0], 1u);
 
@@ -1534,7 +1510,12 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 			ns = got;
 			have = true;
 			for (uint32_t j = tid; j < ns; j += 256)
-				s.e_id[j] = tid_of(s.e_pos[j]);
+			{
+				uint32_t	gpos;
+
+				s.e_id[j] = tid_of(s.e_pos[j], gpos);
+				s.e_pos[j] = gpos;
+			}
 			__syncthreads();
 		}
 	}
@@ -1552,9 +1533,11 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 			auto		emit = [&](int cls, uint32_t rank, uint32_t i, uint32_t bits) {
 				const uint32_t slot = cls ? (m_less + rank) : rank;
 
+				uint32_t	gpos;
+
 				s.e_bits[slot] = bits;
-				s.e_pos[slot] = i;
-				s.e_id[slot] = tid_of(i);
+				s.e_id[slot] = tid_of(i, gpos);
+				s.e_pos[slot] = gpos;
 			};
 			block_ordered_gather(ld, total, T, n_eq, s.sh, emit);
 		}
@@ -1564,7 +1547,7 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 	/* number of candidates this rank holds = what bounds kk locally; globally `total` */
 	uint32_t	kk;
 	const uint32_t npad = next_pow2(ns > 0 ? ns : 1);
-	const uint32_t cut = block_sort_cut(s.e_bits, s.e_pos, ns, npad, k, partial ? (uint64_t) ns : (uint64_t) total,
+	const uint32_t cut = block_sort_cut(s.e_bits, s.e_pos, ns, npad, k, partial ? (uint64_t) ns : (uint64_t) gtotal,
 										s.fs, kk);
 
 	if (partial)
@@ -1582,7 +1565,7 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		if (tid == 0)
 		{
 			out_ncand[q] = (int) cut;
-			out_total[q] = (int64_t) total;
+			out_total[q] = (int64_t) gtotal;
 		}
 		return;
 	}
@@ -1964,6 +1947,28 @@ ndbhip_ivf_max_candidates(const ndbhip_ivf *ix, int nprobe)
 	return s;
 }
 
+/* the same bound over the rows THIS mirror holds: sizes the candidate-distance buffer */
+static int64_t
+ivf_local_max_candidates(const ndbhip_ivf *ix, int nprobe)
+{
+	if (!ix->sharded)
+		return ndbhip_ivf_max_candidates(ix, nprobe);
+	std::vector<int64_t> v(ix->glob_len.size());
+
+	for (size_t i = 0; i < v.size(); i++)
+		v[i] = ix->owned[i] ? ix->glob_len[i] : 0;
+	int			n = std::min<int>(nprobe, (int) v.size());
+
+	std::partial_sort(v.begin(), v.begin() + n, v.end(), std::greater<int64_t>());
+	int64_t		s = 0;
+
+	for (int i = 0; i < n; i++)
+		s += v[i];
+	if (nprobe > n && !v.empty() && ix->owned[0])
+		s += (int64_t) (nprobe - n) * ix->glob_len[0];
+	return s;
+}
+
 /*
  * Fold the pending aminsert entries into the packed layout: every list keeps its
  * old rows in place order and gains its new entries at the tail, in arrival order —
@@ -2143,6 +2148,13 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const IvfDev d = ivf_dev(ix);
 	const int	ncmp = std::min(ix->nlists, ix->ncent);
 	const uint32_t cstride = (uint32_t) ((ncmp + 63) & ~63);
+	/*
+	 * Two position spaces: cand_off = place in the reference's candidates[] (what the selection
+	 * replay orders by); lco = place among the rows held HERE (what addresses w_dist).  They only
+	 * differ on a sharded mirror, whose scan / top-k then cost what its own lists cost.
+	 */
+	uint32_t   *lco_w = ix->sharded ? ix->w_candoff + (size_t) nq * (npr + 1) : nullptr;
+	const uint32_t *lco = ix->sharded ? lco_w : ix->w_candoff;
 
 	/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680) */
 	{
@@ -2154,7 +2166,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
 					   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
 					   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4), ix->w_probes,
-					   ix->w_candoff, full ? g.d_counters : (unsigned long long *) nullptr);
+					   ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
 	HIP_TRY(hipGetLastError());
 	if (!full)
 		return 0;
@@ -2162,7 +2174,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	/* HOT LOOP 2 */
 	const int	R = ivf_recipe(strategy);
 	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
-		(g_scan_mode == 2 || (g_scan_mode == 0 && nq >= 64));
+		(g_scan_mode == 2 || (g_scan_mode == 0 && nq >= NDB_GROUPED_MIN_NQ));
 
 	if (grouped)
 	{
@@ -2186,10 +2198,6 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		hipLaunchKernelGGL(k_group_pack, dim3((ix->dim + 255) / 256, maxgroups), dim3(256), 0, g.stream, d_q,
 						   ix->dim, nc, (const uint32_t *) cnt, (const uint32_t *) pair_off,
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, ix->w_qblock);
-		if (ix->sharded)
-			hipLaunchKernelGGL(k_mark_absent, dim3(8, nq), dim3(256), 0, g.stream, (const int *) ix->w_probes,
-							   (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq, (const uint8_t *) d.owned,
-							   ix->w_dist, stride);
 		const dim3	pgrid(g.num_cus * 10);	/* one wave per block; LDS admits 10 per CU */
 
 		if (R == R_IVF_COS)
@@ -2200,7 +2208,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 #define LAUNCH_GROUPED(RR, CC, GRID) LAUNCH_GROUPED_H(RR, CC, false, GRID)
 #define LAUNCH_GROUPED_H(RR, CC, HH, GRID)                                                                       \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_scan_grouped<RR, CC, HH>), GRID, dim3(64), 0, g.stream, d,    \
-						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, npr,                \
+						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, lco, npr,           \
 						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,   \
 						   stride, (const float *) ix->w_qnorm)
@@ -2244,18 +2252,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 		if (t.start()) return NDBHIP_ERR_HIP;
 		if (ix->f16)
-			LAUNCH_BY_RECIPE(R, k_ivf_scan_h, grid, dim3(256), d, d_q, (const int *) ix->w_probes,
-							 (const uint32_t *) ix->w_candoff, npr, ix->w_dist, stride);
+			LAUNCH_BY_RECIPE(R, k_ivf_scan_h, grid, dim3(256), d, d_q, (const int *) ix->w_probes, lco, npr,
+							 ix->w_dist, stride);
 		else
-			LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) ix->w_probes,
-							 (const uint32_t *) ix->w_candoff, npr, ix->w_dist, stride);
+			LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) ix->w_probes, lco, npr,
+							 ix->w_dist, stride);
 		if (t.stop()) return NDBHIP_ERR_HIP;
 	}
 	{
 		const size_t smem = topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k);
 
 		hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) ix->w_probes,
-						   (const uint32_t *) ix->w_candoff, npr, (const float *) ix->w_dist, stride,
+						   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
 						   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt);
 	}
 	HIP_TRY(hipGetLastError());
@@ -2299,7 +2307,7 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k) > NDB_TOPK_MAX_SMEM)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "k too large for the LDS top-k stage");
 
-	int64_t		maxc = ndbhip_ivf_max_candidates(ix, nprobe);
+	int64_t		maxc = ivf_local_max_candidates(ix, nprobe);
 
 	if (max_candidates > 0 && maxc > max_candidates)
 		maxc = max_candidates;
@@ -2314,13 +2322,13 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 
 	if (grow(ix->w_cdist, ix->w_cdist_n, (size_t) qb * cstride)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_probes, ix->w_probes_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) 2 * qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 4)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) qb)) return NDBHIP_ERR_HIP;
-	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= 64 || g_scan_mode == 2))
+	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode == 2))
 		if (grow(ix->w_qblock, ix->w_qblock_n,
 				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))
 			return NDBHIP_ERR_HIP;
@@ -2428,7 +2436,7 @@ ndbhip_ivf_select_clusters(ndbhip_ivf *ix, const float *queries, int nq, int npr
 	if (grow(ix->w_q, ix->w_q_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_cdist, ix->w_cdist_n, (size_t) std::min(qb, nq) * cstride)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_probes, ix->w_probes_n, (size_t) std::min(qb, nq) * nprobe)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) std::min(qb, nq) * (nprobe + 1))) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) 2 * std::min(qb, nq) * (nprobe + 1))) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(ix->w_q, queries, (size_t) nq * ix->dim * sizeof(float), hipMemcpyHostToDevice,
 						   g.stream));
 	for (int q0 = 0; q0 < nq; q0 += qb)

@@ -30,7 +30,6 @@
 #define NDB_HD
 #endif
 
-#define NDB_ABSENT_BITS 0xFFFFFFFFu	/* "row not held by this rank": never produced by arithmetic */
 
 NDB_HD static inline uint32_t
 ndb_f2u(float f)

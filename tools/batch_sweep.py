@@ -19,10 +19,10 @@ def main():
     _lib.ensure_init(0)
     n, dim, nlists, nprobe, k = 1_000_000, 768, 1024, 32, 10
     base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
-    q = make_data(4096, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    q = make_data(16384, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
     ix = IvfIndex(dim, nlists)
     ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
-    for nq in (1, 8, 16, 32, 64, 128, 256, 512, 1024, 4096):
+    for nq in (1, 8, 16, 32, 64, 128, 256, 512, 1024, 4096, 16384):
         ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
         od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
         oc = torch.zeros(nq, dtype=torch.int32, device=dev)
