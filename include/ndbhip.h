@@ -262,6 +262,19 @@ int			ndbhip_hnsw_load(ndbhip_hnsw *g, uint32_t nblocks, const float *vecs, cons
  * L2 and ef = k = ef_construction, as the reference does (quirk Q12). */
 int			ndbhip_hnsw_build_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 									 const int32_t *levels, int ef_construction);
+/* How the last ndbhip_hnsw_build_device ran: out[0] walks (one per insert and linked level), out[1] walks
+ * that had to run again because an earlier insert of their batch wrote a list they had read, out[2] walks
+ * whose read-set log overflowed, out[3] speculate+commit rounds, out[4] batches, out[5] largest batch.
+ * All zero after a sequential (one-wave) build. */
+int			ndbhip_hnsw_build_stats(const ndbhip_hnsw *g, int64_t out[6]);
+/* How ndbhip_hnsw_build_device schedules the inserts.  optimistic = 0: one wave inserts row after row.
+ * optimistic = 1 (default): the walks of up to min(batch_max, nodes so far / batch_div) inserts run in
+ * parallel against the graph as it stands and are committed in insert order up to the first walk that
+ * read a list an earlier insert of the batch has written since; the rest runs again in the next round.
+ * Both produce the same graph, slot for slot
+ * (defaults: batch_div 64, batch_max 1024). */
+int			ndbhip_hnsw_set_build_mode(int optimistic, int batch_div, int batch_max);
+
 /* Read the graph back in the dense 16-level layout (any pointer may be NULL):
  * levels [nblocks], ncount [nblocks*16], nbrs [nblocks*16*2m]. */
 int			ndbhip_hnsw_export(const ndbhip_hnsw *g, uint32_t *nblocks, int32_t *levels, int16_t *ncount,

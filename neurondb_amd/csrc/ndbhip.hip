@@ -60,6 +60,10 @@ static int	g_scan_mode = 0;
 /* rows staged per step by the grouped kernels: 64 floats (16 KiB tile, 3 waves/SIMD) or 32 (8 KiB, 4 waves/SIMD);
  * NDBHIP_GCHUNK overrides for experiments */
 static int	g_gchunk = 32;
+/* hnswbuild: optimistic batches (1) or the one-wave sequential kernel (0); batch = min(max, nodes so far / div) walks */
+static int	g_hnsw_spec = 1;
+static int	g_hnsw_batch_div = 64;
+static int	g_hnsw_batch_max = 1024;
 
 struct Ctx
 {
@@ -3580,17 +3584,187 @@ carve_hnsw_lds(unsigned char *sp, uint32_t ef, uint32_t k, uint32_t m)
  * ties) is then replayed in neighbour order.  Leaves candidates[0..cc) / their distances in L.cand /
  * L.cdist.  Returns false when the reference returns "no results" before level 0.
  */
-template <int R, bool MUT>
+/*
+ * Build-time scorer: the 64 lanes of the walking wave each hold (at most) one row to score; the whole
+ * 256-thread block scores them together, K = 4..16 threads per row, thread `part` summing the float4
+ * pieces part, part + K, ... of (double)(q - x)^2 in fp64 (a row's K threads read K consecutive float4 =
+ * one coalesced line per step, and all of a thread's loads are in flight at once: the walk is a chain of
+ * dependent fetches, so latency is what it costs).
+ *
+ * That is NOT the reference's summation order, so the result is only accepted when it provably cannot
+ * matter: every term is >= 0, hence any order of fp64 summation lies within n*u of the exact sum
+ * (u = 2^-53), so the sequential sum s* lies in [s(1-eps), s(1+eps)] with eps = 3*dim*u; sqrt and the
+ * narrowing to float are correctly rounded, hence monotone, so if (float)sqrt(s(1-eps)) ==
+ * (float)sqrt(s(1+eps)) that IS (float)sqrt(s*), bit for bit.  Otherwise (about 2e-6 of the rows) the
+ * lane redoes its row in the reference's order.
+ */
+struct HnswFast
+{
+	float	   *q;				/* [dim] the inserted vector, in LDS */
+	uint32_t   *rows;			/* [64] compacted rows to score */
+	uint32_t   *ctl;			/* [0] 1 = score, 0 = helpers may leave; [1] rows to score */
+	double	   *part;			/* [64 * 16] partial sums */
+};
+
+#define NDB_HNSW_FAST_MAX_DIM 1920	/* q + rows + ctl + part must fit the 16 KiB tile region */
+
+__device__ __forceinline__ HnswFast
+carve_hnsw_fast(float *tile, int dim)
+{
+	HnswFast	F;
+
+	F.part = (double *) tile;					/* 8 KiB */
+	F.rows = (uint32_t *) (tile + 2048);
+	F.ctl = F.rows + 64;
+	F.q = (float *) (F.ctl + 4);				/* 16-byte aligned: 8192 + 256 + 16 */
+	return F;
+}
+
+__device__ __forceinline__ void
+hnsw_fast_part(const float *__restrict__ vecs, int dim, const HnswFast &F)
+{
+	const uint32_t na = F.ctl[1];
+	const uint32_t r2 = next_pow2(na);
+	const uint32_t K = (256u / r2) > 16u ? 16u : (256u / r2);	/* a power of two, 4..16 */
+	const uint32_t part = threadIdx.x & (K - 1u);
+	const uint32_t slot = threadIdx.x / K;
+
+	if (slot >= na)
+		return;
+	const float4 *x = reinterpret_cast<const float4 *>(vecs + (size_t) F.rows[slot] * dim);
+	const float4 *q4 = reinterpret_cast<const float4 *>(F.q);
+	const int	nf4 = dim >> 2;
+	Acc<R_HNSW_L2> a;
+	constexpr int U = 12;
+
+	for (int f0 = (int) part; f0 < nf4; f0 += U * (int) K)
+	{
+		float4		buf[U];
+
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int	f = f0 + u * (int) K;
+
+			if (f < nf4)
+				buf[u] = x[f];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int	f = f0 + u * (int) K;
+
+			if (f < nf4)
+			{
+				const float4 qq = q4[f];
+
+				a.step(qq.x, buf[u].x);
+				a.step(qq.y, buf[u].y);
+				a.step(qq.z, buf[u].z);
+				a.step(qq.w, buf[u].w);
+			}
+		}
+	}
+	F.part[slot * 16u + part] = a.s;
+}
+
+/* helper waves of a build walk: score on demand until released */
+__device__ void
+hnsw_fast_helper(const float *__restrict__ vecs, int dim, const HnswFast &F)
+{
+	for (;;)
+	{
+		__syncthreads();
+		if (F.ctl[0] == 0u)
+			return;
+		hnsw_fast_part(vecs, dim, F);
+		__syncthreads();
+	}
+}
+
+/* the walking wave: this lane's row (if act) -> its float4 L2 distance to the inserted vector */
+__device__ float
+hnsw_fast_score(const float *__restrict__ vecs, int dim, const HnswFast &F, uint32_t row, bool act)
+{
+	const uint32_t lane = threadIdx.x;
+	const unsigned long long mask = __ballot(act);
+	const uint32_t na = (uint32_t) __popcll(mask);
+	const uint32_t slot = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+	float		r = 0.0f;
+
+	if (na == 0)
+		return r;
+	if (act)
+		F.rows[slot] = row;
+	if (lane == 0)
+	{
+		F.ctl[0] = 1u;
+		F.ctl[1] = na;
+	}
+	__syncthreads();
+	hnsw_fast_part(vecs, dim, F);
+	__syncthreads();
+	if (act)
+	{
+		const uint32_t r2 = next_pow2(na);
+		const uint32_t K = (256u / r2) > 16u ? 16u : (256u / r2);
+		double		s = 0.0;
+
+		for (uint32_t p = 0; p < K; p++)
+			s = s + F.part[slot * 16u + p];
+		const double eps = 3.0 * (double) dim * 1.1102230246251565e-16;
+		const float lo = (float) __builtin_sqrt(s * (1.0 - eps));
+		const float hi = (float) __builtin_sqrt(s * (1.0 + eps));
+
+		r = lo;
+		if (lo != hi)
+		{
+			Acc<R_HNSW_L2> a;
+			const float *x = vecs + (size_t) row * dim;
+
+			for (int d = 0; d < dim; d++)
+				a.step(F.q[d], x[d]);
+			r = a.fin();
+		}
+	}
+	return r;
+}
+
+#define NDB_HNSW_RS_CAP 256u		/* read-set entries logged per speculative walk */
+#define NDB_HNSW_RS_NODE_BITS 28
+
+template <int R, bool MUT, bool LOG = false, bool FAST = false>
 __device__ bool
 hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L, uint32_t &cc_out,
-		  long long &scored)
+		  long long &scored, uint32_t *__restrict__ rs = nullptr, uint32_t *rs_count = nullptr,
+		  const HnswFast *F = nullptr)
 {
+	static_assert(!FAST || R == R_HNSW_L2, "the block-cooperative scorer is the build's (always L2)");
+	/* this lane's row -> its distance; every lane of the wave calls it together */
+	auto		score = [&](uint32_t row, uint32_t idle_row, bool act) -> float {
+		if (FAST)
+			return hnsw_fast_score(g.vecs, g.dim, *F, row, act);
+		return score_rows<R>(q, g.vecs, act ? row : idle_row, g.dim, L.tile);
+	};
+	uint32_t	rs_local = 0;
+	uint32_t   &rs_n = LOG ? *rs_count : rs_local;	/* wave-uniform; the caller publishes it */
+
+	/* LOG: record every (node, level) whose neighbour list this walk reads — the only mutable data
+	 * a walk depends on (vectors and node levels never change once written) */
+	auto		log_read = [&](uint32_t node, int level) {
+		if (LOG)
+		{
+			if (threadIdx.x == 0 && rs_n < NDB_HNSW_RS_CAP)
+				rs[rs_n] = node | ((uint32_t) level << NDB_HNSW_RS_NODE_BITS);
+			rs_n++;
+		}
+	};
+
 	const uint32_t lane = threadIdx.x;
 	const int	m2 = 2 * g.m;
 	const uint32_t nblocks = g.nblocks;
 	uint32_t	cur = g.entry_point;
 	int			curLevel = g.entry_level;
-	float	   *tile = L.tile;
 	uint32_t   *cand = L.cand, *cdist = L.cdist, *visited = L.visited;
 
 	cc_out = 0;
@@ -3609,6 +3783,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 			found = false;
 			if (!hnsw_valid(nblocks, cur))
 				break;
+			log_read(cur, level);
 			const int	nc = (gload<MUT>(&g.levels[cur]) >= level)
 				? hnsw_clamp(gload<MUT>(&g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level]), g.m) : 0;
 			const uint32_t *nb = hnsw_nbr_base(g, cur) + (size_t) level * m2;
@@ -3621,7 +3796,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 				const int	j = j0 + (int) lane;
 				uint32_t	my = (j < 0) ? node : ((j < nc) ? gload<MUT>(&nb[j]) : NDBHIP_INVALID_BLOCK);
 				const bool	act = hnsw_valid(nblocks, my);
-				const float d = score_rows<R>(q, g.vecs, act ? my : node, g.dim, tile);
+				const float d = score(my, node, act);
 				const unsigned long long am = __ballot(act);
 
 				scored += __popcll(am);
@@ -3655,7 +3830,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 	/* ---- level 0 (:1765-1975) ---- */
 	uint32_t	cc = 1, vc = 1;
 	{
-		const float d0 = score_rows<R>(q, g.vecs, cur, g.dim, tile);
+		const float d0 = score(cur, cur, lane == 0);
 
 		scored += 1;
 		if (lane == 0)
@@ -3672,6 +3847,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 
 		if (!hnsw_valid(nblocks, c))
 			continue;
+		log_read(c, 0);
 		const int	nc = hnsw_clamp(gload<MUT>(&g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + 0]), g.m);
 		const uint32_t *nb = hnsw_nbr_base(g, c);
 
@@ -3702,7 +3878,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 
 			if (mask0 == 0ull)
 				continue;
-			const float d = score_rows<R>(q, g.vecs, ok ? my : c, g.dim, tile);
+			const float d = score(my, c, ok);
 			unsigned long long mask = mask0;
 
 			scored += __popcll(mask0);
@@ -3768,7 +3944,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 __device__ uint32_t
 hnsw_topk(HnswLds &L, uint32_t cc, uint32_t k, float *out_dist)
 {
-	for (uint32_t t = threadIdx.x; t < cc; t += 64)
+	for (uint32_t t = threadIdx.x; t < cc; t += blockDim.x)
 	{
 		L.e_pos[t] = t;
 		L.e_id[t] = L.cand[t];
@@ -3938,6 +4114,326 @@ k_hnsw_build(float *vecs, int *levels_out, int16_t *ncount, uint32_t *nbrs, uint
 	}
 }
 
+/* ------------------------------------------------------------------ */
+/* Optimistic batched hnswbuild                                         */
+/*                                                                      */
+/* hnswInsertNode is sequential by definition: insert i searches the    */
+/* graph inserts 0..i-1 left.  But a walk only READS the neighbour      */
+/* lists of the few nodes it passes (descent path + the level-0 nodes   */
+/* it expands), and an insert only WRITES the lists of the <= m nodes   */
+/* it back-links (and not even those once they are full).  So a batch   */
+/* of inserts proceeds in ROUNDS:                                       */
+/*   speculate  every not yet committed walk whose result is missing or */
+/*              stale runs, one wave each and all in parallel, against  */
+/*              the graph as it stands, logging the (node, level) lists */
+/*              it read;                                                */
+/*   commit     ONE wave applies the walks' selections in insert order  */
+/*              for as long as every list a walk read is unwritten      */
+/*              since that walk ran — such a walk saw exactly the graph */
+/*              the sequential run would have shown it — and stops at   */
+/*              the first stale one, which the next round redoes.       */
+/* The first walk of a round's commit ran in that very round with       */
+/* nothing written since, so every round commits at least one walk; the */
+/* result is the sequential graph, slot for slot (tests: device build   */
+/* == oracle).  A "walk" is one (insert, level) pair = one hnswSearch   */
+/* call of hnswInsertNode's level loop (:2360-2520).  Staleness is      */
+/* tracked per node in two classes, level 0 and levels >= 1: stamp[c]   */
+/* [node] = the last round that wrote such a list.                      */
+/* ------------------------------------------------------------------ */
+
+struct HnswTask
+{
+	uint32_t	row;			/* heap row i; its node is block i + 1 */
+	int32_t		cl;				/* level being linked */
+};
+
+/* Step 4 (:2288-2332) for every row at once: a node page is unreachable until its own insert links it,
+ * and nobody writes into it before that (back-links only go to older nodes). */
+__global__ __launch_bounds__(256) void
+k_hnsw_init_nodes(float *vecs, int *levels_out, int16_t *ncount, uint32_t *nbrs, uint64_t *tids_out,
+				  const float *__restrict__ rows, const uint64_t *__restrict__ tids_in,
+				  const int *__restrict__ levels_in, uint32_t n, int dim, int64_t stride)
+{
+	const uint32_t i = blockIdx.x;
+	const uint32_t blk = i + 1;
+
+	if (i >= n)
+		return;
+	for (int j = threadIdx.x; j < dim; j += 256)
+		vecs[(size_t) blk * dim + j] = rows[(size_t) i * dim + j];
+	for (int64_t j = threadIdx.x; j < stride; j += 256)
+		nbrs[(size_t) blk * stride + j] = NDBHIP_INVALID_BLOCK;
+	if (threadIdx.x < NDBHIP_HNSW_MAX_LEVEL)
+		ncount[(size_t) blk * NDBHIP_HNSW_MAX_LEVEL + threadIdx.x] = 0;
+	if (threadIdx.x == 0)
+	{
+		int			level = levels_in[i];
+
+		if (level >= NDBHIP_HNSW_MAX_LEVEL) level = NDBHIP_HNSW_MAX_LEVEL - 1;
+		if (level < 0) level = 0;
+		levels_out[blk] = level;
+		tids_out[blk] = tids_in[i];
+	}
+}
+
+/* per-batch state of the rounds */
+struct HnswRounds
+{
+	uint32_t   *next;			/* [1] first uncommitted walk of the batch */
+	uint32_t   *spec_round;		/* [batch] round each walk last ran in (0 = never) */
+	uint32_t   *sel;			/* [batch * ksel] its selection */
+	int		   *nsel;			/* [batch] */
+	uint32_t   *rs;				/* [batch * NDB_HNSW_RS_CAP] its read set */
+	uint32_t   *rsn;			/* [batch] entries logged (> cap: overflowed, never validates) */
+	uint32_t   *stamp0;			/* [nblocks] last round that wrote the node's level-0 list */
+	uint32_t   *stampU;			/* [nblocks] ... one of its upper-level lists */
+	unsigned long long *stats;	/* [0] walks run, [1] commit stops on a stale walk, [2] read-set overflows */
+};
+
+/* has any list this walk read been written in round `since` or later? (wave-uniform) */
+template <bool MUT>
+__device__ __forceinline__ bool
+hnsw_walk_is_stale(const HnswRounds &R, uint32_t t, uint32_t since)
+{
+	const uint32_t rsn = R.rsn[t];
+
+	if (rsn > NDB_HNSW_RS_CAP)
+		return true;
+	for (uint32_t e0 = 0; e0 < rsn; e0 += 64)
+	{
+		bool		hit = false;
+
+		if (e0 + (threadIdx.x & 63u) < rsn)	/* every wave of the block checks the whole log */
+		{
+			const uint32_t enc = R.rs[(size_t) t * NDB_HNSW_RS_CAP + e0 + (threadIdx.x & 63u)];
+			const uint32_t node = enc & ((1u << NDB_HNSW_RS_NODE_BITS) - 1u);
+			const uint32_t *st = (enc >> NDB_HNSW_RS_NODE_BITS) ? R.stampU : R.stamp0;
+
+			hit = gload<MUT>(&st[node]) >= since;
+		}
+		if (__ballot(hit) != 0ull)
+			return true;
+	}
+	return false;
+}
+
+/*
+ * One block per walk of the batch: (re)run it if it is uncommitted and has no valid result.  Wave 0 walks;
+ * FAST: three more waves help it score (hnsw_fast_score), else the block is that one wave.
+ */
+template <bool FAST>
+__global__ __launch_bounds__(FAST ? 256 : 64) void
+k_hnsw_spec(HnswDev g, const float *__restrict__ rows, const HnswTask *__restrict__ tasks, uint32_t efc,
+			uint32_t ksel, HnswRounds R, uint32_t round)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	const uint32_t t = blockIdx.x;
+
+	if (t < *R.next)
+		return;
+	const uint32_t ran = R.spec_round[t];
+
+	if (ran != 0 && !hnsw_walk_is_stale<false>(R, t, ran))	/* block-uniform: every wave sees the same lists */
+		return;
+	HnswLds		L = carve_hnsw_lds(smem_raw, efc, efc, (uint32_t) g.m);
+	const HnswTask task = tasks[t];
+	const float *q = rows + (size_t) task.row * g.dim;
+	HnswFast	F = carve_hnsw_fast(L.tile, g.dim);
+
+	if (FAST)
+	{
+		for (int d = threadIdx.x; d < g.dim; d += 256)
+			F.q[d] = q[d];
+		if (threadIdx.x == 0)
+			F.ctl[0] = 1u;
+		__syncthreads();
+	}
+	long long	scored = 0;
+	uint32_t	cc = 0, rsn = 0;
+	bool		ok = false;
+
+	g.nblocks = task.row + 2;	/* the relation ends at this row's own page */
+	if (FAST && threadIdx.x >= 64)
+		hnsw_fast_helper(g.vecs, g.dim, F);
+	else
+	{
+		ok = hnsw_walk<R_HNSW_L2, false, true, FAST>(g, q, efc, L, cc, scored,
+													   R.rs + (size_t) t * NDB_HNSW_RS_CAP, &rsn, &F);
+		if (FAST)
+		{
+			if (threadIdx.x == 0)
+			{
+				F.ctl[0] = 0u;
+				F.ctl[2] = ok ? 1u : 0u;
+				F.ctl[3] = cc;
+			}
+			__syncthreads();	/* releases the helpers */
+		}
+	}
+	if (FAST)
+	{
+		ok = F.ctl[2] != 0u;	/* the whole block selects together */
+		cc = F.ctl[3];
+	}
+	uint32_t	kk = 0;
+
+	if (ok)
+		kk = hnsw_topk(L, cc, ksel, (float *) L.fs.curpos);
+	for (uint32_t i = threadIdx.x; i < kk; i += blockDim.x)
+		R.sel[(size_t) t * ksel + i] = L.cand[L.fs.perm[L.fs.order[i]]];
+	if (threadIdx.x == 0)
+	{
+		R.nsel[t] = (int) kk;
+		R.rsn[t] = rsn;
+		R.spec_round[t] = round;
+		atomicAdd(&R.stats[0], 1ull);
+		if (rsn > NDB_HNSW_RS_CAP)
+			atomicAdd(&R.stats[2], 1ull);
+	}
+}
+
+template <class T>
+__device__ __forceinline__ void
+gstore(T *p, T v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* publish this wave's global writes to its own later (cache-bypassing) reads */
+__device__ __forceinline__ void
+hnsw_publish()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+/*
+ * The linking half of one level of hnswInsertNode (:2416-2520): node blk takes sel[0..nsel) as its level-cl
+ * neighbours, and every selected node gets blk written into the first InvalidBlockNumber slot among its
+ * first `count` level-cl slots, else appended (dropped when the 2m slots are full).  The selected nodes are
+ * distinct (the walk never scores a block twice), so the back-links are independent and run one per lane —
+ * unless blk selected ITSELF (reachable through its own upper-level back-links, quirk Q12), where the
+ * reference's statement order decides which write survives: that case is replayed by one lane in order.
+ * Every list actually written is stamped with `round`; a back-link dropped because the list is full writes
+ * nothing — which is what keeps saturated hub nodes from serialising the build.
+ */
+__device__ void
+hnsw_link(uint32_t *nbrs, int16_t *ncount, uint32_t blk, int cl, int m, int64_t stride, const uint32_t *sel,
+		  uint32_t nsel, uint32_t *stamp0, uint32_t *stampU, uint32_t round)
+{
+	const uint32_t lane = threadIdx.x;
+	const int	m2 = 2 * m;
+	uint32_t   *newn = nbrs + (size_t) blk * stride + (size_t) cl * m2;
+	int16_t    *newc = &ncount[(size_t) blk * NDBHIP_HNSW_MAX_LEVEL + cl];
+	uint32_t   *stamp = cl ? stampU : stamp0;
+	bool		self = false;
+
+	if (nsel == 0)
+		return;
+	for (uint32_t i0 = 0; i0 < nsel; i0 += 64)
+		self = self || __ballot(i0 + lane < nsel && sel[i0 + lane] == blk) != 0ull;
+	if (self)
+	{
+		if (lane == 0)
+			for (uint32_t idx = 0; idx < nsel; idx++)
+			{
+				const uint32_t nbk = sel[idx];
+				uint32_t   *nn = nbrs + (size_t) nbk * stride + (size_t) cl * m2;
+				int16_t    *ncp = &ncount[(size_t) nbk * NDBHIP_HNSW_MAX_LEVEL + cl];
+
+				gstore(&newn[idx], nbk);			/* :2452-2456 */
+				gstore(newc, (int16_t) (idx + 1));
+				const int	cnt = hnsw_clamp(gload<true>(ncp), m);
+				int			pos = cnt;
+
+				for (int j = 0; j < cnt; j++)
+					if (gload<true>(&nn[j]) == NDBHIP_INVALID_BLOCK)
+					{
+						pos = j;
+						break;
+					}
+				if (pos < m2)
+				{
+					gstore(&nn[pos], blk);
+					if (pos >= cnt)
+						gstore(ncp, (int16_t) (pos + 1));
+					gstore(&stamp[nbk], round);
+				}
+			}
+	}
+	else
+	{
+		for (uint32_t i0 = 0; i0 < nsel; i0 += 64)
+		{
+			const uint32_t idx = i0 + lane;
+
+			if (idx < nsel)
+			{
+				const uint32_t nbk = sel[idx];
+				uint32_t   *nn = nbrs + (size_t) nbk * stride + (size_t) cl * m2;
+				int16_t    *ncp = &ncount[(size_t) nbk * NDBHIP_HNSW_MAX_LEVEL + cl];
+				const int	cnt = hnsw_clamp(gload<true>(ncp), m);
+				int			pos = cnt;
+
+				gstore(&newn[idx], nbk);
+				for (int j = cnt - 1; j >= 0; j--)	/* first invalid slot = the lowest one */
+					if (gload<true>(&nn[j]) == NDBHIP_INVALID_BLOCK)
+						pos = j;
+				if (pos < m2)
+				{
+					gstore(&nn[pos], blk);
+					if (pos >= cnt)
+						gstore(ncp, (int16_t) (pos + 1));
+					gstore(&stamp[nbk], round);
+				}
+			}
+		}
+		if (lane == 0)
+			gstore(newc, (int16_t) nsel);
+	}
+	/* blk's own list changed too (only reachable through a stamped list, but a stale check is cheap) */
+	if (lane == 0)
+		gstore(&stamp[blk], round);
+}
+
+/* ONE wave commits the batch's walks in insert order until it meets a stale one */
+__global__ __launch_bounds__(64) void
+k_hnsw_commit(int16_t *ncount, uint32_t *nbrs, const HnswTask *__restrict__ tasks, uint32_t ntasks, int m,
+			  uint32_t ksel, HnswRounds R, uint32_t round)
+{
+	__shared__ uint32_t sel[NDBHIP_MAX_EF];
+	const uint32_t lane = threadIdx.x;
+	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * 2 * m;
+	const uint32_t first = *R.next;
+	uint32_t	t = first;
+
+	for (; t < ntasks; t++)
+	{
+		const uint32_t ran = R.spec_round[t];
+
+		/* the round's first walk ran in this round with nothing written since: valid by construction
+		 * (also what lets a walk whose read set overflowed the log get through) */
+		if (!(t == first && ran == round) && (ran == 0 || hnsw_walk_is_stale<true>(R, t, ran)))
+			break;
+		const HnswTask task = tasks[t];
+		const uint32_t nsel = (uint32_t) R.nsel[t];
+
+		for (uint32_t i = lane; i < nsel; i += 64)
+			sel[i] = R.sel[(size_t) t * ksel + i];
+		__syncthreads();
+		hnsw_link(nbrs, ncount, task.row + 1, task.cl, m, stride, sel, nsel, R.stamp0, R.stampU, round);
+		hnsw_publish();
+		__syncthreads();
+	}
+	if (lane == 0)
+	{
+		*R.next = t;
+		if (t < ntasks)
+			atomicAdd(&R.stats[1], 1ull);
+	}
+}
+
 static int
 set_kernel_attributes_hnsw()
 {
@@ -3945,11 +4441,14 @@ set_kernel_attributes_hnsw()
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_COS>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_build, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_spec<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_spec<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	return NDBHIP_OK;
 }
 
 struct ndbhip_hnsw
 {
+	int64_t		build_stats[6] = {0, 0, 0, 0, 0, 0};
 	int			dim = 0, m = 0;
 	uint32_t	nblocks = 0;
 	uint32_t	entry_point = NDBHIP_INVALID_BLOCK;
@@ -4100,12 +4599,165 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 	HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
 	HIP_TRY(hipMemcpyAsync(d_lv_in, levels, (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemcpyAsync(d_entry, entry, sizeof(entry), hipMemcpyHostToDevice, g.stream));
-	hipLaunchKernelGGL(k_hnsw_build, dim3(1), dim3(64), smem, g.stream, h->d_vecs, h->d_levels, h->d_ncount,
-					   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, h->m,
-					   (uint32_t) ef_construction, d_entry);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(entry, d_entry, sizeof(entry), hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipStreamSynchronize(g.stream));
+	{	/* experiment knobs */
+		const char *e;
+
+		if ((e = getenv("NDBHIP_HNSW_SPEC")) != nullptr) g_hnsw_spec = atoi(e) != 0;
+		if ((e = getenv("NDBHIP_HNSW_BATCH_DIV")) != nullptr && atoi(e) > 0) g_hnsw_batch_div = atoi(e);
+		if ((e = getenv("NDBHIP_HNSW_BATCH_MAX")) != nullptr && atoi(e) > 0) g_hnsw_batch_max = atoi(e);
+	}
+	const bool	spec = g_hnsw_spec && nb < (1u << NDB_HNSW_RS_NODE_BITS);
+
+	memset(h->build_stats, 0, sizeof(h->build_stats));
+	if (!spec)
+	{
+		hipLaunchKernelGGL(k_hnsw_build, dim3(1), dim3(64), smem, g.stream, h->d_vecs, h->d_levels, h->d_ncount,
+						   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, h->m,
+						   (uint32_t) ef_construction, d_entry);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(entry, d_entry, sizeof(entry), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	else
+	{
+		/*
+		 * The entry point is a pure function of the drawn levels (Step 6, :2642-2663: the first node of each
+		 * new maximum level), so the host knows it for every insert and cuts the batches so that it is
+		 * constant inside one.
+		 */
+		const uint32_t ksel = (uint32_t) std::min(h->m, ef_construction);
+		std::vector<HnswTask> tasks;
+		struct Batch { size_t t0, t1; uint32_t entry; int entry_level; };
+		std::vector<Batch> batches;
+		uint32_t	e_pt = NDBHIP_INVALID_BLOCK;
+		int			e_lv = -1;
+		size_t		maxb = 0;
+
+		tasks.reserve((size_t) n + n / 8);
+		for (uint32_t i = 0; i < n;)
+		{
+			const size_t want = std::min<size_t>((size_t) g_hnsw_batch_max, std::max<size_t>(1, (size_t) i / (size_t) g_hnsw_batch_div));
+			Batch		b{tasks.size(), tasks.size(), e_pt, e_lv};
+
+			while (i < n && tasks.size() - b.t0 < want)
+			{
+				int			level = levels[i];
+
+				if (level >= NDBHIP_HNSW_MAX_LEVEL) level = NDBHIP_HNSW_MAX_LEVEL - 1;
+				if (level < 0) level = 0;
+				if (e_pt != NDBHIP_INVALID_BLOCK && e_lv >= 0)
+					for (int cl = std::min(level, e_lv); cl >= 0; cl--)
+						tasks.push_back(HnswTask{i, cl});
+				i++;
+				if (e_pt == NDBHIP_INVALID_BLOCK || level > e_lv)
+				{
+					e_pt = i;	/* block of row i-1 */
+					e_lv = level;
+					break;		/* the entry point changes: close the batch */
+				}
+			}
+			b.t1 = tasks.size();
+			if (b.t1 > b.t0)
+				batches.push_back(b);
+			maxb = std::max(maxb, b.t1 - b.t0);
+		}
+		entry[0] = e_pt;
+		entry[1] = (uint32_t) e_lv;
+
+		HnswTask   *d_tasks = nullptr;
+		uint32_t   *d_u32 = nullptr;
+		unsigned long long *d_stats = nullptr;
+		const size_t ntot = std::max<size_t>(tasks.size(), 1);
+		HnswRounds	R;
+
+		maxb = std::max<size_t>(maxb, 1);
+		/* one allocation: next | spec_round | nsel | rsn | sel | rs | stamp0 | stampU */
+		const size_t n_u32 = 1 + 3 * maxb + maxb * ksel + maxb * NDB_HNSW_RS_CAP + (size_t) 2 * nb;
+
+		HIP_TRY(hipMalloc((void **) &d_tasks, ntot * sizeof(HnswTask)));
+		HIP_TRY(hipMalloc((void **) &d_u32, n_u32 * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &d_stats, 4 * sizeof(unsigned long long)));
+		R.next = d_u32;
+		R.spec_round = R.next + 1;
+		R.nsel = (int *) (R.spec_round + maxb);
+		R.rsn = (uint32_t *) R.nsel + maxb;
+		R.sel = R.rsn + maxb;
+		R.rs = R.sel + maxb * ksel;
+		R.stamp0 = R.rs + maxb * NDB_HNSW_RS_CAP;
+		R.stampU = R.stamp0 + nb;
+		R.stats = d_stats;
+		HIP_TRY(hipMemsetAsync(R.stamp0, 0, (size_t) 2 * nb * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), g.stream));
+		if (!tasks.empty())
+			HIP_TRY(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(HnswTask), hipMemcpyHostToDevice,
+								   g.stream));
+		hipLaunchKernelGGL(k_hnsw_init_nodes, dim3(n), dim3(256), 0, g.stream, h->d_vecs, h->d_levels, h->d_ncount,
+						   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, (int64_t) stride);
+		HIP_TRY(hipGetLastError());
+
+		HnswDev		gd;
+
+		gd.vecs = h->d_vecs; gd.levels = h->d_levels; gd.ncount = h->d_ncount; gd.nbr_off = nullptr;
+		gd.nbrs = h->d_nbrs; gd.tids = h->d_tids; gd.dense_stride = (int64_t) stride; gd.nblocks = nb;
+		gd.dim = h->dim; gd.m = h->m;
+		uint32_t	round = 0;
+		int64_t		nrounds = 0;
+		const bool	trace = getenv("NDBHIP_HNSW_TRACE") != nullptr;
+		const bool	fast = (h->dim % 4) == 0 && h->dim <= NDB_HNSW_FAST_MAX_DIM && getenv("NDBHIP_HNSW_NOFAST") == nullptr;
+		uint32_t   *h_next = nullptr;
+
+		HIP_TRY(hipHostMalloc((void **) &h_next, sizeof(uint32_t), hipHostMallocDefault));
+		for (const Batch &b : batches)
+		{
+			const uint32_t nt = (uint32_t) (b.t1 - b.t0);
+			int			burst = 2;	/* rounds queued between looks at `next` */
+
+			gd.entry_point = b.entry;
+			gd.entry_level = b.entry_level;
+			HIP_TRY(hipMemsetAsync(R.next, 0, (1 + (size_t) nt) * sizeof(uint32_t), g.stream));	/* next, spec_round[] */
+			for (;;)
+			{
+				for (int r = 0; r < burst; r++)
+				{
+					round++;
+					nrounds++;
+					if (fast)
+						hipLaunchKernelGGL(k_hnsw_spec<true>, dim3(nt), dim3(256), smem, g.stream, gd, d_rows,
+										   (const HnswTask *) (d_tasks + b.t0), (uint32_t) ef_construction, ksel,
+										   R, round);
+					else
+						hipLaunchKernelGGL(k_hnsw_spec<false>, dim3(nt), dim3(64), smem, g.stream, gd, d_rows,
+										   (const HnswTask *) (d_tasks + b.t0), (uint32_t) ef_construction, ksel,
+										   R, round);
+					hipLaunchKernelGGL(k_hnsw_commit, dim3(1), dim3(64), 0, g.stream, h->d_ncount, h->d_nbrs,
+									   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
+				}
+				HIP_TRY(hipMemcpyAsync(h_next, R.next, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+				HIP_TRY(hipStreamSynchronize(g.stream));
+				if (*h_next >= nt)
+					break;
+				burst = std::min(burst * 2, 16);
+			}
+			if (trace)
+				fprintf(stderr, "hnsw batch: first row %u walks %u rounds so far %lld\n", tasks[b.t0].row, nt,
+						(long long) nrounds);
+		}
+		HIP_TRY(hipGetLastError());
+		unsigned long long st[4] = {0, 0, 0, 0};
+
+		HIP_TRY(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		h->build_stats[0] = (int64_t) tasks.size();
+		h->build_stats[1] = (int64_t) st[0] - (int64_t) tasks.size();	/* walks run again */
+		h->build_stats[2] = (int64_t) st[2];
+		h->build_stats[3] = nrounds;
+		h->build_stats[4] = (int64_t) batches.size();
+		h->build_stats[5] = (int64_t) maxb;
+		HIP_TRY(hipHostFree(h_next));
+		HIP_TRY(hipFree(d_tasks));
+		HIP_TRY(hipFree(d_u32));
+		HIP_TRY(hipFree(d_stats));
+	}
 	HIP_TRY(hipFree(d_lv_in));
 	HIP_TRY(hipFree(d_entry));
 	h->nblocks = nb;
@@ -4113,6 +4765,26 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 	h->entry_level = (int) entry[1];
 	h->loaded = true;
 	h->dense = true;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_set_build_mode(int optimistic, int batch_div, int batch_max)
+{
+	if (batch_div < 1 || batch_max < 1 || batch_max > 65535)
+		return fail(NDBHIP_ERR_INVALID, "batch_div >= 1 and 1 <= batch_max <= 65535 required");
+	g_hnsw_spec = optimistic != 0;
+	g_hnsw_batch_div = batch_div;
+	g_hnsw_batch_max = batch_max;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_build_stats(const ndbhip_hnsw *h, int64_t out[6])
+{
+	if (!h || !out)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	memcpy(out, h->build_stats, sizeof(h->build_stats));
 	return NDBHIP_OK;
 }
 

@@ -73,6 +73,17 @@ class HnswIndex:
                                              _ptr(lv), int(ef_construction)))
         self.nblocks = len(lv) + 1
 
+    def build_stats(self):
+        """How the last build() ran (ndbhip_hnsw_build_stats)."""
+        st = np.zeros(6, np.int64)
+        check(lib().ndbhip_hnsw_build_stats(self._h, _ptr(st)))
+        return dict(zip(("walks", "redone", "overflowed", "rounds", "batches", "max_batch"),
+                        (int(x) for x in st)))
+
+    @staticmethod
+    def set_build_mode(optimistic=True, batch_div=64, batch_max=1024):
+        check(lib().ndbhip_hnsw_set_build_mode(int(bool(optimistic)), int(batch_div), int(batch_max)))
+
     def export(self):
         nb = C.c_uint32()
         ep = C.c_uint32()

@@ -96,11 +96,27 @@ def test_hnsw_scan_state_machine():
     assert [tuple(int(x) for x in t.tolist()) for t in got] == [tuple(int(x) for x in e) for e in exp]
 
 
-@pytest.mark.parametrize("n,dim,m,efc", [(500, 16, 4, 20), (700, 64, 8, 40), (300, 768, 16, 64), (200, 6, 5, 16)])
-def test_hnsw_device_build_matches_oracle_graph(n, dim, m, efc):
-    """hnswbuild on the device (k_hnsw_build) vs the oracle's literal hnswInsertNode: identical neighbour
-    arrays (all 16 levels, incl. the out-of-node back-links of Q12/Q21), counts, entry point."""
+# (optimistic, batch_div, batch_max): the one-wave sequential kernel; the default schedule; and a schedule
+# that batches as many walks as there are nodes, so that conflicts (and their in-order redo) are the rule
+BUILD_MODES = {"sequential": (0, 64, 1024), "optimistic": (1, 64, 1024), "optimistic-greedy": (1, 1, 256)}
+
+
+@pytest.fixture
+def restore_build_mode():
+    yield
     from neurondb_amd import HnswIndex
+    HnswIndex.set_build_mode(True, 64, 1024)
+
+
+@pytest.mark.parametrize("mode", list(BUILD_MODES))
+@pytest.mark.parametrize("n,dim,m,efc", [(500, 16, 4, 20), (700, 64, 8, 40), (300, 768, 16, 64), (200, 6, 5, 16),
+                                         (2500, 128, 16, 200)])     # the reference's default m / ef_construction
+def test_hnsw_device_build_matches_oracle_graph(n, dim, m, efc, mode, restore_build_mode):
+    """hnswbuild on the device vs the oracle's literal hnswInsertNode: identical neighbour arrays (all 16
+    levels, incl. the out-of-node back-links of Q12/Q21), counts, entry point — whichever way the inserts
+    are scheduled (k_hnsw_build, or k_hnsw_spec + k_hnsw_commit)."""
+    from neurondb_amd import HnswIndex
+    HnswIndex.set_build_mode(*BUILD_MODES[mode])
     rng = np.random.default_rng(n * 3 + dim)
     vecs = rng.standard_normal((n, dim)).astype(np.float32)
     vecs[n // 2] = vecs[3]                                   # duplicate vector
@@ -114,6 +130,19 @@ def test_hnsw_device_build_matches_oracle_graph(n, dim, m, efc):
     a = g.arrays()
     ix = HnswIndex(dim, m)
     ix.build(vecs, ndbo.tids_from_rows(np.arange(n)), levels, efc)
+    st = ix.build_stats()
+    if mode == "sequential":
+        assert st["walks"] == 0
+    else:
+        # one walk per insert and linked level: min(level, entry level before the insert) + 1
+        ent, walks = -1, 0
+        for lv in levels:
+            walks += (min(int(lv), ent) + 1) if ent >= 0 else 0
+            ent = max(ent, int(lv))
+        assert st["walks"] == walks
+        assert st["rounds"] >= st["batches"] >= 1 and st["overflowed"] == 0
+        if mode == "optimistic-greedy":
+            assert st["redone"] > 0 and st["max_batch"] > 16    # stale walks were met and run again
     e = ix.export()
     assert e["nblocks"] == a["nblocks"]
     assert (e["entry_point"], e["entry_level"]) == (a["entry_point"], a["entry_level"])

@@ -24,6 +24,12 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--oracle-sample", type=int, default=50)
+    ap.add_argument("--sequential", action="store_true", help="one-wave sequential build (k_hnsw_build)")
+    ap.add_argument("--batch-div", type=int, default=64)
+    ap.add_argument("--batch-max", type=int, default=1024)
+    ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--graph-hash", action="store_true", help="print a digest of the built graph")
+    ap.add_argument("--data", choices=["gauss", "clustered"], default="gauss")
     a = ap.parse_args()
     from neurondb_amd import HnswIndex, _lib
     from neurondb_amd._lib import check, lib
@@ -33,6 +39,9 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0003)
     base = torch.randn((a.nvec, a.dim), generator=g, device=dev)
+    if a.data == "clustered":                                  # same mixture family as bench.py's default
+        cent = torch.randn((1024, a.dim), generator=g, device=dev)
+        base = cent[torch.randint(0, 1024, (a.nvec,), generator=g, device=dev)] + 0.1 * base
     base = base / base.norm(dim=1, keepdim=True)               # unit norm: L2, cosine and IP orders coincide (Q1)
     q = torch.randn((a.nq, a.dim), generator=g, device=dev)
     q = q / q.norm(dim=1, keepdim=True)
@@ -42,12 +51,22 @@ def main():
     tids = torch.arange(a.nvec, device=dev, dtype=torch.int64)
     tids = ((tids // 64 >> 16) & 0xFFFF) | ((tids // 64 & 0xFFFF) << 16) | ((tids % 64 + 1) << 32)
     ix = HnswIndex(a.dim, a.m)
+    HnswIndex.set_build_mode(not a.sequential, a.batch_div, a.batch_max)
     t0 = time.perf_counter()
     check(lib().ndbhip_hnsw_build_device(ix._h, C.c_void_p(base.data_ptr()), C.c_void_p(tids.data_ptr()), a.nvec,
                                          levels.ctypes.data, a.efc))
     tb = time.perf_counter() - t0
     print(f"build: {a.nvec} x {a.dim}, m={a.m}, ef_construction={a.efc}: {tb:.2f} s = {a.nvec / tb:.0f} vectors/s "
-          f"(one wave, sequential inserts)")
+          + ("(one wave, sequential inserts)" if a.sequential else f"(optimistic batches: {ix.build_stats()})"))
+    if a.graph_hash:
+        import hashlib
+        e = ix.export()
+        hh = hashlib.sha1()
+        for key in ("levels", "ncount", "nbrs"):
+            hh.update(np.ascontiguousarray(e[key]).tobytes())
+        print(f"graph digest: {hh.hexdigest()} entry {e['entry_point']}/{e['entry_level']}")
+    if a.build_only:
+        return
     ob = torch.zeros((a.nq, a.k), dtype=torch.int32, device=dev)
     od = torch.zeros((a.nq, a.k), dtype=torch.float32, device=dev)
     oc = torch.zeros(a.nq, dtype=torch.int32, device=dev)
