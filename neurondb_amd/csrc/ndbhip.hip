@@ -3541,17 +3541,24 @@ struct HnswLds
 	float	   *tile;
 	uint64_t   *e_id;
 	FinalizeScratch fs;
-	uint32_t   *cand, *cdist, *e_pos, *visited;
+	uint32_t   *cand, *cdist, *e_pos, *visited;	/* visited: hash set of vmask + 1 slots */
 	int		   *s_count;
-	uint32_t	npad;
+	uint32_t	npad, vmask;
 };
+
+/* slots of the visited hash set: at most ef + 2m + 63 blocks are ever scored at level 0; load factor <= 1/2 */
+__host__ __device__ static inline uint32_t
+hnsw_vslots(uint32_t ef, uint32_t m)
+{
+	return next_pow2(2u * (ef + 2u * m + 64u));
+}
 
 __host__ __device__ static inline size_t
 hnsw_smem_bytes(uint32_t ef, uint32_t k, uint32_t m)
 {
 	const uint32_t npad = next_pow2(ef < 4 ? 4 : ef);
 
-	return (size_t) NDB_TILE_FLOATS * 4 + (size_t) ef * (4 + 4 + 4 + 8) + (size_t) (ef + 2 * m + 64) * 4 +
+	return (size_t) NDB_TILE_FLOATS * 4 + (size_t) ef * (4 + 4 + 4 + 8) + (size_t) hnsw_vslots(ef, m) * 4 +
 		(size_t) npad * (8 + 4 + 4 + 1) + (size_t) k * 4 + 128;
 }
 
@@ -3567,7 +3574,8 @@ carve_hnsw_lds(unsigned char *sp, uint32_t ef, uint32_t k, uint32_t m)
 	L.cand = (uint32_t *) sp;			sp += (size_t) ef * 4;
 	L.cdist = (uint32_t *) sp;			sp += (size_t) ef * 4;	/* float bits */
 	L.e_pos = (uint32_t *) sp;			sp += (size_t) ef * 4;
-	L.visited = (uint32_t *) sp;		sp += (size_t) (ef + 2 * m + 64) * 4;
+	L.vmask = hnsw_vslots(ef, m) - 1u;
+	L.visited = (uint32_t *) sp;		sp += (size_t) (L.vmask + 1u) * 4;
 	L.fs.perm = (uint32_t *) sp;		sp += (size_t) L.npad * 4;
 	L.fs.curpos = (uint32_t *) sp;		sp += (size_t) L.npad * 4;
 	L.fs.order = (uint32_t *) sp;		sp += (size_t) k * 4;
@@ -3765,7 +3773,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 	const uint32_t nblocks = g.nblocks;
 	uint32_t	cur = g.entry_point;
 	int			curLevel = g.entry_level;
-	uint32_t   *cand = L.cand, *cdist = L.cdist, *visited = L.visited;
+	uint32_t   *cand = L.cand, *cdist = L.cdist;
 
 	cc_out = 0;
 	if (cur == NDBHIP_INVALID_BLOCK)	/* :1593-1599 */
@@ -3828,7 +3836,45 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 		return false;
 
 	/* ---- level 0 (:1765-1975) ---- */
-	uint32_t	cc = 1, vc = 1;
+	/*
+	 * visitedSet (:1619-1631, a bool per block in the reference) is a membership test and nothing else, so
+	 * it lives in LDS as an open-addressing hash set of the blocks scored so far (0 = empty: block 0 is
+	 * the meta page and never a node).
+	 */
+	const uint32_t vmask = L.vmask;
+	const uint32_t vshift = 32u - (uint32_t) __popc(vmask);
+	uint32_t   *vhash = L.visited;
+	auto		v_insert = [&](uint32_t key) {
+		uint32_t	h = (key * 2654435761u) >> vshift;
+
+		for (;;)
+		{
+			const uint32_t prev = atomicCAS(&vhash[h], 0u, key);
+
+			if (prev == 0u || prev == key)
+				break;
+			h = (h + 1u) & vmask;
+		}
+	};
+	auto		v_contains = [&](uint32_t key) -> bool {
+		uint32_t	h = (key * 2654435761u) >> vshift;
+
+		for (;;)
+		{
+			const uint32_t v = vhash[h];
+
+			if (v == key)
+				return true;
+			if (v == 0u)
+				return false;
+			h = (h + 1u) & vmask;
+		}
+	};
+	uint32_t	cc = 1;
+
+	for (uint32_t t = lane; t <= vmask; t += 64)
+		vhash[t] = 0u;
+	wave_lds_sync();
 	{
 		const float d0 = score(cur, cur, lane == 0);
 
@@ -3837,7 +3883,7 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 		{
 			cand[0] = cur;
 			cdist[0] = __float_as_uint(d0);
-			visited[0] = cur;
+			v_insert(cur);
 		}
 		wave_lds_sync();
 	}
@@ -3848,30 +3894,28 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 		if (!hnsw_valid(nblocks, c))
 			continue;
 		log_read(c, 0);
-		const int	nc = hnsw_clamp(gload<MUT>(&g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + 0]), g.m);
 		const uint32_t *nb = hnsw_nbr_base(g, c);
+		/* the list and its count are fetched together (one round trip): slots past the count exist in
+		 * both layouts, they are just not neighbours */
+		const uint32_t raw0 = ((int) lane < m2) ? gload<MUT>(&nb[lane]) : NDBHIP_INVALID_BLOCK;
+		const int	nc = hnsw_clamp(gload<MUT>(&g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + 0]), g.m);
 
 		for (int j0 = 0; j0 < nc; j0 += 64)
 		{
 			const int	j = j0 + (int) lane;
-			const uint32_t my = (j < nc) ? gload<MUT>(&nb[j]) : NDBHIP_INVALID_BLOCK;
+			const uint32_t my = (j < nc) ? (j0 == 0 ? raw0 : gload<MUT>(&nb[j])) : NDBHIP_INVALID_BLOCK;
 			bool		ok = hnsw_valid(nblocks, my);
 
 			/* visitedSet test (:1891) against everything scored so far */
 			if (ok)
-				for (uint32_t v = 0; v < vc; v++)
-					if (visited[v] == my)
-					{
-						ok = false;
-						break;
-					}
+				ok = !v_contains(my);
 			/* a block repeated inside this batch is visited by the time its 2nd copy is met */
-			for (uint32_t l = 0; l < 63; l++)
+			for (unsigned long long rem = __ballot(ok); rem; rem &= rem - 1)
 			{
-				const uint32_t other = __shfl(my, l, 64);
-				const int	ook = __shfl((int) ok, l, 64);
+				const int	l = __ffsll((long long) rem) - 1;
+				const uint32_t other = (uint32_t) __builtin_amdgcn_readlane((int) my, l);
 
-				if (l < lane && ook && other == my)
+				if ((int) lane > l && other == my)
 					ok = false;
 			}
 			const unsigned long long mask0 = __ballot(ok);
@@ -3879,56 +3923,60 @@ hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L
 			if (mask0 == 0ull)
 				continue;
 			const float d = score(my, c, ok);
+			const uint32_t nok = (uint32_t) __popcll(mask0);
+			const uint32_t rank = (uint32_t) __popcll(mask0 & ((1ull << lane) - 1ull));
+			/* while there is room the scored neighbours are appended in list order (:1948-1953) — all at
+			 * once; what does not fit goes through replace-worst one by one, as the reference does */
+			const uint32_t napp = cc < ef ? (nok < ef - cc ? nok : ef - cc) : 0u;
+
+			scored += nok;
+			if (ok)
+			{
+				v_insert(my);
+				if (rank < napp)
+				{
+					cand[cc + rank] = my;
+					cdist[cc + rank] = __float_as_uint(d);
+				}
+			}
+			cc += napp;
+			wave_lds_sync();
 			unsigned long long mask = mask0;
 
-			scored += __popcll(mask0);
+			for (uint32_t r = 0; r < napp; r++)
+				mask &= mask - 1;
 			while (mask)
 			{
 				const int	l = __ffsll((long long) mask) - 1;
 
 				mask &= mask - 1;
-				const uint32_t nbk = __shfl(my, l, 64);
-				const float nd = __shfl(d, l, 64);
+				const uint32_t nbk = (uint32_t) __builtin_amdgcn_readlane((int) my, l);
+				const float nd = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(d), l));
+				/* :1954-1972: first maximum, strict > */
+				uint64_t	wk = 0;
 
-				if (lane == 0)
-					visited[vc] = nbk;
-				vc++;
-				if (cc < ef)		/* :1948-1953 */
+				for (uint32_t t = lane; t < cc; t += 64)
 				{
-					if (lane == 0)
-					{
-						cand[cc] = nbk;
-						cdist[cc] = __float_as_uint(nd);
-					}
-					cc++;
+					const uint64_t kk2 = ((uint64_t) ndb_key_from_bits(cdist[t]) << 32) | (0xFFFFFFFFu - t);
+
+					wk = kk2 > wk ? kk2 : wk;
 				}
-				else				/* :1954-1972: first maximum, strict > */
-				{
-					uint64_t	wk = 0;
-
-					for (uint32_t t = lane; t < cc; t += 64)
-					{
-						const uint64_t kk2 = ((uint64_t) ndb_key_from_bits(cdist[t]) << 32) | (0xFFFFFFFFu - t);
-
-						wk = kk2 > wk ? kk2 : wk;
-					}
 #pragma unroll
-					for (int off = 32; off > 0; off >>= 1)
-					{
-						const uint32_t lo = __shfl_xor((uint32_t) wk, off, 64);
-						const uint32_t hi = __shfl_xor((uint32_t) (wk >> 32), off, 64);
-						const uint64_t o = ((uint64_t) hi << 32) | lo;
+				for (int off = 32; off > 0; off >>= 1)
+				{
+					const uint32_t lo = __shfl_xor((uint32_t) wk, off, 64);
+					const uint32_t hi = __shfl_xor((uint32_t) (wk >> 32), off, 64);
+					const uint64_t o = ((uint64_t) hi << 32) | lo;
 
-						wk = o > wk ? o : wk;
-					}
-					const uint32_t widx = 0xFFFFFFFFu - (uint32_t) wk;
-					const float wd = __uint_as_float(cdist[widx]);
+					wk = o > wk ? o : wk;
+				}
+				const uint32_t widx = 0xFFFFFFFFu - (uint32_t) wk;
+				const float wd = __uint_as_float(cdist[widx]);
 
-					if (nd < wd && lane == 0)
-					{
-						cand[widx] = nbk;
-						cdist[widx] = __float_as_uint(nd);
-					}
+				if (nd < wd && lane == 0)
+				{
+					cand[widx] = nbk;
+					cdist[widx] = __float_as_uint(nd);
 				}
 				wave_lds_sync();
 			}
