@@ -151,14 +151,14 @@ def main():
         ix = ix_full
 
     # ---------------- one step ----------------
-    buf = ShardedSearchBuffers(nq, k, world, dev)
+    buf = ShardedSearchBuffers(nq, k, world, dev, nprobe=nprobe if use_dist else 0)
     out_t, out_d, out_c = buf.out_tids, buf.out_dist, buf.out_count
 
     def step(qs):
         if not use_dist:
             ix.search_device(qs, out_t, out_d, out_c, 1, nprobe, k, 0)
         else:
-            sharded_search(ix, qs, buf, 1, nprobe, k, 0)
+            sharded_search(ix, qs, buf, 1, nprobe, k, 0, rank=rank)
 
     def barrier():
         if use_dist:

@@ -212,6 +212,16 @@ typedef struct ndbhip_cand
 int			ndbhip_ivf_search_partial_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy,
 											 int nprobe, int k, int64_t max_candidates,
 											 ndbhip_cand *d_out_cand, int *d_out_ncand, int64_t *d_out_total);
+/* The two halves of ndbhip_ivf_search_partial_device, so that the ranks of a sharded search can split the
+ * centroid scan + ivfSelectClusters (ivf_am.c:1597-1717) by QUERIES instead of all repeating it: each rank
+ * selects for its slice, the probe lists ([nq][nprobe] int32, same values ndbhip_ivf_select_clusters
+ * returns) are all-gathered, and every rank scans its own lists for all queries. */
+int			ndbhip_ivf_select_clusters_device(ndbhip_ivf *ix, const float *d_queries, int nq, int nprobe,
+											  int *d_out_probes);
+int			ndbhip_ivf_search_partial_probes_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy,
+													int nprobe, int k, int64_t max_candidates,
+													const int *d_probes, ndbhip_cand *d_out_cand,
+													int *d_out_ncand, int64_t *d_out_total);
 /* d_cand: [world][nq][cap] records, d_ncand: [world][nq], d_total: [nq]
  * (number of candidates over all ranks, identical on every rank). */
 int			ndbhip_merge_topk_device(const ndbhip_cand *d_cand, const int *d_ncand, const int64_t *d_total,

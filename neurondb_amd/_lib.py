@@ -98,6 +98,8 @@ def lib():
         "ndbhip_ivf_search_device": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),
         "ndbhip_ivf_select_clusters": (i, [vp, vp, i, i, vp]),
         "ndbhip_ivf_search_partial_device": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),
+        "ndbhip_ivf_search_partial_probes_device": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp, vp]),
+        "ndbhip_ivf_select_clusters_device": (i, [vp, vp, i, i, vp]),
         "ndbhip_merge_topk_device": (i, [vp, vp, vp, i, i, i, i, vp, vp, vp]),
         "ndbhip_merge_topk_host": (i, [vp, vp, vp, i, i, i, i, vp, vp, vp]),
         "ndbhip_kmeans_device": (i, [vp, i, i, i, i, f, vp, vp, vp, C.POINTER(i), C.POINTER(f)]),

@@ -791,6 +791,47 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 	}
 }
 
+/* the tail of k_probe_select alone, for probes chosen elsewhere (another rank): candidates[] offsets of
+ * every probe, globally and among the rows held here */
+__global__ __launch_bounds__(256) void
+k_probe_offsets(const int *__restrict__ probes, uint32_t nq, int npr, int ncent,
+				const uint32_t *__restrict__ glob_len, const uint8_t *__restrict__ owned, uint64_t cap, int dim,
+				uint32_t *__restrict__ cand_off, uint32_t *__restrict__ loc_cand_off,
+				unsigned long long *__restrict__ counters)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (q >= nq)
+		return;
+	uint64_t	acc = 0, mine = 0;
+	uint32_t   *co = cand_off + (size_t) q * (npr + 1);
+	uint32_t   *lco = loc_cand_off ? loc_cand_off + (size_t) q * (npr + 1) : nullptr;
+
+	co[0] = 0;
+	if (lco)
+		lco[0] = 0;
+	for (int i = 0; i < npr; i++)
+	{
+		const int	c = probes[(size_t) q * npr + i];
+		uint64_t	l = (c >= 0 && c < ncent) ? glob_len[c] : 0u;
+
+		if (cap > 0 && acc + l > cap)
+			l = cap - acc;
+		acc += l;
+		if (l > 0 && owned[c])
+			mine += l;
+		co[i + 1] = (uint32_t) acc;
+		if (lco)
+			lco[i + 1] = (uint32_t) mine;
+	}
+	if (counters)
+	{
+		atomicAdd(&counters[0], (unsigned long long) acc);
+		atomicAdd(&counters[1], (unsigned long long) mine);
+		atomicAdd(&counters[2], (unsigned long long) mine * (unsigned long long) dim);
+	}
+}
+
 /* position -> (probe index) : largest p with co[p] <= pos */
 __device__ __forceinline__ uint32_t
 find_probe(const uint32_t *__restrict__ co, int npr, uint32_t pos)
@@ -2147,7 +2188,8 @@ static int
 ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr, int k,
 				 int64_t max_candidates, uint32_t stride, bool full, int partial,
 				 ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
-				 uint64_t *d_otid, float *d_odist, int *d_ocnt)
+				 uint64_t *d_otid, float *d_odist, int *d_ocnt, const int *d_probes_in = nullptr,
+				 int *d_probes_out = nullptr)
 {
 	const IvfDev d = ivf_dev(ix);
 	const int	ncmp = std::min(ix->nlists, ix->ncent);
@@ -2160,17 +2202,29 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	uint32_t   *lco_w = ix->sharded ? ix->w_candoff + (size_t) nq * (npr + 1) : nullptr;
 	const uint32_t *lco = ix->sharded ? lco_w : ix->w_candoff;
 
-	/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680) */
+	int		   *w_probes = d_probes_out ? d_probes_out : ix->w_probes;
+
+	if (d_probes_in)
 	{
+		/* probes chosen elsewhere (each rank of a sharded search selects for its slice of the queries) */
+		w_probes = const_cast<int *>(d_probes_in);
+		hipLaunchKernelGGL(k_probe_offsets, dim3((nq + 255) / 256), dim3(256), 0, g.stream, d_probes_in,
+						   (uint32_t) nq, npr, ix->ncent, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
+						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
+						   ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
+	}
+	else
+	{
+		/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680) */
 		dim3		grid((ncmp + 255) / 256, nq);
 
 		hipLaunchKernelGGL(k_rows_scan<R_IVF_L2>, grid, dim3(256), 0, g.stream, (const float *) d.centroids,
 						   (uint32_t) ncmp, ix->dim, d_q, ix->w_cdist, cstride);
+		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
+						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
+						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
+						   w_probes, ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
 	}
-	hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
-					   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
-					   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4), ix->w_probes,
-					   ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
 	HIP_TRY(hipGetLastError());
 	if (!full)
 		return 0;
@@ -2192,12 +2246,12 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 1) * sizeof(uint32_t), g.stream));
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
-						   (const int *) ix->w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
+						   (const int *) w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
 						   (const uint8_t *) d.owned, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
 						   (const uint32_t *) d.glob_len, nc, pair_off, item_off, grp_off);
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
-						   (const int *) ix->w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
+						   (const int *) w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
 						   (const uint8_t *) d.owned, (const uint32_t *) pair_off, fill, ix->w_pairs);
 		hipLaunchKernelGGL(k_group_pack, dim3((ix->dim + 255) / 256, maxgroups), dim3(256), 0, g.stream, d_q,
 						   ix->dim, nc, (const uint32_t *) cnt, (const uint32_t *) pair_off,
@@ -2256,17 +2310,17 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 		if (t.start()) return NDBHIP_ERR_HIP;
 		if (ix->f16)
-			LAUNCH_BY_RECIPE(R, k_ivf_scan_h, grid, dim3(256), d, d_q, (const int *) ix->w_probes, lco, npr,
+			LAUNCH_BY_RECIPE(R, k_ivf_scan_h, grid, dim3(256), d, d_q, (const int *) w_probes, lco, npr,
 							 ix->w_dist, stride);
 		else
-			LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) ix->w_probes, lco, npr,
+			LAUNCH_BY_RECIPE(R, k_ivf_scan, grid, dim3(256), d, d_q, (const int *) w_probes, lco, npr,
 							 ix->w_dist, stride);
 		if (t.stop()) return NDBHIP_ERR_HIP;
 	}
 	{
 		const size_t smem = topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k);
 
-		hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) ix->w_probes,
+		hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
 						   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
 						   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt);
 	}
@@ -2297,7 +2351,8 @@ static size_t g_dist_budget_bytes = (size_t) 2 << 30;
 static int
 ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe, int k,
 					   int64_t max_candidates, int partial, ndbhip_cand *d_cand, int *d_ncand,
-					   int64_t *d_total, uint64_t *d_otid, float *d_odist, int *d_ocnt)
+					   int64_t *d_total, uint64_t *d_otid, float *d_odist, int *d_ocnt,
+					   const int *d_probes_in = nullptr)
 {
 	int			rc = ivf_check_search_args(ix, nq, nprobe, k);
 
@@ -2348,7 +2403,8 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 							  d_cand ? d_cand + (size_t) q0 * cap : nullptr,
 							  d_ncand ? d_ncand + q0 : nullptr, d_total ? d_total + q0 : nullptr,
 							  d_otid ? d_otid + (size_t) q0 * k : nullptr,
-							  d_odist ? d_odist + (size_t) q0 * k : nullptr, d_ocnt ? d_ocnt + q0 : nullptr);
+							  d_odist ? d_odist + (size_t) q0 * k : nullptr, d_ocnt ? d_ocnt + q0 : nullptr,
+							  d_probes_in ? d_probes_in + (size_t) q0 * nprobe : nullptr);
 		if (rc)
 			return rc;
 	}
@@ -2375,6 +2431,50 @@ ndbhip_ivf_search_partial_device(ndbhip_ivf *ix, const float *d_queries, int nq,
 		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
 	return ivf_search_device_impl(ix, d_queries, nq, strategy, nprobe, k, max_candidates, 1, d_out_cand,
 								  d_out_ncand, d_out_total, nullptr, nullptr, nullptr);
+}
+
+extern "C" int
+ndbhip_ivf_search_partial_probes_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe,
+										int k, int64_t max_candidates, const int *d_probes,
+										ndbhip_cand *d_out_cand, int *d_out_ncand, int64_t *d_out_total)
+{
+	if (nq > 0 && (!d_queries || !d_probes || !d_out_cand || !d_out_ncand || !d_out_total))
+		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	return ivf_search_device_impl(ix, d_queries, nq, strategy, nprobe, k, max_candidates, 1, d_out_cand,
+								  d_out_ncand, d_out_total, nullptr, nullptr, nullptr, d_probes);
+}
+
+extern "C" int
+ndbhip_ivf_select_clusters_device(ndbhip_ivf *ix, const float *d_queries, int nq, int nprobe, int *d_out_probes)
+{
+	int			rc = ivf_check_search_args(ix, nq, nprobe, 1);
+
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (!d_queries || !d_out_probes)
+		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	rc = ivf_flush(ix);
+	if (rc)
+		return rc;
+	const int	ncmp = std::min(ix->nlists, ix->ncent);
+	const size_t cstride = (size_t) ((ncmp + 63) & ~63);
+	const int	qb = std::min(nq, 4096);
+
+	if (grow(ix->w_cdist, ix->w_cdist_n, (size_t) qb * cstride)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) 2 * qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
+	for (int q0 = 0; q0 < nq; q0 += qb)
+	{
+		const int	n = std::min(qb, nq - q0);
+
+		rc = ivf_search_chunk(ix, d_queries + (size_t) q0 * ix->dim, n, 1, nprobe, 1, 0, 0, false, 0, nullptr,
+							  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+							  d_out_probes + (size_t) q0 * nprobe);
+		if (rc)
+			return rc;
+	}
+	return NDBHIP_OK;
 }
 
 extern "C" int

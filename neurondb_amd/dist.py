@@ -3,8 +3,10 @@ over the ranks, per-rank candidate records all-gathered (RCCL over xGMI when the
 tensors live on the GPU, gloo on CPU tensors in the tests) and merged by replaying
 the reference's selection sort on the union (ndbhip_merge_topk_*).
 
-The only collective the path needs is this all-gather of nq x 3k x 16 B per rank
-(SURVEY 8e); there is no reduction and no all-to-all."""
+The exchange the path needs is this all-gather of nq x 3k x 16 B per rank (SURVEY 8e);
+there is no reduction and no all-to-all.  A second, smaller all-gather (nq x nprobe x 4 B)
+lets the ranks split the centroid scan + ivfSelectClusters by queries instead of all
+repeating it for every query (`split_select`)."""
 from __future__ import annotations
 
 import numpy as np
@@ -34,12 +36,23 @@ def partial_cap(k: int) -> int:
     return 3 * k            # NDBHIP_PARTIAL_CAP
 
 
+def query_slice(nq: int, world: int, rank: int):
+    """Queries [lo, hi) whose probes `rank` selects; every slice has the same padded length ceil(nq / world)."""
+    s = -(-nq // world)
+    return min(rank * s, nq), min((rank + 1) * s, nq), s
+
+
 class ShardedSearchBuffers:
     """Pre-allocated exchange buffers for batches of nq queries."""
 
-    def __init__(self, nq: int, k: int, world: int, device):
+    def __init__(self, nq: int, k: int, world: int, device, nprobe: int = 0):
         cap = partial_cap(k)
         self.nq, self.k, self.world, self.cap = nq, k, world, cap
+        self.nprobe = nprobe
+        if nprobe:
+            s = -(-nq // world)
+            self.probes_mine = torch.zeros((s, nprobe), dtype=torch.int32, device=device)
+            self.probes_all = torch.zeros((world * s, nprobe), dtype=torch.int32, device=device)
         self.cand = torch.zeros((nq, cap, CAND_WORDS), dtype=torch.int64, device=device)
         self.ncand = torch.zeros(nq, dtype=torch.int32, device=device)
         self.total = torch.zeros(nq, dtype=torch.int64, device=device)
@@ -66,8 +79,27 @@ def gather_and_merge(buf: ShardedSearchBuffers, group=None):
     return buf.out_tids, buf.out_dist, buf.out_count
 
 
+def gather_probes(buf: ShardedSearchBuffers, group=None):
+    """all-gather the per-rank probe slices (buf.probes_mine) -> probes of all nq queries [nq, nprobe]."""
+    if buf.world > 1 or (dist.is_available() and dist.is_initialized()):
+        dist.all_gather_into_tensor(buf.probes_all, buf.probes_mine, group=group)
+    else:
+        buf.probes_all.copy_(buf.probes_mine)
+    return buf.probes_all[:buf.nq]
+
+
 def sharded_search(index, d_queries, buf: ShardedSearchBuffers, strategy=1, nprobe=10, k=10, max_candidates=0,
-                   group=None):
-    """One batch on this rank's shard (`index` = IvfIndex.shard(owned)) + exchange + merge."""
-    index.search_partial_device(d_queries, buf.cand, buf.ncand, buf.total, strategy, nprobe, k, max_candidates)
+                   group=None, rank=None):
+    """One batch on this rank's shard (`index` = IvfIndex.shard(owned)) + exchange + merge.
+    With buffers built for `nprobe` (and world > 1) the ranks split cluster selection by queries."""
+    if buf.nprobe == nprobe and buf.world > 1:
+        r = dist.get_rank(group) if rank is None else rank
+        lo, hi, _ = query_slice(buf.nq, buf.world, r)
+        if hi > lo:
+            index.select_clusters_device(d_queries[lo:hi], buf.probes_mine[:hi - lo], nprobe)
+        probes = gather_probes(buf, group)
+        index.search_partial_probes_device(d_queries, probes, buf.cand, buf.ncand, buf.total, strategy, nprobe, k,
+                                           max_candidates)
+    else:
+        index.search_partial_device(d_queries, buf.cand, buf.ncand, buf.total, strategy, nprobe, k, max_candidates)
     return gather_and_merge(buf, group)

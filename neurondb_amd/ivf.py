@@ -166,6 +166,23 @@ class IvfIndex:
             self._h, C.c_void_p(d_queries.data_ptr()), nq, strategy, nprobe, k, int(max_candidates),
             C.c_void_p(out_cand.data_ptr()), C.c_void_p(out_ncand.data_ptr()), C.c_void_p(out_total.data_ptr())))
 
+    def search_partial_probes_device(self, d_queries, d_probes, out_cand, out_ncand, out_total, strategy=1,
+                                     nprobe=IVF_DEFAULT_NPROBE, k=IVF_DEFAULT_K, max_candidates=0):
+        """search_partial_device with the probes given ([nq, nprobe] int32 device tensor, contiguous)."""
+        nq = d_queries.shape[0]
+        assert d_probes.is_contiguous() and tuple(d_probes.shape) == (nq, nprobe)
+        check(lib().ndbhip_ivf_search_partial_probes_device(
+            self._h, C.c_void_p(d_queries.data_ptr()), nq, strategy, nprobe, k, int(max_candidates),
+            C.c_void_p(d_probes.data_ptr()), C.c_void_p(out_cand.data_ptr()), C.c_void_p(out_ncand.data_ptr()),
+            C.c_void_p(out_total.data_ptr())))
+
+    def select_clusters_device(self, d_queries, d_out_probes, nprobe=IVF_DEFAULT_NPROBE):
+        """ivfSelectClusters for device-resident queries -> d_out_probes [nq, nprobe] int32 (device)."""
+        nq = d_queries.shape[0]
+        assert d_out_probes.is_contiguous() and tuple(d_out_probes.shape) == (nq, nprobe)
+        check(lib().ndbhip_ivf_select_clusters_device(self._h, C.c_void_p(d_queries.data_ptr()), nq, nprobe,
+                                                      C.c_void_p(d_out_probes.data_ptr())))
+
     def select_clusters(self, queries, nprobe=IVF_DEFAULT_NPROBE):
         q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
         out = np.zeros((q.shape[0], nprobe), dtype=np.int32)

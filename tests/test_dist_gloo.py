@@ -23,9 +23,10 @@ def _free_port():
     return p
 
 
-def _rank_records(a, img, owner, rank, q, nprobe, k):
+def _rank_records(a, img, owner, rank, q, nprobe, k, sel=None):
     """What ndbhip_ivf_search_partial_device emits on `rank` (restated with the oracle's distances)."""
-    sel = img.select_clusters(q, nprobe)
+    if sel is None:
+        sel = img.select_clusters(q, nprobe)
     ll = a["list_len"]
     off = np.zeros(len(ll) + 1, np.int64)
     off[1:] = np.cumsum(ll)
@@ -51,23 +52,28 @@ def _worker(rank, world, port, seed, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from neurondb_amd.dist import ShardedSearchBuffers, gather_and_merge, partition_lists
+    from neurondb_amd.dist import ShardedSearchBuffers, gather_and_merge, gather_probes, partition_lists, query_slice
     a = make_ivf_arrays(1500, 16, 12, seed=seed, dup_frac=0.2, integer=True)
     img = oracle_image(a)
     owner = partition_lists(a["list_len"], world)
     rng = np.random.default_rng(seed + 1)
-    queries = rng.integers(-3, 4, size=(6, 16)).astype(np.float32)
+    queries = rng.integers(-3, 4, size=(7, 16)).astype(np.float32)      # 7: the last rank's slice is short
     k, nprobe = 10, 5
-    buf = ShardedSearchBuffers(len(queries), k, world, "cpu")
+    buf = ShardedSearchBuffers(len(queries), k, world, "cpu", nprobe=nprobe)
+    # cluster selection split by queries: this rank selects for its slice only, the slices are all-gathered
+    lo, hi, _ = query_slice(len(queries), world, rank)
+    for i in range(lo, hi):
+        buf.probes_mine[i - lo] = torch.from_numpy(img.select_clusters(queries[i], nprobe).astype(np.int32))
+    probes = gather_probes(buf).numpy()
+    ok = all(np.array_equal(probes[i], img.select_clusters(q, nprobe)) for i, q in enumerate(queries))
     for i, q in enumerate(queries):
-        rec, total = _rank_records(a, img, owner, rank, q, nprobe, k)
+        rec, total = _rank_records(a, img, owner, rank, q, nprobe, k, sel=probes[i])
         raw = np.zeros((buf.cap,), dtype=rec.dtype)
         raw[:len(rec)] = rec
         buf.cand[i] = torch.from_numpy(raw.view(np.int64).reshape(buf.cap, 2))
         buf.ncand[i] = len(rec)
         buf.total[i] = total
     ot, od, oc = gather_and_merge(buf)
-    ok = True
     for i, q in enumerate(queries):
         et, ed, _ = img.search(q, 1, nprobe, k, 0)
         got = ndbo.tids_from_device_u64(ot[i, :len(et)].numpy())

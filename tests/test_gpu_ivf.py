@@ -222,6 +222,59 @@ def test_sharded_partial_plus_merge_equals_single_device():
     assert np.array_equal(ndbo.tids_from_device_u64(ot2), et) and np.array_equal(oc2, ec)
 
 
+def test_sharded_search_with_query_split_selection():
+    """The N > 1 flow of neurondb_amd.dist with cluster selection split by queries, 4 ranks emulated on one
+    GPU: each shard selects for its slice (select_clusters_device), the slices are concatenated (= the
+    all-gather), every shard scans its lists for all queries with the given probes, merge == unsharded."""
+    import torch
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd.dist import query_slice
+    a = make_ivf_arrays(5000, 64, 24, seed=31, dup_frac=0.1)
+    img = oracle_image(a)
+    q = _queries(a, 37, seed=32)                       # 37 queries: grouped scan, ragged last slice
+    k, nprobe, world = 10, 6, 4
+    cap = 3 * k
+    off = np.zeros(25, np.int64)
+    off[1:] = np.cumsum(a["list_len"])
+    dq = torch.from_numpy(q).cuda()
+    shards = []
+    for w in range(world):
+        owned = (np.arange(24) % world == w).astype(np.uint8)
+        sel = np.concatenate([np.arange(off[l], off[l + 1]) for l in range(24) if owned[l]]).astype(np.int64)
+        ix = IvfIndex(64, 24)
+        ix.set_centroids(a["centroids"])
+        ix.load(a["list_len"], a["rows"][sel], a["tids"][sel], owned=owned)
+        shards.append(ix)
+    s = query_slice(len(q), world, 0)[2]
+    probes_all = torch.zeros((world * s, nprobe), dtype=torch.int32, device="cuda")
+    for w in range(world):
+        lo, hi, _ = query_slice(len(q), world, w)
+        if hi > lo:
+            shards[w].select_clusters_device(dq[lo:hi], probes_all[w * s:w * s + hi - lo], nprobe)
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    probes = probes_all[:len(q)].contiguous()
+    exp_probes = np.stack([img.select_clusters(qq, nprobe) for qq in q])
+    assert np.array_equal(probes.cpu().numpy(), exp_probes)
+    cand = torch.zeros((world, len(q), cap, 2), dtype=torch.int64, device="cuda")
+    ncand = torch.zeros((world, len(q)), dtype=torch.int32, device="cuda")
+    total = torch.zeros((world, len(q)), dtype=torch.int64, device="cuda")
+    for w in range(world):
+        shards[w].search_partial_probes_device(dq, probes, cand[w], ncand[w], total[w], 1, nprobe, k)
+    ot = torch.zeros((len(q), k), dtype=torch.int64, device="cuda")
+    od = torch.zeros((len(q), k), dtype=torch.float32, device="cuda")
+    oc = torch.zeros(len(q), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().ndbhip_merge_topk_device(cand.data_ptr(), ncand.data_ptr(), total[0].data_ptr(),
+                                                   world, len(q), k, cap, ot.data_ptr(), od.data_ptr(),
+                                                   oc.data_ptr()))
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+    from oracle import ndbo
+    assert np.array_equal(oc.cpu().numpy(), ec)
+    assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
+    assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+    assert np.array_equal(total.cpu().numpy(), np.broadcast_to(total[0].cpu().numpy(), (world, len(q))))
+
+
 @pytest.fixture
 def scan_mode():
     from neurondb_amd import _lib
