@@ -43,13 +43,17 @@ def parse():
     ap.add_argument("--lists", type=int, default=1024)
     ap.add_argument("--probes", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="queries per step")
+    ap.add_argument("--batch", type=int, default=4096, help="queries per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=200)
     ap.add_argument("--data", choices=["clustered", "gauss"], default="clustered",
                     help="clustered: mixture of --components Gaussians (sigma --sigma); gauss: i.i.d. N(0,1)")
     ap.add_argument("--components", type=int, default=1024)
     ap.add_argument("--sigma", type=float, default=0.1)
+    ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
+                    help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
+    ap.add_argument("--dist-parity-queries", type=int, default=128,
+                    help="N>1: merged results of this many queries are checked against the CPU oracle on rank 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded path (process group, partial search, all-gather, merge) even at N=1")
     return ap.parse_args()
@@ -138,6 +142,9 @@ def main():
     build_vps = n / t_build
     cent_h, list_len, _, _ = ix_full.export(rows=False)
     del base
+    full_image = None
+    if use_dist and rank == 0 and args.dist_parity_queries > 0:
+        full_image = ix_full.export(rows=True)          # host copy of the unsharded index for the parity sample
 
     # ---------------- shard lists over ranks ----------------
     owner = partition_lists(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
@@ -233,6 +240,22 @@ def main():
         if args.cpu_seconds > 0:
             cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_h, tids_h, qs, out_t, out_d, out_c)
 
+    dist_parity = None
+    if use_dist and args.dist_parity_queries > 0:
+        # every rank runs the step (collectives); rank 0 replays a sample on the CPU oracle
+        qs = queries[args.warmup * nq: args.warmup * nq + nq]
+        step(qs)
+        barrier()
+        if rank == 0:
+            dist_parity = run_dist_parity(args, full_image, qs, out_t, out_d, out_c)
+
+    hnsw = None
+    if rank == 0 and world == 1 and args.hnsw_nvec > 0:
+        try:
+            hnsw = hnsw_leg(args, dev)
+        except Exception as e:                      # the IVF line must not depend on this leg
+            hnsw = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         line = {
             "metric": "kNN queries/sec @ recall@10, 1M x 768 fp32 (IVFFlat lists=1024 probes=32 k=10 L2)",
@@ -253,10 +276,115 @@ def main():
             "bytes_per_query": int(st["bytes_scored"] / max(1, nq * args.steps)) + nlists * dim * 4,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "dist_parity_on_sample": dist_parity,
+            "hnsw": hnsw,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+
+
+def run_dist_parity(args, image, qs, out_t, out_d, out_c):
+    """N > 1: the merged (all-gather + replay) results of a sample against the oracle's single-process search."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import ndbo
+    cent_h, list_len, rows_h, tid_h = image
+    tid_h = np.ascontiguousarray(tid_h).view(ndbo.TID_DTYPE).reshape(-1)
+    off = np.zeros(len(list_len) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(list_len)
+    img = ndbo.IvfImage(cent_h, off, rows_h, tid_h)
+    ns = min(args.dist_parity_queries, len(qs))
+    q_h = qs[:ns].cpu().numpy()
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as ex:
+        res = list(ex.map(lambda i: img.search(q_h[i], 1, args.probes, args.k, 0), range(ns)))
+    gt = ndbo.tids_from_device_u64(out_t[:ns].cpu().numpy())
+    gd = out_d[:ns].cpu().numpy()
+    gc = out_c[:ns].cpu().numpy()
+    bad = 0
+    for i, (et, ed, _) in enumerate(res):
+        bad += not (gc[i] == len(et) and np.array_equal(gt[i, :len(et)], ndbo.tids_to_u64(et)) and
+                    np.array_equal(gd[i, :len(et)].view(np.uint32), ed.view(np.uint32)))
+    return {"queries": ns, "mismatches": int(bad)}
+
+
+def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=2000):
+    """BASELINE config C3: HNSW m=16 ef_search=64 k=10 cosine on unit-norm rows — device build
+    (ndbhip_hnsw_build_device) and batch search, with a sample of the queries replayed by the CPU oracle
+    on the exported graph (blocks, ranks, float4 bits and evaluation counts must all agree)."""
+    import ctypes as C
+    from neurondb_amd import HnswIndex
+    from neurondb_amd._lib import check, lib
+    from oracle import ndbo
+    n, dim, k = args.hnsw_nvec, args.dim, args.k
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0003)
+    base = torch.randn((n, dim), generator=g, device=dev)
+    base = base / base.norm(dim=1, keepdim=True)
+    q = torch.randn((nq, dim), generator=g, device=dev)
+    q = q / q.norm(dim=1, keepdim=True)
+    r = np.random.default_rng(11).uniform(1e-12, 1.0, n)
+    levels = np.clip((-np.log(r) * np.float32(0.36)).astype(np.int32), 0, 15)      # hnsw_am.c:1143-1161
+    tids = pack_tids(torch.arange(n, device=dev))
+    ix = HnswIndex(dim, m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    check(lib().ndbhip_hnsw_build_device(ix._h, C.c_void_p(base.data_ptr()), C.c_void_p(tids.data_ptr()), n,
+                                         levels.ctypes.data, efc))
+    check(lib().ndbhip_synchronize())
+    tb = time.perf_counter() - t0
+    ix.nblocks = n + 1
+    ob = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+    od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+    ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    osc = torch.zeros(nq, dtype=torch.int64, device=dev)
+
+    def run():
+        check(lib().ndbhip_hnsw_search_device(ix._h, C.c_void_p(q.data_ptr()), nq, 2, ef, k,
+                                              C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
+                                              C.c_void_p(oc.data_ptr()), C.c_void_p(ot.data_ptr()),
+                                              C.c_void_p(osc.data_ptr())))
+        check(lib().ndbhip_synchronize())
+    run()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    ts = (time.perf_counter() - t0) / reps
+    evals = float(osc.double().mean())
+    bytes_q = evals * (48 + 4 * dim + 4 * 2 * m)            # SURVEY 8d: E x (node header + vector + level-0 slots)
+    sims = q[:200].double() @ base.double().T
+    gt = torch.topk(sims, k, dim=1).indices.cpu().numpy() + 1
+    got = ob.cpu().numpy()
+    cnt = oc.cpu().numpy()
+    recall = float(np.mean([len(set(got[i][:cnt[i]]) & set(gt[i])) / k for i in range(200)]))
+    # oracle replay on the device-built graph
+    e = ix.export()
+    vecs = np.zeros((n + 1, dim), np.float32)
+    vecs[1:] = base.cpu().numpy()
+    og = ndbo.HnswGraph.from_arrays(vecs, e["levels"], e["ncount"], e["nbrs"], None, e["entry_point"],
+                                    e["entry_level"], m, efc)
+    sample, bad = 32, 0
+    qh, gd, gs = q[:sample].cpu().numpy(), od.cpu().numpy(), osc.cpu().numpy()
+    t0 = time.perf_counter()
+    for i in range(sample):
+        eb, ed, ns = og.search(qh[i], 2, ef, k)
+        bad += not (cnt[i] == len(eb) and np.array_equal(got[i, :len(eb)], eb) and
+                    np.array_equal(gd[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and gs[i] == ns)
+    tc = (time.perf_counter() - t0) / sample
+    return {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k} cosine, "
+                        f"{nq}-query batches (BASELINE config C3)",
+            "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 3), "build_schedule": ix.build_stats(),
+            "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
+            "evaluations_per_query": round(evals, 1), "bytes_per_query": int(bytes_q),
+            "roofline": {"bound": "hbm", "achieved": round(nq / ts * bytes_q / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(nq / ts * bytes_q / 1e9 / HBM_PEAK_GBPS, 4),
+                         "note": "dependent graph walk: latency-bound, as SURVEY 8d expects"},
+            "recall_at_10": round(recall, 4),
+            "recall_note": "the reference's level-0 walk is BFS-until-ef (quirk Q10); the oracle returns the same ids",
+            "oracle_parity": {"queries": sample, "mismatches": int(bad),
+                              "checked": "blocks, ranks, float4 bits, evaluation counts"},
+            "cpu_oracle_ms_per_query_single_thread": round(tc * 1e3, 3)}
 
 
 def pmc_traffic(args, world, kernel="k_ivf_scan"):
