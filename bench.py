@@ -50,6 +50,9 @@ def parse():
                     help="clustered: mixture of --components Gaussians (sigma --sigma); gauss: i.i.d. N(0,1)")
     ap.add_argument("--components", type=int, default=1024)
     ap.add_argument("--sigma", type=float, default=0.1)
+    ap.add_argument("--rows", choices=["f32", "f16"], default="f32",
+                    help="f16: search a halfvec twin of the index (rows narrowed round-to-nearest-even on the device)")
+    ap.add_argument("--strategy", choices=["l2", "cosine", "ip"], default="l2")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
     ap.add_argument("--dist-parity-queries", type=int, default=128,
@@ -143,8 +146,14 @@ def main():
     cent_h, list_len, _, _ = ix_full.export(rows=False)
     del base
     full_image = None
-    if use_dist and rank == 0 and args.dist_parity_queries > 0:
+    if use_dist and rank == 0 and args.dist_parity_queries > 0 and args.rows == "f32" and args.strategy == "l2":
         full_image = ix_full.export(rows=True)          # host copy of the unsharded index for the parity sample
+
+    if args.rows == "f16":
+        ix16 = ix_full.to_f16(reference_encoder=False)
+        ix_full.close()
+        ix_full = ix16
+    strategy = {"l2": 1, "cosine": 2, "ip": 3}[args.strategy]
 
     # ---------------- shard lists over ranks ----------------
     owner = partition_lists(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
@@ -163,9 +172,9 @@ def main():
 
     def step(qs):
         if not use_dist:
-            ix.search_device(qs, out_t, out_d, out_c, 1, nprobe, k, 0)
+            ix.search_device(qs, out_t, out_d, out_c, strategy, nprobe, k, 0)
         else:
-            sharded_search(ix, qs, buf, 1, nprobe, k, 0, rank=rank)
+            sharded_search(ix, qs, buf, strategy, nprobe, k, 0, rank=rank)
 
     def barrier():
         if use_dist:
@@ -193,13 +202,17 @@ def main():
 
     # ---------------- roofline of the dominant kernel ----------------
     grouped = (nq >= 8 and dim % 64 == 0)
-    kernel = "k_ivf_scan_grouped<R_IVF_L2>" if grouped else "k_ivf_scan<R_IVF_L2>"
+    recipe = {"l2": "R_IVF_L2", "cosine": "R_IVF_COS", "ip": "R_IVF_IP"}[args.strategy]
+    esz = 2 if args.rows == "f16" else 4
+    kernel = (f"k_ivf_scan_grouped<{recipe}{', fp16 rows' if esz == 2 else ''}>" if grouped
+              else f"k_ivf_scan{'_h' if esz == 2 else ''}<{recipe}>")
     launches = max(1, st["scan_launches"])
     bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B per query
     ms_per_launch = st["scan_kernel_ms"] / launches
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     # every scored (row element, query) pair costs one subtract, one multiply, one add, unfused
-    flops_per_launch = 3.0 * bytes_per_launch / 4.0
+    # (inner product: multiply + add; cosine: two of those — the query's norm is computed once)
+    flops_per_launch = {"l2": 3.0, "ip": 2.0, "cosine": 4.0}[args.strategy] * bytes_per_launch / esz
     valu_tflops = flops_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -214,7 +227,8 @@ def main():
     # ---------------- recall@10 vs exact float64 brute force ----------------
     recall = None
     cpu_baseline = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.rows == "f32" and args.strategy == "l2" and \
+            (args.recall_queries > 0 or args.cpu_seconds > 0):
         rq = min(args.recall_queries, nq)
         qs = queries[args.warmup * nq: args.warmup * nq + nq]
         step(qs)
@@ -234,14 +248,14 @@ def main():
             sel = torch.topk(dd, k, dim=1, largest=False)
             best_d, best_i = sel.values, torch.gather(ii, 1, sel.indices)
         gt = best_i.cpu().numpy()
-        recall = float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(rq)]))
+        recall = float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(rq)])) if rq > 0 else None
 
         # ---------------- CPU baseline: the oracle on the host cores (bounded sample) ----------------
         if args.cpu_seconds > 0:
             cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_h, tids_h, qs, out_t, out_d, out_c)
 
     dist_parity = None
-    if use_dist and args.dist_parity_queries > 0:
+    if use_dist and args.dist_parity_queries > 0 and args.rows == "f32" and args.strategy == "l2":
         # every rank runs the step (collectives); rank 0 replays a sample on the CPU oracle
         qs = queries[args.warmup * nq: args.warmup * nq + nq]
         step(qs)
@@ -261,9 +275,11 @@ def main():
             "metric": "kNN queries/sec @ recall@10, 1M x 768 fp32 (IVFFlat lists=1024 probes=32 k=10 L2)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if esz == 4 else "f32 arithmetic on fp16 rows",
             "data": "synthetic (torch generator, seeds 0x5EED0001 base / 0x5EED0002 queries)",
-            "config": {"workload": f"IVFFlat {n}x{dim} fp32 lists={nlists} probes={nprobe} k={k} L2, "
+            "config": {"workload": f"IVFFlat {n}x{dim} {'fp32' if esz == 4 else 'fp16'} lists={nlists} probes={nprobe} "
+                                   f"k={k} {args.strategy.upper()}, "
                                    f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
                        "sharding": "none" if world == 1 else f"lists over {world} ranks (LPT), RCCL all-gather + merge",
                        "data": (f"mixture of {args.components} Gaussians, sigma={args.sigma}" if args.data == "clustered"
@@ -274,6 +290,8 @@ def main():
             "recall_at_10": None if recall is None else round(recall, 4),
             "build_vectors_per_s": None if build_vps is None else round(build_vps, 1),
             "bytes_per_query": int(st["bytes_scored"] / max(1, nq * args.steps)) + nlists * dim * 4,
+            "note": None if (args.rows == "f32" and args.strategy == "l2") else
+            "recall / CPU legs run for the default fp32 L2 workload only; parity of this variant: tests/test_gpu_ivf.py",
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "dist_parity_on_sample": dist_parity,

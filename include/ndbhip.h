@@ -169,6 +169,11 @@ int			ndbhip_ivf_write_pages(const ndbhip_ivf *ix, int nprobe, uint8_t *pages, u
  * per GPU keeps its share); list lengths stay global, so candidate positions —
  * and therefore the merged result — are identical to the unsharded index. */
 int			ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out);
+/* A halfvec twin of a float4 mirror (same centroids, lists, TIDs): rows narrowed on the device with the
+ * reference's own encoder float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal
+ * results flushed to zero) when reference_encoder != 0 — what a halfvec column cast by the reference holds —
+ * else round-to-nearest-even. */
+int			ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out);
 int64_t		ndbhip_ivf_nrows(const ndbhip_ivf *ix);			/* rows resident on this device */
 int64_t		ndbhip_ivf_max_candidates(const ndbhip_ivf *ix, int nprobe);	/* sum of the nprobe longest lists */
 

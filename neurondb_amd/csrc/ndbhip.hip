@@ -3516,8 +3516,6 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 	for (int c = 0; c < src->ncent; c++)
 		if (owned[c] && !src->owned[c])
 			return fail(NDBHIP_ERR_INVALID, "list %d is not resident in the source index", c);
-	if (src->f16)
-		return fail(NDBHIP_ERR_UNSUPPORTED, "sharding an fp16 mirror is not implemented: load each shard with ndbhip_ivf_load_f16");
 	if (!src->pend_list.empty())
 		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
 	ndbhip_ivf *ix = nullptr;
@@ -3539,24 +3537,105 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 		return rc;
 	const int64_t cap = nrows > 0 ? nrows : 1;
 
-	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * sizeof(float)));
+	const size_t esz = src->f16 ? sizeof(uint16_t) : sizeof(float);	/* rows are fp16 images or float4 */
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * esz));
 	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
 	ix->own_rows = true;
 	ix->cap_rows = cap;
+	ix->f16 = src->f16;
 	for (int c = 0; c < src->ncent; c++)
 	{
 		const int64_t n = src->glob_len[c];
 
 		if (!owned[c] || n == 0)
 			continue;
-		HIP_TRY(hipMemcpyAsync(ix->d_vecs + (size_t) ix->loc_off[c] * ix->dim,
-							   src->d_vecs + (size_t) src->loc_off[c] * src->dim,
-							   (size_t) n * ix->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync((char *) ix->d_vecs + (size_t) ix->loc_off[c] * ix->dim * esz,
+							   (const char *) src->d_vecs + (size_t) src->loc_off[c] * src->dim * esz,
+							   (size_t) n * ix->dim * esz, hipMemcpyDeviceToDevice, g.stream));
 		HIP_TRY(hipMemcpyAsync(ix->d_tids + ix->loc_off[c], src->d_tids + src->loc_off[c],
 							   (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = nrows;
+	ix->loaded = true;
+	*out = ix;
+	return NDBHIP_OK;
+}
+
+/* float4 -> IEEE half image.  REF = the reference's float4_to_fp16 (src/types/quantization.c:141-168:
+ * mantissa truncated, subnormal results flushed to signed zero, overflow and NaN -> infinity); else
+ * round-to-nearest-even (v_cvt_f16_f32). */
+template <bool REF>
+__global__ __launch_bounds__(256) void
+k_rows_to_f16(const float *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
+{
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+
+	if (i >= n)
+		return;
+	if (REF)
+	{
+		const uint32_t u = __float_as_uint(src[i]);
+		const uint16_t sign = (uint16_t) ((u >> 16) & 0x8000u);
+		const int	e = (int) ((u >> 23) & 0xffu) - 127 + 15;
+
+		dst[i] = e <= 0 ? sign : (e >= 31 ? (uint16_t) (sign | 0x7c00u)
+								  : (uint16_t) (sign | ((uint32_t) e << 10) | ((u & 0x7fffffu) >> 13)));
+	}
+	else
+		dst[i] = __half_as_ushort(__float2half_rn(src[i]));
+}
+
+/* A halfvec twin of a float4 mirror: same centroids, lists and TIDs, rows narrowed on the device. */
+extern "C" int
+ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!src || !src->loaded || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (src->f16)
+		return fail(NDBHIP_ERR_STATE, "the mirror already holds fp16 rows");
+	if (src->dim % 64 != 0)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "fp16 rows need dim %% 64 == 0 (dim = %d)", src->dim);
+	if (!src->pend_list.empty())
+		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
+	ndbhip_ivf *ix = nullptr;
+	int			rc = ndbhip_ivf_create(src->dim, src->nlists, &ix);
+
+	if (rc)
+		return rc;
+	HIP_TRY(hipMalloc((void **) &ix->d_centroids, (size_t) src->ncent * src->dim * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(ix->d_centroids, src->d_centroids, (size_t) src->ncent * src->dim * sizeof(float),
+						   hipMemcpyDeviceToDevice, g.stream));
+	ix->ncent = src->ncent;
+	rc = ivf_set_layout(ix, src->glob_len.data(), src->owned.data(), src->nrows);
+	if (rc)
+		return rc;
+	const int64_t cap = src->nrows > 0 ? src->nrows : 1;
+	const size_t nel = (size_t) src->nrows * src->dim;
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * sizeof(uint16_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
+	ix->own_rows = true;
+	ix->cap_rows = cap;
+	if (nel > 0)
+	{
+		const dim3	grid((unsigned) ((nel + 255) / 256));
+
+		if (reference_encoder)
+			hipLaunchKernelGGL(k_rows_to_f16<true>, grid, dim3(256), 0, g.stream, (const float *) src->d_vecs,
+							   (uint16_t *) ix->d_vecs, nel);
+		else
+			hipLaunchKernelGGL(k_rows_to_f16<false>, grid, dim3(256), 0, g.stream, (const float *) src->d_vecs,
+							   (uint16_t *) ix->d_vecs, nel);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(ix->d_tids, src->d_tids, (size_t) src->nrows * sizeof(uint64_t),
+							   hipMemcpyDeviceToDevice, g.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	ix->nrows = src->nrows;
+	ix->f16 = true;
 	ix->loaded = true;
 	*out = ix;
 	return NDBHIP_OK;

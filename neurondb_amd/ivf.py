@@ -121,6 +121,15 @@ class IvfIndex:
         sub.ncent = getattr(self, "ncent", self.nlists)
         return sub
 
+    def to_f16(self, reference_encoder=True):
+        """Halfvec twin of this float4 mirror (rows narrowed on the device; ndbhip_ivf_to_f16)."""
+        h = C.c_void_p()
+        check(lib().ndbhip_ivf_to_f16(self._h, int(bool(reference_encoder)), C.byref(h)))
+        sub = IvfIndex.__new__(IvfIndex)
+        sub.dim, sub.nlists, sub._h, sub._keep = self.dim, self.nlists, h, []
+        sub.ncent = getattr(self, "ncent", self.nlists)
+        return sub
+
     def export(self, rows=True):
         """Read the mirror back: (centroids, list_len, rows, tids structured)."""
         nc = lib().ndbhip_ivf_ncentroids(self._h)

@@ -430,3 +430,60 @@ def test_fp16_rows_are_bit_identical_to_expanded_float4_rows(dim, n, nlists, sca
             t, d, c = ix.search(q, strategy, 5, 10)
             et, ed, ec, _ = oracle_search_batch(img, q, strategy, 5, 10)
             assert_same_results(t, d, c, et, ed, ec)
+
+
+@pytest.mark.parametrize("reference_encoder", [True, False])
+def test_to_f16_twin_and_its_shards(reference_encoder):
+    """ndbhip_ivf_to_f16: rows narrowed on the device with the reference's float4_to_fp16 (truncating,
+    flush-to-zero) or round-to-nearest-even; the twin — and its list shards — search like the oracle over
+    the re-expanded rows."""
+    import torch
+    from neurondb_amd import IvfIndex, _lib
+    from oracle import ndbo
+    L = ndbo.lib()
+    dim, n, nlists = 128, 4000, 16
+    a = make_ivf_arrays(n, dim, nlists, seed=77, dup_frac=0.05)
+    rows = (a["rows"] * 0.37).astype(np.float32)
+    # flush-to-zero and the smallest-normal edge; values that overflow fp16 (-> inf, then inf - inf = NaN in a
+    # score) are left out: a NaN distance is outside the parity contract (DESIGN.md, "Non-finite distances")
+    rows[5, :6] = [1e-6, -1e-6, 65000.0, -65000.0, 6.1e-5, 5.9e-5]
+    a = dict(a, rows=rows)
+    if reference_encoder:
+        h = np.array([L.ndbo_float4_to_fp16(float(v)) for v in rows.reshape(-1)], np.uint16).reshape(rows.shape)
+    else:
+        with np.errstate(over="ignore"):
+            h = rows.astype(np.float16).view(np.uint16)
+    lut = np.array([L.ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+    img = oracle_image(dict(a, rows=lut[h]))
+    full = IvfIndex(dim, nlists)
+    full.set_centroids(a["centroids"])
+    full.load(a["list_len"], a["rows"], a["tids"])
+    twin = full.to_f16(reference_encoder)
+    q = _queries(a, 40, seed=78)
+    for strategy in (3, 1):
+        t, d, c = twin.search(q, strategy, 6, 10)
+        et, ed, ec, _ = oracle_search_batch(img, q, strategy, 6, 10)
+        assert_same_results(t, d, c, et, ed, ec)
+    # shards of the fp16 twin + merge == the twin
+    world, k, nprobe = 2, 10, 6
+    cap = 3 * k
+    dq = torch.from_numpy(q).cuda()
+    cand = torch.zeros((world, len(q), cap, 2), dtype=torch.int64, device="cuda")
+    ncand = torch.zeros((world, len(q)), dtype=torch.int32, device="cuda")
+    total = torch.zeros((world, len(q)), dtype=torch.int64, device="cuda")
+    keep = []
+    for w in range(world):
+        sh = twin.shard((np.arange(nlists) % world == w).astype(np.uint8))
+        sh.search_partial_device(dq, cand[w], ncand[w], total[w], 3, nprobe, k)
+        keep.append(sh)
+    ot = torch.zeros((len(q), k), dtype=torch.int64, device="cuda")
+    od = torch.zeros((len(q), k), dtype=torch.float32, device="cuda")
+    oc = torch.zeros(len(q), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().ndbhip_merge_topk_device(cand.data_ptr(), ncand.data_ptr(), total[0].data_ptr(),
+                                                   world, len(q), k, cap, ot.data_ptr(), od.data_ptr(),
+                                                   oc.data_ptr()))
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    et, ed, ec, _ = oracle_search_batch(img, q, 3, nprobe, k)
+    assert np.array_equal(oc.cpu().numpy(), ec)
+    assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
+    assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
