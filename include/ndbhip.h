@@ -131,6 +131,12 @@ int			ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint
 /* aminsert: append one entry to the tail of list `list_id`
  * (src/index/ivf_am.c:954-1157) — see ndbhip_ivf_assign for the list choice. */
 int			ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6);
+/* ambulkdelete (src/index/ivf_am.c:1172-1357): every entry whose heapPtr is one of the n given TIDs is
+ * dropped from the mirror (the reference marks its line pointer dead and scans skip it, :1816-1822);
+ * survivors keep their list and their order inside it.  *removed = entries dropped.  Runs on the device
+ * (mark by binary search, prefix scan, move).  Not for sharded mirrors: delete on the full mirror and shard
+ * again, the other ranks' candidate positions change with it. */
+int			ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *removed);
 
 /* Read the mirror back to the host (any pointer may be NULL): centroids
  * [ncentroids*dim], list_len [ncentroids] (owned lists only), rows/tids6 of

@@ -83,6 +83,7 @@ def lib():
         "ndbhip_ivf_append": (i, [vp, i, vp, vp]),
         "ndbhip_ivf_export": (i, [vp, vp, vp, vp, vp]),
         "ndbhip_ivf_ncentroids": (i, [vp]),
+        "ndbhip_ivf_delete": (i, [vp, vp, i64, C.POINTER(i64)]),
         "ndbhip_ivf_to_f16": (i, [vp, i, C.POINTER(vp)]),
         "ndbhip_ivf_shard": (i, [vp, vp, C.POINTER(vp)]),
         "ndbhip_ivf_shape": (i, [vp, C.POINTER(i), C.POINTER(i)]),

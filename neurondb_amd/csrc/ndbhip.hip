@@ -2123,6 +2123,227 @@ ivf_flush(ndbhip_ivf *ix)
 	return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* ambulkdelete (src/index/ivf_am.c:1172-1357): the callback is a set    */
+/* test on heapPtr; entries it hits get a dead line pointer and every    */
+/* later scan skips them (:1816-1822).  On the mirror: drop those rows,  */
+/* survivors keep their list and their order inside it.                  */
+/* ------------------------------------------------------------------ */
+
+/* keep[r] = heapPtr of row r is NOT in the sorted dead set; block_sum[b] = keeps in rows [256b, 256b+256) */
+__global__ __launch_bounds__(256) void
+k_delete_mark(const uint64_t *__restrict__ tids, int64_t nrows, const uint64_t *__restrict__ dead, int64_t ndead,
+			  uint8_t *__restrict__ keep, uint32_t *__restrict__ block_sum)
+{
+	__shared__ uint32_t wsum[4];
+	const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	bool		k = false;
+
+	if (r < nrows)
+	{
+		const uint64_t t = tids[r];
+		int64_t		lo = 0, hi = ndead;
+
+		while (lo < hi)
+		{
+			const int64_t mid = (lo + hi) >> 1;
+
+			if (dead[mid] < t)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		k = !(lo < ndead && dead[lo] == t);
+		keep[r] = k ? 1 : 0;
+	}
+	const unsigned long long b = __ballot(k);
+
+	if ((threadIdx.x & 63) == 0)
+		wsum[threadIdx.x >> 6] = (uint32_t) __popcll(b);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		block_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+/* exclusive scan of block_sum in place (one block); total -> *total */
+__global__ __launch_bounds__(1024) void
+k_delete_scan(uint32_t *__restrict__ block_sum, uint32_t nblocks, uint32_t *__restrict__ total)
+{
+	__shared__ uint32_t sh[1024];
+	__shared__ uint32_t carry;
+
+	if (threadIdx.x == 0)
+		carry = 0;
+	__syncthreads();
+	for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024)
+	{
+		const uint32_t i = b0 + threadIdx.x;
+		const uint32_t v = i < nblocks ? block_sum[i] : 0u;
+
+		sh[threadIdx.x] = v;
+		__syncthreads();
+		for (uint32_t off = 1; off < 1024; off <<= 1)
+		{
+			const uint32_t add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+
+			__syncthreads();
+			sh[threadIdx.x] += add;
+			__syncthreads();
+		}
+		if (i < nblocks)
+			block_sum[i] = carry + sh[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 1023)
+			carry += sh[1023];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		*total = carry;
+}
+
+/* new position of every kept row; pref[r] = survivors before row r (pref[nrows] = total) */
+__global__ __launch_bounds__(256) void
+k_delete_positions(const uint8_t *__restrict__ keep, int64_t nrows, const uint32_t *__restrict__ block_base,
+				   uint32_t *__restrict__ pref)
+{
+	__shared__ uint32_t wsum[4];
+	const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	const bool	k = r < nrows && keep[r];
+	const unsigned long long b = __ballot(k);
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+
+	if (lane == 0)
+		wsum[w] = (uint32_t) __popcll(b);
+	__syncthreads();
+	uint32_t	base = block_base[blockIdx.x];
+
+	for (uint32_t i = 0; i < w; i++)
+		base += wsum[i];
+	if (r < nrows)
+		pref[r] = base + (uint32_t) __popcll(b & ((1ull << lane) - 1ull));
+	if (r == nrows - 1)
+		pref[nrows] = base + (uint32_t) __popcll(b & ((1ull << lane) - 1ull)) + (k ? 1u : 0u);
+}
+
+/* one block per row: survivors move to pref[r] (rows are `row_bytes` bytes, a multiple of 4) */
+__global__ __launch_bounds__(256) void
+k_delete_move(const uint8_t *__restrict__ keep, const uint32_t *__restrict__ pref, const uint32_t *__restrict__ src,
+			  const uint64_t *__restrict__ src_tids, uint32_t *__restrict__ dst, uint64_t *__restrict__ dst_tids,
+			  uint32_t row_words)
+{
+	const size_t r = blockIdx.x;
+
+	if (!keep[r])
+		return;
+	const size_t d = pref[r];
+
+	for (uint32_t j = threadIdx.x; j < row_words; j += 256)
+		dst[d * row_words + j] = src[r * row_words + j];
+	if (threadIdx.x == 0)
+		dst_tids[d] = src_tids[r];
+}
+
+__global__ void
+k_delete_list_len(const uint32_t *__restrict__ pref, const int64_t *__restrict__ loc_off, int ncent,
+				  int64_t *__restrict__ new_len)
+{
+	const int	L = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (L < ncent)
+		new_len[L] = (int64_t) pref[loc_off[L + 1]] - (int64_t) pref[loc_off[L]];
+}
+
+extern "C" int
+ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *removed)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || n < 0 || (n > 0 && !tids6))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!ix->loaded)
+		return fail(NDBHIP_ERR_STATE, "index has no lists loaded");
+	if (ix->sharded)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "delete on the unsharded mirror and shard again: the other ranks' "
+					"list lengths (global candidate positions) must change with it");
+	if (!ix->own_rows)
+		return fail(NDBHIP_ERR_STATE, "the rows belong to the caller (ndbhip_ivf_load_device): rebuild the layout there");
+	int			rc = ivf_flush(ix);
+
+	if (rc)
+		return rc;
+	if (removed)
+		*removed = 0;
+	if (n == 0 || ix->nrows == 0)
+		return NDBHIP_OK;
+	std::vector<uint64_t> dead((size_t) n);
+
+	for (int64_t i = 0; i < n; i++)
+		dead[(size_t) i] = ndb_tid_pack(tids6 + 6 * i);
+	std::sort(dead.begin(), dead.end());
+	const int64_t nrows = ix->nrows;
+	const uint32_t nblk = (uint32_t) ((nrows + 255) / 256);
+	const size_t esz = ix->f16 ? sizeof(uint16_t) : sizeof(float);
+	const uint32_t row_words = (uint32_t) ((size_t) ix->dim * esz / 4);
+	uint64_t   *d_dead = nullptr;
+	uint8_t    *d_keep = nullptr;
+	uint32_t   *d_bs = nullptr, *d_pref = nullptr, *d_total = nullptr;
+	int64_t    *d_newlen = nullptr;
+	uint32_t	total = 0;
+
+	if (((size_t) ix->dim * esz) % 4 != 0)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "row size must be a multiple of 4 bytes");
+	HIP_TRY(hipMalloc((void **) &d_dead, (size_t) n * sizeof(uint64_t)));
+	HIP_TRY(hipMalloc((void **) &d_keep, (size_t) nrows));
+	HIP_TRY(hipMalloc((void **) &d_bs, (size_t) nblk * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &d_pref, ((size_t) nrows + 1) * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &d_total, sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &d_newlen, (size_t) ix->ncent * sizeof(int64_t)));
+	HIP_TRY(hipMemcpyAsync(d_dead, dead.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_delete_mark, dim3(nblk), dim3(256), 0, g.stream, (const uint64_t *) ix->d_tids, nrows,
+					   (const uint64_t *) d_dead, n, d_keep, d_bs);
+	hipLaunchKernelGGL(k_delete_scan, dim3(1), dim3(1024), 0, g.stream, d_bs, nblk, d_total);
+	hipLaunchKernelGGL(k_delete_positions, dim3(nblk), dim3(256), 0, g.stream, (const uint8_t *) d_keep, nrows,
+					   (const uint32_t *) d_bs, d_pref);
+	hipLaunchKernelGGL(k_delete_list_len, dim3((ix->ncent + 255) / 256), dim3(256), 0, g.stream,
+					   (const uint32_t *) d_pref, (const int64_t *) ix->d_loc_off, ix->ncent, d_newlen);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, g.stream));
+	std::vector<int64_t> newlen((size_t) ix->ncent);
+
+	HIP_TRY(hipMemcpyAsync(newlen.data(), d_newlen, (size_t) ix->ncent * sizeof(int64_t), hipMemcpyDeviceToHost,
+						   g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if ((int64_t) total < nrows)
+	{
+		const int64_t cap = total > 0 ? (int64_t) total : 1;
+		void	   *nv = nullptr;
+		uint64_t   *nt = nullptr;
+
+		HIP_TRY(hipMalloc(&nv, (size_t) cap * ix->dim * esz));
+		HIP_TRY(hipMalloc((void **) &nt, (size_t) cap * sizeof(uint64_t)));
+		hipLaunchKernelGGL(k_delete_move, dim3((unsigned) nrows), dim3(256), 0, g.stream, (const uint8_t *) d_keep,
+						   (const uint32_t *) d_pref, (const uint32_t *) ix->d_vecs, (const uint64_t *) ix->d_tids,
+						   (uint32_t *) nv, nt, row_words);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		ivf_free_rows(ix);
+		ix->d_vecs = (float *) nv;
+		ix->d_tids = nt;
+		ix->own_rows = true;
+		ix->cap_rows = cap;
+		ix->nrows = (int64_t) total;
+		rc = ivf_set_layout(ix, newlen.data(), nullptr, (int64_t) total);
+	}
+	if (removed)
+		*removed = nrows - (int64_t) total;
+	HIP_TRY(hipFree(d_dead));
+	HIP_TRY(hipFree(d_keep));
+	HIP_TRY(hipFree(d_bs));
+	HIP_TRY(hipFree(d_pref));
+	HIP_TRY(hipFree(d_total));
+	HIP_TRY(hipFree(d_newlen));
+	return rc;
+}
+
 extern "C" int
 ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6)
 {

@@ -121,6 +121,15 @@ class IvfIndex:
         sub.ncent = getattr(self, "ncent", self.nlists)
         return sub
 
+    def delete(self, tids):
+        """ambulkdelete: drop every entry whose heapPtr is in `tids` (structured TID array or [n, 6] bytes);
+        returns the number of entries removed."""
+        t = np.ascontiguousarray(tids)
+        t6 = np.ascontiguousarray(t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6))
+        removed = C.c_int64(0)
+        check(lib().ndbhip_ivf_delete(self._h, _ptr(t6), t6.shape[0], C.byref(removed)))
+        return int(removed.value)
+
     def to_f16(self, reference_encoder=True):
         """Halfvec twin of this float4 mirror (rows narrowed on the device; ndbhip_ivf_to_f16)."""
         h = C.c_void_p()

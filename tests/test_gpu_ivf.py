@@ -487,3 +487,48 @@ def test_to_f16_twin_and_its_shards(reference_encoder):
     assert np.array_equal(oc.cpu().numpy(), ec)
     assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
     assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+
+
+def test_bulkdelete_drops_rows_and_keeps_list_order(scan_mode):
+    """ndbhip_ivf_delete = ambulkdelete's effect on later scans (dead line pointers are skipped,
+    ivf_am.c:1816-1822): results equal the oracle's over the arrays without the deleted entries; a whole list
+    can vanish; unknown TIDs are ignored; appends keep working afterwards."""
+    from neurondb_amd import IvfIndex
+    a = make_ivf_arrays(6000, 64, 24, seed=91, dup_frac=0.1)
+    n = len(a["rows"])
+    rng = np.random.default_rng(92)
+    off = np.zeros(25, np.int64)
+    off[1:] = np.cumsum(a["list_len"])
+    dead = np.zeros(n, bool)
+    dead[rng.choice(n, 900, replace=False)] = True
+    dead[off[5]:off[6]] = True                              # list 5 loses every entry
+    ix = IvfIndex(64, 24)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    ghost = a["tids"][:3].copy()
+    ghost["bi_lo"] = 65000                                  # TIDs the index does not hold
+    assert ix.delete(ghost) == 0
+    victims = np.concatenate([a["tids"][dead], ghost])
+    assert ix.delete(victims[rng.permutation(len(victims))]) == int(dead.sum())
+    assert ix.delete(a["tids"][dead][:10]) == 0             # already gone
+    keep = ~dead
+    new_len = np.array([keep[off[l]:off[l + 1]].sum() for l in range(24)], np.int64)
+    b = dict(a, rows=a["rows"][keep], tids=a["tids"][keep], list_len=new_len)
+    cent, ll, rows, tids = ix.export()
+    assert np.array_equal(ll, new_len) and np.array_equal(rows, b["rows"]) and np.array_equal(tids, b["tids"])
+    img = oracle_image(b)
+    q = _queries(a, 40, seed=93)
+    for mode in (1, 2):
+        scan_mode(mode)
+        for strategy in (1, 2, 3):
+            t, d, c = ix.search(q, strategy, 6, 10)
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, 6, 10)
+            assert_same_results(t, d, c, et, ed, ec)
+    # aminsert after vacuum: the entry lands at the tail of its list
+    from oracle import ndbo
+    newtid = ghost[:1]
+    vnew = (a["rows"][0] + 37.0).astype(np.float32)
+    ix.append(5, vnew, newtid)
+    t, d, c = ix.search(vnew[None, :], 1, 24, 1)
+    assert c[0] == 1 and d[0, 0] == 0.0 and ndbo.tids_to_u64(t[0, :1])[0] == ndbo.tids_to_u64(newtid)[0]
+    assert ix.export()[1][5] == 1
