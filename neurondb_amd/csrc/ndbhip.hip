@@ -60,7 +60,8 @@ static int	g_scan_mode = 0;
 /* rows staged per step by the grouped kernels: 64 floats (16 KiB tile, 3 waves/SIMD) or 32 (8 KiB, 4 waves/SIMD);
  * NDBHIP_GCHUNK overrides for experiments */
 static int	g_gchunk = 32;
-/* hnswbuild: optimistic batches (1) or the one-wave sequential kernel (0); batch = min(max, nodes so far / div) walks */
+/* hnswbuild: 0 the one-wave sequential kernel, 1 optimistic batches with the chunked block-wide commit,
+ * 2 optimistic batches with the one-wave commit; batch = min(max, nodes so far / div) walks */
 static int	g_hnsw_spec = 1;
 static int	g_hnsw_batch_div = 64;
 static int	g_hnsw_batch_max = 1024;
@@ -4882,6 +4883,393 @@ k_hnsw_commit(int16_t *ncount, uint32_t *nbrs, const HnswTask *__restrict__ task
 	}
 }
 
+/*
+ * The same commit, a chunk of walks at a time by a whole block.  What makes that legal: the lists of different
+ * (node, level) pairs evolve independently — a back-link goes to the first InvalidBlockNumber slot of ITS
+ * list, else to the tail — so the requests of a chunk are sorted by (node, level, walk) and every list replays
+ * its own requests in walk order (one thread per list), assuming for the moment that every walk of the chunk
+ * commits.  That replay yields, per list, the first walk that really writes it.  A walk is stale if a list it
+ * read was written before the chunk since it ran (stamps), or is first written inside the chunk by an EARLIER
+ * walk; `stop` = the first stale walk.  For every walk up to `stop` the assumption held (all its predecessors
+ * do commit), so its verdict and its slot positions are the sequential ones; the writes of walks < stop are
+ * then applied, all at once.  A node's own list (hnsw_am.c:2452-2456) takes part as a request that always
+ * writes.  A walk that selected its own node (quirk Q12) is committed alone through hnsw_link.
+ */
+#define NDB_HC_TASKS 64u			/* walks per chunk */
+#define NDB_HC_REQ 2048u			/* requests per chunk, padded (a power of two) */
+#define NDB_HC_MAXSEL 31u			/* NDB_HC_TASKS * (NDB_HC_MAXSEL + 1) <= NDB_HC_REQ */
+#define NDB_HC_NONE 0xFFu
+
+__device__ __forceinline__ uint64_t
+hc_key(uint32_t node, int level, uint32_t j, uint32_t own)
+{
+	return ((uint64_t) node << 16) | ((uint64_t) level << 12) | ((uint64_t) j << 4) | own;
+}
+
+__global__ __launch_bounds__(256) void
+k_hnsw_commit_par(int16_t *ncount, uint32_t *nbrs, const HnswTask *__restrict__ tasks, uint32_t ntasks, int m,
+				  uint32_t ksel, HnswRounds R, uint32_t round)
+{
+	__shared__ uint64_t key[NDB_HC_REQ];
+	__shared__ uint32_t sel[NDB_HC_TASKS * NDB_HC_MAXSEL];
+	__shared__ uint16_t fw[NDB_HC_REQ];			/* at a run head: first walk of the chunk that writes this list */
+	__shared__ uint8_t pos[NDB_HC_REQ];			/* slot a back-link request lands in, NDB_HC_NONE = dropped */
+	__shared__ uint8_t cnt0s[NDB_HC_REQ];		/* at a run head: the list's count before the chunk */
+	__shared__ uint32_t t_ran[NDB_HC_TASKS], t_rsn[NDB_HC_TASKS], t_nsel[NDB_HC_TASKS], t_blk[NDB_HC_TASKS];
+	__shared__ int t_cl[NDB_HC_TASKS];
+	__shared__ uint32_t t_stale[NDB_HC_TASKS], t_off[NDB_HC_TASKS + 1];
+	__shared__ uint32_t s_stop, s_self;
+	const uint32_t tid = threadIdx.x;
+	const int	m2 = 2 * m;
+	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+	const uint32_t first = *R.next;
+	const uint32_t cmax = min(NDB_HC_TASKS, NDB_HC_REQ / (ksel + 1u));
+	uint32_t	cur = first;
+	bool		stopped = false;
+
+	while (cur < ntasks && !stopped)
+	{
+		uint32_t	C = min(cmax, ntasks - cur);
+
+		/* ---- the chunk's walks ---- */
+		if (tid < C)
+		{
+			const uint32_t t = cur + tid;
+			const HnswTask task = tasks[t];
+
+			t_ran[tid] = R.spec_round[t];
+			t_rsn[tid] = R.rsn[t];
+			t_nsel[tid] = (uint32_t) R.nsel[t];
+			t_blk[tid] = task.row + 1;
+			t_cl[tid] = task.cl;
+			/* never run, or its read-set log overflowed: cannot be validated (unless it opens the round) */
+			t_stale[tid] = (t_ran[tid] == 0 || t_rsn[tid] > NDB_HNSW_RS_CAP) ? 1u : 0u;
+		}
+		if (tid == 0)
+		{
+			s_stop = C;
+			s_self = C;
+		}
+		__syncthreads();
+		for (uint32_t e = tid; e < C * ksel; e += 256)
+		{
+			const uint32_t j = e / ksel, idx = e % ksel;
+
+			if (idx < t_nsel[j])
+			{
+				const uint32_t v = R.sel[(size_t) (cur + j) * ksel + idx];
+
+				sel[j * NDB_HC_MAXSEL + idx] = v;
+				if (v == t_blk[j])
+					atomicMin(&s_self, j);
+			}
+		}
+		__syncthreads();
+		const bool	solo = s_self == 0;	/* the chunk's first walk selected its own node: commit it alone */
+
+		if (solo)
+			C = 1;
+		else if (s_self < C)
+			C = s_self;					/* ... a later one: it will open the next chunk */
+		const bool	opens_round = cur == first && t_ran[0] == round;	/* valid by construction */
+
+		if (tid == 0)
+		{
+			s_stop = C;
+			if (opens_round)
+				t_stale[0] = 0;
+		}
+		__syncthreads();
+
+		/* ---- stale against what was written before this chunk ---- */
+		/* (walk, read-set entry) pairs are spread over the block, 8 per thread in flight */
+		if (tid == 0)
+		{
+			uint32_t	acc = 0;
+
+			for (uint32_t j = 0; j < C; j++)
+			{
+				t_off[j] = acc;
+				acc += t_rsn[j] > NDB_HNSW_RS_CAP ? 0u : t_rsn[j];
+			}
+			t_off[C] = acc;
+		}
+		__syncthreads();
+		const uint32_t npairs = t_off[C];
+		auto		pair_walk = [&](uint32_t p) -> uint32_t {	/* largest j with t_off[j] <= p */
+			uint32_t	lo = 0, hi = C;
+
+			while (hi - lo > 1)
+			{
+				const uint32_t mid = (lo + hi) >> 1;
+
+				if (t_off[mid] <= p)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			return lo;
+		};
+
+		for (uint32_t base = 0; base < npairs; base += 256u * 8u)
+		{
+			uint32_t	enc[8], jj[8], stv[8];
+
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t p = base + (uint32_t) u * 256u + tid;
+
+				jj[u] = 0xFFFFFFFFu;
+				enc[u] = 0;
+				if (p < npairs)
+				{
+					jj[u] = pair_walk(p);
+					enc[u] = R.rs[(size_t) (cur + jj[u]) * NDB_HNSW_RS_CAP + (p - t_off[jj[u]])];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t node = enc[u] & ((1u << NDB_HNSW_RS_NODE_BITS) - 1u);
+				const uint32_t *st = (enc[u] >> NDB_HNSW_RS_NODE_BITS) ? R.stampU : R.stamp0;
+
+				stv[u] = jj[u] != 0xFFFFFFFFu ? gload<true>(&st[node]) : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (jj[u] != 0xFFFFFFFFu && !(jj[u] == 0 && opens_round) && stv[u] >= t_ran[jj[u]])
+					t_stale[jj[u]] = 1u;
+		}
+		__syncthreads();
+		if (solo)
+		{
+			if (!t_stale[0])
+			{
+				if (tid < 64)
+				{
+					hnsw_link(nbrs, ncount, t_blk[0], t_cl[0], m, stride, sel, t_nsel[0], R.stamp0, R.stampU, round);
+					hnsw_publish();
+				}
+				cur += 1;
+			}
+			else
+				stopped = true;
+			__syncthreads();
+			continue;
+		}
+
+		/* ---- requests, sorted by (node, level, walk) ---- */
+		const uint32_t nreq = C * (ksel + 1u);
+		uint32_t	npad = 2;
+
+		while (npad < nreq)
+			npad <<= 1;
+		for (uint32_t e = tid; e < npad; e += 256)
+		{
+			uint64_t	kv = ~0ull;
+
+			if (e < nreq)
+			{
+				const uint32_t j = e / (ksel + 1u), idx = e % (ksel + 1u);
+
+				if (idx < t_nsel[j])
+					kv = hc_key(sel[j * NDB_HC_MAXSEL + idx], t_cl[j], j, 0u);
+				else if (idx == ksel && t_nsel[j] > 0)
+					kv = hc_key(t_blk[j], t_cl[j], j, 1u);	/* the node's own list */
+			}
+			key[e] = kv;
+		}
+		for (uint32_t size = 2; size <= npad; size <<= 1)
+			for (uint32_t sd = size >> 1; sd > 0; sd >>= 1)
+			{
+				__syncthreads();
+				for (uint32_t t = tid; t < (npad >> 1); t += 256)
+				{
+					const uint32_t lo = 2 * t - (t & (sd - 1));
+					const uint32_t hi = lo + sd;
+					const bool	up = ((lo & size) == 0);
+					const uint64_t a = key[lo], b = key[hi];
+
+					if ((a > b) == up)
+					{
+						key[lo] = b;
+						key[hi] = a;
+					}
+				}
+			}
+		__syncthreads();
+
+		/* ---- every list replays its requests in walk order ---- */
+		for (uint32_t i = tid; i < npad; i += 256)
+		{
+			const uint64_t k0 = key[i];
+
+			if (k0 == ~0ull || (i > 0 && (key[i - 1] >> 12) == (k0 >> 12)))
+				continue;
+			const uint32_t X = (uint32_t) (k0 >> 16);
+			const int	cl = (int) ((k0 >> 12) & 15u);
+			const uint32_t *nn = nbrs + (size_t) X * stride + (size_t) cl * m2;
+			/* count and all 2m slots in one round trip (plain loads: every wave passed hnsw_publish's acquire
+			 * after the previous chunk's stores); the holes below the count become a bit mask */
+			const int16_t craw = ncount[(size_t) X * NDBHIP_HNSW_MAX_LEVEL + cl];
+			unsigned long long inv = 0ull;
+
+#pragma unroll 16
+			for (int q = 0; q < m2; q++)
+				inv |= (unsigned long long) (nn[q] == NDBHIP_INVALID_BLOCK) << q;
+			int			c0 = hnsw_clamp(craw, m);
+			int			cnt = c0;
+			unsigned long long holes = c0 >= 64 ? inv : (inv & ((1ull << c0) - 1ull));
+			uint32_t	firstw = 0xFFFFu;
+
+			cnt0s[i] = (uint8_t) c0;
+			for (uint32_t r = i; r < npad && (key[r] >> 12) == (k0 >> 12); r++)
+			{
+				const uint32_t j = (uint32_t) (key[r] >> 4) & 0xFFu;
+
+				if (key[r] & 1u)
+				{
+					/* own list: slots 0..nsel-1 written, count = nsel (:2452-2456) */
+					cnt = (int) t_nsel[j];
+					holes = 0ull;
+					pos[r] = NDB_HC_NONE;
+					firstw = min(firstw, j);
+					continue;
+				}
+				int			p;
+
+				if (holes)				/* first InvalidBlockNumber among the first `count` slots (:2487-2511) */
+				{
+					p = __ffsll((long long) holes) - 1;
+					holes &= holes - 1;
+				}
+				else
+					p = cnt;
+				if (p < m2)
+				{
+					pos[r] = (uint8_t) p;
+					if (p >= cnt)
+						cnt = p + 1;
+					firstw = min(firstw, j);
+				}
+				else
+					pos[r] = NDB_HC_NONE;
+			}
+			fw[i] = (uint16_t) firstw;
+		}
+		__syncthreads();
+
+		/* ---- stale against the chunk's own earlier walks ---- */
+		for (uint32_t base = 0; base < npairs; base += 256u * 8u)
+		{
+			uint32_t	enc[8], jj[8];
+
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t p = base + (uint32_t) u * 256u + tid;
+
+				jj[u] = 0xFFFFFFFFu;
+				enc[u] = 0;
+				if (p < npairs)
+				{
+					jj[u] = pair_walk(p);
+					enc[u] = R.rs[(size_t) (cur + jj[u]) * NDB_HNSW_RS_CAP + (p - t_off[jj[u]])];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				if (jj[u] == 0xFFFFFFFFu || jj[u] == 0)
+					continue;
+				const uint64_t want = ((uint64_t) (enc[u] & ((1u << NDB_HNSW_RS_NODE_BITS) - 1u)) << 4) |
+					(enc[u] >> NDB_HNSW_RS_NODE_BITS);	/* (node, level) = key >> 12 */
+				uint32_t	lo = 0, hi = npad;
+
+				while (lo < hi)
+				{
+					const uint32_t mid = (lo + hi) >> 1;
+
+					if ((key[mid] >> 12) < want)
+						lo = mid + 1;
+					else
+						hi = mid;
+				}
+				if (lo < npad && (key[lo] >> 12) == want && fw[lo] < jj[u])
+					t_stale[jj[u]] = 1u;
+			}
+		}
+		__syncthreads();
+		if (tid < C && t_stale[tid])
+			atomicMin(&s_stop, tid);
+		__syncthreads();
+		const uint32_t stop = s_stop;
+
+		/* ---- apply the walks before `stop` ---- */
+		for (uint32_t i = tid; i < npad; i += 256)
+		{
+			const uint64_t k0 = key[i];
+
+			if (k0 == ~0ull)
+				continue;
+			const uint32_t X = (uint32_t) (k0 >> 16);
+			const int	cl = (int) ((k0 >> 12) & 15u);
+			const uint32_t j = (uint32_t) (k0 >> 4) & 0xFFu;
+
+			if (j < stop && !(k0 & 1u) && pos[i] != NDB_HC_NONE)
+				gstore(&nbrs[(size_t) X * stride + (size_t) cl * m2 + pos[i]], t_blk[j]);
+			if (i > 0 && (key[i - 1] >> 12) == (k0 >> 12))
+				continue;
+			/* run head: the list's final count and its stamp */
+			int			cnt = cnt0s[i];
+			bool		wrote = false;
+
+			for (uint32_t r = i; r < npad && (key[r] >> 12) == (k0 >> 12); r++)
+			{
+				const uint32_t jr = (uint32_t) (key[r] >> 4) & 0xFFu;
+
+				if (jr >= stop)
+					break;
+				if (key[r] & 1u)
+				{
+					cnt = (int) t_nsel[jr];
+					wrote = true;
+				}
+				else if (pos[r] != NDB_HC_NONE)
+				{
+					if ((int) pos[r] >= cnt)
+						cnt = (int) pos[r] + 1;
+					wrote = true;
+				}
+			}
+			if (wrote)
+			{
+				gstore(&ncount[(size_t) X * NDBHIP_HNSW_MAX_LEVEL + cl], (int16_t) cnt);
+				gstore(cl ? &R.stampU[X] : &R.stamp0[X], round);
+			}
+		}
+		for (uint32_t e = tid; e < stop * ksel; e += 256)
+		{
+			const uint32_t j = e / ksel, idx = e % ksel;
+
+			if (idx < t_nsel[j])
+				gstore(&nbrs[(size_t) t_blk[j] * stride + (size_t) t_cl[j] * m2 + idx], sel[j * NDB_HC_MAXSEL + idx]);
+		}
+		hnsw_publish();
+		__syncthreads();
+		cur += stop;
+		if (stop < C)
+			stopped = true;
+	}
+	if (tid == 0)
+	{
+		*R.next = cur;
+		if (cur < ntasks)
+			atomicAdd(&R.stats[1], 1ull);
+	}
+}
+
 static int
 set_kernel_attributes_hnsw()
 {
@@ -5050,7 +5438,7 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 	{	/* experiment knobs */
 		const char *e;
 
-		if ((e = getenv("NDBHIP_HNSW_SPEC")) != nullptr) g_hnsw_spec = atoi(e) != 0;
+		if ((e = getenv("NDBHIP_HNSW_SPEC")) != nullptr) g_hnsw_spec = atoi(e);
 		if ((e = getenv("NDBHIP_HNSW_BATCH_DIV")) != nullptr && atoi(e) > 0) g_hnsw_batch_div = atoi(e);
 		if ((e = getenv("NDBHIP_HNSW_BATCH_MAX")) != nullptr && atoi(e) > 0) g_hnsw_batch_max = atoi(e);
 	}
@@ -5151,6 +5539,8 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 		uint32_t	round = 0;
 		int64_t		nrounds = 0;
 		const bool	trace = getenv("NDBHIP_HNSW_TRACE") != nullptr;
+		/* the chunked commit keeps a list's slots in a 64-bit mask and a chunk's requests in LDS */
+		const bool	par_commit = g_hnsw_spec == 1 && ksel <= NDB_HC_MAXSEL && 2 * h->m <= 64;
 		const bool	fast = (h->dim % 4) == 0 && h->dim <= NDB_HNSW_FAST_MAX_DIM && getenv("NDBHIP_HNSW_NOFAST") == nullptr;
 		uint32_t   *h_next = nullptr;
 
@@ -5177,8 +5567,12 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 						hipLaunchKernelGGL(k_hnsw_spec<false>, dim3(nt), dim3(64), smem, g.stream, gd, d_rows,
 										   (const HnswTask *) (d_tasks + b.t0), (uint32_t) ef_construction, ksel,
 										   R, round);
-					hipLaunchKernelGGL(k_hnsw_commit, dim3(1), dim3(64), 0, g.stream, h->d_ncount, h->d_nbrs,
-									   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
+					if (par_commit)
+						hipLaunchKernelGGL(k_hnsw_commit_par, dim3(1), dim3(256), 0, g.stream, h->d_ncount, h->d_nbrs,
+										   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
+					else
+						hipLaunchKernelGGL(k_hnsw_commit, dim3(1), dim3(64), 0, g.stream, h->d_ncount, h->d_nbrs,
+										   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
 				}
 				HIP_TRY(hipMemcpyAsync(h_next, R.next, sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
 				HIP_TRY(hipStreamSynchronize(g.stream));
@@ -5221,7 +5615,7 @@ ndbhip_hnsw_set_build_mode(int optimistic, int batch_div, int batch_max)
 {
 	if (batch_div < 1 || batch_max < 1 || batch_max > 65535)
 		return fail(NDBHIP_ERR_INVALID, "batch_div >= 1 and 1 <= batch_max <= 65535 required");
-	g_hnsw_spec = optimistic != 0;
+	g_hnsw_spec = optimistic < 0 ? 0 : (optimistic > 2 ? 2 : optimistic);
 	g_hnsw_batch_div = batch_div;
 	g_hnsw_batch_max = batch_max;
 	return NDBHIP_OK;

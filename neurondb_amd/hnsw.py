@@ -82,7 +82,7 @@ class HnswIndex:
 
     @staticmethod
     def set_build_mode(optimistic=True, batch_div=64, batch_max=1024):
-        check(lib().ndbhip_hnsw_set_build_mode(int(bool(optimistic)), int(batch_div), int(batch_max)))
+        check(lib().ndbhip_hnsw_set_build_mode(int(optimistic), int(batch_div), int(batch_max)))
 
     def export(self):
         nb = C.c_uint32()

@@ -98,7 +98,8 @@ def test_hnsw_scan_state_machine():
 
 # (optimistic, batch_div, batch_max): the one-wave sequential kernel; the default schedule; and a schedule
 # that batches as many walks as there are nodes, so that conflicts (and their in-order redo) are the rule
-BUILD_MODES = {"sequential": (0, 64, 1024), "optimistic": (1, 64, 1024), "optimistic-greedy": (1, 1, 256)}
+BUILD_MODES = {"sequential": (0, 64, 1024), "optimistic": (1, 64, 1024), "optimistic-greedy": (1, 1, 256),
+               "optimistic-wave-commit": (2, 64, 1024), "optimistic-wave-commit-greedy": (2, 1, 256)}
 
 
 @pytest.fixture
@@ -141,7 +142,7 @@ def test_hnsw_device_build_matches_oracle_graph(n, dim, m, efc, mode, restore_bu
             ent = max(ent, int(lv))
         assert st["walks"] == walks
         assert st["rounds"] >= st["batches"] >= 1 and st["overflowed"] == 0
-        if mode == "optimistic-greedy":
+        if mode.endswith("greedy"):
             assert st["redone"] > 0 and st["max_batch"] > 16    # stale walks were met and run again
     e = ix.export()
     assert e["nblocks"] == a["nblocks"]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--nq", type=int, default=2000)
     ap.add_argument("--oracle-sample", type=int, default=50)
     ap.add_argument("--sequential", action="store_true", help="one-wave sequential build (k_hnsw_build)")
+    ap.add_argument("--wave-commit", action="store_true", help="optimistic batches with the one-wave commit")
     ap.add_argument("--batch-div", type=int, default=64)
     ap.add_argument("--batch-max", type=int, default=1024)
     ap.add_argument("--build-only", action="store_true")
@@ -51,7 +52,7 @@ def main():
     tids = torch.arange(a.nvec, device=dev, dtype=torch.int64)
     tids = ((tids // 64 >> 16) & 0xFFFF) | ((tids // 64 & 0xFFFF) << 16) | ((tids % 64 + 1) << 32)
     ix = HnswIndex(a.dim, a.m)
-    HnswIndex.set_build_mode(not a.sequential, a.batch_div, a.batch_max)
+    HnswIndex.set_build_mode(0 if a.sequential else (2 if a.wave_commit else 1), a.batch_div, a.batch_max)
     t0 = time.perf_counter()
     check(lib().ndbhip_hnsw_build_device(ix._h, C.c_void_p(base.data_ptr()), C.c_void_p(tids.data_ptr()), a.nvec,
                                          levels.ctypes.data, a.efc))
