@@ -4923,7 +4923,9 @@ k_hnsw_commit_par(int16_t *ncount, uint32_t *nbrs, const HnswTask *__restrict__ 
 	const int	m2 = 2 * m;
 	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * m2;
 	const uint32_t first = *R.next;
-	const uint32_t cmax = min(NDB_HC_TASKS, NDB_HC_REQ / (ksel + 1u));
+	/* as many walks as keep the padded request count at 1024 when they fit (60 walks at m = 16): the sort is
+	 * the chunk's biggest fixed cost */
+	const uint32_t cmax = min(NDB_HC_TASKS, (1024u / (ksel + 1u)) >= 16u ? 1024u / (ksel + 1u) : NDB_HC_REQ / (ksel + 1u));
 	uint32_t	cur = first;
 	bool		stopped = false;
 
