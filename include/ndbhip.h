@@ -297,6 +297,14 @@ int			ndbhip_hnsw_build_stats(const ndbhip_hnsw *g, int64_t out[6]);
  * (defaults: batch_div 64, batch_max 1024). */
 int			ndbhip_hnsw_set_build_mode(int optimistic, int batch_div, int batch_max);
 
+/* hnswbulkdelete (src/index/hnsw_am.c:544-720) with the callback = "heapPtr is one of the n TIDs": live
+ * hits are processed in block order — unlinked from the lists of the nodes THEIR lists name
+ * (hnswRemoveNodeFromNeighbor, :2747-2840), the entry point moves to the hit's first valid neighbour (top
+ * level first) or becomes invalid, the line pointer is marked dead.  As in the reference nothing else changes:
+ * links INTO a dead node stay and hnswSearch does not test the dead flag, so it can still be walked and
+ * returned.  A loaded (packed) graph is converted to the dense 16-level layout first.  m <= 32. */
+int			ndbhip_hnsw_delete(ndbhip_hnsw *g, const uint8_t *tids6, int64_t n, int64_t *removed);
+
 /* Read the graph back in the dense 16-level layout (any pointer may be NULL):
  * levels [nblocks], ncount [nblocks*16], nbrs [nblocks*16*2m]. */
 int			ndbhip_hnsw_export(const ndbhip_hnsw *g, uint32_t *nblocks, int32_t *levels, int16_t *ncount,

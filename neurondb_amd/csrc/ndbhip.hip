@@ -5297,6 +5297,7 @@ struct ndbhip_hnsw
 	int64_t    *d_nbr_off = nullptr;
 	uint32_t   *d_nbrs = nullptr;
 	uint64_t   *d_tids = nullptr;
+	uint8_t    *d_dead = nullptr;		/* [nblocks] line pointer marked dead by bulkdelete (allocated on first use) */
 	bool		loaded = false;
 	bool		dense = false;			/* neighbour slots in the 16-level dense layout (device-built graphs) */
 	/* host-call workspace */
@@ -5329,10 +5330,11 @@ ndbhip_hnsw_create(int dim, int m, ndbhip_hnsw **out)
 static void
 hnsw_free_dev(ndbhip_hnsw *h)
 {
-	void	   *ptrs[] = {h->d_vecs, h->d_levels, h->d_ncount, h->d_nbr_off, h->d_nbrs, h->d_tids};
+	void	   *ptrs[] = {h->d_vecs, h->d_levels, h->d_ncount, h->d_nbr_off, h->d_nbrs, h->d_tids, h->d_dead};
 
 	for (void *p : ptrs)
 		if (p) (void) hipFree(p);
+	h->d_dead = nullptr;
 	h->d_vecs = nullptr; h->d_levels = nullptr; h->d_ncount = nullptr;
 	h->d_nbr_off = nullptr; h->d_nbrs = nullptr; h->d_tids = nullptr;
 	h->loaded = false;
@@ -5629,6 +5631,239 @@ ndbhip_hnsw_build_stats(const ndbhip_hnsw *h, int64_t out[6])
 	if (!h || !out)
 		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
 	memcpy(out, h->build_stats, sizeof(h->build_stats));
+	return NDBHIP_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* hnswbulkdelete on the mirror (src/index/hnsw_am.c:544-720)           */
+/* ------------------------------------------------------------------ */
+
+/* packed (loaded) neighbour slots -> the dense 16-level layout the writers use */
+__global__ __launch_bounds__(256) void
+k_hnsw_densify(const int *__restrict__ levels, const int64_t *__restrict__ nbr_off,
+			   const uint32_t *__restrict__ packed, uint32_t nblocks, int m2, uint32_t *__restrict__ dense)
+{
+	const uint32_t b = blockIdx.x;
+	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+
+	if (b >= nblocks)
+		return;
+	int			lv = levels[b];
+
+	lv = lv < 0 ? -1 : (lv >= NDBHIP_HNSW_MAX_LEVEL ? NDBHIP_HNSW_MAX_LEVEL - 1 : lv);
+	const int64_t have = b == 0 ? 0 : (int64_t) (lv + 1) * m2;
+
+	for (int64_t j = threadIdx.x; j < stride; j += 256)
+		dense[(size_t) b * stride + j] = j < have ? packed[nbr_off[b] + j] : NDBHIP_INVALID_BLOCK;
+}
+
+/* hit[b] = node b is live, has a sane level and its heapPtr is in the sorted set */
+__global__ __launch_bounds__(256) void
+k_hnsw_delete_mark(const uint64_t *__restrict__ tids, const int *__restrict__ levels,
+				   const uint8_t *__restrict__ dead, uint32_t nblocks, const uint64_t *__restrict__ set,
+				   int64_t nset, uint8_t *__restrict__ hit)
+{
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+
+	if (b >= nblocks)
+		return;
+	bool		h = false;
+
+	if (b != 0 && !dead[b] && levels[b] >= 0 && levels[b] < NDBHIP_HNSW_MAX_LEVEL)
+	{
+		const uint64_t t = tids[b];
+		int64_t		lo = 0, hi = nset;
+
+		while (lo < hi)
+		{
+			const int64_t mid = (lo + hi) >> 1;
+
+			if (set[mid] < t)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		h = lo < nset && set[lo] == t;
+	}
+	hit[b] = h ? 1 : 0;
+}
+
+/* ONE wave unlinks the hit nodes in block order, statement for statement (:618-699) */
+__global__ __launch_bounds__(64) void
+k_hnsw_delete_seq(const int *__restrict__ levels, int16_t *ncount, uint32_t *nbrs, uint8_t *dead,
+				  const uint32_t *__restrict__ victims, uint32_t nvict, uint32_t nblocks, int m,
+				  uint32_t *entry_io)
+{
+	const uint32_t lane = threadIdx.x;
+	const int	m2 = 2 * m;
+	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+	uint32_t	entry = entry_io[0];
+	int			entry_level = (int) entry_io[1];
+
+	for (uint32_t v = 0; v < nvict; v++)
+	{
+		const uint32_t blk = victims[v];
+		const int	nodeLevel = levels[blk];
+
+		for (int level = 0; level <= nodeLevel; level++)
+		{
+			const int	nc = hnsw_clamp(gload<true>(&ncount[(size_t) blk * NDBHIP_HNSW_MAX_LEVEL + level]), m);
+			const uint32_t *mine = nbrs + (size_t) blk * stride + (size_t) level * m2;
+
+			for (int i = 0; i < nc; i++)
+			{
+				const uint32_t nb = gload<true>(&mine[i]);
+
+				/* :630-638, then hnswRemoveNodeFromNeighbor (:2747-2840) */
+				if (nb == NDBHIP_INVALID_BLOCK || nb >= nblocks || nb == 0)
+					continue;
+				int16_t    *ncp = &ncount[(size_t) nb * NDBHIP_HNSW_MAX_LEVEL + level];
+				uint32_t   *nn = nbrs + (size_t) nb * stride + (size_t) level * m2;
+				const int16_t raw = gload<true>(ncp);
+				const int	cnt = hnsw_clamp(raw, m);
+				const uint32_t val = (int) lane < cnt ? gload<true>(&nn[lane]) : NDBHIP_INVALID_BLOCK;
+				const unsigned long long match = __ballot((int) lane < cnt && val == blk);
+
+				if (match)
+				{
+					const int	idx = __ffsll((long long) match) - 1;
+					const uint32_t next = __shfl_down(val, 1, 64);
+
+					if ((int) lane >= idx && (int) lane < cnt - 1)
+						gstore(&nn[lane], next);
+					if ((int) lane == cnt - 1)
+						gstore(&nn[lane], (uint32_t) NDBHIP_INVALID_BLOCK);
+					if (lane == 0)
+						gstore(ncp, (int16_t) (raw - 1));
+					hnsw_publish();
+				}
+			}
+		}
+		if (entry == blk)	/* :642-690 */
+		{
+			bool		found = false;
+
+			for (int level = nodeLevel; level >= 0 && !found; level--)
+			{
+				const int	nc = hnsw_clamp(gload<true>(&ncount[(size_t) blk * NDBHIP_HNSW_MAX_LEVEL + level]), m);
+				const uint32_t *mine = nbrs + (size_t) blk * stride + (size_t) level * m2;
+
+				for (int i = 0; i < nc && !found; i++)
+				{
+					const uint32_t nb = gload<true>(&mine[i]);
+
+					if (hnsw_valid(nblocks, nb) && levels[nb] >= 0 && levels[nb] < NDBHIP_HNSW_MAX_LEVEL)
+					{
+						entry = nb;
+						entry_level = levels[nb];
+						found = true;
+					}
+				}
+			}
+			if (!found)
+			{
+				entry = NDBHIP_INVALID_BLOCK;
+				entry_level = -1;
+			}
+		}
+		if (lane == 0)
+			dead[blk] = 1;
+	}
+	if (lane == 0)
+	{
+		entry_io[0] = entry;
+		entry_io[1] = (uint32_t) entry_level;
+	}
+}
+
+extern "C" int
+ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *removed)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || n < 0 || (n > 0 && !tids6))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!h->loaded)
+		return fail(NDBHIP_ERR_STATE, "hnsw mirror not loaded");
+	if (2 * h->m > 64)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "bulkdelete on the mirror supports m <= 32");
+	if (removed)
+		*removed = 0;
+	if (n == 0 || h->nblocks < 2)
+		return NDBHIP_OK;
+	const uint32_t nb = h->nblocks;
+	const int	m2 = 2 * h->m;
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+
+	if (!h->dense)
+	{
+		/* loaded graphs hold (level+1)*2m slots per node; the reference's unlinking writes at `level` into
+		 * whatever node a list names (as its inserts do, Q12/Q21), so give every node all 16 levels */
+		uint32_t   *d_dense = nullptr;
+
+		HIP_TRY(hipMalloc((void **) &d_dense, (size_t) nb * stride * sizeof(uint32_t)));
+		hipLaunchKernelGGL(k_hnsw_densify, dim3(nb), dim3(256), 0, g.stream, (const int *) h->d_levels,
+						   (const int64_t *) h->d_nbr_off, (const uint32_t *) h->d_nbrs, nb, m2, d_dense);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		HIP_TRY(hipFree(h->d_nbrs));
+		HIP_TRY(hipFree(h->d_nbr_off));
+		h->d_nbrs = d_dense;
+		h->d_nbr_off = nullptr;
+		h->dense = true;
+	}
+	if (!h->d_dead)
+	{
+		HIP_TRY(hipMalloc((void **) &h->d_dead, (size_t) nb));
+		HIP_TRY(hipMemsetAsync(h->d_dead, 0, (size_t) nb, g.stream));
+	}
+	std::vector<uint64_t> set((size_t) n);
+
+	for (int64_t i = 0; i < n; i++)
+		set[(size_t) i] = ndb_tid_pack(tids6 + 6 * i);
+	std::sort(set.begin(), set.end());
+	uint64_t   *d_set = nullptr;
+	uint8_t    *d_hit = nullptr;
+	uint32_t   *d_vict = nullptr, *d_entry = nullptr;
+	std::vector<uint8_t> hit((size_t) nb);
+
+	HIP_TRY(hipMalloc((void **) &d_set, (size_t) n * sizeof(uint64_t)));
+	HIP_TRY(hipMalloc((void **) &d_hit, (size_t) nb));
+	HIP_TRY(hipMemcpyAsync(d_set, set.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_hnsw_delete_mark, dim3((nb + 255) / 256), dim3(256), 0, g.stream,
+					   (const uint64_t *) h->d_tids, (const int *) h->d_levels, (const uint8_t *) h->d_dead, nb,
+					   (const uint64_t *) d_set, n, d_hit);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(hit.data(), d_hit, (size_t) nb, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	std::vector<uint32_t> victims;
+
+	for (uint32_t b = 1; b < nb; b++)	/* ascending block order: :586 */
+		if (hit[b])
+			victims.push_back(b);
+	if (!victims.empty())
+	{
+		uint32_t	entry[2] = {h->entry_point, (uint32_t) h->entry_level};
+
+		HIP_TRY(hipMalloc((void **) &d_vict, victims.size() * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &d_entry, sizeof(entry)));
+		HIP_TRY(hipMemcpyAsync(d_vict, victims.data(), victims.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+							   g.stream));
+		HIP_TRY(hipMemcpyAsync(d_entry, entry, sizeof(entry), hipMemcpyHostToDevice, g.stream));
+		hipLaunchKernelGGL(k_hnsw_delete_seq, dim3(1), dim3(64), 0, g.stream, (const int *) h->d_levels,
+						   h->d_ncount, h->d_nbrs, h->d_dead, (const uint32_t *) d_vict, (uint32_t) victims.size(),
+						   nb, h->m, d_entry);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(entry, d_entry, sizeof(entry), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		h->entry_point = entry[0];
+		h->entry_level = (int) entry[1];
+		HIP_TRY(hipFree(d_vict));
+		HIP_TRY(hipFree(d_entry));
+	}
+	if (removed)
+		*removed = (int64_t) victims.size();
+	HIP_TRY(hipFree(d_set));
+	HIP_TRY(hipFree(d_hit));
 	return NDBHIP_OK;
 }
 

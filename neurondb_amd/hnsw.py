@@ -73,6 +73,14 @@ class HnswIndex:
                                              _ptr(lv), int(ef_construction)))
         self.nblocks = len(lv) + 1
 
+    def delete(self, tids):
+        """hnswbulkdelete: unlink and mark dead every live node whose heapPtr is in `tids`; returns the count."""
+        t = np.ascontiguousarray(tids)
+        t6 = np.ascontiguousarray(t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6))
+        removed = C.c_int64(0)
+        check(lib().ndbhip_hnsw_delete(self._h, _ptr(t6), t6.shape[0], C.byref(removed)))
+        return int(removed.value)
+
     def build_stats(self):
         """How the last build() ran (ndbhip_hnsw_build_stats)."""
         st = np.zeros(6, np.int64)

@@ -944,6 +944,7 @@ ndbo_hnsw_create(int dim, int m, int ef_construction, uint32_t cap_nodes)
 	g->ncount = (int16_t *) calloc(cap * NDBO_HNSW_MAX_LEVEL, sizeof(int16_t));
 	g->nbrs = (uint32_t *) malloc(cap * NDBO_HNSW_MAX_LEVEL * 2 * (size_t) m * sizeof(uint32_t));
 	memset(g->nbrs, 0xFF, cap * NDBO_HNSW_MAX_LEVEL * 2 * (size_t) m * sizeof(uint32_t));
+	g->dead = (uint8_t *) calloc(cap, 1);
 	return g;
 }
 
@@ -957,6 +958,7 @@ ndbo_hnsw_free(ndbo_hnsw *g)
 	free(g->levels);
 	free(g->ncount);
 	free(g->nbrs);
+	free(g->dead);
 	free(g);
 }
 
@@ -1164,6 +1166,110 @@ ndbo_hnsw_search(const ndbo_hnsw *g, const float *query, int strategy, int efSea
 }
 
 /* src/index/hnsw_am.c:1143-1161 with r injected */
+/* hnswRemoveNodeFromNeighbor: src/index/hnsw_am.c:2747-2840 */
+static void
+hnsw_remove_from_neighbor(ndbo_hnsw *g, uint32_t neighborBlkno, uint32_t nodeBlkno, int level)
+{
+	uint32_t   *neighbors;
+	int			neighborCount;
+	int			i,
+				j;
+
+	if (!hnsw_valid_block(g, neighborBlkno))	/* :2761, and PageIsEmpty(meta page) at :2778 */
+		return;
+	if (level < 0 || level >= NDBO_HNSW_MAX_LEVEL)
+		return;
+	neighbors = hnsw_nbrs(g, neighborBlkno, level);
+	neighborCount = hnsw_clamp_ncount(g->ncount[(size_t) neighborBlkno * NDBO_HNSW_MAX_LEVEL + level], g->m);
+	for (i = 0; i < neighborCount; i++)
+	{
+		if (neighbors[i] == nodeBlkno)
+		{
+			for (j = i; j < neighborCount - 1; j++)		/* :2826-2828 */
+				neighbors[j] = neighbors[j + 1];
+			neighbors[neighborCount - 1] = NDBO_INVALID_BLOCK;
+			g->ncount[(size_t) neighborBlkno * NDBO_HNSW_MAX_LEVEL + level]--;	/* the raw count, :2829 */
+			break;
+		}
+	}
+}
+
+static int
+tid_in_set(const ndbo_tid *tids, int64_t n, ndbo_tid t)
+{
+	int64_t		i;
+
+	for (i = 0; i < n; i++)
+		if (tids[i].bi_hi == t.bi_hi && tids[i].bi_lo == t.bi_lo && tids[i].posid == t.posid)
+			return 1;
+	return 0;
+}
+
+/* src/index/hnsw_am.c:544-720 */
+int64_t
+ndbo_hnsw_bulkdelete(ndbo_hnsw *g, const ndbo_tid *tids, int64_t n)
+{
+	uint32_t	blkno;
+	int64_t		removed = 0;
+
+	for (blkno = 1; blkno < g->nblocks; blkno++)	/* :586 */
+	{
+		int			level,
+					i,
+					nodeLevel = g->levels[blkno];
+
+		if (g->dead[blkno])			/* ItemIdIsDead: :601 */
+			continue;
+		if (nodeLevel < 0 || nodeLevel >= NDBO_HNSW_MAX_LEVEL)	/* :610-615 */
+			continue;
+		if (!tid_in_set(tids, n, g->heap_tids[blkno]))	/* callback: :618 */
+			continue;
+		for (level = 0; level <= nodeLevel; level++)	/* :620-640 */
+		{
+			const uint32_t *neighbors = hnsw_nbrs(g, blkno, level);
+			int			neighborCount = hnsw_clamp_ncount(g->ncount[(size_t) blkno * NDBO_HNSW_MAX_LEVEL + level], g->m);
+
+			for (i = 0; i < neighborCount; i++)
+				if (neighbors[i] != NDBO_INVALID_BLOCK && neighbors[i] < g->nblocks)
+					hnsw_remove_from_neighbor(g, neighbors[i], blkno, level);
+		}
+		if (g->entry_point == blkno)	/* :642-690 */
+		{
+			int			foundNewEntry = 0;
+
+			for (level = nodeLevel; level >= 0 && !foundNewEntry; level--)
+			{
+				const uint32_t *neighbors = hnsw_nbrs(g, blkno, level);
+				int			neighborCount = hnsw_clamp_ncount(g->ncount[(size_t) blkno * NDBO_HNSW_MAX_LEVEL + level], g->m);
+
+				for (i = 0; i < neighborCount && !foundNewEntry; i++)
+				{
+					const uint32_t nb = neighbors[i];
+
+					/* valid block whose page holds an item (the meta page does not) with a sane level */
+					if (hnsw_valid_block(g, nb) && g->levels[nb] >= 0 && g->levels[nb] < NDBO_HNSW_MAX_LEVEL)
+					{
+						g->entry_point = nb;
+						g->entry_level = g->levels[nb];
+						foundNewEntry = 1;
+					}
+				}
+			}
+			if (!foundNewEntry)
+			{
+				g->entry_point = NDBO_INVALID_BLOCK;
+				g->entry_level = -1;
+			}
+		}
+		g->dead[blkno] = 1;			/* ItemIdSetDead: :693 */
+		removed++;
+		g->inserted--;
+		if (g->inserted < 0)
+			g->inserted = 0;
+	}
+	return removed;
+}
+
 int
 ndbo_hnsw_level_from_uniform(double r, float ml)
 {

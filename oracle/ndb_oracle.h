@@ -175,6 +175,7 @@ typedef struct ndbo_hnsw
 	int		   *levels;			/* [cap_blocks] */
 	int16_t    *ncount;			/* [cap_blocks * HNSW_MAX_LEVEL] */
 	uint32_t   *nbrs;			/* [cap_blocks * HNSW_MAX_LEVEL * 2m] */
+	uint8_t    *dead;			/* [cap_blocks] line pointer marked dead by hnswbulkdelete */
 }			ndbo_hnsw;
 
 ndbo_hnsw  *ndbo_hnsw_create(int dim, int m, int ef_construction, uint32_t cap_nodes);
@@ -188,6 +189,15 @@ int			ndbo_hnsw_search(const ndbo_hnsw *g, const float *query, int strategy, int
 /* src/index/hnsw_am.c:2091-2670 with the level injected (hnswGetRandomLevel
  * uses random(): :1143-1161).  Returns the new block number. */
 uint32_t	ndbo_hnsw_insert(ndbo_hnsw *g, const float *vec, ndbo_tid heap_tid, int level);
+
+/* hnswbulkdelete (src/index/hnsw_am.c:544-720) with the callback = "heapPtr is one of tids[0..n)".
+ * Blocks are visited in ascending order; a node whose line pointer is already dead is skipped (:601);
+ * a hit is unlinked from the lists of the nodes ITS lists name (hnswRemoveNodeFromNeighbor, :2747-2840:
+ * first occurrence among the first count entries, shift down, count--), the entry point moves to the hit's
+ * first valid neighbour (top level first) or to InvalidBlockNumber, and the line pointer is marked dead.
+ * Nothing else changes: links INTO the dead node from other nodes stay, and hnswSearch does not test the dead
+ * flag, so the node can still be walked and returned.  Returns tuples_removed. */
+int64_t		ndbo_hnsw_bulkdelete(ndbo_hnsw *g, const ndbo_tid *tids, int64_t n);
 
 /* level = (int)(-log(r) * ml), clamped [0, 15]: src/index/hnsw_am.c:1143-1161 */
 int			ndbo_hnsw_level_from_uniform(double r, float ml);

@@ -44,7 +44,7 @@ class NdboHnsw(C.Structure):
         ("inserted", C.c_int64), ("nblocks", C.c_uint32), ("cap_blocks", C.c_uint32),
         ("vecs", C.POINTER(C.c_float)), ("heap_tids", C.POINTER(NdboTid)),
         ("levels", C.POINTER(C.c_int)), ("ncount", C.POINTER(C.c_int16)),
-        ("nbrs", C.POINTER(C.c_uint32)),
+        ("nbrs", C.POINTER(C.c_uint32)), ("dead", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -84,6 +84,7 @@ def lib(native: bool = False):
         "ndbo_op_l2": (f, [f32p, f32p, i, i]),
         "ndbo_op_ip": (f, [f32p, f32p, i, i]),
         "ndbo_op_cosine": (f, [f32p, f32p, i, i]),
+        "ndbo_hnsw_bulkdelete": (C.c_int64, [C.POINTER(NdboHnsw), C.c_void_p, C.c_int64]),
         "ndbo_float4_to_fp16": (C.c_uint16, [f]),
         "ndbo_fp16_to_float": (f, [C.c_uint16]),
         "ndbo_halfvec_l2": (f, [u16p, u16p, i]),
@@ -258,6 +259,11 @@ class HnswGraph:
         t = tids_from_rows(np.array([row]))[0]
         return self.L.ndbo_hnsw_insert(self.g, _f32(vec), NdboTid(int(t["bi_hi"]), int(t["bi_lo"]),
                                                                    int(t["posid"])), int(level))
+
+    def bulkdelete(self, tids):
+        """hnswbulkdelete with callback = membership in `tids` (structured TID array); returns tuples_removed."""
+        t = np.ascontiguousarray(tids)
+        return int(self.L.ndbo_hnsw_bulkdelete(self.g, t.ctypes.data, len(t)))
 
     def search(self, query, strategy=1, ef=64, k=10):
         ob = np.zeros(max(k, 1), dtype=np.uint32)

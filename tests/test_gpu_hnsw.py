@@ -154,3 +154,49 @@ def test_hnsw_device_build_matches_oracle_graph(n, dim, m, efc, mode, restore_bu
     q = rng.standard_normal((8, dim)).astype(np.float32)
     for strategy in (1, 2, 3):
         check(g, ix, q, strategy, 32, 10)
+
+
+@pytest.mark.parametrize("built_on_device", [False, True])
+def test_hnsw_bulkdelete_matches_oracle(built_on_device, restore_build_mode):
+    """ndbhip_hnsw_delete vs the oracle's literal hnswbulkdelete: same unlinking (counts, shifted lists), same
+    entry point hand-over, dead nodes stay reachable through the links that still name them (the reference's
+    search never tests the dead flag), second VACUUM of the same TIDs is a no-op — on a loaded (packed) graph
+    and on a device-built (dense) one."""
+    from neurondb_amd import HnswIndex
+    n, dim, m, efc = 900, 32, 6, 30
+    rng = np.random.default_rng(5)
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    L = ndbo.lib()
+    levels = np.array([L.ndbo_hnsw_level_from_uniform(float(r), np.float32(0.36))
+                       for r in rng.uniform(1e-9, 1.0, n)], np.int32)
+    levels[11] = 4
+    g = ndbo.HnswGraph(dim, m=m, ef_construction=efc, cap_nodes=n + 2)
+    for i in range(n):
+        g.insert(vecs[i], i, int(levels[i]))
+    a = g.arrays()
+    ix = HnswIndex(dim, m)
+    if built_on_device:
+        ix.build(vecs, ndbo.tids_from_rows(np.arange(n)), levels, efc)
+    else:
+        ix.load(a["vecs"], a["levels"], a["ncount"], a["nbrs"], a["tids"], a["entry_point"], a["entry_level"])
+    rows = np.unique(np.concatenate([rng.choice(n, 120, replace=False), [a["entry_point"] - 1, 11]]))
+    tids = ndbo.tids_from_rows(rows)
+    ghost = ndbo.tids_from_rows(np.array([n + 50, n + 51]))
+    victims = np.concatenate([tids, ghost])
+    assert g.bulkdelete(victims) == len(rows)
+    assert ix.delete(victims[rng.permutation(len(victims))]) == len(rows)
+    assert g.bulkdelete(victims) == 0 and ix.delete(victims) == 0
+    b, e = g.arrays(), ix.export()
+    assert (e["entry_point"], e["entry_level"]) == (b["entry_point"], b["entry_level"])
+    assert (b["entry_point"], b["entry_level"]) != (a["entry_point"], a["entry_level"])
+    if built_on_device:
+        assert np.array_equal(e["ncount"][1:], b["ncount"][1:])
+        assert np.array_equal(e["nbrs"][1:], b["nbrs"][1:])
+    else:       # slots above a node's own levels (the Q12/Q21 out-of-node writes) are not part of a packed image
+        for blk in range(1, n + 1):
+            lv = b["levels"][blk]
+            assert np.array_equal(e["ncount"][blk, :lv + 1], b["ncount"][blk, :lv + 1])
+            assert np.array_equal(e["nbrs"][blk, :lv + 1], b["nbrs"][blk, :lv + 1])
+    q = rng.standard_normal((16, dim)).astype(np.float32)
+    for strategy in (1, 2, 3):
+        check(g, ix, q, strategy, 32, 10)
