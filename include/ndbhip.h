@@ -283,6 +283,11 @@ int			ndbhip_hnsw_load(ndbhip_hnsw *g, uint32_t nblocks, const float *vecs, cons
  * L2 and ef = k = ef_construction, as the reference does (quirk Q12). */
 int			ndbhip_hnsw_build_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 									 const int32_t *levels, int ef_construction);
+/* hnswinsert (src/index/hnsw_am.c:478-538) = the same hnswInsertNode for n MORE rows on top of the graph the
+ * mirror holds (built here or loaded; a loaded graph is first given the dense 16-level layout): node
+ * nblocks + i = row i.  On an empty mirror this is ndbhip_hnsw_build_device. */
+int			ndbhip_hnsw_insert_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+									  const int32_t *levels, int ef_construction);
 /* How the last ndbhip_hnsw_build_device ran: out[0] walks (one per insert and linked level), out[1] walks
  * that had to run again because an earlier insert of their batch wrote a list they had read, out[2] walks
  * whose read-set log overflowed, out[3] speculate+commit rounds, out[4] batches, out[5] largest batch.

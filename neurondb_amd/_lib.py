@@ -111,6 +111,7 @@ def lib():
         "ndbhip_hnsw_destroy": (i, [vp]),
         "ndbhip_hnsw_load": (i, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i]),
         "ndbhip_hnsw_build_device": (i, [vp, vp, vp, C.c_uint32, vp, i]),
+        "ndbhip_hnsw_insert_device": (i, [vp, vp, vp, C.c_uint32, vp, i]),
         "ndbhip_hnsw_delete": (i, [vp, vp, i64, C.POINTER(i64)]),
         "ndbhip_hnsw_build_stats": (i, [vp, vp]),
         "ndbhip_hnsw_set_build_mode": (i, [i, i, i]),

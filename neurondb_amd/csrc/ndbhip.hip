@@ -4452,7 +4452,7 @@ __global__ __launch_bounds__(64) void
 k_hnsw_build(float *vecs, int *levels_out, int16_t *ncount, uint32_t *nbrs, uint64_t *tids_out,
 			 const float *__restrict__ rows, const uint64_t *__restrict__ tids_in,
 			 const int *__restrict__ levels_in, uint32_t n, int dim, int m, uint32_t efc,
-			 uint32_t *entry_io /* [0] entry point, [1] entry level (as int) */)
+			 uint32_t *entry_io /* [0] entry point, [1] entry level (as int) */, uint32_t base)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	const uint32_t ksel = (uint32_t) m < efc ? (uint32_t) m : efc;
@@ -4466,7 +4466,7 @@ k_hnsw_build(float *vecs, int *levels_out, int16_t *ncount, uint32_t *nbrs, uint
 
 	for (uint32_t i = 0; i < n; i++)
 	{
-		const uint32_t blk = i + 1;
+		const uint32_t blk = base + i + 1;
 		int			level = levels_in[i];
 
 		if (level >= NDBHIP_HNSW_MAX_LEVEL) level = NDBHIP_HNSW_MAX_LEVEL - 1;
@@ -4601,10 +4601,10 @@ struct HnswTask
 __global__ __launch_bounds__(256) void
 k_hnsw_init_nodes(float *vecs, int *levels_out, int16_t *ncount, uint32_t *nbrs, uint64_t *tids_out,
 				  const float *__restrict__ rows, const uint64_t *__restrict__ tids_in,
-				  const int *__restrict__ levels_in, uint32_t n, int dim, int64_t stride)
+				  const int *__restrict__ levels_in, uint32_t n, int dim, int64_t stride, uint32_t base)
 {
 	const uint32_t i = blockIdx.x;
-	const uint32_t blk = i + 1;
+	const uint32_t blk = base + i + 1;	/* `base` nodes exist already (hnswinsert into a built graph) */
 
 	if (i >= n)
 		return;
@@ -4673,7 +4673,7 @@ hnsw_walk_is_stale(const HnswRounds &R, uint32_t t, uint32_t since)
 template <bool FAST>
 __global__ __launch_bounds__(FAST ? 256 : 64) void
 k_hnsw_spec(HnswDev g, const float *__restrict__ rows, const HnswTask *__restrict__ tasks, uint32_t efc,
-			uint32_t ksel, HnswRounds R, uint32_t round)
+			uint32_t ksel, HnswRounds R, uint32_t round, uint32_t base)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	const uint32_t t = blockIdx.x;
@@ -4686,7 +4686,7 @@ k_hnsw_spec(HnswDev g, const float *__restrict__ rows, const HnswTask *__restric
 		return;
 	HnswLds		L = carve_hnsw_lds(smem_raw, efc, efc, (uint32_t) g.m);
 	const HnswTask task = tasks[t];
-	const float *q = rows + (size_t) task.row * g.dim;
+	const float *q = rows + (size_t) (task.row - base) * g.dim;	/* rows[] holds the new rows only */
 	HnswFast	F = carve_hnsw_fast(L.tile, g.dim);
 
 	if (FAST)
@@ -5404,10 +5404,12 @@ ndbhip_hnsw_load(ndbhip_hnsw *h, uint32_t nblocks, const float *vecs, const int3
 	return NDBHIP_OK;
 }
 
-/* hnswbuild on rows already in HBM: node i+1 = row i, levels[i] = its drawn level (host array). */
-extern "C" int
-ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
-						 const int32_t *levels, int ef_construction)
+static int hnsw_densify(ndbhip_hnsw *h);
+
+/* hnswInsertNode for rows 0..n-1 on top of the `base` nodes the mirror already holds (0: build from nothing) */
+static int
+hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n, const int32_t *levels,
+				 int ef_construction, uint32_t base)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!h || !d_rows || !d_tids || !levels || n < 1)
@@ -5418,25 +5420,72 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 
 	if (smem > NDB_TOPK_MAX_SMEM)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "ef_construction too large for the LDS-resident candidate set");
-	hnsw_free_dev(h);
-	const uint32_t nb = n + 1;
+	if ((uint64_t) base + n + 1 > 0xFFFFFFF0ull)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 blocks");
+	const uint32_t nb = base + n + 1;
 	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
 	int		   *d_lv_in = nullptr;
 	uint32_t   *d_entry = nullptr;
 	uint32_t	entry[2] = {NDBHIP_INVALID_BLOCK, (uint32_t) -1};
 
-	HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
-	HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
-	HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
+	if (base == 0)
+	{
+		hnsw_free_dev(h);
+		HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
+		HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
+		HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
+		HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));	/* row 0 = meta page */
+		HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
+	}
+	else
+	{
+		/* the relation grows by n pages: move the mirror into arrays of the new size */
+		int			rc = hnsw_densify(h);
+
+		if (rc)
+			return rc;
+		const uint32_t ob = base + 1;
+		float	   *nv = nullptr;
+		int		   *nl = nullptr;
+		int16_t    *nc = nullptr;
+		uint32_t   *nn = nullptr;
+		uint64_t   *nt = nullptr;
+
+		HIP_TRY(hipMalloc((void **) &nv, (size_t) nb * h->dim * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &nl, (size_t) nb * sizeof(int)));
+		HIP_TRY(hipMalloc((void **) &nc, (size_t) nb * 16 * sizeof(int16_t)));
+		HIP_TRY(hipMalloc((void **) &nn, (size_t) nb * stride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &nt, (size_t) nb * sizeof(uint64_t)));
+		HIP_TRY(hipMemcpyAsync(nv, h->d_vecs, (size_t) ob * h->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(nl, h->d_levels, (size_t) ob * sizeof(int), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(nc, h->d_ncount, (size_t) ob * 16 * sizeof(int16_t), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(nn, h->d_nbrs, (size_t) ob * stride * sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(nt, h->d_tids, (size_t) ob * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+		if (h->d_dead)
+		{
+			uint8_t    *nd = nullptr;
+
+			HIP_TRY(hipMalloc((void **) &nd, (size_t) nb));
+			HIP_TRY(hipMemsetAsync(nd, 0, (size_t) nb, g.stream));
+			HIP_TRY(hipMemcpyAsync(nd, h->d_dead, (size_t) ob, hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			HIP_TRY(hipFree(h->d_dead));
+			h->d_dead = nd;
+		}
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		HIP_TRY(hipFree(h->d_vecs)); HIP_TRY(hipFree(h->d_levels)); HIP_TRY(hipFree(h->d_ncount));
+		HIP_TRY(hipFree(h->d_nbrs)); HIP_TRY(hipFree(h->d_tids));
+		h->d_vecs = nv; h->d_levels = nl; h->d_ncount = nc; h->d_nbrs = nn; h->d_tids = nt;
+		entry[0] = h->entry_point;
+		entry[1] = (uint32_t) h->entry_level;
+	}
 	HIP_TRY(hipMalloc((void **) &d_lv_in, (size_t) n * sizeof(int)));
 	HIP_TRY(hipMalloc((void **) &d_entry, 2 * sizeof(uint32_t)));
-	HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));	/* row 0 = meta page */
-	HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
 	HIP_TRY(hipMemcpyAsync(d_lv_in, levels, (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemcpyAsync(d_entry, entry, sizeof(entry), hipMemcpyHostToDevice, g.stream));
 	{	/* experiment knobs */
@@ -5453,7 +5502,7 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 	{
 		hipLaunchKernelGGL(k_hnsw_build, dim3(1), dim3(64), smem, g.stream, h->d_vecs, h->d_levels, h->d_ncount,
 						   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, h->m,
-						   (uint32_t) ef_construction, d_entry);
+						   (uint32_t) ef_construction, d_entry, base);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(entry, d_entry, sizeof(entry), hipMemcpyDeviceToHost, g.stream));
 		HIP_TRY(hipStreamSynchronize(g.stream));
@@ -5469,14 +5518,15 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 		std::vector<HnswTask> tasks;
 		struct Batch { size_t t0, t1; uint32_t entry; int entry_level; };
 		std::vector<Batch> batches;
-		uint32_t	e_pt = NDBHIP_INVALID_BLOCK;
-		int			e_lv = -1;
+		uint32_t	e_pt = entry[0];
+		int			e_lv = (int) entry[1];
 		size_t		maxb = 0;
 
 		tasks.reserve((size_t) n + n / 8);
 		for (uint32_t i = 0; i < n;)
 		{
-			const size_t want = std::min<size_t>((size_t) g_hnsw_batch_max, std::max<size_t>(1, (size_t) i / (size_t) g_hnsw_batch_div));
+			const size_t want = std::min<size_t>((size_t) g_hnsw_batch_max,
+												 std::max<size_t>(1, ((size_t) base + i) / (size_t) g_hnsw_batch_div));
 			Batch		b{tasks.size(), tasks.size(), e_pt, e_lv};
 
 			while (i < n && tasks.size() - b.t0 < want)
@@ -5487,11 +5537,11 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 				if (level < 0) level = 0;
 				if (e_pt != NDBHIP_INVALID_BLOCK && e_lv >= 0)
 					for (int cl = std::min(level, e_lv); cl >= 0; cl--)
-						tasks.push_back(HnswTask{i, cl});
+						tasks.push_back(HnswTask{base + i, cl});
 				i++;
 				if (e_pt == NDBHIP_INVALID_BLOCK || level > e_lv)
 				{
-					e_pt = i;	/* block of row i-1 */
+					e_pt = base + i;	/* block of row i-1 */
 					e_lv = level;
 					break;		/* the entry point changes: close the batch */
 				}
@@ -5532,7 +5582,8 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 			HIP_TRY(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(HnswTask), hipMemcpyHostToDevice,
 								   g.stream));
 		hipLaunchKernelGGL(k_hnsw_init_nodes, dim3(n), dim3(256), 0, g.stream, h->d_vecs, h->d_levels, h->d_ncount,
-						   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, (int64_t) stride);
+						   h->d_nbrs, h->d_tids, d_rows, d_tids, (const int *) d_lv_in, n, h->dim, (int64_t) stride,
+						   base);
 		HIP_TRY(hipGetLastError());
 
 		HnswDev		gd;
@@ -5566,11 +5617,11 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 					if (fast)
 						hipLaunchKernelGGL(k_hnsw_spec<true>, dim3(nt), dim3(256), smem, g.stream, gd, d_rows,
 										   (const HnswTask *) (d_tasks + b.t0), (uint32_t) ef_construction, ksel,
-										   R, round);
+										   R, round, base);
 					else
 						hipLaunchKernelGGL(k_hnsw_spec<false>, dim3(nt), dim3(64), smem, g.stream, gd, d_rows,
 										   (const HnswTask *) (d_tasks + b.t0), (uint32_t) ef_construction, ksel,
-										   R, round);
+										   R, round, base);
 					if (par_commit)
 						hipLaunchKernelGGL(k_hnsw_commit_par, dim3(1), dim3(256), 0, g.stream, h->d_ncount, h->d_nbrs,
 										   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
@@ -5612,6 +5663,26 @@ ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_
 	h->loaded = true;
 	h->dense = true;
 	return NDBHIP_OK;
+}
+
+/* hnswbuild on rows already in HBM: node i+1 = row i, levels[i] = its drawn level (host array). */
+extern "C" int
+ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+						 const int32_t *levels, int ef_construction)
+{
+	return hnsw_insert_rows(h, d_rows, d_tids, n, levels, ef_construction, 0);
+}
+
+/* hnswinsert (src/index/hnsw_am.c:478-538): n more rows on top of the graph the mirror holds */
+extern "C" int
+ndbhip_hnsw_insert_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+						  const int32_t *levels, int ef_construction)
+{
+	if (!h)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!h->loaded || h->nblocks < 1)
+		return hnsw_insert_rows(h, d_rows, d_tids, n, levels, ef_construction, 0);
+	return hnsw_insert_rows(h, d_rows, d_tids, n, levels, ef_construction, h->nblocks - 1);
 }
 
 extern "C" int
@@ -5776,6 +5847,31 @@ k_hnsw_delete_seq(const int *__restrict__ levels, int16_t *ncount, uint32_t *nbr
 	}
 }
 
+/* loaded graphs hold (level+1)*2m slots per node; the reference's writers put entries at `level` into
+ * whatever node a list names (Q12/Q21), so before the mirror is modified every node gets all 16 levels */
+static int
+hnsw_densify(ndbhip_hnsw *h)
+{
+	if (h->dense)
+		return 0;
+	const uint32_t nb = h->nblocks;
+	const int	m2 = 2 * h->m;
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+	uint32_t   *d_dense = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_dense, (size_t) nb * stride * sizeof(uint32_t)));
+	hipLaunchKernelGGL(k_hnsw_densify, dim3(nb), dim3(256), 0, g.stream, (const int *) h->d_levels,
+					   (const int64_t *) h->d_nbr_off, (const uint32_t *) h->d_nbrs, nb, m2, d_dense);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(h->d_nbrs));
+	HIP_TRY(hipFree(h->d_nbr_off));
+	h->d_nbrs = d_dense;
+	h->d_nbr_off = nullptr;
+	h->dense = true;
+	return 0;
+}
+
 extern "C" int
 ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *removed)
 {
@@ -5791,25 +5887,12 @@ ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *rem
 	if (n == 0 || h->nblocks < 2)
 		return NDBHIP_OK;
 	const uint32_t nb = h->nblocks;
-	const int	m2 = 2 * h->m;
-	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * m2;
 
-	if (!h->dense)
 	{
-		/* loaded graphs hold (level+1)*2m slots per node; the reference's unlinking writes at `level` into
-		 * whatever node a list names (as its inserts do, Q12/Q21), so give every node all 16 levels */
-		uint32_t   *d_dense = nullptr;
+		int			rc = hnsw_densify(h);
 
-		HIP_TRY(hipMalloc((void **) &d_dense, (size_t) nb * stride * sizeof(uint32_t)));
-		hipLaunchKernelGGL(k_hnsw_densify, dim3(nb), dim3(256), 0, g.stream, (const int *) h->d_levels,
-						   (const int64_t *) h->d_nbr_off, (const uint32_t *) h->d_nbrs, nb, m2, d_dense);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(g.stream));
-		HIP_TRY(hipFree(h->d_nbrs));
-		HIP_TRY(hipFree(h->d_nbr_off));
-		h->d_nbrs = d_dense;
-		h->d_nbr_off = nullptr;
-		h->dense = true;
+		if (rc)
+			return rc;
 	}
 	if (!h->d_dead)
 	{

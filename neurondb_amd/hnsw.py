@@ -73,6 +73,20 @@ class HnswIndex:
                                              _ptr(lv), int(ef_construction)))
         self.nblocks = len(lv) + 1
 
+    def insert(self, rows, tids, levels, ef_construction=200):
+        """hnswinsert: more rows on top of the graph the mirror holds (node nblocks + i = row i)."""
+        import torch
+        r = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.dim)).cuda()
+        t = np.ascontiguousarray(tids)
+        t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
+        t8 = np.zeros((t6.shape[0], 8), dtype=np.uint8)
+        t8[:, :6] = t6
+        tt = torch.from_numpy(t8.view(np.int64).reshape(-1)).cuda()
+        lv = np.ascontiguousarray(levels, dtype=np.int32).reshape(-1)
+        check(lib().ndbhip_hnsw_insert_device(self._h, C.c_void_p(r.data_ptr()), C.c_void_p(tt.data_ptr()), len(lv),
+                                              _ptr(lv), int(ef_construction)))
+        self.nblocks = max(getattr(self, "nblocks", 1), 1) + len(lv)
+
     def delete(self, tids):
         """hnswbulkdelete: unlink and mark dead every live node whose heapPtr is in `tids`; returns the count."""
         t = np.ascontiguousarray(tids)

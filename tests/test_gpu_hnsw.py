@@ -200,3 +200,54 @@ def test_hnsw_bulkdelete_matches_oracle(built_on_device, restore_build_mode):
     q = rng.standard_normal((16, dim)).astype(np.float32)
     for strategy in (1, 2, 3):
         check(g, ix, q, strategy, 32, 10)
+
+
+@pytest.mark.parametrize("mode", ["sequential", "optimistic"])
+def test_hnsw_insert_on_top_of_a_built_graph(mode, restore_build_mode):
+    """hnswinsert after hnswbuild: 600 rows built, then 250 more in one call, then single rows — the graph is
+    the oracle's after the same 900 inserts; and on top of a LOADED (packed) graph the searchable part of the
+    graph (levels <= node level) and the search results agree."""
+    from neurondb_amd import HnswIndex
+    HnswIndex.set_build_mode(*BUILD_MODES[mode])
+    n, n0, dim, m, efc = 900, 600, 24, 6, 30
+    rng = np.random.default_rng(8)
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    L = ndbo.lib()
+    levels = np.array([L.ndbo_hnsw_level_from_uniform(float(r), np.float32(0.36))
+                       for r in rng.uniform(1e-9, 1.0, n)], np.int32)
+    levels[700] = 5                                          # a later insert takes the entry point over
+    tids = ndbo.tids_from_rows(np.arange(n))
+    g = ndbo.HnswGraph(dim, m=m, ef_construction=efc, cap_nodes=n + 2)
+    for i in range(n0):
+        g.insert(vecs[i], i, int(levels[i]))
+    half = g.arrays()
+    for i in range(n0, n):
+        g.insert(vecs[i], i, int(levels[i]))
+    a = g.arrays()
+    q = rng.standard_normal((12, dim)).astype(np.float32)
+
+    ix = HnswIndex(dim, m)
+    ix.build(vecs[:n0], tids[:n0], levels[:n0], efc)
+    ix.insert(vecs[n0:n0 + 250], tids[n0:n0 + 250], levels[n0:n0 + 250], efc)
+    for i in range(n0 + 250, n):
+        ix.insert(vecs[i], tids[i:i + 1], levels[i:i + 1], efc)
+    e = ix.export()
+    assert (e["nblocks"], e["entry_point"], e["entry_level"]) == (a["nblocks"], a["entry_point"], a["entry_level"])
+    assert np.array_equal(e["levels"][1:], a["levels"][1:])
+    assert np.array_equal(e["ncount"][1:], a["ncount"][1:])
+    assert np.array_equal(e["nbrs"][1:], a["nbrs"][1:])
+    for strategy in (1, 2):
+        check(g, ix, q, strategy, 32, 10)
+
+    ld = HnswIndex(dim, m)
+    ld.load(half["vecs"], half["levels"], half["ncount"], half["nbrs"], half["tids"], half["entry_point"],
+            half["entry_level"])
+    ld.insert(vecs[n0:], tids[n0:], levels[n0:], efc)
+    e = ld.export()
+    assert (e["nblocks"], e["entry_point"], e["entry_level"]) == (a["nblocks"], a["entry_point"], a["entry_level"])
+    for blk in range(1, n + 1):
+        lv = a["levels"][blk]
+        assert np.array_equal(e["ncount"][blk, :lv + 1], a["ncount"][blk, :lv + 1])
+        assert np.array_equal(e["nbrs"][blk, :lv + 1], a["nbrs"][blk, :lv + 1])
+    for strategy in (1, 3):
+        check(g, ld, q, strategy, 32, 10)
