@@ -326,6 +326,30 @@ int			ndbhip_hnsw_search_device(ndbhip_hnsw *g, const float *d_queries, int nq, 
 									  uint64_t *d_out_tids, int64_t *d_out_scored);
 
 /* ------------------------------------------------------------------ */
+/* hnsw relation pages <-> mirror, PostgreSQL-free (src/index/hnsw_am.c:108-181, 1091-1110, 2288-2332):
+ * block 0 = HnswMetaPageData, every other block = ONE item = HnswNodeData (48 B) + vector + neighbour slots
+ * of levels 0..level; a line pointer hnswbulkdelete marked dead (:693) comes back in dead[].  The array
+ * layout is ndbhip_hnsw_export's (dense: nbrs [nblocks][16][2m]).  pack/unpack/info are pure host code. */
+/* ------------------------------------------------------------------ */
+int			ndbhip_hnsw_pages_info(const uint8_t *pages, uint32_t nblocks, int *dim, int *m, int *ef_construction,
+								   int *ef_search, uint32_t *entry_point, int *entry_level);
+int			ndbhip_hnsw_pages_unpack(const uint8_t *pages, uint32_t nblocks, float *vecs, int32_t *levels,
+									 int16_t *ncount, uint32_t *nbrs, uint8_t *tids6, uint8_t *dead);
+int			ndbhip_hnsw_pages_pack(int dim, int m, int ef_construction, int ef_search, uint32_t nblocks,
+								   const float *vecs, const int32_t *levels, const int16_t *ncount,
+								   const uint32_t *nbrs, const uint8_t *tids6, const uint8_t *dead,
+								   uint32_t entry_point, int entry_level, uint8_t *pages, uint32_t nblocks_cap);
+int			ndbhip_hnsw_load_pages(ndbhip_hnsw **out, const uint8_t *pages, uint32_t nblocks);
+/* pages == NULL: only *nblocks_out (= blocks the relation needs) */
+int			ndbhip_hnsw_write_pages(const ndbhip_hnsw *g, int ef_construction, int ef_search, uint8_t *pages,
+									uint32_t nblocks_cap, uint32_t *nblocks_out);
+int			ndbhip_hnsw_shape(const ndbhip_hnsw *g, int *dim, int *m);
+/* the rest of the mirror ndbhip_hnsw_export does not return: vectors [nblocks*dim], heapPtrs [nblocks*6],
+ * dead flags [nblocks] (each may be NULL); ndbhip_hnsw_set_dead_flags restores the latter after a load */
+int			ndbhip_hnsw_export_rows(const ndbhip_hnsw *g, float *vecs, uint8_t *tids6, uint8_t *dead);
+int			ndbhip_hnsw_set_dead_flags(ndbhip_hnsw *g, const uint8_t *dead);
+
+/* ------------------------------------------------------------------ */
 /* Datum -> dense float4[] (replaces ivfExtractVectorData, src/index/ivf_am.c:117-218,
  * and hnswExtractVectorData, src/index/hnsw_am.c:1402-1519).  `datum` is the
  * DETOASTED varlena image of the indexed value (vector / halfvec / sparsevec /

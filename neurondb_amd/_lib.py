@@ -111,6 +111,15 @@ def lib():
         "ndbhip_hnsw_destroy": (i, [vp]),
         "ndbhip_hnsw_load": (i, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i]),
         "ndbhip_hnsw_build_device": (i, [vp, vp, vp, C.c_uint32, vp, i]),
+        "ndbhip_hnsw_pages_info": (i, [vp, C.c_uint32, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i),
+                                    C.POINTER(C.c_uint32), C.POINTER(i)]),
+        "ndbhip_hnsw_pages_unpack": (i, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
+        "ndbhip_hnsw_pages_pack": (i, [i, i, i, i, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i, vp, C.c_uint32]),
+        "ndbhip_hnsw_load_pages": (i, [C.POINTER(vp), vp, C.c_uint32]),
+        "ndbhip_hnsw_write_pages": (i, [vp, i, i, vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "ndbhip_hnsw_shape": (i, [vp, C.POINTER(i), C.POINTER(i)]),
+        "ndbhip_hnsw_export_rows": (i, [vp, vp, vp, vp]),
+        "ndbhip_hnsw_set_dead_flags": (i, [vp, vp]),
         "ndbhip_hnsw_insert_device": (i, [vp, vp, vp, C.c_uint32, vp, i]),
         "ndbhip_hnsw_delete": (i, [vp, vp, i64, C.POINTER(i64)]),
         "ndbhip_hnsw_build_stats": (i, [vp, vp]),

@@ -5950,6 +5950,60 @@ ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *rem
 	return NDBHIP_OK;
 }
 
+extern "C" int
+ndbhip_hnsw_shape(const ndbhip_hnsw *h, int *dim, int *m)
+{
+	if (!h)
+		return fail(NDBHIP_ERR_INVALID, "graph is NULL");
+	if (dim) *dim = h->dim;
+	if (m) *m = h->m;
+	return NDBHIP_OK;
+}
+
+/* vectors [nblocks * dim], heapPtrs [nblocks * 6], dead flags [nblocks] (any may be NULL) */
+extern "C" int
+ndbhip_hnsw_export_rows(const ndbhip_hnsw *h, float *vecs, uint8_t *tids6, uint8_t *dead)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !h->loaded)
+		return fail(NDBHIP_ERR_STATE, "hnsw mirror not loaded");
+	const uint32_t nb = h->nblocks;
+
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (vecs)
+		HIP_TRY(hipMemcpy(vecs, h->d_vecs, (size_t) nb * h->dim * sizeof(float), hipMemcpyDeviceToHost));
+	if (tids6)
+	{
+		std::vector<uint64_t> t64(nb);
+
+		HIP_TRY(hipMemcpy(t64.data(), h->d_tids, (size_t) nb * sizeof(uint64_t), hipMemcpyDeviceToHost));
+		for (uint32_t b = 0; b < nb; b++)
+			ndb_tid_unpack(t64[b], tids6 + (size_t) b * 6);
+	}
+	if (dead)
+	{
+		if (h->d_dead)
+			HIP_TRY(hipMemcpy(dead, h->d_dead, (size_t) nb, hipMemcpyDeviceToHost));
+		else
+			memset(dead, 0, (size_t) nb);
+	}
+	return NDBHIP_OK;
+}
+
+/* line pointers hnswbulkdelete had marked dead before the mirror was packed ([nblocks]) */
+extern "C" int
+ndbhip_hnsw_set_dead_flags(ndbhip_hnsw *h, const uint8_t *dead)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !h->loaded || !dead)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!h->d_dead)
+		HIP_TRY(hipMalloc((void **) &h->d_dead, (size_t) h->nblocks));
+	HIP_TRY(hipMemcpyAsync(h->d_dead, dead, (size_t) h->nblocks, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return NDBHIP_OK;
+}
+
 /* Read a graph back in the dense layout: levels [nblocks], ncount [nblocks*16],
  * nbrs [nblocks*16*2m] (slots a packed graph does not hold come back as 0xFFFFFFFF). */
 extern "C" int

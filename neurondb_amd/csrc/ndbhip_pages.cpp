@@ -451,3 +451,290 @@ ndbhip_ivf_write_pages(const ndbhip_ivf *ix, int nprobe, uint8_t *pages, uint32_
 	return ndbhip_ivf_pages_pack(dim, nlists, nprobe, nc, cent.data(), ll.data(), rows.data(), tids.data(), pages,
 								 nblocks_cap, nblocks_out);
 }
+
+/* ================================================================== */
+/* hnsw relation pages                                                  */
+/*   block 0: HnswMetaPageData at PageGetContents (src/index/hnsw_am.c:108-120, 1091-1110):              */
+/*     magic 0x48534E57 @0, version @4, entryPoint @8, entryLevel @12, maxLevel @16, int16 m @20,        */
+/*     efConstruction @22, efSearch @24, float4 ml @28, int64 insertedVectors @32 (40 B)                 */
+/*   block b >= 1: ONE item (hnsw_am.c:2288-2332) = HnswNodeData{ItemPointerData heapPtr @0; int level   */
+/*     @8; int16 dim @12; int16 neighborCount[16] @14} (48 B) + float4 vector[dim] @48 +                  */
+/*     BlockNumber neighbors[level+1][2m] (:124-181); hnswbulkdelete leaves the item with LP_DEAD (:693) */
+/* ================================================================== */
+
+#define HNSW_MAGIC 0x48534E57u
+#define HNSW_NODE_HDR 48
+#define HNSW_LEVELS 16
+
+struct HnswPagesInfo
+{
+	int			dim, m, ef_construction, ef_search, entry_level, max_level;
+	uint32_t	entry_point, nblocks;
+	int64_t		inserted;
+};
+
+/* count / validate (outputs NULL) or unpack into the dense arrays of ndbhip_hnsw_export's layout */
+static int
+hnsw_walk_pages(const uint8_t *pages, uint32_t nblocks, HnswPagesInfo *info, float *vecs, int32_t *levels,
+				int16_t *ncount, uint32_t *nbrs, uint8_t *tids6, uint8_t *dead)
+{
+	if (!pages || nblocks < 1)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "no pages");
+	const PageView mv = page_view(pages);
+
+	if (!mv.ok)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "block 0 is not an initialised page");
+	const uint8_t *meta = pages + PG_PAGE_HEADER;
+
+	if (rd32(meta) != HNSW_MAGIC)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: invalid magic number in metadata");
+	const int	m = (int16_t) rd16(meta + 20);
+
+	if (m < 2 || m > 128)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: m in the meta page out of range");
+	int			dim = 0;
+	const size_t stride = (size_t) HNSW_LEVELS * 2 * m;
+
+	for (uint32_t b = 1; b < nblocks; b++)
+	{
+		const PageView v = page_view(pages + (size_t) b * PG_BLCKSZ);
+		uint32_t	off, flags, len;
+
+		if (!v.ok || v.nitems < 1)
+			return ndbhip_pages_fail(NDBHIP_ERR_UNSUPPORTED, "hnsw: empty node page (the reference never leaves one)");
+		item_id(v, 0, off, flags, len);
+		if ((flags != LP_NORMAL && flags != LP_DEAD) || off + HNSW_NODE_HDR > PG_BLCKSZ)
+			return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: bad line pointer on a node page");
+		const uint8_t *node = v.p + off;
+		const int	level = (int32_t) rd32(node + 8);
+		const int	ndim = (int16_t) rd16(node + 12);
+
+		if (level < 0 || level >= HNSW_LEVELS || ndim < 1)
+			return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: node level / dim out of range");
+		if (dim == 0)
+			dim = ndim;
+		if (ndim != dim)
+			return ndbhip_pages_fail(NDBHIP_ERR_UNSUPPORTED, "hnsw: nodes of different dimensions");
+		const size_t need = HNSW_NODE_HDR + (size_t) ndim * 4 + (size_t) (level + 1) * 2 * m * 4;
+
+		if (need > len || off + need > PG_BLCKSZ)
+			return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: node item shorter than its level needs");
+		if (!vecs)
+			continue;
+		memcpy(tids6 + (size_t) b * 6, node, 6);
+		levels[b] = level;
+		memcpy(ncount + (size_t) b * HNSW_LEVELS, node + 14, HNSW_LEVELS * 2);
+		memcpy(vecs + (size_t) b * dim, node + HNSW_NODE_HDR, (size_t) dim * 4);
+		memcpy(nbrs + (size_t) b * stride, node + HNSW_NODE_HDR + (size_t) dim * 4, (size_t) (level + 1) * 2 * m * 4);
+		dead[b] = flags == LP_DEAD;
+	}
+	if (info)
+	{
+		info->dim = dim;
+		info->m = m;
+		info->entry_point = rd32(meta + 8);
+		info->entry_level = (int32_t) rd32(meta + 12);
+		info->max_level = (int32_t) rd32(meta + 16);
+		info->ef_construction = (int16_t) rd16(meta + 22);
+		info->ef_search = (int16_t) rd16(meta + 24);
+		info->nblocks = nblocks;
+		memcpy(&info->inserted, meta + 32, 8);
+	}
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_pages_info(const uint8_t *pages, uint32_t nblocks, int *dim, int *m, int *ef_construction,
+					   int *ef_search, uint32_t *entry_point, int *entry_level)
+{
+	HnswPagesInfo info;
+	int			rc = hnsw_walk_pages(pages, nblocks, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+
+	if (rc)
+		return rc;
+	if (dim) *dim = info.dim;
+	if (m) *m = info.m;
+	if (ef_construction) *ef_construction = info.ef_construction;
+	if (ef_search) *ef_search = info.ef_search;
+	if (entry_point) *entry_point = info.entry_point;
+	if (entry_level) *entry_level = info.entry_level;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_pages_unpack(const uint8_t *pages, uint32_t nblocks, float *vecs, int32_t *levels, int16_t *ncount,
+						 uint32_t *nbrs, uint8_t *tids6, uint8_t *dead)
+{
+	HnswPagesInfo info;
+	int			rc = hnsw_walk_pages(pages, nblocks, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+
+	if (rc)
+		return rc;
+	if (!vecs || !levels || !ncount || !nbrs || !tids6 || !dead)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "NULL output");
+	const size_t stride = (size_t) HNSW_LEVELS * 2 * info.m;
+
+	memset(vecs, 0, (size_t) info.dim * 4);
+	levels[0] = 0;
+	memset(ncount, 0, HNSW_LEVELS * 2);
+	memset(nbrs, 0xFF, (size_t) nblocks * stride * 4);
+	memset(tids6, 0, 6);
+	dead[0] = 0;
+	return hnsw_walk_pages(pages, nblocks, nullptr, vecs, levels, ncount, nbrs, tids6, dead);
+}
+
+/* dense arrays -> relation image: block 0 meta + one node page per block */
+extern "C" int
+ndbhip_hnsw_pages_pack(int dim, int m, int ef_construction, int ef_search, uint32_t nblocks, const float *vecs,
+					   const int32_t *levels, const int16_t *ncount, const uint32_t *nbrs, const uint8_t *tids6,
+					   const uint8_t *dead, uint32_t entry_point, int entry_level, uint8_t *pages,
+					   uint32_t nblocks_cap)
+{
+	if (dim < 1 || m < 2 || m > 128 || nblocks < 1 || !pages || (nblocks > 1 && (!vecs || !levels || !ncount || !nbrs || !tids6)))
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nblocks_cap < nblocks)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "page buffer too small");
+	const size_t stride = (size_t) HNSW_LEVELS * 2 * m;
+	int			max_level = -1;
+	int64_t		live = 0;
+
+	for (uint32_t b = 1; b < nblocks; b++)
+	{
+		uint8_t    *p = pages + (size_t) b * PG_BLCKSZ;
+		const int	level = levels[b];
+
+		if (level < 0 || level >= HNSW_LEVELS)
+			return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: node level out of range");
+		const size_t size = PG_MAXALIGN(HNSW_NODE_HDR + (size_t) dim * 4 + (size_t) (level + 1) * 2 * m * 4);
+
+		page_init(p, 0);
+		if (page_free(p) < size)	/* "node size exceeds free space" (:2306-2312) */
+			return ndbhip_pages_fail(NDBHIP_ERR_UNSUPPORTED, "hnsw: node does not fit one page");
+		uint8_t    *node = page_add(p, size);
+
+		memset(node, 0, size);
+		memcpy(node, tids6 + (size_t) b * 6, 6);
+		wr32(node + 8, (uint32_t) level);
+		wr16(node + 12, (uint16_t) dim);
+		memcpy(node + 14, ncount + (size_t) b * HNSW_LEVELS, HNSW_LEVELS * 2);
+		memcpy(node + HNSW_NODE_HDR, vecs + (size_t) b * dim, (size_t) dim * 4);
+		memcpy(node + HNSW_NODE_HDR + (size_t) dim * 4, nbrs + (size_t) b * stride, (size_t) (level + 1) * 2 * m * 4);
+		if (dead && dead[b])
+		{
+			const uint32_t w = rd32(p + PG_PAGE_HEADER);
+
+			wr32(p + PG_PAGE_HEADER, (w & ~(3u << 15)) | ((uint32_t) LP_DEAD << 15));
+		}
+		else
+			live++;
+		if (level > max_level)
+			max_level = level;
+	}
+	uint8_t    *p0 = pages;
+
+	page_init(p0, 40);				/* PageInit(page, size, sizeof(HnswMetaPageData)): :1097 */
+	uint8_t    *meta = p0 + PG_PAGE_HEADER;
+
+	wr32(meta, HNSW_MAGIC);
+	wr32(meta + 4, 1);
+	wr32(meta + 8, entry_point);
+	wr32(meta + 12, (uint32_t) entry_level);
+	wr32(meta + 16, (uint32_t) max_level);
+	wr16(meta + 20, (uint16_t) m);
+	wr16(meta + 22, (uint16_t) ef_construction);
+	wr16(meta + 24, (uint16_t) ef_search);
+	{
+		const float ml = 0.36f;		/* HNSW_DEFAULT_ML: :84 */
+
+		memcpy(meta + 28, &ml, 4);
+	}
+	wr64(meta + 32, (uint64_t) live);
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_load_pages(ndbhip_hnsw **out, const uint8_t *pages, uint32_t nblocks)
+{
+	HnswPagesInfo info;
+	int			rc = hnsw_walk_pages(pages, nblocks, &info, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+
+	if (rc)
+		return rc;
+	if (!out)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "out is NULL");
+	if (nblocks < 2 || info.dim < 1)
+		return ndbhip_pages_fail(NDBHIP_ERR_STATE, "hnsw: the relation holds no node");
+	const size_t stride = (size_t) HNSW_LEVELS * 2 * info.m;
+	std::vector<float> vecs((size_t) nblocks * info.dim);
+	std::vector<int32_t> levels(nblocks);
+	std::vector<int16_t> ncount((size_t) nblocks * HNSW_LEVELS);
+	std::vector<uint32_t> nbrs((size_t) nblocks * stride);
+	std::vector<uint8_t> tids((size_t) nblocks * 6), dead(nblocks);
+
+	rc = ndbhip_hnsw_pages_unpack(pages, nblocks, vecs.data(), levels.data(), ncount.data(), nbrs.data(),
+								  tids.data(), dead.data());
+	if (rc)
+		return rc;
+	/* ndbhip_hnsw_load takes the packed slots: (level+1)*2m per node */
+	std::vector<int64_t> off((size_t) nblocks + 1);
+	std::vector<uint32_t> packed;
+
+	off[0] = 0;
+	off[1] = 0;
+	for (uint32_t b = 1; b < nblocks; b++)
+	{
+		const size_t n = (size_t) (levels[b] + 1) * 2 * info.m;
+
+		packed.insert(packed.end(), nbrs.begin() + (size_t) b * stride, nbrs.begin() + (size_t) b * stride + n);
+		off[b + 1] = (int64_t) packed.size();
+	}
+	ndbhip_hnsw *h = nullptr;
+
+	rc = ndbhip_hnsw_create(info.dim, info.m, &h);
+	if (rc)
+		return rc;
+	rc = ndbhip_hnsw_load(h, nblocks, vecs.data(), levels.data(), ncount.data(), off.data(),
+						  packed.empty() ? nullptr : packed.data(), tids.data(), info.entry_point, info.entry_level);
+	if (!rc)
+		rc = ndbhip_hnsw_set_dead_flags(h, dead.data());
+	if (rc)
+	{
+		ndbhip_hnsw_destroy(h);
+		return rc;
+	}
+	*out = h;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_write_pages(const ndbhip_hnsw *h, int ef_construction, int ef_search, uint8_t *pages,
+						uint32_t nblocks_cap, uint32_t *nblocks_out)
+{
+	uint32_t	nb = 0, entry = 0;
+	int			entry_level = -1, dim = 0, m = 0;
+	int			rc = ndbhip_hnsw_export(h, &nb, nullptr, nullptr, nullptr, &entry, &entry_level);
+
+	if (rc)
+		return rc;
+	rc = ndbhip_hnsw_shape(h, &dim, &m);
+	if (rc)
+		return rc;
+	if (nblocks_out)
+		*nblocks_out = nb;
+	if (!pages)
+		return NDBHIP_OK;		/* size query */
+	const size_t stride = (size_t) HNSW_LEVELS * 2 * m;
+	std::vector<float> vecs((size_t) nb * dim);
+	std::vector<int32_t> levels(nb);
+	std::vector<int16_t> ncount((size_t) nb * HNSW_LEVELS);
+	std::vector<uint32_t> nbrs((size_t) nb * stride);
+	std::vector<uint8_t> tids((size_t) nb * 6), dead(nb);
+
+	rc = ndbhip_hnsw_export(h, nullptr, levels.data(), ncount.data(), nbrs.data(), nullptr, nullptr);
+	if (!rc)
+		rc = ndbhip_hnsw_export_rows(h, vecs.data(), tids.data(), dead.data());
+	if (rc)
+		return rc;
+	return ndbhip_hnsw_pages_pack(dim, m, ef_construction, ef_search, nb, vecs.data(), levels.data(), ncount.data(),
+								  nbrs.data(), tids.data(), dead.data(), entry, entry_level, pages, nblocks_cap);
+}

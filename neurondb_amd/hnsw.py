@@ -73,6 +73,29 @@ class HnswIndex:
                                              _ptr(lv), int(ef_construction)))
         self.nblocks = len(lv) + 1
 
+    @classmethod
+    def load_pages(cls, pages):
+        """Mirror of an hnsw relation image (bytes / uint8 array of 8 KB blocks): ndbhip_hnsw_load_pages."""
+        ensure_init(None)
+        buf = np.frombuffer(bytes(pages), np.uint8) if not isinstance(pages, np.ndarray) else pages
+        nb = buf.size // 8192
+        h = C.c_void_p()
+        check(lib().ndbhip_hnsw_load_pages(C.byref(h), buf.ctypes.data, nb))
+        d, m = C.c_int(), C.c_int()
+        check(lib().ndbhip_hnsw_shape(h, C.byref(d), C.byref(m)))
+        ix = cls.__new__(cls)
+        ix.dim, ix.m, ix._h, ix.nblocks = d.value, m.value, h, nb
+        return ix
+
+    def write_pages(self, ef_construction=200, ef_search=64):
+        """The relation image of this mirror (bytes): block 0 meta + one node page per block."""
+        nb = C.c_uint32()
+        check(lib().ndbhip_hnsw_write_pages(self._h, ef_construction, ef_search, None, 0, C.byref(nb)))
+        pages = np.zeros(nb.value * 8192, np.uint8)
+        check(lib().ndbhip_hnsw_write_pages(self._h, ef_construction, ef_search, pages.ctypes.data, nb.value,
+                                            C.byref(nb)))
+        return pages.tobytes()
+
     def insert(self, rows, tids, levels, ef_construction=200):
         """hnswinsert: more rows on top of the graph the mirror holds (node nblocks + i = row i)."""
         import torch

@@ -238,10 +238,11 @@ class HnswGraph:
 
     @classmethod
     def from_arrays(cls, vecs, levels, ncount, nbrs, tids, entry_point, entry_level, m, ef_construction=200,
-                    native=False):
-        """Oracle graph image filled from dense arrays (node b = row b of vecs, row 0 unused)."""
+                    native=False, cap_nodes=None):
+        """Oracle graph image filled from dense arrays (node b = row b of vecs, row 0 unused);
+        cap_nodes = room for later inserts."""
         nb, dim = vecs.shape
-        g = cls(dim, m=m, ef_construction=ef_construction, cap_nodes=nb, native=native)
+        g = cls(dim, m=m, ef_construction=ef_construction, cap_nodes=max(nb, cap_nodes or 0), native=native)
         s = g.g.contents
         C.memmove(s.vecs, np.ascontiguousarray(vecs, np.float32).ctypes.data, nb * dim * 4)
         C.memmove(s.levels, np.ascontiguousarray(levels, np.int32).ctypes.data, nb * 4)

@@ -131,3 +131,62 @@ def read_image(img):
     rows = np.array(rows, np.float32).reshape(-1, dim)
     t6 = np.frombuffer(b"".join(tids), np.uint8).reshape(-1, 6) if tids else np.zeros((0, 6), np.uint8)
     return dim, np.array(cents, np.float32), np.array(lens, np.int64), rows, t6, version
+
+
+# ---------------------------------------------------------------------------------------------
+# hnsw relation (src/index/hnsw_am.c:108-181): block 0 meta, every other block one node item
+# ---------------------------------------------------------------------------------------------
+
+def write_hnsw_reference_format(vecs, levels, ncount, nbrs, tids6, entry_point, entry_level, m, efc=200, efs=64,
+                                dead=()):
+    """Image as hnswbuild/hnswinsert leave it (node b on block b, neighbour slots of levels 0..level only);
+    `dead`: blocks whose line pointer hnswbulkdelete marked dead."""
+    nb, dim = vecs.shape
+    pages = [Page(40)]
+    live = 0
+    for b in range(1, nb):
+        lv = int(levels[b])
+        item = bytes(tids6[b]) + b"\0\0" + struct.pack("<ih", lv, dim) + np.asarray(ncount[b], np.int16).tobytes()
+        assert len(item) == 46
+        item += b"\0\0" + np.asarray(vecs[b], np.float32).tobytes()
+        item += np.asarray(nbrs[b, :lv + 1], np.uint32).tobytes()
+        pg = Page(0)
+        off = pg.add(item)
+        if b in dead:
+            pg.set_flags(off, 3)
+        else:
+            live += 1
+        pages.append(pg)
+    struct.pack_into("<IIIiihhhxxfq", pages[0].b, 24, 0x48534E57, 1, entry_point & 0xFFFFFFFF, entry_level,
+                     int(max(levels[1:])) if nb > 1 else -1, m, efc, efs, 0.36, live)
+    return b"".join(bytes(p.b) for p in pages)
+
+
+def read_hnsw_image(img, m):
+    """Independent reader -> dense arrays (slots above a node's level = 0xFFFFFFFF) + dead flags + meta."""
+    nb = len(img) // BLCKSZ
+    magic, version, entry, entry_level, max_level, mm, efc, efs, ml, inserted = \
+        struct.unpack_from("<IIIiihhhxxfq", img, 24)
+    assert magic == 0x48534E57 and mm == m
+    vecs = levels = None
+    ncount = np.zeros((nb, 16), np.int16)
+    nbrs = np.full((nb, 16, 2 * m), INVALID, np.uint32)
+    tids = np.zeros((nb, 6), np.uint8)
+    dead = np.zeros(nb, np.uint8)
+    levels = np.zeros(nb, np.int32)
+    for b in range(1, nb):
+        base = b * BLCKSZ
+        w, = struct.unpack_from("<I", img, base + 24)
+        off, flags = w & 0x7FFF, (w >> 15) & 3
+        lv, dim = struct.unpack_from("<ih", img, base + off + 8)
+        if vecs is None:
+            vecs = np.zeros((nb, dim), np.float32)
+        tids[b] = np.frombuffer(img, np.uint8, 6, base + off)
+        levels[b] = lv
+        ncount[b] = np.frombuffer(img, np.int16, 16, base + off + 14)
+        vecs[b] = np.frombuffer(img, np.float32, dim, base + off + 48)
+        nbrs[b, :lv + 1] = np.frombuffer(img, np.uint32, (lv + 1) * 2 * m, base + off + 48 + 4 * dim) \
+            .reshape(lv + 1, 2 * m)
+        dead[b] = flags == 3
+    return dict(vecs=vecs, levels=levels, ncount=ncount, nbrs=nbrs, tids=tids, dead=dead, entry_point=entry,
+                entry_level=entry_level, max_level=max_level, efc=efc, efs=efs, inserted=inserted)

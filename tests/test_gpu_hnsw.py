@@ -251,3 +251,50 @@ def test_hnsw_insert_on_top_of_a_built_graph(mode, restore_build_mode):
         assert np.array_equal(e["nbrs"][blk, :lv + 1], a["nbrs"][blk, :lv + 1])
     for strategy in (1, 3):
         check(g, ld, q, strategy, 32, 10)
+
+
+def test_hnsw_relation_pages_round_trip():
+    """index pages -> mirror -> search (== oracle on the same graph) -> VACUUM + inserts on the mirror ->
+    pages again, read by the test's own reader: the image holds the mirror's graph incl. the dead flags."""
+    from neurondb_amd import HnswIndex
+    from tests import pgpages
+    g, vecs = build_graph(500, 16, 6, 24, seed=12)
+    a = g.arrays()
+    t6 = np.ascontiguousarray(a["tids"]).view(np.uint8).reshape(-1, 6)
+    img = pgpages.write_hnsw_reference_format(a["vecs"], a["levels"], a["ncount"], a["nbrs"], t6, a["entry_point"],
+                                              a["entry_level"], 6, efc=24, efs=32)
+    ix = HnswIndex.load_pages(img)
+    assert (ix.dim, ix.m, ix.nblocks) == (16, 6, a["nblocks"])
+    # From here on the model is the oracle over what the PAGES hold: the reference's writes above a node's
+    # own level (Q12/Q21) land outside the item — on a real page outside the buffer — so the image has no
+    # such slots, while the oracle's in-memory build kept them and later inserts would read them back.
+    r0 = pgpages.read_hnsw_image(img, 6)
+    g = ndbo.HnswGraph.from_arrays(r0["vecs"], r0["levels"], r0["ncount"], r0["nbrs"], a["tids"],
+                                   r0["entry_point"], r0["entry_level"], 6, 24, cap_nodes=600)
+    rng = np.random.default_rng(13)
+    q = rng.standard_normal((10, 16)).astype(np.float32)
+    for strategy in (1, 2, 3):
+        check(g, ix, q, strategy, 32, 10)
+    victims = ndbo.tids_from_rows(np.array([4, 77, 300]))
+    assert ix.delete(victims) == 3 and g.bulkdelete(victims) == 3
+    more = rng.standard_normal((40, 16)).astype(np.float32)
+    lv = np.zeros(40, np.int32)
+    lv[5] = 2
+    ix.insert(more, ndbo.tids_from_rows(np.arange(500, 540)), lv, 24)
+    for i in range(40):
+        g.insert(more[i], 500 + i, int(lv[i]))
+    for strategy in (1, 2):
+        check(g, ix, q, strategy, 32, 10)
+    r = pgpages.read_hnsw_image(ix.write_pages(24, 32), 6)
+    b = g.arrays()
+    assert (r["entry_point"], r["entry_level"]) == (b["entry_point"], b["entry_level"])
+    assert set(np.nonzero(r["dead"])[0].tolist()) == {5, 78, 301} and r["inserted"] == 540 - 3
+    assert np.array_equal(r["vecs"][1:], b["vecs"][1:]) and np.array_equal(r["levels"][1:], b["levels"][1:])
+    for blk in range(1, b["nblocks"]):
+        lvl = b["levels"][blk]
+        assert np.array_equal(r["ncount"][blk, :lvl + 1], b["ncount"][blk, :lvl + 1])
+        assert np.array_equal(r["nbrs"][blk, :lvl + 1], b["nbrs"][blk, :lvl + 1])
+    # and the image loads back into an equivalent mirror
+    again = HnswIndex.load_pages(r and ix.write_pages(24, 32))
+    for strategy in (1, 3):
+        check(g, again, q, strategy, 32, 10)

@@ -110,3 +110,81 @@ def test_bad_images_are_errors():
     a = np.frombuffer(bytes(img), np.uint8).copy()
     assert L.ndbhip_ivf_pages_info(a.ctypes.data, len(a) // 8192, None, None, None, None, None) == _lib.ERR_INVALID
     assert "magic" in _lib.last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# hnsw relation pages
+# ---------------------------------------------------------------------------------------------
+
+def _small_graph(n=120, dim=12, m=5, efc=16, seed=4):
+    from oracle import ndbo
+    rng = np.random.default_rng(seed)
+    L = ndbo.lib()
+    g = ndbo.HnswGraph(dim, m=m, ef_construction=efc, cap_nodes=n + 2)
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    for i in range(n):
+        lv = 3 if i == 9 else L.ndbo_hnsw_level_from_uniform(float(rng.uniform(1e-9, 1)), np.float32(0.36))
+        g.insert(vecs[i], i, int(lv))
+    a = g.arrays()
+    # what a page can hold: slots of levels 0..level (the Q12/Q21 out-of-node writes are not on the item)
+    for b in range(1, a["nblocks"]):
+        a["nbrs"][b, a["levels"][b] + 1:] = 0xFFFFFFFF
+    a["tids6"] = np.ascontiguousarray(a["tids"]).view(np.uint8).reshape(-1, 6)
+    return g, a
+
+
+def test_hnsw_pages_unpack_reads_the_reference_layout():
+    import ctypes as C
+    from neurondb_amd import _lib
+    g, a = _small_graph()
+    nb, m, dim = a["nblocks"], a["m"], a["dim"]
+    dead = {7, 30}
+    img = pgpages.write_hnsw_reference_format(a["vecs"], a["levels"], a["ncount"], a["nbrs"], a["tids6"],
+                                              a["entry_point"], a["entry_level"], m, efc=16, efs=40, dead=dead)
+    L = _lib.lib()
+    buf = np.frombuffer(img, np.uint8)
+    d, mm, efc, efs, ep, el = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint32(), C.c_int()
+    _lib.check(L.ndbhip_hnsw_pages_info(buf.ctypes.data, nb, C.byref(d), C.byref(mm), C.byref(efc), C.byref(efs),
+                                        C.byref(ep), C.byref(el)))
+    assert (d.value, mm.value, efc.value, efs.value, ep.value, el.value) == \
+        (dim, m, 16, 40, a["entry_point"], a["entry_level"])
+    vecs = np.zeros((nb, dim), np.float32)
+    levels = np.zeros(nb, np.int32)
+    ncount = np.zeros((nb, 16), np.int16)
+    nbrs = np.zeros((nb, 16, 2 * m), np.uint32)
+    tids = np.zeros((nb, 6), np.uint8)
+    dd = np.zeros(nb, np.uint8)
+    _lib.check(L.ndbhip_hnsw_pages_unpack(buf.ctypes.data, nb, vecs.ctypes.data, levels.ctypes.data,
+                                          ncount.ctypes.data, nbrs.ctypes.data, tids.ctypes.data, dd.ctypes.data))
+    assert np.array_equal(vecs[1:], a["vecs"][1:]) and np.array_equal(levels[1:], a["levels"][1:])
+    assert np.array_equal(ncount[1:], a["ncount"][1:]) and np.array_equal(nbrs[1:], a["nbrs"][1:])
+    assert np.array_equal(tids[1:], a["tids6"][1:])
+    assert set(np.nonzero(dd)[0].tolist()) == dead
+    # a truncated item or a foreign magic number is refused, not read
+    bad = bytearray(img)
+    bad[24:28] = b"\0\0\0\0"
+    assert L.ndbhip_hnsw_pages_info(np.frombuffer(bytes(bad), np.uint8).ctypes.data, nb, None, None, None, None,
+                                    None, None) != 0
+
+
+def test_hnsw_pages_pack_is_readable_by_an_independent_reader():
+    from neurondb_amd import _lib
+    g, a = _small_graph(seed=6)
+    nb, m, dim = a["nblocks"], a["m"], a["dim"]
+    dead = np.zeros(nb, np.uint8)
+    dead[[3, 44]] = 1
+    pages = np.zeros(nb * pgpages.BLCKSZ, np.uint8)
+    _lib.check(_lib.lib().ndbhip_hnsw_pages_pack(
+        dim, m, 16, 40, nb, a["vecs"].ctypes.data, a["levels"].ctypes.data, a["ncount"].ctypes.data,
+        a["nbrs"].ctypes.data, a["tids6"].ctypes.data, dead.ctypes.data, a["entry_point"], a["entry_level"],
+        pages.ctypes.data, nb))
+    r = pgpages.read_hnsw_image(pages.tobytes(), m)
+    assert np.array_equal(r["vecs"][1:], a["vecs"][1:]) and np.array_equal(r["levels"][1:], a["levels"][1:])
+    assert np.array_equal(r["ncount"][1:], a["ncount"][1:]) and np.array_equal(r["nbrs"][1:], a["nbrs"][1:])
+    assert np.array_equal(r["tids"][1:], a["tids6"][1:]) and np.array_equal(r["dead"], dead)
+    assert (r["entry_point"], r["entry_level"], r["efc"], r["efs"]) == (a["entry_point"], a["entry_level"], 16, 40)
+    assert r["max_level"] == int(a["levels"][1:].max()) and r["inserted"] == nb - 1 - 2
+    # byte-identical to the image the independent writer produces for the same graph
+    img = pgpages.write_hnsw_reference_format(a["vecs"], a["levels"], a["ncount"], a["nbrs"], a["tids6"],
+                                              a["entry_point"], a["entry_level"], m, efc=16, efs=40, dead={3, 44})
+    assert pages.tobytes() == img
