@@ -1,0 +1,88 @@
+/*
+ * ndb_am.h — the index access-method callbacks of the reference, PostgreSQL-free.
+ *
+ * The reference's scan entry points are static functions reached through IndexAmRoutine
+ * (src/index/ivf_am.c:390-432, src/index/hnsw_am.c:293-335).  This header declares the same
+ * four per-AM callbacks with the same meaning of every argument and the same state machine,
+ * over the device mirror instead of the buffer manager, so that the glue in INTEGRATION.md is
+ * a field-by-field forwarding.  What PostgreSQL supplies is replaced by the smallest plain-C
+ * equivalent:
+ *
+ *   IndexScanDesc            -> ndb_index_scan (only the fields the callbacks touch)
+ *   ScanKey                  -> ndb_scan_key   (sk_strategy + the DETOASTED datum image of sk_argument)
+ *   ItemPointerData          -> ndb_item_pointer (6 bytes, same layout)
+ *   GUCs read with GetConfigOption -> ndb_am_set_guc / ndb_am_get_guc
+ *   ereport(ERROR)           -> negative NDBHIP_ERR_* return, text in ndbhip_last_error()
+ *
+ * Every callback cites the reference lines it mirrors in ndb_am.cpp.
+ */
+#ifndef NDB_AM_H
+#define NDB_AM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ndbhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ndb_item_pointer
+{
+	uint16_t	bi_hi;			/* ItemPointerData: ip_blkid.bi_hi, bi_lo, ip_posid */
+	uint16_t	bi_lo;
+	uint16_t	posid;
+}			ndb_item_pointer;
+
+/* one ORDER BY key: orderbys[0] of amrescan (ivf_am.c:1455-1536, hnsw_am.c:904-976) */
+typedef struct ndb_scan_key
+{
+	int			sk_strategy;	/* operator strategy number: 1 <-> (L2), 2 <=> (cosine), 3 <#> (inner product) */
+	int			sk_type;		/* NDBHIP_TYPE_VECTOR / HALFVEC / SPARSEVEC / BIT: the indexed column's type */
+	const void *sk_argument;	/* detoasted varlena image of the query value, NULL = SK_ISNULL */
+	size_t		sk_len;
+}			ndb_scan_key;
+
+typedef struct ndb_index_scan
+{
+	void	   *indexRelation;	/* ndbhip_ivf * or ndbhip_hnsw *: the mirror of the index relation */
+	int			numberOfKeys;
+	int			numberOfOrderBys;
+	ndb_item_pointer xs_heaptid;	/* set by amgettuple when it returns true */
+	float		xs_orderbyval;		/* xs_orderbyvals[0] (ivf sets it: ivf_am.c:2013-2020; hnsw does not, Q13) */
+	int			xs_orderbynull;		/* xs_orderbynulls[0]: 1 when no value was set */
+	int			xs_recheckorderby;	/* always 0 */
+	void	   *opaque;
+}			ndb_index_scan;
+
+#define NDB_FORWARD_SCAN_DIRECTION 1
+
+/* GUCs the callbacks read.  Names as in the reference where it has them (src/util/neurondb_guc.c):
+ *   neurondb.hnsw_ef_search (64), neurondb.hnsw_k (10)             hnsw_am.c:923-936
+ *   neurondb.ivf_probes (10)   defined by the reference but never read (Q4)
+ *   neurondb.ivf_k (10)        the reference hard-codes k = 10 (Q3)
+ *   neurondb.ref_compat (0)    1 = keep Q1/Q3/Q4: strategy 1, nprobe 10, k 10 and the k*10 candidate cap
+ * Returns NDBHIP_ERR_INVALID for an unknown name or an out-of-range value. */
+int			ndb_am_set_guc(const char *name, int value);
+int			ndb_am_get_guc(const char *name, int *value);
+
+/* ivf: src/index/ivf_am.c:1412-1437 / 1439-1545 / 1911-2027 / 2029-2048 */
+ndb_index_scan *ndb_ivfbeginscan(ndbhip_ivf *index, int nkeys, int norderbys);
+int			ndb_ivfrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys,
+						  const ndb_scan_key *orderbys, int norderbys);
+/* 1 = a tuple is in xs_heaptid / xs_orderbyval, 0 = no more tuples, < 0 = the reference's ERROR */
+int			ndb_ivfgettuple(ndb_index_scan *scan, int direction);
+void		ndb_ivfendscan(ndb_index_scan *scan);
+
+/* hnsw: src/index/hnsw_am.c:880-902 / 904-976 / 978-1056 / 1058-1084 */
+ndb_index_scan *ndb_hnswbeginscan(ndbhip_hnsw *index, int nkeys, int norderbys);
+int			ndb_hnswrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys,
+						   const ndb_scan_key *orderbys, int norderbys);
+int			ndb_hnswgettuple(ndb_index_scan *scan, int direction);
+void		ndb_hnswendscan(ndb_index_scan *scan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif							/* NDB_AM_H */

@@ -36,11 +36,28 @@ def lib_path() -> str:
 
 
 def declared_symbols() -> list:
-    """Every function include/ndbhip.h declares."""
-    with open(_HDR) as f:
-        text = f.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ndbhip_[a-z0-9_]+)\s*\(", text)))
+    """Every function include/*.h declares (ndbhip.h: the C ABI; ndb_am.h: the AM callbacks over it)."""
+    out = set()
+    for name in ("ndbhip.h", "ndb_am.h"):
+        with open(os.path.join(_ROOT, "include", name)) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out.update(re.findall(r"\b(ndbhip_[a-z0-9_]+|ndb_[a-z][a-z0-9_]+)\s*\(", text))
+    return sorted(out)
+
+
+class NdbItemPointer(C.Structure):
+    _fields_ = [("bi_hi", C.c_uint16), ("bi_lo", C.c_uint16), ("posid", C.c_uint16)]
+
+
+class NdbScanKey(C.Structure):
+    _fields_ = [("sk_strategy", C.c_int), ("sk_type", C.c_int), ("sk_argument", C.c_void_p), ("sk_len", C.c_size_t)]
+
+
+class NdbIndexScan(C.Structure):
+    _fields_ = [("indexRelation", C.c_void_p), ("numberOfKeys", C.c_int), ("numberOfOrderBys", C.c_int),
+                ("xs_heaptid", NdbItemPointer), ("xs_orderbyval", C.c_float), ("xs_orderbynull", C.c_int),
+                ("xs_recheckorderby", C.c_int), ("opaque", C.c_void_p)]
 
 
 _lib = None
@@ -129,6 +146,17 @@ def lib():
         "ndbhip_hnsw_search_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_batch_distance": (i, [vp, vp, vp, i, i, i, i, i]),
         "ndbhip_extract_vector": (i, [i, vp, C.c_size_t, vp, i, C.POINTER(i)]),
+        # include/ndb_am.h
+        "ndb_am_set_guc": (i, [C.c_char_p, i]),
+        "ndb_am_get_guc": (i, [C.c_char_p, C.POINTER(i)]),
+        "ndb_ivfbeginscan": (C.POINTER(NdbIndexScan), [vp, i, i]),
+        "ndb_ivfrescan": (i, [C.POINTER(NdbIndexScan), C.POINTER(NdbScanKey), i, C.POINTER(NdbScanKey), i]),
+        "ndb_ivfgettuple": (i, [C.POINTER(NdbIndexScan), i]),
+        "ndb_ivfendscan": (None, [C.POINTER(NdbIndexScan)]),
+        "ndb_hnswbeginscan": (C.POINTER(NdbIndexScan), [vp, i, i]),
+        "ndb_hnswrescan": (i, [C.POINTER(NdbIndexScan), C.POINTER(NdbScanKey), i, C.POINTER(NdbScanKey), i]),
+        "ndb_hnswgettuple": (i, [C.POINTER(NdbIndexScan), i]),
+        "ndb_hnswendscan": (None, [C.POINTER(NdbIndexScan)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly

@@ -1,0 +1,137 @@
+"""The reference's AM scan callbacks (include/ndb_am.h: ndb_ivfbeginscan / rescan / gettuple / endscan and the
+hnsw four) driven the way PostgreSQL's executor drives ivf_am.c / hnsw_am.c: rescan with the ORDER BY key's
+datum, gettuple until false.  Every tuple and distance must be the oracle's."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import ndbo
+from tests.test_extract_vector import halfvec_datum, vector_datum
+from tests.test_gpu_hnsw import build_graph, load
+from tests.util import make_ivf_arrays, oracle_image
+
+pytestmark = pytest.mark.gpu
+
+VECTOR, HALFVEC = 0, 1
+
+
+def _key(datum, strategy, kind=VECTOR):
+    from neurondb_amd._lib import NdbScanKey
+    buf = C.create_string_buffer(datum, len(datum)) if datum is not None else None
+    k = NdbScanKey(strategy, kind, C.cast(buf, C.c_void_p) if buf is not None else None, len(datum) if datum else 0)
+    return k, buf                                           # keep buf alive
+
+
+def _drain(L, gettuple, scan):
+    out = []
+    while True:
+        rc = gettuple(scan, 1)
+        assert rc >= 0, L.ndbhip_last_error()
+        if rc == 0:
+            return out
+        s = scan.contents
+        out.append(((s.xs_heaptid.bi_hi, s.xs_heaptid.bi_lo, s.xs_heaptid.posid), s.xs_orderbyval, s.xs_orderbynull))
+
+
+@pytest.fixture
+def gucs():
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    yield lambda n, v: _lib.check(L.ndb_am_set_guc(n.encode(), v))
+    for n, v in (("neurondb.ivf_probes", 10), ("neurondb.ivf_k", 10), ("neurondb.hnsw_ef_search", 64),
+                 ("neurondb.hnsw_k", 10), ("neurondb.ref_compat", 0)):
+        L.ndb_am_set_guc(n.encode(), v)
+
+
+def test_ivf_scan_callbacks(gucs):
+    from neurondb_amd import IvfIndex, _lib
+    L = _lib.lib()
+    a = make_ivf_arrays(5000, 64, 20, seed=61, dup_frac=0.1)
+    img = oracle_image(a)
+    ix = IvfIndex(64, 20)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    rng = np.random.default_rng(62)
+    q = (a["rows"][17] + rng.standard_normal(64).astype(np.float32) * 0.05).astype(np.float32)
+    scan = L.ndb_ivfbeginscan(ix._h, 0, 1)
+    assert scan and L.ndb_ivfgettuple(scan, 1) == 0          # no rescan yet: no query, no tuple
+
+    def run(strategy, datum, kind=VECTOR):
+        key, keep = _key(datum, strategy, kind)
+        _lib.check(L.ndb_ivfrescan(scan, None, 0, C.byref(key), 1))
+        return _drain(L, L.ndb_ivfgettuple, scan)
+
+    def expect(query, strategy, nprobe, k, cap=0):
+        et, ed, _ = img.search(query, strategy, nprobe, k, cap)
+        return [((int(t["bi_hi"]), int(t["bi_lo"]), int(t["posid"])), d) for t, d in zip(et, ed)]
+
+    for strategy in (1, 2, 3):                               # defaults: probes 10, k 10
+        got = run(strategy, vector_datum(q))
+        exp = expect(q, strategy, 10, 10)
+        assert [g[0] for g in got] == [e[0] for e in exp]
+        assert [np.float32(g[1]).view(np.uint32) for g in got] == [np.float32(e[1]).view(np.uint32) for e in exp]
+        assert all(g[2] == 0 for g in got)
+    gucs("neurondb.ivf_probes", 4)
+    gucs("neurondb.ivf_k", 25)
+    got = run(1, vector_datum(q))
+    assert [g[0] for g in got] == [e[0] for e in expect(q, 1, 4, 25)] and len(got) == 25
+    # a halfvec ORDER BY value goes through fp16_to_float like ivfExtractVectorData does
+    h = (q * 0.5).astype(np.float16)
+    lut_q = np.array([ndbo.lib().ndbo_fp16_to_float(int(v)) for v in h.view(np.uint16)], np.float32)
+    got = run(3, halfvec_datum(h.view(np.uint16)), HALFVEC)
+    assert [g[0] for g in got] == [e[0] for e in expect(lut_q, 3, 4, 25)]
+    # reference-compatible mode: strategy 1 whatever the operator (Q1), nprobe 10, k 10 (Q3/Q4), k*10 cap (:1743)
+    gucs("neurondb.ref_compat", 1)
+    got = run(2, vector_datum(q))
+    assert [g[0] for g in got] == [e[0] for e in expect(q, 1, 10, 10, cap=100)]
+    gucs("neurondb.ref_compat", 0)
+    # wrong dimension: "does not match index dimension" -> no tuples (:1961-1972); NULL argument keeps the query
+    assert run(1, vector_datum(q[:32])) == []
+    _lib.check(L.ndb_ivfrescan(scan, None, 0, C.byref(_key(vector_datum(q), 1)[0]), 1))
+    nullkey, _ = _key(None, 1)
+    _lib.check(L.ndb_ivfrescan(scan, None, 0, C.byref(nullkey), 1))
+    assert len(_drain(L, L.ndb_ivfgettuple, scan)) == 25
+    # a malformed datum is the reference's ERROR: a negative code, not a crash
+    bad = struct.pack("<ihh", 8 + 4 * 64, 70, 0) + q.tobytes()
+    key, keep = _key(bad, 1)
+    assert L.ndb_ivfrescan(scan, None, 0, C.byref(key), 1) < 0
+    assert L.ndb_am_set_guc(b"neurondb.no_such", 1) < 0 and L.ndb_am_set_guc(b"neurondb.ivf_probes", 0) < 0
+    L.ndb_ivfendscan(scan)
+
+
+def test_hnsw_scan_callbacks(gucs):
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    g, vecs = build_graph(800, 32, 8, 40, seed=63)
+    ix, a = load(g)
+    rng = np.random.default_rng(64)
+    q = rng.standard_normal(32).astype(np.float32)
+    scan = L.ndb_hnswbeginscan(ix._h, 0, 1)
+    assert scan and L.ndb_hnswgettuple(scan, 1) == 0
+
+    def run(strategy, datum):
+        key, keep = _key(datum, strategy)
+        rc = L.ndb_hnswrescan(scan, None, 0, C.byref(key), 1)
+        assert rc == 0, L.ndbhip_last_error()
+        return key, keep
+
+    def expect(query, strategy, ef, k):
+        eb, ed, _ = g.search(query, strategy, ef, k)
+        t = a["tids"][eb]
+        return [tuple(int(x) for x in row) for row in np.asarray(t).reshape(len(eb), -1)]
+
+    for strategy in (1, 2, 3):
+        run(strategy, vector_datum(q))
+        got = _drain(L, L.ndb_hnswgettuple, scan)
+        assert [x[0] for x in got] == expect(q, strategy, 64, 10)
+        assert all(x[2] == 1 for x in got)                   # hnswgettuple sets no ORDER BY value (Q13)
+    gucs("neurondb.hnsw_ef_search", 16)
+    gucs("neurondb.hnsw_k", 4)
+    run(1, vector_datum(q))
+    assert [x[0] for x in _drain(L, L.ndb_hnswgettuple, scan)] == expect(q, 1, 16, 4)
+    # an operator strategy the AM does not know is hnswComputeDistance's ERROR (:1339-1343)
+    run(4, vector_datum(q))
+    assert L.ndb_hnswgettuple(scan, 1) < 0
+    L.ndb_hnswendscan(scan)
