@@ -82,6 +82,26 @@ int			ndb_hnswrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys,
 int			ndb_hnswgettuple(ndb_index_scan *scan, int direction);
 void		ndb_hnswendscan(ndb_index_scan *scan);
 
+/* aminsert.  value = the detoasted datum of values[0] (NULL = isnull[0]: nothing is inserted, returns 0);
+ * returns 1 when an entry was added, 0 when not, < 0 for the reference's ERROR.
+ *   ivfinsert  src/index/ivf_am.c:797-1167
+ *   hnswinsert src/index/hnsw_am.c:478-538; `level` = what hnswGetRandomLevel (:1143-1161) drew in the
+ *              backend — it uses random(), so the draw stays with the caller; ndb_hnsw_level_from_uniform
+ *              is the formula for a caller-supplied uniform r in (0, 1]. */
+int			ndb_ivfinsert(ndbhip_ivf *index, const void *value, size_t value_len, int value_type,
+						  const ndb_item_pointer *ht_ctid);
+int			ndb_hnswinsert(ndbhip_hnsw *index, const void *value, size_t value_len, int value_type,
+						   const ndb_item_pointer *ht_ctid, int level);
+int			ndb_hnsw_level_from_uniform(double r, float ml);
+
+/* ambulkdelete (ivf_am.c:1172-1357, hnsw_am.c:544-720): callback(itemptr, state) != 0 = delete this entry.
+ * *tuples_removed as IndexBulkDeleteResult.tuples_removed. */
+typedef int (*ndb_bulkdelete_callback) (const ndb_item_pointer *itemptr, void *state);
+int			ndb_ivfbulkdelete(ndbhip_ivf *index, ndb_bulkdelete_callback callback, void *callback_state,
+							  int64_t *tuples_removed);
+int			ndb_hnswbulkdelete(ndbhip_hnsw *index, ndb_bulkdelete_callback callback, void *callback_state,
+							   int64_t *tuples_removed);
+
 #ifdef __cplusplus
 }
 #endif

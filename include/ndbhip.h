@@ -131,6 +131,9 @@ int			ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint
 /* aminsert: append one entry to the tail of list `list_id`
  * (src/index/ivf_am.c:954-1157) — see ndbhip_ivf_assign for the list choice. */
 int			ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6);
+/* ivfinsert (src/index/ivf_am.c:797-1167) for one host row: nearest centroid by the insert-time rule
+ * (:905-935) on the device, then ndbhip_ivf_append to that list; *list_out (optional) = the list chosen. */
+int			ndbhip_ivf_insert(ndbhip_ivf *ix, const float *vec, const uint8_t *tid6, int *list_out);
 /* ambulkdelete (src/index/ivf_am.c:1172-1357): every entry whose heapPtr is one of the n given TIDs is
  * dropped from the mirror (the reference marks its line pointer dead and scans skip it, :1816-1822);
  * survivors keep their list and their order inside it.  *removed = entries dropped.  Runs on the device
@@ -288,6 +291,9 @@ int			ndbhip_hnsw_build_device(ndbhip_hnsw *g, const float *d_rows, const uint64
  * nblocks + i = row i.  On an empty mirror this is ndbhip_hnsw_build_device. */
 int			ndbhip_hnsw_insert_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 									  const int32_t *levels, int ef_construction);
+/* ... and for host rows / heapPtrs (6 bytes each), staged by the library */
+int			ndbhip_hnsw_insert(ndbhip_hnsw *g, const float *rows, const uint8_t *tids6, uint32_t n,
+							   const int32_t *levels, int ef_construction);
 /* How the last ndbhip_hnsw_build_device ran: out[0] walks (one per insert and linked level), out[1] walks
  * that had to run again because an earlier insert of their batch wrote a list they had read, out[2] walks
  * whose read-set log overflowed, out[3] speculate+commit rounds, out[4] batches, out[5] largest batch.

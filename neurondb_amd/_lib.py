@@ -60,6 +60,8 @@ class NdbIndexScan(C.Structure):
                 ("xs_recheckorderby", C.c_int), ("opaque", C.c_void_p)]
 
 
+BULKDELETE_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(NdbItemPointer), C.c_void_p)
+
 _lib = None
 
 
@@ -157,6 +159,13 @@ def lib():
         "ndb_hnswrescan": (i, [C.POINTER(NdbIndexScan), C.POINTER(NdbScanKey), i, C.POINTER(NdbScanKey), i]),
         "ndb_hnswgettuple": (i, [C.POINTER(NdbIndexScan), i]),
         "ndb_hnswendscan": (None, [C.POINTER(NdbIndexScan)]),
+        "ndb_ivfinsert": (i, [vp, vp, C.c_size_t, i, C.POINTER(NdbItemPointer)]),
+        "ndb_hnswinsert": (i, [vp, vp, C.c_size_t, i, C.POINTER(NdbItemPointer), i]),
+        "ndb_hnsw_level_from_uniform": (i, [C.c_double, C.c_float]),
+        "ndb_ivfbulkdelete": (i, [vp, BULKDELETE_CALLBACK, vp, C.POINTER(i64)]),
+        "ndb_hnswbulkdelete": (i, [vp, BULKDELETE_CALLBACK, vp, C.POINTER(i64)]),
+        "ndbhip_ivf_insert": (i, [vp, vp, vp, C.POINTER(i)]),
+        "ndbhip_hnsw_insert": (i, [vp, vp, vp, C.c_uint32, vp, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly

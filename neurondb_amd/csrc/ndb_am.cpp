@@ -320,3 +320,143 @@ ndb_hnswendscan(ndb_index_scan *scan)
 {
 	end_scan(scan);
 }
+
+/* ---- aminsert / ambulkdelete ------------------------------------------------------------------ */
+
+static int
+datum_to_row(const void *value, size_t len, int type, std::vector<float> &row)
+{
+	int			dim = 0;
+	int			rc = ndbhip_extract_vector(type, value, len, nullptr, 0, &dim);
+
+	if (rc)
+		return rc;
+	row.assign((size_t) (dim > 0 ? dim : 1), 0.0f);
+	rc = ndbhip_extract_vector(type, value, len, row.data(), dim, &dim);
+	if (!rc)
+		row.resize((size_t) dim);
+	return rc;
+}
+
+/* ivfinsert: src/index/ivf_am.c:797-1167 */
+extern "C" int
+ndb_ivfinsert(ndbhip_ivf *index, const void *value, size_t value_len, int value_type, const ndb_item_pointer *ht_ctid)
+{
+	if (!index || !ht_ctid)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!value)					/* isnull[0]: "don't insert NULLs" (:817-818) */
+		return 0;
+	std::vector<float> row;
+	int			rc = datum_to_row(value, value_len, value_type, row);
+	int			dim = 0;
+
+	if (rc)
+		return rc;
+	rc = ndbhip_ivf_shape(index, &dim, nullptr);
+	if (rc)
+		return rc;
+	if ((int) row.size() != dim)	/* centroids of another dimension are skipped (:921-923): nothing can be nearest */
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "ivf: vector dimension does not match the index");
+	rc = ndbhip_ivf_insert(index, row.data(), (const uint8_t *) ht_ctid, nullptr);
+	return rc ? rc : 1;
+}
+
+/* hnswGetRandomLevel's formula (hnsw_am.c:1143-1161): (int)(-log(r) * ml), clamped to [0, 15] */
+extern "C" int
+ndb_hnsw_level_from_uniform(double r, float ml)
+{
+	if (!(r > 0.0))
+		return 0;
+	int			level = (int) (-__builtin_log(r) * ml);
+
+	return level < 0 ? 0 : (level > 15 ? 15 : level);
+}
+
+/* hnswinsert: src/index/hnsw_am.c:478-538 */
+extern "C" int
+ndb_hnswinsert(ndbhip_hnsw *index, const void *value, size_t value_len, int value_type,
+			   const ndb_item_pointer *ht_ctid, int level)
+{
+	if (!index || !ht_ctid)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!value)					/* isnull[0] (:497-498) */
+		return 0;
+	std::vector<float> row;
+	int			rc = datum_to_row(value, value_len, value_type, row);
+	int			dim = 0, m = 0;
+
+	if (rc)
+		return rc;
+	rc = ndbhip_hnsw_shape(index, &dim, &m);
+	if (rc)
+		return rc;
+	if ((int) row.size() != dim)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: vector dimension does not match the index");
+	const int32_t lv = level;
+
+	rc = ndbhip_hnsw_insert(index, row.data(), (const uint8_t *) ht_ctid, 1, &lv, 200 /* HNSW_DEFAULT_EF_CONSTRUCTION */);
+	return rc ? rc : 1;
+}
+
+/* ivfbulkdelete: src/index/ivf_am.c:1172-1357 */
+extern "C" int
+ndb_ivfbulkdelete(ndbhip_ivf *index, ndb_bulkdelete_callback callback, void *callback_state, int64_t *tuples_removed)
+{
+	if (!index || !callback)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	const int64_t n = ndbhip_ivf_nrows(index);
+	std::vector<uint8_t> tids((size_t) (n > 0 ? n : 1) * 6), hit;
+	int			rc = ndbhip_ivf_export(index, nullptr, nullptr, nullptr, tids.data());
+
+	if (rc)
+		return rc;
+	for (int64_t i = 0; i < n; i++)	/* every live entry, list by list, chain order (:1226-1290) */
+	{
+		ndb_item_pointer ip;
+
+		memcpy(&ip, tids.data() + (size_t) i * 6, 6);
+		if (callback(&ip, callback_state))
+			hit.insert(hit.end(), tids.begin() + (size_t) i * 6, tids.begin() + (size_t) i * 6 + 6);
+	}
+	int64_t		removed = 0;
+
+	rc = ndbhip_ivf_delete(index, hit.empty() ? nullptr : hit.data(), (int64_t) (hit.size() / 6), &removed);
+	if (tuples_removed)
+		*tuples_removed = removed;
+	return rc;
+}
+
+/* hnswbulkdelete: src/index/hnsw_am.c:544-720 */
+extern "C" int
+ndb_hnswbulkdelete(ndbhip_hnsw *index, ndb_bulkdelete_callback callback, void *callback_state,
+				   int64_t *tuples_removed)
+{
+	if (!index || !callback)
+		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	uint32_t	nb = 0;
+	int			rc = ndbhip_hnsw_export(index, &nb, nullptr, nullptr, nullptr, nullptr, nullptr);
+
+	if (rc)
+		return rc;
+	std::vector<uint8_t> tids((size_t) (nb > 0 ? nb : 1) * 6), dead(nb > 0 ? nb : 1), hit;
+
+	rc = ndbhip_hnsw_export_rows(index, nullptr, tids.data(), dead.data());
+	if (rc)
+		return rc;
+	for (uint32_t b = 1; b < nb; b++)	/* blocks in order; dead line pointers are not offered again (:586-601) */
+	{
+		ndb_item_pointer ip;
+
+		if (dead[b])
+			continue;
+		memcpy(&ip, tids.data() + (size_t) b * 6, 6);
+		if (callback(&ip, callback_state))
+			hit.insert(hit.end(), tids.begin() + (size_t) b * 6, tids.begin() + (size_t) b * 6 + 6);
+	}
+	int64_t		removed = 0;
+
+	rc = ndbhip_hnsw_delete(index, hit.empty() ? nullptr : hit.data(), (int64_t) (hit.size() / 6), &removed);
+	if (tuples_removed)
+		*tuples_removed = removed;
+	return rc;
+}

@@ -3448,6 +3448,36 @@ ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, cons
 	return assign_rows(d_rows, nrows, dim, d_centroids, ncentroids, true, d_out_list, nullptr);
 }
 
+/* ivfinsert (src/index/ivf_am.c:797-1167) for one host row: nearest centroid by the insert-time rule
+ * (sqrtf of the fp32 sum, strict <, first minimum: :905-935) on the device, then the entry goes to the tail
+ * of that list (ndbhip_ivf_append). */
+extern "C" int
+ndbhip_ivf_insert(ndbhip_ivf *ix, const float *vec, const uint8_t *tid6, int *list_out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !vec || !tid6)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!ix->loaded || ix->ncent < 1)
+		return fail(NDBHIP_ERR_STATE, "index has no centroids/lists loaded");
+	if (ix->sharded)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "insert into the unsharded mirror");
+	const int	ncmp = std::min(ix->nlists, ix->ncent);	/* i < nlist && i < maxoff: :917 */
+	int			list = 0;
+
+	if (grow(ix->w_q, ix->w_q_n, (size_t) ix->dim)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_ocnt, ix->w_ocnt_n, (size_t) 1)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(ix->w_q, vec, (size_t) ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	int			rc = assign_rows(ix->w_q, 1, ix->dim, ix->d_centroids, ncmp, true, ix->w_ocnt, nullptr);
+
+	if (rc)
+		return rc;
+	HIP_TRY(hipMemcpyAsync(&list, ix->w_ocnt, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (list_out)
+		*list_out = list;
+	return ndbhip_ivf_append(ix, list, vec, tid6);
+}
+
 extern "C" int
 ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter, float threshold,
 					 float *d_centroids, int *d_assign, int *d_counts, int *out_iters, float *out_cost)
@@ -5683,6 +5713,32 @@ ndbhip_hnsw_insert_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d
 	if (!h->loaded || h->nblocks < 1)
 		return hnsw_insert_rows(h, d_rows, d_tids, n, levels, ef_construction, 0);
 	return hnsw_insert_rows(h, d_rows, d_tids, n, levels, ef_construction, h->nblocks - 1);
+}
+
+/* the same for host rows: staged to the device, then ndbhip_hnsw_insert_device */
+extern "C" int
+ndbhip_hnsw_insert(ndbhip_hnsw *h, const float *rows, const uint8_t *tids6, uint32_t n, const int32_t *levels,
+				   int ef_construction)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !rows || !tids6 || !levels || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_rows = nullptr;
+	uint64_t   *d_tids = nullptr;
+	std::vector<uint64_t> t64(n);
+
+	for (uint32_t i = 0; i < n; i++)
+		t64[i] = ndb_tid_pack(tids6 + (size_t) i * 6);
+	HIP_TRY(hipMalloc((void **) &d_rows, (size_t) n * h->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_tids, (size_t) n * sizeof(uint64_t)));
+	HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t) n * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_tids, t64.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	const int	rc = ndbhip_hnsw_insert_device(h, d_rows, d_tids, n, levels, ef_construction);
+
+	(void) hipStreamSynchronize(g.stream);
+	(void) hipFree(d_rows);
+	(void) hipFree(d_tids);
+	return rc;
 }
 
 extern "C" int

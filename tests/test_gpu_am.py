@@ -135,3 +135,81 @@ def test_hnsw_scan_callbacks(gucs):
     run(4, vector_datum(q))
     assert L.ndb_hnswgettuple(scan, 1) < 0
     L.ndb_hnswendscan(scan)
+
+
+def test_ivf_insert_and_bulkdelete_callbacks():
+    """aminsert / ambulkdelete through the AM-level entry points: the entry lands in the list the oracle's
+    insert-time rule picks, at its tail; VACUUM's callback sees every live heapPtr once and its hits vanish."""
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import BULKDELETE_CALLBACK, NdbItemPointer
+    L = _lib.lib()
+    a = make_ivf_arrays(3000, 32, 12, seed=71, dup_frac=0.05)
+    ix = IvfIndex(32, 12)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    rng = np.random.default_rng(72)
+    new = (a["rows"][rng.integers(0, 3000, 20)] + rng.standard_normal((20, 32)).astype(np.float32) * 0.1) \
+        .astype(np.float32)
+    exp_list = ndbo.ivf_assign_all(a["centroids"], new)
+    for i in range(20):
+        tid = NdbItemPointer(0, 900 + i, 1 + i)
+        assert L.ndb_ivfinsert(ix._h, vector_datum(new[i]), 8 + 4 * 32, VECTOR, C.byref(tid)) == 1
+    assert L.ndb_ivfinsert(ix._h, None, 0, VECTOR, C.byref(NdbItemPointer(0, 1, 1))) == 0      # NULL value
+    assert L.ndb_ivfinsert(ix._h, vector_datum(new[0][:8]), 8 + 4 * 8, VECTOR, C.byref(NdbItemPointer(0, 1, 1))) < 0
+    cent, ll, rows, tids = ix.export()
+    assert np.array_equal(ll, np.asarray(a["list_len"]) + np.bincount(exp_list, minlength=12))
+    off = np.concatenate([[0], np.cumsum(ll)])
+    for lst in range(12):                                     # arrivals sit at the tail, in arrival order
+        mine = [i for i in range(20) if exp_list[i] == lst]
+        tail = tids[off[lst + 1] - len(mine):off[lst + 1]]
+        assert [int(t["bi_lo"]) for t in tail] == [900 + i for i in mine]
+    seen = []
+
+    def cb(ip, state):
+        t = ip.contents
+        seen.append((t.bi_hi, t.bi_lo, t.posid))
+        return 1 if (t.bi_lo >= 900 or t.posid % 7 == 0) else 0
+    removed = C.c_int64(0)
+    _lib.check(L.ndb_ivfbulkdelete(ix._h, BULKDELETE_CALLBACK(cb), None, C.byref(removed)))
+    assert len(seen) == 3020 and len(set(seen)) == len(set((int(t["bi_hi"]), int(t["bi_lo"]), int(t["posid"]))
+                                                          for t in tids))
+    kept = [t for t in tids if not (t["bi_lo"] >= 900 or t["posid"] % 7 == 0)]
+    assert removed.value == 3020 - len(kept)
+    assert [tuple(t) for t in ix.export()[3].tolist()] == [tuple(t) for t in np.array(kept).tolist()]
+
+
+def test_hnsw_insert_and_bulkdelete_callbacks():
+    from neurondb_amd import HnswIndex, _lib
+    from neurondb_amd._lib import BULKDELETE_CALLBACK, NdbItemPointer
+    L = _lib.lib()
+    g, vecs = build_graph(400, 16, 5, 200, seed=73)           # ef_construction 200: what ndb_hnswinsert uses
+    ix, a = load(g)
+    # model = the oracle over what the loaded (packed) mirror holds
+    e = ix.export()
+    model = ndbo.HnswGraph.from_arrays(a["vecs"], e["levels"], e["ncount"], e["nbrs"], a["tids"], e["entry_point"],
+                                       e["entry_level"], 5, 200, cap_nodes=500)
+    rng = np.random.default_rng(74)
+    more = rng.standard_normal((30, 16)).astype(np.float32)
+    for i in range(30):
+        lv = L.ndb_hnsw_level_from_uniform(float(rng.uniform(1e-9, 1.0)), np.float32(0.36))
+        t = ndbo.tids_from_rows(np.array([400 + i]))[0]
+        tid = NdbItemPointer(int(t["bi_hi"]), int(t["bi_lo"]), int(t["posid"]))
+        assert L.ndb_hnswinsert(ix._h, vector_datum(more[i]), 8 + 4 * 16, VECTOR, C.byref(tid), lv) == 1
+        model.insert(more[i], 400 + i, lv)
+    q = rng.standard_normal((8, 16)).astype(np.float32)
+    from tests.test_gpu_hnsw import check
+    ix.nblocks = 431
+    for strategy in (1, 2):
+        check(model, ix, q, strategy, 32, 10)
+
+    def cb(ip, state):
+        return 1 if ip.contents.posid % 9 == 0 else 0
+    removed = C.c_int64(0)
+    _lib.check(L.ndb_hnswbulkdelete(ix._h, BULKDELETE_CALLBACK(cb), None, C.byref(removed)))
+    b = model.arrays()
+    victims = np.array([t for t in ndbo.tids_from_rows(np.arange(430)) if t["posid"] % 9 == 0])
+    assert model.bulkdelete(victims) == removed.value > 0
+    for strategy in (1, 3):
+        check(model, ix, q, strategy, 32, 10)
+    _lib.check(L.ndb_hnswbulkdelete(ix._h, BULKDELETE_CALLBACK(cb), None, C.byref(removed)))
+    assert removed.value == 0                                 # dead line pointers are not offered again
