@@ -260,6 +260,9 @@ int			ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int ma
 /* Nearest centroid by sqrtf(fp32 L2), strict <, first wins (:915-934). */
 int			ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim,
 									 const float *d_rows, int64_t nrows, int *d_out_list);
+/* The same from host memory (rows in heap order, heapPtrs 6 bytes each): staged by the library. */
+int			ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_t nrows, int max_iter,
+							 int *out_iters);
 /* Whole build in HBM: sample first min(10000, 100*nlists) rows, k-means,
  * assign all nrows, pack lists in insertion (heap) order, adopt into ix. */
 int			ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids,

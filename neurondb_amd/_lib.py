@@ -164,6 +164,7 @@ def lib():
         "ndb_hnsw_level_from_uniform": (i, [C.c_double, C.c_float]),
         "ndb_ivfbulkdelete": (i, [vp, BULKDELETE_CALLBACK, vp, C.POINTER(i64)]),
         "ndb_hnswbulkdelete": (i, [vp, BULKDELETE_CALLBACK, vp, C.POINTER(i64)]),
+        "ndbhip_ivf_build": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
         "ndbhip_ivf_insert": (i, [vp, vp, vp, C.POINTER(i)]),
         "ndbhip_hnsw_insert": (i, [vp, vp, vp, C.c_uint32, vp, i]),
     }

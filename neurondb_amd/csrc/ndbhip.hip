@@ -3636,6 +3636,34 @@ k_pack_scatter(const int *__restrict__ lists, int64_t nrows, int dim, uint32_t n
 	}
 }
 
+extern "C" int ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
+									   int max_iter, int *out_iters);
+
+/* ivfbuild (src/index/ivf_am.c:501-745) for host rows in heap order: staged H2D, then ndbhip_ivf_build_device */
+extern "C" int
+ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_t nrows, int max_iter, int *out_iters)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !rows || !tids6 || nrows < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_rows = nullptr;
+	uint64_t   *d_tids = nullptr;
+	std::vector<uint64_t> t64((size_t) nrows);
+
+	for (int64_t i = 0; i < nrows; i++)
+		t64[(size_t) i] = ndb_tid_pack(tids6 + (size_t) i * 6);
+	HIP_TRY(hipMalloc((void **) &d_rows, (size_t) nrows * ix->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_tids, (size_t) nrows * sizeof(uint64_t)));
+	HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t) nrows * ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_tids, t64.data(), (size_t) nrows * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	const int	rc = ndbhip_ivf_build_device(ix, d_rows, d_tids, nrows, max_iter, out_iters);
+
+	(void) hipStreamSynchronize(g.stream);
+	(void) hipFree(d_rows);
+	(void) hipFree(d_tids);
+	return rc;
+}
+
 extern "C" int
 ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
 						int max_iter, int *out_iters)

@@ -130,3 +130,25 @@ def test_append_keeps_lists_in_insertion_order_and_matches_oracle():
     assert np.array_equal(ll, np.diff(off))
     assert np.array_equal(rows.view(np.uint32), img.vecs.view(np.uint32))
     assert np.array_equal(ndbo.tids_to_u64(tt), ndbo.tids_to_u64(img.tids))
+
+
+def test_host_pointer_build_is_the_device_build():
+    """ndbhip_ivf_build (rows and heapPtrs in host memory, staged by the library) == the oracle's build:
+    what an ambuild written in C calls, with no device allocation of its own."""
+    import ctypes as C
+    from neurondb_amd import IvfIndex, _lib
+    rng = np.random.default_rng(3)
+    n, dim, nlists = 4000, 48, 16
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    img, asg, iters = ndbo.build_ivf_image(base, nlists, max_iter=50)
+    ix = IvfIndex(dim, nlists)
+    t6 = np.ascontiguousarray(ndbo.tids_from_rows(np.arange(n))).view(np.uint8).reshape(-1, 6)
+    it = C.c_int()
+    _lib.check(_lib.lib().ndbhip_ivf_build(ix._h, base.ctypes.data, t6.ctypes.data, n, 50, C.byref(it)))
+    ix.ncent = nlists
+    cent, ll, rows, tids = ix.export()
+    assert it.value == iters
+    assert np.array_equal(cent.view(np.uint32), img.centroids.view(np.uint32))
+    assert np.array_equal(ll, np.diff(img.list_off))
+    assert np.array_equal(ndbo.tids_to_u64(tids), ndbo.tids_to_u64(img.tids))
+    assert np.array_equal(rows.view(np.uint32), img.vecs.view(np.uint32))
