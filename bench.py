@@ -211,8 +211,9 @@ def main():
     ms_per_launch = st["scan_kernel_ms"] / launches
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     # every scored (row element, query) pair costs one subtract, one multiply, one add, unfused
-    # (inner product: multiply + add; cosine: two of those — the query's norm is computed once)
-    flops_per_launch = {"l2": 3.0, "ip": 2.0, "cosine": 4.0}[args.strategy] * bytes_per_launch / esz
+    # (inner product: multiply + add; cosine: the same plus the row's own norm chain, shared by the 16 queries
+    # of a group — the query's norm is computed once per query)
+    flops_per_launch = {"l2": 3.0, "ip": 2.0, "cosine": 2.0 + 2.0 / 16.0}[args.strategy] * bytes_per_launch / esz
     valu_tflops = flops_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -1142,16 +1142,29 @@ template <> struct GAcc<R_IVF_L2>
 	{
 		const ndb_f2 xx = (ndb_f2) (x);
 
+		/* four pairs at a time, phase by phase: a packed multiply must not be followed directly by the add
+		 * that consumes it (one wait state on gfx950), and with a single temporary hipcc pads every such
+		 * pair with s_nop (406 per 768 packed ops in the chunk loop) */
 #pragma unroll
-		for (int i = 0; i < NDB_QG / 2; i++)
+		for (int i0 = 0; i0 < NDB_QG / 2; i0 += 4)
 		{
-			ndb_f2		qp;
+			ndb_f2		d[4];
 
-			qp.x = q[2 * i];
-			qp.y = q[2 * i + 1];
-			const ndb_f2 d = qp - xx;
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				ndb_f2		qp;
 
-			s[i] = s[i] + d * d;
+				qp.x = q[2 * (i0 + u)];
+				qp.y = q[2 * (i0 + u) + 1];
+				d[u] = qp - xx;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				d[u] = d[u] * d[u];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				s[i0 + u] = s[i0 + u] + d[u];
 		}
 	}
 	__device__ __forceinline__ float fin(int j, float) const
@@ -1174,13 +1187,22 @@ template <> struct GAcc<R_IVF_IP>
 		const ndb_f2 xx = (ndb_f2) (x);
 
 #pragma unroll
-		for (int i = 0; i < NDB_QG / 2; i++)
+		for (int i0 = 0; i0 < NDB_QG / 2; i0 += 4)	/* products first, sums after: see GAcc<R_IVF_L2>::step */
 		{
-			ndb_f2		qp;
+			ndb_f2		d[4];
 
-			qp.x = q[2 * i];
-			qp.y = q[2 * i + 1];
-			s[i] = s[i] + qp * xx;
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				ndb_f2		qp;
+
+				qp.x = q[2 * (i0 + u)];
+				qp.y = q[2 * (i0 + u) + 1];
+				d[u] = qp * xx;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				s[i0 + u] = s[i0 + u] + d[u];
 		}
 	}
 	__device__ __forceinline__ float fin(int j, float) const
@@ -1208,13 +1230,22 @@ template <> struct GAcc<R_IVF_COS>
 		const ndb_f2 xx = (ndb_f2) (x);
 
 #pragma unroll
-		for (int i = 0; i < NDB_QG / 2; i++)
+		for (int i0 = 0; i0 < NDB_QG / 2; i0 += 4)	/* products first, sums after: see GAcc<R_IVF_L2>::step */
 		{
-			ndb_f2		qp;
+			ndb_f2		d[4];
 
-			qp.x = q[2 * i];
-			qp.y = q[2 * i + 1];
-			s[i] = s[i] + qp * xx;
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				ndb_f2		qp;
+
+				qp.x = q[2 * (i0 + u)];
+				qp.y = q[2 * (i0 + u) + 1];
+				d[u] = qp * xx;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				s[i0 + u] = s[i0 + u] + d[u];
 		}
 		n2 = n2 + x * x;
 	}
