@@ -21,6 +21,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/ndbhip.h"
 #include "ndbhip_kernels.h"
@@ -1102,6 +1103,18 @@ k_group_pack(const float *__restrict__ queries, int dim, int ncent, const uint32
 		dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
+/* compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) */
+template <int B, int E, class F>
+__device__ __forceinline__ void
+ndb_static_for(F &&f)
+{
+	if constexpr (B < E)
+	{
+		f(std::integral_constant<int, B>{});
+		ndb_static_for<B + 1, E>(f);
+	}
+}
+
 typedef float ndb_f2 __attribute__((ext_vector_type(2)));
 typedef float ndb_f16 __attribute__((ext_vector_type(16)));
 
@@ -1118,6 +1131,16 @@ sload2x16(ndb_f16 &a, ndb_f16 &b, const float *p)
 {
 	asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
 				 : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+
+/* the same at a compile-time byte offset from one base pointer: no per-batch address arithmetic (hipcc
+ * materialised, and then spilled to VGPR lanes, a 64-bit address per batch) */
+template <int OFF>
+__device__ __forceinline__ void
+sload2x16_at(ndb_f16 &a, ndb_f16 &b, const float *base)
+{
+	asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"
+				 : "=&s"(a), "=&s"(b) : "s"(base), "n"(OFF), "n"(OFF + 64) : "memory");
 }
 
 __device__ __forceinline__ void
@@ -1383,21 +1406,28 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 			float4		x[CH / 4];
 
 			stage_chunk_w<CH>(x, ix.vecs, rowsN, dim, c, tile, lane);
-#pragma unroll
-			for (int p = 0; p < CH / 4; p++)
-			{
+			/* the chunk's query values sit at fixed byte offsets from qs (16 queries x 4 B = 64 B per
+			 * dimension); the batch issued last belongs to the next chunk — on the last chunk it re-reads
+			 * this group's final 128 B instead of running past the block */
+			const float *qnext = (c + CH >= dim) ? qs - 2 * NDB_QG : qs;
+
+			ndb_static_for<0, CH / 4>([&](auto pc) {
+				constexpr int p = decltype(pc)::value;
+
 				/* dims 4p, 4p+1 from A; 4p+2, 4p+3 from B */
 				swait2(qa0, qa1);
-				sload2x16(qb0, qb1, qs + 2 * NDB_QG);
+				sload2x16_at<(4 * p + 2) * 64>(qb0, qb1, qs);
 				acc.step(qa0, x[p].x);
 				acc.step(qa1, x[p].y);
 				swait2(qb0, qb1);
-				qs += 4 * NDB_QG;
-				/* the last batch of the last chunk re-reads the final 128 B of this group's block */
-				sload2x16(qa0, qa1, (c + CH >= dim && p == CH / 4 - 1) ? qs - 2 * NDB_QG : qs);
+				if constexpr (p == CH / 4 - 1)
+					sload2x16_at<CH * 64>(qa0, qa1, qnext);
+				else
+					sload2x16_at<(4 * p + 4) * 64>(qa0, qa1, qs);
 				acc.step(qb0, x[p].z);
 				acc.step(qb1, x[p].w);
-			}
+			});
+			qs += CH * NDB_QG;
 		}
 		}
 		swait2(qa0, qa1);
@@ -3177,19 +3207,24 @@ k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const 
 		float4		x[CH / 4];
 
 		stage_chunk_w<CH>(x, rows, rowsN, dim, c, tile, lane);
-#pragma unroll
-		for (int p = 0; p < CH / 4; p++)
-		{
+		const float *qnext = (c + CH >= dim) ? qs - 2 * NDB_QG : qs;
+
+		ndb_static_for<0, CH / 4>([&](auto pc) {
+			constexpr int p = decltype(pc)::value;
+
 			swait2(qa0, qa1);
-			sload2x16(qb0, qb1, qs + 2 * NDB_QG);
+			sload2x16_at<(4 * p + 2) * 64>(qb0, qb1, qs);
 			acc.step(qa0, x[p].x);
 			acc.step(qa1, x[p].y);
 			swait2(qb0, qb1);
-			qs += 4 * NDB_QG;
-			sload2x16(qa0, qa1, (c + CH >= dim && p == CH / 4 - 1) ? qs - 2 * NDB_QG : qs);
+			if constexpr (p == CH / 4 - 1)
+				sload2x16_at<CH * 64>(qa0, qa1, qnext);
+			else
+				sload2x16_at<(4 * p + 4) * 64>(qa0, qa1, qs);
 			acc.step(qb0, x[p].z);
 			acc.step(qb1, x[p].w);
-		}
+		});
+		qs += CH * NDB_QG;
 	}
 	swait2(qa0, qa1);
 	float		best = FLT_MAX;
