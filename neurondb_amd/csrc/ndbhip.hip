@@ -1373,30 +1373,34 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				float4		raw[8];
 
 				stage_chunk_w<32>(raw, ix.vecs, rowsN, dim >> 1, c >> 1, tile, lane);
-#pragma unroll
-				for (int p = 0; p < 8; p++)
-				{
+				const float *qnext = (c + 64 >= dim) ? qs - 2 * NDB_QG : qs;
+
+				ndb_static_for<0, 8>([&](auto pc) {
+					constexpr int p = decltype(pc)::value;
 					float		x[8];
 
 					decode8(raw[p], x);
 					swait2(qa0, qa1);
-					sload2x16(qb0, qb1, qs + 2 * NDB_QG);
+					sload2x16_at<(8 * p + 2) * 64>(qb0, qb1, qs);
 					acc.step(qa0, x[0]);
 					acc.step(qa1, x[1]);
 					swait2(qb0, qb1);
-					sload2x16(qa0, qa1, qs + 4 * NDB_QG);
+					sload2x16_at<(8 * p + 4) * 64>(qa0, qa1, qs);
 					acc.step(qb0, x[2]);
 					acc.step(qb1, x[3]);
 					swait2(qa0, qa1);
-					sload2x16(qb0, qb1, qs + 6 * NDB_QG);
+					sload2x16_at<(8 * p + 6) * 64>(qb0, qb1, qs);
 					acc.step(qa0, x[4]);
 					acc.step(qa1, x[5]);
 					swait2(qb0, qb1);
-					qs += 8 * NDB_QG;
-					sload2x16(qa0, qa1, (c + 64 >= dim && p == 7) ? qs - 2 * NDB_QG : qs);
+					if constexpr (p == 7)
+						sload2x16_at<64 * 64>(qa0, qa1, qnext);
+					else
+						sload2x16_at<(8 * p + 8) * 64>(qa0, qa1, qs);
 					acc.step(qb0, x[6]);
 					acc.step(qb1, x[7]);
-				}
+				});
+				qs += 64 * NDB_QG;
 			}
 		}
 		else
