@@ -323,6 +323,11 @@ int			ndbhip_hnsw_delete(ndbhip_hnsw *g, const uint8_t *tids6, int64_t n, int64_
  * levels [nblocks], ncount [nblocks*16], nbrs [nblocks*16*2m]. */
 int			ndbhip_hnsw_export(const ndbhip_hnsw *g, uint32_t *nblocks, int32_t *levels, int16_t *ncount,
 							   uint32_t *nbrs, uint32_t *entry_point, int *entry_level);
+/* Which hnswSearch kernel serves queries: 0 auto (block-cooperative when dim % 4 == 0), 1 one wave per query
+ * scoring every row in the reference's own summation order, 2 block-cooperative (one 256-thread block per
+ * query; partial sums accepted only when the float4 result is provably the sequential one, else redone in
+ * order).  Both return the same bits. */
+int			ndbhip_hnsw_set_search_mode(int mode);
 /* hnswSearch for nq queries: strategy in {1,2,3}; ef = neurondb.hnsw_ef_search;
  * k = neurondb.hnsw_k.  out_blocks/out_dist [nq*k]; out_tids6 nullable
  * (hnswgettuple's node->heapPtr lookup, :1009-1053); out_scored nullable

@@ -142,6 +142,7 @@ def lib():
         "ndbhip_hnsw_insert_device": (i, [vp, vp, vp, C.c_uint32, vp, i]),
         "ndbhip_hnsw_delete": (i, [vp, vp, i64, C.POINTER(i64)]),
         "ndbhip_hnsw_build_stats": (i, [vp, vp]),
+        "ndbhip_hnsw_set_search_mode": (i, [i]),
         "ndbhip_hnsw_set_build_mode": (i, [i, i, i]),
         "ndbhip_hnsw_export": (i, [vp, C.POINTER(C.c_uint32), vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(i)]),
         "ndbhip_hnsw_search": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),

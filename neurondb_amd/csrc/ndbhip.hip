@@ -63,6 +63,7 @@ static int	g_scan_mode = 0;
 static int	g_gchunk = 32;
 /* hnswbuild: 0 the one-wave sequential kernel, 1 optimistic batches with the chunked block-wide commit,
  * 2 optimistic batches with the one-wave commit; batch = min(max, nodes so far / div) walks */
+static int	g_hnsw_search_mode = 0;
 static int	g_hnsw_spec = 1;
 static int	g_hnsw_batch_div = 64;
 static int	g_hnsw_batch_max = 1024;
@@ -4083,21 +4084,21 @@ hnsw_vslots(uint32_t ef, uint32_t m)
 }
 
 __host__ __device__ static inline size_t
-hnsw_smem_bytes(uint32_t ef, uint32_t k, uint32_t m)
+hnsw_smem_bytes(uint32_t ef, uint32_t k, uint32_t m, size_t tile_bytes = (size_t) NDB_TILE_FLOATS * 4)
 {
 	const uint32_t npad = next_pow2(ef < 4 ? 4 : ef);
 
-	return (size_t) NDB_TILE_FLOATS * 4 + (size_t) ef * (4 + 4 + 4 + 8) + (size_t) hnsw_vslots(ef, m) * 4 +
+	return tile_bytes + (size_t) ef * (4 + 4 + 4 + 8) + (size_t) hnsw_vslots(ef, m) * 4 +
 		(size_t) npad * (8 + 4 + 4 + 1) + (size_t) k * 4 + 128;
 }
 
 __device__ static inline HnswLds
-carve_hnsw_lds(unsigned char *sp, uint32_t ef, uint32_t k, uint32_t m)
+carve_hnsw_lds(unsigned char *sp, uint32_t ef, uint32_t k, uint32_t m, size_t tile_bytes = (size_t) NDB_TILE_FLOATS * 4)
 {
 	HnswLds		L;
 
 	L.npad = next_pow2(ef < 4 ? 4 : ef);
-	L.tile = (float *) sp;				sp += (size_t) NDB_TILE_FLOATS * 4;
+	L.tile = (float *) sp;				sp += tile_bytes;	/* staging tile, or the block-cooperative scorer's region */
 	L.e_id = (uint64_t *) sp;			sp += (size_t) ef * 8;
 	L.fs.comp = (uint64_t *) sp;		sp += (size_t) L.npad * 8;
 	L.cand = (uint32_t *) sp;			sp += (size_t) ef * 4;
@@ -4122,47 +4123,66 @@ carve_hnsw_lds(unsigned char *sp, uint32_t ef, uint32_t k, uint32_t m)
  * L.cdist.  Returns false when the reference returns "no results" before level 0.
  */
 /*
- * Build-time scorer: the 64 lanes of the walking wave each hold (at most) one row to score; the whole
- * 256-thread block scores them together, K = 4..16 threads per row, thread `part` summing the float4
- * pieces part, part + K, ... of (double)(q - x)^2 in fp64 (a row's K threads read K consecutive float4 =
- * one coalesced line per step, and all of a thread's loads are in flight at once: the walk is a chain of
- * dependent fetches, so latency is what it costs).
+ * Block-cooperative scorer: the 64 lanes of the walking wave each hold (at most) one row to score; the
+ * whole 256-thread block scores them together, K = 4..KMAX threads per row, thread `part` summing the float4
+ * pieces part, part + K, ... in fp64 (a row's K threads read K consecutive float4 = one coalesced line per
+ * step, and all of a thread's loads are in flight at once: the walk is a chain of dependent fetches, so
+ * latency is what it costs).
  *
- * That is NOT the reference's summation order, so the result is only accepted when it provably cannot
- * matter: every term is >= 0, hence any order of fp64 summation lies within n*u of the exact sum
- * (u = 2^-53), so the sequential sum s* lies in [s(1-eps), s(1+eps)] with eps = 3*dim*u; sqrt and the
- * narrowing to float are correctly rounded, hence monotone, so if (float)sqrt(s(1-eps)) ==
- * (float)sqrt(s(1+eps)) that IS (float)sqrt(s*), bit for bit.  Otherwise (about 2e-6 of the rows) the
- * lane redoes its row in the reference's order.
+ * That is NOT the reference's summation order, so a result is only accepted when it provably cannot matter.
+ * Every term is what the reference adds ((double)(q-x) squared; the fp32 product q*x widened), so:
+ *   sums of terms >= 0 (L2's sum, cosine's row norm): any fp64 summation order lies within n*u of the exact
+ *     sum (u = 2^-53), hence the reference's sequential sum s* is in [s(1-eps), s(1+eps)], eps = 3*dim*u;
+ *   signed sums (the dot product): |s - s*| <= E = 3*dim*u*A with A = the sum of |terms|, accumulated
+ *     beside it;
+ *   the query's own norm (cosine) is computed ONCE per walk in the reference's order: exact.
+ * sqrt, *, /, 1 - x and the narrowing to float are correctly rounded, hence monotone in each argument; the
+ * distance is therefore bracketed by its values at the interval end points, and when those agree as floats
+ * that float IS the reference's result, bit for bit.  Otherwise (1e-6 .. 1e-5 of the rows) the lane redoes
+ * its row in the reference's order.  Zero norms are exact either way (a sum of squares is 0 iff every term is).
  */
+#define NDB_HNSW_FAST_MAX_DIM 1920	/* build: partial sums + rows + ctl + q must fit the 16 KiB tile region */
+
 struct HnswFast
 {
-	float	   *q;				/* [dim] the inserted vector, in LDS */
+	float	   *q;				/* [dim] the query / inserted vector, in LDS */
 	uint32_t   *rows;			/* [64] compacted rows to score */
 	uint32_t   *ctl;			/* [0] 1 = score, 0 = helpers may leave; [1] rows to score */
-	double	   *part;			/* [64 * 16] partial sums */
+	double	   *part;			/* [nacc][64 * KMAX] partial sums */
+	double		qnorm;			/* cosine: the query's sum of squares, reference order */
 };
 
-#define NDB_HNSW_FAST_MAX_DIM 1920	/* q + rows + ctl + part must fit the 16 KiB tile region */
+template <int R> struct FastAcc;
+template <> struct FastAcc<R_HNSW_L2> { static constexpr int N = 1; };
+template <> struct FastAcc<R_HNSW_IP> { static constexpr int N = 2; };	/* dot, sum |terms| */
+template <> struct FastAcc<R_HNSW_COS> { static constexpr int N = 3; };	/* dot, sum |terms|, row norm */
+
+__host__ __device__ static inline size_t
+hnsw_fast_bytes(int nacc, int kmax, int dim)
+{
+	return (size_t) nacc * 64 * kmax * 8 + 64 * 4 + 16 + (((size_t) dim * 4 + 15) & ~(size_t) 15);
+}
 
 __device__ __forceinline__ HnswFast
-carve_hnsw_fast(float *tile, int dim)
+carve_hnsw_fast(void *base, int nacc, int kmax, int dim)
 {
 	HnswFast	F;
 
-	F.part = (double *) tile;					/* 8 KiB */
-	F.rows = (uint32_t *) (tile + 2048);
+	F.part = (double *) base;
+	F.rows = (uint32_t *) (F.part + (size_t) nacc * 64 * kmax);
 	F.ctl = F.rows + 64;
-	F.q = (float *) (F.ctl + 4);				/* 16-byte aligned: 8192 + 256 + 16 */
+	F.q = (float *) (F.ctl + 4);	/* 16-byte aligned */
+	F.qnorm = 0.0;
 	return F;
 }
 
+template <int R, int KMAX>
 __device__ __forceinline__ void
 hnsw_fast_part(const float *__restrict__ vecs, int dim, const HnswFast &F)
 {
 	const uint32_t na = F.ctl[1];
 	const uint32_t r2 = next_pow2(na);
-	const uint32_t K = (256u / r2) > 16u ? 16u : (256u / r2);	/* a power of two, 4..16 */
+	const uint32_t K = (256u / r2) > (uint32_t) KMAX ? (uint32_t) KMAX : (256u / r2);	/* a power of two >= 4 */
 	const uint32_t part = threadIdx.x & (K - 1u);
 	const uint32_t slot = threadIdx.x / K;
 
@@ -4171,8 +4191,25 @@ hnsw_fast_part(const float *__restrict__ vecs, int dim, const HnswFast &F)
 	const float4 *x = reinterpret_cast<const float4 *>(vecs + (size_t) F.rows[slot] * dim);
 	const float4 *q4 = reinterpret_cast<const float4 *>(F.q);
 	const int	nf4 = dim >> 2;
-	Acc<R_HNSW_L2> a;
+	double		s0 = 0.0, s1 = 0.0, s2 = 0.0;
 	constexpr int U = 12;
+	auto		term = [&](float qv, float xv) {
+		if (R == R_HNSW_L2)
+		{
+			const double d = (double) (qv - xv);
+
+			s0 = s0 + d * d;
+		}
+		else
+		{
+			const double t = (double) (qv * xv);	/* fp32 product, widened: hnsw_am.c:1322-1326 */
+
+			s0 = s0 + t;
+			s1 = s1 + __builtin_fabs(t);
+			if (R == R_HNSW_COS)
+				s2 = s2 + (double) (xv * xv);
+		}
+	};
 
 	for (int f0 = (int) part; f0 < nf4; f0 += U * (int) K)
 	{
@@ -4195,17 +4232,24 @@ hnsw_fast_part(const float *__restrict__ vecs, int dim, const HnswFast &F)
 			{
 				const float4 qq = q4[f];
 
-				a.step(qq.x, buf[u].x);
-				a.step(qq.y, buf[u].y);
-				a.step(qq.z, buf[u].z);
-				a.step(qq.w, buf[u].w);
+				term(qq.x, buf[u].x);
+				term(qq.y, buf[u].y);
+				term(qq.z, buf[u].z);
+				term(qq.w, buf[u].w);
 			}
 		}
 	}
-	F.part[slot * 16u + part] = a.s;
+	const uint32_t o = slot * (uint32_t) KMAX + part;
+
+	F.part[o] = s0;
+	if (R != R_HNSW_L2)
+		F.part[64u * KMAX + o] = s1;
+	if (R == R_HNSW_COS)
+		F.part[2u * 64u * KMAX + o] = s2;
 }
 
-/* helper waves of a build walk: score on demand until released */
+/* helper waves of a walk: score on demand until released */
+template <int R, int KMAX>
 __device__ void
 hnsw_fast_helper(const float *__restrict__ vecs, int dim, const HnswFast &F)
 {
@@ -4214,12 +4258,13 @@ hnsw_fast_helper(const float *__restrict__ vecs, int dim, const HnswFast &F)
 		__syncthreads();
 		if (F.ctl[0] == 0u)
 			return;
-		hnsw_fast_part(vecs, dim, F);
+		hnsw_fast_part<R, KMAX>(vecs, dim, F);
 		__syncthreads();
 	}
 }
 
-/* the walking wave: this lane's row (if act) -> its float4 L2 distance to the inserted vector */
+/* the walking wave: this lane's row (if act) -> its float4 distance to the query under recipe R */
+template <int R, int KMAX>
 __device__ float
 hnsw_fast_score(const float *__restrict__ vecs, int dim, const HnswFast &F, uint32_t row, bool act)
 {
@@ -4239,29 +4284,70 @@ hnsw_fast_score(const float *__restrict__ vecs, int dim, const HnswFast &F, uint
 		F.ctl[1] = na;
 	}
 	__syncthreads();
-	hnsw_fast_part(vecs, dim, F);
+	hnsw_fast_part<R, KMAX>(vecs, dim, F);
 	__syncthreads();
 	if (act)
 	{
 		const uint32_t r2 = next_pow2(na);
-		const uint32_t K = (256u / r2) > 16u ? 16u : (256u / r2);
-		double		s = 0.0;
+		const uint32_t K = (256u / r2) > (uint32_t) KMAX ? (uint32_t) KMAX : (256u / r2);
+		const double eps = 3.0 * (double) dim * 1.1102230246251565e-16;
+		double		s0 = 0.0, s1 = 0.0, s2 = 0.0;
+		bool		sure;
 
 		for (uint32_t p = 0; p < K; p++)
-			s = s + F.part[slot * 16u + p];
-		const double eps = 3.0 * (double) dim * 1.1102230246251565e-16;
-		const float lo = (float) __builtin_sqrt(s * (1.0 - eps));
-		const float hi = (float) __builtin_sqrt(s * (1.0 + eps));
-
-		r = lo;
-		if (lo != hi)
 		{
-			Acc<R_HNSW_L2> a;
+			s0 = s0 + F.part[slot * KMAX + p];
+			if (R != R_HNSW_L2)
+				s1 = s1 + F.part[64u * KMAX + slot * KMAX + p];
+			if (R == R_HNSW_COS)
+				s2 = s2 + F.part[2u * 64u * KMAX + slot * KMAX + p];
+		}
+		if (R == R_HNSW_L2)
+		{
+			const float lo = (float) __builtin_sqrt(s0 * (1.0 - eps));
+			const float hi = (float) __builtin_sqrt(s0 * (1.0 + eps));
+
+			r = lo;
+			sure = lo == hi;
+		}
+		else if (R == R_HNSW_IP)
+		{
+			const double E = eps * s1;
+			const float lo = (float) (-(s0 + E));
+			const float hi = (float) (-(s0 - E));
+
+			r = lo;
+			sure = lo == hi;
+		}
+		else
+		{
+			if (F.qnorm == 0.0 || s2 == 0.0)	/* :1331-1332, exact */
+			{
+				r = 2.0f;
+				sure = true;
+			}
+			else
+			{
+				const double a = __builtin_sqrt(F.qnorm);
+				const double E = eps * s1;
+				const double blo = __builtin_sqrt(s2 * (1.0 - eps)), bhi = __builtin_sqrt(s2 * (1.0 + eps));
+				const float f0 = (float) (1.0 - ((s0 - E) / (a * blo)));
+				const float f1 = (float) (1.0 - ((s0 - E) / (a * bhi)));
+				const float f2 = (float) (1.0 - ((s0 + E) / (a * blo)));
+				const float f3 = (float) (1.0 - ((s0 + E) / (a * bhi)));
+
+				r = f0;
+				sure = f0 == f1 && f0 == f2 && f0 == f3;
+			}
+		}
+		if (!sure)
+		{
+			Acc<R>		acc;
 			const float *x = vecs + (size_t) row * dim;
 
 			for (int d = 0; d < dim; d++)
-				a.step(F.q[d], x[d]);
-			r = a.fin();
+				acc.step(F.q[d], x[d]);
+			r = acc.fin();
 		}
 	}
 	return r;
@@ -4270,17 +4356,16 @@ hnsw_fast_score(const float *__restrict__ vecs, int dim, const HnswFast &F, uint
 #define NDB_HNSW_RS_CAP 256u		/* read-set entries logged per speculative walk */
 #define NDB_HNSW_RS_NODE_BITS 28
 
-template <int R, bool MUT, bool LOG = false, bool FAST = false>
+template <int R, bool MUT, bool LOG = false, bool FAST = false, int KMAX = 16>
 __device__ bool
 hnsw_walk(const HnswDev &g, const float *__restrict__ q, uint32_t ef, HnswLds &L, uint32_t &cc_out,
 		  long long &scored, uint32_t *__restrict__ rs = nullptr, uint32_t *rs_count = nullptr,
 		  const HnswFast *F = nullptr)
 {
-	static_assert(!FAST || R == R_HNSW_L2, "the block-cooperative scorer is the build's (always L2)");
 	/* this lane's row -> its distance; every lane of the wave calls it together */
 	auto		score = [&](uint32_t row, uint32_t idle_row, bool act) -> float {
 		if (FAST)
-			return hnsw_fast_score(g.vecs, g.dim, *F, row, act);
+			return hnsw_fast_score<R, KMAX>(g.vecs, g.dim, *F, row, act);
 		return score_rows<R>(q, g.vecs, act ? row : idle_row, g.dim, L.tile);
 	};
 	uint32_t	rs_local = 0;
@@ -4569,6 +4654,80 @@ k_hnsw_search(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_
 }
 
 /*
+ * The same search with the block-cooperative scorer: one 256-thread block per query, wave 0 walks, the other
+ * three help it score (hnsw_fast_score<R>).  A walk is a chain of dependent fetches, so what a batch of
+ * queries costs is walks in flight x latency of one: spreading a neighbour list's rows over the block takes
+ * the fetch from 12 staged chunks to one round trip.  dim % 4 == 0.
+ */
+#define NDB_HNSW_SEARCH_KMAX 8
+template <int R>
+__global__ __launch_bounds__(256) void
+k_hnsw_search_fast(HnswDev g, const float *__restrict__ queries, uint32_t ef, uint32_t k,
+				   uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
+				   uint64_t *__restrict__ out_tids, long long *__restrict__ out_scored)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	constexpr int NACC = FastAcc<R>::N;
+	HnswLds		L = carve_hnsw_lds(smem_raw, ef, k, (uint32_t) g.m, hnsw_fast_bytes(NACC, NDB_HNSW_SEARCH_KMAX, g.dim));
+	HnswFast	F = carve_hnsw_fast(L.tile, NACC, NDB_HNSW_SEARCH_KMAX, g.dim);
+	const uint32_t qi = blockIdx.x;
+	const float *q = queries + (size_t) qi * g.dim;
+	long long	scored = 0;
+	uint32_t	cc = 0;
+	bool		ok = false;
+
+	for (int d = threadIdx.x; d < g.dim; d += 256)
+		F.q[d] = q[d];
+	if (threadIdx.x == 0)
+		F.ctl[0] = 1u;
+	__syncthreads();
+	if (R == R_HNSW_COS && threadIdx.x < 64)
+	{
+		/* norm1 in the reference's order (hnsw_am.c:1322-1326): one chain, once per query; every lane of
+		 * the walking wave computes it (LDS broadcast reads) so that no exchange is needed */
+		double		n1 = 0.0;
+
+		for (int d = 0; d < g.dim; d++)
+			n1 = n1 + (double) (F.q[d] * F.q[d]);
+		F.qnorm = n1;
+	}
+	if (threadIdx.x >= 64)
+		hnsw_fast_helper<R, NDB_HNSW_SEARCH_KMAX>(g.vecs, g.dim, F);
+	else
+	{
+		ok = hnsw_walk<R, false, false, true, NDB_HNSW_SEARCH_KMAX>(g, q, ef, L, cc, scored, nullptr, nullptr, &F);
+		if (threadIdx.x == 0)
+		{
+			F.ctl[0] = 0u;
+			F.ctl[2] = ok ? 1u : 0u;
+			F.ctl[3] = cc;
+		}
+		__syncthreads();		/* releases the helpers */
+	}
+	ok = F.ctl[2] != 0u;
+	cc = F.ctl[3];
+	uint32_t	kk = 0;
+
+	if (ok)
+	{
+		kk = hnsw_topk(L, cc, k, out_dist + (size_t) qi * k);
+		for (uint32_t i2 = threadIdx.x; i2 < kk; i2 += 256)
+		{
+			const uint32_t b = L.cand[L.fs.perm[L.fs.order[i2]]];
+
+			out_blocks[(size_t) qi * k + i2] = b;
+			if (out_tids)
+				out_tids[(size_t) qi * k + i2] = g.tids[b];
+		}
+	}
+	if (threadIdx.x == 0)
+	{
+		out_count[qi] = (int) kk;
+		if (out_scored) out_scored[qi] = scored;
+	}
+}
+
+/*
  * hnswbuild (hnsw_am.c:343-415) = hnswInsertNode for every heap row in order (:2091-2670).  The inserts
  * depend on each other (each one searches the graph the previous ones left), so ONE wave walks them in
  * order inside ONE launch; the graph lives in the dense 16-level layout so that the reference's writes
@@ -4815,7 +4974,7 @@ k_hnsw_spec(HnswDev g, const float *__restrict__ rows, const HnswTask *__restric
 	HnswLds		L = carve_hnsw_lds(smem_raw, efc, efc, (uint32_t) g.m);
 	const HnswTask task = tasks[t];
 	const float *q = rows + (size_t) (task.row - base) * g.dim;	/* rows[] holds the new rows only */
-	HnswFast	F = carve_hnsw_fast(L.tile, g.dim);
+	HnswFast	F = carve_hnsw_fast(L.tile, 1, 16, g.dim);	/* 8 KiB of partial sums + the row, inside the tile region */
 
 	if (FAST)
 	{
@@ -4831,7 +4990,7 @@ k_hnsw_spec(HnswDev g, const float *__restrict__ rows, const HnswTask *__restric
 
 	g.nblocks = task.row + 2;	/* the relation ends at this row's own page */
 	if (FAST && threadIdx.x >= 64)
-		hnsw_fast_helper(g.vecs, g.dim, F);
+		hnsw_fast_helper<R_HNSW_L2, 16>(g.vecs, g.dim, F);
 	else
 	{
 		ok = hnsw_walk<R_HNSW_L2, false, true, FAST>(g, q, efc, L, cc, scored,
@@ -5406,6 +5565,9 @@ set_kernel_attributes_hnsw()
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_COS>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search<R_HNSW_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search_fast<R_HNSW_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search_fast<R_HNSW_COS>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_search_fast<R_HNSW_IP>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_build, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_spec<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_spec<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NDB_TOPK_MAX_SMEM));
@@ -5840,6 +6002,15 @@ ndbhip_hnsw_insert(ndbhip_hnsw *h, const float *rows, const uint8_t *tids6, uint
 }
 
 extern "C" int
+ndbhip_hnsw_set_search_mode(int mode)
+{
+	if (mode < 0 || mode > 2)
+		return fail(NDBHIP_ERR_INVALID, "search mode must be 0 (auto), 1 (one wave per query) or 2 (block-cooperative)");
+	g_hnsw_search_mode = mode;
+	return NDBHIP_OK;
+}
+
+extern "C" int
 ndbhip_hnsw_set_build_mode(int optimistic, int batch_div, int batch_max)
 {
 	if (batch_div < 1 || batch_max < 1 || batch_max > 65535)
@@ -6234,31 +6405,38 @@ ndbhip_hnsw_search_device(ndbhip_hnsw *h, const float *d_queries, int nq, int st
 	d.nbrs = h->d_nbrs; d.tids = h->d_tids; d.nblocks = h->nblocks; d.dim = h->dim; d.m = h->m;
 	d.dense_stride = h->dense ? (int64_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m : 0;
 	d.entry_point = h->entry_point; d.entry_level = h->entry_level;
-	const size_t smem = hnsw_smem_bytes((uint32_t) ef, (uint32_t) k, (uint32_t) h->m);
+	const int	nacc = strategy == 1 ? FastAcc<R_HNSW_L2>::N : (strategy == 2 ? FastAcc<R_HNSW_COS>::N : FastAcc<R_HNSW_IP>::N);
+	const size_t smem_fast = hnsw_smem_bytes((uint32_t) ef, (uint32_t) k, (uint32_t) h->m,
+											 hnsw_fast_bytes(nacc, NDB_HNSW_SEARCH_KMAX, h->dim));
+	/* g_hnsw_search_mode: 0 auto, 1 one wave per query (the literal per-lane recipe), 2 block-cooperative */
+	const bool	fast = (h->dim % 4) == 0 && smem_fast <= NDB_TOPK_MAX_SMEM && g_hnsw_search_mode != 1;
+	const size_t smem = fast ? smem_fast : hnsw_smem_bytes((uint32_t) ef, (uint32_t) k, (uint32_t) h->m);
 
+	if (g_hnsw_search_mode == 2 && !fast)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "the block-cooperative search needs dim %% 4 == 0 and an LDS-resident state");
 	if (smem > NDB_TOPK_MAX_SMEM)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "ef/k too large for the LDS-resident candidate set");
 	ScanTimer	t;
 
 	if (t.start()) return NDBHIP_ERR_HIP;
+#define LAUNCH_HNSW_SEARCH(RR)                                                                                       \
+	do {                                                                                                             \
+		if (fast)                                                                                                    \
+			hipLaunchKernelGGL(k_hnsw_search_fast<RR>, dim3(nq), dim3(256), smem, g.stream, d, d_queries,            \
+							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,         \
+							   (long long *) d_out_scored);                                                          \
+		else                                                                                                         \
+			hipLaunchKernelGGL(k_hnsw_search<RR>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,                  \
+							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,         \
+							   (long long *) d_out_scored);                                                          \
+	} while (0)
 	switch (strategy)
 	{
-		case 1:
-			hipLaunchKernelGGL(k_hnsw_search<R_HNSW_L2>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,
-							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,
-							   (long long *) d_out_scored);
-			break;
-		case 2:
-			hipLaunchKernelGGL(k_hnsw_search<R_HNSW_COS>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,
-							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,
-							   (long long *) d_out_scored);
-			break;
-		default:
-			hipLaunchKernelGGL(k_hnsw_search<R_HNSW_IP>, dim3(nq), dim3(64), smem, g.stream, d, d_queries,
-							   (uint32_t) ef, (uint32_t) k, d_out_blocks, d_out_dist, d_out_count, d_out_tids,
-							   (long long *) d_out_scored);
-			break;
+		case 1: LAUNCH_HNSW_SEARCH(R_HNSW_L2); break;
+		case 2: LAUNCH_HNSW_SEARCH(R_HNSW_COS); break;
+		default: LAUNCH_HNSW_SEARCH(R_HNSW_IP); break;
 	}
+#undef LAUNCH_HNSW_SEARCH
 	if (t.stop()) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipGetLastError());
 	g.stats.queries += (uint64_t) nq;

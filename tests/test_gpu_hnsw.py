@@ -34,13 +34,22 @@ def load(g):
 
 
 def check(g, ix, queries, strategy, ef, k):
-    ob, od, oc, ot, sc = ix.search(queries, strategy, ef, k)
-    for i, q in enumerate(queries):
-        eb, ed, ns = g.search(q, strategy, ef, k)
-        assert oc[i] == len(eb), (i, oc[i], len(eb))
-        assert np.array_equal(ob[i, :len(eb)], eb), (i, ob[i, :len(eb)], eb, od[i, :len(eb)], ed)
-        assert np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)), (i, od[i, :len(eb)], ed)
-        assert sc[i] == ns, (i, sc[i], ns)
+    """Both search kernels — one wave per query in the reference's summation order, and the block-cooperative
+    one (dim % 4 == 0) — against the oracle: blocks, ranks, float4 bits, evaluation counts."""
+    from neurondb_amd import _lib
+    exp = [g.search(q, strategy, ef, k) for q in queries]
+    try:
+        for mode in ((1, 2) if ix.dim % 4 == 0 else (1,)):
+            _lib.check(_lib.lib().ndbhip_hnsw_set_search_mode(mode))
+            ob, od, oc, ot, sc = ix.search(queries, strategy, ef, k)
+            for i, (eb, ed, ns) in enumerate(exp):
+                assert oc[i] == len(eb), (mode, i, oc[i], len(eb))
+                assert np.array_equal(ob[i, :len(eb)], eb), (mode, i, ob[i, :len(eb)], eb, od[i, :len(eb)], ed)
+                assert np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)), \
+                    (mode, i, od[i, :len(eb)], ed)
+                assert sc[i] == ns, (mode, i, sc[i], ns)
+    finally:
+        _lib.check(_lib.lib().ndbhip_hnsw_set_search_mode(0))
 
 
 @pytest.mark.parametrize("n,dim,m,efc", [(600, 16, 4, 20), (1500, 32, 8, 40), (400, 768, 16, 32), (300, 6, 5, 16)])
