@@ -326,7 +326,7 @@ def run_dist_parity(args, image, qs, out_t, out_d, out_c):
     return {"queries": ns, "mismatches": int(bad)}
 
 
-def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=2000):
+def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
     """BASELINE config C3: HNSW m=16 ef_search=64 k=10 cosine on unit-norm rows — device build
     (ndbhip_hnsw_build_device) and batch search, with a sample of the queries replayed by the CPU oracle
     on the exported graph (blocks, ranks, float4 bits and evaluation counts must all agree)."""
