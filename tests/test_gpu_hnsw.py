@@ -9,9 +9,12 @@ from oracle import ndbo
 pytestmark = pytest.mark.gpu
 
 
-def build_graph(n, dim, m, efc, seed, normalize=False, dup=False):
+def build_graph(n, dim, m, efc, seed, normalize=False, dup=False, integer=False):
     rng = np.random.default_rng(seed)
     vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    if integer:                                     # exact ties, exact zero dot products, zero vectors
+        vecs = rng.integers(-2, 3, size=(n, dim)).astype(np.float32)
+        vecs[5] = 0.0
     if normalize:
         vecs /= np.linalg.norm(vecs, axis=1, keepdims=True).astype(np.float32)
     if dup:
@@ -62,6 +65,21 @@ def test_hnsw_search_matches_oracle(n, dim, m, efc):
     q[:3] = vecs[:3]
     for strategy in (1, 2, 3):
         for ef, k in ((64, 10), (8, 3), (200, 200), (4, 10)):
+            check(g, ix, q, strategy, ef, k)
+
+
+def test_hnsw_search_on_small_integer_vectors():
+    """Ties everywhere, dot products that are exactly 0 (the interval of the block-cooperative scorer then
+    straddles +-0 and the row is redone in order), a zero row and a zero query (cosine's 2.0f)."""
+    g, vecs = build_graph(900, 16, 8, 40, seed=21, integer=True)
+    ix, a = load(g)
+    rng = np.random.default_rng(22)
+    q = rng.integers(-2, 3, size=(24, 16)).astype(np.float32)
+    q[0] = 0.0
+    q[1] = vecs[5]
+    q[2] = vecs[17]
+    for strategy in (1, 2, 3):
+        for ef, k in ((64, 10), (16, 16)):
             check(g, ix, q, strategy, ef, k)
 
 
