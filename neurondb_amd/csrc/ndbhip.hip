@@ -674,7 +674,7 @@ k_rows_scan(const float *__restrict__ base, uint32_t nrows, int dim,
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t q = blockIdx.y;
-	const uint32_t r0 = (blockIdx.x * 4 + wave) * 64;
+	const uint32_t r0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64;	/* block = 1..4 waves of 64 rows */
 
 	if (r0 >= nrows)
 		return;
@@ -705,6 +705,7 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 	__shared__ uint32_t hist[256];
 	__shared__ uint32_t sh[16];
 	__shared__ uint64_t comp[NDBHIP_MAX_NPROBE];
+	__shared__ uint64_t full[2048];
 	__shared__ uint32_t perm[NDBHIP_MAX_NPROBE];
 	__shared__ uint32_t lens[NDBHIP_MAX_NPROBE];
 	__shared__ int selc[NDBHIP_MAX_NPROBE];
@@ -724,6 +725,53 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 		return v < FLT_MAX;
 	};
 
+	if (ncmp <= 2048)
+	{
+		/* few centroids (the reference's build fits them on ONE page: <= 185 at dim 4): sort all of them by
+		 * (distance, index) in LDS — the nprobe-times "first strict minimum" selection (:1685-1714) is the
+		 * head of that order — instead of four histogram passes with their barriers */
+		uint32_t	np2 = 2;
+
+		while (np2 < (uint32_t) ncmp)
+			np2 <<= 1;
+		if (tid == 0)
+			sh[0] = 0;
+		__syncthreads();
+		for (uint32_t j = tid; j < np2; j += blockDim.x)
+		{
+			uint32_t	bits = 0;
+			const bool	ok = j < (uint32_t) ncmp && ld(j, bits);
+
+			full[j] = ok ? (((uint64_t) ndb_key_from_bits(bits) << 32) | j) : ~0ull;
+			if (ok)
+				atomicAdd(&sh[0], 1u);
+		}
+		for (uint32_t size = 2; size <= np2; size <<= 1)
+			for (uint32_t sd = size >> 1; sd > 0; sd >>= 1)
+			{
+				__syncthreads();
+				for (uint32_t t = tid; t < (np2 >> 1); t += blockDim.x)
+				{
+					const uint32_t lo = 2 * t - (t & (sd - 1));
+					const uint32_t hi = lo + sd;
+					const bool	up = ((lo & size) == 0);
+					const uint64_t a = full[lo], b = full[hi];
+
+					if ((a > b) == up)
+					{
+						full[lo] = b;
+						full[hi] = a;
+					}
+				}
+			}
+		__syncthreads();
+		kk = min((uint32_t) npr_eff, sh[0]);
+		for (uint32_t j = tid; j < kk; j += blockDim.x)
+			perm[j] = (uint32_t) full[j];
+		__syncthreads();
+	}
+	else
+	{
 	block_radix_select(ld, (uint32_t) ncmp, (uint32_t) npr_eff, hist, sh, T, m_less, kk, cnt_eq);
 
 	uint32_t	npad = 1;
@@ -748,6 +796,7 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 		block_bitonic_sort(comp, perm, npad);
 	}
 	__syncthreads();
+	}
 	for (uint32_t i = tid; i < (uint32_t) npr; i += blockDim.x)
 	{
 		int			c;
@@ -1533,7 +1582,8 @@ __global__ __launch_bounds__(256) void
 k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict__ cand_off,
 		   const uint32_t *__restrict__ loc_cand_off, int npr, const float *__restrict__ dist, uint32_t stride, uint32_t k, int partial,
 		   ndbhip_cand *__restrict__ out_cand, int *__restrict__ out_ncand, int64_t *__restrict__ out_total,
-		   uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count)
+		   uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count,
+		   uint32_t nq)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	const uint32_t ecap = topk_entry_cap(k);
@@ -1543,8 +1593,18 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 	const uint32_t *co = cand_off + (size_t) q * (npr + 1);		/* positions in the reference's candidates[] */
 	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);	/* positions among the rows held here */
 	const uint32_t gtotal = co[npr];
-	const uint32_t total = lco[npr];
-	const float *d = dist + (size_t) q * stride;
+	/*
+	 * gridDim.y > 1 (partial mode only): a query's candidates are cut into gridDim.y position ranges, one
+	 * block each — for small batches one block per query cannot keep enough loads in flight (a single
+	 * query: 130 k candidates in 129 us).  Every range emits its tie-complete subset exactly like a rank of
+	 * a sharded search does, and k_merge_topk replays the union; rec. layout [(range * nq + q) * 3k + j].
+	 */
+	const uint32_t all = lco[npr];
+	const uint32_t per = (all + gridDim.y - 1) / gridDim.y;
+	const uint32_t lo = min(all, blockIdx.y * per);
+	const uint32_t total = min(all, lo + per) - lo;
+	const float *d = dist + (size_t) q * stride + lo;
+	const size_t oq = (size_t) blockIdx.y * nq + q;
 	uint32_t	ns = 0;
 	bool		have = false;
 
@@ -1552,8 +1612,9 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		bits = __float_as_uint(d[i]);
 		return true;
 	};
-	/* local position -> (TID, position in candidates[]) */
-	auto		tid_of = [&](uint32_t i, uint32_t &gpos) -> uint64_t {
+	/* local position (inside this block's range) -> (TID, position in candidates[]) */
+	auto		tid_of = [&](uint32_t i0, uint32_t &gpos) -> uint64_t {
+		const uint32_t i = i0 + lo;
 		const uint32_t p = find_probe(lco, npr, i);
 		const int	L = probes[(size_t) q * npr + p];
 
@@ -1672,11 +1733,11 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 			c.key = s.e_bits[e];	/* raw float4 bits; the merge derives the order key */
 			c.pos = s.e_pos[e];
 			c.tid = s.e_id[e];
-			out_cand[(size_t) q * (3 * k) + j] = c;
+			out_cand[oq * (3 * k) + j] = c;
 		}
 		if (tid == 0)
 		{
-			out_ncand[q] = (int) cut;
+			out_ncand[oq] = (int) cut;
 			out_total[q] = (int64_t) gtotal;
 		}
 		return;
@@ -1789,6 +1850,10 @@ struct ndbhip_ivf
 	PairRec    *w_pairs = nullptr;	size_t w_pairs_n = 0;
 	float	   *w_qblock = nullptr;	size_t w_qblock_n = 0;	/* [groups][dim][16] interleaved queries */
 	float	   *w_qnorm = nullptr;	size_t w_qnorm_n = 0;	/* [nq] sum of squares of every query (cosine) */
+	/* split top-k of small batches: per-range records, counts, totals */
+	ndbhip_cand *w_scand = nullptr;	size_t w_scand_n = 0;
+	int		   *w_sncand = nullptr;	size_t w_sncand_n = 0;
+	int64_t    *w_stotal = nullptr;	size_t w_stotal_n = 0;
 };
 
 template <class T>
@@ -1852,7 +1917,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		ivf_free_rows(ix);
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
-			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm};
+			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2503,10 +2568,12 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	}
 	else
 	{
-		/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680) */
-		dim3		grid((ncmp + 255) / 256, nq);
+		/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680); a small batch spreads its
+		 * 64-centroid tiles over more CUs (one wave per block) */
+		const int	rsw = nq <= 16 ? 1 : 4;
+		dim3		grid((ncmp + 64 * rsw - 1) / (64 * rsw), nq);
 
-		hipLaunchKernelGGL(k_rows_scan<R_IVF_L2>, grid, dim3(256), 0, g.stream, (const float *) d.centroids,
+		hipLaunchKernelGGL(k_rows_scan<R_IVF_L2>, grid, dim3(64 * rsw), 0, g.stream, (const float *) d.centroids,
 						   (uint32_t) ncmp, ix->dim, d_q, ix->w_cdist, cstride);
 		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
@@ -2607,10 +2674,44 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	}
 	{
 		const size_t smem = topk_smem_bytes(topk_entry_cap((uint32_t) k), (uint32_t) k);
+		/*
+		 * Small batches: one block per query is latency-bound (its 256 threads cannot keep enough of the
+		 * distance buffer in flight), so the query's candidates are cut into position ranges — partial
+		 * top-k per range, then the same replay merge the sharded search uses.
+		 */
+		uint32_t	nsplit = 1;
 
-		hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
-						   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
-						   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt);
+		if (!partial && nq <= 64)
+		{
+			const uint32_t by_work = stride / 2048u;					/* >= 2048 candidates per block */
+			const uint32_t by_merge = 2048u / (3u * (uint32_t) k);		/* records the merge stage sorts in LDS */
+			const uint32_t by_grid = 1024u / (uint32_t) nq;
+
+			nsplit = std::min(std::min(by_work, by_merge), std::min(by_grid, 64u));
+			if (nsplit < 2 || topk_smem_bytes(3u * (uint32_t) k * nsplit, (uint32_t) k) > NDB_TOPK_MAX_SMEM)
+				nsplit = 1;
+		}
+		if (nsplit > 1)
+		{
+			const size_t nrec = (size_t) nsplit * nq * 3 * k;
+
+			if (grow(ix->w_scand, ix->w_scand_n, nrec)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_sncand, ix->w_sncand_n, (size_t) nsplit * nq)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_stotal, ix->w_stotal_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_ivf_topk, dim3(nq, nsplit), dim3(256), smem, g.stream, d, (const int *) w_probes,
+							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
+							   (uint32_t) k, 1, ix->w_scand, ix->w_sncand, ix->w_stotal, (uint64_t *) nullptr,
+							   (float *) nullptr, (int *) nullptr, (uint32_t) nq);
+			hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(256),
+							   topk_smem_bytes(3u * (uint32_t) k * nsplit, (uint32_t) k), g.stream,
+							   (const ndbhip_cand *) ix->w_scand, (const int *) ix->w_sncand,
+							   (const int64_t *) ix->w_stotal, (int) nsplit, nq, (uint32_t) k, 3u * (uint32_t) k,
+							   d_otid, d_odist, d_ocnt);
+		}
+		else
+			hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
+							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
+							   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, (uint32_t) nq);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
