@@ -2681,7 +2681,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		 */
 		uint32_t	nsplit = 1;
 
-		if (!partial && nq <= 64)
+		if (!partial && nq <= 512)
 		{
 			const uint32_t by_work = stride / 2048u;					/* >= 2048 candidates per block */
 			const uint32_t by_merge = 2048u / (3u * (uint32_t) k);		/* records the merge stage sorts in LDS */
