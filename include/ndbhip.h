@@ -382,9 +382,17 @@ int			ndbhip_extract_vector(int kind, const void *datum, size_t datum_len, float
 /* ------------------------------------------------------------------ */
 /* Batch distance (replaces neurondb_gpu_batch_l2_distance & co:
  * include/neurondb_gpu.h:94-106, src/gpu/common/gpu_batch.c:27-83, whose
- * body is a CPU loop).  recipe selects the rounding:
- *   0 ivf (fp32 sequential), 1 hnsw (fp64 accumulate).
- * results[q*nv + v], host pointers.                                     */
+ * body is a CPU loop).  results[q*nv + v], host pointers.  recipe selects
+ * whose arithmetic is reproduced, bit for bit:
+ *   0 ivf   ivfComputeDistance (fp32 sequential), strategy 1/2/3, 4 = squared L2
+ *   1 hnsw  hnswComputeDistance (fp64 accumulate), strategy 1/2/3
+ *   2 the SQL operators <-> <=> <#> as a default x86-64 build runs them: the scalar
+ *     kernels of src/vector/vector_distance.c (Kahan double L2, double cosine / IP)
+ *     through the dispatchers of vector_distance_simd.c:467-613 (strategy 3 = +dot, Q15)
+ *   3 / 4 the same operators in an AVX2 / AVX-512 build: 8 / 16 fp32 lane accumulators,
+ *     FMA cosine, the fixed horizontal-sum tree (vector_distance_simd.c:84-392)
+ *   5 the halfvec operators (src/types/quantization.c:1985-2116): queries and vectors are
+ *     uint16 fp16 images, decoded per element like fp16_to_float (strategy 3 = -dot)       */
 /* ------------------------------------------------------------------ */
 int			ndbhip_batch_distance(const float *queries, const float *vectors, float *results,
 								  int nq, int nv, int dim, int strategy, int recipe);

@@ -55,6 +55,41 @@ def test_batch_distance_all_recipes_bitexact():
                 assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), (dim, recipe, s)
 
 
+def test_batch_distance_operator_recipes_bitexact():
+    """The SQL operators' own kernels on the device: scalar double (what a default x86-64
+    build runs, incl. the Kahan L2 and the Q15 sign of <#>), the AVX2 / AVX-512 lane orders with their
+    horizontal-sum tree and FMA cosine, and the halfvec operators (per-element fp16_to_float, Q20)."""
+    from neurondb_amd import _lib
+    from oracle import ndbo
+    _lib.ensure_init()
+    L = ndbo.lib()
+    rng = np.random.default_rng(5)
+    ops = {1: L.ndbo_op_l2, 2: L.ndbo_op_cosine, 3: L.ndbo_op_ip}
+    hops = {1: L.ndbo_halfvec_l2, 2: L.ndbo_halfvec_cosine, 3: L.ndbo_halfvec_ip}
+    for dim in (3, 7, 8, 15, 16, 28, 100, 768):
+        nq, nv = 2, 130
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        v = (rng.standard_normal((nv, dim)) * rng.choice([1e-3, 1.0, 1e3], (nv, 1))).astype(np.float32)
+        v[5] = 0.0
+        v[7] = q[0]
+        for recipe, simd in ((2, 0), (3, 8), (4, 16)):
+            for s_ in (1, 2, 3):
+                out = np.zeros((nq, nv), np.float32)
+                _lib.check(_lib.lib().ndbhip_batch_distance(q.ctypes.data, v.ctypes.data, out.ctypes.data,
+                                                            nq, nv, dim, s_, recipe))
+                exp = np.array([[ops[s_](q[i], v[j], dim, simd) for j in range(nv)] for i in range(nq)], np.float32)
+                assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), (dim, recipe, s_)
+        qh = (q * 0.5).astype(np.float16).view(np.uint16).copy()
+        vh = np.clip(v, -6e4, 6e4).astype(np.float16).view(np.uint16).copy()
+        vh[3, :min(dim, 4)] = [0x0001, 0x83FF, 0x0200, 0x8000][:min(dim, 4)]        # subnormals, -0
+        for s_ in (1, 2, 3):
+            out = np.zeros((nq, nv), np.float32)
+            _lib.check(_lib.lib().ndbhip_batch_distance(qh.ctypes.data, vh.ctypes.data, out.ctypes.data,
+                                                        nq, nv, dim, s_, 5))
+            exp = np.array([[hops[s_](qh[i], vh[j], dim) for j in range(nv)] for i in range(nq)], np.float32)
+            assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), (dim, "halfvec", s_)
+
+
 @pytest.mark.parametrize("dim,n,nlists", [(4, 100, 10), (28, 1000, 10), (128, 10000, 100), (768, 4000, 64),
                                            (3, 300, 7), (100, 2000, 20)])
 @pytest.mark.parametrize("strategy", [1, 2, 3])
