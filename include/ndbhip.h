@@ -303,7 +303,8 @@ int			ndbhip_hnsw_insert(ndbhip_hnsw *g, const float *rows, const uint8_t *tids6
  * All zero after a sequential (one-wave) build. */
 int			ndbhip_hnsw_build_stats(const ndbhip_hnsw *g, int64_t out[6]);
 /* How ndbhip_hnsw_build_device schedules the inserts.  optimistic = 0: one wave inserts row after row.
- * optimistic = 2: as 1, but the commit is done walk by walk by one wave (kept for cross-checking).
+ * optimistic = 2: as 1, but the commit is done walk by walk by one wave; 3: as 1 with the sorted-replay
+ * chunked commit whatever m (both kept for cross-checking).
  * optimistic = 1 (default): the walks of up to min(batch_max, nodes so far / batch_div) inserts run in
  * parallel against the graph as it stands and are committed in insert order up to the first walk that
  * read a list an earlier insert of the batch has written since; the rest runs again in the next round.

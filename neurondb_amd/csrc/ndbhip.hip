@@ -61,8 +61,9 @@ static int	g_scan_mode = 0;
 /* rows staged per step by the grouped kernels: 64 floats (16 KiB tile, 3 waves/SIMD) or 32 (8 KiB, 4 waves/SIMD);
  * NDBHIP_GCHUNK overrides for experiments */
 static int	g_gchunk = 32;
-/* hnswbuild: 0 the one-wave sequential kernel, 1 optimistic batches with the chunked block-wide commit,
- * 2 optimistic batches with the one-wave commit; batch = min(max, nodes so far / div) walks */
+/* hnswbuild: 0 the one-wave sequential kernel, 1 optimistic batches with the chunked block-wide commit (hashed
+ * when m <= 16, else sorted), 2 optimistic batches with the one-wave commit, 3 optimistic batches with the
+ * sorted chunked commit; batch = min(max, nodes so far / div) walks */
 static int	g_hnsw_search_mode = 0;
 static int	g_hnsw_spec = 1;
 static int	g_hnsw_batch_div = 64;
@@ -5869,6 +5870,359 @@ k_hnsw_commit_par(int16_t *ncount, uint32_t *nbrs, const HnswTask *__restrict__ 
 	}
 }
 
+#define NDB_HH_BITS 11
+#define NDB_HH_SLOTS (1u << NDB_HH_BITS)	/* >= 2 x the chunk's distinct lists (64 walks x 17) */
+#define NDB_HH_MAXSEL 16u					/* ksel <= 16 and 2m <= 32: the default m = 16 */
+
+/*
+ * The chunked commit without the sort: with at most 64 walks per chunk "who back-links into this list, in
+ * walk order" is one 64-bit mask per list, kept in an LDS hash table keyed by (node, level).  A list's free
+ * places are known up front — its holes below the count, then the tail up to 2m — so request number r (the
+ * r-th set bit of the mask) lands in the r-th free place or is dropped, in closed form; no replay loop, no
+ * sort, and the first writer of a list is the mask's lowest bit (if there is room at all).
+ */
+__global__ __launch_bounds__(256) void
+k_hnsw_commit_hash(int16_t *ncount, uint32_t *nbrs, const HnswTask *__restrict__ tasks, uint32_t ntasks, int m,
+				  uint32_t ksel, HnswRounds R, uint32_t round)
+{
+	__shared__ uint64_t tkey[NDB_HH_SLOTS];		/* (node << 4 | level) + 1, 0 = empty */
+	__shared__ uint64_t tmask[NDB_HH_SLOTS];	/* walks of the chunk that back-link into this list */
+	__shared__ uint32_t tholes[NDB_HH_SLOTS];	/* InvalidBlockNumber slots below the list's count */
+	__shared__ uint8_t tcnt0[NDB_HH_SLOTS];		/* the list's count before the chunk (own list: the walk's nsel) */
+	__shared__ uint8_t tfw[NDB_HH_SLOTS];		/* first walk of the chunk that writes the list, NDB_HC_NONE = none */
+	__shared__ uint8_t town[NDB_HH_SLOTS];		/* the walk whose own list this is, NDB_HC_NONE = nobody's */
+	__shared__ uint16_t rslot[NDB_HC_TASKS * (NDB_HH_MAXSEL + 1)];
+	__shared__ uint32_t sel[NDB_HC_TASKS * NDB_HC_MAXSEL];
+	__shared__ uint32_t t_ran[NDB_HC_TASKS], t_rsn[NDB_HC_TASKS], t_nsel[NDB_HC_TASKS], t_blk[NDB_HC_TASKS];
+	__shared__ int t_cl[NDB_HC_TASKS];
+	__shared__ uint32_t t_stale[NDB_HC_TASKS], t_off[NDB_HC_TASKS + 1];
+	__shared__ uint32_t s_stop, s_self;
+	const uint32_t tid = threadIdx.x;
+	const int	m2 = 2 * m;
+	const int64_t stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * m2;
+	const uint32_t first = *R.next;
+	const uint32_t cmax = NDB_HC_TASKS;			/* <= 64 walks: one bit each in tmask */
+	uint32_t	cur = first;
+	bool		stopped = false;
+
+	while (cur < ntasks && !stopped)
+	{
+		uint32_t	C = min(cmax, ntasks - cur);
+
+		/* ---- the chunk's walks ---- */
+		if (tid < C)
+		{
+			const uint32_t t = cur + tid;
+			const HnswTask task = tasks[t];
+
+			t_ran[tid] = R.spec_round[t];
+			t_rsn[tid] = R.rsn[t];
+			t_nsel[tid] = (uint32_t) R.nsel[t];
+			t_blk[tid] = task.row + 1;
+			t_cl[tid] = task.cl;
+			/* never run, or its read-set log overflowed: cannot be validated (unless it opens the round) */
+			t_stale[tid] = (t_ran[tid] == 0 || t_rsn[tid] > NDB_HNSW_RS_CAP) ? 1u : 0u;
+		}
+		if (tid == 0)
+		{
+			s_stop = C;
+			s_self = C;
+		}
+		__syncthreads();
+		for (uint32_t e = tid; e < C * ksel; e += 256)
+		{
+			const uint32_t j = e / ksel, idx = e % ksel;
+
+			if (idx < t_nsel[j])
+			{
+				const uint32_t v = R.sel[(size_t) (cur + j) * ksel + idx];
+
+				sel[j * NDB_HC_MAXSEL + idx] = v;
+				if (v == t_blk[j])
+					atomicMin(&s_self, j);
+			}
+		}
+		__syncthreads();
+		const bool	solo = s_self == 0;	/* the chunk's first walk selected its own node: commit it alone */
+
+		if (solo)
+			C = 1;
+		else if (s_self < C)
+			C = s_self;					/* ... a later one: it will open the next chunk */
+		const bool	opens_round = cur == first && t_ran[0] == round;	/* valid by construction */
+
+		if (tid == 0)
+		{
+			s_stop = C;
+			if (opens_round)
+				t_stale[0] = 0;
+		}
+		__syncthreads();
+
+		/* ---- stale against what was written before this chunk ---- */
+		/* (walk, read-set entry) pairs are spread over the block, 8 per thread in flight */
+		if (tid == 0)
+		{
+			uint32_t	acc = 0;
+
+			for (uint32_t j = 0; j < C; j++)
+			{
+				t_off[j] = acc;
+				acc += t_rsn[j] > NDB_HNSW_RS_CAP ? 0u : t_rsn[j];
+			}
+			t_off[C] = acc;
+		}
+		__syncthreads();
+		const uint32_t npairs = t_off[C];
+		auto		pair_walk = [&](uint32_t p) -> uint32_t {	/* largest j with t_off[j] <= p */
+			uint32_t	lo = 0, hi = C;
+
+			while (hi - lo > 1)
+			{
+				const uint32_t mid = (lo + hi) >> 1;
+
+				if (t_off[mid] <= p)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			return lo;
+		};
+
+		for (uint32_t base = 0; base < npairs; base += 256u * 8u)
+		{
+			uint32_t	enc[8], jj[8], stv[8];
+
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t p = base + (uint32_t) u * 256u + tid;
+
+				jj[u] = 0xFFFFFFFFu;
+				enc[u] = 0;
+				if (p < npairs)
+				{
+					jj[u] = pair_walk(p);
+					enc[u] = R.rs[(size_t) (cur + jj[u]) * NDB_HNSW_RS_CAP + (p - t_off[jj[u]])];
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t node = enc[u] & ((1u << NDB_HNSW_RS_NODE_BITS) - 1u);
+				const uint32_t *st = (enc[u] >> NDB_HNSW_RS_NODE_BITS) ? R.stampU : R.stamp0;
+
+				stv[u] = jj[u] != 0xFFFFFFFFu ? gload<true>(&st[node]) : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				if (jj[u] != 0xFFFFFFFFu && !(jj[u] == 0 && opens_round) && stv[u] >= t_ran[jj[u]])
+					t_stale[jj[u]] = 1u;
+		}
+		__syncthreads();
+		if (solo)
+		{
+			if (!t_stale[0])
+			{
+				if (tid < 64)
+				{
+					hnsw_link(nbrs, ncount, t_blk[0], t_cl[0], m, stride, sel, t_nsel[0], R.stamp0, R.stampU, round);
+					hnsw_publish();
+				}
+				cur += 1;
+			}
+			else
+				stopped = true;
+			__syncthreads();
+			continue;
+		}
+
+		/* ---- the chunk's requests, hashed by (node, level): who asks, in walk order, is a bit mask ---- */
+		for (uint32_t i = tid; i < NDB_HH_SLOTS; i += 256)
+		{
+			tkey[i] = 0ull;
+			tmask[i] = 0ull;
+			town[i] = NDB_HC_NONE;
+			tfw[i] = NDB_HC_NONE;
+		}
+		__syncthreads();
+		auto		slot_of = [&](uint32_t node, uint32_t level, bool insert) -> uint32_t {
+			const uint64_t kv = (((uint64_t) node << 4) | level) + 1ull;
+			uint32_t	h = (uint32_t) ((kv * 0x9E3779B97F4A7C15ull) >> (64 - NDB_HH_BITS));
+
+			for (;;)
+			{
+				uint64_t	cur = tkey[h];
+
+				if (cur == kv)
+					return h;
+				if (cur == 0ull)
+				{
+					if (!insert)
+						return NDB_HH_SLOTS;
+					cur = atomicCAS((unsigned long long *) &tkey[h], 0ull, (unsigned long long) kv);
+					if (cur == 0ull || cur == kv)
+						return h;
+				}
+				h = (h + 1u) & (NDB_HH_SLOTS - 1u);
+			}
+		};
+		const uint32_t nreq = C * (ksel + 1u);
+
+		for (uint32_t e = tid; e < nreq; e += 256)
+		{
+			const uint32_t j = e / (ksel + 1u), idx = e % (ksel + 1u);
+
+			if (idx < t_nsel[j])
+			{
+				const uint32_t sl = slot_of(sel[j * NDB_HC_MAXSEL + idx], (uint32_t) t_cl[j], true);
+
+				atomicOr((unsigned long long *) &tmask[sl], 1ull << j);
+				rslot[e] = (uint16_t) sl;
+			}
+			else if (idx == ksel && t_nsel[j] > 0)
+			{
+				const uint32_t sl = slot_of(t_blk[j], (uint32_t) t_cl[j], true);	/* the node's own list */
+
+				town[sl] = (uint8_t) j;
+			}
+		}
+		__syncthreads();
+
+		/* ---- per list: what it holds now, hence which requests will write and where ---- */
+		for (uint32_t i = tid; i < NDB_HH_SLOTS; i += 256)
+		{
+			const uint64_t kv = tkey[i];
+
+			if (kv == 0ull)
+				continue;
+			const uint32_t X = (uint32_t) ((kv - 1ull) >> 4);
+			const int	cl = (int) ((kv - 1ull) & 15ull);
+			const uint32_t *nn = nbrs + (size_t) X * stride + (size_t) cl * m2;
+			int			c0;
+			uint32_t	holes = 0;
+
+			if (town[i] != NDB_HC_NONE)
+			{
+				c0 = (int) t_nsel[town[i]];		/* slots 0..nsel-1 written, count = nsel (:2452-2456) */
+				tfw[i] = town[i];
+			}
+			else
+			{
+				/* count and the 2m slots in one round trip (plain loads: every wave passed hnsw_publish's
+				 * acquire after the previous chunk's stores) */
+				const int16_t craw = ncount[(size_t) X * NDBHIP_HNSW_MAX_LEVEL + cl];
+				uint32_t	inv = 0;
+
+#pragma unroll 16
+				for (int q = 0; q < m2; q++)
+					inv |= (uint32_t) (nn[q] == NDBHIP_INVALID_BLOCK) << q;
+				c0 = hnsw_clamp(craw, m);
+				holes = c0 >= 32 ? inv : (inv & ((1u << c0) - 1u));
+				if (tmask[i] != 0ull && (__popc(holes) + (m2 - c0)) > 0)
+					tfw[i] = (uint8_t) (__ffsll((long long) tmask[i]) - 1);
+			}
+			tcnt0[i] = (uint8_t) c0;
+			tholes[i] = holes;
+		}
+		__syncthreads();
+
+		/* ---- stale against the chunk's own earlier walks ---- */
+		for (uint32_t base = 0; base < npairs; base += 256u * 8u)
+		{
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t p = base + (uint32_t) u * 256u + tid;
+
+				if (p >= npairs)
+					continue;
+				const uint32_t j = pair_walk(p);
+
+				if (j == 0)
+					continue;
+				const uint32_t enc = R.rs[(size_t) (cur + j) * NDB_HNSW_RS_CAP + (p - t_off[j])];
+				const uint32_t sl = slot_of(enc & ((1u << NDB_HNSW_RS_NODE_BITS) - 1u), enc >> NDB_HNSW_RS_NODE_BITS,
+											false);
+
+				if (sl < NDB_HH_SLOTS && tfw[sl] < j)
+					t_stale[j] = 1u;
+			}
+		}
+		__syncthreads();
+		if (tid < C && t_stale[tid])
+			atomicMin(&s_stop, tid);
+		__syncthreads();
+		const uint32_t stop = s_stop;
+		const uint64_t below_stop = stop >= 64 ? ~0ull : ((1ull << stop) - 1ull);
+
+		/* ---- apply the walks before `stop`: every request knows its rank among the list's requests ---- */
+		for (uint32_t e = tid; e < stop * (ksel + 1u); e += 256)
+		{
+			const uint32_t j = e / (ksel + 1u), idx = e % (ksel + 1u);
+
+			if (idx >= t_nsel[j])
+				continue;
+			const uint32_t sl = rslot[e];
+			const uint64_t kv = tkey[sl] - 1ull;
+			const uint32_t X = (uint32_t) (kv >> 4);
+			const int	cl = (int) (kv & 15ull);
+			const uint32_t r = (uint32_t) __popcll(tmask[sl] & ((1ull << j) - 1ull));
+			uint32_t	holes = tholes[sl];
+			const uint32_t nh = (uint32_t) __popc(holes);
+			int			p;
+
+			if (r < nh)			/* first InvalidBlockNumber among the first `count` slots (:2487-2511) */
+			{
+				for (uint32_t z = 0; z < r; z++)
+					holes &= holes - 1;
+				p = __ffs((int) holes) - 1;
+			}
+			else
+				p = (int) tcnt0[sl] + (int) (r - nh);
+			if (p < m2)
+				gstore(&nbrs[(size_t) X * stride + (size_t) cl * m2 + p], t_blk[j]);
+			/* the node's own list: sel is what it links to */
+			gstore(&nbrs[(size_t) t_blk[j] * stride + (size_t) t_cl[j] * m2 + idx], sel[j * NDB_HC_MAXSEL + idx]);
+		}
+		for (uint32_t i = tid; i < NDB_HH_SLOTS; i += 256)
+		{
+			const uint64_t kv = tkey[i];
+
+			if (kv == 0ull)
+				continue;
+			const uint32_t X = (uint32_t) ((kv - 1ull) >> 4);
+			const int	cl = (int) ((kv - 1ull) & 15ull);
+			const bool	own = town[i] != NDB_HC_NONE && town[i] < stop;
+			const int	nh = __popc(tholes[i]);
+			const int	w = __popcll(tmask[i] & below_stop);	/* requests of committed walks, in order */
+			const int	room = nh + (m2 - (int) tcnt0[i]);
+			const int	writes = w < room ? w : room;
+
+			if (town[i] != NDB_HC_NONE && !own)
+				continue;			/* this node's own walk did not commit: nothing of its list exists yet */
+			if (writes > 0 || own)
+			{
+				const int	appended = writes > nh ? writes - nh : 0;
+
+				gstore(&ncount[(size_t) X * NDBHIP_HNSW_MAX_LEVEL + cl], (int16_t) ((int) tcnt0[i] + appended));
+				gstore(cl ? &R.stampU[X] : &R.stamp0[X], round);
+			}
+		}
+		hnsw_publish();
+		__syncthreads();
+		cur += stop;
+		if (stop < C)
+			stopped = true;
+	}
+	if (tid == 0)
+	{
+		*R.next = cur;
+		if (cur < ntasks)
+			atomicAdd(&R.stats[1], 1ull);
+	}
+}
+
 static int
 set_kernel_attributes_hnsw()
 {
@@ -6195,7 +6549,11 @@ hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, ui
 		int64_t		nrounds = 0;
 		const bool	trace = getenv("NDBHIP_HNSW_TRACE") != nullptr;
 		/* the chunked commit keeps a list's slots in a 64-bit mask and a chunk's requests in LDS */
-		const bool	par_commit = g_hnsw_spec == 1 && ksel <= NDB_HC_MAXSEL && 2 * h->m <= 64;
+		/* commit kernel: 1 = hashed closed-form chunks (m <= 16), else / 3 = sorted-replay chunks (m <= 32),
+		 * 2 = one wave, walk by walk */
+		const bool	hash_commit = g_hnsw_spec == 1 && ksel <= NDB_HH_MAXSEL && 2 * h->m <= 32;
+		const bool	par_commit = !hash_commit && (g_hnsw_spec == 1 || g_hnsw_spec == 3) && ksel <= NDB_HC_MAXSEL &&
+			2 * h->m <= 64;
 		const bool	fast = (h->dim % 4) == 0 && h->dim <= NDB_HNSW_FAST_MAX_DIM && getenv("NDBHIP_HNSW_NOFAST") == nullptr;
 		uint32_t   *h_next = nullptr;
 
@@ -6222,7 +6580,10 @@ hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, ui
 						hipLaunchKernelGGL(k_hnsw_spec<false>, dim3(nt), dim3(64), smem, g.stream, gd, d_rows,
 										   (const HnswTask *) (d_tasks + b.t0), (uint32_t) ef_construction, ksel,
 										   R, round, base);
-					if (par_commit)
+					if (hash_commit)
+						hipLaunchKernelGGL(k_hnsw_commit_hash, dim3(1), dim3(256), 0, g.stream, h->d_ncount, h->d_nbrs,
+										   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
+					else if (par_commit)
 						hipLaunchKernelGGL(k_hnsw_commit_par, dim3(1), dim3(256), 0, g.stream, h->d_ncount, h->d_nbrs,
 										   (const HnswTask *) (d_tasks + b.t0), nt, h->m, ksel, R, round);
 					else
@@ -6325,7 +6686,7 @@ ndbhip_hnsw_set_build_mode(int optimistic, int batch_div, int batch_max)
 {
 	if (batch_div < 1 || batch_max < 1 || batch_max > 65535)
 		return fail(NDBHIP_ERR_INVALID, "batch_div >= 1 and 1 <= batch_max <= 65535 required");
-	g_hnsw_spec = optimistic < 0 ? 0 : (optimistic > 2 ? 2 : optimistic);
+	g_hnsw_spec = optimistic < 0 ? 0 : (optimistic > 3 ? 3 : optimistic);
 	g_hnsw_batch_div = batch_div;
 	g_hnsw_batch_max = batch_max;
 	return NDBHIP_OK;

@@ -126,7 +126,8 @@ def test_hnsw_scan_state_machine():
 # (optimistic, batch_div, batch_max): the one-wave sequential kernel; the default schedule; and a schedule
 # that batches as many walks as there are nodes, so that conflicts (and their in-order redo) are the rule
 BUILD_MODES = {"sequential": (0, 64, 1024), "optimistic": (1, 64, 1024), "optimistic-greedy": (1, 1, 256),
-               "optimistic-wave-commit": (2, 64, 1024), "optimistic-wave-commit-greedy": (2, 1, 256)}
+               "optimistic-wave-commit": (2, 64, 1024), "optimistic-wave-commit-greedy": (2, 1, 256),
+               "optimistic-sorted-commit": (3, 64, 1024), "optimistic-sorted-commit-greedy": (3, 1, 256)}
 
 
 @pytest.fixture
