@@ -2736,7 +2736,7 @@ ivf_check_search_args(ndbhip_ivf *ix, int nq, int nprobe, int k)
 }
 
 /* per-sub-batch budget for the candidate-distance buffer */
-static size_t g_dist_budget_bytes = (size_t) 2 << 30;
+static size_t g_dist_budget_bytes = (size_t) 8 << 30;	/* of 288 GB: a 4096-query step of the 1M x 768 workload needs 2.1 GB */
 
 static int
 ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe, int k,
