@@ -1367,15 +1367,46 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 	const int	lane = threadIdx.x & 63;
 	const int	dim = ix.dim;
 	const uint32_t nitems = item_off[ix.ncent];
+	/*
+	 * XCD-aware work queues.  The items (list-major) are cut into 8 runs of whole lists with about the same
+	 * number of items, one per XCD; a block serves the run of ITS XCD first (block b runs on XCD b % 8 —
+	 * observed, used for speed only) and then helps the others.  All query groups of a list are therefore
+	 * scored through one XCD's L2, and — consecutive items being the same row tile for consecutive groups —
+	 * at about the same time: a tile comes from HBM once, not once per group.
+	 */
+	auto		run_start = [&](uint32_t x) -> uint32_t {
+		if (x == 0)
+			return 0u;
+		if (x >= 8)
+			return nitems;
+		const uint32_t target = (uint32_t) (((uint64_t) nitems * x) >> 3);
+		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;	/* smallest L with item_off[L] >= target */
+
+		while (lo < hi)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if (item_off[mid] < target)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return item_off[lo];
+	};
+
+	for (uint32_t hop = 0; hop < 8; hop++)
+	{
+	const uint32_t xq = (blockIdx.x + hop) & 7u;
+	const uint32_t run_lo = run_start(xq), run_hi = run_start(xq + 1);
 
 	for (;;)
 	{
 		uint32_t	item = 0;
 
 		if (lane == 0)
-			item = atomicAdd(next_item, 1u);
+			item = run_lo + atomicAdd(&next_item[xq], 1u);
 		item = __builtin_amdgcn_readfirstlane(item);
-		if (item >= nitems)
+		if (item >= run_hi)
 			break;
 		/* list of this item: the L with item_off[L] <= item < item_off[L+1] */
 		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;
@@ -1393,10 +1424,12 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 			lo++;
 		const uint32_t L = lo;
 		const uint32_t len = ix.glob_len[L];
-		const uint32_t ntile = (len + 63u) >> 6;
 		const uint32_t local = item - item_off[L];
-		const uint32_t t = local % ntile;
-		const uint32_t gi = local / ntile;
+		/* consecutive items = the same 64-row tile for the list's consecutive query groups: the waves that
+		 * pull them stream the same rows at about the same time, so all but the first find them in cache */
+		const uint32_t ngrp = (cnt[L] + NDB_QG - 1) / NDB_QG;
+		const uint32_t gi = local % ngrp;
+		const uint32_t t = local / ngrp;
 		const uint32_t g0 = gi * NDB_QG;
 		const uint32_t nmem = min((uint32_t) NDB_QG, cnt[L] - g0);
 		const PairRec *mem = pairs + pair_off[L] + g0;
@@ -1501,6 +1534,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 					dist[(size_t) qid * stride + la + ridx] = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
 			}
 		}
+	}
 	}
 }
 
@@ -2600,7 +2634,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
 		ScanTimer	t;
 
-		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 1) * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
 						   (const uint8_t *) d.owned, cnt);
@@ -2773,7 +2807,7 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (grow(ix->w_probes, ix->w_probes_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) 2 * qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 4)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 8)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) qb)) return NDBHIP_ERR_HIP;
