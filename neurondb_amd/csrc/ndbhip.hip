@@ -3540,13 +3540,25 @@ k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const 
 {
 	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x;
-	const uint32_t r = blockIdx.x * 64 + lane;
+	/*
+	 * 1-D grid, XCD-aware: block b runs on XCD b % 8 (observed; speed only).  XCD x takes the row tiles
+	 * congruent to x mod 8 and walks each one through ALL centroid groups before the next, so a tile's
+	 * rows come from HBM once and from that XCD's L2 for the other groups.
+	 */
+	const uint32_t ngroups = ((uint32_t) ncent + NDB_QG - 1) / NDB_QG;
+	const uint32_t seq = blockIdx.x >> 3;
+	const uint32_t tileno = (seq / ngroups) * 8u + (blockIdx.x & 7u);
+	const uint32_t cgrp = seq % ngroups;
+
+	if (tileno * 64u >= nrows)
+		return;
+	const uint32_t r = tileno * 64 + lane;
 	const uint32_t row = (r < nrows) ? r : (nrows - 1);
-	const int	c0 = blockIdx.y * NDB_QG;
+	const int	c0 = (int) cgrp * NDB_QG;
 	const int	gc = (ncent - c0 < NDB_QG) ? (ncent - c0) : NDB_QG;
 	uint32_t	rowsN[CH / 4];
 	GAcc<R_IVF_L2> acc;
-	const float *qs = cblock + (size_t) blockIdx.y * (size_t) dim * NDB_QG;
+	const float *qs = cblock + (size_t) cgrp * (size_t) dim * NDB_QG;
 	ndb_f16		qa0, qa1, qb0, qb1;
 
 	acc.init();
@@ -3595,8 +3607,8 @@ k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const 
 	}
 	if (r < nrows)
 	{
-		part_dist[(size_t) blockIdx.y * nrows + r] = best;
-		part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
+		part_dist[(size_t) cgrp * nrows + r] = best;
+		part_idx[(size_t) cgrp * nrows + r] = bidx;
 	}
 }
 
@@ -3815,11 +3827,14 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 
 		if (fast)
 		{
+			/* 1-D, XCD-aware: ceil(tiles / 8) * 8 tiles x ngroups blocks (k_assign_grouped decodes it) */
+			const dim3	g1((unsigned) ((((size_t) (n + 63) / 64 + 7) / 8) * 8 * (size_t) ngroups));
+
 			if (use_sqrt)
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), grid, dim3(64), 0, g.stream, rows, n, dim,
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), g1, dim3(64), 0, g.stream, rows, n, dim,
 								   (const float *) cblock, ncent, pd, pi);
 			else
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<false, 32>), grid, dim3(64), 0, g.stream, rows, n, dim,
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<false, 32>), g1, dim3(64), 0, g.stream, rows, n, dim,
 								   (const float *) cblock, ncent, pd, pi);
 		}
 		else if ((dim & 3) == 0)
