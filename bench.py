@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--sigma", type=float, default=0.1)
     ap.add_argument("--rows", choices=["f32", "f16"], default="f32",
                     help="f16: search a halfvec twin of the index (rows narrowed round-to-nearest-even on the device)")
+    ap.add_argument("--f16-encoder", choices=["rne", "reference"], default="rne",
+                    help="--rows f16: narrow with round-to-nearest-even, or with the reference's float4_to_fp16 "
+                         "(truncating, subnormals flushed)")
     ap.add_argument("--strategy", choices=["l2", "cosine", "ip"], default="l2")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
@@ -155,7 +158,7 @@ def main():
         full_image = ix_full.export(rows=True)          # host copy of the unsharded index for the parity sample
 
     if args.rows == "f16":
-        ix16 = ix_full.to_f16(reference_encoder=False)
+        ix16 = ix_full.to_f16(reference_encoder=(args.f16_encoder == "reference"))
         ix_full.close()
         ix_full = ix16
     strategy = {"l2": 1, "cosine": 2, "ip": 3}[args.strategy]

@@ -1355,7 +1355,9 @@ k_query_norms(const float *__restrict__ queries, uint32_t nq, int dim, float *__
  * Persistent kernel: every wave pulls work items (list, 64-row tile, query group)
  * from a global counter.  block = 256 (4 independent waves, 16 KiB LDS tile each).
  */
-template <int R, int CH, bool H16>
+/* H16: 0 = float4 rows, 1 = fp16 rows decoded like fp16_to_float incl. the subnormal quirk (Q20), 2 = fp16 rows
+ * of a mirror that holds no subnormal (the hardware conversion alone is exact there) */
+template <int R, int CH, int H16>
 __global__ __launch_bounds__(64, (H16 ? 4 : (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD))) void
 k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ cand_off,
 				   const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
@@ -1463,7 +1465,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 					constexpr int p = decltype(pc)::value;
 					float		x[8];
 
-					decode8(raw[p], x);
+					decode8<H16 == 1>(raw[p], x);
 					swait2(qa0, qa1);
 					sload2x16_at<(8 * p + 2) * 64>(qb0, qb1, qs);
 					acc.step(qa0, x[0]);
@@ -1867,6 +1869,7 @@ struct ndbhip_ivf
 	bool		loaded = false;
 	bool		sharded = false;		/* some list is not held here */
 	bool		f16 = false;			/* rows held as fp16 (halfvec column): d_vecs points at uint16 data */
+	bool		f16_sub = true;			/* ... and some element is an fp16 subnormal (decode needs the Q20 fix) */
 	/* aminsert: entries appended since the last repack (flushed before the next search) */
 	std::vector<int> pend_list;
 	std::vector<float> pend_rows;
@@ -2064,6 +2067,46 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 	return NDBHIP_OK;
 }
 
+/* does any element have a zero exponent and a non-zero mantissa? (sets *flag) */
+__global__ __launch_bounds__(256) void
+k_f16_has_subnormal(const uint16_t *__restrict__ v, size_t n, int *__restrict__ flag)
+{
+	size_t		i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	bool		sub = false;
+
+	for (; i < n; i += (size_t) gridDim.x * 256)
+	{
+		const uint32_t h = v[i];
+
+		sub = sub || ((h & 0x7C00u) == 0u && (h & 0x03FFu) != 0u);
+	}
+	if (__syncthreads_or(sub) && threadIdx.x == 0)
+		*flag = 1;
+}
+
+/* fp16 mirrors: look once whether the Q20 subnormal fix can ever matter for these rows */
+static int
+ivf_note_f16_subnormals(ndbhip_ivf *ix)
+{
+	ix->f16_sub = true;
+	if (!ix->f16 || ix->nrows <= 0)
+		return 0;
+	int		   *d_flag = nullptr;
+	int			flag = 0;
+	const size_t n = (size_t) ix->nrows * ix->dim;
+
+	HIP_TRY(hipMalloc((void **) &d_flag, sizeof(int)));
+	HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), g.stream));
+	hipLaunchKernelGGL(k_f16_has_subnormal, dim3((unsigned) std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0,
+					   g.stream, (const uint16_t *) ix->d_vecs, n, d_flag);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_flag));
+	ix->f16_sub = flag != 0;
+	return 0;
+}
+
 /* halfvec column: rows as IEEE fp16 images (uint16), decoded on the fly exactly like fp16_to_float */
 extern "C" int
 ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
@@ -2100,7 +2143,7 @@ ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owne
 	ix->nrows = nrows;
 	ix->f16 = true;
 	ix->loaded = true;
-	return NDBHIP_OK;
+	return ivf_note_f16_subnormals(ix);
 }
 
 extern "C" int
@@ -2653,7 +2696,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 							   ix->dim, ix->w_qnorm);
 		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
-#define LAUNCH_GROUPED(RR, CC, GRID) LAUNCH_GROUPED_H(RR, CC, false, GRID)
+#define LAUNCH_GROUPED(RR, CC, GRID) LAUNCH_GROUPED_H(RR, CC, 0, GRID)
 #define LAUNCH_GROUPED_H(RR, CC, HH, GRID)                                                                       \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_scan_grouped<RR, CC, HH>), GRID, dim3(64), 0, g.stream, d,    \
 						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, lco, npr,           \
@@ -2664,12 +2707,24 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		{
 			const dim3	g16(g.num_cus * 16);	/* 8 KiB tile, 4 waves per SIMD */
 
-			if (R == R_IVF_IP)
-				LAUNCH_GROUPED_H(R_IVF_IP, 32, true, g16);
-			else if (R == R_IVF_COS)
-				LAUNCH_GROUPED_H(R_IVF_COS, 32, true, g16);
+			if (ix->f16_sub)
+			{
+				if (R == R_IVF_IP)
+					LAUNCH_GROUPED_H(R_IVF_IP, 32, 1, g16);
+				else if (R == R_IVF_COS)
+					LAUNCH_GROUPED_H(R_IVF_COS, 32, 1, g16);
+				else
+					LAUNCH_GROUPED_H(R_IVF_L2, 32, 1, g16);
+			}
 			else
-				LAUNCH_GROUPED_H(R_IVF_L2, 32, true, g16);
+			{
+				if (R == R_IVF_IP)
+					LAUNCH_GROUPED_H(R_IVF_IP, 32, 2, g16);
+				else if (R == R_IVF_COS)
+					LAUNCH_GROUPED_H(R_IVF_COS, 32, 2, g16);
+				else
+					LAUNCH_GROUPED_H(R_IVF_L2, 32, 2, g16);
+			}
 		}
 		else if (g_gchunk == 32)
 		{
@@ -4270,6 +4325,7 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = nrows;
 	ix->loaded = true;
+	ix->f16_sub = src->f16_sub;	/* a shard holds a subset of the source's rows */
 	*out = ix;
 	return NDBHIP_OK;
 }
@@ -4349,7 +4405,7 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	ix->f16 = true;
 	ix->loaded = true;
 	*out = ix;
-	return NDBHIP_OK;
+	return ivf_note_f16_subnormals(ix);	/* the reference's encoder flushes them; round-to-nearest may not */
 }
 
 extern "C" int

@@ -266,7 +266,9 @@ h2f_ref(uint32_t h16)
 	return ((h16 & 0x7c00u) == 0u && (h16 & 0x03ffu) != 0u) ? f * 0x1p-10f : f;
 }
 
-/* 8 halves (one 16-byte piece) -> 8 floats, element order preserved */
+/* 8 halves (one 16-byte piece) -> 8 floats, element order preserved.  SUBFIX = false: the mirror is known
+ * to hold no fp16 subnormal (checked once at load), so the hardware conversion alone IS fp16_to_float */
+template <bool SUBFIX = true>
 __device__ __forceinline__ void
 decode8(const float4 &raw, float (&out)[8])
 {
@@ -276,8 +278,16 @@ decode8(const float4 &raw, float (&out)[8])
 #pragma unroll
 	for (int i = 0; i < 4; i++)
 	{
-		out[2 * i] = h2f_ref(w[i] & 0xFFFFu);
-		out[2 * i + 1] = h2f_ref(w[i] >> 16);
+		if (SUBFIX)
+		{
+			out[2 * i] = h2f_ref(w[i] & 0xFFFFu);
+			out[2 * i + 1] = h2f_ref(w[i] >> 16);
+		}
+		else
+		{
+			out[2 * i] = __half2float(__ushort_as_half((unsigned short) (w[i] & 0xFFFFu)));
+			out[2 * i + 1] = __half2float(__ushort_as_half((unsigned short) (w[i] >> 16)));
+		}
 	}
 }
 
