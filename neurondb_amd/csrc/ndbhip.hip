@@ -6357,6 +6357,7 @@ struct ndbhip_hnsw
 	uint32_t   *d_nbrs = nullptr;
 	uint64_t   *d_tids = nullptr;
 	uint8_t    *d_dead = nullptr;		/* [nblocks] line pointer marked dead by bulkdelete (allocated on first use) */
+	uint32_t	cap_blocks = 0;			/* blocks the dense arrays have room for (hnswinsert grows them geometrically) */
 	bool		loaded = false;
 	bool		dense = false;			/* neighbour slots in the 16-level dense layout (device-built graphs) */
 	/* host-call workspace */
@@ -6394,6 +6395,7 @@ hnsw_free_dev(ndbhip_hnsw *h)
 	for (void *p : ptrs)
 		if (p) (void) hipFree(p);
 	h->d_dead = nullptr;
+	h->cap_blocks = 0;
 	h->d_vecs = nullptr; h->d_levels = nullptr; h->d_ncount = nullptr;
 	h->d_nbr_off = nullptr; h->d_nbrs = nullptr; h->d_tids = nullptr;
 	h->loaded = false;
@@ -6456,6 +6458,7 @@ ndbhip_hnsw_load(ndbhip_hnsw *h, uint32_t nblocks, const float *vecs, const int3
 	HIP_TRY(hipMemcpyAsync(h->d_tids, t64.data(), (size_t) nblocks * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	h->nblocks = nblocks;
+	h->cap_blocks = nblocks;
 	h->entry_point = entry_point;
 	h->entry_level = entry_level;
 	h->loaded = true;
@@ -6500,46 +6503,55 @@ hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, ui
 		HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
 		HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
 		HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
+		h->cap_blocks = nb;
 	}
 	else
 	{
-		/* the relation grows by n pages: move the mirror into arrays of the new size */
+		/* the relation grows by n pages; the arrays grow geometrically so that a stream of single-row
+		 * hnswinsert calls does not copy the graph every time */
 		int			rc = hnsw_densify(h);
 
 		if (rc)
 			return rc;
 		const uint32_t ob = base + 1;
-		float	   *nv = nullptr;
-		int		   *nl = nullptr;
-		int16_t    *nc = nullptr;
-		uint32_t   *nn = nullptr;
-		uint64_t   *nt = nullptr;
 
-		HIP_TRY(hipMalloc((void **) &nv, (size_t) nb * h->dim * sizeof(float)));
-		HIP_TRY(hipMalloc((void **) &nl, (size_t) nb * sizeof(int)));
-		HIP_TRY(hipMalloc((void **) &nc, (size_t) nb * 16 * sizeof(int16_t)));
-		HIP_TRY(hipMalloc((void **) &nn, (size_t) nb * stride * sizeof(uint32_t)));
-		HIP_TRY(hipMalloc((void **) &nt, (size_t) nb * sizeof(uint64_t)));
-		HIP_TRY(hipMemcpyAsync(nv, h->d_vecs, (size_t) ob * h->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(nl, h->d_levels, (size_t) ob * sizeof(int), hipMemcpyDeviceToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(nc, h->d_ncount, (size_t) ob * 16 * sizeof(int16_t), hipMemcpyDeviceToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(nn, h->d_nbrs, (size_t) ob * stride * sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(nt, h->d_tids, (size_t) ob * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
-		if (h->d_dead)
+		if (h->cap_blocks < nb)
 		{
-			uint8_t    *nd = nullptr;
+			const uint64_t want = std::max<uint64_t>(nb, (uint64_t) h->cap_blocks + h->cap_blocks / 2 + 1024);
+			const uint32_t cap = (uint32_t) std::min<uint64_t>(want, 0xFFFFFFF0ull);
+			float	   *nv = nullptr;
+			int		   *nl = nullptr;
+			int16_t    *nc = nullptr;
+			uint32_t   *nn = nullptr;
+			uint64_t   *nt = nullptr;
 
-			HIP_TRY(hipMalloc((void **) &nd, (size_t) nb));
-			HIP_TRY(hipMemsetAsync(nd, 0, (size_t) nb, g.stream));
-			HIP_TRY(hipMemcpyAsync(nd, h->d_dead, (size_t) ob, hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMalloc((void **) &nv, (size_t) cap * h->dim * sizeof(float)));
+			HIP_TRY(hipMalloc((void **) &nl, (size_t) cap * sizeof(int)));
+			HIP_TRY(hipMalloc((void **) &nc, (size_t) cap * 16 * sizeof(int16_t)));
+			HIP_TRY(hipMalloc((void **) &nn, (size_t) cap * stride * sizeof(uint32_t)));
+			HIP_TRY(hipMalloc((void **) &nt, (size_t) cap * sizeof(uint64_t)));
+			HIP_TRY(hipMemcpyAsync(nv, h->d_vecs, (size_t) ob * h->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(nl, h->d_levels, (size_t) ob * sizeof(int), hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(nc, h->d_ncount, (size_t) ob * 16 * sizeof(int16_t), hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(nn, h->d_nbrs, (size_t) ob * stride * sizeof(uint32_t), hipMemcpyDeviceToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(nt, h->d_tids, (size_t) ob * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+			if (h->d_dead)
+			{
+				uint8_t    *nd = nullptr;
+
+				HIP_TRY(hipMalloc((void **) &nd, (size_t) cap));
+				HIP_TRY(hipMemsetAsync(nd, 0, (size_t) cap, g.stream));
+				HIP_TRY(hipMemcpyAsync(nd, h->d_dead, (size_t) ob, hipMemcpyDeviceToDevice, g.stream));
+				HIP_TRY(hipStreamSynchronize(g.stream));
+				HIP_TRY(hipFree(h->d_dead));
+				h->d_dead = nd;
+			}
 			HIP_TRY(hipStreamSynchronize(g.stream));
-			HIP_TRY(hipFree(h->d_dead));
-			h->d_dead = nd;
+			HIP_TRY(hipFree(h->d_vecs)); HIP_TRY(hipFree(h->d_levels)); HIP_TRY(hipFree(h->d_ncount));
+			HIP_TRY(hipFree(h->d_nbrs)); HIP_TRY(hipFree(h->d_tids));
+			h->d_vecs = nv; h->d_levels = nl; h->d_ncount = nc; h->d_nbrs = nn; h->d_tids = nt;
+			h->cap_blocks = cap;
 		}
-		HIP_TRY(hipStreamSynchronize(g.stream));
-		HIP_TRY(hipFree(h->d_vecs)); HIP_TRY(hipFree(h->d_levels)); HIP_TRY(hipFree(h->d_ncount));
-		HIP_TRY(hipFree(h->d_nbrs)); HIP_TRY(hipFree(h->d_tids));
-		h->d_vecs = nv; h->d_levels = nl; h->d_ncount = nc; h->d_nbrs = nn; h->d_tids = nt;
 		entry[0] = h->entry_point;
 		entry[1] = (uint32_t) h->entry_level;
 	}
