@@ -21,6 +21,13 @@
  *   - HIP is initialised lazily by ndbhip_init() in the calling process, never
  *     at library load (PostgreSQL loads the library pre-fork:
  *     src/worker/worker_init.c:77-84).
+ *   - the library serves ONE thread per process (a PostgreSQL backend is single-
+ *     threaded): the runtime context, the mode switches (ndbhip_set_scan_mode,
+ *     ndbhip_hnsw_set_*_mode) and a mirror's scratch buffers are process-wide /
+ *     per-mirror state without locks.  Several backends = several processes, each
+ *     with its own context and mirrors.
+ *   - a failing call releases what it had built only as far as cheap; after
+ *     NDBHIP_ERR_HIP / NDBHIP_ERR_NOMEM destroy the mirror and rebuild it.
  *
  * Heap TIDs cross the boundary as PostgreSQL ItemPointerData images
  * (6 bytes: bi_hi, bi_lo, ip_posid, each little-endian uint16).  On the device
