@@ -366,6 +366,10 @@ int			ndbhip_hnsw_load_pages(ndbhip_hnsw **out, const uint8_t *pages, uint32_t n
 int			ndbhip_hnsw_write_pages(const ndbhip_hnsw *g, int ef_construction, int ef_search, uint8_t *pages,
 									uint32_t nblocks_cap, uint32_t *nblocks_out);
 int			ndbhip_hnsw_shape(const ndbhip_hnsw *g, int *dim, int *m);
+/* efConstruction / efSearch of the meta page (hnsw_am.c:108-120; defaults 200 / 64): taken from the pages by
+ * ndbhip_hnsw_load_pages, from the argument by a build, and read back by the AM callbacks of ndb_am.h */
+int			ndbhip_hnsw_get_meta(const ndbhip_hnsw *g, int *ef_construction, int *ef_search);
+int			ndbhip_hnsw_set_meta(ndbhip_hnsw *g, int ef_construction, int ef_search);
 /* the rest of the mirror ndbhip_hnsw_export does not return: vectors [nblocks*dim], heapPtrs [nblocks*6],
  * dead flags [nblocks] (each may be NULL); ndbhip_hnsw_set_dead_flags restores the latter after a load */
 int			ndbhip_hnsw_export_rows(const ndbhip_hnsw *g, float *vecs, uint8_t *tids6, uint8_t *dead);

@@ -136,6 +136,8 @@ def lib():
         "ndbhip_hnsw_pages_pack": (i, [i, i, i, i, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i, vp, C.c_uint32]),
         "ndbhip_hnsw_load_pages": (i, [C.POINTER(vp), vp, C.c_uint32]),
         "ndbhip_hnsw_write_pages": (i, [vp, i, i, vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "ndbhip_hnsw_get_meta": (i, [vp, C.POINTER(i), C.POINTER(i)]),
+        "ndbhip_hnsw_set_meta": (i, [vp, i, i]),
         "ndbhip_hnsw_shape": (i, [vp, C.POINTER(i), C.POINTER(i)]),
         "ndbhip_hnsw_export_rows": (i, [vp, vp, vp, vp]),
         "ndbhip_hnsw_set_dead_flags": (i, [vp, vp]),

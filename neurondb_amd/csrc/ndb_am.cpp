@@ -261,8 +261,15 @@ ndb_hnswrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys, const 
 	so->currentResult = 0;
 	so->resultCount = 0;
 	so->strategy = norderbys > 0 && orderbys ? orderbys[0].sk_strategy : 1;	/* :918-921 */
-	/* :923-936: the GUC when positive, else the meta page's efSearch (the mirror keeps the default) */
-	so->efSearch = guc_hnsw_ef_search > 0 ? guc_hnsw_ef_search : HNSW_DEFAULT_EF_SEARCH;
+	/* :923-936: the GUC when positive, else the meta page's efSearch */
+	so->efSearch = guc_hnsw_ef_search;
+	if (so->efSearch <= 0)
+	{
+		int			efs = HNSW_DEFAULT_EF_SEARCH;
+
+		(void) ndbhip_hnsw_get_meta((ndbhip_hnsw *) scan->indexRelation, nullptr, &efs);
+		so->efSearch = efs;
+	}
 	if (norderbys > 0 && orderbys && orderbys[0].sk_argument)
 	{
 		int			rc = take_query(so, orderbys, norderbys);	/* :941-971 */
@@ -393,8 +400,10 @@ ndb_hnswinsert(ndbhip_hnsw *index, const void *value, size_t value_len, int valu
 	if ((int) row.size() != dim)
 		return ndbhip_pages_fail(NDBHIP_ERR_INVALID, "hnsw: vector dimension does not match the index");
 	const int32_t lv = level;
+	int			efc = 200;		/* HNSW_DEFAULT_EF_CONSTRUCTION; the mirror carries meta->efConstruction (:2369-2378) */
 
-	rc = ndbhip_hnsw_insert(index, row.data(), (const uint8_t *) ht_ctid, 1, &lv, 200 /* HNSW_DEFAULT_EF_CONSTRUCTION */);
+	(void) ndbhip_hnsw_get_meta(index, &efc, nullptr);
+	rc = ndbhip_hnsw_insert(index, row.data(), (const uint8_t *) ht_ctid, 1, &lv, efc);
 	return rc ? rc : 1;
 }
 

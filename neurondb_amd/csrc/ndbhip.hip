@@ -6358,6 +6358,8 @@ struct ndbhip_hnsw
 	uint64_t   *d_tids = nullptr;
 	uint8_t    *d_dead = nullptr;		/* [nblocks] line pointer marked dead by bulkdelete (allocated on first use) */
 	uint32_t	cap_blocks = 0;			/* blocks the dense arrays have room for (hnswinsert grows them geometrically) */
+	int			ef_construction = 200;	/* HnswMetaPageData.efConstruction / efSearch (hnsw_am.c:108-120), defaults :82-83 */
+	int			ef_search = 64;
 	bool		loaded = false;
 	bool		dense = false;			/* neighbour slots in the 16-level dense layout (device-built graphs) */
 	/* host-call workspace */
@@ -6735,6 +6737,7 @@ hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, ui
 	}
 	HIP_TRY(hipFree(d_lv_in));
 	HIP_TRY(hipFree(d_entry));
+	h->ef_construction = ef_construction;
 	h->nblocks = nb;
 	h->entry_point = entry[0];
 	h->entry_level = (int) entry[1];
@@ -7060,6 +7063,29 @@ ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *rem
 		*removed = (int64_t) victims.size();
 	HIP_TRY(hipFree(d_set));
 	HIP_TRY(hipFree(d_hit));
+	return NDBHIP_OK;
+}
+
+/* the two search-width fields of the meta page the AM callbacks read (hnsw_am.c:923-936, 2369-2378) */
+extern "C" int
+ndbhip_hnsw_get_meta(const ndbhip_hnsw *h, int *ef_construction, int *ef_search)
+{
+	if (!h)
+		return fail(NDBHIP_ERR_INVALID, "graph is NULL");
+	if (ef_construction) *ef_construction = h->ef_construction;
+	if (ef_search) *ef_search = h->ef_search;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_set_meta(ndbhip_hnsw *h, int ef_construction, int ef_search)
+{
+	if (!h)
+		return fail(NDBHIP_ERR_INVALID, "graph is NULL");
+	if (ef_construction < 4 || ef_construction > NDBHIP_MAX_EF || ef_search < 4 || ef_search > NDBHIP_MAX_EF)
+		return fail(NDBHIP_ERR_INVALID, "ef_construction / ef_search out of range 4..%d", NDBHIP_MAX_EF);
+	h->ef_construction = ef_construction;
+	h->ef_search = ef_search;
 	return NDBHIP_OK;
 }
 

@@ -697,6 +697,9 @@ ndbhip_hnsw_load_pages(ndbhip_hnsw **out, const uint8_t *pages, uint32_t nblocks
 						  packed.empty() ? nullptr : packed.data(), tids.data(), info.entry_point, info.entry_level);
 	if (!rc)
 		rc = ndbhip_hnsw_set_dead_flags(h, dead.data());
+	if (!rc && info.ef_construction >= 4 && info.ef_construction <= NDBHIP_MAX_EF && info.ef_search >= 4 &&
+		info.ef_search <= NDBHIP_MAX_EF)
+		rc = ndbhip_hnsw_set_meta(h, info.ef_construction, info.ef_search);
 	if (rc)
 	{
 		ndbhip_hnsw_destroy(h);

@@ -131,6 +131,15 @@ def test_hnsw_scan_callbacks(gucs):
     gucs("neurondb.hnsw_k", 4)
     run(1, vector_datum(q))
     assert [x[0] for x in _drain(L, L.ndb_hnswgettuple, scan)] == expect(q, 1, 16, 4)
+    # GUC <= 0: the meta page's efSearch decides (:923-936); the mirror carries it
+    gucs("neurondb.hnsw_ef_search", 0)
+    _lib.check(L.ndbhip_hnsw_set_meta(ix._h, 40, 24))
+    efc, efs = C.c_int(), C.c_int()
+    _lib.check(L.ndbhip_hnsw_get_meta(ix._h, C.byref(efc), C.byref(efs)))
+    assert (efc.value, efs.value) == (40, 24)
+    run(1, vector_datum(q))
+    assert [x[0] for x in _drain(L, L.ndb_hnswgettuple, scan)] == expect(q, 1, 24, 4)
+    gucs("neurondb.hnsw_ef_search", 16)
     # an operator strategy the AM does not know is hnswComputeDistance's ERROR (:1339-1343)
     run(4, vector_datum(q))
     assert L.ndb_hnswgettuple(scan, 1) < 0

@@ -293,6 +293,11 @@ def test_hnsw_relation_pages_round_trip():
                                               a["entry_level"], 6, efc=24, efs=32)
     ix = HnswIndex.load_pages(img)
     assert (ix.dim, ix.m, ix.nblocks) == (16, 6, a["nblocks"])
+    import ctypes as C
+    from neurondb_amd import _lib
+    efc, efs = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().ndbhip_hnsw_get_meta(ix._h, C.byref(efc), C.byref(efs)))
+    assert (efc.value, efs.value) == (24, 32)               # HnswMetaPageData.efConstruction / efSearch
     # From here on the model is the oracle over what the PAGES hold: the reference's writes above a node's
     # own level (Q12/Q21) land outside the item — on a real page outside the buffer — so the image has no
     # such slots, while the oracle's in-memory build kept them and later inserts would read them back.
