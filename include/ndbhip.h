@@ -155,6 +155,10 @@ int			ndbhip_ivf_export(const ndbhip_ivf *ix, float *centroids, int64_t *list_le
 							  uint8_t *tids6);
 int			ndbhip_ivf_ncentroids(const ndbhip_ivf *ix);
 int			ndbhip_ivf_shape(const ndbhip_ivf *ix, int *dim, int *nlists);
+/* IvfMetaPageData.nprobe (ivf_am.c:75-89): set from the pages by ndbhip_ivf_load_pages, default 10; what
+ * ivfrescan uses (:1487-1513) */
+int			ndbhip_ivf_get_nprobe(const ndbhip_ivf *ix, int *nprobe);
+int			ndbhip_ivf_set_nprobe(ndbhip_ivf *ix, int nprobe);
 
 /* ------------------------------------------------------------------ */
 /* Index pages <-> mirror.  PostgreSQL-free codec of the ivf

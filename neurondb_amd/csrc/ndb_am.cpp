@@ -165,8 +165,11 @@ ndb_ivfrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys, const n
 	 */
 	if (guc_ref_compat)
 	{
+		int			np = IVF_DEFAULT_NPROBE;
+
+		(void) ndbhip_ivf_get_nprobe((ndbhip_ivf *) scan->indexRelation, &np);	/* reloptions / meta->nprobe */
 		so->strategy = 1;
-		so->nprobe = IVF_DEFAULT_NPROBE;
+		so->nprobe = np > 0 ? np : IVF_DEFAULT_NPROBE;	/* :1512-1513 */
 		so->k = IVF_DEFAULT_K;
 	}
 	else

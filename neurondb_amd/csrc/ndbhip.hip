@@ -1870,6 +1870,7 @@ struct ndbhip_ivf
 	bool		sharded = false;		/* some list is not held here */
 	bool		f16 = false;			/* rows held as fp16 (halfvec column): d_vecs points at uint16 data */
 	bool		f16_sub = true;			/* ... and some element is an fp16 subnormal (decode needs the Q20 fix) */
+	int			meta_nprobe = 10;		/* IvfMetaPageData.nprobe (ivf_am.c:75-89), IVF_DEFAULT_NPROBE */
 	/* aminsert: entries appended since the last repack (flushed before the next search) */
 	std::vector<int> pend_list;
 	std::vector<float> pend_rows;
@@ -4406,6 +4407,25 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	ix->loaded = true;
 	*out = ix;
 	return ivf_note_f16_subnormals(ix);	/* the reference's encoder flushes them; round-to-nearest may not */
+}
+
+/* nprobe as the meta page / reloptions carry it: what ivfrescan reads (ivf_am.c:1487-1513) */
+extern "C" int
+ndbhip_ivf_get_nprobe(const ndbhip_ivf *ix, int *nprobe)
+{
+	if (!ix || !nprobe)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	*nprobe = ix->meta_nprobe;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_set_nprobe(ndbhip_ivf *ix, int nprobe)
+{
+	if (!ix)
+		return fail(NDBHIP_ERR_INVALID, "index is NULL");
+	ix->meta_nprobe = nprobe;	/* <= 0 is legal on the page: ivfrescan then takes the default (:1512-1513) */
+	return NDBHIP_OK;
 }
 
 extern "C" int

@@ -255,6 +255,8 @@ ndbhip_ivf_load_pages(ndbhip_ivf **out, const uint8_t *pages, uint32_t nblocks)
 	rc = ndbhip_ivf_set_centroids(ix, cent.data(), info.ncentroids);
 	if (!rc)
 		rc = ndbhip_ivf_load(ix, ll.data(), nullptr, rows.data(), tids.data(), info.live_rows);
+	if (!rc)
+		rc = ndbhip_ivf_set_nprobe(ix, info.nprobe);
 	if (rc)
 	{
 		ndbhip_ivf_destroy(ix);

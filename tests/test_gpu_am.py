@@ -86,6 +86,12 @@ def test_ivf_scan_callbacks(gucs):
     gucs("neurondb.ref_compat", 1)
     got = run(2, vector_datum(q))
     assert [g[0] for g in got] == [e[0] for e in expect(q, 1, 10, 10, cap=100)]
+    _lib.check(L.ndbhip_ivf_set_nprobe(ix._h, 3))           # meta->nprobe / the reloption (:1487-1513)
+    got = run(1, vector_datum(q))
+    assert [g[0] for g in got] == [e[0] for e in expect(q, 1, 3, 10, cap=100)]
+    _lib.check(L.ndbhip_ivf_set_nprobe(ix._h, 0))           # <= 0 on the page: the default
+    got = run(1, vector_datum(q))
+    assert [g[0] for g in got] == [e[0] for e in expect(q, 1, 10, 10, cap=100)]
     gucs("neurondb.ref_compat", 0)
     # wrong dimension: "does not match index dimension" -> no tuples (:1961-1972); NULL argument keeps the query
     assert run(1, vector_datum(q[:32])) == []
