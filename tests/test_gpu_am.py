@@ -228,3 +228,15 @@ def test_hnsw_insert_and_bulkdelete_callbacks():
         check(model, ix, q, strategy, 32, 10)
     _lib.check(L.ndb_hnswbulkdelete(ix._h, BULKDELETE_CALLBACK(cb), None, C.byref(removed)))
     assert removed.value == 0                                 # dead line pointers are not offered again
+
+
+def test_plain_c_program_drives_the_abi():
+    """examples/c_demo.c — ambuild, the AM scan callbacks, aminsert and ambulkdelete for both AMs from a C
+    program that links libndbhip.so and nothing else (no Python, no torch in that process)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "neurondb_amd", "lib", "c_demo")
+    assert os.path.exists(exe), "build it: make -C neurondb_amd/csrc"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "c_demo: OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
