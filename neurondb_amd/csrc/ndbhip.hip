@@ -1363,7 +1363,8 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				   const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
-				   float *__restrict__ dist, uint32_t stride, const float *__restrict__ qnorm)
+				   float *__restrict__ dist, uint32_t stride, const float *__restrict__ qnorm,
+				   uint32_t *__restrict__ tmin, uint32_t tstride)
 {
 	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x & 63;
@@ -1532,8 +1533,19 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				const uint32_t nrow = co[pp + 1] - co[pp];	/* may be capped below len (ivf_am.c:1743) */
 				const uint32_t la = loc_cand_off[(size_t) qid * (npr + 1) + pp];
 
+				const float dv = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
+
 				if (ridx < nrow)
-					dist[(size_t) qid * stride + la + ridx] = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
+					dist[(size_t) qid * stride + la + ridx] = dv;
+				/* the smallest order key of this (query, 64-candidate tile): k_ivf_topk bounds the k-th
+				 * candidate with these and then only opens the tiles that can hold one */
+				uint32_t	mk = ridx < nrow ? ndb_key_from_bits(__float_as_uint(dv)) : 0xFFFFFFFFu;
+
+#pragma unroll
+				for (int off = 32; off > 0; off >>= 1)
+					mk = min(mk, (uint32_t) __shfl_xor((int) mk, off, 64));
+				if (lane == 0 && t * 64u < nrow)	/* a tile wholly beyond a capped list (:1743) has no slot */
+					tmin[(size_t) qid * tstride + (la >> 6) + pp + t] = mk;
 			}
 		}
 	}
@@ -1620,7 +1632,7 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		   const uint32_t *__restrict__ loc_cand_off, int npr, const float *__restrict__ dist, uint32_t stride, uint32_t k, int partial,
 		   ndbhip_cand *__restrict__ out_cand, int *__restrict__ out_ncand, int64_t *__restrict__ out_total,
 		   uint64_t *__restrict__ out_tids, float *__restrict__ out_dist, int *__restrict__ out_count,
-		   uint32_t nq)
+		   uint32_t nq, const uint32_t *__restrict__ tmin, uint32_t tstride)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	const uint32_t ecap = topk_entry_cap(k);
@@ -1659,7 +1671,105 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		return ix.tids[ix.loc_off[L] + (i - lco[p])];
 	};
 
-	if (k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
+	if (tmin && gridDim.y == 1 && k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
+	{
+		/*
+		 * Tile path (the grouped scan left the smallest key of every 64-candidate tile): the k-th smallest
+		 * of the thread minima over TILE minima bounds the k-th candidate just like the minima over
+		 * candidates do, and a tile whose minimum is above the bound holds nothing to gather — so the
+		 * distance buffer is only read where it matters (a few tiles of 256 B instead of all of it twice).
+		 */
+		const uint32_t *tm = tmin + (size_t) q * tstride;
+		const uint32_t nslots = min(tstride, (all >> 6) + (uint32_t) npr + 1u);
+		uint32_t	mn = 0xFFFFFFFFu;
+
+		for (uint32_t sidx = tid; sidx < nslots; sidx += 256)
+			mn = min(mn, tm[sidx]);
+		const uint32_t nth = (uint32_t) __syncthreads_count(mn != 0xFFFFFFFFu);
+
+		s.fs.comp[tid] = ((uint64_t) mn << 32) | tid;
+		s.fs.perm[tid] = tid;
+		block_bitonic_sort(s.fs.comp, s.fs.perm, 256);
+		const uint32_t U = (nth >= k) ? (uint32_t) (s.fs.comp[k - 1] >> 32) : 0xFFFFFFFEu;	/* 0xFFFFFFFF = empty slot */
+		uint32_t   *tlist = s.fs.curpos;	/* tiles to open (curpos is replay scratch, free until then) */
+
+		__syncthreads();
+		if (tid == 0)
+		{
+			s.sh[0] = 0;		/* gathered candidates */
+			s.sh[1] = 0;		/* tiles to open */
+		}
+		__syncthreads();
+		for (uint32_t sidx = tid; sidx < nslots; sidx += 256)
+			if (tm[sidx] <= U)
+			{
+				const uint32_t at = atomicAdd(&s.sh[1], 1u);
+
+				if (at < NDB_TOPK_FAST_CAP)
+					tlist[at] = sidx;
+			}
+		__syncthreads();
+		const uint32_t ntl = s.sh[1];
+
+		if (ntl <= NDB_TOPK_FAST_CAP)
+		{
+			const uint32_t lane = tid & 63u, wave = tid >> 6;
+
+			for (uint32_t ti = wave; ti < ntl; ti += 4)
+			{
+				const uint32_t sidx = tlist[ti];
+				/* slot -> (probe, tile): the largest p with (lco[p] >> 6) + p <= slot */
+				uint32_t	lo2 = 0, hi2 = (uint32_t) npr;
+
+				while (hi2 - lo2 > 1)
+				{
+					const uint32_t mid = (lo2 + hi2) >> 1;
+
+					if ((lco[mid] >> 6) + mid <= sidx)
+						lo2 = mid;
+					else
+						hi2 = mid;
+				}
+				const uint32_t base = lco[lo2] + ((sidx - ((lco[lo2] >> 6) + lo2)) << 6);
+				const uint32_t i = base + lane;
+
+				if (base < lco[lo2 + 1] && i < lco[lo2 + 1])
+				{
+					const uint32_t b0 = __float_as_uint(d[i]);
+
+					if (ndb_key_from_bits(b0) <= U)
+					{
+						const uint32_t slot = atomicAdd(&s.sh[0], 1u);
+
+						if (slot < NDB_TOPK_FAST_CAP)
+						{
+							s.e_bits[slot] = b0;
+							s.e_pos[slot] = i;
+						}
+					}
+				}
+			}
+			__syncthreads();
+			const uint32_t got = s.sh[0];
+
+			__syncthreads();
+			if (got <= NDB_TOPK_FAST_CAP)
+			{
+				ns = got;
+				have = true;
+				for (uint32_t j = tid; j < ns; j += 256)
+				{
+					uint32_t	gpos;
+
+					s.e_id[j] = tid_of(s.e_pos[j], gpos);
+					s.e_pos[j] = gpos;
+				}
+				__syncthreads();
+			}
+		}
+		__syncthreads();
+	}
+	else if (k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
 	{
 		/* pass 1: thread minima (4 independent loads in flight per thread) */
 		uint32_t	mn = 0xFFFFFFFFu;
@@ -1889,6 +1999,7 @@ struct ndbhip_ivf
 	PairRec    *w_pairs = nullptr;	size_t w_pairs_n = 0;
 	float	   *w_qblock = nullptr;	size_t w_qblock_n = 0;	/* [groups][dim][16] interleaved queries */
 	float	   *w_qnorm = nullptr;	size_t w_qnorm_n = 0;	/* [nq] sum of squares of every query (cosine) */
+	uint32_t   *w_tmin = nullptr;	size_t w_tmin_n = 0;	/* [nq][tstride] smallest order key per 64-candidate tile */
 	/* split top-k of small batches: per-range records, counts, totals */
 	ndbhip_cand *w_scand = nullptr;	size_t w_scand_n = 0;
 	int		   *w_sncand = nullptr;	size_t w_sncand_n = 0;
@@ -1956,7 +2067,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		ivf_free_rows(ix);
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
-			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal};
+			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2665,6 +2776,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 	/* HOT LOOP 2 */
 	const int	R = ivf_recipe(strategy);
+	/* one slot per (probe, 64-candidate tile): slot = (local offset of the probe >> 6) + probe + tile */
+	const uint32_t tstride = (((stride >> 6) + (uint32_t) npr + 2u) + 63u) & ~63u;
 	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
 		(g_scan_mode == 2 || (g_scan_mode == 0 && nq >= NDB_GROUPED_MIN_NQ));
 
@@ -2695,6 +2808,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (R == R_IVF_COS)
 			hipLaunchKernelGGL(k_query_norms, dim3((nq + 63) / 64), dim3(64), 0, g.stream, d_q, (uint32_t) nq,
 							   ix->dim, ix->w_qnorm);
+		HIP_TRY(hipMemsetAsync(ix->w_tmin, 0xFF, (size_t) nq * tstride * sizeof(uint32_t), g.stream));
 		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
 #define LAUNCH_GROUPED(RR, CC, GRID) LAUNCH_GROUPED_H(RR, CC, 0, GRID)
@@ -2703,7 +2817,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, lco, npr,           \
 						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,   \
-						   stride, (const float *) ix->w_qnorm)
+						   stride, (const float *) ix->w_qnorm, ix->w_tmin, tstride)
 		if (ix->f16)
 		{
 			const dim3	g16(g.num_cus * 16);	/* 8 KiB tile, 4 waves per SIMD */
@@ -2772,7 +2886,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		 */
 		uint32_t	nsplit = 1;
 
-		if (!partial && nq <= 512)
+		if (!partial && nq <= 512 && !grouped)	/* the grouped scan leaves tile minima: one block per query is cheap */
 		{
 			const uint32_t by_work = stride / 2048u;					/* >= 2048 candidates per block */
 			const uint32_t by_merge = 2048u / (3u * (uint32_t) k);		/* records the merge stage sorts in LDS */
@@ -2792,7 +2906,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			hipLaunchKernelGGL(k_ivf_topk, dim3(nq, nsplit), dim3(256), smem, g.stream, d, (const int *) w_probes,
 							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
 							   (uint32_t) k, 1, ix->w_scand, ix->w_sncand, ix->w_stotal, (uint64_t *) nullptr,
-							   (float *) nullptr, (int *) nullptr, (uint32_t) nq);
+							   (float *) nullptr, (int *) nullptr, (uint32_t) nq, (const uint32_t *) nullptr, 0u);
 			hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(256),
 							   topk_smem_bytes(3u * (uint32_t) k * nsplit, (uint32_t) k), g.stream,
 							   (const ndbhip_cand *) ix->w_scand, (const int *) ix->w_sncand,
@@ -2802,7 +2916,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		else
 			hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
 							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
-							   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, (uint32_t) nq);
+							   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, (uint32_t) nq,
+							   grouped ? (const uint32_t *) ix->w_tmin : (const uint32_t *) nullptr, tstride);
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -2867,6 +2982,8 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) qb)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_tmin, ix->w_tmin_n, (size_t) qb * ((((stride >> 6) + (size_t) nprobe + 2) + 63) & ~(size_t) 63)))
+		return NDBHIP_ERR_HIP;
 	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode == 2))
 		if (grow(ix->w_qblock, ix->w_qblock_n,
 				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))
