@@ -1999,6 +1999,7 @@ struct ndbhip_ivf
 	PairRec    *w_pairs = nullptr;	size_t w_pairs_n = 0;
 	float	   *w_qblock = nullptr;	size_t w_qblock_n = 0;	/* [groups][dim][16] interleaved queries */
 	float	   *w_qnorm = nullptr;	size_t w_qnorm_n = 0;	/* [nq] sum of squares of every query (cosine) */
+	float	   *w_cblock = nullptr;	size_t w_cblock_n = 0;	/* centroids interleaved 16 per block (batch centroid scan) */
 	uint32_t   *w_tmin = nullptr;	size_t w_tmin_n = 0;	/* [nq][tstride] smallest order key per 64-candidate tile */
 	/* split top-k of small batches: per-range records, counts, totals */
 	ndbhip_cand *w_scand = nullptr;	size_t w_scand_n = 0;
@@ -2067,7 +2068,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		ivf_free_rows(ix);
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
-			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin};
+			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2726,6 +2727,14 @@ ivf_recipe(int strategy)
 		}                                                                                        \
 	} while (0)
 
+/* defined with the build kernels below; the batch centroid scan of the search reuses them */
+__global__ void k_interleave16(const float *__restrict__ cents, int ncent, int dim, float *__restrict__ cblock);
+template <bool SQRT, int CH>
+__global__ void k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim,
+								 const float *__restrict__ cblock, int ncent, float *__restrict__ part_dist,
+								 int *__restrict__ part_idx, float *__restrict__ all_dist = nullptr,
+								 uint32_t all_stride = 0);
+
 /* queries already on the device; runs select (+ scan + topk when `full`) for one sub-batch */
 static int
 ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr, int k,
@@ -2760,11 +2769,30 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	{
 		/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680); a small batch spreads its
 		 * 64-centroid tiles over more CUs (one wave per block) */
+		if (nq >= 64 && (ix->dim % NDB_CHUNK) == 0 && true)
+		{
+			/* a batch: the same 64 rows x 16 columns engine as the list scan and the build's assignment, the
+			 * queries as rows and the centroids (interleaved 16 per block, 3 MB at 1024 x 768: redone per
+			 * call, 4 us) as the scalar operand; (c - q)^2 == (q - c)^2 exactly */
+			const int	ngroups = (ncmp + NDB_QG - 1) / NDB_QG;
+
+			if (grow(ix->w_cblock, ix->w_cblock_n, (size_t) ngroups * ix->dim * NDB_QG)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_interleave16, dim3((ix->dim + 255) / 256, ngroups), dim3(256), 0, g.stream,
+							   (const float *) d.centroids, ncmp, ix->dim, ix->w_cblock);
+			const dim3	g1((unsigned) ((((size_t) (nq + 63) / 64 + 7) / 8) * 8 * (size_t) ngroups));
+
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), g1, dim3(64), 0, g.stream, d_q,
+							   (uint32_t) nq, ix->dim, (const float *) ix->w_cblock, ncmp, (float *) nullptr,
+							   (int *) nullptr, ix->w_cdist, cstride);
+		}
+		else
+		{
 		const int	rsw = nq <= 16 ? 1 : 4;
 		dim3		grid((ncmp + 64 * rsw - 1) / (64 * rsw), nq);
 
 		hipLaunchKernelGGL(k_rows_scan<R_IVF_L2>, grid, dim3(64 * rsw), 0, g.stream, (const float *) d.centroids,
 						   (uint32_t) ncmp, ix->dim, d_q, ix->w_cdist, cstride);
+		}
 		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
@@ -3709,7 +3737,8 @@ k_interleave16(const float *__restrict__ cents, int ncent, int dim, float *__res
 template <bool SQRT, int CH>
 __global__ __launch_bounds__(64, (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD)) void
 k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const float *__restrict__ cblock,
-				 int ncent, float *__restrict__ part_dist, int *__restrict__ part_idx)
+				 int ncent, float *__restrict__ part_dist, int *__restrict__ part_idx,
+				 float *__restrict__ all_dist, uint32_t all_stride)
 {
 	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x;
@@ -3762,6 +3791,24 @@ k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const 
 		qs += CH * NDB_QG;
 	}
 	swait2(qa0, qa1);
+	if (all_dist)
+	{
+		/* every distance, not the nearest: the query x centroid scan of ivfSelectClusters (rows = queries) */
+		if (r < nrows)
+		{
+#pragma unroll
+			for (int j = 0; j < NDB_QG; j++)
+			{
+				float		d = (j & 1) ? acc.s[j >> 1].y : acc.s[j >> 1].x;
+
+				if (SQRT)
+					d = __builtin_sqrtf(d);
+				if (j < gc)
+					all_dist[(size_t) r * all_stride + c0 + j] = d;
+			}
+		}
+		return;
+	}
 	float		best = FLT_MAX;
 	int			bidx = -1;
 
