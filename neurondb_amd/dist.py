@@ -18,17 +18,23 @@ from ._lib import check, lib
 CAND_WORDS = 2          # one ndbhip_cand = 16 bytes = 2 x int64
 
 
-def partition_lists(list_len, world: int) -> np.ndarray:
-    """Size-balanced list -> rank map (longest-processing-time first). Deterministic:
-    every rank computes the same map from the replicated list lengths."""
+def partition_lists(list_len, world: int, probe_count=None) -> np.ndarray:
+    """Balanced list -> rank map (longest-processing-time first). Deterministic: every rank computes the same
+    map from replicated inputs.  A list costs len x (queries that probe it) per batch, so with `probe_count`
+    (how often each list was probed by a calibration batch, e.g. ndbhip_ivf_select_clusters on recent queries)
+    the WORK is balanced; without it the rows are (popular lists then overload their rank: at 1M x 768,
+    lists = 1024 the 28 k-row list alone is 10 % of a batch's sums)."""
     list_len = np.asarray(list_len, dtype=np.int64)
-    order = np.argsort(-list_len, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
+    weight = list_len.astype(np.float64)
+    if probe_count is not None:
+        weight = weight * (np.asarray(probe_count, dtype=np.float64) + 1.0)
+    order = np.argsort(-weight, kind="stable")
+    load = np.zeros(world, dtype=np.float64)
     owner = np.zeros(len(list_len), dtype=np.int32)
     for l in order:
         r = int(load.argmin())
         owner[l] = r
-        load[r] += list_len[l]
+        load[r] += weight[l]
     return owner
 
 

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU sharded search does per step, timed on ONE GPU (no collectives): cluster selection
+for its query slice, the scan + partial top-k over its 1/N of the lists for all queries, and the replay merge
+of N record sets.  Gives the compute side of the strong-scaling curve that bench.py --gpus N will trace."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from bench import make_data, pack_tids
+
+
+def timed(fn, sync, reps=5):
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import check, lib
+    from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, query_slice
+    dev = torch.device("cuda", 0)
+    _lib.ensure_init(0)
+    check(lib().ndbhip_set_stream(torch.cuda.current_stream().cuda_stream))
+    n, dim, nlists, nprobe, k, nq = 1_000_000, 768, 1024, 32, 10, int(os.environ.get("NQ", 4096))
+    base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
+    q = make_data(nq, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    full = IvfIndex(dim, nlists)
+    full.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
+    _, ll, _, _ = full.export(rows=False)
+    sync = lambda: check(lib().ndbhip_synchronize())
+    ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+    t1 = timed(lambda: full.search_device(q, ot, od, oc, 1, nprobe, k, 0), sync)
+    print(f"N=1: full step {t1:.3f} ms ({nq / t1 * 1e3:.0f} q/s)")
+    qcal = make_data(nq, dim, "clustered", 1024, 0.1, 0x5EED0007, 0x5EEDC0DE, dev)     # calibration batch
+    pc = torch.zeros((nq, nprobe), dtype=torch.int32, device=dev)
+    full.select_clusters_device(qcal, pc, nprobe)
+    sync()
+    pcn = pc.cpu().numpy()
+    cnt = np.bincount(pcn[pcn >= 0].ravel(), minlength=nlists)
+    for world, balanced in ((2, 1), (4, 1), (8, 0), (8, 1)):
+        owner = partition_lists(ll, world, cnt if balanced else None)
+        loads = np.bincount(owner, weights=ll, minlength=world)
+        work = np.bincount(owner, weights=ll * cnt, minlength=world)
+        worst = int(work.argmax())
+        print(f"  partition by {'work' if balanced else 'rows'}: heaviest rank has {work[worst] / work.sum():.3f} of the work")
+        ix = full.shard((owner == worst).astype(np.uint8))
+        buf = ShardedSearchBuffers(nq, k, world, dev, nprobe=nprobe)
+        lo, hi, s = query_slice(nq, world, 0)
+        probes = torch.zeros((nq, nprobe), dtype=torch.int32, device=dev)
+        full.select_clusters_device(q, probes, nprobe)
+        sync()
+        t_sel = timed(lambda: ix.select_clusters_device(q[lo:hi], buf.probes_mine[:hi - lo], nprobe), sync)
+        t_scan = timed(lambda: ix.search_partial_probes_device(q, probes, buf.cand, buf.ncand, buf.total, 1, nprobe, k, 0),
+                       sync)
+        for w in range(world):
+            buf.cand_all[w].copy_(buf.cand)
+            buf.ncand_all[w].copy_(buf.ncand)
+        t_merge = timed(lambda: check(lib().ndbhip_merge_topk_device(
+            buf.cand_all.data_ptr(), buf.ncand_all.data_ptr(), buf.total.data_ptr(), world, nq, k, buf.cap,
+            buf.out_tids.data_ptr(), buf.out_dist.data_ptr(), buf.out_count.data_ptr())), sync)
+        tot = t_sel + t_scan + t_merge
+        print(f"N={world}: heaviest shard holds {loads[worst] / loads.sum():.3f} of the rows; select(slice) {t_sel:.3f} ms, "
+              f"scan+partial top-k {t_scan:.3f} ms, merge {t_merge:.3f} ms -> {tot:.3f} ms compute per step "
+              f"(speed-up {t1 / tot:.2f}, before the two all-gathers)")
+        ix.close()
+
+
+if __name__ == "__main__":
+    main()
