@@ -56,6 +56,8 @@ def parse():
                     help="--rows f16: narrow with round-to-nearest-even, or with the reference's float4_to_fp16 "
                          "(truncating, subnormals flushed)")
     ap.add_argument("--strategy", choices=["l2", "cosine", "ip"], default="l2")
+    ap.add_argument("--shard", choices=["slices", "lists"], default="slices",
+                    help="N > 1: cut heavy lists into per-rank slices (default) or keep lists whole")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
     ap.add_argument("--dist-parity-queries", type=int, default=128,
@@ -122,7 +124,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from neurondb_amd import IvfIndex, _lib
-    from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, sharded_search
+    from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, partition_slices, sharded_search
     from neurondb_amd._lib import check, lib
     _lib.ensure_init(local_rank)
     stream = torch.cuda.current_stream()
@@ -164,10 +166,29 @@ def main():
     strategy = {"l2": 1, "cosine": 2, "ip": 3}[args.strategy]
 
     # ---------------- shard lists over ranks ----------------
-    owner = partition_lists(list_len, world) if world > 1 else np.zeros(nlists, dtype=np.int32)
-    owned = (owner == rank).astype(np.uint8)
+    # Balanced by WORK: a list costs len x (queries probing it).  The probe counts come from a calibration batch
+    # drawn like the queries but with its own seed (a deployment uses recent traffic); every rank computes the
+    # same partition from the same inputs.  Lists too heavy for one rank are cut into slices.
+    shard_info = None
     if use_dist:
-        ix = ix_full.shard(owned)
+        qcal = make_data(nq, dim, args.data, args.components, args.sigma, 0x5EED0007, 0x5EEDC0DE, dev)
+        pcal = torch.zeros((nq, nprobe), dtype=torch.int32, device=dev)
+        ix_full.select_clusters_device(qcal, pcal, nprobe)
+        check(lib().ndbhip_synchronize())
+        pc = pcal.cpu().numpy()
+        cnt = np.bincount(pc[pc >= 0].ravel(), minlength=len(list_len))[:len(list_len)]
+        del qcal, pcal
+        if args.shard == "slices":
+            slo, sln, stl = partition_slices(list_len, world, cnt)
+            ix = ix_full.shard_slices(slo[rank], sln[rank], stl[rank])
+            work = (sln * (cnt[None] + 1.0)).sum(1)
+            shard_info = {"by": "slices", "lists_cut": int(((sln > 0).sum(0) > 1).sum()),
+                          "max_work_share": round(float(work.max() / work.sum()), 4)}
+        else:
+            owner = partition_lists(list_len, world, cnt)
+            ix = ix_full.shard((owner == rank).astype(np.uint8))
+            work = np.bincount(owner, weights=np.asarray(list_len) * (cnt + 1.0), minlength=world)
+            shard_info = {"by": "lists", "max_work_share": round(float(work.max() / work.sum()), 4)}
         ix_full.close()
         ix_full = None
         torch.cuda.empty_cache()
@@ -290,7 +311,10 @@ def main():
             "config": {"workload": f"IVFFlat {n}x{dim} {'fp32' if esz == 4 else 'fp16'} lists={nlists} probes={nprobe} "
                                    f"k={k} {args.strategy.upper()}, "
                                    f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
-                       "sharding": "none" if world == 1 else f"lists over {world} ranks (LPT), RCCL all-gather + merge",
+                       "sharding": "none" if world == 1 else
+                                   f"{'list slices' if args.shard == 'slices' else 'whole lists'} over {world} ranks, "
+                                   f"balanced by calibration-batch work; RCCL all-gather of probes and records + merge",
+                       "shard": shard_info,
                        "data": (f"mixture of {args.components} Gaussians, sigma={args.sigma}" if args.data == "clustered"
                                 else "i.i.d. N(0,1)"),
                        "index_build": f"ndbhip_ivf_build_device: first-10000-row sample, {kmeans_iters} Lloyd iterations "

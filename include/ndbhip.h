@@ -189,6 +189,14 @@ int			ndbhip_ivf_write_pages(const ndbhip_ivf *ix, int nprobe, uint8_t *pages, u
  * per GPU keeps its share); list lengths stay global, so candidate positions —
  * and therefore the merged result — are identical to the unsharded index. */
 int			ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out);
+/* The same for slices: the new mirror holds positions [lo[c], lo[c] + len[c]) of every list c (len 0 = none).
+ * Slices let several ranks share one long, popular list — a list-granular shard cannot scale past the work of
+ * its heaviest list; candidates keep their positions in the reference's candidates[], so the merged result is
+ * the unsharded one.
+ * tail[c] != 0 marks the one rank that takes later appends to list c (ndbhip_ivf_append lands on the list's
+ * tail page); NULL = the rank holding the list's last row, and nobody for an empty list. */
+int			ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const int64_t *len, const uint8_t *tail,
+									ndbhip_ivf **out);
 /* A halfvec twin of a float4 mirror (same centroids, lists, TIDs): rows narrowed on the device with the
  * reference's own encoder float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal
  * results flushed to zero) when reference_encoder != 0 — what a halfvec column cast by the reference holds —

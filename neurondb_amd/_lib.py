@@ -106,6 +106,7 @@ def lib():
         "ndbhip_ivf_to_f16": (i, [vp, i, C.POINTER(vp)]),
         "ndbhip_ivf_get_nprobe": (i, [vp, C.POINTER(i)]),
         "ndbhip_ivf_set_nprobe": (i, [vp, i]),
+        "ndbhip_ivf_shard_slices": (i, [vp, vp, vp, vp, C.POINTER(vp)]),
         "ndbhip_ivf_shard": (i, [vp, vp, C.POINTER(vp)]),
         "ndbhip_ivf_shape": (i, [vp, C.POINTER(i), C.POINTER(i)]),
         "ndbhip_ivf_pages_info": (i, [vp, C.c_uint32, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i64),

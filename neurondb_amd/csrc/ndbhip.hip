@@ -307,12 +307,24 @@ struct IvfDev
 	const float *centroids;		/* [ncent * dim] */
 	const int64_t *loc_off;		/* [ncent + 1] local row offsets */
 	const uint32_t *glob_len;	/* [ncent] global live entries per list */
-	const uint8_t *owned;		/* [ncent] */
+	const uint8_t *owned;		/* [ncent] this mirror holds some of the list's rows */
+	const uint32_t *own_lo;		/* [ncent] first list position held here (0 unless a list is split over ranks) */
+	const uint32_t *own_len;	/* [ncent] rows of the list held here: positions own_lo .. own_lo + own_len */
 	int			dim;
 	int			ncent;			/* centroid items present ("maxoff") */
 	int			nlists;			/* meta->nlists */
 	int			f16;			/* rows are fp16 (vecs points at them; dim % 64 == 0) */
 };
+
+/* of the first l positions of list c, how many does this mirror hold */
+__device__ __forceinline__ uint64_t
+ndb_local_part(uint64_t l, const uint32_t *__restrict__ own_lo, const uint32_t *__restrict__ own_len, int c)
+{
+	const uint64_t lo = own_lo[c];
+	const uint64_t hi = lo + own_len[c];
+
+	return l > lo ? ((l < hi ? l : hi) - lo) : 0;
+}
 
 /* ================================================================== */
 /* block-level primitives                                              */
@@ -699,7 +711,8 @@ k_rows_scan(const float *__restrict__ base, uint32_t nrows, int dim,
  */
 __global__ __launch_bounds__(256) void
 k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int ncent, int npr,
-			   const uint32_t *__restrict__ glob_len, const uint8_t *__restrict__ owned, uint64_t cap,
+			   const uint32_t *__restrict__ glob_len, const uint32_t *__restrict__ own_lo,
+			   const uint32_t *__restrict__ own_len, uint64_t cap,
 			   int dim, int *__restrict__ probes, uint32_t *__restrict__ cand_off,
 			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters)
 {
@@ -829,8 +842,8 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			if (cap > 0 && acc + l > cap)
 				l = cap - acc;	/* candidateCount < maxCandidates guards: ivf_am.c:1764, 1793, 1811 */
 			acc += l;
-			if (l > 0 && owned[selc[i]])
-				mine += l;
+			if (l > 0)
+				mine += ndb_local_part(l, own_lo, own_len, selc[i]);
 			co[i + 1] = (uint32_t) acc;
 			if (lco)			/* positions of the rows THIS rank holds (sharded mirrors) */
 				lco[i + 1] = (uint32_t) mine;
@@ -848,7 +861,8 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
  * every probe, globally and among the rows held here */
 __global__ __launch_bounds__(256) void
 k_probe_offsets(const int *__restrict__ probes, uint32_t nq, int npr, int ncent,
-				const uint32_t *__restrict__ glob_len, const uint8_t *__restrict__ owned, uint64_t cap, int dim,
+				const uint32_t *__restrict__ glob_len, const uint32_t *__restrict__ own_lo,
+				const uint32_t *__restrict__ own_len, uint64_t cap, int dim,
 				uint32_t *__restrict__ cand_off, uint32_t *__restrict__ loc_cand_off,
 				unsigned long long *__restrict__ counters)
 {
@@ -871,8 +885,8 @@ k_probe_offsets(const int *__restrict__ probes, uint32_t nq, int npr, int ncent,
 		if (cap > 0 && acc + l > cap)
 			l = cap - acc;
 		acc += l;
-		if (l > 0 && owned[c])
-			mine += l;
+		if (l > 0)
+			mine += ndb_local_part(l, own_lo, own_len, c);
 		co[i + 1] = (uint32_t) acc;
 		if (lco)
 			lco[i + 1] = (uint32_t) mine;
@@ -994,22 +1008,19 @@ struct PairRec
 
 /* pass 1: how many (query, probe) pairs hit each owned list */
 __global__ void
-k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr, uint32_t nq,
-			 const uint8_t *__restrict__ owned, uint32_t *__restrict__ cnt)
+k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
+			 uint32_t *__restrict__ cnt)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 
 	if (i >= nq * (uint32_t) npr)
 		return;
 	const uint32_t q = i / npr, p = i % npr;
-	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);	/* rows held HERE for this (query, probe) */
 
 	if (co[p + 1] == co[p])
 		return;
-	const int	L = probes[(size_t) q * npr + p];
-
-	if (owned[L])
-		atomicAdd(&cnt[L], 1u);
+	atomicAdd(&cnt[probes[(size_t) q * npr + p]], 1u);
 }
 
 /* pass 2 (one block of 1024 threads): per-list pair / work-item / group offsets */
@@ -1074,8 +1085,8 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 
 /* pass 3: bucket the pairs */
 __global__ void
-k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ cand_off, int npr, uint32_t nq,
-			const uint8_t *__restrict__ owned, const uint32_t *__restrict__ pair_off,
+k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
+			const uint32_t *__restrict__ pair_off,
 			uint32_t *__restrict__ fill, PairRec *__restrict__ pairs)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1083,14 +1094,11 @@ k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ cand_of
 	if (i >= nq * (uint32_t) npr)
 		return;
 	const uint32_t q = i / npr, p = i % npr;
-	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
+	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
 
 	if (co[p + 1] == co[p])
 		return;
 	const int	L = probes[(size_t) q * npr + p];
-
-	if (!owned[L])
-		return;
 	const uint32_t slot = pair_off[L] + atomicAdd(&fill[L], 1u);
 	PairRec		r;
 
@@ -1426,7 +1434,7 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 		while (lo + 1 < (uint32_t) ix.ncent && item_off[lo + 1] <= item)
 			lo++;
 		const uint32_t L = lo;
-		const uint32_t len = ix.glob_len[L];
+		const uint32_t len = ix.own_len[L];	/* the rows of the list held here */
 		const uint32_t local = item - item_off[L];
 		/* consecutive items = the same 64-row tile for the list's consecutive query groups: the waves that
 		 * pull them stream the same rows at about the same time, so all but the first find them in cache */
@@ -1529,9 +1537,9 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 			{
 				const uint32_t qid = mem[j].q;
 				const uint32_t pp = mem[j].p;
-				const uint32_t *co = cand_off + (size_t) qid * (npr + 1);
-				const uint32_t nrow = co[pp + 1] - co[pp];	/* may be capped below len (ivf_am.c:1743) */
-				const uint32_t la = loc_cand_off[(size_t) qid * (npr + 1) + pp];
+				const uint32_t *lq = loc_cand_off + (size_t) qid * (npr + 1);
+				const uint32_t la = lq[pp];
+				const uint32_t nrow = lq[pp + 1] - la;	/* may be capped below len (ivf_am.c:1743) */
 
 				const float dv = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
 
@@ -1667,7 +1675,7 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		const uint32_t p = find_probe(lco, npr, i);
 		const int	L = probes[(size_t) q * npr + p];
 
-		gpos = co[p] + (i - lco[p]);
+		gpos = co[p] + ix.own_lo[L] + (i - lco[p]);	/* a split list: this mirror starts at position own_lo */
 		return ix.tids[ix.loc_off[L] + (i - lco[p])];
 	};
 
@@ -1973,6 +1981,8 @@ struct ndbhip_ivf
 	int64_t    *d_loc_off = nullptr;
 	uint32_t   *d_glob_len = nullptr;
 	uint8_t    *d_owned = nullptr;
+	uint32_t   *d_own_lo = nullptr, *d_own_len = nullptr;
+	std::vector<int64_t> own_lo, own_len;	/* list positions [own_lo, own_lo + own_len) are held here */
 	std::vector<int64_t> glob_len;
 	std::vector<int64_t> loc_off;
 	std::vector<uint8_t> owned;
@@ -2066,7 +2076,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 	{
 		(void) hipStreamSynchronize(g.stream);
 		ivf_free_rows(ix);
-		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->w_cdist,
+		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->d_own_lo, ix->d_own_len, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
 			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock};
 
@@ -2095,8 +2105,11 @@ ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncent)
 	return NDBHIP_OK;
 }
 
+/* own_lo / own_len (optional): the slice of every list this mirror holds; without them a list is held
+ * whole (owned[c] != 0, or owned == NULL) or not at all */
 static int
-ivf_set_layout(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned, int64_t nrows)
+ivf_set_layout(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned, int64_t nrows,
+			   const int64_t *own_lo = nullptr, const int64_t *own_len = nullptr)
 {
 	const int	nc = ix->ncent;
 	int64_t		acc = 0;
@@ -2105,40 +2118,62 @@ ivf_set_layout(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned, in
 		return fail(NDBHIP_ERR_STATE, "set centroids before loading lists");
 	ix->glob_len.assign(list_len, list_len + nc);
 	ix->owned.resize(nc);
+	ix->own_lo.resize(nc);
+	ix->own_len.resize(nc);
 	ix->loc_off.resize(nc + 1);
-	std::vector<uint32_t> gl32(nc);
+	std::vector<uint32_t> gl32(nc), lo32(nc), ln32(nc);
 
+	ix->sharded = false;
 	for (int c = 0; c < nc; c++)
 	{
 		if (list_len[c] < 0 || list_len[c] > 0xFFFFFFFFll)
 			return fail(NDBHIP_ERR_INVALID, "list_len[%d] out of range", c);
-		ix->owned[c] = owned ? (owned[c] != 0) : 1;
+		if (own_len)
+		{
+			const int64_t lo = own_lo ? own_lo[c] : 0;
+
+			if (lo < 0 || own_len[c] < 0 || lo + own_len[c] > list_len[c])
+				return fail(NDBHIP_ERR_INVALID, "slice of list %d is outside the list", c);
+			ix->own_lo[c] = own_len[c] > 0 ? lo : 0;
+			ix->own_len[c] = own_len[c];
+		}
+		else
+		{
+			ix->own_lo[c] = 0;
+			ix->own_len[c] = (owned ? (owned[c] != 0) : true) ? list_len[c] : 0;
+		}
+		/* owned = this mirror takes the appends to list c: it holds the list's tail (or is told so) */
+		ix->owned[c] = owned ? owned[c] != 0 : (!own_len || (own_len[c] > 0 && ix->own_lo[c] + own_len[c] == list_len[c]));
+		if (ix->own_len[c] != list_len[c])
+			ix->sharded = true;
 		ix->loc_off[c] = acc;
-		if (ix->owned[c])
-			acc += list_len[c];
+		acc += ix->own_len[c];
 		gl32[c] = (uint32_t) list_len[c];
+		lo32[c] = (uint32_t) ix->own_lo[c];
+		ln32[c] = (uint32_t) ix->own_len[c];
 	}
 	ix->loc_off[nc] = acc;
-	ix->sharded = false;
-	for (int c = 0; c < nc; c++)
-		if (!ix->owned[c])
-			ix->sharded = true;
 	if (acc != nrows)
-		return fail(NDBHIP_ERR_INVALID, "nrows %lld does not match the owned lists' total %lld",
+		return fail(NDBHIP_ERR_INVALID, "nrows %lld does not match the held slices' total %lld",
 					(long long) nrows, (long long) acc);
 	if (acc > 0xFFFFFFFFll)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 rows on one device");
-	void	  **ptrs[] = {(void **) &ix->d_loc_off, (void **) &ix->d_glob_len, (void **) &ix->d_owned};
+	void	  **ptrs[] = {(void **) &ix->d_loc_off, (void **) &ix->d_glob_len, (void **) &ix->d_owned,
+		(void **) &ix->d_own_lo, (void **) &ix->d_own_len};
 
 	for (void **p : ptrs)
 		if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
 	HIP_TRY(hipMalloc((void **) &ix->d_loc_off, (size_t) (nc + 1) * sizeof(int64_t)));
 	HIP_TRY(hipMalloc((void **) &ix->d_glob_len, (size_t) nc * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_own_lo, (size_t) nc * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_own_len, (size_t) nc * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc((void **) &ix->d_owned, (size_t) nc));
 	HIP_TRY(hipMemcpyAsync(ix->d_loc_off, ix->loc_off.data(), (size_t) (nc + 1) * sizeof(int64_t),
 						   hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemcpyAsync(ix->d_glob_len, gl32.data(), (size_t) nc * sizeof(uint32_t),
 						   hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_own_lo, lo32.data(), (size_t) nc * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_own_len, ln32.data(), (size_t) nc * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemcpyAsync(ix->d_owned, ix->owned.data(), (size_t) nc, hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	return 0;
@@ -2324,7 +2359,7 @@ ivf_local_max_candidates(const ndbhip_ivf *ix, int nprobe)
 	std::vector<int64_t> v(ix->glob_len.size());
 
 	for (size_t i = 0; i < v.size(); i++)
-		v[i] = ix->owned[i] ? ix->glob_len[i] : 0;
+		v[i] = ix->own_len[i];
 	int			n = std::min<int>(nprobe, (int) v.size());
 
 	std::partial_sort(v.begin(), v.begin() + n, v.end(), std::greater<int64_t>());
@@ -2332,8 +2367,8 @@ ivf_local_max_candidates(const ndbhip_ivf *ix, int nprobe)
 
 	for (int i = 0; i < n; i++)
 		s += v[i];
-	if (nprobe > n && !v.empty() && ix->owned[0])
-		s += (int64_t) (nprobe - n) * ix->glob_len[0];
+	if (nprobe > n && !v.empty())
+		s += (int64_t) (nprobe - n) * ix->own_len[0];
 	return s;
 }
 
@@ -2362,11 +2397,14 @@ ivf_flush(ndbhip_ivf *ix)
 		add[ix->pend_list[i]]++;
 		new_len[ix->pend_list[i]]++;
 	}
+	std::vector<int64_t> new_own(ix->own_len);
+
 	for (int c = 0; c < nc; c++)
 	{
 		new_off[c] = nown;
 		if (ix->owned[c])
-			nown += new_len[c];
+			new_own[c] += add[c];
+		nown += new_own[c];
 	}
 	new_off[nc] = nown;
 	if (nown > 0xFFFFFFFFll)
@@ -2407,9 +2445,10 @@ ivf_flush(ndbhip_ivf *ix)
 	}
 	for (int c = 0; c < nc; c++)
 	{
-		if (!ix->owned[c])
+		const int64_t oldn = ix->own_len[c];
+
+		if (new_own[c] == 0)
 			continue;
-		const int64_t oldn = ix->glob_len[c];
 
 		if (oldn > 0)
 		{
@@ -2418,7 +2457,7 @@ ivf_flush(ndbhip_ivf *ix)
 			HIP_TRY(hipMemcpyAsync(ntids_d + new_off[c], ix->d_tids + ix->loc_off[c], (size_t) oldn * sizeof(uint64_t),
 								   hipMemcpyDeviceToDevice, g.stream));
 		}
-		if (add[c] > 0)
+		if (add[c] > 0 && ix->owned[c])
 		{
 			HIP_TRY(hipMemcpyAsync(nrows_d + (size_t) (new_off[c] + oldn) * dim, stage_d + (size_t) stage_off[c] * dim,
 								   (size_t) add[c] * dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
@@ -2430,7 +2469,8 @@ ivf_flush(ndbhip_ivf *ix)
 	if (stage_d) HIP_TRY(hipFree(stage_d));
 	if (stids_d) HIP_TRY(hipFree(stids_d));
 	std::vector<uint8_t> owned(ix->owned);
-	int			rc = ivf_set_layout(ix, new_len.data(), owned.data(), nown);
+	std::vector<int64_t> lo(ix->own_lo);
+	int			rc = ivf_set_layout(ix, new_len.data(), owned.data(), nown, lo.data(), new_own.data());
 
 	if (rc)
 		return rc;
@@ -2696,6 +2736,8 @@ ivf_dev(const ndbhip_ivf *ix)
 	d.loc_off = ix->d_loc_off;
 	d.glob_len = ix->d_glob_len;
 	d.owned = ix->d_owned;
+	d.own_lo = ix->d_own_lo;
+	d.own_len = ix->d_own_len;
 	d.dim = ix->dim;
 	d.ncent = ix->ncent;
 	d.nlists = ix->nlists;
@@ -2761,7 +2803,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		/* probes chosen elsewhere (each rank of a sharded search selects for its slice of the queries) */
 		w_probes = const_cast<int *>(d_probes_in);
 		hipLaunchKernelGGL(k_probe_offsets, dim3((nq + 255) / 256), dim3(256), 0, g.stream, d_probes_in,
-						   (uint32_t) nq, npr, ix->ncent, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
+						   (uint32_t) nq, npr, ix->ncent, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
 						   ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
 	}
@@ -2794,7 +2836,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (uint32_t) ncmp, ix->dim, d_q, ix->w_cdist, cstride);
 		}
 		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
-						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, (const uint8_t *) d.owned,
+						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
 						   w_probes, ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
 	}
@@ -2821,13 +2863,12 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
-						   (const int *) w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
-						   (const uint8_t *) d.owned, cnt);
+						   (const int *) w_probes, lco, npr, (uint32_t) nq, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
-						   (const uint32_t *) d.glob_len, nc, pair_off, item_off, grp_off);
+						   d.own_len, nc, pair_off, item_off, grp_off);
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
-						   (const int *) w_probes, (const uint32_t *) ix->w_candoff, npr, (uint32_t) nq,
-						   (const uint8_t *) d.owned, (const uint32_t *) pair_off, fill, ix->w_pairs);
+						   (const int *) w_probes, lco, npr, (uint32_t) nq, (const uint32_t *) pair_off, fill,
+						   ix->w_pairs);
 		hipLaunchKernelGGL(k_group_pack, dim3((ix->dim + 255) / 256, maxgroups), dim3(256), 0, g.stream, d_q,
 						   ix->dim, nc, (const uint32_t *) cnt, (const uint32_t *) pair_off,
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, ix->w_qblock);
@@ -4420,7 +4461,7 @@ ndbhip_ivf_export(const ndbhip_ivf *cix, float *centroids, int64_t *list_len, fl
 		HIP_TRY(hipMemcpy(centroids, ix->d_centroids, (size_t) ix->ncent * ix->dim * 4, hipMemcpyDeviceToHost));
 	if (list_len)
 		for (int c = 0; c < ix->ncent; c++)
-			list_len[c] = ix->owned[c] ? ix->glob_len[c] : 0;
+			list_len[c] = ix->own_len[c];
 	if (rows && ix->f16)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "fp16 mirror: rows are not exported as float4");
 	if (rows && ix->nrows > 0)
@@ -4438,15 +4479,20 @@ ndbhip_ivf_export(const ndbhip_ivf *cix, float *centroids, int64_t *list_len, fl
 
 /* New index holding only the lists with owned[L] != 0 (device-to-device copy);
  * list lengths stay global so candidate positions are identical on every rank. */
+/* New mirror holding positions [lo[c], lo[c] + len[c]) of every list c of `src` (device-to-device copy).
+ * Whole lists are the usual shard; a slice lets several ranks share one long, popular list (its candidates keep
+ * their positions in the reference's candidates[], so the merged result is unchanged). */
 extern "C" int
-ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
+ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const int64_t *len, const uint8_t *tail,
+						ndbhip_ivf **out)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
-	if (!src || !src->loaded || !owned || !out)
+	if (!src || !src->loaded || !lo || !len || !out)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	for (int c = 0; c < src->ncent; c++)
-		if (owned[c] && !src->owned[c])
-			return fail(NDBHIP_ERR_INVALID, "list %d is not resident in the source index", c);
+		if (len[c] < 0 || lo[c] < 0 ||
+			(len[c] > 0 && (lo[c] < src->own_lo[c] || lo[c] + len[c] > src->own_lo[c] + src->own_len[c])))
+			return fail(NDBHIP_ERR_INVALID, "slice of list %d is not resident in the source index", c);
 	if (!src->pend_list.empty())
 		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
 	ndbhip_ivf *ix = nullptr;
@@ -4458,16 +4504,15 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 	HIP_TRY(hipMemcpyAsync(ix->d_centroids, src->d_centroids, (size_t) src->ncent * src->dim * sizeof(float),
 						   hipMemcpyDeviceToDevice, g.stream));
 	ix->ncent = src->ncent;
+	ix->meta_nprobe = src->meta_nprobe;
 	int64_t		nrows = 0;
 
 	for (int c = 0; c < src->ncent; c++)
-		if (owned[c])
-			nrows += src->glob_len[c];
-	rc = ivf_set_layout(ix, src->glob_len.data(), owned, nrows);
+		nrows += len[c];
+	rc = ivf_set_layout(ix, src->glob_len.data(), tail, nrows, lo, len);
 	if (rc)
 		return rc;
 	const int64_t cap = nrows > 0 ? nrows : 1;
-
 	const size_t esz = src->f16 ? sizeof(uint16_t) : sizeof(float);	/* rows are fp16 images or float4 */
 
 	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * esz));
@@ -4477,15 +4522,17 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 	ix->f16 = src->f16;
 	for (int c = 0; c < src->ncent; c++)
 	{
-		const int64_t n = src->glob_len[c];
+		const int64_t n = len[c];
 
-		if (!owned[c] || n == 0)
+		if (n == 0)
 			continue;
+		const int64_t from = src->loc_off[c] + (lo[c] - src->own_lo[c]);
+
 		HIP_TRY(hipMemcpyAsync((char *) ix->d_vecs + (size_t) ix->loc_off[c] * ix->dim * esz,
-							   (const char *) src->d_vecs + (size_t) src->loc_off[c] * src->dim * esz,
+							   (const char *) src->d_vecs + (size_t) from * src->dim * esz,
 							   (size_t) n * ix->dim * esz, hipMemcpyDeviceToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(ix->d_tids + ix->loc_off[c], src->d_tids + src->loc_off[c],
-							   (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_tids + ix->loc_off[c], src->d_tids + from, (size_t) n * sizeof(uint64_t),
+							   hipMemcpyDeviceToDevice, g.stream));
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = nrows;
@@ -4493,6 +4540,23 @@ ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
 	ix->f16_sub = src->f16_sub;	/* a shard holds a subset of the source's rows */
 	*out = ix;
 	return NDBHIP_OK;
+}
+
+/* the lists with owned[L] != 0, whole */
+extern "C" int
+ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
+{
+	if (!src || !src->loaded || !owned || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	std::vector<int64_t> lo((size_t) src->ncent, 0), len((size_t) src->ncent, 0);
+
+	for (int c = 0; c < src->ncent; c++)
+	{
+		if (owned[c] && src->own_len[c] != src->glob_len[c])
+			return fail(NDBHIP_ERR_INVALID, "list %d is not resident in the source index", c);
+		len[(size_t) c] = owned[c] ? src->glob_len[c] : 0;
+	}
+	return ndbhip_ivf_shard_slices(src, lo.data(), len.data(), owned, out);
 }
 
 /* float4 -> IEEE half image.  REF = the reference's float4_to_fp16 (src/types/quantization.c:141-168:
@@ -4541,7 +4605,7 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	HIP_TRY(hipMemcpyAsync(ix->d_centroids, src->d_centroids, (size_t) src->ncent * src->dim * sizeof(float),
 						   hipMemcpyDeviceToDevice, g.stream));
 	ix->ncent = src->ncent;
-	rc = ivf_set_layout(ix, src->glob_len.data(), src->owned.data(), src->nrows);
+	rc = ivf_set_layout(ix, src->glob_len.data(), src->owned.data(), src->nrows, src->own_lo.data(), src->own_len.data());
 	if (rc)
 		return rc;
 	const int64_t cap = src->nrows > 0 ? src->nrows : 1;

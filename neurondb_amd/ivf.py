@@ -139,6 +139,19 @@ class IvfIndex:
         sub.ncent = getattr(self, "ncent", self.nlists)
         return sub
 
+    def shard_slices(self, lo, length, tail=None):
+        """New IvfIndex holding positions [lo[L], lo[L] + length[L]) of every list L (ndbhip_ivf_shard_slices);
+        tail[L] != 0 = this shard takes later appends to list L."""
+        a = np.ascontiguousarray(lo, dtype=np.int64)
+        b = np.ascontiguousarray(length, dtype=np.int64)
+        t = None if tail is None else np.ascontiguousarray(tail, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().ndbhip_ivf_shard_slices(self._h, _ptr(a), _ptr(b), None if t is None else _ptr(t), C.byref(h)))
+        sub = IvfIndex.__new__(IvfIndex)
+        sub.dim, sub.nlists, sub._h, sub._keep = self.dim, self.nlists, h, []
+        sub.ncent = getattr(self, "ncent", self.nlists)
+        return sub
+
     def export(self, rows=True):
         """Read the mirror back: (centroids, list_len, rows, tids structured)."""
         nc = lib().ndbhip_ivf_ncentroids(self._h)

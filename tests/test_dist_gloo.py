@@ -39,7 +39,11 @@ def _rank_records(a, img, owner, rank, q, nprobe, k, sel=None):
         if c < 0:
             continue
         for r in range(off[c], off[c + 1]):
-            if owner[c] == rank:
+            if isinstance(owner, tuple):          # (lo, length) of partition_slices: this rank's slice of list c
+                mine = owner[0][rank, c] <= r - off[c] < owner[0][rank, c] + owner[1][rank, c]
+            else:
+                mine = owner[c] == rank
+            if mine:
                 dist_l.append(L.ndbo_ivf_distance(q, a["rows"][r], a["rows"].shape[1], 1))
                 pos_l.append(pos)
                 tid_l.append(t64[r])
@@ -48,14 +52,18 @@ def _rank_records(a, img, owner, rank, q, nprobe, k, sel=None):
     return rec, pos
 
 
-def _worker(rank, world, port, seed, ret):
+def _worker(rank, world, port, seed, slices, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from neurondb_amd.dist import ShardedSearchBuffers, gather_and_merge, gather_probes, partition_lists, query_slice
+    from neurondb_amd.dist import (ShardedSearchBuffers, gather_and_merge, gather_probes, partition_lists,
+                                   partition_slices, query_slice)
     a = make_ivf_arrays(1500, 16, 12, seed=seed, dup_frac=0.2, integer=True)
     img = oracle_image(a)
-    owner = partition_lists(a["list_len"], world)
+    if slices:                                   # every list with >= 2 x 8 rows is cut in two
+        owner = partition_slices(a["list_len"], world, None, split_frac=0.0, align=8)[:2]
+    else:
+        owner = partition_lists(a["list_len"], world)
     rng = np.random.default_rng(seed + 1)
     queries = rng.integers(-3, 4, size=(7, 16)).astype(np.float32)      # 7: the last rank's slice is short
     k, nprobe = 10, 5
@@ -84,12 +92,12 @@ def _worker(rank, world, port, seed, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_gloo_world2_exchange_and_merge_equals_oracle(world):
+@pytest.mark.parametrize("world,slices", [(2, False), (2, True)])
+def test_gloo_world2_exchange_and_merge_equals_oracle(world, slices):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, 77, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 77, slices, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
 
 
@@ -101,3 +109,29 @@ def test_partition_is_balanced_and_deterministic():
     assert np.array_equal(o1, o2)
     loads = np.bincount(o1, weights=ll, minlength=8)
     assert loads.max() - loads.min() <= ll.max()
+
+
+def test_partition_slices_covers_every_list_once_and_balances_work():
+    from neurondb_amd.dist import partition_slices
+    rng = np.random.default_rng(1)
+    ll = rng.integers(0, 3000, 1024)
+    ll[5], ll[7] = 28000, 0                               # one long, popular list; one empty list
+    pc = rng.integers(0, 400, 1024)
+    pc[5] = 3000
+    for world in (1, 2, 8):
+        lo, ln, tail = partition_slices(ll, world, pc)
+        lo2, ln2, tail2 = partition_slices(ll, world, pc)
+        assert np.array_equal(lo, lo2) and np.array_equal(ln, ln2) and np.array_equal(tail, tail2)
+        assert (ln.sum(0) == ll).all() and (tail.sum(0) == 1).all()
+        for l in np.nonzero((ln > 0).sum(0) > 1)[0]:      # slices of a cut list tile it, on 64-row boundaries
+            parts = sorted((int(lo[r, l]), int(ln[r, l])) for r in range(world) if ln[r, l] > 0)
+            pos = 0
+            for a, n in parts:
+                assert a == pos and a % 64 == 0
+                pos += n
+            assert pos == ll[l]
+            assert tail[np.argmax(lo[:, l] + ln[:, l]), l] == 1
+        work = (ln * (pc[None] + 1.0)).sum(1)
+        assert work.max() / work.sum() < 1.0 / world + 0.01
+        if world == 8:
+            assert (ln[:, 5] > 0).all()                   # the 28 k-row list is shared by all ranks

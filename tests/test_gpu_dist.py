@@ -1,5 +1,5 @@
 """The N > 1 flow end to end on ONE device: two processes share cuda:0, hold one shard each
-(IvfIndex.shard), and run neurondb_amd.dist.sharded_search — query-split cluster selection, probe
+(IvfIndex.shard / shard_slices), and run neurondb_amd.dist.sharded_search — query-split cluster selection, probe
 all-gather, per-shard scan, record all-gather, replay merge — over a gloo group (RCCL refuses two ranks
 on one device; the 8-GPU run of bench.py uses the same code over RCCL).  Result == the oracle's."""
 import os
@@ -25,14 +25,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, slices, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from neurondb_amd import IvfIndex, _lib
-        from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, sharded_search
+        from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, partition_slices, sharded_search
         _lib.ensure_init(0)
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
@@ -47,8 +47,12 @@ def _worker(rank, world, port, ret):
         full = IvfIndex(64, 20)
         full.set_centroids(a["centroids"])
         full.load(a["list_len"], a["rows"], a["tids"])
-        owner = partition_lists(a["list_len"], world)
-        ix = full.shard((owner == rank).astype(np.uint8))
+        if slices:
+            lo, ln, tail = partition_slices(a["list_len"], world, None, split_frac=0.0, align=16)
+            ix = full.shard_slices(lo[rank], ln[rank], tail[rank])
+        else:
+            owner = partition_lists(a["list_len"], world)
+            ix = full.shard((owner == rank).astype(np.uint8))
         full.close()
         buf = ShardedSearchBuffers(len(q), k, world, dev, nprobe=nprobe)
         dq = torch.from_numpy(q).to(dev)
@@ -65,9 +69,10 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_device_sharded_search_equals_oracle():
+@pytest.mark.parametrize("slices", [False, True])
+def test_two_ranks_one_device_sharded_search_equals_oracle(slices):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), slices, ret), nprocs=world, join=True)
     assert all(ret.get(r) is True for r in range(world)), dict(ret)

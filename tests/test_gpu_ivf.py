@@ -567,3 +567,127 @@ def test_bulkdelete_drops_rows_and_keeps_list_order(scan_mode):
     t, d, c = ix.search(vnew[None, :], 1, 24, 1)
     assert c[0] == 1 and d[0, 0] == 0.0 and ndbo.tids_to_u64(t[0, :1])[0] == ndbo.tids_to_u64(newtid)[0]
     assert ix.export()[1][5] == 1
+
+
+def _merged_partial(shards, dq, strategy, nprobe, k, max_candidates=0, probes=None):
+    """per-shard partial records -> device merge (what dist.sharded_search does around the all-gather)"""
+    import torch
+    from neurondb_amd import _lib
+    from oracle import ndbo
+    world, nq, cap = len(shards), dq.shape[0], 3 * k
+    cand = torch.zeros((world, nq, cap, 2), dtype=torch.int64, device="cuda")
+    ncand = torch.zeros((world, nq), dtype=torch.int32, device="cuda")
+    total = torch.zeros((world, nq), dtype=torch.int64, device="cuda")
+    for w, sh in enumerate(shards):
+        if probes is None:
+            sh.search_partial_device(dq, cand[w], ncand[w], total[w], strategy, nprobe, k, max_candidates)
+        else:
+            sh.search_partial_probes_device(dq, probes, cand[w], ncand[w], total[w], strategy, nprobe, k,
+                                            max_candidates)
+    ot = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    oc = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().ndbhip_merge_topk_device(cand.data_ptr(), ncand.data_ptr(), total[0].data_ptr(),
+                                                   world, nq, k, cap, ot.data_ptr(), od.data_ptr(), oc.data_ptr()))
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    tot = total.cpu().numpy()
+    assert np.array_equal(tot, np.broadcast_to(tot[0], tot.shape))     # every rank knows the global count
+    return ndbo.tids_from_device_u64(ot.cpu().numpy()), od.cpu().numpy(), oc.cpu().numpy()
+
+
+def _same_u64(t, d, c, et, ed, ec):
+    assert np.array_equal(c, ec), (c, ec)
+    for i in range(len(ec)):
+        n = ec[i]
+        assert np.array_equal(t[i, :n], et[i, :n]), (i, t[i, :n], et[i, :n], d[i, :n], ed[i, :n])
+        assert np.array_equal(d[i, :n].view(np.uint32), ed[i, :n].view(np.uint32)), (i, d[i, :n], ed[i, :n])
+
+
+@pytest.mark.parametrize("world,split_frac,align", [(4, 0.0, 16), (3, 0.0, 64), (8, 0.25, 64)])
+def test_slice_shards_merge_to_the_unsharded_result(world, split_frac, align, scan_mode):
+    """Lists cut into per-rank slices (partition_slices / ndbhip_ivf_shard_slices): the merged result is the
+    oracle's for all strategies, with and without the candidate cap, for batches on the grouped and on the
+    per-query scan, for fp16 rows, and with the probes chosen elsewhere."""
+    import torch
+    from neurondb_amd.dist import partition_slices
+    nl = 16
+    a = make_ivf_arrays(7000, 64, nl, seed=131, dup_frac=0.1, empty_lists=(3,))
+    img = oracle_image(a)
+    full = _index(a)
+    pc = np.ones(nl)
+    pc[np.argmax(a["list_len"])] = 50
+    lo, ln, tail = partition_slices(a["list_len"], world, pc, split_frac=split_frac, align=align)
+    assert (ln.sum(0) == a["list_len"]).all() and (tail.sum(0) == 1).all()
+    if split_frac == 0.0:
+        assert ((ln > 0).sum(0) > 1).any()                  # some list really is split
+    shards = [full.shard_slices(lo[w], ln[w], tail[w]) for w in range(world)]
+    assert sum(s.nrows for s in shards) == full.nrows
+    k, nprobe = 10, 6
+    for nq in (100, 3):
+        q = _queries(a, nq, seed=132 + nq)
+        dq = torch.from_numpy(q).cuda()
+        for strategy in (1, 2, 3):
+            for cap in (0, 700):
+                for mode in (1, 2):
+                    scan_mode(mode)
+                    t, d, c = _merged_partial(shards, dq, strategy, nprobe, k, cap)
+                    et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
+                    _same_u64(t, d, c, et, ed, ec)
+        probes = torch.from_numpy(np.stack([img.select_clusters(qq, nprobe) for qq in q]).astype(np.int32)).cuda()
+        t, d, c = _merged_partial(shards, dq, 1, nprobe, k, 0, probes)
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+        _same_u64(t, d, c, et, ed, ec)
+    # fp16 twins of the slices
+    twin = full.to_f16(False)
+    from oracle import ndbo
+    lut = np.array([ndbo.lib().ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+    img16 = oracle_image(dict(a, rows=lut[a["rows"].astype(np.float16).view(np.uint16)]))
+    sh16 = [twin.shard_slices(lo[w], ln[w], tail[w]) for w in range(world)]
+    q = _queries(a, 40, seed=139)
+    dq = torch.from_numpy(q).cuda()
+    for strategy in (1, 3):
+        t, d, c = _merged_partial(sh16, dq, strategy, nprobe, k)
+        et, ed, ec, _ = oracle_search_batch(img16, q, strategy, nprobe, k)
+        _same_u64(t, d, c, et, ed, ec)
+    # a slice of a slice (re-sharding a shard) and the bounds check
+    sub = shards[0].shard_slices(lo[0], np.minimum(ln[0], 5))
+    assert sub.nrows == int(np.minimum(ln[0], 5).sum())
+    with pytest.raises(Exception):
+        shards[0].shard_slices(lo[0], ln[0] + 1)
+
+
+def test_slice_shards_take_appends_on_the_tail_rank():
+    """aminsert after slicing: every rank is told of the append (list lengths are global), the rank holding the
+    list's tail stores the row; merged results equal the oracle's over the grown lists."""
+    import torch
+    from neurondb_amd.dist import partition_slices
+    from oracle import ndbo
+    nl, world = 12, 3
+    a = make_ivf_arrays(4000, 64, nl, seed=141, empty_lists=(2,))
+    full = _index(a)
+    lo, ln, tail = partition_slices(a["list_len"], world, None, split_frac=0.0, align=32)
+    shards = [full.shard_slices(lo[w], ln[w], tail[w]) for w in range(world)]
+    rng = np.random.default_rng(142)
+    off = np.zeros(nl + 1, np.int64)
+    off[1:] = np.cumsum(a["list_len"])
+    lists = [list(range(off[l], off[l + 1])) for l in range(nl)]
+    rows, tids = [a["rows"]], [a["tids"]]
+    nbase = len(a["rows"])
+    for i, l in enumerate([0, 2, 2, 7, 0, 11, 5]):                     # list 2 starts empty
+        v = rng.standard_normal(64).astype(np.float32)
+        t = ndbo.tids_from_rows(np.array([900000 + i]))
+        for s in shards:
+            s.append(l, v, t)
+        lists[l].append(nbase + i)
+        rows.append(v[None])
+        tids.append(t)
+    rows, tids = np.concatenate(rows), np.concatenate(tids)
+    order = np.concatenate([np.asarray(x, np.int64) for x in lists])
+    grown = dict(a, rows=rows[order], tids=tids[order], list_len=np.array([len(x) for x in lists], np.int64))
+    img = oracle_image(grown)
+    q = _queries(a, 50, seed=143)
+    dq = torch.from_numpy(q).cuda()
+    t, d, c = _merged_partial(shards, dq, 1, 5, 10)
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, 5, 10)
+    _same_u64(t, d, c, et, ed, ec)
+    assert sum(s.nrows for s in shards) == nbase + 7

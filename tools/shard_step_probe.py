@@ -27,7 +27,7 @@ def timed(fn, sync, reps=5):
 def main():
     from neurondb_amd import IvfIndex, _lib
     from neurondb_amd._lib import check, lib
-    from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, query_slice
+    from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, partition_slices, query_slice
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
     check(lib().ndbhip_set_stream(torch.cuda.current_stream().cuda_stream))
@@ -49,13 +49,23 @@ def main():
     sync()
     pcn = pc.cpu().numpy()
     cnt = np.bincount(pcn[pcn >= 0].ravel(), minlength=nlists)
-    for world, balanced in ((2, 1), (4, 1), (8, 0), (8, 1)):
-        owner = partition_lists(ll, world, cnt if balanced else None)
-        loads = np.bincount(owner, weights=ll, minlength=world)
-        work = np.bincount(owner, weights=ll * cnt, minlength=world)
-        worst = int(work.argmax())
-        print(f"  partition by {'work' if balanced else 'rows'}: heaviest rank has {work[worst] / work.sum():.3f} of the work")
-        ix = full.shard((owner == worst).astype(np.uint8))
+    for world, how in ((2, "slices"), (4, "slices"), (8, "rows"), (8, "work"), (8, "slices")):
+        if how == "slices":
+            slo, sln, stl = partition_slices(ll, world, cnt)
+            loads = sln.sum(1).astype(np.float64)
+            work = (sln * (cnt[None] + 1.0)).sum(1)
+            worst = int(work.argmax())
+            nsplit = int(((sln > 0).sum(0) > 1).sum())
+            print(f"  partition by work with {nsplit} lists cut into slices: heaviest rank has "
+                  f"{work[worst] / work.sum():.3f} of the work")
+            ix = full.shard_slices(slo[worst], sln[worst], stl[worst])
+        else:
+            owner = partition_lists(ll, world, cnt if how == "work" else None)
+            loads = np.bincount(owner, weights=ll, minlength=world)
+            work = np.bincount(owner, weights=ll * cnt, minlength=world)
+            worst = int(work.argmax())
+            print(f"  partition of whole lists by {how}: heaviest rank has {work[worst] / work.sum():.3f} of the work")
+            ix = full.shard((owner == worst).astype(np.uint8))
         buf = ShardedSearchBuffers(nq, k, world, dev, nprobe=nprobe)
         lo, hi, s = query_slice(nq, world, 0)
         probes = torch.zeros((nq, nprobe), dtype=torch.int32, device=dev)
