@@ -36,9 +36,10 @@ def lib_path() -> str:
 
 
 def declared_symbols() -> list:
-    """Every function include/*.h declares (ndbhip.h: the C ABI; ndb_am.h: the AM callbacks over it)."""
+    """Every function include/*.h declares (ndbhip.h: the C ABI; ndb_am.h: the AM callbacks over it; ndb_sql.h:
+    the SQL-level batch functions over it)."""
     out = set()
-    for name in ("ndbhip.h", "ndb_am.h"):
+    for name in ("ndbhip.h", "ndb_am.h", "ndb_sql.h"):
         with open(os.path.join(_ROOT, "include", name)) as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -58,6 +59,10 @@ class NdbIndexScan(C.Structure):
     _fields_ = [("indexRelation", C.c_void_p), ("numberOfKeys", C.c_int), ("numberOfOrderBys", C.c_int),
                 ("xs_heaptid", NdbItemPointer), ("xs_orderbyval", C.c_float), ("xs_orderbynull", C.c_int),
                 ("xs_recheckorderby", C.c_int), ("opaque", C.c_void_p)]
+
+
+class NdbKnnRow(C.Structure):
+    _fields_ = [("query_no", C.c_int32), ("heaptid", NdbItemPointer), ("id", C.c_int64), ("distance", C.c_float)]
 
 
 BULKDELETE_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(NdbItemPointer), C.c_void_p)
@@ -170,6 +175,15 @@ def lib():
         "ndb_hnsw_level_from_uniform": (i, [C.c_double, C.c_float]),
         "ndb_ivfbulkdelete": (i, [vp, BULKDELETE_CALLBACK, vp, C.POINTER(i64)]),
         "ndb_hnswbulkdelete": (i, [vp, BULKDELETE_CALLBACK, vp, C.POINTER(i64)]),
+        # include/ndb_sql.h
+        "ndb_vector_l2_distance_batch": (i, [vp, vp, i, vp, C.c_size_t, vp]),
+        "ndb_vector_cosine_distance_batch": (i, [vp, vp, i, vp, C.c_size_t, vp]),
+        "ndb_vector_inner_product_batch": (i, [vp, vp, i, vp, C.c_size_t, vp]),
+        "ndb_vector_l2_distance_gpu": (i, [vp, C.c_size_t, vp, C.c_size_t, vp]),
+        "ndb_vector_cosine_distance_gpu": (i, [vp, C.c_size_t, vp, C.c_size_t, vp]),
+        "ndb_vector_inner_product_gpu": (i, [vp, C.c_size_t, vp, C.c_size_t, vp]),
+        "ndb_ivf_knn_search_gpu": (i, [vp, i, vp, vp, i, i, i, vp, C.POINTER(i64)]),
+        "ndb_hnsw_knn_search_gpu": (i, [vp, i, vp, vp, i, i, i, vp, C.POINTER(i64)]),
         "ndbhip_ivf_build": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
         "ndbhip_ivf_insert": (i, [vp, vp, vp, C.POINTER(i)]),
         "ndbhip_hnsw_insert": (i, [vp, vp, vp, C.c_uint32, vp, i]),
