@@ -423,6 +423,33 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         bad += not (cnt[i] == len(eb) and np.array_equal(got[i, :len(eb)], eb) and
                     np.array_equal(gd[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and gs[i] == ns)
     tc = (time.perf_counter() - t0) / sample
+
+    # the reference's unused best-first search (src/scan/hnsw_scan.c) on the same graph and queries
+    # (always compute_l2_distance; on unit-norm rows L2 and cosine rank alike, so the same ground truth serves)
+    def run_layer():
+        check(lib().ndbhip_hnsw_search_layer_device(ix._h, C.c_void_p(q.data_ptr()), nq, 1, ef, k,
+                                                    C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
+                                                    C.c_void_p(oc.data_ptr()), C.c_void_p(ot.data_ptr()),
+                                                    C.c_void_p(osc.data_ptr())))
+        check(lib().ndbhip_synchronize())
+    run_layer()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        run_layer()
+    tl = (time.perf_counter() - t0) / 3
+    got_l, cnt_l, gd_l, gs_l = ob.cpu().numpy(), oc.cpu().numpy(), od.cpu().numpy(), osc.cpu().numpy()
+    recall_l = float(np.mean([len(set(got_l[i][:cnt_l[i]]) & set(gt[i])) / k for i in range(200)]))
+    bad_l = 0
+    for i in range(sample):
+        eb, ed, ns = og.search_layer(qh[i], ef, k)
+        bad_l += not (cnt_l[i] == len(eb) and np.array_equal(got_l[i, :len(eb)], eb) and
+                      np.array_equal(gd_l[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and gs_l[i] == ns)
+    layer = {"what": "hnsw_search_layer (src/scan/hnsw_scan.c, the reference's unused best-first search), "
+                     f"ef={ef} k={k}, same graph and queries",
+             "queries_per_s": round(nq / tl, 1), "ms_per_batch": round(tl * 1e3, 3),
+             "evaluations_per_query": round(float(gs_l.mean()), 1), "recall_at_10": round(recall_l, 4),
+             "oracle_parity": {"queries": sample, "mismatches": int(bad_l),
+                               "checked": "blocks in slot order, float4 bits, evaluation counts"}}
     return {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k} cosine, "
                         f"{nq}-query batches (BASELINE config C3)",
             "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 3), "build_schedule": ix.build_stats(),
@@ -435,7 +462,8 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             "recall_note": "the reference's level-0 walk is BFS-until-ef (quirk Q10); the oracle returns the same ids",
             "oracle_parity": {"queries": sample, "mismatches": int(bad),
                               "checked": "blocks, ranks, float4 bits, evaluation counts"},
-            "cpu_oracle_ms_per_query_single_thread": round(tc * 1e3, 3)}
+            "cpu_oracle_ms_per_query_single_thread": round(tc * 1e3, 3),
+            "search_layer": layer}
 
 
 def pmc_traffic(args, world, kernel="k_ivf_scan"):

@@ -358,6 +358,18 @@ int			ndbhip_hnsw_search(ndbhip_hnsw *g, const float *queries, int nq, int strat
 int			ndbhip_hnsw_search_device(ndbhip_hnsw *g, const float *d_queries, int nq, int strategy, int ef,
 									  int k, uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 									  uint64_t *d_out_tids, int64_t *d_out_scored);
+/* hnsw_search_layer (src/scan/hnsw_scan.c:379-477): the best-first search the reference ships next to
+ * hnswSearch and never calls, rule for rule — compute_l2_distance (fp32 sequential + sqrtf,
+ * :105-118) whatever `strategy` says (the reference's body never reads that argument), hill climb on the upper
+ * layers (:485-636), at layer 0 a min-heap of at most 2 * ef candidates, the bound results[k - 1], k unsorted
+ * result slots (:645-844).  Same outputs as ndbhip_hnsw_search, results in SLOT order (not sorted), as the
+ * reference returns them (:826-830).  A packed mirror is converted to the dense layout first. */
+int			ndbhip_hnsw_search_layer(ndbhip_hnsw *g, const float *queries, int nq, int strategy, int ef, int k,
+									 uint32_t *out_blocks, float *out_dist, int *out_count,
+									 uint8_t *out_tids6, int64_t *out_scored);
+int			ndbhip_hnsw_search_layer_device(ndbhip_hnsw *g, const float *d_queries, int nq, int strategy, int ef,
+											int k, uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
+											uint64_t *d_out_tids, int64_t *d_out_scored);
 
 /* ------------------------------------------------------------------ */
 /* hnsw relation pages <-> mirror, PostgreSQL-free (src/index/hnsw_am.c:108-181, 1091-1110, 2288-2332):

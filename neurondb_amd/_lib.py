@@ -157,6 +157,8 @@ def lib():
         "ndbhip_hnsw_export": (i, [vp, C.POINTER(C.c_uint32), vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(i)]),
         "ndbhip_hnsw_search": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_hnsw_search_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
+        "ndbhip_hnsw_search_layer": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
+        "ndbhip_hnsw_search_layer_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_batch_distance": (i, [vp, vp, vp, i, i, i, i, i]),
         "ndbhip_extract_vector": (i, [i, vp, C.c_size_t, vp, i, C.POINTER(i)]),
         # include/ndb_am.h

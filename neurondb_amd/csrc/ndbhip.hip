@@ -5392,6 +5392,307 @@ k_hnsw_search_fast(HnswDev g, const float *__restrict__ queries, uint32_t ef, ui
 }
 
 /*
+ * src/scan/hnsw_scan.c: hnsw_search_layer (:379-477) — the best-first search the reference ships next to
+ * hnswSearch and never calls, restated rule for rule (oracle: ndbo_hnsw_search_layer):
+ * compute_l2_distance (:105-118, fp32 sequential + sqrtf = Acc<R_IVF_L2>) whatever the operator class; a hill
+ * climb per upper layer that keeps scanning the neighbours of the node the pass started from (:485-636);
+ * at layer 0 (:645-844) a binary min-heap of at most 2 * efSearch candidates (inserts into a full heap are
+ * dropped), the entry point pushed with distance 0.0, "visited" = was offered to the heap, the bound
+ * results[k - 1] (the k-th slot, not the worst), k unsorted result slots where a better node replaces the
+ * first worst one, returned in slot order.
+ *
+ * One wave per query, persistent blocks.  The distance evaluations of one neighbour list are batched, one
+ * lane per neighbour (they do not depend on the sequential state: results and the bound only change after
+ * the list); heap and result bookkeeping is replayed in neighbour order by lane 0 in LDS.  The visited set
+ * is a bitmap in global memory owned by the block (all-zero between queries: the wave clears the words it
+ * set, from a log, or the whole map when the log overflowed).
+ */
+#define NDB_SCAN_VLOG 4096u
+
+__device__ __forceinline__ bool
+scan_readable(uint32_t nblocks, uint32_t b)
+{
+	return b < nblocks && b != 0;	/* :562-566 / :756-760; the meta page holds no item (PageIsEmpty) */
+}
+
+__global__ __launch_bounds__(64) void
+k_hnsw_scan_layer(HnswDev g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k,
+				  uint32_t *__restrict__ vbits_all, uint32_t vwords, uint32_t *__restrict__ vlog_all,
+				  uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
+				  uint64_t *__restrict__ out_tids, long long *__restrict__ out_scored)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	float	   *tile = (float *) smem_raw;
+	uint2	   *heap = (uint2 *) (smem_raw + (size_t) NDB_TILE_FLOATS * 4);	/* .x block, .y float bits */
+	uint2	   *res = heap + 2u * ef;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t nblocks = g.nblocks;
+	const int	m2 = 2 * g.m;
+	const uint32_t cap = 2u * ef;
+	uint32_t   *vbits = vbits_all + (size_t) blockIdx.x * vwords;
+	uint32_t   *vlog = vlog_all + (size_t) blockIdx.x * NDB_SCAN_VLOG;
+
+	auto		v_test = [&](uint32_t b) -> bool {
+		return (__hip_atomic_load(&vbits[b >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31u)) & 1u;
+	};
+
+	for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x)
+	{
+		const float *q = queries + (size_t) qi * g.dim;
+		long long	scored = 0;
+		uint32_t	entry = g.entry_point;
+		int			level = g.entry_level;
+		uint32_t	candCount = 0, resCount = 0, vcount = 0;
+
+		if (entry == NDBHIP_INVALID_BLOCK || level < 0)	/* :396-402 */
+		{
+			if (lane == 0)
+			{
+				out_count[qi] = 0;
+				if (out_scored) out_scored[qi] = 0;
+			}
+			continue;
+		}
+
+		/* ---- hnswSearchLayerGreedy per upper layer (:448-457, :485-636) ---- */
+		for (; level > 0; level--)
+		{
+			uint32_t	best = entry;
+			bool		changed = true;
+
+			while (changed)
+			{
+				changed = false;
+				if (!scan_readable(nblocks, best))
+					break;
+				const int	lv = g.levels[best];
+
+				if (lv < 0 || lv >= NDBHIP_HNSW_MAX_LEVEL)	/* :535-540 */
+					break;
+				const int	nc = hnsw_clamp(g.ncount[(size_t) best * NDBHIP_HNSW_MAX_LEVEL + level], g.m);
+				const uint32_t *nb = hnsw_nbr_base(g, best) + (size_t) level * m2;	/* :549: no test of the node's level */
+				const uint32_t node = best;
+				float		bestDist = 0.0f;
+
+				for (int j0 = -1; j0 < nc; j0 += 64)
+				{
+					const int	j = j0 + (int) lane;
+					const uint32_t my = (j < 0) ? node : ((j < nc) ? nb[j] : NDBHIP_INVALID_BLOCK);
+					const bool	act = my != NDBHIP_INVALID_BLOCK && scan_readable(nblocks, my);
+					const float d = score_rows<R_IVF_L2>(q, g.vecs, act ? my : node, g.dim, tile);
+
+					scored += __popcll(__ballot(act));
+					if (j0 < 0)
+						bestDist = __shfl(d, 0, 64);
+					/* `if (neighborDist < bestDist)` in neighbour order = the first strict minimum */
+					const bool	isnb = act && j >= 0;
+					const uint64_t key = isnb ? (((uint64_t) ndb_key_from_bits(__float_as_uint(d)) << 32) | lane) : ~0ull;
+					const uint64_t mn = wave_min_u64(key);
+
+					if (mn != ~0ull)
+					{
+						const uint32_t bl = (uint32_t) mn & 63u;
+						const float bd = __shfl(d, bl, 64);
+
+						if (bd < bestDist)
+						{
+							best = __shfl(my, bl, 64);
+							bestDist = bd;
+							changed = true;
+						}
+					}
+				}
+			}
+			entry = best;
+		}
+
+		/* ---- hnswSearchLayer0 (:645-844) ---- */
+		auto		heap_insert = [&](uint32_t block, uint32_t dbits) {	/* hnswInsertCandidate :235-266 */
+			if (candCount >= cap)
+				return;
+			if (lane == 0)
+			{
+				uint32_t	i = candCount;
+				const float d = __uint_as_float(dbits);
+
+				while (i > 0)
+				{
+					const uint32_t parent = (i - 1u) / 2u;
+					const uint2 pe = heap[parent];
+
+					if (d >= __uint_as_float(pe.y))
+						break;
+					heap[i] = pe;
+					i = parent;
+				}
+				heap[i] = make_uint2(block, dbits);
+			}
+			candCount++;
+			wave_lds_sync();
+		};
+		auto		mark = [&](uint32_t block) {	/* hnswMarkVisited :217-230 */
+			if (lane == 0)
+			{
+				if (block < nblocks)
+					__hip_atomic_fetch_or(&vbits[block >> 5], 1u << (block & 31u), __ATOMIC_RELAXED,
+										  __HIP_MEMORY_SCOPE_AGENT);
+				if (vcount < NDB_SCAN_VLOG)
+					vlog[vcount] = block;
+			}
+			vcount++;
+		};
+
+		heap_insert(entry, 0u);	/* distance 0.0: :668-671 */
+		mark(entry);
+
+		while (candCount > 0)
+		{
+			/* hnswExtractMinCandidate :271-327 */
+			const uint2 top = heap[0];
+			const uint32_t block = top.x;
+			float		distance = __uint_as_float(top.y);
+
+			candCount--;
+			wave_lds_sync();
+			if (candCount > 0 && lane == 0)
+			{
+				const uint2 last = heap[candCount];
+				const float ld = __uint_as_float(last.y);
+				uint32_t	i = 0;
+
+				for (;;)
+				{
+					const uint32_t left = 2u * i + 1u, right = left + 1u;
+					uint32_t	smallest = i;
+					float		sd = ld;
+
+					if (left < candCount && __uint_as_float(heap[left].y) < sd)
+					{
+						smallest = left;
+						sd = __uint_as_float(heap[left].y);
+					}
+					if (right < candCount && __uint_as_float(heap[right].y) < sd)
+						smallest = right;
+					if (smallest == i)
+						break;
+					heap[i] = heap[smallest];
+					i = smallest;
+				}
+				heap[i] = last;
+			}
+			wave_lds_sync();
+
+			if (resCount >= k && distance > __uint_as_float(res[k - 1u].y))	/* :684-686 */
+				continue;
+			if (!scan_readable(nblocks, block))
+				continue;
+			const int	lv = g.levels[block];
+
+			if (lv < 0 || lv >= NDBHIP_HNSW_MAX_LEVEL)	/* :715-720 */
+				continue;
+			const int	nc = hnsw_clamp(g.ncount[(size_t) block * NDBHIP_HNSW_MAX_LEVEL + 0], g.m);
+			const uint32_t *nb = hnsw_nbr_base(g, block);
+			const float furthest = resCount >= k ? __uint_as_float(res[k - 1u].y) : FLT_MAX;	/* :744-746 */
+			const bool	open = resCount < k;
+
+			for (int j0 = -1; j0 < nc; j0 += 64)
+			{
+				const int	j = j0 + (int) lane;
+				const uint32_t my = (j < 0) ? block : ((j < nc) ? nb[j] : NDBHIP_INVALID_BLOCK);
+				/* a neighbour is scored unless invalid, unreadable or already visited (:749-764) */
+				bool		act = my != NDBHIP_INVALID_BLOCK && scan_readable(nblocks, my);
+
+				if (act && j >= 0 && v_test(my))
+					act = false;
+				const float d = score_rows<R_IVF_L2>(q, g.vecs, act ? my : block, g.dim, tile);
+
+				if (j0 < 0)
+					distance = __shfl(d, 0, 64);	/* the node itself: :741 */
+				const bool	take = act && j >= 0 && (d < furthest || open);	/* :804-810 */
+				unsigned long long tm = __ballot(take);
+				unsigned long long am = __ballot(act);
+
+				/* replay in neighbour order; a block listed twice is scored again only if its first
+				 * occurrence was not offered to the heap (it is "visited" from then on) */
+				unsigned long long rest = tm;
+
+				while (rest)
+				{
+					const int	idx = __ffsll((long long) rest) - 1;
+					const uint32_t b = __shfl(my, idx, 64);
+					const uint32_t db = __shfl(__float_as_uint(d), idx, 64);
+					const unsigned long long same = __ballot(act && my == b) & ~((2ull << idx) - 1ull);
+
+					rest &= rest - 1ull;
+					heap_insert(b, db);
+					mark(b);
+					am &= ~same;		/* later occurrences: visited, neither scored nor offered */
+					rest &= ~same;
+				}
+				scored += __popcll(am);
+			}
+
+			/* hnswAddResult :333-365 */
+			if (resCount < k)
+			{
+				if (lane == 0)
+					res[resCount] = make_uint2(block, __float_as_uint(distance));
+				resCount++;
+			}
+			else
+			{
+				/* the first slot holding the largest distance */
+				uint64_t	bestk = ~0ull;
+
+				for (uint32_t i = lane; i < resCount; i += 64)
+				{
+					const uint64_t c = ((uint64_t) (~ndb_key_from_bits(res[i].y)) << 32) | i;
+
+					bestk = c < bestk ? c : bestk;
+				}
+				bestk = wave_min_u64(bestk);
+				const uint32_t wi = (uint32_t) bestk;
+
+				if (lane == 0 && distance < __uint_as_float(res[wi].y))
+					res[wi] = make_uint2(block, __float_as_uint(distance));
+			}
+			wave_lds_sync();
+		}
+
+		for (uint32_t i = lane; i < resCount; i += 64)	/* :826-830: slot order */
+		{
+			const uint2 r = res[i];
+
+			out_blocks[(size_t) qi * k + i] = r.x;
+			out_dist[(size_t) qi * k + i] = __uint_as_float(r.y);
+			if (out_tids)
+				out_tids[(size_t) qi * k + i] = r.x < nblocks ? g.tids[r.x] : 0ull;
+		}
+		if (lane == 0)
+		{
+			out_count[qi] = (int) resCount;
+			if (out_scored) out_scored[qi] = scored;
+		}
+		/* leave the bitmap all-zero for the next query */
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+		if (vcount <= NDB_SCAN_VLOG)
+			for (uint32_t i = lane; i < vcount; i += 64)
+			{
+				const uint32_t b = __hip_atomic_load(&vlog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+				if (b < nblocks)
+					__hip_atomic_store(&vbits[b >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		else
+			for (uint32_t i = lane; i < vwords; i += 64)
+				__hip_atomic_store(&vbits[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+	}
+}
+
+/*
  * hnswbuild (hnsw_am.c:343-415) = hnswInsertNode for every heap row in order (:2091-2670).  The inserts
  * depend on each other (each one searches the graph the previous ones left), so ONE wave walks them in
  * order inside ONE launch; the graph lives in the dense 16-level layout so that the reference's writes
@@ -6617,6 +6918,8 @@ struct ndbhip_hnsw
 	int		   *w_oc = nullptr;		size_t w_oc_n = 0;
 	uint64_t   *w_ot = nullptr;		size_t w_ot_n = 0;
 	long long  *w_os = nullptr;		size_t w_os_n = 0;
+	uint32_t   *w_vbits = nullptr;	size_t w_vbits_n = 0;	/* hnsw_search_layer: per-block visited bitmaps, all-zero at rest */
+	uint32_t   *w_vlog = nullptr;	size_t w_vlog_n = 0;
 };
 
 extern "C" int
@@ -6660,7 +6963,7 @@ ndbhip_hnsw_destroy(ndbhip_hnsw *h)
 	{
 		(void) hipStreamSynchronize(g.stream);
 		hnsw_free_dev(h);
-		void	   *ptrs[] = {h->w_q, h->w_ob, h->w_od, h->w_oc, h->w_ot, h->w_os};
+		void	   *ptrs[] = {h->w_q, h->w_ob, h->w_od, h->w_oc, h->w_ot, h->w_os, h->w_vbits, h->w_vlog};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -7505,11 +7808,79 @@ ndbhip_hnsw_search_device(ndbhip_hnsw *h, const float *d_queries, int nq, int st
 	return NDBHIP_OK;
 }
 
+/* hnsw_search_layer (src/scan/hnsw_scan.c:379-477) for nq queries: see k_hnsw_scan_layer */
 extern "C" int
-ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, int ef, int k,
-				   uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_scored)
+ndbhip_hnsw_search_layer_device(ndbhip_hnsw *h, const float *d_queries, int nq, int strategy, int ef, int k,
+								uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
+								uint64_t *d_out_tids, int64_t *d_out_scored)
 {
-	int			rc = hnsw_check(h, nq, strategy, ef, k);
+	/* `strategy` is an argument of the reference's function that its body never reads (:384): every
+	 * distance is compute_l2_distance */
+	int			rc = hnsw_check(h, nq, 1, ef, k);
+
+	(void) strategy;
+	if (rc)
+		return rc;
+	if (nq == 0)
+		return NDBHIP_OK;
+	if (!d_queries || !d_out_blocks || !d_out_dist || !d_out_count)
+		return fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	if (!h->dense)				/* layer reads are not guarded by the node's own level (:549): dense slots */
+	{
+		rc = hnsw_densify(h);
+		if (rc)
+			return rc;
+	}
+	const size_t smem = (size_t) NDB_TILE_FLOATS * 4 + ((size_t) 2 * ef + (size_t) k) * 8;
+
+	if (smem > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "ef/k too large for the LDS-resident candidate heap");
+	static bool attr_set = false;
+
+	if (!attr_set)
+	{
+		HIP_TRY(hipFuncSetAttribute((const void *) k_hnsw_scan_layer, hipFuncAttributeMaxDynamicSharedMemorySize,
+									NDB_TOPK_MAX_SMEM));
+		attr_set = true;
+	}
+	/* persistent single-wave blocks, each with its own visited bitmap (1 bit per block of the relation) */
+	const uint32_t vwords = (h->nblocks + 31u) / 32u;
+	uint32_t	grid = (uint32_t) std::min<int64_t>(nq, (int64_t) g.num_cus * 8);
+	const size_t max_bitmap_bytes = (size_t) 1 << 30;
+
+	while (grid > 1 && (size_t) grid * vwords * 4 > max_bitmap_bytes)
+		grid /= 2;
+	const size_t want = (size_t) grid * vwords;
+
+	if (want > h->w_vbits_n)
+	{
+		if (grow(h->w_vbits, h->w_vbits_n, want)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(h->w_vbits, 0, want * 4, g.stream));	/* every query leaves its map zero */
+	}
+	if (grow(h->w_vlog, h->w_vlog_n, (size_t) grid * NDB_SCAN_VLOG)) return NDBHIP_ERR_HIP;
+	HnswDev		d;
+
+	d.vecs = h->d_vecs; d.levels = h->d_levels; d.ncount = h->d_ncount; d.nbr_off = h->d_nbr_off;
+	d.nbrs = h->d_nbrs; d.tids = h->d_tids; d.nblocks = h->nblocks; d.dim = h->dim; d.m = h->m;
+	d.dense_stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
+	d.entry_point = h->entry_point; d.entry_level = h->entry_level;
+	ScanTimer	t;
+
+	if (t.start()) return NDBHIP_ERR_HIP;
+	hipLaunchKernelGGL(k_hnsw_scan_layer, dim3(grid), dim3(64), smem, g.stream, d, d_queries, (uint32_t) nq,
+					   (uint32_t) ef, (uint32_t) k, h->w_vbits, vwords, h->w_vlog, d_out_blocks, d_out_dist,
+					   d_out_count, d_out_tids, (long long *) d_out_scored);
+	if (t.stop()) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipGetLastError());
+	g.stats.queries += (uint64_t) nq;
+	return NDBHIP_OK;
+}
+
+static int
+hnsw_search_host(ndbhip_hnsw *h, bool scan_layer, const float *queries, int nq, int strategy, int ef, int k,
+				 uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_scored)
+{
+	int			rc = hnsw_check(h, nq, scan_layer ? 1 : strategy, ef, k);
 
 	if (rc)
 		return rc;
@@ -7527,8 +7898,11 @@ ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, i
 	HIP_TRY(hipMemsetAsync(h->w_ob, 0, (size_t) nq * k * 4, g.stream));
 	HIP_TRY(hipMemsetAsync(h->w_od, 0, (size_t) nq * k * 4, g.stream));
 	HIP_TRY(hipMemsetAsync(h->w_ot, 0, (size_t) nq * k * 8, g.stream));
-	rc = ndbhip_hnsw_search_device(h, h->w_q, nq, strategy, ef, k, h->w_ob, h->w_od, h->w_oc, h->w_ot,
-								   (int64_t *) h->w_os);
+	rc = scan_layer
+		? ndbhip_hnsw_search_layer_device(h, h->w_q, nq, strategy, ef, k, h->w_ob, h->w_od, h->w_oc, h->w_ot,
+										  (int64_t *) h->w_os)
+		: ndbhip_hnsw_search_device(h, h->w_q, nq, strategy, ef, k, h->w_ob, h->w_od, h->w_oc, h->w_ot,
+									(int64_t *) h->w_os);
 	if (rc)
 		return rc;
 	std::vector<uint64_t> t64((size_t) nq * k);
@@ -7554,6 +7928,23 @@ ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, i
 	g.host_rows += tot;
 	g.host_bytes += tot * (uint64_t) h->dim * 4;
 	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, int ef, int k,
+				   uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_scored)
+{
+	return hnsw_search_host(h, false, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
+							out_scored);
+}
+
+extern "C" int
+ndbhip_hnsw_search_layer(ndbhip_hnsw *h, const float *queries, int nq, int strategy, int ef, int k,
+						 uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6,
+						 int64_t *out_scored)
+{
+	return hnsw_search_host(h, true, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
+							out_scored);
 }
 
 

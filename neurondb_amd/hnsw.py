@@ -154,6 +154,20 @@ class HnswIndex:
                                        _ptr(t6), _ptr(sc)))
         return ob, od, oc, t6.view(TID_DTYPE).reshape(nq, k), sc
 
+    def search_layer(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K, strategy=1):
+        """hnsw_search_layer (src/scan/hnsw_scan.c:379-477, the reference's unused best-first search): same
+        outputs as search(), results in slot order; `strategy` is accepted and ignored like the reference's."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ob = np.zeros((nq, k), dtype=np.uint32)
+        od = np.zeros((nq, k), dtype=np.float32)
+        oc = np.zeros(nq, dtype=np.int32)
+        t6 = np.zeros((nq, k, 6), dtype=np.uint8)
+        sc = np.zeros(nq, dtype=np.int64)
+        check(lib().ndbhip_hnsw_search_layer(self._h, _ptr(q), nq, strategy, ef, k, _ptr(ob), _ptr(od), _ptr(oc),
+                                             _ptr(t6), _ptr(sc)))
+        return ob, od, oc, t6.view(TID_DTYPE).reshape(nq, k), sc
+
 
 class HnswScan:
     """hnswbeginscan / hnswrescan / hnswgettuple / hnswendscan (hnsw_am.c:880-1084)."""

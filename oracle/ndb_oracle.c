@@ -1205,6 +1205,258 @@ tid_in_set(const ndbo_tid *tids, int64_t n, ndbo_tid t)
 	return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* src/scan/hnsw_scan.c — the best-first search the reference ships but  */
+/* never calls.  Restated with its own rules:             */
+/*   - distances are compute_l2_distance (:105-118): fp32 sequential,    */
+/*     sqrtf, whatever the index's operator class;                       */
+/*   - the upper layers are a hill climb that scans the neighbours of     */
+/*     the node it STARTED the pass from while `best` moves (:485-636);  */
+/*   - layer 0 (:645-844): a binary min-heap of at most 2*efSearch        */
+/*     candidates (an insert into a full heap is dropped, :241-242), the  */
+/*     entry point enters with distance 0.0 (:668-671), a node counts as  */
+/*     visited only once it was offered to the heap, the bound is         */
+/*     results[k-1] — the k-th SLOT, not the worst result (:684-686,      */
+/*     :744-746) — and results are k unsorted slots where a better node   */
+/*     replaces the first worst one (:333-365); they are returned in slot */
+/*     order (:826-830).                                                  */
+/* ------------------------------------------------------------------ */
+typedef struct
+{
+	uint32_t	block;
+	float		distance;
+}			scan_elem;
+
+/* hnswInsertCandidate: hnsw_scan.c:235-266 */
+static void
+scan_heap_insert(scan_elem *h, int *count, int cap, uint32_t block, float distance)
+{
+	int			i,
+				parent;
+
+	if (*count >= cap)
+		return;
+	i = (*count)++;
+	h[i].block = block;
+	h[i].distance = distance;
+	while (i > 0)
+	{
+		scan_elem	t;
+
+		parent = (i - 1) / 2;
+		if (h[i].distance >= h[parent].distance)
+			break;
+		t = h[i];
+		h[i] = h[parent];
+		h[parent] = t;
+		i = parent;
+	}
+}
+
+/* hnswExtractMinCandidate: hnsw_scan.c:271-327 */
+static int
+scan_heap_pop(scan_elem *h, int *count, uint32_t *block, float *distance)
+{
+	int			i,
+				left,
+				right,
+				smallest;
+
+	if (*count == 0)
+		return 0;
+	*block = h[0].block;
+	*distance = h[0].distance;
+	(*count)--;
+	if (*count > 0)
+	{
+		h[0] = h[*count];
+		i = 0;
+		for (;;)
+		{
+			scan_elem	t;
+
+			smallest = i;
+			left = 2 * i + 1;
+			right = 2 * i + 2;
+			if (left < *count && h[left].distance < h[smallest].distance)
+				smallest = left;
+			if (right < *count && h[right].distance < h[smallest].distance)
+				smallest = right;
+			if (smallest == i)
+				break;
+			t = h[i];
+			h[i] = h[smallest];
+			h[smallest] = t;
+			i = smallest;
+		}
+	}
+	return 1;
+}
+
+/* a block hnsw_scan.c can read a node from: inside the relation (:562-566, :756-760) and not the meta page,
+ * which holds no item (PageIsEmpty, :520-524, :700-704) */
+static inline int
+scan_readable(const ndbo_hnsw *g, uint32_t b)
+{
+	return b < g->nblocks && b != 0;
+}
+
+/* hnsw_search_layer: src/scan/hnsw_scan.c:379-477 (+ :485-636, :645-844).  Returns resultCount. */
+int
+ndbo_hnsw_search_layer(const ndbo_hnsw *g, const float *query, int efSearch, int k,
+					   uint32_t *out_blocks, float *out_dist, int64_t *n_scored)
+{
+	uint32_t	currentEntry = g->entry_point;
+	int			currentLevel = g->entry_level;
+	int			dim = g->dim,
+				m = g->m;
+	int64_t		scored = 0;
+	scan_elem  *cand,
+			   *results;
+	uint8_t    *visited;
+	int			candCount = 0,
+				candCap = efSearch * 2,
+				resultCount = 0;
+	uint32_t	block;
+	float		distance;
+	int			i;
+
+	if (n_scored)
+		*n_scored = 0;
+	if (currentEntry == NDBO_INVALID_BLOCK || currentLevel < 0)	/* :396-402 */
+		return 0;
+
+	/* Step 1 (:448-457): hnswSearchLayerGreedy per upper layer */
+	while (currentLevel > 0)
+	{
+		uint32_t	best = currentEntry;
+		int			changed = 1;
+
+		while (changed)
+		{
+			const uint32_t *neighbors;
+			int			neighborCount;
+			float		bestDist;
+
+			changed = 0;
+			if (!scan_readable(g, best))	/* :520-524 */
+				break;
+			if (g->levels[best] < 0 || g->levels[best] >= NDBO_HNSW_MAX_LEVEL)	/* :535-540 */
+				break;
+			neighbors = hnsw_nbrs(g, best, currentLevel);	/* :549-550: no test of the node's own level */
+			neighborCount = hnsw_clamp_ncount(g->ncount[(size_t) best * NDBO_HNSW_MAX_LEVEL + currentLevel], m);
+			bestDist = ndbo_ivf_distance(query, hnsw_vec(g, best), dim, 1);
+			scored++;
+			for (i = 0; i < neighborCount; i++)
+			{
+				float		neighborDist;
+
+				if (neighbors[i] == NDBO_INVALID_BLOCK)
+					continue;
+				if (!scan_readable(g, neighbors[i]))
+					continue;
+				neighborDist = ndbo_ivf_distance(query, hnsw_vec(g, neighbors[i]), dim, 1);
+				scored++;
+				if (neighborDist < bestDist)	/* :617-622 */
+				{
+					best = neighbors[i];
+					bestDist = neighborDist;
+					changed = 1;
+				}
+			}
+		}
+		currentEntry = best;
+		currentLevel--;
+	}
+
+	/* Step 2 (:460-469): hnswSearchLayer0 */
+	if (efSearch < 1 || k < 1)
+		return 0;
+	cand = (scan_elem *) malloc((size_t) candCap * sizeof(scan_elem));
+	results = (scan_elem *) malloc((size_t) k * sizeof(scan_elem));
+	visited = (uint8_t *) calloc(g->nblocks ? g->nblocks : 1, 1);	/* membership is all hnswIsVisited asks (:201-212) */
+
+	scan_heap_insert(cand, &candCount, candCap, currentEntry, 0.0f);	/* :668-671 */
+	if (currentEntry < g->nblocks)
+		visited[currentEntry] = 1;
+
+	while (scan_heap_pop(cand, &candCount, &block, &distance))
+	{
+		const uint32_t *neighbors;
+		int			neighborCount;
+		float		furthestDist;
+		int			j;
+
+		if (resultCount >= k && distance > results[k - 1].distance)	/* :684-686 */
+			continue;
+		if (!scan_readable(g, block))	/* :700-704 */
+			continue;
+		if (g->levels[block] < 0 || g->levels[block] >= NDBO_HNSW_MAX_LEVEL)	/* :715-720 */
+			continue;
+		neighbors = hnsw_nbrs(g, block, 0);
+		neighborCount = hnsw_clamp_ncount(g->ncount[(size_t) block * NDBO_HNSW_MAX_LEVEL + 0], m);
+		distance = ndbo_ivf_distance(query, hnsw_vec(g, block), dim, 1);	/* :741 */
+		scored++;
+		furthestDist = (resultCount >= k) ? results[k - 1].distance : FLT_MAX;	/* :744-746 */
+
+		for (j = 0; j < neighborCount; j++)
+		{
+			float		neighborDist;
+
+			if (neighbors[j] == NDBO_INVALID_BLOCK)
+				continue;
+			if (!scan_readable(g, neighbors[j]))
+				continue;
+			if (visited[neighbors[j]])	/* :763-764 */
+				continue;
+			neighborDist = ndbo_ivf_distance(query, hnsw_vec(g, neighbors[j]), dim, 1);
+			scored++;
+			if (neighborDist < furthestDist || resultCount < k)	/* :804-810 */
+			{
+				scan_heap_insert(cand, &candCount, candCap, neighbors[j], neighborDist);
+				visited[neighbors[j]] = 1;
+			}
+		}
+
+		/* hnswAddResult: :333-365 */
+		if (resultCount < k)
+		{
+			results[resultCount].block = block;
+			results[resultCount].distance = distance;
+			resultCount++;
+		}
+		else
+		{
+			int			worstIdx = 0;
+			float		worstDist = results[0].distance;
+
+			for (i = 1; i < resultCount; i++)
+				if (results[i].distance > worstDist)
+				{
+					worstDist = results[i].distance;
+					worstIdx = i;
+				}
+			if (distance < worstDist)
+			{
+				results[worstIdx].block = block;
+				results[worstIdx].distance = distance;
+			}
+		}
+	}
+
+	for (i = 0; i < resultCount; i++)	/* :826-830 */
+	{
+		out_blocks[i] = results[i].block;
+		out_dist[i] = results[i].distance;
+	}
+	free(cand);
+	free(results);
+	free(visited);
+	if (n_scored)
+		*n_scored = scored;
+	return resultCount;
+}
+
 /* src/index/hnsw_am.c:544-720 */
 int64_t
 ndbo_hnsw_bulkdelete(ndbo_hnsw *g, const ndbo_tid *tids, int64_t n)

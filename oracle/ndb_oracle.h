@@ -185,6 +185,10 @@ void		ndbo_hnsw_free(ndbo_hnsw *g);
  * Returns resultCount; *n_scored counts hnswComputeDistance calls. */
 int			ndbo_hnsw_search(const ndbo_hnsw *g, const float *query, int strategy, int ef_search, int k,
 							 uint32_t *out_blocks, float *out_dist, int64_t *n_scored);
+/* src/scan/hnsw_scan.c:379-477 hnsw_search_layer (the unused best-first search): always
+ * compute_l2_distance; results in slot order, not sorted */
+int			ndbo_hnsw_search_layer(const ndbo_hnsw *g, const float *query, int ef_search, int k,
+								   uint32_t *out_blocks, float *out_dist, int64_t *n_scored);
 
 /* src/index/hnsw_am.c:2091-2670 with the level injected (hnswGetRandomLevel
  * uses random(): :1143-1161).  Returns the new block number. */

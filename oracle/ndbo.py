@@ -102,6 +102,7 @@ def lib(native: bool = False):
         "ndbo_ivf_assign": (i, [f32p, p, i, i, i, f32p, C.POINTER(f)]),
         "ndbo_hnsw_create": (C.POINTER(NdboHnsw), [i, i, i, C.c_uint32]),
         "ndbo_hnsw_free": (None, [C.POINTER(NdboHnsw)]),
+        "ndbo_hnsw_search_layer": (i, [C.POINTER(NdboHnsw), f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
         "ndbo_hnsw_search": (i, [C.POINTER(NdboHnsw), f32p, i, i, i, u32p, f32p,
                                   C.POINTER(C.c_int64)]),
         "ndbo_hnsw_insert": (C.c_uint32, [C.POINTER(NdboHnsw), f32p, NdboTid, i]),
@@ -271,6 +272,14 @@ class HnswGraph:
         od = np.zeros(max(k, 1), dtype=np.float32)
         ns = C.c_int64(0)
         n = self.L.ndbo_hnsw_search(self.g, _f32(query), strategy, ef, k, ob, od, C.byref(ns))
+        return ob[:n], od[:n], ns.value
+
+    def search_layer(self, query, ef=64, k=10):
+        """src/scan/hnsw_scan.c: hnsw_search_layer (best-first, compute_l2_distance); results in slot order"""
+        ob = np.zeros(max(k, 1), dtype=np.uint32)
+        od = np.zeros(max(k, 1), dtype=np.float32)
+        ns = C.c_int64(0)
+        n = self.L.ndbo_hnsw_search_layer(self.g, _f32(query), ef, k, ob, od, C.byref(ns))
         return ob[:n], od[:n], ns.value
 
     # views of the graph arrays (for loading the device mirror)

@@ -331,3 +331,107 @@ def test_hnsw_relation_pages_round_trip():
     again = HnswIndex.load_pages(r and ix.write_pages(24, 32))
     for strategy in (1, 3):
         check(g, again, q, strategy, 32, 10)
+
+
+def check_layer(g, ix, queries, ef, k):
+    """hnsw_search_layer on the device against the oracle's restatement of src/scan/hnsw_scan.c: blocks in slot
+    order, float4 bits, counts and the number of compute_l2_distance calls."""
+    exp = [g.search_layer(q, ef, k) for q in queries]
+    ob, od, oc, ot, sc = ix.search_layer(queries, ef, k)
+    for i, (eb, ed, ns) in enumerate(exp):
+        assert oc[i] == len(eb), (i, oc[i], len(eb))
+        assert np.array_equal(ob[i, :len(eb)], eb), (i, ob[i, :len(eb)], eb, od[i, :len(eb)], ed)
+        assert np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)), (i, od[i, :len(eb)], ed)
+        assert sc[i] == ns, (i, sc[i], ns)
+    return exp
+
+
+def pages_model(g, cap_nodes=None):
+    """The oracle graph a mirror loaded from PAGES stands for: a node's item ends after its own level's slots,
+    so the reference's writes above that level (Q12 / Q21) are not in the image.  hnsw_scan.c reads layers
+    without testing the node's level (:549), so — unlike hnswSearch — it can tell the difference."""
+    a = g.arrays()
+    nbrs = a["nbrs"].copy()
+    for b in range(a["nblocks"]):
+        nbrs[b, a["levels"][b] + 1:] = 0xFFFFFFFF
+    return ndbo.HnswGraph.from_arrays(a["vecs"], a["levels"], a["ncount"], nbrs, a["tids"], a["entry_point"],
+                                      a["entry_level"], a["m"], cap_nodes=cap_nodes)
+
+
+@pytest.mark.parametrize("n,dim,m,efc", [(600, 16, 4, 20), (1500, 32, 8, 40), (400, 768, 16, 32), (300, 6, 5, 16),
+                                         (700, 20, 40, 30)])
+def test_hnsw_search_layer_matches_oracle(n, dim, m, efc):
+    """the reference's unused best-first search (src/scan/hnsw_scan.c), rule for rule — heap of
+    2 * ef with dropped inserts (ef = 1, 2), the results[k - 1] bound, replace-first-worst, slot order."""
+    g, vecs = build_graph(n, dim, m, efc, seed=n + dim)
+    ix, a = load(g)
+    g = pages_model(g)
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((70, dim)).astype(np.float32)          # 70 queries: persistent blocks reuse bitmaps
+    q[:3] = vecs[:3]
+    for ef, k in ((64, 10), (8, 3), (1, 10), (2, 1), (200, 200), (16, 40)):
+        check_layer(g, ix, q, ef, k)
+    # the visited bitmaps were left clean: the same batch again gives the same answer
+    check_layer(g, ix, q, 64, 10)
+    # `strategy` is accepted and ignored (hnsw_scan.c:384): same rows for any value
+    b1 = ix.search_layer(q[:5], 64, 10, strategy=1)
+    b2 = ix.search_layer(q[:5], 64, 10, strategy=2)
+    assert np.array_equal(b1[0], b2[0]) and np.array_equal(b1[1].view(np.uint32), b2[1].view(np.uint32))
+
+
+def test_hnsw_search_layer_ties_duplicates_and_tiny_graphs():
+    g, vecs = build_graph(900, 16, 8, 40, seed=21, integer=True)   # exact ties in the heap and in the results
+    ix, _ = load(g)
+    g = pages_model(g)
+    q = np.random.default_rng(22).integers(-2, 3, size=(24, 16)).astype(np.float32)
+    q[1] = vecs[5]
+    for ef, k in ((64, 10), (4, 16)):
+        check_layer(g, ix, q, ef, k)
+    g, vecs = build_graph(500, 8, 6, 24, seed=9, dup=True)
+    ix, _ = load(g)
+    check_layer(pages_model(g), ix, vecs[:10].copy(), 32, 10)
+    g, vecs = build_graph(1, 8, 4, 8, seed=1)
+    ix, _ = load(g)
+    exp = check_layer(g, ix, vecs[:1] + 1.0, 64, 10)
+    assert len(exp[0][0]) == 1
+
+
+def test_hnsw_search_layer_on_a_graph_loaded_from_pages_and_after_vacuum():
+    from neurondb_amd import HnswIndex
+    from tests import pgpages
+    g, vecs = build_graph(500, 16, 6, 24, seed=12)
+    a = g.arrays()
+    t6 = np.ascontiguousarray(a["tids"]).view(np.uint8).reshape(-1, 6)
+    img = pgpages.write_hnsw_reference_format(a["vecs"], a["levels"], a["ncount"], a["nbrs"], t6, a["entry_point"],
+                                              a["entry_level"], 6, efc=24, efs=32)
+    ix = HnswIndex.load_pages(img)                               # packed mirror: densified on first use
+    r0 = pgpages.read_hnsw_image(img, 6)
+    g = ndbo.HnswGraph.from_arrays(r0["vecs"], r0["levels"], r0["ncount"], r0["nbrs"], a["tids"],
+                                   r0["entry_point"], r0["entry_level"], 6, 24, cap_nodes=600)
+    q = np.random.default_rng(13).standard_normal((10, 16)).astype(np.float32)
+    check_layer(g, ix, q, 32, 10)
+    check(g, ix, q, 1, 32, 10)                                    # hnswSearch still agrees on the dense mirror
+    victims = ndbo.tids_from_rows(np.array([4, 77, 300]))
+    assert ix.delete(victims) == 3 and g.bulkdelete(victims) == 3
+    check_layer(g, ix, q, 32, 10)
+
+
+def test_hnsw_search_layer_on_a_device_built_graph(restore_build_mode):
+    """A graph built on the device keeps the dense 16-level slots, out-of-node back-links included, exactly
+    like the oracle's in-memory build: hnsw_search_layer reads them on both sides."""
+    from neurondb_amd import HnswIndex
+    n, dim, m, efc = 1200, 32, 8, 40
+    rng = np.random.default_rng(77)
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    L = ndbo.lib()
+    levels = np.array([L.ndbo_hnsw_level_from_uniform(float(r), np.float32(0.36))
+                       for r in rng.uniform(1e-9, 1.0, n)], np.int32)
+    levels[7] = 3
+    g = ndbo.HnswGraph(dim, m=m, ef_construction=efc, cap_nodes=n + 2)
+    for i in range(n):
+        g.insert(vecs[i], i, int(levels[i]))
+    ix = HnswIndex(dim, m)
+    ix.build(vecs, ndbo.tids_from_rows(np.arange(n)), levels, efc)
+    q = rng.standard_normal((40, dim)).astype(np.float32)
+    for ef, k in ((64, 10), (8, 20)):
+        check_layer(g, ix, q, ef, k)
