@@ -11,7 +11,8 @@
  *   - scalar distance recipes: PINNED to the reference's own known-answer
  *     cases (NeuronDB/t/005_distances_comprehensive.t, sql/03_distance_metrics.sql,
  *     sql/10_gpu_distance_wrappers.sql) in tests/test_oracle_known_answers.py.
- *   - kNN id lists, k-means centroids, HNSW graphs: PARITY UNPINNED — the
+ *   - kNN id lists, k-means centroids, HNSW graphs, the unused best-first search of
+ *     src/scan/hnsw_scan.c (ndbo_hnsw_search_layer): PARITY UNPINNED — the
  *     reference holds no golden output for them (its tree has no expected/ .out files)
  *     and its sources cannot be compiled here (every file includes postgres.h).
  *     These functions follow the cited reference lines statement by statement.
