@@ -8,7 +8,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_LIB = os.path.join(_HERE, "lib", "libndbhip.so")
+_LIB = os.environ.get("NDBHIP_LIB") or os.path.join(_HERE, "lib", "libndbhip.so")     # override: A/B of two builds
 _HDR = os.path.join(_ROOT, "include", "ndbhip.h")
 
 OK = 0

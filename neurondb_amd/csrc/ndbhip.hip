@@ -56,8 +56,9 @@ fail(int code, const char *fmt, ...)
 /* list-scan kernel choice: 0 auto (grouped for batches >= NDB_GROUPED_MIN_NQ queries and dim % 64 == 0),
  * 1 always per-query (k_ivf_scan), 2 always grouped (k_ivf_scan_grouped) */
 static int	g_scan_mode = 0;
-/* measured crossover on MI355X (tools/batch_sweep.py, 1M x 768, probes 32): per-query wins only below 8 queries */
-#define NDB_GROUPED_MIN_NQ 8
+/* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32): the grouped path costs 0.38 ms for 1..16
+ * queries, the per-query path 0.18 / 0.24 / 0.35 / 0.50 ms for 1 / 2 / 4 / 7 */
+#define NDB_GROUPED_MIN_NQ 5
 /* rows staged per step by the grouped kernels: 64 floats (16 KiB tile, 3 waves/SIMD) or 32 (8 KiB, 4 waves/SIMD);
  * NDBHIP_GCHUNK overrides for experiments */
 static int	g_gchunk = 32;
@@ -993,6 +994,7 @@ k_ivf_scan_h(IvfDev ix, const float *__restrict__ queries, const int *__restrict
  * Requires dim % 64 == 0 (otherwise the per-query kernel is used).          */
 /* ------------------------------------------------------------------ */
 #define NDB_QG 16
+#define NDB_QHEAD_STRIDE 32u		/* words between the scan's work-queue heads: one 128-byte line each */
 #ifndef NDB_G32_WAVES
 #define NDB_G32_WAVES 5
 #endif
@@ -1027,7 +1029,7 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 __global__ __launch_bounds__(1024) void
 k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
 			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
-			   uint32_t *__restrict__ grp_off)
+			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs)
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
@@ -1080,6 +1082,33 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		pair_off[ncent] = sa[1023];
 		item_off[ncent] = sb[1023];
 		grp_off[ncent] = sc[1023];
+	}
+	/* the scan's 8 work queues (one per XCD): runs of whole lists with about the same number of items;
+	 * runs[x] = first item of run x, runs[8] = nitems.  Computed once here instead of by every block. */
+	__threadfence_block();
+	__syncthreads();
+	if (t <= 8)
+	{
+		const uint32_t nitems = sb[1023];
+		uint32_t	r = t == 0 ? 0u : nitems;
+
+		if (t > 0 && t < 8)
+		{
+			const uint32_t target = (uint32_t) (((uint64_t) nitems * (uint32_t) t) >> 3);
+			uint32_t	lo = 0, hi = (uint32_t) ncent;	/* smallest L with item_off[L] >= target */
+
+			while (lo < hi)
+			{
+				const uint32_t mid = (lo + hi) >> 1;
+
+				if (__hip_atomic_load(&item_off[mid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+					lo = mid + 1;
+				else
+					hi = mid;
+			}
+			r = __hip_atomic_load(&item_off[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		runs[t] = r;
 	}
 }
 
@@ -1371,13 +1400,12 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				   const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
-				   float *__restrict__ dist, uint32_t stride, const float *__restrict__ qnorm,
-				   uint32_t *__restrict__ tmin, uint32_t tstride)
+				   const uint32_t *__restrict__ runs, float *__restrict__ dist, uint32_t stride,
+				   const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite)
 {
 	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x & 63;
 	const int	dim = ix.dim;
-	const uint32_t nitems = item_off[ix.ncent];
 	/*
 	 * XCD-aware work queues.  The items (list-major) are cut into 8 runs of whole lists with about the same
 	 * number of items, one per XCD; a block serves the run of ITS XCD first (block b runs on XCD b % 8 —
@@ -1385,37 +1413,29 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 	 * scored through one XCD's L2, and — consecutive items being the same row tile for consecutive groups —
 	 * at about the same time: a tile comes from HBM once, not once per group.
 	 */
-	auto		run_start = [&](uint32_t x) -> uint32_t {
-		if (x == 0)
-			return 0u;
-		if (x >= 8)
-			return nitems;
-		const uint32_t target = (uint32_t) (((uint64_t) nitems * x) >> 3);
-		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;	/* smallest L with item_off[L] >= target */
-
-		while (lo < hi)
-		{
-			const uint32_t mid = (lo + hi) >> 1;
-
-			if (item_off[mid] < target)
-				lo = mid + 1;
-			else
-				hi = mid;
-		}
-		return item_off[lo];
-	};
-
+	/* next_item: 8 queue heads, one per 128-byte line (NDB_QHEAD_STRIDE words apart: every block of the grid
+	 * hits them, and device-scope atomics on one line serialise); runs: the 9 run bounds k_pair_offsets left
+	 * (read-only here and away from the hot lines) */
 	for (uint32_t hop = 0; hop < 8; hop++)
 	{
 	const uint32_t xq = (blockIdx.x + hop) & 7u;
-	const uint32_t run_lo = run_start(xq), run_hi = run_start(xq + 1);
+	const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+
+	if (run_lo == run_hi)
+		continue;
 
 	for (;;)
 	{
 		uint32_t	item = 0;
 
+		/* polite (small batches): look before taking.  A small batch has fewer items than the grid has blocks;
+		 * 8 failing read-modify-writes per block on eight hot lines then cost more than the scan itself (0.54 ms
+		 * for 8 queries), and a load does not serialise on the line like a read-modify-write does.  Large
+		 * batches skip the look: under load it queues behind the other blocks' atomics (4 % of the step). */
 		if (lane == 0)
-			item = run_lo + atomicAdd(&next_item[xq], 1u);
+			item = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
+														  __HIP_MEMORY_SCOPE_AGENT) >= run_hi)
+				? run_hi : run_lo + atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
 		item = __builtin_amdgcn_readfirstlane(item);
 		if (item >= run_hi)
 			break;
@@ -2857,15 +2877,16 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		uint32_t   *cnt = ix->w_gcnt, *fill = ix->w_gcnt + nc;
 		unsigned int *next_item = ix->w_gcnt + 2 * nc;
 		uint32_t   *pair_off = ix->w_goff, *item_off = ix->w_goff + (nc + 1), *grp_off = ix->w_goff + 2 * (nc + 1);
+		uint32_t   *runs = ix->w_goff + 3 * (nc + 1) + 32;	/* 9 words, on a line of their own */
 		const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
 		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
 		ScanTimer	t;
 
-		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
-						   d.own_len, nc, pair_off, item_off, grp_off);
+						   d.own_len, nc, pair_off, item_off, grp_off, runs);
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, (const uint32_t *) pair_off, fill,
 						   ix->w_pairs);
@@ -2885,8 +2906,9 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_scan_grouped<RR, CC, HH>), GRID, dim3(64), 0, g.stream, d,    \
 						   (const float *) ix->w_qblock, (const uint32_t *) ix->w_candoff, lco, npr,           \
 						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
-						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item, ix->w_dist,   \
-						   stride, (const float *) ix->w_qnorm, ix->w_tmin, tstride)
+						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item,               \
+						   (const uint32_t *) runs, ix->w_dist, stride, (const float *) ix->w_qnorm, ix->w_tmin, tstride, \
+						   nq < 1024 ? 1 : 0)
 		if (ix->f16)
 		{
 			const dim3	g16(g.num_cus * 16);	/* 8 KiB tile, 4 waves per SIMD */
@@ -2961,7 +2983,9 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			const uint32_t by_merge = 2048u / (3u * (uint32_t) k);		/* records the merge stage sorts in LDS */
 			const uint32_t by_grid = 1024u / (uint32_t) nq;
 
-			nsplit = std::min(std::min(by_work, by_merge), std::min(by_grid, 64u));
+			/* 16 ranges: the merge sorts 16 x 3k records instead of 64 x 3k (68 -> ~25 us per query) while a
+			 * range's partial top-k stays short; measured p50 276 -> 242 us for one 1M x 768 query */
+			nsplit = std::min(std::min(by_work, by_merge), std::min(by_grid, 16u));
 			if (nsplit < 2 || topk_smem_bytes(3u * (uint32_t) k * nsplit, (uint32_t) k) > NDB_TOPK_MAX_SMEM)
 				nsplit = 1;
 		}
@@ -3047,8 +3071,8 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (grow(ix->w_probes, ix->w_probes_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) 2 * qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 8)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1))) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 8 * NDB_QHEAD_STRIDE + 16)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1) + 80)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) qb)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_tmin, ix->w_tmin_n, (size_t) qb * ((((stride >> 6) + (size_t) nprobe + 2) + 63) & ~(size_t) 63)))
