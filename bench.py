@@ -127,8 +127,9 @@ def main():
     from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, partition_slices, sharded_search
     from neurondb_amd._lib import check, lib
     _lib.ensure_init(local_rank)
-    stream = torch.cuda.current_stream()
-    check(lib().ndbhip_set_stream(stream.cuda_stream))
+    # one stream for torch (data, RCCL collectives) and the library's kernels: the device-pointer calls are
+    # asynchronous, and their inputs / outputs are produced / consumed by torch
+    stream = _lib.use_torch_stream()
 
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
 

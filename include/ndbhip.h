@@ -79,7 +79,9 @@ int			ndbhip_device_count(void);		/* >= 0, or NDBHIP_ERR_NODEVICE; does not crea
 int			ndbhip_init(int device);		/* idempotent per process */
 int			ndbhip_shutdown(void);
 const char *ndbhip_last_error(void);
-/* Run all work on this hipStream_t (NULL = the library's own stream). */
+/* Run all work on this hipStream_t.  NULL = the library's own stream, which is NON-BLOCKING: it does not
+ * synchronise with the legacy default stream (handle 0) either — a caller that produces or consumes device
+ * buffers on another stream passes that stream here (neurondb_amd/_lib.py: use_torch_stream). */
 int			ndbhip_set_stream(void *hip_stream);
 int			ndbhip_synchronize(void);
 

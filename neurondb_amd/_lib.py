@@ -228,3 +228,22 @@ def stats() -> dict:
     s = Stats()
     check(lib().ndbhip_stats_get(C.byref(s)))
     return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+
+def use_torch_stream():
+    """Order the library's kernels with torch's: both run on torch's current stream afterwards.  The
+    device-pointer entry points are asynchronous on the library's stream, so a caller that fills, gathers or
+    reads their buffers with torch (bench.py, dist.py, the GPU tests) has to share a stream with them.
+    torch's default stream has the handle 0, which ndbhip_set_stream reads as "the library's own stream" — a
+    non-blocking stream that does NOT synchronise with the default stream — so in that case torch is first
+    switched to a stream of its own (ordered after the work already queued on the default stream)."""
+    import torch
+    ensure_init(torch.cuda.current_device())
+    s = torch.cuda.current_stream()
+    if s.cuda_stream == 0:
+        new = torch.cuda.Stream()
+        new.wait_stream(s)
+        torch.cuda.set_stream(new)
+        s = new
+    check(lib().ndbhip_set_stream(s.cuda_stream))
+    return s

@@ -34,3 +34,20 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def library_on_torch_stream():
+    """The device-pointer entry points are asynchronous on the library's stream (include/ndbhip.h); the GPU tests
+    fill and read their buffers with torch, so both run on torch's stream — the ordering contract a caller has
+    to keep, and what bench.py does."""
+    if not _have_gpu():
+        yield
+        return
+    import torch
+    from neurondb_amd import _lib
+    _lib.ensure_init(0)
+    _lib.use_torch_stream()     # torch's default stream has handle 0 = "the library's own stream": see there
+    yield
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().ndbhip_set_stream(None))

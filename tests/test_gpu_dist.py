@@ -37,7 +37,7 @@ def _worker(rank, world, port, slices, ret):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         # kernels and collectives are ordered by sharing torch's stream (what bench.py does)
-        _lib.check(_lib.lib().ndbhip_set_stream(torch.cuda.current_stream().cuda_stream))
+        _lib.use_torch_stream()
         a = make_ivf_arrays(4000, 64, 20, seed=51, dup_frac=0.1)
         img = oracle_image(a)
         rng = np.random.default_rng(52)

@@ -221,3 +221,64 @@ def test_c3_hnsw_at_full_size():
     e2 = ix2.export()
     assert hashlib.sha256(e2["nbrs"].tobytes() + e2["ncount"].tobytes()).hexdigest() == digest
     ix2.close()
+
+
+def _free_gib():
+    free, _ = torch.cuda.mem_get_info(0)
+    return free / 2 ** 30
+
+
+@pytest.mark.parametrize("cfg", ["C4", "C5"])
+def test_c4_c5_single_gpu_share_properties(cfg):
+    """configs[3] / configs[4] at their full row counts on ONE device (the 8-GPU runs shard these rows):
+    C4 = 10M x 768 fp32, lists = 4096, probes = 32, L2;  C5 = 10M x 1536 fp16 rows, inner product, batches of 256.
+    Device-only properties: sorted results, bit-identical repeats, a query's result independent of its batch,
+    and every returned distance recomputed on the device by the exact-scan kernel of the same recipe
+    (ndbhip_batch_distance recipe 0 on the returned rows, itself oracle-checked in test_gpu_ivf.py)."""
+    from neurondb_amd import IvfIndex, _lib
+    lib, check = _lib.lib(), _lib.check
+    n, dim, lists, strategy, nq = (10_000_000, 768, 4096, 1, 1024) if cfg == "C4" else (10_000_000, 1536, 4096, 3, 256)
+    need = n * dim * 4 / 2 ** 30 * (1.2 if cfg == "C4" else 1.8) + 8
+    if _free_gib() < need:
+        pytest.skip(f"needs {need:.0f} GiB of free HBM")
+    dev = torch.device("cuda", 0)
+    _lib.ensure_init(0)
+    base = make_data(n, dim, "clustered", 4096, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
+    q = make_data(nq, dim, "clustered", 4096, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    ix = IvfIndex(dim, lists)
+    ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
+    if cfg == "C5":
+        twin = ix.to_f16(False)
+        ix.close()
+        ix = twin
+        # what the fp16 rows decode to: fp16_to_float, whose subnormals come out 2^-10 too small (quirk Q20)
+        for s0 in range(0, n, 1 << 20):
+            h = base[s0:s0 + (1 << 20)].to(torch.float16)
+            f = h.to(torch.float32)
+            sub = (h.abs() < 2.0 ** -14) & (h != 0)
+            base[s0:s0 + (1 << 20)] = torch.where(sub, f * 2.0 ** -10, f)
+
+    def search(qs):
+        m = qs.shape[0]
+        ot = torch.zeros((m, K), dtype=torch.int64, device=dev)
+        od = torch.zeros((m, K), dtype=torch.float32, device=dev)
+        oc = torch.zeros(m, dtype=torch.int32, device=dev)
+        ix.search_device(qs.contiguous(), ot, od, oc, strategy, PROBES, K, 0)
+        check(lib.ndbhip_synchronize())
+        return unpack_tids(ot).cpu().numpy(), od.cpu().numpy(), oc.cpu().numpy()
+
+    rows, dist, cnt = search(q)
+    assert (cnt == K).all() and (np.diff(dist, axis=1) >= 0).all()
+    rows2, dist2, _ = search(q)
+    assert np.array_equal(rows, rows2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32))
+    for lo, m in ((0, 1), (17, 8), (100, 64)):
+        r, d, _ = search(q[lo:lo + m])
+        assert np.array_equal(r, rows[lo:lo + m]) and np.array_equal(d.view(np.uint32), dist[lo:lo + m].view(np.uint32))
+    # distances of the returned rows, recomputed one query at a time by the exact-scan kernel
+    qh = q.cpu().numpy()
+    for i in range(0, nq, max(1, nq // 24)):
+        v = np.ascontiguousarray(base[torch.from_numpy(rows[i]).to(dev)].cpu().numpy())
+        out = np.zeros((1, K), np.float32)
+        check(lib.ndbhip_batch_distance(qh[i].ctypes.data, v.ctypes.data, out.ctypes.data, 1, K, dim, strategy, 0))
+        assert np.array_equal(out[0].view(np.uint32), dist[i].view(np.uint32)), i
+    ix.close()

@@ -17,6 +17,7 @@ def main():
     from neurondb_amd._lib import check, lib
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
+    _lib.use_torch_stream()
     n, dim, nlists, nprobe, k = 1_000_000, 768, 1024, 32, 10
     base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
     q = make_data(16384, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)

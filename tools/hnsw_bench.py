@@ -36,6 +36,7 @@ def main():
     from neurondb_amd._lib import check, lib
     import ctypes as C
     _lib.ensure_init(0)
+    _lib.use_torch_stream()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0003)

@@ -27,6 +27,7 @@ def main():
     from neurondb_amd import IvfIndex, _lib
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
+    _lib.use_torch_stream()
     base = make_data(a.nvec, a.dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
     q = make_data(a.n + 20, a.dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev).cpu().numpy()
     ix = IvfIndex(a.dim, a.lists)

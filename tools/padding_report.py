@@ -17,6 +17,7 @@ def main():
     from neurondb_amd import IvfIndex, _lib
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
+    _lib.use_torch_stream()
     n, dim, nlists, nprobe = 1_000_000, 768, 1024, 32
     base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
     ix = IvfIndex(dim, nlists)

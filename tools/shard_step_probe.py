@@ -30,7 +30,7 @@ def main():
     from neurondb_amd.dist import ShardedSearchBuffers, partition_lists, partition_slices, query_slice
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
-    check(lib().ndbhip_set_stream(torch.cuda.current_stream().cuda_stream))
+    _lib.use_torch_stream()
     n, dim, nlists, nprobe, k, nq = 1_000_000, 768, 1024, 32, 10, int(os.environ.get("NQ", 4096))
     base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
     q = make_data(nq, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)

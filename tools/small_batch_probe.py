@@ -18,6 +18,7 @@ def main():
     from neurondb_amd._lib import check, lib
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
+    _lib.use_torch_stream()
     n, dim = int(os.environ.get("NVEC", 1_000_000)), 768
     base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
     qd = make_data(4096, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
