@@ -89,6 +89,10 @@ class ShardedSearchBuffers:
     """Pre-allocated exchange buffers for batches of nq queries."""
 
     def __init__(self, nq: int, k: int, world: int, device, nprobe: int = 0):
+        if torch.device(device).type == "cuda":
+            # the library's kernels, torch's copies and the collectives must run in one order: one stream
+            from . import _lib
+            _lib.use_torch_stream()
         cap = partial_cap(k)
         self.nq, self.k, self.world, self.cap = nq, k, world, cap
         self.nprobe = nprobe
