@@ -69,6 +69,18 @@ def hnsw():
             B[i, :len(b)], D[i, :len(b)] = b, d
         out[f"s{strategy}_blocks"], out[f"s{strategy}_dist"] = B, D
         out[f"s{strategy}_count"], out[f"s{strategy}_scored"] = C, S
+    # src/scan/hnsw_scan.c (hnsw_search_layer) on the same graph: slot order, compute_l2_distance
+    for ef, k in ((32, 10), (2, 5)):
+        B = np.zeros((len(q), k), np.uint32)
+        D = np.zeros((len(q), k), np.float32)
+        C = np.zeros(len(q), np.int32)
+        S = np.zeros(len(q), np.int64)
+        for i, qq in enumerate(q):
+            b, d, ns = g.search_layer(qq, ef, k)
+            C[i], S[i] = len(b), ns
+            B[i, :len(b)], D[i, :len(b)] = b, d
+        out[f"layer{ef}_blocks"], out[f"layer{ef}_dist"] = B, D
+        out[f"layer{ef}_count"], out[f"layer{ef}_scored"] = C, S
     np.savez_compressed(os.path.join(HERE, "hnsw_small.npz"), **out)
 
 

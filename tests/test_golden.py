@@ -47,6 +47,12 @@ def test_oracle_reproduces_hnsw_golden():
             c = int(z[f"s{s}_count"][i])
             assert np.array_equal(b, z[f"s{s}_blocks"][i, :c]) and ns == int(z[f"s{s}_scored"][i])
             assert np.array_equal(d.view(np.uint32), z[f"s{s}_dist"][i, :c].view(np.uint32))
+    for ef, k in ((32, 10), (2, 5)):                       # src/scan/hnsw_scan.c: hnsw_search_layer
+        for i, q in enumerate(z["queries"]):
+            b, d, ns = g.search_layer(q, ef, k)
+            c = int(z[f"layer{ef}_count"][i])
+            assert np.array_equal(b, z[f"layer{ef}_blocks"][i, :c]) and ns == int(z[f"layer{ef}_scored"][i])
+            assert np.array_equal(d.view(np.uint32), z[f"layer{ef}_dist"][i, :c].view(np.uint32))
 
 
 @pytest.mark.gpu
@@ -85,3 +91,21 @@ def test_hip_hnsw_reproduces_golden():
         for i in range(len(c)):
             assert np.array_equal(b[i, :c[i]], z[f"s{s}_blocks"][i, :c[i]])
             assert np.array_equal(d[i, :c[i]].view(np.uint32), z[f"s{s}_dist"][i, :c[i]].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_hnsw_search_layer_reproduces_golden():
+    """hnsw_search_layer on a graph BUILT on the device from the golden inputs (a device-built mirror keeps the
+    out-of-node slots the in-memory oracle graph has, which this search can read)."""
+    from neurondb_amd import HnswIndex
+    z = np.load(os.path.join(G, "hnsw_small.npz"))
+    ix = HnswIndex(z["vecs"].shape[1], int(z["m"]))
+    ix.build(z["vecs"], ndbo.tids_from_rows(np.arange(len(z["vecs"]))), z["levels_in"], int(z["efc"]))
+    e = ix.export()
+    assert np.array_equal(e["nbrs"], z["g_nbrs"]) and np.array_equal(e["ncount"], z["g_ncount"])
+    for ef, k in ((32, 10), (2, 5)):
+        b, d, c, _, sc = ix.search_layer(z["queries"], ef, k)
+        assert np.array_equal(c, z[f"layer{ef}_count"]) and np.array_equal(sc, z[f"layer{ef}_scored"])
+        for i in range(len(c)):
+            assert np.array_equal(b[i, :c[i]], z[f"layer{ef}_blocks"][i, :c[i]])
+            assert np.array_equal(d[i, :c[i]].view(np.uint32), z[f"layer{ef}_dist"][i, :c[i]].view(np.uint32))
