@@ -435,6 +435,26 @@ int			ndbhip_extract_vector(int kind, const void *datum, size_t datum_len, float
 int			ndbhip_batch_distance(const float *queries, const float *vectors, float *results,
 								  int nq, int nv, int dim, int strategy, int recipe);
 
+/* ------------------------------------------------------------------ */
+/* The launcher shapes of the reference's GPU vtable (struct ndb_gpu_backend,
+ * include/neurondb_gpu_backend.h:54-84; ROCm bodies src/gpu/rocm/gpu_backend_rocm.c:752-1000), host
+ * pointers in and out like there — with the arithmetic of the CPU functions the reference falls back to,
+ * so an answer does not depend on which side produced it.  include/ndb_backend.h wraps them in a vtable.
+ *   pair_distance  out[i] = l2_distance / cosine_distance / inner_product (A[i], B[i])  (launch_l2_distance,
+ *                  launch_cosine: n PAIRS, not a matrix); strategy 1 / 2 / 3, scalar double kernels of
+ *                  src/vector/vector_distance.c:93-227 (3 = +dot, the operator's sign)
+ *   kmeans_assign  idx[i] = first minimum of the fp32 squared L2 to the k centroids (launch_kmeans_assign;
+ *                  ivf_am.c:2157-2180, 2274-2294)
+ *   kmeans_update  C[c] = members of c added in sample order / (float) count, empty clusters keep their
+ *                  centroid (launch_kmeans_update; ivf_am.c:2182-2213); n is bounded by the LDS-resident
+ *                  member list (37 k rows — the reference's k-means never sees more than 10 000)
+ *   quant_fp16     float4_to_fp16 (launch_quant_fp16; src/types/quantization.c:141-168)     */
+/* ------------------------------------------------------------------ */
+int			ndbhip_pair_distance(const float *A, const float *B, float *out, int n, int dim, int strategy);
+int			ndbhip_kmeans_assign(const float *X, const float *C, int *idx, int n, int dim, int k);
+int			ndbhip_kmeans_update(const float *X, const int *idx, float *C, int n, int dim, int k);
+int			ndbhip_quant_fp16(const float *in, uint16_t *out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,9 +37,9 @@ def lib_path() -> str:
 
 def declared_symbols() -> list:
     """Every function include/*.h declares (ndbhip.h: the C ABI; ndb_am.h: the AM callbacks over it; ndb_sql.h:
-    the SQL-level batch functions over it)."""
+    the SQL-level batch functions over it; ndb_backend.h: the GPU plugin vtable over it)."""
     out = set()
-    for name in ("ndbhip.h", "ndb_am.h", "ndb_sql.h"):
+    for name in ("ndbhip.h", "ndb_am.h", "ndb_sql.h", "ndb_backend.h"):
         with open(os.path.join(_ROOT, "include", name)) as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -59,6 +59,34 @@ class NdbIndexScan(C.Structure):
     _fields_ = [("indexRelation", C.c_void_p), ("numberOfKeys", C.c_int), ("numberOfOrderBys", C.c_int),
                 ("xs_heaptid", NdbItemPointer), ("xs_orderbyval", C.c_float), ("xs_orderbynull", C.c_int),
                 ("xs_recheckorderby", C.c_int), ("opaque", C.c_void_p)]
+
+
+class NdbHipDeviceInfo(C.Structure):
+    _fields_ = [("device_id", C.c_int), ("name", C.c_char * 256), ("total_memory_bytes", C.c_size_t),
+                ("free_memory_bytes", C.c_size_t), ("compute_units", C.c_int), ("is_available", C.c_int)]
+
+
+_FN = C.CFUNCTYPE
+
+
+class NdbHipBackend(C.Structure):
+    """include/ndb_backend.h: struct ndb_hip_backend (the reference's ndb_gpu_backend members for this path)"""
+    _fields_ = [("name", C.c_char_p), ("provider", C.c_char_p), ("features", C.c_uint), ("priority", C.c_int),
+                ("init", _FN(C.c_int)), ("shutdown", _FN(None)), ("is_available", _FN(C.c_int)),
+                ("device_count", _FN(C.c_int)), ("device_info", _FN(C.c_int, C.c_int, C.POINTER(NdbHipDeviceInfo))),
+                ("set_device", _FN(C.c_int, C.c_int)),
+                ("mem_alloc", _FN(C.c_int, C.POINTER(C.c_void_p), C.c_size_t)), ("mem_free", _FN(C.c_int, C.c_void_p)),
+                ("memcpy_h2d", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("memcpy_d2h", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("launch_l2_distance", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)),
+                ("launch_cosine", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)),
+                ("launch_kmeans_assign", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p)),
+                ("launch_kmeans_update", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p)),
+                ("launch_quant_fp16", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)),
+                ("stream_create", _FN(C.c_int, C.POINTER(C.c_void_p))), ("stream_destroy", _FN(C.c_int, C.c_void_p)),
+                ("stream_synchronize", _FN(C.c_int, C.c_void_p))]
 
 
 class NdbKnnRow(C.Structure):
@@ -161,6 +189,10 @@ def lib():
         "ndbhip_hnsw_search_layer_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_batch_distance": (i, [vp, vp, vp, i, i, i, i, i]),
         "ndbhip_extract_vector": (i, [i, vp, C.c_size_t, vp, i, C.POINTER(i)]),
+        "ndbhip_pair_distance": (i, [vp, vp, vp, i, i, i]),
+        "ndbhip_kmeans_assign": (i, [vp, vp, vp, i, i, i]),
+        "ndbhip_kmeans_update": (i, [vp, vp, vp, i, i, i]),
+        "ndbhip_quant_fp16": (i, [vp, vp, i64]),
         # include/ndb_am.h
         "ndb_am_set_guc": (i, [C.c_char_p, i]),
         "ndb_am_get_guc": (i, [C.c_char_p, C.POINTER(i)]),
@@ -185,6 +217,8 @@ def lib():
         "ndb_vector_cosine_distance_gpu": (i, [vp, C.c_size_t, vp, C.c_size_t, vp]),
         "ndb_vector_inner_product_gpu": (i, [vp, C.c_size_t, vp, C.c_size_t, vp]),
         "ndb_ivf_knn_search_gpu": (i, [vp, i, vp, vp, i, i, i, vp, C.POINTER(i64)]),
+        # include/ndb_backend.h
+        "ndb_hip_backend_get": (C.POINTER(NdbHipBackend), []),
         "ndb_hnsw_knn_search_gpu": (i, [vp, i, vp, vp, i, i, i, vp, C.POINTER(i64)]),
         "ndbhip_ivf_build": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
         "ndbhip_ivf_insert": (i, [vp, vp, vp, C.POINTER(i)]),

@@ -3617,6 +3617,53 @@ ndbhip_batch_distance(const float *queries, const float *vectors, float *results
 }
 
 
+/* out[i] = the SQL operator's distance of the PAIR (A[i], B[i]): the pairwise shape of the reference's GPU
+ * vtable launchers (include/neurondb_gpu_backend.h:54-65), with the arithmetic of the CPU functions they fall
+ * back to (src/vector/vector_distance.c:93-227), so a result does not depend on whether the device served it */
+__global__ __launch_bounds__(256) void
+k_op_pairs(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n, int dim,
+		   int strategy)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+
+	if (i < n)
+		out[i] = op_scalar_pair<false>((const char *) (a + (size_t) i * dim), (const char *) (b + (size_t) i * dim),
+									   dim, strategy);
+}
+
+extern "C" int
+ndbhip_pair_distance(const float *A, const float *B, float *out, int n, int dim, int strategy)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (n < 0 || dim < 1 || dim > 32767)
+		return fail(NDBHIP_ERR_INVALID, "bad sizes");
+	if (strategy < 1 || strategy > 3)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "operator kernels: strategy must be 1 (<->), 2 (<=>) or 3 (<#>)");
+	if (n == 0)
+		return NDBHIP_OK;
+	if (!A || !B || !out)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	float	   *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+	const size_t bytes = (size_t) n * dim * sizeof(float);
+
+	HIP_TRY(hipMalloc((void **) &d_a, bytes));
+	HIP_TRY(hipMalloc((void **) &d_b, bytes));
+	HIP_TRY(hipMalloc((void **) &d_o, (size_t) n * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(d_a, A, bytes, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_b, B, bytes, hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_op_pairs, dim3((n + 255) / 256), dim3(256), 0, g.stream, (const float *) d_a,
+					   (const float *) d_b, d_o, (uint32_t) n, dim, strategy);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out, d_o, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_a));
+	HIP_TRY(hipFree(d_b));
+	HIP_TRY(hipFree(d_o));
+	g.host_rows += (uint64_t) n;
+	g.host_bytes += (uint64_t) n * dim * 8;
+	return NDBHIP_OK;
+}
+
 /* ================================================================== */
 /* IVF build: k-means (ivf_am.c:2070-2294), insert-time assignment     */
 /* (:905-935), list packing                                            */
@@ -4244,6 +4291,78 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 	return NDBHIP_OK;
 }
 
+/* One Lloyd half-step each, from host memory: kmeans_assign (ivf_am.c:2157-2180: first minimum of the fp32
+ * squared L2 over the k centroids) and kmeans_update_centroids (:2182-2213: members added in sample order,
+ * divided by (float) count; an empty cluster keeps its centroid).  The shapes of the GPU vtable's
+ * launch_kmeans_assign / launch_kmeans_update (include/neurondb_gpu_backend.h:66-79). */
+extern "C" int
+ndbhip_kmeans_assign(const float *X, const float *C, int *idx, int n, int dim, int k)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!X || !C || !idx || n < 1 || dim < 1 || dim > 32767 || k < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_x = nullptr, *d_c = nullptr;
+	int		   *d_i = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_x, (size_t) n * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_c, (size_t) k * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_i, (size_t) n * sizeof(int)));
+	HIP_TRY(hipMemcpyAsync(d_x, X, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_c, C, (size_t) k * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	int			rc = assign_rows(d_x, n, dim, d_c, k, false, d_i, nullptr);
+
+	if (!rc)
+	{
+		HIP_TRY(hipMemcpyAsync(idx, d_i, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	HIP_TRY(hipFree(d_x));
+	HIP_TRY(hipFree(d_c));
+	HIP_TRY(hipFree(d_i));
+	return rc;
+}
+
+__global__ void
+k_count_members(const int *__restrict__ idx, int n, int k, int *__restrict__ counts)
+{
+	const int	i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i < n && idx[i] >= 0 && idx[i] < k)
+		atomicAdd(&counts[idx[i]], 1);
+}
+
+extern "C" int
+ndbhip_kmeans_update(const float *X, const int *idx, float *C, int n, int dim, int k)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!X || !C || !idx || n < 1 || dim < 1 || dim > 32767 || k < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if ((size_t) n * 4 + 64 > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "k-means update of %d rows exceeds the LDS-resident member list", n);
+	float	   *d_x = nullptr, *d_c = nullptr;
+	int		   *d_i = nullptr, *d_n = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_x, (size_t) n * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_c, (size_t) k * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_i, (size_t) n * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &d_n, (size_t) k * sizeof(int)));
+	HIP_TRY(hipMemcpyAsync(d_x, X, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_c, C, (size_t) k * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_i, idx, (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(d_n, 0, (size_t) k * sizeof(int), g.stream));
+	hipLaunchKernelGGL(k_count_members, dim3((n + 255) / 256), dim3(256), 0, g.stream, (const int *) d_i, n, k, d_n);
+	hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), (size_t) n * 4 + 64, g.stream, (const float *) d_x, n, dim,
+					   (const int *) d_i, (const int *) d_n, d_c);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(C, d_c, (size_t) k * dim * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_x));
+	HIP_TRY(hipFree(d_c));
+	HIP_TRY(hipFree(d_i));
+	HIP_TRY(hipFree(d_n));
+	return NDBHIP_OK;
+}
+
 /* ---- list packing: stable counting sort of rows by list id (heap order kept inside a list) ---- */
 
 #define NDB_PACK_BLOCK 256
@@ -4660,6 +4779,31 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	*out = ix;
 	return ivf_note_f16_subnormals(ix);	/* the reference's encoder flushes them; round-to-nearest may not */
 }
+
+/* float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal results flushed) for n
+ * values from host memory: the GPU vtable's launch_quant_fp16 with the CPU encoder's bits */
+extern "C" int
+ndbhip_quant_fp16(const float *in, uint16_t *out, int64_t n)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!in || !out || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_in = nullptr;
+	uint16_t   *d_out = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_in, (size_t) n * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_out, (size_t) n * sizeof(uint16_t)));
+	HIP_TRY(hipMemcpyAsync(d_in, in, (size_t) n * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_rows_to_f16<true>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, g.stream,
+					   (const float *) d_in, d_out, (size_t) n);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out, d_out, (size_t) n * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_in));
+	HIP_TRY(hipFree(d_out));
+	return NDBHIP_OK;
+}
+
 
 /* nprobe as the meta page / reloptions carry it: what ivfrescan reads (ivf_am.c:1487-1513) */
 extern "C" int
