@@ -93,13 +93,17 @@ typedef struct ndbhip_stats
 	uint64_t	bytes_scored;		/* algorithmic bytes = rows_scored * dim * elem size */
 	uint64_t	scan_launches;		/* launches of the dominant kernel (list scan / hnsw walk) */
 	double		scan_kernel_ms;		/* HIP-event time of those launches (only while profiling is on) */
+	uint64_t	rows_rescored;		/* screened L2 scan: candidates given the reference's arithmetic in the second pass */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);
 int			ndbhip_profile(int on);			/* bracket the dominant kernel with HIP events */
 /* List-scan kernel choice (results are bit-identical either way): 0 = auto
- * (query-grouped scan for batches of >= 8 queries when dim % 64 == 0, per-query
- * scan otherwise), 1 = always per-query, 2 = always grouped. */
+ * (query-grouped scan for batches of >= 5 queries when dim % 64 == 0, per-query
+ * scan otherwise; L2 batches of >= 64 queries over float4 rows are screened), 1 = always per-query,
+ * 2 = always grouped, 3 = grouped and screened whenever the recipe allows, 4 = grouped, never screened.
+ * Screened = a fused-multiply-add pass bounds every candidate's distance from below, and only the candidates
+ * that can still be among the k nearest get the reference's own arithmetic. */
 int			ndbhip_set_scan_mode(int mode);
 
 /* ------------------------------------------------------------------ */

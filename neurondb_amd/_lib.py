@@ -28,7 +28,7 @@ class Cand(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("rows_scored", C.c_uint64), ("bytes_scored", C.c_uint64),
-                ("scan_launches", C.c_uint64), ("scan_kernel_ms", C.c_double)]
+                ("scan_launches", C.c_uint64), ("scan_kernel_ms", C.c_double), ("rows_rescored", C.c_uint64)]
 
 
 def lib_path() -> str:

@@ -56,6 +56,10 @@ fail(int code, const char *fmt, ...)
 /* list-scan kernel choice: 0 auto (grouped for batches >= NDB_GROUPED_MIN_NQ queries and dim % 64 == 0),
  * 1 always per-query (k_ivf_scan), 2 always grouped (k_ivf_scan_grouped) */
 static int	g_scan_mode = 0;
+/* screened L2 scan in auto mode (NDBHIP_SCREEN=0 turns it off); batches below this many queries keep the
+ * exact scan (the two extra passes cost more than they save there) */
+static bool g_screen_auto = true;
+#define NDB_SCREEN_MIN_NQ 64
 /* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32): the grouped path costs 0.38 ms for 1..16
  * queries, the per-query path 0.18 / 0.24 / 0.35 / 0.50 ms for 1 / 2 / 4 / 7 */
 #define NDB_GROUPED_MIN_NQ 5
@@ -156,6 +160,8 @@ ndbhip_init(int device)
 	g.device = device;
 	g.inited = true;
 	{
+		if (getenv("NDBHIP_SCREEN"))
+			g_screen_auto = atoi(getenv("NDBHIP_SCREEN")) != 0;
 		const char *e = getenv("NDBHIP_GCHUNK");
 
 		if (e && atoi(e) == 32)
@@ -231,6 +237,7 @@ ndbhip_stats_get(ndbhip_stats *out)
 		HIP_TRY(hipMemcpy(c, g.d_counters, sizeof(c), hipMemcpyDeviceToHost));
 		g.stats.rows_scored = g.host_rows + c[1];
 		g.stats.bytes_scored = g.host_bytes + c[2];
+		g.stats.rows_rescored = c[3];
 	}
 	*out = g.stats;
 	return NDBHIP_OK;
@@ -254,8 +261,9 @@ ndbhip_stats_reset(void)
 extern "C" int
 ndbhip_set_scan_mode(int mode)
 {
-	if (mode < 0 || mode > 2)
-		return fail(NDBHIP_ERR_INVALID, "scan mode must be 0 (auto), 1 (per-query) or 2 (grouped)");
+	if (mode < 0 || mode > 4)
+		return fail(NDBHIP_ERR_INVALID, "scan mode must be 0 (auto), 1 (per-query), 2 (grouped), 3 (grouped, screened) "
+					"or 4 (grouped, never screened)");
 	g_scan_mode = mode;
 	return NDBHIP_OK;
 }
@@ -1372,6 +1380,55 @@ template <> struct GAcc<R_IVF_COS>
 	}
 };
 
+/*
+ * Screening recipe for L2 (not a reference recipe: a BOUND on one).  Per (row, query) one fused
+ * multiply-add per dimension instead of subtract / multiply / add: dot += q * x, and the row's norm
+ * n2 += x * x once per row.  a = (|q|^2 + n2) - 2 dot approximates the squared distance with
+ *   |a - D| <= E = gamma_(dim+8) * 2 * (|q|^2 + |x|^2)          (D = the real squared distance)
+ * (sequential-FMA dot: gamma_dim * sum |q_i x_i| <= gamma_dim * |q||x|; the two norm chains gamma_dim each;
+ * three roundings to combine), so l = a - E is a LOWER bound of D and l + 2E an upper bound.  The kernel
+ * stores sqrt(max(l, 0)) rounded down as the candidate's provisional distance; k_ivf_rescore then replaces
+ * it by the reference's own sequential sqrtf(sum (q - x)^2) for every candidate that can still be among the
+ * k nearest, and the top-k runs on that: ids, ranks and float4 bits are the exact path's (proof in DESIGN.md).
+ */
+template <> struct GAcc<R_SCR_L2>
+{
+	ndb_f2		s[NDB_QG / 2];
+	float		n2;
+	__device__ __forceinline__ void init()
+	{
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+			s[i] = (ndb_f2) (0.0f);
+		n2 = 0.0f;
+	}
+	__device__ __forceinline__ void step(const ndb_f16 &q, float x)
+	{
+		const ndb_f2 xx = (ndb_f2) (x);
+
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+		{
+			ndb_f2		qp;
+
+			qp.x = q[2 * i];
+			qp.y = q[2 * i + 1];
+			s[i] = __builtin_elementwise_fma(qp, xx, s[i]);
+		}
+		n2 = __builtin_fmaf(x, x, n2);
+	}
+	/* lower bound of the distance, in the distance's own domain: qn = |q|^2, e = E of this query */
+	__device__ __forceinline__ float bound(int j, float qn, float e) const
+	{
+		const float dot = (j & 1) ? s[j >> 1].y : s[j >> 1].x;
+		const float a = (qn + n2) - 2.0f * dot;
+		const float l = a - e;
+
+		return __builtin_sqrtf(fmaxf(l, 0.0f) * 0.99999905f);	/* 1 - 2^-20: sqrtf's own rounding stays below */
+	}
+	__device__ __forceinline__ float fin(int, float) const { return 0.0f; }
+};
+
 /* norm1 of every query: `norm1 += vec1[i] * vec1[i]` in dimension order (ivf_am.c:1574) */
 __global__ void
 k_query_norms(const float *__restrict__ queries, uint32_t nq, int dim, float *__restrict__ out)
@@ -1401,7 +1458,8 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				   const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
 				   const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 				   const uint32_t *__restrict__ runs, float *__restrict__ dist, uint32_t stride,
-				   const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite)
+				   const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite,
+				   uint32_t nq_all)
 {
 	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
 	const int	lane = threadIdx.x & 63;
@@ -1561,7 +1619,12 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 				const uint32_t la = lq[pp];
 				const uint32_t nrow = lq[pp + 1] - la;	/* may be capped below len (ivf_am.c:1743) */
 
-				const float dv = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
+				float		dv;
+
+				if constexpr (R == R_SCR_L2)
+					dv = acc.bound(j, qnorm[qid], qnorm[nq_all + qid]);	/* [|q|^2 ... | E ...] */
+				else
+					dv = acc.fin(j, R == R_IVF_COS ? qnorm[qid] : 0.0f);
 
 				if (ridx < nrow)
 					dist[(size_t) qid * stride + la + ridx] = dv;
@@ -1578,6 +1641,199 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 		}
 	}
 	}
+}
+
+/* ------------------------------------------------------------------ */
+/* Screened L2 scan (grouped path): see GAcc<R_SCR_L2>.                 */
+/* ------------------------------------------------------------------ */
+#define NDB_SCR_U 5.9604645e-8f		/* 2^-24 */
+
+/* largest float of a non-negative array (bits order like values) */
+__global__ void
+k_max_nonneg(const float *__restrict__ v, int64_t n, uint32_t *__restrict__ out_bits)
+{
+	uint32_t	m = 0;
+
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+		m = max(m, __float_as_uint(v[i]));
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		m = max(m, (uint32_t) __shfl_xor((int) m, off, 64));
+	if ((threadIdx.x & 63) == 0)
+		atomicMax(out_bits, m);
+}
+
+/* qe[q] = |q|^2 (already there), qe[nq + q] = E of query q: gamma_(dim+8) * 2 * (|q|^2 + max |x|^2), inflated by
+ * 1 % for the rounding of the norms themselves, plus an absolute floor for underflow */
+__global__ void
+k_screen_eq(float *__restrict__ qe, uint32_t nq, int dim, const float *__restrict__ xxmax)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (q >= nq)
+		return;
+	const float nu = (float) (dim + 8) * NDB_SCR_U;
+	const float gam = nu / (1.0f - nu);
+
+	qe[nq + q] = gam * 2.02f * (qe[q] + *xxmax) + 1e-30f;
+}
+
+/*
+ * Second pass of the screened scan.  lk = the k-th smallest provisional distance (a lower bound of that
+ * candidate's distance; first-pass top-k).  With l = lk^2 the k-th smallest LOWER bound of the squared
+ * distances, l + 2E is the k-th smallest UPPER bound, so the k-th smallest real squared distance is at most
+ * l + 2E, the reference's k-th sequential sum T at most (l + 2E)(1 + gamma), and every candidate whose float4
+ * distance can be <= the k-th float4 distance has a lower bound <= thr (slack m covers the sequential sum's own
+ * rounding and the two sqrtf roundings).  k_ivf_survivors (one block per query) finds those candidates through
+ * the tile minima — a few dozen per query — and lists them; k_ivf_rescore_list gives each the reference's own
+ * arithmetic, one lane per candidate.  The rest keep their provisional value, which is above the k-th
+ * distance.  Tile minima are recomputed over what the buffer then holds.
+ */
+struct ScrRec
+{
+	uint32_t	q, pos, row, slot;
+};
+
+__device__ __forceinline__ float
+scr_exact_l2(const float *__restrict__ qq, const float *__restrict__ x, int dim)
+{
+	Acc<R_IVF_L2> acc;
+	int			i = 0;
+
+	for (; i + 64 <= dim; i += 64)	/* 16 + 16 loads in flight, then the reference's chain */
+	{
+		float4		xv[16], qv[16];
+
+#pragma unroll
+		for (int u = 0; u < 16; u++)
+		{
+			xv[u] = *reinterpret_cast<const float4 *>(x + i + 4 * u);
+			qv[u] = *reinterpret_cast<const float4 *>(qq + i + 4 * u);
+		}
+#pragma unroll
+		for (int u = 0; u < 16; u++)
+		{
+			acc.step(qv[u].x, xv[u].x);
+			acc.step(qv[u].y, xv[u].y);
+			acc.step(qv[u].z, xv[u].z);
+			acc.step(qv[u].w, xv[u].w);
+		}
+	}
+	for (; i < dim; i++)
+		acc.step(qq[i], x[i]);
+	return acc.fin();
+}
+
+__global__ __launch_bounds__(256) void
+k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
+				const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride,
+				uint32_t *__restrict__ tmin, uint32_t tstride, const float *__restrict__ qe, uint32_t nq, uint32_t k,
+				const float *__restrict__ first_dist, const int *__restrict__ first_count,
+				ScrRec *__restrict__ recs, uint32_t rec_cap, unsigned int *__restrict__ rec_count)
+{
+	const uint32_t q = blockIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
+	const int	dim = ix.dim;
+	float		thr = FLT_MAX;
+
+	if (first_count[q] >= (int) k)
+	{
+		const float lk = first_dist[(size_t) q * k + (k - 1)];
+		const float e = qe[nq + q];
+		const float m = (float) (16 * dim + 64) * NDB_SCR_U;
+		const float l2 = lk * lk * 1.0000039f;		/* undo the kernel's round-down (2^-20) and sqrtf's */
+		const float t2 = (l2 + 2.0f * e) * (1.0f + m);
+
+		thr = __builtin_sqrtf(t2) * 1.000001f;
+	}
+	const uint32_t kthr = ndb_key_from_bits(__float_as_uint(thr));
+	uint32_t   *tm = tmin + (size_t) q * tstride;
+	uint32_t	unit = 0;
+
+	/* units of 64 tile slots, dealt to the block's 4 waves in turn */
+	for (int pp = 0; pp < npr; pp++)
+	{
+		const uint32_t la = lco[pp], nrow = lco[pp + 1] - la;
+		const uint32_t ntile = (nrow + 63u) >> 6;
+
+		for (uint32_t tbase = 0; tbase < ntile; tbase += 64, unit++)
+		{
+			if ((unit & 3u) != wave)
+				continue;
+			const uint32_t tt = tbase + lane;
+			unsigned long long hits = __ballot(tt < ntile && tm[(la >> 6) + pp + tt] <= kthr);
+
+			while (hits)
+			{
+				const uint32_t t = tbase + (uint32_t) (__ffsll((long long) hits) - 1);
+
+				hits &= hits - 1ull;
+				const uint32_t ridx = t * 64 + lane;
+				const bool	valid = ridx < nrow;
+				float	   *dp = dist + (size_t) q * stride + la + ridx;
+				float		v = valid ? *dp : FLT_MAX;
+				const bool	surv = valid && v <= thr;
+				const unsigned long long sm = __ballot(surv);
+				const int	L = probes[(size_t) q * npr + pp];
+				const uint32_t row = (uint32_t) ix.loc_off[L] + ridx;
+				const uint32_t slot = (la >> 6) + (uint32_t) pp + t;
+				uint32_t	base = 0;
+
+				if (lane == 0 && sm)
+					base = atomicAdd(rec_count, (unsigned int) __popcll(sm));
+				base = __shfl(base, 0, 64);
+				if (surv)
+				{
+					const uint32_t at = base + (uint32_t) __popcll(sm & ((1ull << lane) - 1ull));
+
+					if (at < rec_cap)
+					{
+						ScrRec		r;
+
+						r.q = q; r.pos = la + ridx; r.row = row; r.slot = slot;
+						recs[at] = r;
+						v = FLT_MAX;	/* its exact value is min-ed into the tile by k_ivf_rescore_list */
+					}
+					else
+					{
+						/* list full: do it here */
+						v = scr_exact_l2(queries + (size_t) q * dim, ix.vecs + (size_t) row * (size_t) dim, dim);
+						*dp = v;
+					}
+				}
+				/* the tile's minimum over what stays as it is */
+				uint32_t	mk = (valid && v != FLT_MAX) ? ndb_key_from_bits(__float_as_uint(v)) : 0xFFFFFFFFu;
+
+#pragma unroll
+				for (int off = 32; off > 0; off >>= 1)
+					mk = min(mk, (uint32_t) __shfl_xor((int) mk, off, 64));
+				if (lane == 0)
+					tm[slot] = mk;
+			}
+		}
+	}
+}
+
+/* one lane per listed candidate: the reference's arithmetic, the value into the distance buffer and into its
+ * tile's minimum */
+__global__ __launch_bounds__(64) void
+k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restrict__ dist, uint32_t stride,
+				   uint32_t *__restrict__ tmin, uint32_t tstride, const ScrRec *__restrict__ recs, uint32_t rec_cap,
+				   const unsigned int *__restrict__ rec_count, unsigned long long *__restrict__ counters)
+{
+	const uint32_t n = min(*rec_count, rec_cap);
+	const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+
+	if (blockIdx.x == 0 && threadIdx.x == 0 && counters)
+		atomicAdd(&counters[3], (unsigned long long) *rec_count);
+	if (i >= n)
+		return;
+	const ScrRec r = recs[i];
+	const float v = scr_exact_l2(queries + (size_t) r.q * ix.dim, ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
+
+	dist[(size_t) r.q * stride + r.pos] = v;
+	atomicMin(&tmin[(size_t) r.q * tstride + r.slot], ndb_key_from_bits(__float_as_uint(v)));
 }
 
 /* dynamic LDS layout of k_ivf_topk / k_merge_topk */
@@ -2028,7 +2284,15 @@ struct ndbhip_ivf
 	uint32_t   *w_goff = nullptr;	size_t w_goff_n = 0;	/* [2*(ncent+1)]: pair_off, item_off */
 	PairRec    *w_pairs = nullptr;	size_t w_pairs_n = 0;
 	float	   *w_qblock = nullptr;	size_t w_qblock_n = 0;	/* [groups][dim][16] interleaved queries */
-	float	   *w_qnorm = nullptr;	size_t w_qnorm_n = 0;	/* [nq] sum of squares of every query (cosine) */
+	float	   *w_qnorm = nullptr;	size_t w_qnorm_n = 0;	/* [2 nq] sum of squares of every query (cosine, screening) | screening E */
+	/* screened L2 scan: largest row norm^2 of the rows held here (valid while norm_valid), first-pass top-k scratch */
+	float	   *d_xxmax = nullptr;
+	bool		norm_valid = false;
+	float	   *w_rnorm = nullptr;	size_t w_rnorm_n = 0;
+	uint64_t   *w_scrt = nullptr;	size_t w_scrt_n = 0;
+	float	   *w_scrd = nullptr;	size_t w_scrd_n = 0;
+	int		   *w_scrc = nullptr;	size_t w_scrc_n = 0;
+	uint32_t   *w_screc = nullptr;	size_t w_screc_n = 0;	/* survivor records (4 words each) + their count */
 	float	   *w_cblock = nullptr;	size_t w_cblock_n = 0;	/* centroids interleaved 16 per block (batch centroid scan) */
 	uint32_t   *w_tmin = nullptr;	size_t w_tmin_n = 0;	/* [nq][tstride] smallest order key per 64-candidate tile */
 	/* split top-k of small batches: per-range records, counts, totals */
@@ -2084,6 +2348,7 @@ ivf_free_rows(ndbhip_ivf *ix)
 	ix->d_tids = nullptr;
 	ix->own_rows = false;
 	ix->nrows = 0;
+	ix->norm_valid = false;
 	ix->cap_rows = 0;
 }
 
@@ -2098,7 +2363,8 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		ivf_free_rows(ix);
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->d_own_lo, ix->d_own_len, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
-			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock};
+			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock,
+			ix->d_xxmax, ix->w_rnorm, ix->w_scrt, ix->w_scrd, ix->w_scrc, ix->w_screc};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2231,6 +2497,7 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
+	ix->norm_valid = false;
 	ix->loaded = true;
 	return NDBHIP_OK;
 }
@@ -2309,6 +2576,7 @@ ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owne
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
+	ix->norm_valid = false;
 	ix->f16 = true;
 	ix->loaded = true;
 	return ivf_note_f16_subnormals(ix);
@@ -2333,6 +2601,7 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 	ix->own_rows = false;
 	ix->f16 = false;
 	ix->nrows = nrows;
+	ix->norm_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
 	return NDBHIP_OK;
@@ -2499,6 +2768,7 @@ ivf_flush(ndbhip_ivf *ix)
 	ix->d_tids = ntids_d;
 	ix->own_rows = true;
 	ix->nrows = nown;
+	ix->norm_valid = false;
 	ix->cap_rows = cap;
 	ix->pend_list.clear();
 	ix->pend_rows.clear();
@@ -2714,6 +2984,7 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 		ix->own_rows = true;
 		ix->cap_rows = cap;
 		ix->nrows = (int64_t) total;
+		ix->norm_valid = false;
 		rc = ivf_set_layout(ix, newlen.data(), nullptr, (int64_t) total);
 	}
 	if (removed)
@@ -2869,7 +3140,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	/* one slot per (probe, 64-candidate tile): slot = (local offset of the probe >> 6) + probe + tile */
 	const uint32_t tstride = (((stride >> 6) + (uint32_t) npr + 2u) + 63u) & ~63u;
 	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
-		(g_scan_mode == 2 || (g_scan_mode == 0 && nq >= NDB_GROUPED_MIN_NQ));
+		(g_scan_mode >= 2 || (g_scan_mode == 0 && nq >= NDB_GROUPED_MIN_NQ));
+	bool		screen = false;
 
 	if (grouped)
 	{
@@ -2881,6 +3153,9 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
 		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
 		ScanTimer	t;
+		/* screened L2 scan (GAcc<R_SCR_L2>): float4 rows, 32-float chunks; mode 0 = auto, 3 = always, 4 = never */
+		screen = R == R_IVF_L2 && !ix->f16 && g_gchunk == 32 &&
+			(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
@@ -2895,9 +3170,39 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, ix->w_qblock);
 		const dim3	pgrid(g.num_cus * 10);	/* one wave per block; LDS admits 10 per CU */
 
-		if (R == R_IVF_COS)
+		if (R == R_IVF_COS || screen)
 			hipLaunchKernelGGL(k_query_norms, dim3((nq + 63) / 64), dim3(64), 0, g.stream, d_q, (uint32_t) nq,
 							   ix->dim, ix->w_qnorm);
+		if (screen)
+		{
+			/* the largest row norm of the rows held here, once per version of the mirror */
+			if (!ix->norm_valid)
+			{
+				if (!ix->d_xxmax)
+					HIP_TRY(hipMalloc((void **) &ix->d_xxmax, sizeof(float)));
+				HIP_TRY(hipMemsetAsync(ix->d_xxmax, 0, sizeof(float), g.stream));
+				if (ix->nrows > 0)
+				{
+					if (grow(ix->w_rnorm, ix->w_rnorm_n, (size_t) ix->nrows + (size_t) ix->dim)) return NDBHIP_ERR_HIP;
+					float	   *zero = ix->w_rnorm + ix->nrows;	/* a zero query: sum (0 - x)^2 = the row's norm^2 */
+
+					HIP_TRY(hipMemsetAsync(zero, 0, (size_t) ix->dim * sizeof(float), g.stream));
+					for (int64_t r0 = 0; r0 < ix->nrows; r0 += (int64_t) 1 << 30)
+					{
+						const uint32_t nr = (uint32_t) std::min<int64_t>((int64_t) 1 << 30, ix->nrows - r0);
+
+						hipLaunchKernelGGL(k_rows_scan<R_IVF_L2SQ>, dim3((nr + 255) / 256, 1), dim3(256), 0, g.stream,
+										   (const float *) ix->d_vecs + (size_t) r0 * ix->dim, nr, ix->dim,
+										   (const float *) zero, ix->w_rnorm + r0, nr);
+					}
+					hipLaunchKernelGGL(k_max_nonneg, dim3(1024), dim3(256), 0, g.stream, (const float *) ix->w_rnorm,
+									   ix->nrows, (uint32_t *) ix->d_xxmax);
+				}
+				ix->norm_valid = true;
+			}
+			hipLaunchKernelGGL(k_screen_eq, dim3((nq + 255) / 256), dim3(256), 0, g.stream, ix->w_qnorm, (uint32_t) nq,
+							   ix->dim, (const float *) ix->d_xxmax);
+		}
 		HIP_TRY(hipMemsetAsync(ix->w_tmin, 0xFF, (size_t) nq * tstride * sizeof(uint32_t), g.stream));
 		if (t.start()) return NDBHIP_ERR_HIP;	/* events bracket the dominant kernel only */
 
@@ -2908,7 +3213,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,   \
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item,               \
 						   (const uint32_t *) runs, ix->w_dist, stride, (const float *) ix->w_qnorm, ix->w_tmin, tstride, \
-						   nq < 1024 ? 1 : 0)
+						   nq < 1024 ? 1 : 0, (uint32_t) nq)
 		if (ix->f16)
 		{
 			const dim3	g16(g.num_cus * 16);	/* 8 KiB tile, 4 waves per SIMD */
@@ -2931,6 +3236,12 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 				else
 					LAUNCH_GROUPED_H(R_IVF_L2, 32, 2, g16);
 			}
+		}
+		else if (screen)
+		{
+			const dim3	g32(g.num_cus * 4 * NDB_G32_WAVES);
+
+			LAUNCH_GROUPED(R_SCR_L2, 32, g32);
 		}
 		else if (g_gchunk == 32)
 		{
@@ -3007,10 +3318,38 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 							   d_otid, d_odist, d_ocnt);
 		}
 		else
+		{
+			if (screen)
+			{
+				/* first pass: the k smallest provisional distances -> the survivors' threshold; then the
+				 * reference's arithmetic for the survivors; the top-k below sees exact values wherever it matters */
+				if (grow(ix->w_scrt, ix->w_scrt_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+				if (grow(ix->w_scrd, ix->w_scrd_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
+				if (grow(ix->w_scrc, ix->w_scrc_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+				hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
+								   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
+								   (uint32_t) k, 0, (ndbhip_cand *) nullptr, (int *) nullptr, (int64_t *) nullptr,
+								   ix->w_scrt, ix->w_scrd, ix->w_scrc, (uint32_t) nq, (const uint32_t *) ix->w_tmin,
+								   tstride);
+				const uint32_t rec_cap = (uint32_t) std::min<size_t>((size_t) nq * 256u, (size_t) 1 << 26);
+
+				if (grow(ix->w_screc, ix->w_screc_n, (size_t) rec_cap * 4 + 16)) return NDBHIP_ERR_HIP;
+				unsigned int *rec_count = (unsigned int *) (ix->w_screc + (size_t) rec_cap * 4);
+
+				HIP_TRY(hipMemsetAsync(rec_count, 0, sizeof(unsigned int), g.stream));
+				hipLaunchKernelGGL(k_ivf_survivors, dim3(nq), dim3(256), 0, g.stream, d, d_q, (const int *) w_probes, lco,
+								   npr, ix->w_dist, stride, ix->w_tmin, tstride, (const float *) ix->w_qnorm,
+								   (uint32_t) nq, (uint32_t) k, (const float *) ix->w_scrd, (const int *) ix->w_scrc,
+								   (ScrRec *) ix->w_screc, rec_cap, rec_count);
+				hipLaunchKernelGGL(k_ivf_rescore_list, dim3((rec_cap + 63) / 64), dim3(64), 0, g.stream, d, d_q,
+								   ix->w_dist, stride, ix->w_tmin, tstride, (const ScrRec *) ix->w_screc, rec_cap,
+								   (const unsigned int *) rec_count, g.d_counters);
+			}
 			hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
 							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
 							   (uint32_t) k, partial, d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, (uint32_t) nq,
 							   grouped ? (const uint32_t *) ix->w_tmin : (const uint32_t *) nullptr, tstride);
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -3074,7 +3413,7 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 8 * NDB_QHEAD_STRIDE + 16)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1) + 80)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) qb)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) 2 * qb)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_tmin, ix->w_tmin_n, (size_t) qb * ((((stride >> 6) + (size_t) nprobe + 2) + 63) & ~(size_t) 63)))
 		return NDBHIP_ERR_HIP;
 	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode == 2))
@@ -4582,6 +4921,7 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	ix->d_tids = d_ptid;
 	ix->own_rows = true;
 	ix->nrows = nrows;
+	ix->norm_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
 	if (out_iters)
@@ -4679,6 +5019,7 @@ ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const int64_t 
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = nrows;
+	ix->norm_valid = false;
 	ix->loaded = true;
 	ix->f16_sub = src->f16_sub;	/* a shard holds a subset of the source's rows */
 	*out = ix;
@@ -4774,6 +5115,7 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = src->nrows;
+	ix->norm_valid = false;
 	ix->f16 = true;
 	ix->loaded = true;
 	*out = ix;

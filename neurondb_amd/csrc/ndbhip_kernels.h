@@ -45,6 +45,7 @@ enum
 	R_IVF_COS = 1,				/* ivf_am.c:1570-1581 */
 	R_IVF_IP = 2,				/* new (quirk Q2): -dot, fp32 sequential */
 	R_IVF_L2SQ = 3,				/* ivf_am.c:2255-2269 (k-means) */
+	R_SCR_L2 = 32,				/* grouped scan only: fused dot + norms, a bound on L2 (screening, ndbhip.hip) */
 	R_HNSW_L2 = 4,				/* hnsw_am.c:1312-1319 */
 	R_HNSW_COS = 5,				/* hnsw_am.c:1321-1332 */
 	R_HNSW_IP = 6,				/* hnsw_am.c:1334-1337 */
