@@ -1729,9 +1729,16 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 				const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride,
 				uint32_t *__restrict__ tmin, uint32_t tstride, const float *__restrict__ qe, uint32_t nq, uint32_t k,
 				const float *__restrict__ first_dist, const int *__restrict__ first_count,
-				ScrRec *__restrict__ recs, uint32_t rec_cap, unsigned int *__restrict__ rec_count)
+				ScrRec *__restrict__ recs_all, uint32_t rec_cap, unsigned int *__restrict__ rec_counts)
 {
+	/* the query's own slice of the list and an LDS counter: one global counter for all blocks would serialise */
+	__shared__ unsigned int s_count;
 	const uint32_t q = blockIdx.x;
+	ScrRec	   *recs = recs_all + (size_t) q * rec_cap;
+
+	if (threadIdx.x == 0)
+		s_count = 0;
+	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
 	const int	dim = ix.dim;
@@ -1781,7 +1788,7 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 				uint32_t	base = 0;
 
 				if (lane == 0 && sm)
-					base = atomicAdd(rec_count, (unsigned int) __popcll(sm));
+					base = atomicAdd(&s_count, (unsigned int) __popcll(sm));
 				base = __shfl(base, 0, 64);
 				if (surv)
 				{
@@ -1813,6 +1820,9 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 			}
 		}
 	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+		rec_counts[q] = min(s_count, rec_cap);
 }
 
 /* one lane per listed candidate: the reference's arithmetic, the value into the distance buffer and into its
@@ -1820,16 +1830,17 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 __global__ __launch_bounds__(64) void
 k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restrict__ dist, uint32_t stride,
 				   uint32_t *__restrict__ tmin, uint32_t tstride, const ScrRec *__restrict__ recs, uint32_t rec_cap,
-				   const unsigned int *__restrict__ rec_count, unsigned long long *__restrict__ counters)
+				   const unsigned int *__restrict__ rec_counts, unsigned long long *__restrict__ counters)
 {
-	const uint32_t n = min(*rec_count, rec_cap);
+	const uint32_t q = blockIdx.y;
+	const uint32_t n = rec_counts[q];
 	const uint32_t i = blockIdx.x * 64 + threadIdx.x;
 
-	if (blockIdx.x == 0 && threadIdx.x == 0 && counters)
-		atomicAdd(&counters[3], (unsigned long long) *rec_count);
+	if (blockIdx.x == 0 && threadIdx.x == 0 && counters && n)
+		atomicAdd(&counters[3], (unsigned long long) n);
 	if (i >= n)
 		return;
-	const ScrRec r = recs[i];
+	const ScrRec r = recs[(size_t) q * rec_cap + i];
 	const float v = scr_exact_l2(queries + (size_t) r.q * ix.dim, ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
 
 	dist[(size_t) r.q * stride + r.pos] = v;
@@ -3154,7 +3165,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
 		ScanTimer	t;
 		/* screened L2 scan (GAcc<R_SCR_L2>): float4 rows, 32-float chunks; mode 0 = auto, 3 = always, 4 = never */
-		screen = R == R_IVF_L2 && !ix->f16 && g_gchunk == 32 &&
+		screen = R == R_IVF_L2 && !ix->f16 &&
 			(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
@@ -3241,7 +3252,10 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		{
 			const dim3	g32(g.num_cus * 4 * NDB_G32_WAVES);
 
-			LAUNCH_GROUPED(R_SCR_L2, 32, g32);
+			if (g_gchunk == 32)
+				LAUNCH_GROUPED(R_SCR_L2, 32, g32);
+			else
+				LAUNCH_GROUPED(R_SCR_L2, 64, pgrid);
 		}
 		else if (g_gchunk == 32)
 		{
@@ -3331,19 +3345,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 								   (uint32_t) k, 0, (ndbhip_cand *) nullptr, (int *) nullptr, (int64_t *) nullptr,
 								   ix->w_scrt, ix->w_scrd, ix->w_scrc, (uint32_t) nq, (const uint32_t *) ix->w_tmin,
 								   tstride);
-				const uint32_t rec_cap = (uint32_t) std::min<size_t>((size_t) nq * 256u, (size_t) 1 << 26);
+				const uint32_t rec_cap = 256;	/* survivors listed per query; more are rescored in place */
 
-				if (grow(ix->w_screc, ix->w_screc_n, (size_t) rec_cap * 4 + 16)) return NDBHIP_ERR_HIP;
-				unsigned int *rec_count = (unsigned int *) (ix->w_screc + (size_t) rec_cap * 4);
+				if (grow(ix->w_screc, ix->w_screc_n, (size_t) nq * rec_cap * 4 + (size_t) nq)) return NDBHIP_ERR_HIP;
+				unsigned int *rec_counts = (unsigned int *) (ix->w_screc + (size_t) nq * rec_cap * 4);
 
-				HIP_TRY(hipMemsetAsync(rec_count, 0, sizeof(unsigned int), g.stream));
 				hipLaunchKernelGGL(k_ivf_survivors, dim3(nq), dim3(256), 0, g.stream, d, d_q, (const int *) w_probes, lco,
 								   npr, ix->w_dist, stride, ix->w_tmin, tstride, (const float *) ix->w_qnorm,
 								   (uint32_t) nq, (uint32_t) k, (const float *) ix->w_scrd, (const int *) ix->w_scrc,
-								   (ScrRec *) ix->w_screc, rec_cap, rec_count);
-				hipLaunchKernelGGL(k_ivf_rescore_list, dim3((rec_cap + 63) / 64), dim3(64), 0, g.stream, d, d_q,
+								   (ScrRec *) ix->w_screc, rec_cap, rec_counts);
+				hipLaunchKernelGGL(k_ivf_rescore_list, dim3(rec_cap / 64, nq), dim3(64), 0, g.stream, d, d_q,
 								   ix->w_dist, stride, ix->w_tmin, tstride, (const ScrRec *) ix->w_screc, rec_cap,
-								   (const unsigned int *) rec_count, g.d_counters);
+								   (const unsigned int *) rec_counts, g.d_counters);
 			}
 			hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
 							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
