@@ -59,7 +59,7 @@ static int	g_scan_mode = 0;
 /* screened L2 scan in auto mode (NDBHIP_SCREEN=0 turns it off); batches below this many queries keep the
  * exact scan (the two extra passes cost more than they save there) */
 static bool g_screen_auto = true;
-#define NDB_SCREEN_MIN_NQ 64
+#define NDB_SCREEN_MIN_NQ 128
 /* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32): the grouped path costs 0.38 ms for 1..16
  * queries, the per-query path 0.18 / 0.24 / 0.35 / 0.50 ms for 1 / 2 / 4 / 7 */
 #define NDB_GROUPED_MIN_NQ 5
@@ -1729,7 +1729,8 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 				const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride,
 				uint32_t *__restrict__ tmin, uint32_t tstride, const float *__restrict__ qe, uint32_t nq, uint32_t k,
 				const float *__restrict__ first_dist, const int *__restrict__ first_count,
-				ScrRec *__restrict__ recs_all, uint32_t rec_cap, unsigned int *__restrict__ rec_counts)
+				ScrRec *__restrict__ recs_all, uint32_t rec_cap, unsigned int *__restrict__ rec_counts,
+				unsigned long long *__restrict__ counters)
 {
 	/* the query's own slice of the list and an LDS counter: one global counter for all blocks would serialise */
 	__shared__ unsigned int s_count;
@@ -1808,6 +1809,13 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 						v = scr_exact_l2(queries + (size_t) q * dim, ix.vecs + (size_t) row * (size_t) dim, dim);
 						*dp = v;
 					}
+				}
+				if (counters && base + (uint32_t) __popcll(sm) > rec_cap)	/* wave-uniform */
+				{
+					const uint32_t first_over = base > rec_cap ? base : rec_cap;
+
+					if (lane == 0)
+						atomicAdd(&counters[3], (unsigned long long) (base + (uint32_t) __popcll(sm) - first_over));
 				}
 				/* the tile's minimum over what stays as it is */
 				uint32_t	mk = (valid && v != FLT_MAX) ? ndb_key_from_bits(__float_as_uint(v)) : 0xFFFFFFFFu;
@@ -3353,7 +3361,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 				hipLaunchKernelGGL(k_ivf_survivors, dim3(nq), dim3(256), 0, g.stream, d, d_q, (const int *) w_probes, lco,
 								   npr, ix->w_dist, stride, ix->w_tmin, tstride, (const float *) ix->w_qnorm,
 								   (uint32_t) nq, (uint32_t) k, (const float *) ix->w_scrd, (const int *) ix->w_scrc,
-								   (ScrRec *) ix->w_screc, rec_cap, rec_counts);
+								   (ScrRec *) ix->w_screc, rec_cap, rec_counts, g.d_counters);
 				hipLaunchKernelGGL(k_ivf_rescore_list, dim3(rec_cap / 64, nq), dim3(64), 0, g.stream, d, d_q,
 								   ix->w_dist, stride, ix->w_tmin, tstride, (const ScrRec *) ix->w_screc, rec_cap,
 								   (const unsigned int *) rec_counts, g.d_counters);

@@ -691,3 +691,60 @@ def test_slice_shards_take_appends_on_the_tail_rank():
     et, ed, ec, _ = oracle_search_batch(img, q, 1, 5, 10)
     _same_u64(t, d, c, et, ed, ec)
     assert sum(s.nrows for s in shards) == nbase + 7
+
+
+@pytest.mark.parametrize("case", ["cancellation", "ties", "spread_norms", "wide", "tiny"])
+def test_screened_scan_is_exact_where_its_bound_is_weakest(case, scan_mode):
+    """The screened L2 scan (mode 3: fused dot + norms as a lower bound, the reference's arithmetic for the
+    survivors) against the oracle on data chosen to stress the bound: rows far from the origin and close to each
+    other (the expansion |q|^2 + |x|^2 - 2 q.x cancels almost completely, so nearly everything survives and the
+    per-query survivor list overflows into the in-place path), exact ties and duplicates, norms spread over six
+    orders of magnitude, a wide dimension, and tiny values."""
+    rng = np.random.default_rng(hash(case) % 1000)
+    dim, n, nlists, nq = 64, 6000, 10, 70
+    if case == "cancellation":
+        center = rng.standard_normal(dim).astype(np.float32) * 300.0
+        base = (center + rng.standard_normal((n, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+        q = (center + rng.standard_normal((nq, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    elif case == "ties":
+        base = rng.integers(-2, 3, size=(n, dim)).astype(np.float32)
+        base[n // 2:] = base[: n - n // 2]
+        q = rng.integers(-2, 3, size=(nq, dim)).astype(np.float32)
+        q[:5] = base[:5]
+    elif case == "spread_norms":
+        base = (rng.standard_normal((n, dim)) * 10.0 ** rng.uniform(-3, 3, (n, 1))).astype(np.float32)
+        base[7] = 0.0
+        q = (rng.standard_normal((nq, dim)) * 10.0 ** rng.uniform(-3, 3, (nq, 1))).astype(np.float32)
+        q[3] = 0.0
+    elif case == "wide":
+        dim, n, nlists = 1536, 3000, 6
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        q = (base[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float32)
+    else:
+        base = (rng.standard_normal((n, dim)) * 1e-18).astype(np.float32)
+        q = (rng.standard_normal((nq, dim)) * 1e-18).astype(np.float32)
+    cent = base[rng.choice(n, nlists, replace=False)].copy()
+    d2 = ((base[:, None, :].astype(np.float64) - cent[None].astype(np.float64)) ** 2).sum(-1) if dim <= 64 else \
+        (base.astype(np.float64) ** 2).sum(1)[:, None] + (cent.astype(np.float64) ** 2).sum(1)[None] - \
+        2.0 * base.astype(np.float64) @ cent.astype(np.float64).T
+    asg = d2.argmin(1)
+    order = np.argsort(asg, kind="stable")
+    from oracle import ndbo
+    a = dict(centroids=cent, list_len=np.bincount(asg, minlength=nlists).astype(np.int64),
+             rows=np.ascontiguousarray(base[order]), tids=ndbo.tids_from_rows(order))
+    img = oracle_image(a)
+    ix = _index(a)
+    for k, nprobe, cap in ((10, 4, 0), (100, nlists, 0), (10, nlists, 300)):
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k, cap)
+        for mode in (3, 2):
+            scan_mode(mode)
+            t, d, c = ix.search(q, 1, nprobe, k, cap)
+            assert_same_results(t, d, c, et, ed, ec)
+    from neurondb_amd import _lib
+    scan_mode(3)
+    _lib.check(_lib.lib().ndbhip_stats_reset())
+    ix.search(q, 1, nlists, 10)
+    st = _lib.stats()
+    assert 0 < st["rows_rescored"] <= nq * n                  # the second pass ran
+    if case == "cancellation":
+        assert st["rows_rescored"] > nq * 256                 # ... and overflowed the per-query list
