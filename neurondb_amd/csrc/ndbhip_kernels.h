@@ -208,7 +208,8 @@ template <int CH>
 __device__ __forceinline__ int
 tile_swz(int r)
 {
-	return CH == 64 ? (r & 15) : ((r >> 1) & 7);
+	/* CH = 16: four rows per 256-B bank row, the row's position in it picks the quarter */
+	return CH == 64 ? (r & 15) : (CH == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3));
 }
 
 template <int CH>
