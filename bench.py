@@ -256,7 +256,7 @@ def main():
                 "candidate's distance from below for up to 16 queries per staged row tile; the candidates that can still be "
                 f"among the k nearest ({st['rows_rescored'] / max(1, nq * args.steps):.0f} per query) get the reference's "
                 "sequential arithmetic in a second pass, so ids, ranks and float4 bits are the exact path's.  The pass is "
-                "bound by memory latency (VALU 45 % busy, 3.0 TB/s of HBM reads at an L2 hit rate of 0.76)")
+                "bound by row-tile fetches (VALU 64 % busy, 3.8 TB/s of HBM reads at an L2 hit rate of 0.85)")
     elif grouped:
         note = ("algorithmic bytes = rows scored x 3072 B per query; the grouped kernel stages each row tile once "
                 "for up to 16 queries, so HBM traffic is ~1/16 of that and the limiter is the fp32 vector ALU")
