@@ -748,3 +748,20 @@ def test_screened_scan_is_exact_where_its_bound_is_weakest(case, scan_mode):
     assert 0 < st["rows_rescored"] <= nq * n                  # the second pass ran
     if case == "cancellation":
         assert st["rows_rescored"] > nq * 256                 # ... and overflowed the per-query list
+
+
+def test_randomised_parity_campaign_all_scan_modes():
+    """A few seconds of tools/fuzz_scan.py (random shapes, scales, k, nprobe, caps, strategies; scan modes screened /
+    grouped / per-query / auto) — the long runs are in profiles/r01l_fuzz_scan.txt."""
+    import time
+    from neurondb_amd import IvfIndex, _lib
+    from tools.fuzz_scan import one_case
+    rng = np.random.default_rng(12345)
+    t0, n = time.time(), 0
+    try:
+        while time.time() - t0 < 6.0:
+            one_case(rng, _lib.lib(), IvfIndex, _lib.check)
+            n += 1
+    finally:
+        _lib.check(_lib.lib().ndbhip_set_scan_mode(0))
+    assert n >= 20

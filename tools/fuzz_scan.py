@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign: IVF search on the device (all scan modes, screened included) against the CPU
+oracle over random shapes, data scales, k, nprobe, candidate caps and strategies.
+usage: python tools/fuzz_scan.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+from oracle import ndbo
+from tests.util import assert_same_results, oracle_image, oracle_search_batch
+
+
+def one_case(rng, lib, IvfIndex, check):
+    dim = int(rng.choice([64, 128, 192, 256, 768]))
+    n = int(rng.integers(200, 5000))
+    nlists = int(rng.integers(1, 24))
+    nq = int(rng.choice([5, 16, 17, 64, 130, 200]))
+    kind = rng.choice(["normal", "offset", "scaled", "integer", "clustered"])
+    if kind == "integer":
+        base = rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+        q = rng.integers(-3, 4, size=(nq, dim)).astype(np.float32)
+    elif kind == "offset":
+        c = rng.standard_normal(dim).astype(np.float32) * float(10.0 ** rng.uniform(0, 3))
+        s = float(10.0 ** rng.uniform(-3, 0))
+        base = (c + s * rng.standard_normal((n, dim))).astype(np.float32)
+        q = (c + s * rng.standard_normal((nq, dim))).astype(np.float32)
+    elif kind == "scaled":
+        base = (rng.standard_normal((n, dim)) * 10.0 ** rng.uniform(-4, 4, (n, 1))).astype(np.float32)
+        q = (rng.standard_normal((nq, dim)) * 10.0 ** rng.uniform(-4, 4, (nq, 1))).astype(np.float32)
+    elif kind == "clustered":
+        cen = rng.standard_normal((8, dim)).astype(np.float32)
+        base = (cen[rng.integers(0, 8, n)] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+        q = (cen[rng.integers(0, 8, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float32)
+    else:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if rng.random() < 0.3:
+        base[rng.integers(0, n, n // 10)] = base[rng.integers(0, n, n // 10)]       # duplicates
+    if rng.random() < 0.2:
+        q[0] = base[0]
+    cent = base[rng.choice(n, nlists, replace=False)].copy()
+    asg = rng.integers(0, nlists, n) if rng.random() < 0.3 else \
+        (((base[:, None, :64].astype(np.float64) - cent[None, :, :64]) ** 2).sum(-1)).argmin(1)
+    order = np.argsort(asg, kind="stable")
+    a = dict(centroids=cent, list_len=np.bincount(asg, minlength=nlists).astype(np.int64),
+             rows=np.ascontiguousarray(base[order]), tids=ndbo.tids_from_rows(order))
+    img = oracle_image(a)
+    ix = IvfIndex(dim, nlists)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    k = int(rng.choice([1, 10, 37, 100]))
+    nprobe = int(rng.integers(1, nlists + 3))
+    cap = int(rng.choice([0, 0, k * 10, 500]))
+    strategy = int(rng.choice([1, 1, 1, 2, 3]))
+    et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
+    for mode in (3, 2, 1, 0):
+        check(lib.ndbhip_set_scan_mode(mode))
+        t, d, c = ix.search(q, strategy, nprobe, k, cap)
+        try:
+            assert_same_results(t, d, c, et, ed, ec)
+        except AssertionError:
+            print("MISMATCH", dict(dim=dim, n=n, nlists=nlists, nq=nq, kind=kind, k=k, nprobe=nprobe, cap=cap,
+                                   strategy=strategy, mode=mode), flush=True)
+            raise
+    check(lib.ndbhip_set_scan_mode(0))
+    ix.close()
+    return kind
+
+
+def main():
+    from neurondb_amd import IvfIndex, _lib
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    _lib.ensure_init(0)
+    rng = np.random.default_rng(seed)
+    t0, n, kinds = time.time(), 0, {}
+    while time.time() - t0 < secs:
+        kd = one_case(rng, _lib.lib(), IvfIndex, _lib.check)
+        kinds[kd] = kinds.get(kd, 0) + 1
+        n += 1
+    print(f"fuzz_scan: {n} random cases x 4 scan modes identical to the oracle (seed {seed}): {kinds}")
+
+
+if __name__ == "__main__":
+    main()
