@@ -1040,7 +1040,7 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 __global__ __launch_bounds__(1024) void
 k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
 			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
-			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs)
+			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv)
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
@@ -1054,7 +1054,7 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
 
 		a += c;
-		b += ((glob_len[L] + 63u) >> 6) * ng;
+		b += ((glob_len[L] + 63u) >> 6) * ((ng + gdiv - 1u) / gdiv);
 		c2 += ng;
 	}
 	sa[t] = a;
@@ -1085,7 +1085,7 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		item_off[L] = b;
 		grp_off[L] = c2;
 		a += c;
-		b += ((glob_len[L] + 63u) >> 6) * ng;
+		b += ((glob_len[L] + 63u) >> 6) * ((ng + gdiv - 1u) / gdiv);
 		c2 += ng;
 	}
 	if (t == 1023)
@@ -1856,6 +1856,179 @@ k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restri
 
 	dist[(size_t) r.q * stride + r.pos] = v;
 	atomicMin(&tmin[(size_t) r.q * tstride + r.slot], ndb_key_from_bits(__float_as_uint(v)));
+}
+
+/* a row piece fetched outside the compiler's view: hipcc drains every outstanding vector load in front of each
+ * `asm volatile` of the query stream, so a C++ load issued ahead of the arithmetic is waited for at once; this
+ * one is only waited for where ndb_gwait says so */
+typedef float ndb_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void
+ndb_gload4(ndb_f4 &v, const float *p)
+{
+	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+}
+
+__device__ __forceinline__ void
+ndb_gwait(ndb_f4 &v)
+{
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory");
+}
+
+/*
+ * The bound pass of the screened scan, cooperative form: one 256-thread block per (list, 64-row tile, FOUR
+ * consecutive query groups).  The four waves of the block score the same rows for four different groups, so
+ * a 16-float chunk of the tile is fetched once — one float4 per thread — into a double-buffered LDS tile and
+ * consumed by all four; with single-wave blocks the sibling waves drift apart over the 48 chunks of an item and
+ * the lines the first one brought in are gone when the others arrive (a row tile came from HBM ~4 times per
+ * batch).  Everything else — work queues, query stream through SGPRs, epilogue — is k_ivf_scan_grouped's.
+ */
+__global__ __launch_bounds__(256, 8) void
+k_ivf_bound_coop(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ loc_cand_off, int npr,
+				 const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
+				 const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
+				 const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
+				 const uint32_t *__restrict__ runs, float *__restrict__ dist, uint32_t stride,
+				 const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite,
+				 uint32_t nq_all)
+{
+	constexpr int CH = 16;
+	__shared__ __attribute__((aligned(16))) float tile[2][64 * CH];
+	__shared__ uint32_t s_item;
+	const int	tid = threadIdx.x;
+	const int	lane = tid & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int	dim = ix.dim;
+	const int	srow = tid >> 2, sslot = tid & 3;	/* staging: thread = (row of the tile, 16-byte slot) */
+
+	for (uint32_t hop = 0; hop < 8; hop++)
+	{
+	const uint32_t xq = (blockIdx.x + hop) & 7u;
+	const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+
+	if (run_lo == run_hi)
+		continue;
+	for (;;)
+	{
+		if (tid == 0)
+			s_item = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
+															__HIP_MEMORY_SCOPE_AGENT) >= run_hi)
+				? run_hi : run_lo + atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
+		__syncthreads();
+		const uint32_t item = s_item;
+
+		__syncthreads();		/* everybody has read it before thread 0 can write the next one */
+		if (item >= run_hi)
+			break;				/* uniform: every thread leaves */
+		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;
+
+		while (hi - lo > 1)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if (item_off[mid] <= item)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (lo + 1 < (uint32_t) ix.ncent && item_off[lo + 1] <= item)
+			lo++;
+		const uint32_t L = lo;
+		const uint32_t len = ix.own_len[L];
+		const uint32_t local = item - item_off[L];
+		const uint32_t ngrp = (cnt[L] + NDB_QG - 1) / NDB_QG;
+		const uint32_t nquad = (ngrp + 3u) >> 2;
+		const uint32_t quad = local % nquad;
+		const uint32_t t = local / nquad;
+		const uint32_t gi = quad * 4u + wave;
+		const bool	active = gi < ngrp;		/* wave-uniform */
+		const uint32_t g0 = (active ? gi : 0u) * NDB_QG;
+		const uint32_t nmem = active ? min((uint32_t) NDB_QG, cnt[L] - g0) : 0u;
+		const PairRec *mem = pairs + pair_off[L] + g0;
+		const float *__restrict__ qb = qblock + (size_t) (grp_off[L] + (active ? gi : 0u)) * (size_t) dim * NDB_QG;
+		const uint32_t ridx = t * 64 + lane;
+		const uint32_t sr = t * 64 + (uint32_t) srow;
+		const float *srcrow = ix.vecs + ((size_t) ix.loc_off[L] + (sr < len ? sr : len - 1)) * (size_t) dim +
+			((sslot ^ tile_swz<CH>(srow)) * 4);
+		GAcc<R_SCR_L2> acc;
+
+		acc.init();
+		const float *qs = qb;
+		ndb_f16		qa0, qa1, qb0, qb1;
+
+		asm volatile("s_nop 4" ::: "memory");
+		if (active)
+			sload2x16(qa0, qa1, qs);
+		ndb_f4		st;
+
+		ndb_gload4(st, srcrow);
+		for (int c = 0; c < dim; c += CH)
+		{
+			float	   *tb = tile[(c / CH) & 1];
+
+			ndb_gwait(st);
+			*reinterpret_cast<ndb_f4 *>(tb + srow * CH + sslot * 4) = st;
+			__syncthreads();
+			if (c + CH < dim)
+				ndb_gload4(st, srcrow + c + CH);	/* in flight while this chunk is consumed */
+			if (active)
+			{
+				float4		x[CH / 4];
+
+#pragma unroll
+				for (int p = 0; p < CH / 4; p++)
+					x[p] = *reinterpret_cast<const float4 *>(tb + lane * CH + ((p ^ tile_swz<CH>(lane)) * 4));
+				const float *qnext = (c + CH >= dim) ? qs - 2 * NDB_QG : qs;
+
+				ndb_static_for<0, CH / 4>([&](auto pc) {
+					constexpr int p = decltype(pc)::value;
+
+					swait2(qa0, qa1);
+					sload2x16_at<(4 * p + 2) * 64>(qb0, qb1, qs);
+					acc.step(qa0, x[p].x);
+					acc.step(qa1, x[p].y);
+					swait2(qb0, qb1);
+					if constexpr (p == CH / 4 - 1)
+						sload2x16_at<CH * 64>(qa0, qa1, qnext);
+					else
+						sload2x16_at<(4 * p + 4) * 64>(qa0, qa1, qs);
+					acc.step(qb0, x[p].z);
+					acc.step(qb1, x[p].w);
+				});
+				qs += CH * NDB_QG;
+			}
+			/* double-buffered tile: the barrier of the next chunk keeps any wave from running two chunks ahead */
+		}
+		if (active)
+		{
+			swait2(qa0, qa1);
+#pragma unroll
+			for (int j = 0; j < NDB_QG; j++)
+			{
+				if ((uint32_t) j < nmem)
+				{
+					const uint32_t qid = mem[j].q;
+					const uint32_t pp = mem[j].p;
+					const uint32_t *lq = loc_cand_off + (size_t) qid * (npr + 1);
+					const uint32_t la = lq[pp];
+					const uint32_t nrow = lq[pp + 1] - la;
+					const float dv = acc.bound(j, qnorm[qid], qnorm[nq_all + qid]);
+
+					if (ridx < nrow)
+						dist[(size_t) qid * stride + la + ridx] = dv;
+					uint32_t	mk = ridx < nrow ? ndb_key_from_bits(__float_as_uint(dv)) : 0xFFFFFFFFu;
+
+#pragma unroll
+					for (int off = 32; off > 0; off >>= 1)
+						mk = min(mk, (uint32_t) __shfl_xor((int) mk, off, 64));
+					if (lane == 0 && t * 64u < nrow)
+						tmin[(size_t) qid * tstride + (la >> 6) + pp + t] = mk;
+				}
+			}
+		}
+		__syncthreads();		/* s_item and the tile are reused by the next item */
+	}
+	}
 }
 
 /* dynamic LDS layout of k_ivf_topk / k_merge_topk */
@@ -3163,7 +3336,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const uint32_t tstride = (((stride >> 6) + (uint32_t) npr + 2u) + 63u) & ~63u;
 	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
 		(g_scan_mode >= 2 || (g_scan_mode == 0 && nq >= NDB_GROUPED_MIN_NQ));
-	bool		screen = false;
+	bool		screen = false, coop = false;
 
 	if (grouped)
 	{
@@ -3178,12 +3351,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		/* screened L2 scan (GAcc<R_SCR_L2>): float4 rows, 32-float chunks; mode 0 = auto, 3 = always, 4 = never */
 		screen = R == R_IVF_L2 && !ix->f16 &&
 			(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
+		{
+			/* default on: 13.7 -> 13.1 ms per 4096 queries; NDBHIP_SCR_COOP=0 for the single-wave bound pass */
+			static const int scr_coop = getenv("NDBHIP_SCR_COOP") ? atoi(getenv("NDBHIP_SCR_COOP")) : 1;
+
+			coop = screen && scr_coop != 0 && (ix->dim % 16) == 0;
+		}
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
-						   d.own_len, nc, pair_off, item_off, grp_off, runs);
+						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u);
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, (const uint32_t *) pair_off, fill,
 						   ix->w_pairs);
@@ -3267,7 +3446,13 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * per SIMD overlap them instead of 5 (16.5 -> 13.6 ms per 4096 queries); NDBHIP_SCR_CH=32 for A/B */
 			static const int scr_ch = getenv("NDBHIP_SCR_CH") ? atoi(getenv("NDBHIP_SCR_CH")) : 16;
 
-			if (scr_ch == 16)
+			if (coop)
+				hipLaunchKernelGGL(k_ivf_bound_coop, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d,
+								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
+								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off,
+								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride,
+								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq);
+			else if (scr_ch == 16)
 			{
 				const dim3	g16w(g.num_cus * 4 * NDB_G16_WAVES);	/* 4 KiB tile */
 
