@@ -1040,7 +1040,7 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 __global__ __launch_bounds__(1024) void
 k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
 			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
-			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv)
+			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv, uint32_t rt)
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
@@ -1054,7 +1054,7 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
 
 		a += c;
-		b += ((glob_len[L] + 63u) >> 6) * ((ng + gdiv - 1u) / gdiv);
+		b += ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
 		c2 += ng;
 	}
 	sa[t] = a;
@@ -1085,7 +1085,7 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		item_off[L] = b;
 		grp_off[L] = c2;
 		a += c;
-		b += ((glob_len[L] + 63u) >> 6) * ((ng + gdiv - 1u) / gdiv);
+		b += ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
 		c2 += ng;
 	}
 	if (t == 1023)
@@ -3336,7 +3336,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const uint32_t tstride = (((stride >> 6) + (uint32_t) npr + 2u) + 63u) & ~63u;
 	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
 		(g_scan_mode >= 2 || (g_scan_mode == 0 && nq >= NDB_GROUPED_MIN_NQ));
-	bool		screen = false, coop = false;
+	bool		screen = false;
+	int			coop = 0;			/* bound pass: 0 one wave per item, 1 a block per 4 query groups of a tile */
 
 	if (grouped)
 	{
@@ -3355,14 +3356,14 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			/* default on: 13.7 -> 13.1 ms per 4096 queries; NDBHIP_SCR_COOP=0 for the single-wave bound pass */
 			static const int scr_coop = getenv("NDBHIP_SCR_COOP") ? atoi(getenv("NDBHIP_SCR_COOP")) : 1;
 
-			coop = screen && scr_coop != 0 && (ix->dim % 16) == 0;
+			coop = (screen && (ix->dim % 16) == 0 && scr_coop) ? 1 : 0;
 		}
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
-						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u);
+						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u, 1u);
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, (const uint32_t *) pair_off, fill,
 						   ix->w_pairs);
