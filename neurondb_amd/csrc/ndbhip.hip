@@ -2031,6 +2031,166 @@ k_ivf_bound_coop(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__
 	}
 }
 
+/*
+ * The same with TWO 64-row tiles per item (128 rows x 4 query groups per block): a lane scores rows r and r + 64
+ * against the same query values, so the query stream — as many bytes per item as the row tile itself with one
+ * tile per item, and re-read for every tile of the list — is fetched half as often, and the scalar loads per
+ * vector instruction halve.
+ */
+__global__ __launch_bounds__(256, 5) void
+k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ loc_cand_off, int npr,
+				 const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
+				 const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
+				 const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
+				 const uint32_t *__restrict__ runs, float *__restrict__ dist, uint32_t stride,
+				 const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite,
+				 uint32_t nq_all)
+{
+	constexpr int CH = 16;
+	__shared__ __attribute__((aligned(16))) float tile[2][128 * CH];
+	__shared__ uint32_t s_item;
+	const int	tid = threadIdx.x;
+	const int	lane = tid & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int	dim = ix.dim;
+	const int	srow = tid >> 2, sslot = tid & 3;	/* staging: thread = (row of the tile, 16-byte slot) */
+
+	for (uint32_t hop = 0; hop < 8; hop++)
+	{
+	const uint32_t xq = (blockIdx.x + hop) & 7u;
+	const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+
+	if (run_lo == run_hi)
+		continue;
+	for (;;)
+	{
+		if (tid == 0)
+			s_item = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
+															__HIP_MEMORY_SCOPE_AGENT) >= run_hi)
+				? run_hi : run_lo + atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
+		__syncthreads();
+		const uint32_t item = s_item;
+
+		__syncthreads();		/* everybody has read it before thread 0 can write the next one */
+		if (item >= run_hi)
+			break;				/* uniform: every thread leaves */
+		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;
+
+		while (hi - lo > 1)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if (item_off[mid] <= item)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (lo + 1 < (uint32_t) ix.ncent && item_off[lo + 1] <= item)
+			lo++;
+		const uint32_t L = lo;
+		const uint32_t len = ix.own_len[L];
+		const uint32_t local = item - item_off[L];
+		const uint32_t ngrp = (cnt[L] + NDB_QG - 1) / NDB_QG;
+		const uint32_t nquad = (ngrp + 3u) >> 2;
+		const uint32_t quad = local % nquad;
+		const uint32_t t2 = local / nquad;		/* 128-row tile */
+		const uint32_t gi = quad * 4u + wave;
+		const bool	active = gi < ngrp;		/* wave-uniform */
+		const uint32_t g0 = (active ? gi : 0u) * NDB_QG;
+		const uint32_t nmem = active ? min((uint32_t) NDB_QG, cnt[L] - g0) : 0u;
+		const PairRec *mem = pairs + pair_off[L] + g0;
+		const float *__restrict__ qb = qblock + (size_t) (grp_off[L] + (active ? gi : 0u)) * (size_t) dim * NDB_QG;
+		const uint32_t sr0 = t2 * 128 + (uint32_t) srow, sr1 = sr0 + 64;
+		const int	spiece = (sslot ^ tile_swz<CH>(srow)) * 4;
+		const float *src0 = ix.vecs + ((size_t) ix.loc_off[L] + (sr0 < len ? sr0 : len - 1)) * (size_t) dim + spiece;
+		const float *src1 = ix.vecs + ((size_t) ix.loc_off[L] + (sr1 < len ? sr1 : len - 1)) * (size_t) dim + spiece;
+		GAcc<R_SCR_L2> acc0, acc1;
+
+		acc0.init();
+		acc1.init();
+		const float *qs = qb;
+		ndb_f16		qa0, qa1, qb0, qb1;
+
+		asm volatile("s_nop 4" ::: "memory");
+		/* the query stream is primed per chunk, not carried over the loop edge: the compiler copies loop-carried
+		 * registers at the edge, and a copy of a register an asm load is still filling copies garbage (this is
+		 * what broke the first version of this kernel; tools/check_asm_hazards.py finds it in the ISA) */
+		for (int c = 0; c < dim; c += CH)
+		{
+			float	   *tb = tile[(c / CH) & 1];
+			/* plain loads: 5 waves per SIMD hide them, and nothing asm-loaded then lives across the loop edge */
+			const float4 st0 = *reinterpret_cast<const float4 *>(src0 + c);
+			const float4 st1 = *reinterpret_cast<const float4 *>(src1 + c);
+
+			*reinterpret_cast<float4 *>(tb + srow * CH + sslot * 4) = st0;
+			*reinterpret_cast<float4 *>(tb + (64 + srow) * CH + sslot * 4) = st1;
+			__syncthreads();
+			if (active)
+			{
+				sload2x16(qa0, qa1, qs);
+				ndb_static_for<0, CH / 4>([&](auto pc) {
+					constexpr int p = decltype(pc)::value;
+					const float4 x0 = *reinterpret_cast<const float4 *>(tb + lane * CH + ((p ^ tile_swz<CH>(lane)) * 4));
+					const float4 x1 = *reinterpret_cast<const float4 *>(tb + (64 + lane) * CH + ((p ^ tile_swz<CH>(lane)) * 4));
+
+					swait2(qa0, qa1);
+					sload2x16_at<(4 * p + 2) * 64>(qb0, qb1, qs);
+					acc0.step(qa0, x0.x);
+					acc1.step(qa0, x1.x);
+					acc0.step(qa1, x0.y);
+					acc1.step(qa1, x1.y);
+					swait2(qb0, qb1);
+					if constexpr (p < CH / 4 - 1)
+						sload2x16_at<(4 * p + 4) * 64>(qa0, qa1, qs);
+					acc0.step(qb0, x0.z);
+					acc1.step(qb0, x1.z);
+					acc0.step(qb1, x0.w);
+					acc1.step(qb1, x1.w);
+				});
+				qs += CH * NDB_QG;
+			}
+			/* double-buffered tile: the barrier of the next chunk keeps any wave from running two chunks ahead */
+		}
+		if (active)
+		{
+#pragma unroll
+			for (int j = 0; j < NDB_QG; j++)
+			{
+				if ((uint32_t) j < nmem)
+				{
+					const uint32_t qid = mem[j].q;
+					const uint32_t pp = mem[j].p;
+					const uint32_t *lq = loc_cand_off + (size_t) qid * (npr + 1);
+					const uint32_t la = lq[pp];
+					const uint32_t nrow = lq[pp + 1] - la;
+					const float qn = qnorm[qid], qe = qnorm[nq_all + qid];
+
+#pragma unroll
+					for (int u = 0; u < 2; u++)
+					{
+						const uint32_t t = t2 * 2u + (uint32_t) u;
+						const uint32_t ridx = t * 64 + lane;
+						const float dv = u ? acc1.bound(j, qn, qe) : acc0.bound(j, qn, qe);
+
+						if (ridx < nrow)
+							dist[(size_t) qid * stride + la + ridx] = dv;
+						uint32_t	mk = ridx < nrow ? ndb_key_from_bits(__float_as_uint(dv)) : 0xFFFFFFFFu;
+
+#pragma unroll
+						for (int off = 32; off > 0; off >>= 1)
+							mk = min(mk, (uint32_t) __shfl_xor((int) mk, off, 64));
+						if (lane == 0 && t * 64u < nrow)
+							tmin[(size_t) qid * tstride + (la >> 6) + pp + t] = mk;
+					}
+				}
+			}
+		}
+		__syncthreads();		/* s_item and the tile are reused by the next item */
+	}
+	}
+}
+
+
 /* dynamic LDS layout of k_ivf_topk / k_merge_topk */
 struct TopkSmem
 {
@@ -3353,17 +3513,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		screen = R == R_IVF_L2 && !ix->f16 &&
 			(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
 		{
-			/* default on: 13.7 -> 13.1 ms per 4096 queries; NDBHIP_SCR_COOP=0 for the single-wave bound pass */
-			static const int scr_coop = getenv("NDBHIP_SCR_COOP") ? atoi(getenv("NDBHIP_SCR_COOP")) : 1;
+			/* 2 (default): a block per 128 rows x 4 query groups, 11.5 ms per 4096 queries; 1: per 64 rows x 4 groups,
+			 * 13.1 ms; 0: the single-wave bound pass, 13.7 ms (NDBHIP_SCR_COOP for A/B) */
+			static const int scr_coop = getenv("NDBHIP_SCR_COOP") ? atoi(getenv("NDBHIP_SCR_COOP")) : 2;
 
-			coop = (screen && (ix->dim % 16) == 0 && scr_coop) ? 1 : 0;
+			coop = (screen && (ix->dim % 16) == 0) ? scr_coop : 0;
 		}
 
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));	/* + 8 queue heads */
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt,
-						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u, 1u);
+						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u, coop == 2 ? 2u : 1u);
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, (const uint32_t *) pair_off, fill,
 						   ix->w_pairs);
@@ -3447,7 +3608,13 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * per SIMD overlap them instead of 5 (16.5 -> 13.6 ms per 4096 queries); NDBHIP_SCR_CH=32 for A/B */
 			static const int scr_ch = getenv("NDBHIP_SCR_CH") ? atoi(getenv("NDBHIP_SCR_CH")) : 16;
 
-			if (coop)
+			if (coop == 2)
+				hipLaunchKernelGGL(k_ivf_bound_coop2, dim3(g.num_cus * 5), dim3(256), 0, g.stream, d,
+								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
+								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off,
+								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride,
+								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq);
+			else if (coop)
 				hipLaunchKernelGGL(k_ivf_bound_coop, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d,
 								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
 								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off,
