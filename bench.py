@@ -239,6 +239,8 @@ def main():
     esz = 2 if args.rows == "f16" else 4
     kernel = (f"k_ivf_scan_grouped<{recipe}{', fp16 rows' if esz == 2 else ''}>" if grouped
               else f"k_ivf_scan{'_h' if esz == 2 else ''}<{recipe}>")
+    if screened and os.environ.get("NDBHIP_SCR_COOP", "2") != "0" and dim % 16 == 0:
+        kernel = "k_ivf_bound_coop2<R_SCR_L2>" if os.environ.get("NDBHIP_SCR_COOP", "2") == "2" else "k_ivf_bound_coop<R_SCR_L2>"
     launches = max(1, st["scan_launches"])
     bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B per query
     ms_per_launch = st["scan_kernel_ms"] / launches
@@ -255,8 +257,8 @@ def main():
         note = ("algorithmic bytes = rows scored x 3072 B per query.  Screened scan: a fused-multiply-add pass bounds every "
                 "candidate's distance from below for up to 16 queries per staged row tile; the candidates that can still be "
                 f"among the k nearest ({st['rows_rescored'] / max(1, nq * args.steps):.0f} per query) get the reference's "
-                "sequential arithmetic in a second pass, so ids, ranks and float4 bits are the exact path's.  The pass is "
-                "bound by row-tile fetches (VALU 64 % busy, 3.8 TB/s of HBM reads at an L2 hit rate of 0.85)")
+                "sequential arithmetic in a second pass, so ids, ranks and float4 bits are the exact path's.  One block "
+                "scores 128 rows against 4 query groups (64 queries) from one staged tile")
     elif grouped:
         note = ("algorithmic bytes = rows scored x 3072 B per query; the grouped kernel stages each row tile once "
                 "for up to 16 queries, so HBM traffic is ~1/16 of that and the limiter is the fp32 vector ALU")
