@@ -1429,6 +1429,30 @@ template <> struct GAcc<R_SCR_L2>
 
 		return __builtin_sqrtf(fmaxf(l, 0.0f) * 0.99999905f);	/* 1 - 2^-20: sqrtf's own rounding stays below */
 	}
+	/* the same with the row's norm supplied (k_ivf_bound_coop2 reads it from the per-row norms the mirror keeps
+	 * for the bound's constant: one instruction per dimension less) */
+	__device__ __forceinline__ void step_dot(const ndb_f16 &q, float x)
+	{
+		const ndb_f2 xx = (ndb_f2) (x);
+
+#pragma unroll
+		for (int i = 0; i < NDB_QG / 2; i++)
+		{
+			ndb_f2		qp;
+
+			qp.x = q[2 * i];
+			qp.y = q[2 * i + 1];
+			s[i] = __builtin_elementwise_fma(qp, xx, s[i]);
+		}
+	}
+	__device__ __forceinline__ float bound_n2(int j, float qn, float e, float rn2) const
+	{
+		const float dot = (j & 1) ? s[j >> 1].y : s[j >> 1].x;
+		const float a = (qn + rn2) - 2.0f * dot;
+		const float l = a - e;
+
+		return __builtin_sqrtf(fmaxf(l, 0.0f) * 0.99999905f);
+	}
 	__device__ __forceinline__ float fin(int, float) const { return 0.0f; }
 };
 
@@ -2044,7 +2068,7 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 				 const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 				 const uint32_t *__restrict__ runs, float *__restrict__ dist, uint32_t stride,
 				 const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite,
-				 uint32_t nq_all)
+				 uint32_t nq_all, const float *__restrict__ rnorm)
 {
 	constexpr int CH = 16;
 	__shared__ __attribute__((aligned(16))) float tile[2][128 * CH];
@@ -2135,17 +2159,17 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 
 					swait2(qa0, qa1);
 					sload2x16_at<(4 * p + 2) * 64>(qb0, qb1, qs);
-					acc0.step(qa0, x0.x);
-					acc1.step(qa0, x1.x);
-					acc0.step(qa1, x0.y);
-					acc1.step(qa1, x1.y);
+					acc0.step_dot(qa0, x0.x);
+					acc1.step_dot(qa0, x1.x);
+					acc0.step_dot(qa1, x0.y);
+					acc1.step_dot(qa1, x1.y);
 					swait2(qb0, qb1);
 					if constexpr (p < CH / 4 - 1)
 						sload2x16_at<(4 * p + 4) * 64>(qa0, qa1, qs);
-					acc0.step(qb0, x0.z);
-					acc1.step(qb0, x1.z);
-					acc0.step(qb1, x0.w);
-					acc1.step(qb1, x1.w);
+					acc0.step_dot(qb0, x0.z);
+					acc1.step_dot(qb0, x1.z);
+					acc0.step_dot(qb1, x0.w);
+					acc1.step_dot(qb1, x1.w);
 				});
 				qs += CH * NDB_QG;
 			}
@@ -2153,6 +2177,12 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 		}
 		if (active)
 		{
+			/* |x|^2 of this lane's two rows: the exact kernel's sequential sum against a zero query, kept per row
+			 * (relative error gamma_dim, like the fused chain it replaces) */
+			const uint32_t r0 = t2 * 128 + lane, r1 = r0 + 64;
+			const float rn0 = rnorm[(size_t) ix.loc_off[L] + (r0 < len ? r0 : len - 1)];
+			const float rn1 = rnorm[(size_t) ix.loc_off[L] + (r1 < len ? r1 : len - 1)];
+
 #pragma unroll
 			for (int j = 0; j < NDB_QG; j++)
 			{
@@ -2170,7 +2200,7 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 					{
 						const uint32_t t = t2 * 2u + (uint32_t) u;
 						const uint32_t ridx = t * 64 + lane;
-						const float dv = u ? acc1.bound(j, qn, qe) : acc0.bound(j, qn, qe);
+						const float dv = u ? acc1.bound_n2(j, qn, qe, rn1) : acc0.bound_n2(j, qn, qe, rn0);
 
 						if (ridx < nrow)
 							dist[(size_t) qid * stride + la + ridx] = dv;
@@ -3613,7 +3643,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
 								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off,
 								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride,
-								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq);
+								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq,
+								   (const float *) ix->w_rnorm);
 			else if (coop)
 				hipLaunchKernelGGL(k_ivf_bound_coop, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d,
 								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
