@@ -1003,6 +1003,9 @@ k_ivf_scan_h(IvfDev ix, const float *__restrict__ queries, const int *__restrict
 /* ------------------------------------------------------------------ */
 #define NDB_QG 16
 #define NDB_QHEAD_STRIDE 32u		/* words between the scan's work-queue heads: one 128-byte line each */
+#ifndef NDB_COOP2_WAVES
+#define NDB_COOP2_WAVES 5		/* measured: 4 -> 12.1 ms, 5 -> 11.0 ms, 6 (45 scratch spills) -> 11.7 ms per 4096 queries */
+#endif
 #ifndef NDB_G16_WAVES
 #define NDB_G16_WAVES 8
 #endif
@@ -2061,7 +2064,7 @@ k_ivf_bound_coop(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__
  * tile per item, and re-read for every tile of the list — is fetched half as often, and the scalar loads per
  * vector instruction halve.
  */
-__global__ __launch_bounds__(256, 5) void
+__global__ __launch_bounds__(256, NDB_COOP2_WAVES) void
 k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ loc_cand_off, int npr,
 				 const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
 				 const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
@@ -3639,7 +3642,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			static const int scr_ch = getenv("NDBHIP_SCR_CH") ? atoi(getenv("NDBHIP_SCR_CH")) : 16;
 
 			if (coop == 2)
-				hipLaunchKernelGGL(k_ivf_bound_coop2, dim3(g.num_cus * 5), dim3(256), 0, g.stream, d,
+				hipLaunchKernelGGL(k_ivf_bound_coop2, dim3(g.num_cus * NDB_COOP2_WAVES), dim3(256), 0, g.stream, d,
 								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
 								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off,
 								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride,
