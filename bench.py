@@ -235,21 +235,22 @@ def main():
     screened = st.get("rows_rescored", 0) > 0                 # the L2 scan ran as bound + exact second pass
     recipe = {"l2": "R_IVF_L2", "cosine": "R_IVF_COS", "ip": "R_IVF_IP"}[args.strategy]
     if screened:
-        recipe = "R_SCR_L2"
+        recipe = {"l2": "R_SCR_L2", "cosine": "R_SCR_COS", "ip": "R_SCR_IP"}[args.strategy]
     esz = 2 if args.rows == "f16" else 4
     kernel = (f"k_ivf_scan_grouped<{recipe}{', fp16 rows' if esz == 2 else ''}>" if grouped
               else f"k_ivf_scan{'_h' if esz == 2 else ''}<{recipe}>")
     if screened and os.environ.get("NDBHIP_SCR_COOP", "2") != "0" and dim % 16 == 0:
-        kernel = "k_ivf_bound_coop2<R_SCR_L2>" if os.environ.get("NDBHIP_SCR_COOP", "2") == "2" else "k_ivf_bound_coop<R_SCR_L2>"
+        kernel = (f"k_ivf_bound_coop2<{recipe}>" if os.environ.get("NDBHIP_SCR_COOP", "2") == "2"
+                  else "k_ivf_bound_coop<R_SCR_L2>")
     launches = max(1, st["scan_launches"])
     bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B per query
     ms_per_launch = st["scan_kernel_ms"] / launches
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     # exact recipes: every scored (row element, query) pair costs one subtract, one multiply, one add, unfused
     # (inner product: multiply + add; cosine: the same plus the row's own norm chain, shared by the 16 queries
-    # of a group — the query's norm is computed once per query).  Screened L2: one fused multiply-add per pair
-    # element plus the row's norm chain per group; the fused peak is twice the unfused one.
-    per_elem = 2.0 + 2.0 / 16.0 if screened else {"l2": 3.0, "ip": 2.0, "cosine": 2.0 + 2.0 / 16.0}[args.strategy]
+    # of a group — the query's norm is computed once per query).  Screened scans: one fused multiply-add per pair
+    # element (the rows' norms are kept per row); the fused peak is twice the unfused one.
+    per_elem = 2.0 if screened else {"l2": 3.0, "ip": 2.0, "cosine": 2.0 + 2.0 / 16.0}[args.strategy]
     valu_peak = 2.0 * UNFUSED_FP32_PEAK_TFLOPS if screened else UNFUSED_FP32_PEAK_TFLOPS
     flops_per_launch = per_elem * bytes_per_launch / esz
     valu_tflops = flops_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0

@@ -100,7 +100,7 @@ int			ndbhip_stats_reset(void);
 int			ndbhip_profile(int on);			/* bracket the dominant kernel with HIP events */
 /* List-scan kernel choice (results are bit-identical either way): 0 = auto
  * (query-grouped scan for batches of >= 5 queries when dim % 64 == 0, per-query
- * scan otherwise; L2 batches of >= 64 queries over float4 rows are screened), 1 = always per-query,
+ * scan otherwise; batches of >= 128 queries over float4 rows are screened — L2, inner product, cosine), 1 = always per-query,
  * 2 = always grouped, 3 = grouped and screened whenever the recipe allows, 4 = grouped, never screened.
  * Screened = a fused-multiply-add pass bounds every candidate's distance from below, and only the candidates
  * that can still be among the k nearest get the reference's own arithmetic. */

@@ -1456,6 +1456,28 @@ template <> struct GAcc<R_SCR_L2>
 
 		return __builtin_sqrtf(fmaxf(l, 0.0f) * 0.99999905f);
 	}
+	/* inner product (the -dot recipe): the fused and the reference's unfused chain are both within
+	 * gamma_dim |q||x| of the real dot product, so -dot - e with e >= gamma (|q|^2 + |x|^2) is a lower bound
+	 * of the reference's value; rounded down */
+	__device__ __forceinline__ float bound_ip(int j, float e) const
+	{
+		const float dot = (j & 1) ? s[j >> 1].y : s[j >> 1].x;
+		const float l = -dot - e;
+
+		return l - fabsf(l) * 2.4e-7f - 1e-37f;
+	}
+	/* cosine: the norms ARE the reference's (same sequential chains, bit for bit), only the dot product differs
+	 * by at most gamma_dim |q||x|, i.e. gamma_dim in the quotient; e = 4 gamma_(dim+8) also covers the quotient's
+	 * own roundings.  A zero norm is the reference's exact 1.0 */
+	__device__ __forceinline__ float bound_cos(int j, float qn, float rn2, float e) const
+	{
+		const float dot = (j & 1) ? s[j >> 1].y : s[j >> 1].x;
+		const float a = __builtin_sqrtf(qn), b = __builtin_sqrtf(rn2);
+		const float c = (a == 0.0f || b == 0.0f) ? 1.0f : 1.0f - (dot / (a * b));
+		const float l = c - e;
+
+		return l - fabsf(l) * 2.4e-7f - 1e-37f;
+	}
 	__device__ __forceinline__ float fin(int, float) const { return 0.0f; }
 };
 
@@ -1724,10 +1746,11 @@ struct ScrRec
 	uint32_t	q, pos, row, slot;
 };
 
+template <int R>
 __device__ __forceinline__ float
-scr_exact_l2(const float *__restrict__ qq, const float *__restrict__ x, int dim)
+scr_exact(const float *__restrict__ qq, const float *__restrict__ x, int dim)
 {
-	Acc<R_IVF_L2> acc;
+	Acc<R>		acc;
 	int			i = 0;
 
 	for (; i + 64 <= dim; i += 64)	/* 16 + 16 loads in flight, then the reference's chain */
@@ -1754,6 +1777,7 @@ scr_exact_l2(const float *__restrict__ qq, const float *__restrict__ x, int dim)
 	return acc.fin();
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void
 k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 				const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride,
@@ -1780,10 +1804,23 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 		const float lk = first_dist[(size_t) q * k + (k - 1)];
 		const float e = qe[nq + q];
 		const float m = (float) (16 * dim + 64) * NDB_SCR_U;
-		const float l2 = lk * lk * 1.0000039f;		/* undo the kernel's round-down (2^-20) and sqrtf's */
-		const float t2 = (l2 + 2.0f * e) * (1.0f + m);
 
-		thr = __builtin_sqrtf(t2) * 1.000001f;
+		if (R == R_IVF_L2)
+		{
+			const float l2 = lk * lk * 1.0000039f;		/* undo the kernel's round-down (2^-20) and sqrtf's */
+			const float t2 = (l2 + 2.0f * e) * (1.0f + m);
+
+			thr = __builtin_sqrtf(t2) * 1.000001f;
+		}
+		else
+		{
+			/* inner product / cosine: the k-th smallest lower bound + 2E is the k-th smallest upper bound; the
+			 * values are signed, so the slack is absolute as well as relative */
+			const float e2 = (R == R_IVF_COS) ? 4.0f * ((float) (dim + 8) * NDB_SCR_U) / (1.0f - (float) (dim + 8) * NDB_SCR_U) : e;
+			const float u = lk + 2.0f * e2;
+
+			thr = u + (fabsf(u) + fabsf(lk) + 2.0f * e2) * 2e-6f + 1e-36f;
+		}
 	}
 	const uint32_t kthr = ndb_key_from_bits(__float_as_uint(thr));
 	uint32_t   *tm = tmin + (size_t) q * tstride;
@@ -1836,7 +1873,7 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 					else
 					{
 						/* list full: do it here */
-						v = scr_exact_l2(queries + (size_t) q * dim, ix.vecs + (size_t) row * (size_t) dim, dim);
+						v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + (size_t) row * (size_t) dim, dim);
 						*dp = v;
 					}
 				}
@@ -1865,6 +1902,7 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 
 /* one lane per listed candidate: the reference's arithmetic, the value into the distance buffer and into its
  * tile's minimum */
+template <int R>
 __global__ __launch_bounds__(64) void
 k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restrict__ dist, uint32_t stride,
 				   uint32_t *__restrict__ tmin, uint32_t tstride, const ScrRec *__restrict__ recs, uint32_t rec_cap,
@@ -1879,7 +1917,7 @@ k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restri
 	if (i >= n)
 		return;
 	const ScrRec r = recs[(size_t) q * rec_cap + i];
-	const float v = scr_exact_l2(queries + (size_t) r.q * ix.dim, ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
+	const float v = scr_exact<R>(queries + (size_t) r.q * ix.dim, ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
 
 	dist[(size_t) r.q * stride + r.pos] = v;
 	atomicMin(&tmin[(size_t) r.q * tstride + r.slot], ndb_key_from_bits(__float_as_uint(v)));
@@ -2064,6 +2102,7 @@ k_ivf_bound_coop(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__
  * tile per item, and re-read for every tile of the list — is fetched half as often, and the scalar loads per
  * vector instruction halve.
  */
+template <int R>
 __global__ __launch_bounds__(256, NDB_COOP2_WAVES) void
 k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ loc_cand_off, int npr,
 				 const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
@@ -2203,7 +2242,19 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 					{
 						const uint32_t t = t2 * 2u + (uint32_t) u;
 						const uint32_t ridx = t * 64 + lane;
-						const float dv = u ? acc1.bound_n2(j, qn, qe, rn1) : acc0.bound_n2(j, qn, qe, rn0);
+						float		dv;
+
+						if (R == R_IVF_L2)
+							dv = u ? acc1.bound_n2(j, qn, qe, rn1) : acc0.bound_n2(j, qn, qe, rn0);
+						else if (R == R_IVF_IP)
+							dv = u ? acc1.bound_ip(j, qe) : acc0.bound_ip(j, qe);
+						else
+						{
+							const float nu = (float) (dim + 8) * NDB_SCR_U;
+							const float ec = 4.0f * nu / (1.0f - nu);
+
+							dv = u ? acc1.bound_cos(j, qn, rn1, ec) : acc0.bound_cos(j, qn, rn0, ec);
+						}
 
 						if (ridx < nrow)
 							dist[(size_t) qid * stride + la + ridx] = dv;
@@ -3543,13 +3594,17 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		const uint32_t maxgroups = npairs / NDB_QG + (uint32_t) nc;
 		ScanTimer	t;
 		/* screened L2 scan (GAcc<R_SCR_L2>): float4 rows, 32-float chunks; mode 0 = auto, 3 = always, 4 = never */
-		screen = R == R_IVF_L2 && !ix->f16 &&
-			(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
 		{
-			/* 2 (default): a block per 128 rows x 4 query groups, 11.5 ms per 4096 queries; 1: per 64 rows x 4 groups,
-			 * 13.1 ms; 0: the single-wave bound pass, 13.7 ms (NDBHIP_SCR_COOP for A/B) */
+			/* 2 (default): a block per 128 rows x 4 query groups, 11 ms per 4096 queries; 1: per 64 rows x 4 groups,
+			 * 13.1 ms; 0: the single-wave bound pass, 13.7 ms (NDBHIP_SCR_COOP for A/B).  Inner product and cosine
+			 * are screened by the two-tile kernel only (its pass is the plain dot product; the norms come from
+			 * the per-row norms) */
 			static const int scr_coop = getenv("NDBHIP_SCR_COOP") ? atoi(getenv("NDBHIP_SCR_COOP")) : 2;
+			const bool	want = !ix->f16 &&
+				(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
+			const bool	two_tile = scr_coop == 2 && (ix->dim % 16) == 0;
 
+			screen = want && (R == R_IVF_L2 || ((R == R_IVF_IP || R == R_IVF_COS) && two_tile));
 			coop = (screen && (ix->dim % 16) == 0) ? scr_coop : 0;
 		}
 
@@ -3641,13 +3696,22 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * per SIMD overlap them instead of 5 (16.5 -> 13.6 ms per 4096 queries); NDBHIP_SCR_CH=32 for A/B */
 			static const int scr_ch = getenv("NDBHIP_SCR_CH") ? atoi(getenv("NDBHIP_SCR_CH")) : 16;
 
+#define LAUNCH_COOP2(RR)                                                                                       \
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_bound_coop2<RR>), dim3(g.num_cus * NDB_COOP2_WAVES), dim3(256), 0, \
+								   g.stream, d, (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,        \
+								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off, \
+								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride, \
+								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq, \
+								   (const float *) ix->w_rnorm)
 			if (coop == 2)
-				hipLaunchKernelGGL(k_ivf_bound_coop2, dim3(g.num_cus * NDB_COOP2_WAVES), dim3(256), 0, g.stream, d,
-								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
-								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off,
-								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride,
-								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq,
-								   (const float *) ix->w_rnorm);
+			{
+				if (R == R_IVF_IP)
+					LAUNCH_COOP2(R_IVF_IP);
+				else if (R == R_IVF_COS)
+					LAUNCH_COOP2(R_IVF_COS);
+				else
+					LAUNCH_COOP2(R_IVF_L2);
+			}
 			else if (coop)
 				hipLaunchKernelGGL(k_ivf_bound_coop, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d,
 								   (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,
@@ -3758,13 +3822,24 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 				if (grow(ix->w_screc, ix->w_screc_n, (size_t) nq * rec_cap * 4 + (size_t) nq)) return NDBHIP_ERR_HIP;
 				unsigned int *rec_counts = (unsigned int *) (ix->w_screc + (size_t) nq * rec_cap * 4);
 
-				hipLaunchKernelGGL(k_ivf_survivors, dim3(nq), dim3(256), 0, g.stream, d, d_q, (const int *) w_probes, lco,
-								   npr, ix->w_dist, stride, ix->w_tmin, tstride, (const float *) ix->w_qnorm,
-								   (uint32_t) nq, (uint32_t) k, (const float *) ix->w_scrd, (const int *) ix->w_scrc,
-								   (ScrRec *) ix->w_screc, rec_cap, rec_counts, g.d_counters);
-				hipLaunchKernelGGL(k_ivf_rescore_list, dim3(rec_cap / 64, nq), dim3(64), 0, g.stream, d, d_q,
-								   ix->w_dist, stride, ix->w_tmin, tstride, (const ScrRec *) ix->w_screc, rec_cap,
-								   (const unsigned int *) rec_counts, g.d_counters);
+#define LAUNCH_SECOND_PASS(RR)                                                                                 \
+				do {                                                                                                   \
+					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_survivors<RR>), dim3(nq), dim3(256), 0, g.stream, d, d_q,   \
+									   (const int *) w_probes, lco, npr, ix->w_dist, stride, ix->w_tmin, tstride,       \
+									   (const float *) ix->w_qnorm, (uint32_t) nq, (uint32_t) k,                          \
+									   (const float *) ix->w_scrd, (const int *) ix->w_scrc, (ScrRec *) ix->w_screc,      \
+									   rec_cap, rec_counts, g.d_counters);                                             \
+					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_rescore_list<RR>), dim3(rec_cap / 64, nq), dim3(64), 0,     \
+									   g.stream, d, d_q, ix->w_dist, stride, ix->w_tmin, tstride,                         \
+									   (const ScrRec *) ix->w_screc, rec_cap, (const unsigned int *) rec_counts,          \
+									   g.d_counters);                                                                  \
+				} while (0)
+				if (R == R_IVF_IP)
+					LAUNCH_SECOND_PASS(R_IVF_IP);
+				else if (R == R_IVF_COS)
+					LAUNCH_SECOND_PASS(R_IVF_COS);
+				else
+					LAUNCH_SECOND_PASS(R_IVF_L2);
 			}
 			hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
 							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
