@@ -1777,7 +1777,60 @@ scr_exact(const float *__restrict__ qq, const float *__restrict__ x, int dim)
 	return acc.fin();
 }
 
-template <int R>
+/* the same over an fp16 row (halfvec column): every element decoded like fp16_to_float (SUBFIX: with the Q20
+ * subnormal quirk), then the reference's chain */
+template <int R, bool SUBFIX>
+__device__ __forceinline__ float
+scr_exact_h(const float *__restrict__ qq, const uint16_t *__restrict__ x, int dim)
+{
+	Acc<R>		acc;
+
+	for (int i = 0; i < dim; i += 8)	/* fp16 mirrors have dim % 64 == 0 */
+	{
+		const float4 raw = *reinterpret_cast<const float4 *>(x + i);
+		const float4 q0 = *reinterpret_cast<const float4 *>(qq + i);
+		const float4 q1 = *reinterpret_cast<const float4 *>(qq + i + 4);
+		float		v[8];
+
+		decode8<SUBFIX>(raw, v);
+		acc.step(q0.x, v[0]);
+		acc.step(q0.y, v[1]);
+		acc.step(q0.z, v[2]);
+		acc.step(q0.w, v[3]);
+		acc.step(q1.x, v[4]);
+		acc.step(q1.y, v[5]);
+		acc.step(q1.z, v[6]);
+		acc.step(q1.w, v[7]);
+	}
+	return acc.fin();
+}
+
+/* |x|^2 of every fp16 row, the sequential unfused chain over the decoded values (= the reference's norm2) */
+template <bool SUBFIX>
+__global__ void
+k_row_norms_h(const uint16_t *__restrict__ vecs, int64_t nrows, int dim, float *__restrict__ out)
+{
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (r >= nrows)
+		return;
+	const uint16_t *x = vecs + (size_t) r * dim;
+	float		n2 = 0.0f;
+
+	for (int i = 0; i < dim; i += 8)
+	{
+		const float4 raw = *reinterpret_cast<const float4 *>(x + i);
+		float		v[8];
+
+		decode8<SUBFIX>(raw, v);
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+			n2 = n2 + v[u] * v[u];
+	}
+	out[r] = n2;
+}
+
+template <int R, int H16>
 __global__ __launch_bounds__(256) void
 k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 				const uint32_t *__restrict__ loc_cand_off, int npr, float *__restrict__ dist, uint32_t stride,
@@ -1873,7 +1926,11 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 					else
 					{
 						/* list full: do it here */
-						v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + (size_t) row * (size_t) dim, dim);
+						if constexpr (H16 != 0)
+							v = scr_exact_h<R, H16 == 1>(queries + (size_t) q * dim,
+														 (const uint16_t *) ix.vecs + (size_t) row * (size_t) dim, dim);
+						else
+							v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + (size_t) row * (size_t) dim, dim);
 						*dp = v;
 					}
 				}
@@ -1902,7 +1959,7 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 
 /* one lane per listed candidate: the reference's arithmetic, the value into the distance buffer and into its
  * tile's minimum */
-template <int R>
+template <int R, int H16>
 __global__ __launch_bounds__(64) void
 k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restrict__ dist, uint32_t stride,
 				   uint32_t *__restrict__ tmin, uint32_t tstride, const ScrRec *__restrict__ recs, uint32_t rec_cap,
@@ -1917,7 +1974,13 @@ k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restri
 	if (i >= n)
 		return;
 	const ScrRec r = recs[(size_t) q * rec_cap + i];
-	const float v = scr_exact<R>(queries + (size_t) r.q * ix.dim, ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
+	float		v;
+
+	if constexpr (H16 != 0)
+		v = scr_exact_h<R, H16 == 1>(queries + (size_t) r.q * ix.dim,
+									 (const uint16_t *) ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
+	else
+		v = scr_exact<R>(queries + (size_t) r.q * ix.dim, ix.vecs + (size_t) r.row * (size_t) ix.dim, ix.dim);
 
 	dist[(size_t) r.q * stride + r.pos] = v;
 	atomicMin(&tmin[(size_t) r.q * tstride + r.slot], ndb_key_from_bits(__float_as_uint(v)));
@@ -2102,7 +2165,32 @@ k_ivf_bound_coop(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__
  * tile per item, and re-read for every tile of the list — is fetched half as often, and the scalar loads per
  * vector instruction halve.
  */
-template <int R>
+/* four halfs (one 16-byte slot of decoded floats) of an fp16 row */
+template <bool SUBFIX>
+__device__ __forceinline__ float4
+ndb_decode4(const uint16_t *p)
+{
+	const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+	float4		o;
+
+	if (SUBFIX)
+	{
+		o.x = h2f_ref(raw.x & 0xFFFFu);
+		o.y = h2f_ref(raw.x >> 16);
+		o.z = h2f_ref(raw.y & 0xFFFFu);
+		o.w = h2f_ref(raw.y >> 16);
+	}
+	else
+	{
+		o.x = __half2float(__ushort_as_half((unsigned short) (raw.x & 0xFFFFu)));
+		o.y = __half2float(__ushort_as_half((unsigned short) (raw.x >> 16)));
+		o.z = __half2float(__ushort_as_half((unsigned short) (raw.y & 0xFFFFu)));
+		o.w = __half2float(__ushort_as_half((unsigned short) (raw.y >> 16)));
+	}
+	return o;
+}
+
+template <int R, int H16>
 __global__ __launch_bounds__(256, NDB_COOP2_WAVES) void
 k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ loc_cand_off, int npr,
 				 const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
@@ -2170,6 +2258,8 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 		const int	spiece = (sslot ^ tile_swz<CH>(srow)) * 4;
 		const float *src0 = ix.vecs + ((size_t) ix.loc_off[L] + (sr0 < len ? sr0 : len - 1)) * (size_t) dim + spiece;
 		const float *src1 = ix.vecs + ((size_t) ix.loc_off[L] + (sr1 < len ? sr1 : len - 1)) * (size_t) dim + spiece;
+		const uint16_t *h0 = (const uint16_t *) ix.vecs + ((size_t) ix.loc_off[L] + (sr0 < len ? sr0 : len - 1)) * (size_t) dim + spiece;
+		const uint16_t *h1 = (const uint16_t *) ix.vecs + ((size_t) ix.loc_off[L] + (sr1 < len ? sr1 : len - 1)) * (size_t) dim + spiece;
 		GAcc<R_SCR_L2> acc0, acc1;
 
 		acc0.init();
@@ -2185,8 +2275,19 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 		{
 			float	   *tb = tile[(c / CH) & 1];
 			/* plain loads: 5 waves per SIMD hide them, and nothing asm-loaded then lives across the loop edge */
-			const float4 st0 = *reinterpret_cast<const float4 *>(src0 + c);
-			const float4 st1 = *reinterpret_cast<const float4 *>(src1 + c);
+			float4		st0, st1;
+
+			if constexpr (H16 != 0)
+			{
+				/* fp16 rows: the slot's four halfs, decoded like fp16_to_float here; from LDS on it is the float4 path */
+				st0 = ndb_decode4<H16 == 1>(h0 + c);
+				st1 = ndb_decode4<H16 == 1>(h1 + c);
+			}
+			else
+			{
+				st0 = *reinterpret_cast<const float4 *>(src0 + c);
+				st1 = *reinterpret_cast<const float4 *>(src1 + c);
+			}
 
 			*reinterpret_cast<float4 *>(tb + srow * CH + sslot * 4) = st0;
 			*reinterpret_cast<float4 *>(tb + (64 + srow) * CH + sslot * 4) = st1;
@@ -3600,11 +3701,11 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * are screened by the two-tile kernel only (its pass is the plain dot product; the norms come from
 			 * the per-row norms) */
 			static const int scr_coop = getenv("NDBHIP_SCR_COOP") ? atoi(getenv("NDBHIP_SCR_COOP")) : 2;
-			const bool	want = !ix->f16 &&
-				(g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ));
+			const bool	want = g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ);
 			const bool	two_tile = scr_coop == 2 && (ix->dim % 16) == 0;
 
-			screen = want && (R == R_IVF_L2 || ((R == R_IVF_IP || R == R_IVF_COS) && two_tile));
+			/* fp16 rows (decoded when the tile is staged), inner product and cosine: the two-tile kernel only */
+			screen = want && ((R == R_IVF_L2 && !ix->f16) || two_tile);
 			coop = (screen && (ix->dim % 16) == 0) ? scr_coop : 0;
 		}
 
@@ -3638,6 +3739,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 					float	   *zero = ix->w_rnorm + ix->nrows;	/* a zero query: sum (0 - x)^2 = the row's norm^2 */
 
 					HIP_TRY(hipMemsetAsync(zero, 0, (size_t) ix->dim * sizeof(float), g.stream));
+					if (ix->f16)
+					{
+						const dim3	gn((unsigned) ((ix->nrows + 255) / 256));
+
+						if (ix->f16_sub)
+							hipLaunchKernelGGL(k_row_norms_h<true>, gn, dim3(256), 0, g.stream, (const uint16_t *) ix->d_vecs,
+											   ix->nrows, ix->dim, ix->w_rnorm);
+						else
+							hipLaunchKernelGGL(k_row_norms_h<false>, gn, dim3(256), 0, g.stream, (const uint16_t *) ix->d_vecs,
+											   ix->nrows, ix->dim, ix->w_rnorm);
+					}
+					else
 					for (int64_t r0 = 0; r0 < ix->nrows; r0 += (int64_t) 1 << 30)
 					{
 						const uint32_t nr = (uint32_t) std::min<int64_t>((int64_t) 1 << 30, ix->nrows - r0);
@@ -3665,7 +3778,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (const uint32_t *) grp_off, (const PairRec *) ix->w_pairs, next_item,               \
 						   (const uint32_t *) runs, ix->w_dist, stride, (const float *) ix->w_qnorm, ix->w_tmin, tstride, \
 						   nq < 1024 ? 1 : 0, (uint32_t) nq)
-		if (ix->f16)
+		if (ix->f16 && !screen)
 		{
 			const dim3	g16(g.num_cus * 16);	/* 8 KiB tile, 4 waves per SIMD */
 
@@ -3696,13 +3809,19 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * per SIMD overlap them instead of 5 (16.5 -> 13.6 ms per 4096 queries); NDBHIP_SCR_CH=32 for A/B */
 			static const int scr_ch = getenv("NDBHIP_SCR_CH") ? atoi(getenv("NDBHIP_SCR_CH")) : 16;
 
-#define LAUNCH_COOP2(RR)                                                                                       \
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_bound_coop2<RR>), dim3(g.num_cus * NDB_COOP2_WAVES), dim3(256), 0, \
+#define LAUNCH_COOP2_H(RR, HH)                                                                                  \
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_bound_coop2<RR, HH>), dim3(g.num_cus * NDB_COOP2_WAVES), dim3(256), 0, \
 								   g.stream, d, (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,        \
 								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off, \
 								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride, \
 								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq, \
 								   (const float *) ix->w_rnorm)
+#define LAUNCH_COOP2(RR)                                                                                       \
+				do {                                                                                                   \
+					if (!ix->f16) LAUNCH_COOP2_H(RR, 0);                                                               \
+					else if (ix->f16_sub) LAUNCH_COOP2_H(RR, 1);                                                       \
+					else LAUNCH_COOP2_H(RR, 2);                                                                        \
+				} while (0)
 			if (coop == 2)
 			{
 				if (R == R_IVF_IP)
@@ -3824,12 +3943,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 #define LAUNCH_SECOND_PASS(RR)                                                                                 \
 				do {                                                                                                   \
-					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_survivors<RR>), dim3(nq), dim3(256), 0, g.stream, d, d_q,   \
+					if (!ix->f16) LAUNCH_SECOND_PASS_H(RR, 0);                                                         \
+					else if (ix->f16_sub) LAUNCH_SECOND_PASS_H(RR, 1);                                                 \
+					else LAUNCH_SECOND_PASS_H(RR, 2);                                                                  \
+				} while (0)
+#define LAUNCH_SECOND_PASS_H(RR, HH)                                                                           \
+				do {                                                                                                   \
+					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_survivors<RR, HH>), dim3(nq), dim3(256), 0, g.stream, d, d_q, \
 									   (const int *) w_probes, lco, npr, ix->w_dist, stride, ix->w_tmin, tstride,       \
 									   (const float *) ix->w_qnorm, (uint32_t) nq, (uint32_t) k,                          \
 									   (const float *) ix->w_scrd, (const int *) ix->w_scrc, (ScrRec *) ix->w_screc,      \
 									   rec_cap, rec_counts, g.d_counters);                                             \
-					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_rescore_list<RR>), dim3(rec_cap / 64, nq), dim3(64), 0,     \
+					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_rescore_list<RR, HH>), dim3(rec_cap / 64, nq), dim3(64), 0, \
 									   g.stream, d, d_q, ix->w_dist, stride, ix->w_tmin, tstride,                         \
 									   (const ScrRec *) ix->w_screc, rec_cap, (const unsigned int *) rec_counts,          \
 									   g.d_counters);                                                                  \
