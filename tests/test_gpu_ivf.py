@@ -468,7 +468,7 @@ def test_fp16_rows_are_bit_identical_to_expanded_float4_rows(dim, n, nlists, sca
 
 
 @pytest.mark.parametrize("reference_encoder", [True, False])
-def test_to_f16_twin_and_its_shards(reference_encoder):
+def test_to_f16_twin_and_its_shards(reference_encoder, scan_mode):
     """ndbhip_ivf_to_f16: rows narrowed on the device with the reference's float4_to_fp16 (truncating,
     flush-to-zero) or round-to-nearest-even; the twin — and its list shards — search like the oracle over
     the re-expanded rows."""
@@ -495,10 +495,13 @@ def test_to_f16_twin_and_its_shards(reference_encoder):
     full.load(a["list_len"], a["rows"], a["tids"])
     twin = full.to_f16(reference_encoder)
     q = _queries(a, 40, seed=78)
-    for strategy in (3, 1):
-        t, d, c = twin.search(q, strategy, 6, 10)
+    for strategy in (3, 1, 2):
         et, ed, ec, _ = oracle_search_batch(img, q, strategy, 6, 10)
-        assert_same_results(t, d, c, et, ed, ec)
+        for mode in (0, 3):                            # 3: screened — the twin without subnormals decodes with the plain conversion
+            scan_mode(mode)
+            t, d, c = twin.search(q, strategy, 6, 10)
+            assert_same_results(t, d, c, et, ed, ec)
+    scan_mode(0)
     # shards of the fp16 twin + merge == the twin
     world, k, nprobe = 2, 10, 6
     cap = 3 * k
