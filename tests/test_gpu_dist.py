@@ -41,7 +41,8 @@ def _worker(rank, world, port, slices, ret):
         a = make_ivf_arrays(4000, 64, 20, seed=51, dup_frac=0.1)
         img = oracle_image(a)
         rng = np.random.default_rng(52)
-        q = a["rows"][rng.integers(0, len(a["rows"]), 29)] + rng.standard_normal((29, 64)).astype(np.float32) * 0.05
+        nq = 150 if slices else 29                       # 150: the screened scan (>= 128 queries) in partial mode
+        q = a["rows"][rng.integers(0, len(a["rows"]), nq)] + rng.standard_normal((nq, 64)).astype(np.float32) * 0.05
         q = np.ascontiguousarray(q, dtype=np.float32)
         k, nprobe = 10, 5
         full = IvfIndex(64, 20)
