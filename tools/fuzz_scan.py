@@ -14,6 +14,42 @@ from oracle import ndbo
 from tests.util import assert_same_results, oracle_image, oracle_search_batch
 
 
+_LUT = None
+
+
+def sharded_case(rng, ix, img, q, strategy, nprobe, k, cap, et, ed, ec):
+    """the same search through 2..4 slice shards + merge (what an N-GPU run does), screened mode"""
+    import torch
+    from neurondb_amd import _lib
+    from neurondb_amd.dist import partition_slices
+    world = int(rng.integers(2, 5))
+    _, ll, _, _ = ix.export(rows=False)
+    lo, ln, tail = partition_slices(ll, world, None, split_frac=0.0, align=int(rng.choice([16, 64])))
+    shards = [ix.shard_slices(lo[w], ln[w], tail[w]) for w in range(world)]
+    dq = torch.from_numpy(q).cuda()
+    nq, rcap = len(q), 3 * k
+    cand = torch.zeros((world, nq, rcap, 2), dtype=torch.int64, device="cuda")
+    ncand = torch.zeros((world, nq), dtype=torch.int32, device="cuda")
+    total = torch.zeros((world, nq), dtype=torch.int64, device="cuda")
+    for w, sh in enumerate(shards):
+        sh.search_partial_device(dq, cand[w], ncand[w], total[w], strategy, nprobe, k, cap)
+    ot = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    oc = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().ndbhip_merge_topk_device(cand.data_ptr(), ncand.data_ptr(), total[0].data_ptr(), world, nq, k,
+                                                   rcap, ot.data_ptr(), od.data_ptr(), oc.data_ptr()))
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    c = oc.cpu().numpy()
+    t = ndbo.tids_from_device_u64(ot.cpu().numpy())
+    d = od.cpu().numpy()
+    assert np.array_equal(c, ec)
+    for i in range(nq):
+        assert np.array_equal(t[i, :c[i]], et[i, :c[i]]) and \
+            np.array_equal(d[i, :c[i]].view(np.uint32), ed[i, :c[i]].view(np.uint32)), ("sharded", world, i)
+    for sh in shards:
+        sh.close()
+
+
 def one_case(rng, lib, IvfIndex, check):
     dim = int(rng.choice([64, 128, 192, 256, 768]))
     n = int(rng.integers(200, 5000))
@@ -48,10 +84,21 @@ def one_case(rng, lib, IvfIndex, check):
     order = np.argsort(asg, kind="stable")
     a = dict(centroids=cent, list_len=np.bincount(asg, minlength=nlists).astype(np.int64),
              rows=np.ascontiguousarray(base[order]), tids=ndbo.tids_from_rows(order))
-    img = oracle_image(a)
     ix = IvfIndex(dim, nlists)
     ix.set_centroids(a["centroids"])
-    ix.load(a["list_len"], a["rows"], a["tids"])
+    half = kind in ("normal", "clustered", "integer") and rng.random() < 0.35
+    if half:
+        # a halfvec column: rows kept as fp16 (some of them subnormal); the oracle sees what fp16_to_float gives
+        h = (a["rows"] * np.float32(rng.choice([1.0, 1e-3]))).astype(np.float16).view(np.uint16).copy()
+        global _LUT
+        if _LUT is None:
+            _LUT = np.array([ndbo.lib().ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+        a = dict(a, rows=_LUT[h])
+        ix.load_f16(a["list_len"], h, a["tids"])
+        kind = kind + "/fp16"
+    else:
+        ix.load(a["list_len"], a["rows"], a["tids"])
+    img = oracle_image(a)
     k = int(rng.choice([1, 10, 37, 100]))
     nprobe = int(rng.integers(1, nlists + 3))
     cap = int(rng.choice([0, 0, k * 10, 500]))
@@ -66,6 +113,10 @@ def one_case(rng, lib, IvfIndex, check):
             print("MISMATCH", dict(dim=dim, n=n, nlists=nlists, nq=nq, kind=kind, k=k, nprobe=nprobe, cap=cap,
                                    strategy=strategy, mode=mode), flush=True)
             raise
+    if not half and rng.random() < 0.25:
+        check(lib.ndbhip_set_scan_mode(3))
+        sharded_case(rng, ix, img, q, strategy, nprobe, k, cap, et, ed, ec)
+        kind = kind + "/sharded"
     check(lib.ndbhip_set_scan_mode(0))
     ix.close()
     return kind
@@ -76,6 +127,7 @@ def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     _lib.ensure_init(0)
+    _lib.use_torch_stream()
     rng = np.random.default_rng(seed)
     t0, n, kinds = time.time(), 0, {}
     while time.time() - t0 < secs:
