@@ -161,3 +161,33 @@ def test_hnsw_knn_search_gpu_rows_equal_the_index_scan():
     n = C.c_int64()
     assert L.ndb_hnsw_knn_search_gpu(ix._h, 1, ptrs, lens, len(datums), 10, 0, buf, C.byref(n)) < 0
     assert b"ef_search must be between" in L.ndbhip_last_error()
+
+
+def test_ivf_knn_search_gpu_with_a_large_query_array_takes_the_screened_scan():
+    """150 queries in one call: the batch is large enough for the screened scan (bound pass + the reference's
+    arithmetic for the survivors); rows still equal the oracle's index scan, for all three operator classes."""
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import NdbKnnRow
+    L = _lib.lib()
+    a = make_ivf_arrays(5000, 64, 16, seed=81, dup_frac=0.1)
+    img = oracle_image(a)
+    ix = IvfIndex(64, 16)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    rng = np.random.default_rng(82)
+    qs = [a["rows"][rng.integers(0, 5000)] + rng.standard_normal(64).astype(np.float32) * 0.1 for _ in range(150)]
+    ptrs, lens, keep = _datum_array([vector_datum(q) for q in qs])
+    k, nprobe = 10, 6
+    for strategy in (1, 2, 3):
+        _lib.check(L.ndbhip_stats_reset())
+        buf = (NdbKnnRow * (len(qs) * k))()
+        n = C.c_int64()
+        _lib.check(L.ndb_ivf_knn_search_gpu(ix._h, strategy, ptrs, lens, len(qs), k, nprobe, buf, C.byref(n)))
+        assert _lib.stats()["rows_rescored"] > 0                      # the second pass ran
+        got = _rows(buf, n.value)
+        exp = []
+        for i, q in enumerate(qs):
+            et, ed, _ = img.search(q, strategy, nprobe, k, 0)
+            exp += [(i, (int(t["bi_hi"]), int(t["bi_lo"]), int(t["posid"])), np.float32(d)) for t, d in zip(et, ed)]
+        assert [(g[0], g[1]) for g in got] == [(e[0], e[1]) for e in exp]
+        assert np.array_equal(np.array([g[3] for g in got]).view(np.uint32), np.array([e[2] for e in exp]).view(np.uint32))
