@@ -2833,6 +2833,7 @@ struct ndbhip_ivf
 	float	   *w_scrd = nullptr;	size_t w_scrd_n = 0;
 	int		   *w_scrc = nullptr;	size_t w_scrc_n = 0;
 	uint32_t   *w_screc = nullptr;	size_t w_screc_n = 0;	/* survivor records (4 words each) + their count */
+	void	   *pin = nullptr;		size_t pin_n = 0;		/* pinned host block of ndbhip_ivf_search: query + results */
 	float	   *w_cblock = nullptr;	size_t w_cblock_n = 0;	/* centroids interleaved 16 per block (batch centroid scan) */
 	uint32_t   *w_tmin = nullptr;	size_t w_tmin_n = 0;	/* [nq][tstride] smallest order key per 64-candidate tile */
 	/* split top-k of small batches: per-range records, counts, totals */
@@ -2908,6 +2909,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
+		if (ix->pin) (void) hipHostFree(ix->pin);
 	}
 	delete ix;
 	return NDBHIP_OK;
@@ -4140,21 +4142,41 @@ ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, in
 	if (!queries || !out_tids6 || !out_dist || !out_count)
 		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
 	if (grow(ix->w_q, ix->w_q_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_otid, ix->w_otid_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_odist, ix->w_odist_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_ocnt, ix->w_ocnt_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-	HIP_TRY(hipMemcpyAsync(ix->w_q, queries, (size_t) nq * ix->dim * sizeof(float), hipMemcpyHostToDevice,
-						   g.stream));
+	/* one device block for the results — [TIDs | distances | counts] — and one pinned host block for the query
+	 * and the results: a call is one H2D, the kernels, one D2H (what one amgettuple costs: every pageable copy
+	 * is ~10 us of it) */
+	const size_t nk = (size_t) nq * k;
+	const size_t out_words = nk * 2 + nk + (size_t) nq;		/* in 4-byte words */
+
+	if (grow(ix->w_otid, ix->w_otid_n, (out_words + 1) / 2)) return NDBHIP_ERR_HIP;	/* uint64 units */
+	uint64_t   *d_tid = ix->w_otid;
+	float	   *d_dist = (float *) (ix->w_otid + nk);
+	int		   *d_cnt = (int *) (d_dist + nk);
+	const size_t pin_bytes = (size_t) nq * ix->dim * sizeof(float) + 8 + out_words * 4;
+
+	if (pin_bytes > ix->pin_n)
+	{
+		if (ix->pin) HIP_TRY(hipHostFree(ix->pin));
+		ix->pin = nullptr;
+		ix->pin_n = 0;
+		HIP_TRY(hipHostMalloc((void **) &ix->pin, pin_bytes, hipHostMallocDefault));
+		ix->pin_n = pin_bytes;
+	}
+	float	   *h_q = (float *) ix->pin;
+	unsigned char *h_out = (unsigned char *) ix->pin + (((size_t) nq * ix->dim * sizeof(float) + 7) & ~(size_t) 7);
+
+	memcpy(h_q, queries, (size_t) nq * ix->dim * sizeof(float));
+	HIP_TRY(hipMemcpyAsync(ix->w_q, h_q, (size_t) nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
 	rc = ivf_search_device_impl(ix, ix->w_q, nq, strategy, nprobe, k, max_candidates, 0, nullptr, nullptr,
-								nullptr, ix->w_otid, ix->w_odist, ix->w_ocnt);
+								nullptr, d_tid, d_dist, d_cnt);
 	if (rc)
 		return rc;
-	std::vector<uint64_t> t64((size_t) nq * k);
-
-	HIP_TRY(hipMemcpyAsync(t64.data(), ix->w_otid, t64.size() * 8, hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipMemcpyAsync(out_dist, ix->w_odist, (size_t) nq * k * 4, hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipMemcpyAsync(out_count, ix->w_ocnt, (size_t) nq * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(h_out, d_tid, out_words * 4, hipMemcpyDeviceToHost, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));
+	const uint64_t *t64 = (const uint64_t *) h_out;
+
+	memcpy(out_dist, h_out + nk * 8, nk * 4);
+	memcpy(out_count, h_out + nk * 8 + nk * 4, (size_t) nq * 4);
 	for (int q = 0; q < nq; q++)
 		for (int i = 0; i < k; i++)
 		{
