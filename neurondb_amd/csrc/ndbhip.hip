@@ -8073,6 +8073,7 @@ struct ndbhip_hnsw
 	long long  *w_os = nullptr;		size_t w_os_n = 0;
 	uint32_t   *w_vbits = nullptr;	size_t w_vbits_n = 0;	/* hnsw_search_layer: per-block visited bitmaps, all-zero at rest */
 	uint32_t   *w_vlog = nullptr;	size_t w_vlog_n = 0;
+	void	   *pin = nullptr;		size_t pin_n = 0;		/* pinned host block of the host-pointer search: queries + results */
 };
 
 extern "C" int
@@ -8120,6 +8121,7 @@ ndbhip_hnsw_destroy(ndbhip_hnsw *h)
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
+		if (h->pin) (void) hipHostFree(h->pin);
 	}
 	delete h;
 	return NDBHIP_OK;
@@ -9042,31 +9044,45 @@ hnsw_search_host(ndbhip_hnsw *h, bool scan_layer, const float *queries, int nq, 
 	if (!queries || !out_blocks || !out_dist || !out_count)
 		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
 	if (grow(h->w_q, h->w_q_n, (size_t) nq * h->dim)) return NDBHIP_ERR_HIP;
-	if (grow(h->w_ob, h->w_ob_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
-	if (grow(h->w_od, h->w_od_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
-	if (grow(h->w_oc, h->w_oc_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-	if (grow(h->w_ot, h->w_ot_n, (size_t) nq * k)) return NDBHIP_ERR_HIP;
-	if (grow(h->w_os, h->w_os_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-	HIP_TRY(hipMemcpyAsync(h->w_q, queries, (size_t) nq * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
-	HIP_TRY(hipMemsetAsync(h->w_ob, 0, (size_t) nq * k * 4, g.stream));
-	HIP_TRY(hipMemsetAsync(h->w_od, 0, (size_t) nq * k * 4, g.stream));
-	HIP_TRY(hipMemsetAsync(h->w_ot, 0, (size_t) nq * k * 8, g.stream));
+	/* one device block for the results — [TIDs | evaluation counts | blocks | distances | counts] — and one
+	 * pinned host block for the queries and the results: one H2D, one clear, the walk, one D2H per call */
+	const size_t nk = (size_t) nq * k;
+	const size_t out_bytes = nk * 8 + (size_t) nq * 8 + nk * 4 + nk * 4 + (size_t) nq * 4;
+
+	if (grow(h->w_ot, h->w_ot_n, (out_bytes + 7) / 8)) return NDBHIP_ERR_HIP;
+	uint64_t   *d_tid = h->w_ot;
+	long long  *d_sc = (long long *) (d_tid + nk);
+	uint32_t   *d_blk = (uint32_t *) (d_sc + nq);
+	float	   *d_dist = (float *) (d_blk + nk);
+	int		   *d_cnt = (int *) (d_dist + nk);
+	const size_t q_bytes = ((size_t) nq * h->dim * sizeof(float) + 7) & ~(size_t) 7;
+
+	if (q_bytes + out_bytes > h->pin_n)
+	{
+		if (h->pin) HIP_TRY(hipHostFree(h->pin));
+		h->pin = nullptr;
+		h->pin_n = 0;
+		HIP_TRY(hipHostMalloc((void **) &h->pin, q_bytes + out_bytes, hipHostMallocDefault));
+		h->pin_n = q_bytes + out_bytes;
+	}
+	unsigned char *h_out = (unsigned char *) h->pin + q_bytes;
+
+	memcpy(h->pin, queries, (size_t) nq * h->dim * sizeof(float));
+	HIP_TRY(hipMemcpyAsync(h->w_q, h->pin, (size_t) nq * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(d_tid, 0, out_bytes, g.stream));
 	rc = scan_layer
-		? ndbhip_hnsw_search_layer_device(h, h->w_q, nq, strategy, ef, k, h->w_ob, h->w_od, h->w_oc, h->w_ot,
-										  (int64_t *) h->w_os)
-		: ndbhip_hnsw_search_device(h, h->w_q, nq, strategy, ef, k, h->w_ob, h->w_od, h->w_oc, h->w_ot,
-									(int64_t *) h->w_os);
+		? ndbhip_hnsw_search_layer_device(h, h->w_q, nq, strategy, ef, k, d_blk, d_dist, d_cnt, d_tid, (int64_t *) d_sc)
+		: ndbhip_hnsw_search_device(h, h->w_q, nq, strategy, ef, k, d_blk, d_dist, d_cnt, d_tid, (int64_t *) d_sc);
 	if (rc)
 		return rc;
-	std::vector<uint64_t> t64((size_t) nq * k);
-	std::vector<long long> sc((size_t) nq);
-
-	HIP_TRY(hipMemcpyAsync(out_blocks, h->w_ob, (size_t) nq * k * 4, hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipMemcpyAsync(out_dist, h->w_od, (size_t) nq * k * 4, hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipMemcpyAsync(out_count, h->w_oc, (size_t) nq * 4, hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipMemcpyAsync(t64.data(), h->w_ot, t64.size() * 8, hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipMemcpyAsync(sc.data(), h->w_os, sc.size() * 8, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(h_out, d_tid, out_bytes, hipMemcpyDeviceToHost, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));
+	const uint64_t *t64 = (const uint64_t *) h_out;
+	const long long *sc = (const long long *) (h_out + nk * 8);
+
+	memcpy(out_blocks, h_out + nk * 8 + (size_t) nq * 8, nk * 4);
+	memcpy(out_dist, h_out + nk * 8 + (size_t) nq * 8 + nk * 4, nk * 4);
+	memcpy(out_count, h_out + nk * 8 + (size_t) nq * 8 + nk * 8, (size_t) nq * 4);
 	uint64_t	tot = 0;
 
 	for (int q2 = 0; q2 < nq; q2++)
