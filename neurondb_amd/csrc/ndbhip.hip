@@ -857,12 +857,8 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			if (lco)			/* positions of the rows THIS rank holds (sharded mirrors) */
 				lco[i + 1] = (uint32_t) mine;
 		}
-		if (counters)
-		{
-			atomicAdd(&counters[0], (unsigned long long) acc);
-			atomicAdd(&counters[1], (unsigned long long) mine);
-			atomicAdd(&counters[2], (unsigned long long) mine * (unsigned long long) dim);
-		}
+		(void) counters;		/* summed by k_sum_candidates: three atomics per query on one line serialise */
+		(void) dim;
 	}
 }
 
@@ -900,11 +896,43 @@ k_probe_offsets(const int *__restrict__ probes, uint32_t nq, int npr, int ncent,
 		if (lco)
 			lco[i + 1] = (uint32_t) mine;
 	}
-	if (counters)
+	(void) counters;
+	(void) dim;
+}
+
+/* counters[0] += candidates of all queries (every rank's view), [1] += those held here, [2] += their bytes:
+ * one block over the per-query offset tables the two kernels above leave */
+__global__ __launch_bounds__(256) void
+k_sum_candidates(const uint32_t *__restrict__ cand_off, const uint32_t *__restrict__ loc_cand_off, uint32_t nq, int npr,
+				 int row_bytes, unsigned long long *__restrict__ counters)
+{
+	__shared__ unsigned long long pa[4], pm[4];
+	unsigned long long a = 0, m = 0;
+
+	for (uint32_t q = threadIdx.x; q < nq; q += 256)
 	{
-		atomicAdd(&counters[0], (unsigned long long) acc);
-		atomicAdd(&counters[1], (unsigned long long) mine);
-		atomicAdd(&counters[2], (unsigned long long) mine * (unsigned long long) dim);
+		a += cand_off[(size_t) q * (npr + 1) + npr];
+		m += (loc_cand_off ? loc_cand_off : cand_off)[(size_t) q * (npr + 1) + npr];
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		a += ((unsigned long long) (uint32_t) __shfl_xor((uint32_t) (a >> 32), off, 64) << 32) | (uint32_t) __shfl_xor((uint32_t) a, off, 64);
+		m += ((unsigned long long) (uint32_t) __shfl_xor((uint32_t) (m >> 32), off, 64) << 32) | (uint32_t) __shfl_xor((uint32_t) m, off, 64);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		pa[threadIdx.x >> 6] = a;
+		pm[threadIdx.x >> 6] = m;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const unsigned long long ta = pa[0] + pa[1] + pa[2] + pa[3], tm = pm[0] + pm[1] + pm[2] + pm[3];
+
+		atomicAdd(&counters[0], ta);
+		atomicAdd(&counters[1], tm);
+		atomicAdd(&counters[2], tm * (unsigned long long) row_bytes);
 	}
 }
 
@@ -1959,6 +1987,30 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 
 /* one lane per listed candidate: the reference's arithmetic, the value into the distance buffer and into its
  * tile's minimum */
+/* counters[3] += sum of v[0..n): one block */
+__global__ __launch_bounds__(256) void
+k_sum_u32(const unsigned int *__restrict__ v, uint32_t n, unsigned long long *__restrict__ out)
+{
+	__shared__ unsigned long long part[4];
+	unsigned long long s = 0;
+
+	for (uint32_t i = threadIdx.x; i < n; i += 256)
+		s += v[i];
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const uint32_t lo = __shfl_xor((uint32_t) s, off, 64);
+		const uint32_t hi = __shfl_xor((uint32_t) (s >> 32), off, 64);
+
+		s += ((unsigned long long) hi << 32) | lo;
+	}
+	if ((threadIdx.x & 63) == 0)
+		part[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0 && out)
+		atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
 template <int R, int H16>
 __global__ __launch_bounds__(64) void
 k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restrict__ dist, uint32_t stride,
@@ -1969,8 +2021,7 @@ k_ivf_rescore_list(IvfDev ix, const float *__restrict__ queries, float *__restri
 	const uint32_t n = rec_counts[q];
 	const uint32_t i = blockIdx.x * 64 + threadIdx.x;
 
-	if (blockIdx.x == 0 && threadIdx.x == 0 && counters && n)
-		atomicAdd(&counters[3], (unsigned long long) n);
+	(void) counters;			/* counted by k_sum_u32: one atomic per launch, not one per query on one line */
 	if (i >= n)
 		return;
 	const ScrRec r = recs[(size_t) q * rec_cap + i];
@@ -3676,6 +3727,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	HIP_TRY(hipGetLastError());
 	if (!full)
 		return 0;
+	hipLaunchKernelGGL(k_sum_candidates, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) ix->w_candoff,
+					   (const uint32_t *) lco_w, (uint32_t) nq, npr, ix->dim * (ix->f16 ? 2 : 4), g.d_counters);
 
 	/* HOT LOOP 2 */
 	const int	R = ivf_recipe(strategy);
@@ -3967,6 +4020,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 					LAUNCH_SECOND_PASS(R_IVF_COS);
 				else
 					LAUNCH_SECOND_PASS(R_IVF_L2);
+				hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) rec_counts,
+								   (uint32_t) nq, g.d_counters + 3);
 			}
 			hipLaunchKernelGGL(k_ivf_topk, dim3(nq), dim3(256), smem, g.stream, d, (const int *) w_probes,
 							   (const uint32_t *) ix->w_candoff, lco, npr, (const float *) ix->w_dist, stride,
