@@ -31,6 +31,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s meas
 # fp32 vector peak is 157.3 TFLOP/s with FMA (64 FLOP/clk/SIMD); the reference's recipe needs separately
 # rounded subtract, multiply and add (no FMA), i.e. 32 FLOP/clk/SIMD = 78.6 TFLOP/s
 UNFUSED_FP32_PEAK_TFLOPS = 78.6
+FP32_MFMA_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 4 x 256 CUs x 2.4 GHz
 
 
 def parse():
@@ -242,6 +243,10 @@ def main():
     if screened and os.environ.get("NDBHIP_SCR_COOP", "2") != "0" and dim % 16 == 0:
         kernel = (f"k_ivf_bound_coop2<{recipe}>" if os.environ.get("NDBHIP_SCR_COOP", "2") == "2"
                   else "k_ivf_bound_coop<R_SCR_L2>")
+    mfma = (screened and os.environ.get("NDBHIP_SCR_COOP", "2") == "2" and dim % 16 == 0
+            and os.environ.get("NDBHIP_SCR_MFMA", "1") != "0")
+    if mfma:
+        kernel = f"k_ivf_bound_mfma<{recipe}>"
     launches = max(1, st["scan_launches"])
     bytes_per_launch = st["bytes_scored"] / launches          # algorithmic: probed rows x dim x 4 B per query
     ms_per_launch = st["scan_kernel_ms"] / launches
@@ -274,6 +279,29 @@ def main():
                 "valu": {"achieved": round(valu_tflops, 2), "peak": valu_peak, "unit": "TFLOP/s",
                          "frac": round(valu_tflops / valu_peak, 4),
                          "ops": "fused multiply-add" if screened else "unfused subtract / multiply / add"}}
+
+    if mfma:
+        # The bound pass runs on the matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fmaf chain, dense
+        # fp32 MFMA peak 157.3 TFLOP/s = 64 FLOP/clk/SIMD at 2.4 GHz, MI355X_MICROARCH.md): that is the roof
+        # that bounds it.  flops = 2 per (row element, query) pair actually scored; the algorithmic-bytes figure
+        # of SURVEY 8d (no reuse across queries) and the measured HBM traffic stay alongside.
+        roofline = {"bound": "mfma", "kernel": kernel, "achieved": round(valu_tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(valu_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": roofline["traffic"], "flops_per_launch": int(flops_per_launch),
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(ms_per_launch, 4),
+                    "launches": int(launches),
+                    "rows_rescored_per_query": roofline["rows_rescored_per_query"],
+                    "note": ("bound pass of the screened scan on fp32 MFMA: one block scores 128 rows against 64 queries "
+                             "(4 groups) from one staged LDS tile; the MFMA's k-ordered fmaf chain is the chain the "
+                             "vector-ALU bound kernel ran, so the lower bounds have the same bits and the "
+                             f"{roofline['rows_rescored_per_query']:.0f} candidates per query that can still be among the "
+                             "k nearest get the reference's sequential arithmetic in a second pass: ids, ranks and float4 "
+                             "bits are the exact path's.  flops = 2 x dim per scored (row, query) pair"),
+                    "hbm_algorithmic": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                                        "note": "rows scored x row bytes per query (SURVEY 8d, no reuse across queries); "
+                                                "the kernel reuses a staged tile for 64 queries, so the real HBM "
+                                                "traffic is `traffic`"}}
 
     # ---------------- recall@10 vs exact float64 brute force ----------------
     recall = None

@@ -2426,6 +2426,286 @@ k_ivf_bound_coop2(IvfDev ix, const float *__restrict__ qblock, const uint32_t *_
 	}
 }
 
+/*
+ * The bound pass on the matrix cores: v_mfma_f32_32x32x2_f32.  Its numerics are a k-ordered f32 fmaf chain per
+ * output element (one rounding per product-and-add, no wider accumulator: cdna_hip_programming.md, "FP32-input
+ * MFMA") — the kind of chain GAcc::step_dot runs (dot = fma(q_d, x_d, dot)), in a permuted dimension order
+ * (below) — so the error term E_q of the screened scan, which holds for any order of the dim fused
+ * multiply-adds, holds unchanged.  What changes is who does the work: one MFMA (64 cycles of the
+ * matrix pipe, two operand registers) replaces 1024 packed FMAs' worth of issue slots, operand moves and
+ * scalar-load waits.
+ *
+ * Same items as the two-tile kernel: (list, 128 rows, four query groups = 64 queries).  Wave w scores the
+ * 32 queries of groups {2(w&1), 2(w&1)+1} against the 64 rows of tile half (w>>1): A = queries (M = 32),
+ * B = rows (N = 32, two blocks), so a result's column — the lane — is the row and a half-wave stores 128
+ * contiguous bytes of a query's distance array.  Rows are staged through LDS in 16-dimension chunks (a
+ * lane's eight values of a chunk are two 16-byte reads); the query values come straight from the
+ * [group][dim][16] block, one dword per lane and step; both are fetched two chunks ahead.
+ */
+typedef float ndb_f16acc __attribute__((ext_vector_type(16)));
+
+#ifndef NDB_MFMA_BLOCKS
+#define NDB_MFMA_BLOCKS 4		/* measured per 4096 queries: 2 -> 9.5 ms, 3 -> 8.7 ms, 4 -> 8.6 ms */
+#endif
+
+__device__ __forceinline__ float
+scr_bound_l2(float dot, float qn, float e, float rn2)
+{
+	const float a = (qn + rn2) - 2.0f * dot;
+	const float l = a - e;
+
+	return __builtin_sqrtf(fmaxf(l, 0.0f) * 0.99999905f);
+}
+__device__ __forceinline__ float
+scr_bound_ip(float dot, float e)
+{
+	const float l = -dot - e;
+
+	return l - fabsf(l) * 2.4e-7f - 1e-37f;
+}
+__device__ __forceinline__ float
+scr_bound_cos(float dot, float qn, float rn2, float e)
+{
+	const float a = __builtin_sqrtf(qn), b = __builtin_sqrtf(rn2);
+	const float c = (a == 0.0f || b == 0.0f) ? 1.0f : 1.0f - (dot / (a * b));
+	const float l = c - e;
+
+	return l - fabsf(l) * 2.4e-7f - 1e-37f;
+}
+
+template <int R, int H16>
+__global__ __launch_bounds__(256, NDB_MFMA_BLOCKS) void
+k_ivf_bound_mfma(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__restrict__ loc_cand_off, int npr,
+				 const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off,
+				 const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ grp_off,
+				 const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
+				 const uint32_t *__restrict__ runs, float *__restrict__ dist, uint32_t stride,
+				 const float *__restrict__ qnorm, uint32_t *__restrict__ tmin, uint32_t tstride, int polite,
+				 uint32_t nq_all, const float *__restrict__ rnorm)
+{
+	constexpr int CH = 16;
+	__shared__ __attribute__((aligned(16))) float tile[2][128 * CH];
+	__shared__ uint32_t s_item;
+	const int	tid = threadIdx.x;
+	const int	lane = tid & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t qhalf = wave & 1u, rhalf = wave >> 1;
+	const int	kh = lane >> 5, ln = lane & 31;
+	const int	dim = ix.dim;
+	const int	srow = tid >> 2, sslot = tid & 3;	/* staging: thread = (row of the tile, four dimensions) */
+	/* Within a 16-dimension chunk, step s of the MFMA sequence multiplies dimension s (k = 0, lanes 0-31) and
+	 * dimension 8 + s (k = 1, lanes 32-63): a lane's eight values are 32 contiguous bytes of the row, the tile
+	 * keeps the row's natural layout and staging is a straight 16-byte copy.  The chain of an output element
+	 * then runs 0, 8, 1, 9, ... instead of 0, 1, 2, ...: a different order of the same fused multiply-adds, to
+	 * which the error term applies unchanged (gamma_n bounds recursive summation in any order).  16-byte slots
+	 * are XOR-swizzled by the row so that 16 consecutive rows reading one logical slot cover all 64 banks */
+	const int	woff = srow * CH + ((sslot ^ ((srow >> 2) & 3)) * 4);	/* rows srow and srow + 64 share the swizzle */
+
+	for (uint32_t hop = 0; hop < 8; hop++)
+	{
+	const uint32_t xq = (blockIdx.x + hop) & 7u;
+	const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+
+	if (run_lo == run_hi)
+		continue;
+	for (;;)
+	{
+		if (tid == 0)
+			s_item = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
+															__HIP_MEMORY_SCOPE_AGENT) >= run_hi)
+				? run_hi : run_lo + atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
+		__syncthreads();
+		const uint32_t item = s_item;
+
+		__syncthreads();		/* everybody has read it before thread 0 can write the next one */
+		if (item >= run_hi)
+			break;				/* uniform: every thread leaves */
+		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;
+
+		while (hi - lo > 1)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if (item_off[mid] <= item)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (lo + 1 < (uint32_t) ix.ncent && item_off[lo + 1] <= item)
+			lo++;
+		const uint32_t L = lo;
+		const uint32_t len = ix.own_len[L];
+		const uint32_t local = item - item_off[L];
+		const uint32_t nmemL = cnt[L];
+		const uint32_t ngrp = (nmemL + NDB_QG - 1) / NDB_QG;
+		const uint32_t nquad = (ngrp + 3u) >> 2;
+		const uint32_t quad = local % nquad;
+		const uint32_t t2 = local / nquad;		/* 128-row tile */
+		const uint32_t gw = quad * 4u + qhalf * 2u;	/* this wave's first group */
+		const bool	active = gw < ngrp;		/* wave-uniform */
+		/* the lane's query column of A: group gw + (ln >> 4), member ln & 15; a missing second group reads the
+		 * first one again (its results are not stored) */
+		const uint32_t ga = (active && gw + (uint32_t) (ln >> 4) < ngrp) ? gw + (uint32_t) (ln >> 4) : (active ? gw : 0u);
+		const float *__restrict__ qp = qblock + (size_t) (grp_off[L] + ga) * (size_t) dim * NDB_QG + (ln & 15) + kh * 8 * NDB_QG;
+		const uint32_t sr0 = t2 * 128 + (uint32_t) srow, sr1 = sr0 + 64;
+		const float *src0 = ix.vecs + ((size_t) ix.loc_off[L] + (sr0 < len ? sr0 : len - 1)) * (size_t) dim + sslot * 4;
+		const float *src1 = ix.vecs + ((size_t) ix.loc_off[L] + (sr1 < len ? sr1 : len - 1)) * (size_t) dim + sslot * 4;
+		const uint16_t *h0 = (const uint16_t *) ix.vecs + ((size_t) ix.loc_off[L] + (sr0 < len ? sr0 : len - 1)) * (size_t) dim + sslot * 4;
+		const uint16_t *h1 = (const uint16_t *) ix.vecs + ((size_t) ix.loc_off[L] + (sr1 < len ? sr1 : len - 1)) * (size_t) dim + sslot * 4;
+		ndb_f16acc	acc0, acc1;
+
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			acc0[i] = 0.0f;
+			acc1[i] = 0.0f;
+		}
+		/* Two register sets rotate (the chunk loop is unrolled by two): the rows of chunk c + 2 are fetched while
+		 * chunk c is multiplied and the set fetched one chunk earlier is written to LDS, so a row fetch has two
+		 * chunks of MFMAs to arrive; the query values of chunk c + 2 go into the registers chunk c has just
+		 * used.  Nothing is copied between the sets: a copy would wait for its load. */
+		float4		sa0, sa1, sb0, sb1;
+		float		qa[CH / 2], qb[CH / 2];
+		const int	clast = dim - CH;
+
+		auto fetch_rows = [&](int c, float4 &st0, float4 &st1) {
+			if constexpr (H16 != 0)
+			{
+				st0 = ndb_decode4<H16 == 1>(h0 + c);
+				st1 = ndb_decode4<H16 == 1>(h1 + c);
+			}
+			else
+			{
+				st0 = *reinterpret_cast<const float4 *>(src0 + c);
+				st1 = *reinterpret_cast<const float4 *>(src1 + c);
+			}
+		};
+		auto store_rows = [&](float *tb, const float4 &st0, const float4 &st1) {
+			*reinterpret_cast<float4 *>(tb + woff) = st0;
+			*reinterpret_cast<float4 *>(tb + 64 * CH + woff) = st1;
+		};
+		auto load_q = [&](int c, float (&q)[CH / 2]) {
+#pragma unroll
+			for (int s = 0; s < CH / 2; s++)
+				q[s] = qp[(size_t) (c + s) * NDB_QG];
+		};
+		const int	r0 = (int) rhalf * 64 + ln, r1 = r0 + 32;
+		const int	ro0a = r0 * CH + (((kh * 2) ^ ((r0 >> 2) & 3)) * 4), ro0b = r0 * CH + (((kh * 2 + 1) ^ ((r0 >> 2) & 3)) * 4);
+		const int	ro1a = r1 * CH + (((kh * 2) ^ ((r1 >> 2) & 3)) * 4), ro1b = r1 * CH + (((kh * 2 + 1) ^ ((r1 >> 2) & 3)) * 4);
+		auto multiply = [&](const float *tb, const float (&q)[CH / 2]) {
+			const float4 xa0 = *reinterpret_cast<const float4 *>(tb + ro0a);
+			const float4 xb0 = *reinterpret_cast<const float4 *>(tb + ro0b);
+			const float4 xa1 = *reinterpret_cast<const float4 *>(tb + ro1a);
+			const float4 xb1 = *reinterpret_cast<const float4 *>(tb + ro1b);
+			const float x0[8] = {xa0.x, xa0.y, xa0.z, xa0.w, xb0.x, xb0.y, xb0.z, xb0.w};
+			const float x1[8] = {xa1.x, xa1.y, xa1.z, xa1.w, xb1.x, xb1.y, xb1.z, xb1.w};
+
+#pragma unroll
+			for (int s = 0; s < CH / 2; s++)
+			{
+				acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q[s], x0[s], acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q[s], x1[s], acc1, 0, 0, 0);
+			}
+		};
+
+		/* chunk indices past the end fetch the last chunk again (never multiplied) instead of branching */
+		fetch_rows(0, sa0, sa1);
+		load_q(0, qa);
+		fetch_rows(min(CH, clast), sb0, sb1);
+		load_q(min(CH, clast), qb);
+		store_rows(tile[0], sa0, sa1);
+		__syncthreads();
+		for (int c = 0; c < dim; c += 2 * CH)
+		{
+			/* even chunk c: tile[0]; set a refills with chunk c + 2, set b (chunk c + 1) goes to tile[1] */
+			fetch_rows(min(c + 2 * CH, clast), sa0, sa1);
+			if (active)
+				multiply(tile[0], qa);
+			load_q(min(c + 2 * CH, clast), qa);
+			store_rows(tile[1], sb0, sb1);
+			__syncthreads();
+			if (c + CH >= dim)
+				break;			/* uniform: an odd number of chunks */
+			/* odd chunk c + 1: tile[1]; set b refills with chunk c + 3, set a (chunk c + 2) goes to tile[0] */
+			fetch_rows(min(c + 3 * CH, clast), sb0, sb1);
+			if (active)
+				multiply(tile[1], qb);
+			load_q(min(c + 3 * CH, clast), qb);
+			store_rows(tile[0], sa0, sa1);
+			__syncthreads();
+		}
+		if (active)
+		{
+			const uint32_t rb = t2 * 128 + rhalf * 64 + (uint32_t) ln;	/* row of acc0; acc1: + 32 */
+			const float rn0 = rnorm[(size_t) ix.loc_off[L] + (rb < len ? rb : len - 1)];
+			const float rn1 = rnorm[(size_t) ix.loc_off[L] + (rb + 32 < len ? rb + 32 : len - 1)];
+			const uint32_t t = t2 * 2u + rhalf;
+			const uint32_t ridx0 = t * 64 + (uint32_t) ln, ridx1 = ridx0 + 32;
+
+#pragma unroll
+			for (int reg = 0; reg < 16; reg++)
+			{
+				const uint32_t m = (uint32_t) ((reg & 3) + 8 * (reg >> 2) + 4 * kh);	/* query row of C */
+				const uint32_t mi = (gw + (m >> 4)) * NDB_QG + (m & 15);		/* member index in the list's pairs */
+				const bool	qv = mi < nmemL;		/* uniform over the half-wave */
+				uint32_t	mk = 0xFFFFFFFFu;
+				uint32_t	qid = 0, pp = 0, la = 0, nrow = 0;
+
+				if (qv)
+				{
+					const PairRec pr = pairs[pair_off[L] + mi];
+
+					qid = pr.q;
+					pp = pr.p;
+					const uint32_t *lq = loc_cand_off + (size_t) qid * (npr + 1);
+
+					la = lq[pp];
+					nrow = lq[pp + 1] - la;
+					const float qn = qnorm[qid], qe = qnorm[nq_all + qid];
+					float		d0, d1;
+
+					if (R == R_IVF_L2)
+					{
+						d0 = scr_bound_l2(acc0[reg], qn, qe, rn0);
+						d1 = scr_bound_l2(acc1[reg], qn, qe, rn1);
+					}
+					else if (R == R_IVF_IP)
+					{
+						d0 = scr_bound_ip(acc0[reg], qe);
+						d1 = scr_bound_ip(acc1[reg], qe);
+					}
+					else
+					{
+						const float nu = (float) (dim + 8) * NDB_SCR_U;
+						const float ec = 4.0f * nu / (1.0f - nu);
+
+						d0 = scr_bound_cos(acc0[reg], qn, rn0, ec);
+						d1 = scr_bound_cos(acc1[reg], qn, rn1, ec);
+					}
+					if (ridx0 < nrow)
+					{
+						dist[(size_t) qid * stride + la + ridx0] = d0;
+						mk = ndb_key_from_bits(__float_as_uint(d0));
+					}
+					if (ridx1 < nrow)
+					{
+						dist[(size_t) qid * stride + la + ridx1] = d1;
+						mk = min(mk, ndb_key_from_bits(__float_as_uint(d1)));
+					}
+				}
+				/* minimum over the half-wave's 32 lanes (both halves shuffle; they hold different queries) */
+#pragma unroll
+				for (int off = 16; off > 0; off >>= 1)
+					mk = min(mk, (uint32_t) __shfl_xor((int) mk, off, 64));
+				if (qv && ln == 0 && t * 64u < nrow)
+					tmin[(size_t) qid * tstride + (la >> 6) + pp + t] = mk;
+			}
+		}
+		__syncthreads();		/* s_item and the tile are reused by the next item */
+	}
+	}
+}
+
 
 /* dynamic LDS layout of k_ivf_topk / k_merge_topk */
 struct TopkSmem
@@ -3877,7 +4157,32 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 					else if (ix->f16_sub) LAUNCH_COOP2_H(RR, 1);                                                       \
 					else LAUNCH_COOP2_H(RR, 2);                                                                        \
 				} while (0)
-			if (coop == 2)
+			/* the same items on the matrix cores (k_ivf_bound_mfma: the same fmaf chains, hence the same bits);
+			 * NDBHIP_SCR_MFMA=0 keeps the vector-ALU kernel for A/B */
+			static const int scr_mfma = getenv("NDBHIP_SCR_MFMA") ? atoi(getenv("NDBHIP_SCR_MFMA")) : 1;
+#define LAUNCH_MFMA_H(RR, HH)                                                                                   \
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ivf_bound_mfma<RR, HH>), dim3(g.num_cus * NDB_MFMA_BLOCKS), dim3(256), 0, \
+								   g.stream, d, (const float *) ix->w_qblock, lco, npr, (const uint32_t *) cnt,        \
+								   (const uint32_t *) pair_off, (const uint32_t *) item_off, (const uint32_t *) grp_off, \
+								   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ix->w_dist, stride, \
+								   (const float *) ix->w_qnorm, ix->w_tmin, tstride, nq < 1024 ? 1 : 0, (uint32_t) nq, \
+								   (const float *) ix->w_rnorm)
+#define LAUNCH_MFMA(RR)                                                                                        \
+				do {                                                                                                   \
+					if (!ix->f16) LAUNCH_MFMA_H(RR, 0);                                                                \
+					else if (ix->f16_sub) LAUNCH_MFMA_H(RR, 1);                                                        \
+					else LAUNCH_MFMA_H(RR, 2);                                                                         \
+				} while (0)
+			if (coop == 2 && scr_mfma)
+			{
+				if (R == R_IVF_IP)
+					LAUNCH_MFMA(R_IVF_IP);
+				else if (R == R_IVF_COS)
+					LAUNCH_MFMA(R_IVF_COS);
+				else
+					LAUNCH_MFMA(R_IVF_L2);
+			}
+			else if (coop == 2)
 			{
 				if (R == R_IVF_IP)
 					LAUNCH_COOP2(R_IVF_IP);
