@@ -2489,7 +2489,7 @@ k_ivf_bound_mfma(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__
 	const int	tid = threadIdx.x;
 	const int	lane = tid & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t qhalf = wave & 1u, rhalf = wave >> 1;
+	const uint32_t rhalf = wave >> 1;
 	const int	kh = lane >> 5, ln = lane & 31;
 	const int	dim = ix.dim;
 	const int	srow = tid >> 2, sslot = tid & 3;	/* staging: thread = (row of the tile, four dimensions) */
@@ -2541,6 +2541,10 @@ k_ivf_bound_mfma(IvfDev ix, const float *__restrict__ qblock, const uint32_t *__
 		const uint32_t nquad = (ngrp + 3u) >> 2;
 		const uint32_t quad = local % nquad;
 		const uint32_t t2 = local / nquad;		/* 128-row tile */
+		/* which waves take the quad's upper two groups alternates from item to item: a quad with one or two
+		 * groups leaves two waves without work, and wave i of every block runs on SIMD i — always idling the
+		 * same two SIMDs would leave the other two as the bottleneck of the four blocks that share the CU */
+		const uint32_t qhalf = (wave ^ t2 ^ L) & 1u;
 		const uint32_t gw = quad * 4u + qhalf * 2u;	/* this wave's first group */
 		const bool	active = gw < ngrp;		/* wave-uniform */
 		/* the lane's query column of A: group gw + (ln >> 4), member ln & 15; a missing second group reads the
