@@ -375,6 +375,7 @@ def main():
             "note": None if (args.rows == "f32" and args.strategy == "l2") else
             "recall / CPU legs run for the default fp32 L2 workload only; parity of this variant: tests/test_gpu_ivf.py",
             "roofline": roofline,
+            "library_stats": {k2: (round(v2, 3) if isinstance(v2, float) else int(v2)) for k2, v2 in st.items()},
             "cpu_baseline": cpu_baseline,
             "dist_parity_on_sample": dist_parity,
             "hnsw": hnsw,

@@ -93,7 +93,10 @@ typedef struct ndbhip_stats
 	uint64_t	bytes_scored;		/* algorithmic bytes = rows_scored * dim * elem size */
 	uint64_t	scan_launches;		/* launches of the dominant kernel (list scan / hnsw walk) */
 	double		scan_kernel_ms;		/* HIP-event time of those launches (only while profiling is on) */
-	uint64_t	rows_rescored;		/* screened L2 scan: candidates given the reference's arithmetic in the second pass */
+	uint64_t	rows_rescored;		/* screened scan: candidates given the reference's arithmetic in the second pass */
+	uint64_t	rows_emitted;		/* fp16 matrix-core screen: candidates the bound pass could not exclude */
+	uint64_t	screen16_batches;	/* sub-batches served by the fp16 matrix-core screen */
+	uint64_t	screen16_fallbacks;	/* ... that overflowed a query's record capacity and were rerun on the fp32 screen */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);
@@ -105,6 +108,27 @@ int			ndbhip_profile(int on);			/* bracket the dominant kernel with HIP events *
  * Screened = a fused-multiply-add pass bounds every candidate's distance from below, and only the candidates
  * that can still be among the k nearest get the reference's own arithmetic. */
 int			ndbhip_set_scan_mode(int mode);
+/* ... 5 = screened by the fp16 matrix-core pass whenever it applies (L2 / inner product, k <= 64, float4 or
+ * halfvec rows, any dim), which is also what auto mode picks for batches of >= 128 queries: the bound pass runs
+ * as a query-tile x row-tile contraction on v_mfma_f32_32x32x16_f16 over rows and queries split into two fp16
+ * planes, emits the candidates it cannot exclude, and the reference's arithmetic decides among those
+ * (csrc/ndbhip_screen16.h; the error term is derived in csrc/ndbhip_common.h).
+ * Rows or queries holding NaN / infinity (or sums beyond fp32) are outside the parity contract — the index paths
+ * of the reference never test for them (ivf_am.c:1550-1592) and x86 / gfx950 do not even agree on the NaN they
+ * produce — but they only affect the candidates they take part in: such a row is always handed to the
+ * reference's arithmetic, never allowed to distort another row's bound. */
+
+/* Process-wide switches that used to be environment variables: "screen16" (1; 0 = auto mode keeps the fp32 bound
+ * pass), "screen16_records" (2048: candidates a query may emit before its batch is rerun on the fp32 screen),
+ * "screen" (1; 0 = auto mode never screens). */
+int			ndbhip_set_option(const char *name, int value);
+
+/* The matrix-core instruction the bound pass rests on, in isolation, so that its accumulation-error model
+ * (csrc/ndbhip_common.h (4)) is checked on the part the library runs on (tests/test_gpu_mfma_model.py):
+ * per tile t, D = C + chain x (A.B) with A [ntiles][32][16], B [ntiles][16][32] fp16 bit patterns and
+ * C, D [ntiles][32][32] floats, all device pointers; asynchronous on the library's stream. */
+int			ndbhip_mfma_probe(const uint16_t *d_a, const uint16_t *d_b, const float *d_c, float *d_d,
+							  int ntiles, int chain);
 
 /* ------------------------------------------------------------------ */
 /* IVF mirror lifecycle.  Replaces the page walk of ivfSelectClusters /

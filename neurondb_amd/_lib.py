@@ -28,7 +28,8 @@ class Cand(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("rows_scored", C.c_uint64), ("bytes_scored", C.c_uint64),
-                ("scan_launches", C.c_uint64), ("scan_kernel_ms", C.c_double), ("rows_rescored", C.c_uint64)]
+                ("scan_launches", C.c_uint64), ("scan_kernel_ms", C.c_double), ("rows_rescored", C.c_uint64),
+                ("rows_emitted", C.c_uint64), ("screen16_batches", C.c_uint64), ("screen16_fallbacks", C.c_uint64)]
 
 
 def lib_path() -> str:
@@ -126,6 +127,8 @@ def lib():
         "ndbhip_stats_reset": (i, []),
         "ndbhip_profile": (i, [i]),
         "ndbhip_set_scan_mode": (i, [i]),
+        "ndbhip_set_option": (i, [C.c_char_p, i]),
+        "ndbhip_mfma_probe": (i, [vp, vp, vp, vp, i, i]),
         "ndbhip_ivf_create": (i, [i, i, C.POINTER(vp)]),
         "ndbhip_ivf_destroy": (i, [vp]),
         "ndbhip_ivf_set_centroids": (i, [vp, vp, i]),

@@ -155,8 +155,8 @@ ndbhip_init(int device)
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
 	g.stream = g.own_stream;
-	HIP_TRY(hipMalloc((void **) &g.d_counters, 4 * sizeof(unsigned long long)));
-	HIP_TRY(hipMemset(g.d_counters, 0, 4 * sizeof(unsigned long long)));
+	HIP_TRY(hipMalloc((void **) &g.d_counters, 8 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
 	g.device = device;
 	g.inited = true;
 	{
@@ -229,7 +229,7 @@ ndbhip_stats_get(ndbhip_stats *out)
 		return fail(NDBHIP_ERR_INVALID, "out is NULL");
 	if (g.inited)
 	{
-		unsigned long long c[4];
+		unsigned long long c[8];
 
 		if (drain_profile_events())
 			return NDBHIP_ERR_HIP;
@@ -238,6 +238,7 @@ ndbhip_stats_get(ndbhip_stats *out)
 		g.stats.rows_scored = g.host_rows + c[1];
 		g.stats.bytes_scored = g.host_bytes + c[2];
 		g.stats.rows_rescored = c[3];
+		g.stats.rows_emitted = c[4];
 	}
 	*out = g.stats;
 	return NDBHIP_OK;
@@ -251,7 +252,7 @@ ndbhip_stats_reset(void)
 		if (drain_profile_events())
 			return NDBHIP_ERR_HIP;
 		HIP_TRY(hipStreamSynchronize(g.stream));
-		HIP_TRY(hipMemset(g.d_counters, 0, 4 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
 	}
 	g.host_rows = g.host_bytes = 0;
 	g.stats = ndbhip_stats();
@@ -261,9 +262,9 @@ ndbhip_stats_reset(void)
 extern "C" int
 ndbhip_set_scan_mode(int mode)
 {
-	if (mode < 0 || mode > 4)
-		return fail(NDBHIP_ERR_INVALID, "scan mode must be 0 (auto), 1 (per-query), 2 (grouped), 3 (grouped, screened) "
-					"or 4 (grouped, never screened)");
+	if (mode < 0 || mode > 5)
+		return fail(NDBHIP_ERR_INVALID, "scan mode must be 0 (auto), 1 (per-query), 2 (grouped), 3 (grouped, screened by "
+					"the fp32 bound pass), 4 (grouped, never screened) or 5 (screened by the fp16 matrix-core pass)");
 	g_scan_mode = mode;
 	return NDBHIP_OK;
 }
@@ -1053,7 +1054,7 @@ struct PairRec
 /* pass 1: how many (query, probe) pairs hit each owned list */
 __global__ void
 k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
-			 uint32_t *__restrict__ cnt)
+			 uint32_t *__restrict__ cnt, const unsigned int *__restrict__ active = nullptr)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -1062,7 +1063,7 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 	const uint32_t q = i / npr, p = i % npr;
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);	/* rows held HERE for this (query, probe) */
 
-	if (co[p + 1] == co[p])
+	if (co[p + 1] == co[p] || (active && !active[q]))
 		return;
 	atomicAdd(&cnt[probes[(size_t) q * npr + p]], 1u);
 }
@@ -1158,7 +1159,7 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 __global__ void
 k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
 			const uint32_t *__restrict__ pair_off,
-			uint32_t *__restrict__ fill, PairRec *__restrict__ pairs)
+			uint32_t *__restrict__ fill, PairRec *__restrict__ pairs, const unsigned int *__restrict__ active = nullptr)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -1167,7 +1168,7 @@ k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	const uint32_t q = i / npr, p = i % npr;
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
 
-	if (co[p + 1] == co[p])
+	if (co[p + 1] == co[p] || (active && !active[q]))
 		return;
 	const int	L = probes[(size_t) q * npr + p];
 	const uint32_t slot = pair_off[L] + atomicAdd(&fill[L], 1u);
@@ -1728,14 +1729,22 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 /* ------------------------------------------------------------------ */
 #define NDB_SCR_U 5.9604645e-8f		/* 2^-24 */
 
-/* largest float of a non-negative array (bits order like values) */
+/* largest FINITE float of a non-negative array (bits order like values).  A row whose norm is NaN or infinite
+ * must not reach the bound's constant: it would turn every query's E into NaN and with it every provisional
+ * distance of the batch.  Such a row's own provisional distance is 0 (NaN) or inf, i.e. it is handed
+ * to the reference's arithmetic or ordered last, like the exact scan does. */
 __global__ void
 k_max_nonneg(const float *__restrict__ v, int64_t n, uint32_t *__restrict__ out_bits)
 {
 	uint32_t	m = 0;
 
 	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
-		m = max(m, __float_as_uint(v[i]));
+	{
+		const uint32_t b = __float_as_uint(v[i]);
+
+		if ((b & 0x7F800000u) != 0x7F800000u)
+			m = max(m, b & 0x7FFFFFFFu);
+	}
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1)
 		m = max(m, (uint32_t) __shfl_xor((int) m, off, 64));
@@ -3171,6 +3180,19 @@ struct ndbhip_ivf
 	void	   *pin = nullptr;		size_t pin_n = 0;		/* pinned host block of ndbhip_ivf_search: query + results */
 	float	   *w_cblock = nullptr;	size_t w_cblock_n = 0;	/* centroids interleaved 16 per block (batch centroid scan) */
 	uint32_t   *w_tmin = nullptr;	size_t w_tmin_n = 0;	/* [nq][tstride] smallest order key per 64-candidate tile */
+	/* fp16-MFMA screened scan (ndbhip_screen16.h): per-row split planes / norms / exponents, valid while s16_valid */
+	unsigned char *d_planes = nullptr; size_t d_planes_n = 0;
+	float	   *d_rn2 = nullptr;	size_t d_rn2_n = 0;
+	int16_t    *d_rexp = nullptr;	size_t d_rexp_n = 0;
+	uint32_t   *d_xmax16 = nullptr;
+	bool		s16_valid = false;
+	unsigned char *w_qplanes = nullptr; size_t w_qplanes_n = 0;
+	float	   *w_qn2 = nullptr;	size_t w_qn2_n = 0;
+	int		   *w_qexp = nullptr;	size_t w_qexp_n = 0;
+	float2	   *w_qthr = nullptr;	size_t w_qthr_n = 0;
+	unsigned int *w_ecount = nullptr; size_t w_ecount_n = 0;	/* [nq] emitted per query | [nq] survivors | [nq] seeds | 4 flags */
+	uint2	   *w_erec = nullptr;	size_t w_erec_n = 0;
+	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
 	/* split top-k of small batches: per-range records, counts, totals */
 	ndbhip_cand *w_scand = nullptr;	size_t w_scand_n = 0;
 	int		   *w_sncand = nullptr;	size_t w_sncand_n = 0;
@@ -3224,7 +3246,7 @@ ivf_free_rows(ndbhip_ivf *ix)
 	ix->d_tids = nullptr;
 	ix->own_rows = false;
 	ix->nrows = 0;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->cap_rows = 0;
 }
 
@@ -3240,7 +3262,9 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		void	   *ptrs[] = {ix->d_centroids, ix->d_loc_off, ix->d_glob_len, ix->d_owned, ix->d_own_lo, ix->d_own_len, ix->w_cdist,
 			ix->w_probes, ix->w_candoff, ix->w_dist, ix->w_q, ix->w_otid, ix->w_odist, ix->w_ocnt,
 			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock,
-			ix->d_xxmax, ix->w_rnorm, ix->w_scrt, ix->w_scrd, ix->w_scrc, ix->w_screc};
+			ix->d_xxmax, ix->w_rnorm, ix->w_scrt, ix->w_scrd, ix->w_scrc, ix->w_screc,
+			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
+			ix->w_ecount, ix->w_erec, ix->w_bmin};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3374,7 +3398,7 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->loaded = true;
 	return NDBHIP_OK;
 }
@@ -3453,7 +3477,7 @@ ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owne
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->f16 = true;
 	ix->loaded = true;
 	return ivf_note_f16_subnormals(ix);
@@ -3478,7 +3502,7 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 	ix->own_rows = false;
 	ix->f16 = false;
 	ix->nrows = nrows;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
 	return NDBHIP_OK;
@@ -3645,7 +3669,7 @@ ivf_flush(ndbhip_ivf *ix)
 	ix->d_tids = ntids_d;
 	ix->own_rows = true;
 	ix->nrows = nown;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->cap_rows = cap;
 	ix->pend_list.clear();
 	ix->pend_rows.clear();
@@ -3861,7 +3885,7 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 		ix->own_rows = true;
 		ix->cap_rows = cap;
 		ix->nrows = (int64_t) total;
-		ix->norm_valid = false;
+		ix->norm_valid = false; ix->s16_valid = false;
 		rc = ivf_set_layout(ix, newlen.data(), nullptr, (int64_t) total);
 	}
 	if (removed)
@@ -3938,6 +3962,223 @@ ivf_recipe(int strategy)
 	} while (0)
 
 /* defined with the build kernels below; the batch centroid scan of the search reuses them */
+#include "ndbhip_screen16.h"
+
+/* the fp16-MFMA screened scan in auto mode (ndbhip_set_option("screen16", 0) turns it off: the older fp32 bound
+ * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
+static int	g_s16_auto = 1;
+static uint32_t g_s16_ecap = 2048;
+
+static bool
+ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
+{
+	const size_t dimp = (size_t) ((ix->dim + 31) & ~31);
+
+	if (R != R_IVF_L2 && R != R_IVF_IP)
+		return false;
+	if (k > NDB_TOPK_FAST_MAXK || ix->nrows < 1)
+		return false;
+	if (ix->f16 && (ix->dim % 32) != 0)
+		return false;
+	if ((size_t) nq * dimp * 4 >= ((size_t) 1 << 32) || (size_t) S16_RT * dimp * 4 >= ((size_t) 1 << 31))
+		return false;
+	return true;
+}
+
+/* Runs the sweep + finalize for one sub-batch whose probes / candidate offsets are already on the device.
+ * Returns 0, a negative error, or 1 when some query overflowed (nothing usable was written: rerun on the older path). */
+static int
+ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, int npr, int k, const int *w_probes,
+			const uint32_t *lco, int partial, ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
+			uint64_t *d_otid, float *d_odist, int *d_ocnt)
+{
+	const int	dim = ix->dim, dimp = (dim + 31) & ~31;
+	const uint32_t rowbytes = ix->f16 ? (uint32_t) dim * 2u : (uint32_t) dimp * 4u;
+	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
+	const int	nc = ix->ncent;
+	const int	H = !ix->f16 ? 0 : (ix->f16_sub ? 1 : 2);
+	const uint32_t ecap = g_s16_ecap;
+
+	if (!ix->s16_valid)
+	{
+		if (grow(ix->d_rn2, ix->d_rn2_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+		if (!ix->d_xmax16)
+			HIP_TRY(hipMalloc((void **) &ix->d_xmax16, sizeof(uint32_t)));
+		HIP_TRY(hipMemsetAsync(ix->d_xmax16, 0, sizeof(uint32_t), g.stream));
+		const dim3	gp((unsigned) ((ix->nrows + 3) / 4));
+
+		if (!ix->f16)
+		{
+			if (grow(ix->d_rexp, ix->d_rexp_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+			if (grow(ix->d_planes, ix->d_planes_n, (size_t) ix->nrows * rowbytes)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_s16_row_prep<0>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp,
+							   (ndb_h2 *) ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16);
+		}
+		else if (ix->f16_sub)
+			hipLaunchKernelGGL(k_s16_row_prep<1>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp,
+							   (ndb_h2 *) nullptr, ix->d_rn2, (int16_t *) nullptr, ix->d_xmax16);
+		else
+			hipLaunchKernelGGL(k_s16_row_prep<2>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp,
+							   (ndb_h2 *) nullptr, ix->d_rn2, (int16_t *) nullptr, ix->d_xmax16);
+		HIP_TRY(hipGetLastError());
+		ix->s16_valid = true;
+	}
+	if (grow(ix->w_qplanes, ix->w_qplanes_n, (size_t) nq * qrowbytes)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_qn2, ix->w_qn2_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_qexp, ix->w_qexp_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_ecount, ix->w_ecount_n, (size_t) 3 * nq + 4)) return NDBHIP_ERR_HIP;	/* emitted | survivors | active | flags */
+	if (grow(ix->w_erec, ix->w_erec_n, (size_t) nq * ecap)) return NDBHIP_ERR_HIP;
+	unsigned int *ecount = ix->w_ecount, *surv = ix->w_ecount + nq, *flags = ix->w_ecount + 3 * (size_t) nq;
+
+	if (grow(ix->w_bmin, ix->w_bmin_n, (size_t) nq * S16_NB)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemsetAsync(ix->w_ecount, 0, ((size_t) 3 * nq + 4) * sizeof(unsigned int), g.stream));
+	HIP_TRY(hipMemsetAsync(ix->w_bmin, 0xFF, (size_t) nq * S16_NB * sizeof(uint32_t), g.stream));
+	hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, dim, dimp,
+					   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
+#define S16_BY_RH(KERNEL, ...)                                                                  \
+	do {                                                                                        \
+		if (R == R_IVF_IP)                                                                      \
+		{                                                                                       \
+			if (H == 0) KERNEL(R_IVF_IP, 0, __VA_ARGS__);                                        \
+			else if (H == 1) KERNEL(R_IVF_IP, 1, __VA_ARGS__);                                   \
+			else KERNEL(R_IVF_IP, 2, __VA_ARGS__);                                               \
+		}                                                                                       \
+		else                                                                                    \
+		{                                                                                       \
+			if (H == 0) KERNEL(R_IVF_L2, 0, __VA_ARGS__);                                        \
+			else if (H == 1) KERNEL(R_IVF_L2, 1, __VA_ARGS__);                                   \
+			else KERNEL(R_IVF_L2, 2, __VA_ARGS__);                                               \
+		}                                                                                       \
+	} while (0)
+#define S16_SEED_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
+	S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
+			  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr);
+
+	/* the (query, probe) pairs bucketed by list; items of 128 rows x 128 queries */
+	uint32_t   *cnt = ix->w_gcnt, *fill = ix->w_gcnt + nc;
+	unsigned int *next_item = ix->w_gcnt + 2 * nc;
+	uint32_t   *pair_off = ix->w_goff, *item_off = ix->w_goff + (nc + 1), *grp_off = ix->w_goff + 2 * (nc + 1);
+	uint32_t   *runs = ix->w_goff + 3 * (nc + 1) + 32;
+	const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
+	ScanTimer	t;
+
+#define S16_SWEEP_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<RR, HH>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__)
+	/*
+	 * Round 0 sweeps every (query, probe) pair against the seed threshold.  A query that emits more than its
+	 * record capacity (its nearest list is huge, or the data has no cluster structure) keeps the first `ecap`
+	 * records — any subset is valid evidence — and k_s16_retarget turns their k-th smallest into a far tighter
+	 * threshold (a sample of 2048 values below the seed threshold puts its 10th smallest ~200x deeper); round 1
+	 * sweeps those queries alone against it.  Whatever still overflows after that sends the batch to the older path.
+	 */
+	unsigned int *active = ix->w_ecount + 2 * (size_t) nq;
+
+	for (int round = 0; round < 2; round++)
+	{
+		const unsigned int *act = round ? active : (const unsigned int *) nullptr;
+
+		if (round)
+		{
+			if (R == R_IVF_IP)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_IP>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
+								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_L2>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
+								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1);
+		}
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
+		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
+						   (uint32_t) nq, cnt, act);
+		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, d.own_len, nc,
+						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (S16_RT / 64));
+		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
+						   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act);
+		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
+		S16_BY_RH(S16_SWEEP_L, d, ix->f16 ? (const unsigned char *) ix->d_vecs : (const unsigned char *) ix->d_planes, rowbytes,
+				  (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qplanes, qrowbytes,
+				  (const float *) ix->w_qn2, (const int *) ix->w_qexp, (const float2 *) ix->w_qthr, lco, npr,
+				  (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
+				  (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ecount, ix->w_erec, ecap,
+				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH);
+		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
+	}
+	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k) + (size_t) ecap * 8;
+
+#define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(256), fsmem, g.stream, __VA_ARGS__)
+	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
+			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
+			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags);
+	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
+					   g.d_counters + 3);
+	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
+					   g.d_counters + 4);
+	HIP_TRY(hipGetLastError());
+	unsigned int over = 0;
+
+	HIP_TRY(hipMemcpyAsync(&over, flags, sizeof(over), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (getenv("NDBHIP_DEBUG_S16"))
+	{
+		std::vector<unsigned int> h((size_t) 3 * nq + 4);
+		std::vector<float2> th((size_t) nq);
+
+		HIP_TRY(hipMemcpy(h.data(), ix->w_ecount, h.size() * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(th.data(), ix->w_qthr, th.size() * 8, hipMemcpyDeviceToHost));
+		unsigned int mx = 0, nact = 0, nover = 0, mxs = 0;
+		int			arg = -1;
+		for (int q = 0; q < nq; q++)
+		{
+			if (h[q] > mx) { mx = h[q]; arg = q; }
+			nact += h[2 * (size_t) nq + q];
+			nover += h[q] > ecap;
+			mxs = std::max(mxs, h[(size_t) nq + q]);
+		}
+		fprintf(stderr, "s16 debug: nq %d max ecount %u (q %d, thrE %g E %g active %u) active %u still-over %u max surv %u flags %u %u\n",
+				nq, mx, arg, arg >= 0 ? th[arg].x : 0.f, arg >= 0 ? th[arg].y : 0.f, arg >= 0 ? h[2 * (size_t) nq + arg] : 0u,
+				nact, nover, mxs, h[3 * (size_t) nq], h[3 * (size_t) nq + 1]);
+	}
+	if (over)
+	{
+		g.stats.screen16_fallbacks++;
+		return 1;
+	}
+	g.stats.screen16_batches++;
+	return 0;
+}
+
+extern "C" int
+ndbhip_mfma_probe(const uint16_t *d_a, const uint16_t *d_b, const float *d_c, float *d_d, int ntiles, int chain)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ntiles < 0 || chain < 0 || (ntiles > 0 && (!d_a || !d_b || !d_c || !d_d)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ntiles == 0)
+		return NDBHIP_OK;
+	hipLaunchKernelGGL(k_s16_mfma_probe, dim3(ntiles), dim3(64), 0, g.stream, d_a, d_b, d_c, d_d, chain);
+	HIP_TRY(hipGetLastError());
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_set_option(const char *name, int value)
+{
+	if (!name)
+		return fail(NDBHIP_ERR_INVALID, "name is NULL");
+	if (!strcmp(name, "screen16"))
+		g_s16_auto = value != 0;
+	else if (!strcmp(name, "screen16_records"))
+	{
+		if (value < 64 || value > 16384)
+			return fail(NDBHIP_ERR_INVALID, "screen16_records must be 64..16384");
+		g_s16_ecap = (uint32_t) value;
+	}
+	else if (!strcmp(name, "screen"))
+		g_screen_auto = value != 0;
+	else
+		return fail(NDBHIP_ERR_INVALID, "unknown option '%s'", name);
+	return NDBHIP_OK;
+}
+
 __global__ void k_interleave16(const float *__restrict__ cents, int ncent, int dim, float *__restrict__ cblock);
 template <bool SQRT, int CH>
 __global__ void k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim,
@@ -4016,6 +4257,18 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 	/* HOT LOOP 2 */
 	const int	R = ivf_recipe(strategy);
+
+	/* batches of >= 128 queries: the bound pass on fp16 matrix cores (ndbhip_screen16.h); mode 5 forces it */
+	if ((g_scan_mode == 5 || (g_scan_mode == 0 && g_screen_auto && g_s16_auto && nq >= NDB_SCREEN_MIN_NQ)) &&
+		ivf_s16_eligible(ix, nq, R, k))
+	{
+		const int	rc = ivf_s16_run(ix, d, d_q, nq, R, npr, k, w_probes, lco, partial, d_cand, d_ncand, d_total,
+									 d_otid, d_odist, d_ocnt);
+
+		if (rc <= 0)
+			return rc;
+		/* some query emitted more than its record capacity: the older path has none */
+	}
 	/* one slot per (probe, 64-candidate tile): slot = (local offset of the probe >> 6) + probe + tile */
 	const uint32_t tstride = (((stride >> 6) + (uint32_t) npr + 2u) + 63u) & ~63u;
 	const bool	grouped = (ix->dim % NDB_CHUNK) == 0 &&
@@ -5928,7 +6181,7 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	ix->d_tids = d_ptid;
 	ix->own_rows = true;
 	ix->nrows = nrows;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
 	if (out_iters)
@@ -6026,7 +6279,7 @@ ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const int64_t 
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = nrows;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->loaded = true;
 	ix->f16_sub = src->f16_sub;	/* a shard holds a subset of the source's rows */
 	*out = ix;
@@ -6122,7 +6375,7 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	ix->nrows = src->nrows;
-	ix->norm_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false;
 	ix->f16 = true;
 	ix->loaded = true;
 	*out = ix;

@@ -139,4 +139,84 @@ ndb_replay_selection_host(const uint32_t *key, uint32_t *pos, uint8_t *taken, in
 	return i;
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Error model of the screened scan's bound pass on fp16 matrix cores (k_scr16_sweep, ndbhip_screen16.h).
+ *
+ * The pass computes, for a query q and a row x (dim elements, any finite fp32 values), an approximation `dot`
+ * of the real dot product q.x and from it a = (Q2 + X2) - 2 dot ~ |q - x|^2.  Every constant below is the
+ * right-hand side of an inequality that is proved from the lines above it; u = 2^-24 throughout, S = |q||x|.
+ *
+ * (1) Norms.  Q2, X2 = the fp32 rounding of the sum of squares accumulated in fp64 (a square of an fp32 value is
+ *     exact in fp64; dim <= 32767 additions err by <= dim 2^-53 relative):  |Q2 - |q|^2| <= NDB_S16_NORM |q|^2.
+ * (2) Scaling.  e_q = the integer with 2^(e_q - 1) <= |q| < 2^e_q taken from the fp64 norm, v = q 2^(14 - e_q):
+ *     a power of two, exact; |v| in [2^13, 2^14), |v_i| < 2^14 (fits fp16: max 65504).  Same for x.  A zero
+ *     vector keeps e = 0.  fp16 rows (halfvec mirrors) are used as they are: e_x = 14.
+ * (3) Split.  h = fp16_rne(v_i), l = fp16_rne(v_i - h) (the subtraction is exact in fp32).  fp16 has an 11-bit
+ *     significand and subnormals with spacing 2^-24, so |v_i - h - l| <= max(2^-22 |v_i|, 2^-25) and
+ *     |l| <= 2^-11 |v_i| + 2^-25.  The pass multiplies h_q h_x + h_q l_x + l_q h_x and drops l_q l_x:
+ *       |v_q.v_x - sum(...)| <= sum_i ( |l_q l_x| + |dv_q| |v_x| + |v_q| |dv_x| )_i
+ *                            <= (2^-22 + 2^-22 + 2^-22 + 3 sqrt(dim) 2^-38) |v_q||v_x|   (Cauchy-Schwarz; |v| >= 2^13)
+ *                            <= NDB_S16_SPLIT |v_q||v_x|                                  (dim <= 32767: sqrt < 2^7.5)
+ *     The matrix cores take fp16 subnormal inputs at face value (tools/mfma_probe.hip T7/T7b, and
+ *     tests/test_gpu_mfma_model.py); a part that flushed them would add 2^-14 sqrt(dim) / 2^13 <= 2^-19.5, which
+ *     NDB_S16_SPLIT = 2^-19 also covers.
+ * (4) Matrix-core accumulation.  The ISA text gives no rounding rule for v_mfma_f32_32x32x16_f16.  MODEL
+ *     (checked on the device by the test above, which fails the suite on any part that breaks it):
+ *       | D - (C + sum_{k<16} a_k b_k) | <= NDB_MFMA_THETA ( |C| + sum_k |a_k b_k| ),  NDB_MFMA_THETA = 34 u
+ *     i.e. 17 addends, each allowed a relative error of 2^-23 — it holds for a chain of fp32 additions in any
+ *     order or tree with round-to-nearest or truncation, and for an adder that aligns the 17 addends to the
+ *     largest exponent and keeps >= 24 bits.  Measured worst case on gfx950 over directed and adversarial
+ *     inputs: 5.3 u (profiles/r02_mfma_probe.txt: two groups of 8 products, each aligned to its largest exponent
+ *     with two guard bits and truncated, then one rounding to nearest).
+ *     The pass starts a fresh accumulator (C = 0) every NDB_S16_FLUSH_DIMS = 64 dimensions, i.e. a chain of
+ *     12 instructions (4 k-steps x 3 products) whose products' absolute values sum to at most
+ *     (1 + 2^-10) S_blk, and adds it to the running sum with one fp32 addition (error <= u |partial sum|):
+ *       |dot_scaled - sum| <= (12 * 1.01 * NDB_MFMA_THETA + nblk u) |v_q||v_x|,   nblk = ceil(dim / 64)
+ *     (chain of n instructions: C_j <= sum so far (1 + n theta), folded into the 1.01).
+ * (5) Unscaling is a power of two (ldexp): exact unless the result leaves the normal range (then the bound pass
+ *     sees inf / NaN / a flushed value: inf and NaN are emitted as "cannot be excluded", a flushed value errs by
+ *     <= 2^-126, inside NDB_S16_ABS).
+ *     Together:  |dot - q.x| <= c_dot(dim) S,  c_dot = NDB_S16_SPLIT + (12.12 * 34 + nblk) u.
+ * (6) a = fma(-2, dot, fl(Q2 + X2)): two roundings of values <= 2 (|q|^2 + |x|^2).  With (1):
+ *       |a - |q - x|^2| <= (2 NDB_S16_NORM + 5 u)(|q|^2 + |x|^2)/1 ... + 2 c_dot S
+ *                       <= (c_dot + NDB_S16_NORMS)(|q|^2 + |x|^2)          since 2 S <= |q|^2 + |x|^2
+ *     E_q = ndb_s16_e_l2(dim, Q2, X2max) evaluates that with X2max = the largest finite row norm of the mirror,
+ *     rounded up, plus NDB_S16_ABS.
+ * (7) The reference's float4 distance d = sqrtf(T), T = the sequential fp32 sum of fl(fl(q_i - x_i)^2)
+ *     (ivf_am.c:1562-1568): (1 - u)^(dim + 2) D <= T <= (1 + u)^(dim + 2) D (non-negative terms), and sqrtf is
+ *     correctly rounded.  m = NDB_S16_REFSLACK(dim) = 2 (dim + 16) u exceeds gamma_(dim+2) + 2u, so
+ *       a > thr^2 (1 + m) + E   ==>   D > thr^2 (1 + m)   ==>   d > thr      ("cannot be among the k nearest"),
+ *       D_k <= a_(k) + E        ==>   d_k^2 <= (a_(k) + E)(1 + m)            (k-th smallest of each side).
+ *     Inner product: the reference's -sum fl(q_i x_i) is within gamma_dim S of -q.x, so E_ip = (c_dot + gamma_dim) S.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define NDB_S16_U 5.9604645e-8f				/* 2^-24 */
+#define NDB_MFMA_THETA (34.0f * NDB_S16_U)		/* (4) */
+#define NDB_S16_SPLIT 1.9073486e-6f			/* 2^-19, (3) */
+#define NDB_S16_NORM 1.1920929e-7f			/* 2^-23 >= u (1 + dim 2^-29), (1) */
+#define NDB_S16_NORMS (2.0f * NDB_S16_NORM + 6.0f * NDB_S16_U)	/* (6) */
+#define NDB_S16_ABS 1e-30f
+#define NDB_S16_FLUSH_DIMS 64
+
+NDB_HD static inline float
+ndb_s16_cdot(int dim)
+{
+	const float nblk = (float) ((dim + NDB_S16_FLUSH_DIMS - 1) / NDB_S16_FLUSH_DIMS);
+
+	return (NDB_S16_SPLIT + (12.12f * 34.0f + nblk) * NDB_S16_U) * 1.0001f;
+}
+NDB_HD static inline float
+ndb_s16_refslack(int dim)
+{
+	return 2.0f * (float) (dim + 16) * NDB_S16_U;
+}
+/* gamma_n = n u / (1 - n u), rounded up */
+NDB_HD static inline float
+ndb_s16_gamma(int n)
+{
+	const float nu = (float) n * NDB_S16_U;
+
+	return nu / (1.0f - nu) * 1.0001f;
+}
+
 #endif							/* NDBHIP_COMMON_H */

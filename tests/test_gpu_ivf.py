@@ -331,11 +331,11 @@ def test_grouped_scan_is_bit_identical_to_per_query_scan_and_oracle(dim, n, nlis
     for strategy in (1, 3, 2):                  # cosine falls back to the per-query kernel
         for nprobe, k, cap in ((8, 10, 0), (3, 7, 0), (10, 10, 100)):
             res = {}
-            for mode in (1, 2, 3):
+            for mode in (1, 2, 3, 5):
                 scan_mode(mode)
                 res[mode] = ix.search(q, strategy, nprobe, k, cap)
             et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
-            for mode in (1, 2, 3):
+            for mode in (1, 2, 3, 5):
                 assert_same_results(*res[mode], et, ed, ec)
 
 
@@ -350,7 +350,7 @@ def test_grouped_scan_sharded(scan_mode):
     full = _index(a)
     dq = torch.from_numpy(q).cuda()
     et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 5):
         scan_mode(mode)
         bufs = [ShardedSearchBuffers(len(q), k, world, "cuda") for _ in range(world)]
         for w in range(world):
@@ -459,7 +459,7 @@ def test_fp16_rows_are_bit_identical_to_expanded_float4_rows(dim, n, nlists, sca
     ix.load_f16(a["list_len"], h, a["tids"])
     q = _queries(a, 100, seed=dim)
     q[0] = rows32[3]
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 5):
         scan_mode(mode)
         for strategy in (3, 1, 2):                    # config 5 is inner product
             t, d, c = ix.search(q, strategy, 5, 10)
@@ -497,7 +497,7 @@ def test_to_f16_twin_and_its_shards(reference_encoder, scan_mode):
     q = _queries(a, 40, seed=78)
     for strategy in (3, 1, 2):
         et, ed, ec, _ = oracle_search_batch(img, q, strategy, 6, 10)
-        for mode in (0, 3):                            # 3: screened — the twin without subnormals decodes with the plain conversion
+        for mode in (0, 3, 5):                          # 3: screened — the twin without subnormals decodes with the plain conversion
             scan_mode(mode)
             t, d, c = twin.search(q, strategy, 6, 10)
             assert_same_results(t, d, c, et, ed, ec)
@@ -556,7 +556,7 @@ def test_bulkdelete_drops_rows_and_keeps_list_order(scan_mode):
     assert np.array_equal(ll, new_len) and np.array_equal(rows, b["rows"]) and np.array_equal(tids, b["tids"])
     img = oracle_image(b)
     q = _queries(a, 40, seed=93)
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 5):
         scan_mode(mode)
         for strategy in (1, 2, 3):
             t, d, c = ix.search(q, strategy, 6, 10)
@@ -631,7 +631,7 @@ def test_slice_shards_merge_to_the_unsharded_result(world, split_frac, align, sc
         dq = torch.from_numpy(q).cuda()
         for strategy in (1, 2, 3):
             for cap in (0, 700):
-                for mode in (1, 2, 3):
+                for mode in (1, 2, 3, 5):
                     scan_mode(mode)
                     t, d, c = _merged_partial(shards, dq, strategy, nprobe, k, cap)
                     et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
@@ -742,7 +742,7 @@ def test_screened_scan_is_exact_where_its_bound_is_weakest(case, scan_mode):
             if strategy != 1 and case == "tiny":
                 continue                                          # products of 1e-18 values underflow to NaN-free zeros: L2 only
             et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
-            for mode in (3, 2):
+            for mode in (3, 2, 5):
                 scan_mode(mode)
                 t, d, c = ix.search(q, strategy, nprobe, k, cap)
                 assert_same_results(t, d, c, et, ed, ec)

@@ -1,0 +1,176 @@
+"""The screened scan on fp16 matrix cores (csrc/ndbhip_screen16.h; scan mode 5, and auto mode from 128 queries):
+results must be the oracle's bit for bit — ivfCollectCandidates, /root/reference/NeuronDB/src/index/ivf_am.c:1722-1909 —
+and the statistics must show that this path (not a fallback) produced them."""
+import numpy as np
+import pytest
+
+from tests.util import assert_same_results, make_ivf_arrays, oracle_image, oracle_search_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(a, nlists=None):
+    from neurondb_amd import IvfIndex
+    ix = IvfIndex(a["centroids"].shape[1], nlists if nlists is not None else len(a["list_len"]))
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    return ix
+
+
+@pytest.fixture
+def lib():
+    from neurondb_amd import _lib
+    _lib.ensure_init()
+    yield _lib
+    _lib.check(_lib.lib().ndbhip_set_scan_mode(0))
+    _lib.check(_lib.lib().ndbhip_set_option(b"screen16", 1))
+    _lib.check(_lib.lib().ndbhip_set_option(b"screen16_records", 2048))
+
+
+@pytest.mark.parametrize("dim,n,nlists,nq", [(768, 6000, 24, 200), (100, 5000, 16, 150), (33, 4000, 9, 130),
+                                               (128, 20000, 40, 300), (1536, 2500, 6, 128)])
+def test_screen16_matches_oracle_and_really_runs(dim, n, nlists, nq, lib):
+    """Any dim (the planes are padded to 32), ragged lists and query tiles, k up to 64, candidate cap, L2 and
+    inner product; auto mode picks this path from 128 queries."""
+    a = make_ivf_arrays(n, dim, nlists, seed=dim + 11, dup_frac=0.05, zero_rows=2, empty_lists=(1,))
+    ix = _index(a)
+    img = oracle_image(a)
+    rng = np.random.default_rng(dim)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[: nq // 4] = a["base"][rng.integers(0, n, nq // 4)]                  # exact hits
+    q[nq // 4: nq // 2] = (a["base"][rng.integers(0, n, nq // 2 - nq // 4)] +
+                           0.01 * rng.standard_normal((nq // 2 - nq // 4, dim))).astype(np.float32)
+    q[-1] = 0.0
+    for mode in (5, 0):
+        lib.check(lib.lib().ndbhip_set_scan_mode(mode))
+        for strategy in (1, 3):
+            for nprobe, k, cap in ((8, 10, 0), (nlists, 64, 0), (3, 1, 0), (6, 10, 100)):
+                lib.check(lib.lib().ndbhip_stats_reset())
+                t, d, c = ix.search(q, strategy, nprobe, k, cap)
+                st = lib.stats()
+                et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
+                assert_same_results(t, d, c, et, ed, ec)
+                assert st["screen16_batches"] + st["screen16_fallbacks"] == 1, st
+                assert st["rows_emitted"] >= st["rows_rescored"] > 0 or st["screen16_fallbacks"] == 1, st
+    ix.close()
+
+
+def test_screen16_keeps_most_candidates_out_of_the_second_pass(lib):
+    """On clustered data (the bench's kind) the bound pass must exclude nearly everything: a handful of
+    survivors per query, no fallback — otherwise the path is correct but pointless."""
+    rng = np.random.default_rng(5)
+    dim, n, nlists, nq = 256, 40000, 64, 512
+    cen = rng.standard_normal((nlists, dim)).astype(np.float32)
+    lab = rng.integers(0, nlists, n)
+    base = (cen[lab] + 0.1 * rng.standard_normal((n, dim))).astype(np.float32)
+    order = np.argsort(lab, kind="stable")
+    from oracle import ndbo
+    a = dict(centroids=cen, list_len=np.bincount(lab, minlength=nlists).astype(np.int64),
+             rows=np.ascontiguousarray(base[order]), tids=ndbo.tids_from_rows(order))
+    ix = _index(a)
+    img = oracle_image(a)
+    q = (cen[rng.integers(0, nlists, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    lib.check(lib.lib().ndbhip_stats_reset())
+    t, d, c = ix.search(q, 1, 8, 10)
+    st = lib.stats()
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, 8, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+    assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
+    per_query = st["rows_rescored"] / nq
+    assert 10 <= per_query < 80, per_query             # of ~5000 candidates per query
+    ix.close()
+
+
+def test_a_nan_row_only_affects_the_queries_that_probe_it(lib):
+    """a single NaN row used to poison the bound of EVERY query of a screened batch (its norm won the
+    row-norm maximum).  Now a row with a non-finite norm is excluded from the maximum and always handed to the
+    reference's arithmetic; queries that do not probe its list must equal the oracle, in every scan mode."""
+    a = make_ivf_arrays(6000, 64, 12, seed=77)
+    img_clean = oracle_image(a)
+    rng = np.random.default_rng(78)
+    nq = 160
+    q = (a["base"][rng.integers(0, 6000, nq)] + 0.01 * rng.standard_normal((nq, 64))).astype(np.float32)
+    nprobe, k = 3, 10
+    # the list the FEWEST queries probe gets the NaN row; only queries that do not probe it are compared
+    probes = np.stack([img_clean.select_clusters(qq, nprobe) for qq in q])
+    counts = np.bincount(probes.ravel(), minlength=12)
+    victim = int(np.argmin(np.where(a["list_len"] > 0, counts, 10 ** 9)))
+    off = np.concatenate([[0], np.cumsum(a["list_len"])])
+    rows = a["rows"].copy()
+    rows[off[victim] + 1, 5] = np.nan
+    rows[off[victim] + 2, 7] = np.inf
+    b = dict(a, rows=rows)
+    ix = _index(b)
+    clean = ~(probes == victim).any(1)
+    assert clean.sum() >= 100
+    et, ed, ec, _ = oracle_search_batch(img_clean, q[clean], 1, nprobe, k)
+    for mode in (5, 3, 2, 1, 0):
+        lib.check(lib.lib().ndbhip_set_scan_mode(mode))
+        t, d, c = ix.search(q, 1, nprobe, k)
+        assert_same_results(t[clean], d[clean], c[clean], et, ed, ec)
+    ix.close()
+
+
+def test_overflowing_queries_fall_back_and_stay_exact(lib):
+    """Rows 300 from the origin and 0.01 apart: |q|^2 + |x|^2 - 2 q.x cancels almost completely, nothing can be
+    excluded, every query overflows its records -> the batch is rerun on the fp32 screen; still the oracle's bits."""
+    rng = np.random.default_rng(3)
+    dim, n, nlists, nq = 64, 6000, 10, 140
+    center = rng.standard_normal(dim).astype(np.float32) * 300.0
+    base = (center + rng.standard_normal((n, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    q = (center + rng.standard_normal((nq, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    cent = base[rng.choice(n, nlists, replace=False)].copy()
+    asg = ((base[:, None, :].astype(np.float64) - cent[None]) ** 2).sum(-1).argmin(1)
+    order = np.argsort(asg, kind="stable")
+    from oracle import ndbo
+    a = dict(centroids=cent, list_len=np.bincount(asg, minlength=nlists).astype(np.int64),
+             rows=np.ascontiguousarray(base[order]), tids=ndbo.tids_from_rows(order))
+    ix = _index(a)
+    img = oracle_image(a)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    lib.check(lib.lib().ndbhip_set_option(b"screen16_records", 256))
+    lib.check(lib.lib().ndbhip_stats_reset())
+    t, d, c = ix.search(q, 1, nlists, 10)
+    st = lib.stats()
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, nlists, 10)
+    assert_same_results(t, d, c, et, ed, ec)
+    assert st["screen16_fallbacks"] == 1 and st["screen16_batches"] == 0, st
+    ix.close()
+
+
+def test_screen16_on_a_sharded_mirror_merges_to_the_unsharded_result(lib):
+    import torch
+    from neurondb_amd.dist import ShardedSearchBuffers
+    a = make_ivf_arrays(9000, 96, 16, seed=41, dup_frac=0.1)
+    img = oracle_image(a)
+    rng = np.random.default_rng(42)
+    nq, k, nprobe, world = 192, 10, 6, 4
+    q = (a["base"][rng.integers(0, 9000, nq)] + 0.05 * rng.standard_normal((nq, 96))).astype(np.float32)
+    full = _index(a)
+    dq = torch.from_numpy(q).cuda()
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    bufs = [ShardedSearchBuffers(nq, k, world, "cuda") for _ in range(world)]
+    lib.check(lib.lib().ndbhip_stats_reset())
+    for w in range(world):
+        owned = (np.arange(16) % world == w).astype(np.uint8)
+        sh = full.shard(owned)
+        sh.search_partial_device(dq, bufs[w].cand, bufs[w].ncand, bufs[w].total, 1, nprobe, k)
+        lib.check(lib.lib().ndbhip_synchronize())
+        bufs[0].cand_all[w].copy_(bufs[w].cand)
+        bufs[0].ncand_all[w].copy_(bufs[w].ncand)
+        sh.close()
+    assert lib.stats()["screen16_batches"] == world
+    b = bufs[0]
+    ot = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    oc = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    lib.check(lib.lib().ndbhip_merge_topk_device(b.cand_all.data_ptr(), b.ncand_all.data_ptr(), bufs[0].total.data_ptr(),
+                                                 world, nq, k, 3 * k, ot.data_ptr(), od.data_ptr(), oc.data_ptr()))
+    lib.check(lib.lib().ndbhip_synchronize())
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+    from oracle import ndbo
+    assert np.array_equal(oc.cpu().numpy(), ec)
+    assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
+    assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+    full.close()

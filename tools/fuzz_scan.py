@@ -104,7 +104,7 @@ def one_case(rng, lib, IvfIndex, check):
     cap = int(rng.choice([0, 0, k * 10, 500]))
     strategy = int(rng.choice([1, 1, 1, 2, 3]))
     et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
-    for mode in (3, 2, 1, 0):
+    for mode in (5, 3, 2, 1, 0):
         check(lib.ndbhip_set_scan_mode(mode))
         t, d, c = ix.search(q, strategy, nprobe, k, cap)
         try:
