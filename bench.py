@@ -63,6 +63,8 @@ def parse():
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
     ap.add_argument("--dist-parity-queries", type=int, default=128,
                     help="N>1: merged results of this many queries are checked against the CPU oracle on rank 0")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="ndbhip_set_option(NAME, VALUE) before the run (A/B of library switches), repeatable")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded path (process group, partial search, all-gather, merge) even at N=1")
     return ap.parse_args()
@@ -131,6 +133,9 @@ def main():
     # one stream for torch (data, RCCL collectives) and the library's kernels: the device-pointer calls are
     # asynchronous, and their inputs / outputs are produced / consumed by torch
     stream = _lib.use_torch_stream()
+    for o in args.opt:
+        name, value = o.split("=")
+        check(lib().ndbhip_set_option(name.encode(), int(value)))
 
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
 

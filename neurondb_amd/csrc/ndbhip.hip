@@ -3185,6 +3185,7 @@ struct ndbhip_ivf
 	float	   *d_rn2 = nullptr;	size_t d_rn2_n = 0;
 	int16_t    *d_rexp = nullptr;	size_t d_rexp_n = 0;
 	uint32_t   *d_xmax16 = nullptr;
+	uint32_t   *d_blkoff = nullptr;	size_t d_blkoff_n = 0;	/* [ncent + 1] first 32-row block of every list in d_planes */
 	bool		s16_valid = false;
 	unsigned char *w_qplanes = nullptr; size_t w_qplanes_n = 0;
 	float	   *w_qn2 = nullptr;	size_t w_qn2_n = 0;
@@ -3192,6 +3193,7 @@ struct ndbhip_ivf
 	float2	   *w_qthr = nullptr;	size_t w_qthr_n = 0;
 	unsigned int *w_ecount = nullptr; size_t w_ecount_n = 0;	/* [nq] emitted per query | [nq] survivors | [nq] seeds | 4 flags */
 	uint2	   *w_erec = nullptr;	size_t w_erec_n = 0;
+	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
 	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
 	/* split top-k of small batches: per-range records, counts, totals */
 	ndbhip_cand *w_scand = nullptr;	size_t w_scand_n = 0;
@@ -3264,7 +3266,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock,
 			ix->d_xxmax, ix->w_rnorm, ix->w_scrt, ix->w_scrd, ix->w_scrc, ix->w_screc,
 			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
-			ix->w_ecount, ix->w_erec, ix->w_bmin};
+			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3967,20 +3969,22 @@ ivf_recipe(int strategy)
 /* the fp16-MFMA screened scan in auto mode (ndbhip_set_option("screen16", 0) turns it off: the older fp32 bound
  * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
 static int	g_s16_auto = 1;
+static int	g_s16_waves = 4;
+static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
 static uint32_t g_s16_ecap = 2048;
 
 static bool
 ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 {
-	const size_t dimp = (size_t) ((ix->dim + 31) & ~31);
+	const size_t dimp = (size_t) ((ix->dim + 63) & ~63);
 
 	if (R != R_IVF_L2 && R != R_IVF_IP)
 		return false;
 	if (k > NDB_TOPK_FAST_MAXK || ix->nrows < 1)
 		return false;
-	if (ix->f16 && (ix->dim % 32) != 0)
+	if (ix->f16 && (ix->dim % 64) != 0)
 		return false;
-	if ((size_t) nq * dimp * 4 >= ((size_t) 1 << 32) || (size_t) S16_RT * dimp * 4 >= ((size_t) 1 << 31))
+	if ((size_t) nq * dimp * 4 >= ((size_t) 1 << 32) || (size_t) 256 * dimp * 4 >= ((size_t) 1 << 31))
 		return false;
 	return true;
 }
@@ -3992,8 +3996,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			const uint32_t *lco, int partial, ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
 			uint64_t *d_otid, float *d_odist, int *d_ocnt)
 {
-	const int	dim = ix->dim, dimp = (dim + 31) & ~31;
-	const uint32_t rowbytes = ix->f16 ? (uint32_t) dim * 2u : (uint32_t) dimp * 4u;
+	const int	dim = ix->dim, dimp = (dim + 63) & ~63;	/* two chunks per accumulator block */
 	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
 	const int	nc = ix->ncent;
 	const int	H = !ix->f16 ? 0 : (ix->f16_sub ? 1 : 2);
@@ -4001,25 +4004,42 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	if (!ix->s16_valid)
 	{
+		/* every list starts a new 32-row block of the blocked planes */
+		std::vector<uint32_t> bo((size_t) nc + 1);
+		uint64_t	nb = 0;
+
+		for (int c = 0; c < nc; c++)
+		{
+			bo[c] = (uint32_t) nb;
+			nb += (uint64_t) ((ix->own_len[c] + 31) / 32);
+		}
+		bo[nc] = (uint32_t) nb;
+		if (nb + 8 > 0xFFFFFFFFull)
+			return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 row blocks");
+		const size_t blk_bytes = (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
+
+		if (grow(ix->d_blkoff, ix->d_blkoff_n, (size_t) nc + 1)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemcpyAsync(ix->d_blkoff, bo.data(), ((size_t) nc + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));		/* bo is a local */
 		if (grow(ix->d_rn2, ix->d_rn2_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_rexp, ix->d_rexp_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_planes, ix->d_planes_n, (size_t) (nb + 8) * blk_bytes)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(ix->d_planes, 0, (size_t) (nb + 8) * blk_bytes, g.stream));
 		if (!ix->d_xmax16)
 			HIP_TRY(hipMalloc((void **) &ix->d_xmax16, sizeof(uint32_t)));
 		HIP_TRY(hipMemsetAsync(ix->d_xmax16, 0, sizeof(uint32_t), g.stream));
 		const dim3	gp((unsigned) ((ix->nrows + 3) / 4));
 
+#define S16_PREP_L(HH)                                                                                          \
+		hipLaunchKernelGGL(k_s16_row_prep<HH>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp, \
+						   (const int64_t *) ix->d_loc_off, (const uint32_t *) ix->d_blkoff, nc, ix->d_planes, ix->d_rn2, \
+						   ix->d_rexp, ix->d_xmax16)
 		if (!ix->f16)
-		{
-			if (grow(ix->d_rexp, ix->d_rexp_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
-			if (grow(ix->d_planes, ix->d_planes_n, (size_t) ix->nrows * rowbytes)) return NDBHIP_ERR_HIP;
-			hipLaunchKernelGGL(k_s16_row_prep<0>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp,
-							   (ndb_h2 *) ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16);
-		}
+			S16_PREP_L(0);
 		else if (ix->f16_sub)
-			hipLaunchKernelGGL(k_s16_row_prep<1>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp,
-							   (ndb_h2 *) nullptr, ix->d_rn2, (int16_t *) nullptr, ix->d_xmax16);
+			S16_PREP_L(1);
 		else
-			hipLaunchKernelGGL(k_s16_row_prep<2>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp,
-							   (ndb_h2 *) nullptr, ix->d_rn2, (int16_t *) nullptr, ix->d_xmax16);
+			S16_PREP_L(2);
 		HIP_TRY(hipGetLastError());
 		ix->s16_valid = true;
 	}
@@ -4063,7 +4083,20 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
 	ScanTimer	t;
 
-#define S16_SWEEP_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<RR, HH>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__)
+	/* tile geometry: 8 waves, 256 rows x 128 queries, ring of 3 chunk buffers, one block per CU (default), or
+	 * 4 waves, 128 x 128, ring of 2, two blocks per CU (ndbhip_set_option("screen16_waves", 4)) */
+	const int	s16_rt = g_s16_waves == 8 ? 256 : 128;
+#define S16_SWEEP_L(RR, HH, ...)                                                                                  \
+	do {                                                                                                          \
+		if (g_s16_debug == 1 && HH == 0 && RR == R_IVF_L2)                                                         \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 1>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
+		else if (g_s16_debug == 2 && HH == 0 && RR == R_IVF_L2)                                                    \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
+		else if (g_s16_waves == 8)                                                                                \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<RR, HH, 8, 3>), dim3(g.num_cus), dim3(512), 0, g.stream, __VA_ARGS__); \
+		else                                                                                                      \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<RR, HH, 4, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
+	} while (0)
 	/*
 	 * Round 0 sweeps every (query, probe) pair against the seed threshold.  A query that emits more than its
 	 * record capacity (its nearest list is huge, or the data has no cluster structure) keeps the first `ecap`
@@ -4076,6 +4109,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	for (int round = 0; round < 2; round++)
 	{
 		const unsigned int *act = round ? active : (const unsigned int *) nullptr;
+		uint32_t	desc_cap = 0;
 
 		if (round)
 		{
@@ -4090,19 +4124,33 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 						   (uint32_t) nq, cnt, act);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, d.own_len, nc,
-						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (S16_RT / 64));
+						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (s16_rt / 64));
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 						   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act);
+		{
+			/* items <= (row tiles) x (query tiles of the fullest list); a query probes a list once — except list 0,
+			 * which the reference scans again for every probe slot beyond nlists (ivf_am.c:1978, palloc0) */
+			const int	ncmp = std::min(ix->nlists, ix->ncent);
+			const size_t dup = npr > ncmp ? (size_t) (npr - ncmp + 1) : 1;
+			const size_t cap_items = ((size_t) ix->nrows / (size_t) s16_rt + (size_t) nc) *
+				(((size_t) nq * dup + S16_QT - 1) / S16_QT);
+
+			if (grow(ix->w_s16desc, ix->w_s16desc_n, cap_items * 4)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_s16_items, dim3((unsigned) ((cap_items + 255) / 256)), dim3(256), 0, g.stream,
+							   (const uint32_t *) item_off, (const uint32_t *) cnt, d.own_len, nc, (uint32_t) s16_rt,
+							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags);
+			desc_cap = (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu);
+		}
 		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
-		S16_BY_RH(S16_SWEEP_L, d, ix->f16 ? (const unsigned char *) ix->d_vecs : (const unsigned char *) ix->d_planes, rowbytes,
+		S16_BY_RH(S16_SWEEP_L, d, (const unsigned char *) ix->d_planes, (const uint32_t *) ix->d_blkoff,
 				  (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qplanes, qrowbytes,
 				  (const float *) ix->w_qn2, (const int *) ix->w_qexp, (const float2 *) ix->w_qthr, lco, npr,
-				  (const uint32_t *) cnt, (const uint32_t *) pair_off, (const uint32_t *) item_off,
+				  (const uint32_t *) cnt, (const uint32_t *) pair_off, (const S16Desc *) ix->w_s16desc,
 				  (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ecount, ix->w_erec, ecap,
-				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH);
+				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
 	}
-	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k) + (size_t) ecap * 8;
+	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
 
 #define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(256), fsmem, g.stream, __VA_ARGS__)
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
@@ -4172,6 +4220,14 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16_records must be 64..16384");
 		g_s16_ecap = (uint32_t) value;
 	}
+	else if (!strcmp(name, "screen16_waves"))
+	{
+		if (value != 4 && value != 8)
+			return fail(NDBHIP_ERR_INVALID, "screen16_waves must be 4 or 8");
+		g_s16_waves = value;
+	}
+	else if (!strcmp(name, "screen16_debug"))
+		g_s16_debug = value;
 	else if (!strcmp(name, "screen"))
 		g_screen_auto = value != 0;
 	else

@@ -31,10 +31,9 @@ typedef _Float16 ndb_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ndb_h2 __attribute__((ext_vector_type(2)));
 
 #define S16_QT 128				/* queries per tile */
-#define S16_RT 128				/* rows per tile */
 #define S16_CH 32				/* dimensions per staged chunk (two MFMA k-steps) */
 #define S16_SEED 64				/* candidates scored exactly per query for the first threshold */
-#define S16_SURV_CAP 1024		/* survivors per query the finalize stage holds (= NDB_TOPK_FAST_CAP) */
+#define S16_SURV_CAP 256		/* survivors per query the finalize stage holds in LDS (typically 10-30; more: fall back) */
 #define S16_NB_LOG2 7
 #define S16_NB (1 << S16_NB_LOG2)	/* hash buckets of candidate positions per query (>= 2 x the largest k) */
 
@@ -84,16 +83,26 @@ s16_split(float x, int e, _Float16 &hi, _Float16 &lo)
 }
 
 /*
- * One wave per row.  planes: [row][chunk of 32 dims][hi 32 halves | lo 32 halves], dimp = dim rounded up to 32
- * (the tail is zero).  rn2[row] = |x|^2, NaN for a row whose norm is not a finite fp32 (the sweep emits every
- * candidate of such a row, so it only affects itself: the reference's arithmetic decides).  rexp[row] = e.
- * xmax_bits: largest finite rn2 (bits order like values for non-negative floats).
- * H16 rows (halfvec mirror): decoded like fp16_to_float (SUBFIX: quirk Q20), norm only — the mirror itself is
- * the hi plane, there is no lo plane and e = 14.
+ * One wave per row.  The planes are stored the way the sweep wants them in LDS, so that a 32-row block's share
+ * of a chunk is ONE contiguous piece the DMA copies verbatim (no per-lane gather, full DRAM pages instead of
+ * 128 bytes out of every 3 KB row):
+ *
+ *   planes[(blk * nchunk + c) * ROW_BLK + image of the block's 32 rows for chunk c]
+ *
+ * blk = blk_off[list] + (position in the list) / 32 (every list starts a new block; the tail of a list's last
+ * block stays zero), nchunk = dimp / 32 with dimp = dim rounded up to 64 (the tail dimensions are zero).  Image,
+ * float4 rows: [r][8 slots of 16 bytes] = 4096 bytes, logical slot s = 2 * kstep + khalf for the hi plane,
+ * 4 + 2 * kstep + khalf for the lo plane, stored at slot s ^ ((r >> 1) & 7).  H16 rows (halfvec mirror): the
+ * mirror's own fp16 values are the hi plane and there is no lo plane: [r][4 slots] = 2048 bytes, slot
+ * s ^ ((r >> 2) & 3); decoded like fp16_to_float for the norm (SUBFIX: quirk Q20), scale exponent 14.
+ * rn2[row] = |x|^2, NaN for a row whose norm is not a finite fp32 (the sweep emits every candidate of such a
+ * row, so it only affects itself: the reference's arithmetic decides).  rexp[row] = e.  xmax_bits: largest
+ * finite rn2 (bits order like values for non-negative floats).
  */
 template <int H16>
 __global__ __launch_bounds__(256) void
-k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, ndb_h2 *__restrict__ planes,
+k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, const int64_t *__restrict__ loc_off,
+			   const uint32_t *__restrict__ blk_off, int ncent, unsigned char *__restrict__ planes,
 			   float *__restrict__ rn2, int16_t *__restrict__ rexp, uint32_t *__restrict__ xmax_bits)
 {
 	const int	lane = threadIdx.x & 63;
@@ -134,15 +143,44 @@ k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, 
 		if (ok)
 			atomicMax(xmax_bits, __float_as_uint(n2));
 	}
-	if constexpr (H16 == 0)
-	{
-		const float *x = (const float *) vecs + (size_t) row * dim;
-		ndb_h2	   *out = planes + (size_t) row * dimp;	/* dimp * 4 bytes per row = dimp h2 */
+	/* the row's list (largest L with loc_off[L] <= row) and its place in the blocked planes */
+	int			lo = 0, hi = ncent;
 
-		/* lane handles the element pairs (2p, 2p+1): hi pair p of the chunk, lo pair 16 + p */
-		for (int p = lane; p < dimp / 2; p += 64)
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (loc_off[mid] <= row)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < ncent && loc_off[lo + 1] <= row)
+		lo++;
+	const uint32_t pos = (uint32_t) (row - loc_off[lo]);
+	const size_t blk = (size_t) blk_off[lo] + (pos >> 5);
+	const int	rr = (int) (pos & 31u);
+	const int	nchunk = dimp / 32;
+	constexpr int ROW_BLK = H16 ? 2048 : 4096;
+	constexpr int ROW_CHUNK = H16 ? 64 : 128;
+	unsigned char *img = planes + blk * (size_t) nchunk * ROW_BLK + (size_t) rr * ROW_CHUNK;
+
+	/* lane handles the element pairs (2p, 2p + 1): pair j = p % 16 of chunk c = p / 16 lives in logical slot j / 4 */
+	for (int p = lane; p < dimp / 2; p += 64)
+	{
+		const int	i = 2 * p, c = p >> 4, j = p & 15;
+		unsigned char *rowimg = img + (size_t) c * ROW_BLK;
+
+		if constexpr (H16 != 0)
 		{
-			const int	i = 2 * p, c = i >> 5, j = (i & 31) >> 1;
+			const uint16_t *x = (const uint16_t *) vecs + (size_t) row * dim;
+			const uint32_t v = (i < dim ? (uint32_t) x[i] : 0u) | ((i + 1 < dim ? (uint32_t) x[i + 1] : 0u) << 16);
+
+			*reinterpret_cast<uint32_t *>(rowimg + 16 * ((j >> 2) ^ ((rr >> 2) & 3)) + 4 * (j & 3)) = v;
+		}
+		else
+		{
+			const float *x = (const float *) vecs + (size_t) row * dim;
 			_Float16	h0 = 0, l0 = 0, h1 = 0, l1 = 0;
 
 			if (ok && i < dim)
@@ -152,8 +190,8 @@ k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, 
 			ndb_h2		h, l;
 
 			h.x = h0; h.y = h1; l.x = l0; l.y = l1;
-			out[c * 32 + j] = h;
-			out[c * 32 + 16 + j] = l;
+			*reinterpret_cast<ndb_h2 *>(rowimg + 16 * ((j >> 2) ^ ((rr >> 1) & 7)) + 4 * (j & 3)) = h;
+			*reinterpret_cast<ndb_h2 *>(rowimg + 16 * ((4 + (j >> 2)) ^ ((rr >> 1) & 7)) + 4 * (j & 3)) = l;
 		}
 	}
 }
@@ -307,170 +345,310 @@ k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 }
 
 /* ------------------------------------------------------------------------------------------------------------
- * The sweep.  Work item = (list, 128-row tile, 128-query tile) from the same queues as the other grouped scans
- * (k_pair_offsets with 8 groups of 16 queries and 2 tiles of 64 rows per item).  256 threads = 4 waves; wave
- * (wq, wr) owns the 64 queries x 64 rows sub-tile as 2 x 2 MFMA blocks.
+ * The sweep.  Work item = (list, RT-row tile, 128-query tile) from the same queues as the other grouped scans
+ * (k_pair_offsets with 8 groups of 16 queries and RT / 64 tiles of 64 rows per item).  NW waves per block; wave
+ * (wq, wr) = (w & 1, w >> 1) owns the 64 queries x 64 rows sub-tile as 2 x 2 MFMA blocks, so RT = 32 NW:
+ * 128 rows for 4 waves, 256 for 8.
  *
  * LDS image of a 32-row (or 32-query) block for one 32-dimension chunk: [r][8 slots of 16 bytes], logical slot
  * s = 2 * kstep + khalf for the hi plane, 4 + 2 * kstep + khalf for the lo plane, stored at slot s ^ ((r >> 1) & 7):
  * the 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-byte bank
- * slots.  The DMA writes LDS linearly in lane order (lane i -> byte 16 i of the instruction's 1 KiB), so the
- * swizzle is applied to the global address each lane reads: 8 rows x 128 contiguous bytes per instruction.
- * H16 rows: the mirror's own fp16 row is the hi plane (64 bytes per row and chunk, slot s ^ ((r >> 2) & 3)).
+ * slots (SQ_LDS_BANK_CONFLICT = 0).  The DMA writes LDS linearly in lane order (lane i -> byte 16 i of the
+ * instruction's 1 KiB), so the swizzle is applied to the global address each lane reads: 8 rows x 128
+ * contiguous bytes per instruction.  H16 rows: the mirror's own fp16 row is the hi plane (64 bytes per row and
+ * chunk, slot s ^ ((r >> 2) & 3)).
  *
- * Pipeline per chunk: wait for the chunk's DMA, one barrier, issue the next chunk's DMA into the other buffer
- * (which every wave has finished reading), then 8 ds_read_b128 + 12 MFMAs per k-step.  Every 64 dimensions the
- * block accumulator is added to the running sum and restarted from zero (ndbhip_common.h (4)).
+ * Pipeline: a ring of NBUF chunk buffers, the DMA runs NBUF - 1 chunks ahead.  Per chunk: wait until the chunk's
+ * own DMA has landed (s_waitcnt vmcnt leaves the later chunks' requests in flight), one barrier, issue the DMA of
+ * chunk c + NBUF - 1 into the buffer every wave finished reading before that barrier, then 8 ds_read_b128 +
+ * 12 MFMAs per k-step.  Every 64 dimensions the block accumulator is added to the running sum and restarted
+ * from zero (ndbhip_common.h (4)).
  * ------------------------------------------------------------------------------------------------------------ */
-template <int H16> struct S16Geom
+template <int H16, int NW> struct S16Geom
 {
+	static constexpr int RT = 32 * NW;						/* rows per tile */
 	static constexpr int ROW_BLK = H16 ? 2048 : 4096;		/* bytes of a 32-row block per chunk */
-	static constexpr int ROWS_BYTES = 4 * ROW_BLK;			/* 128 rows */
+	static constexpr int ROWS_BYTES = NW * ROW_BLK;
 	static constexpr int Q_OFF = ROWS_BYTES;
 	static constexpr int BUF = ROWS_BYTES + 4 * 4096;		/* + 128 queries x 128 bytes */
 	static constexpr int ROW_CHUNK = H16 ? 64 : 128;		/* bytes of a row per chunk */
+	static constexpr int ROW_DMA = H16 ? 2 : 4;				/* DMA instructions per wave, chunk and row block */
+	static constexpr int Q_DMA = 16 / NW;					/* ... and for the wave's share of the 4 query blocks */
+	static constexpr int PER = ROW_DMA + Q_DMA;
 };
 
 typedef __attribute__((address_space(3))) void *ndb_lds_ptr;
 typedef const __attribute__((address_space(1))) void *ndb_glb_ptr;
 
+/*
+ * One LDS-DMA instruction: every lane fetches 16 bytes from base + voff (base wave-uniform) and the wave's 1 KiB
+ * lands at LDS address `la` (wave-uniform), lane i at la + 16 i.  Written as inline asm on purpose: with the
+ * __builtin_amdgcn_global_load_lds form hipcc tracks "an LDS DMA may be pending" per LDS object and puts
+ * s_waitcnt vmcnt(0) in front of every later ds_read it cannot prove disjoint — all of them once the chunk
+ * buffers are a ring with a run-time index — which waits for the chunk just requested and serialises the whole
+ * pipeline (measured: the 3-deep ring ran slower than the 2-deep one).  The kernel orders DMA against reads
+ * itself: s_waitcnt vmcnt(n) + barrier before a buffer is read, a barrier before it is refilled.  M0 is
+ * written here and nowhere else in the kernel (tools/check_asm_hazards.py checks that); one wait state between
+ * the SALU write of M0 and its use.
+ */
 __device__ __forceinline__ void
-s16_dma16(const unsigned char *gp, unsigned char *lp)
+s16_dma16(const unsigned char *base, uint32_t voff, uint32_t la)
 {
-	__builtin_amdgcn_global_load_lds((ndb_glb_ptr) gp, (ndb_lds_ptr) lp, 16, 0, 0);
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+				 :: "s"(la), "v"(voff), "s"(base) : "memory", "m0");
 }
 
-template <int R, int H16>
-__global__ __launch_bounds__(256, 2) void
-k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbytes,
+/* the same for a piece that is contiguous on both sides: N instructions, lane i of instruction j copies the 16
+ * bytes at base + 1024 j + 16 i to la + 1024 j + 16 i (the instruction offset applies to both addresses) */
+template <int N>
+__device__ __forceinline__ void
+s16_dma_linear(const unsigned char *base, uint32_t lane16, uint32_t la)
+{
+	if constexpr (N == 4)
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+					 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+					 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+					 :: "s"(la), "v"(lane16), "s"(base) : "memory", "m0");
+	else
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+					 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+					 :: "s"(la), "v"(lane16), "s"(base) : "memory", "m0");
+}
+
+__device__ __forceinline__ const unsigned char *
+s16_uniform_ptr(const unsigned char *p)
+{
+	const uint64_t v = (uint64_t) p;
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v), hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
+
+	return (const unsigned char *) (((uint64_t) hi << 32) | lo);
+}
+
+template <int N> __device__ __forceinline__ void s16_wait_vm();
+template <> __device__ __forceinline__ void s16_wait_vm<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void s16_wait_vm<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <> __device__ __forceinline__ void s16_wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void s16_wait_vm<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void s16_wait_vm<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+template <> __device__ __forceinline__ void s16_wait_vm<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+
+/* one work item of the sweep, expanded once per batch (k_s16_items) so that a block finds its next item with one
+ * load instead of a binary search over the lists */
+struct S16Desc
+{
+	uint32_t	L;				/* list */
+	uint32_t	t2;				/* row tile of the list */
+	uint32_t	qt;				/* 128-query tile of the list's (query, probe) pairs */
+	uint32_t	pad;
+};
+
+/* Consecutive items of a list walk super-tiles of up to 8 row tiles x 8 query tiles (query tile fastest inside):
+ * the blocks of an XCD that pull them together then share 8 + 8 operand tiles through that XCD's L2 — with
+ * "query tile fastest" across ALL of a list's query tiles (32 of them where every query probes the list) the
+ * 12.6 MB of query planes went round the 4 MB L2 once per row tile (hit rate 0.45 -> 0.59) */
+__global__ void
+k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ own_len,
+			int ncent, uint32_t rt, uint32_t cap, S16Desc *__restrict__ desc, unsigned int *__restrict__ flags)
+{
+	const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (item == 0 && item_off[ncent] > cap)
+		atomicAdd(flags, 1u);		/* cannot happen (the host sizes the table by an upper bound); if it does, fall back */
+	if (item >= item_off[ncent] || item >= cap)
+		return;
+	uint32_t	lo = 0, hi = (uint32_t) ncent;
+
+	while (hi - lo > 1)
+	{
+		const uint32_t mid = (lo + hi) >> 1;
+
+		if (item_off[mid] <= item)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < (uint32_t) ncent && item_off[lo + 1] <= item)
+		lo++;
+	const uint32_t L = lo, local = item - item_off[L];
+	const uint32_t nqt = (cnt[L] + S16_QT - 1) / S16_QT, nrt = (own_len[L] + rt - 1) / rt;
+	const uint32_t band = local / (8u * nqt);			/* bands of 8 row tiles: all but the last are full */
+	const uint32_t lb = local - band * 8u * nqt;
+	const uint32_t br = min(8u, nrt - 8u * band);
+	const uint32_t grp = lb / (br * 8u);				/* groups of 8 query tiles: all but the last are full */
+	const uint32_t lg = lb - grp * br * 8u;
+	const uint32_t gq = min(8u, nqt - 8u * grp);
+	S16Desc		d;
+
+	d.L = L;
+	d.t2 = 8u * band + lg / gq;
+	d.qt = 8u * grp + lg % gq;
+	d.pad = 0;
+	desc[item] = d;
+}
+
+#define S16_NOITEM 0xFFFFFFFFu
+#ifndef S16_SETPRIO
+#define S16_SETPRIO 0
+#endif
+
+template <int R, int H16, int NW, int NBUF, int DBG = 0>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && NBUF == 2) ? 2 : 1) void
+k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
 			const float *__restrict__ rn2, const int16_t *__restrict__ rexp,
 			const unsigned char *__restrict__ qplanes, uint32_t qrowbytes, const float *__restrict__ qn2,
 			const int *__restrict__ qexp, const float2 *__restrict__ qthr,
 			const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt,
-			const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ item_off,
+			const uint32_t *__restrict__ pair_off, const S16Desc *__restrict__ desc,
 			const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 			const uint32_t *__restrict__ runs, unsigned int *__restrict__ ecount, uint2 *__restrict__ erec,
-			uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk)
+			uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk, uint32_t desc_cap)
 {
-	typedef S16Geom<H16> G;
-	__shared__ __attribute__((aligned(1024))) unsigned char bufA[G::BUF];
-	__shared__ __attribute__((aligned(1024))) unsigned char bufB[G::BUF];
-	__shared__ S16Q qinfo[S16_QT];
-	__shared__ uint32_t s_item;
+	typedef S16Geom<H16, NW> G;
+	__shared__ __attribute__((aligned(1024))) unsigned char ring[NBUF * G::BUF];
+	__shared__ S16Q qinfo[2][S16_QT];
+	__shared__ uint32_t s_desc[2][5];		/* item (S16_NOITEM = none), L, t2, qt, members of the current / next item's tile */
 	const int	tid = threadIdx.x;
 	const int	lane = tid & 63;
 	const int	wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int	wq = wave & 1, wr = wave >> 1;
 	const int	r32 = lane & 31, kh = lane >> 5;
+	/* work queues: thread 0 only */
+	uint32_t	hop = 0;
 
-	for (uint32_t hop = 0; hop < 8; hop++)
+	/* next item of this block's queues, or S16_NOITEM; `got` = the value a previously issued atomicAdd on the
+	 * current hop's head returned (0xFFFFFFFF: none issued) */
+	auto		pop = [&](uint32_t got) -> uint32_t {
+		for (; hop < 8; hop++)
+		{
+			const uint32_t xq = (blockIdx.x + hop) & 7u;
+			const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+
+			if (run_lo != run_hi)
+			{
+				if (got == 0xFFFFFFFFu)
+					got = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
+																__HIP_MEMORY_SCOPE_AGENT) >= run_hi)
+						? run_hi : atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
+				if (got < run_hi - run_lo && run_lo + got < desc_cap)	/* (the table holds every item: k_s16_items flags it otherwise) */
+					return run_lo + got;
+			}
+			got = 0xFFFFFFFFu;
+		}
+		return S16_NOITEM;
+	};
+	/* thread 0: publish item `it` (and its descriptor) in slot sl */
+	auto		put_desc = [&](int sl, uint32_t it, const S16Desc &d) {
+		s_desc[sl][0] = it;
+		s_desc[sl][1] = d.L;
+		s_desc[sl][2] = d.t2;
+		s_desc[sl][3] = d.qt;
+		s_desc[sl][4] = it == S16_NOITEM ? 0u : min((uint32_t) S16_QT, cnt[d.L] - d.qt * S16_QT);
+	};
+	/* threads < 128: the tile's member record */
+	auto		load_pair = [&](int sl, PairRec &pr) -> bool {
+		const uint32_t L = s_desc[sl][1], qt = s_desc[sl][3];
+
+		if (s_desc[sl][0] == S16_NOITEM || qt * S16_QT + (uint32_t) tid >= cnt[L])
+			return false;
+		pr = pairs[pair_off[L] + qt * S16_QT + (uint32_t) tid];
+		return true;
+	};
+	auto		load_qinfo = [&](bool have, const PairRec &pr, S16Q &qi) {
+		qi.q2 = 0.0f; qi.thrE = 0.0f; qi.eq = 0; qi.la = 0; qi.nrow = 0; qi.qid = 0;
+		if (have)
+		{
+			const uint32_t *lq = loc_cand_off + (size_t) pr.q * (npr + 1);
+
+			qi.qid = pr.q;
+			qi.la = lq[pr.p];
+			qi.nrow = lq[pr.p + 1] - qi.la;
+			qi.q2 = qn2[pr.q];
+			qi.eq = qexp[pr.q];
+			qi.thrE = qthr[pr.q].x;
+		}
+	};
+
+	/* ---- first item: everything synchronously ---- */
+	if (tid == 0)
 	{
-	const uint32_t xq = (blockIdx.x + hop) & 7u;
-	const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+		const uint32_t it = pop(0xFFFFFFFFu);
+		S16Desc		d = {0, 0, 0, 0};
 
-	if (run_lo == run_hi)
-		continue;
+		if (it != S16_NOITEM)
+			d = desc[it];
+		put_desc(0, it, d);
+	}
+	__syncthreads();
+	if (s_desc[0][0] == S16_NOITEM)
+		return;					/* uniform */
+	if (tid < S16_QT)
+	{
+		PairRec		pr = {0, 0};
+		S16Q		qi;
+		const bool	have = load_pair(0, pr);
+
+		load_qinfo(have, pr, qi);
+		qinfo[0][tid] = qi;
+	}
+	__syncthreads();
+
+	uint32_t	voff_q[G::Q_DMA];
+	const unsigned char *rbase;
+	const uint32_t lane16 = (uint32_t) lane * 16u;
+
+	/* DMA addresses for the item in slot sl: wave w stages 32-row block w of the tile (one contiguous piece of
+	 * the blocked planes per chunk) and its share of the 4 query blocks (gathered by query id) */
+	auto		set_dma = [&](int sl) {
+		const uint32_t L = s_desc[sl][1], t2 = s_desc[sl][2];
+		/* a tile's last blocks may lie beyond the list's last block: they read that one again (results of rows
+		 * >= the list's length are never looked at) */
+		const uint32_t nb = blk_off[L + 1] - blk_off[L];
+		const uint32_t b = min(t2 * (uint32_t) NW + (uint32_t) wave, nb - 1u);
+		/* 1 KiB pieces of the 16 KiB query area, in order: piece -> query block piece / 4, rows 8 (piece % 4) .. + 7 */
+#pragma unroll
+		for (int j = 0; j < G::Q_DMA; j++)
+		{
+			const int	piece = wave * G::Q_DMA + j;
+			const int	rr = 8 * (piece & 3) + (lane >> 3);
+
+			voff_q[j] = qinfo[sl][32 * (piece >> 2) + rr].qid * qrowbytes + 16u * (uint32_t) ((lane & 7) ^ ((rr >> 1) & 7));
+		}
+		rbase = planes + ((size_t) blk_off[L] + b) * (size_t) nchunk * G::ROW_BLK;
+	};
+	const uint32_t ring_la = (uint32_t) (uintptr_t) (ndb_lds_ptr) ring;
+	auto		issue = [&](int c, int bufi) {
+		/* DBG (timing experiments only, results are garbage): 1 = no DMA at all, 2 = every chunk re-reads
+		 * chunk 0 of the mirror's first rows and of query 0 (always cache hits) */
+		if constexpr (DBG == 1)
+			return;
+		/* (3: only the queries are always hits, 4: only the rows) */
+		const unsigned char *rb = s16_uniform_ptr((DBG == 2 || DBG == 4) ? planes : rbase + (size_t) c * G::ROW_BLK);
+		const unsigned char *qb = s16_uniform_ptr((DBG == 2 || DBG == 3) ? qplanes : qplanes + (size_t) c * 128);
+		const uint32_t la = ring_la + (uint32_t) bufi * G::BUF;
+
+		s16_dma_linear<G::ROW_DMA>(rb, lane16, la + wave * G::ROW_BLK);
+#pragma unroll
+		for (int j = 0; j < G::Q_DMA; j++)
+			s16_dma16(qb, voff_q[j], la + G::Q_OFF + (wave * G::Q_DMA + j) * 1024);
+	};
+
+	/* fragment addresses (bytes inside a buffer) */
+	const int	qsw = (r32 >> 1) & 7;
+	const int	qfrag = G::Q_OFF + (2 * wq) * 4096 + r32 * 128;
+	const int	rsw = H16 ? ((r32 >> 2) & 3) : ((r32 >> 1) & 7);
+	const int	rfrag = (2 * wr) * G::ROW_BLK + r32 * G::ROW_CHUNK;
+	int			cur = 0;
+
+	set_dma(0);
+	/* nchunk is even (the planes are padded to 64 dimensions) and >= 2 */
+#pragma unroll
+	for (int p = 0; p < NBUF - 1; p++)
+		if (p < nchunk)
+			issue(p, p);
+
 	for (;;)
 	{
-		if (tid == 0)
-			s_item = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
-															__HIP_MEMORY_SCOPE_AGENT) >= run_hi)
-				? run_hi : run_lo + atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
-		__syncthreads();
-		const uint32_t item = s_item;
-
-		if (item >= run_hi)
-		{
-			__syncthreads();
-			break;				/* uniform */
-		}
-		uint32_t	lo = 0, hi = (uint32_t) ix.ncent;
-
-		while (hi - lo > 1)
-		{
-			const uint32_t mid = (lo + hi) >> 1;
-
-			if (item_off[mid] <= item)
-				lo = mid;
-			else
-				hi = mid;
-		}
-		while (lo + 1 < (uint32_t) ix.ncent && item_off[lo + 1] <= item)
-			lo++;
-		const uint32_t L = lo;
-		const uint32_t len = ix.own_len[L];
-		const uint32_t local = item - item_off[L];
-		const uint32_t nmemL = cnt[L];
-		const uint32_t nqt = (nmemL + S16_QT - 1) / S16_QT;
-		const uint32_t qt = local % nqt;		/* query tile fastest: neighbours stream the same rows */
-		const uint32_t t2 = local / nqt;		/* 128-row tile */
-		const uint32_t nmem = min((uint32_t) S16_QT, nmemL - qt * S16_QT);
-		const size_t row0 = (size_t) ix.loc_off[L] + (size_t) t2 * S16_RT;
-
-		if (tid < S16_QT)
-		{
-			S16Q		qi;
-
-			qi.q2 = 0.0f; qi.thrE = 0.0f; qi.eq = 0; qi.la = 0; qi.nrow = 0; qi.qid = 0;
-			if ((uint32_t) tid < nmem)
-			{
-				const PairRec pr = pairs[pair_off[L] + qt * S16_QT + (uint32_t) tid];
-				const uint32_t *lq = loc_cand_off + (size_t) pr.q * (npr + 1);
-
-				qi.qid = pr.q;
-				qi.la = lq[pr.p];
-				qi.nrow = lq[pr.p + 1] - qi.la;
-				qi.q2 = qn2[pr.q];
-				qi.eq = qexp[pr.q];
-				qi.thrE = qthr[pr.q].x;
-			}
-			qinfo[tid] = qi;
-		}
-		__syncthreads();		/* also: everybody has read s_item */
-
-		/* DMA addresses of this lane: wave w stages 32-row block w and 32-query block w */
-		uint32_t	voff_r[4], voff_q[4];
-
-#pragma unroll
-		for (int j = 0; j < 4; j++)
-		{
-			if constexpr (H16 != 0)
-			{
-				/* 16 rows x 4 slots per instruction; two instructions per 32-row block and chunk */
-				const int	rr = 16 * (j & 1) + (lane >> 2);		/* j = 0, 1 only */
-				const uint32_t ridx = t2 * S16_RT + (uint32_t) (32 * wave + rr);
-				const uint32_t rc = ridx < len ? (uint32_t) (32 * wave + rr) : (len - 1 - t2 * S16_RT);
-
-				voff_r[j] = rc * rowbytes + 16u * (uint32_t) ((lane & 3) ^ ((rr >> 2) & 3));
-			}
-			else
-			{
-				const int	rr = 8 * j + (lane >> 3);
-				const uint32_t ridx = t2 * S16_RT + (uint32_t) (32 * wave + rr);
-				const uint32_t rc = ridx < len ? (uint32_t) (32 * wave + rr) : (len - 1 - t2 * S16_RT);
-
-				voff_r[j] = rc * rowbytes + 16u * (uint32_t) ((lane & 7) ^ ((rr >> 1) & 7));
-			}
-			{
-				const int	rr = 8 * j + (lane >> 3);
-
-				voff_q[j] = qinfo[32 * wave + rr].qid * qrowbytes + 16u * (uint32_t) ((lane & 7) ^ ((rr >> 1) & 7));
-			}
-		}
-		const unsigned char *rbase = planes + row0 * (size_t) rowbytes;
-
-		auto		issue = [&](int c, unsigned char *buf) {
-			const unsigned char *rb = rbase + (size_t) c * G::ROW_CHUNK;
-			const unsigned char *qb = qplanes + (size_t) c * 128;
-
-#pragma unroll
-			for (int j = 0; j < (H16 ? 2 : 4); j++)
-				s16_dma16(rb + voff_r[j], buf + wave * G::ROW_BLK + j * 1024);
-#pragma unroll
-			for (int j = 0; j < 4; j++)
-				s16_dma16(qb + voff_q[j], buf + G::Q_OFF + wave * 4096 + j * 1024);
-		};
-
+		const int	nxt = cur ^ 1;
 		ndb_f16acc	run[2][2], blk[2][2];
 
 #pragma unroll
@@ -483,38 +661,104 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbyt
 					run[a][b][i] = 0.0f;
 					blk[a][b][i] = 0.0f;
 				}
-		/* fragment addresses (bytes inside a buffer) */
-		const int	qsw = (r32 >> 1) & 7;
-		const int	qfrag = G::Q_OFF + (2 * wq) * 4096 + r32 * 128;
-		const int	rsw = H16 ? ((r32 >> 2) & 3) : ((r32 >> 1) & 7);
-		const int	rfrag = (2 * wr) * G::ROW_BLK + r32 * G::ROW_CHUNK;
 
-		auto		compute = [&](const unsigned char *buf) {
+		/* query blocks of this wave's half that hold a member of the current item's tile */
+		const uint32_t nmem_cur = s_desc[cur][4];
+		const int	na = nmem_cur > (uint32_t) (64 * wq + 32) ? 2 : (nmem_cur > (uint32_t) (64 * wq) ? 1 : 0);
+
+		/* the first query block only */
+		auto		compute_half = [&](const unsigned char *buf) {
+			ndb_h8		ah[2], al[2], bh[2][2], bl[2][2];
+
 #pragma unroll
 			for (int s = 0; s < 2; s++)
 			{
-				ndb_h8		ah[2], al[2], bh[2], bl[2];
-
+				ah[s] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + (((2 * s + kh) ^ qsw) * 16));
+				al[s] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + (((4 + 2 * s + kh) ^ qsw) * 16));
 #pragma unroll
 				for (int b = 0; b < 2; b++)
 				{
-					ah[b] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + b * 4096 + (((2 * s + kh) ^ qsw) * 16));
-					al[b] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + b * 4096 + (((4 + 2 * s + kh) ^ qsw) * 16));
-					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * G::ROW_BLK + (((2 * s + kh) ^ rsw) * 16));
+					bh[s][b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * G::ROW_BLK + (((2 * s + kh) ^ rsw) * 16));
 					if constexpr (H16 == 0)
-						bl[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * G::ROW_BLK + (((4 + 2 * s + kh) ^ rsw) * 16));
+						bl[s][b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * G::ROW_BLK + (((4 + 2 * s + kh) ^ rsw) * 16));
+				}
+			}
+#pragma unroll
+			for (int s = 0; s < 2; s++)
+			{
+#pragma unroll
+				for (int b = 0; b < 2; b++)
+					blk[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s][b], blk[0][b], 0, 0, 0);
+				if constexpr (H16 == 0)
+				{
+#pragma unroll
+					for (int b = 0; b < 2; b++)
+						blk[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s][b], blk[0][b], 0, 0, 0);
+				}
+#pragma unroll
+				for (int b = 0; b < 2; b++)
+					blk[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s][b], blk[0][b], 0, 0, 0);
+			}
+		};
+		/* both k-steps' fragments are requested before the first k-step is multiplied: the second set arrives
+		 * under the first 12 MFMAs instead of after them */
+		/* a short query tile (most lists are probed by a handful of queries) leaves query blocks without a
+		 * member: a wave multiplies only the blocks of its half that have one (na = 0, 1 or 2, wave-uniform) */
+		auto		compute = [&](const unsigned char *buf) {
+			if (na == 0)
+				return;
+			if (na == 1)
+			{
+				compute_half(buf);
+				return;
+			}
+			ndb_h8		ah[2][2], al[2][2], bh[2][2], bl[2][2];
+
+#pragma unroll
+			for (int s = 0; s < 2; s++)
+#pragma unroll
+				for (int b = 0; b < 2; b++)
+				{
+					ah[s][b] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + b * 4096 + (((2 * s + kh) ^ qsw) * 16));
+					al[s][b] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + b * 4096 + (((4 + 2 * s + kh) ^ qsw) * 16));
+					bh[s][b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * G::ROW_BLK + (((2 * s + kh) ^ rsw) * 16));
+					if constexpr (H16 == 0)
+						bl[s][b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * G::ROW_BLK + (((4 + 2 * s + kh) ^ rsw) * 16));
+				}
+#if S16_SETPRIO == 1
+			__builtin_amdgcn_s_setprio(1);
+#elif S16_SETPRIO == 2
+			__builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+			for (int s = 0; s < 2; s++)
+			{
+				/* the three products of a block are spread over the step, so that no MFMA follows the one it
+				 * depends on */
+#pragma unroll
+				for (int a = 0; a < 2; a++)
+#pragma unroll
+					for (int b = 0; b < 2; b++)
+						blk[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][a], bh[s][b], blk[a][b], 0, 0, 0);
+				if constexpr (H16 == 0)
+				{
+#pragma unroll
+					for (int a = 0; a < 2; a++)
+#pragma unroll
+						for (int b = 0; b < 2; b++)
+							blk[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][a], bl[s][b], blk[a][b], 0, 0, 0);
 				}
 #pragma unroll
 				for (int a = 0; a < 2; a++)
 #pragma unroll
 					for (int b = 0; b < 2; b++)
-					{
-						blk[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], blk[a][b], 0, 0, 0);
-						if constexpr (H16 == 0)
-							blk[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], blk[a][b], 0, 0, 0);
-						blk[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], blk[a][b], 0, 0, 0);
-					}
+						blk[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][a], bh[s][b], blk[a][b], 0, 0, 0);
 			}
+#if S16_SETPRIO == 1
+			__builtin_amdgcn_s_setprio(0);
+#elif S16_SETPRIO == 2
+			__builtin_amdgcn_s_setprio(1);		/* requests (DMA, fragment reads) go ahead of the other wave's MFMAs */
+#endif
 		};
 		auto		flush = [&]() {
 #pragma unroll
@@ -529,25 +773,126 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbyt
 					}
 		};
 
-		issue(0, bufA);
-		for (int c = 0; c < nchunk; c += 2)
-		{
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__syncthreads();
-			if (c + 1 < nchunk)
-				issue(c + 1, bufB);
-			compute(bufA);
-			if (c + 1 >= nchunk)
+		/*
+		 * The next item is prepared while this one is multiplied, one stage per chunk, each stage right after
+		 * the chunk's barrier: a stage consumes what the previous stage requested one chunk earlier (so the
+		 * request had a chunk of MFMAs to arrive) and what it writes to LDS is published by the next barrier.
+		 *   0  thread 0: atomicAdd on its queue head          3  threads < 128: the member's (query, probe) record
+		 *   1  thread 0: the item's descriptor                4  threads < 128: its offsets, norm, exponent, threshold
+		 *   2  thread 0: descriptor -> LDS                    5  threads < 128: record -> LDS
+		 * Items with fewer than 6 chunks run the remaining stages after their last chunk.
+		 */
+		uint32_t	got = 0xFFFFFFFFu, nit = S16_NOITEM;
+		S16Desc		nd = {0, 0, 0, 0};
+		PairRec		npair = {0, 0};
+		bool		nhave = false;
+		S16Q		nqi;
+
+		auto		stage = [&](int st) {
+			if (st == 0)
 			{
-				flush();
-				break;
+				if (tid == 0 && hop < 8 && !polite)
+				{
+					const uint32_t xq = (blockIdx.x + hop) & 7u;
+
+					if (runs[xq] != runs[xq + 1])
+						got = atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
+				}
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			else if (st == 1)
+			{
+				if (tid == 0)
+				{
+					nit = pop(got);
+					if (nit != S16_NOITEM)
+						nd = desc[nit];
+				}
+			}
+			else if (st == 2)
+			{
+				if (tid == 0)
+					put_desc(nxt, nit, nd);
+			}
+			else if (st == 3)
+			{
+				if (tid < S16_QT)
+					nhave = load_pair(nxt, npair);
+			}
+			else if (st == 4)
+			{
+				if (tid < S16_QT)
+					load_qinfo(nhave, npair, nqi);
+			}
+			else if (st == 5)
+			{
+				if (tid < S16_QT)
+					qinfo[nxt][tid] = nqi;
+			}
+		};
+
+		if constexpr (NBUF == 2)
+		{
+			for (int c = 0; c < nchunk; c += 2)
+			{
+				s16_wait_vm<0>();
+				__syncthreads();
+				if (c < 6)
+					stage(c);
+				issue(c + 1, 1);
+				compute(ring);
+				s16_wait_vm<0>();
+				__syncthreads();
+				if (c + 1 < 6)
+					stage(c + 1);
+				if (c + 2 < nchunk)
+					issue(c + 2, 0);
+				compute(ring + G::BUF);
+				flush();			/* NDB_S16_FLUSH_DIMS = 2 chunks */
+			}
+		}
+		else
+		{
+			int			bc = 0;			/* buffer of chunk c; the DMA target is (bc + NBUF - 1) % NBUF */
+
+			for (int c = 0; c < nchunk; c++)
+			{
+				/* the chunks after c that are already requested: min(NBUF - 2, nchunk - 1 - c) */
+				if (c + NBUF - 2 < nchunk)
+					s16_wait_vm<G::PER * (NBUF - 2)>();
+				else
+					s16_wait_vm<0>();		/* (the tail of a ring deeper than 3 drains a little early) */
+				__syncthreads();
+				if (c < 6)
+					stage(c);
+				const int	bt = bc == 0 ? NBUF - 1 : bc - 1;
+
+				if (c + NBUF - 1 < nchunk)
+					issue(c + NBUF - 1, bt);
+				compute(ring + bc * G::BUF);
+				if (c & 1)
+					flush();
+				bc = bc + 1 == NBUF ? 0 : bc + 1;
+			}
+		}
+		for (int st = nchunk; st < 6; st++)
+		{
 			__syncthreads();
-			if (c + 2 < nchunk)
-				issue(c + 2, bufA);
-			compute(bufB);
-			flush();			/* NDB_S16_FLUSH_DIMS = 2 chunks */
+			stage(st);
+		}
+		__syncthreads();		/* every wave has finished reading the ring; the next item's records are published */
+
+		const bool	more = s_desc[nxt][0] != S16_NOITEM;	/* uniform */
+		const uint32_t L = s_desc[cur][1], t2 = s_desc[cur][2];
+		const uint32_t len = ix.own_len[L];
+
+		if (more)
+		{
+			/* the next item's first chunks travel while this item's results are looked at */
+			set_dma(nxt);
+#pragma unroll
+			for (int p = 0; p < NBUF - 1; p++)
+				if (p < nchunk)
+					issue(p, p);
 		}
 
 		/* epilogue: element (reg, lane) of block (a, b) = query 32 (2 wq + a) + (reg & 3) + 8 (reg >> 2) + 4 kh,
@@ -555,7 +900,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbyt
 #pragma unroll
 		for (int b = 0; b < 2; b++)
 		{
-			const uint32_t ridx = t2 * S16_RT + (uint32_t) (32 * (2 * wr + b) + r32);
+			const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (2 * wr + b) + r32);
 			const bool	rok = ridx < len;
 			const size_t grow = (size_t) ix.loc_off[L] + (rok ? ridx : len - 1);
 			const float x2 = rn2[grow];
@@ -567,7 +912,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbyt
 				for (int reg = 0; reg < 16; reg++)
 				{
 					const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-					const S16Q	qi = qinfo[m];
+					const S16Q	qi = qinfo[cur][m];
 
 					if (ridx < qi.nrow)
 					{
@@ -578,7 +923,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbyt
 							av = __builtin_fmaf(-2.0f, dot, qi.q2 + x2);
 						else
 							av = -dot;
-						if (!(av > qi.thrE))
+						if (DBG ? av == 1234.5f : !(av > qi.thrE))
 						{
 							const uint32_t slot = atomicAdd(&ecount[qi.qid], 1u);
 							const uint32_t pos = qi.la + ridx, ab = __float_as_uint(av);
@@ -594,8 +939,10 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, uint32_t rowbyt
 					}
 				}
 		}
-		__syncthreads();		/* qinfo, s_item and the buffers are reused by the next item */
-	}
+		if (!more)
+			break;
+		cur = nxt;
+		/* (no barrier: qinfo[cur ^ 1] and s_desc[cur ^ 1] are next written in stages 2 and 5, behind barriers) */
 	}
 }
 
@@ -667,8 +1014,6 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	TopkSmem	s = carve_topk_smem(smem_raw, S16_SURV_CAP, k);
-	uint32_t   *r_pos = (uint32_t *) (smem_raw + topk_smem_bytes(S16_SURV_CAP, k));
-	uint32_t   *r_a = r_pos + ecap;
 	const uint32_t q = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
@@ -686,14 +1031,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		}
 		return;					/* uniform */
 	}
-	for (uint32_t i = tid; i < nraw; i += 256)
-	{
-		const uint2 r = erec[(size_t) q * ecap + i];
-
-		r_pos[i] = r.x;
-		r_a[i] = r.y;
-	}
-	__syncthreads();
+	const uint2 *rec = erec + (size_t) q * ecap;	/* a few hundred records, read from L2 as often as needed */
 	float		thrE = qthr[q].x;
 	const float e = qthr[q].y;
 
@@ -703,7 +1041,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		/* only finite values stand for a candidate whose distance is known to within E (a NaN or an infinity is
 		 * what a row or a product beyond fp32 leaves behind: emitted, never counted) */
 		auto		ld = [&](uint32_t i, uint32_t &bits) -> bool {
-			bits = r_a[i];
+			bits = rec[i].y;
 			return (bits & 0x7FFFFFFFu) < 0x7F800000u;
 		};
 
@@ -721,14 +1059,14 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	__syncthreads();
 	for (uint32_t i = tid; i < nraw; i += 256)
 	{
-		const float av = __uint_as_float(r_a[i]);
+		const uint2 r = rec[i];
 
-		if (!(av > thrE))
+		if (!(__uint_as_float(r.y) > thrE))
 		{
 			const uint32_t slot = atomicAdd(&s.sh[0], 1u);
 
 			if (slot < S16_SURV_CAP)
-				s.e_pos[slot] = r_pos[i];
+				s.e_pos[slot] = r.x;
 		}
 	}
 	__syncthreads();

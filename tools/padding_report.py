@@ -32,6 +32,19 @@ def main():
         by_q = int((((cnt + 15) // 16) * 16 * ll).sum())
         print(f"nq={nq:5d}: useful {useful:.3e} pair-rows, computed {done:.3e} (x{done / useful:.3f}); "
               f"query-group padding alone x{by_q / useful:.3f}, row-tile padding alone x{done / by_q:.3f}")
+        for qt, rt in ((128, 128), (64, 128), (128, 256), (64, 256), (32, 128), (256, 128)):
+            d2 = int((((cnt + qt - 1) // qt) * qt * ((ll + rt - 1) // rt) * rt).sum())
+            items = int((((cnt + qt - 1) // qt) * ((ll + rt - 1) // rt)).sum())
+            print(f"          fp16 matrix-core sweep, tiles of {qt} queries x {rt} rows: x{d2 / useful:.3f} ({items} items)")
+        # mixed: lists take 128-query tiles, the remainder of <= 64 queries a 64-query tile
+        rem = cnt % 128
+        full = (cnt // 128) * 128
+        mixed = (full + np.where(rem == 0, 0, np.where(rem <= 64, 64, 128))) * ((ll + 127) // 128) * 128
+        print(f"          128 x 128 tiles with a 64-query tile for remainders <= 64: x{int(mixed.sum()) / useful:.3f}")
+        if nq == 4096:
+            order = np.argsort(-ll)[:8]
+            print("          longest lists (len, queries probing):", [(int(ll[i]), int(cnt[i])) for i in order])
+            print("          cnt quantiles:", np.quantile(cnt, [0, .1, .25, .5, .75, .9, 1]).tolist(), "mean", cnt.mean())
 
 
 if __name__ == "__main__":
