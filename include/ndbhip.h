@@ -83,6 +83,7 @@ const char *ndbhip_last_error(void);
  * synchronise with the legacy default stream (handle 0) either — a caller that produces or consumes device
  * buffers on another stream passes that stream here (neurondb_amd/_lib.py: use_torch_stream). */
 int			ndbhip_set_stream(void *hip_stream);
+int			ndbhip_get_stream(void **out_hip_stream);	/* the stream every asynchronous entry point is ordered on */
 int			ndbhip_synchronize(void);
 
 /* Per-process counters (replaces GPUStats, include/neurondb_gpu.h:34-42). */
@@ -122,6 +123,16 @@ int			ndbhip_set_scan_mode(int mode);
  * pass), "screen16_records" (2048: candidates a query may emit before its batch is rerun on the fp32 screen),
  * "screen" (1; 0 = auto mode never screens). */
 int			ndbhip_set_option(const char *name, int value);
+
+/* Synthetic data for benches and full-size tests (a counter-based generator in the repo): element
+ * (row, d) is a pure function of the seeds — any slice, any order — and ndbhip_gen_rows_host (pure C, needs no
+ * device: what an oracle run is fed) returns the SAME BITS as ndbhip_gen_rows_device (csrc/ndbhip_gen.h says why).
+ * kind 0: i.i.d. N(0,1); kind 1: mixture of `components` Gaussians (sigma) around centers ~ N(0,1) drawn from
+ * center_seed.  out: [nrows][dim] floats, rows first_row .. first_row + nrows. */
+int			ndbhip_gen_rows_device(int kind, uint64_t seed, uint64_t center_seed, int64_t first_row, int64_t nrows,
+								   int dim, int components, float sigma, float *d_out);
+int			ndbhip_gen_rows_host(int kind, uint64_t seed, uint64_t center_seed, int64_t first_row, int64_t nrows,
+								 int dim, int components, float sigma, float *out);
 
 /* The matrix-core instruction the bound pass rests on, in isolation, so that its accumulation-error model
  * (csrc/ndbhip_common.h (4)) is checked on the part the library runs on (tests/test_gpu_mfma_model.py):
@@ -184,6 +195,7 @@ int			ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t
 int			ndbhip_ivf_export(const ndbhip_ivf *ix, float *centroids, int64_t *list_len, float *rows,
 							  uint8_t *tids6);
 int			ndbhip_ivf_ncentroids(const ndbhip_ivf *ix);
+int			ndbhip_ivf_dim(const ndbhip_ivf *ix);
 int			ndbhip_ivf_shape(const ndbhip_ivf *ix, int *dim, int *nlists);
 /* IvfMetaPageData.nprobe (ivf_am.c:75-89): set from the pages by ndbhip_ivf_load_pages, default 10; what
  * ivfrescan uses (:1487-1513) */
@@ -290,6 +302,36 @@ int			ndbhip_ivf_search_partial_probes_device(ndbhip_ivf *ix, const float *d_que
 int			ndbhip_merge_topk_device(const ndbhip_cand *d_cand, const int *d_ncand, const int64_t *d_total,
 									 int world, int nq, int k, int cap,
 									 uint64_t *d_out_tids, float *d_out_dist, int *d_out_count);
+/* ------------------------------------------------------------------ */
+/* The exchange itself, in C (csrc/ndbhip_comm.cpp): a PostgreSQL backend cannot import torch.  One process per
+ * GPU; the reference has no multi-GPU path of its own (no NCCL / RCCL / MPI call anywhere in the tree), the
+ * merge rule it would have to follow is src/util/distributed.c:204-244 (smaller distance first, ties by the
+ * order a single backend meets them), which the replay merge reproduces exactly.
+ *
+ *   rank 0:  ndbhip_comm_unique_id(id);  hand the 128 bytes to the other ranks (any side channel: the
+ *            postmaster's shared memory, a file, MPI, torch.distributed ...)
+ *   all:     ndbhip_comm_init(id, rank, world);          RCCL communicator on this process's device
+ *   all:     ndbhip_ivf_search_sharded(shard, ...);      per batch: select (split by queries) -> all-gather of
+ *            probes -> scan of the own lists -> all-gather of <= 3k records per query -> replay merge;
+ *            asynchronous on the library's stream, every rank gets the full result
+ *
+ * ndbhip_comm_init_shm is the same group over a POSIX shared-memory segment on the host (name "/...", created
+ * by rank 0, `slot_bytes` >= the largest per-rank message: nq * 3k * 16): for ranks that cannot form an RCCL
+ * communicator (several processes on one device, no librccl).  Its collectives block the calling thread.
+ * librccl is opened with dlopen by ndbhip_comm_unique_id / ndbhip_comm_init, never at library load. */
+#define NDBHIP_COMM_ID_BYTES 128
+int			ndbhip_comm_unique_id(void *out_id);
+int			ndbhip_comm_init(const void *unique_id, int rank, int world);
+int			ndbhip_comm_init_shm(const char *name, int rank, int world, size_t slot_bytes);
+int			ndbhip_comm_rank(void);
+int			ndbhip_comm_world(void);
+int			ndbhip_comm_destroy(void);
+/* d_recv[r * bytes .. (r + 1) * bytes) = rank r's d_send[0 .. bytes); without a communicator: a copy */
+int			ndbhip_comm_allgather(const void *d_send, void *d_recv, size_t bytes);
+int			ndbhip_ivf_search_sharded(ndbhip_ivf *shard, const float *d_queries, int nq, int strategy, int nprobe,
+									  int k, int64_t max_candidates, uint64_t *d_out_tids, float *d_out_dist,
+									  int *d_out_count);
+
 /* Host form of the same merge (results already on the host, e.g. gathered by
  * the PostgreSQL backend from several device-owner processes). Pure C, needs
  * no device. */

@@ -123,12 +123,24 @@ def lib():
         "ndbhip_last_error": (C.c_char_p, []),
         "ndbhip_set_stream": (i, [vp]),
         "ndbhip_synchronize": (i, []),
+        "ndbhip_get_stream": (i, [C.POINTER(vp)]),
+        "ndbhip_comm_unique_id": (i, [vp]),
+        "ndbhip_comm_init": (i, [vp, i, i]),
+        "ndbhip_comm_init_shm": (i, [C.c_char_p, i, i, C.c_size_t]),
+        "ndbhip_comm_rank": (i, []),
+        "ndbhip_comm_world": (i, []),
+        "ndbhip_comm_destroy": (i, []),
+        "ndbhip_comm_allgather": (i, [vp, vp, C.c_size_t]),
+        "ndbhip_ivf_search_sharded": (i, [vp, vp, i, i, i, i, i64, vp, vp, vp]),
+        "ndbhip_ivf_dim": (i, [vp]),
         "ndbhip_stats_get": (i, [C.POINTER(Stats)]),
         "ndbhip_stats_reset": (i, []),
         "ndbhip_profile": (i, [i]),
         "ndbhip_set_scan_mode": (i, [i]),
         "ndbhip_set_option": (i, [C.c_char_p, i]),
         "ndbhip_mfma_probe": (i, [vp, vp, vp, vp, i, i]),
+        "ndbhip_gen_rows_device": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),
+        "ndbhip_gen_rows_host": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),
         "ndbhip_ivf_create": (i, [i, i, C.POINTER(vp)]),
         "ndbhip_ivf_destroy": (i, [vp]),
         "ndbhip_ivf_set_centroids": (i, [vp, vp, i]),

@@ -21,6 +21,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <chrono>
 #include <type_traits>
 
 #include "../../include/ndbhip.h"
@@ -196,6 +197,28 @@ ndbhip_set_stream(void *s)
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	g.stream = s ? (hipStream_t) s : g.own_stream;
 	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_get_stream(void **out_hip_stream)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!out_hip_stream)
+		return fail(NDBHIP_ERR_INVALID, "out is NULL");
+	*out_hip_stream = (void *) g.stream;
+	return NDBHIP_OK;
+}
+
+/* the other translation units of the library report errors through the same thread-local message */
+extern "C" int
+ndbhip_internal_fail(int code, const char *fmt, ...)
+{
+	va_list		ap;
+
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
 }
 
 extern "C" int
@@ -4194,6 +4217,57 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* synthetic data (ndbhip_gen.h): the same bits on host and device       */
+/* ------------------------------------------------------------------ */
+#include "ndbhip_gen.h"
+
+__global__ void
+k_gen_rows(int kind, uint64_t seed, uint64_t center_seed, uint64_t first_row, uint64_t n_elems, int dim, int components,
+		   float sigma, float *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += (uint64_t) gridDim.x * blockDim.x)
+		out[i] = ndb_gen_element(kind, seed, center_seed, first_row + i / (uint64_t) dim, (int) (i % (uint64_t) dim), dim,
+								 components, sigma);
+}
+
+static int
+gen_check(int kind, int64_t first_row, int64_t nrows, int dim, int components, const void *out)
+{
+	if ((kind != 0 && kind != 1) || first_row < 0 || nrows < 0 || dim < 1 || (kind == 1 && components < 1) || (nrows > 0 && !out))
+		return fail(NDBHIP_ERR_INVALID, "bad generator arguments");
+	return 0;
+}
+
+extern "C" int
+ndbhip_gen_rows_device(int kind, uint64_t seed, uint64_t center_seed, int64_t first_row, int64_t nrows, int dim,
+					   int components, float sigma, float *d_out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (gen_check(kind, first_row, nrows, dim, components, d_out))
+		return NDBHIP_ERR_INVALID;
+	if (nrows == 0)
+		return NDBHIP_OK;
+	const uint64_t n = (uint64_t) nrows * (uint64_t) dim;
+
+	hipLaunchKernelGGL(k_gen_rows, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, g.stream, kind,
+					   seed, center_seed, (uint64_t) first_row, n, dim, components, sigma, d_out);
+	HIP_TRY(hipGetLastError());
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_gen_rows_host(int kind, uint64_t seed, uint64_t center_seed, int64_t first_row, int64_t nrows, int dim,
+					 int components, float sigma, float *out)
+{
+	if (gen_check(kind, first_row, nrows, dim, components, out))
+		return NDBHIP_ERR_INVALID;
+	for (int64_t r = 0; r < nrows; r++)
+		for (int d = 0; d < dim; d++)
+			out[(size_t) r * dim + d] = ndb_gen_element(kind, seed, center_seed, (uint64_t) (first_row + r), d, dim, components, sigma);
+	return NDBHIP_OK;
+}
+
 extern "C" int
 ndbhip_mfma_probe(const uint16_t *d_a, const uint16_t *d_b, const float *d_c, float *d_d, int ntiles, int chain)
 {
@@ -6174,6 +6248,15 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	float	   *d_cent = nullptr;
 	int		   *d_sasg = nullptr, *d_scnt = nullptr, *d_list = nullptr;
 	int			iters = 0, rc;
+	const bool	dbg = getenv("NDBHIP_DEBUG_BUILD") != nullptr;
+	auto		now = [&]() { if (dbg) (void) hipStreamSynchronize(g.stream); return std::chrono::steady_clock::now(); };
+	auto		t_start = now();
+	auto		lap = [&](const char *what) {
+		if (!dbg) return;
+		auto		t = now();
+		fprintf(stderr, "build: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count());
+		t_start = t;
+	};
 
 	HIP_TRY(hipMalloc((void **) &d_cent, (size_t) k * dim * sizeof(float)));
 	HIP_TRY(hipMalloc((void **) &d_sasg, (size_t) ns * sizeof(int)));
@@ -6181,14 +6264,27 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	rc = ndbhip_kmeans_device(d_rows, ns, dim, k, max_iter, 0.001f, d_cent, d_sasg, d_scnt, &iters, nullptr);
 	if (rc)
 		return rc;
+	lap("k-means on the sample");
 	HIP_TRY(hipFree(d_sasg));
 	HIP_TRY(hipFree(d_scnt));
 
 	/* every row goes to the list ivfinsert would choose (Q5: the reference leaves this to later INSERTs) */
 	HIP_TRY(hipMalloc((void **) &d_list, (size_t) nrows * sizeof(int)));
-	rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr);
+	lap("free + malloc list ids");
+	AssignWs	aws;				/* own workspace: assign_rows then returns without waiting for its kernels */
+
+	rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr, &aws);
 	if (rc)
 		return rc;
+	/* The packed mirror is allocated while the assignment kernels run: a fresh multi-GB hipMalloc is host-side
+	 * work (page-table setup) that took 0.3 ms in one process and 63 ms in the next on the same box — as much
+	 * as the rest of the build — and it needs nothing the GPU is busy with. */
+	float	   *d_prow = nullptr;
+	uint64_t   *d_ptid = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+	lap("assign every row (+ malloc of the packed rows under it)");
 
 	const uint32_t nblocks = (uint32_t) ((nrows + NDB_PACK_BLOCK - 1) / NDB_PACK_BLOCK);
 	const size_t nh = (size_t) k * nblocks;
@@ -6210,19 +6306,18 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 					   (const int64_t *) d_llen, d_scan);
 	HIP_TRY(hipMemcpyAsync(list_len.data(), d_llen, (size_t) k * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
 
-	float	   *d_prow = nullptr;
-	uint64_t   *d_ptid = nullptr;
-
-	HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+	lap("histograms / offsets");
 	hipLaunchKernelGGL(k_pack_scatter, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list,
 					   nrows, dim, nblocks, (const int64_t *) d_scan, d_rows, d_tids, d_prow, d_ptid);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(g.stream));
+	lap("scatter");
+	if (aws.release()) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipFree(d_hist));
 	HIP_TRY(hipFree(d_scan));
 	HIP_TRY(hipFree(d_list));
 	HIP_TRY(hipFree(d_llen));
+	lap("frees");
 
 	/* adopt: centroids + packed lists become the index */
 	if (ix->d_centroids)
@@ -6240,6 +6335,7 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	ix->norm_valid = false; ix->s16_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
+	lap("adopt (layout upload, old rows freed)");
 	if (out_iters)
 		*out_iters = iters;
 	return NDBHIP_OK;
@@ -6497,6 +6593,12 @@ int
 ndbhip_pages_fail(int code, const char *msg)
 {
 	return fail(code, "%s", msg);
+}
+
+extern "C" int
+ndbhip_ivf_dim(const ndbhip_ivf *ix)
+{
+	return ix ? ix->dim : fail(NDBHIP_ERR_INVALID, "index is NULL");
 }
 
 extern "C" int

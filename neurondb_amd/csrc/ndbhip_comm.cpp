@@ -1,0 +1,410 @@
+/*
+ * ndbhip_comm.cpp — the multi-GPU exchange of the sharded IVF search, inside the C ABI.
+ *
+ * One process per GPU; every rank holds a shard of the lists (ndbhip_ivf_shard / _shard_slices) and the same
+ * centroids.  ndbhip_ivf_search_sharded runs one batch:
+ *
+ *   1. this rank selects the probes of ITS slice of the queries (the selection is a pure function of query and
+ *      centroids: ivfSelectClusters, src/index/ivf_am.c:1597-1717) and the slices are all-gathered
+ *      (nq x nprobe x 4 bytes);
+ *   2. it scans the probed lists it holds for ALL queries and keeps, per query, its tie-complete subset
+ *      (<= 3k records of 16 bytes: float4 bits, position in the reference's candidates[], TID);
+ *   3. the records are all-gathered (nq x 3k x 16 bytes per rank) and the union is merged by replaying the
+ *      reference's selection sort (ivf_am.c:1856-1881; merge order of src/util/distributed.c:204-244: the
+ *      smaller distance first, ties by position = by the order a single backend would have met them).
+ *
+ * Two transports behind ndbhip_comm_allgather:
+ *   RCCL  (ndbhip_comm_init)      ncclAllGather on the library's stream, over xGMI between the GPUs of a node.
+ *         librccl is opened with dlopen when a communicator is created, so the library loads without it
+ *         (a PostgreSQL backend that never shards does not pull it in).
+ *   SHM   (ndbhip_comm_init_shm)  a POSIX shared-memory segment on the host: D2H, process-shared barrier, H2D.
+ *         For ranks that cannot form an RCCL communicator — several backends on ONE device (RCCL refuses two
+ *         ranks per device; tests/test_gpu_dist.py runs the whole flow that way) or a node without RCCL.
+ *
+ * Everything here sits on top of the public ABI (include/ndbhip.h): the comm layer owns no kernels.
+ */
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/ndbhip.h"
+
+extern "C" int ndbhip_internal_fail(int code, const char *fmt, ...);
+
+namespace
+{
+struct ShmHeader
+{
+	volatile uint32_t magic;		/* set last by rank 0 */
+	uint32_t	world;
+	uint64_t	slot_bytes;
+	pthread_barrier_t barrier;
+};
+
+struct RcclApi
+{
+	void	   *handle = nullptr;
+	ncclResult_t (*GetUniqueId) (ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank) (ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*AllGather) (const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*CommDestroy) (ncclComm_t) = nullptr;
+	const char *(*GetErrorString) (ncclResult_t) = nullptr;
+};
+
+struct Comm
+{
+	int			kind = 0;			/* 0 none, 1 RCCL, 2 SHM */
+	int			rank = 0, world = 1;
+	ncclComm_t	nccl = nullptr;
+	/* SHM */
+	std::string shm_name;
+	ShmHeader  *hdr = nullptr;
+	unsigned char *slots = nullptr;
+	size_t		map_bytes = 0, slot_bytes = 0;
+	/* workspace of ndbhip_ivf_search_sharded */
+	int		   *probes_mine = nullptr;	size_t probes_mine_n = 0;
+	int		   *probes_all = nullptr;	size_t probes_all_n = 0;
+	ndbhip_cand *cand = nullptr;		size_t cand_n = 0;
+	ndbhip_cand *cand_all = nullptr;	size_t cand_all_n = 0;
+	int		   *ncand = nullptr;		size_t ncand_n = 0;
+	int		   *ncand_all = nullptr;	size_t ncand_all_n = 0;
+	int64_t    *total = nullptr;		size_t total_n = 0;
+};
+
+RcclApi		rccl;
+Comm		comm;
+
+int
+load_rccl()
+{
+	if (rccl.handle)
+		return 0;
+	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+
+	for (const char *n : names)
+	{
+		rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+		if (rccl.handle)
+			break;
+	}
+	if (!rccl.handle)
+		return ndbhip_internal_fail(NDBHIP_ERR_UNSUPPORTED, "librccl not found: %s", dlerror());
+#define SYM(field, name)                                                              \
+	do {                                                                              \
+		*(void **) (&rccl.field) = dlsym(rccl.handle, name);                          \
+		if (!rccl.field)                                                              \
+			return ndbhip_internal_fail(NDBHIP_ERR_UNSUPPORTED, "librccl has no %s", name); \
+	} while (0)
+	SYM(GetUniqueId, "ncclGetUniqueId");
+	SYM(CommInitRank, "ncclCommInitRank");
+	SYM(AllGather, "ncclAllGather");
+	SYM(CommDestroy, "ncclCommDestroy");
+	SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+	return 0;
+}
+
+template <class T>
+int
+grow_dev(T *&p, size_t &have, size_t want)
+{
+	if (want <= have)
+		return 0;
+	if (p)
+		(void) hipFree(p);
+	p = nullptr;
+	have = 0;
+	if (hipMalloc((void **) &p, want * sizeof(T)) != hipSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "hipMalloc of %zu bytes failed", want * sizeof(T));
+	have = want;
+	return 0;
+}
+
+void
+free_workspace()
+{
+	void	   *ptrs[] = {comm.probes_mine, comm.probes_all, comm.cand, comm.cand_all, comm.ncand, comm.ncand_all, comm.total};
+
+	for (void *p : ptrs)
+		if (p)
+			(void) hipFree(p);
+	comm.probes_mine = comm.probes_all = nullptr;
+	comm.cand = comm.cand_all = nullptr;
+	comm.ncand = comm.ncand_all = nullptr;
+	comm.total = nullptr;
+	comm.probes_mine_n = comm.probes_all_n = comm.cand_n = comm.cand_all_n = comm.ncand_n = comm.ncand_all_n = comm.total_n = 0;
+}
+}	/* namespace */
+
+extern "C" int
+ndbhip_comm_unique_id(void *out_id)
+{
+	if (!out_id)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "out_id is NULL");
+	if (load_rccl())
+		return NDBHIP_ERR_UNSUPPORTED;
+	ncclUniqueId id;
+	const ncclResult_t r = rccl.GetUniqueId(&id);
+
+	if (r != ncclSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "ncclGetUniqueId: %s", rccl.GetErrorString(r));
+	static_assert(sizeof(id) == NDBHIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+	memcpy(out_id, &id, sizeof(id));
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_comm_init(const void *unique_id, int rank, int world)
+{
+	void	   *stream = nullptr;
+
+	if (ndbhip_get_stream(&stream))
+		return NDBHIP_ERR_NODEVICE;
+	if (comm.kind)
+		return ndbhip_internal_fail(NDBHIP_ERR_STATE, "a communicator already exists (ndbhip_comm_destroy first)");
+	if (!unique_id || world < 1 || rank < 0 || rank >= world)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad communicator arguments");
+	if (load_rccl())
+		return NDBHIP_ERR_UNSUPPORTED;
+	ncclUniqueId id;
+
+	memcpy(&id, unique_id, sizeof(id));
+	const ncclResult_t r = rccl.CommInitRank(&comm.nccl, world, id, rank);
+
+	if (r != ncclSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl.GetErrorString(r));
+	comm.kind = 1;
+	comm.rank = rank;
+	comm.world = world;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_comm_init_shm(const char *name, int rank, int world, size_t slot_bytes)
+{
+	void	   *stream = nullptr;
+
+	if (ndbhip_get_stream(&stream))
+		return NDBHIP_ERR_NODEVICE;
+	if (comm.kind)
+		return ndbhip_internal_fail(NDBHIP_ERR_STATE, "a communicator already exists (ndbhip_comm_destroy first)");
+	if (!name || name[0] != '/' || world < 1 || rank < 0 || rank >= world || slot_bytes < 4096)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad communicator arguments (name must start with '/')");
+	const size_t bytes = 4096 + (size_t) world * slot_bytes;
+	int			fd = -1;
+
+	if (rank == 0)
+	{
+		(void) shm_unlink(name);
+		fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+		if (fd < 0 || ftruncate(fd, (off_t) bytes) != 0)
+		{
+			if (fd >= 0) close(fd);
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "shm_open(%s): %s", name, strerror(errno));
+		}
+	}
+	else
+	{
+		/* wait (bounded) until rank 0 has created and sized the segment */
+		for (int tries = 0; tries < 3000; tries++)
+		{
+			struct stat st;
+
+			fd = shm_open(name, O_RDWR, 0600);
+			if (fd >= 0 && fstat(fd, &st) == 0 && (size_t) st.st_size >= bytes)
+				break;
+			if (fd >= 0) { close(fd); fd = -1; }
+			struct timespec ts = {0, 10 * 1000 * 1000};
+
+			nanosleep(&ts, nullptr);
+		}
+		if (fd < 0)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "shm segment %s did not appear", name);
+	}
+	void	   *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+
+	close(fd);
+	if (m == MAP_FAILED)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "mmap(%s): %s", name, strerror(errno));
+	ShmHeader  *h = (ShmHeader *) m;
+
+	if (rank == 0)
+	{
+		pthread_barrierattr_t at;
+
+		pthread_barrierattr_init(&at);
+		pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+		pthread_barrier_init(&h->barrier, &at, (unsigned) world);
+		pthread_barrierattr_destroy(&at);
+		h->world = (uint32_t) world;
+		h->slot_bytes = slot_bytes;
+		__sync_synchronize();
+		h->magic = 0x4E444243u;
+	}
+	else
+	{
+		for (int tries = 0; tries < 3000 && h->magic != 0x4E444243u; tries++)
+		{
+			struct timespec ts = {0, 10 * 1000 * 1000};
+
+			nanosleep(&ts, nullptr);
+		}
+		if (h->magic != 0x4E444243u || h->world != (uint32_t) world || h->slot_bytes != slot_bytes)
+		{
+			munmap(m, bytes);
+			return ndbhip_internal_fail(NDBHIP_ERR_STATE, "shm segment %s was not initialised for this group", name);
+		}
+	}
+	comm.kind = 2;
+	comm.rank = rank;
+	comm.world = world;
+	comm.shm_name = name;
+	comm.hdr = h;
+	comm.slots = (unsigned char *) m + 4096;
+	comm.map_bytes = bytes;
+	comm.slot_bytes = slot_bytes;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_comm_rank(void)
+{
+	return comm.kind ? comm.rank : 0;
+}
+
+extern "C" int
+ndbhip_comm_world(void)
+{
+	return comm.kind ? comm.world : 1;
+}
+
+extern "C" int
+ndbhip_comm_destroy(void)
+{
+	free_workspace();
+	if (comm.kind == 1 && comm.nccl)
+		(void) rccl.CommDestroy(comm.nccl);
+	if (comm.kind == 2 && comm.hdr)
+	{
+		munmap((void *) comm.hdr, comm.map_bytes);
+		if (comm.rank == 0)
+			(void) shm_unlink(comm.shm_name.c_str());
+	}
+	comm = Comm();
+	return NDBHIP_OK;
+}
+
+/* recv[r * bytes .. (r + 1) * bytes) = rank r's send; device pointers; ordered on the library's stream (RCCL:
+ * asynchronous; SHM: returns after the exchange) */
+extern "C" int
+ndbhip_comm_allgather(const void *d_send, void *d_recv, size_t bytes)
+{
+	void	   *sv = nullptr;
+
+	if (ndbhip_get_stream(&sv))
+		return NDBHIP_ERR_NODEVICE;
+	hipStream_t stream = (hipStream_t) sv;
+
+	if (bytes == 0)
+		return NDBHIP_OK;
+	if (!d_send || !d_recv)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	if (comm.kind == 0 || comm.world == 1)
+	{
+		if (hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "hipMemcpyAsync failed");
+		return NDBHIP_OK;
+	}
+	if (comm.kind == 1)
+	{
+		const ncclResult_t r = rccl.AllGather(d_send, d_recv, bytes, ncclInt8, comm.nccl, stream);
+
+		if (r != ncclSuccess)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "ncclAllGather: %s", rccl.GetErrorString(r));
+		return NDBHIP_OK;
+	}
+	if (bytes > comm.slot_bytes)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "all-gather of %zu bytes per rank exceeds the segment's slots (%zu)",
+									bytes, comm.slot_bytes);
+	if (hipMemcpyAsync(comm.slots + (size_t) comm.rank * comm.slot_bytes, d_send, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		hipStreamSynchronize(stream) != hipSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "device-to-host copy failed");
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot is written */
+	for (int r = 0; r < comm.world; r++)
+		if (hipMemcpyAsync((unsigned char *) d_recv + (size_t) r * bytes, comm.slots + (size_t) r * comm.slot_bytes, bytes,
+						   hipMemcpyHostToDevice, stream) != hipSuccess)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "host-to-device copy failed");
+	if (hipStreamSynchronize(stream) != hipSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "stream synchronisation failed");
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot has been read: it may be overwritten */
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_search_sharded(ndbhip_ivf *shard, const float *d_queries, int nq, int strategy, int nprobe, int k,
+						  int64_t max_candidates, uint64_t *d_out_tids, float *d_out_dist, int *d_out_count)
+{
+	void	   *sv = nullptr;
+
+	if (ndbhip_get_stream(&sv))
+		return NDBHIP_ERR_NODEVICE;
+	if (!shard || nq < 0 || (nq > 0 && (!d_queries || !d_out_tids || !d_out_dist || !d_out_count)))
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nprobe < 1 || nprobe > NDBHIP_MAX_NPROBE || k < 1 || k > NDBHIP_MAX_K)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "nprobe / k out of range");
+	if (nq == 0)
+		return NDBHIP_OK;
+	const int	world = ndbhip_comm_world(), rank = ndbhip_comm_rank();
+	const int	dim = ndbhip_ivf_dim(shard);
+	const int	s = (nq + world - 1) / world;			/* padded slice: every rank sends the same count */
+	const int	lo = std::min(rank * s, nq), hi = std::min((rank + 1) * s, nq);
+	const size_t cap = (size_t) NDBHIP_PARTIAL_CAP(k);
+	int			rc;
+
+	if (dim < 1)
+		return NDBHIP_ERR_INVALID;
+	if ((rc = grow_dev(comm.probes_mine, comm.probes_mine_n, (size_t) s * nprobe)) != 0) return rc;
+	if ((rc = grow_dev(comm.probes_all, comm.probes_all_n, (size_t) world * s * nprobe)) != 0) return rc;
+	if ((rc = grow_dev(comm.cand, comm.cand_n, (size_t) nq * cap)) != 0) return rc;
+	if ((rc = grow_dev(comm.cand_all, comm.cand_all_n, (size_t) world * nq * cap)) != 0) return rc;
+	if ((rc = grow_dev(comm.ncand, comm.ncand_n, (size_t) nq)) != 0) return rc;
+	if ((rc = grow_dev(comm.ncand_all, comm.ncand_all_n, (size_t) world * nq)) != 0) return rc;
+	if ((rc = grow_dev(comm.total, comm.total_n, (size_t) nq)) != 0) return rc;
+
+	/* 1. cluster selection, split by queries */
+	if (hi > lo)
+	{
+		rc = ndbhip_ivf_select_clusters_device(shard, d_queries + (size_t) lo * dim, hi - lo, nprobe, comm.probes_mine);
+		if (rc)
+			return rc;
+	}
+	rc = ndbhip_comm_allgather(comm.probes_mine, comm.probes_all, (size_t) s * nprobe * sizeof(int));
+	if (rc)
+		return rc;
+	/* 2. this shard's lists for all queries */
+	rc = ndbhip_ivf_search_partial_probes_device(shard, d_queries, nq, strategy, nprobe, k, max_candidates,
+												 comm.probes_all, comm.cand, comm.ncand, comm.total);
+	if (rc)
+		return rc;
+	/* 3. records of every rank, then the replay merge */
+	rc = ndbhip_comm_allgather(comm.cand, comm.cand_all, (size_t) nq * cap * sizeof(ndbhip_cand));
+	if (rc)
+		return rc;
+	rc = ndbhip_comm_allgather(comm.ncand, comm.ncand_all, (size_t) nq * sizeof(int));
+	if (rc)
+		return rc;
+	return ndbhip_merge_topk_device(comm.cand_all, comm.ncand_all, comm.total, world, nq, k, (int) cap,
+									d_out_tids, d_out_dist, d_out_count);
+}

@@ -388,14 +388,15 @@ typedef const __attribute__((address_space(1))) void *ndb_glb_ptr;
  * buffers are a ring with a run-time index — which waits for the chunk just requested and serialises the whole
  * pipeline (measured: the 3-deep ring ran slower than the 2-deep one).  The kernel orders DMA against reads
  * itself: s_waitcnt vmcnt(n) + barrier before a buffer is read, a barrier before it is refilled.  M0 is
- * written here and nowhere else in the kernel (tools/check_asm_hazards.py checks that); one wait state between
- * the SALU write of M0 and its use.
+ * written here and nowhere else in the kernel (tools/check_asm_hazards.py checks that — M0 is a reserved
+ * register hipcc does not model as a clobber, so the guarantee has to come from the generated code); one wait
+ * state between the SALU write of M0 and its use.
  */
 __device__ __forceinline__ void
 s16_dma16(const unsigned char *base, uint32_t voff, uint32_t la)
 {
 	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-				 :: "s"(la), "v"(voff), "s"(base) : "memory", "m0");
+				 :: "s"(la), "v"(voff), "s"(base) : "memory");
 }
 
 /* the same for a piece that is contiguous on both sides: N instructions, lane i of instruction j copies the 16
@@ -408,11 +409,11 @@ s16_dma_linear(const unsigned char *base, uint32_t lane16, uint32_t la)
 		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
 					 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
 					 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
-					 :: "s"(la), "v"(lane16), "s"(base) : "memory", "m0");
+					 :: "s"(la), "v"(lane16), "s"(base) : "memory");
 	else
 		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
 					 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
-					 :: "s"(la), "v"(lane16), "s"(base) : "memory", "m0");
+					 :: "s"(la), "v"(lane16), "s"(base) : "memory");
 }
 
 __device__ __forceinline__ const unsigned char *

@@ -75,6 +75,26 @@ def partition_slices(list_len, world: int, probe_count=None, split_frac: float =
     return lo, length, tail
 
 
+def init_library_comm(group=None, device=None):
+    """Create the library's own RCCL communicator (ndbhip_comm_init) for the ranks of a torch.distributed group:
+    rank 0 draws the unique id, torch.distributed only carries its 128 bytes to the others.  After this
+    IvfIndex.search_sharded_device exchanges inside the C library — the path a PostgreSQL backend uses."""
+    import ctypes as C
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu")
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        check(lib().ndbhip_comm_unique_id(C.byref(buf)))
+        ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+    ident = ident.to(dev)
+    dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    raw = bytes(ident.cpu().numpy().tobytes())
+    check(lib().ndbhip_comm_init(C.c_char_p(raw), rank, world))
+    return rank, world
+
+
 def partial_cap(k: int) -> int:
     return 3 * k            # NDBHIP_PARTIAL_CAP
 

@@ -190,6 +190,16 @@ class IvfIndex:
                                              int(max_candidates), C.c_void_p(out_tids.data_ptr()),
                                              C.c_void_p(out_dist.data_ptr()), C.c_void_p(out_count.data_ptr())))
 
+    def search_sharded_device(self, d_queries, out_tids, out_dist, out_count, strategy=1, nprobe=IVF_DEFAULT_NPROBE,
+                              k=IVF_DEFAULT_K, max_candidates=0):
+        """One batch on this rank's shard with the exchange done inside the library (ndbhip_ivf_search_sharded:
+        probe all-gather, record all-gather, replay merge over the communicator of ndbhip_comm_init /
+        ndbhip_comm_init_shm); every rank gets the full result.  Asynchronous on the library's stream over RCCL."""
+        nq = d_queries.shape[0]
+        check(lib().ndbhip_ivf_search_sharded(self._h, C.c_void_p(d_queries.data_ptr()), nq, strategy, nprobe, k,
+                                              int(max_candidates), C.c_void_p(out_tids.data_ptr()),
+                                              C.c_void_p(out_dist.data_ptr()), C.c_void_p(out_count.data_ptr())))
+
     def search_partial_device(self, d_queries, out_cand, out_ncand, out_total, strategy=1,
                               nprobe=IVF_DEFAULT_NPROBE, k=IVF_DEFAULT_K, max_candidates=0):
         nq = d_queries.shape[0]

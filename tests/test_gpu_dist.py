@@ -1,7 +1,10 @@
 """The N > 1 flow end to end on ONE device: two processes share cuda:0, hold one shard each
-(IvfIndex.shard / shard_slices), and run neurondb_amd.dist.sharded_search — query-split cluster selection, probe
-all-gather, per-shard scan, record all-gather, replay merge — over a gloo group (RCCL refuses two ranks
-on one device; the 8-GPU run of bench.py uses the same code over RCCL).  Result == the oracle's."""
+(IvfIndex.shard / shard_slices), and run the sharded search — query-split cluster selection, probe all-gather,
+per-shard scan, record all-gather, replay merge.  Result == the oracle's.
+  * through the C ABI (ndbhip_ivf_search_sharded, csrc/ndbhip_comm.cpp) over the library's shared-memory
+    transport (RCCL refuses two ranks on one device), and in one process over a world-1 RCCL communicator — the
+    same function bench.py --gpus N runs over RCCL;
+  * through neurondb_amd.dist.sharded_search over a gloo group (the torch.distributed form of the same steps)."""
 import os
 import socket
 
@@ -77,3 +80,98 @@ def test_two_ranks_one_device_sharded_search_equals_oracle(slices):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), slices, ret), nprocs=world, join=True)
     assert all(ret.get(r) is True for r in range(world)), dict(ret)
+
+
+def _worker_c(rank, world, name, slices, ret):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        from neurondb_amd import IvfIndex, _lib
+        from neurondb_amd.dist import partition_lists, partition_slices
+        _lib.ensure_init(0)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        _lib.use_torch_stream()
+        a = make_ivf_arrays(6000, 96, 20, seed=61, dup_frac=0.1)
+        img = oracle_image(a)
+        rng = np.random.default_rng(62)
+        nq, k, nprobe = 157, 10, 5                      # ragged query slices; >= 128 queries: the fp16 matrix-core screen
+        q = a["rows"][rng.integers(0, len(a["rows"]), nq)] + rng.standard_normal((nq, 96)).astype(np.float32) * 0.05
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        full = IvfIndex(96, 20)
+        full.set_centroids(a["centroids"])
+        full.load(a["list_len"], a["rows"], a["tids"])
+        if slices:
+            lo, ln, tail = partition_slices(a["list_len"], world, None, split_frac=0.0, align=16)
+            ix = full.shard_slices(lo[rank], ln[rank], tail[rank])
+        else:
+            owner = partition_lists(a["list_len"], world)
+            ix = full.shard((owner == rank).astype(np.uint8))
+        full.close()
+        _lib.check(_lib.lib().ndbhip_comm_init_shm(name.encode(), rank, world, 1 << 20))
+        assert _lib.lib().ndbhip_comm_world() == world and _lib.lib().ndbhip_comm_rank() == rank
+        dq = torch.from_numpy(q).to(dev)
+        ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+        od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+        ok = True
+        for strategy in (1, 3):
+            ix.search_sharded_device(dq, ot, od, oc, strategy, nprobe, k, 0)
+            _lib.check(_lib.lib().ndbhip_synchronize())
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k)
+            ok &= bool(np.array_equal(oc.cpu().numpy(), ec))
+            ok &= bool(np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et))
+            ok &= bool(np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32)))
+        _lib.check(_lib.lib().ndbhip_comm_destroy())
+        ret[rank] = ok
+    except Exception as e:
+        ret[rank] = f"{type(e).__name__}: {e}"
+
+
+@pytest.mark.parametrize("slices", [False, True])
+def test_c_abi_sharded_search_two_ranks_over_shared_memory(slices):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_c, args=(world, f"/ndbhip_test_{os.getpid()}_{int(slices)}", slices, ret), nprocs=world, join=True)
+    assert all(ret.get(r) is True for r in range(world)), dict(ret)
+
+
+def test_c_abi_sharded_search_over_a_world_1_rccl_communicator():
+    """ncclCommInitRank / ncclAllGather really run (one rank): the RCCL transport of ndbhip_comm.cpp, as far as
+    one device can exercise it."""
+    import ctypes as C
+    from neurondb_amd import IvfIndex, _lib
+    _lib.ensure_init(0)
+    L = _lib.lib()
+    a = make_ivf_arrays(5000, 64, 16, seed=71, dup_frac=0.05)
+    img = oracle_image(a)
+    rng = np.random.default_rng(72)
+    nq, k, nprobe = 140, 10, 6
+    q = np.ascontiguousarray(a["rows"][rng.integers(0, 5000, nq)] +
+                             0.05 * rng.standard_normal((nq, 64)), dtype=np.float32)
+    ix = IvfIndex(64, 16)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    ident = (C.c_ubyte * 128)()
+    _lib.check(L.ndbhip_comm_unique_id(C.byref(ident)))
+    _lib.check(L.ndbhip_comm_init(C.byref(ident), 0, 1))
+    try:
+        dev = torch.device("cuda", 0)
+        dq = torch.from_numpy(q).to(dev)
+        ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+        od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+        # the raw collective first
+        src = torch.arange(1000, dtype=torch.int32, device=dev)
+        dst = torch.zeros(1000, dtype=torch.int32, device=dev)
+        _lib.check(L.ndbhip_comm_allgather(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 4000))
+        ix.search_sharded_device(dq, ot, od, oc, 1, nprobe, k, 0)
+        _lib.check(L.ndbhip_synchronize())
+        assert torch.equal(src, dst)
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+        assert np.array_equal(oc.cpu().numpy(), ec)
+        assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
+        assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+    finally:
+        _lib.check(L.ndbhip_comm_destroy())
+        ix.close()

@@ -73,8 +73,42 @@ def check(path, want=("k_ivf_scan_grouped", "k_ivf_bound_coop", "k_assign_groupe
     return seen, bad
 
 
+def check_m0(path, want=("k_s16_sweep",)):
+    """k_s16_sweep writes M0 inside its LDS-DMA asm statements (s_mov_b32 m0 + global_load_lds_dwordx4) and hipcc
+    does not model M0 as an asm clobber (it is a reserved register).  That is only safe while nothing the
+    COMPILER emitted in the same kernel reads or writes M0: every mention of m0 must sit inside an asm block."""
+    s = open(path).read()
+    bad, seen = [], 0
+    for m in re.finditer(r"^(_Z\w+):\s*; @", s, re.M):
+        sym = m.group(1)
+        if not any(w in sym for w in want):
+            continue
+        end = s.index(".end_amdhsa_kernel", m.end())
+        body = s[m.end():end]
+        code = body[:body.index(".amdhsa_kernel")] if ".amdhsa_kernel" in body else body
+        in_asm = False
+        for line in code.split("\n"):
+            t = line.strip()
+            if t.startswith(";;#ASMSTART") or t.startswith(";APP"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND") or t.startswith(";NO_APP"):
+                in_asm = False
+                continue
+            ins = t.split(";")[0]
+            if re.search(r"\bm0\b", ins):
+                if in_asm:
+                    seen += 1
+                else:
+                    bad.append((sym[:48], ins.strip(), "m0 outside the DMA asm"))
+    return seen, bad
+
+
 if __name__ == "__main__":
     seen, bad = check(sys.argv[1])
+    seen_m0, bad_m0 = check_m0(sys.argv[1])
+    print(f"{seen_m0} M0 writes inside asm, {len(bad_m0)} uses of M0 by compiler-generated code")
+    bad = bad + bad_m0
     print(f"{seen} asm loads checked, {len(bad)} hazards")
     for b in bad[:20]:
         print("  ", b)

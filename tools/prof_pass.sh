@@ -5,7 +5,7 @@ set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --recall-queries 0 --hnsw-nvec 0 "$@" > /tmp/prof_$tag.json 2> /tmp/prof_$tag.log </dev/null
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --recall-queries 0 --hnsw-nvec 0 --gauss-steps 0 "$@" > /tmp/prof_$tag.json 2> /tmp/prof_$tag.log </dev/null
 f=$(find /tmp/prof_$tag -name "*.db" | head -1)
 if [ -z "$f" ]; then echo "no db for $tag"; grep -v amdgpu /tmp/prof_$tag.log | tail -8; exit 0; fi
 python3 $GRAFT_REPO_ROOT/tools/rocpd_summary.py $f 40 > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.txt </dev/null
