@@ -66,6 +66,10 @@ typedef struct ndb_index_scan
  * Returns NDBHIP_ERR_INVALID for an unknown name or an out-of-range value. */
 int			ndb_am_set_guc(const char *name, int value);
 int			ndb_am_get_guc(const char *name, int *value);
+/* GUC neurondb.device_service (a string: the shared-memory name of the device-owner process, include/ndb_service.h;
+ * NULL or "" detaches).  While set, an ivf scan opened with index == NULL is answered by that process: the
+ * backend itself never initialises HIP and holds no mirror.  Connect failure = NDBHIP_ERR_NODEVICE. */
+int			ndb_am_use_service(const char *name);
 
 /* ivf: src/index/ivf_am.c:1412-1437 / 1439-1545 / 1911-2027 / 2029-2048 */
 ndb_index_scan *ndb_ivfbeginscan(ndbhip_ivf *index, int nkeys, int norderbys);

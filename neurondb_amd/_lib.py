@@ -32,15 +32,20 @@ class Stats(C.Structure):
                 ("rows_emitted", C.c_uint64), ("screen16_batches", C.c_uint64), ("screen16_fallbacks", C.c_uint64)]
 
 
+class ServiceStats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("queries", C.c_uint64), ("max_batch", C.c_uint64), ("busy_s", C.c_double)]
+
+
 def lib_path() -> str:
     return _LIB
 
 
 def declared_symbols() -> list:
     """Every function include/*.h declares (ndbhip.h: the C ABI; ndb_am.h: the AM callbacks over it; ndb_sql.h:
-    the SQL-level batch functions over it; ndb_backend.h: the GPU plugin vtable over it)."""
+    the SQL-level batch functions over it; ndb_backend.h: the GPU plugin vtable over it; ndb_service.h: the
+    device-owner process and its shared-memory ring)."""
     out = set()
-    for name in ("ndbhip.h", "ndb_am.h", "ndb_sql.h", "ndb_backend.h"):
+    for name in ("ndbhip.h", "ndb_am.h", "ndb_sql.h", "ndb_backend.h", "ndb_service.h"):
         with open(os.path.join(_ROOT, "include", name)) as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -209,6 +214,21 @@ def lib():
         "ndbhip_kmeans_update": (i, [vp, vp, vp, i, i, i]),
         "ndbhip_quant_fp16": (i, [vp, vp, i64]),
         # include/ndb_am.h
+        "ndb_service_create": (i, [C.c_char_p, i, i, i, C.POINTER(vp)]),
+        "ndb_service_destroy": (i, [vp]),
+        "ndb_service_poll": (i, [vp, i, i, i, vp, vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i64)]),
+        "ndb_service_complete": (i, [vp, i, vp, vp, vp, vp, i, i]),
+        "ndb_service_serve_ivf": (i, [vp, vp, i, i, i64, C.POINTER(ServiceStats)]),
+        "ndb_service_stop": (i, [vp]),
+        "ndb_service_stopped": (i, [vp]),
+        "ndb_client_connect": (i, [C.c_char_p, C.POINTER(vp)]),
+        "ndb_client_disconnect": (i, [vp]),
+        "ndb_client_dim": (i, [vp]),
+        "ndb_client_stop_service": (i, [vp]),
+        "ndb_client_submit": (i, [vp, vp, i, i, i, i64, C.POINTER(i)]),
+        "ndb_client_wait": (i, [vp, i, vp, vp, C.POINTER(i), i]),
+        "ndb_client_search": (i, [vp, vp, i, i, i, i64, vp, vp, C.POINTER(i), i]),
+        "ndb_am_use_service": (i, [C.c_char_p]),
         "ndb_am_set_guc": (i, [C.c_char_p, i]),
         "ndb_am_get_guc": (i, [C.c_char_p, C.POINTER(i)]),
         "ndb_ivfbeginscan": (C.POINTER(NdbIndexScan), [vp, i, i]),

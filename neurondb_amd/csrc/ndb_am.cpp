@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ndb_am.h"
+#include "../../include/ndb_service.h"
 
 int			ndbhip_pages_fail(int code, const char *msg);	/* sets the thread-local error text (ndbhip.hip) */
 
@@ -17,6 +18,10 @@ int			ndbhip_pages_fail(int code, const char *msg);	/* sets the thread-local err
 #define IVF_DEFAULT_K 10			/* so->k = 10: ivf_am.c:1421 */
 #define HNSW_DEFAULT_EF_SEARCH 64	/* src/index/hnsw_am.c:83 */
 #define HNSW_DEFAULT_K 10			/* hnsw_am.c:974 */
+
+/* neurondb.device_service: when set, this backend does not touch the device — its index scans go to the
+ * device-owner process through the shared-memory ring (include/ndb_service.h) */
+static ndb_client *am_client = nullptr;
 
 /* ---- GUCs ------------------------------------------------------------------------------------ */
 static int	guc_ivf_probes = IVF_DEFAULT_NPROBE;
@@ -36,6 +41,19 @@ guc_slot(const char *name, int *lo, int *hi)
 	if (!strcmp(name, "neurondb.hnsw_k")) { *lo = 0; *hi = NDBHIP_MAX_K; return &guc_hnsw_k; }
 	if (!strcmp(name, "neurondb.ref_compat")) { *lo = 0; *hi = 1; return &guc_ref_compat; }
 	return nullptr;
+}
+
+extern "C" int
+ndb_am_use_service(const char *name)
+{
+	if (am_client)
+	{
+		ndb_client_disconnect(am_client);
+		am_client = nullptr;
+	}
+	if (!name || !name[0])
+		return NDBHIP_OK;
+	return ndb_client_connect(name, &am_client);
 }
 
 extern "C" int
@@ -83,7 +101,7 @@ struct ScanOpaque
 static ndb_index_scan *
 begin_scan(void *index, int nkeys, int norderbys)
 {
-	if (!index)
+	if (!index && !am_client)	/* (a NULL index is the device-owner process's: ndb_am_use_service) */
 	{
 		ndbhip_pages_fail(NDBHIP_ERR_INVALID, "index is NULL");
 		return nullptr;
@@ -192,7 +210,28 @@ ndb_ivfgettuple(ndb_index_scan *scan, int direction)
 
 	if (!so->haveQuery)			/* :1921-1925 */
 		return 0;
-	if (so->firstCall)
+	if (so->firstCall && !ix && am_client)
+	{
+		/* a backend without a mirror of its own: the device-owner process answers (its mirror knows whether the
+		 * index is empty; a query of another dimension is "no rows", :1961-1972) */
+		int			count = 0;
+
+		so->firstCall = false;
+		so->currentResult = 0;
+		so->resultCount = 0;
+		if ((int) so->queryVector.size() != ndb_client_dim(am_client))
+			return 0;
+		so->results.assign((size_t) so->k * 6, 0);
+		so->distances.assign((size_t) so->k, 0.0f);
+		const int	rc = ndb_client_search(am_client, so->queryVector.data(), so->strategy, so->nprobe, so->k,
+										   guc_ref_compat ? (int64_t) so->k * 10 : 0, so->results.data(),
+										   so->distances.data(), &count, 30000);
+
+		if (rc)
+			return rc;			/* NDBHIP_ERR_NODEVICE: the caller applies neurondb.compute_mode (CPU scan or ERROR) */
+		so->resultCount = count;
+	}
+	else if (so->firstCall)
 	{
 		int			dim = 0;
 		int			rc = ndbhip_ivf_shape(ix, &dim, nullptr);

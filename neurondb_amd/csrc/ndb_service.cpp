@@ -1,0 +1,500 @@
+/*
+ * ndb_service.cpp — see include/ndb_service.h: a shared-memory submission ring between PostgreSQL backends
+ * (clients) and the one process that owns the device and the index mirror.
+ */
+#include <errno.h>
+#include <fcntl.h>
+#include <linux/futex.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ndb_service.h"
+
+extern "C" int ndbhip_internal_fail(int code, const char *fmt, ...);
+
+namespace
+{
+enum : uint32_t { S_FREE = 0, S_CLAIMED = 1, S_READY = 2, S_RUNNING = 3, S_DONE = 4 };
+const uint32_t MAGIC = 0x4E445356u;		/* "NDSV" */
+
+struct Header
+{
+	std::atomic<uint32_t> magic;
+	uint32_t	dim, max_k, nslots;
+	uint64_t	slot_bytes;
+	std::atomic<uint32_t> submitted;	/* bumped by every submit: the owner sleeps on it */
+	std::atomic<uint32_t> stop;
+	std::atomic<uint32_t> cursor;		/* where clients start looking for a free slot */
+	std::atomic<uint64_t> seq;			/* arrival order */
+};
+
+struct Slot
+{
+	std::atomic<uint32_t> state;
+	int32_t		status;
+	int32_t		strategy, nprobe, k, count;
+	int64_t		max_candidates;
+	uint64_t	seq;
+	/* followed by: float query[dim]; float dist[max_k]; uint8_t tids6[max_k][6] */
+};
+
+static_assert(std::atomic<uint32_t>::is_always_lock_free, "futex words must be plain 32-bit atomics");
+
+size_t
+slot_bytes_for(int dim, int max_k)
+{
+	size_t		b = sizeof(Slot) + (size_t) dim * 4 + (size_t) max_k * 4 + (size_t) max_k * 6;
+
+	return (b + 63) & ~(size_t) 63;
+}
+
+long
+futex(std::atomic<uint32_t> *addr, int op, uint32_t val, const struct timespec *ts)
+{
+	return syscall(SYS_futex, (uint32_t *) addr, op, val, ts, nullptr, 0);
+}
+
+struct Map
+{
+	void	   *base = nullptr;
+	size_t		bytes = 0;
+	Header	   *h = nullptr;
+	unsigned char *slots = nullptr;
+	Slot *slot(uint32_t i) const { return (Slot *) (slots + (size_t) i * h->slot_bytes); }
+	float *query(Slot *s) const { return (float *) (s + 1); }
+	float *dist(Slot *s) const { return query(s) + h->dim; }
+	uint8_t *tids(Slot *s) const { return (uint8_t *) (dist(s) + h->max_k); }
+};
+}	/* namespace */
+
+struct ndb_service
+{
+	Map			m;
+	std::string name;
+};
+
+struct ndb_client
+{
+	Map			m;
+};
+
+extern "C" int
+ndb_service_create(const char *name, int dim, int max_k, int nslots, ndb_service **out)
+{
+	if (!name || name[0] != '/' || !out || dim < 1 || dim > 32767 || max_k < 1 || max_k > NDBHIP_MAX_K || nslots < 1 || nslots > (1 << 20))
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad service arguments (name must start with '/')");
+	const size_t sb = slot_bytes_for(dim, max_k);
+	const size_t bytes = 4096 + sb * (size_t) nslots;
+
+	(void) shm_unlink(name);
+	const int	fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+
+	if (fd < 0 || ftruncate(fd, (off_t) bytes) != 0)
+	{
+		if (fd >= 0) close(fd);
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "shm_open(%s): %s", name, strerror(errno));
+	}
+	void	   *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+
+	close(fd);
+	if (p == MAP_FAILED)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "mmap(%s): %s", name, strerror(errno));
+	memset(p, 0, bytes);
+	ndb_service *s = new (std::nothrow) ndb_service();
+
+	if (!s)
+	{
+		munmap(p, bytes);
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	}
+	s->name = name;
+	s->m.base = p;
+	s->m.bytes = bytes;
+	s->m.h = (Header *) p;
+	s->m.slots = (unsigned char *) p + 4096;
+	s->m.h->dim = (uint32_t) dim;
+	s->m.h->max_k = (uint32_t) max_k;
+	s->m.h->nslots = (uint32_t) nslots;
+	s->m.h->slot_bytes = sb;
+	s->m.h->magic.store(MAGIC, std::memory_order_release);
+	*out = s;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_service_destroy(ndb_service *s)
+{
+	if (!s)
+		return NDBHIP_OK;
+	s->m.h->stop.store(1);
+	s->m.h->magic.store(0);
+	munmap(s->m.base, s->m.bytes);
+	(void) shm_unlink(s->name.c_str());
+	delete s;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_service_stop(ndb_service *s)
+{
+	if (!s)
+		return NDBHIP_ERR_INVALID;
+	s->m.h->stop.store(1);
+	s->m.h->submitted.fetch_add(1);
+	futex(&s->m.h->submitted, FUTEX_WAKE, 1 << 30, nullptr);
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_service_stopped(const ndb_service *s)
+{
+	return s ? (int) s->m.h->stop.load() : 1;
+}
+
+extern "C" int
+ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int *slot_ids, float *queries,
+				 int *strategy, int *nprobe, int *k, int64_t *max_candidates)
+{
+	if (!s || max_batch < 1 || !slot_ids || !queries || !strategy || !nprobe || !k || !max_candidates)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad poll arguments");
+	Header	   *h = s->m.h;
+	const auto	t0 = std::chrono::steady_clock::now();
+	auto		us_since = [&](std::chrono::steady_clock::time_point t) {
+		return (int64_t) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count();
+	};
+	int			n = 0;
+	bool		have_key = false;
+	auto		last_gain = t0;
+
+	for (;;)
+	{
+		if (h->stop.load(std::memory_order_acquire) && n == 0)
+			return 0;
+		const uint32_t seen = h->submitted.load(std::memory_order_acquire);
+		/* oldest first: a backend must not starve behind newer arrivals with another parameter set */
+		if (!have_key)
+		{
+			uint64_t	best = ~0ull;
+			int			bi = -1;
+
+			for (uint32_t i = 0; i < h->nslots; i++)
+			{
+				Slot	   *sl = s->m.slot(i);
+
+				if (sl->state.load(std::memory_order_acquire) == S_READY && sl->seq < best)
+				{
+					best = sl->seq;
+					bi = (int) i;
+				}
+			}
+			if (bi >= 0)
+			{
+				Slot	   *sl = s->m.slot((uint32_t) bi);
+
+				*strategy = sl->strategy; *nprobe = sl->nprobe; *k = sl->k; *max_candidates = sl->max_candidates;
+				have_key = true;
+			}
+		}
+		int			gained = 0;
+
+		if (have_key)
+			for (uint32_t i = 0; i < h->nslots && n < max_batch; i++)
+			{
+				Slot	   *sl = s->m.slot(i);
+				uint32_t	st = S_READY;
+
+				if (sl->state.load(std::memory_order_acquire) != S_READY)
+					continue;
+				if (sl->strategy != *strategy || sl->nprobe != *nprobe || sl->k != *k || sl->max_candidates != *max_candidates)
+					continue;
+				if (!sl->state.compare_exchange_strong(st, S_RUNNING, std::memory_order_acq_rel))
+					continue;
+				memcpy(queries + (size_t) n * h->dim, s->m.query(sl), (size_t) h->dim * 4);
+				slot_ids[n++] = (int) i;
+				gained++;
+			}
+		if (gained)
+			last_gain = std::chrono::steady_clock::now();
+		if (n >= max_batch)
+			return n;
+		if (n > 0)
+		{
+			if (us_since(last_gain) >= linger_us)
+				return n;
+			/* linger: a short sleep, not a futex — arrivals are expected within microseconds */
+			struct timespec ts = {0, 5 * 1000};
+
+			nanosleep(&ts, nullptr);
+			continue;
+		}
+		const int64_t left = (int64_t) wait_us - us_since(t0);
+
+		if (left <= 0)
+			return 0;
+		struct timespec ts = {(time_t) (left / 1000000), (long) (left % 1000000) * 1000};
+
+		futex(&h->submitted, FUTEX_WAIT, seen, &ts);	/* returns at once if something was submitted meanwhile */
+	}
+}
+
+extern "C" int
+ndb_service_complete(ndb_service *s, int n, const int *slot_ids, const uint8_t *tids6, const float *dist,
+					 const int *count, int k, int status)
+{
+	if (!s || n < 0 || (n > 0 && !slot_ids))
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad complete arguments");
+	Header	   *h = s->m.h;
+
+	for (int i = 0; i < n; i++)
+	{
+		Slot	   *sl = s->m.slot((uint32_t) slot_ids[i]);
+
+		sl->status = status;
+		sl->count = 0;
+		if (status == 0 && tids6 && dist && count)
+		{
+			const int	c = count[i] < (int) h->max_k ? count[i] : (int) h->max_k;
+
+			sl->count = c;
+			memcpy(s->m.dist(sl), dist + (size_t) i * k, (size_t) c * 4);
+			memcpy(s->m.tids(sl), tids6 + (size_t) i * k * 6, (size_t) c * 6);
+		}
+		sl->state.store(S_DONE, std::memory_order_release);
+		futex(&sl->state, FUTEX_WAKE, 1 << 30, nullptr);
+	}
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_us, int64_t max_batches,
+					  ndb_service_stats *stats)
+{
+	if (!s || !ix || max_batch < 1)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad serve arguments");
+	Header	   *h = s->m.h;
+
+	if (ndbhip_ivf_dim(ix) != (int) h->dim)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "service dim %u != index dim %d", h->dim, ndbhip_ivf_dim(ix));
+	std::vector<int> ids((size_t) max_batch), cnt((size_t) max_batch);
+	std::vector<float> q((size_t) max_batch * h->dim), dist((size_t) max_batch * h->max_k);
+	std::vector<uint8_t> tids((size_t) max_batch * h->max_k * 6);
+	ndb_service_stats st = {0, 0, 0, 0.0};
+	int			rc_last = NDBHIP_OK;
+
+	while (!h->stop.load(std::memory_order_acquire) && (max_batches <= 0 || (int64_t) st.batches < max_batches))
+	{
+		int			strategy, nprobe, k;
+		int64_t		cap;
+		const int	n = ndb_service_poll(s, max_batch, 50 * 1000, linger_us, ids.data(), q.data(), &strategy, &nprobe, &k, &cap);
+
+		if (n <= 0)
+			continue;
+		const auto	t0 = std::chrono::steady_clock::now();
+		int			rc = (k < 1 || k > (int) h->max_k) ? ndbhip_internal_fail(NDBHIP_ERR_INVALID, "k %d beyond the service's max_k %u", k, h->max_k)
+			: ndbhip_ivf_search(ix, q.data(), n, strategy, nprobe, k, cap, tids.data(), dist.data(), cnt.data());
+
+		ndb_service_complete(s, n, ids.data(), tids.data(), dist.data(), cnt.data(), k, rc);
+		st.busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		st.batches++;
+		st.queries += (uint64_t) n;
+		if ((uint64_t) n > st.max_batch)
+			st.max_batch = (uint64_t) n;
+		if (rc)
+			rc_last = rc;
+	}
+	if (stats)
+		*stats = st;
+	return rc_last;
+}
+
+/* ------------------------------------------------------------------ */
+/* backend side                                                        */
+/* ------------------------------------------------------------------ */
+extern "C" int
+ndb_client_connect(const char *name, ndb_client **out)
+{
+	if (!name || !out)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad connect arguments");
+	const int	fd = shm_open(name, O_RDWR, 0600);
+	struct stat st;
+
+	if (fd < 0 || fstat(fd, &st) != 0 || (size_t) st.st_size < 4096)
+	{
+		if (fd >= 0) close(fd);
+		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "no service segment %s", name);
+	}
+	void	   *p = mmap(nullptr, (size_t) st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+
+	close(fd);
+	if (p == MAP_FAILED)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "mmap(%s): %s", name, strerror(errno));
+	Header	   *h = (Header *) p;
+
+	if (h->magic.load(std::memory_order_acquire) != MAGIC ||
+		4096 + h->slot_bytes * (size_t) h->nslots > (size_t) st.st_size)
+	{
+		munmap(p, (size_t) st.st_size);
+		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "service segment %s is not initialised", name);
+	}
+	ndb_client *c = new (std::nothrow) ndb_client();
+
+	if (!c)
+	{
+		munmap(p, (size_t) st.st_size);
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	}
+	c->m.base = p;
+	c->m.bytes = (size_t) st.st_size;
+	c->m.h = h;
+	c->m.slots = (unsigned char *) p + 4096;
+	*out = c;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_client_disconnect(ndb_client *c)
+{
+	if (!c)
+		return NDBHIP_OK;
+	munmap(c->m.base, c->m.bytes);
+	delete c;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_client_dim(const ndb_client *c)
+{
+	return c ? (int) c->m.h->dim : NDBHIP_ERR_INVALID;
+}
+
+extern "C" int
+ndb_client_stop_service(ndb_client *c)
+{
+	if (!c)
+		return NDBHIP_ERR_INVALID;
+	c->m.h->stop.store(1);
+	c->m.h->submitted.fetch_add(1);
+	futex(&c->m.h->submitted, FUTEX_WAKE, 1 << 30, nullptr);
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_client_submit(ndb_client *c, const float *query, int strategy, int nprobe, int k, int64_t max_candidates, int *ticket)
+{
+	if (!c || !query || !ticket)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad submit arguments");
+	Header	   *h = c->m.h;
+
+	if (h->magic.load(std::memory_order_acquire) != MAGIC || h->stop.load())
+		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service is gone");
+	if (k < 1 || k > (int) h->max_k)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "k %d beyond the service's max_k %u", k, h->max_k);
+	/* a free slot: start at the shared cursor, bounded number of rounds */
+	for (int round = 0; round < 2000; round++)
+	{
+		const uint32_t start = h->cursor.fetch_add(1, std::memory_order_relaxed);
+
+		for (uint32_t j = 0; j < h->nslots; j++)
+		{
+			const uint32_t i = (start + j) % h->nslots;
+			Slot	   *sl = c->m.slot(i);
+			uint32_t	st = S_FREE;
+
+			if (sl->state.load(std::memory_order_relaxed) != S_FREE ||
+				!sl->state.compare_exchange_strong(st, S_CLAIMED, std::memory_order_acq_rel))
+				continue;
+			memcpy(c->m.query(sl), query, (size_t) h->dim * 4);
+			sl->strategy = strategy;
+			sl->nprobe = nprobe;
+			sl->k = k;
+			sl->max_candidates = max_candidates;
+			sl->status = 0;
+			sl->count = 0;
+			sl->seq = h->seq.fetch_add(1, std::memory_order_relaxed);
+			sl->state.store(S_READY, std::memory_order_release);
+			h->submitted.fetch_add(1, std::memory_order_release);
+			futex(&h->submitted, FUTEX_WAKE, 1, nullptr);
+			*ticket = (int) i;
+			return NDBHIP_OK;
+		}
+		struct timespec ts = {0, 50 * 1000};	/* every slot busy: more backends than slots */
+
+		nanosleep(&ts, nullptr);
+	}
+	return ndbhip_internal_fail(NDBHIP_ERR_STATE, "no free request slot");
+}
+
+extern "C" int
+ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *count, int timeout_ms)
+{
+	if (!c || ticket < 0 || (uint32_t) ticket >= c->m.h->nslots || !count)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad wait arguments");
+	Header	   *h = c->m.h;
+	Slot	   *sl = c->m.slot((uint32_t) ticket);
+	const auto	t0 = std::chrono::steady_clock::now();
+
+	for (int spins = 0;; spins++)
+	{
+		const uint32_t st = sl->state.load(std::memory_order_acquire);
+
+		if (st == S_DONE)
+			break;
+		if (st != S_READY && st != S_RUNNING)
+			return ndbhip_internal_fail(NDBHIP_ERR_STATE, "ticket %d is not in flight", ticket);
+		const int64_t waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+
+		if ((timeout_ms >= 0 && waited >= timeout_ms) || (h->stop.load() && st == S_READY))
+		{
+			/* give the slot back only if the owner has not taken it; a RUNNING slot is the owner's */
+			uint32_t	exp = S_READY;
+
+			if (sl->state.compare_exchange_strong(exp, S_FREE))
+				return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service did not answer");
+			if (timeout_ms >= 0 && waited >= 4 * (int64_t) timeout_ms + 1000)
+				return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service took the request and never finished it");
+		}
+		if (spins < 200)
+			continue;			/* a batch returns within a fraction of a millisecond: spin first */
+		struct timespec ts = {0, 2 * 1000 * 1000};
+
+		futex(&sl->state, FUTEX_WAIT, st, &ts);
+	}
+	const int	rc = sl->status;
+	const int	n = sl->count;
+
+	*count = n;
+	if (rc == 0)
+	{
+		if (dist)
+			memcpy(dist, c->m.dist(sl), (size_t) n * 4);
+		if (tids6)
+			memcpy(tids6, c->m.tids(sl), (size_t) n * 6);
+	}
+	sl->state.store(S_FREE, std::memory_order_release);
+	if (rc)
+		return ndbhip_internal_fail(rc, "the device service reported error %d for this query", rc);
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_client_search(ndb_client *c, const float *query, int strategy, int nprobe, int k, int64_t max_candidates,
+				  uint8_t *tids6, float *dist, int *count, int timeout_ms)
+{
+	int			ticket = -1;
+	const int	rc = ndb_client_submit(c, query, strategy, nprobe, k, max_candidates, &ticket);
+
+	if (rc)
+		return rc;
+	return ndb_client_wait(c, ticket, tids6, dist, count, timeout_ms);
+}
