@@ -3105,8 +3105,12 @@ k_merge_topk(const ndbhip_cand *__restrict__ cand, const int *__restrict__ ncand
 
 		for (int w = 0; w < world; w++)
 		{
+			/* a count from a peer is data, not a promise: more than `cap` records (or a negative count) would
+			 * overrun the LDS arrays sized for world x cap */
+			const int	nc_w = ncand[(size_t) w * nq + q];
+
 			woff[w] = acc;
-			acc += (uint32_t) ncand[(size_t) w * nq + q];
+			acc += (uint32_t) (nc_w < 0 ? 0 : (nc_w > (int) cap ? (int) cap : nc_w));
 		}
 		woff[world] = acc;
 	}
@@ -3161,6 +3165,9 @@ struct ndbhip_ivf
 	bool		own_rows = false;
 	int64_t		nrows = 0;
 	int64_t		cap_rows = 0;
+	float	   *d_vecs_alt = nullptr;	/* second row buffer of ivf_flush (appends): the new layout is gathered into it */
+	uint64_t   *d_tids_alt = nullptr;
+	size_t		alt_cap = 0;
 	int64_t    *d_loc_off = nullptr;
 	uint32_t   *d_glob_len = nullptr;
 	uint8_t    *d_owned = nullptr;
@@ -3239,6 +3246,37 @@ grow(T *&p, size_t &have, size_t want)
 	return 0;
 }
 
+/* temporaries of one call: freed on every way out of the scope unless keep() hands one over (the
+ * HIP_TRY early returns of ivf_flush / ndbhip_ivf_delete leaked their device buffers) */
+struct DevGuard
+{
+	std::vector<void **> owned;
+	template <class T> int alloc(T *&p, size_t bytes)
+	{
+		p = nullptr;
+		if (bytes == 0)
+			bytes = 16;
+		HIP_TRY(hipMalloc((void **) &p, bytes));
+		owned.push_back((void **) &p);
+		return 0;
+	}
+	template <class T> void keep(T *&p)
+	{
+		for (auto &o : owned)
+			if (o == (void **) &p)
+				o = nullptr;
+	}
+	~DevGuard()
+	{
+		for (auto o : owned)
+			if (o && *o)
+			{
+				(void) hipFree(*o);
+				*o = nullptr;
+			}
+	}
+};
+
 extern "C" int
 ndbhip_ivf_create(int dim, int nlists, ndbhip_ivf **out)
 {
@@ -3267,6 +3305,11 @@ ivf_free_rows(ndbhip_ivf *ix)
 		if (ix->d_vecs) (void) hipFree(ix->d_vecs);
 		if (ix->d_tids) (void) hipFree(ix->d_tids);
 	}
+	if (ix->d_vecs_alt) (void) hipFree(ix->d_vecs_alt);
+	if (ix->d_tids_alt) (void) hipFree(ix->d_tids_alt);
+	ix->d_vecs_alt = nullptr;
+	ix->d_tids_alt = nullptr;
+	ix->alt_cap = 0;
 	ix->d_vecs = nullptr;
 	ix->d_tids = nullptr;
 	ix->own_rows = false;
@@ -3587,12 +3630,54 @@ ivf_local_max_candidates(const ndbhip_ivf *ix, int nprobe)
 	return s;
 }
 
+/* one block per 64 new rows: row r of the new layout comes from the old mirror or from the staged appends */
+__global__ __launch_bounds__(256) void
+k_flush_gather(const float *__restrict__ old_rows, const uint64_t *__restrict__ old_tids,
+			   const float *__restrict__ stage_rows, const uint64_t *__restrict__ stage_tids,
+			   const int64_t *__restrict__ new_off, const int64_t *__restrict__ old_off, const int64_t *__restrict__ old_own,
+			   const int64_t *__restrict__ stage_off, int ncent, int dim, int64_t nnew, float *__restrict__ out_rows,
+			   uint64_t *__restrict__ out_tids)
+{
+	const int64_t r0 = (int64_t) blockIdx.x * 64;
+
+	for (int rr = threadIdx.x >> 6; rr < 64; rr += 4)
+	{
+		const int64_t r = r0 + rr;
+
+		if (r >= nnew)
+			break;
+		int			lo = 0, hi = ncent;	/* largest c with new_off[c] <= r (empty lists share an offset: skip forward) */
+
+		while (hi - lo > 1)
+		{
+			const int	mid = (lo + hi) >> 1;
+
+			if (new_off[mid] <= r)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (lo + 1 < ncent && new_off[lo + 1] <= r)
+			lo++;
+		const int64_t idx = r - new_off[lo];
+		const bool	from_old = idx < old_own[lo];
+		const float *src = from_old ? old_rows + (size_t) (old_off[lo] + idx) * dim
+			: stage_rows + (size_t) (stage_off[lo] + idx - old_own[lo]) * dim;
+		float	   *dst = out_rows + (size_t) r * dim;
+
+		for (int d = threadIdx.x & 63; d < dim; d += 64)
+			dst[d] = src[d];
+		if ((threadIdx.x & 63) == 0)
+			out_tids[r] = from_old ? old_tids[old_off[lo] + idx] : stage_tids[stage_off[lo] + idx - old_own[lo]];
+	}
+}
+
 /*
- * Fold the pending aminsert entries into the packed layout: every list keeps its
- * old rows in place order and gains its new entries at the tail, in arrival order —
- * exactly where ivfinsert's PageAddItem on the tail page puts them
- * (src/index/ivf_am.c:985-1157).  Cost O(nlists) copies per flush, amortised over
- * all inserts since the previous search.
+ * The first search after ndbhip_ivf_append() folds the pending entries into the mirror: every list keeps its
+ * order, the appended entries follow in insertion order (the page chain's order, ivf_am.c:985-1120).  One gather
+ * kernel writes the new layout into the mirror's second buffer (kept between flushes, grown with 1/8 slack: no
+ * multi-GB hipMalloc and no per-list copies on the scan that follows an INSERT), the buffers swap.  O(N) bytes
+ * still move; the norms / fp16 planes of the batched scans are rebuilt lazily by the next batch that needs them.
  */
 static int
 ivf_flush(ndbhip_ivf *ix)
@@ -3645,57 +3730,72 @@ ivf_flush(ndbhip_ivf *ix)
 		stids[(size_t) cur[c]] = ix->pend_tids[i];
 		cur[c]++;
 	}
-	float	   *nrows_d = nullptr, *stage_d = nullptr;
-	uint64_t   *ntids_d = nullptr, *stids_d = nullptr;
-	const int64_t cap = std::max<int64_t>(nown, 1);
-
-	HIP_TRY(hipMalloc((void **) &nrows_d, (size_t) cap * dim * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &ntids_d, (size_t) cap * sizeof(uint64_t)));
-	if (nstage > 0)
+	if (nown > 0)
 	{
-		HIP_TRY(hipMalloc((void **) &stage_d, (size_t) nstage * dim * sizeof(float)));
-		HIP_TRY(hipMalloc((void **) &stids_d, (size_t) nstage * sizeof(uint64_t)));
-		HIP_TRY(hipMemcpyAsync(stage_d, srows.data(), (size_t) nstage * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(stids_d, stids.data(), (size_t) nstage * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-	}
-	for (int c = 0; c < nc; c++)
-	{
-		const int64_t oldn = ix->own_len[c];
+		DevGuard	tmp;
+		float	   *stage_d = nullptr;
+		uint64_t   *stids_d = nullptr;
+		int64_t    *meta_d = nullptr;	/* new_off | old_off | old_own | stage_off, nc + 1 each */
+		std::vector<int64_t> meta((size_t) 4 * (nc + 1), 0);
 
-		if (new_own[c] == 0)
-			continue;
+		for (int c = 0; c <= nc; c++)
+		{
+			meta[c] = new_off[c];
+			meta[(size_t) (nc + 1) + c] = ix->loc_off[c];
+			meta[(size_t) 2 * (nc + 1) + c] = c < nc ? ix->own_len[c] : 0;
+			meta[(size_t) 3 * (nc + 1) + c] = stage_off[c];
+		}
+		if (tmp.alloc(stage_d, (size_t) std::max<int64_t>(nstage, 1) * dim * sizeof(float))) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(stids_d, (size_t) std::max<int64_t>(nstage, 1) * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(meta_d, meta.size() * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+		/* the second buffer: kept between flushes */
+		if (!ix->own_rows || (int64_t) ix->alt_cap < nown)
+		{
+			const int64_t cap = nown + nown / 8 + 1024;
 
-		if (oldn > 0)
-		{
-			HIP_TRY(hipMemcpyAsync(nrows_d + (size_t) new_off[c] * dim, ix->d_vecs + (size_t) ix->loc_off[c] * dim,
-								   (size_t) oldn * dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-			HIP_TRY(hipMemcpyAsync(ntids_d + new_off[c], ix->d_tids + ix->loc_off[c], (size_t) oldn * sizeof(uint64_t),
-								   hipMemcpyDeviceToDevice, g.stream));
+			if (ix->d_vecs_alt) HIP_TRY(hipFree(ix->d_vecs_alt));
+			if (ix->d_tids_alt) HIP_TRY(hipFree(ix->d_tids_alt));
+			ix->d_vecs_alt = nullptr;
+			ix->d_tids_alt = nullptr;
+			ix->alt_cap = 0;
+			HIP_TRY(hipMalloc((void **) &ix->d_vecs_alt, (size_t) cap * dim * sizeof(float)));
+			HIP_TRY(hipMalloc((void **) &ix->d_tids_alt, (size_t) cap * sizeof(uint64_t)));
+			ix->alt_cap = (size_t) cap;
 		}
-		if (add[c] > 0 && ix->owned[c])
-		{
-			HIP_TRY(hipMemcpyAsync(nrows_d + (size_t) (new_off[c] + oldn) * dim, stage_d + (size_t) stage_off[c] * dim,
-								   (size_t) add[c] * dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-			HIP_TRY(hipMemcpyAsync(ntids_d + new_off[c] + oldn, stids_d + stage_off[c],
-								   (size_t) add[c] * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
-		}
+		HIP_TRY(hipMemcpyAsync(stage_d, srows.data(), (size_t) std::max<int64_t>(nstage, 1) * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(stids_d, stids.data(), (size_t) std::max<int64_t>(nstage, 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(meta_d, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+		hipLaunchKernelGGL(k_flush_gather, dim3((unsigned) ((nown + 63) / 64)), dim3(256), 0, g.stream,
+						   (const float *) ix->d_vecs, (const uint64_t *) ix->d_tids, (const float *) stage_d,
+						   (const uint64_t *) stids_d, (const int64_t *) meta_d, (const int64_t *) meta_d + (nc + 1),
+						   (const int64_t *) meta_d + 2 * (nc + 1), (const int64_t *) meta_d + 3 * (nc + 1), nc, dim, nown,
+						   ix->d_vecs_alt, ix->d_tids_alt);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
-	HIP_TRY(hipStreamSynchronize(g.stream));
-	if (stage_d) HIP_TRY(hipFree(stage_d));
-	if (stids_d) HIP_TRY(hipFree(stids_d));
 	std::vector<uint8_t> owned(ix->owned);
 	std::vector<int64_t> lo(ix->own_lo);
 	int			rc = ivf_set_layout(ix, new_len.data(), owned.data(), nown, lo.data(), new_own.data());
 
 	if (rc)
 		return rc;
-	ivf_free_rows(ix);
-	ix->d_vecs = nrows_d;
-	ix->d_tids = ntids_d;
-	ix->own_rows = true;
+	if (nown > 0)
+	{
+		/* swap: the old mirror becomes the second buffer (if the library owns it) */
+		float	   *ov = ix->own_rows ? ix->d_vecs : nullptr;
+		uint64_t   *ot = ix->own_rows ? ix->d_tids : nullptr;
+		const size_t ocap = ix->own_rows ? (size_t) ix->cap_rows : 0;
+
+		ix->d_vecs = ix->d_vecs_alt;
+		ix->d_tids = ix->d_tids_alt;
+		ix->cap_rows = (int64_t) ix->alt_cap;
+		ix->d_vecs_alt = ov;
+		ix->d_tids_alt = ot;
+		ix->alt_cap = ocap;
+		ix->own_rows = true;
+	}
 	ix->nrows = nown;
 	ix->norm_valid = false; ix->s16_valid = false;
-	ix->cap_rows = cap;
 	ix->pend_list.clear();
 	ix->pend_rows.clear();
 	ix->pend_tids.clear();
@@ -3870,12 +3970,14 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 
 	if (((size_t) ix->dim * esz) % 4 != 0)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "row size must be a multiple of 4 bytes");
-	HIP_TRY(hipMalloc((void **) &d_dead, (size_t) n * sizeof(uint64_t)));
-	HIP_TRY(hipMalloc((void **) &d_keep, (size_t) nrows));
-	HIP_TRY(hipMalloc((void **) &d_bs, (size_t) nblk * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **) &d_pref, ((size_t) nrows + 1) * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **) &d_total, sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **) &d_newlen, (size_t) ix->ncent * sizeof(int64_t)));
+	DevGuard	tmp;				/* freed on every way out */
+
+	if (tmp.alloc(d_dead, (size_t) n * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_keep, (size_t) nrows)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_bs, (size_t) nblk * sizeof(uint32_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_pref, ((size_t) nrows + 1) * sizeof(uint32_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_total, sizeof(uint32_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_newlen, (size_t) ix->ncent * sizeof(int64_t))) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(d_dead, dead.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
 	hipLaunchKernelGGL(k_delete_mark, dim3(nblk), dim3(256), 0, g.stream, (const uint64_t *) ix->d_tids, nrows,
 					   (const uint64_t *) d_dead, n, d_keep, d_bs);
@@ -3894,11 +3996,11 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 	if ((int64_t) total < nrows)
 	{
 		const int64_t cap = total > 0 ? (int64_t) total : 1;
-		void	   *nv = nullptr;
+		unsigned char *nv = nullptr;
 		uint64_t   *nt = nullptr;
 
-		HIP_TRY(hipMalloc(&nv, (size_t) cap * ix->dim * esz));
-		HIP_TRY(hipMalloc((void **) &nt, (size_t) cap * sizeof(uint64_t)));
+		if (tmp.alloc(nv, (size_t) cap * ix->dim * esz)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(nt, (size_t) cap * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
 		hipLaunchKernelGGL(k_delete_move, dim3((unsigned) nrows), dim3(256), 0, g.stream, (const uint8_t *) d_keep,
 						   (const uint32_t *) d_pref, (const uint32_t *) ix->d_vecs, (const uint64_t *) ix->d_tids,
 						   (uint32_t *) nv, nt, row_words);
@@ -3907,6 +4009,8 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 		ivf_free_rows(ix);
 		ix->d_vecs = (float *) nv;
 		ix->d_tids = nt;
+		tmp.keep(nv);				/* the mirror owns them now */
+		tmp.keep(nt);
 		ix->own_rows = true;
 		ix->cap_rows = cap;
 		ix->nrows = (int64_t) total;
@@ -3915,12 +4019,6 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 	}
 	if (removed)
 		*removed = nrows - (int64_t) total;
-	HIP_TRY(hipFree(d_dead));
-	HIP_TRY(hipFree(d_keep));
-	HIP_TRY(hipFree(d_bs));
-	HIP_TRY(hipFree(d_pref));
-	HIP_TRY(hipFree(d_total));
-	HIP_TRY(hipFree(d_newlen));
 	return rc;
 }
 
