@@ -269,11 +269,11 @@ def main():
     esz = 2 if args.rows == "f16" else 4
     kernel = (f"k_ivf_scan_grouped<{recipe}{', fp16 rows' if esz == 2 else ''}>" if grouped
               else f"k_ivf_scan{'_h' if esz == 2 else ''}<{recipe}>")
-    if screened and os.environ.get("NDBHIP_SCR_COOP", "2") != "0" and dim % 16 == 0:
-        kernel = (f"k_ivf_bound_coop2<{recipe}>" if os.environ.get("NDBHIP_SCR_COOP", "2") == "2"
-                  else "k_ivf_bound_coop<R_SCR_L2>")
-    mfma = (screened and os.environ.get("NDBHIP_SCR_COOP", "2") == "2" and dim % 16 == 0
-            and os.environ.get("NDBHIP_SCR_MFMA", "1") != "0")
+    opts = dict(o.split("=") for o in args.opt)          # the library switches this run set (ndbhip_set_option)
+    scr_coop, scr_mfma = opts.get("scr_coop", "2"), opts.get("scr_mfma", "1")
+    if screened and scr_coop != "0" and dim % 16 == 0:
+        kernel = (f"k_ivf_bound_coop2<{recipe}>" if scr_coop == "2" else "k_ivf_bound_coop<R_SCR_L2>")
+    mfma = screened and scr_coop == "2" and dim % 16 == 0 and scr_mfma != "0"
     if mfma:
         kernel = f"k_ivf_bound_mfma<{recipe}>"
     launches = max(1, st["scan_launches"])

@@ -119,9 +119,16 @@ int			ndbhip_set_scan_mode(int mode);
  * produce — but they only affect the candidates they take part in: such a row is always handed to the
  * reference's arithmetic, never allowed to distort another row's bound. */
 
-/* Process-wide switches that used to be environment variables: "screen16" (1; 0 = auto mode keeps the fp32 bound
- * pass), "screen16_records" (2048: candidates a query may emit before its batch is rerun on the fp32 screen),
- * "screen" (1; 0 = auto mode never screens). */
+/* Process-wide switches (round 1 read some of them from the environment; nothing in the library reads the
+ * environment any more).  Results are bit-identical whichever way they are set.
+ *   "screen"            1   auto mode screens batches of >= 128 queries (0 = never)
+ *   "screen16"          1   ... on the fp16 matrix cores (0 = the fp32 bound pass)
+ *   "screen16_records"  2048  candidates a query may emit before it is swept again / its batch falls back
+ *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
+ *   "screen16_debug"    0   timing experiments of the sweep (1 no DMA, 2 DMA of cache-hot lines: WRONG results)
+ *   "scr_coop" 2, "scr_ch" 16, "scr_mfma" 1, "gchunk" 32   A/B switches of the fp32 screened / grouped kernels
+ *   "debug_s16", "debug_build", "hnsw_trace"  0   progress / timing lines on stderr
+ *   "hnsw_nofast"       0   hnsw build walks score rows in the reference's own summation order only */
 int			ndbhip_set_option(const char *name, int value);
 
 /* Synthetic data for benches and full-size tests (a counter-based generator in the repo): element

@@ -69,7 +69,8 @@ class NdbIndexScan(C.Structure):
 
 class NdbHipDeviceInfo(C.Structure):
     _fields_ = [("device_id", C.c_int), ("name", C.c_char * 256), ("total_memory_bytes", C.c_size_t),
-                ("free_memory_bytes", C.c_size_t), ("compute_units", C.c_int), ("is_available", C.c_int)]
+                ("free_memory_bytes", C.c_size_t), ("compute_major", C.c_int), ("compute_minor", C.c_int),
+                ("is_available", C.c_bool)]
 
 
 _FN = C.CFUNCTYPE
@@ -77,7 +78,8 @@ _FN = C.CFUNCTYPE
 
 class NdbHipBackend(C.Structure):
     """include/ndb_backend.h: struct ndb_hip_backend (the reference's ndb_gpu_backend members for this path)"""
-    _fields_ = [("name", C.c_char_p), ("provider", C.c_char_p), ("features", C.c_uint), ("priority", C.c_int),
+    _fields_ = [("name", C.c_char_p), ("provider", C.c_char_p), ("kind", C.c_int), ("features", C.c_uint),
+                ("priority", C.c_int),
                 ("init", _FN(C.c_int)), ("shutdown", _FN(None)), ("is_available", _FN(C.c_int)),
                 ("device_count", _FN(C.c_int)), ("device_info", _FN(C.c_int, C.c_int, C.POINTER(NdbHipDeviceInfo))),
                 ("set_device", _FN(C.c_int, C.c_int)),
@@ -91,8 +93,13 @@ class NdbHipBackend(C.Structure):
                 ("launch_kmeans_update", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                              C.c_void_p)),
                 ("launch_quant_fp16", _FN(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)),
-                ("stream_create", _FN(C.c_int, C.POINTER(C.c_void_p))), ("stream_destroy", _FN(C.c_int, C.c_void_p)),
-                ("stream_synchronize", _FN(C.c_int, C.c_void_p))]
+                ("launch_quant_int8", C.c_void_p), ("launch_quant_int4", C.c_void_p),
+                ("launch_quant_fp8_e4m3", C.c_void_p), ("launch_quant_fp8_e5m2", C.c_void_p),
+                ("launch_quant_binary", C.c_void_p), ("launch_pq_encode", C.c_void_p)]
+
+
+STREAM_CREATE = _FN(C.c_int, C.POINTER(C.c_void_p))
+STREAM_OP = _FN(C.c_int, C.c_void_p)
 
 
 class NdbKnnRow(C.Structure):
@@ -254,6 +261,7 @@ def lib():
         "ndb_ivf_knn_search_gpu": (i, [vp, i, vp, vp, i, i, i, vp, C.POINTER(i64)]),
         # include/ndb_backend.h
         "ndb_hip_backend_get": (C.POINTER(NdbHipBackend), []),
+        "ndb_hip_backend_streams": (None, [C.POINTER(STREAM_CREATE), C.POINTER(STREAM_OP), C.POINTER(STREAM_OP)]),
         "ndb_hnsw_knn_search_gpu": (i, [vp, i, vp, vp, i, i, i, vp, C.POINTER(i64)]),
         "ndbhip_ivf_build": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
         "ndbhip_ivf_insert": (i, [vp, vp, vp, C.POINTER(i)]),

@@ -51,8 +51,9 @@ be_device_info(int device_id, ndb_hip_device_info *info)
 	info->device_id = device_id;
 	strncpy(info->name, prop.name, sizeof info->name - 1);
 	info->total_memory_bytes = prop.totalGlobalMem;
-	info->compute_units = prop.multiProcessorCount;
-	info->is_available = 1;
+	info->compute_major = prop.major;	/* as ndb_rocm_device_info does: gpu_backend_rocm.c:336-337 */
+	info->compute_minor = prop.minor;
+	info->is_available = true;
 	if (device_id == be_device && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 		info->free_memory_bytes = free_b;
 	return 0;
@@ -165,14 +166,23 @@ be_stream_synchronize(ndb_stream_t stream)
 }
 
 static const ndb_hip_backend the_backend = {
-	"ndbhip", "AMD", 0u, 100,
+	"ndbhip", "AMD", NDB_HIP_BACKEND_ROCM, 0u, 100,
 	be_init, be_shutdown, be_is_available,
 	be_device_count, be_device_info, be_set_device,
 	be_mem_alloc, be_mem_free, be_memcpy_h2d, be_memcpy_d2h,
 	be_launch_l2_distance, be_launch_cosine, be_launch_kmeans_assign, be_launch_kmeans_update,
 	be_launch_quant_fp16,
-	be_stream_create, be_stream_destroy, be_stream_synchronize,
+	nullptr, nullptr, nullptr, nullptr, nullptr,	/* int8 / int4 / fp8 / binary quantisers: out of scope -> CPU */
+	nullptr,										/* launch_pq_encode */
 };
+
+extern "C" void
+ndb_hip_backend_streams(int (**create) (ndb_stream_t *), int (**destroy) (ndb_stream_t), int (**synchronize) (ndb_stream_t))
+{
+	if (create) *create = be_stream_create;
+	if (destroy) *destroy = be_stream_destroy;
+	if (synchronize) *synchronize = be_stream_synchronize;
+}
 
 extern "C" const ndb_hip_backend *
 ndb_hip_backend_get(void)

@@ -1,0 +1,1222 @@
+/*
+ * ndbhip_build.h — ivfbuild / ivfinsert on the device (part of ndbhip.hip's translation unit): k-means with the
+ * reference's rules (src/index/ivf_am.c:2070-2294), the insert-time assignment (:905-935), list packing,
+ * ndbhip_ivf_build_device / _assign_device / export and the GPU plugin's k-means launchers.
+ */
+#ifndef NDBHIP_BUILD_H
+#define NDBHIP_BUILD_H
+
+/* ================================================================== */
+/* IVF build: k-means (ivf_am.c:2070-2294), insert-time assignment     */
+/* (:905-935), list packing                                            */
+/* ================================================================== */
+#define NDB_CGROUP 64			/* centroids handled by one wave */
+
+/*
+ * Nearest-centroid search for 64 rows x one group of NDB_CGROUP centroids.
+ * The row tile is staged ONCE per 64-float chunk and every centroid of the
+ * group is accumulated against it: acc[c] lives in LDS ([c][lane], conflict
+ * free), the centroid chunk arrives through the scalar cache.  Each
+ * (row, centroid) sum is still the reference's sequential fp32 chain
+ * (vector_distance_l2 / the accum loop of ivfinsert).
+ * SQRT = false: compare squared sums (find_nearest_centroid, :2274-2294)
+ * SQRT = true : compare sqrtf(sum)     (ivfinsert, :915-934)
+ * grid = (ceil(nrows/64), ngroups), block = 64.
+ */
+template <bool SQRT>
+__global__ __launch_bounds__(64) void
+k_assign_partial(const float *__restrict__ rows, uint32_t nrows, int dim,
+				 const float *__restrict__ cents, int ncent,
+				 float *__restrict__ part_dist, int *__restrict__ part_idx)
+{
+	__shared__ __attribute__((aligned(16))) float tile[NDB_TILE_FLOATS];
+	__shared__ float accs[NDB_CGROUP * 64];
+	const int	lane = threadIdx.x;
+	const int	grp = lane >> 4;
+	const int	slot = lane & 15;
+	const uint32_t r = blockIdx.x * 64 + lane;
+	const uint32_t row = (r < nrows) ? r : (nrows - 1);
+	const int	c0 = blockIdx.y * NDB_CGROUP;
+	const int	gc = (ncent - c0 < NDB_CGROUP) ? (ncent - c0) : NDB_CGROUP;
+	uint32_t	rows16[16];
+
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		rows16[i] = __shfl(row, 4 * i + grp, 64);
+	for (int cl = 0; cl < gc; cl++)
+		accs[cl * 64 + lane] = 0.0f;
+
+	for (int c = 0; c < dim; c += NDB_CHUNK)
+	{
+		const bool	full = (dim - c) >= NDB_CHUNK;
+		const int	npieces = full ? 16 : ((dim - c) >> 2);
+		float4		x[16];
+
+		if (full)
+			stage_chunk<true>(x, rows, rows16, dim, c, tile, lane, grp, slot);
+		else
+			stage_chunk<false>(x, rows, rows16, dim, c, tile, lane, grp, slot);
+
+		for (int cl = 0; cl < gc; cl++)
+		{
+			const float *__restrict__ q = cents + (size_t) (c0 + cl) * (size_t) dim + c;
+			float		a = accs[cl * 64 + lane];
+
+			if (full)
+			{
+#pragma unroll
+				for (int p = 0; p < 16; p++)
+				{
+					const float4 qq = *reinterpret_cast<const float4 *>(q + p * 4);
+					float		d;
+
+					d = x[p].x - qq.x; a = a + d * d;
+					d = x[p].y - qq.y; a = a + d * d;
+					d = x[p].z - qq.z; a = a + d * d;
+					d = x[p].w - qq.w; a = a + d * d;
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int p = 0; p < 16; p++)
+					if (p < npieces)
+					{
+						const float4 qq = *reinterpret_cast<const float4 *>(q + p * 4);
+						float		d;
+
+						d = x[p].x - qq.x; a = a + d * d;
+						d = x[p].y - qq.y; a = a + d * d;
+						d = x[p].z - qq.z; a = a + d * d;
+						d = x[p].w - qq.w; a = a + d * d;
+					}
+			}
+			accs[cl * 64 + lane] = a;
+		}
+	}
+	float		best = FLT_MAX;
+	int			bidx = -1;
+
+	for (int cl = 0; cl < gc; cl++)
+	{
+		float		d = accs[cl * 64 + lane];
+
+		if (SQRT)
+			d = __builtin_sqrtf(d);
+		if (d < best)
+		{
+			best = d;
+			bidx = c0 + cl;
+		}
+	}
+	if (r < nrows)
+	{
+		part_dist[(size_t) blockIdx.y * nrows + r] = best;
+		part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
+	}
+}
+
+/* dim % 4 != 0: one lane walks its row against every centroid of the group directly */
+template <bool SQRT>
+__global__ __launch_bounds__(64) void
+k_assign_partial_direct(const float *__restrict__ rows, uint32_t nrows, int dim,
+						const float *__restrict__ cents, int ncent,
+						float *__restrict__ part_dist, int *__restrict__ part_idx)
+{
+	const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+	const int	c0 = blockIdx.y * NDB_CGROUP;
+	const int	gc = (ncent - c0 < NDB_CGROUP) ? (ncent - c0) : NDB_CGROUP;
+
+	if (r >= nrows)
+		return;
+	float		best = FLT_MAX;
+	int			bidx = -1;
+
+	for (int cl = 0; cl < gc; cl++)
+	{
+		const float *q = cents + (size_t) (c0 + cl) * dim;
+		const float *x = rows + (size_t) r * dim;
+		float		a = 0.0f;
+
+		for (int i = 0; i < dim; i++)
+		{
+			const float d = x[i] - q[i];
+
+			a = a + d * d;
+		}
+		if (SQRT)
+			a = __builtin_sqrtf(a);
+		if (a < best)
+		{
+			best = a;
+			bidx = c0 + cl;
+		}
+	}
+	part_dist[(size_t) blockIdx.y * nrows + r] = best;
+	part_idx[(size_t) blockIdx.y * nrows + r] = bidx;
+}
+
+/* cblock[g][d][j] = cents[16 g + j][d] (j beyond the last centroid repeats centroid 0 and is ignored) */
+__global__ void
+k_interleave16(const float *__restrict__ cents, int ncent, int dim, float *__restrict__ cblock)
+{
+	const int	g16 = blockIdx.y;
+	const int	d = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (d >= dim)
+		return;
+	float		v[NDB_QG];
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG; j++)
+	{
+		const int	c = g16 * NDB_QG + j;
+
+		v[j] = cents[(size_t) (c < ncent ? c : 0) * dim + d];
+	}
+	float4	   *dst = reinterpret_cast<float4 *>(cblock + ((size_t) g16 * dim + d) * NDB_QG);
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG / 4; j++)
+		dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+/*
+ * Nearest centroid, fast form (dim % 64 == 0): one wave = 64 rows x 16 centroids, the row chunk
+ * staged once per chunk, the 16 centroids' values of a dimension arriving as ONE scalar load and
+ * the arithmetic running on centroid pairs (v_pk_*_f32) — the same engine as k_ivf_scan_grouped.
+ * Every (row, centroid) sum is still the sequential fp32 chain of vector_distance_l2 / ivfinsert
+ * ((x-c)^2 == (c-x)^2 exactly).  grid = (row tiles, centroid groups of 16), block = 64.
+ */
+template <bool SQRT, int CH>
+__global__ __launch_bounds__(64, (CH == 32 ? NDB_G32_WAVES : NDB_GROUPED_WAVES_PER_SIMD)) void
+k_assign_grouped(const float *__restrict__ rows, uint32_t nrows, int dim, const float *__restrict__ cblock,
+				 int ncent, float *__restrict__ part_dist, int *__restrict__ part_idx,
+				 float *__restrict__ all_dist, uint32_t all_stride)
+{
+	__shared__ __attribute__((aligned(16))) float tile[64 * CH];
+	const int	lane = threadIdx.x;
+	/*
+	 * 1-D grid, XCD-aware: block b runs on XCD b % 8 (observed; speed only).  XCD x takes the row tiles
+	 * congruent to x mod 8 and walks each one through ALL centroid groups before the next, so a tile's
+	 * rows come from HBM once and from that XCD's L2 for the other groups.
+	 */
+	const uint32_t ngroups = ((uint32_t) ncent + NDB_QG - 1) / NDB_QG;
+	const uint32_t seq = blockIdx.x >> 3;
+	const uint32_t tileno = (seq / ngroups) * 8u + (blockIdx.x & 7u);
+	const uint32_t cgrp = seq % ngroups;
+
+	if (tileno * 64u >= nrows)
+		return;
+	const uint32_t r = tileno * 64 + lane;
+	const uint32_t row = (r < nrows) ? r : (nrows - 1);
+	const int	c0 = (int) cgrp * NDB_QG;
+	const int	gc = (ncent - c0 < NDB_QG) ? (ncent - c0) : NDB_QG;
+	uint32_t	rowsN[CH / 4];
+	GAcc<R_IVF_L2> acc;
+	const float *qs = cblock + (size_t) cgrp * (size_t) dim * NDB_QG;
+	ndb_f16		qa0, qa1, qb0, qb1;
+
+	acc.init();
+	rows_for_loads<CH>(rowsN, row, lane);
+	sload2x16(qa0, qa1, qs);
+	for (int c = 0; c < dim; c += CH)
+	{
+		float4		x[CH / 4];
+
+		stage_chunk_w<CH>(x, rows, rowsN, dim, c, tile, lane);
+		const float *qnext = (c + CH >= dim) ? qs - 2 * NDB_QG : qs;
+
+		ndb_static_for<0, CH / 4>([&](auto pc) {
+			constexpr int p = decltype(pc)::value;
+
+			swait2(qa0, qa1);
+			sload2x16_at<(4 * p + 2) * 64>(qb0, qb1, qs);
+			acc.step(qa0, x[p].x);
+			acc.step(qa1, x[p].y);
+			swait2(qb0, qb1);
+			if constexpr (p == CH / 4 - 1)
+				sload2x16_at<CH * 64>(qa0, qa1, qnext);
+			else
+				sload2x16_at<(4 * p + 4) * 64>(qa0, qa1, qs);
+			acc.step(qb0, x[p].z);
+			acc.step(qb1, x[p].w);
+		});
+		qs += CH * NDB_QG;
+	}
+	swait2(qa0, qa1);
+	if (all_dist)
+	{
+		/* every distance, not the nearest: the query x centroid scan of ivfSelectClusters (rows = queries) */
+		if (r < nrows)
+		{
+#pragma unroll
+			for (int j = 0; j < NDB_QG; j++)
+			{
+				float		d = (j & 1) ? acc.s[j >> 1].y : acc.s[j >> 1].x;
+
+				if (SQRT)
+					d = __builtin_sqrtf(d);
+				if (j < gc)
+					all_dist[(size_t) r * all_stride + c0 + j] = d;
+			}
+		}
+		return;
+	}
+	float		best = FLT_MAX;
+	int			bidx = -1;
+
+#pragma unroll
+	for (int j = 0; j < NDB_QG; j++)
+	{
+		float		d = (j & 1) ? acc.s[j >> 1].y : acc.s[j >> 1].x;
+
+		if (SQRT)
+			d = __builtin_sqrtf(d);
+		if (j < gc && d < best)
+		{
+			best = d;
+			bidx = c0 + j;
+		}
+	}
+	if (r < nrows)
+	{
+		part_dist[(size_t) cgrp * nrows + r] = best;
+		part_idx[(size_t) cgrp * nrows + r] = bidx;
+	}
+}
+
+/* first strict minimum over the groups, in centroid order; none below FLT_MAX -> 0
+ * (best = 0 / min_idx = 0 initialisers: ivf_am.c:2277, 812) */
+__global__ void
+k_assign_combine(const float *__restrict__ part_dist, const int *__restrict__ part_idx, int ngroups,
+				 uint32_t nrows, int *__restrict__ out_list, int *__restrict__ counts)
+{
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (r >= nrows)
+		return;
+	float		best = FLT_MAX;
+	int			bidx = 0;
+
+	for (int g2 = 0; g2 < ngroups; g2++)
+	{
+		const float d = part_dist[(size_t) g2 * nrows + r];
+		const int	i = part_idx[(size_t) g2 * nrows + r];
+
+		if (i >= 0 && d < best)
+		{
+			best = d;
+			bidx = i;
+		}
+	}
+	out_list[r] = bidx;
+	if (counts)
+		atomicAdd(&counts[bidx], 1);
+}
+
+/* kmeans_update_centroids (:2182-2213): block = centroid.  The members are first compacted IN SAMPLE
+ * ORDER into LDS (ballot + popcount prefix), then thread = coordinate adds them in that order and
+ * divides by (float) count — the reference's summation order, without scanning all n samples per
+ * coordinate.  Dynamic LDS: n uint32. */
+__global__ __launch_bounds__(256) void
+k_kmeans_update(const float *__restrict__ data, int n, int dim, const int *__restrict__ assign,
+				const int *__restrict__ counts, float *__restrict__ cents)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	uint32_t   *members = (uint32_t *) smem_raw;
+	uint32_t   *sh = members + n;		/* 8 words */
+	const int	c = blockIdx.x;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	uint32_t	base = 0;
+
+	for (int start = 0; start < n; start += 256)
+	{
+		const int	i = start + (int) tid;
+		const bool	mine = i < n && assign[i] == c;
+		const unsigned long long m = __ballot(mine);
+		const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+		if (lane == 0)
+			sh[wave] = __popcll(m);
+		__syncthreads();
+		uint32_t	woff = 0, tot = 0;
+
+		for (uint32_t w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				woff += sh[w];
+			tot += sh[w];
+		}
+		if (mine)
+			members[base + woff + __popcll(m & below)] = (uint32_t) i;
+		base += tot;
+		__syncthreads();
+	}
+	const uint32_t cnt = base;		/* == counts[c] */
+
+	for (int j = tid; j < dim; j += 256)
+	{
+		float		s = 0.0f;
+
+		for (uint32_t k2 = 0; k2 < cnt; k2++)
+			s = s + data[(size_t) members[k2] * dim + j];
+		if (counts[c] > 0)
+			s = s / (float) counts[c];
+		cents[(size_t) c * dim + j] = s;
+	}
+}
+
+/* per-sample squared distance to its own centroid (:2225-2230) */
+__global__ void
+k_kmeans_point_cost(const float *__restrict__ data, int n, int dim, const int *__restrict__ assign,
+					const float *__restrict__ cents, float *__restrict__ pc)
+{
+	const int	i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= n)
+		return;
+	const float *x = data + (size_t) i * dim;
+	const float *q = cents + (size_t) assign[i] * dim;
+	float		s = 0.0f;
+
+	for (int j = 0; j < dim; j++)
+	{
+		const float d = x[j] - q[j];
+
+		s = s + d * d;
+	}
+	pc[i] = s;
+}
+
+/* cost += d_i strictly in sample order, in fp32 (:2221-2232): the block stages the terms in LDS,
+ * one lane then adds them in order (the sum is order-dependent and decides the stopping iteration) */
+__global__ __launch_bounds__(256) void
+k_seq_sum(const float *__restrict__ pc, int n, float *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	float	   *v = (float *) smem_raw;
+
+	for (int i = threadIdx.x; i < n; i += 256)
+		v[i] = pc[i];
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		float		s = 0.0f;
+
+		for (int i = 0; i < n; i++)
+			s = s + v[i];
+		*out = s;
+	}
+}
+
+/* kmeans_init (:2092-2104): first k samples, zeros beyond n */
+__global__ void
+k_kmeans_init(const float *__restrict__ data, int n, int dim, int k, float *__restrict__ cents)
+{
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= (size_t) k * dim)
+		return;
+	const int	c = (int) (i / dim);
+
+	cents[i] = (c < n) ? data[i] : 0.0f;
+}
+
+
+static int
+set_kernel_attributes_build()
+{
+	HIP_TRY(hipFuncSetAttribute((const void *) k_kmeans_update, hipFuncAttributeMaxDynamicSharedMemorySize,
+								NDB_TOPK_MAX_SMEM));
+	HIP_TRY(hipFuncSetAttribute((const void *) k_seq_sum, hipFuncAttributeMaxDynamicSharedMemorySize,
+								NDB_TOPK_MAX_SMEM));
+	return set_kernel_attributes_hnsw();
+}
+
+/* scratch of assign_rows, reusable across calls (the k-means loop calls it once per iteration) */
+struct AssignWs
+{
+	float	   *pd = nullptr;
+	int		   *pi = nullptr;
+	float	   *cblock = nullptr;
+	size_t		pn = 0, cn = 0;
+	int release()
+	{
+		if (pd) HIP_TRY(hipFree(pd));
+		if (pi) HIP_TRY(hipFree(pi));
+		if (cblock) HIP_TRY(hipFree(cblock));
+		pd = nullptr; pi = nullptr; cblock = nullptr; pn = cn = 0;
+		return 0;
+	}
+};
+
+static int
+assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int ncent, bool use_sqrt,
+			int *d_out_list, int *d_counts, AssignWs *ws = nullptr)
+{
+	AssignWs	local;
+
+	if (!ws)
+		ws = &local;
+	const bool	fast = (dim % NDB_CHUNK) == 0;
+	const int	gsize = fast ? NDB_QG : NDB_CGROUP;
+	const int	ngroups = (ncent + gsize - 1) / gsize;
+	const int64_t chunk = 1 << 18;
+	const int64_t cmax = std::min<int64_t>(chunk, nrows);
+
+	if (nrows <= 0)
+		return 0;
+	if (ws->pn < (size_t) ngroups * cmax)
+	{
+		if (ws->pd) HIP_TRY(hipFree(ws->pd));
+		if (ws->pi) HIP_TRY(hipFree(ws->pi));
+		ws->pd = nullptr; ws->pi = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->pd, (size_t) ngroups * cmax * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &ws->pi, (size_t) ngroups * cmax * sizeof(int)));
+		ws->pn = (size_t) ngroups * cmax;
+	}
+	if (fast && ws->cn < (size_t) ngroups * dim * NDB_QG)
+	{
+		if (ws->cblock) HIP_TRY(hipFree(ws->cblock));
+		ws->cblock = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->cblock, (size_t) ngroups * dim * NDB_QG * sizeof(float)));
+		ws->cn = (size_t) ngroups * dim * NDB_QG;
+	}
+	float	   *pd = ws->pd, *cblock = ws->cblock;
+	int		   *pi = ws->pi;
+
+	if (fast)
+	{
+		hipLaunchKernelGGL(k_interleave16, dim3((dim + 255) / 256, ngroups), dim3(256), 0, g.stream, d_cents,
+						   ncent, dim, cblock);
+	}
+	for (int64_t r0 = 0; r0 < nrows; r0 += chunk)
+	{
+		const uint32_t n = (uint32_t) std::min<int64_t>(chunk, nrows - r0);
+		dim3		grid((n + 63) / 64, ngroups);
+		const float *rows = d_rows + (size_t) r0 * dim;
+
+		if (fast)
+		{
+			/* 1-D, XCD-aware: ceil(tiles / 8) * 8 tiles x ngroups blocks (k_assign_grouped decodes it) */
+			const dim3	g1((unsigned) ((((size_t) (n + 63) / 64 + 7) / 8) * 8 * (size_t) ngroups));
+
+			if (use_sqrt)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), g1, dim3(64), 0, g.stream, rows, n, dim,
+								   (const float *) cblock, ncent, pd, pi);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<false, 32>), g1, dim3(64), 0, g.stream, rows, n, dim,
+								   (const float *) cblock, ncent, pd, pi);
+		}
+		else if ((dim & 3) == 0)
+		{
+			if (use_sqrt)
+				hipLaunchKernelGGL(k_assign_partial<true>, grid, dim3(64), 0, g.stream, rows, n, dim, d_cents,
+								   ncent, pd, pi);
+			else
+				hipLaunchKernelGGL(k_assign_partial<false>, grid, dim3(64), 0, g.stream, rows, n, dim, d_cents,
+								   ncent, pd, pi);
+		}
+		else
+		{
+			if (use_sqrt)
+				hipLaunchKernelGGL(k_assign_partial_direct<true>, grid, dim3(64), 0, g.stream, rows, n, dim,
+								   d_cents, ncent, pd, pi);
+			else
+				hipLaunchKernelGGL(k_assign_partial_direct<false>, grid, dim3(64), 0, g.stream, rows, n, dim,
+								   d_cents, ncent, pd, pi);
+		}
+		hipLaunchKernelGGL(k_assign_combine, dim3((n + 255) / 256), dim3(256), 0, g.stream, (const float *) pd,
+						   (const int *) pi, ngroups, n, d_out_list + r0, d_counts);
+	}
+	HIP_TRY(hipGetLastError());
+	if (ws == &local)
+	{
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		return local.release();
+	}
+	return 0;
+}
+
+extern "C" int
+ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, const float *d_rows,
+						 int64_t nrows, int *d_out_list)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!d_centroids || ncentroids < 1 || dim < 1 || nrows < 0 || (nrows > 0 && (!d_rows || !d_out_list)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nrows > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "too many rows");
+	return assign_rows(d_rows, nrows, dim, d_centroids, ncentroids, true, d_out_list, nullptr);
+}
+
+/* ivfinsert (src/index/ivf_am.c:797-1167) for one host row: nearest centroid by the insert-time rule
+ * (sqrtf of the fp32 sum, strict <, first minimum: :905-935) on the device, then the entry goes to the tail
+ * of that list (ndbhip_ivf_append). */
+extern "C" int
+ndbhip_ivf_insert(ndbhip_ivf *ix, const float *vec, const uint8_t *tid6, int *list_out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !vec || !tid6)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!ix->loaded || ix->ncent < 1)
+		return fail(NDBHIP_ERR_STATE, "index has no centroids/lists loaded");
+	if (ix->sharded)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "insert into the unsharded mirror");
+	const int	ncmp = std::min(ix->nlists, ix->ncent);	/* i < nlist && i < maxoff: :917 */
+	int			list = 0;
+
+	if (grow(ix->w_q, ix->w_q_n, (size_t) ix->dim)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_ocnt, ix->w_ocnt_n, (size_t) 1)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(ix->w_q, vec, (size_t) ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	int			rc = assign_rows(ix->w_q, 1, ix->dim, ix->d_centroids, ncmp, true, ix->w_ocnt, nullptr);
+
+	if (rc)
+		return rc;
+	HIP_TRY(hipMemcpyAsync(&list, ix->w_ocnt, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (list_out)
+		*list_out = list;
+	return ndbhip_ivf_append(ix, list, vec, tid6);
+}
+
+extern "C" int
+ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter, float threshold,
+					 float *d_centroids, int *d_assign, int *d_counts, int *out_iters, float *out_cost)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!d_samples || !d_centroids || !d_assign || !d_counts || n < 1 || dim < 1 || k < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if ((size_t) n * 4 + 64 > NDB_TOPK_MAX_SMEM)	/* the reference samples at most 10000 rows (ivf_am.c:580) */
+		return fail(NDBHIP_ERR_UNSUPPORTED, "k-means sample of %d rows exceeds the LDS-resident limit", n);
+	float	   *d_pc = nullptr, *d_cost = nullptr;
+	float		prevCost = FLT_MAX, cost = 0.0f;
+	int			iters = 0;
+	AssignWs	ws;
+
+	HIP_TRY(hipMalloc((void **) &d_pc, (size_t) n * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_cost, sizeof(float)));
+	hipLaunchKernelGGL(k_kmeans_init, dim3((unsigned) (((size_t) k * dim + 255) / 256)), dim3(256), 0, g.stream,
+					   d_samples, n, dim, k, d_centroids);
+	for (int iter = 0; iter < max_iter; iter++)
+	{
+		int			rc;
+
+		HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t) k * sizeof(int), g.stream));
+		rc = assign_rows(d_samples, n, dim, d_centroids, k, false, d_assign, d_counts, &ws);
+		if (rc)
+			return rc;
+		hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), (size_t) n * 4 + 64, g.stream, d_samples, n, dim,
+						   (const int *) d_assign, (const int *) d_counts, d_centroids);
+		hipLaunchKernelGGL(k_kmeans_point_cost, dim3((n + 255) / 256), dim3(256), 0, g.stream, d_samples, n, dim,
+						   (const int *) d_assign, (const float *) d_centroids, d_pc);
+		hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(256), (size_t) n * 4, g.stream, (const float *) d_pc, n, d_cost);
+		HIP_TRY(hipMemcpyAsync(&cost, d_cost, sizeof(float), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		iters = iter + 1;
+		/* fabs(prevCost - cost) < threshold, float difference widened (ivf_am.c:2141) */
+		if (fabs((double) (float) (prevCost - cost)) < (double) threshold)
+			break;
+		prevCost = cost;
+	}
+	HIP_TRY(hipFree(d_pc));
+	HIP_TRY(hipFree(d_cost));
+	if (ws.release())
+		return NDBHIP_ERR_HIP;
+	if (out_iters)
+		*out_iters = iters;
+	if (out_cost)
+		*out_cost = cost;
+	return NDBHIP_OK;
+}
+
+/* One Lloyd half-step each, from host memory: kmeans_assign (ivf_am.c:2157-2180: first minimum of the fp32
+ * squared L2 over the k centroids) and kmeans_update_centroids (:2182-2213: members added in sample order,
+ * divided by (float) count; an empty cluster keeps its centroid).  The shapes of the GPU vtable's
+ * launch_kmeans_assign / launch_kmeans_update (include/neurondb_gpu_backend.h:66-79). */
+extern "C" int
+ndbhip_kmeans_assign(const float *X, const float *C, int *idx, int n, int dim, int k)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!X || !C || !idx || n < 1 || dim < 1 || dim > 32767 || k < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_x = nullptr, *d_c = nullptr;
+	int		   *d_i = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_x, (size_t) n * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_c, (size_t) k * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_i, (size_t) n * sizeof(int)));
+	HIP_TRY(hipMemcpyAsync(d_x, X, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_c, C, (size_t) k * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	int			rc = assign_rows(d_x, n, dim, d_c, k, false, d_i, nullptr);
+
+	if (!rc)
+	{
+		HIP_TRY(hipMemcpyAsync(idx, d_i, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	HIP_TRY(hipFree(d_x));
+	HIP_TRY(hipFree(d_c));
+	HIP_TRY(hipFree(d_i));
+	return rc;
+}
+
+__global__ void
+k_count_members(const int *__restrict__ idx, int n, int k, int *__restrict__ counts)
+{
+	const int	i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i < n && idx[i] >= 0 && idx[i] < k)
+		atomicAdd(&counts[idx[i]], 1);
+}
+
+extern "C" int
+ndbhip_kmeans_update(const float *X, const int *idx, float *C, int n, int dim, int k)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!X || !C || !idx || n < 1 || dim < 1 || dim > 32767 || k < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if ((size_t) n * 4 + 64 > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "k-means update of %d rows exceeds the LDS-resident member list", n);
+	float	   *d_x = nullptr, *d_c = nullptr;
+	int		   *d_i = nullptr, *d_n = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_x, (size_t) n * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_c, (size_t) k * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_i, (size_t) n * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &d_n, (size_t) k * sizeof(int)));
+	HIP_TRY(hipMemcpyAsync(d_x, X, (size_t) n * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_c, C, (size_t) k * dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_i, idx, (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(d_n, 0, (size_t) k * sizeof(int), g.stream));
+	hipLaunchKernelGGL(k_count_members, dim3((n + 255) / 256), dim3(256), 0, g.stream, (const int *) d_i, n, k, d_n);
+	hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), (size_t) n * 4 + 64, g.stream, (const float *) d_x, n, dim,
+					   (const int *) d_i, (const int *) d_n, d_c);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(C, d_c, (size_t) k * dim * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_x));
+	HIP_TRY(hipFree(d_c));
+	HIP_TRY(hipFree(d_i));
+	HIP_TRY(hipFree(d_n));
+	return NDBHIP_OK;
+}
+
+/* ---- list packing: stable counting sort of rows by list id (heap order kept inside a list) ---- */
+
+#define NDB_PACK_BLOCK 256
+
+/* per-block histogram: hist[list * nblocks + block] */
+__global__ __launch_bounds__(NDB_PACK_BLOCK) void
+k_pack_hist(const int *__restrict__ lists, int64_t nrows, int nlists, uint32_t nblocks,
+			uint32_t *__restrict__ hist)
+{
+	const int64_t r = (int64_t) blockIdx.x * NDB_PACK_BLOCK + threadIdx.x;
+
+	if (r < nrows)
+		atomicAdd(&hist[(size_t) lists[r] * nblocks + blockIdx.x], 1u);
+}
+
+/* exclusive scan of hist[list][block] in (list-major, block) order, on the device:
+ * pass A: one thread per list adds up its blocks -> list_len; pass B (single thread): list bases;
+ * pass C: one thread per list walks its blocks again writing the running offsets */
+__global__ void
+k_pack_list_totals(const uint32_t *__restrict__ hist, int nlists, uint32_t nblocks, int64_t *__restrict__ list_len)
+{
+	const int	L = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (L >= nlists)
+		return;
+	int64_t		t = 0;
+
+	for (uint32_t b = 0; b < nblocks; b++)
+		t += hist[(size_t) L * nblocks + b];
+	list_len[L] = t;
+}
+
+__global__ void
+k_pack_offsets(const uint32_t *__restrict__ hist, int nlists, uint32_t nblocks,
+			   const int64_t *__restrict__ list_len, int64_t *__restrict__ scanned)
+{
+	__shared__ int64_t base_sh;
+	const int	L = blockIdx.x;
+
+	if (threadIdx.x == 0)
+	{
+		int64_t		b0 = 0;
+
+		for (int l2 = 0; l2 < L; l2++)
+			b0 += list_len[l2];
+		base_sh = b0;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		int64_t		acc = base_sh;
+
+		for (uint32_t b = 0; b < nblocks; b++)
+		{
+			scanned[(size_t) L * nblocks + b] = acc;
+			acc += hist[(size_t) L * nblocks + b];
+		}
+	}
+}
+
+/* dest = scanned[list][block] + rank of the row among earlier same-list rows of its block; copies the row */
+__global__ __launch_bounds__(NDB_PACK_BLOCK) void
+k_pack_scatter(const int *__restrict__ lists, int64_t nrows, int dim, uint32_t nblocks,
+			   const int64_t *__restrict__ scanned, const float *__restrict__ rows,
+			   const uint64_t *__restrict__ tids, float *__restrict__ out_rows, uint64_t *__restrict__ out_tids)
+{
+	__shared__ int sl[NDB_PACK_BLOCK];
+	__shared__ int64_t sdest[NDB_PACK_BLOCK];
+	const int	t = threadIdx.x;
+	const int64_t r0 = (int64_t) blockIdx.x * NDB_PACK_BLOCK;
+	const int64_t r = r0 + t;
+	const int	L = (r < nrows) ? lists[r] : -1;
+
+	sl[t] = L;
+	__syncthreads();
+	if (r < nrows)
+	{
+		int			rank = 0;
+
+		for (int u = 0; u < t; u++)
+			rank += (sl[u] == L);
+		sdest[t] = scanned[(size_t) L * nblocks + blockIdx.x] + rank;
+		out_tids[sdest[t]] = tids[r];
+	}
+	__syncthreads();
+	const int	nb = (int) ((nrows - r0 < NDB_PACK_BLOCK) ? (nrows - r0) : NDB_PACK_BLOCK);
+
+	if ((dim & 3) == 0)
+	{
+		const int	d4 = dim >> 2;
+
+		for (int rr = 0; rr < nb; rr++)
+		{
+			const float4 *src = reinterpret_cast<const float4 *>(rows + (size_t) (r0 + rr) * dim);
+			float4	   *dst = reinterpret_cast<float4 *>(out_rows + (size_t) sdest[rr] * dim);
+
+			for (int j = t; j < d4; j += NDB_PACK_BLOCK)
+				dst[j] = src[j];
+		}
+	}
+	else
+	{
+		for (int rr = 0; rr < nb; rr++)
+			for (int j = t; j < dim; j += NDB_PACK_BLOCK)
+				out_rows[(size_t) sdest[rr] * dim + j] = rows[(size_t) (r0 + rr) * dim + j];
+	}
+}
+
+extern "C" int ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
+									   int max_iter, int *out_iters);
+
+/* ivfbuild (src/index/ivf_am.c:501-745) for host rows in heap order: staged H2D, then ndbhip_ivf_build_device */
+extern "C" int
+ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_t nrows, int max_iter, int *out_iters)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !rows || !tids6 || nrows < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_rows = nullptr;
+	uint64_t   *d_tids = nullptr;
+	std::vector<uint64_t> t64((size_t) nrows);
+
+	for (int64_t i = 0; i < nrows; i++)
+		t64[(size_t) i] = ndb_tid_pack(tids6 + (size_t) i * 6);
+	HIP_TRY(hipMalloc((void **) &d_rows, (size_t) nrows * ix->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_tids, (size_t) nrows * sizeof(uint64_t)));
+	HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t) nrows * ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_tids, t64.data(), (size_t) nrows * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	const int	rc = ndbhip_ivf_build_device(ix, d_rows, d_tids, nrows, max_iter, out_iters);
+
+	(void) hipStreamSynchronize(g.stream);
+	(void) hipFree(d_rows);
+	(void) hipFree(d_tids);
+	return rc;
+}
+
+extern "C" int
+ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
+						int max_iter, int *out_iters)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !d_rows || !d_tids || nrows < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (nrows > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "too many rows");
+	const int	dim = ix->dim;
+	const int	k = ix->nlists;
+	/* maxSamples = Min(10000, nlists * 100): the FIRST rows in heap order (ivf_am.c:580, 486-495) */
+	const int	ns = (int) std::min<int64_t>(std::min<int64_t>(10000, (int64_t) k * 100), nrows);
+
+	if (ns < k)					/* ivf_am.c:596-601 */
+		return fail(NDBHIP_ERR_INVALID, "ivf: not enough sample vectors (%d < %d)", ns, k);
+
+	float	   *d_cent = nullptr;
+	int		   *d_sasg = nullptr, *d_scnt = nullptr, *d_list = nullptr;
+	int			iters = 0, rc;
+	const bool	dbg = g_debug_build != 0;
+	auto		now = [&]() { if (dbg) (void) hipStreamSynchronize(g.stream); return std::chrono::steady_clock::now(); };
+	auto		t_start = now();
+	auto		lap = [&](const char *what) {
+		if (!dbg) return;
+		auto		t = now();
+		fprintf(stderr, "build: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count());
+		t_start = t;
+	};
+
+	HIP_TRY(hipMalloc((void **) &d_cent, (size_t) k * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_sasg, (size_t) ns * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &d_scnt, (size_t) k * sizeof(int)));
+	rc = ndbhip_kmeans_device(d_rows, ns, dim, k, max_iter, 0.001f, d_cent, d_sasg, d_scnt, &iters, nullptr);
+	if (rc)
+		return rc;
+	lap("k-means on the sample");
+	HIP_TRY(hipFree(d_sasg));
+	HIP_TRY(hipFree(d_scnt));
+
+	/* every row goes to the list ivfinsert would choose (Q5: the reference leaves this to later INSERTs) */
+	HIP_TRY(hipMalloc((void **) &d_list, (size_t) nrows * sizeof(int)));
+	lap("free + malloc list ids");
+	AssignWs	aws;				/* own workspace: assign_rows then returns without waiting for its kernels */
+
+	rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr, &aws);
+	if (rc)
+		return rc;
+	/* The packed mirror is allocated while the assignment kernels run: a fresh multi-GB hipMalloc is host-side
+	 * work (page-table setup) that took 0.3 ms in one process and 63 ms in the next on the same box — as much
+	 * as the rest of the build — and it needs nothing the GPU is busy with. */
+	float	   *d_prow = nullptr;
+	uint64_t   *d_ptid = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+	lap("assign every row (+ malloc of the packed rows under it)");
+
+	const uint32_t nblocks = (uint32_t) ((nrows + NDB_PACK_BLOCK - 1) / NDB_PACK_BLOCK);
+	const size_t nh = (size_t) k * nblocks;
+	uint32_t   *d_hist = nullptr;
+	int64_t    *d_scan = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_hist, nh * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &d_scan, nh * sizeof(int64_t)));
+	HIP_TRY(hipMemsetAsync(d_hist, 0, nh * sizeof(uint32_t), g.stream));
+	hipLaunchKernelGGL(k_pack_hist, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list, nrows,
+					   k, nblocks, d_hist);
+	std::vector<int64_t> list_len((size_t) k, 0);
+	int64_t    *d_llen = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_llen, (size_t) k * sizeof(int64_t)));
+	hipLaunchKernelGGL(k_pack_list_totals, dim3((k + 63) / 64), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k,
+					   nblocks, d_llen);
+	hipLaunchKernelGGL(k_pack_offsets, dim3(k), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k, nblocks,
+					   (const int64_t *) d_llen, d_scan);
+	HIP_TRY(hipMemcpyAsync(list_len.data(), d_llen, (size_t) k * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+
+	lap("histograms / offsets");
+	hipLaunchKernelGGL(k_pack_scatter, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list,
+					   nrows, dim, nblocks, (const int64_t *) d_scan, d_rows, d_tids, d_prow, d_ptid);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	lap("scatter");
+	if (aws.release()) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipFree(d_hist));
+	HIP_TRY(hipFree(d_scan));
+	HIP_TRY(hipFree(d_list));
+	HIP_TRY(hipFree(d_llen));
+	lap("frees");
+
+	/* adopt: centroids + packed lists become the index */
+	if (ix->d_centroids)
+		HIP_TRY(hipFree(ix->d_centroids));
+	ix->d_centroids = d_cent;
+	ix->ncent = k;
+	rc = ivf_set_layout(ix, list_len.data(), nullptr, nrows);
+	if (rc)
+		return rc;
+	ivf_free_rows(ix);
+	ix->d_vecs = d_prow;
+	ix->d_tids = d_ptid;
+	ix->own_rows = true;
+	ix->nrows = nrows;
+	ix->norm_valid = false; ix->s16_valid = false;
+	ix->cap_rows = nrows;
+	ix->loaded = true;
+	lap("adopt (layout upload, old rows freed)");
+	if (out_iters)
+		*out_iters = iters;
+	return NDBHIP_OK;
+}
+
+/* read the index image back (tests, bench cpu baseline, PostgreSQL page writer) */
+extern "C" int
+ndbhip_ivf_export(const ndbhip_ivf *cix, float *centroids, int64_t *list_len, float *rows, uint8_t *tids6)
+{
+	ndbhip_ivf *ix = const_cast<ndbhip_ivf *>(cix);
+
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix || !ix->loaded)
+		return fail(NDBHIP_ERR_STATE, "index not loaded");
+	if (ivf_flush(ix))
+		return NDBHIP_ERR_HIP;
+	if (centroids)
+		HIP_TRY(hipMemcpy(centroids, ix->d_centroids, (size_t) ix->ncent * ix->dim * 4, hipMemcpyDeviceToHost));
+	if (list_len)
+		for (int c = 0; c < ix->ncent; c++)
+			list_len[c] = ix->own_len[c];
+	if (rows && ix->f16)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "fp16 mirror: rows are not exported as float4");
+	if (rows && ix->nrows > 0)
+		HIP_TRY(hipMemcpy(rows, ix->d_vecs, (size_t) ix->nrows * ix->dim * 4, hipMemcpyDeviceToHost));
+	if (tids6 && ix->nrows > 0)
+	{
+		std::vector<uint64_t> t((size_t) ix->nrows);
+
+		HIP_TRY(hipMemcpy(t.data(), ix->d_tids, t.size() * 8, hipMemcpyDeviceToHost));
+		for (int64_t r = 0; r < ix->nrows; r++)
+			ndb_tid_unpack(t[(size_t) r], tids6 + 6 * r);
+	}
+	return NDBHIP_OK;
+}
+
+/* New index holding only the lists with owned[L] != 0 (device-to-device copy);
+ * list lengths stay global so candidate positions are identical on every rank. */
+/* New mirror holding positions [lo[c], lo[c] + len[c]) of every list c of `src` (device-to-device copy).
+ * Whole lists are the usual shard; a slice lets several ranks share one long, popular list (its candidates keep
+ * their positions in the reference's candidates[], so the merged result is unchanged). */
+extern "C" int
+ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const int64_t *len, const uint8_t *tail,
+						ndbhip_ivf **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!src || !src->loaded || !lo || !len || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	for (int c = 0; c < src->ncent; c++)
+		if (len[c] < 0 || lo[c] < 0 ||
+			(len[c] > 0 && (lo[c] < src->own_lo[c] || lo[c] + len[c] > src->own_lo[c] + src->own_len[c])))
+			return fail(NDBHIP_ERR_INVALID, "slice of list %d is not resident in the source index", c);
+	if (!src->pend_list.empty())
+		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
+	ndbhip_ivf *ix = nullptr;
+	int			rc = ndbhip_ivf_create(src->dim, src->nlists, &ix);
+
+	if (rc)
+		return rc;
+	HIP_TRY(hipMalloc((void **) &ix->d_centroids, (size_t) src->ncent * src->dim * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(ix->d_centroids, src->d_centroids, (size_t) src->ncent * src->dim * sizeof(float),
+						   hipMemcpyDeviceToDevice, g.stream));
+	ix->ncent = src->ncent;
+	ix->meta_nprobe = src->meta_nprobe;
+	int64_t		nrows = 0;
+
+	for (int c = 0; c < src->ncent; c++)
+		nrows += len[c];
+	rc = ivf_set_layout(ix, src->glob_len.data(), tail, nrows, lo, len);
+	if (rc)
+		return rc;
+	const int64_t cap = nrows > 0 ? nrows : 1;
+	const size_t esz = src->f16 ? sizeof(uint16_t) : sizeof(float);	/* rows are fp16 images or float4 */
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * esz));
+	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
+	ix->own_rows = true;
+	ix->cap_rows = cap;
+	ix->f16 = src->f16;
+	for (int c = 0; c < src->ncent; c++)
+	{
+		const int64_t n = len[c];
+
+		if (n == 0)
+			continue;
+		const int64_t from = src->loc_off[c] + (lo[c] - src->own_lo[c]);
+
+		HIP_TRY(hipMemcpyAsync((char *) ix->d_vecs + (size_t) ix->loc_off[c] * ix->dim * esz,
+							   (const char *) src->d_vecs + (size_t) from * src->dim * esz,
+							   (size_t) n * ix->dim * esz, hipMemcpyDeviceToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_tids + ix->loc_off[c], src->d_tids + from, (size_t) n * sizeof(uint64_t),
+							   hipMemcpyDeviceToDevice, g.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	ix->nrows = nrows;
+	ix->norm_valid = false; ix->s16_valid = false;
+	ix->loaded = true;
+	ix->f16_sub = src->f16_sub;	/* a shard holds a subset of the source's rows */
+	*out = ix;
+	return NDBHIP_OK;
+}
+
+/* the lists with owned[L] != 0, whole */
+extern "C" int
+ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf **out)
+{
+	if (!src || !src->loaded || !owned || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	std::vector<int64_t> lo((size_t) src->ncent, 0), len((size_t) src->ncent, 0);
+
+	for (int c = 0; c < src->ncent; c++)
+	{
+		if (owned[c] && src->own_len[c] != src->glob_len[c])
+			return fail(NDBHIP_ERR_INVALID, "list %d is not resident in the source index", c);
+		len[(size_t) c] = owned[c] ? src->glob_len[c] : 0;
+	}
+	return ndbhip_ivf_shard_slices(src, lo.data(), len.data(), owned, out);
+}
+
+/* float4 -> IEEE half image.  REF = the reference's float4_to_fp16 (src/types/quantization.c:141-168:
+ * mantissa truncated, subnormal results flushed to signed zero, overflow and NaN -> infinity); else
+ * round-to-nearest-even (v_cvt_f16_f32). */
+template <bool REF>
+__global__ __launch_bounds__(256) void
+k_rows_to_f16(const float *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
+{
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+
+	if (i >= n)
+		return;
+	if (REF)
+	{
+		const uint32_t u = __float_as_uint(src[i]);
+		const uint16_t sign = (uint16_t) ((u >> 16) & 0x8000u);
+		const int	e = (int) ((u >> 23) & 0xffu) - 127 + 15;
+
+		dst[i] = e <= 0 ? sign : (e >= 31 ? (uint16_t) (sign | 0x7c00u)
+								  : (uint16_t) (sign | ((uint32_t) e << 10) | ((u & 0x7fffffu) >> 13)));
+	}
+	else
+		dst[i] = __half_as_ushort(__float2half_rn(src[i]));
+}
+
+/* A halfvec twin of a float4 mirror: same centroids, lists and TIDs, rows narrowed on the device. */
+extern "C" int
+ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!src || !src->loaded || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (src->f16)
+		return fail(NDBHIP_ERR_STATE, "the mirror already holds fp16 rows");
+	if (src->dim % 64 != 0)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "fp16 rows need dim %% 64 == 0 (dim = %d)", src->dim);
+	if (!src->pend_list.empty())
+		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
+	ndbhip_ivf *ix = nullptr;
+	int			rc = ndbhip_ivf_create(src->dim, src->nlists, &ix);
+
+	if (rc)
+		return rc;
+	HIP_TRY(hipMalloc((void **) &ix->d_centroids, (size_t) src->ncent * src->dim * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(ix->d_centroids, src->d_centroids, (size_t) src->ncent * src->dim * sizeof(float),
+						   hipMemcpyDeviceToDevice, g.stream));
+	ix->ncent = src->ncent;
+	rc = ivf_set_layout(ix, src->glob_len.data(), src->owned.data(), src->nrows, src->own_lo.data(), src->own_len.data());
+	if (rc)
+		return rc;
+	const int64_t cap = src->nrows > 0 ? src->nrows : 1;
+	const size_t nel = (size_t) src->nrows * src->dim;
+
+	HIP_TRY(hipMalloc((void **) &ix->d_vecs, (size_t) cap * ix->dim * sizeof(uint16_t)));
+	HIP_TRY(hipMalloc((void **) &ix->d_tids, (size_t) cap * sizeof(uint64_t)));
+	ix->own_rows = true;
+	ix->cap_rows = cap;
+	if (nel > 0)
+	{
+		const dim3	grid((unsigned) ((nel + 255) / 256));
+
+		if (reference_encoder)
+			hipLaunchKernelGGL(k_rows_to_f16<true>, grid, dim3(256), 0, g.stream, (const float *) src->d_vecs,
+							   (uint16_t *) ix->d_vecs, nel);
+		else
+			hipLaunchKernelGGL(k_rows_to_f16<false>, grid, dim3(256), 0, g.stream, (const float *) src->d_vecs,
+							   (uint16_t *) ix->d_vecs, nel);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(ix->d_tids, src->d_tids, (size_t) src->nrows * sizeof(uint64_t),
+							   hipMemcpyDeviceToDevice, g.stream));
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	ix->nrows = src->nrows;
+	ix->norm_valid = false; ix->s16_valid = false;
+	ix->f16 = true;
+	ix->loaded = true;
+	*out = ix;
+	return ivf_note_f16_subnormals(ix);	/* the reference's encoder flushes them; round-to-nearest may not */
+}
+
+/* float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal results flushed) for n
+ * values from host memory: the GPU vtable's launch_quant_fp16 with the CPU encoder's bits */
+extern "C" int
+ndbhip_quant_fp16(const float *in, uint16_t *out, int64_t n)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!in || !out || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_in = nullptr;
+	uint16_t   *d_out = nullptr;
+
+	HIP_TRY(hipMalloc((void **) &d_in, (size_t) n * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_out, (size_t) n * sizeof(uint16_t)));
+	HIP_TRY(hipMemcpyAsync(d_in, in, (size_t) n * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_rows_to_f16<true>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, g.stream,
+					   (const float *) d_in, d_out, (size_t) n);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out, d_out, (size_t) n * sizeof(uint16_t), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipFree(d_in));
+	HIP_TRY(hipFree(d_out));
+	return NDBHIP_OK;
+}
+
+
+/* nprobe as the meta page / reloptions carry it: what ivfrescan reads (ivf_am.c:1487-1513) */
+extern "C" int
+ndbhip_ivf_get_nprobe(const ndbhip_ivf *ix, int *nprobe)
+{
+	if (!ix || !nprobe)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	*nprobe = ix->meta_nprobe;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_set_nprobe(ndbhip_ivf *ix, int nprobe)
+{
+	if (!ix)
+		return fail(NDBHIP_ERR_INVALID, "index is NULL");
+	ix->meta_nprobe = nprobe;	/* <= 0 is legal on the page: ivfrescan then takes the default (:1512-1513) */
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_shape(const ndbhip_ivf *ix, int *dim, int *nlists)
+{
+	if (!ix)
+		return fail(NDBHIP_ERR_INVALID, "index is NULL");
+	if (dim) *dim = ix->dim;
+	if (nlists) *nlists = ix->nlists;
+	return NDBHIP_OK;
+}
+
+/* error text for the PostgreSQL-free page codec (ndbhip_pages.cpp) */
+int
+ndbhip_pages_fail(int code, const char *msg)
+{
+	return fail(code, "%s", msg);
+}
+
+extern "C" int
+ndbhip_ivf_dim(const ndbhip_ivf *ix)
+{
+	return ix ? ix->dim : fail(NDBHIP_ERR_INVALID, "index is NULL");
+}
+
+extern "C" int
+ndbhip_ivf_ncentroids(const ndbhip_ivf *ix)
+{
+	return ix ? ix->ncent : -1;
+}
+
+
+#endif							/* NDBHIP_BUILD_H */

@@ -20,10 +20,12 @@ def test_vtable_members_and_launchers():
     from neurondb_amd._lib import NdbHipDeviceInfo
     _lib.ensure_init()
     be = _lib.lib().ndb_hip_backend_get().contents
-    assert be.name == b"ndbhip" and be.provider == b"AMD"
+    assert be.name == b"ndbhip" and be.provider == b"AMD" and be.kind == 2      # NDB_GPU_BACKEND_ROCM
+    assert not be.launch_quant_int8 and not be.launch_pq_encode                   # out of scope: NULL = CPU fallback
     assert be.is_available() == 1 and be.device_count() >= 1 and be.init() == 0
     info = NdbHipDeviceInfo()
-    assert be.device_info(0, C.byref(info)) == 0 and info.compute_units > 0 and info.total_memory_bytes > 2 ** 30
+    assert be.device_info(0, C.byref(info)) == 0 and info.compute_major == 9 and info.is_available and \
+        info.total_memory_bytes > 2 ** 30
     assert be.device_info(99, C.byref(info)) < 0 and be.set_device(99) < 0 and be.set_device(0) == 0
     # memory helpers + streams
     p, s = C.c_void_p(), C.c_void_p()
@@ -31,7 +33,10 @@ def test_vtable_members_and_launchers():
     dst = np.zeros_like(src)
     assert be.mem_alloc(C.byref(p), src.nbytes) == 0 and be.memcpy_h2d(p, _p(src), src.nbytes) == 0
     assert be.memcpy_d2h(_p(dst), p, src.nbytes) == 0 and np.array_equal(src, dst) and be.mem_free(p) == 0
-    assert be.stream_create(C.byref(s)) == 0 and be.stream_synchronize(s) == 0 and be.stream_destroy(s) == 0
+    # the reference keeps its three stream members at the very end of ndb_gpu_backend: separate accessor
+    sc, sy, sd = _lib.STREAM_CREATE(), _lib.STREAM_OP(), _lib.STREAM_OP()
+    _lib.lib().ndb_hip_backend_streams(C.byref(sc), C.byref(sd), C.byref(sy))
+    assert sc(C.byref(s)) == 0 and sy(s) == 0 and sd(s) == 0
     # launch_l2_distance / launch_cosine: n PAIRS, the CPU functions' arithmetic (Kahan L2, double cosine)
     O = ndbo.lib()
     rng = np.random.default_rng(3)
