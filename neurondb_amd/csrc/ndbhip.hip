@@ -2053,18 +2053,20 @@ k_delete_positions(const uint8_t *__restrict__ keep, int64_t nrows, const uint32
 __global__ __launch_bounds__(256) void
 k_delete_move(const uint8_t *__restrict__ keep, const uint32_t *__restrict__ pref, const uint32_t *__restrict__ src,
 			  const uint64_t *__restrict__ src_tids, uint32_t *__restrict__ dst, uint64_t *__restrict__ dst_tids,
-			  uint32_t row_words)
+			  uint32_t row_words, size_t nrows)
 {
-	const size_t r = blockIdx.x;
+	/* (blocks stride over the rows: a launch carries at most 2^32 - 1 work-items, i.e. 16.7 M blocks of 256) */
+	for (size_t r = blockIdx.x; r < nrows; r += gridDim.x)
+	{
+		if (!keep[r])
+			continue;
+		const size_t d = pref[r];
 
-	if (!keep[r])
-		return;
-	const size_t d = pref[r];
-
-	for (uint32_t j = threadIdx.x; j < row_words; j += 256)
-		dst[d * row_words + j] = src[r * row_words + j];
-	if (threadIdx.x == 0)
-		dst_tids[d] = src_tids[r];
+		for (uint32_t j = threadIdx.x; j < row_words; j += 256)
+			dst[d * row_words + j] = src[r * row_words + j];
+		if (threadIdx.x == 0)
+			dst_tids[d] = src_tids[r];
+	}
 }
 
 __global__ void
@@ -2146,9 +2148,9 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 
 		if (tmp.alloc(nv, (size_t) cap * ix->dim * esz)) return NDBHIP_ERR_HIP;
 		if (tmp.alloc(nt, (size_t) cap * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
-		hipLaunchKernelGGL(k_delete_move, dim3((unsigned) nrows), dim3(256), 0, g.stream, (const uint8_t *) d_keep,
-						   (const uint32_t *) d_pref, (const uint32_t *) ix->d_vecs, (const uint64_t *) ix->d_tids,
-						   (uint32_t *) nv, nt, row_words);
+		hipLaunchKernelGGL(k_delete_move, dim3((unsigned) std::min<int64_t>(nrows, 1 << 23)), dim3(256), 0, g.stream,
+						   (const uint8_t *) d_keep, (const uint32_t *) d_pref, (const uint32_t *) ix->d_vecs,
+						   (const uint64_t *) ix->d_tids, (uint32_t *) nv, nt, row_words, (size_t) nrows);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(g.stream));
 		ivf_free_rows(ix);

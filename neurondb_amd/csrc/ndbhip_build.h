@@ -1073,21 +1073,23 @@ template <bool REF>
 __global__ __launch_bounds__(256) void
 k_rows_to_f16(const float *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
 {
-	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
-
-	if (i >= n)
-		return;
-	if (REF)
+	/* grid-stride: a launch carries at most 2^32 - 1 work-items per dimension, a 10M x 1536 mirror has 1.5e10
+	 * elements (found by the full-size oracle replay of tests/test_gpu_fullsize.py: with one thread per element
+	 * the launch wrapped and left most of the twin unwritten) */
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256)
 	{
-		const uint32_t u = __float_as_uint(src[i]);
-		const uint16_t sign = (uint16_t) ((u >> 16) & 0x8000u);
-		const int	e = (int) ((u >> 23) & 0xffu) - 127 + 15;
+		if (REF)
+		{
+			const uint32_t u = __float_as_uint(src[i]);
+			const uint16_t sign = (uint16_t) ((u >> 16) & 0x8000u);
+			const int	e = (int) ((u >> 23) & 0xffu) - 127 + 15;
 
-		dst[i] = e <= 0 ? sign : (e >= 31 ? (uint16_t) (sign | 0x7c00u)
-								  : (uint16_t) (sign | ((uint32_t) e << 10) | ((u & 0x7fffffu) >> 13)));
+			dst[i] = e <= 0 ? sign : (e >= 31 ? (uint16_t) (sign | 0x7c00u)
+									  : (uint16_t) (sign | ((uint32_t) e << 10) | ((u & 0x7fffffu) >> 13)));
+		}
+		else
+			dst[i] = __half_as_ushort(__float2half_rn(src[i]));
 	}
-	else
-		dst[i] = __half_as_ushort(__float2half_rn(src[i]));
 }
 
 /* A halfvec twin of a float4 mirror: same centroids, lists and TIDs, rows narrowed on the device. */
@@ -1124,7 +1126,7 @@ ndbhip_ivf_to_f16(const ndbhip_ivf *src, int reference_encoder, ndbhip_ivf **out
 	ix->cap_rows = cap;
 	if (nel > 0)
 	{
-		const dim3	grid((unsigned) ((nel + 255) / 256));
+		const dim3	grid((unsigned) std::min<size_t>((nel + 255) / 256, (size_t) 1 << 22));
 
 		if (reference_encoder)
 			hipLaunchKernelGGL(k_rows_to_f16<true>, grid, dim3(256), 0, g.stream, (const float *) src->d_vecs,

@@ -281,4 +281,44 @@ def test_c4_c5_single_gpu_share_properties(cfg):
         out = np.zeros((1, K), np.float32)
         check(lib.ndbhip_batch_distance(qh[i].ctypes.data, v.ctypes.data, out.ctypes.data, 1, K, dim, strategy, 0))
         assert np.array_equal(out[0].view(np.uint32), dist[i].view(np.uint32)), i
+
+    # Oracle replay at full size: ivfSelectClusters + ivfCollectCandidates of the CPU oracle
+    # (ivf_am.c:1597-1909) for a few of the batch's queries, over an image that holds every centroid and the rows
+    # of the lists those queries probe (an unprobed list is never walked, so its rows need not leave the device).
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import ndbo
+    cent_h, ll, _, _ = ix.export(rows=False)
+    t6 = np.zeros((n, 6), np.uint8)
+    check(lib.ndbhip_ivf_export(ix._h, None, None, None, t6.ctypes.data_as(C.c_void_p)))
+    tid_all = t6.view(ndbo.TID_DTYPE).reshape(n)
+    order = (((tid_all["bi_hi"].astype(np.int64) << 16) | tid_all["bi_lo"]) * 64 + tid_all["posid"] - 1)   # heap row of every mirror row
+    off = np.zeros(len(ll) + 1, np.int64)
+    off[1:] = np.cumsum(ll)
+    picks, lists_u = [], set()
+    for i in range(0, nq, max(1, nq // 8)):
+        pr = [int(x) for x in ix.select_clusters(qh[i:i + 1], PROBES)[0] if x >= 0]
+        grown = lists_u | set(pr)
+        if sum(int(ll[L]) for L in grown) * dim * 4 > 16 * 2 ** 30 and picks:     # keep the host image under 16 GiB
+            continue
+        lists_u = grown
+        picks.append(i)
+    keep = np.zeros(len(ll), bool)
+    keep[list(lists_u)] = True
+    ll2 = np.where(keep, ll, 0)
+    off2 = np.zeros(len(ll) + 1, np.int64)
+    off2[1:] = np.cumsum(ll2)
+    sel = np.concatenate([np.arange(off[L], off[L + 1]) for L in sorted(lists_u)]) if lists_u else np.zeros(0, np.int64)
+    rows_img = np.empty((len(sel), dim), np.float32)
+    for s0 in range(0, len(sel), 1 << 18):
+        idx = torch.from_numpy(order[sel[s0:s0 + (1 << 18)]]).to(dev)
+        rows_img[s0:s0 + (1 << 18)] = base[idx].cpu().numpy()
+    img = ndbo.IvfImage(cent_h, off2, rows_img, np.ascontiguousarray(tid_all[sel]))
+    with ThreadPoolExecutor(max_workers=len(picks)) as ex:
+        res = list(ex.map(lambda i: img.search(qh[i], strategy, PROBES, K, 0), picks))
+    for i, (et, ed, _) in zip(picks, res):
+        erow = ((et["bi_hi"].astype(np.int64) << 16) | et["bi_lo"]) * 64 + et["posid"] - 1
+        assert len(et) == cnt[i] and np.array_equal(erow, rows[i, :len(et)]), (cfg, i)
+        assert np.array_equal(ed.view(np.uint32), dist[i, :len(et)].view(np.uint32)), (cfg, i)
+    assert len(picks) >= 4
     ix.close()
