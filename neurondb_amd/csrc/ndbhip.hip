@@ -2237,6 +2237,7 @@ ivf_recipe(int strategy)
 /* the fp16-MFMA screened scan in auto mode (ndbhip_set_option("screen16", 0) turns it off: the older fp32 bound
  * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
 static int	g_s16_auto = 1;
+static int	g_build_s16 = 1;		/* ndbhip_set_option("build_screen16", 0): the build assigns on the vector ALU only */
 static int	g_s16_waves = 4;
 static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
 static uint32_t g_s16_ecap = 2048;
@@ -2547,6 +2548,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_debug"))
 		g_s16_debug = value;
+	else if (!strcmp(name, "build_screen16"))
+		g_build_s16 = value != 0;
 	else if (!strcmp(name, "gchunk"))
 	{
 		if (value != 32 && value != 64)

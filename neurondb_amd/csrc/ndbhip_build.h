@@ -539,6 +539,9 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 	return 0;
 }
 
+static int	assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int k, int *d_out_list,
+							unsigned long long *stats, const std::function<int()> &while_running);
+
 extern "C" int
 ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, const float *d_rows,
 						 int64_t nrows, int *d_out_list)
@@ -548,6 +551,13 @@ ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, cons
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (nrows > 0xFFFFFFFFll)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "too many rows");
+	if (g_build_s16 && nrows >= 4096)
+	{
+		const int	rc = assign_rows_s16(d_rows, nrows, dim, d_centroids, ncentroids, d_out_list, nullptr, nullptr);
+
+		if (rc != 1)
+			return rc;
+	}
 	return assign_rows(d_rows, nrows, dim, d_centroids, ncentroids, true, d_out_list, nullptr);
 }
 
@@ -811,6 +821,310 @@ k_pack_scatter(const int *__restrict__ lists, int64_t nrows, int dim, uint32_t n
 	}
 }
 
+__global__ void __launch_bounds__(256)
+k_rows_gather(const float *__restrict__ rows, int dim, const int64_t *__restrict__ which, float *__restrict__ out)
+{
+	const float *src = rows + (size_t) which[blockIdx.x] * dim;
+	float	   *dst = out + (size_t) blockIdx.x * dim;
+
+	for (int j = threadIdx.x; j < dim; j += 256)
+		dst[j] = src[j];
+}
+
+__global__ void
+k_list_scatter(const int *__restrict__ lists, const int64_t *__restrict__ which, uint32_t n, int *__restrict__ out_list)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i < n)
+		out_list[which[i]] = lists[i];
+}
+
+/* 64-bit content hash of every centroid (wave per centroid; a sum of mixed words, so lane order does not matter) */
+__global__ void __launch_bounds__(256)
+k_cent_hash(const float *__restrict__ cents, int k, int dim, unsigned long long *__restrict__ hash)
+{
+	const int	lane = threadIdx.x & 63;
+	const int	c = blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (c >= k)
+		return;
+	const uint32_t *x = reinterpret_cast<const uint32_t *>(cents) + (size_t) c * dim;
+	unsigned long long h = 0;
+
+	for (int i = lane; i < dim; i += 64)
+	{
+		unsigned long long z = ((unsigned long long) x[i] << 32 | (uint32_t) i) + 0x9E3779B97F4A7C15ull;
+
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		h += z ^ (z >> 31);
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const uint32_t lo = __shfl_xor((uint32_t) h, off, 64);
+		const uint32_t hi = __shfl_xor((uint32_t) (h >> 32), off, 64);
+
+		h += ((unsigned long long) hi << 32) | lo;
+	}
+	if (lane == 0)
+		hash[c] = h;
+}
+
+/* dup[c] = 1 when a centroid with a smaller id holds the same bits.  Such a centroid can never be chosen: its
+ * distance to any row is the earlier one's, and the insert rule's test is a strict < (ivf_am.c:905-935). */
+__global__ void __launch_bounds__(256)
+k_cent_dups(const float *__restrict__ cents, int k, int dim, const unsigned long long *__restrict__ hash,
+			unsigned char *__restrict__ dup)
+{
+	const int	c = blockIdx.x * 256 + threadIdx.x;
+
+	if (c >= k)
+		return;
+	const unsigned long long h = hash[c];
+	unsigned char d = 0;
+
+	for (int j = 0; j < c && !d; j++)
+		if (hash[j] == h)
+		{
+			const uint32_t *a = reinterpret_cast<const uint32_t *>(cents) + (size_t) c * dim;
+			const uint32_t *b = reinterpret_cast<const uint32_t *>(cents) + (size_t) j * dim;
+			int			i = 0;
+
+			while (i < dim && a[i] == b[i])
+				i++;
+			d = i == dim;
+		}
+	dup[c] = d;
+}
+
+/* words of the sweep's tables for one slab shape: blk_off[2] | own_len[1] | cnt[1] | pair_off[2] | item_off[2] |
+ * runs[9] | loc_cand_off[k][2] */
+#define NDB_ASG_META(k) ((size_t) 17 + 2 * (size_t) (k))
+
+/* One wave: the centroids that are not duplicates, in id order, become the sweep's "(query, probe) pairs"; the
+ * tables of the full slab (meta_a) and of the last, shorter one (meta_b) */
+__global__ void __launch_bounds__(64)
+k_assign_tables(const unsigned char *__restrict__ dup, int k, uint32_t rows_a, uint32_t rows_b,
+				PairRec *__restrict__ pairs, uint32_t *__restrict__ meta_a, uint32_t *__restrict__ meta_b)
+{
+	const int	lane = threadIdx.x;
+	uint32_t	total = 0;
+
+	for (int c0 = 0; c0 < k; c0 += 64)
+	{
+		const int	c = c0 + lane;
+		const bool	keep = c < k && dup[c] == 0;
+		const unsigned long long m = __ballot(keep);
+
+		if (keep)
+		{
+			PairRec		pr;
+
+			pr.q = (uint32_t) c;
+			pr.p = 0;
+			pairs[total + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = pr;
+		}
+		total += (uint32_t) __popcll(m);
+	}
+	const uint32_t nqt = (total + S16_QT - 1) / S16_QT;
+
+	for (int v = 0; v < 2; v++)
+	{
+		uint32_t   *m32 = v ? meta_b : meta_a;
+		const uint32_t n = v ? rows_b : rows_a;
+		const uint32_t nitems = ((n + 127u) / 128u) * nqt;
+
+		if (lane == 0)
+		{
+			m32[0] = 0; m32[1] = (n + 31u) / 32u;
+			m32[2] = n;
+			m32[3] = total;
+			m32[4] = 0; m32[5] = total;
+			m32[6] = 0; m32[7] = nitems;
+		}
+		if (lane <= 8)
+			m32[8 + lane] = (uint32_t) (((unsigned long long) nitems * (uint32_t) lane) >> 3);
+		for (int c = lane; c < k; c += 64)
+		{
+			m32[17 + 2 * c] = 0;
+			m32[17 + 2 * c + 1] = n;
+		}
+	}
+}
+
+/*
+ * The assignment of every row to its nearest centroid (the insert-time rule, ivf_am.c:905-935) through the fp16
+ * matrix-core sweep: a slab of rows is one "list", the distinct centroids are the "queries".  Sweep 1
+ * (k_s16_sweep MODE 1) leaves every row's smallest bound a_min; sweep 2 (MODE 2) records the centroids whose a
+ * lies within the error bound of it, i.e. every centroid that can be the nearest in the reference's arithmetic;
+ * k_s16_assign_resolve decides by that arithmetic where more than one is left.  Rows with more candidates than
+ * record slots go through assign_rows.  Same list ids as assign_rows (tests/test_gpu_build.py compares both with
+ * the oracle).  Returns 1 when the shape is outside what the sweep handles (the caller then runs assign_rows).
+ * Temporaries are sized by the slab (2^20 rows), not by the table.
+ */
+static int
+assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int k, int *d_out_list,
+				unsigned long long *stats /* host [2] or NULL: rows decided among several candidates, rows sent to the exact assignment */ ,
+				const std::function<int()> &while_running /* host work done while the kernels run */ )
+{
+	const int	dimp = (dim + 63) & ~63;
+	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
+	const uint32_t nqt = (uint32_t) ((k + S16_QT - 1) / S16_QT);
+	const int64_t slab = std::min<int64_t>(nrows, (int64_t) 1 << 20);
+	const int64_t tail = nrows % slab == 0 ? slab : nrows % slab;
+	const uint64_t nb = (uint64_t) ((slab + 31) / 32);
+	const uint32_t nrt = (uint32_t) ((slab + 127) / 128);
+
+	if (nrows < 1 || k < 1 || k > 65535 || (size_t) k * qrowbytes >= ((size_t) 1 << 32) ||
+		(size_t) nrt * nqt > 0x7FFFFFFFull)
+		return 1;
+	DevGuard	tmp;
+	unsigned char *planes = nullptr, *qplanes = nullptr, *dup = nullptr;
+	float	   *rn2 = nullptr, *qn2 = nullptr;
+	int16_t    *rexp = nullptr;
+	int		   *qexp = nullptr;
+	float2	   *aux = nullptr;
+	uint32_t   *xmax = nullptr, *rowmin = nullptr, *meta = nullptr;
+	int64_t    *locoff = nullptr;
+	unsigned int *acnt = nullptr, *heads = nullptr, *over_n = nullptr;
+	unsigned long long *hash = nullptr;
+	int64_t    *over_rows = nullptr;
+	uint2	   *arec = nullptr;
+	PairRec    *pairs = nullptr;
+	S16Desc    *desc = nullptr;
+	const size_t blk_bytes = (size_t) (dimp / S16_CH) * 4096;
+	const uint32_t nitems = nrt * nqt;		/* upper bound: duplicates only shrink it */
+	const size_t mw = NDB_ASG_META(k);
+
+	if (tmp.alloc(planes, (size_t) (nb + 8) * blk_bytes)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(qplanes, (size_t) k * qrowbytes)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(rn2, (size_t) slab * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(rexp, (size_t) slab * 2)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(qn2, (size_t) k * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(qexp, (size_t) k * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(aux, (size_t) k * sizeof(float2))) return NDBHIP_ERR_HIP;	/* the sweep's per-query slot; only [0].x is used */
+	if (tmp.alloc(xmax, 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(rowmin, (size_t) slab * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(acnt, (size_t) slab * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(arec, (size_t) slab * S16_ASSIGN_SLOTS * sizeof(uint2))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(over_n, 16)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(over_rows, (size_t) nrows * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(pairs, (size_t) k * sizeof(PairRec))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(desc, (size_t) 2 * nitems * sizeof(S16Desc))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(locoff, 4 * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(meta, 2 * mw * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(heads, 2 * 8 * NDB_QHEAD_STRIDE * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(hash, (size_t) k * 8)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(dup, (size_t) k)) return NDBHIP_ERR_HIP;
+	const int64_t hloc[4] = {0, slab, 0, tail};
+
+	HIP_TRY(hipMemcpyAsync(locoff, hloc, sizeof(hloc), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(over_n, 0, 16, g.stream));
+	HIP_TRY(hipMemsetAsync(planes, 0, (size_t) (nb + 8) * blk_bytes, g.stream));
+	HIP_TRY(hipMemsetAsync(xmax, 0, 4, g.stream));
+	HIP_TRY(hipMemsetAsync(heads, 0, 2 * 8 * NDB_QHEAD_STRIDE * 4, g.stream));
+	/* the centroids: duplicates dropped, split into fp16 planes, the sweep's tables for both slab shapes */
+	hipLaunchKernelGGL(k_cent_hash, dim3((k + 3) / 4), dim3(256), 0, g.stream, d_cents, k, dim, hash);
+	hipLaunchKernelGGL(k_cent_dups, dim3((k + 255) / 256), dim3(256), 0, g.stream, d_cents, k, dim,
+					   (const unsigned long long *) hash, dup);
+	hipLaunchKernelGGL(k_assign_tables, dim3(1), dim3(64), 0, g.stream, (const unsigned char *) dup, k, (uint32_t) slab,
+					   (uint32_t) tail, pairs, meta, meta + mw);
+	hipLaunchKernelGGL(k_s16_qprep, dim3((k + 3) / 4), dim3(256), 0, g.stream, d_cents, (uint32_t) k, dim, dimp,
+					   (ndb_h2 *) qplanes, qn2, qexp);
+	/* aux[0].x = the largest finite centroid norm (bits order like values for non-negative floats) */
+	HIP_TRY(hipMemsetAsync(aux, 0, (size_t) k * sizeof(float2), g.stream));
+	hipLaunchKernelGGL(k_max_nonneg, dim3(4), dim3(256), 0, g.stream, (const float *) qn2, (int64_t) k, (uint32_t *) aux);
+	for (int v = 0; v < 2; v++)
+		hipLaunchKernelGGL(k_s16_items, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, meta + v * mw + 6, meta + v * mw + 3,
+						   meta + v * mw + 2, 1, 128u, nitems, desc + (size_t) v * nitems, heads + 8 * NDB_QHEAD_STRIDE - 1);
+	HIP_TRY(hipGetLastError());
+
+	bool		overlapped = false;
+
+	for (int64_t s0 = 0; s0 < nrows; s0 += slab)
+	{
+		const int64_t ns = std::min<int64_t>(slab, nrows - s0);
+		const int	v = ns == slab ? 0 : 1;
+		const uint32_t *m32 = meta + v * mw;
+		const float *srows = d_rows + (size_t) s0 * dim;
+		IvfDev		dv = {};
+
+		dv.vecs = srows;
+		dv.loc_off = locoff + 2 * v;
+		dv.own_len = m32 + 2;
+		dv.glob_len = m32 + 2;
+		dv.dim = dim;
+		dv.ncent = 1;
+		dv.nlists = 1;
+		if (s0 > 0)
+			HIP_TRY(hipMemsetAsync(heads, 0, 2 * 8 * NDB_QHEAD_STRIDE * 4, g.stream));
+		HIP_TRY(hipMemsetAsync(rowmin, 0xFF, (size_t) ns * 4, g.stream));
+		HIP_TRY(hipMemsetAsync(acnt, 0, (size_t) ns * 4, g.stream));
+		hipLaunchKernelGGL(k_s16_row_prep<0>, dim3((unsigned) ((ns + 3) / 4)), dim3(256), 0, g.stream, (const void *) srows,
+						   ns, dim, dimp, (const int64_t *) (locoff + 2 * v), m32, 1, planes, rn2, rexp, xmax);
+		/* two sweeps over the same items: the minimum of every row, then the centroids within reach of it */
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 1>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
+						   (const unsigned char *) planes, m32, (const float *) rn2, (const int16_t *) rexp,
+						   (const unsigned char *) qplanes, qrowbytes, (const float *) qn2, (const int *) qexp,
+						   (const float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
+						   (const PairRec *) pairs, heads, m32 + 8, acnt, arec, 1u, rowmin, 0, dimp / S16_CH, nitems);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
+						   (const unsigned char *) planes, m32, (const float *) rn2, (const int16_t *) rexp,
+						   (const unsigned char *) qplanes, qrowbytes, (const float *) qn2, (const int *) qexp,
+						   (const float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
+						   (const PairRec *) pairs, heads + 8 * NDB_QHEAD_STRIDE, m32 + 8, acnt, arec, 1u, rowmin, 0,
+						   dimp / S16_CH, nitems);
+		hipLaunchKernelGGL(k_s16_assign_resolve, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
+						   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
+						   (unsigned long long *) (over_n + 2));
+		HIP_TRY(hipGetLastError());
+		if (!overlapped && while_running)
+		{
+			const int	wrc = while_running();
+
+			overlapped = true;
+			if (wrc != 0)
+			{
+				(void) hipStreamSynchronize(g.stream);
+				return wrc;
+			}
+		}
+	}
+	struct { unsigned int over, none; unsigned long long multi; } hs;
+
+	HIP_TRY(hipMemcpyAsync(&hs, over_n, 16, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));	/* the temporaries go out of scope */
+	if (g_debug_build)
+		fprintf(stderr, "build: assign_rows_s16: %lld rows, %llu decided among several candidates, %u sent to the exact assignment (%u with no record)\n",
+				(long long) nrows, hs.multi, hs.over, hs.none);
+	if (stats)
+	{
+		stats[0] = hs.multi;
+		stats[1] = hs.over;
+	}
+	if (hs.over > 0)
+	{
+		/* rows the bound could not narrow to S16_ASSIGN_SLOTS centroids: the exact assignment on a packed copy */
+		float	   *orows = nullptr;
+		int		   *olist = nullptr;
+
+		if (tmp.alloc(orows, (size_t) hs.over * dim * sizeof(float))) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(olist, (size_t) hs.over * sizeof(int))) return NDBHIP_ERR_HIP;
+		hipLaunchKernelGGL(k_rows_gather, dim3(hs.over), dim3(256), 0, g.stream, d_rows, dim, (const int64_t *) over_rows, orows);
+		const int	rc = assign_rows(orows, (int64_t) hs.over, dim, d_cents, k, true, olist, nullptr);
+
+		if (rc != 0)
+			return rc;
+		hipLaunchKernelGGL(k_list_scatter, dim3((hs.over + 255) / 256), dim3(256), 0, g.stream, (const int *) olist,
+						   (const int64_t *) over_rows, hs.over, d_out_list);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	return 0;
+}
+
 extern "C" int ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
 									   int max_iter, int *out_iters);
 
@@ -884,17 +1198,29 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	lap("free + malloc list ids");
 	AssignWs	aws;				/* own workspace: assign_rows then returns without waiting for its kernels */
 
-	rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr, &aws);
-	if (rc)
-		return rc;
 	/* The packed mirror is allocated while the assignment kernels run: a fresh multi-GB hipMalloc is host-side
 	 * work (page-table setup) that took 0.3 ms in one process and 63 ms in the next on the same box — as much
 	 * as the rest of the build — and it needs nothing the GPU is busy with. */
 	float	   *d_prow = nullptr;
 	uint64_t   *d_ptid = nullptr;
+	auto		alloc_mirror = [&]() -> int {
+		if (d_prow)
+			return 0;
+		HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+		return 0;
+	};
 
-	HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+	rc = g_build_s16 ? assign_rows_s16(d_rows, nrows, dim, d_cent, k, d_list, nullptr, alloc_mirror) : 1;
+	if (rc < 0)
+		return rc;
+	if (rc == 1)				/* a shape the sweep does not take: the exact assignment on the vector ALU */
+		rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr, &aws);
+	if (rc)
+		return rc;
+	rc = alloc_mirror();
+	if (rc)
+		return rc;
 	lap("assign every row (+ malloc of the packed rows under it)");
 
 	const uint32_t nblocks = (uint32_t) ((nrows + NDB_PACK_BLOCK - 1) / NDB_PACK_BLOCK);

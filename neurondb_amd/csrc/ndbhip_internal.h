@@ -19,6 +19,7 @@
 #include <mutex>
 #include <chrono>
 #include <type_traits>
+#include <functional>
 #include "../../include/ndbhip.h"
 #include "ndbhip_kernels.h"
 #pragma clang fp contract(off)

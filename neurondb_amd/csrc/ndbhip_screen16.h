@@ -140,7 +140,9 @@ k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, 
 		rn2[row] = n2;
 		if (rexp)
 			rexp[row] = (int16_t) e;
-		if (ok)
+		/* one address for every row of the index: only a row that would raise the maximum goes to the atomic unit
+		 * (a stale read is merely smaller; a million same-address atomics cost 10 ms) */
+		if (ok && __float_as_uint(n2) > __atomic_load_n(xmax_bits, __ATOMIC_RELAXED))
 			atomicMax(xmax_bits, __float_as_uint(n2));
 	}
 	/* the row's list (largest L with loc_off[L] <= row) and its place in the blocked planes */
@@ -427,6 +429,7 @@ s16_uniform_ptr(const unsigned char *p)
 
 template <int N> __device__ __forceinline__ void s16_wait_vm();
 template <> __device__ __forceinline__ void s16_wait_vm<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void s16_wait_vm<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 template <> __device__ __forceinline__ void s16_wait_vm<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 template <> __device__ __forceinline__ void s16_wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void s16_wait_vm<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
@@ -492,7 +495,14 @@ k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ 
 #define S16_SETPRIO 0
 #endif
 
-template <int R, int H16, int NW, int NBUF, int DBG = 0>
+/* MODE 1 / 2 (the build's assignment, ndbhip_build.h: assign_rows_s16): the "queries" are the distinct centroids,
+ * one list holds a slab of rows.  MODE 1 leaves bmin[row] = the row's smallest a over all centroids (order key).
+ * MODE 2 records, per row, the centroids whose a lies within the error bound of that minimum: ecount[row] = how
+ * many, erec[row][S16_ASSIGN_SLOTS] = (centroid, a).  qthr has one slot per centroid like in a search, of which
+ * only qthr[0].x = the largest centroid norm is used. */
+#define S16_ASSIGN_SLOTS 8
+
+template <int R, int H16, int NW, int NBUF, int DBG = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && NBUF == 2) ? 2 : 1) void
 k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
 			const float *__restrict__ rn2, const int16_t *__restrict__ rexp,
@@ -594,6 +604,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 	__syncthreads();
 
 	uint32_t	voff_q[G::Q_DMA];
+	bool		qdma = true;	/* this wave's share of the query area holds a member (wave-uniform) */
 	const unsigned char *rbase;
 	const uint32_t lane16 = (uint32_t) lane * 16u;
 
@@ -615,6 +626,10 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 			voff_q[j] = qinfo[sl][32 * (piece >> 2) + rr].qid * qrowbytes + 16u * (uint32_t) ((lane & 7) ^ ((rr >> 1) & 7));
 		}
 		rbase = planes + ((size_t) blk_off[L] + b) * (size_t) nchunk * G::ROW_BLK;
+		/* most lists are probed by a handful of queries: their tiles leave three of the four query blocks empty,
+		 * and an empty block is neither fetched nor multiplied (pieces wave * Q_DMA .. belong to block
+		 * (wave * Q_DMA) / 4) */
+		qdma = s_desc[sl][4] > (uint32_t) (32 * ((wave * G::Q_DMA) >> 2));
 	};
 	const uint32_t ring_la = (uint32_t) (uintptr_t) (ndb_lds_ptr) ring;
 	auto		issue = [&](int c, int bufi) {
@@ -628,9 +643,12 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 		const uint32_t la = ring_la + (uint32_t) bufi * G::BUF;
 
 		s16_dma_linear<G::ROW_DMA>(rb, lane16, la + wave * G::ROW_BLK);
+		if (qdma)
+		{
 #pragma unroll
-		for (int j = 0; j < G::Q_DMA; j++)
-			s16_dma16(qb, voff_q[j], la + G::Q_OFF + (wave * G::Q_DMA + j) * 1024);
+			for (int j = 0; j < G::Q_DMA; j++)
+				s16_dma16(qb, voff_q[j], la + G::Q_OFF + (wave * G::Q_DMA + j) * 1024);
+		}
 	};
 
 	/* fragment addresses (bytes inside a buffer) */
@@ -859,7 +877,12 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 			{
 				/* the chunks after c that are already requested: min(NBUF - 2, nchunk - 1 - c) */
 				if (c + NBUF - 2 < nchunk)
-					s16_wait_vm<G::PER * (NBUF - 2)>();
+				{
+					if (qdma)
+						s16_wait_vm<G::PER * (NBUF - 2)>();
+					else
+						s16_wait_vm<G::ROW_DMA * (NBUF - 2)>();	/* this wave requests rows only */
+				}
 				else
 					s16_wait_vm<0>();		/* (the tail of a ring deeper than 3 drains a little early) */
 				__syncthreads();
@@ -898,6 +921,100 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 
 		/* epilogue: element (reg, lane) of block (a, b) = query 32 (2 wq + a) + (reg & 3) + 8 (reg >> 2) + 4 kh,
 		 * row 32 (2 wr + b) + r32 */
+		if constexpr (MODE == 1)
+		{
+			/* build, first sweep: the smallest a of every row over all centroids (rowmin = bmin[row]) */
+			__shared__ uint32_t s_rowmin[G::RT];
+			auto		aval = [&](int a, int b, int reg, const S16Q &qi, float x2, int ex) {
+				const float dot = ldexpf(run[a][b][reg], qi.eq + ex - 28);
+
+				return __builtin_fmaf(-2.0f, dot, qi.q2 + x2);
+			};
+
+			if (tid < G::RT)
+				s_rowmin[tid] = 0xFFFFFFFFu;
+			__syncthreads();
+#pragma unroll
+			for (int b = 0; b < 2; b++)
+			{
+				const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (2 * wr + b) + r32);
+				const size_t grow = (size_t) ix.loc_off[L] + (ridx < len ? ridx : len - 1);
+				const float x2 = rn2[grow];
+				const int	ex = (int) rexp[grow];
+				uint32_t	mn = 0xFFFFFFFFu;
+
+#pragma unroll
+				for (int a = 0; a < 2; a++)
+#pragma unroll
+					for (int reg = 0; reg < 16; reg++)
+					{
+						const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+						const S16Q	qi = qinfo[cur][m];
+
+						if (qi.nrow != 0)
+						{
+							const float av = aval(a, b, reg, qi, x2, ex);
+
+							/* a NaN (a row or centroid beyond fp32) bounds nothing: it is left out of the minimum
+							 * and emitted by the second sweep, which sends the row to the reference's arithmetic */
+							if (av == av)
+								mn = min(mn, ndb_key_from_bits(__float_as_uint(av)));
+						}
+					}
+				mn = min(mn, (uint32_t) __shfl_xor((int) mn, 32, 64));
+				if (kh == 0 && ridx < len)
+					atomicMin(&s_rowmin[32 * (2 * wr + b) + r32], mn);
+			}
+			__syncthreads();
+			if (tid < G::RT && t2 * G::RT + (uint32_t) tid < len)
+				atomicMin(&bmin[(size_t) ix.loc_off[L] + t2 * G::RT + tid], s_rowmin[tid]);
+			__syncthreads();		/* s_rowmin is reused by the next item */
+		}
+		else if constexpr (MODE == 2)
+		{
+			/* build, second sweep: every centroid within reach of the row's minimum, S16_ASSIGN_SLOTS records a row */
+			const float c2max = qthr[0].x;
+
+#pragma unroll
+			for (int b = 0; b < 2; b++)
+			{
+				const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (2 * wr + b) + r32);
+
+				if (ridx >= len)
+					continue;
+				const size_t grow = (size_t) ix.loc_off[L] + ridx;
+				const float x2 = rn2[grow];
+				const int	ex = (int) rexp[grow];
+				const uint32_t gmin = bmin[grow];
+				const uint32_t gb = (gmin & 0x80000000u) ? (gmin & 0x7FFFFFFFu) : ~gmin;
+				const float e_r = s16_e<R_IVF_L2>(ix.dim, x2, c2max, false);
+				const float thr = gmin == 0xFFFFFFFFu ? __uint_as_float(0x7F800000u) : s16_thr_from_a<R_IVF_L2>(__uint_as_float(gb), e_r, ix.dim);
+
+#pragma unroll
+				for (int a = 0; a < 2; a++)
+#pragma unroll
+					for (int reg = 0; reg < 16; reg++)
+					{
+						const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+						const S16Q	qi = qinfo[cur][m];
+
+						if (qi.nrow != 0)
+						{
+							const float dot = ldexpf(run[a][b][reg], qi.eq + ex - 28);
+							const float av = __builtin_fmaf(-2.0f, dot, qi.q2 + x2);
+
+							if (!(av > thr))
+							{
+								const uint32_t slot = atomicAdd(&ecount[grow], 1u);
+
+								if (slot < S16_ASSIGN_SLOTS)
+									erec[grow * S16_ASSIGN_SLOTS + slot] = make_uint2(qi.qid, __float_as_uint(av));
+							}
+						}
+					}
+			}
+		}
+		else
 #pragma unroll
 		for (int b = 0; b < 2; b++)
 		{
@@ -1128,6 +1245,92 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	}
 	block_replay_emit(s.e_bits, s.e_id, cut, kk, s.fs, out_tids + (size_t) q * k, out_dist + (size_t) q * k,
 					  out_count + q);
+}
+
+/*
+ * Build: the list of every row from the second sweep's records.  One candidate: that centroid (the bound proved
+ * every other one farther in the reference's arithmetic).  Several: the reference's own loop (ivf_am.c:905-935:
+ * sqrtf of the sequential sum, minDist from FLT_MAX, strict <, so the first minimum in centroid order wins) over
+ * the candidates in centroid order.  More than S16_ASSIGN_SLOTS (duplicated centroids, rows beyond fp32): the row
+ * goes on the overflow list, which the host sends through the exact assignment.
+ */
+__global__ void __launch_bounds__(256)
+k_s16_assign_resolve(const float *__restrict__ rows, int64_t nrows, int dim, const float *__restrict__ cents,
+					 const unsigned int *__restrict__ acnt, const uint2 *__restrict__ arec,
+					 int *__restrict__ out_list, int64_t row_base, unsigned int *__restrict__ over_n,
+					 int64_t *__restrict__ over_rows, unsigned long long *__restrict__ multi_n)
+{
+	const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+
+	if (r >= nrows)
+		return;
+	const uint32_t n = acnt[r];
+
+	if (n == 1)
+	{
+		out_list[r] = (int) arec[(size_t) r * S16_ASSIGN_SLOTS].x;
+		return;
+	}
+	if (n == 0 || n > S16_ASSIGN_SLOTS)
+	{
+		/* n == 0 cannot happen for a finite row (its minimum is within its own threshold); treated like overflow */
+		out_list[r] = -1;
+		over_rows[atomicAdd(over_n, 1u)] = row_base + r;
+		if (n == 0)
+			atomicAdd(over_n + 1, 1u);
+		return;
+	}
+	int			cand[S16_ASSIGN_SLOTS];
+
+	for (uint32_t j = 0; j < n; j++)
+	{
+		/* kept in centroid order (insertion: a handful of entries) */
+		const int	c = (int) arec[(size_t) r * S16_ASSIGN_SLOTS + j].x;
+		int			p = (int) j;
+
+		while (p > 0 && cand[p - 1] > c)
+		{
+			cand[p] = cand[p - 1];
+			p--;
+		}
+		cand[p] = c;
+	}
+	const float *x = rows + (size_t) r * dim;
+	float		best = 0.0f;
+	int			bi = -1;
+
+	for (uint32_t j = 0; j < n; j++)
+	{
+		const float *cv = cents + (size_t) cand[j] * dim;
+		float		dv;
+
+		if ((dim & 3) == 0)
+			dv = scr_exact<R_IVF_L2>(x, cv, dim);	/* 16-byte pieces, 32 loads in flight, then the sequential chain */
+		else
+		{
+			Acc<R_IVF_L2> acc;
+
+			for (int d = 0; d < dim; d++)
+				acc.step(x[d], cv[d]);
+			dv = acc.fin();
+		}
+		/* minDist starts at FLT_MAX and the test is strict: the first minimum wins; a NaN distance never does,
+		 * and a row whose every distance is NaN or +inf keeps the initial list 0 */
+		if (dv < (bi < 0 ? __uint_as_float(0x7F7FFFFFu) : best))
+		{
+			best = dv;
+			bi = cand[j];
+		}
+	}
+	if (bi < 0)
+	{
+		out_list[r] = -1;
+		over_rows[atomicAdd(over_n, 1u)] = row_base + r;
+		return;
+	}
+	out_list[r] = bi;
+	if (multi_n)
+		atomicAdd(multi_n, 1ull);
 }
 
 /* The instruction the error model of ndbhip_common.h (4) is about, in isolation (ndbhip_mfma_probe): one wave per

@@ -48,6 +48,9 @@ def library_on_torch_stream():
     from neurondb_amd import _lib
     _lib.ensure_init(0)
     _lib.use_torch_stream()     # torch's default stream has handle 0 = "the library's own stream": see there
+    for kv in filter(None, os.environ.get("NDBHIP_TEST_OPTS", "").split(",")):    # e.g. debug_build=1 (diagnostics only)
+        name, _, val = kv.partition("=")
+        _lib.check(_lib.lib().ndbhip_set_option(name.encode(), int(val or "1")))
     yield
     torch.cuda.synchronize()
     _lib.check(_lib.lib().ndbhip_set_stream(None))

@@ -98,6 +98,55 @@ def test_assign_device_matches_insert_rule():
     assert np.array_equal(out.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("n,dim,k,kind", [
+    (6000, 64, 130, "gauss"),          # few rows a tile, ragged last tiles
+    (5000, 768, 300, "clustered"),     # tight clusters: the bound leaves one centroid for most rows
+    (4500, 100, 40, "dups"),           # a centroid repeated 12 times: more candidates than record slots
+    (4200, 64, 70, "special"),         # NaN / inf / huge rows and a NaN centroid
+    (4100, 30, 5, "gauss"),            # dim not a multiple of 4, fewer centroids than a tile
+])
+def test_screened_assignment_matches_insert_rule(n, dim, k, kind):
+    """ndbhip_ivf_assign_device with >= 4096 rows goes through the fp16 matrix-core sweeps (assign_rows_s16); the
+    lists must be the insert rule's (oracle ivf_assign_all), and the same as with build_screen16=0."""
+    import torch
+    from neurondb_amd import _lib
+    _lib.ensure_init()
+    rng = np.random.default_rng(n + dim)
+    cent = rng.standard_normal((k, dim)).astype(np.float32)
+    if kind == "clustered":
+        rows = (cent[rng.integers(0, k, n)] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+        cent[11] = cent[10] + np.float32(1e-4)        # two centroids the bound cannot separate
+    else:
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+    if kind == "dups":
+        cent[20:32] = cent[5]
+        rows[:500] = cent[5] + 0.01 * rng.standard_normal((500, dim)).astype(np.float32)
+    if kind == "special":
+        rows[0, 3] = np.nan
+        rows[1, 0] = np.inf
+        rows[2] = 3e19                                   # the squared norm overflows fp32
+        rows[3] = 0
+        rows[4] = 1e-30
+        cent[9, 1] = np.nan
+        cent[12] = 0
+    rows[100:100 + k] = cent                             # exact hits
+    with np.errstate(all="ignore"):
+        exp = ndbo.ivf_assign_all(cent, rows)
+    dc, dr = _torch(cent), _torch(rows)
+    got = {}
+    try:
+        for opt in (1, 0):
+            _lib.check(_lib.lib().ndbhip_set_option(b"build_screen16", opt))
+            out = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+            _lib.check(_lib.lib().ndbhip_ivf_assign_device(dc.data_ptr(), k, dim, dr.data_ptr(), n, out.data_ptr()))
+            _lib.check(_lib.lib().ndbhip_synchronize())
+            got[opt] = out.cpu().numpy()
+    finally:
+        _lib.check(_lib.lib().ndbhip_set_option(b"build_screen16", 1))
+    assert np.array_equal(got[0], exp)
+    assert np.array_equal(got[1], exp)
+
+
 def test_append_keeps_lists_in_insertion_order_and_matches_oracle():
     """aminsert path: 70 % of the rows loaded, 30 % appended one by one to the list ivfinsert
     would choose; the result must equal the oracle image holding all rows."""
