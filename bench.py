@@ -173,14 +173,36 @@ def main():
         # SURVEY 8d "IVF build roofline": the assignment of all N rows is 2 N lists dim flops (a dense contraction;
         # k-means on the 10 000-row sample adds iterations x 10 000 rows of the same)
         flops = 2.0 * (n + kmeans_iters * min(10000, 100 * nlists, n)) * nlists * dim
+        # the same rows through both assignment paths of the library (outside the timed region): the screened
+        # matrix-core path the build used and the exact vector-ALU path must give the same list for every row
+        cent_d = torch.from_numpy(cent_h).to(dev)
+        asg = {}
+        for opt in (1, 0):
+            check(lib().ndbhip_set_option(b"build_screen16", opt))
+            out = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            check(lib().ndbhip_ivf_assign_device(cent_d.data_ptr(), nlists, dim, base.data_ptr(), n, out.data_ptr()))
+            check(lib().ndbhip_synchronize())
+            asg[opt] = out
+        check(lib().ndbhip_set_option(b"build_screen16", 1))
+        for kv in args.opt:                              # (an explicit --opt build_screen16=... stays in force)
+            name, _, val = kv.partition("=")
+            if name == "build_screen16":
+                check(lib().ndbhip_set_option(b"build_screen16", int(val)))
+        same = bool(torch.equal(asg[0], asg[1]))
+        counts_ok = bool(np.array_equal(torch.bincount(asg[0].long(), minlength=nlists).cpu().numpy(), list_len))
+        del asg, cent_d
         build = {"vectors_per_s": round(build_vps, 1), "seconds": round(t_build, 4), "kmeans_iterations": int(kmeans_iters),
-                 "roofline": {"bound": "mfma", "achieved": round(flops / t_build / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(flops / t_build / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                 "lists_identical_to_exact_assignment": same and counts_ok,
+                 "roofline": {"bound": "mfma", "achieved": round(flops / t_build / 1e12, 2), "peak": FP16_MFMA_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(flops / t_build / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),
                               "flops": int(flops),
-                              "note": "whole build (sample k-means, assignment of every row, list packing) against the "
-                                      "dense fp32 MFMA peak SURVEY 8d assigns to it; the assignment is the reference's "
-                                      "unfused fp32 recipe on the vector ALU (3 rounded operations per multiply-add of "
-                                      "this count, unfused VALU peak 78.6 TFLOP/s)"},
+                              "executed_flops": int(6.0 * 2.0 * n * nlists * dim + flops - 2.0 * n * nlists * dim),
+                              "note": "whole build (sample k-means, assignment of every row, list packing) over the "
+                                      "algorithmic flops SURVEY 8d assigns to it (2 N lists dim), against the dense fp16 "
+                                      "matrix-core peak: the assignment runs as two sweeps of k_s16_sweep (row minimum, "
+                                      "then the centroids within the error bound of it), each 3 fp16 products per "
+                                      "multiply (split operands) = executed_flops; the reference's fp32 arithmetic decides "
+                                      "only among the centroids the bound leaves (about 1 % of the rows have more than one)"},
                  "cpu_baseline": (build_cpu_baseline(args, base, cent_h, kmeans_iters) if args.cpu_seconds > 0 and world == 1
                                   else None)}
     del base
@@ -663,9 +685,10 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 3), "build_schedule": ix.build_stats(),
             "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
             "evaluations_per_query": round(evals, 1), "bytes_per_query": int(bytes_q),
-            "roofline": {"bound": "hbm", "achieved": round(nq / ts * bytes_q / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(nq / ts * bytes_q / 1e9 / HBM_PEAK_GBPS, 4),
-                         "note": "dependent graph walk: latency-bound, as SURVEY 8d expects"},
+            "roofline": dict({"bound": "hbm", "achieved": round(nq / ts * bytes_q / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                              "unit": "GB/s", "frac": round(nq / ts * bytes_q / 1e9 / HBM_PEAK_GBPS, 4),
+                              "note": "dependent graph walk: latency-bound, as SURVEY 8d expects"},
+                             **hnsw_pmc_traffic(n, dim, m, ef, nq, ts)),
             "recall_at_10": round(recall, 4),
             "recall_note": "the reference's level-0 walk is BFS-until-ef (quirk Q10); the oracle returns the same ids",
             "oracle_parity": {"queries": sample, "mismatches": int(bad),
@@ -675,6 +698,21 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
                              "sample": f"{ncpu} of the same queries through oracle/ndb_oracle.c ndbo_hnsw_search on the "
                                        "exported graph, one thread per core"},
             "search_layer": layer}
+
+
+def hnsw_pmc_traffic(n, dim, m, ef, nq, seconds):
+    """HBM-side bytes of one k_hnsw_search_fast launch from the newest committed PMC pass of this workload
+    (profiles/*_pmc_traffic.json, written by tools/pmc_traffic_json.py from tools/pmc_hnsw.sh), and the HBM fraction
+    that traffic gives over this run's batch time."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        with open(path) as f:
+            k = json.load(f)["kernels"].get("k_hnsw_search_fast", {}).get("gauss_unit")
+        if k and k.get("queries_per_dispatch") == nq and (n, dim, m, ef) == (1_000_000, 768, 16, 64):
+            t = int(k["traffic_bytes_per_launch"])
+            return {"traffic": t, "traffic_source": "committed PMC pass " + os.path.relpath(path, ROOT),
+                    "traffic_frac": round(t / seconds / 1e9 / HBM_PEAK_GBPS, 4)}
+    return {"traffic": None, "traffic_source": None}
 
 
 def pmc_traffic(args, world, kernel="k_ivf_scan"):

@@ -121,6 +121,8 @@ ndbhip_shutdown(void)
 		(void) hipStreamDestroy(g.own_stream);
 	if (g.d_counters)
 		(void) hipFree(g.d_counters);
+	if (g.asg_arena)
+		(void) hipFree(g.asg_arena);
 	g = Ctx();
 	return NDBHIP_OK;
 }

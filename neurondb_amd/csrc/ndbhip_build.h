@@ -972,13 +972,17 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 	const int	dimp = (dim + 63) & ~63;
 	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
 	const uint32_t nqt = (uint32_t) ((k + S16_QT - 1) / S16_QT);
-	const int64_t slab = std::min<int64_t>(nrows, (int64_t) 1 << 20);
+	/* rows per slab: about 512 MiB of fp16 planes, whatever the table's size (so that the scratch a small build
+	 * leaves behind fits the next large one) */
+	const int64_t slab_cap = std::min<int64_t>((int64_t) 1 << 20,
+											   std::max<int64_t>(4096, (((int64_t) 512 << 20) / ((int64_t) dimp * 4)) & ~(int64_t) 127));
+	const int64_t slab = std::min<int64_t>(nrows, slab_cap);
 	const int64_t tail = nrows % slab == 0 ? slab : nrows % slab;
-	const uint64_t nb = (uint64_t) ((slab + 31) / 32);
-	const uint32_t nrt = (uint32_t) ((slab + 127) / 128);
+	const uint64_t nb = (uint64_t) ((slab_cap + 31) / 32);
+	const uint32_t nrt = (uint32_t) ((slab + 127) / 128), nrt_cap = (uint32_t) ((slab_cap + 127) / 128);
 
 	if (nrows < 1 || k < 1 || k > 65535 || (size_t) k * qrowbytes >= ((size_t) 1 << 32) ||
-		(size_t) nrt * nqt > 0x7FFFFFFFull)
+		(size_t) nrt_cap * nqt > 0x7FFFFFFFull)
 		return 1;
 	DevGuard	tmp;
 	unsigned char *planes = nullptr, *qplanes = nullptr, *dup = nullptr;
@@ -996,33 +1000,57 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 	S16Desc    *desc = nullptr;
 	const size_t blk_bytes = (size_t) (dimp / S16_CH) * 4096;
 	const uint32_t nitems = nrt * nqt;		/* upper bound: duplicates only shrink it */
+	const uint32_t nitems_cap = nrt_cap * nqt;
 	const size_t mw = NDB_ASG_META(k);
+	/* everything but the list of overflowing rows comes out of the arena kept in g: laid out twice, first to size it */
+	size_t		used = 0;
+	auto		take = [&](auto *&p, size_t bytes, bool commit) {
+		if (commit)
+			p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(g.asg_arena + used);
+		used += (bytes + 255) & ~(size_t) 255;
+	};
+	auto		layout = [&](bool commit) {
+		used = 0;
+		take(planes, (size_t) (nb + 8) * blk_bytes, commit);
+		take(qplanes, (size_t) k * qrowbytes, commit);
+		take(rn2, (size_t) slab_cap * 4, commit);
+		take(rexp, (size_t) slab_cap * 2, commit);
+		take(qn2, (size_t) k * 4, commit);
+		take(qexp, (size_t) k * 4, commit);
+		take(aux, (size_t) k * sizeof(float2), commit);	/* the sweep's per-query slot; only [0].x is used */
+		take(xmax, 4, commit);
+		take(rowmin, (size_t) slab_cap * 4, commit);
+		take(acnt, (size_t) slab_cap * 4, commit);
+		take(arec, (size_t) slab_cap * S16_ASSIGN_SLOTS * sizeof(uint2), commit);
+		take(over_n, 16, commit);
+		take(pairs, (size_t) k * sizeof(PairRec), commit);
+		take(desc, (size_t) 2 * nitems_cap * sizeof(S16Desc), commit);
+		take(locoff, 4 * sizeof(int64_t), commit);
+		take(meta, 2 * mw * 4, commit);
+		take(heads, 2 * 8 * NDB_QHEAD_STRIDE * 4, commit);
+		take(hash, (size_t) k * 8, commit);
+		take(dup, (size_t) k, commit);
+	};
 
-	if (tmp.alloc(planes, (size_t) (nb + 8) * blk_bytes)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(qplanes, (size_t) k * qrowbytes)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(rn2, (size_t) slab * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(rexp, (size_t) slab * 2)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(qn2, (size_t) k * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(qexp, (size_t) k * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(aux, (size_t) k * sizeof(float2))) return NDBHIP_ERR_HIP;	/* the sweep's per-query slot; only [0].x is used */
-	if (tmp.alloc(xmax, 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(rowmin, (size_t) slab * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(acnt, (size_t) slab * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(arec, (size_t) slab * S16_ASSIGN_SLOTS * sizeof(uint2))) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(over_n, 16)) return NDBHIP_ERR_HIP;
+	layout(false);
+	if (used > g.asg_arena_cap)
+	{
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		if (g.asg_arena)
+			HIP_TRY(hipFree(g.asg_arena));
+		g.asg_arena = nullptr;
+		g.asg_arena_cap = 0;
+		HIP_TRY(hipMalloc((void **) &g.asg_arena, used));
+		g.asg_arena_cap = used;
+	}
+	layout(true);
 	if (tmp.alloc(over_rows, (size_t) nrows * sizeof(int64_t))) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(pairs, (size_t) k * sizeof(PairRec))) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(desc, (size_t) 2 * nitems * sizeof(S16Desc))) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(locoff, 4 * sizeof(int64_t))) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(meta, 2 * mw * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(heads, 2 * 8 * NDB_QHEAD_STRIDE * 4)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(hash, (size_t) k * 8)) return NDBHIP_ERR_HIP;
-	if (tmp.alloc(dup, (size_t) k)) return NDBHIP_ERR_HIP;
 	const int64_t hloc[4] = {0, slab, 0, tail};
 
 	HIP_TRY(hipMemcpyAsync(locoff, hloc, sizeof(hloc), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemsetAsync(over_n, 0, 16, g.stream));
-	HIP_TRY(hipMemsetAsync(planes, 0, (size_t) (nb + 8) * blk_bytes, g.stream));
+	/* (the arena holds an earlier build's planes: rows past a slab's end are never looked at, zeroed all the same) */
+	HIP_TRY(hipMemsetAsync(planes, 0, (size_t) ((slab + 31) / 32 + 8) * blk_bytes, g.stream));
 	HIP_TRY(hipMemsetAsync(xmax, 0, 4, g.stream));
 	HIP_TRY(hipMemsetAsync(heads, 0, 2 * 8 * NDB_QHEAD_STRIDE * 4, g.stream));
 	/* the centroids: duplicates dropped, split into fp16 planes, the sweep's tables for both slab shapes */

@@ -66,6 +66,10 @@ struct Ctx
 	uint64_t	host_rows = 0, host_bytes = 0;	/* counted on the host (batch distance) */
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;	/* profiling events not yet read */
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+	/* scratch of the build's screened assignment (ndbhip_build.h: assign_rows_s16), kept between calls: a fresh
+	 * multi-GB hipMalloc costs anything from 0.3 to 60 ms on this runtime, which is as much as a whole build */
+	unsigned char *asg_arena = nullptr;
+	size_t		asg_arena_cap = 0;
 };
 extern Ctx	g;
 
