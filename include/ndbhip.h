@@ -123,7 +123,8 @@ int			ndbhip_set_scan_mode(int mode);
  * environment any more).  Results are bit-identical whichever way they are set.
  *   "screen"            1   auto mode screens batches of >= 128 queries (0 = never)
  *   "screen16"          1   ... on the fp16 matrix cores (0 = the fp32 bound pass)
- *   "screen16_records"  2048  candidates a query may emit before it is swept again / its batch falls back
+ *   "screen16_records"  8192  candidates a query may emit before it is swept again / its batch falls back
+ *   "screen16_tighten"  1     a query's threshold is lowered inside the sweep every 256 emitted records (0: only between the two rounds)
  *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
  *   "screen16_debug"    0   timing experiments of the sweep (1 no DMA, 2 DMA of cache-hot lines: WRONG results)
  *   "scr_coop" 2, "scr_ch" 16, "scr_mfma" 1, "gchunk" 32   A/B switches of the fp32 screened / grouped kernels

@@ -2242,7 +2242,8 @@ static int	g_s16_auto = 1;
 static int	g_build_s16 = 1;		/* ndbhip_set_option("build_screen16", 0): the build assigns on the vector ALU only */
 static int	g_s16_waves = 4;
 static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
-static uint32_t g_s16_ecap = 2048;
+static uint32_t g_s16_ecap = 8192;
+static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
 
 static bool
 ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
@@ -2271,7 +2272,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
 	const int	nc = ix->ncent;
 	const int	H = !ix->f16 ? 0 : (ix->f16_sub ? 1 : 2);
-	const uint32_t ecap = g_s16_ecap;
+	/* records a query may leave: the option's value, less for batches whose record array would pass 1 GiB */
+	const uint32_t ecap = std::max<uint32_t>(std::min<uint32_t>(g_s16_ecap, (uint32_t) ((((size_t) 1 << 30) / 8) / (size_t) nq)), 64u);
 
 	if (!ix->s16_valid)
 	{
@@ -2415,10 +2417,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
 		S16_BY_RH(S16_SWEEP_L, d, (const unsigned char *) ix->d_planes, (const uint32_t *) ix->d_blkoff,
 				  (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qplanes, qrowbytes,
-				  (const float *) ix->w_qn2, (const int *) ix->w_qexp, (const float2 *) ix->w_qthr, lco, npr,
+				  (const float *) ix->w_qn2, (const int *) ix->w_qexp, (float2 *) ix->w_qthr, lco, npr,
 				  (const uint32_t *) cnt, (const uint32_t *) pair_off, (const S16Desc *) ix->w_s16desc,
 				  (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ecount, ix->w_erec, ecap,
-				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap);
+				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
 	}
 	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
@@ -2542,6 +2544,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16_records must be 64..16384");
 		g_s16_ecap = (uint32_t) value;
 	}
+	else if (!strcmp(name, "screen16_tighten"))
+		g_s16_tighten = value != 0;
 	else if (!strcmp(name, "screen16_waves"))
 	{
 		if (value != 4 && value != 8)

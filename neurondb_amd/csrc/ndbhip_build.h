@@ -1096,14 +1096,14 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 1>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
 						   (const unsigned char *) planes, m32, (const float *) rn2, (const int16_t *) rexp,
 						   (const unsigned char *) qplanes, qrowbytes, (const float *) qn2, (const int *) qexp,
-						   (const float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
-						   (const PairRec *) pairs, heads, m32 + 8, acnt, arec, 1u, rowmin, 0, dimp / S16_CH, nitems);
+						   (float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
+						   (const PairRec *) pairs, heads, m32 + 8, acnt, arec, 1u, rowmin, 0, dimp / S16_CH, nitems, 0u);
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
 						   (const unsigned char *) planes, m32, (const float *) rn2, (const int16_t *) rexp,
 						   (const unsigned char *) qplanes, qrowbytes, (const float *) qn2, (const int *) qexp,
-						   (const float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
+						   (float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
 						   (const PairRec *) pairs, heads + 8 * NDB_QHEAD_STRIDE, m32 + 8, acnt, arec, 1u, rowmin, 0,
-						   dimp / S16_CH, nitems);
+						   dimp / S16_CH, nitems, 0u);
 		hipLaunchKernelGGL(k_s16_assign_resolve, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
 						   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
 						   (unsigned long long *) (over_n + 2));

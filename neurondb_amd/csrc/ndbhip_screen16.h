@@ -491,6 +491,10 @@ k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ 
 }
 
 #define S16_NOITEM 0xFFFFFFFFu
+#ifndef S16_TIGHT
+#define S16_TIGHT 128			/* a query's threshold is tightened every time it has emitted this many more records */
+#endif
+#define S16_TIGHT_Q 8			/* such queries a block handles per item (more: the next multiple gets them) */
 #ifndef S16_SETPRIO
 #define S16_SETPRIO 0
 #endif
@@ -507,14 +511,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && NBUF == 2) ? 2 : 1) void
 k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
 			const float *__restrict__ rn2, const int16_t *__restrict__ rexp,
 			const unsigned char *__restrict__ qplanes, uint32_t qrowbytes, const float *__restrict__ qn2,
-			const int *__restrict__ qexp, const float2 *__restrict__ qthr,
+			const int *__restrict__ qexp, float2 *qthr,
 			const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt,
 			const uint32_t *__restrict__ pair_off, const S16Desc *__restrict__ desc,
 			const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 			const uint32_t *__restrict__ runs, unsigned int *__restrict__ ecount, uint2 *__restrict__ erec,
-			uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk, uint32_t desc_cap)
+			uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk, uint32_t desc_cap, uint32_t topk)
 {
 	typedef S16Geom<H16, NW> G;
+	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];	/* queries whose threshold is due for tightening */
 	__shared__ __attribute__((aligned(1024))) unsigned char ring[NBUF * G::BUF];
 	__shared__ S16Q qinfo[2][S16_QT];
 	__shared__ uint32_t s_desc[2][5];		/* item (S16_NOITEM = none), L, t2, qt, members of the current / next item's tile */
@@ -582,6 +587,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 	/* ---- first item: everything synchronously ---- */
 	if (tid == 0)
 	{
+		s_tn = 0;
 		const uint32_t it = pop(0xFFFFFFFFu);
 		S16Desc		d = {0, 0, 0, 0};
 
@@ -1053,9 +1059,72 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 							if ((ab & 0x7FFFFFFFu) < 0x7F800000u)
 								atomicMin(&bmin[(size_t) qi.qid * S16_NB + ((pos * 2654435761u) >> (32 - S16_NB_LOG2))],
 										  ndb_key_from_bits(ab));
+							if (DBG == 0 && (slot & (S16_TIGHT - 1)) == S16_TIGHT - 1)
+							{
+								const uint32_t ti = atomicAdd(&s_tn, 1u);
+
+								if (ti < S16_TIGHT_Q)
+									s_tq[ti] = qi.qid;
+							}
 						}
 					}
 				}
+		}
+		if constexpr (DBG == 0)
+		{
+			/*
+			 * A query that keeps emitting has a loose threshold (its seeds missed its own cluster).  The bucket
+			 * minima its emissions have left are real candidates: the k-th smallest of them bounds its k-th
+			 * distance like in k_s16_retarget, so the threshold is lowered HERE, while the sweep is still running,
+			 * and the items that follow emit against it.  Any value read in between is a valid bound (the slot
+			 * only ever decreases), so the result does not depend on who sees which.
+			 */
+			__syncthreads();
+			const uint32_t tn = min(s_tn, (uint32_t) S16_TIGHT_Q);	/* uniform */
+
+			for (uint32_t j = 0; j < tn; j++)
+			{
+				const uint32_t q = s_tq[j];
+				uint32_t	mine = 0xFFFFFFFFu;
+
+				if (tid < S16_NB)
+				{
+					mine = __hip_atomic_load(&bmin[(size_t) q * S16_NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					s_tkeys[tid] = mine;
+				}
+				__syncthreads();
+				if (tid < S16_NB)
+				{
+					uint32_t	rank = 0;
+
+					for (uint32_t o = 0; o < S16_NB; o++)
+					{
+						const uint32_t ok = s_tkeys[o];
+
+						rank += (ok < mine || (ok == mine && o < (uint32_t) tid)) ? 1u : 0u;
+					}
+					if (rank == topk - 1 && mine != 0xFFFFFFFFu)
+					{
+						const uint32_t tb = (mine & 0x80000000u) ? (mine & 0x7FFFFFFFu) : ~mine;
+						const float nt = s16_thr_from_a<R>(__uint_as_float(tb), qthr[q].y, ix.dim);
+						unsigned int *px = reinterpret_cast<unsigned int *>(&qthr[q].x);
+						unsigned int old = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+						while (nt < __uint_as_float(old))
+						{
+							const unsigned int prev = atomicCAS(px, old, __float_as_uint(nt));
+
+							if (prev == old)
+								break;
+							old = prev;
+						}
+					}
+				}
+				__syncthreads();
+			}
+			if (tid == 0 && s_tn != 0)
+				s_tn = 0;
+			/* (the next write of s_tn is an emission of the next item, behind that item's barriers) */
 		}
 		if (!more)
 			break;

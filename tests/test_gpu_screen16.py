@@ -24,7 +24,7 @@ def lib():
     yield _lib
     _lib.check(_lib.lib().ndbhip_set_scan_mode(0))
     _lib.check(_lib.lib().ndbhip_set_option(b"screen16", 1))
-    _lib.check(_lib.lib().ndbhip_set_option(b"screen16_records", 2048))
+    _lib.check(_lib.lib().ndbhip_set_option(b"screen16_records", 8192))
 
 
 @pytest.mark.parametrize("dim,n,nlists,nq", [(768, 6000, 24, 200), (100, 5000, 16, 150), (33, 4000, 9, 130),
