@@ -123,8 +123,80 @@ ndbhip_shutdown(void)
 		(void) hipFree(g.d_counters);
 	if (g.asg_arena)
 		(void) hipFree(g.asg_arena);
+	big_cache_flush();
 	g = Ctx();
 	return NDBHIP_OK;
+}
+
+/*
+ * Allocation of an index's large device blocks.  hipMalloc of a few GB costs between 0.3 and 60 ms on this runtime
+ * (page-table work on the host), as much as a whole 1 M-row build, and hipFree about as much; a REINDEX frees
+ * exactly the blocks its successor needs.  Up to NDB_BIG_CACHE_SLOTS freed blocks of >= 64 MiB are therefore kept
+ * and handed to the next request of (nearly) the same size; ndbhip_set_option("block_cache", 0) or
+ * ndbhip_shutdown() releases them.
+ */
+#define NDB_BIG_CACHE_SLOTS 4
+#define NDB_BIG_CACHE_MIN ((size_t) 64 << 20)
+
+int
+big_alloc(void **out, size_t bytes)
+{
+	*out = nullptr;
+	if (bytes == 0)
+		bytes = 16;
+	for (size_t i = 0; i < g.big_cached.size(); i++)
+	{
+		const size_t have = g.big_cached[i].second;
+
+		if (have >= bytes && have - bytes <= bytes / 8)
+		{
+			*out = g.big_cached[i].first;
+			g.big_live.push_back(g.big_cached[i]);
+			g.big_cached.erase(g.big_cached.begin() + (long) i);
+			return 0;
+		}
+	}
+	if (hipMalloc(out, bytes) != hipSuccess)
+	{
+		(void) hipGetLastError();
+		big_cache_flush();		/* the cache must never be the reason an allocation fails */
+		HIP_TRY(hipMalloc(out, bytes));
+	}
+	if (bytes >= NDB_BIG_CACHE_MIN)
+		g.big_live.push_back(std::make_pair(*out, bytes));
+	return 0;
+}
+
+void
+big_free(void *p)
+{
+	if (!p)
+		return;
+	for (size_t i = 0; i < g.big_live.size(); i++)
+		if (g.big_live[i].first == p)
+		{
+			const std::pair<void *, size_t> b = g.big_live[i];
+
+			g.big_live.erase(g.big_live.begin() + (long) i);
+			if (!g.big_cache_on)
+				break;
+			if (g.big_cached.size() >= NDB_BIG_CACHE_SLOTS)
+			{
+				(void) hipFree(g.big_cached.front().first);
+				g.big_cached.erase(g.big_cached.begin());
+			}
+			g.big_cached.push_back(b);
+			return;
+		}
+	(void) hipFree(p);
+}
+
+void
+big_cache_flush(void)
+{
+	for (auto &b : g.big_cached)
+		(void) hipFree(b.first);
+	g.big_cached.clear();
 }
 
 extern "C" int
@@ -1449,11 +1521,11 @@ ivf_free_rows(ndbhip_ivf *ix)
 {
 	if (ix->own_rows)
 	{
-		if (ix->d_vecs) (void) hipFree(ix->d_vecs);
-		if (ix->d_tids) (void) hipFree(ix->d_tids);
+		big_free(ix->d_vecs);	/* (blocks that did not come from big_alloc go straight to hipFree) */
+		big_free(ix->d_tids);
 	}
-	if (ix->d_vecs_alt) (void) hipFree(ix->d_vecs_alt);
-	if (ix->d_tids_alt) (void) hipFree(ix->d_tids_alt);
+	big_free(ix->d_vecs_alt);
+	big_free(ix->d_tids_alt);
 	ix->d_vecs_alt = nullptr;
 	ix->d_tids_alt = nullptr;
 	ix->alt_cap = 0;
@@ -1900,8 +1972,8 @@ ivf_flush(ndbhip_ivf *ix)
 		{
 			const int64_t cap = nown + nown / 8 + 1024;
 
-			if (ix->d_vecs_alt) HIP_TRY(hipFree(ix->d_vecs_alt));
-			if (ix->d_tids_alt) HIP_TRY(hipFree(ix->d_tids_alt));
+			big_free(ix->d_vecs_alt);	/* (either buffer may be a block the build took from big_alloc) */
+			big_free(ix->d_tids_alt);
 			ix->d_vecs_alt = nullptr;
 			ix->d_tids_alt = nullptr;
 			ix->alt_cap = 0;
@@ -2543,6 +2615,12 @@ ndbhip_set_option(const char *name, int value)
 		if (value < 64 || value > 16384)
 			return fail(NDBHIP_ERR_INVALID, "screen16_records must be 64..16384");
 		g_s16_ecap = (uint32_t) value;
+	}
+	else if (!strcmp(name, "block_cache"))
+	{
+		g.big_cache_on = value != 0;
+		if (!g.big_cache_on)
+			big_cache_flush();
 	}
 	else if (!strcmp(name, "screen16_tighten"))
 		g_s16_tighten = value != 0;

@@ -1234,8 +1234,8 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	auto		alloc_mirror = [&]() -> int {
 		if (d_prow)
 			return 0;
-		HIP_TRY(hipMalloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float)));
-		HIP_TRY(hipMalloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t)));
+		if (big_alloc((void **) &d_prow, (size_t) nrows * dim * sizeof(float))) return NDBHIP_ERR_HIP;
+		if (big_alloc((void **) &d_ptid, (size_t) nrows * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
 		return 0;
 	};
 

@@ -70,8 +70,15 @@ struct Ctx
 	 * multi-GB hipMalloc costs anything from 0.3 to 60 ms on this runtime, which is as much as a whole build */
 	unsigned char *asg_arena = nullptr;
 	size_t		asg_arena_cap = 0;
+	/* large device blocks (an index's packed rows and TIDs) handed back by a destroyed or rebuilt index, kept for
+	 * the next build of similar size for the same reason (big_alloc / big_free in ndbhip.hip) */
+	std::vector<std::pair<void *, size_t>> big_live, big_cached;
+	bool		big_cache_on = true;
 };
 extern Ctx	g;
+int			big_alloc(void **out, size_t bytes);
+void		big_free(void *p);
+void		big_cache_flush(void);
 
 
 static int
