@@ -433,7 +433,7 @@ def main():
         if rank == 0:
             dist_parity = run_dist_parity(args, full_image, qs, out_t, out_d, out_c)
 
-    gauss = None
+    gauss = balanced = None
     if rank == 0 and world == 1 and args.gauss_steps > 0 and args.data == "clustered" and args.rows == "f32" and \
             args.strategy == "l2":
         try:
@@ -443,6 +443,12 @@ def main():
             gauss = gauss_leg(args, dev, steps=args.gauss_steps)
         except Exception as e:
             gauss = {"error": f"{type(e).__name__}: {e}"}
+        if args.components == args.lists:
+            try:
+                torch.cuda.empty_cache()
+                balanced = gauss_leg(args, dev, steps=args.gauss_steps, kind="balanced")
+            except Exception as e:
+                balanced = {"error": f"{type(e).__name__}: {e}"}
 
     hnsw = None
     if rank == 0 and world == 1 and args.hnsw_nvec > 0:
@@ -485,6 +491,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "dist_parity_on_sample": dist_parity,
             "iid_gauss": gauss,
+            "balanced_index": balanced,
             "hnsw": hnsw,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -517,22 +524,56 @@ def run_dist_parity(args, image, qs, out_t, out_d, out_c):
     return {"queries": ns, "mismatches": int(bad)}
 
 
-def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128):
-    """The same workload on i.i.d. N(0,1) data (SURVEY 8d's default distribution; reported separately because the
-    reference's build rule — k-means on the first 10 000 rows for 1024 centroids — collapses on it: the probed lists
-    hold most of the table).  Build, search, recall@10 vs float64 brute force, oracle parity on a sample."""
+def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
+    """kind "gauss": the same workload on i.i.d. N(0,1) data (SURVEY 8d's default distribution; reported separately
+    because the reference's build rule — k-means on the first 10 000 rows for 1024 centroids — collapses on it: the
+    probed lists hold most of the table).  kind "balanced": the headline's clustered table under a BALANCED index —
+    the generator's own component centres as centroids (what a k-means that converged would find), every row
+    assigned with the insert rule — i.e. the same kernels without the skew the reference's sampling rule puts
+    into the lists ("report both").  Build, search, recall@10 vs float64 brute force, oracle parity
+    on a sample."""
+    import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
     from neurondb_amd import IvfIndex, _lib
     from neurondb_amd._lib import check, lib
     from oracle import ndbo
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
-    base = make_data(n, dim, "gauss", 1, 0.0, 0x5EED0001, 0, dev)
-    q = make_data(nq * (steps + 1), dim, "gauss", 1, 0.0, 0x5EED0002, 0, dev)
     ix = IvfIndex(dim, nlists, device=dev.index or 0)
-    t0 = time.perf_counter()
-    iters = ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
-    check(lib().ndbhip_synchronize())
-    tb = time.perf_counter() - t0
+    if kind == "gauss":
+        base = make_data(n, dim, "gauss", 1, 0.0, 0x5EED0001, 0, dev)
+        q = make_data(nq * (steps + 1), dim, "gauss", 1, 0.0, 0x5EED0002, 0, dev)
+        t0 = time.perf_counter()
+        iters = ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
+        check(lib().ndbhip_synchronize())
+        tb = time.perf_counter() - t0
+    else:
+        base = make_data(n, dim, "clustered", args.components, args.sigma, 0x5EED0001, 0x5EEDC0DE, dev)
+        q = make_data(nq * (steps + 1), dim, "clustered", args.components, args.sigma, 0x5EED0002, 0x5EEDC0DE, dev)
+        # sigma = 0 rows are their component's centre: one of each
+        c0 = make_data(max(200000, 200 * args.components), dim, "clustered", args.components, 0.0, 0x5EED0009, 0x5EEDC0DE, dev)
+        key = c0[:, 0].contiguous()
+        uniq, inv = torch.unique(key, return_inverse=True)
+        first = torch.full((len(uniq),), len(key), dtype=torch.int64, device=dev)
+        first.scatter_reduce_(0, inv, torch.arange(len(key), device=dev), reduce="amin")
+        cents = c0[first].contiguous()
+        del c0
+        if len(cents) != nlists:
+            raise RuntimeError(f"{len(cents)} distinct centres for {nlists} lists")
+        t0 = time.perf_counter()
+        ix.set_centroids(cents.cpu().numpy())
+        asg = torch.empty(n, dtype=torch.int32, device=dev)
+        check(lib().ndbhip_ivf_assign_device(C.c_void_p(cents.data_ptr()), nlists, dim, C.c_void_p(base.data_ptr()), n,
+                                            C.c_void_p(asg.data_ptr())))
+        check(lib().ndbhip_synchronize())
+        order = torch.argsort(asg.long(), stable=True)
+        ll = torch.bincount(asg.long(), minlength=nlists).cpu().numpy()
+        rows_sorted = base[order].contiguous()
+        ix.load_device(ll, rows_sorted, pack_tids(order))
+        check(lib().ndbhip_synchronize())
+        tb = time.perf_counter() - t0
+        iters = 0
+        base = rows_sorted                      # (recall below needs row ids: recover them from the TIDs' order)
+        row_id = order
     ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
     od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
     oc = torch.zeros(nq, dtype=torch.int32, device=dev)
@@ -557,6 +598,8 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128):
         ii = torch.cat([best_i, torch.arange(s0, s0 + len(x), device=dev)[None, :].expand(nrecall, -1)], 1)
         sel = torch.topk(dd, k, dim=1, largest=False)
         best_d, best_i = sel.values, torch.gather(ii, 1, sel.indices)
+    if kind != "gauss":
+        best_i = row_id[best_i]                 # brute force ran over the list-major copy
     gt = best_i.cpu().numpy()
     recall = float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(nrecall)]))
     del base
@@ -575,7 +618,9 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128):
         bad += not (gc[i] == len(et) and np.array_equal(gtid[i, :len(et)], ndbo.tids_to_u64(et)) and
                     np.array_equal(gd[i, :len(et)].view(np.uint32), ed.view(np.uint32)))
     ix.close()
-    return {"workload": f"IVFFlat {n}x{dim} fp32 lists={nlists} probes={nprobe} k={k} L2, {nq} queries/step, i.i.d. N(0,1)",
+    what = "i.i.d. N(0,1)" if kind == "gauss" else \
+        "the headline's clustered table, centroids = the generator's component centres (balanced lists)"
+    return {"workload": f"IVFFlat {n}x{dim} fp32 lists={nlists} probes={nprobe} k={k} L2, {nq} queries/step, {what}",
             "queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3), "recall_at_10": round(recall, 4),
             "build_vectors_per_s": round(n / tb, 1), "kmeans_iterations": int(iters),
             "bytes_per_query": int(st["bytes_scored"] / max(1, nq * steps)) + nlists * dim * 4,

@@ -339,6 +339,21 @@ int			ndbhip_comm_allgather(const void *d_send, void *d_recv, size_t bytes);
 int			ndbhip_ivf_search_sharded(ndbhip_ivf *shard, const float *d_queries, int nq, int strategy, int nprobe,
 									  int k, int64_t max_candidates, uint64_t *d_out_tids, float *d_out_dist,
 									  int *d_out_count);
+/* Personalised exchange (csrc/ndbhip_comm.cpp): bytes [send_off[p], send_off[p + 1]) of d_send go to rank p and
+ * land at [recv_off[r], recv_off[r + 1]) of p's d_recv (r = the sender); host arrays of world + 1 byte offsets. */
+int			ndbhip_comm_alltoallv(const void *d_send, const size_t *send_off, void *d_recv, const size_t *recv_off);
+/*
+ * ivfbuild over the communicator's ranks, each holding a contiguous slice of the table in heap order (rank 0 the
+ * first rows, rank 1 the next ...): rank 0 runs the k-means on the sample (the table's first min(10000, 100 lists)
+ * rows, which its slice must hold), the centroids are broadcast, every rank assigns its own rows, the list
+ * histograms are all-gathered, whole lists are dealt to ranks by length (longest first to the least loaded rank,
+ * the same deal on every rank) and every row travels once, to its list's owner.  `ix` becomes this rank's shard:
+ * all centroids, the global list lengths, and the rows of its own lists in heap order — the mirror
+ * ndbhip_ivf_shard(full, owned) would cut out of the single-process build, row for row.  out_owned (optional,
+ * [nlists] bytes): which lists this rank holds.  Without a communicator: ndbhip_ivf_build_device.
+ */
+int			ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows_local,
+									 int max_iter, int *out_iters, uint8_t *out_owned);
 
 /* Host form of the same merge (results already on the host, e.g. gathered by
  * the PostgreSQL backend from several device-owner processes). Pure C, needs

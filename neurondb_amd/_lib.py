@@ -187,6 +187,8 @@ def lib():
         "ndbhip_merge_topk_device": (i, [vp, vp, vp, i, i, i, i, vp, vp, vp]),
         "ndbhip_merge_topk_host": (i, [vp, vp, vp, i, i, i, i, vp, vp, vp]),
         "ndbhip_kmeans_device": (i, [vp, i, i, i, i, f, vp, vp, vp, C.POINTER(i), C.POINTER(f)]),
+        "ndbhip_ivf_build_sharded": (i, [vp, vp, vp, i64, i, vp, vp]),
+        "ndbhip_comm_alltoallv": (i, [vp, vp, vp, vp]),
         "ndbhip_ivf_assign_device": (i, [vp, i, i, vp, i64, vp]),
         "ndbhip_ivf_build_device": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
         "ndbhip_hnsw_create": (i, [i, i, C.POINTER(vp)]),

@@ -1469,30 +1469,28 @@ struct ndbhip_ivf
  * HIP_TRY early returns of ivf_flush / ndbhip_ivf_delete leaked their device buffers) */
 struct DevGuard
 {
-	std::vector<void **> owned;
+	std::vector<void *> owned;	/* the blocks themselves, not the addresses of the caller's variables: a variable
+								 * declared in an inner scope is gone by the time the guard goes */
 	template <class T> int alloc(T *&p, size_t bytes)
 	{
 		p = nullptr;
 		if (bytes == 0)
 			bytes = 16;
 		HIP_TRY(hipMalloc((void **) &p, bytes));
-		owned.push_back((void **) &p);
+		owned.push_back((void *) p);
 		return 0;
 	}
 	template <class T> void keep(T *&p)
 	{
 		for (auto &o : owned)
-			if (o == (void **) &p)
+			if (o == (void *) p)
 				o = nullptr;
 	}
 	~DevGuard()
 	{
 		for (auto o : owned)
-			if (o && *o)
-			{
-				(void) hipFree(*o);
-				*o = nullptr;
-			}
+			if (o)
+				(void) hipFree(o);
 	}
 };
 
@@ -2668,13 +2666,47 @@ __global__ void k_assign_grouped(const float *__restrict__ rows, uint32_t nrows,
 								 int *__restrict__ part_idx, float *__restrict__ all_dist = nullptr,
 								 uint32_t all_stride = 0);
 
+/* per-sub-batch budget for the candidate-distance buffer of the paths that keep one (the fp16 matrix-core screen
+ * does not) */
+static size_t g_dist_budget_bytes = (size_t) 8 << 30;	/* of 288 GB: a 4096-query step of the 1M x 768 workload needs 2.1 GB */
+
+static int
+ivf_dist_budget_queries(uint32_t stride, int nq)
+{
+	const int	qb = (int) std::min<size_t>(65535, std::max<size_t>(1, g_dist_budget_bytes / ((size_t) stride * 4)));
+
+	return std::min(qb, std::max(nq, 1));
+}
+
+/* buffers only the exact / grouped / fp32-screened scans use */
+static int
+ivf_grow_scan_buffers(ndbhip_ivf *ix, int qb, uint32_t stride, int nprobe)
+{
+	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_tmin, ix->w_tmin_n, (size_t) qb * ((((stride >> 6) + (size_t) nprobe + 2) + 63) & ~(size_t) 63)))
+		return NDBHIP_ERR_HIP;
+	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode == 2))
+		if (grow(ix->w_qblock, ix->w_qblock_n,
+				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))
+			return NDBHIP_ERR_HIP;
+	return 0;
+}
+
+/* does a sub-batch of nq queries go to the fp16 matrix-core screen (ndbhip_screen16.h)?  mode 5 forces it */
+static bool
+ivf_s16_wanted(const ndbhip_ivf *ix, int nq, int R, int k)
+{
+	return (g_scan_mode == 5 || (g_scan_mode == 0 && g_screen_auto && g_s16_auto && nq >= NDB_SCREEN_MIN_NQ)) &&
+		ivf_s16_eligible(ix, nq, R, k);
+}
+
 /* queries already on the device; runs select (+ scan + topk when `full`) for one sub-batch */
 static int
 ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr, int k,
 				 int64_t max_candidates, uint32_t stride, bool full, int partial,
 				 ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
 				 uint64_t *d_otid, float *d_odist, int *d_ocnt, const int *d_probes_in = nullptr,
-				 int *d_probes_out = nullptr)
+				 int *d_probes_out = nullptr, bool allow_s16 = true)
 {
 	const IvfDev d = ivf_dev(ix);
 	const int	ncmp = std::min(ix->nlists, ix->ncent);
@@ -2741,8 +2773,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const int	R = ivf_recipe(strategy);
 
 	/* batches of >= 128 queries: the bound pass on fp16 matrix cores (ndbhip_screen16.h); mode 5 forces it */
-	if ((g_scan_mode == 5 || (g_scan_mode == 0 && g_screen_auto && g_s16_auto && nq >= NDB_SCREEN_MIN_NQ)) &&
-		ivf_s16_eligible(ix, nq, R, k))
+	if (allow_s16 && ivf_s16_wanted(ix, nq, R, k))
 	{
 		const int	rc = ivf_s16_run(ix, d, d_q, nq, R, npr, k, w_probes, lco, partial, d_cand, d_ncand, d_total,
 									 d_otid, d_odist, d_ocnt);
@@ -2750,6 +2781,34 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (rc <= 0)
 			return rc;
 		/* some query emitted more than its record capacity: the older path has none */
+	}
+	/* The paths below keep a [queries x candidates] distance array, which the caller did not size when it expected
+	 * the matrix-core screen to serve the batch: sub-batches that fit the array's budget, then the array itself */
+	{
+		const int	qb_old = ivf_dist_budget_queries(stride, nq);
+
+		if (nq > qb_old)
+		{
+			const uint32_t cap3 = 3u * (uint32_t) k;
+
+			for (int q0 = 0; q0 < nq; q0 += qb_old)
+			{
+				const int	n = std::min(qb_old, nq - q0);
+				const int	rc = ivf_search_chunk(ix, d_q + (size_t) q0 * ix->dim, n, strategy, npr, k, max_candidates,
+												  stride, full, partial, d_cand ? d_cand + (size_t) q0 * cap3 : nullptr,
+												  d_ncand ? d_ncand + q0 : nullptr, d_total ? d_total + q0 : nullptr,
+												  d_otid ? d_otid + (size_t) q0 * k : nullptr,
+												  d_odist ? d_odist + (size_t) q0 * k : nullptr, d_ocnt ? d_ocnt + q0 : nullptr,
+												  d_probes_in ? d_probes_in + (size_t) q0 * npr : nullptr,
+												  d_probes_out ? d_probes_out + (size_t) q0 * npr : nullptr, false);
+
+				if (rc)
+					return rc;
+			}
+			return 0;
+		}
+		if (ivf_grow_scan_buffers(ix, nq, stride, npr))
+			return NDBHIP_ERR_HIP;
 	}
 	/* one slot per (probe, 64-candidate tile): slot = (local offset of the probe >> 6) + probe + tile */
 	const uint32_t tstride = (((stride >> 6) + (uint32_t) npr + 2u) + 63u) & ~63u;
@@ -3094,9 +3153,6 @@ ivf_check_search_args(ndbhip_ivf *ix, int nq, int nprobe, int k)
 	return 0;
 }
 
-/* per-sub-batch budget for the candidate-distance buffer */
-static size_t g_dist_budget_bytes = (size_t) 8 << 30;	/* of 288 GB: a 4096-query step of the 1M x 768 workload needs 2.1 GB */
-
 static int
 ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy, int nprobe, int k,
 					   int64_t max_candidates, int partial, ndbhip_cand *d_cand, int *d_ncand,
@@ -3122,26 +3178,23 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 	if (maxc > 0xFFFFFF00ll)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 candidates per query");
 	const uint32_t stride = (uint32_t) std::max<int64_t>(64, (maxc + 63) & ~63ll);
-	int			qb = (int) std::max<size_t>(1, g_dist_budget_bytes / ((size_t) stride * 4));
-
-	qb = std::min(qb, std::min(nq, 65535));
+	/* sub-batches: what the distance array's budget allows — or, when the matrix-core screen serves the batch (it
+	 * keeps no such array), what its 32-bit query-plane offsets allow */
+	const size_t dimp4 = (size_t) ((ix->dim + 63) & ~63) * 4;
+	const int	qb_s16 = (int) std::min<size_t>(std::min(nq, 65535), (((size_t) 1 << 32) - 1) / dimp4);
+	const bool	s16 = ivf_s16_wanted(ix, qb_s16, ivf_recipe(strategy), k);
+	const int	qb = s16 ? qb_s16 : ivf_dist_budget_queries(stride, nq);
 	const int	ncmp = std::min(ix->nlists, ix->ncent);
 	const size_t cstride = (size_t) ((ncmp + 63) & ~63);
 
 	if (grow(ix->w_cdist, ix->w_cdist_n, (size_t) qb * cstride)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_probes, ix->w_probes_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_candoff, ix->w_candoff_n, (size_t) 2 * qb * (nprobe + 1))) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
+	if (!s16 && ivf_grow_scan_buffers(ix, qb, stride, nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ix->ncent + 8 * NDB_QHEAD_STRIDE + 16)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ix->ncent + 1) + 80)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_pairs, ix->w_pairs_n, (size_t) qb * nprobe)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qnorm, ix->w_qnorm_n, (size_t) 2 * qb)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_tmin, ix->w_tmin_n, (size_t) qb * ((((stride >> 6) + (size_t) nprobe + 2) + 63) & ~(size_t) 63)))
-		return NDBHIP_ERR_HIP;
-	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode == 2))
-		if (grow(ix->w_qblock, ix->w_qblock_n,
-				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))
-			return NDBHIP_ERR_HIP;
 
 	const uint32_t cap = 3u * (uint32_t) k;
 

@@ -1121,6 +1121,8 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 		}
 	}
 	struct { unsigned int over, none; unsigned long long multi; } hs;
+	float	   *orows = nullptr;		/* (function scope: DevGuard keeps their addresses) */
+	int		   *olist = nullptr;
 
 	HIP_TRY(hipMemcpyAsync(&hs, over_n, 16, hipMemcpyDeviceToHost, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));	/* the temporaries go out of scope */
@@ -1135,9 +1137,6 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 	if (hs.over > 0)
 	{
 		/* rows the bound could not narrow to S16_ASSIGN_SLOTS centroids: the exact assignment on a packed copy */
-		float	   *orows = nullptr;
-		int		   *olist = nullptr;
-
 		if (tmp.alloc(orows, (size_t) hs.over * dim * sizeof(float))) return NDBHIP_ERR_HIP;
 		if (tmp.alloc(olist, (size_t) hs.over * sizeof(int))) return NDBHIP_ERR_HIP;
 		hipLaunchKernelGGL(k_rows_gather, dim3(hs.over), dim3(256), 0, g.stream, d_rows, dim, (const int64_t *) over_rows, orows);
@@ -1180,6 +1179,9 @@ ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_
 	(void) hipFree(d_tids);
 	return rc;
 }
+
+static int	pack_by_list(const int *d_list, int64_t nrows, int dim, int k, const float *d_rows, const uint64_t *d_tids,
+						 float *d_prow, uint64_t *d_ptid, std::vector<int64_t> &list_len);
 
 extern "C" int
 ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
@@ -1251,37 +1253,14 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 		return rc;
 	lap("assign every row (+ malloc of the packed rows under it)");
 
-	const uint32_t nblocks = (uint32_t) ((nrows + NDB_PACK_BLOCK - 1) / NDB_PACK_BLOCK);
-	const size_t nh = (size_t) k * nblocks;
-	uint32_t   *d_hist = nullptr;
-	int64_t    *d_scan = nullptr;
+	std::vector<int64_t> list_len;
 
-	HIP_TRY(hipMalloc((void **) &d_hist, nh * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **) &d_scan, nh * sizeof(int64_t)));
-	HIP_TRY(hipMemsetAsync(d_hist, 0, nh * sizeof(uint32_t), g.stream));
-	hipLaunchKernelGGL(k_pack_hist, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list, nrows,
-					   k, nblocks, d_hist);
-	std::vector<int64_t> list_len((size_t) k, 0);
-	int64_t    *d_llen = nullptr;
-
-	HIP_TRY(hipMalloc((void **) &d_llen, (size_t) k * sizeof(int64_t)));
-	hipLaunchKernelGGL(k_pack_list_totals, dim3((k + 63) / 64), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k,
-					   nblocks, d_llen);
-	hipLaunchKernelGGL(k_pack_offsets, dim3(k), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k, nblocks,
-					   (const int64_t *) d_llen, d_scan);
-	HIP_TRY(hipMemcpyAsync(list_len.data(), d_llen, (size_t) k * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
-
-	lap("histograms / offsets");
-	hipLaunchKernelGGL(k_pack_scatter, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, (const int *) d_list,
-					   nrows, dim, nblocks, (const int64_t *) d_scan, d_rows, d_tids, d_prow, d_ptid);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(g.stream));
-	lap("scatter");
+	rc = pack_by_list(d_list, nrows, dim, k, d_rows, d_tids, d_prow, d_ptid, list_len);
+	if (rc)
+		return rc;
+	lap("histograms / offsets / scatter");
 	if (aws.release()) return NDBHIP_ERR_HIP;
-	HIP_TRY(hipFree(d_hist));
-	HIP_TRY(hipFree(d_scan));
 	HIP_TRY(hipFree(d_list));
-	HIP_TRY(hipFree(d_llen));
 	lap("frees");
 
 	/* adopt: centroids + packed lists become the index */
@@ -1303,6 +1282,325 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	lap("adopt (layout upload, old rows freed)");
 	if (out_iters)
 		*out_iters = iters;
+	return NDBHIP_OK;
+}
+
+/* stable scatter of rows and TIDs by list id (list-major, input order inside a list): hist per 256-row block,
+ * offsets, scatter; list_len out (host).  Synchronises the stream. */
+static int
+pack_by_list(const int *d_list, int64_t nrows, int dim, int k, const float *d_rows, const uint64_t *d_tids,
+			 float *d_prow, uint64_t *d_ptid, std::vector<int64_t> &list_len)
+{
+	list_len.assign((size_t) k, 0);
+	if (nrows == 0)
+		return 0;
+	const uint32_t nblocks = (uint32_t) ((nrows + NDB_PACK_BLOCK - 1) / NDB_PACK_BLOCK);
+	const size_t nh = (size_t) k * nblocks;
+	DevGuard	tmp;
+	uint32_t   *d_hist = nullptr;
+	int64_t    *d_scan = nullptr, *d_llen = nullptr;
+
+	if (tmp.alloc(d_hist, nh * sizeof(uint32_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_scan, nh * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_llen, (size_t) k * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemsetAsync(d_hist, 0, nh * sizeof(uint32_t), g.stream));
+	hipLaunchKernelGGL(k_pack_hist, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, d_list, nrows, k, nblocks, d_hist);
+	hipLaunchKernelGGL(k_pack_list_totals, dim3((k + 63) / 64), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k,
+					   nblocks, d_llen);
+	hipLaunchKernelGGL(k_pack_offsets, dim3(k), dim3(64), 0, g.stream, (const uint32_t *) d_hist, k, nblocks,
+					   (const int64_t *) d_llen, d_scan);
+	HIP_TRY(hipMemcpyAsync(list_len.data(), d_llen, (size_t) k * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+	hipLaunchKernelGGL(k_pack_scatter, dim3(nblocks), dim3(NDB_PACK_BLOCK), 0, g.stream, d_list, nrows, dim, nblocks,
+					   (const int64_t *) d_scan, d_rows, d_tids, d_prow, d_ptid);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return 0;
+}
+
+__global__ void
+k_map_lists(const int *__restrict__ lists, int64_t n, const int *__restrict__ slot_of, int *__restrict__ out)
+{
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i < n)
+		out[i] = slot_of[lists[i]];
+}
+
+extern "C" int ndbhip_comm_rank(void);
+extern "C" int ndbhip_comm_world(void);
+extern "C" int ndbhip_comm_allgather(const void *d_send, void *d_recv, size_t bytes);
+extern "C" int ndbhip_comm_alltoallv(const void *d_send, const size_t *send_off, void *d_recv, const size_t *recv_off);
+
+/* ivfbuild over the ranks of the communicator: include/ndbhip.h */
+extern "C" int
+ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows_local,
+						 int max_iter, int *out_iters, uint8_t *out_owned)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	const int	W = ndbhip_comm_world(), me = ndbhip_comm_rank();
+
+	if (W <= 1)
+	{
+		const int	rc = ndbhip_ivf_build_device(ix, d_rows, d_tids, nrows_local, max_iter, out_iters);
+
+		if (rc == 0 && out_owned)
+			memset(out_owned, 1, (size_t) ix->nlists);
+		return rc;
+	}
+	if (!ix || nrows_local < 0 || (nrows_local > 0 && (!d_rows || !d_tids)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	const int	dim = ix->dim, k = ix->nlists;
+	DevGuard	tmp;
+	int64_t    *d_i64 = nullptr, *d_i64_all = nullptr;
+	int			rc;
+
+	auto		trace = [&](const char *what) {
+		if (g_debug_build)
+			fprintf(stderr, "build_sharded[%d]: %s (last HIP error: %s)\n", me, what, hipGetErrorName(hipPeekAtLastError()));
+	};
+
+	/* 1. how many rows everyone holds */
+	if (tmp.alloc(d_i64, (size_t) (k + 2) * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_i64_all, (size_t) W * (k + 2) * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	std::vector<int64_t> h_send((size_t) k + 2, 0), h_all((size_t) W * (k + 2), 0);
+
+	h_send[0] = nrows_local;
+	HIP_TRY(hipMemcpyAsync(d_i64, h_send.data(), sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+	if ((rc = ndbhip_comm_allgather(d_i64, d_i64_all, sizeof(int64_t))) != 0) return rc;
+	HIP_TRY(hipMemcpyAsync(h_all.data(), d_i64_all, (size_t) W * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	std::vector<int64_t> nloc(h_all.begin(), h_all.begin() + W);
+	int64_t		ntotal = 0;
+
+	for (int r = 0; r < W; r++)
+		ntotal += nloc[(size_t) r];
+	if (ntotal < 1 || ntotal > 0xFFFFFFFFll)
+		return fail(NDBHIP_ERR_INVALID, "table of %lld rows", (long long) ntotal);
+	const int	ns = (int) std::min<int64_t>(std::min<int64_t>(10000, (int64_t) k * 100), ntotal);
+
+	if (ns < k)					/* ivf_am.c:596-601 */
+		return fail(NDBHIP_ERR_INVALID, "ivf: not enough sample vectors (%d < %d)", ns, k);
+	if (nloc[0] < ns)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "rank 0 holds %lld rows, the sample is the table's first %d", (long long) nloc[0], ns);
+
+	trace("row counts gathered");
+	/* 2. k-means on rank 0, centroids (and the iteration count) to everyone */
+	float	   *d_cent = nullptr, *d_cent_all = nullptr;
+	int			iters = 0;
+
+	HIP_TRY(hipMalloc((void **) &d_cent, ((size_t) k * dim + 1) * sizeof(float)));
+	if (tmp.alloc(d_cent_all, (size_t) W * ((size_t) k * dim + 1) * sizeof(float))) { (void) hipFree(d_cent); return NDBHIP_ERR_HIP; }
+	auto		bail = [&](int code) { (void) hipStreamSynchronize(g.stream); (void) hipFree(d_cent); return code; };
+
+	int		   *d_sasg = nullptr, *d_scnt = nullptr;	/* (function scope: DevGuard keeps their addresses) */
+
+	if (me == 0)
+	{
+		if (tmp.alloc(d_sasg, (size_t) ns * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+		if (tmp.alloc(d_scnt, (size_t) k * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+		rc = ndbhip_kmeans_device(d_rows, ns, dim, k, max_iter, 0.001f, d_cent, d_sasg, d_scnt, &iters, nullptr);
+		if (rc)
+			return bail(rc);		/* (the other ranks are left in the all-gather: a failed build ends the job) */
+		const float fi = (float) iters;
+
+		if (hipMemcpyAsync(d_cent + (size_t) k * dim, &fi, sizeof(float), hipMemcpyHostToDevice, g.stream) != hipSuccess ||
+			hipStreamSynchronize(g.stream) != hipSuccess)
+			return bail(NDBHIP_ERR_HIP);
+	}
+	if ((rc = ndbhip_comm_allgather(d_cent, d_cent_all, ((size_t) k * dim + 1) * sizeof(float))) != 0) return bail(rc);
+	if (me != 0)
+	{
+		float		fi = 0.0f;
+
+		if (hipMemcpyAsync(d_cent, d_cent_all, ((size_t) k * dim + 1) * sizeof(float), hipMemcpyDeviceToDevice, g.stream) != hipSuccess ||
+			hipMemcpyAsync(&fi, d_cent_all + (size_t) k * dim, sizeof(float), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+			hipStreamSynchronize(g.stream) != hipSuccess)
+			return bail(NDBHIP_ERR_HIP);
+		iters = (int) fi;
+	}
+
+	trace("centroids broadcast");
+	/* 3. every rank assigns its own rows (the insert rule, screened on the matrix cores where the shape allows) */
+	int		   *d_list = nullptr, *d_cnt = nullptr;
+	const int64_t nl = nrows_local;
+
+	if (tmp.alloc(d_list, (size_t) std::max<int64_t>(nl, 1) * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+	if (tmp.alloc(d_cnt, (size_t) k * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+	if (nl > 0)
+	{
+		rc = g_build_s16 ? assign_rows_s16(d_rows, nl, dim, d_cent, k, d_list, nullptr, nullptr) : 1;
+		if (rc == 1)
+			rc = assign_rows(d_rows, nl, dim, d_cent, k, true, d_list, nullptr);
+		if (rc)
+			return bail(rc);
+	}
+
+	trace("rows assigned");
+	/* 4. list histograms of every rank */
+	if (hipMemsetAsync(d_cnt, 0, (size_t) k * sizeof(int), g.stream) != hipSuccess) return bail(NDBHIP_ERR_HIP);
+	if (nl > 0)
+		hipLaunchKernelGGL(k_count_members, dim3((unsigned) ((nl + 255) / 256)), dim3(256), 0, g.stream, (const int *) d_list,
+						   (int) nl, k, d_cnt);
+	std::vector<int> hcnt((size_t) k);
+
+	if (hipMemcpyAsync(hcnt.data(), d_cnt, (size_t) k * sizeof(int), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+		hipStreamSynchronize(g.stream) != hipSuccess)
+		return bail(NDBHIP_ERR_HIP);
+	for (int L = 0; L < k; L++)
+		h_send[(size_t) L] = hcnt[(size_t) L];
+	if (hipMemcpyAsync(d_i64, h_send.data(), (size_t) k * sizeof(int64_t), hipMemcpyHostToDevice, g.stream) != hipSuccess)
+		return bail(NDBHIP_ERR_HIP);
+	if ((rc = ndbhip_comm_allgather(d_i64, d_i64_all, (size_t) k * sizeof(int64_t))) != 0) return bail(rc);
+	if (hipMemcpyAsync(h_all.data(), d_i64_all, (size_t) W * k * sizeof(int64_t), hipMemcpyDeviceToHost, g.stream) != hipSuccess ||
+		hipStreamSynchronize(g.stream) != hipSuccess)
+		return bail(NDBHIP_ERR_HIP);
+	auto		cnt = [&](int r, int L) -> int64_t { return h_all[(size_t) r * k + (size_t) L]; };
+	std::vector<int64_t> glob((size_t) k, 0);
+
+	for (int r = 0; r < W; r++)
+		for (int L = 0; L < k; L++)
+			glob[(size_t) L] += cnt(r, L);
+
+	trace("histograms gathered");
+	/* 5. the deal: longest list first, to the rank with the fewest rows so far (ties: the lower rank); every rank
+	 * computes the same one */
+	std::vector<int> order((size_t) k), owner((size_t) k, 0);
+	std::vector<int64_t> load((size_t) W, 0);
+
+	for (int L = 0; L < k; L++)
+		order[(size_t) L] = L;
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return glob[(size_t) a] > glob[(size_t) b]; });
+	for (int L : order)
+	{
+		int			best = 0;
+
+		for (int r = 1; r < W; r++)
+			if (load[(size_t) r] < load[(size_t) best])
+				best = r;
+		owner[(size_t) L] = best;
+		load[(size_t) best] += glob[(size_t) L];
+	}
+
+	/* 6. local rows ordered by (owner, list, heap order): a stable pack by slot_of[list] */
+	std::vector<int> by_owner((size_t) k), slot_of((size_t) k);
+
+	for (int L = 0; L < k; L++)
+		by_owner[(size_t) L] = L;
+	std::stable_sort(by_owner.begin(), by_owner.end(), [&](int a, int b) { return owner[(size_t) a] < owner[(size_t) b]; });
+	for (int s2 = 0; s2 < k; s2++)
+		slot_of[(size_t) by_owner[(size_t) s2]] = s2;
+	int		   *d_slot_of = nullptr, *d_slots = nullptr;
+	float	   *d_srow = nullptr;
+	uint64_t   *d_stid = nullptr;
+	std::vector<int64_t> slot_len;
+
+	if (tmp.alloc(d_slot_of, (size_t) k * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+	if (tmp.alloc(d_slots, (size_t) std::max<int64_t>(nl, 1) * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+	if (tmp.alloc(d_srow, (size_t) std::max<int64_t>(nl, 1) * dim * sizeof(float))) return bail(NDBHIP_ERR_HIP);
+	if (tmp.alloc(d_stid, (size_t) std::max<int64_t>(nl, 1) * sizeof(uint64_t))) return bail(NDBHIP_ERR_HIP);
+	if (hipMemcpyAsync(d_slot_of, slot_of.data(), (size_t) k * sizeof(int), hipMemcpyHostToDevice, g.stream) != hipSuccess)
+		return bail(NDBHIP_ERR_HIP);
+	if (nl > 0)
+		hipLaunchKernelGGL(k_map_lists, dim3((unsigned) ((nl + 255) / 256)), dim3(256), 0, g.stream, (const int *) d_list, nl,
+						   (const int *) d_slot_of, d_slots);
+	if ((rc = pack_by_list(d_slots, nl, dim, k, d_rows, d_tids, d_srow, d_stid, slot_len)) != 0) return bail(rc);
+
+	trace("packed by owner");
+	/* 7. every row to its list's owner */
+	std::vector<size_t> so_rows((size_t) W + 1, 0), ro_rows((size_t) W + 1, 0), so((size_t) W + 1), ro((size_t) W + 1);
+
+	for (int L = 0; L < k; L++)
+		so_rows[(size_t) owner[(size_t) L] + 1] += (size_t) cnt(me, L);
+	for (int r = 0; r < W; r++)
+	{
+		so_rows[(size_t) r + 1] += so_rows[(size_t) r];
+		size_t		from_r = 0;
+
+		for (int L = 0; L < k; L++)
+			if (owner[(size_t) L] == me)
+				from_r += (size_t) cnt(r, L);
+		ro_rows[(size_t) r + 1] = ro_rows[(size_t) r] + from_r;
+	}
+	const int64_t nmine = (int64_t) ro_rows[(size_t) W];
+	float	   *d_rrow = nullptr, *d_prow = nullptr;
+	uint64_t   *d_rtid = nullptr, *d_ptid = nullptr;
+	int		   *d_rlist = nullptr;
+
+	if (tmp.alloc(d_rrow, (size_t) std::max<int64_t>(nmine, 1) * dim * sizeof(float))) return bail(NDBHIP_ERR_HIP);
+	if (tmp.alloc(d_rtid, (size_t) std::max<int64_t>(nmine, 1) * sizeof(uint64_t))) return bail(NDBHIP_ERR_HIP);
+	if (tmp.alloc(d_rlist, (size_t) std::max<int64_t>(nmine, 1) * sizeof(int))) return bail(NDBHIP_ERR_HIP);
+	for (int r = 0; r <= W; r++)
+	{
+		so[(size_t) r] = so_rows[(size_t) r] * (size_t) dim * sizeof(float);
+		ro[(size_t) r] = ro_rows[(size_t) r] * (size_t) dim * sizeof(float);
+	}
+	if ((rc = ndbhip_comm_alltoallv(d_srow, so.data(), d_rrow, ro.data())) != 0) return bail(rc);
+	for (int r = 0; r <= W; r++)
+	{
+		so[(size_t) r] = so_rows[(size_t) r] * sizeof(uint64_t);
+		ro[(size_t) r] = ro_rows[(size_t) r] * sizeof(uint64_t);
+	}
+	if ((rc = ndbhip_comm_alltoallv(d_stid, so.data(), d_rtid, ro.data())) != 0) return bail(rc);
+
+	trace("rows exchanged");
+	/* 8. what arrived is ordered (source rank, list, heap order); sources hold consecutive heap ranges, so a stable
+	 * pack by list puts every list in heap order */
+	std::vector<int> rlist((size_t) std::max<int64_t>(nmine, 1));
+	size_t		w = 0;
+
+	for (int r = 0; r < W; r++)
+		for (int L = 0; L < k; L++)
+			if (owner[(size_t) L] == me)
+				for (int64_t j = 0; j < cnt(r, L); j++)
+					rlist[w++] = L;
+	if (hipMemcpyAsync(d_rlist, rlist.data(), (size_t) std::max<int64_t>(nmine, 1) * sizeof(int), hipMemcpyHostToDevice, g.stream) != hipSuccess)
+		return bail(NDBHIP_ERR_HIP);
+	if (big_alloc((void **) &d_prow, (size_t) std::max<int64_t>(nmine, 1) * dim * sizeof(float))) return bail(NDBHIP_ERR_HIP);
+	if (big_alloc((void **) &d_ptid, (size_t) std::max<int64_t>(nmine, 1) * sizeof(uint64_t)))
+	{
+		big_free(d_prow);
+		return bail(NDBHIP_ERR_HIP);
+	}
+	std::vector<int64_t> own_len;
+
+	if ((rc = pack_by_list(d_rlist, nmine, dim, k, d_rrow, d_rtid, d_prow, d_ptid, own_len)) != 0)
+	{
+		big_free(d_prow);
+		big_free(d_ptid);
+		return bail(rc);
+	}
+
+	trace("packed by list");
+	/* 9. adopt: all centroids, global lengths, the rows of the lists held here */
+	std::vector<uint8_t> owned((size_t) k);
+
+	for (int L = 0; L < k; L++)
+		owned[(size_t) L] = owner[(size_t) L] == me;
+	if (ix->d_centroids)
+		(void) hipFree(ix->d_centroids);
+	ix->d_centroids = d_cent;
+	ix->ncent = k;
+	rc = ivf_set_layout(ix, glob.data(), owned.data(), nmine);
+	if (rc)
+	{
+		big_free(d_prow);
+		big_free(d_ptid);
+		return rc;
+	}
+	ivf_free_rows(ix);
+	ix->d_vecs = d_prow;
+	ix->d_tids = d_ptid;
+	ix->own_rows = true;
+	ix->nrows = nmine;
+	ix->norm_valid = false; ix->s16_valid = false;
+	ix->cap_rows = std::max<int64_t>(nmine, 1);
+	ix->f16 = false;
+	ix->loaded = true;
+	trace("adopted");
+	if (out_iters)
+		*out_iters = iters;
+	if (out_owned)
+		memcpy(out_owned, owned.data(), (size_t) k);
 	return NDBHIP_OK;
 }
 

@@ -61,6 +61,11 @@ struct RcclApi
 	ncclResult_t (*AllGather) (const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*CommDestroy) (ncclComm_t) = nullptr;
 	const char *(*GetErrorString) (ncclResult_t) = nullptr;
+	/* point-to-point, for ndbhip_comm_alltoallv (the distributed build's row routing) */
+	ncclResult_t (*Send) (const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv) (void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart) (void) = nullptr;
+	ncclResult_t (*GroupEnd) (void) = nullptr;
 };
 
 struct Comm
@@ -112,6 +117,10 @@ load_rccl()
 	SYM(AllGather, "ncclAllGather");
 	SYM(CommDestroy, "ncclCommDestroy");
 	SYM(GetErrorString, "ncclGetErrorString");
+	SYM(Send, "ncclSend");
+	SYM(Recv, "ncclRecv");
+	SYM(GroupStart, "ncclGroupStart");
+	SYM(GroupEnd, "ncclGroupEnd");
 #undef SYM
 	return 0;
 }
@@ -350,6 +359,96 @@ ndbhip_comm_allgather(const void *d_send, void *d_recv, size_t bytes)
 		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "stream synchronisation failed");
 	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot has been read: it may be overwritten */
 	return NDBHIP_OK;
+}
+
+/*
+ * Personalised exchange: bytes [send_off[p], send_off[p + 1]) of this rank's d_send go to rank p and arrive at
+ * [recv_off[r], recv_off[r + 1]) of p's d_recv (r = this rank); host arrays of world + 1 byte offsets, the sizes
+ * agreed by the caller (rank r's piece for p is as long as p expects from r).  Device pointers, ordered on the
+ * library's stream.  RCCL: grouped ncclSend / ncclRecv.  SHM: the whole send buffer travels through the rank's
+ * slot, so it must fit one (with its offset table).
+ */
+extern "C" int
+ndbhip_comm_alltoallv(const void *d_send, const size_t *send_off, void *d_recv, const size_t *recv_off)
+{
+	void	   *sv = nullptr;
+
+	if (ndbhip_get_stream(&sv))
+		return NDBHIP_ERR_NODEVICE;
+	hipStream_t stream = (hipStream_t) sv;
+
+	if (!send_off || !recv_off)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "NULL offset table");
+	const int	W = comm.kind == 0 ? 1 : comm.world, me = comm.kind == 0 ? 0 : comm.rank;
+
+	if ((send_off[W] > 0 && !d_send) || (recv_off[W] > 0 && !d_recv))
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	if (send_off[me + 1] - send_off[me] != recv_off[me + 1] - recv_off[me])
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "a rank's piece for itself has two sizes");
+	if (W == 1)
+	{
+		if (send_off[1] > send_off[0] &&
+			hipMemcpyAsync((unsigned char *) d_recv + recv_off[0], (const unsigned char *) d_send + send_off[0],
+						   send_off[1] - send_off[0], hipMemcpyDeviceToDevice, stream) != hipSuccess)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "hipMemcpyAsync failed");
+		return NDBHIP_OK;
+	}
+	if (comm.kind == 1)
+	{
+		ncclResult_t r = rccl.GroupStart();
+
+		for (int p = 0; p < W && r == ncclSuccess; p++)
+		{
+			const size_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
+
+			if (ns > 0)
+				r = rccl.Send((const unsigned char *) d_send + send_off[p], ns, ncclInt8, p, comm.nccl, stream);
+			if (r == ncclSuccess && nr > 0)
+				r = rccl.Recv((unsigned char *) d_recv + recv_off[p], nr, ncclInt8, p, comm.nccl, stream);
+		}
+		const ncclResult_t e = rccl.GroupEnd();
+
+		if (r == ncclSuccess)
+			r = e;
+		if (r != ncclSuccess)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "ncclSend/ncclRecv: %s", rccl.GetErrorString(r));
+		return NDBHIP_OK;
+	}
+	/* SHM: slot = [world + 1 offsets][send buffer] */
+	const size_t head = (size_t) (W + 1) * sizeof(uint64_t);
+
+	if (head + send_off[W] > comm.slot_bytes)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "exchange of %zu bytes from one rank exceeds the segment's slots (%zu)",
+									send_off[W], comm.slot_bytes);
+	unsigned char *mine = comm.slots + (size_t) me * comm.slot_bytes;
+
+	for (int p = 0; p <= W; p++)
+		((uint64_t *) mine)[p] = (uint64_t) send_off[p];
+	if (send_off[W] > 0 &&
+		hipMemcpyAsync(mine + head, d_send, send_off[W], hipMemcpyDeviceToHost, stream) != hipSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "device-to-host copy failed");
+	if (hipStreamSynchronize(stream) != hipSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "stream synchronisation failed");
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot is written */
+	int			rc = NDBHIP_OK;
+
+	for (int p = 0; p < W; p++)
+	{
+		const unsigned char *theirs = comm.slots + (size_t) p * comm.slot_bytes;
+		const uint64_t lo = ((const uint64_t *) theirs)[me], hi = ((const uint64_t *) theirs)[me + 1];
+		const size_t nr = recv_off[p + 1] - recv_off[p];
+
+		if (hi - lo != nr)
+			rc = ndbhip_internal_fail(NDBHIP_ERR_INVALID, "rank %d sends %llu bytes where %zu are expected", p,
+									  (unsigned long long) (hi - lo), nr);
+		else if (nr > 0 && hipMemcpyAsync((unsigned char *) d_recv + recv_off[p], theirs + head + lo, nr,
+										  hipMemcpyHostToDevice, stream) != hipSuccess)
+			rc = ndbhip_internal_fail(NDBHIP_ERR_HIP, "host-to-device copy failed");
+	}
+	if (hipStreamSynchronize(stream) != hipSuccess && rc == NDBHIP_OK)
+		rc = ndbhip_internal_fail(NDBHIP_ERR_HIP, "stream synchronisation failed");
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot has been read: it may be overwritten */
+	return rc;
 }
 
 extern "C" int

@@ -141,7 +141,7 @@ ndb_replay_selection_host(const uint32_t *key, uint32_t *pos, uint8_t *taken, in
 
 
 /* ------------------------------------------------------------------------------------------------------------
- * Error model of the screened scan's bound pass on fp16 matrix cores (k_scr16_sweep, ndbhip_screen16.h).
+ * Error model of the screened scan's bound pass on fp16 matrix cores (k_s16_sweep, ndbhip_screen16.h).
  *
  * The pass computes, for a query q and a row x (dim elements, any finite fp32 values), an approximation `dot`
  * of the real dot product q.x and from it a = (Q2 + X2) - 2 dot ~ |q - x|^2.  Every constant below is the
@@ -178,9 +178,12 @@ ndb_replay_selection_host(const uint32_t *key, uint32_t *pos, uint8_t *taken, in
  *     sees inf / NaN / a flushed value: inf and NaN are emitted as "cannot be excluded", a flushed value errs by
  *     <= 2^-126, inside NDB_S16_ABS).
  *     Together:  |dot - q.x| <= c_dot(dim) S,  c_dot = NDB_S16_SPLIT + (12.12 * 34 + nblk) u.
- * (6) a = fma(-2, dot, fl(Q2 + X2)): two roundings of values <= 2 (|q|^2 + |x|^2).  With (1):
- *       |a - |q - x|^2| <= (2 NDB_S16_NORM + 5 u)(|q|^2 + |x|^2)/1 ... + 2 c_dot S
- *                       <= (c_dot + NDB_S16_NORMS)(|q|^2 + |x|^2)          since 2 S <= |q|^2 + |x|^2
+ * (6) a = fma(-2, dot, fl(Q2 + X2)).  Write N = |q|^2 + |x|^2 and note |q - x|^2 = N - 2 q.x, 2 S <= N:
+ *       |fl(Q2 + X2) - N| <= NDB_S16_NORM N (1 + u) + u N (1 + NDB_S16_NORM)   ((1), then one rounding)
+ *       the fma rounds a value of magnitude <= 2 N (1 + small) once:            <= 2 u N (1 + small)
+ *       2 |dot - q.x| <= 2 c_dot S <= c_dot N
+ *     Sum:  |a - |q - x|^2| <= (c_dot + NDB_S16_NORM + 3 u + small) N <= (c_dot + NDB_S16_NORMS) N,
+ *     NDB_S16_NORMS = 2 NDB_S16_NORM + 6 u leaving a factor two of room on the norm and rounding terms.
  *     E_q = ndb_s16_e_l2(dim, Q2, X2max) evaluates that with X2max = the largest finite row norm of the mirror,
  *     rounded up, plus NDB_S16_ABS.
  * (7) The reference's float4 distance d = sqrtf(T), T = the sequential fp32 sum of fl(fl(q_i - x_i)^2)

@@ -98,6 +98,18 @@ class IvfIndex:
         self.ncent = self.nlists
         return iters.value
 
+    def build_sharded_device(self, d_rows, d_tids, max_iter=50):
+        """ambuild over the ranks of the library's communicator (ndbhip_ivf_build_sharded): this rank passes its
+        contiguous slice of the table in heap order and ends up holding its own lists' rows.  Returns (Lloyd
+        iterations, owned flags [nlists] uint8)."""
+        iters = C.c_int(0)
+        owned = np.zeros(self.nlists, dtype=np.uint8)
+        assert d_rows.is_contiguous() and d_tids.is_contiguous()
+        check(lib().ndbhip_ivf_build_sharded(self._h, C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_tids.data_ptr()),
+                                             d_rows.shape[0], max_iter, C.byref(iters), _ptr(owned)))
+        self.ncent = self.nlists
+        return iters.value, owned
+
     def build(self, rows, tids, max_iter=50):
         """Host-array form of build_device (stages through torch device tensors)."""
         import torch

@@ -175,3 +175,124 @@ def test_c_abi_sharded_search_over_a_world_1_rccl_communicator():
     finally:
         _lib.check(L.ndbhip_comm_destroy())
         ix.close()
+
+
+def _worker_build(rank, world, name, n, dim, nlists, ret):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        from neurondb_amd import IvfIndex, _lib
+        from bench import pack_tids
+        _lib.ensure_init(0)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        _lib.use_torch_stream()
+        rng = np.random.default_rng(81)
+        cents = rng.standard_normal((nlists, dim)).astype(np.float32) * 3
+        base = (cents[rng.integers(0, nlists, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+        base[n // 3] = base[n // 3 + 1]                          # a duplicate row across the cut is still two rows
+        # oracle: the single-process build of the whole table
+        img, asg, iters = ndbo.build_ivf_image(base, nlists, max_iter=50)
+        cut = [0, 5000 + (n - 5000) // 3, n][: world + 1] if world == 2 else [0, n]   # uneven slices; rank 0 holds the sample
+        lo, hi = cut[rank], cut[rank + 1]
+        _lib.check(_lib.lib().ndbhip_comm_init_shm(name.encode(), rank, world, 64 << 20))
+        ix = IvfIndex(dim, nlists)
+        d_rows = torch.from_numpy(base[lo:hi]).to(dev)
+        d_tids = pack_tids(torch.arange(lo, hi, device=dev))
+        if os.environ.get("NDBHIP_TEST_TRACE"):
+            _lib.check(_lib.lib().ndbhip_set_option(b"debug_build", 1))
+        it, owned = ix.build_sharded_device(d_rows, d_tids, 50)
+        _lib.check(_lib.lib().ndbhip_synchronize())
+        why = []
+        tr = (lambda m: print(f"[rank {rank}] {m}", file=__import__("sys").stderr, flush=True)) \
+            if os.environ.get("NDBHIP_TEST_TRACE") else (lambda m: None)
+        tr("built")
+        try:                                                     # (no exception may keep this rank from the collectives below)
+            cent, ll, rows, tids = ix.export()
+            glen = np.diff(img.list_off)
+            if it != iters:
+                why.append(f"iterations {it} != {iters}")
+            if not np.array_equal(cent.view(np.uint32), img.centroids.view(np.uint32)):
+                why.append("centroids")
+            if not np.array_equal(ll, np.where(owned != 0, glen, 0)):
+                why.append("list lengths")
+            # the rows of the lists held here, list by list in heap order = the oracle image's rows of those lists
+            keep = np.concatenate([np.arange(img.list_off[L], img.list_off[L + 1]) for L in range(nlists) if owned[L]] +
+                                  [np.zeros(0, np.int64)]).astype(np.int64)
+            if not np.array_equal(rows.view(np.uint32), img.vecs[keep].view(np.uint32)):
+                why.append("rows")
+            if not np.array_equal(ndbo.tids_to_u64(tids), ndbo.tids_to_u64(img.tids[keep])):
+                why.append("tids")
+        except Exception as e:
+            why.append(f"{type(e).__name__}: {e}")
+        ok = not why
+        tr(f"checked: {why}")
+        # and the shard answers like one: sharded search over both ranks = the oracle on the whole image
+        nq, k, nprobe = 150, 10, 6
+        q = np.ascontiguousarray(base[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim)), dtype=np.float32)
+        dq = torch.from_numpy(q).to(dev)
+        ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+        od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+        tr("searching")
+        ix.search_sharded_device(dq, ot, od, oc, 1, nprobe, k, 0)
+        _lib.check(_lib.lib().ndbhip_synchronize())
+        tr("searched")
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+        ok &= bool(np.array_equal(oc.cpu().numpy(), ec))
+        ok &= bool(np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et))
+        ok &= bool(np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32)))
+        _lib.check(_lib.lib().ndbhip_comm_destroy())
+        ret[rank] = (bool(ok), int(owned.sum()), int(ix.nrows)) if ok else f"mismatch: {why}"
+    except Exception as e:
+        import sys
+        import traceback
+        ret[rank] = f"{type(e).__name__}: {e} {traceback.format_exc()[-600:]}"
+        print(f"[rank {rank}] {ret[rank]}", file=sys.stderr, flush=True)
+        raise                                                    # a dead rank ends mp.spawn instead of leaving its peer in a collective
+
+
+def test_c_abi_sharded_build_two_ranks_over_shared_memory():
+    """ndbhip_ivf_build_sharded: rank 0 holds the first rows (and the k-means sample), rank 1 the rest; the
+    centroids are the single-process build's, every list ends up whole on one rank in heap order, and a sharded
+    search over the two shards equals the oracle on the whole table."""
+    world, n, dim, nlists = 2, 9000, 64, 48
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    try:
+        mp.spawn(_worker_build, args=(world, f"/ndbhip_testb_{os.getpid()}", n, dim, nlists, ret), nprocs=world, join=True)
+    except Exception as e:
+        raise AssertionError(f"{e}; {dict(ret)}")
+    assert all(isinstance(ret.get(r), tuple) and ret[r][0] is True for r in range(world)), dict(ret)
+    assert ret[0][1] + ret[1][1] == nlists and ret[0][2] + ret[1][2] == n
+    assert min(ret[0][2], ret[1][2]) > n // 4                  # the deal balances rows, not lists
+
+
+def test_c_abi_alltoallv_and_sharded_build_over_a_world_1_rccl_communicator():
+    """ncclSend / ncclRecv to self inside a group, and the sharded build's whole path on a one-rank communicator
+    (it must give the single-process build)."""
+    import ctypes as C
+    from neurondb_amd import IvfIndex, _lib
+    from bench import pack_tids
+    _lib.ensure_init(0)
+    L = _lib.lib()
+    ident = (C.c_ubyte * 128)()
+    _lib.check(L.ndbhip_comm_unique_id(C.byref(ident)))
+    _lib.check(L.ndbhip_comm_init(C.byref(ident), 0, 1))
+    try:
+        dev = torch.device("cuda", 0)
+        src = torch.arange(5000, dtype=torch.int32, device=dev)
+        dst = torch.zeros(5000, dtype=torch.int32, device=dev)
+        off = (C.c_size_t * 2)(0, 20000)
+        _lib.check(L.ndbhip_comm_alltoallv(C.c_void_p(src.data_ptr()), off, C.c_void_p(dst.data_ptr()), off))
+        _lib.check(L.ndbhip_synchronize())
+        assert torch.equal(src, dst)
+        rng = np.random.default_rng(5)
+        base = rng.standard_normal((6000, 32)).astype(np.float32)
+        img, _, iters = ndbo.build_ivf_image(base, 20, max_iter=50)
+        ix = IvfIndex(32, 20)
+        it, owned = ix.build_sharded_device(torch.from_numpy(base).to(dev), pack_tids(torch.arange(6000, device=dev)), 50)
+        cent, ll, rows, tids = ix.export()
+        assert it == iters and owned.all()
+        assert np.array_equal(ll, np.diff(img.list_off)) and np.array_equal(rows.view(np.uint32), img.vecs.view(np.uint32))
+    finally:
+        _lib.check(L.ndbhip_comm_destroy())
