@@ -98,6 +98,8 @@ typedef struct ndbhip_stats
 	uint64_t	rows_emitted;		/* fp16 matrix-core screen: candidates the bound pass could not exclude */
 	uint64_t	screen16_batches;	/* sub-batches served by the fp16 matrix-core screen */
 	uint64_t	screen16_fallbacks;	/* ... that overflowed a query's record capacity and were rerun on the fp32 screen */
+	uint64_t	pairs_pruned;		/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep */
+	uint64_t	rows_swept;			/* candidate rows of the pairs the sweep did multiply (<= rows_scored) */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);
@@ -124,6 +126,7 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen"            1   auto mode screens batches of >= 128 queries (0 = never)
  *   "screen16"          1   ... on the fp16 matrix cores (0 = the fp32 bound pass)
  *   "screen16_records"  8192  candidates a query may emit before it is swept again / its batch falls back
+ *   "screen16_prune"    1     L2: a (query, list) pair whose |q - centroid| - list radius already exceeds the query's threshold is not swept
  *   "screen16_tighten"  1     a query's threshold is lowered inside the sweep every 256 emitted records (0: only between the two rounds)
  *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
  *   "screen16_debug"    0   timing experiments of the sweep (1 no DMA, 2 DMA of cache-hot lines: WRONG results)

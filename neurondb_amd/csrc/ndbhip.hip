@@ -270,6 +270,8 @@ ndbhip_stats_get(ndbhip_stats *out)
 		g.stats.bytes_scored = g.host_bytes + c[2];
 		g.stats.rows_rescored = c[3];
 		g.stats.rows_emitted = c[4];
+		g.stats.pairs_pruned = c[5];
+		g.stats.rows_swept = c[6];
 	}
 	*out = g.stats;
 	return NDBHIP_OK;
@@ -709,7 +711,8 @@ struct PairRec
 /* pass 1: how many (query, probe) pairs hit each owned list */
 __global__ void
 k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
-			 uint32_t *__restrict__ cnt, const unsigned int *__restrict__ active = nullptr)
+			 uint32_t *__restrict__ cnt, const unsigned int *__restrict__ active = nullptr,
+			 const uint8_t *__restrict__ drop = nullptr /* [nq][npr]: pairs a bound has already excluded */ )
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -718,7 +721,7 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 	const uint32_t q = i / npr, p = i % npr;
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);	/* rows held HERE for this (query, probe) */
 
-	if (co[p + 1] == co[p] || (active && !active[q]))
+	if (co[p + 1] == co[p] || (active && !active[q]) || (drop && drop[i]))
 		return;
 	atomicAdd(&cnt[probes[(size_t) q * npr + p]], 1u);
 }
@@ -814,7 +817,8 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 __global__ void
 k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
 			const uint32_t *__restrict__ pair_off,
-			uint32_t *__restrict__ fill, PairRec *__restrict__ pairs, const unsigned int *__restrict__ active = nullptr)
+			uint32_t *__restrict__ fill, PairRec *__restrict__ pairs, const unsigned int *__restrict__ active = nullptr,
+			const uint8_t *__restrict__ drop = nullptr)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -823,7 +827,7 @@ k_pair_fill(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	const uint32_t q = i / npr, p = i % npr;
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
 
-	if (co[p + 1] == co[p] || (active && !active[q]))
+	if (co[p + 1] == co[p] || (active && !active[q]) || (drop && drop[i]))
 		return;
 	const int	L = probes[(size_t) q * npr + p];
 	const uint32_t slot = pair_off[L] + atomicAdd(&fill[L], 1u);
@@ -1456,6 +1460,8 @@ struct ndbhip_ivf
 	float2	   *w_qthr = nullptr;	size_t w_qthr_n = 0;
 	unsigned int *w_ecount = nullptr; size_t w_ecount_n = 0;	/* [nq] emitted per query | [nq] survivors | [nq] seeds | 4 flags */
 	uint2	   *w_erec = nullptr;	size_t w_erec_n = 0;
+	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
+	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
 	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
 	/* split top-k of small batches: per-range records, counts, totals */
@@ -1549,7 +1555,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock,
 			ix->d_xxmax, ix->w_rnorm, ix->w_scrt, ix->w_scrd, ix->w_scrc, ix->w_screc,
 			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
-			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff};
+			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2313,6 +2319,7 @@ static int	g_build_s16 = 1;		/* ndbhip_set_option("build_screen16", 0): the buil
 static int	g_s16_waves = 4;
 static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
 static uint32_t g_s16_ecap = 8192;
+static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep ("screen16_prune") */
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
 
 static bool
@@ -2383,6 +2390,20 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			S16_PREP_L(1);
 		else
 			S16_PREP_L(2);
+		/* radius of every list around its centroid (largest |x - c| over the rows held here, rounded up; +inf for a
+		 * list with a row or centroid beyond fp32): lets a whole (query, list) pair be excluded by the triangle
+		 * inequality before any of its rows is scored (k_s16_pair_prune) */
+		if (grow(ix->d_lrad, ix->d_lrad_n, (size_t) nc)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(ix->d_lrad, 0, (size_t) nc * sizeof(uint32_t), g.stream));
+		if (!ix->f16)
+			hipLaunchKernelGGL(k_s16_list_radius<0>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim,
+							   (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
+		else if (ix->f16_sub)
+			hipLaunchKernelGGL(k_s16_list_radius<1>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim,
+							   (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
+		else
+			hipLaunchKernelGGL(k_s16_list_radius<2>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim,
+							   (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
 		HIP_TRY(hipGetLastError());
 		ix->s16_valid = true;
 	}
@@ -2464,12 +2485,26 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1);
 		}
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
+		const uint8_t *drop = nullptr;
+
+		if (R == R_IVF_L2 && g_s16_prune)
+		{
+			/* (query, list) pairs whose every row lies beyond the query's current threshold: |q - c| - radius */
+			if (grow(ix->w_drop, ix->w_drop_n, (size_t) npairs)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_s16_pair_prune, dim3(nq), dim3(256), 0, g.stream, d_q, (uint32_t) nq, npr, dim,
+							   w_probes, nc, (const float *) ix->d_centroids, (const uint32_t *) ix->d_lrad,
+							   (const float2 *) ix->w_qthr, act, ix->w_drop);
+			drop = ix->w_drop;
+		}
+		if (round == 0)
+			hipLaunchKernelGGL(k_s16_prune_stats, dim3((nq + 255) / 256), dim3(256), 0, g.stream, drop, lco, (uint32_t) nq, npr,
+							   g.d_counters + 5);
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
-						   (uint32_t) nq, cnt, act);
+						   (uint32_t) nq, cnt, act, drop);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, d.own_len, nc,
 						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (s16_rt / 64));
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
-						   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act);
+						   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
 		{
 			/* items <= (row tiles) x (query tiles of the fullest list); a query probes a list once — except list 0,
 			 * which the reference scans again for every probe slot beyond nlists (ivf_am.c:1978, palloc0) */
@@ -2620,6 +2655,8 @@ ndbhip_set_option(const char *name, int value)
 		if (!g.big_cache_on)
 			big_cache_flush();
 	}
+	else if (!strcmp(name, "screen16_prune"))
+		g_s16_prune = value != 0;
 	else if (!strcmp(name, "screen16_tighten"))
 		g_s16_tighten = value != 0;
 	else if (!strcmp(name, "screen16_waves"))

@@ -198,6 +198,169 @@ k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, 
 	}
 }
 
+/*
+ * Radius of every list around its centroid: lrad_bits[L] = bits of the largest |x - c_L| over the rows of L held
+ * here, in fp64, rounded to fp32 and up by 2^-20 (bits order like values for non-negative floats); +inf when a
+ * row or the centroid is not finite.  One wave per row.
+ */
+template <int H16>
+__global__ __launch_bounds__(256) void
+k_s16_list_radius(const void *__restrict__ vecs, int64_t nrows, int dim, const int64_t *__restrict__ loc_off, int ncent,
+				  const float *__restrict__ cents, uint32_t *__restrict__ lrad_bits)
+{
+	const int	lane = threadIdx.x & 63;
+	const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (row >= nrows)
+		return;
+	int			lo = 0, hi = ncent;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (loc_off[mid] <= row)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < ncent && loc_off[lo + 1] <= row)
+		lo++;
+	const float *c = cents + (size_t) lo * dim;
+	double		s = 0.0;
+
+	for (int i = lane; i < dim; i += 64)
+	{
+		float		v;
+
+		if constexpr (H16 != 0)
+		{
+			const uint16_t h = ((const uint16_t *) vecs)[(size_t) row * dim + i];
+
+			v = (H16 == 1) ? h2f_ref(h) : __half2float(__ushort_as_half(h));
+		}
+		else
+			v = ((const float *) vecs)[(size_t) row * dim + i];
+		const double d = (double) v - (double) c[i];
+
+		s += d * d;
+	}
+	s = wave_sum_f64(s);
+	if (lane == 0)
+	{
+		const double r = __builtin_sqrt(s) * (1.0 + 9.5367431640625e-7);
+		const uint32_t bits = (r <= 3.0e38) ? __float_as_uint(__double2float_ru(r)) : 0x7F800000u;	/* NaN fails the test: +inf */
+
+		if (bits > __atomic_load_n(&lrad_bits[lo], __ATOMIC_RELAXED))
+			atomicMax(&lrad_bits[lo], bits);
+	}
+}
+
+/*
+ * drop[q][p] = 1 when no row of the p-th probed list can be among query q's k nearest: every row x of list L
+ * satisfies |q - x| >= |q - c_L| - radius_L (triangle inequality, real numbers), so if that lower bound, squared,
+ * exceeds thrE = thr^2 (1 + m) + E (qthr[q].x, the value the sweep compares a candidate's bound with) the rows'
+ * real squared distances D do too, hence D > thr^2 (1 + m) and the reference's float4 distance exceeds thr
+ * (ndbhip_common.h (7)).  |q - c_L| is computed in fp64 (error ~1e-13 relative) and shaved by 1e-9; the radius is
+ * rounded up by k_s16_list_radius.
+ */
+__global__ __launch_bounds__(256) void
+k_s16_pair_prune(const float *__restrict__ queries, uint32_t nq, int npr, int dim, const int *__restrict__ probes, int ncent,
+				 const float *__restrict__ cents, const uint32_t *__restrict__ lrad_bits, const float2 *__restrict__ qthr,
+				 const unsigned int *__restrict__ active, uint8_t *__restrict__ drop)
+{
+	/* one block per query: wave w takes probes w, w + 4, ...; the query's elements stay in registers (dim <= 768:
+	 * 12 per lane) or are re-read from L1 */
+	const int	lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t q = blockIdx.x;
+
+	if (active && !active[q])
+		return;					/* (round 1 only rebuilds the pairs of the queries still active) */
+	const float *x = queries + (size_t) q * dim;
+	const double te = (double) qthr[q].x;
+	float		xr[12];
+	const bool	inreg = dim <= 768;
+
+	if (inreg)
+#pragma unroll
+		for (int j = 0; j < 12; j++)
+			xr[j] = lane + 64 * j < dim ? x[lane + 64 * j] : 0.0f;
+	for (int p = wave; p < npr; p += 4)
+	{
+		const int	L = probes[(size_t) q * npr + p];
+		bool		out = false;
+
+		if (L >= 0 && L < ncent)
+		{
+			const float *c = cents + (size_t) L * dim;
+			double		s = 0.0;
+
+			if (inreg)
+			{
+#pragma unroll
+				for (int j = 0; j < 12; j++)
+				{
+					const double t = (double) xr[j] - (double) (lane + 64 * j < dim ? c[lane + 64 * j] : 0.0f);
+
+					s += t * t;
+				}
+			}
+			else
+				for (int d = lane; d < dim; d += 64)
+				{
+					const double t = (double) x[d] - (double) c[d];
+
+					s += t * t;
+				}
+			s = wave_sum_f64(s);
+			const double rad = (double) __uint_as_float(lrad_bits[L]);
+			const double lb = __builtin_sqrt(s) * (1.0 - 1e-9) - rad;
+
+			out = lb > 0.0 && lb * lb * (1.0 - 1e-9) > te && te >= 0.0;		/* (NaN or inf anywhere: false) */
+		}
+		if (lane == 0)
+			drop[(size_t) q * npr + p] = out ? 1 : 0;
+	}
+}
+
+/* statistics of one batch: counters[0] += pairs dropped, counters[1] += candidate rows of the pairs kept
+ * (grid-stride; two atomics per block) */
+__global__ __launch_bounds__(256) void
+k_s16_prune_stats(const uint8_t *__restrict__ drop, const uint32_t *__restrict__ loc_cand_off, uint32_t nq, int npr,
+				  unsigned long long *__restrict__ counters)
+{
+	__shared__ unsigned long long sd[256], sr[256];
+	unsigned long long nd = 0, nr = 0;
+
+	for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256)
+	{
+		const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
+
+		for (int p = 0; p < npr; p++)
+			if (drop && drop[(size_t) q * npr + p])
+				nd++;
+			else
+				nr += co[p + 1] - co[p];
+	}
+	sd[threadIdx.x] = nd;
+	sr[threadIdx.x] = nr;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1)
+	{
+		if ((int) threadIdx.x < o)
+		{
+			sd[threadIdx.x] += sd[threadIdx.x + o];
+			sr[threadIdx.x] += sr[threadIdx.x + o];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+	{
+		atomicAdd(&counters[0], sd[0]);
+		atomicAdd(&counters[1], sr[0]);
+	}
+}
+
 /* One wave per query: the same split for the batch's queries; qn2 / qexp like rn2 / rexp.  A query whose norm is
  * not finite gets qn2 = NaN: every candidate of it is emitted and the batch falls back to the older path. */
 __global__ __launch_bounds__(256) void

@@ -174,3 +174,58 @@ def test_screen16_on_a_sharded_mirror_merges_to_the_unsharded_result(lib):
     assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
     assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
     full.close()
+
+
+def test_list_level_pruning_drops_pairs_and_changes_nothing(lib):
+    """screen16_prune: a (query, list) pair whose |q - centroid| - list radius already exceeds the query's threshold
+    is not swept.  Tight clusters far apart (most pairs go), a list holding one row (radius 0), a list whose rows
+    surround the query's own cluster at the same distance (radius as large as its centroid distance: must stay),
+    a NaN row (its list's radius is +inf: never pruned), a query sitting exactly on a centroid."""
+    rng = np.random.default_rng(77)
+    dim, nlists, per = 96, 24, 300
+    cents = (rng.standard_normal((nlists, dim)) * 5).astype(np.float32)    # (far apart, yet norms small enough for a tight bound)
+    rows, lens = [], []
+    for L in range(nlists):
+        n = 1 if L == 5 else (120 if L == 7 else per)     # (120 equidistant rows: fewer than the 256 survivors finalize holds)
+        r = cents[L] + 0.2 * rng.standard_normal((n, dim)).astype(np.float32)
+        if L == 7:                                  # a shell of radius 8 around centroid 7
+            u = rng.standard_normal((n, dim)).astype(np.float32)
+            r = (cents[L] + 8.0 * u / np.linalg.norm(u, axis=1, keepdims=True)).astype(np.float32)
+        rows.append(r.astype(np.float32))
+        lens.append(n)
+    rows = np.concatenate(rows)
+    rows[per * 9 + 3, 2] = np.nan                   # one row of one list is not finite
+    from oracle import ndbo
+    a = dict(centroids=cents, list_len=np.asarray(lens, np.int64), rows=rows, tids=ndbo.tids_from_rows(np.arange(len(rows))))
+    ix = _index(a)
+    img = oracle_image(a)
+    nq, k, nprobe = 200, 10, 12
+    src = rng.integers(0, nlists, nq)
+    q = (cents[src] + 0.2 * rng.standard_normal((nq, dim))).astype(np.float32)
+    q[0] = cents[3]                                 # exactly a centroid
+    q[1] = rows[per * 7 + 2]                        # a stored row (distance 0 to itself)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    got = {}
+    try:
+        for prune in (1, 0):
+            lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", prune))
+            lib.check(lib.lib().ndbhip_stats_reset())
+            got[prune] = ix.search(q, 1, nprobe, k) + (lib.stats(),)
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", 1))
+    # (a query that probes the list with the NaN row is outside the contract, include/ndbhip.h: the others must not notice it)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    victim = int(np.searchsorted(off, per * 9 + 3, side="right") - 1)
+    with np.errstate(all="ignore"):
+        probes = np.stack([img.select_clusters(qq, nprobe) for qq in q])
+        clean = ~(probes == victim).any(1)
+        assert clean.sum() >= 60
+        et, ed, ec, _ = oracle_search_batch(img, q[clean], 1, nprobe, k)
+    for prune in (1, 0):
+        t, d, c, st = got[prune]
+        assert_same_results(t[clean], d[clean], c[clean], et, ed, ec)
+        assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
+    assert got[0][3]["pairs_pruned"] == 0
+    assert got[1][3]["pairs_pruned"] > nq * nprobe // 2, got[1][3]           # most probed lists are far clusters
+    assert got[1][3]["rows_swept"] < got[0][3]["rows_swept"]
+    ix.close()
