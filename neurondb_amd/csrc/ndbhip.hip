@@ -1460,6 +1460,22 @@ struct ndbhip_ivf
 	float2	   *w_qthr = nullptr;	size_t w_qthr_n = 0;
 	unsigned int *w_ecount = nullptr; size_t w_ecount_n = 0;	/* [nq] emitted per query | [nq] survivors | [nq] seeds | 4 flags */
 	uint2	   *w_erec = nullptr;	size_t w_erec_n = 0;
+	/* sublists (ndbhip_screen16.h): the planes' own grouping of the rows of long lists */
+	bool		s16_sub = false;
+	int			s16_sub_cfg = -1;			/* sublist settings the planes were laid out under */
+	int			nsub = 0, nsub_g = 0;	/* sublists in all / centres of regrouped lists */
+	uint32_t   *d_sub_first = nullptr;	size_t d_sub_first_n = 0;	/* [ncent + 1] first sublist of every list */
+	uint32_t   *d_sub_len = nullptr;	size_t d_sub_len_n = 0;		/* [nsub] */
+	int64_t    *d_sub_loc = nullptr;	size_t d_sub_loc_n = 0;		/* [nsub + 1] first plane row */
+	uint32_t   *d_sub_blk = nullptr;	size_t d_sub_blk_n = 0;		/* [nsub + 1] first 32-row block */
+	uint32_t   *d_sub_rad = nullptr;	size_t d_sub_rad_n = 0;		/* [nsub] radius (float bits, rounded up) */
+	int		   *d_sub_gidx = nullptr;	size_t d_sub_gidx_n = 0;	/* [nsub] column of its centre in w_subdist, -1: the list's own centroid */
+	float	   *d_subcent = nullptr;	size_t d_subcent_n = 0;		/* [nsub_g][dim] */
+	float	   *d_subcblock = nullptr;	size_t d_subcblock_n = 0;	/* the same, interleaved 16 per block for the distance engine */
+	const float **d_sub_cptr = nullptr;	size_t d_sub_cptr_n = 0;	/* [nsub] centre of every sublist */
+	int64_t    *d_perm = nullptr;		size_t d_perm_n = 0;		/* [nrows] plane row -> mirror row */
+	uint32_t   *d_posof = nullptr;		size_t d_posof_n = 0;		/* [nrows] plane row -> index in its list */
+	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
@@ -1555,7 +1571,9 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_gcnt, ix->w_goff, ix->w_pairs, ix->w_qblock, ix->w_qnorm, ix->w_scand, ix->w_sncand, ix->w_stotal, ix->w_tmin, ix->w_cblock,
 			ix->d_xxmax, ix->w_rnorm, ix->w_scrt, ix->w_scrd, ix->w_scrc, ix->w_screc,
 			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
-			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop};
+			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
+			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
+			ix->d_subcblock, (void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2338,6 +2356,12 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 	return true;
 }
 
+static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host);	/* ndbhip_build.h */
+static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
+static int	g_s16_sublists = 1;	/* long lists regrouped into sublists ("screen16_sublists") */
+static int	g_s16_sub_min = 2048;	/* lists longer than this are regrouped ("screen16_sub_min") */
+static int	g_s16_sub_rows = 256;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
+
 /* Runs the sweep + finalize for one sub-batch whose probes / candidate offsets are already on the device.
  * Returns 0, a negative error, or 1 when some query overflowed (nothing usable was written: rerun on the older path). */
 static int
@@ -2352,25 +2376,44 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* records a query may leave: the option's value, less for batches whose record array would pass 1 GiB */
 	const uint32_t ecap = std::max<uint32_t>(std::min<uint32_t>(g_s16_ecap, (uint32_t) ((((size_t) 1 << 30) / 8) / (size_t) nq)), 64u);
 
+	const int	sub_cfg = g_s16_sublists ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
+
+	if (ix->s16_valid && ix->s16_sub_cfg != sub_cfg)
+		ix->s16_valid = false;	/* the planes were laid out under other sublist settings */
 	if (!ix->s16_valid)
 	{
-		/* every list starts a new 32-row block of the blocked planes */
-		std::vector<uint32_t> bo((size_t) nc + 1);
+		std::vector<uint32_t> bo;
 		uint64_t	nb = 0;
 
-		for (int c = 0; c < nc; c++)
+		ix->s16_sub = false;
+		ix->s16_sub_cfg = sub_cfg;
+		if (g_s16_sublists && !ix->f16 && (dim % 64) == 0)
 		{
-			bo[c] = (uint32_t) nb;
-			nb += (uint64_t) ((ix->own_len[c] + 31) / 32);
+			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
+			const int	rc = ivf_s16_build_sublists(ix, bo);
+
+			if (rc)
+				return rc;
 		}
-		bo[nc] = (uint32_t) nb;
-		if (nb + 8 > 0xFFFFFFFFull)
-			return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 row blocks");
+		if (!ix->s16_sub)
+		{
+			/* every list starts a new 32-row block of the blocked planes */
+			bo.assign((size_t) nc + 1, 0);
+			for (int c = 0; c < nc; c++)
+			{
+				bo[c] = (uint32_t) nb;
+				nb += (uint64_t) ((ix->own_len[c] + 31) / 32);
+			}
+			bo[nc] = (uint32_t) nb;
+			if (nb + 8 > 0xFFFFFFFFull)
+				return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 row blocks");
+			if (grow(ix->d_blkoff, ix->d_blkoff_n, (size_t) nc + 1)) return NDBHIP_ERR_HIP;
+			HIP_TRY(hipMemcpyAsync(ix->d_blkoff, bo.data(), ((size_t) nc + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));		/* bo is a local */
+		}
+		nb = bo.back();
 		const size_t blk_bytes = (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
 
-		if (grow(ix->d_blkoff, ix->d_blkoff_n, (size_t) nc + 1)) return NDBHIP_ERR_HIP;
-		HIP_TRY(hipMemcpyAsync(ix->d_blkoff, bo.data(), ((size_t) nc + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-		HIP_TRY(hipStreamSynchronize(g.stream));		/* bo is a local */
 		if (grow(ix->d_rn2, ix->d_rn2_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
 		if (grow(ix->d_rexp, ix->d_rexp_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
 		if (grow(ix->d_planes, ix->d_planes_n, (size_t) (nb + 8) * blk_bytes)) return NDBHIP_ERR_HIP;
@@ -2382,8 +2425,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 #define S16_PREP_L(HH)                                                                                          \
 		hipLaunchKernelGGL(k_s16_row_prep<HH>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp, \
-						   (const int64_t *) ix->d_loc_off, (const uint32_t *) ix->d_blkoff, nc, ix->d_planes, ix->d_rn2, \
-						   ix->d_rexp, ix->d_xmax16)
+						   ix->s16_sub ? (const int64_t *) ix->d_sub_loc : (const int64_t *) ix->d_loc_off,              \
+						   ix->s16_sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,            \
+						   ix->s16_sub ? ix->nsub : nc, ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16,               \
+						   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr)
 		if (!ix->f16)
 			S16_PREP_L(0);
 		else if (ix->f16_sub)
@@ -2439,13 +2484,38 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
 			  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr);
 
-	/* the (query, probe) pairs bucketed by list; items of 128 rows x 128 queries */
-	uint32_t   *cnt = ix->w_gcnt, *fill = ix->w_gcnt + nc;
-	unsigned int *next_item = ix->w_gcnt + 2 * nc;
-	uint32_t   *pair_off = ix->w_goff, *item_off = ix->w_goff + (nc + 1), *grp_off = ix->w_goff + 2 * (nc + 1);
-	uint32_t   *runs = ix->w_goff + 3 * (nc + 1) + 32;
+	/* the (query, probe) pairs bucketed by list — by sublist when the planes are regrouped (`ncs` buckets) —; items
+	 * of 128 rows x 128 queries */
+	const bool	sub = ix->s16_sub;
+	const int	ncs = sub ? ix->nsub : nc;
+	const int	ncmp0 = std::min(ix->nlists, ix->ncent);
+	const size_t dup0 = npr > ncmp0 ? (size_t) (npr - ncmp0 + 1) : 1;
+	/* a (query, probe) pair expands to at most the sublists of its list: per query, npr buckets plus the extra
+	 * sublists of the regrouped lists */
+	const size_t pairs_cap = (size_t) nq * ((size_t) npr * dup0 + (size_t) (ncs - nc));
+
+	if (sub)
+	{
+		if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ncs + 8 * NDB_QHEAD_STRIDE + 16)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ncs + 1) + 80)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_pairs, ix->w_pairs_n, pairs_cap)) return NDBHIP_ERR_HIP;
+	}
+	uint32_t   *cnt = ix->w_gcnt, *fill = ix->w_gcnt + ncs;
+	unsigned int *next_item = ix->w_gcnt + 2 * ncs;
+	uint32_t   *pair_off = ix->w_goff, *item_off = ix->w_goff + (ncs + 1), *grp_off = ix->w_goff + 2 * (ncs + 1);
+	uint32_t   *runs = ix->w_goff + 3 * (ncs + 1) + 32;
 	const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
 	ScanTimer	t;
+	/* the sweep sees the sublists as its lists */
+	IvfDev		ds = d;
+	uint32_t	sstride = 0;
+
+	if (sub)
+	{
+		ds.loc_off = ix->d_sub_loc;
+		ds.own_len = ix->d_sub_len;
+		ds.ncent = ncs;
+	}
 
 	/* tile geometry: 8 waves, 256 rows x 128 queries, ring of 3 chunk buffers, one block per CU (default), or
 	 * 4 waves, 128 x 128, ring of 2, two blocks per CU (ndbhip_set_option("screen16_waves", 4)) */
@@ -2484,7 +2554,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_L2>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1);
 		}
-		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * nc + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
 		const uint8_t *drop = nullptr;
 
 		if (R == R_IVF_L2 && g_s16_prune)
@@ -2498,34 +2568,63 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		}
 		if (round == 0)
 			hipLaunchKernelGGL(k_s16_prune_stats, dim3((nq + 255) / 256), dim3(256), 0, g.stream, drop, lco, (uint32_t) nq, npr,
-							   g.d_counters + 5);
-		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
-						   (uint32_t) nq, cnt, act, drop);
-		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, d.own_len, nc,
+							   g.d_counters + 5, sub ? 0 : 1);
+		if (sub)
+		{
+			/* distances of every query to the centres of the regrouped lists (once per batch), then the expansion */
+			if (round == 0 && drop && ix->nsub_g > 0)
+			{
+				const int	rc = ivf_s16_sub_distances(ix, d_q, nq, &sstride);
+
+				if (rc)
+					return rc;
+			}
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
+							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
+							   sstride, (const float2 *) ix->w_qthr, drop, act, cnt, (const uint32_t *) nullptr,
+							   (uint32_t *) nullptr, (PairRec *) nullptr);
+		}
+		else
+			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
+							   (uint32_t) nq, cnt, act, drop);
+		if (sub && round == 0)
+			hipLaunchKernelGGL(k_s16_swept_rows, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) cnt,
+							   (const uint32_t *) ix->d_sub_len, ncs, g.d_counters + 6);
+		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
 						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (s16_rt / 64));
-		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
-						   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
+		if (sub)
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
+							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
+							   sstride, (const float2 *) ix->w_qthr, drop, act, cnt, (const uint32_t *) pair_off, fill,
+							   ix->w_pairs);
+		else
+			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
+							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
 		{
 			/* items <= (row tiles) x (query tiles of the fullest list); a query probes a list once — except list 0,
 			 * which the reference scans again for every probe slot beyond nlists (ivf_am.c:1978, palloc0) */
 			const int	ncmp = std::min(ix->nlists, ix->ncent);
 			const size_t dup = npr > ncmp ? (size_t) (npr - ncmp + 1) : 1;
-			const size_t cap_items = ((size_t) ix->nrows / (size_t) s16_rt + (size_t) nc) *
+			const size_t cap_items = ((size_t) ix->nrows / (size_t) s16_rt + (size_t) ncs) *
 				(((size_t) nq * dup + S16_QT - 1) / S16_QT);
 
 			if (grow(ix->w_s16desc, ix->w_s16desc_n, cap_items * 4)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_s16_items, dim3((unsigned) ((cap_items + 255) / 256)), dim3(256), 0, g.stream,
-							   (const uint32_t *) item_off, (const uint32_t *) cnt, d.own_len, nc, (uint32_t) s16_rt,
+							   (const uint32_t *) item_off, (const uint32_t *) cnt, ds.own_len, ncs, (uint32_t) s16_rt,
 							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags);
 			desc_cap = (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu);
 		}
 		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
-		S16_BY_RH(S16_SWEEP_L, d, (const unsigned char *) ix->d_planes, (const uint32_t *) ix->d_blkoff,
+		S16_BY_RH(S16_SWEEP_L, ds, (const unsigned char *) ix->d_planes,
+				  sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,
 				  (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qplanes, qrowbytes,
 				  (const float *) ix->w_qn2, (const int *) ix->w_qexp, (float2 *) ix->w_qthr, lco, npr,
 				  (const uint32_t *) cnt, (const uint32_t *) pair_off, (const S16Desc *) ix->w_s16desc,
 				  (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ecount, ix->w_erec, ecap,
-				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u);
+				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,
+				  sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
 	}
 	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
@@ -2654,6 +2753,20 @@ ndbhip_set_option(const char *name, int value)
 		g.big_cache_on = value != 0;
 		if (!g.big_cache_on)
 			big_cache_flush();
+	}
+	else if (!strcmp(name, "screen16_sublists"))
+		g_s16_sublists = value != 0;
+	else if (!strcmp(name, "screen16_sub_min"))
+	{
+		if (value < 256)
+			return fail(NDBHIP_ERR_INVALID, "screen16_sub_min must be >= 256");
+		g_s16_sub_min = value;
+	}
+	else if (!strcmp(name, "screen16_sub_rows"))
+	{
+		if (value < 32 || value > 65536)
+			return fail(NDBHIP_ERR_INVALID, "screen16_sub_rows must be 32..65536");
+		g_s16_sub_rows = value;
 	}
 	else if (!strcmp(name, "screen16_prune"))
 		g_s16_prune = value != 0;

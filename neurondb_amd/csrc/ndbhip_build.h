@@ -1604,6 +1604,275 @@ ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_
 	return NDBHIP_OK;
 }
 
+/*
+ * Sublists of the matrix-core screen (ndbhip_screen16.h, "Sublists"): every list longer than screen16_sub_min rows
+ * is regrouped, inside the planes only, by the nearest of len / screen16_sub_rows of its own rows (taken at equal
+ * strides; no k-means: a sample row of every cluster the list mixes is enough, and the assignment is one screened
+ * pass).  Outputs the d_sub_* tables, the planes' order (d_perm, d_posof) and bo = first 32-row block of every
+ * sublist.  Leaves ix->s16_sub false when no list is long enough.
+ */
+/* radius of the sublists one list was just assigned to: rad_bits[sid[i]] = max |row i - cents[sid[i]]| (rounded up) */
+__global__ __launch_bounds__(256) void
+k_s16_assigned_radius(const float *__restrict__ rows, int64_t n, int dim, const float *__restrict__ cents,
+					  const int *__restrict__ sid, uint32_t *__restrict__ rad_bits)
+{
+	const int	lane = threadIdx.x & 63;
+	const int64_t i = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (i >= n)
+		return;
+	const int	sd = sid[i];
+	const float *x = rows + (size_t) i * dim, *c = cents + (size_t) sd * dim;
+	double		s = 0.0;
+
+	for (int d = lane; d < dim; d += 64)
+	{
+		const double t = (double) x[d] - (double) c[d];
+
+		s += t * t;
+	}
+	s = wave_sum_f64(s);
+	if (lane == 0)
+	{
+		const double r = __builtin_sqrt(s) * (1.0 + 9.5367431640625e-7);
+		const uint32_t bits = (r <= 3.0e38) ? __float_as_uint(__double2float_ru(r)) : 0x7F800000u;
+
+		if (bits > __atomic_load_n(&rad_bits[sd], __ATOMIC_RELAXED))
+			atomicMax(&rad_bits[sd], bits);
+	}
+}
+
+static int
+ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
+{
+	const int	nc = ix->ncent, dim = ix->dim;
+	std::vector<int> giant;
+
+	for (int c = 0; c < nc; c++)
+		if (ix->own_len[c] > (int64_t) g_s16_sub_min)
+			giant.push_back(c);
+	if (giant.empty() || ix->nrows < 1)
+		return 0;
+	/* the lists' own radii (around their centroids): what regrouping has to beat */
+	if (grow(ix->d_lrad, ix->d_lrad_n, (size_t) nc)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemsetAsync(ix->d_lrad, 0, (size_t) nc * sizeof(uint32_t), g.stream));
+	hipLaunchKernelGGL(k_s16_list_radius<0>, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const void *) ix->d_vecs,
+					   ix->nrows, dim, (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
+	std::vector<float> lrad((size_t) nc);
+
+	HIP_TRY(hipMemcpyAsync(lrad.data(), ix->d_lrad, (size_t) nc * 4, hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipStreamSynchronize(g.stream));
+
+	/* phase A: every long list assigned to sample rows of its own; kept only where that shrinks the radius */
+	DevGuard	tmp;
+	int64_t		maxlen = 0, sumlen = 0;
+	size_t		maxS = 0;
+	std::vector<uint32_t> nsub_of((size_t) nc, 1);
+
+	for (int c : giant)
+	{
+		nsub_of[(size_t) c] = (uint32_t) std::min<int64_t>(4096, (ix->own_len[c] + g_s16_sub_rows - 1) / g_s16_sub_rows);
+		maxlen = std::max<int64_t>(maxlen, ix->own_len[c]);
+		sumlen += ix->own_len[c];
+		maxS = std::max<size_t>(maxS, nsub_of[(size_t) c]);
+	}
+	int		   *d_sid = nullptr;
+	float	   *d_dummy = nullptr, *d_dummy2 = nullptr, *d_cents = nullptr;
+	uint64_t   *d_iota = nullptr, *d_sorted_all = nullptr;
+	int64_t    *d_which = nullptr;
+	uint32_t   *d_radtmp = nullptr;
+	size_t		ncent_all = 0;
+
+	for (int c : giant)
+		ncent_all += nsub_of[(size_t) c];
+	if (tmp.alloc(d_sid, (size_t) maxlen * sizeof(int))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_dummy, (size_t) maxlen * sizeof(float))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_dummy2, (size_t) maxlen * sizeof(float))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_iota, (size_t) maxlen * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_sorted_all, (size_t) sumlen * sizeof(uint64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_which, maxS * sizeof(int64_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_radtmp, maxS * sizeof(uint32_t))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_cents, ncent_all * (size_t) dim * sizeof(float))) return NDBHIP_ERR_HIP;
+	{
+		std::vector<uint64_t> iota((size_t) maxlen);
+
+		for (int64_t j = 0; j < maxlen; j++)
+			iota[(size_t) j] = (uint64_t) j;
+		HIP_TRY(hipMemcpyAsync(d_iota, iota.data(), (size_t) maxlen * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemsetAsync(d_dummy, 0, (size_t) maxlen * sizeof(float), g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+	}
+	struct Kept { int c; size_t cent0, sorted0; std::vector<int64_t> lens; };
+	std::vector<Kept> kept;
+	size_t		cbase = 0, sbase = 0;
+
+	for (int c : giant)
+	{
+		const int64_t len = ix->own_len[c], row0 = ix->loc_off[c];
+		const int	S = (int) nsub_of[(size_t) c];
+		const float *lrows = ix->d_vecs + (size_t) row0 * dim;
+		float	   *cents = d_cents + cbase * (size_t) dim;
+		std::vector<int64_t> which((size_t) S);
+		std::vector<uint32_t> rad((size_t) S);
+
+		for (int j = 0; j < S; j++)
+			which[(size_t) j] = (int64_t) (((__int128) len * j) / S);
+		HIP_TRY(hipMemcpyAsync(d_which, which.data(), (size_t) S * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+		hipLaunchKernelGGL(k_rows_gather, dim3(S), dim3(256), 0, g.stream, lrows, dim, (const int64_t *) d_which, cents);
+		HIP_TRY(hipStreamSynchronize(g.stream));		/* `which` is a local */
+		int			rc = g_build_s16 ? assign_rows_s16(lrows, len, dim, cents, S, d_sid, nullptr, nullptr) : 1;
+
+		if (rc == 1)
+			rc = assign_rows(lrows, len, dim, cents, S, true, d_sid, nullptr);
+		if (rc)
+			return rc;
+		HIP_TRY(hipMemsetAsync(d_radtmp, 0, (size_t) S * 4, g.stream));
+		hipLaunchKernelGGL(k_s16_assigned_radius, dim3((unsigned) ((len + 3) / 4)), dim3(256), 0, g.stream, lrows, len, dim,
+						   (const float *) cents, (const int *) d_sid, d_radtmp);
+		HIP_TRY(hipMemcpyAsync(rad.data(), d_radtmp, (size_t) S * 4, hipMemcpyDeviceToHost, g.stream));
+		/* the list's rows in sublist order: a stable pack of (dummy row, index in list) by sublist id */
+		Kept		kp;
+
+		kp.c = c;
+		kp.cent0 = cbase;
+		kp.sorted0 = sbase;
+		rc = pack_by_list(d_sid, len, 1, S, d_dummy, d_iota, d_dummy2, d_sorted_all + sbase, kp.lens);	/* (synchronises) */
+		if (rc)
+			return rc;
+		double		wr = 0.0;
+
+		for (int j = 0; j < S; j++)
+		{
+			float		r;
+
+			memcpy(&r, &rad[(size_t) j], 4);
+			wr += (double) kp.lens[(size_t) j] * (std::isfinite(r) ? (double) r : 3.0e38);
+		}
+		wr /= (double) len;
+		/* worth it when a sublist's rows sit well inside their list's ball: clustered rows do (a component's spread
+		 * against the distance between components), rows without structure do not (every pair is equally far) */
+		if (std::isfinite(lrad[(size_t) c]) && wr < 0.6 * (double) lrad[(size_t) c])
+		{
+			kept.push_back(std::move(kp));
+			cbase += (size_t) S;
+			sbase += (size_t) len;
+		}
+		else
+			nsub_of[(size_t) c] = 1;
+	}
+	if (g_debug_s16)
+		fprintf(stderr, "s16 sublists: %zu of %zu long lists are worth regrouping\n", kept.size(), giant.size());
+	if (kept.empty())
+		return 0;
+
+	/* phase B: the tables */
+	std::vector<uint32_t> first((size_t) nc + 1, 0);
+	size_t		nsub = 0;
+	const size_t nsub_g = cbase;
+
+	for (int c = 0; c < nc; c++)
+	{
+		first[(size_t) c] = (uint32_t) nsub;
+		nsub += nsub_of[(size_t) c];
+	}
+	first[(size_t) nc] = (uint32_t) nsub;
+	if (grow(ix->d_perm, ix->d_perm_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_posof, ix->d_posof_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_subcent, ix->d_subcent_n, nsub_g * (size_t) dim)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(ix->d_subcent, d_cents, nsub_g * (size_t) dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+	hipLaunchKernelGGL(k_s16_identity_perm, dim3((unsigned) ((ix->nrows + 255) / 256)), dim3(256), 0, g.stream, ix->nrows,
+					   (const int64_t *) ix->d_loc_off, nc, ix->d_perm, ix->d_posof);
+	std::vector<uint32_t> sub_len(nsub, 0);
+	std::vector<int> sub_gidx(nsub, -1);
+
+	for (const Kept &kp : kept)
+	{
+		const int64_t len = ix->own_len[kp.c], row0 = ix->loc_off[kp.c];
+
+		hipLaunchKernelGGL(k_s16_sub_perm, dim3((unsigned) ((len + 255) / 256)), dim3(256), 0, g.stream,
+						   (const uint64_t *) (d_sorted_all + kp.sorted0), len, row0, ix->d_perm, ix->d_posof);
+		for (size_t j = 0; j < kp.lens.size(); j++)
+		{
+			sub_len[first[(size_t) kp.c] + j] = (uint32_t) kp.lens[j];
+			sub_gidx[first[(size_t) kp.c] + j] = (int) (kp.cent0 + j);
+		}
+	}
+	for (int c = 0; c < nc; c++)
+		if (nsub_of[(size_t) c] == 1)
+			sub_len[first[(size_t) c]] = (uint32_t) ix->own_len[c];
+	/* offsets: sublists are consecutive in the planes, every one starts a new 32-row block */
+	std::vector<int64_t> sub_loc(nsub + 1, 0);
+	std::vector<const float *> cptr(nsub);
+	uint64_t	nb = 0;
+
+	bo.assign(nsub + 1, 0);
+	for (size_t s2 = 0; s2 < nsub; s2++)
+	{
+		sub_loc[s2 + 1] = sub_loc[s2] + (int64_t) sub_len[s2];
+		bo[s2] = (uint32_t) nb;
+		nb += (uint64_t) ((sub_len[s2] + 31) / 32);
+	}
+	bo[nsub] = (uint32_t) nb;
+	if (nb + 8 > 0xFFFFFFFFull)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 row blocks");
+	for (int c = 0; c < nc; c++)
+		for (uint32_t j = 0; j < nsub_of[(size_t) c]; j++)
+		{
+			const size_t s2 = first[(size_t) c] + j;
+
+			cptr[s2] = sub_gidx[s2] >= 0 ? ix->d_subcent + (size_t) sub_gidx[s2] * dim : ix->d_centroids + (size_t) c * dim;
+		}
+	if (grow(ix->d_sub_first, ix->d_sub_first_n, (size_t) nc + 1)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_sub_len, ix->d_sub_len_n, nsub)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_sub_loc, ix->d_sub_loc_n, nsub + 1)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_sub_blk, ix->d_sub_blk_n, nsub + 1)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_sub_rad, ix->d_sub_rad_n, nsub)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_sub_gidx, ix->d_sub_gidx_n, nsub)) return NDBHIP_ERR_HIP;
+	if (grow(ix->d_sub_cptr, ix->d_sub_cptr_n, nsub)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(ix->d_sub_first, first.data(), ((size_t) nc + 1) * 4, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_sub_len, sub_len.data(), nsub * 4, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_sub_loc, sub_loc.data(), (nsub + 1) * 8, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_sub_blk, bo.data(), (nsub + 1) * 4, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_sub_gidx, sub_gidx.data(), nsub * 4, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_sub_cptr, cptr.data(), nsub * sizeof(const float *), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(ix->d_sub_rad, 0, nsub * 4, g.stream));
+	hipLaunchKernelGGL(k_s16_sub_radius, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
+					   ix->nrows, dim, (const int64_t *) ix->d_sub_loc, (int) nsub, (const int64_t *) ix->d_perm,
+					   (const float *const *) ix->d_sub_cptr, ix->d_sub_rad);
+	/* the centres of the regrouped lists in the distance engine's layout (16 per block) */
+	const int	ngroups = (int) ((nsub_g + NDB_QG - 1) / NDB_QG);
+
+	if (grow(ix->d_subcblock, ix->d_subcblock_n, (size_t) ngroups * dim * NDB_QG)) return NDBHIP_ERR_HIP;
+	hipLaunchKernelGGL(k_interleave16, dim3((dim + 255) / 256, ngroups), dim3(256), 0, g.stream, (const float *) ix->d_subcent,
+					   (int) nsub_g, dim, ix->d_subcblock);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));			/* the host tables are locals */
+	ix->nsub = (int) nsub;
+	ix->nsub_g = (int) nsub_g;
+	ix->s16_sub = true;
+	if (g_debug_s16)
+		fprintf(stderr, "s16 sublists: %zu lists regrouped into %zu sublists (%zu in all), %llu row blocks\n", kept.size(), nsub_g,
+				nsub, (unsigned long long) nb);
+	return 0;
+}
+
+/* distances of every query of the batch to every centre of the regrouped lists: w_subdist[nq][*sstride], the
+ * reference's float4 L2 distance (the centroid scan's engine) */
+static int
+ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride)
+{
+	const int	ng = ix->nsub_g, ngroups = (ng + NDB_QG - 1) / NDB_QG;
+	const uint32_t st = (uint32_t) ((ng + 63) & ~63);
+
+	if (grow(ix->w_subdist, ix->w_subdist_n, (size_t) nq * st)) return NDBHIP_ERR_HIP;
+	const dim3	g1((unsigned) ((((size_t) (nq + 63) / 64 + 7) / 8) * 8 * (size_t) ngroups));
+
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), g1, dim3(64), 0, g.stream, d_q, (uint32_t) nq, ix->dim,
+					   (const float *) ix->d_subcblock, ng, (float *) nullptr, (int *) nullptr, ix->w_subdist, st);
+	*sstride = st;
+	return 0;
+}
+
 /* read the index image back (tests, bench cpu baseline, PostgreSQL page writer) */
 extern "C" int
 ndbhip_ivf_export(const ndbhip_ivf *cix, float *centroids, int64_t *list_len, float *rows, uint8_t *tids6)

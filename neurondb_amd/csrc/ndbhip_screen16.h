@@ -103,13 +103,15 @@ template <int H16>
 __global__ __launch_bounds__(256) void
 k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, const int64_t *__restrict__ loc_off,
 			   const uint32_t *__restrict__ blk_off, int ncent, unsigned char *__restrict__ planes,
-			   float *__restrict__ rn2, int16_t *__restrict__ rexp, uint32_t *__restrict__ xmax_bits)
+			   float *__restrict__ rn2, int16_t *__restrict__ rexp, uint32_t *__restrict__ xmax_bits,
+			   const int64_t *__restrict__ perm = nullptr /* plane row -> mirror row (sublists: rows regrouped inside a list) */ )
 {
 	const int	lane = threadIdx.x & 63;
-	const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int64_t prow = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);	/* place in the planes' order */
 
-	if (row >= nrows)
+	if (prow >= nrows)
 		return;
+	const int64_t row = perm ? perm[prow] : prow;						/* the row it holds */
 	double		s = 0.0;
 
 	if constexpr (H16 != 0)
@@ -137,9 +139,9 @@ k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, 
 
 	if (lane == 0)
 	{
-		rn2[row] = n2;
+		rn2[prow] = n2;
 		if (rexp)
-			rexp[row] = (int16_t) e;
+			rexp[prow] = (int16_t) e;
 		/* one address for every row of the index: only a row that would raise the maximum goes to the atomic unit
 		 * (a stale read is merely smaller; a million same-address atomics cost 10 ms) */
 		if (ok && __float_as_uint(n2) > __atomic_load_n(xmax_bits, __ATOMIC_RELAXED))
@@ -152,14 +154,14 @@ k_s16_row_prep(const void *__restrict__ vecs, int64_t nrows, int dim, int dimp, 
 	{
 		const int	mid = (lo + hi) >> 1;
 
-		if (loc_off[mid] <= row)
+		if (loc_off[mid] <= prow)
 			lo = mid;
 		else
 			hi = mid;
 	}
-	while (lo + 1 < ncent && loc_off[lo + 1] <= row)
+	while (lo + 1 < ncent && loc_off[lo + 1] <= prow)
 		lo++;
-	const uint32_t pos = (uint32_t) (row - loc_off[lo]);
+	const uint32_t pos = (uint32_t) (prow - loc_off[lo]);
 	const size_t blk = (size_t) blk_off[lo] + (pos >> 5);
 	const int	rr = (int) (pos & 31u);
 	const int	nchunk = dimp / 32;
@@ -327,7 +329,7 @@ k_s16_pair_prune(const float *__restrict__ queries, uint32_t nq, int npr, int di
  * (grid-stride; two atomics per block) */
 __global__ __launch_bounds__(256) void
 k_s16_prune_stats(const uint8_t *__restrict__ drop, const uint32_t *__restrict__ loc_cand_off, uint32_t nq, int npr,
-				  unsigned long long *__restrict__ counters)
+				  unsigned long long *__restrict__ counters, int count_rows)
 {
 	__shared__ unsigned long long sd[256], sr[256];
 	unsigned long long nd = 0, nr = 0;
@@ -357,7 +359,178 @@ k_s16_prune_stats(const uint8_t *__restrict__ drop, const uint32_t *__restrict__
 	if (threadIdx.x == 0)
 	{
 		atomicAdd(&counters[0], sd[0]);
-		atomicAdd(&counters[1], sr[0]);
+		if (count_rows)
+			atomicAdd(&counters[1], sr[0]);
+	}
+}
+
+/* sublists: rows the sweep multiplies = sum over sublists of (pairs kept) x (rows); one block */
+__global__ __launch_bounds__(256) void
+k_s16_swept_rows(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ sub_len, int nsub,
+				 unsigned long long *__restrict__ counter)
+{
+	__shared__ unsigned long long sr[256];
+	unsigned long long nr = 0;
+
+	for (int s2 = threadIdx.x; s2 < nsub; s2 += 256)
+		nr += (unsigned long long) cnt[s2] * sub_len[s2];
+	sr[threadIdx.x] = nr;
+	__syncthreads();
+	for (int o = 128; o > 0; o >>= 1)
+	{
+		if ((int) threadIdx.x < o)
+			sr[threadIdx.x] += sr[threadIdx.x + o];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		atomicAdd(counter, sr[0]);
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sublists.  A list of the reference's index can be huge and unrelated to any one query (its k-means runs on the
+ * table's first 10 000 rows: components without a sample pile up in a few lists every query probes).  The rows
+ * of such a list are regrouped INSIDE THE PLANES — which are this library's own copy — by their nearest of a few
+ * sample rows of the list ("sublists"), every sublist with a centre and a radius; a (query, probe) pair then
+ * expands only to the sublists the triangle inequality cannot exclude.  Positions, candidate caps and ties stay
+ * defined on the row's index in its list (pos_of), so nothing downstream changes.
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* list-major identity: plane row = mirror row */
+__global__ void
+k_s16_identity_perm(int64_t nrows, const int64_t *__restrict__ loc_off, int ncent, int64_t *__restrict__ perm,
+					uint32_t *__restrict__ pos_of)
+{
+	const int64_t row = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (row >= nrows)
+		return;
+	int			lo = 0, hi = ncent;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (loc_off[mid] <= row)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < ncent && loc_off[lo + 1] <= row)
+		lo++;
+	perm[row] = row;
+	pos_of[row] = (uint32_t) (row - loc_off[lo]);
+}
+
+/* a regrouped list: sorted[j] = index in the list of the row that comes j-th in the planes */
+__global__ void
+k_s16_sub_perm(const uint64_t *__restrict__ sorted, int64_t n, int64_t first_row, int64_t *__restrict__ perm,
+			   uint32_t *__restrict__ pos_of)
+{
+	const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (j >= n)
+		return;
+	perm[first_row + j] = first_row + (int64_t) sorted[j];
+	pos_of[first_row + j] = (uint32_t) sorted[j];
+}
+
+/* radius of every sublist around its centre (cptr[sub]): like k_s16_list_radius, over the planes' order */
+__global__ __launch_bounds__(256) void
+k_s16_sub_radius(const float *__restrict__ vecs, int64_t nrows, int dim, const int64_t *__restrict__ sub_loc, int nsub,
+				 const int64_t *__restrict__ perm, const float *const *__restrict__ cptr, uint32_t *__restrict__ rad_bits)
+{
+	const int	lane = threadIdx.x & 63;
+	const int64_t prow = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (prow >= nrows)
+		return;
+	int			lo = 0, hi = nsub;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (sub_loc[mid] <= prow)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < nsub && sub_loc[lo + 1] <= prow)
+		lo++;
+	const float *x = vecs + (size_t) perm[prow] * dim, *c = cptr[lo];
+	double		s = 0.0;
+
+	for (int i = lane; i < dim; i += 64)
+	{
+		const double d = (double) x[i] - (double) c[i];
+
+		s += d * d;
+	}
+	s = wave_sum_f64(s);
+	if (lane == 0)
+	{
+		const double r = __builtin_sqrt(s) * (1.0 + 9.5367431640625e-7);
+		const uint32_t bits = (r <= 3.0e38) ? __float_as_uint(__double2float_ru(r)) : 0x7F800000u;
+
+		if (bits > __atomic_load_n(&rad_bits[lo], __ATOMIC_RELAXED))
+			atomicMax(&rad_bits[lo], bits);
+	}
+}
+
+/* can sublist `s` be left out for a query whose squared threshold is te?  d = the reference's float4 L2 distance
+ * of the query to the sublist's centre (within (dim + 3) 2^-24 of the real one: shaved by 1e-3), rad = the
+ * sublist's radius, rounded up.  Same argument as k_s16_pair_prune. */
+__device__ __forceinline__ bool
+s16_sub_excluded(float d, uint32_t rad_bits, float te)
+{
+	const double lb = (double) d * (1.0 - 1e-3) - (double) __uint_as_float(rad_bits);
+
+	return lb > 0.0 && lb * lb * (1.0 - 1e-9) > (double) te && te >= 0.0f;	/* NaN / inf: false */
+}
+
+/* (query, probe) -> the sublists of the probed list that stay.  A list that is its own single sublist takes the
+ * list-level verdict (drop, from k_s16_pair_prune); a regrouped one tests every sublist against subdist
+ * [nq][sstride] (distances of every query to every centre of a regrouped list, column gidx).  FILL = 0: count. */
+template <int FILL>
+__global__ void
+k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
+			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
+			const uint32_t *__restrict__ sub_rad, const float *__restrict__ subdist, uint32_t sstride,
+			const float2 *__restrict__ qthr, const uint8_t *__restrict__ drop, const unsigned int *__restrict__ active,
+			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
+			PairRec *__restrict__ pairs)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i >= nq * (uint32_t) npr)
+		return;
+	const uint32_t q = i / npr, p = i % npr;
+	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
+
+	if (co[p + 1] == co[p] || (active && !active[q]))
+		return;
+	const int	L = probes[(size_t) q * npr + p];
+	const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
+	const float te = qthr[q].x;
+
+	for (uint32_t s = s0; s < s1; s++)
+	{
+		if (sub_len[s] == 0)
+			continue;
+		const int	gi = sub_gidx[s];
+
+		if (gi < 0 ? (drop && drop[i]) : (drop != nullptr && s16_sub_excluded(subdist[(size_t) q * sstride + gi], sub_rad[s], te)))
+			continue;
+		if (FILL)
+		{
+			PairRec		r;
+
+			r.q = q;
+			r.p = p;
+			pairs[pair_off[s] + atomicAdd(&fill[s], 1u)] = r;
+		}
+		else
+			atomicAdd(&cnt[s], 1u);
 	}
 }
 
@@ -679,7 +852,8 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 			const uint32_t *__restrict__ pair_off, const S16Desc *__restrict__ desc,
 			const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 			const uint32_t *__restrict__ runs, unsigned int *__restrict__ ecount, uint2 *__restrict__ erec,
-			uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk, uint32_t desc_cap, uint32_t topk)
+			uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk, uint32_t desc_cap, uint32_t topk,
+			const uint32_t *__restrict__ pos_of = nullptr /* plane row -> the row's index in its list (sublists) */ )
 {
 	typedef S16Geom<H16, NW> G;
 	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];	/* queries whose threshold is due for tightening */
@@ -1192,6 +1366,8 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 			const size_t grow = (size_t) ix.loc_off[L] + (rok ? ridx : len - 1);
 			const float x2 = rn2[grow];
 			const int	ex = H16 ? 14 : (int) rexp[grow];
+			/* the row's index in its list: what positions, candidate caps and ties are defined on */
+			const uint32_t porig = pos_of ? pos_of[grow] : ridx;
 
 #pragma unroll
 			for (int a = 0; a < 2; a++)
@@ -1201,7 +1377,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 					const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
 					const S16Q	qi = qinfo[cur][m];
 
-					if (ridx < qi.nrow)
+					if (rok && porig < qi.nrow)
 					{
 						const float dot = ldexpf(run[a][b][reg], qi.eq + ex - 28);
 						float		av;
@@ -1213,7 +1389,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 						if (DBG ? av == 1234.5f : !(av > qi.thrE))
 						{
 							const uint32_t slot = atomicAdd(&ecount[qi.qid], 1u);
-							const uint32_t pos = qi.la + ridx, ab = __float_as_uint(av);
+							const uint32_t pos = qi.la + porig, ab = __float_as_uint(av);
 
 							if (slot < ecap)
 								erec[(size_t) qi.qid * ecap + slot] = make_uint2(pos, ab);
