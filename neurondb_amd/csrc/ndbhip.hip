@@ -1476,6 +1476,7 @@ struct ndbhip_ivf
 	int64_t    *d_perm = nullptr;		size_t d_perm_n = 0;		/* [nrows] plane row -> mirror row */
 	uint32_t   *d_posof = nullptr;		size_t d_posof_n = 0;		/* [nrows] plane row -> index in its list */
 	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] */
+	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
@@ -1573,7 +1574,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
-			ix->d_subcblock, (void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist};
+			ix->d_subcblock, (void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2360,7 +2361,7 @@ static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
 static int	g_s16_sublists = 1;	/* long lists regrouped into sublists ("screen16_sublists") */
 static int	g_s16_sub_min = 2048;	/* lists longer than this are regrouped ("screen16_sub_min") */
-static int	g_s16_sub_rows = 256;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
+static int	g_s16_sub_rows = 128;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
 
 /* Runs the sweep + finalize for one sub-batch whose probes / candidate offsets are already on the device.
  * Returns 0, a negative error, or 1 when some query overflowed (nothing usable was written: rerun on the older path). */
@@ -2481,8 +2482,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		}                                                                                       \
 	} while (0)
 #define S16_SEED_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
-	S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
-			  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr);
+	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
+	const bool	seed_by_sublist = ix->s16_sub && R == R_IVF_L2 && g_s16_prune && ix->nsub_g > 0;
+
+	if (!seed_by_sublist)
+		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
+				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr);
 
 	/* the (query, probe) pairs bucketed by list — by sublist when the planes are regrouped (`ncs` buckets) —; items
 	 * of 128 rows x 128 queries */
@@ -2556,33 +2561,43 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		}
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
 		const uint8_t *drop = nullptr;
+		const float *pdist = nullptr;
 
 		if (R == R_IVF_L2 && g_s16_prune)
 		{
 			/* (query, list) pairs whose every row lies beyond the query's current threshold: |q - c| - radius */
 			if (grow(ix->w_drop, ix->w_drop_n, (size_t) npairs)) return NDBHIP_ERR_HIP;
+			if (sub && grow(ix->w_pdist, ix->w_pdist_n, (size_t) npairs)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_s16_pair_prune, dim3(nq), dim3(256), 0, g.stream, d_q, (uint32_t) nq, npr, dim,
 							   w_probes, nc, (const float *) ix->d_centroids, (const uint32_t *) ix->d_lrad,
-							   (const float2 *) ix->w_qthr, act, ix->w_drop);
+							   (const float2 *) ix->w_qthr, act, ix->w_drop, sub ? ix->w_pdist : (float *) nullptr);
 			drop = ix->w_drop;
+			pdist = sub ? ix->w_pdist : nullptr;
 		}
 		if (round == 0)
-			hipLaunchKernelGGL(k_s16_prune_stats, dim3((nq + 255) / 256), dim3(256), 0, g.stream, drop, lco, (uint32_t) nq, npr,
-							   g.d_counters + 5, sub ? 0 : 1);
+			hipLaunchKernelGGL(k_s16_prune_stats, dim3((nq + 255) / 256), dim3(256), 0, g.stream, sub ? (const uint8_t *) nullptr : drop,
+							   lco, (uint32_t) nq, npr, g.d_counters + 5, sub ? 0 : 1);
 		if (sub)
 		{
 			/* distances of every query to the centres of the regrouped lists (once per batch), then the expansion */
-			if (round == 0 && drop && ix->nsub_g > 0)
+			if (round == 0 && pdist && ix->nsub_g > 0)
 			{
 				const int	rc = ivf_s16_sub_distances(ix, d_q, nq, &sstride);
 
 				if (rc)
 					return rc;
+				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_L2>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
+								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
+								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
+								   (const float *) ix->w_subdist, sstride, pdist, (const float *) ix->w_qn2,
+								   (const uint32_t *) ix->d_xmax16, ix->w_qthr);
 			}
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
-							   sstride, (const float2 *) ix->w_qthr, drop, act, cnt, (const uint32_t *) nullptr,
+							   sstride, (const float2 *) ix->w_qthr, pdist, act, cnt, (const uint32_t *) nullptr,
 							   (uint32_t *) nullptr, (PairRec *) nullptr);
 		}
 		else
@@ -2597,7 +2612,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
-							   sstride, (const float2 *) ix->w_qthr, drop, act, cnt, (const uint32_t *) pair_off, fill,
+							   sstride, (const float2 *) ix->w_qthr, pdist, act, cnt, (const uint32_t *) pair_off, fill,
 							   ix->w_pairs);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -2615,6 +2630,16 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) item_off, (const uint32_t *) cnt, ds.own_len, ncs, (uint32_t) s16_rt,
 							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags);
 			desc_cap = (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu);
+		}
+		if (g_debug_s16 && round == 0)
+		{
+			uint32_t	np = 0, ni = 0;
+
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			HIP_TRY(hipMemcpy(&np, pair_off + ncs, 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(&ni, item_off + ncs, 4, hipMemcpyDeviceToHost));
+			fprintf(stderr, "s16 debug: %u (query, probe, %s) triples in %u items of %d x %d, %d buckets\n", np,
+					sub ? "sublist" : "list", ni, s16_rt, S16_QT, ncs);
 		}
 		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
 		S16_BY_RH(S16_SWEEP_L, ds, (const unsigned char *) ix->d_planes,

@@ -269,7 +269,8 @@ k_s16_list_radius(const void *__restrict__ vecs, int64_t nrows, int dim, const i
 __global__ __launch_bounds__(256) void
 k_s16_pair_prune(const float *__restrict__ queries, uint32_t nq, int npr, int dim, const int *__restrict__ probes, int ncent,
 				 const float *__restrict__ cents, const uint32_t *__restrict__ lrad_bits, const float2 *__restrict__ qthr,
-				 const unsigned int *__restrict__ active, uint8_t *__restrict__ drop)
+				 const unsigned int *__restrict__ active, uint8_t *__restrict__ drop,
+				 float *__restrict__ pdist = nullptr /* [nq][npr]: |q - c_L|, rounded down (sublists decide with it later) */ )
 {
 	/* one block per query: wave w takes probes w, w + 4, ...; the query's elements stay in registers (dim <= 768:
 	 * 12 per lane) or are re-read from L1 */
@@ -319,7 +320,11 @@ k_s16_pair_prune(const float *__restrict__ queries, uint32_t nq, int npr, int di
 			const double lb = __builtin_sqrt(s) * (1.0 - 1e-9) - rad;
 
 			out = lb > 0.0 && lb * lb * (1.0 - 1e-9) > te && te >= 0.0;		/* (NaN or inf anywhere: false) */
+			if (pdist && lane == 0)
+				pdist[(size_t) q * npr + p] = __double2float_rd(__builtin_sqrt(s) * (1.0 - 1e-9));
 		}
+		else if (pdist && lane == 0)
+			pdist[(size_t) q * npr + p] = 0.0f;		/* (no such list: never excluded) */
 		if (lane == 0)
 			drop[(size_t) q * npr + p] = out ? 1 : 0;
 	}
@@ -391,7 +396,8 @@ k_s16_swept_rows(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ 
  * table's first 10 000 rows: components without a sample pile up in a few lists every query probes).  The rows
  * of such a list are regrouped INSIDE THE PLANES — which are this library's own copy — by their nearest of a few
  * sample rows of the list ("sublists"), every sublist with a centre and a radius; a (query, probe) pair then
- * expands only to the sublists the triangle inequality cannot exclude.  Positions, candidate caps and ties stay
+ * expands only to the sublists the triangle inequality cannot exclude, and the query's first threshold comes from
+ * the rows of the sublist nearest to it (k_s16_seed_sub).  Positions, candidate caps and ties stay
  * defined on the row's index in its list (pos_of), so nothing downstream changes.
  * --------------------------------------------------------------------------------------------------------- */
 
@@ -488,15 +494,16 @@ s16_sub_excluded(float d, uint32_t rad_bits, float te)
 	return lb > 0.0 && lb * lb * (1.0 - 1e-9) > (double) te && te >= 0.0f;	/* NaN / inf: false */
 }
 
-/* (query, probe) -> the sublists of the probed list that stay.  A list that is its own single sublist takes the
- * list-level verdict (drop, from k_s16_pair_prune); a regrouped one tests every sublist against subdist
- * [nq][sstride] (distances of every query to every centre of a regrouped list, column gidx).  FILL = 0: count. */
+/* (query, probe) -> the sublists of the probed list that stay.  The distance of the query to the sublist's centre is
+ * pdist[q][p] for a list that is its own single sublist (its centroid; k_s16_pair_prune) and subdist[q][gidx] for
+ * the sublists of a regrouped one ([nq][sstride], every query against every such centre).  FILL = 0: count. */
 template <int FILL>
 __global__ void
 k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
 			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
 			const uint32_t *__restrict__ sub_rad, const float *__restrict__ subdist, uint32_t sstride,
-			const float2 *__restrict__ qthr, const uint8_t *__restrict__ drop, const unsigned int *__restrict__ active,
+			const float2 *__restrict__ qthr, const float *__restrict__ pdist /* NULL: nothing is excluded */,
+			const unsigned int *__restrict__ active,
 			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
 			PairRec *__restrict__ pairs)
 {
@@ -519,7 +526,7 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			continue;
 		const int	gi = sub_gidx[s];
 
-		if (gi < 0 ? (drop && drop[i]) : (drop != nullptr && s16_sub_excluded(subdist[(size_t) q * sstride + gi], sub_rad[s], te)))
+		if (pdist && s16_sub_excluded(gi < 0 ? pdist[i] : subdist[(size_t) q * sstride + gi], sub_rad[s], te))
 			continue;
 		if (FILL)
 		{
@@ -681,6 +688,127 @@ k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
 }
+
+/*
+ * The first threshold when the planes are regrouped (L2, float4 rows): k_s16_seed scores the query's first 64
+ * candidates, which belong to its nearest LIST — and say nothing about the query when that list is one of the
+ * long mixed ones.  Here the seeds are the first 64 rows of the SUBLIST whose centre is nearest to the query
+ * (among the sublists of its probed lists that hold at least k visible rows): the same exact arithmetic, the same
+ * rule (the k-th smallest of distinct candidates bounds the k-th distance); without such a sublist, k_s16_seed's
+ * own candidates.  One wave per query.
+ */
+template <int R>
+__global__ __launch_bounds__(64) void
+k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
+			   const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, const uint32_t *__restrict__ sub_first,
+			   const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len, const int64_t *__restrict__ sub_loc,
+			   const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of, const float *__restrict__ subdist,
+			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ qn2,
+			   const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr)
+{
+	const uint32_t q = blockIdx.x;
+	const int	lane = threadIdx.x;
+	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
+	const int	dim = ix.dim;
+	const float e = s16_e<R>(dim, qn2[q], __uint_as_float(*xmax_bits), false);
+	float		bd = __uint_as_float(0x7F800000u);
+	uint32_t	bs = 0xFFFFFFFFu, bp = 0;
+
+	for (int p = lane; p < npr; p += 64)
+	{
+		const uint32_t vis = lco[p + 1] - lco[p];
+		const int	L = probes[(size_t) q * npr + p];
+
+		if (vis < k || L < 0 || L >= ix.ncent)
+			continue;
+		for (uint32_t s = sub_first[L]; s < sub_first[L + 1]; s++)
+		{
+			if (sub_len[s] < k)
+				continue;
+			const int	gi = sub_gidx[s];
+			const float dd = gi < 0 ? pdist[(size_t) q * npr + p] : subdist[(size_t) q * sstride + gi];
+
+			if (dd < bd)
+			{
+				bd = dd;
+				bs = s;
+				bp = (uint32_t) p;
+			}
+		}
+	}
+	/* the wave's nearest (ties: the lower lane) */
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const float od = __shfl_xor(bd, off, 64);
+		const uint32_t os = (uint32_t) __shfl_xor((int) bs, off, 64), op = (uint32_t) __shfl_xor((int) bp, off, 64);
+		const bool	take = od < bd || (od == bd && os < bs);
+
+		if (take)
+		{
+			bd = od;
+			bs = os;
+			bp = op;
+		}
+	}
+	bool		ok = false;
+	float		v = 0.0f;
+
+	if (bs != 0xFFFFFFFFu)		/* uniform */
+	{
+		const uint32_t vis = lco[bp + 1] - lco[bp];
+		const uint32_t n = min(sub_len[bs], (uint32_t) S16_SEED);
+
+		if ((uint32_t) lane < n)
+		{
+			const int64_t prow = sub_loc[bs] + lane;
+
+			ok = pos_of[prow] < vis;			/* a candidate of this (query, probe) under the candidate cap */
+			if (ok)
+				v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + (size_t) perm[prow] * (size_t) dim, dim);
+		}
+	}
+	if (__ballot(ok) == 0 || (uint32_t) __popcll(__ballot(ok)) < k)
+	{
+		/* no sublist holds k visible rows (short lists, a tight candidate cap): k_s16_seed's rule, the query's
+		 * first 64 candidates */
+		const uint32_t n = min(lco[npr], (uint32_t) S16_SEED);
+
+		ok = (uint32_t) lane < n;
+		v = 0.0f;
+		if (ok)
+		{
+			const uint32_t p = find_probe(lco, npr, (uint32_t) lane);
+			const int	L = probes[(size_t) q * npr + p];
+			const size_t row = (size_t) ix.loc_off[L] + ((uint32_t) lane - lco[p]);
+
+			v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + row * (size_t) dim, dim);
+		}
+	}
+	const uint32_t key = ok ? ndb_key_from_bits(__float_as_uint(v)) : 0xFFFFFFFFu;
+	uint32_t	rank = 0;
+
+	for (int j = 0; j < S16_SEED; j++)
+	{
+		const uint32_t kj = (uint32_t) __shfl((int) key, j, 64);
+
+		rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+	}
+	const unsigned long long have = __ballot(ok);
+	const unsigned long long pick = __ballot(ok && rank == k - 1);
+	float		thrE = __uint_as_float(0x7F800000u);	/* +inf */
+
+	if ((uint32_t) __popcll(have) >= k && pick)
+	{
+		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
+
+		if (thr == thr)			/* a NaN distance bounds nothing */
+			thrE = s16_thr_from_ref<R>(thr, e, dim);
+	}
+	if (lane == 0)
+		qthr[q] = make_float2(thrE, e);
+}
+
 
 /* ------------------------------------------------------------------------------------------------------------
  * The sweep.  Work item = (list, RT-row tile, 128-query tile) from the same queues as the other grouped scans
