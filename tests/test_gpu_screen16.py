@@ -229,3 +229,113 @@ def test_list_level_pruning_drops_pairs_and_changes_nothing(lib):
     assert got[1][3]["pairs_pruned"] > nq * nprobe // 2, got[1][3]           # most probed lists are far clusters
     assert got[1][3]["rows_swept"] < got[0][3]["rows_swept"]
     ix.close()
+
+
+@pytest.mark.parametrize("strategy,cap,nprobe", [(1, 0, 6), (1, 40, 6), (3, 0, 4), (1, 0, 14)])
+def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, lib):
+    """screen16_sublists with the threshold lowered to 300 rows: lists that mix several tight clusters are regrouped
+    inside the planes (and a list of unstructured rows is not), (query, probe) pairs expand to sublists, seeds come
+    from the nearest sublist.  Results must be the oracle's with and without it: positions, the k*10 candidate cap
+    and ties are defined on the rows' places in their lists, which the regrouping must not disturb."""
+    rng = np.random.default_rng(31 + nprobe)
+    dim, nlists = 64, 14
+    comp = (rng.standard_normal((60, dim)) * 4).astype(np.float32)          # 60 tight clusters ...
+    rows, lens = [], []
+    for L in range(nlists):
+        if L == 3:
+            r = rng.standard_normal((900, dim)).astype(np.float32) * 4        # ... one list without structure
+        else:
+            mine = rng.choice(60, 1 + L % 5, replace=False)                   # ... mixed 1 to 5 per list, interleaved
+            n = 150 + 170 * len(mine)
+            r = (comp[mine[rng.integers(0, len(mine), n)]] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+            r[7] = r[3]                                                       # duplicates: ties by position
+            r[n - 1] = r[3]
+        rows.append(r)
+        lens.append(len(r))
+    rows = np.concatenate(rows)
+    cents = np.stack([rows[sum(lens[:L]):sum(lens[:L + 1])].mean(0) for L in range(nlists)]).astype(np.float32)
+    from oracle import ndbo
+    a = dict(centroids=cents, list_len=np.asarray(lens, np.int64), rows=rows, tids=ndbo.tids_from_rows(np.arange(len(rows))))
+    img = oracle_image(a)
+    nq, k = 180, 10
+    q = (rows[rng.integers(0, len(rows), nq)] + 0.02 * rng.standard_normal((nq, dim))).astype(np.float32)
+    et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    try:
+        for sublists in (1, 0):
+            lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", sublists))
+            lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 300))
+            ix = _index(a)
+            lib.check(lib.lib().ndbhip_stats_reset())
+            t, d, c = ix.search(q, strategy, nprobe, k, cap)
+            st = lib.stats()
+            assert_same_results(t, d, c, et, ed, ec)
+            assert st["screen16_batches"] + st["screen16_fallbacks"] == 1, st
+            if sublists and strategy == 1 and cap == 0:
+                assert st["rows_swept"] < st["rows_scored"] // 2, st          # most sublists of the probed lists are excluded
+            # the mirror changes: an append invalidates the planes, the next batch regroups again
+            ix.append(2, rows[5] + np.float32(0.001), ndbo.tids_from_rows(np.asarray([len(rows)]))[0])
+            t2, d2, c2 = ix.search(q[:140], strategy, nprobe, k, cap)
+            b = dict(a)
+            off = np.concatenate([[0], np.cumsum(lens)])
+            b["rows"] = np.insert(rows, off[3], rows[5] + np.float32(0.001), axis=0)
+            b["tids"] = np.insert(a["tids"], off[3], ndbo.tids_from_rows(np.asarray([len(rows)]))[0])
+            b["list_len"] = a["list_len"].copy()
+            b["list_len"][2] += 1
+            et2, ed2, ec2, _ = oracle_search_batch(oracle_image(b), q[:140], strategy, nprobe, k, cap)
+            assert_same_results(t2, d2, c2, et2, ed2, ec2)
+            ix.close()
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", 1))
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 2048))
+
+
+def test_sublists_on_slice_shards_merge_to_the_unsharded_result(lib):
+    import torch
+    from neurondb_amd.dist import ShardedSearchBuffers
+    rng = np.random.default_rng(91)
+    dim, nlists, world = 64, 6, 3
+    comp = (rng.standard_normal((30, dim)) * 4).astype(np.float32)
+    rows, lens = [], []
+    for L in range(nlists):
+        mine = rng.choice(30, 4, replace=False)
+        n = 1200
+        rows.append((comp[mine[rng.integers(0, 4, n)]] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32))
+        lens.append(n)
+    rows = np.concatenate(rows)
+    cents = np.stack([rows[1200 * L:1200 * (L + 1)].mean(0) for L in range(nlists)]).astype(np.float32)
+    from oracle import ndbo
+    from neurondb_amd.dist import partition_slices
+    a = dict(centroids=cents, list_len=np.asarray(lens, np.int64), rows=rows, tids=ndbo.tids_from_rows(np.arange(len(rows))))
+    img = oracle_image(a)
+    nq, k, nprobe = 150, 10, 4
+    q = (rows[rng.integers(0, len(rows), nq)] + 0.02 * rng.standard_normal((nq, dim))).astype(np.float32)
+    et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 300))
+    try:
+        full = _index(a)
+        lo, ln, tail = partition_slices(a["list_len"], world, None, split_frac=0.0, align=16)    # every list cut into 3 slices
+        shards = [full.shard_slices(lo[r], ln[r], tail[r]) for r in range(world)]
+        dq = torch.from_numpy(q).cuda()
+        bufs = [ShardedSearchBuffers(nq, k, world, "cuda") for _ in range(world)]
+        for r in range(world):
+            shards[r].search_partial_device(dq, bufs[r].cand, bufs[r].ncand, bufs[r].total, 1, nprobe, k)
+            lib.check(lib.lib().ndbhip_synchronize())
+            bufs[0].cand_all[r].copy_(bufs[r].cand)
+            bufs[0].ncand_all[r].copy_(bufs[r].ncand)
+        b0 = bufs[0]
+        ot = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+        od = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+        oc = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        lib.check(lib.lib().ndbhip_merge_topk_device(b0.cand_all.data_ptr(), b0.ncand_all.data_ptr(), b0.total.data_ptr(),
+                                                     world, nq, k, 3 * k, ot.data_ptr(), od.data_ptr(), oc.data_ptr()))
+        lib.check(lib.lib().ndbhip_synchronize())
+        assert np.array_equal(oc.cpu().numpy(), ec)
+        assert np.array_equal(ndbo.tids_from_device_u64(ot.cpu().numpy()), et)
+        assert np.array_equal(od.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+        for sh in shards:
+            sh.close()
+        full.close()
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 2048))
