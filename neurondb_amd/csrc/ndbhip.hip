@@ -2496,8 +2496,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const int	ncmp0 = std::min(ix->nlists, ix->ncent);
 	const size_t dup0 = npr > ncmp0 ? (size_t) (npr - ncmp0 + 1) : 1;
 	/* a (query, probe) pair expands to at most the sublists of its list: per query, npr buckets plus the extra
-	 * sublists of the regrouped lists */
-	const size_t pairs_cap = (size_t) nq * ((size_t) npr * dup0 + (size_t) (ncs - nc));
+	 * sublists of the regrouped lists — dup0 times over, because list 0 can be probed that often by one query
+	 * (ivf_am.c:1978: the probe slots beyond nlists all read list 0) */
+	const size_t pairs_cap = (size_t) nq * ((size_t) npr + dup0 * (size_t) (ncs - nc));
 
 	if (sub)
 	{

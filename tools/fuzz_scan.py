@@ -104,8 +104,20 @@ def one_case(rng, lib, IvfIndex, check):
     cap = int(rng.choice([0, 0, k * 10, 500]))
     strategy = int(rng.choice([1, 1, 1, 2, 3]))
     et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
+    # the matrix-core screen's own variants: lists regrouped into sublists from 256 rows up (so that these small
+    # tables have some), 32- to 256-row sublists, list-level exclusion and in-sweep tightening on or off
+    check(lib.ndbhip_set_option(b"screen16_sub_min", int(rng.choice([256, 256, 2048]))))
+    check(lib.ndbhip_set_option(b"screen16_sub_rows", int(rng.choice([32, 128, 256]))))
+    check(lib.ndbhip_set_option(b"screen16_sublists", int(rng.random() < 0.8)))
+    check(lib.ndbhip_set_option(b"screen16_prune", int(rng.random() < 0.8)))
+    check(lib.ndbhip_set_option(b"screen16_tighten", int(rng.random() < 0.8)))
+    if os.environ.get("FUZZ_TRACE"):
+        print("CASE", dict(dim=dim, n=n, nlists=nlists, nq=nq, kind=kind, k=k, nprobe=nprobe, cap=cap, strategy=strategy,
+                           lens=a["list_len"].tolist()), flush=True)
     for mode in (5, 3, 2, 1, 0):
         check(lib.ndbhip_set_scan_mode(mode))
+        if os.environ.get("FUZZ_TRACE"):
+            print(" mode", mode, flush=True)
         t, d, c = ix.search(q, strategy, nprobe, k, cap)
         try:
             assert_same_results(t, d, c, et, ed, ec)
@@ -134,7 +146,7 @@ def main():
         kd = one_case(rng, _lib.lib(), IvfIndex, _lib.check)
         kinds[kd] = kinds.get(kd, 0) + 1
         n += 1
-    print(f"fuzz_scan: {n} random cases x 4 scan modes identical to the oracle (seed {seed}): {kinds}")
+    print(f"fuzz_scan: {n} random cases x 5 scan modes identical to the oracle (seed {seed}): {kinds}")
 
 
 if __name__ == "__main__":
