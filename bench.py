@@ -387,15 +387,25 @@ def main():
                                  "pairs_swept_frac": round(pairs_exe / max(1.0, pairs), 4),
                                  "note": "matrix-core flops actually issued: 6 x dim per (row, query) pair of the lists "
                                          "the sweep multiplied (tile padding not counted; pairs_swept_frac of the "
-                                         "algorithmic pairs survive the list-level bound)"},
+                                         "algorithmic pairs survive the list- and sublist-level bounds)"},
+                    "hbm_traffic": (None if not tr or ms_per_launch <= 0 else
+                                    {"achieved": round(tr / (ms_per_launch * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": round(tr / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                     "note": "PMC bytes of one launch (traffic) over this run's launch time: with most "
+                                             "(query, sublist) pairs excluded before the sweep, what remains is reading "
+                                             "the touched row planes once per batch, so this is the roof that binds"}),
                     "rows_rescored_per_query": round(st.get("rows_rescored", 0) / max(1, nq * args.steps), 1),
                     "rows_emitted_per_query": round(st.get("rows_emitted", 0) / max(1, nq * args.steps), 1),
                     "note": ("bound pass of the screened scan on fp16 matrix cores: rows and queries are split into two fp16 "
                              "planes (x 2^(14-e) = hi + lo), a block multiplies 128 rows x 128 queries from LDS tiles filled "
                              "by LDS DMA, 3 v_mfma_f32_32x32x16_f16 per 16 dimensions; a candidate whose bound cannot "
                              "exclude it is emitted (no distance array), and the reference's sequential arithmetic decides "
-                             "among those: ids, ranks and float4 bits are the exact path's.  avg_launch_ms = the first "
-                             "(all-queries) sweep; the second sweep for the queries that overflowed is in ms_per_step"),
+                             "among those: ids, ranks and float4 bits are the exact path's.  Before the sweep, the rows of long "
+                             "lists are regrouped into sublists (inside the planes only) and a (query, probe) pair expands "
+                             "only to the sublists the triangle inequality cannot exclude, so `achieved` (the algorithmic "
+                             "flops of ALL scored pairs over the launch time) exceeds `executed` (what was issued).  "
+                             "avg_launch_ms = the first (all-queries) sweep; the second sweep for queries that overflowed "
+                             "their records is in ms_per_step"),
                     "hbm_algorithmic": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
                                         "note": "rows scored x row bytes per query (SURVEY 8d, no reuse across queries); "

@@ -2377,7 +2377,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* records a query may leave: the option's value, less for batches whose record array would pass 1 GiB */
 	const uint32_t ecap = std::max<uint32_t>(std::min<uint32_t>(g_s16_ecap, (uint32_t) ((((size_t) 1 << 30) / 8) / (size_t) nq)), 64u);
 
-	const int	sub_cfg = g_s16_sublists ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
+	/* sublists only pay where a bound can exclude them: L2 (an index has one operator class, hence one strategy;
+	 * a caller that alternates strategies on one mirror has its planes laid out again at every change) */
+	const int	sub_cfg = (g_s16_sublists && g_s16_prune && R == R_IVF_L2) ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
 
 	if (ix->s16_valid && ix->s16_sub_cfg != sub_cfg)
 		ix->s16_valid = false;	/* the planes were laid out under other sublist settings */
@@ -2388,7 +2390,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = sub_cfg;
-		if (g_s16_sublists && !ix->f16 && (dim % 64) == 0)
+		if (sub_cfg != 0 && !ix->f16 && (dim % 64) == 0)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
 			const int	rc = ivf_s16_build_sublists(ix, bo);
