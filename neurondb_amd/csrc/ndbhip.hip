@@ -1476,6 +1476,19 @@ struct ndbhip_ivf
 	int64_t    *d_perm = nullptr;		size_t d_perm_n = 0;		/* [nrows] plane row -> mirror row */
 	uint32_t   *d_posof = nullptr;		size_t d_posof_n = 0;		/* [nrows] plane row -> index in its list */
 	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] */
+	/* the centres of the regrouped lists as one list of the matrix-core sweep (its MODE 3 gives every query's
+	 * squared distance to every centre) */
+	unsigned char *d_cplanes = nullptr;	size_t d_cplanes_n = 0;
+	float	   *d_crn2 = nullptr;		size_t d_crn2_n = 0;
+	int16_t    *d_crexp = nullptr;		size_t d_crexp_n = 0;
+	uint32_t   *d_cxmax = nullptr;		size_t d_cxmax_n = 0;
+	int64_t    *d_dm_loc = nullptr;		size_t d_dm_loc_n = 0;		/* {0, nsub_g} */
+	uint32_t   *d_dm_meta = nullptr;	size_t d_dm_meta_n = 0;		/* the sweep's tables for (centres x dm_nq queries) */
+	PairRec    *d_dm_pairs = nullptr;	size_t d_dm_pairs_n = 0;
+	uint4	   *d_dm_desc = nullptr;	size_t d_dm_desc_n = 0;		/* S16Desc[] */
+	unsigned int *d_dm_heads = nullptr;	size_t d_dm_heads_n = 0;
+	unsigned char *d_dm_zero = nullptr;	size_t d_dm_zero_n = 0;
+	int			dm_nq = -1;				/* batch size the tables were built for */
 	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
@@ -1574,7 +1587,9 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
-			ix->d_subcblock, (void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist};
+			ix->d_subcblock, (void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
+			ix->d_cplanes, ix->d_crn2, ix->d_crexp, ix->d_cxmax, ix->d_dm_loc, ix->d_dm_meta, ix->d_dm_pairs, ix->d_dm_desc,
+			ix->d_dm_heads, ix->d_dm_zero};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2600,8 +2615,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
-							   sstride, (const float2 *) ix->w_qthr, pdist, act, cnt, (const uint32_t *) nullptr,
-							   (uint32_t *) nullptr, (PairRec *) nullptr);
+							   sstride, (const float2 *) ix->w_qthr, pdist, (const float *) ix->w_qn2, (const uint32_t *) ix->d_cxmax, dim,
+							   act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr, (PairRec *) nullptr);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -2615,8 +2630,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
-							   sstride, (const float2 *) ix->w_qthr, pdist, act, cnt, (const uint32_t *) pair_off, fill,
-							   ix->w_pairs);
+							   sstride, (const float2 *) ix->w_qthr, pdist, (const float *) ix->w_qn2, (const uint32_t *) ix->d_cxmax, dim,
+							   act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);

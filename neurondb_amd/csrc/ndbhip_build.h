@@ -1839,13 +1839,29 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 	hipLaunchKernelGGL(k_s16_sub_radius, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
 					   ix->nrows, dim, (const int64_t *) ix->d_sub_loc, (int) nsub, (const int64_t *) ix->d_perm,
 					   (const float *const *) ix->d_sub_cptr, ix->d_sub_rad);
-	/* the centres of the regrouped lists in the distance engine's layout (16 per block) */
-	const int	ngroups = (int) ((nsub_g + NDB_QG - 1) / NDB_QG);
+	/* the centres of the regrouped lists as one list of the matrix-core sweep: planes, norms, exponents */
+	{
+		const int	dimp = (dim + 63) & ~63;
+		const size_t cblk = (nsub_g + 31) / 32;
+		const int64_t hloc[2] = {0, (int64_t) nsub_g};
+		const uint32_t hblk[2] = {0, (uint32_t) cblk};
 
-	if (grow(ix->d_subcblock, ix->d_subcblock_n, (size_t) ngroups * dim * NDB_QG)) return NDBHIP_ERR_HIP;
-	hipLaunchKernelGGL(k_interleave16, dim3((dim + 255) / 256, ngroups), dim3(256), 0, g.stream, (const float *) ix->d_subcent,
-					   (int) nsub_g, dim, ix->d_subcblock);
-	HIP_TRY(hipGetLastError());
+		if (grow(ix->d_cplanes, ix->d_cplanes_n, (cblk + 8) * (size_t) (dimp / S16_CH) * 4096)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_crn2, ix->d_crn2_n, nsub_g)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_crexp, ix->d_crexp_n, nsub_g)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_cxmax, ix->d_cxmax_n, (size_t) 4)) return NDBHIP_ERR_HIP;		/* [0] max norm, [2..3] block offsets */
+		if (grow(ix->d_dm_loc, ix->d_dm_loc_n, (size_t) 2)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(ix->d_cplanes, 0, (cblk + 8) * (size_t) (dimp / S16_CH) * 4096, g.stream));
+		HIP_TRY(hipMemsetAsync(ix->d_cxmax, 0, 16, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_dm_loc, hloc, sizeof(hloc), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(ix->d_cxmax + 2, hblk, sizeof(hblk), hipMemcpyHostToDevice, g.stream));
+		hipLaunchKernelGGL(k_s16_row_prep<0>, dim3((unsigned) ((nsub_g + 3) / 4)), dim3(256), 0, g.stream, (const void *) ix->d_subcent,
+						   (int64_t) nsub_g, dim, dimp, (const int64_t *) ix->d_dm_loc, (const uint32_t *) (ix->d_cxmax + 2), 1,
+						   ix->d_cplanes, ix->d_crn2, ix->d_crexp, ix->d_cxmax, (const int64_t *) nullptr);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(g.stream));		/* hloc / hblk are locals */
+		ix->dm_nq = -1;
+	}
 	HIP_TRY(hipStreamSynchronize(g.stream));			/* the host tables are locals */
 	ix->nsub = (int) nsub;
 	ix->nsub_g = (int) nsub_g;
@@ -1856,19 +1872,55 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 	return 0;
 }
 
-/* distances of every query of the batch to every centre of the regrouped lists: w_subdist[nq][*sstride], the
- * reference's float4 L2 distance (the centroid scan's engine) */
+/* squared distances of every query of the batch to every centre of the regrouped lists, as the matrix-core sweep
+ * computes them (k_s16_sweep MODE 3 over the centres' planes; the queries' planes are the batch's): w_subdist
+ * [nq][*sstride], each within s16_e(dim, |q|^2, largest centre norm) of the real value.  The sweep's tables
+ * depend on the batch size only and are kept. */
 static int
 ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride)
 {
-	const int	ng = ix->nsub_g, ngroups = (ng + NDB_QG - 1) / NDB_QG;
+	const int	ng = ix->nsub_g, dim = ix->dim, dimp = (dim + 63) & ~63;
 	const uint32_t st = (uint32_t) ((ng + 63) & ~63);
+	const uint32_t nrt = (uint32_t) ((ng + 127) / 128), nqt = (uint32_t) ((nq + S16_QT - 1) / S16_QT), nitems = nrt * nqt;
+	const size_t mw = NDB_ASG_META(nq);
 
+	(void) d_q;
 	if (grow(ix->w_subdist, ix->w_subdist_n, (size_t) nq * st)) return NDBHIP_ERR_HIP;
-	const dim3	g1((unsigned) ((((size_t) (nq + 63) / 64 + 7) / 8) * 8 * (size_t) ngroups));
+	if (ix->dm_nq != nq)
+	{
+		if (grow(ix->d_dm_meta, ix->d_dm_meta_n, 2 * mw)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_dm_pairs, ix->d_dm_pairs_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_dm_desc, ix->d_dm_desc_n, (size_t) nitems)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_dm_heads, ix->d_dm_heads_n, (size_t) 8 * NDB_QHEAD_STRIDE)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_dm_zero, ix->d_dm_zero_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(ix->d_dm_zero, 0, (size_t) nq, g.stream));
+		/* the build's table kernel with the roles it has there: the "rows" are the centres, the "centroids" the queries */
+		hipLaunchKernelGGL(k_assign_tables, dim3(1), dim3(64), 0, g.stream, (const unsigned char *) ix->d_dm_zero, nq, (uint32_t) ng,
+						   (uint32_t) ng, ix->d_dm_pairs, ix->d_dm_meta, ix->d_dm_meta + mw);
+		hipLaunchKernelGGL(k_s16_items, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, (const uint32_t *) (ix->d_dm_meta + 6),
+						   (const uint32_t *) (ix->d_dm_meta + 3), (const uint32_t *) (ix->d_dm_meta + 2), 1, 128u, nitems,
+						   (S16Desc *) ix->d_dm_desc, ix->d_dm_heads + 8 * NDB_QHEAD_STRIDE - 1);
+		ix->dm_nq = nq;
+	}
+	HIP_TRY(hipMemsetAsync(ix->d_dm_heads, 0, (size_t) 8 * NDB_QHEAD_STRIDE * sizeof(unsigned int), g.stream));
+	const uint32_t *m32 = ix->d_dm_meta;
+	IvfDev		dv = {};
 
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign_grouped<true, 32>), g1, dim3(64), 0, g.stream, d_q, (uint32_t) nq, ix->dim,
-					   (const float *) ix->d_subcblock, ng, (float *) nullptr, (int *) nullptr, ix->w_subdist, st);
+	dv.vecs = ix->d_subcent;
+	dv.loc_off = ix->d_dm_loc;
+	dv.own_len = m32 + 2;
+	dv.glob_len = m32 + 2;
+	dv.dim = dim;
+	dv.ncent = 1;
+	dv.nlists = 1;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 3>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
+					   (const unsigned char *) ix->d_cplanes, m32, (const float *) ix->d_crn2, (const int16_t *) ix->d_crexp,
+					   (const unsigned char *) ix->w_qplanes, (uint32_t) dimp * 4u, (const float *) ix->w_qn2, (const int *) ix->w_qexp,
+					   (float2 *) ix->w_qthr, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) ix->d_dm_desc,
+					   (const PairRec *) ix->d_dm_pairs, ix->d_dm_heads, m32 + 8, (unsigned int *) nullptr,
+					   reinterpret_cast<uint2 *>(ix->w_subdist), st, (uint32_t *) nullptr, 0, dimp / S16_CH, nitems, 0u,
+					   (const uint32_t *) nullptr);
+	HIP_TRY(hipGetLastError());
 	*sstride = st;
 	return 0;
 }

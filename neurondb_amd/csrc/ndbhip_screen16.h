@@ -391,6 +391,8 @@ k_s16_swept_rows(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ 
 		atomicAdd(counter, sr[0]);
 }
 
+template <int R> __device__ __forceinline__ float s16_e(int dim, float q2, float x2max, bool sub);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Sublists.  A list of the reference's index can be huge and unrelated to any one query (its k-means runs on the
  * table's first 10 000 rows: components without a sample pile up in a few lists every query probes).  The rows
@@ -486,6 +488,16 @@ k_s16_sub_radius(const float *__restrict__ vecs, int64_t nrows, int dim, const i
 /* can sublist `s` be left out for a query whose squared threshold is te?  d = the reference's float4 L2 distance
  * of the query to the sublist's centre (within (dim + 3) 2^-24 of the real one: shaved by 1e-3), rad = the
  * sublist's radius, rounded up.  Same argument as k_s16_pair_prune. */
+/* the same with a = the matrix-core sweep's |q - c|^2 (k_s16_sweep MODE 3), |a - |q - c|^2| <= e */
+__device__ __forceinline__ bool
+s16_sub_excluded_a(float a, float e, uint32_t rad_bits, float te)
+{
+	const double alo = (double) a - (double) e * (1.0 + 1e-6);
+	const double lb = __builtin_sqrt(alo > 0.0 ? alo : 0.0) - (double) __uint_as_float(rad_bits);
+
+	return lb > 0.0 && lb * lb * (1.0 - 1e-9) > (double) te && te >= 0.0f;	/* NaN / inf: false */
+}
+
 __device__ __forceinline__ bool
 s16_sub_excluded(float d, uint32_t rad_bits, float te)
 {
@@ -495,14 +507,16 @@ s16_sub_excluded(float d, uint32_t rad_bits, float te)
 }
 
 /* (query, probe) -> the sublists of the probed list that stay.  The distance of the query to the sublist's centre is
- * pdist[q][p] for a list that is its own single sublist (its centroid; k_s16_pair_prune) and subdist[q][gidx] for
- * the sublists of a regrouped one ([nq][sstride], every query against every such centre).  FILL = 0: count. */
+ * pdist[q][p] for a list that is its own single sublist (its centroid; k_s16_pair_prune); for the sublists of a
+ * regrouped one, subdist[q][gidx] holds the SQUARED distance as the matrix-core sweep computes it (MODE 3, every
+ * query against every such centre, within the sweep's own error bound).  FILL = 0: count. */
 template <int FILL>
 __global__ void
 k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
 			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
 			const uint32_t *__restrict__ sub_rad, const float *__restrict__ subdist, uint32_t sstride,
 			const float2 *__restrict__ qthr, const float *__restrict__ pdist /* NULL: nothing is excluded */,
+			const float *__restrict__ qn2, const uint32_t *__restrict__ cxmax_bits, int dim,
 			const unsigned int *__restrict__ active,
 			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
 			PairRec *__restrict__ pairs)
@@ -519,6 +533,8 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	const int	L = probes[(size_t) q * npr + p];
 	const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
 	const float te = qthr[q].x;
+	/* error of the centre distances: the sweep's own bound with the largest centre norm in the rows' place */
+	const float ec = (pdist && s1 - s0 > 1) ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
 
 	for (uint32_t s = s0; s < s1; s++)
 	{
@@ -526,7 +542,8 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			continue;
 		const int	gi = sub_gidx[s];
 
-		if (pdist && s16_sub_excluded(gi < 0 ? pdist[i] : subdist[(size_t) q * sstride + gi], sub_rad[s], te))
+		if (pdist && (gi < 0 ? s16_sub_excluded(pdist[i], sub_rad[s], te)
+					  : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
 			continue;
 		if (FILL)
 		{
@@ -726,7 +743,8 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			if (sub_len[s] < k)
 				continue;
 			const int	gi = sub_gidx[s];
-			const float dd = gi < 0 ? pdist[(size_t) q * npr + p] : subdist[(size_t) q * sstride + gi];
+			const float pd = pdist[(size_t) q * npr + p];
+			const float dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
 
 			if (dd < bd)
 			{
@@ -1440,6 +1458,40 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 			if (tid < G::RT && t2 * G::RT + (uint32_t) tid < len)
 				atomicMin(&bmin[(size_t) ix.loc_off[L] + t2 * G::RT + tid], s_rowmin[tid]);
 			__syncthreads();		/* s_rowmin is reused by the next item */
+		}
+		else if constexpr (MODE == 3)
+		{
+			/* distance matrix (sublist centres as the rows of one list): a of every (query, row) pair, no test;
+			 * erec is a float array [query][ecap] */
+			float	   *out = reinterpret_cast<float *>(erec);
+
+#pragma unroll
+			for (int b = 0; b < 2; b++)
+			{
+				const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (2 * wr + b) + r32);
+
+				if (ridx >= len)
+					continue;
+				const size_t grow = (size_t) ix.loc_off[L] + ridx;
+				const float x2 = rn2[grow];
+				const int	ex = (int) rexp[grow];
+
+#pragma unroll
+				for (int a = 0; a < 2; a++)
+#pragma unroll
+					for (int reg = 0; reg < 16; reg++)
+					{
+						const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+						const S16Q	qi = qinfo[cur][m];
+
+						if (qi.nrow != 0)
+						{
+							const float dot = ldexpf(run[a][b][reg], qi.eq + ex - 28);
+
+							out[(size_t) qi.qid * ecap + ridx] = __builtin_fmaf(-2.0f, dot, qi.q2 + x2);
+						}
+					}
+			}
 		}
 		else if constexpr (MODE == 2)
 		{
