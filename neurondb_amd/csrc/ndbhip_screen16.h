@@ -20,6 +20,12 @@
  *                    reference's own sequential arithmetic (one lane per candidate), and replay the
  *                    reference's selection sort over them (block_sort_cut / block_replay_emit).
  *
+ * For L2, two cheaper bounds run first: k_s16_pair_prune drops a (query, probe) pair whose list lies
+ * wholly beyond the threshold (|q - centroid| - list radius), and on mirrors whose long lists were regrouped into
+ * sublists (ivf_s16_build_sublists: rows reordered inside the planes only, pos_of = their place in the list) the
+ * pair expands just to the sublists that survive the same test against the sublist centres (k_sub_pairs; the
+ * centre distances come from this sweep's MODE 3), and the seeds are the nearest sublist's rows (k_s16_seed_sub).
+ *
  * Every value the selection can pick or tie with is exact; everything else is provably larger, so the result
  * is the exact path's bit for bit.  If a query emits more than its record capacity (adversarial data: nearly
  * everything ties) the host reruns the batch through the older screened path, which has no capacity.
