@@ -2612,7 +2612,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								   (const float *) ix->w_subdist, sstride, pdist, (const float *) ix->w_qn2,
 								   (const uint32_t *) ix->d_xmax16, ix->w_qthr);
 			}
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
 							   sstride, (const float2 *) ix->w_qthr, pdist, (const float *) ix->w_qn2, (const uint32_t *) ix->d_cxmax, dim,
@@ -2627,7 +2627,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
 						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (s16_rt / 64));
 		if (sub)
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco,
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
 							   sstride, (const float2 *) ix->w_qthr, pdist, (const float *) ix->w_qn2, (const uint32_t *) ix->d_cxmax, dim,

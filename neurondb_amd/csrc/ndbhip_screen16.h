@@ -517,7 +517,7 @@ s16_sub_excluded(float d, uint32_t rad_bits, float te)
  * regrouped one, subdist[q][gidx] holds the SQUARED distance as the matrix-core sweep computes it (MODE 3, every
  * query against every such centre, within the sweep's own error bound).  FILL = 0: count. */
 template <int FILL>
-__global__ void
+__global__ __launch_bounds__(256) void
 k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
 			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
 			const uint32_t *__restrict__ sub_rad, const float *__restrict__ subdist, uint32_t sstride,
@@ -527,40 +527,45 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
 			PairRec *__restrict__ pairs)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	/* one wave per query; its probes one after the other, a list's sublists spread over the lanes */
+	const int	lane = threadIdx.x & 63;
+	const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
 
-	if (i >= nq * (uint32_t) npr)
+	if (q >= nq || (active && !active[q]))
 		return;
-	const uint32_t q = i / npr, p = i % npr;
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
-
-	if (co[p + 1] == co[p] || (active && !active[q]))
-		return;
-	const int	L = probes[(size_t) q * npr + p];
-	const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
 	const float te = qthr[q].x;
 	/* error of the centre distances: the sweep's own bound with the largest centre norm in the rows' place */
-	const float ec = (pdist && s1 - s0 > 1) ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
+	const float ec = pdist ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
 
-	for (uint32_t s = s0; s < s1; s++)
+	for (int p = 0; p < npr; p++)
 	{
-		if (sub_len[s] == 0)
+		if (co[p + 1] == co[p])
 			continue;
-		const int	gi = sub_gidx[s];
+		const int	L = probes[(size_t) q * npr + p];
+		const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
+		const float pd = pdist ? pdist[(size_t) q * npr + p] : 0.0f;
 
-		if (pdist && (gi < 0 ? s16_sub_excluded(pdist[i], sub_rad[s], te)
-					  : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
-			continue;
-		if (FILL)
+		for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
 		{
-			PairRec		r;
+			if (sub_len[s] == 0)
+				continue;
+			const int	gi = sub_gidx[s];
 
-			r.q = q;
-			r.p = p;
-			pairs[pair_off[s] + atomicAdd(&fill[s], 1u)] = r;
+			if (pdist && (gi < 0 ? s16_sub_excluded(pd, sub_rad[s], te)
+						  : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
+				continue;
+			if (FILL)
+			{
+				PairRec		r;
+
+				r.q = q;
+				r.p = (uint32_t) p;
+				pairs[pair_off[s] + atomicAdd(&fill[s], 1u)] = r;
+			}
+			else
+				atomicAdd(&cnt[s], 1u);
 		}
-		else
-			atomicAdd(&cnt[s], 1u);
 	}
 }
 
@@ -737,19 +742,23 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	float		bd = __uint_as_float(0x7F800000u);
 	uint32_t	bs = 0xFFFFFFFFu, bp = 0;
 
-	for (int p = lane; p < npr; p += 64)
+	/* probes one after the other (wave-uniform), a list's sublists spread over the lanes: coalesced reads, a
+	 * handful of iterations even for a list of 200 sublists */
+	for (int p = 0; p < npr; p++)
 	{
 		const uint32_t vis = lco[p + 1] - lco[p];
 		const int	L = probes[(size_t) q * npr + p];
 
 		if (vis < k || L < 0 || L >= ix.ncent)
 			continue;
-		for (uint32_t s = sub_first[L]; s < sub_first[L + 1]; s++)
+		const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
+		const float pd = pdist[(size_t) q * npr + p];
+
+		for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
 		{
 			if (sub_len[s] < k)
 				continue;
 			const int	gi = sub_gidx[s];
-			const float pd = pdist[(size_t) q * npr + p];
 			const float dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
 
 			if (dd < bd)
