@@ -2383,7 +2383,9 @@ static int	g_s16_sub_rows = 128;	/* ... into sublists of about this many rows ("
 static int
 ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, int npr, int k, const int *w_probes,
 			const uint32_t *lco, int partial, ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
-			uint64_t *d_otid, float *d_odist, int *d_ocnt)
+			uint64_t *d_otid, float *d_odist, int *d_ocnt,
+			const float *cdist /* the centroid scan's [nq][cstride] L2 distances, or NULL (probes chosen elsewhere) */,
+			uint32_t cstride)
 {
 	const int	dim = ix->dim, dimp = (dim + 63) & ~63;	/* two chunks per accumulator block */
 	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
@@ -2581,9 +2583,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		const uint8_t *drop = nullptr;
 		const float *pdist = nullptr;
 
-		if (R == R_IVF_L2 && g_s16_prune)
+		const bool	prune = R == R_IVF_L2 && g_s16_prune;
+
+		if (prune && !(sub && cdist))
 		{
-			/* (query, list) pairs whose every row lies beyond the query's current threshold: |q - c| - radius */
+			/* (query, list) pairs whose every row lies beyond the query's current threshold: |q - c| - radius
+			 * (with sublists and the centroid scan's distances at hand, k_sub_pairs applies the same test itself) */
 			if (grow(ix->w_drop, ix->w_drop_n, (size_t) npairs)) return NDBHIP_ERR_HIP;
 			if (sub && grow(ix->w_pdist, ix->w_pdist_n, (size_t) npairs)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_s16_pair_prune, dim3(nq), dim3(256), 0, g.stream, d_q, (uint32_t) nq, npr, dim,
@@ -2598,7 +2603,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (sub)
 		{
 			/* distances of every query to the centres of the regrouped lists (once per batch), then the expansion */
-			if (round == 0 && pdist && ix->nsub_g > 0)
+			if (round == 0 && prune && ix->nsub_g > 0)
 			{
 				const int	rc = ivf_s16_sub_distances(ix, d_q, nq, &sstride);
 
@@ -2609,14 +2614,15 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
 								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
-								   (const float *) ix->w_subdist, sstride, pdist, (const float *) ix->w_qn2,
+								   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
 								   (const uint32_t *) ix->d_xmax16, ix->w_qthr);
 			}
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
-							   sstride, (const float2 *) ix->w_qthr, pdist, (const float *) ix->w_qn2, (const uint32_t *) ix->d_cxmax, dim,
-							   act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr, (PairRec *) nullptr);
+							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
+							   (const uint32_t *) ix->d_cxmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
+							   (PairRec *) nullptr);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -2630,8 +2636,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
-							   sstride, (const float2 *) ix->w_qthr, pdist, (const float *) ix->w_qn2, (const uint32_t *) ix->d_cxmax, dim,
-							   act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs);
+							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
+							   (const uint32_t *) ix->d_cxmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
@@ -2969,7 +2975,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	if (allow_s16 && ivf_s16_wanted(ix, nq, R, k))
 	{
 		const int	rc = ivf_s16_run(ix, d, d_q, nq, R, npr, k, w_probes, lco, partial, d_cand, d_ncand, d_total,
-									 d_otid, d_odist, d_ocnt);
+									 d_otid, d_odist, d_ocnt, d_probes_in ? (const float *) nullptr : (const float *) ix->w_cdist,
+									 cstride);
 
 		if (rc <= 0)
 			return rc;

@@ -513,7 +513,8 @@ s16_sub_excluded(float d, uint32_t rad_bits, float te)
 }
 
 /* (query, probe) -> the sublists of the probed list that stay.  The distance of the query to the sublist's centre is
- * pdist[q][p] for a list that is its own single sublist (its centroid; k_s16_pair_prune); for the sublists of a
+ * the centroid scan's own value (cdist, the reference's float4 distance, shaved by 1e-3) or pdist[q][p]
+ * (k_s16_pair_prune, when the probes came from elsewhere) for a list that is its own single sublist; for the sublists of a
  * regrouped one, subdist[q][gidx] holds the SQUARED distance as the matrix-core sweep computes it (MODE 3, every
  * query against every such centre, within the sweep's own error bound).  FILL = 0: count. */
 template <int FILL>
@@ -521,8 +522,10 @@ __global__ __launch_bounds__(256) void
 k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
 			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
 			const uint32_t *__restrict__ sub_rad, const float *__restrict__ subdist, uint32_t sstride,
-			const float2 *__restrict__ qthr, const float *__restrict__ pdist /* NULL: nothing is excluded */,
-			const float *__restrict__ qn2, const uint32_t *__restrict__ cxmax_bits, int dim,
+			const float2 *__restrict__ qthr, int prune /* 0: nothing is excluded */,
+			const float *__restrict__ pdist /* |q - centroid| per (query, probe) ... */,
+			const float *__restrict__ cdist /* ... or, when the centroid scan ran here, its [nq][cstride] distances */,
+			uint32_t cstride, const float *__restrict__ qn2, const uint32_t *__restrict__ cxmax_bits, int dim,
 			const unsigned int *__restrict__ active,
 			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
 			PairRec *__restrict__ pairs)
@@ -536,7 +539,7 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
 	const float te = qthr[q].x;
 	/* error of the centre distances: the sweep's own bound with the largest centre norm in the rows' place */
-	const float ec = pdist ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
+	const float ec = prune ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
 
 	for (int p = 0; p < npr; p++)
 	{
@@ -544,7 +547,7 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			continue;
 		const int	L = probes[(size_t) q * npr + p];
 		const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
-		const float pd = pdist ? pdist[(size_t) q * npr + p] : 0.0f;
+		const float pd = !prune ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
 
 		for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
 		{
@@ -552,7 +555,7 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 				continue;
 			const int	gi = sub_gidx[s];
 
-			if (pdist && (gi < 0 ? s16_sub_excluded(pd, sub_rad[s], te)
+			if (prune && (gi < 0 ? s16_sub_excluded(pd, sub_rad[s], te)
 						  : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
 				continue;
 			if (FILL)
@@ -731,8 +734,8 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, const uint32_t *__restrict__ sub_first,
 			   const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len, const int64_t *__restrict__ sub_loc,
 			   const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of, const float *__restrict__ subdist,
-			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ qn2,
-			   const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr)
+			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ cdist, uint32_t cstride,
+			   const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr)
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x;
@@ -752,7 +755,7 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		if (vis < k || L < 0 || L >= ix.ncent)
 			continue;
 		const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
-		const float pd = pdist[(size_t) q * npr + p];
+		const float pd = cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p];
 
 		for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
 		{
