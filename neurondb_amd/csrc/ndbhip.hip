@@ -1471,11 +1471,10 @@ struct ndbhip_ivf
 	uint32_t   *d_sub_rad = nullptr;	size_t d_sub_rad_n = 0;		/* [nsub] radius (float bits, rounded up) */
 	int		   *d_sub_gidx = nullptr;	size_t d_sub_gidx_n = 0;	/* [nsub] column of its centre in w_subdist, -1: the list's own centroid */
 	float	   *d_subcent = nullptr;	size_t d_subcent_n = 0;		/* [nsub_g][dim] */
-	float	   *d_subcblock = nullptr;	size_t d_subcblock_n = 0;	/* the same, interleaved 16 per block for the distance engine */
 	const float **d_sub_cptr = nullptr;	size_t d_sub_cptr_n = 0;	/* [nsub] centre of every sublist */
 	int64_t    *d_perm = nullptr;		size_t d_perm_n = 0;		/* [nrows] plane row -> mirror row */
 	uint32_t   *d_posof = nullptr;		size_t d_posof_n = 0;		/* [nrows] plane row -> index in its list */
-	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] */
+	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] squared distances to the centres (sweep MODE 3) */
 	/* the centres of the regrouped lists as one list of the matrix-core sweep (its MODE 3 gives every query's
 	 * squared distance to every centre) */
 	unsigned char *d_cplanes = nullptr;	size_t d_cplanes_n = 0;
@@ -1587,7 +1586,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr,
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
-			ix->d_subcblock, (void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
+			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
 			ix->d_cplanes, ix->d_crn2, ix->d_crexp, ix->d_cxmax, ix->d_dm_loc, ix->d_dm_meta, ix->d_dm_pairs, ix->d_dm_desc,
 			ix->d_dm_heads, ix->d_dm_zero};
 
