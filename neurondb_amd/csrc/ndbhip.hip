@@ -2352,6 +2352,7 @@ static int	g_build_s16 = 1;		/* ndbhip_set_option("build_screen16", 0): the buil
 static int	g_s16_waves = 4;
 static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
 static uint32_t g_s16_ecap = 8192;
+static int	g_s16_fin_threads = 64;	/* threads of a k_s16_finalize block (one block per query; "screen16_fin_threads": 64 / 128 / 256) */
 static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep ("screen16_prune") */
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
 
@@ -2677,7 +2678,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	}
 	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
 
-#define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(256), fsmem, g.stream, __VA_ARGS__)
+#define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__)
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
 			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags);
@@ -2815,6 +2816,12 @@ ndbhip_set_option(const char *name, int value)
 		if (value < 32 || value > 65536)
 			return fail(NDBHIP_ERR_INVALID, "screen16_sub_rows must be 32..65536");
 		g_s16_sub_rows = value;
+	}
+	else if (!strcmp(name, "screen16_fin_threads"))
+	{
+		if (value != 64 && value != 128 && value != 256)
+			return fail(NDBHIP_ERR_INVALID, "screen16_fin_threads must be 64, 128 or 256");
+		g_s16_fin_threads = value;
 	}
 	else if (!strcmp(name, "screen16_prune"))
 		g_s16_prune = value != 0;

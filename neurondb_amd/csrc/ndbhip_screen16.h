@@ -1781,7 +1781,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	if (tid == 0)
 		s.sh[0] = 0;
 	__syncthreads();
-	for (uint32_t i = tid; i < nraw; i += 256)
+	for (uint32_t i = tid; i < nraw; i += blockDim.x)
 	{
 		const uint2 r = rec[i];
 
@@ -1809,7 +1809,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	if (tid == 0)
 		rec_counts[q] = ns;
 	/* the reference's arithmetic for every survivor: one lane per candidate */
-	for (uint32_t j = tid; j < ns; j += 256)
+	for (uint32_t j = tid; j < ns; j += blockDim.x)
 	{
 		const uint32_t i = s.e_pos[j];
 		const uint32_t p = find_probe(lco, npr, i);
