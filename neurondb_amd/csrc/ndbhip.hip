@@ -381,7 +381,7 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			   const uint32_t *__restrict__ glob_len, const uint32_t *__restrict__ own_lo,
 			   const uint32_t *__restrict__ own_len, uint64_t cap,
 			   int dim, int *__restrict__ probes, uint32_t *__restrict__ cand_off,
-			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters)
+			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters, int full_sort = 1)
 {
 	__shared__ uint32_t hist[256];
 	__shared__ uint32_t sh[16];
@@ -406,7 +406,7 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 		return v < FLT_MAX;
 	};
 
-	if (ncmp <= 2048)
+	if (ncmp <= 2048 && full_sort)
 	{
 		/* few centroids (the reference's build fits them on ONE page: <= 185 at dim 4): sort all of them by
 		 * (distance, index) in LDS — the nprobe-times "first strict minimum" selection (:1685-1714) is the
@@ -2352,6 +2352,7 @@ static int	g_build_s16 = 1;		/* ndbhip_set_option("build_screen16", 0): the buil
 static int	g_s16_waves = 4;
 static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
 static uint32_t g_s16_ecap = 8192;
+static int	g_probe_sel_radix = 0;	/* batches of >= 512 queries: radix select instead of the full LDS sort ("probe_select_radix") */
 static int	g_probe_sel_threads = 256;	/* threads of a k_probe_select block for batches of >= 512 queries ("probe_select_threads") */
 static int	g_s16_fin_threads = 64;	/* threads of a k_s16_finalize block (one block per query; "screen16_fin_threads": 64 / 128 / 256) */
 static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep ("screen16_prune") */
@@ -2818,6 +2819,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16_sub_rows must be 32..65536");
 		g_s16_sub_rows = value;
 	}
+	else if (!strcmp(name, "probe_select_radix"))
+		g_probe_sel_radix = value != 0;
 	else if (!strcmp(name, "probe_select_threads"))
 	{
 		if (value != 64 && value != 128 && value != 256)
@@ -2975,7 +2978,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(nq >= 512 ? g_probe_sel_threads : 256), 0, g.stream, (const float *) ix->w_cdist, cstride,
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
-						   w_probes, ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
+						   w_probes, ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr,
+						   (nq >= 512 && g_probe_sel_radix) ? 0 : 1);
 	}
 	HIP_TRY(hipGetLastError());
 	if (!full)
