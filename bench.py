@@ -6,10 +6,14 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (centroid scan -> probe select -> list scan -> top-k)
-over one batch of --batch synthetic queries, inputs resident in HBM.  N > 1: the inverted
-lists are sharded over the ranks (size-balanced), every rank scans its own lists for the
-whole batch, the per-rank candidate records are all-gathered over RCCL and merged (strong
-scaling: the index and the query stream are the same as at N = 1).
+over one batch of --batch synthetic queries, inputs resident in HBM.  N > 1 (--shard): a table
+that fits one device several times over is REPLICATED and every rank answers its own batches —
+queries are the independent units of this path, a step costs 1.8 ms and most of it is per-query
+work that list sharding cannot divide — so `value` = N batches per step, weak
+scaling, no data-path collective; the SHARDED path (lists cut over the ranks, every batch merged
+over the library's RCCL communicator: what a table too large for one device needs) then runs
+after the timed region and is checked against the oracle (`sharded_leg`).  --shard slices|lists
+makes the sharded path the timed one (strong scaling: same index and query stream as N = 1).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -58,8 +62,12 @@ def parse():
                     help="--rows f16: narrow with round-to-nearest-even, or with the reference's float4_to_fp16 "
                          "(truncating, subnormals flushed)")
     ap.add_argument("--strategy", choices=["l2", "cosine", "ip"], default="l2")
-    ap.add_argument("--shard", choices=["slices", "lists"], default="slices",
-                    help="N > 1: cut heavy lists into per-rank slices (default) or keep lists whole")
+    ap.add_argument("--shard", choices=["auto", "replicas", "slices", "lists"], default="auto",
+                    help="N > 1: replicas = every rank holds the whole index and answers its own batches (weak scaling, no "
+                         "data-path collective); slices / lists = the index is sharded (heavy lists cut into per-rank slices, "
+                         "or lists kept whole) and every batch is merged over RCCL (strong scaling); auto = replicas when "
+                         "four copies of the table fit half the device memory, else slices.  With replicas the sharded "
+                         "path is still run and checked after the timed region (`sharded_leg`)")
     ap.add_argument("--gauss-steps", type=int, default=3,
                     help="N=1, default workload: also run this many steps on i.i.d. N(0,1) data (0 = skip)")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
@@ -145,12 +153,19 @@ def main():
         init_library_comm(device=dev)
 
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
+    shard_mode = args.shard
+    if shard_mode == "auto":
+        fits = 4.0 * n * dim * 4 < 0.5 * torch.cuda.get_device_properties(dev).total_memory
+        shard_mode = "replicas" if fits else "slices"
+    sharded = use_dist and shard_mode in ("slices", "lists")       # the timed step is the RCCL-merged sharded search
+    replicas = use_dist and not sharded                              # the timed step is each rank's own batch on a full copy
 
     # ---------------- synthetic data (identical on every rank) ----------------
     base = make_data(n, dim, args.data, args.components, args.sigma, 0x5EED0001, 0x5EEDC0DE, dev)
     nq_total = nq * (args.steps + args.warmup)
+    # (replicas: every rank answers its own queries; rank 0's are the N = 1 run's)
     queries = make_data(max(nq_total, args.recall_queries), dim, args.data, args.components, args.sigma,
-                        0x5EED0002, 0x5EEDC0DE, dev)
+                        0x5EED0002 + (0x100000 * rank if replicas else 0), 0x5EEDC0DE, dev)
 
     # ---------------- index build: the product's build path, timed ----------------
     # sample first min(10000, 100*lists) rows + k-means (reference rule) + assign all rows + pack lists
@@ -226,26 +241,31 @@ def main():
     # Balanced by WORK: a list costs len x (queries probing it).  The probe counts come from a calibration batch
     # drawn like the queries but with its own seed (a deployment uses recent traffic); every rank computes the
     # same partition from the same inputs.  Lists too heavy for one rank are cut into slices.
-    shard_info = None
-    if use_dist:
+    def make_shard(src, mode):
+        """this rank's shard of `src` (a full mirror) and a description of the partition"""
         qcal = make_data(nq, dim, args.data, args.components, args.sigma, 0x5EED0007, 0x5EEDC0DE, dev)
         pcal = torch.zeros((nq, nprobe), dtype=torch.int32, device=dev)
-        ix_full.select_clusters_device(qcal, pcal, nprobe)
+        src.select_clusters_device(qcal, pcal, nprobe)
         check(lib().ndbhip_synchronize())
         pc = pcal.cpu().numpy()
         cnt = np.bincount(pc[pc >= 0].ravel(), minlength=len(list_len))[:len(list_len)]
         del qcal, pcal
-        if args.shard == "slices":
+        if mode == "slices":
             slo, sln, stl = partition_slices(list_len, world, cnt)
-            ix = ix_full.shard_slices(slo[rank], sln[rank], stl[rank])
+            sh = src.shard_slices(slo[rank], sln[rank], stl[rank])
             work = (sln * (cnt[None] + 1.0)).sum(1)
-            shard_info = {"by": "slices", "lists_cut": int(((sln > 0).sum(0) > 1).sum()),
-                          "max_work_share": round(float(work.max() / work.sum()), 4)}
+            info = {"by": "slices", "lists_cut": int(((sln > 0).sum(0) > 1).sum()),
+                    "max_work_share": round(float(work.max() / work.sum()), 4)}
         else:
             owner = partition_lists(list_len, world, cnt)
-            ix = ix_full.shard((owner == rank).astype(np.uint8))
+            sh = src.shard((owner == rank).astype(np.uint8))
             work = np.bincount(owner, weights=np.asarray(list_len) * (cnt + 1.0), minlength=world)
-            shard_info = {"by": "lists", "max_work_share": round(float(work.max() / work.sum()), 4)}
+            info = {"by": "lists", "max_work_share": round(float(work.max() / work.sum()), 4)}
+        return sh, info
+
+    shard_info = None
+    if sharded:
+        ix, shard_info = make_shard(ix_full, shard_mode)
         ix_full.close()
         ix_full = None
         torch.cuda.empty_cache()
@@ -257,7 +277,7 @@ def main():
     out_t, out_d, out_c = buf.out_tids, buf.out_dist, buf.out_count
 
     def step(qs):
-        if not use_dist:
+        if not sharded:
             ix.search_device(qs, out_t, out_d, out_c, strategy, nprobe, k, 0)
         elif args.dist_impl == "c":
             ix.search_sharded_device(qs, out_t, out_d, out_c, strategy, nprobe, k, 0)
@@ -286,7 +306,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    qps = nq * args.steps / elapsed
+    qps = nq * args.steps * (world if replicas else 1) / elapsed       # whole job: replicas answer `world` batches a step
 
     # ---------------- roofline of the dominant kernel ----------------
     grouped = (nq >= 5 and dim % 64 == 0)
@@ -414,8 +434,8 @@ def main():
     # ---------------- recall@10 vs exact float64 brute force ----------------
     recall = None
     cpu_baseline = None
-    if rank == 0 and world == 1 and args.rows == "f32" and args.strategy == "l2" and \
-            (args.recall_queries > 0 or args.cpu_seconds > 0):
+    if rank == 0 and not sharded and args.rows == "f32" and args.strategy == "l2" and \
+            (args.recall_queries > 0 or (args.cpu_seconds > 0 and world == 1)):
         rq = min(args.recall_queries, nq)
         qs = queries[args.warmup * nq: args.warmup * nq + nq]
         step(qs)
@@ -438,17 +458,51 @@ def main():
         recall = float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(rq)])) if rq > 0 else None
 
         # ---------------- CPU baseline: the oracle on the host cores (bounded sample) ----------------
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:
             cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_h, tids_h, qs, out_t, out_d, out_c)
 
     dist_parity = None
-    if use_dist and args.dist_parity_queries > 0 and args.rows == "f32" and args.strategy == "l2":
+    if sharded and args.dist_parity_queries > 0 and args.rows == "f32" and args.strategy == "l2":
         # every rank runs the step (collectives); rank 0 replays a sample on the CPU oracle
         qs = queries[args.warmup * nq: args.warmup * nq + nq]
         step(qs)
         barrier()
         if rank == 0:
             dist_parity = run_dist_parity(args, full_image, qs, out_t, out_d, out_c)
+
+    # ---------------- replicas: the sharded path all the same, after the timed region ----------------
+    # One index sharded over the ranks (heavy lists cut into slices), every batch merged over the library's RCCL
+    # communicator: what a table too large for one device needs (BASELINE configs 4 and 5).  Same queries on every
+    # rank; rank 0 replays a sample on the CPU oracle.
+    sharded_leg = None
+    if replicas and args.dist_impl == "c":
+        try:
+            sh, sh_info = make_shard(ix, "slices")
+            qsh = make_data(nq * 6, dim, args.data, args.components, args.sigma, 0x5EED0008, 0x5EEDC0DE, dev)
+            sh.search_sharded_device(qsh[:nq], out_t, out_d, out_c, strategy, nprobe, k, 0)        # warm-up
+            barrier()
+            t0 = time.perf_counter()
+            for sidx in range(1, 6):
+                sh.search_sharded_device(qsh[sidx * nq:(sidx + 1) * nq], out_t, out_d, out_c, strategy, nprobe, k, 0)
+            barrier()
+            tsh = time.perf_counter() - t0
+            tt = torch.tensor([tsh], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tsh = float(tt.item())
+            par = None
+            if args.dist_parity_queries > 0 and args.rows == "f32" and args.strategy == "l2":
+                sh.search_sharded_device(qsh[:nq], out_t, out_d, out_c, strategy, nprobe, k, 0)
+                barrier()
+                if rank == 0:
+                    par = run_dist_parity(args, full_image, qsh[:nq], out_t, out_d, out_c)
+            sh.close()
+            sharded_leg = {"what": "the same index cut into list slices over the ranks, every 4096-query batch answered by "
+                                   "ndbhip_ivf_search_sharded (query-split selection, two RCCL all-gathers, replay merge): "
+                                   "strong scaling of one batch stream",
+                           "queries_per_s": round(nq * 5 / tsh, 1), "ms_per_step": round(tsh / 5 * 1e3, 3),
+                           "shard": sh_info, "dist_parity_on_sample": par}
+        except Exception as e:
+            sharded_leg = {"error": f"{type(e).__name__}: {e}"}
 
     gauss = balanced = None
     if rank == 0 and world == 1 and args.gauss_steps > 0 and args.data == "clustered" and args.rows == "f32" and \
@@ -480,15 +534,18 @@ def main():
                       f"(IVFFlat lists={nlists} probes={nprobe} k={k} {args.strategy.upper()})",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (replicas or world == 1) else "strong", "vs_baseline": None,
             "dtype": "f32" if esz == 4 else "f32 arithmetic on fp16 rows",
             "data": "synthetic (in-repo counter-based generator csrc/ndbhip_gen.h: ndbhip_gen_rows_device, seeds 0x5EED0001 "
                     "base / 0x5EED0002 queries / 0x5EEDC0DE centers; ndbhip_gen_rows_host regenerates the same bits)",
             "config": {"workload": f"IVFFlat {n}x{dim} {'fp32' if esz == 4 else 'fp16'} lists={nlists} probes={nprobe} "
                                    f"k={k} {args.strategy.upper()}, "
                                    f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
-                       "sharding": "none" if world == 1 else
-                                   f"{'list slices' if args.shard == 'slices' else 'whole lists'} over {world} ranks, "
+                       "sharding": "none" if not use_dist else
+                                   (f"replicas: each of the {world} ranks holds the whole index and answers its own "
+                                    f"{nq}-query batches (value = {world} batches per step; no data-path collective); the "
+                                    f"sharded path runs after the timed region: sharded_leg") if replicas else
+                                   f"{'list slices' if shard_mode == 'slices' else 'whole lists'} over {world} ranks, "
                                    f"balanced by calibration-batch work; RCCL all-gather of probes and records + merge "
                                    f"({'inside the C library: ndbhip_ivf_search_sharded' if args.dist_impl == 'c' else 'torch.distributed calls'})",
                        "shard": shard_info,
@@ -507,6 +564,7 @@ def main():
             "library_stats": {k2: (round(v2, 3) if isinstance(v2, float) else int(v2)) for k2, v2 in st.items()},
             "cpu_baseline": cpu_baseline,
             "dist_parity_on_sample": dist_parity,
+            "sharded_leg": sharded_leg,
             "iid_gauss": gauss,
             "balanced_index": balanced,
             "hnsw": hnsw,
