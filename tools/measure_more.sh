@@ -26,4 +26,4 @@ for cfg in "1 1 400" "16 1 400" "16 16 2000" "32 32 2000"; do set -- $cfg
   timeout 300 python3 tools/service_bench.py --backends $1 --inflight $2 --queries $3 --n 1000000 --dim 768 --nlists 1024 --nprobe 32 >> $sb 2>/dev/null </dev/null
 done; cut -c1-200 $sb
 timeout 300 python3 tools/small_batch_probe.py > gpurun_out/${tag}_small_batch.txt 2>/dev/null </dev/null; tail -12 gpurun_out/${tag}_small_batch.txt
-timeout 600 python3 tools/fuzz_scan.py 240 7 > gpurun_out/${tag}_fuzz_scan.txt 2>&1 </dev/null; tail -3 gpurun_out/${tag}_fuzz_scan.txt
+if [ "${NOFUZZ:-0}" != "1" ]; then timeout 600 python3 tools/fuzz_scan.py 240 7 > gpurun_out/${tag}_fuzz_scan.txt 2>&1 </dev/null; tail -3 gpurun_out/${tag}_fuzz_scan.txt; fi
