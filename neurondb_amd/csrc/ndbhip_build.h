@@ -1604,13 +1604,6 @@ ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_
 	return NDBHIP_OK;
 }
 
-/*
- * Sublists of the matrix-core screen (ndbhip_screen16.h, "Sublists"): every list longer than screen16_sub_min rows
- * is regrouped, inside the planes only, by the nearest of len / screen16_sub_rows of its own rows (taken at equal
- * strides; no k-means: a sample row of every cluster the list mixes is enough, and the assignment is one screened
- * pass).  Outputs the d_sub_* tables, the planes' order (d_perm, d_posof) and bo = first 32-row block of every
- * sublist.  Leaves ix->s16_sub false when no list is long enough.
- */
 /* radius of the sublists one list was just assigned to: rad_bits[sid[i]] = max |row i - cents[sid[i]]| (rounded up) */
 __global__ __launch_bounds__(256) void
 k_s16_assigned_radius(const float *__restrict__ rows, int64_t n, int dim, const float *__restrict__ cents,
@@ -1642,6 +1635,14 @@ k_s16_assigned_radius(const float *__restrict__ rows, int64_t n, int dim, const 
 	}
 }
 
+/*
+ * Sublists of the matrix-core screen (ndbhip_screen16.h, "Sublists"): every list longer than screen16_sub_min rows
+ * is regrouped, inside the planes only, by the nearest of len / screen16_sub_rows of its own rows (taken at equal
+ * strides; no k-means: a sample row of every cluster the list mixes is enough, and the assignment is one screened
+ * pass).  A regrouping is kept per list only where it shrinks the radius
+ * (row-weighted mean sublist radius < 0.6 x the list's own).  Outputs the d_sub_* tables, the planes' order (d_perm, d_posof) and bo = first 32-row block of every
+ * sublist.  Leaves ix->s16_sub false when no list is long enough.
+ */
 static int
 ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 {
