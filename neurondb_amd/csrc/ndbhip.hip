@@ -2409,7 +2409,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = sub_cfg;
-		if (sub_cfg != 0 && !ix->f16 && (dim % 64) == 0)
+		if (sub_cfg != 0 && !ix->f16)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
 			const int	rc = ivf_s16_build_sublists(ix, bo);
