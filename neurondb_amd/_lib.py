@@ -288,12 +288,15 @@ def check(rc: int):
 
 
 _inited = False
+_device = -1
 
 
 def ensure_init(device: int | None = None):
     """Lazy per-process device init (the reference's ndb_gpu_init_if_needed pattern)."""
-    global _inited
+    global _inited, _device
     if _inited:
+        if device is not None and int(device) != _device:
+            raise RuntimeError(f"the library is initialised on device {_device}, not {device} (one device per process)")
         return
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -302,6 +305,7 @@ def ensure_init(device: int | None = None):
             device %= n
     check(lib().ndbhip_init(int(device)))
     _inited = True
+    _device = int(device)
 
 
 def stats() -> dict:

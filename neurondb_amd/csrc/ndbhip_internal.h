@@ -86,6 +86,10 @@ need_init()
 {
 	if (!g.inited)
 		return fail(NDBHIP_ERR_NODEVICE, "ndbhip_init() has not succeeded in this process");
+	/* HIP's current device is per thread, and the caller (torch, another library) may have changed it: an entry
+	 * point called from another thread than ndbhip_init's must not allocate and launch on device 0 */
+	if (hipSetDevice(g.device) != hipSuccess)
+		return fail(NDBHIP_ERR_HIP, "hipSetDevice(%d) failed", g.device);
 	return 0;
 }
 
