@@ -129,6 +129,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    comm_error = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -150,7 +151,11 @@ def main():
         # the exchange runs inside the C library (ndbhip_ivf_search_sharded over its own RCCL communicator);
         # torch.distributed only carries the 128-byte unique id and the timing barrier
         from neurondb_amd.dist import init_library_comm
-        init_library_comm(device=dev)
+        try:
+            init_library_comm(device=dev)
+        except Exception as e:              # (a collective: it fails on every rank or on none)
+            comm_error = f"{type(e).__name__}: {e}"
+            args.dist_impl = "torch"        # the same exchange through torch.distributed (neurondb_amd/dist.py)
 
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
     shard_mode = args.shard
@@ -503,6 +508,8 @@ def main():
                            "shard": sh_info, "dist_parity_on_sample": par}
         except Exception as e:
             sharded_leg = {"error": f"{type(e).__name__}: {e}"}
+    elif replicas and comm_error:
+        sharded_leg = {"error": "the library's RCCL communicator could not be opened: " + comm_error}
 
     gauss = balanced = None
     if rank == 0 and world == 1 and args.gauss_steps > 0 and args.data == "clustered" and args.rows == "f32" and \
