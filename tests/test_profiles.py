@@ -1,0 +1,53 @@
+"""The committed measurement artefacts are what bench.py's roofline.traffic reads: they must parse, agree with each other
+and match the workload bench.py runs by default (no GPU needed)."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pmc_traffic_json_is_what_the_summaries_say(tmp_path):
+    out = tmp_path / "t.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"),
+                           os.path.join(ROOT, "profiles", "r02_pmc"), str(out), "3",
+                           "--hnsw", os.path.join(ROOT, "profiles", "r02_pmc_hnsw"), "8192"], stdout=subprocess.DEVNULL)
+    fresh = json.load(open(out))["kernels"]
+    kept = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
+    for kern, sub in (("k_s16_sweep", "clustered"), ("k_s16_finalize", "clustered"), ("k_hnsw_search_fast", "gauss_unit")):
+        assert fresh[kern][sub]["traffic_bytes_per_launch"] == kept[kern][sub]["traffic_bytes_per_launch"]
+    e = kept["k_s16_sweep"]["clustered"]
+    # 2 x FETCH_SIZE + WRITE_SIZE (KiB per step) is the per-step traffic the file reports
+    assert abs((2 * e["fetch_kib_per_step"] + e["write_kib_per_step"]) * 1024 - e["traffic_bytes_per_step"]) < 4096
+    assert 1e9 < e["traffic_bytes_per_launch"] < 2e10
+
+
+def test_bench_finds_the_committed_traffic_for_its_default_workload():
+    sys.path.insert(0, ROOT)
+    import bench
+    args = types.SimpleNamespace(data="clustered", nvec=1_000_000, dim=768, lists=1024, probes=32, batch=4096, k=10,
+                                 rows="f32", strategy="l2")
+    traffic, source = bench.pmc_traffic(args, 1, "k_s16_sweep")
+    assert traffic and "profiles/r" in source
+    assert bench.pmc_traffic(args, 8, "k_s16_sweep") == (None, None)          # a PMC pass describes one GPU
+    args.strategy = "ip"
+    assert bench.pmc_traffic(args, 1, "k_s16_sweep") == (None, None)          # ... and one workload
+    hn = bench.hnsw_pmc_traffic(1_000_000, 768, 16, 64, 8192, 1e-3)
+    assert hn["traffic"] and hn["traffic_source"]
+
+
+def test_the_committed_bench_line_is_one_json_object_with_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    r, c = d["roofline"], d["cpu_baseline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert c["gpu_parity_on_sample"]["mismatches"] == 0 and d["recall_at_10"] == 1.0
+    assert "workload" in d["config"] and "model" not in d["config"]
