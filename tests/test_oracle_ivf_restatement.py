@@ -155,3 +155,99 @@ def test_c_oracle_equals_the_python_restatement_of_the_reference(kind, seed):
             exp_t = ndbo.tids_to_u64(img.tids[np.asarray(rows_p, np.int64)]) if rows_p else np.zeros(0, np.uint64)
             assert np.array_equal(ndbo.tids_to_u64(t), exp_t), (kind, strategy, nprobe, k, cap)
             assert np.array_equal(d.view(np.uint32), np.asarray(dist_p, np.float32).view(np.uint32)), (kind, strategy)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The build: kmeans_init / kmeans_run and their helpers (ivf_am.c:2070-2294) and the insert-time choice of a list
+# (:812-814, :905-935), restated the same way.
+# ---------------------------------------------------------------------------------------------------------------
+
+def ref_l2_squared(a, b):
+    """vector_distance_l2 (:2255-2269): the SQUARED distance, float4 accumulator"""
+    s = F(0)
+    for x, y in zip(a, b):
+        d = F(x - y)
+        s = F(s + F(d * d))
+    return s
+
+
+def ref_kmeans(data, k, max_iter=50, threshold=0.001):
+    """kmeans_init + kmeans_run; returns centroids, assignments, counts, Lloyd iterations run, last cost"""
+    n, dim = data.shape
+    cent = np.zeros((k, dim), np.float32)
+    for i in range(k):                               # "Initialize with random data points (KMeans++)": the first k
+        if i < n:
+            cent[i] = data[i]
+    asg = np.zeros(n, np.int64)
+    counts = np.zeros(k, np.int64)
+    prev = FLT_MAX
+    thr = F(threshold)                               # float4 threshold = IVF_CONVERGENCE_THRESHOLD
+    iters = 0
+    cost = F(0)
+    with np.errstate(all="ignore"):
+        for it in range(max_iter):
+            counts[:] = 0                            # kmeans_assign
+            for i in range(n):
+                best, best_d = 0, FLT_MAX            # find_nearest_centroid: best = 0, bestDist = FLT_MAX
+                for c in range(k):
+                    d = ref_l2_squared(data[i], cent[c])
+                    if d < best_d:
+                        best_d, best = d, c
+                asg[i] = best
+                counts[best] += 1
+            cent[:] = 0                              # kmeans_update_centroids: sums in sample order, then / count
+            for i in range(n):
+                c = asg[i]
+                for j in range(dim):
+                    cent[c, j] = F(cent[c, j] + data[i, j])
+            for c in range(k):
+                if counts[c] > 0:
+                    for j in range(dim):
+                        cent[c, j] = F(cent[c, j] / F(counts[c]))
+            cost = F(0)                              # kmeans_compute_cost: float4 sum in sample order
+            for i in range(n):
+                cost = F(cost + ref_l2_squared(data[i], cent[asg[i]]))
+            iters = it + 1
+            if abs(float(F(prev - cost))) < float(thr):          # fabs(prevCost - cost) < state->threshold
+                break
+            prev = cost
+    return cent, asg, counts, iters, cost
+
+
+def ref_insert_list(cent, x):
+    """ivfinsert's choice: min_idx = 0, min_dist = FLT_MAX, sqrtf of the float4 sum, strict <"""
+    best, best_d = 0, FLT_MAX
+    with np.errstate(all="ignore"):
+        for i in range(len(cent)):
+            d = np.sqrt(ref_l2_squared(x, cent[i]))
+            if d < best_d:
+                best_d, best = d, i
+    return best
+
+
+@pytest.mark.parametrize("kind", ["normal", "integer", "clustered", "huge"])
+def test_c_oracle_kmeans_and_insert_rule_equal_the_python_restatement(kind):
+    rng = np.random.default_rng(len(kind) * 7)
+    for _ in range(5):
+        dim = int(rng.choice([2, 5, 12]))
+        k = int(rng.integers(1, 7))
+        n = int(rng.integers(k, 70))
+        if kind == "integer":                        # ties everywhere, duplicate initial centroids, empty clusters
+            data = rng.integers(-1, 2, size=(n, dim)).astype(np.float32)
+        elif kind == "clustered":
+            cen = rng.standard_normal((3, dim)).astype(np.float32) * 5
+            data = (cen[rng.integers(0, 3, n)] + 0.1 * rng.standard_normal((n, dim))).astype(np.float32)
+        elif kind == "huge":                         # squared distances overflow: nothing is < FLT_MAX, everything goes to 0
+            data = (rng.standard_normal((n, dim)) * 2e19).astype(np.float32)
+        else:
+            data = rng.standard_normal((n, dim)).astype(np.float32)
+        cent_p, asg_p, cnt_p, it_p, cost_p = ref_kmeans(data, k)
+        cent_c, asg_c, cnt_c, it_c, cost_c = ndbo.kmeans(data, k)
+        assert it_c == it_p, (kind, it_c, it_p)
+        assert np.array_equal(asg_c, asg_p) and np.array_equal(cnt_c, cnt_p), kind
+        assert np.array_equal(cent_c.view(np.uint32), cent_p.view(np.uint32)), kind
+        assert np.float32(cost_c).view(np.uint32) == np.float32(cost_p).view(np.uint32), (kind, cost_c, cost_p)
+        # every row to the list ivfinsert would choose
+        got = ndbo.ivf_assign_all(cent_c, data)
+        exp = np.asarray([ref_insert_list(cent_p, data[i]) for i in range(n)])
+        assert np.array_equal(got, exp), kind
