@@ -131,7 +131,9 @@ int			ndbhip_set_scan_mode(int mode);
  *                             own copy of the rows, into sublists of about "screen16_sub_rows" (128) rows — kept per list only
  *                             where that shrinks the radius — and a (query, probe) pair expands only to the sublists the
  *                             triangle inequality cannot exclude (csrc/ndbhip_screen16.h, "Sublists")
- *   "screen16_tighten"  1     a query's threshold is lowered inside the sweep every 256 emitted records (0: only between the two rounds)
+ *   "screen16_tighten"  1     a query's threshold is lowered inside the sweep every 128 emitted records (0: only between the two rounds)
+ *   "build_screen16"    1     build / ndbhip_ivf_assign_device (>= 4096 rows): the assignment is screened on the matrix cores (0: exact kernels)
+ *   "block_cache"       1     keep up to 4 freed packed-row blocks (>= 64 MiB) for the next build (0: release them now, stop caching)
  *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
  *   "screen16_debug"    0   timing experiments of the sweep (1 no DMA, 2 DMA of cache-hot lines: WRONG results)
  *   "scr_coop" 2, "scr_ch" 16, "scr_mfma" 1, "gchunk" 32   A/B switches of the fp32 screened / grouped kernels

@@ -47,3 +47,28 @@ def test_no_device_is_a_loud_error_not_a_fallback():
     assert "init" in _lib.last_error()
     with pytest.raises(_lib.NdbHipError):
         _lib.check(rc)
+
+
+def test_every_documented_option_is_accepted_and_bad_ones_are_refused():
+    """ndbhip_set_option needs no device: the names include/ndbhip.h lists must be the names the library knows."""
+    import ctypes as C
+    import re
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ndbhip.h")).read()
+    block = hdr[hdr.index("ndbhip_set_option") - 6000: hdr.index("int			ndbhip_set_option")]
+    names = set(re.findall(r'"([a-z0-9_]+)"', block))
+    assert {"screen16", "screen16_records", "screen16_prune", "screen16_sublists", "build_screen16", "block_cache"} <= names
+    defaults = {"screen16": 1, "screen16_records": 8192, "screen16_tighten": 1, "screen16_prune": 1, "screen16_sublists": 1,
+                "screen16_sub_min": 2048, "screen16_sub_rows": 128, "screen16_fin_threads": 64, "screen16_waves": 4,
+                "probe_select_threads": 256, "probe_select_radix": 0, "build_screen16": 1, "block_cache": 1, "gchunk": 32,
+                "scr_coop": 2, "scr_mfma": 1, "screen": 1}
+    for n in sorted(names):
+        rc = L.ndbhip_set_option(n.encode(), defaults.get(n, 0))
+        assert rc == 0, (n, L.ndbhip_last_error().decode() if hasattr(L, "ndbhip_last_error") else rc)
+    assert L.ndbhip_set_option(b"no_such_option", 1) != 0
+    assert L.ndbhip_set_option(b"screen16_records", 3) != 0
+    assert L.ndbhip_set_option(b"screen16_fin_threads", 100) != 0
+    assert L.ndbhip_set_option(b"screen16_sub_rows", 1) != 0
+    assert L.ndbhip_set_option(None, 1) != 0
