@@ -127,11 +127,17 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen16"          1   ... on the fp16 matrix cores (0 = the fp32 bound pass)
  *   "screen16_records"  8192  candidates a query may emit before it is swept again / its batch falls back
  *   "screen16_prune"    1     L2: a (query, list) pair whose |q - centroid| - list radius already exceeds the query's threshold is not swept
- *   "screen16_sublists" 1     L2, float4 rows: lists longer than "screen16_sub_min" (2048) rows are regrouped, inside the library's
+ *   "screen16_sublists" 1     L2, float4 rows: lists longer than "screen16_sub_min" (256) rows are regrouped, inside the library's
  *                             own copy of the rows, into sublists of about "screen16_sub_rows" (128) rows — kept per list only
  *                             where that shrinks the radius — and a (query, probe) pair expands only to the sublists the
  *                             triangle inequality cannot exclude (csrc/ndbhip_screen16.h, "Sublists")
  *   "screen16_tighten"  1     a query's threshold is lowered inside the sweep every 128 emitted records (0: only between the two rounds)
+ *   "screen16_centered" 1     L2, float4 rows: the sweep multiplies (query - centre) with (row - centre) of the row's list / sublist,
+ *                             ONE fp16 plane of each (2 bytes per row element instead of 4); the error term scales with the distances
+ *                             to the centre instead of the vectors' norms (csrc/ndbhip_screen16c.h, csrc/ndbhip_common.h (8));
+ *                             0: the two-plane sweep over the rows as they are
+ *   "screen16c_qb"      0     (query, list) pairs per tile of the centred sweep / 32: 4 | 1, 0 = chosen from the previous batch's pairs per list
+ *   "screen16c_nbuf"    0     ring depth of the centred sweep: 2 | 3, 0 = the tile geometry's default
  *   "build_screen16"    1     build / ndbhip_ivf_assign_device (>= 4096 rows): the assignment is screened on the matrix cores (0: exact kernels)
  *   "block_cache"       1     keep up to 4 freed packed-row blocks (>= 64 MiB) for the next build (0: release them now, stop caching)
  *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
@@ -392,6 +398,12 @@ int			ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, 
  * assign all nrows, pack lists in insertion (heap) order, adopt into ix. */
 int			ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids,
 									int64_t nrows, int max_iter, int *out_iters);
+/* Optional last step of a build (or of a load): prepare now what the first batched scan of operator class
+ * `strategy` would otherwise prepare lazily — sublists of the long lists, the rows' fp16 planes in the matrix-core
+ * sweep's layout, norms, radii — so that an index is searchable at full speed when ambuild returns (ivf_am.c:501-745
+ * has no such step: its lists are read from the buffer manager as they are).  Later appends / deletes are folded
+ * in by the next scan. */
+int			ndbhip_ivf_prepare(ndbhip_ivf *ix, int strategy);
 
 /* ------------------------------------------------------------------ */
 /* HNSW mirror and search (src/index/hnsw_am.c:1545-2080).  Node b = block

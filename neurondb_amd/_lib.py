@@ -192,6 +192,7 @@ def lib():
         "ndbhip_comm_alltoallv": (i, [vp, vp, vp, vp]),
         "ndbhip_ivf_assign_device": (i, [vp, i, i, vp, i64, vp]),
         "ndbhip_ivf_build_device": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
+        "ndbhip_ivf_prepare": (i, [vp, i]),
         "ndbhip_hnsw_create": (i, [i, i, C.POINTER(vp)]),
         "ndbhip_hnsw_destroy": (i, [vp]),
         "ndbhip_hnsw_load": (i, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i]),

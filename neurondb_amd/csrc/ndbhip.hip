@@ -1460,6 +1460,13 @@ struct ndbhip_ivf
 	float2	   *w_qthr = nullptr;	size_t w_qthr_n = 0;
 	unsigned int *w_ecount = nullptr; size_t w_ecount_n = 0;	/* [nq] emitted per query | [nq] survivors | [nq] seeds | 4 flags */
 	uint2	   *w_erec = nullptr;	size_t w_erec_n = 0;
+	/* the centred one-plane sweep (ndbhip_screen16c.h): upper bounds of the emitted records, the batch's (query,
+	 * bucket) pair planes / norms / exponents, and what the last batch looked like (pairs per bucket with pairs) */
+	float	   *w_eub = nullptr;	size_t w_eub_n = 0;
+	_Float16   *w_qcplanes = nullptr; size_t w_qcplanes_n = 0;
+	float	   *w_qcn2 = nullptr;	size_t w_qcn2_n = 0;
+	int		   *w_qcexp = nullptr;	size_t w_qcexp_n = 0;
+	float		s16c_density = -1.0f;	/* pairs per bucket that had any, previous batch (-1: none yet) */
 	/* sublists (ndbhip_screen16.h): the planes' own grouping of the rows of long lists */
 	bool		s16_sub = false;
 	int			s16_sub_cfg = -1;			/* sublist settings the planes were laid out under */
@@ -1588,7 +1595,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
 			ix->d_cplanes, ix->d_crn2, ix->d_crexp, ix->d_cxmax, ix->d_dm_loc, ix->d_dm_meta, ix->d_dm_pairs, ix->d_dm_desc,
-			ix->d_dm_heads, ix->d_dm_zero};
+			ix->d_dm_heads, ix->d_dm_zero, ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2344,6 +2351,7 @@ ivf_recipe(int strategy)
 
 /* defined with the build kernels below; the batch centroid scan of the search reuses them */
 #include "ndbhip_screen16.h"
+#include "ndbhip_screen16c.h"
 
 /* the fp16-MFMA screened scan in auto mode (ndbhip_set_option("screen16", 0) turns it off: the older fp32 bound
  * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
@@ -2357,6 +2365,9 @@ static int	g_probe_sel_threads = 256;	/* threads of a k_probe_select block for b
 static int	g_s16_fin_threads = 64;	/* threads of a k_s16_finalize block (one block per query; "screen16_fin_threads": 64 / 128 / 256) */
 static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep ("screen16_prune") */
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
+static int	g_s16_cen = 1;		/* L2 on float4 rows: the centred one-plane sweep (ndbhip_screen16c.h; "screen16_centered", 0: the two-plane sweep) */
+static int	g_s16c_qb = 0;		/* pairs per tile of the centred sweep / 32: 4 or 1; 0 = from the previous batch's pairs per bucket ("screen16c_qb") */
+static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
 static bool
 ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
@@ -2377,38 +2388,43 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host);	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
 static int	g_s16_sublists = 1;	/* long lists regrouped into sublists ("screen16_sublists") */
-static int	g_s16_sub_min = 2048;	/* lists longer than this are regrouped ("screen16_sub_min") */
+static int	g_s16_sub_min = 256;	/* lists longer than this are regrouped where that shrinks their radius ("screen16_sub_min") */
 static int	g_s16_sub_rows = 128;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
 
-/* Runs the sweep + finalize for one sub-batch whose probes / candidate offsets are already on the device.
- * Returns 0, a negative error, or 1 when some query overflowed (nothing usable was written: rerun on the older path). */
-static int
-ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, int npr, int k, const int *w_probes,
-			const uint32_t *lco, int partial, ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
-			uint64_t *d_otid, float *d_odist, int *d_ocnt,
-			const float *cdist /* the centroid scan's [nq][cstride] L2 distances, or NULL (probes chosen elsewhere) */,
-			uint32_t cstride)
+/* does the centred one-plane sweep (ndbhip_screen16c.h) serve this recipe on this mirror */
+static bool
+ivf_s16_centered(const ndbhip_ivf *ix, int R)
 {
-	const int	dim = ix->dim, dimp = (dim + 63) & ~63;	/* two chunks per accumulator block */
-	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
-	const int	nc = ix->ncent;
-	const int	H = !ix->f16 ? 0 : (ix->f16_sub ? 1 : 2);
-	/* records a query may leave: the option's value, less for batches whose record array would pass 1 GiB */
-	const uint32_t ecap = std::max<uint32_t>(std::min<uint32_t>(g_s16_ecap, (uint32_t) ((((size_t) 1 << 30) / 8) / (size_t) nq)), 64u);
+	return R == R_IVF_L2 && !ix->f16 && g_s16_cen != 0;
+}
 
+/*
+ * The sweep's operands, once per version of the mirror (and per layout: sublist settings, centred or not): sublists
+ * of the long lists, the rows' fp16 planes / norms / exponents in the blocked layout, list radii.  The first
+ * screened batch runs it if nobody did (ndbhip_ivf_prepare: a build that wants its index searchable at once).
+ */
+static int
+ivf_s16_prepare(ndbhip_ivf *ix, int R)
+{
+	const int	dim = ix->dim, dimp = (dim + 63) & ~63;
+	const int	nc = ix->ncent;
 	/* sublists only pay where a bound can exclude them: L2 (an index has one operator class, hence one strategy;
 	 * a caller that alternates strategies on one mirror has its planes laid out again at every change) */
 	const int	sub_cfg = (g_s16_sublists && g_s16_prune && R == R_IVF_L2) ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
 
-	if (ix->s16_valid && ix->s16_sub_cfg != sub_cfg)
-		ix->s16_valid = false;	/* the planes were laid out under other sublist settings */
+	/* L2 on float4 rows: the planes hold the rows minus their bucket's centre, one fp16 plane (ndbhip_screen16c.h) */
+	const bool	cen = ivf_s16_centered(ix, R);
+	const int	lay_cfg = sub_cfg * 2 + (cen ? 1 : 0);
+
+	if (ix->s16_valid && ix->s16_sub_cfg != lay_cfg)
+		ix->s16_valid = false;	/* the planes were laid out under other settings */
 	if (!ix->s16_valid)
 	{
 		std::vector<uint32_t> bo;
 		uint64_t	nb = 0;
 
 		ix->s16_sub = false;
-		ix->s16_sub_cfg = sub_cfg;
+		ix->s16_sub_cfg = lay_cfg;
 		if (sub_cfg != 0 && !ix->f16)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
@@ -2434,7 +2450,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			HIP_TRY(hipStreamSynchronize(g.stream));		/* bo is a local */
 		}
 		nb = bo.back();
-		const size_t blk_bytes = (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
+		const size_t blk_bytes = cen ? (size_t) (dimp / S16C_CH) * 4096 : (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
 
 		if (grow(ix->d_rn2, ix->d_rn2_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
 		if (grow(ix->d_rexp, ix->d_rexp_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
@@ -2451,7 +2467,15 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 						   ix->s16_sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,            \
 						   ix->s16_sub ? ix->nsub : nc, ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16,               \
 						   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr)
-		if (!ix->f16)
+		if (cen)
+			hipLaunchKernelGGL(k_s16c_row_prep, gp, dim3(256), 0, g.stream, (const float *) ix->d_vecs, ix->nrows, dim, dimp,
+							   ix->s16_sub ? (const int64_t *) ix->d_sub_loc : (const int64_t *) ix->d_loc_off,
+							   ix->s16_sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,
+							   ix->s16_sub ? ix->nsub : nc, (const float *) ix->d_centroids,
+							   ix->s16_sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
+							   ix->d_planes, ix->d_rn2, ix->d_rexp,
+							   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr);
+		else if (!ix->f16)
 			S16_PREP_L(0);
 		else if (ix->f16_sub)
 			S16_PREP_L(1);
@@ -2474,16 +2498,43 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		HIP_TRY(hipGetLastError());
 		ix->s16_valid = true;
 	}
+	return 0;
+}
+
+/* Runs the sweep + finalize for one sub-batch whose probes / candidate offsets are already on the device.
+ * Returns 0, a negative error, or 1 when some query overflowed (nothing usable was written: rerun on the older path). */
+static int
+ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, int npr, int k, const int *w_probes,
+			const uint32_t *lco, int partial, ndbhip_cand *d_cand, int *d_ncand, int64_t *d_total,
+			uint64_t *d_otid, float *d_odist, int *d_ocnt,
+			const float *cdist /* the centroid scan's [nq][cstride] L2 distances, or NULL (probes chosen elsewhere) */,
+			uint32_t cstride)
+{
+	const int	dim = ix->dim, dimp = (dim + 63) & ~63;	/* two chunks per accumulator block */
+	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
+	const int	nc = ix->ncent;
+	const int	H = !ix->f16 ? 0 : (ix->f16_sub ? 1 : 2);
+	/* records a query may leave: the option's value, less for batches whose record array would pass 1 GiB */
+	const uint32_t ecap = std::max<uint32_t>(std::min<uint32_t>(g_s16_ecap, (uint32_t) ((((size_t) 1 << 30) / 8) / (size_t) nq)), 64u);
+
+	const bool	cen = ivf_s16_centered(ix, R);
+	{
+		const int	rc = ivf_s16_prepare(ix, R);
+
+		if (rc)
+			return rc;
+	}
 	if (grow(ix->w_qplanes, ix->w_qplanes_n, (size_t) nq * qrowbytes)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qn2, ix->w_qn2_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qexp, ix->w_qexp_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-	if (grow(ix->w_ecount, ix->w_ecount_n, (size_t) 3 * nq + 4)) return NDBHIP_ERR_HIP;	/* emitted | survivors | active | flags */
+	if (grow(ix->w_ecount, ix->w_ecount_n, (size_t) 3 * nq + 8)) return NDBHIP_ERR_HIP;	/* emitted | survivors | active | flags (4) | pairs, buckets with pairs */
 	if (grow(ix->w_erec, ix->w_erec_n, (size_t) nq * ecap)) return NDBHIP_ERR_HIP;
+	if (cen && grow(ix->w_eub, ix->w_eub_n, (size_t) nq * ecap)) return NDBHIP_ERR_HIP;
 	unsigned int *ecount = ix->w_ecount, *surv = ix->w_ecount + nq, *flags = ix->w_ecount + 3 * (size_t) nq;
 
 	if (grow(ix->w_bmin, ix->w_bmin_n, (size_t) nq * S16_NB)) return NDBHIP_ERR_HIP;
-	HIP_TRY(hipMemsetAsync(ix->w_ecount, 0, ((size_t) 3 * nq + 4) * sizeof(unsigned int), g.stream));
+	HIP_TRY(hipMemsetAsync(ix->w_ecount, 0, ((size_t) 3 * nq + 8) * sizeof(unsigned int), g.stream));
 	HIP_TRY(hipMemsetAsync(ix->w_bmin, 0xFF, (size_t) nq * S16_NB * sizeof(uint32_t), g.stream));
 	hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, dim, dimp,
 					   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
@@ -2508,7 +2559,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
-				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr);
+				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr, cen ? 1 : 0);
 
 	/* the (query, probe) pairs bucketed by list — by sublist when the planes are regrouped (`ncs` buckets) —; items
 	 * of 128 rows x 128 queries */
@@ -2546,7 +2597,21 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	/* tile geometry: 8 waves, 256 rows x 128 queries, ring of 3 chunk buffers, one block per CU (default), or
 	 * 4 waves, 128 x 128, ring of 2, two blocks per CU (ndbhip_set_option("screen16_waves", 4)) */
-	const int	s16_rt = g_s16_waves == 8 ? 256 : 128;
+	const int	s16_rt = cen ? 128 : (g_s16_waves == 8 ? 256 : 128);
+	/* the centred sweep's tile holds 128 pairs, or 32 where the buckets are probed by a handful of queries each (what
+	 * the previous batch on this mirror looked like; before any: regrouped planes mean clustered rows, i.e. few) */
+	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4) ? g_s16c_qb :
+		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : 4) : (ix->s16_sub ? 1 : 4));
+	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
+	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, (size_t) 4 * nq * npr + 1024), 0x7FFFFFFFu);
+	const uint32_t qcrowbytes = (uint32_t) dimp * 2u;
+
+	if (cen)
+	{
+		if (grow(ix->w_qcplanes, ix->w_qcplanes_n, (size_t) qc_cap * dimp)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_qcn2, ix->w_qcn2_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_qcexp, ix->w_qcexp_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
+	}
 #define S16_SWEEP_L(RR, HH, ...)                                                                                  \
 	do {                                                                                                          \
 		if (g_s16_debug == 1 && HH == 0 && RR == R_IVF_L2)                                                         \
@@ -2576,10 +2641,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		{
 			if (R == R_IVF_IP)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_IP>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
-								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1);
+								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 0);
 			else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_L2>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
-								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1);
+								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, cen ? 1 : 0);
 		}
 		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
 		const uint8_t *drop = nullptr;
@@ -2617,7 +2682,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
 								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
 								   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-								   (const uint32_t *) ix->d_xmax16, ix->w_qthr);
+								   (const uint32_t *) ix->d_xmax16, ix->w_qthr, cen ? 1 : 0);
 			}
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -2633,7 +2698,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(k_s16_swept_rows, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) cnt,
 							   (const uint32_t *) ix->d_sub_len, ncs, g.d_counters + 6);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
-						   pair_off, item_off, grp_off, runs, (uint32_t) (S16_QT / NDB_QG), (uint32_t) (s16_rt / 64));
+						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64));
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -2649,13 +2714,23 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			const int	ncmp = std::min(ix->nlists, ix->ncent);
 			const size_t dup = npr > ncmp ? (size_t) (npr - ncmp + 1) : 1;
 			const size_t cap_items = ((size_t) ix->nrows / (size_t) s16_rt + (size_t) ncs) *
-				(((size_t) nq * dup + S16_QT - 1) / S16_QT);
+				(((size_t) nq * dup + s16_qt - 1) / s16_qt);
 
 			if (grow(ix->w_s16desc, ix->w_s16desc_n, cap_items * 4)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_s16_items, dim3((unsigned) ((cap_items + 255) / 256)), dim3(256), 0, g.stream,
 							   (const uint32_t *) item_off, (const uint32_t *) cnt, ds.own_len, ncs, (uint32_t) s16_rt,
-							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags);
+							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags, s16_qt);
 			desc_cap = (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu);
+		}
+		if (cen)
+		{
+			/* q - c of every pair that is left, in the pair tables' order (more pairs than the planes hold: flags[0],
+			 * the batch goes to the older path and the sweep below returns at once) */
+			hipLaunchKernelGGL(k_s16c_qcprep, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d_q, dim, dimp,
+							   (const PairRec *) ix->w_pairs, (const uint32_t *) pair_off, ncs, (const float *) ix->d_centroids,
+							   sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
+							   ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, qc_cap, flags, round == 0 ? flags + 4 : (unsigned int *) nullptr,
+							   (const uint32_t *) cnt);
 		}
 		if (g_debug_s16 && round == 0)
 		{
@@ -2668,6 +2743,34 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 					sub ? "sublist" : "list", ni, s16_rt, S16_QT, ncs);
 		}
 		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
+		if (cen)
+		{
+			const float cE = ndb_s16c_ce(dim);
+			const int	nbuf = g_s16c_nbuf ? g_s16c_nbuf : (c_qb == 1 ? 3 : 2);
+
+#define S16C_SWEEP_L(QB, NB, DB)                                                                                     \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB == 1 || NB == 2) ? 2 : 1)), dim3(256), 0, g.stream, ds, \
+							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
+							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
+							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (float2 *) ix->w_qthr, lco, npr,        \
+							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const S16Desc *) ix->w_s16desc,          \
+							   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
+							   ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,    \
+							   sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr, cE, qc_cap)
+			if (g_s16_debug == 1)
+				S16C_SWEEP_L(4, 2, 1);
+			else if (g_s16_debug == 2)
+				S16C_SWEEP_L(4, 2, 2);
+			else if (c_qb == 1 && nbuf == 2)
+				S16C_SWEEP_L(1, 2, 0);
+			else if (c_qb == 1)
+				S16C_SWEEP_L(1, 3, 0);
+			else if (nbuf == 3)
+				S16C_SWEEP_L(4, 3, 0);
+			else
+				S16C_SWEEP_L(4, 2, 0);
+		}
+		else
 		S16_BY_RH(S16_SWEEP_L, ds, (const unsigned char *) ix->d_planes,
 				  sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,
 				  (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qplanes, qrowbytes,
@@ -2683,16 +2786,19 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 #define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__)
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
-			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags);
+			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr);
 	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
 					   g.d_counters + 3);
 	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
 					   g.d_counters + 4);
 	HIP_TRY(hipGetLastError());
-	unsigned int over = 0;
+	unsigned int over = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-	HIP_TRY(hipMemcpyAsync(&over, flags, sizeof(over), hipMemcpyDeviceToHost, g.stream));
+	HIP_TRY(hipMemcpyAsync(fl8, flags, sizeof(fl8), hipMemcpyDeviceToHost, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));
+	over = fl8[0];
+	if (cen && fl8[5] > 0)
+		ix->s16c_density = (float) fl8[4] / (float) fl8[5];		/* pairs per bucket with pairs: the next batch's tile size */
 	if (g_debug_s16)
 	{
 		std::vector<unsigned int> h((size_t) 3 * nq + 4);
@@ -2712,6 +2818,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		fprintf(stderr, "s16 debug: nq %d max ecount %u (q %d, thrE %g E %g active %u) active %u still-over %u max surv %u flags %u %u\n",
 				nq, mx, arg, arg >= 0 ? th[arg].x : 0.f, arg >= 0 ? th[arg].y : 0.f, arg >= 0 ? h[2 * (size_t) nq + arg] : 0u,
 				nact, nover, mxs, h[3 * (size_t) nq], h[3 * (size_t) nq + 1]);
+		fprintf(stderr, "s16 debug: cen %d qb %d flags %u %u %u %u pairs %u buckets-with-pairs %u qc_cap %u\n", (int) cen, c_qb, fl8[0], fl8[1],
+				fl8[2], fl8[3], fl8[4], fl8[5], qc_cap);
 	}
 	if (over)
 	{
@@ -2720,6 +2828,31 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	}
 	g.stats.screen16_batches++;
 	return 0;
+}
+
+/* ambuild's last step (optional): everything the first batched scan would otherwise prepare lazily — sublists of
+ * the long lists, the rows' fp16 planes, norms and radii — for the operator class `strategy` */
+extern "C" int
+ndbhip_ivf_prepare(ndbhip_ivf *ix, int strategy)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!ix)
+		return fail(NDBHIP_ERR_INVALID, "index is NULL");
+	if (!ix->loaded || ix->ncent < 1)
+		return fail(NDBHIP_ERR_STATE, "index has no centroids/lists loaded");
+	int			rc = ivf_flush(ix);
+
+	if (rc)
+		return rc;
+	const int	R = ivf_recipe(strategy);
+
+	if (ix->nrows < 1 || !ivf_s16_eligible(ix, NDB_SCREEN_MIN_NQ, R, 10))
+		return NDBHIP_OK;		/* nothing is prepared ahead for the other scan paths */
+	rc = ivf_s16_prepare(ix, R);
+	if (rc)
+		return rc;
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	return NDBHIP_OK;
 }
 
 /* ------------------------------------------------------------------ */
@@ -2845,6 +2978,20 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_debug"))
 		g_s16_debug = value;
+	else if (!strcmp(name, "screen16_centered"))
+		g_s16_cen = value != 0;
+	else if (!strcmp(name, "screen16c_qb"))
+	{
+		if (value != 0 && value != 1 && value != 4)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_qb must be 0 (auto), 1 or 4");
+		g_s16c_qb = value;
+	}
+	else if (!strcmp(name, "screen16c_nbuf"))
+	{
+		if (value != 0 && value != 2 && value != 3)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_nbuf must be 0 (default), 2 or 3");
+		g_s16c_nbuf = value;
+	}
 	else if (!strcmp(name, "build_screen16"))
 		g_build_s16 = value != 0;
 	else if (!strcmp(name, "gchunk"))

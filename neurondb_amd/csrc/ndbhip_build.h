@@ -1635,6 +1635,122 @@ k_s16_assigned_radius(const float *__restrict__ rows, int64_t n, int dim, const 
 	}
 }
 
+/* ---- lists of a few hundred to 2048 rows ("mid" lists): all of them regrouped in three launches ---- */
+struct MidDesc
+{
+	int64_t		row0;			/* first mirror row of the list */
+	uint32_t	len;
+	uint32_t	cent0;			/* first of its sample rows in the gathered centre block */
+	uint32_t	S;				/* sample rows = sublists (<= 32) */
+	uint32_t	sorted0;		/* first slot of its rows in the order array */
+};
+
+/* one wave per row of the mid lists: the nearest of its own list's sample rows (fp32 sums: any assignment gives valid
+ * sublists, whose radii are measured afterwards), that sublist's size and an upper estimate of its radius */
+__global__ __launch_bounds__(256) void
+k_s16_mid_assign(const float *__restrict__ vecs, int dim, const MidDesc *__restrict__ md, const uint32_t *__restrict__ mrow_off,
+				 int nmid, const float *__restrict__ cents, uint8_t *__restrict__ sid, uint32_t *__restrict__ rad_bits,
+				 uint32_t *__restrict__ cnt)
+{
+	const int	lane = threadIdx.x & 63;
+	const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (w >= mrow_off[nmid])
+		return;
+	int			lo = 0, hi = nmid;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (mrow_off[mid] <= w)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const MidDesc d = md[lo];
+	const float *x = vecs + (size_t) (d.row0 + (w - mrow_off[lo])) * dim;
+	float		best = __uint_as_float(0x7F800000u);
+	uint32_t	bi = 0;
+
+	for (uint32_t j = 0; j < d.S; j++)
+	{
+		const float *c = cents + (size_t) (d.cent0 + j) * dim;
+		float		a = 0.0f;
+
+		for (int i = lane; i < dim; i += 64)
+		{
+			const float t = x[i] - c[i];
+
+			a = __builtin_fmaf(t, t, a);
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+			a += __shfl_xor(a, off, 64);
+		if (a < best)
+		{
+			best = a;
+			bi = j;
+		}
+	}
+	if (lane == 0)
+	{
+		const float r = __builtin_sqrtf(best) * 1.001f;
+
+		sid[w] = (uint8_t) bi;
+		atomicAdd(&cnt[d.cent0 + bi], 1u);
+		if (r == r && __float_as_uint(r) > __atomic_load_n(&rad_bits[d.cent0 + bi], __ATOMIC_RELAXED))
+			atomicMax(&rad_bits[d.cent0 + bi], __float_as_uint(r));
+		if (!(r == r))
+			atomicMax(&rad_bits[d.cent0 + bi], 0x7F800000u);
+	}
+}
+
+/* one block per mid list: its rows in sublist order, stable (sorted[sorted0 + j] = index in the list of the row that
+ * comes j-th) */
+__global__ __launch_bounds__(256) void
+k_s16_mid_sort(const MidDesc *__restrict__ md, const uint32_t *__restrict__ mrow_off, const uint8_t *__restrict__ sid,
+			   uint64_t *__restrict__ sorted)
+{
+	__shared__ uint8_t s_sid[2048];
+	__shared__ uint32_t s_part[256], s_base;
+	const MidDesc d = md[blockIdx.x];
+	const uint8_t *mine = sid + mrow_off[blockIdx.x];
+	const uint32_t t = threadIdx.x, per = (d.len + 255) / 256, r0 = t * per, r1 = min(d.len, r0 + per);
+
+	for (uint32_t r = t; r < d.len; r += 256)
+		s_sid[r] = mine[r];
+	if (t == 0)
+		s_base = 0;
+	__syncthreads();
+	for (uint32_t v = 0; v < d.S; v++)
+	{
+		uint32_t	n = 0;
+
+		for (uint32_t r = r0; r < r1; r++)
+			n += s_sid[r] == v ? 1u : 0u;
+		s_part[t] = n;
+		__syncthreads();
+		for (int off = 1; off < 256; off <<= 1)
+		{
+			const uint32_t a = t >= (uint32_t) off ? s_part[t - off] : 0u;
+
+			__syncthreads();
+			s_part[t] += a;
+			__syncthreads();
+		}
+		uint32_t	pos = s_base + s_part[t] - n;
+
+		for (uint32_t r = r0; r < r1; r++)
+			if (s_sid[r] == v)
+				sorted[d.sorted0 + pos++] = (uint64_t) r;
+		__syncthreads();
+		if (t == 255)
+			s_base += s_part[255];
+		__syncthreads();
+	}
+}
+
 /*
  * Sublists of the matrix-core screen (ndbhip_screen16.h, "Sublists"): every list longer than screen16_sub_min rows
  * is regrouped, inside the planes only, by the nearest of len / screen16_sub_rows of its own rows (taken at equal
@@ -1647,12 +1763,18 @@ static int
 ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 {
 	const int	nc = ix->ncent, dim = ix->dim;
-	std::vector<int> giant;
+	std::vector<int> giant, midl;
 
 	for (int c = 0; c < nc; c++)
 		if (ix->own_len[c] > (int64_t) g_s16_sub_min)
-			giant.push_back(c);
-	if (giant.empty() || ix->nrows < 1)
+		{
+			/* up to 2048 rows and 32 sample rows: regrouped together with all the other lists of that size */
+			if (ix->own_len[c] <= 2048 && (ix->own_len[c] + g_s16_sub_rows - 1) / g_s16_sub_rows <= 32)
+				midl.push_back(c);
+			else
+				giant.push_back(c);
+		}
+	if ((giant.empty() && midl.empty()) || ix->nrows < 1)
 		return 0;
 	/* the lists' own radii (around their centroids): what regrouping has to beat */
 	if (grow(ix->d_lrad, ix->d_lrad_n, (size_t) nc)) return NDBHIP_ERR_HIP;
@@ -1686,6 +1808,16 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 
 	for (int c : giant)
 		ncent_all += nsub_of[(size_t) c];
+	size_t		mid_rows = 0, mid_cents = 0;
+
+	for (int c : midl)
+	{
+		nsub_of[(size_t) c] = (uint32_t) ((ix->own_len[c] + g_s16_sub_rows - 1) / g_s16_sub_rows);
+		mid_rows += (size_t) ix->own_len[c];
+		mid_cents += nsub_of[(size_t) c];
+	}
+	ncent_all += mid_cents;
+	maxlen = std::max<int64_t>(maxlen, 1);
 	if (tmp.alloc(d_sid, (size_t) maxlen * sizeof(int))) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_dummy, (size_t) maxlen * sizeof(float))) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_dummy2, (size_t) maxlen * sizeof(float))) return NDBHIP_ERR_HIP;
@@ -1703,9 +1835,110 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 		HIP_TRY(hipMemsetAsync(d_dummy, 0, (size_t) maxlen * sizeof(float), g.stream));
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
-	struct Kept { int c; size_t cent0, sorted0; std::vector<int64_t> lens; };
+	struct Kept { int c; size_t cent0; const uint64_t *sorted; std::vector<int64_t> lens; };
 	std::vector<Kept> kept;
 	size_t		cbase = 0, sbase = 0;
+
+	if (!midl.empty())
+	{
+		/* the mid lists, all at once: sample rows gathered, every row to the nearest sample of its own list, the
+		 * lists' rows ordered by sublist; kept, as for the long lists, only where that shrinks the radius */
+		const int	nmid = (int) midl.size();
+		std::vector<MidDesc> md((size_t) nmid);
+		std::vector<uint32_t> mro((size_t) nmid + 1, 0);
+		std::vector<int64_t> which(mid_cents);
+		MidDesc    *d_md = nullptr;
+		uint32_t   *d_mro = nullptr, *d_mrad = nullptr, *d_mcnt = nullptr;
+		int64_t    *d_mwhich = nullptr, *d_keep = nullptr;
+		float	   *d_mcents = nullptr;
+		uint8_t    *d_msid = nullptr;
+		uint64_t   *d_msorted = nullptr;
+		size_t		c0 = 0;
+
+		for (int m = 0; m < nmid; m++)
+		{
+			const int	c = midl[(size_t) m];
+			const int64_t len = ix->own_len[c];
+			const uint32_t S = nsub_of[(size_t) c];
+
+			md[(size_t) m].row0 = ix->loc_off[c];
+			md[(size_t) m].len = (uint32_t) len;
+			md[(size_t) m].cent0 = (uint32_t) c0;
+			md[(size_t) m].S = S;
+			md[(size_t) m].sorted0 = mro[(size_t) m];
+			mro[(size_t) m + 1] = mro[(size_t) m] + (uint32_t) len;
+			for (uint32_t j = 0; j < S; j++)
+				which[c0 + j] = ix->loc_off[c] + (int64_t) (((__int128) len * j) / S);
+			c0 += S;
+		}
+		if (tmp.alloc(d_md, (size_t) nmid * sizeof(MidDesc))) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_mro, ((size_t) nmid + 1) * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_mrad, mid_cents * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_mcnt, mid_cents * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_mwhich, mid_cents * 8)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_keep, mid_cents * 8)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_mcents, mid_cents * (size_t) dim * sizeof(float))) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_msid, mid_rows)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_msorted, mid_rows * 8)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemcpyAsync(d_md, md.data(), (size_t) nmid * sizeof(MidDesc), hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(d_mro, mro.data(), ((size_t) nmid + 1) * 4, hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemcpyAsync(d_mwhich, which.data(), mid_cents * 8, hipMemcpyHostToDevice, g.stream));
+		HIP_TRY(hipMemsetAsync(d_mrad, 0, mid_cents * 4, g.stream));
+		HIP_TRY(hipMemsetAsync(d_mcnt, 0, mid_cents * 4, g.stream));
+		hipLaunchKernelGGL(k_rows_gather, dim3((unsigned) mid_cents), dim3(256), 0, g.stream, (const float *) ix->d_vecs, dim,
+						   (const int64_t *) d_mwhich, d_mcents);
+		hipLaunchKernelGGL(k_s16_mid_assign, dim3((unsigned) ((mid_rows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
+						   dim, (const MidDesc *) d_md, (const uint32_t *) d_mro, nmid, (const float *) d_mcents, d_msid, d_mrad, d_mcnt);
+		hipLaunchKernelGGL(k_s16_mid_sort, dim3((unsigned) nmid), dim3(256), 0, g.stream, (const MidDesc *) d_md,
+						   (const uint32_t *) d_mro, (const uint8_t *) d_msid, d_msorted);
+		std::vector<uint32_t> mrad(mid_cents), mcnt(mid_cents);
+		std::vector<int64_t> keepidx;
+
+		HIP_TRY(hipMemcpyAsync(mrad.data(), d_mrad, mid_cents * 4, hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipMemcpyAsync(mcnt.data(), d_mcnt, mid_cents * 4, hipMemcpyDeviceToHost, g.stream));
+		HIP_TRY(hipStreamSynchronize(g.stream));
+		for (int m = 0; m < nmid; m++)
+		{
+			const int	c = midl[(size_t) m];
+			const MidDesc &d = md[(size_t) m];
+			double		wr = 0.0;
+
+			for (uint32_t j = 0; j < d.S; j++)
+			{
+				float		r;
+
+				memcpy(&r, &mrad[d.cent0 + j], 4);
+				wr += (double) mcnt[d.cent0 + j] * (std::isfinite(r) ? (double) r : 3.0e38);
+			}
+			wr /= (double) d.len;
+			if (std::isfinite(lrad[(size_t) c]) && wr < 0.6 * (double) lrad[(size_t) c])
+			{
+				Kept		kp;
+
+				kp.c = c;
+				kp.cent0 = cbase;
+				kp.sorted = d_msorted + d.sorted0;
+				for (uint32_t j = 0; j < d.S; j++)
+				{
+					kp.lens.push_back((int64_t) mcnt[d.cent0 + j]);
+					keepidx.push_back((int64_t) (d.cent0 + j));
+				}
+				kept.push_back(std::move(kp));
+				cbase += d.S;
+			}
+			else
+				nsub_of[(size_t) c] = 1;
+		}
+		if (!keepidx.empty())
+		{
+			HIP_TRY(hipMemcpyAsync(d_keep, keepidx.data(), keepidx.size() * 8, hipMemcpyHostToDevice, g.stream));
+			hipLaunchKernelGGL(k_rows_gather, dim3((unsigned) keepidx.size()), dim3(256), 0, g.stream, (const float *) d_mcents, dim,
+							   (const int64_t *) d_keep, d_cents);
+			HIP_TRY(hipStreamSynchronize(g.stream));		/* keepidx is a local */
+		}
+		if (g_debug_s16)
+			fprintf(stderr, "s16 sublists: %zu of %d lists of %d .. 2048 rows are worth regrouping\n", kept.size(), nmid, g_s16_sub_min);
+	}
 
 	for (int c : giant)
 	{
@@ -1736,7 +1969,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 
 		kp.c = c;
 		kp.cent0 = cbase;
-		kp.sorted0 = sbase;
+		kp.sorted = d_sorted_all + sbase;
 		rc = pack_by_list(d_sid, len, 1, S, d_dummy, d_iota, d_dummy2, d_sorted_all + sbase, kp.lens);	/* (synchronises) */
 		if (rc)
 			return rc;
@@ -1791,7 +2024,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 		const int64_t len = ix->own_len[kp.c], row0 = ix->loc_off[kp.c];
 
 		hipLaunchKernelGGL(k_s16_sub_perm, dim3((unsigned) ((len + 255) / 256)), dim3(256), 0, g.stream,
-						   (const uint64_t *) (d_sorted_all + kp.sorted0), len, row0, ix->d_perm, ix->d_posof);
+						   kp.sorted, len, row0, ix->d_perm, ix->d_posof);
 		for (size_t j = 0; j < kp.lens.size(); j++)
 		{
 			sub_len[first[(size_t) kp.c] + j] = (uint32_t) kp.lens[j];

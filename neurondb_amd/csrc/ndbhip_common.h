@@ -192,8 +192,29 @@ ndb_replay_selection_host(const uint32_t *key, uint32_t *pos, uint8_t *taken, in
  *       a > thr^2 (1 + m) + E   ==>   D > thr^2 (1 + m)   ==>   d > thr      ("cannot be among the k nearest"),
  *       D_k <= a_(k) + E        ==>   d_k^2 <= (a_(k) + E)(1 + m)            (k-th smallest of each side).
  *     Inner product: the reference's -sum fl(q_i x_i) is within gamma_dim S of -q.x, so E_ip = (c_dot + gamma_dim) S.
+ *
+ * (8) The CENTRED pass (k_s16c_sweep, ndbhip_screen16c.h; L2, float4 rows).  Every bucket of rows (a list, or a
+ *     sublist of a regrouped list) has a centre c (the list's centroid, or the sublist's sample row).  With
+ *     qc = q - c, r = x - c (real numbers): |q - x|^2 = |qc - r|^2.  Stored: r~_i = fl32(x_i - c_i), one plane
+ *     h_r = fp16_rne(r~ 2^(14 - e_r)) (2 bytes per element, no lo plane), X2 = fl32(fp64 sum r~_i^2); per (query,
+ *     bucket) pair qc~_i = fl32(q_i - c_i), h_q, Q2 likewise.  The pass computes dot ~ qc~.r~ with ONE product
+ *     h_q h_x per element, one accumulator chain over all k-steps (no restart), and a = (Q2 + X2) - 2 dot.
+ *       centring:  |qc~_i - qc_i| <= u |qc_i|, same for r: ||qc~ - r~|^2 - |q - x|^2| <= 4 u (|qc~|^2 + |r~|^2) (1 + small)
+ *       rounding to one fp16:  |v_i - h_i| <= max(2^-11 |v_i|, 2^-25);
+ *         |v_q.v_x - sum h_q h_x| <= sum |dv_q||v_x| + |h_q||dv_x| <= (2^-11 + 2^-11 (1 + 2^-11) + 3 sqrt(dim) 2^-38) |v_q||v_x|
+ *                                 <= NDB_S16C_SPLIT |v_q||v_x|,  NDB_S16C_SPLIT = 2^-10 (1 + 2^-9)
+ *       accumulation, (4) with a chain of n = ceil(dim / 64) * 4 instructions:  <= 1.01 n NDB_MFMA_THETA |v_q||v_x|
+ *     so |dot - qc~.r~| <= c_cen(dim) |qc~||r~|, c_cen = NDB_S16C_SPLIT + 1.01 n 34 u, and as in (6)
+ *       |a - |q - x|^2| <= E = (c_cen + NDB_S16_NORMS + 4 u) (Q2 + X2) + NDB_S16_ABS     (per ELEMENT: its own Q2, X2)
+ *     What makes one plane enough is the size of the operands, not of the constant: for a row of the query's own
+ *     cluster |qc~||r~| is the product of two in-cluster distances (C2's clustered table: 3.9 x 2.8 against
+ *     |q||x| = 770), so E ~ 0.02 there — below what the two-plane uncentred pass reaches (0.04).
+ *     A candidate is left out when a - E > T with T = thr^2 (1 + m) (7); an emitted one carries lb = a - E and
+ *     ub = a + E, and the k-th smallest ub of distinct candidates, U, gives d_k^2 <= U (1 + m), hence
+ *     T = U (1 + m)^2 <= U (1 + 2.5 m).
  * ------------------------------------------------------------------------------------------------------------ */
 #define NDB_S16_U 5.9604645e-8f				/* 2^-24 */
+#define NDB_S16C_SPLIT (9.765625e-4f * 1.002f)	/* 2^-10 (1 + 2^-9), (8) */
 #define NDB_MFMA_THETA (34.0f * NDB_S16_U)		/* (4) */
 #define NDB_S16_SPLIT 1.9073486e-6f			/* 2^-19, (3) */
 #define NDB_S16_NORM 1.1920929e-7f			/* 2^-23 >= u (1 + dim 2^-29), (1) */
@@ -212,6 +233,14 @@ NDB_HD static inline float
 ndb_s16_refslack(int dim)
 {
 	return 2.0f * (float) (dim + 16) * NDB_S16_U;
+}
+/* (8): the centred one-plane pass; E of an element = ndb_s16c_ce(dim) (Q2 + X2) + NDB_S16_ABS */
+NDB_HD static inline float
+ndb_s16c_ce(int dim)
+{
+	const float n = (float) (((dim + 63) / 64) * 4);
+
+	return (NDB_S16C_SPLIT + 1.01f * 34.0f * n * NDB_S16_U + NDB_S16_NORMS + 4.0f * NDB_S16_U) * 1.0001f;
 }
 /* gamma_n = n u / (1 - n u), rounded up */
 NDB_HD static inline float

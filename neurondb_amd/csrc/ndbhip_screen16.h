@@ -674,7 +674,8 @@ template <int R, int H16>
 __global__ __launch_bounds__(64) void
 k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 		   const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, const float *__restrict__ qn2,
-		   const uint32_t *__restrict__ xmax_bits, int sub, float2 *__restrict__ qthr)
+		   const uint32_t *__restrict__ xmax_bits, int sub, float2 *__restrict__ qthr,
+		   int cen = 0 /* the centred sweep's threshold: thr^2 (1 + m) without an error term (ndbhip_screen16c.h) */ )
 {
 	const uint32_t q = blockIdx.x;
 	const uint32_t lane = threadIdx.x;
@@ -714,7 +715,7 @@ k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
 
 		if (thr == thr)			/* a NaN distance bounds nothing */
-			thrE = s16_thr_from_ref<R>(thr, e, dim);
+			thrE = s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
 	}
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
@@ -735,7 +736,8 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len, const int64_t *__restrict__ sub_loc,
 			   const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of, const float *__restrict__ subdist,
 			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ cdist, uint32_t cstride,
-			   const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr)
+			   const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr,
+			   int cen = 0)
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x;
@@ -839,7 +841,7 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
 
 		if (thr == thr)			/* a NaN distance bounds nothing */
-			thrE = s16_thr_from_ref<R>(thr, e, dim);
+			thrE = s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
 	}
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
@@ -927,14 +929,12 @@ s16_uniform_ptr(const unsigned char *p)
 	return (const unsigned char *) (((uint64_t) hi << 32) | lo);
 }
 
-template <int N> __device__ __forceinline__ void s16_wait_vm();
-template <> __device__ __forceinline__ void s16_wait_vm<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void s16_wait_vm<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-template <> __device__ __forceinline__ void s16_wait_vm<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-template <> __device__ __forceinline__ void s16_wait_vm<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-template <> __device__ __forceinline__ void s16_wait_vm<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-template <> __device__ __forceinline__ void s16_wait_vm<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-template <> __device__ __forceinline__ void s16_wait_vm<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void
+s16_wait_vm()
+{
+	static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
 
 /* one work item of the sweep, expanded once per batch (k_s16_items) so that a block finds its next item with one
  * load instead of a binary search over the lists */
@@ -952,7 +952,8 @@ struct S16Desc
  * 12.6 MB of query planes went round the 4 MB L2 once per row tile (hit rate 0.45 -> 0.59) */
 __global__ void
 k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ own_len,
-			int ncent, uint32_t rt, uint32_t cap, S16Desc *__restrict__ desc, unsigned int *__restrict__ flags)
+			int ncent, uint32_t rt, uint32_t cap, S16Desc *__restrict__ desc, unsigned int *__restrict__ flags,
+			uint32_t qtile = S16_QT /* (query, probe) pairs per tile */ )
 {
 	const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
 
@@ -974,7 +975,7 @@ k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ 
 	while (lo + 1 < (uint32_t) ncent && item_off[lo + 1] <= item)
 		lo++;
 	const uint32_t L = lo, local = item - item_off[L];
-	const uint32_t nqt = (cnt[L] + S16_QT - 1) / S16_QT, nrt = (own_len[L] + rt - 1) / rt;
+	const uint32_t nqt = (cnt[L] + qtile - 1) / qtile, nrt = (own_len[L] + rt - 1) / rt;
 	const uint32_t band = local / (8u * nqt);			/* bands of 8 row tiles: all but the last are full */
 	const uint32_t lb = local - band * 8u * nqt;
 	const uint32_t br = min(8u, nrt - 8u * band);
@@ -1682,7 +1683,7 @@ template <int R>
 __global__ __launch_bounds__(S16_NB) void
 k_s16_retarget(int dim, uint32_t k, float2 *__restrict__ qthr, unsigned int *__restrict__ ecount, uint32_t ecap,
 			   const uint32_t *__restrict__ bmin, unsigned int *__restrict__ active,
-			   unsigned int *__restrict__ flags)
+			   unsigned int *__restrict__ flags, int cen = 0 /* bmin holds upper bounds, the threshold no error term */ )
 {
 	__shared__ uint32_t keys[S16_NB];
 	const uint32_t q = blockIdx.x;
@@ -1712,7 +1713,10 @@ k_s16_retarget(int dim, uint32_t k, float2 *__restrict__ qthr, unsigned int *__r
 		const uint32_t tb = (mine & 0x80000000u) ? (mine & 0x7FFFFFFFu) : ~mine;
 		const float2 o = qthr[q];
 
-		qthr[q] = make_float2(fminf(o.x, s16_thr_from_a<R>(__uint_as_float(tb), o.y, dim)), o.y);
+		const float ak = __uint_as_float(tb);
+		const float nt = cen ? s16_up(s16_up(fmaxf(ak, 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))) : s16_thr_from_a<R>(ak, o.y, dim);
+
+		qthr[q] = make_float2(fminf(o.x, nt), o.y);
 	}
 	if (t == 0)
 	{
@@ -1734,7 +1738,10 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   const uint2 *__restrict__ erec, uint32_t ecap, int partial, ndbhip_cand *__restrict__ out_cand,
 			   int *__restrict__ out_ncand, int64_t *__restrict__ out_total, uint64_t *__restrict__ out_tids,
 			   float *__restrict__ out_dist, int *__restrict__ out_count, unsigned int *__restrict__ rec_counts,
-			   unsigned int *__restrict__ flags)
+			   unsigned int *__restrict__ flags,
+			   const float *__restrict__ eub = nullptr /* the centred sweep (ndbhip_screen16c.h): a record holds the
+														 * candidate's LOWER bound, eub its upper bound, and the
+														 * threshold carries no error term */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	TopkSmem	s = carve_topk_smem(smem_raw, S16_SURV_CAP, k);
@@ -1756,6 +1763,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		return;					/* uniform */
 	}
 	const uint2 *rec = erec + (size_t) q * ecap;	/* a few hundred records, read from L2 as often as needed */
+	const float *ubq = eub ? eub + (size_t) q * ecap : nullptr;
 	float		thrE = qthr[q].x;
 	const float e = qthr[q].y;
 
@@ -1765,7 +1773,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		/* only finite values stand for a candidate whose distance is known to within E (a NaN or an infinity is
 		 * what a row or a product beyond fp32 leaves behind: emitted, never counted) */
 		auto		ld = [&](uint32_t i, uint32_t &bits) -> bool {
-			bits = rec[i].y;
+			bits = ubq ? __float_as_uint(ubq[i]) : rec[i].y;
 			return (bits & 0x7FFFFFFFu) < 0x7F800000u;
 		};
 
@@ -1775,7 +1783,10 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			/* T = order key of the k-th smallest a: back to the float */
 			const uint32_t tb = (T & 0x80000000u) ? (T & 0x7FFFFFFFu) : ~T;
 
-			thrE = fminf(thrE, s16_thr_from_a<R>(__uint_as_float(tb), e, dim));
+			if (ubq)
+				thrE = fminf(thrE, s16_up(s16_up(fmaxf(__uint_as_float(tb), 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))));
+			else
+				thrE = fminf(thrE, s16_thr_from_a<R>(__uint_as_float(tb), e, dim));
 		}
 	}
 	if (tid == 0)

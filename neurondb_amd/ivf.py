@@ -98,6 +98,11 @@ class IvfIndex:
         self.ncent = self.nlists
         return iters.value
 
+    def prepare(self, strategy=1):
+        """ndbhip_ivf_prepare: lay out now what the first batched scan would prepare lazily (sublists, fp16 planes,
+        norms, radii), so the index is searchable at full speed when the build returns."""
+        check(lib().ndbhip_ivf_prepare(self._h, int(strategy)))
+
     def build_sharded_device(self, d_rows, d_tids, max_iter=50):
         """ambuild over the ranks of the library's communicator (ndbhip_ivf_build_sharded): this rank passes its
         contiguous slice of the table in heap order and ends up holding its own lists' rows.  Returns (Lloyd

@@ -112,13 +112,21 @@ def test_a_nan_row_only_affects_the_queries_that_probe_it(lib):
     ix.close()
 
 
-def test_overflowing_queries_fall_back_and_stay_exact(lib):
-    """Rows 300 from the origin and 0.01 apart: |q|^2 + |x|^2 - 2 q.x cancels almost completely, nothing can be
-    excluded, every query overflows its records -> the batch is rerun on the fp32 screen; still the oracle's bits."""
+@pytest.mark.parametrize("centered", [0, 1])
+def test_overflowing_queries_fall_back_and_stay_exact(lib, centered):
+    """centered = 0 (the two-plane sweep over the rows as they are): rows 300 from the origin and 0.01 apart —
+    |q|^2 + |x|^2 - 2 q.x cancels almost completely, nothing can be excluded.  centered = 1 (the default: rows and
+    queries minus the list's centroid, which removes exactly that cancellation): the rows of a list are copies of
+    one another, so every candidate ties.  Either way every query overflows its records -> the batch is rerun on
+    the fp32 screen; still the oracle's bits."""
     rng = np.random.default_rng(3)
     dim, n, nlists, nq = 64, 6000, 10, 140
     center = rng.standard_normal(dim).astype(np.float32) * 300.0
-    base = (center + rng.standard_normal((n, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+    if centered:
+        proto = (center + rng.standard_normal((nlists, dim)).astype(np.float32) * 1e-2).astype(np.float32)
+        base = proto[rng.integers(0, nlists, n)].copy()
+    else:
+        base = (center + rng.standard_normal((n, dim)).astype(np.float32) * 1e-2).astype(np.float32)
     q = (center + rng.standard_normal((nq, dim)).astype(np.float32) * 1e-2).astype(np.float32)
     cent = base[rng.choice(n, nlists, replace=False)].copy()
     asg = ((base[:, None, :].astype(np.float64) - cent[None]) ** 2).sum(-1).argmin(1)
@@ -130,8 +138,12 @@ def test_overflowing_queries_fall_back_and_stay_exact(lib):
     img = oracle_image(a)
     lib.check(lib.lib().ndbhip_set_scan_mode(5))
     lib.check(lib.lib().ndbhip_set_option(b"screen16_records", 256))
+    lib.check(lib.lib().ndbhip_set_option(b"screen16_centered", centered))
     lib.check(lib.lib().ndbhip_stats_reset())
-    t, d, c = ix.search(q, 1, nlists, 10)
+    try:
+        t, d, c = ix.search(q, 1, nlists, 10)
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_centered", 1))
     st = lib.stats()
     et, ed, ec, _ = oracle_search_batch(img, q, 1, nlists, 10)
     assert_same_results(t, d, c, et, ed, ec)
@@ -288,7 +300,7 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
             ix.close()
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", 1))
-        lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 2048))
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 256))
 
 
 def test_sublists_on_slice_shards_merge_to_the_unsharded_result(lib):
@@ -339,4 +351,4 @@ def test_sublists_on_slice_shards_merge_to_the_unsharded_result(lib):
             sh.close()
         full.close()
     finally:
-        lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 2048))
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 256))
