@@ -100,6 +100,10 @@ typedef struct ndbhip_stats
 	uint64_t	screen16_fallbacks;	/* ... that overflowed a query's record capacity and were rerun on the fp32 screen */
 	uint64_t	pairs_pruned;		/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep */
 	uint64_t	rows_swept;			/* candidate rows of the pairs the sweep did multiply (<= rows_scored) */
+	uint64_t	plane_bytes;		/* bytes of row planes the sweeps had to read: every touched 128-row tile once per batch */
+	uint64_t	cent_screen_batches;	/* sub-batches whose centroid scan ran on the matrix cores (k_cent_select) */
+	uint64_t	prepares;			/* full layouts of the sweep's operands (planes, sublists, radii): once per mirror unless ... */
+	uint64_t	prepare_updates;	/* ... appends were folded into the existing layout instead (rows added in place) */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);
@@ -132,11 +136,14 @@ int			ndbhip_set_scan_mode(int mode);
  *                             where that shrinks the radius — and a (query, probe) pair expands only to the sublists the
  *                             triangle inequality cannot exclude (csrc/ndbhip_screen16.h, "Sublists")
  *   "screen16_tighten"  1     a query's threshold is lowered inside the sweep every 128 emitted records (0: only between the two rounds)
+ *   "cent_screen16"     1     screened batches, 256 .. 4096 centroids: |q - centroid|^2 of every pair from the matrix-core sweep, the
+ *                             reference's arithmetic only for the centroids near the nprobe-th (k_cent_select); 0: the exact centroid scan
  *   "screen16_centered" 1     L2, float4 rows: the sweep multiplies (query - centre) with (row - centre) of the row's list / sublist,
  *                             ONE fp16 plane of each (2 bytes per row element instead of 4); the error term scales with the distances
  *                             to the centre instead of the vectors' norms (csrc/ndbhip_screen16c.h, csrc/ndbhip_common.h (8));
  *                             0: the two-plane sweep over the rows as they are
  *   "screen16c_qb"      0     (query, list) pairs per tile of the centred sweep / 32: 4 | 1, 0 = chosen from the previous batch's pairs per list
+ *   "screen16c_seeds"   0     rows per query whose upper bounds make its first threshold: 32 | 64, 0 = 32 for k <= 20, else 64
  *   "screen16c_nbuf"    0     ring depth of the centred sweep: 2 | 3, 0 = the tile geometry's default
  *   "build_screen16"    1     build / ndbhip_ivf_assign_device (>= 4096 rows): the assignment is screened on the matrix cores (0: exact kernels)
  *   "block_cache"       1     keep up to 4 freed packed-row blocks (>= 64 MiB) for the next build (0: release them now, stop caching)

@@ -272,6 +272,7 @@ ndbhip_stats_get(ndbhip_stats *out)
 		g.stats.rows_emitted = c[4];
 		g.stats.pairs_pruned = c[5];
 		g.stats.rows_swept = c[6];
+		g.stats.plane_bytes = c[7];
 	}
 	*out = g.stats;
 	return NDBHIP_OK;
@@ -381,7 +382,8 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			   const uint32_t *__restrict__ glob_len, const uint32_t *__restrict__ own_lo,
 			   const uint32_t *__restrict__ own_len, uint64_t cap,
 			   int dim, int *__restrict__ probes, uint32_t *__restrict__ cand_off,
-			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters, int full_sort = 1)
+			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters, int full_sort = 1,
+			   const uint8_t *__restrict__ only = nullptr /* serve just the queries marked here (k_cent_select's leftovers) */ )
 {
 	__shared__ uint32_t hist[256];
 	__shared__ uint32_t sh[16];
@@ -396,6 +398,8 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 	int			npr_eff = npr < ncmp ? npr : ncmp;
 	uint32_t	T, m_less, kk, cnt_eq;
 
+	if (only && !only[q])
+		return;					/* uniform */
 	if (npr_eff < 0)
 		npr_eff = 0;
 	/* valid = strictly below FLT_MAX (bestDist starts at FLT_MAX: ivf_am.c:1689, 1706) */
@@ -730,7 +734,9 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 __global__ __launch_bounds__(1024) void
 k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
 			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
-			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv, uint32_t rt)
+			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv, uint32_t rt,
+			   int exact_runs = 0 /* runs of exactly nitems / 8 items (a list may straddle two runs): for a sweep whose blocks
+								   * walk their XCD's run at a fixed stride and cannot help another run out */ )
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
@@ -793,7 +799,9 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		const uint32_t nitems = sb[1023];
 		uint32_t	r = t == 0 ? 0u : nitems;
 
-		if (t > 0 && t < 8)
+		if (t > 0 && t < 8 && exact_runs)
+			r = (uint32_t) (((uint64_t) nitems * (uint32_t) t) >> 3);
+		else if (t > 0 && t < 8)
 		{
 			const uint32_t target = (uint32_t) (((uint64_t) nitems * (uint32_t) t) >> 3);
 			uint32_t	lo = 0, hi = (uint32_t) ncent;	/* smallest L with item_off[L] >= target */
@@ -1391,6 +1399,31 @@ k_ivf_scan_grouped(IvfDev ix, const float *__restrict__ qblock, const uint32_t *
 /* host side: IVF mirror                                               */
 /* ================================================================== */
 
+/* see s16mat_prepare / s16mat_run (ndbhip_build.h) */
+struct S16Mat
+{
+	unsigned char *planes = nullptr; size_t planes_n = 0;
+	float	   *rn2 = nullptr;		size_t rn2_n = 0;
+	int16_t    *rexp = nullptr;		size_t rexp_n = 0;
+	uint32_t   *xmax = nullptr;		size_t xmax_n = 0;		/* [0] largest norm (float bits), [2..3] block offsets */
+	int64_t    *loc = nullptr;		size_t loc_n = 0;		/* {0, n} */
+	uint32_t   *meta = nullptr;		size_t meta_n = 0;		/* the sweep's tables for (n vectors x nq queries) */
+	PairRec    *pairs = nullptr;	size_t pairs_n = 0;
+	uint4	   *desc = nullptr;		size_t desc_n = 0;		/* S16Desc[] */
+	unsigned int *heads = nullptr;	size_t heads_n = 0;
+	unsigned char *zero = nullptr;	size_t zero_n = 0;
+	int			nq = -1;			/* batch size the tables were built for */
+	int			n = 0;
+	const float *src = nullptr;
+	void release()
+	{
+		void	   *ptrs[] = {planes, rn2, rexp, xmax, loc, meta, pairs, desc, heads, zero};
+
+		for (void *p : ptrs)
+			if (p) (void) hipFree(p);
+	}
+};
+
 struct ndbhip_ivf
 {
 	int			dim = 0;
@@ -1466,6 +1499,9 @@ struct ndbhip_ivf
 	_Float16   *w_qcplanes = nullptr; size_t w_qcplanes_n = 0;
 	float	   *w_qcn2 = nullptr;	size_t w_qcn2_n = 0;
 	int		   *w_qcexp = nullptr;	size_t w_qcexp_n = 0;
+	uint32_t   *w_pslot = nullptr;	size_t w_pslot_n = 0;	/* [3][qc_cap] per pair slot: query, first candidate position, visible rows */
+	float	   *w_amat = nullptr;	size_t w_amat_n = 0;	/* [nq][astride] the sweep's |q - centroid|^2 (k_cent_select) */
+	uint8_t    *w_cfull = nullptr;	size_t w_cfull_n = 0;	/* [nq] queries k_cent_select left to k_probe_select */
 	float		s16c_density = -1.0f;	/* pairs per bucket that had any, previous batch (-1: none yet) */
 	/* sublists (ndbhip_screen16.h): the planes' own grouping of the rows of long lists */
 	bool		s16_sub = false;
@@ -1482,19 +1518,9 @@ struct ndbhip_ivf
 	int64_t    *d_perm = nullptr;		size_t d_perm_n = 0;		/* [nrows] plane row -> mirror row */
 	uint32_t   *d_posof = nullptr;		size_t d_posof_n = 0;		/* [nrows] plane row -> index in its list */
 	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] squared distances to the centres (sweep MODE 3) */
-	/* the centres of the regrouped lists as one list of the matrix-core sweep (its MODE 3 gives every query's
-	 * squared distance to every centre) */
-	unsigned char *d_cplanes = nullptr;	size_t d_cplanes_n = 0;
-	float	   *d_crn2 = nullptr;		size_t d_crn2_n = 0;
-	int16_t    *d_crexp = nullptr;		size_t d_crexp_n = 0;
-	uint32_t   *d_cxmax = nullptr;		size_t d_cxmax_n = 0;
-	int64_t    *d_dm_loc = nullptr;		size_t d_dm_loc_n = 0;		/* {0, nsub_g} */
-	uint32_t   *d_dm_meta = nullptr;	size_t d_dm_meta_n = 0;		/* the sweep's tables for (centres x dm_nq queries) */
-	PairRec    *d_dm_pairs = nullptr;	size_t d_dm_pairs_n = 0;
-	uint4	   *d_dm_desc = nullptr;	size_t d_dm_desc_n = 0;		/* S16Desc[] */
-	unsigned int *d_dm_heads = nullptr;	size_t d_dm_heads_n = 0;
-	unsigned char *d_dm_zero = nullptr;	size_t d_dm_zero_n = 0;
-	int			dm_nq = -1;				/* batch size the tables were built for */
+	S16Mat		dm_sub;				/* the centres of the regrouped lists: every query's squared distance to every one of them */
+	S16Mat		dm_cent;			/* the index's centroids: the batch centroid scan on the matrix cores (ndbhip_screen16.h) */
+	bool		dm_cent_valid = false;
 	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
@@ -1594,11 +1620,12 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->d_cplanes, ix->d_crn2, ix->d_crexp, ix->d_cxmax, ix->d_dm_loc, ix->d_dm_meta, ix->d_dm_pairs, ix->d_dm_desc,
-			ix->d_dm_heads, ix->d_dm_zero, ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
+		ix->dm_sub.release();
+		ix->dm_cent.release();
 		if (ix->pin) (void) hipHostFree(ix->pin);
 	}
 	delete ix;
@@ -1611,6 +1638,7 @@ ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncent)
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!ix || !centroids || ncent < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	ix->dm_cent_valid = false;
 	if (ix->d_centroids)
 		HIP_TRY(hipFree(ix->d_centroids));
 	ix->d_centroids = nullptr;
@@ -2367,6 +2395,7 @@ static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - 
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
 static int	g_s16_cen = 1;		/* L2 on float4 rows: the centred one-plane sweep (ndbhip_screen16c.h; "screen16_centered", 0: the two-plane sweep) */
 static int	g_s16c_qb = 0;		/* pairs per tile of the centred sweep / 32: 4 or 1; 0 = from the previous batch's pairs per bucket ("screen16c_qb") */
+static int	g_s16c_seeds = 0;	/* rows whose upper bounds give a query its first threshold, 0 = 32 (k <= 20) or 64 ("screen16c_seeds") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
 static bool
@@ -2387,6 +2416,10 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 
 static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host);	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
+static int	s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim);	/* ndbhip_build.h */
+static int	s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr,
+					   int nq, float *out, uint32_t stride);
+static int	g_cent_s16 = 1;		/* screened batches: the centroid scan on the matrix cores + exact arithmetic near the nprobe-th ("cent_screen16") */
 static int	g_s16_sublists = 1;	/* long lists regrouped into sublists ("screen16_sublists") */
 static int	g_s16_sub_min = 256;	/* lists longer than this are regrouped where that shrinks their radius ("screen16_sub_min") */
 static int	g_s16_sub_rows = 128;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
@@ -2423,6 +2456,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		std::vector<uint32_t> bo;
 		uint64_t	nb = 0;
 
+		g.stats.prepares++;
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = lay_cfg;
 		if (sub_cfg != 0 && !ix->f16)
@@ -2536,8 +2570,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	if (grow(ix->w_bmin, ix->w_bmin_n, (size_t) nq * S16_NB)) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipMemsetAsync(ix->w_ecount, 0, ((size_t) 3 * nq + 8) * sizeof(unsigned int), g.stream));
 	HIP_TRY(hipMemsetAsync(ix->w_bmin, 0xFF, (size_t) nq * S16_NB * sizeof(uint32_t), g.stream));
-	hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, dim, dimp,
-					   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
+	/* (the queries' planes, norms and exponents — k_s16_qprep — are the caller's: ivf_search_chunk, which may
+	 * already have needed them for the centroid scan) */
 #define S16_BY_RH(KERNEL, ...)                                                                  \
 	do {                                                                                        \
 		if (R == R_IVF_IP)                                                                      \
@@ -2557,7 +2591,15 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
 	const bool	seed_by_sublist = ix->s16_sub && R == R_IVF_L2 && g_s16_prune && ix->nsub_g > 0;
 
-	if (!seed_by_sublist)
+	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
+	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
+
+	if (!seed_by_sublist && cen)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<false>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
+						   (uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
+						   (const int64_t *) nullptr, (const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
+						   0u, (const float *) nullptr, (const float *) nullptr, 0u, ix->w_qthr);
+	else if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
 				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr, cen ? 1 : 0);
 
@@ -2611,6 +2653,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (grow(ix->w_qcplanes, ix->w_qcplanes_n, (size_t) qc_cap * dimp)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qcn2, ix->w_qcn2_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qcexp, ix->w_qcexp_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_pslot, ix->w_pslot_n, (size_t) 3 * qc_cap)) return NDBHIP_ERR_HIP;
 	}
 #define S16_SWEEP_L(RR, HH, ...)                                                                                  \
 	do {                                                                                                          \
@@ -2677,6 +2720,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				if (rc)
 					return rc;
 				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
+				if (cen)
+					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<true>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
+									   (uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
+									   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
+									   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
+				else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_L2>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
 								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
@@ -2688,7 +2738,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							   (const uint32_t *) ix->d_cxmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
+							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
 							   (PairRec *) nullptr);
 		}
 		else
@@ -2698,13 +2748,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(k_s16_swept_rows, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) cnt,
 							   (const uint32_t *) ix->d_sub_len, ncs, g.d_counters + 6);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
-						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64));
+						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0);
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							   (const uint32_t *) ix->d_cxmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs);
+							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
@@ -2719,7 +2769,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			if (grow(ix->w_s16desc, ix->w_s16desc_n, cap_items * 4)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_s16_items, dim3((unsigned) ((cap_items + 255) / 256)), dim3(256), 0, g.stream,
 							   (const uint32_t *) item_off, (const uint32_t *) cnt, ds.own_len, ncs, (uint32_t) s16_rt,
-							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags, s16_qt);
+							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags, s16_qt,
+							   round == 0 ? g.d_counters + 7 : (unsigned long long *) nullptr,
+							   (uint32_t) (cen ? (dimp / S16C_CH) * 4096 : (dimp / S16_CH) * (ix->f16 ? 2048 : 4096)));
 			desc_cap = (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu);
 		}
 		if (cen)
@@ -2729,7 +2781,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(k_s16c_qcprep, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d_q, dim, dimp,
 							   (const PairRec *) ix->w_pairs, (const uint32_t *) pair_off, ncs, (const float *) ix->d_centroids,
 							   sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
-							   ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, qc_cap, flags, round == 0 ? flags + 4 : (unsigned int *) nullptr,
+							   ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_pslot, ix->w_pslot + qc_cap, ix->w_pslot + 2 * (size_t) qc_cap,
+							   lco, npr, qc_cap, flags, round == 0 ? flags + 4 : (unsigned int *) nullptr,
 							   (const uint32_t *) cnt);
 		}
 		if (g_debug_s16 && round == 0)
@@ -2746,16 +2799,19 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (cen)
 		{
 			const float cE = ndb_s16c_ce(dim);
-			const int	nbuf = g_s16c_nbuf ? g_s16c_nbuf : (c_qb == 1 ? 3 : 2);
+			/* (a ring of 3 looks two chunks ahead, which must not reach past the NEXT item: dims <= 64 are one chunk) */
+			const int	nbuf = dimp / S16C_CH < 2 ? 2 : (g_s16c_nbuf ? g_s16c_nbuf : (c_qb == 1 ? 3 : 2));
 
 #define S16C_SWEEP_L(QB, NB, DB)                                                                                     \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB == 1 || NB == 2) ? 2 : 1)), dim3(256), 0, g.stream, ds, \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB == 1 || NB == 2) ? 2 : 1)), dim3(256), 0, g.stream, \
+							   dim, ncs, (const int64_t *) ds.loc_off, (const uint32_t *) ds.own_len,                         \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
-							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (float2 *) ix->w_qthr, lco, npr,        \
-							   (const uint32_t *) cnt, (const uint32_t *) pair_off, (const S16Desc *) ix->w_s16desc,          \
-							   (const PairRec *) ix->w_pairs, next_item, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
-							   ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,    \
+							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (const uint32_t *) ix->w_pslot,            \
+							   (const uint32_t *) (ix->w_pslot + qc_cap), (const uint32_t *) (ix->w_pslot + 2 * (size_t) qc_cap), \
+							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
+							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
+							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr, cE, qc_cap)
 			if (g_s16_debug == 1)
 				S16C_SWEEP_L(4, 2, 1);
@@ -2980,11 +3036,19 @@ ndbhip_set_option(const char *name, int value)
 		g_s16_debug = value;
 	else if (!strcmp(name, "screen16_centered"))
 		g_s16_cen = value != 0;
+	else if (!strcmp(name, "cent_screen16"))
+		g_cent_s16 = value != 0;
 	else if (!strcmp(name, "screen16c_qb"))
 	{
 		if (value != 0 && value != 1 && value != 4)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_qb must be 0 (auto), 1 or 4");
 		g_s16c_qb = value;
+	}
+	else if (!strcmp(name, "screen16c_seeds"))
+	{
+		if (value != 0 && value != 32 && value != 64)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_seeds must be 0 (default), 32 or 64");
+		g_s16c_seeds = value;
 	}
 	else if (!strcmp(name, "screen16c_nbuf"))
 	{
@@ -3092,7 +3156,66 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
 						   ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr);
 	}
-	else
+	/* the matrix-core screen serves this sub-batch: the queries' fp16 planes first (the centroid scan below and the
+	 * sweep both multiply them) */
+	const bool	s16_here = full && allow_s16 && ivf_s16_wanted(ix, nq, ivf_recipe(strategy), k);
+	bool		cent_done = false;
+
+	if (s16_here)
+	{
+		const int	dimp = (ix->dim + 63) & ~63;
+
+		if (grow(ix->w_qplanes, ix->w_qplanes_n, (size_t) nq * dimp * 4)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_qn2, ix->w_qn2_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_qexp, ix->w_qexp_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, ix->dim, dimp,
+						   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
+	}
+	if (!d_probes_in && s16_here && g_cent_s16 && ncmp >= 256 && ncmp <= 4096 && npr <= NDBHIP_MAX_NPROBE)
+	{
+		/* HOT LOOP 1 for a screened batch: |q - centroid|^2 of every pair from the two-plane sweep (MODE 3), the
+		 * reference's arithmetic for the centroids near the nprobe-th only (k_cent_select) */
+		const uint32_t astride = (uint32_t) ((ncmp + 63) & ~63);
+
+		if (!ix->dm_cent_valid || ix->dm_cent.n != ncmp || ix->dm_cent.src != ix->d_centroids)
+		{
+			const int	rc = s16mat_prepare(ix->dm_cent, ix->d_centroids, ncmp, ix->dim);
+
+			if (rc)
+				return rc;
+			ix->dm_cent_valid = true;
+		}
+		if (grow(ix->w_amat, ix->w_amat_n, (size_t) nq * astride)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_cfull, ix->w_cfull_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		{
+			const int	rc = s16mat_run(ix->dm_cent, ix->dim, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq, ix->w_amat, astride);
+
+			if (rc)
+				return rc;
+		}
+#define CENT_SELECT_L(PER)                                                                                          \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cent_select<PER>), dim3(nq), dim3(64), 0, g.stream, (const float *) ix->w_amat, astride, \
+						   (const float *) ix->w_qn2, (const uint32_t *) ix->dm_cent.xmax, d_q, (const float *) d.centroids, ix->dim, \
+						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,                          \
+						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->w_cdist, cstride, w_probes, ix->w_candoff, \
+						   lco_w, ix->w_cfull)
+		if (ncmp <= 1024)
+			CENT_SELECT_L(16);
+		else if (ncmp <= 2048)
+			CENT_SELECT_L(32);
+		else
+			CENT_SELECT_L(64);
+		/* (a query with too many near-ties, or fewer than nprobe finite bounds, had all its distances computed
+		 * exactly and is selected the old way) */
+		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,
+						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,
+						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
+						   w_probes, ix->w_candoff, lco_w, g.d_counters, 1, (const uint8_t *) ix->w_cfull);
+		g.stats.cent_screen_batches++;
+		cent_done = true;
+	}
+	if (!d_probes_in && !cent_done)
 	{
 		/* HOT LOOP 1: query x centroid, always L2 (ivf_am.c:1676-1680); a small batch spreads its
 		 * 64-centroid tiles over more CUs (one wave per block) */

@@ -1264,6 +1264,7 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	lap("frees");
 
 	/* adopt: centroids + packed lists become the index */
+	ix->dm_cent_valid = false;
 	if (ix->d_centroids)
 		HIP_TRY(hipFree(ix->d_centroids));
 	ix->d_centroids = d_cent;
@@ -1576,6 +1577,7 @@ ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_
 
 	for (int L = 0; L < k; L++)
 		owned[(size_t) L] = owner[(size_t) L] == me;
+	ix->dm_cent_valid = false;
 	if (ix->d_centroids)
 		(void) hipFree(ix->d_centroids);
 	ix->d_centroids = d_cent;
@@ -1633,6 +1635,85 @@ k_s16_assigned_radius(const float *__restrict__ rows, int64_t n, int dim, const 
 		if (bits > __atomic_load_n(&rad_bits[sd], __ATOMIC_RELAXED))
 			atomicMax(&rad_bits[sd], bits);
 	}
+}
+
+/*
+ * A dense block of n vectors (sublist centres; the index's centroids) as ONE list of the two-plane sweep, whose
+ * MODE 3 gives every query's squared distance to every one of them within the sweep's own error bound
+ * s16_e(dim, |q|^2, xmax) — a (queries x vectors x dim) contraction at matrix-core speed where the exact recipe
+ * would run on the vector ALU.  The sweep's tables depend on (n, batch size) only and are kept.
+ */
+static int
+s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim)
+{
+	const int	dimp = (dim + 63) & ~63;
+	const size_t cblk = ((size_t) n + 31) / 32;
+	const int64_t hloc[2] = {0, (int64_t) n};
+	const uint32_t hblk[2] = {0, (uint32_t) cblk};
+
+	if (grow(M.planes, M.planes_n, (cblk + 8) * (size_t) (dimp / S16_CH) * 4096)) return NDBHIP_ERR_HIP;
+	if (grow(M.rn2, M.rn2_n, (size_t) n)) return NDBHIP_ERR_HIP;
+	if (grow(M.rexp, M.rexp_n, (size_t) n)) return NDBHIP_ERR_HIP;
+	if (grow(M.xmax, M.xmax_n, (size_t) 4)) return NDBHIP_ERR_HIP;		/* [0] max norm, [2..3] block offsets */
+	if (grow(M.loc, M.loc_n, (size_t) 2)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemsetAsync(M.planes, 0, (cblk + 8) * (size_t) (dimp / S16_CH) * 4096, g.stream));
+	HIP_TRY(hipMemsetAsync(M.xmax, 0, 16, g.stream));
+	HIP_TRY(hipMemcpyAsync(M.loc, hloc, sizeof(hloc), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(M.xmax + 2, hblk, sizeof(hblk), hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_s16_row_prep<0>, dim3((unsigned) ((n + 3) / 4)), dim3(256), 0, g.stream, (const void *) d_src,
+					   (int64_t) n, dim, dimp, (const int64_t *) M.loc, (const uint32_t *) (M.xmax + 2), 1,
+					   M.planes, M.rn2, M.rexp, M.xmax, (const int64_t *) nullptr);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));		/* hloc / hblk are locals */
+	M.nq = -1;
+	M.n = n;
+	M.src = d_src;
+	return 0;
+}
+
+static int
+s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr, int nq,
+		   float *out, uint32_t stride)
+{
+	const int	ng = M.n, dimp = (dim + 63) & ~63;
+	const uint32_t nrt = (uint32_t) ((ng + 127) / 128), nqt = (uint32_t) ((nq + S16_QT - 1) / S16_QT), nitems = nrt * nqt;
+	const size_t mw = NDB_ASG_META(nq);
+
+	if (M.nq != nq)
+	{
+		if (grow(M.meta, M.meta_n, 2 * mw)) return NDBHIP_ERR_HIP;
+		if (grow(M.pairs, M.pairs_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		if (grow(M.desc, M.desc_n, (size_t) nitems)) return NDBHIP_ERR_HIP;
+		if (grow(M.heads, M.heads_n, (size_t) 8 * NDB_QHEAD_STRIDE)) return NDBHIP_ERR_HIP;
+		if (grow(M.zero, M.zero_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(M.zero, 0, (size_t) nq, g.stream));
+		/* the build's table kernel with the roles it has there: the "rows" are the vectors, the "centroids" the queries */
+		hipLaunchKernelGGL(k_assign_tables, dim3(1), dim3(64), 0, g.stream, (const unsigned char *) M.zero, nq, (uint32_t) ng,
+						   (uint32_t) ng, M.pairs, M.meta, M.meta + mw);
+		hipLaunchKernelGGL(k_s16_items, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, (const uint32_t *) (M.meta + 6),
+						   (const uint32_t *) (M.meta + 3), (const uint32_t *) (M.meta + 2), 1, 128u, nitems,
+						   (S16Desc *) M.desc, M.heads + 8 * NDB_QHEAD_STRIDE - 1);
+		M.nq = nq;
+	}
+	HIP_TRY(hipMemsetAsync(M.heads, 0, (size_t) 8 * NDB_QHEAD_STRIDE * sizeof(unsigned int), g.stream));
+	const uint32_t *m32 = M.meta;
+	IvfDev		dv = {};
+
+	dv.vecs = M.src;
+	dv.loc_off = M.loc;
+	dv.own_len = m32 + 2;
+	dv.glob_len = m32 + 2;
+	dv.dim = dim;
+	dv.ncent = 1;
+	dv.nlists = 1;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 3>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
+					   (const unsigned char *) M.planes, m32, (const float *) M.rn2, (const int16_t *) M.rexp,
+					   qplanes, (uint32_t) dimp * 4u, qn2, qexp, qthr, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) M.desc,
+					   (const PairRec *) M.pairs, M.heads, m32 + 8, (unsigned int *) nullptr,
+					   reinterpret_cast<uint2 *>(out), stride, (uint32_t *) nullptr, 0, dimp / S16_CH, nitems, 0u,
+					   (const uint32_t *) nullptr);
+	HIP_TRY(hipGetLastError());
+	return 0;
 }
 
 /* ---- lists of a few hundred to 2048 rows ("mid" lists): all of them regrouped in three launches ---- */
@@ -2075,26 +2156,10 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 					   (const float *const *) ix->d_sub_cptr, ix->d_sub_rad);
 	/* the centres of the regrouped lists as one list of the matrix-core sweep: planes, norms, exponents */
 	{
-		const int	dimp = (dim + 63) & ~63;
-		const size_t cblk = (nsub_g + 31) / 32;
-		const int64_t hloc[2] = {0, (int64_t) nsub_g};
-		const uint32_t hblk[2] = {0, (uint32_t) cblk};
+		const int	rc = s16mat_prepare(ix->dm_sub, ix->d_subcent, (int) nsub_g, dim);
 
-		if (grow(ix->d_cplanes, ix->d_cplanes_n, (cblk + 8) * (size_t) (dimp / S16_CH) * 4096)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_crn2, ix->d_crn2_n, nsub_g)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_crexp, ix->d_crexp_n, nsub_g)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_cxmax, ix->d_cxmax_n, (size_t) 4)) return NDBHIP_ERR_HIP;		/* [0] max norm, [2..3] block offsets */
-		if (grow(ix->d_dm_loc, ix->d_dm_loc_n, (size_t) 2)) return NDBHIP_ERR_HIP;
-		HIP_TRY(hipMemsetAsync(ix->d_cplanes, 0, (cblk + 8) * (size_t) (dimp / S16_CH) * 4096, g.stream));
-		HIP_TRY(hipMemsetAsync(ix->d_cxmax, 0, 16, g.stream));
-		HIP_TRY(hipMemcpyAsync(ix->d_dm_loc, hloc, sizeof(hloc), hipMemcpyHostToDevice, g.stream));
-		HIP_TRY(hipMemcpyAsync(ix->d_cxmax + 2, hblk, sizeof(hblk), hipMemcpyHostToDevice, g.stream));
-		hipLaunchKernelGGL(k_s16_row_prep<0>, dim3((unsigned) ((nsub_g + 3) / 4)), dim3(256), 0, g.stream, (const void *) ix->d_subcent,
-						   (int64_t) nsub_g, dim, dimp, (const int64_t *) ix->d_dm_loc, (const uint32_t *) (ix->d_cxmax + 2), 1,
-						   ix->d_cplanes, ix->d_crn2, ix->d_crexp, ix->d_cxmax, (const int64_t *) nullptr);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(g.stream));		/* hloc / hblk are locals */
-		ix->dm_nq = -1;
+		if (rc)
+			return rc;
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));			/* the host tables are locals */
 	ix->nsub = (int) nsub;
@@ -2108,55 +2173,16 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 
 /* squared distances of every query of the batch to every centre of the regrouped lists, as the matrix-core sweep
  * computes them (k_s16_sweep MODE 3 over the centres' planes; the queries' planes are the batch's): w_subdist
- * [nq][*sstride], each within s16_e(dim, |q|^2, largest centre norm) of the real value.  The sweep's tables
- * depend on the batch size only and are kept. */
+ * [nq][*sstride], each within s16_e(dim, |q|^2, largest centre norm) of the real value. */
 static int
 ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride)
 {
-	const int	ng = ix->nsub_g, dim = ix->dim, dimp = (dim + 63) & ~63;
-	const uint32_t st = (uint32_t) ((ng + 63) & ~63);
-	const uint32_t nrt = (uint32_t) ((ng + 127) / 128), nqt = (uint32_t) ((nq + S16_QT - 1) / S16_QT), nitems = nrt * nqt;
-	const size_t mw = NDB_ASG_META(nq);
+	const uint32_t st = (uint32_t) ((ix->nsub_g + 63) & ~63);
 
 	(void) d_q;
 	if (grow(ix->w_subdist, ix->w_subdist_n, (size_t) nq * st)) return NDBHIP_ERR_HIP;
-	if (ix->dm_nq != nq)
-	{
-		if (grow(ix->d_dm_meta, ix->d_dm_meta_n, 2 * mw)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_dm_pairs, ix->d_dm_pairs_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_dm_desc, ix->d_dm_desc_n, (size_t) nitems)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_dm_heads, ix->d_dm_heads_n, (size_t) 8 * NDB_QHEAD_STRIDE)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_dm_zero, ix->d_dm_zero_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-		HIP_TRY(hipMemsetAsync(ix->d_dm_zero, 0, (size_t) nq, g.stream));
-		/* the build's table kernel with the roles it has there: the "rows" are the centres, the "centroids" the queries */
-		hipLaunchKernelGGL(k_assign_tables, dim3(1), dim3(64), 0, g.stream, (const unsigned char *) ix->d_dm_zero, nq, (uint32_t) ng,
-						   (uint32_t) ng, ix->d_dm_pairs, ix->d_dm_meta, ix->d_dm_meta + mw);
-		hipLaunchKernelGGL(k_s16_items, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, (const uint32_t *) (ix->d_dm_meta + 6),
-						   (const uint32_t *) (ix->d_dm_meta + 3), (const uint32_t *) (ix->d_dm_meta + 2), 1, 128u, nitems,
-						   (S16Desc *) ix->d_dm_desc, ix->d_dm_heads + 8 * NDB_QHEAD_STRIDE - 1);
-		ix->dm_nq = nq;
-	}
-	HIP_TRY(hipMemsetAsync(ix->d_dm_heads, 0, (size_t) 8 * NDB_QHEAD_STRIDE * sizeof(unsigned int), g.stream));
-	const uint32_t *m32 = ix->d_dm_meta;
-	IvfDev		dv = {};
-
-	dv.vecs = ix->d_subcent;
-	dv.loc_off = ix->d_dm_loc;
-	dv.own_len = m32 + 2;
-	dv.glob_len = m32 + 2;
-	dv.dim = dim;
-	dv.ncent = 1;
-	dv.nlists = 1;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 3>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
-					   (const unsigned char *) ix->d_cplanes, m32, (const float *) ix->d_crn2, (const int16_t *) ix->d_crexp,
-					   (const unsigned char *) ix->w_qplanes, (uint32_t) dimp * 4u, (const float *) ix->w_qn2, (const int *) ix->w_qexp,
-					   (float2 *) ix->w_qthr, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) ix->d_dm_desc,
-					   (const PairRec *) ix->d_dm_pairs, ix->d_dm_heads, m32 + 8, (unsigned int *) nullptr,
-					   reinterpret_cast<uint2 *>(ix->w_subdist), st, (uint32_t *) nullptr, 0, dimp / S16_CH, nitems, 0u,
-					   (const uint32_t *) nullptr);
-	HIP_TRY(hipGetLastError());
 	*sstride = st;
-	return 0;
+	return s16mat_run(ix->dm_sub, ix->dim, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq, ix->w_subdist, st);
 }
 
 /* read the index image back (tests, bench cpu baseline, PostgreSQL page writer) */

@@ -665,6 +665,185 @@ s16_thr_from_a(float ak, float e, int dim)
 }
 
 /*
+ * ivfSelectClusters (src/index/ivf_am.c:1597-1717) for a batch, screened: amat[q][c] = a ~ |q - centroid c|^2 from
+ * the two-plane sweep's MODE 3 (s16mat_run over the centroids' planes; |a - D| <= E = s16_e(dim, |q|^2, largest
+ * centroid norm)).  The reference's float4 distance d of a centroid satisfies (a - E)(1 - m) <= d^2 <= (a + E)(1 + m)
+ * (ndbhip_common.h (7)); with U = the nprobe-th smallest upper bound, at least nprobe centroids have d^2 <= U, so a
+ * centroid whose lower bound exceeds U is neither among the nprobe nearest nor tied with one of them.  The others —
+ * nprobe plus a few — get the reference's own sequential sqrtf(sum (q - c)^2) (one lane each) and the selection
+ * ("nprobe times the first strict minimum" = ascending (distance, index), valid = below FLT_MAX) runs over those.
+ * cdist[q][c] receives the exact distance of every centroid examined (the probed ones among them: what the sublist
+ * code reads).  A query with more than NDB_CSEL_CAP candidates (or fewer than nprobe finite bounds) is marked in
+ * `full` after ALL its distances were computed exactly: k_probe_select serves it from cdist as before.
+ * One wave per query; PER = centroids per lane.
+ */
+#define NDB_CSEL_CAP 256
+
+template <int PER>
+__global__ __launch_bounds__(64) void
+k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__restrict__ qn2, const uint32_t *__restrict__ cmax_bits,
+			  const float *__restrict__ queries, const float *__restrict__ cents, int dim, int ncmp, int ncent, int npr,
+			  const uint32_t *__restrict__ glob_len, const uint32_t *__restrict__ own_lo, const uint32_t *__restrict__ own_len,
+			  uint64_t cap, float *__restrict__ cdist, uint32_t cstride, int *__restrict__ probes,
+			  uint32_t *__restrict__ cand_off, uint32_t *__restrict__ loc_cand_off, uint8_t *__restrict__ full)
+{
+	__shared__ uint32_t s_idx[NDB_CSEL_CAP], s_key[NDB_CSEL_CAP];
+	__shared__ int s_sel[NDBHIP_MAX_NPROBE];
+	__shared__ uint32_t s_len[NDBHIP_MAX_NPROBE];
+	const uint32_t q = blockIdx.x;
+	const int	lane = threadIdx.x;
+	const float *av = amat + (size_t) q * astride;
+	const float *qq = queries + (size_t) q * dim;
+	const int	npr_eff = max(0, min(npr, ncmp));
+	const float e = s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cmax_bits), false);
+	const float m = ndb_s16_refslack(dim);
+	uint32_t	ub[PER], lb[PER];
+
+#pragma unroll
+	for (int j = 0; j < PER; j++)
+	{
+		const int	c = j * 64 + lane;
+		const float a = c < ncmp ? av[c] : 0.0f;
+		const float hi = s16_up(s16_up(fmaxf(a + e, 0.0f)) * (1.0f + m));
+		const float lo0 = fmaxf(a - e, 0.0f) * (1.0f - m);
+		const float lo = fmaxf(lo0 - lo0 * 4.8e-7f - 1e-37f, 0.0f);
+		/* a NaN or an infinity anywhere (fmaxf drops a NaN operand: test the inputs): no bound at all — the centroid
+		 * is always examined and never counts towards the nprobe bounds U rests on */
+		const bool	fin = (__float_as_uint(a) & 0x7FFFFFFFu) < 0x7F800000u && (__float_as_uint(e) & 0x7FFFFFFFu) < 0x7F800000u &&
+			hi < __uint_as_float(0x7F800000u);
+
+		ub[j] = c < ncmp ? (fin ? __float_as_uint(hi) : 0x7F800000u) : 0xFFFFFFFFu;
+		lb[j] = c < ncmp ? (fin ? __float_as_uint(lo) : 0u) : 0xFFFFFFFFu;
+	}
+	/* U = the npr_eff-th smallest upper bound (non-negative floats: the bits order like the values): the largest v
+	 * with #(ub < v) < npr_eff */
+	uint32_t	U = 0;
+
+	if (npr_eff > 0)
+	{
+		for (int bit = 30; bit >= 0; bit--)
+		{
+			const uint32_t t = U | (1u << bit);
+			uint32_t	n = 0;
+
+#pragma unroll
+			for (int j = 0; j < PER; j++)
+				n += ub[j] < t ? 1u : 0u;
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1)
+				n += (uint32_t) __shfl_xor((int) n, off, 64);
+			if (n < (uint32_t) npr_eff)
+				U = t;
+		}
+	}
+	/* the candidates, in index order */
+	uint32_t	total = 0;
+
+#pragma unroll
+	for (int j = 0; j < PER; j++)
+	{
+		const bool	in = lb[j] <= U && j * 64 + lane < ncmp;
+		const unsigned long long mk = __ballot(in);
+
+		if (in)
+		{
+			const uint32_t slot = total + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull));
+
+			if (slot < NDB_CSEL_CAP)
+				s_idx[slot] = (uint32_t) (j * 64 + lane);
+		}
+		total += (uint32_t) __popcll(mk);
+	}
+	if (total > NDB_CSEL_CAP || U >= 0x7F800000u || npr_eff == 0)
+	{
+		/* nothing to gain here: every distance exactly, the old selection kernel does the rest */
+		for (int c = lane; c < ncmp; c += 64)
+			cdist[(size_t) q * cstride + c] = scr_exact<R_IVF_L2>(qq, cents + (size_t) c * dim, dim);
+		if (lane == 0)
+			full[q] = 1;
+		return;
+	}
+	__syncthreads();
+	for (uint32_t i = lane; i < total; i += 64)
+	{
+		const uint32_t c = s_idx[i];
+		const float v = scr_exact<R_IVF_L2>(qq, cents + (size_t) c * dim, dim);
+
+		cdist[(size_t) q * cstride + c] = v;
+		/* valid = strictly below FLT_MAX (bestDist starts at FLT_MAX: ivf_am.c:1689, 1706); the others never win */
+		s_key[i] = v < FLT_MAX ? ndb_key_from_bits(__float_as_uint(v)) : 0xFFFFFFFFu;
+	}
+	__syncthreads();
+	/* rank of every valid candidate by (distance, index); the list is in index order, so ties go to the earlier slot */
+	uint32_t	nvalid = 0;
+
+	for (uint32_t i = lane; i < total; i += 64)
+		nvalid += s_key[i] != 0xFFFFFFFFu ? 1u : 0u;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		nvalid += (uint32_t) __shfl_xor((int) nvalid, off, 64);
+	const uint32_t kk = min((uint32_t) npr_eff, nvalid);
+
+	for (uint32_t i = lane; i < total; i += 64)
+	{
+		const uint32_t ki = s_key[i];
+
+		if (ki == 0xFFFFFFFFu)
+			continue;
+		uint32_t	rank = 0;
+
+		for (uint32_t o = 0; o < total; o++)
+		{
+			const uint32_t ko = s_key[o];
+
+			rank += (ko < ki || (ko == ki && o < i)) ? 1u : 0u;
+		}
+		if (rank < kk)
+			s_sel[rank] = (int) s_idx[i];
+	}
+	__syncthreads();
+	for (int i = lane; i < npr; i += 64)
+	{
+		int			c;
+
+		if ((uint32_t) i < kk)
+			c = s_sel[i];
+		else if (i < npr_eff)
+			c = -1;
+		else
+			c = 0;
+		probes[(size_t) q * npr + i] = c;
+		s_sel[i] = c;
+		s_len[i] = (c >= 0 && c < ncent) ? glob_len[c] : 0u;	/* ivf_am.c:1768-1779 */
+	}
+	__syncthreads();
+	if (lane == 0)
+	{
+		uint64_t	acc = 0, mine = 0;
+		uint32_t   *co = cand_off + (size_t) q * (npr + 1);
+		uint32_t   *lco = loc_cand_off ? loc_cand_off + (size_t) q * (npr + 1) : nullptr;
+
+		full[q] = 0;
+		co[0] = 0;
+		if (lco)
+			lco[0] = 0;
+		for (int i = 0; i < npr; i++)
+		{
+			uint64_t	l = s_len[i];
+
+			if (cap > 0 && acc + l > cap)
+				l = cap - acc;	/* candidateCount < maxCandidates guards: ivf_am.c:1764, 1793, 1811 */
+			acc += l;
+			if (l > 0)
+				mine += ndb_local_part(l, own_lo, own_len, s_sel[i]);
+			co[i + 1] = (uint32_t) acc;
+			if (lco)
+				lco[i + 1] = (uint32_t) mine;
+		}
+	}
+}
+
+/*
  * First threshold: one wave per query scores its first S16_SEED candidates (probe order: the nearest list
  * first) with the reference's arithmetic; the k-th smallest of those distances bounds the query's k-th
  * distance.  Fewer than k candidates: +inf (everything is emitted).  Also E_q.
@@ -953,14 +1132,21 @@ struct S16Desc
 __global__ void
 k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ own_len,
 			int ncent, uint32_t rt, uint32_t cap, S16Desc *__restrict__ desc, unsigned int *__restrict__ flags,
-			uint32_t qtile = S16_QT /* (query, probe) pairs per tile */ )
+			uint32_t qtile = S16_QT /* (query, probe) pairs per tile */,
+			unsigned long long *__restrict__ plane_bytes = nullptr /* statistics: += bytes of row planes the items read, every row tile once */,
+			uint32_t blk_bytes = 0 /* bytes of a 32-row block over all chunks */ )
 {
 	const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long mine = 0;
 
 	if (item == 0 && item_off[ncent] > cap)
 		atomicAdd(flags, 1u);		/* cannot happen (the host sizes the table by an upper bound); if it does, fall back */
-	if (item >= item_off[ncent] || item >= cap)
+	const bool	live = item < item_off[ncent] && item < cap;
+
+	if (!live && !plane_bytes)
 		return;
+	if (live)
+	{
 	uint32_t	lo = 0, hi = (uint32_t) ncent;
 
 	while (hi - lo > 1)
@@ -989,6 +1175,22 @@ k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ 
 	d.qt = 8u * grp + lg % gq;
 	d.pad = 0;
 	desc[item] = d;
+	if (plane_bytes && d.qt == 0)
+		mine = (unsigned long long) min(rt / 32u, (own_len[L] - d.t2 * rt + 31u) / 32u) * blk_bytes;
+	}
+	if (plane_bytes)
+	{
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) mine, off, 64);
+			const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (mine >> 32), off, 64);
+
+			mine += ((unsigned long long) hi << 32) | lo;
+		}
+		if ((threadIdx.x & 63) == 0 && mine != 0)
+			atomicAdd(plane_bytes, mine);
+	}
 }
 
 #define S16_NOITEM 0xFFFFFFFFu

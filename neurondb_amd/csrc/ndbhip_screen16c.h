@@ -112,13 +112,16 @@ k_s16c_row_prep(const float *__restrict__ vecs, int64_t nrows, int dim, int dimp
 /*
  * One wave per (query, bucket) pair record, in the pair tables' order (slot j = pair_off[bucket] + i): the plane of
  * q - c in natural element order (the sweep's DMA applies the LDS swizzle), qcn2[j] = |q - c|^2 as computed (NaN:
- * not a finite fp32 — every element of the pair is emitted), qcexp[j].  Persistent grid.
+ * not a finite fp32 — every element of the pair is emitted), qcexp[j], and the pair's query / first candidate
+ * position / visible rows (pqid, pla, pnrow).  Persistent grid.
  */
 __global__ __launch_bounds__(256) void
 k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRec *__restrict__ pairs,
 			  const uint32_t *__restrict__ pair_off, int nb, const float *__restrict__ cents,
 			  const float *const *__restrict__ cptr, _Float16 *__restrict__ qcplanes, float *__restrict__ qcn2,
-			  int *__restrict__ qcexp, uint32_t cap, unsigned int *__restrict__ flags /* [0]++ when the pairs exceed cap */,
+			  int *__restrict__ qcexp, uint32_t *__restrict__ pqid, uint32_t *__restrict__ pla, uint32_t *__restrict__ pnrow,
+			  const uint32_t *__restrict__ loc_cand_off, int npr,
+			  uint32_t cap, unsigned int *__restrict__ flags /* [0]++ when the pairs exceed cap */,
 			  unsigned int *__restrict__ dens /* statistics or NULL: [0] = pairs, [1] = buckets with pairs */,
 			  const uint32_t *__restrict__ cnt)
 {
@@ -160,7 +163,8 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 		}
 		while (lo + 1 < (uint32_t) nb && pair_off[lo + 1] <= j)
 			lo++;
-		const float *q = queries + (size_t) pairs[j].q * dim;
+		const PairRec pr = pairs[j];
+		const float *q = queries + (size_t) pr.q * dim;
 		const float *c = cptr ? cptr[lo] : cents + (size_t) lo * dim;
 		double		s = 0.0;
 
@@ -176,8 +180,15 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 
 		if (lane == 0)
 		{
+			const uint32_t *lq = loc_cand_off + (size_t) pr.q * (npr + 1);
+
 			qcn2[j] = ok ? (float) s : __uint_as_float(0x7FC00000u);
 			qcexp[j] = e;
+			/* what the sweep needs of the pair besides its plane, in the same order: the query, the first candidate
+			 * position of this (query, probe) and how many rows of the list it may see */
+			pqid[j] = pr.q;
+			pla[j] = lq[pr.p];
+			pnrow[j] = lq[pr.p + 1] - lq[pr.p];
 		}
 		ndb_h2	   *out = reinterpret_cast<ndb_h2 *>(qcplanes + (size_t) j * dimp);
 
@@ -196,6 +207,177 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 			out[p] = h;
 		}
 	}
+}
+
+/*
+ * First thresholds of the centred path.  k_s16_seed / k_s16_seed_sub give `ns` candidates the reference's own
+ * sequential arithmetic, one lane per row — 768 dependent steps a lane, 0.15 ms a batch.  A threshold only has to be
+ * an UPPER bound of the k-th distance, so here the whole wave sums one row's (q_i - x_i)^2 at a time: every term is
+ * the reference's own fl(fl(q_i - x_i)^2) >= 0, and a sum of n non-negative floats in ANY order is within
+ * (1 - n u) .. (1 + n u) of the real sum, so D <= S (1 + m), m = 2 (dim + 16) u (ndbhip_common.h (7)); the k-th
+ * smallest of those upper bounds over distinct candidates bounds the k-th distance, T = s16c_t_from_ub.
+ * Seeds: the first `ns` rows of the sublist whose centre is nearest to the query, among the sublists of its probed
+ * lists that hold at least k visible rows (SUB; k_s16_seed_sub's rule); without one, the query's first `ns` candidates.
+ * One wave per query.
+ */
+template <bool SUB>
+__global__ __launch_bounds__(64) void
+k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
+			const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, uint32_t ns,
+			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
+			const int64_t *__restrict__ sub_loc, const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of,
+			const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
+			const float *__restrict__ cdist, uint32_t cstride, float2 *__restrict__ qthr)
+{
+	const uint32_t q = blockIdx.x;
+	const int	lane = threadIdx.x;
+	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
+	const int	dim = ix.dim;
+	const float *qq = queries + (size_t) q * dim;
+	bool		ok = false;
+	int64_t		row = 0;
+
+	if constexpr (SUB)
+	{
+		float		bd = __uint_as_float(0x7F800000u);
+		uint32_t	bs = 0xFFFFFFFFu, bp = 0;
+
+		for (int p = 0; p < npr; p++)
+		{
+			const uint32_t vis = lco[p + 1] - lco[p];
+			const int	L = probes[(size_t) q * npr + p];
+
+			if (vis < k || L < 0 || L >= ix.ncent)
+				continue;
+			const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
+			const float pd = cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p];
+
+			for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
+			{
+				if (sub_len[s] < k)
+					continue;
+				const int	gi = sub_gidx[s];
+				const float dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+
+				if (dd < bd)
+				{
+					bd = dd;
+					bs = s;
+					bp = (uint32_t) p;
+				}
+			}
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			const float od = __shfl_xor(bd, off, 64);
+			const uint32_t os = (uint32_t) __shfl_xor((int) bs, off, 64), op = (uint32_t) __shfl_xor((int) bp, off, 64);
+
+			if (od < bd || (od == bd && os < bs))
+			{
+				bd = od;
+				bs = os;
+				bp = op;
+			}
+		}
+		if (bs != 0xFFFFFFFFu)		/* uniform */
+		{
+			const uint32_t vis = lco[bp + 1] - lco[bp];
+
+			if ((uint32_t) lane < min(sub_len[bs], ns))
+			{
+				const int64_t prow = sub_loc[bs] + lane;
+
+				ok = pos_of[prow] < vis;			/* a candidate of this (query, probe) under the candidate cap */
+				row = perm[prow];
+			}
+		}
+	}
+	if (!SUB || (uint32_t) __popcll(__ballot(ok)) < k)
+	{
+		/* the query's first candidates (probe order) */
+		ok = (uint32_t) lane < min(lco[npr], ns);
+		row = 0;
+		if (ok)
+		{
+			const uint32_t p = find_probe(lco, npr, (uint32_t) lane);
+			const int	L = probes[(size_t) q * npr + p];
+
+			row = ix.loc_off[L] + ((uint32_t) lane - lco[p]);
+		}
+	}
+	const unsigned long long have = __ballot(ok);
+	const int	n = have ? 64 - __builtin_clzll(have) : 0;		/* slots 0 .. n - 1 may hold a seed */
+	float		v = 0.0f;
+	const bool	vec4 = (dim & 3) == 0;
+
+	for (int j0 = 0; j0 < n; j0 += 4)
+	{
+		float		part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const int	j = j0 + u;
+
+			if (j >= n || !((have >> j) & 1ull))
+				continue;			/* uniform */
+			const uint32_t rlo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) row, j);
+			const uint32_t rhi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (row >> 32), j);
+			const float *x = ix.vecs + (size_t) (((uint64_t) rhi << 32) | rlo) * (size_t) dim;
+			float		a = 0.0f;
+
+			if (vec4)
+				for (int i = lane * 4; i < dim; i += 256)
+				{
+					const float4 xv = *reinterpret_cast<const float4 *>(x + i), qv = *reinterpret_cast<const float4 *>(qq + i);
+					const float d0 = qv.x - xv.x, d1 = qv.y - xv.y, d2 = qv.z - xv.z, d3 = qv.w - xv.w;
+
+					a += d0 * d0;
+					a += d1 * d1;
+					a += d2 * d2;
+					a += d3 * d3;
+				}
+			else
+				for (int i = lane; i < dim; i += 64)
+				{
+					const float d0 = qq[i] - x[i];
+
+					a += d0 * d0;
+				}
+			part[u] = a;
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			float		a = part[u];
+
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1)
+				a += __shfl_xor(a, off, 64);
+			if (lane == j0 + u)
+				v = a;
+		}
+	}
+	/* upper bound of the real squared distance; NaN (a row or query beyond fp32) bounds nothing */
+	const float ub = s16_up(v * (1.0f + ndb_s16_refslack(dim)));
+	const bool	good = ok && ub == ub;
+	const uint32_t key = good ? __float_as_uint(ub) : 0xFFFFFFFFu;	/* (ub >= 0: the bits order like the values) */
+	uint32_t	rank = 0;
+
+	for (int j = 0; j < 64; j++)
+	{
+		const uint32_t kj = (uint32_t) __shfl((int) key, j, 64);
+
+		rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+	}
+	const unsigned long long pick = __ballot(good && rank == k - 1);
+	float		t = __uint_as_float(0x7F800000u);	/* +inf: fewer than k seeds */
+
+	if (pick)
+		t = s16c_t_from_ub(__shfl(ub, __ffsll((long long) pick) - 1, 64), dim);
+	if (lane == 0)
+		qthr[q] = make_float2(t, 0.0f);
 }
 
 /*
@@ -219,158 +401,125 @@ template <int QB> struct S16CGeom
 	static constexpr int QT = 32 * QB;
 };
 
+/* a 4-byte-per-lane LDS DMA: lane i of the wave copies the dword at base + voff to LDS address la + 4 i */
+__device__ __forceinline__ void
+s16_dma4(const void *base, uint32_t voff, uint32_t la)
+{
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+				 :: "s"(la), "v"(voff), "s"(base) : "memory");
+}
+
+/*
+ * The sweep.  Work item = (bucket, 128-row tile, QT-pair tile), expanded by k_s16_items into 8 runs, one per XCD.
+ * A block walks the items of its XCD's run at a fixed stride (item = run start + block / 8 + j blocks / 8): the next
+ * item is known without asking anyone, so its descriptor comes through the scalar cache (s_load: no entry in the
+ * vector-memory counter), its members' constants come by LDS DMA like the operands, and the operand stream never
+ * stops at an item's end — the ring's look-ahead simply runs into the next item's first chunks while the current
+ * item's last chunks are multiplied and its results looked at.  (The first version popped items from atomic queues
+ * and fetched descriptors and member records with ordinary loads, one dependent stage per chunk: every stage's wait
+ * drained the wave's vector-memory counter, i.e. waited for the operand chunks in flight as well, and an item's first
+ * half ran with a ring of depth one.)
+ *
+ * Ring of NBUF chunk buffers; chunk g of the block's stream lives in buffer g % NBUF.  Per chunk: wait until the
+ * chunk's own DMA has landed (s_waitcnt vmcnt leaves the later chunks' requests in flight), barrier, request chunk
+ * g + NBUF - 1 into the buffer everybody has finished reading, 16 ds_read_b128 + 4 AQ BR MFMAs.
+ */
 template <int QB, int NBUF, int DBG = 0>
 __global__ __launch_bounds__(256, ((S16CGeom<QB>::BUF * NBUF + 8192) * 2 <= 160 * 1024) ? 2 : 1) void
-k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
+k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
+			 const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
 			 const float *__restrict__ rn2, const int16_t *__restrict__ rexp,
 			 const unsigned char *__restrict__ qcplanes, uint32_t qrowbytes, const float *__restrict__ qcn2,
-			 const int *__restrict__ qcexp, float2 *qthr,
-			 const uint32_t *__restrict__ loc_cand_off, int npr, const uint32_t *__restrict__ cnt,
+			 const int *__restrict__ qcexp, const uint32_t *__restrict__ pqid, const uint32_t *__restrict__ pla,
+			 const uint32_t *__restrict__ pnrow, float2 *qthr, const uint32_t *__restrict__ cnt,
 			 const uint32_t *__restrict__ pair_off, const S16Desc *__restrict__ desc,
-			 const PairRec *__restrict__ pairs, unsigned int *__restrict__ next_item,
 			 const uint32_t *__restrict__ runs, unsigned int *__restrict__ ecount, uint2 *__restrict__ erec,
-			 float *__restrict__ eub, uint32_t ecap, uint32_t *__restrict__ bmin, int polite, int nchunk,
+			 float *__restrict__ eub, uint32_t ecap, uint32_t *__restrict__ bmin, int nchunk,
 			 uint32_t desc_cap, uint32_t topk, const uint32_t *__restrict__ pos_of, float cE,
 			 uint32_t qc_cap /* rows of qcplanes: more pairs than that and nothing is swept (k_s16c_qcprep raised the flag) */ )
 {
 	typedef S16CGeom<QB> G;
 	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];
 	__shared__ __attribute__((aligned(1024))) unsigned char ring[NBUF * G::BUF];
-	/* per member of the current / next item's tile */
-	__shared__ float s_q2[2][G::QT], s_t2[2][G::QT];
-	__shared__ int s_eq[2][G::QT];
-	__shared__ uint32_t s_la[2][G::QT], s_nrow[2][G::QT], s_qid[2][G::QT];
-	__shared__ uint32_t s_desc[2][5];		/* item (S16_NOITEM = none), bucket, row tile, pair tile, members */
+	/* per member of the two items in flight (by the item's parity): DMA'd from the pair-ordered arrays */
+	__shared__ __attribute__((aligned(256))) float s_q2[2][64 * ((G::QT + 63) / 64)];
+	__shared__ __attribute__((aligned(256))) int s_eq[2][64 * ((G::QT + 63) / 64)];
+	__shared__ __attribute__((aligned(256))) uint32_t s_la[2][64 * ((G::QT + 63) / 64)], s_nrow[2][64 * ((G::QT + 63) / 64)],
+		s_qid[2][64 * ((G::QT + 63) / 64)];
+	__shared__ float s_t2[G::QT];
 	const int	tid = threadIdx.x;
 	const int	lane = tid & 63;
 	const int	wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int	wq = wave % G::NWQ, wr = wave / G::NWQ;
 	const int	r32 = lane & 31, kh = lane >> 5;
-	uint32_t	hop = 0;
 
-	if (pair_off[ix.ncent] > qc_cap)
+	if (pair_off[nbuckets] > qc_cap)
 		return;					/* uniform */
-	auto		pop = [&](uint32_t got) -> uint32_t {
-		for (; hop < 8; hop++)
-		{
-			const uint32_t xq = (blockIdx.x + hop) & 7u;
-			const uint32_t run_lo = runs[xq], run_hi = runs[xq + 1];
+	/* this block's items: those of run (block % 8) at stride (blocks in that XCD) */
+	const uint32_t xq = blockIdx.x & 7u;
+	const uint32_t stride = (gridDim.x - xq + 7u) >> 3;
+	const uint32_t run_hi = min(runs[xq + 1], desc_cap);
+	uint32_t	it_c = runs[xq] + (blockIdx.x >> 3);		/* the item being multiplied */
 
-			if (run_lo != run_hi)
-			{
-				if (got == 0xFFFFFFFFu)
-					got = (polite && run_lo + __hip_atomic_load(next_item + xq * NDB_QHEAD_STRIDE, __ATOMIC_RELAXED,
-																__HIP_MEMORY_SCOPE_AGENT) >= run_hi)
-						? run_hi : atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
-				if (got < run_hi - run_lo && run_lo + got < desc_cap)
-					return run_lo + got;
-			}
-			got = 0xFFFFFFFFu;
-		}
-		return S16_NOITEM;
-	};
-	auto		put_desc = [&](int sl, uint32_t it, const S16Desc &d) {
-		s_desc[sl][0] = it;
-		s_desc[sl][1] = d.L;
-		s_desc[sl][2] = d.t2;
-		s_desc[sl][3] = d.qt;
-		s_desc[sl][4] = it == S16_NOITEM ? 0u : min((uint32_t) G::QT, cnt[d.L] - d.qt * G::QT);
-	};
-	/* threads < QT: the member's pair slot and record */
-	auto		load_pair = [&](int sl, PairRec &pr, uint32_t &slot) -> bool {
-		const uint32_t L = s_desc[sl][1], qt = s_desc[sl][3];
-
-		if (s_desc[sl][0] == S16_NOITEM || qt * G::QT + (uint32_t) tid >= cnt[L])
-			return false;
-		slot = pair_off[L] + qt * G::QT + (uint32_t) tid;
-		pr = pairs[slot];
-		return true;
-	};
-	struct Mem { float q2, t2; int eq; uint32_t la, nrow, qid; };
-	auto		load_mem = [&](bool have, const PairRec &pr, uint32_t slot, Mem &m) {
-		m.q2 = 0.0f; m.t2 = 0.0f; m.eq = 0; m.la = 0; m.nrow = 0; m.qid = 0;
-		if (have)
-		{
-			const uint32_t *lq = loc_cand_off + (size_t) pr.q * (npr + 1);
-			const float t = __hip_atomic_load(&qthr[pr.q].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-			m.qid = pr.q;
-			m.la = lq[pr.p];
-			m.nrow = lq[pr.p + 1] - m.la;
-			m.q2 = qcn2[slot];
-			m.eq = qcexp[slot];
-			/* what the test subtracts: T rounded up with the slack its fused form needs (see the epilogue) */
-			m.t2 = s16_up(t * 1.000001f) + NDB_S16_ABS;
-		}
-	};
-	auto		put_mem = [&](int sl, const Mem &m) {
-		s_q2[sl][tid] = m.q2;
-		s_t2[sl][tid] = m.t2;
-		s_eq[sl][tid] = m.eq;
-		s_la[sl][tid] = m.la;
-		s_nrow[sl][tid] = m.nrow;
-		s_qid[sl][tid] = m.qid;
-	};
-
-	if (tid == 0)
-	{
-		s_tn = 0;
-		const uint32_t it = pop(0xFFFFFFFFu);
-		S16Desc		d = {0, 0, 0, 0};
-
-		if (it != S16_NOITEM)
-			d = desc[it];
-		put_desc(0, it, d);
-	}
-	__syncthreads();
-	if (s_desc[0][0] == S16_NOITEM)
+	if (it_c >= run_hi)
 		return;
-	if (tid < G::QT)
-	{
-		PairRec		pr = {0, 0};
-		uint32_t	slot = 0;
-		Mem			m;
-		const bool	have = load_pair(0, pr, slot);
+	if (tid == 0)
+		s_tn = 0;
 
-		load_mem(have, pr, slot, m);
-		put_mem(0, m);
-	}
-	__syncthreads();
-
+	/* ---- fetch side: the item whose chunks are being requested, and the addresses its DMA needs ---- */
+	uint32_t	it_f = it_c, f_c = 0, f_par = 0;
 	uint32_t	voff_q[G::Q_DMA];
 	bool		qdma = true;
-	const unsigned char *rbase, *qbase;
+	const unsigned char *rbase = planes, *qbase = qcplanes;
 	const uint32_t lane16 = (uint32_t) lane * 16u;
+	const uint32_t ring_la = (uint32_t) (uintptr_t) (ndb_lds_ptr) ring;
+	const uint32_t mem_la[5] = {(uint32_t) (uintptr_t) (ndb_lds_ptr) &s_q2[0][0], (uint32_t) (uintptr_t) (ndb_lds_ptr) &s_eq[0][0],
+		(uint32_t) (uintptr_t) (ndb_lds_ptr) &s_la[0][0], (uint32_t) (uintptr_t) (ndb_lds_ptr) &s_nrow[0][0],
+		(uint32_t) (uintptr_t) (ndb_lds_ptr) &s_qid[0][0]};
+	constexpr uint32_t MEM_STRIDE = 4u * 64u * ((G::QT + 63) / 64);	/* bytes between the two parities of a member array */
 
-	/* wave w stages 32-row block w of the tile (one contiguous 4 KiB piece of the blocked planes per chunk) and its
-	 * share of the tile's pair rows, which are consecutive rows of qcplanes: piece -> pair block piece / 4, rows
-	 * 8 (piece % 4) .. + 7, 128 bytes each, the 16-byte slots XOR-swizzled at the source */
-	auto		set_dma = [&](int sl) {
-		const uint32_t L = s_desc[sl][1], t2 = s_desc[sl][2], qt = s_desc[sl][3], nmem = s_desc[sl][4];
+	/* item `it` becomes the fetch item: addresses of its operand pieces (wave w: 32-row block w of the tile, one
+	 * contiguous 4 KiB piece per chunk, and its share of the tile's pair rows — consecutive rows of qcplanes, 128
+	 * bytes per chunk, 16-byte slots XOR-swizzled at the source), and its members' constants requested into the
+	 * member arrays of parity `par` (waves 0 .. QT / 64: five 4-byte-per-lane DMA instructions each) */
+	auto		enter = [&](uint32_t it, uint32_t par) {
+		const S16Desc d = desc[it];			/* uniform address: scalar loads */
+		const uint32_t L = d.L, nmem = min((uint32_t) G::QT, cnt[L] - d.qt * G::QT);
 		const uint32_t nbk = blk_off[L + 1] - blk_off[L];
-		const uint32_t b = min(t2 * 4u + (uint32_t) wave, nbk - 1u);
+		const uint32_t b = min(d.t2 * 4u + (uint32_t) wave, nbk - 1u);
+		const uint32_t slot0 = pair_off[L] + d.qt * G::QT;
 
 #pragma unroll
 		for (int j = 0; j < G::Q_DMA; j++)
 		{
 			const int	piece = wave * G::Q_DMA + j;
 			const int	rr = 8 * (piece & 3) + (lane >> 3);
-			const uint32_t mem = min((uint32_t) (32 * (piece >> 2) + rr), nmem > 0 ? nmem - 1u : 0u);
+			const uint32_t mem = min((uint32_t) (32 * (piece >> 2) + rr), nmem - 1u);
 
 			voff_q[j] = mem * qrowbytes + 16u * (uint32_t) ((lane & 7) ^ ((rr >> 1) & 7));
 		}
 		rbase = planes + ((size_t) blk_off[L] + b) * (size_t) nchunk * 4096;
-		qbase = qcplanes + ((size_t) pair_off[L] + (size_t) qt * G::QT) * qrowbytes;
+		qbase = qcplanes + (size_t) slot0 * qrowbytes;
 		/* a pair block without a member is neither fetched nor multiplied */
 		qdma = nmem > (uint32_t) (32 * ((wave * G::Q_DMA) >> 2));
+		if (wave * 64 < G::QT)
+		{
+			/* members beyond the tile's count read the last member's constants (never looked at: nrow is tested
+			 * against the member count below) */
+			const uint32_t mo = 4u * min((uint32_t) (wave * 64 + lane), nmem - 1u);
+			const void *src[5] = {qcn2 + slot0, qcexp + slot0, pla + slot0, pnrow + slot0, pqid + slot0};
+
+#pragma unroll
+			for (int a = 0; a < 5; a++)
+				s16_dma4(s16_uniform_ptr((const unsigned char *) src[a]), mo, mem_la[a] + par * MEM_STRIDE + (uint32_t) wave * 256u);
+		}
 	};
-	const uint32_t ring_la = (uint32_t) (uintptr_t) (ndb_lds_ptr) ring;
-	auto		issue = [&](int c, int bufi) {
+	auto		issue = [&](uint32_t c, uint32_t bufi) {
 		if constexpr (DBG == 1)
 			return;
 		const unsigned char *rb = s16_uniform_ptr(DBG == 2 ? planes : rbase + (size_t) c * 4096);
 		const unsigned char *qb = s16_uniform_ptr(DBG == 2 ? qcplanes : qbase + (size_t) c * 128);
-		const uint32_t la = ring_la + (uint32_t) bufi * G::BUF;
+		const uint32_t la = ring_la + bufi * G::BUF;
 
 		s16_dma_linear<4>(rb, lane16, la + wave * 4096);
 		if (qdma)
@@ -380,21 +529,57 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 				s16_dma16(qb, voff_q[j], la + G::Q_OFF + (wave * G::Q_DMA + j) * 1024);
 		}
 	};
+	/* request the next chunk of the stream (none left: nothing); returns whether this wave's request included pair
+	 * rows (what the matching wait has to count) */
+	uint32_t	g_f = 0;		/* chunks requested so far */
+	auto		fetch_next = [&]() -> bool {
+		if (it_f == S16_NOITEM)
+			return false;
+		if (f_c == (uint32_t) nchunk)
+		{
+			/* the next item, entered only now that its first chunk is due: NBUF - 1 <= nchunk chunks ahead of the
+			 * multiplication, i.e. while the item before it is being multiplied — whose member arrays have the
+			 * other parity, and whose predecessor (this parity) has been looked at */
+			f_c = 0;
+			it_f = it_f + stride < run_hi ? it_f + stride : S16_NOITEM;
+			f_par ^= 1u;
+			if (it_f == S16_NOITEM)
+				return false;
+			enter(it_f, f_par);
+		}
+		const bool	had_q = qdma;
+
+		issue(f_c, g_f % NBUF);
+		g_f++;
+		f_c++;
+		return had_q;
+	};
 
 	const int	sw = (r32 >> 1) & 7;
 	const int	qfrag = G::Q_OFF + (G::AQ * wq) * 4096 + r32 * 128;
 	const int	rfrag = (G::BR * wr) * 4096 + r32 * 128;
-	int			cur = 0;
+	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
+	/* did the request for chunk g (g = g_c + 1 .. g_c + NBUF - 2, the ones that stay in flight across a wait) include
+	 * pair rows: one bit per ring slot */
+	uint32_t	qbits = 0;
 
-	set_dma(0);
+	enter(it_c, 0);
 #pragma unroll
 	for (int p = 0; p < NBUF - 1; p++)
-		if (p < nchunk)
-			issue(p, p);
+	{
+		const uint32_t slot = g_f % NBUF;
+		const bool	hq = fetch_next();
+
+		qbits = (qbits & ~(1u << slot)) | ((hq ? 1u : 0u) << slot);
+	}
 
 	for (;;)
 	{
-		const int	nxt = cur ^ 1;
+		/* the item being multiplied: its descriptor again (scalar cache) */
+		const S16Desc dc = desc[it_c];
+		const uint32_t L = dc.L, t2 = dc.t2;
+		const uint32_t nmem_cur = min((uint32_t) G::QT, cnt[L] - dc.qt * G::QT);
+		const uint32_t len = own_len[L];
 		ndb_f16acc	acc[G::AQ][G::BR];
 
 #pragma unroll
@@ -405,7 +590,6 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 				for (int i = 0; i < 16; i++)
 					acc[a][b][i] = 0.0f;
 
-		const uint32_t nmem_cur = s_desc[cur][4];
 		/* pair blocks of this wave that hold a member (wave-uniform) */
 		int			na = 0;
 
@@ -440,100 +624,78 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 			}
 		};
 
-		uint32_t	got = 0xFFFFFFFFu, nit = S16_NOITEM;
-		S16Desc		nd = {0, 0, 0, 0};
-		PairRec		npair = {0, 0};
-		uint32_t	nslot = 0;
-		bool		nhave = false;
-		Mem			nm;
+		/* one chunk of the stream: wait for it, barrier, request the chunk NBUF - 1 ahead, multiply */
+		auto		chunk = [&]() {
+			/* chunk g_c must have landed; the requests for the NBUF - 2 chunks after it may stay in flight: 4 row
+			 * pieces each, plus Q_DMA pair pieces where the request had them (anything else the wave has asked for —
+			 * member constants — is older than those and is waited for along with the chunk) */
+			if constexpr (NBUF == 2)
+				s16_wait_vm<0>();
+			else
+			{
+				static_assert(NBUF == 3, "ring depths 2 and 3");
+				const uint32_t later = g_f - g_c - 1;		/* chunks requested after g_c: NBUF - 2, or fewer at the stream's end */
 
-		/* the next item is prepared while this one is multiplied, one stage per chunk (k_s16_sweep's scheme) */
-		auto		stage = [&](int st) {
-			if (st == 0)
+				if (later == 0)
+					s16_wait_vm<0>();
+				else if ((qbits >> ((g_c + 1) % NBUF)) & 1u)
+					s16_wait_vm<G::PER>();
+				else
+					s16_wait_vm<4>();
+			}
+			__syncthreads();
 			{
-				if (tid == 0 && hop < 8 && !polite)
-				{
-					const uint32_t xq = (blockIdx.x + hop) & 7u;
+				const uint32_t slot = g_f % NBUF;
+				const bool	hq = fetch_next();
 
-					if (runs[xq] != runs[xq + 1])
-						got = atomicAdd(next_item + xq * NDB_QHEAD_STRIDE, 1u);
-				}
+				qbits = (qbits & ~(1u << slot)) | ((hq ? 1u : 0u) << slot);
 			}
-			else if (st == 1)
-			{
-				if (tid == 0)
-				{
-					nit = pop(got);
-					if (nit != S16_NOITEM)
-						nd = desc[nit];
-				}
-			}
-			else if (st == 2)
-			{
-				if (tid == 0)
-					put_desc(nxt, nit, nd);
-			}
-			else if (st == 3)
-			{
-				if (tid < G::QT)
-					nhave = load_pair(nxt, npair, nslot);
-			}
-			else if (st == 4)
-			{
-				if (tid < G::QT)
-					load_mem(nhave, npair, nslot, nm);
-			}
-			else if (st == 5)
-			{
-				if (tid < G::QT)
-					put_mem(nxt, nm);
-			}
+			compute(ring + (g_c % NBUF) * G::BUF);
+			g_c++;
 		};
 
-		{
-			int			bc = 0;
+		chunk();
+		/*
+		 * Everything else the item reads with ordinary loads — its members' thresholds as they stand now (in-sweep
+		 * tightening; a stale value is a valid, looser bound) and its rows' norms / exponents / list positions — is
+		 * requested HERE, once, behind the first chunk's barrier (the member arrays have landed), and looked at after
+		 * the last chunk.  The vector-memory counter retires in order: a load consumed in the epilogue would wait for
+		 * every operand chunk requested before it, and one whose result is not consumed on every path would leave the
+		 * compiler waiting for "it" — i.e. for the whole ring — wherever its register is reused inside the loop.
+		 * Requested here, these loads are older than the stream and cost nothing; the empty asm statements behind
+		 * the loop pin their first use there, so that no arithmetic on them (and no wait) is hoisted into the loop.
+		 */
+		float		tfresh = 0.0f, x2r[G::BR];
+		int			exr[G::BR];
+		uint32_t	porr[G::BR];
+		bool		rokr[G::BR];
 
-			for (int c = 0; c < nchunk; c++)
-			{
-				if (c + NBUF - 2 < nchunk)
-				{
-					if (qdma)
-						s16_wait_vm<G::PER * (NBUF - 2)>();
-					else
-						s16_wait_vm<4 * (NBUF - 2)>();
-				}
-				else
-					s16_wait_vm<0>();
-				__syncthreads();
-				if (c < 6)
-					stage(c);
-				const int	bt = bc == 0 ? NBUF - 1 : bc - 1;
-
-				if (c + NBUF - 1 < nchunk)
-					issue(c + NBUF - 1, bt);
-				compute(ring + bc * G::BUF);
-				bc = bc + 1 == NBUF ? 0 : bc + 1;
-			}
-		}
-		for (int st = nchunk; st < 6; st++)
-		{
-			__syncthreads();
-			stage(st);
-		}
-		__syncthreads();
-
-		const bool	more = s_desc[nxt][0] != S16_NOITEM;
-		const uint32_t L = s_desc[cur][1], t2 = s_desc[cur][2];
-		const uint32_t len = ix.own_len[L];
-
-		if (more)
-		{
-			set_dma(nxt);
+		if (tid < G::QT && (uint32_t) tid < nmem_cur)
+			tfresh = qthr[s_qid[c_par][tid]].x;
 #pragma unroll
-			for (int p = 0; p < NBUF - 1; p++)
-				if (p < nchunk)
-					issue(p, p);
+		for (int b = 0; b < G::BR; b++)
+		{
+			const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (G::BR * wr + b) + r32);
+			const size_t grow = (size_t) loc_off[L] + (ridx < len ? ridx : len - 1);
+
+			rokr[b] = ridx < len;
+			x2r[b] = rn2[grow];
+			exr[b] = (int) rexp[grow];
+			porr[b] = pos_of ? pos_of[grow] : ridx;
 		}
+		for (int c = 1; c < nchunk; c++)
+			chunk();
+		asm volatile("" : "+v"(tfresh));
+#pragma unroll
+		for (int b = 0; b < G::BR; b++)
+		{
+			asm volatile("" : "+v"(x2r[b]), "+v"(exr[b]), "+v"(porr[b]));
+			exr[b] -= 27;
+		}
+		if (tid < G::QT)
+			/* what the test subtracts: T rounded up with the slack its fused form needs (see below) */
+			s_t2[tid] = s16_up(tfresh * 1.000001f) + NDB_S16_ABS;
+		__syncthreads();
 
 		/*
 		 * Epilogue: element (reg, lane) of block (a, b) = member 32 (AQ wq + a) + (reg & 3) + 8 (reg >> 2) + 4 kh,
@@ -546,16 +708,13 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 		 * right-hand side never exceeds the real one.  NaN anywhere: the comparison is false, the element emitted.
 		 */
 		const float K = (1.0f - cE) * 0.99999905f;
+		/* pass 1: which elements cannot be left out — one bit each, bit (b AQ + a) 16 + reg, no memory traffic */
+		unsigned long long emask = 0;
 
 #pragma unroll
 		for (int b = 0; b < G::BR; b++)
 		{
-			const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (G::BR * wr + b) + r32);
-			const bool	rok = ridx < len;
-			const size_t grow = (size_t) ix.loc_off[L] + (rok ? ridx : len - 1);
-			const float x2 = rn2[grow];
-			const int	ex = (int) rexp[grow] - 27;
-			const uint32_t porig = pos_of ? pos_of[grow] : ridx;
+			const bool	rok = rokr[b];
 
 #pragma unroll
 			for (int a = 0; a < G::AQ; a++)
@@ -566,42 +725,110 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 				for (int reg = 0; reg < 16; reg++)
 				{
 					const int	m = 32 * (G::AQ * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-					const float t1 = ldexpf(acc[a][b][reg], s_eq[cur][m] + ex);
-					const float n = s_q2[cur][m] + x2;
-					const float rhs = __builtin_fmaf(n, K, -s_t2[cur][m]);
+					const float t1 = ldexpf(acc[a][b][reg], s_eq[c_par][m] + exr[b]);
+					const float n = s_q2[c_par][m] + x2r[b];
+					const float rhs = __builtin_fmaf(n, K, -s_t2[m]);
 
-					if (DBG ? t1 == 1234.5f : !(t1 < rhs))
+					if ((DBG ? t1 == 1234.5f : !(t1 < rhs)) && rok && (uint32_t) m < nmem_cur && porr[b] < s_nrow[c_par][m])
+						emask |= 1ull << ((b * G::AQ + a) * 16 + reg);
+				}
+			}
+		}
+		/*
+		 * pass 2 (only where something is emitted): the record slots.  The lanes of one half (kh) that emit the same
+		 * element belong to ONE member = one query, so the slots of a member are handed out with a single atomicAdd:
+		 * lane ml (the member's index among this wave's AQ x 32) first counts what its member emits (ballots), takes
+		 * the slots in one go — every member's request travels at the same time — and the records are then written
+		 * at base + rank.
+		 */
+		uint32_t	any_lo = (uint32_t) emask, any_hi = (uint32_t) (emask >> 32);
+
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			any_lo |= (uint32_t) __shfl_xor((int) any_lo, off, 64);
+			any_hi |= (uint32_t) __shfl_xor((int) any_hi, off, 64);
+		}
+		const unsigned long long anym = ((unsigned long long) any_hi << 32) | any_lo;	/* uniform */
+
+		if (anym)
+		{
+			uint32_t	mycnt = 0;
+
+			for (unsigned long long rest = anym; rest; rest &= rest - 1)
+			{
+				const int	e = __builtin_ctzll(rest);
+				const int	reg = e & 15, a = (e >> 4) % G::AQ;
+				const unsigned long long bal = __ballot((emask >> e) & 1ull);
+				const int	ml0 = 32 * a + (reg & 3) + 8 * (reg >> 2);		/* kh = 0; kh = 1: + 4 */
+
+				if (lane == ml0)
+					mycnt += (uint32_t) __popcll(bal & 0xFFFFFFFFull);
+				if (lane == ml0 + 4)
+					mycnt += (uint32_t) __popcll(bal >> 32);
+			}
+			const int	mym = 32 * G::AQ * wq + lane;			/* the member lane `lane` keeps the books of */
+			uint32_t	base = 0;
+
+			if (mycnt != 0)
+				base = atomicAdd(&ecount[s_qid[c_par][mym % G::QT]], mycnt);
+#pragma unroll
+			for (int b = 0; b < G::BR; b++)
+#pragma unroll
+			for (int a = 0; a < G::AQ; a++)
+#pragma unroll
+			for (int reg = 0; reg < 16; reg++)
+			{
+				/* (unrolled: the accumulators are registers, an index known only at run time would send them to scratch) */
+				const int	e = (b * G::AQ + a) * 16 + reg;
+
+				if (!((anym >> e) & 1ull))
+					continue;			/* uniform */
+				const bool	mine = (emask >> e) & 1ull;
+				const unsigned long long bal = __ballot(mine);
+				const int	ml = 32 * a + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+				const unsigned long long half = kh ? (bal >> 32) : (bal & 0xFFFFFFFFull);
+				const uint32_t hb = (uint32_t) __shfl((int) base, ml, 64);
+
+				if (mine)
+				{
+					const int	m = 32 * G::AQ * wq + ml;
+					const uint32_t slot = hb + (uint32_t) __popcll(half & ((1ull << r32) - 1ull));
+					const uint32_t q = s_qid[c_par][m];
+					const float t1 = ldexpf(acc[a][b][reg], s_eq[c_par][m] + exr[b]);
+					const float n = s_q2[c_par][m] + x2r[b];
+					const float av = n - t1;
+					const float er = s16_up(s16_up(cE * n) + NDB_S16_ABS);
+					const float lbv = av - er, ubv = s16_up(av + er);
+					const float lb = lbv - fabsf(lbv) * 4.8e-7f - 1e-37f;
+					const uint32_t pos = s_la[c_par][m] + porr[b], ub_bits = __float_as_uint(ubv);
+
+					if (slot < ecap)
 					{
-						if (rok && porig < s_nrow[cur][m])
-						{
-							const uint32_t q = s_qid[cur][m];
-							const float av = n - t1;
-							const float e = s16_up(s16_up(cE * n) + NDB_S16_ABS);
-							const float lbv = av - e, ubv = s16_up(av + e);
-							const float lb = lbv - fabsf(lbv) * 4.8e-7f - 1e-37f;
-							const uint32_t slot = atomicAdd(&ecount[q], 1u);
-							const uint32_t pos = s_la[cur][m] + porig, ub_bits = __float_as_uint(ubv);
+						erec[(size_t) q * ecap + slot] = make_uint2(pos, __float_as_uint(lb));
+						eub[(size_t) q * ecap + slot] = ubv;
+					}
+					/* the smallest upper bound of every hash bucket of positions (kept whether or not the record
+					 * fit): k non-empty buckets are k distinct candidates */
+					if ((ub_bits & 0x7FFFFFFFu) < 0x7F800000u)
+						atomicMin(&bmin[(size_t) q * S16_NB + ((pos * 2654435761u) >> (32 - S16_NB_LOG2))],
+								  ndb_key_from_bits(ub_bits));
+					if (DBG == 0 && (slot & (S16_TIGHT - 1)) == S16_TIGHT - 1)
+					{
+						const uint32_t ti = atomicAdd(&s_tn, 1u);
 
-							if (slot < ecap)
-							{
-								erec[(size_t) q * ecap + slot] = make_uint2(pos, __float_as_uint(lb));
-								eub[(size_t) q * ecap + slot] = ubv;
-							}
-							/* the smallest upper bound of every hash bucket of positions (kept whether or not the
-							 * record fit): k non-empty buckets are k distinct candidates */
-							if ((ub_bits & 0x7FFFFFFFu) < 0x7F800000u)
-								atomicMin(&bmin[(size_t) q * S16_NB + ((pos * 2654435761u) >> (32 - S16_NB_LOG2))],
-										  ndb_key_from_bits(ub_bits));
-							if (DBG == 0 && (slot & (S16_TIGHT - 1)) == S16_TIGHT - 1)
-							{
-								const uint32_t ti = atomicAdd(&s_tn, 1u);
-
-								if (ti < S16_TIGHT_Q)
-									s_tq[ti] = q;
-							}
-						}
+						if (ti < S16_TIGHT_Q)
+							s_tq[ti] = q;
 					}
 				}
+				/* the two members' books move on by what their halves just took */
+				const uint32_t nlo = (uint32_t) __popcll(bal & 0xFFFFFFFFull), nhi = (uint32_t) __popcll(bal >> 32);
+				const int	ml0 = 32 * a + (reg & 3) + 8 * (reg >> 2);
+
+				if (lane == ml0)
+					base += nlo;
+				if (lane == ml0 + 4)
+					base += nhi;
 			}
 		}
 		if constexpr (DBG == 0)
@@ -635,7 +862,7 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 					if (topk != 0 && rank == topk - 1 && mine != 0xFFFFFFFFu)
 					{
 						const uint32_t tb = (mine & 0x80000000u) ? (mine & 0x7FFFFFFFu) : ~mine;
-						const float nt = s16c_t_from_ub(__uint_as_float(tb), ix.dim);
+						const float nt = s16c_t_from_ub(__uint_as_float(tb), dim);
 
 						/* T >= 0 (or +inf): its bits order like the values */
 						atomicMin(reinterpret_cast<unsigned int *>(&qthr[q].x), __float_as_uint(nt));
@@ -646,9 +873,12 @@ k_s16c_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t
 			if (tid == 0 && s_tn != 0)
 				s_tn = 0;
 		}
-		if (!more)
+		it_c += stride;
+		if (it_c >= run_hi)
 			break;
-		cur = nxt;
+		c_par ^= 1u;
+		/* (no barrier: the next item's first chunk starts with one, and the member arrays of parity c_par ^ 1 are
+		 * requested again only by an `enter` behind that barrier) */
 	}
 }
 

@@ -61,7 +61,7 @@ def test_every_documented_option_is_accepted_and_bad_ones_are_refused():
     names = set(re.findall(r'"([a-z0-9_]+)"', block))
     assert {"screen16", "screen16_records", "screen16_prune", "screen16_sublists", "build_screen16", "block_cache"} <= names
     defaults = {"screen16": 1, "screen16_records": 8192, "screen16_tighten": 1, "screen16_prune": 1, "screen16_sublists": 1,
-                "screen16_sub_min": 256, "screen16_sub_rows": 128, "screen16_centered": 1, "screen16_fin_threads": 64, "screen16_waves": 4,
+                "screen16_sub_min": 256, "screen16_sub_rows": 128, "screen16_centered": 1, "cent_screen16": 1, "screen16_fin_threads": 64, "screen16_waves": 4,
                 "probe_select_threads": 256, "probe_select_radix": 0, "build_screen16": 1, "block_cache": 1, "gchunk": 32,
                 "scr_coop": 2, "scr_mfma": 1, "screen": 1}
     for n in sorted(names):

@@ -352,3 +352,54 @@ def test_sublists_on_slice_shards_merge_to_the_unsharded_result(lib):
         full.close()
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 256))
+
+
+@pytest.mark.parametrize("dim,nlists,integer", [(64, 300, False), (100, 1100, False), (64, 700, True), (128, 2500, False)])
+def test_centroid_scan_on_the_matrix_cores_selects_like_the_reference(dim, nlists, integer, lib):
+    """ivfSelectClusters for a screened batch (k_cent_select, 256 .. 4096 centroids): |q - centroid|^2 from the
+    matrix-core sweep, the reference's arithmetic only near the nprobe-th, the selection over those.  Ties (integer
+    data), duplicated centroids (the lower index must win), a NaN and an overflowing centroid (never < FLT_MAX),
+    nprobe beyond the centroids (everything probed: the old selection serves it), candidate cap."""
+    n = 6 * nlists
+    a = make_ivf_arrays(n, dim, nlists, seed=nlists, dup_frac=0.05, integer=integer)
+    rng = np.random.default_rng(nlists + 1)
+    cent = a["centroids"]
+    cent[7] = cent[3]                       # duplicates: the first wins a tie
+    cent[nlists - 1] = cent[nlists // 2]
+    cent[11, 5] = np.nan
+    cent[13, 2] = 3.0e38                    # the sum of squares overflows: +inf, never selected
+    img = oracle_image(a)
+    ix = _index(a)
+    nq = 160
+    q = rng.standard_normal((nq, dim)).astype(np.float32) if not integer else \
+        rng.integers(-3, 4, size=(nq, dim)).astype(np.float32)
+    q[:40] = cent[rng.integers(0, nlists, 40)]
+    q[:40] = np.where(np.isfinite(q[:40]) & (np.abs(q[:40]) < 1e30), q[:40], 0.0)
+    q[-1] = 0.0
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    for nprobe, k, cap in ((7, 10, 0), (40, 10, 0), (1, 3, 0), (16, 10, 300)):
+        lib.check(lib.lib().ndbhip_stats_reset())
+        t, d, c = ix.search(q, 1, nprobe, k, cap)
+        st = lib.stats()
+        et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k, cap)
+        assert_same_results(t, d, c, et, ed, ec)
+        assert st["cent_screen_batches"] == 1 and st["screen16_batches"] + st["screen16_fallbacks"] == 1, st
+    # the probes themselves, and with the switch off
+    from neurondb_amd import _lib as L
+    lib.check(lib.lib().ndbhip_set_option(b"cent_screen16", 0))
+    try:
+        lib.check(lib.lib().ndbhip_stats_reset())
+        t0, d0, c0 = ix.search(q, 1, 9, 10, 0)
+        assert lib.stats()["cent_screen_batches"] == 0
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"cent_screen16", 1))
+    t1, d1, c1 = ix.search(q, 1, 9, 10, 0)
+    assert np.array_equal(c0, c1) and np.array_equal(np.asarray(t0).view(np.uint8), np.asarray(t1).view(np.uint8)) and \
+        np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+    if nlists <= 1024:
+        # every centroid probed (nprobe >= centroids, also beyond nlists: list 0 again, ivf_am.c:1978)
+        for nprobe in (nlists, nlists + 3):
+            t, d, c = ix.search(q[:130], 1, nprobe, 10, 0)
+            et, ed, ec, _ = oracle_search_batch(img, q[:130], 1, nprobe, 10, 0)
+            assert_same_results(t, d, c, et, ed, ec)
+    ix.close()
