@@ -397,7 +397,11 @@ def main():
                                                 "traffic is `traffic`"}}
 
     s16 = st.get("screen16_batches", 0) > 0 and st.get("screen16_fallbacks", 0) == 0
-    if s16:
+    centred = s16 and st.get("plane_bytes", 0) > 0 and args.strategy == "l2" and args.rows == "f32" and \
+        dict(o.split("=") for o in args.opt).get("screen16_centered", "1") != "0"
+    if centred:
+        roofline = sweep_roofline(args, st, nq, args.steps, elapsed / args.steps * 1e3, args.data, world) or roofline
+    elif s16:
         # The bound pass ran on the fp16 matrix cores (k_s16_sweep, csrc/ndbhip_screen16.h).  Algorithmic flops:
         # SURVEY 8d's per-unit figure, 3 x dim per scored (row, query) pair (subtract, multiply, add), x the pairs
         # one launch scores; the kernel EXECUTES 6 x dim per pair (three fp16 products of 2 flops: hi*hi + hi*lo +
@@ -569,7 +573,13 @@ def main():
                                 else "i.i.d. N(0,1)"),
                        "index_build": f"ndbhip_ivf_build_device: first-10000-row sample, {kmeans_iters} Lloyd iterations "
                                       f"(reference k-means rule), all rows assigned, {t_build:.3f} s",
-                       "list_len_min_mean_max": [int(list_len.min()), float(list_len.mean()), int(list_len.max())]},
+                       "list_len_min_mean_max": [int(list_len.min()), float(list_len.mean()), int(list_len.max())],
+                       "tables": {"this line (`value`)": (f"mixture of {args.components} Gaussians, sigma={args.sigma} (SURVEY 8d's "
+                                                          f"clustered variant): {qps:.0f} queries/s" if args.data == "clustered"
+                                                          else f"i.i.d. N(0,1): {qps:.0f} queries/s"),
+                                  "i.i.d. N(0,1) (BASELINE.md section 2), same shape, same binary: `iid_gauss`":
+                                      (None if not gauss or "queries_per_s" not in gauss else
+                                       f"{gauss['queries_per_s']:.0f} queries/s, recall@10 {gauss['recall_at_10']}")}},
             "recall_at_10": None if recall is None else round(recall, 4),
             "build_vectors_per_s": None if build_vps is None else round(build_vps, 1),
             "build": build,
@@ -671,11 +681,13 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
     ix.search_device(q[:nq], ot, od, oc, 1, nprobe, k, 0)          # warm-up (planes, workspaces)
     torch.cuda.synchronize()
     check(lib().ndbhip_stats_reset())
+    check(lib().ndbhip_profile(1))
     t0 = time.perf_counter()
     for sidx in range(steps):
         ix.search_device(q[(sidx + 1) * nq:(sidx + 2) * nq], ot, od, oc, 1, nprobe, k, 0)
     torch.cuda.synchronize()
     ts = (time.perf_counter() - t0) / steps
+    check(lib().ndbhip_profile(0))
     st = _lib.stats()
     qs = q[steps * nq:(steps + 1) * nq]
     got = unpack_tids(ot[:nrecall]).cpu().numpy()
@@ -700,8 +712,11 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
     off[1:] = np.cumsum(list_len)
     img = ndbo.IvfImage(cent_h, off, rows_h, tid_h)
     q_h = qs[:nparity].cpu().numpy()
-    with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as ex:
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
         res = list(ex.map(lambda i: img.search(q_h[i], 1, nprobe, k, 0), range(nparity)))
+    t_cpu = time.perf_counter() - t0
     gtid = ndbo.tids_from_device_u64(ot[:nparity].cpu().numpy())
     gd, gc = od[:nparity].cpu().numpy(), oc[:nparity].cpu().numpy()
     bad = 0
@@ -720,6 +735,11 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
             "screen16": {"batches": int(st.get("screen16_batches", 0)), "fallbacks": int(st.get("screen16_fallbacks", 0)),
                          "pairs_pruned_frac": round(st.get("pairs_pruned", 0) / max(1, nq * steps * nprobe), 4),
                          "rows_swept_frac": round(st.get("rows_swept", 0) / max(1, st.get("rows_scored", 1)), 4)},
+            "roofline": sweep_roofline(args, st, nq, steps, ts * 1e3, "gauss" if kind == "gauss" else "balanced", 1)
+            if st.get("plane_bytes", 0) > 0 else None,
+            "cpu_baseline": {"value": round(nparity / t_cpu, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                             "sample": f"{nparity} of the step's queries through the C oracle (gcc -O2, the reference's "
+                                       f"default flags), one thread per host core; the same sample checks the GPU results"},
             "oracle_parity": {"queries": nparity, "mismatches": int(bad)}}
 
 
@@ -859,17 +879,18 @@ def hnsw_pmc_traffic(n, dim, m, ef, nq, seconds):
     return {"traffic": None, "traffic_source": None}
 
 
-def pmc_traffic(args, world, kernel="k_ivf_scan"):
+def pmc_traffic(args, world, kernel="k_ivf_scan", data=None, want_busy=False):
     """(HBM-side bytes per launch, source) of the dominant kernel from the newest committed PMC pass that holds
     this kernel for this workload (profiles/*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction
     applied) — counters cannot be read from inside the process being timed, so this is a measurement of an earlier
     run of the same binary and workload, labelled as such; (None, None) when there is none."""
     import glob
+    none = (None, None, None) if want_busy else (None, None)
     if world != 1:
-        return None, None
+        return none
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel, {}).get(args.data)
+            k = json.load(f)["kernels"].get(kernel, {}).get(data or args.data)
         if not k:
             continue
         w = k["workload"]
@@ -877,8 +898,61 @@ def pmc_traffic(args, world, kernel="k_ivf_scan"):
             (args.nvec, args.dim, args.lists, args.probes, args.batch) and args.k == 10 and \
             w.get("rows", "f32") == args.rows and w.get("strategy", "l2") == args.strategy
         if same:
-            return int(k["traffic_bytes_per_launch"]), "committed PMC pass " + os.path.relpath(path, ROOT)
-    return None, None
+            src = "committed PMC pass " + os.path.relpath(path, ROOT)
+            if want_busy:
+                return int(k["traffic_bytes_per_launch"]), src, k.get("mfma_busy")
+            return int(k["traffic_bytes_per_launch"]), src
+    return none
+
+
+def sweep_roofline(args, st, nq, steps, ms_per_step, data_kind, world):
+    """Roofline of k_s16c_sweep (csrc/ndbhip_screen16c.h), the dominant kernel of a screened L2 batch over float4
+    rows, on the work it DOES — every number recomputable from library_stats and profiles/:
+      hbm   bytes = the row-plane tiles the batch touches, each counted once (library_stats.plane_bytes, counted on the
+            device per launch: 128 rows x dim x 2 B per tile) / the launch's HIP-event time, against 8 TB/s;
+      mfma  flops = 2 x dim per (row, pair) element actually multiplied (library_stats.rows_swept: one fp16 product per
+            element, tile padding not counted) / the same time, against the dense fp16 peak 2.5 PFLOP/s.
+    `bound` is the larger of the two fractions.  `traffic` = HBM-side bytes per launch from the newest committed PMC
+    pass of this kernel and workload (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), `mfma.busy_pmc` the matrix
+    pipe's busy share from the same passes.  SURVEY 8d's algorithmic bytes (every probed row once per query) are kept
+    as `algorithmic`: the batch reads each touched tile once for all its queries and excludes most (query, sublist)
+    pairs before the sweep, so that figure is a multiple of what is read, not a fraction of a roof."""
+    launches = max(1, st["scan_launches"])
+    ms = st["scan_kernel_ms"] / launches
+    if ms <= 0:
+        return None
+    dim = args.dim
+    dimp = (dim + 63) // 64 * 64
+    plane = st["plane_bytes"] / launches
+    pairs = st["rows_swept"] / launches
+    issued = 2.0 * dimp * pairs
+    hbm = plane / (ms * 1e-3) / 1e9
+    mf = issued / (ms * 1e-3) / 1e12
+    hf, mfr = hbm / HBM_PEAK_GBPS, mf / FP16_MFMA_PEAK_TFLOPS
+    tr, src, busy = pmc_traffic(args, world, "k_s16c_sweep", data_kind, want_busy=True)
+    alg = st["bytes_scored"] / launches
+    r = {"bound": "hbm" if hf >= mfr else "mfma",
+         "kernel": "k_s16c_sweep (centred one-plane sweep: fp16 planes of row - centre and query - centre, "
+                   "v_mfma_f32_32x32x16_f16, operands by LDS DMA)",
+         "achieved": round(hbm if hf >= mfr else mf, 1), "peak": HBM_PEAK_GBPS if hf >= mfr else FP16_MFMA_PEAK_TFLOPS,
+         "unit": "GB/s" if hf >= mfr else "TFLOP/s", "frac": round(max(hf, mfr), 4),
+         "traffic": tr, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": int(launches),
+         "hbm": {"bytes_per_launch": int(plane), "achieved": round(hbm, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": round(hf, 4),
+                 "step_frac": round(plane / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                 "traffic_over_bytes": None if not tr else round(tr / max(1.0, plane), 3),
+                 "note": "bytes = row-plane tiles touched, each once (device-counted); step_frac = the same bytes over "
+                         "ms_per_step (everything outside the sweep included)"},
+         "mfma": {"flops_per_launch": int(issued), "achieved": round(mf, 1), "peak": FP16_MFMA_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": round(mfr, 4), "busy_pmc": busy,
+                  "pairs_swept_frac": round(st["rows_swept"] / max(1, st["rows_scored"]), 4),
+                  "note": "flops issued for the (row, pair) elements the bounds left (one product per element)"},
+         "algorithmic": {"bytes_per_launch": int(alg), "times_the_bytes_read": round(alg / max(1.0, plane), 1),
+                         "note": "SURVEY 8d: rows probed x row bytes per query, no reuse across queries — not a "
+                                 "fraction of a roof: a tile is read once per batch and most pairs are excluded first"},
+         "rows_rescored_per_query": round(st.get("rows_rescored", 0) / max(1, nq * steps), 1),
+         "rows_emitted_per_query": round(st.get("rows_emitted", 0) / max(1, nq * steps), 1)}
+    return r
 
 
 def build_cpu_baseline(args, base, cent_h, iters):
@@ -898,18 +972,13 @@ def build_cpu_baseline(args, base, cent_h, iters):
     per_row = (time.perf_counter() - t0) / 8
     nrows = int(min(len(base), max(cores * 4, min(args.cpu_seconds, 10.0) * cores / max(per_row, 1e-6))))
     rows = np.ascontiguousarray(base[:nrows].cpu().numpy(), np.float32)
-
-    def work(lo):
-        for r in range(lo, min(nrows, lo + 64)):
-            L.ndbo_ivf_assign(cent, None, nl, nl, dim, rows[r], None)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(work, range(0, nrows, 64)))
-    wall = time.perf_counter() - t0
+    out = np.zeros(nrows, dtype=np.int32)
+    # oracle/ndb_oracle_mt.c: one pthread per core, 256 rows per grab (the rows are read once: no spread copy needed)
+    wall = float(L.ndbo_mt_ivf_assign_batch(rows.ctypes.data, nrows, dim, cent, nl, cores, out))
     rate = nrows / wall                                   # rows assigned per second, all cores
     total_rows = args.nvec + iters * min(10000, 100 * args.lists, args.nvec)
     return {"value": round(args.nvec / (total_rows / rate), 1), "unit": "vectors/s", "cores": cores, "kind": "port",
-            "sample": f"{nrows} rows assigned by oracle/ndb_oracle.c ndbo_ivf_assign on {cores} threads "
+            "sample": f"{nrows} rows assigned by oracle/ndb_oracle.c ndbo_ivf_assign on {cores} pthreads "
                       f"({rate:.0f} rows/s); build = ({iters} Lloyd iterations x sample + N) rows at that rate"}
 
 
@@ -941,33 +1010,38 @@ def run_cpu_baseline(args, cent_h, list_len, rows_h, tid_h, qs, out_t, out_d, ou
         img.search(q_h[0], 1, args.probes, args.k, 0, native=native)
         one = time.perf_counter() - t0
         budget = args.cpu_seconds / (2 if native_ok else 1)
-        nsample = int(max(cores, min(len(q_h), budget * cores / max(one, 1e-4))))
+        # a warm-up of one query per core (it also makes the row copy whose pages the workers touch first), then the
+        # timed sample: the C driver (oracle/ndb_oracle_mt.c), one pthread per core, queries handed out one by one
+        img.search_batch_mt(q_h[:min(len(q_h), cores)], 1, args.probes, args.k, 0, nthreads=cores, native=native)
+        _, _, _, w1 = img.search_batch_mt(q_h[:min(len(q_h), cores)], 1, args.probes, args.k, 0, nthreads=cores,
+                                          native=native)
+        per_round = max(w1, 1e-4)               # all cores busy with one query each
+        nsample = int(max(cores, min(len(q_h), budget / per_round * cores)))
         nsample = min(nsample, len(q_h))
-
-        def work(i):
-            return img.search(q_h[i], 1, args.probes, args.k, 0, native=native)
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as ex:      # ctypes calls release the GIL
-            res = list(ex.map(work, range(nsample)))
-        wall = time.perf_counter() - t0
+        et_all, ed_all, ec_all, wall = img.search_batch_mt(q_h[:nsample], 1, args.probes, args.k, 0, nthreads=cores,
+                                                           native=native)
         # parity of the GPU results on this build's sample (ids + float4 bits)
         gt = ndbo.tids_from_device_u64(out_t[:nsample].cpu().numpy())
         gd = out_d[:nsample].cpu().numpy()
         gc = out_c[:nsample].cpu().numpy()
         vbad = 0
-        for i, (et, ed, _) in enumerate(res):
-            ok = gc[i] == len(et) and np.array_equal(gt[i, :len(et)], ndbo.tids_to_u64(et)) and \
-                np.array_equal(gd[i, :len(et)].view(np.uint32), ed.view(np.uint32))
+        for i in range(nsample):
+            n_i = int(ec_all[i])
+            ok = gc[i] == n_i and np.array_equal(gt[i, :n_i], ndbo.tids_to_u64(et_all[i, :n_i])) and \
+                np.array_equal(gd[i, :n_i].view(np.uint32), ed_all[i, :n_i].view(np.uint32))
             vbad += (not ok)
         variants["gcc -O3 -march=native" if native else "gcc -O2 (reference default flags)"] = {
             "queries_per_s": round(nsample / wall, 2), "single_thread_ms_per_query": round(one * 1e3, 1),
+            "speedup_over_one_thread": round(nsample / wall * one, 1),
             "sample_queries": nsample, "gpu_mismatches": int(vbad)}
         if not native:
             n0, bad = nsample, vbad
+    img.free_spread()
     best = max(variants.values(), key=lambda v: v["queries_per_s"])
     return {"value": best["queries_per_s"], "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{n0} queries of the same workload, oracle/ndb_oracle.c (-ffp-contract=off), one thread per core; "
-                      "both builds in `variants`, `value` = the faster",
+            "sample": f"{n0} queries of the same workload through oracle/ndb_oracle.c (-ffp-contract=off) on one pthread per "
+                      "core (oracle/ndb_oracle_mt.c; the rows in memory first touched by the workers, 2 MiB stripes "
+                      "round-robin over their NUMA nodes); both builds in `variants`, `value` = the faster",
             "variants": variants,
             "gpu_parity_on_sample": {"queries": n0, "mismatches": int(bad)}}
 

@@ -496,6 +496,23 @@ int			ndbhip_hnsw_search_layer_device(ndbhip_hnsw *g, const float *d_queries, in
 											int k, uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 											uint64_t *d_out_tids, int64_t *d_out_scored);
 
+/* The `intended` HNSW: what the reference's index would be with its search-and-link bugs repaired —
+ * the greedy descent's result used as the next level's entry point (hnsw_am.c:2155-2286 drops it), every level searched
+ * on its own links with the best-first layer search src/scan/hnsw_scan.c:379-483 specifies, neighbours chosen among
+ * the ef_construction nearest by the textbook heuristic (or the nearest m), a full list PRUNED when a back-link
+ * arrives (hnsw_am.c:2503-2513 is the unreachable branch).  Same page-level data model (levels, 16 x 2m slots, entry
+ * point), same level draws; every build-time comparison is L2 like hnswInsertNode's.  The build is batch-synchronous
+ * (batches of clamp(nodes so far / batch_div, 1, batch_max): the members search the graph as it stood when their
+ * batch began, their links are applied in insertion order), which is part of the definition:
+ * oracle/ndb_oracle_hnsw2.c states it sequentially and the device graph equals it slot for slot.  Distances are
+ * squared L2 in fp64 (a fixed 64-way summation tree), returned as (float) sqrt. */
+int			ndbhip_hnsw_build_intended_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+											  const int32_t *levels, int ef_construction, int batch_div, int batch_max);
+int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
+											   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
+											   uint64_t *d_out_tids, int64_t *d_out_evals);
+int			ndbhip_hnsw_set_intended_select(int select);	/* 1 (default): the heuristic, 0: the nearest m */
+
 /* ------------------------------------------------------------------ */
 /* hnsw relation pages <-> mirror, PostgreSQL-free (src/index/hnsw_am.c:108-181, 1091-1110, 2288-2332):
  * block 0 = HnswMetaPageData, every other block = ONE item = HnswNodeData (48 B) + vector + neighbour slots

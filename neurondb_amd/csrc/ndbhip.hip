@@ -2645,7 +2645,11 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4) ? g_s16c_qb :
 		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : 4) : (ix->s16_sub ? 1 : 4));
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
-	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, (size_t) 4 * nq * npr + 1024), 0x7FFFFFFFu);
+	/* rows of the pair planes: every pair there can be, up to 4 x (queries x probes) (at least 65 536) — sublists
+	 * multiply the pairs of a probed list, the exclusion bounds remove most again; a batch with more than that goes to
+	 * the older path (flags[2]) */
+	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, std::max<size_t>((size_t) 4 * nq * npr + 1024, (size_t) 1 << 16)),
+														   0x7FFFFFFFu);
 	const uint32_t qcrowbytes = (uint32_t) dimp * 2u;
 
 	if (cen)
@@ -2675,6 +2679,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	 */
 	unsigned int *active = ix->w_ecount + 2 * (size_t) nq;
 
+	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
+	unsigned int over = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 	for (int round = 0; round < 2; round++)
 	{
 		const unsigned int *act = round ? active : (const unsigned int *) nullptr;
@@ -2682,6 +2689,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 		if (round)
 		{
+			/* some query overflowed its records in round 0 (the host has just read the flag): it alone is swept again,
+			 * against the threshold its first records give — rare enough that its nine launches are not worth
+			 * queueing for every batch */
+			HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned int), g.stream));
 			if (R == R_IVF_IP)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_IP>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 0);
@@ -2782,7 +2793,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const PairRec *) ix->w_pairs, (const uint32_t *) pair_off, ncs, (const float *) ix->d_centroids,
 							   sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
 							   ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_pslot, ix->w_pslot + qc_cap, ix->w_pslot + 2 * (size_t) qc_cap,
-							   lco, npr, qc_cap, flags, round == 0 ? flags + 4 : (unsigned int *) nullptr,
+							   lco, npr, qc_cap, flags + 2, round == 0 ? flags + 4 : (unsigned int *) nullptr,
 							   (const uint32_t *) cnt);
 		}
 		if (g_debug_s16 && round == 0)
@@ -2836,23 +2847,33 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,
 				  sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
-	}
-	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
 
 #define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__)
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
 			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr);
-	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
-					   g.d_counters + 3);
-	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
-					   g.d_counters + 4);
-	HIP_TRY(hipGetLastError());
-	unsigned int over = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		if (round == 0)
+		{
+			hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
+							   g.d_counters + 3);
+			hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
+							   g.d_counters + 4);
+		}
+		HIP_TRY(hipGetLastError());
+		{
+			unsigned int f[8];
 
-	HIP_TRY(hipMemcpyAsync(fl8, flags, sizeof(fl8), hipMemcpyDeviceToHost, g.stream));
-	HIP_TRY(hipStreamSynchronize(g.stream));
-	over = fl8[0];
+			HIP_TRY(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			over = f[0] | f[2];
+			if (round == 0)
+				memcpy(fl8, f, sizeof(fl8));
+			if (f[2])
+				break;			/* more pairs than the pair planes hold: nothing was swept, the older path serves the batch */
+		}
+		if (!over)
+			break;
+	}
 	if (cen && fl8[5] > 0)
 		ix->s16c_density = (float) fl8[4] / (float) fl8[5];		/* pairs per bucket with pairs: the next batch's tile size */
 	if (g_debug_s16)

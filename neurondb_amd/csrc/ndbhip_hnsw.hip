@@ -3294,3 +3294,288 @@ ndbhip_hnsw_search_layer(ndbhip_hnsw *h, const float *queries, int nq, int strat
 							out_scored);
 }
 
+/* ================================================================== */
+/* the `intended` HNSW (ndbhip_hnsw2.h; oracle/ndb_oracle_hnsw2.c is its sequential definition)                   */
+/* ================================================================== */
+#include "ndbhip_hnsw2.h"
+
+static int	g_h2_select = 1;		/* 1: the heuristic (ndbhip_hnsw_set_intended_select(0): the nearest m) */
+
+/* device temporaries of one call, freed on every way out */
+struct H2Tmp
+{
+	std::vector<void *> owned;
+	template <class T> int alloc(T *&p, size_t bytes)
+	{
+		p = nullptr;
+		HIP_TRY(hipMalloc((void **) &p, bytes ? bytes : 16));
+		owned.push_back((void *) p);
+		return 0;
+	}
+	~H2Tmp()
+	{
+		for (auto o : owned)
+			if (o)
+				(void) hipFree(o);
+	}
+};
+
+static int
+h2_workspace(ndbhip_hnsw *h, uint32_t nwaves, uint32_t nblocks, uint32_t *nwords_out)
+{
+	const uint32_t nwords = (nblocks + 31u) / 32u + 1u;
+
+	if (h->w_vbits_n < (size_t) nwaves * nwords)
+	{
+		if (grow(h->w_vbits, h->w_vbits_n, (size_t) nwaves * nwords)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(h->w_vbits, 0, h->w_vbits_n * sizeof(uint32_t), g.stream));	/* all zero at rest */
+	}
+	if (grow(h->w_vlog, h->w_vlog_n, (size_t) nwaves * H2_LOG_CAP)) return NDBHIP_ERR_HIP;
+	*nwords_out = nwords;
+	return 0;
+}
+
+static H2Graph
+h2_graph(const ndbhip_hnsw *h, uint32_t nvisible)
+{
+	H2Graph		gr;
+
+	gr.vecs = h->d_vecs;
+	gr.levels = h->d_levels;
+	gr.ncount = h->d_ncount;
+	gr.nbrs = h->d_nbrs;
+	gr.stride = (int64_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
+	gr.nvisible = nvisible;
+	gr.dim = h->dim;
+	gr.m = h->m;
+	return gr;
+}
+
+/*
+ * hnswbuild, `intended` mode: node i + 1 = row i, levels[i] its drawn level (host array), every comparison L2.
+ * Batches of clamp(nodes so far / batch_div, 1, batch_max) inserts: the members search the graph as it stood when the
+ * batch began (k_h2_insert_search), the host groups their back-links by target, every target replays its requests in
+ * insertion order (k_h2_apply).  The graph is the one ndbo_h2_build leaves, slot for slot.
+ */
+extern "C" int
+ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+								  const int32_t *levels, int ef_construction, int batch_div, int batch_max)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !d_rows || !d_tids || !levels || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ef_construction < 4 || ef_construction > NDBHIP_MAX_EF)
+		return fail(NDBHIP_ERR_INVALID, "ef_construction %d out of range 4..%d", ef_construction, NDBHIP_MAX_EF);
+	if (h->m > 64)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "intended build: m <= 64");
+	if ((uint64_t) n + 1 > 0xFFFFFFF0ull)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 blocks");
+	if (batch_div < 1) batch_div = 1;
+	if (batch_max < 1) batch_max = 1;
+	const uint32_t nb = n + 1;
+	const int	m = h->m;
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * m;
+	std::vector<int> lev(n);
+
+	for (uint32_t i = 0; i < n; i++)
+		lev[i] = levels[i] < 0 ? 0 : (levels[i] > NDBHIP_HNSW_MAX_LEVEL - 1 ? NDBHIP_HNSW_MAX_LEVEL - 1 : levels[i]);
+	hnsw_free_dev(h);
+	HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
+	HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
+	h->cap_blocks = nb;
+	/* every page is laid out before anything is linked: a node is unreachable until its own insert links it */
+	HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_vecs + h->dim, d_rows, (size_t) n * h->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_levels + 1, lev.data(), (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_ncount, 0, (size_t) nb * 16 * sizeof(int16_t), g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, (size_t) nb * stride * sizeof(uint32_t), g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_tids + 1, d_tids, (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+	h->dense = true;
+	h->nblocks = nb;
+	h->ef_construction = ef_construction;
+
+	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * 8, std::max(1, batch_max));
+	uint32_t	nwords = 0;
+
+	if (h2_workspace(h, nwaves, nb, &nwords)) return NDBHIP_ERR_HIP;
+	const size_t smem = h2_smem_bytes((uint32_t) ef_construction);
+
+	HIP_TRY(hipFuncSetAttribute((const void *) k_h2_insert_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+	/* per-batch scratch: selections (compact: a member has min(level, entry level) + 1 levels), groups, requests */
+	H2Tmp		tmp;
+	uint32_t   *d_off = nullptr, *d_sid = nullptr;
+	double	   *d_sd2 = nullptr;
+	int		   *d_sn = nullptr;
+	H2Group    *d_grp = nullptr;
+	H2Req	   *d_req = nullptr;
+	const size_t bm = (size_t) batch_max, lvcap = bm * NDBHIP_HNSW_MAX_LEVEL;
+
+	if (tmp.alloc(d_off, bm * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_sid, lvcap * m * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_sd2, lvcap * m * 8)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_sn, lvcap * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_grp, lvcap * m * sizeof(H2Group))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_req, lvcap * m * sizeof(H2Req))) return NDBHIP_ERR_HIP;
+	std::vector<uint32_t> off(bm), sid;
+	std::vector<double> sd2;
+	std::vector<int> sn;
+	std::vector<H2Group> grp;
+	std::vector<H2Req> req;
+	struct Key { uint64_t key; uint32_t seq; uint32_t x; double d2; };
+	std::vector<Key> keys;
+	uint32_t	entry = NDBHIP_INVALID_BLOCK;
+	int			entry_level = -1;
+	uint32_t	done = 0;
+	int64_t		nbatches = 0, maxbatch = 0, nprunes = 0;
+
+	memset(h->build_stats, 0, sizeof(h->build_stats));
+	while (done < n)
+	{
+		uint32_t	b = (uint32_t) std::min<int64_t>(std::max<int64_t>((int64_t) done / batch_div, 1), batch_max);
+
+		b = std::min(b, n - done);
+		const uint32_t first = done + 1;
+
+		if (entry != NDBHIP_INVALID_BLOCK)
+		{
+			uint32_t	nlev = 0;
+
+			for (uint32_t i = 0; i < b; i++)
+			{
+				off[i] = nlev;
+				nlev += (uint32_t) std::min(lev[done + i], entry_level) + 1u;
+			}
+			HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t) b * 4, hipMemcpyHostToDevice, g.stream));
+			hipLaunchKernelGGL(k_h2_insert_search, dim3(std::min(b, nwaves)), dim3(64), smem, g.stream, h2_graph(h, first), first, b,
+							   (uint32_t) ef_construction, g_h2_select, entry, entry_level, (const uint32_t *) d_off, d_sid, d_sd2,
+							   d_sn, h->w_vbits, h->w_vlog, nwords);
+			HIP_TRY(hipGetLastError());
+			sid.resize((size_t) nlev * m);
+			sd2.resize((size_t) nlev * m);
+			sn.resize(nlev);
+			HIP_TRY(hipMemcpyAsync(sid.data(), d_sid, sid.size() * 4, hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipMemcpyAsync(sd2.data(), d_sd2, sd2.size() * 8, hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipMemcpyAsync(sn.data(), d_sn, sn.size() * 4, hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			/* the back-links, grouped by target (node, level), inside a group in insertion order */
+			keys.clear();
+			for (uint32_t i = 0; i < b; i++)
+			{
+				const int	top = std::min(lev[done + i], entry_level);
+
+				for (int lc = top; lc >= 0; lc--)
+				{
+					const size_t row = (size_t) off[i] + (size_t) (top - lc);
+
+					for (int j = 0; j < sn[row]; j++)
+					{
+						Key			kx;
+
+						kx.key = ((uint64_t) sid[row * m + j] << 8) | (uint64_t) lc;
+						kx.seq = (uint32_t) keys.size();
+						kx.x = first + i;
+						kx.d2 = sd2[row * m + j];
+						keys.push_back(kx);
+					}
+				}
+			}
+			std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &c) { return a.key < c.key || (a.key == c.key && a.seq < c.seq); });
+			grp.clear();
+			req.resize(keys.size());
+			for (size_t r = 0; r < keys.size(); r++)
+			{
+				req[r].x = keys[r].x;
+				req[r].pad = 0;
+				req[r].d2 = keys[r].d2;
+				if (r == 0 || keys[r].key != keys[r - 1].key)
+				{
+					H2Group		gr;
+
+					gr.node = (uint32_t) (keys[r].key >> 8);
+					gr.level = (int) (keys[r].key & 0xFF);
+					gr.r0 = (uint32_t) r;
+					gr.r1 = (uint32_t) r;
+					grp.push_back(gr);
+				}
+				grp.back().r1 = (uint32_t) r + 1;
+			}
+			if (!grp.empty())
+			{
+				HIP_TRY(hipMemcpyAsync(d_grp, grp.data(), grp.size() * sizeof(H2Group), hipMemcpyHostToDevice, g.stream));
+				HIP_TRY(hipMemcpyAsync(d_req, req.data(), req.size() * sizeof(H2Req), hipMemcpyHostToDevice, g.stream));
+				hipLaunchKernelGGL(k_h2_apply, dim3((unsigned) std::min<size_t>(grp.size(), (size_t) g.num_cus * 16)), dim3(64), 0, g.stream,
+								   h2_graph(h, first + b), (const H2Group *) d_grp, (uint32_t) grp.size(), (const H2Req *) d_req,
+								   g_h2_select);
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamSynchronize(g.stream));		/* grp / req are reused by the next batch */
+			}
+			nprunes += (int64_t) keys.size();
+		}
+		/* the entry point: the first node of every new top level, in insertion order */
+		for (uint32_t i = 0; i < b; i++)
+			if (entry == NDBHIP_INVALID_BLOCK || lev[done + i] > entry_level)
+			{
+				entry = first + i;
+				entry_level = lev[done + i];
+			}
+		done += b;
+		nbatches++;
+		maxbatch = std::max<int64_t>(maxbatch, b);
+	}
+	h->entry_point = entry;
+	h->entry_level = entry_level;
+	h->loaded = true;
+	h->build_stats[4] = nbatches;
+	h->build_stats[5] = maxbatch;
+	h->build_stats[0] = nprunes;
+	return NDBHIP_OK;
+}
+
+/* kNN search of the `intended` mode on a dense mirror (built by ndbhip_hnsw_build_intended_device, or any graph):
+ * greedy descent, best-first layer search with ef at level 0, the k nearest ascending; distances (float) sqrt(d2)
+ * (L2 whatever the operator class: on unit-norm rows the order is the cosine order).  Device pointers, asynchronous. */
+extern "C" int
+ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+								   float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !h->loaded)
+		return fail(NDBHIP_ERR_STATE, "graph not loaded");
+	if (nq < 0 || (nq > 0 && (!d_queries || !d_out_blocks || !d_out_dist || !d_out_count)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (k < 1 || k > NDBHIP_MAX_K || ef < 1 || ef > NDBHIP_MAX_EF)
+		return fail(NDBHIP_ERR_INVALID, "k or ef out of range");
+	if (nq == 0)
+		return NDBHIP_OK;
+	int			rc = hnsw_densify(h);
+
+	if (rc)
+		return rc;
+	const uint32_t efe = (uint32_t) std::max(ef, k);
+	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * 8, nq);
+	uint32_t	nwords = 0;
+
+	if (h2_workspace(h, nwaves, h->nblocks, &nwords)) return NDBHIP_ERR_HIP;
+	const size_t smem = h2_smem_bytes(efe);
+
+	HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+	hipLaunchKernelGGL(k_h2_search, dim3(nwaves), dim3(64), smem, g.stream, h2_graph(h, h->nblocks), d_queries, (uint32_t) nq, efe,
+					   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
+					   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals);
+	HIP_TRY(hipGetLastError());
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_set_intended_select(int select)
+{
+	if (select != 0 && select != 1)
+		return fail(NDBHIP_ERR_INVALID, "select must be 0 (the nearest m) or 1 (the heuristic)");
+	g_h2_select = select;
+	return NDBHIP_OK;
+}

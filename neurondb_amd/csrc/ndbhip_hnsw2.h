@@ -1,0 +1,693 @@
+/*
+ * ndbhip_hnsw2.h — the `intended` HNSW on the device (part of ndbhip_hnsw.hip's translation unit): the graph SURVEY 8f-2
+ * asks for next to the bug-compatible hnswInsertNode / hnswSearch, built and searched in HBM.
+ *
+ * The algorithm and its relation to the reference (what is kept: page-level data model, injected level draws, L2 for
+ * every build-time comparison, the best-first layer search of src/scan/hnsw_scan.c:379-483, 645-844 as the search's
+ * specification; what is repaired: the greedy descent's result is used, every level is searched on its own links, a
+ * full list is pruned instead of the back-link being dropped — src/index/hnsw_am.c:2155-2286, 2503-2513) are stated
+ * once, in oracle/ndb_oracle_hnsw2.c, whose sequential run this file reproduces slot for slot
+ * (tests/test_gpu_hnsw2.py).  Three things make that possible:
+ *   - one arithmetic: squared L2 in fp64, terms (double) fl32(a_i - b_i) squared, 64 strided partial sums — ONE LANE
+ *     EACH — folded by the xor butterfly 32 .. 1; every comparison is on (d2, block number), so nothing ties;
+ *   - order-free steps: the result set of a layer search after expanding a node is the best ef of (what it was) +
+ *     (the node's unvisited neighbours), whatever order they are offered in;
+ *   - a batch-synchronous schedule that is PART OF THE DEFINITION: the members of a batch search the graph as it
+ *     stood when the batch began (k_h2_insert_search, one wave per member, all in parallel), then their links are
+ *     applied in insertion order — lists of different (node, level) pairs evolve independently, so the requests
+ *     are grouped by target on the host and every target replays its own requests in order (k_h2_apply, one wave
+ *     per target).
+ * Distance evaluations dominate: a wave reads a 3 KB row with twelve coalesced 256-byte loads, four rows in flight.
+ */
+#ifndef NDBHIP_HNSW2_H
+#define NDBHIP_HNSW2_H
+
+#define H2_QREG 16				/* query elements a lane keeps in registers (dim <= 1024); beyond: re-read (L1 / L2) */
+#define H2_LOG_CAP 8192			/* visited blocks a wave logs for clearing its bitmap; more: the whole map is cleared */
+
+struct H2Graph
+{
+	const float *vecs;
+	const int  *levels;
+	int16_t    *ncount;
+	uint32_t   *nbrs;
+	int64_t		stride;			/* 16 levels x 2m slots */
+	uint32_t	nvisible;		/* blocks below this are linked (what a frozen search may meet) */
+	int			dim;
+	int			m;
+};
+
+__device__ __forceinline__ double
+h2_wave_fold(double p)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+		p = p + __shfl_xor(p, off, 64);
+	return p;
+}
+
+__device__ __forceinline__ bool
+h2_less(double d, uint32_t id, double e, uint32_t jd)
+{
+	return d < e || (d == e && id < jd);
+}
+
+/* the wave's query: elements lane, lane + 64, ... in registers while they fit */
+struct H2Query
+{
+	const float *q;
+	float		r[H2_QREG];
+	int			dim;
+
+	__device__ __forceinline__ void load(const float *qq, int d, int lane)
+	{
+		q = qq;
+		dim = d;
+#pragma unroll
+		for (int j = 0; j < H2_QREG; j++)
+			r[j] = lane + 64 * j < d ? qq[lane + 64 * j] : 0.0f;
+	}
+};
+
+/* d2(query, row x) by the whole wave (every lane returns it) */
+__device__ __forceinline__ double
+h2_dist2(const H2Query &Q, const float *__restrict__ x, int lane)
+{
+	double		p = 0.0;
+
+	if (Q.dim <= 64 * H2_QREG)
+	{
+#pragma unroll
+		for (int j = 0; j < H2_QREG; j++)
+			if (lane + 64 * j < Q.dim)
+			{
+				const float d = Q.r[j] - x[lane + 64 * j];
+
+				p += (double) d * (double) d;
+			}
+	}
+	else
+		for (int i = lane; i < Q.dim; i += 64)
+		{
+			const float d = Q.q[i] - x[i];
+
+			p += (double) d * (double) d;
+		}
+	return h2_wave_fold(p);
+}
+
+/* four rows at a time: the loads of all four are in flight before the first sum is folded */
+__device__ __forceinline__ void
+h2_dist2x4(const H2Query &Q, const float *const x[4], int n, int lane, double out[4])
+{
+	double		p[4] = {0.0, 0.0, 0.0, 0.0};
+
+	if (Q.dim <= 64 * H2_QREG)
+	{
+#pragma unroll
+		for (int j = 0; j < H2_QREG; j++)
+			if (lane + 64 * j < Q.dim)
+			{
+				float		v[4];
+
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					v[u] = u < n ? x[u][lane + 64 * j] : 0.0f;
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					const float d = Q.r[j] - v[u];
+
+					p[u] += (double) d * (double) d;
+				}
+			}
+	}
+	else
+		for (int i = lane; i < Q.dim; i += 64)
+		{
+			const float qv = Q.q[i];
+
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				if (u < n)
+				{
+					const float d = qv - x[u][i];
+
+					p[u] += (double) d * (double) d;
+				}
+		}
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+		out[u] = h2_wave_fold(p[u]);
+}
+
+/* d2 of two rows of the graph */
+__device__ __forceinline__ double
+h2_dist2_rows(const float *__restrict__ a, const float *__restrict__ b, int dim, int lane)
+{
+	double		p = 0.0;
+
+	for (int i = lane; i < dim; i += 64)
+	{
+		const float d = a[i] - b[i];
+
+		p += (double) d * (double) d;
+	}
+	return h2_wave_fold(p);
+}
+
+/* a wave's visited set: one bit per block in global memory (all zero at rest), the blocks it set logged for clearing */
+struct H2Visited
+{
+	uint32_t   *bits;
+	uint32_t   *log;
+	uint32_t	nwords;
+	uint32_t	nlog;			/* uniform */
+
+	/* lanes with act: was block b unvisited (and now marked)?  One lane wins where several name the same block. */
+	__device__ __forceinline__ bool mark(bool act, uint32_t b, int lane)
+	{
+		bool		fresh = false;
+
+		if (act)
+		{
+			const uint32_t bit = 1u << (b & 31u);
+
+			fresh = !(atomicOr(&bits[b >> 5], bit) & bit);
+		}
+		const unsigned long long mk = __ballot(fresh);
+
+		if (fresh)
+		{
+			const uint32_t slot = nlog + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull));
+
+			if (slot < H2_LOG_CAP)
+				log[slot] = b;
+		}
+		nlog += (uint32_t) __popcll(mk);
+		return fresh;
+	}
+	__device__ __forceinline__ void clear(int lane)
+	{
+		if (nlog <= H2_LOG_CAP)
+			for (uint32_t i = lane; i < nlog; i += 64)
+				bits[log[i] >> 5] = 0;
+		else
+			for (uint32_t i = lane; i < nwords; i += 64)
+				bits[i] = 0;
+		nlog = 0;
+		__threadfence_block();
+	}
+};
+
+/* the wave's result set of a layer search, in LDS: wd / wid / wx[ef] (wx: already expanded) */
+struct H2Set
+{
+	double	   *wd;
+	uint32_t   *wid;
+	uint8_t    *wx;
+	uint32_t	ef;
+	uint32_t	nw;				/* uniform */
+};
+
+/* nearest unexpanded entry (index, or -1), wave-uniform */
+__device__ __forceinline__ int
+h2_pick(const H2Set &W, int lane)
+{
+	double		bd = 0.0;
+	uint32_t	bid = 0;
+	int			bi = -1;
+
+	for (uint32_t i = lane; i < W.nw; i += 64)
+		if (!W.wx[i] && (bi < 0 || h2_less(W.wd[i], W.wid[i], bd, bid)))
+		{
+			bd = W.wd[i];
+			bid = W.wid[i];
+			bi = (int) i;
+		}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const double od = __shfl_xor(bd, off, 64);
+		const uint32_t oid = (uint32_t) __shfl_xor((int) bid, off, 64);
+		const int	oi = __shfl_xor(bi, off, 64);
+
+		if (oi >= 0 && (bi < 0 || h2_less(od, oid, bd, bid)))
+		{
+			bd = od;
+			bid = oid;
+			bi = oi;
+		}
+	}
+	return bi;
+}
+
+/* farthest entry (index), wave-uniform; nw >= 1 */
+__device__ __forceinline__ int
+h2_worst(const H2Set &W, int lane)
+{
+	double		bd = 0.0;
+	uint32_t	bid = 0;
+	int			bi = -1;
+
+	for (uint32_t i = lane; i < W.nw; i += 64)
+		if (bi < 0 || h2_less(bd, bid, W.wd[i], W.wid[i]))
+		{
+			bd = W.wd[i];
+			bid = W.wid[i];
+			bi = (int) i;
+		}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const double od = __shfl_xor(bd, off, 64);
+		const uint32_t oid = (uint32_t) __shfl_xor((int) bid, off, 64);
+		const int	oi = __shfl_xor(bi, off, 64);
+
+		if (oi >= 0 && (bi < 0 || h2_less(bd, bid, od, oid)))
+		{
+			bd = od;
+			bid = oid;
+			bi = oi;
+		}
+	}
+	return bi;
+}
+
+/* offer (d, id) to the set: appended while there is room, else it replaces the farthest entry it beats (uniform args) */
+__device__ __forceinline__ void
+h2_offer(H2Set &W, double d, uint32_t id, int lane)
+{
+	if (W.nw < W.ef)
+	{
+		if (lane == 0)
+		{
+			W.wd[W.nw] = d;
+			W.wid[W.nw] = id;
+			W.wx[W.nw] = 0;
+		}
+		W.nw++;
+		__threadfence_block();
+		return;
+	}
+	const int	w = h2_worst(W, lane);
+
+	if (h2_less(d, id, W.wd[w], W.wid[w]))
+	{
+		if (lane == 0)
+		{
+			W.wd[w] = d;
+			W.wid[w] = id;
+			W.wx[w] = 0;
+		}
+		__threadfence_block();
+	}
+}
+
+/*
+ * Best-first search of one layer from the single entry point (ep, epd); leaves the result set in W (unsorted).
+ * `evals` counts distance evaluations.  A node's neighbour list is read one slot per lane, the unvisited ones are
+ * scored four rows at a time and offered to the set.
+ */
+__device__ __forceinline__ void
+h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int level, H2Set &W, H2Visited &V, int lane,
+				long long &evals)
+{
+	W.nw = 0;
+	(void) V.mark(lane == 0, ep, lane);
+	h2_offer(W, epd, ep, lane);
+	for (;;)
+	{
+		const int	bi = h2_pick(W, lane);
+
+		if (bi < 0)
+			break;
+		if (lane == 0)
+			W.wx[bi] = 1;
+		__threadfence_block();
+		const uint32_t c = W.wid[bi];
+		const int	cnt = min((int) g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		const uint32_t *nb = g.nbrs + (size_t) c * g.stride + (size_t) level * 2 * g.m;
+		const uint32_t e = lane < cnt ? nb[lane] : NDBHIP_INVALID_BLOCK;
+		const bool	fresh = V.mark(e != NDBHIP_INVALID_BLOCK && e < g.nvisible && e != 0, e, lane);
+		unsigned long long todo = __ballot(fresh);
+
+		while (todo)
+		{
+			const float *x[4];
+			uint32_t	ids[4];
+			double		d[4];
+			int			n = 0;
+
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				ids[u] = 0;
+				x[u] = g.vecs;
+				if (todo)
+				{
+					const int	l = __builtin_ctzll(todo);
+
+					todo &= todo - 1;
+					ids[u] = (uint32_t) __builtin_amdgcn_readlane((int) e, l);
+					x[u] = g.vecs + (size_t) ids[u] * g.dim;
+					n = u + 1;
+				}
+			}
+			h2_dist2x4(Q, x, n, lane, d);
+			evals += n;
+			for (int u = 0; u < n; u++)
+				h2_offer(W, d[u], ids[u], lane);
+		}
+	}
+}
+
+/* greedy step of the upper layers: from (cur, curd) move to the nearest neighbour at `level` while one is nearer */
+__device__ __forceinline__ void
+h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &curd, int lane, long long &evals)
+{
+	for (;;)
+	{
+		const int	cnt = min((int) g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		const uint32_t *nb = g.nbrs + (size_t) cur * g.stride + (size_t) level * 2 * g.m;
+		const uint32_t e = lane < cnt ? nb[lane] : NDBHIP_INVALID_BLOCK;
+		unsigned long long todo = __ballot(e != NDBHIP_INVALID_BLOCK && e < g.nvisible && e != 0);
+		uint32_t	bid = cur;
+		double		bd = curd;
+
+		while (todo)
+		{
+			const float *x[4];
+			uint32_t	ids[4];
+			double		d[4];
+			int			n = 0;
+
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				ids[u] = 0;
+				x[u] = g.vecs;
+				if (todo)
+				{
+					const int	l = __builtin_ctzll(todo);
+
+					todo &= todo - 1;
+					ids[u] = (uint32_t) __builtin_amdgcn_readlane((int) e, l);
+					x[u] = g.vecs + (size_t) ids[u] * g.dim;
+					n = u + 1;
+				}
+			}
+			h2_dist2x4(Q, x, n, lane, d);
+			evals += n;
+			for (int u = 0; u < n; u++)
+				if (h2_less(d[u], ids[u], bd, bid))
+				{
+					bd = d[u];
+					bid = ids[u];
+				}
+		}
+		if (bid == cur)
+			return;
+		cur = bid;
+		curd = bd;
+	}
+}
+
+/* the set's entries ascending by (d2, id) into sid / sd (LDS): every lane ranks its entries by counting */
+__device__ __forceinline__ void
+h2_sort(const H2Set &W, uint32_t *sid, double *sd, int lane)
+{
+	for (uint32_t i = lane; i < W.nw; i += 64)
+	{
+		const double d = W.wd[i];
+		const uint32_t id = W.wid[i];
+		uint32_t	rank = 0;
+
+		for (uint32_t j = 0; j < W.nw; j++)
+			rank += h2_less(W.wd[j], W.wid[j], d, id) ? 1u : 0u;
+		sid[rank] = id;
+		sd[rank] = d;
+	}
+	__threadfence_block();
+}
+
+/*
+ * The links of one node out of candidates ascending by (d2 to the node, id): select 0 = the first M; 1 = the
+ * heuristic — a candidate is taken unless it is nearer to one already taken than to the node.  out / outd in LDS or
+ * global; returns how many (uniform).
+ */
+__device__ __forceinline__ int
+h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M, int select, uint32_t *out, double *outd,
+		  int lane)
+{
+	int			n = 0;
+
+	for (int i = 0; i < nc && n < M; i++)
+	{
+		const uint32_t c = cid[i];
+		const double dc = cd[i];
+		bool		ok = true;
+
+		if (select)
+			for (int j = 0; j < n && ok; j++)
+				if (h2_dist2_rows(g.vecs + (size_t) c * g.dim, g.vecs + (size_t) out[j] * g.dim, g.dim, lane) < dc)
+					ok = false;
+		if (ok)
+		{
+			if (lane == 0)
+			{
+				out[n] = c;
+				outd[n] = dc;
+			}
+			n++;
+			__threadfence_block();
+		}
+	}
+	return n;
+}
+
+__host__ __device__ static inline size_t
+h2_smem_bytes(uint32_t ef)
+{
+	return (size_t) ef * (8 + 4 + 1 + 8 + 4) + 64;
+}
+
+/* kNN queries: greedy descent to level 1, layer search with ef at level 0, the k nearest ascending, distances as
+ * (float) sqrt(d2).  Persistent grid of one-wave blocks; block b owns visited map b. */
+__global__ __launch_bounds__(64) void
+k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level,
+			const uint64_t *__restrict__ tids, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords,
+			uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
+			uint64_t *__restrict__ out_tids, long long *__restrict__ out_evals)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int	lane = threadIdx.x;
+	H2Set		W;
+	H2Visited	V;
+
+	W.wd = (double *) smem;
+	double	   *sd = W.wd + ef;
+	W.wid = (uint32_t *) (sd + ef);
+	uint32_t   *sid = W.wid + ef;
+	W.wx = (uint8_t *) (sid + ef);
+	W.ef = ef;
+	V.bits = vbits + (size_t) blockIdx.x * nwords;
+	V.log = vlog + (size_t) blockIdx.x * H2_LOG_CAP;
+	V.nwords = nwords;
+	V.nlog = 0;
+	for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x)
+	{
+		H2Query		Q;
+		long long	evals = 0;
+		uint32_t	n = 0;
+
+		Q.load(queries + (size_t) q * g.dim, g.dim, lane);
+		if (entry != NDBHIP_INVALID_BLOCK)
+		{
+			uint32_t	cur = entry;
+			double		curd = h2_dist2(Q, g.vecs + (size_t) cur * g.dim, lane);
+
+			evals = 1;
+			for (int lc = entry_level; lc >= 1; lc--)
+				h2_greedy(g, Q, lc, cur, curd, lane, evals);
+			h2_search_layer(g, Q, cur, curd, 0, W, V, lane, evals);
+			V.clear(lane);
+			h2_sort(W, sid, sd, lane);
+			n = min(W.nw, k);
+			for (uint32_t i = lane; i < n; i += 64)
+			{
+				out_blocks[(size_t) q * k + i] = sid[i];
+				out_dist[(size_t) q * k + i] = (float) __builtin_sqrt(sd[i]);
+				if (out_tids)
+					out_tids[(size_t) q * k + i] = tids[sid[i]];
+			}
+		}
+		if (lane == 0)
+		{
+			out_count[q] = (int) n;
+			if (out_evals)
+				out_evals[q] = evals;
+		}
+		__threadfence_block();
+	}
+}
+
+/*
+ * Search phase of a batch of inserts against the graph as it stands (frozen: nothing it reads is written meanwhile).
+ * Member i = block first + i, level lev[i]; its selections of levels top .. 0 (top = min(level, entry level)) go to
+ * sel_ids / sel_d2 [sel_off[i] + (top - lc)][m] and sel_n, AND into its own (not yet reachable) neighbour lists.
+ */
+__global__ __launch_bounds__(64) void
+k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int select, uint32_t entry, int entry_level,
+				   const uint32_t *__restrict__ sel_off, uint32_t *__restrict__ sel_ids, double *__restrict__ sel_d2,
+				   int *__restrict__ sel_n, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	__shared__ uint32_t s_selid[128];
+	__shared__ double s_seld[128];
+	const int	lane = threadIdx.x;
+	H2Set		W;
+	H2Visited	V;
+
+	W.wd = (double *) smem;
+	double	   *sd = W.wd + efc;
+	W.wid = (uint32_t *) (sd + efc);
+	uint32_t   *sid = W.wid + efc;
+	W.wx = (uint8_t *) (sid + efc);
+	W.ef = efc;
+	V.bits = vbits + (size_t) blockIdx.x * nwords;
+	V.log = vlog + (size_t) blockIdx.x * H2_LOG_CAP;
+	V.nwords = nwords;
+	V.nlog = 0;
+	for (uint32_t i = blockIdx.x; i < nmem; i += gridDim.x)
+	{
+		const uint32_t x = first + i;
+		const int	level = g.levels[x];
+		H2Query		Q;
+		long long	evals = 0;
+
+		if (entry == NDBHIP_INVALID_BLOCK)
+			continue;
+		Q.load(g.vecs + (size_t) x * g.dim, g.dim, lane);
+		uint32_t	cur = entry;
+		double		curd = h2_dist2(Q, g.vecs + (size_t) cur * g.dim, lane);
+
+		for (int lc = entry_level; lc > level; lc--)
+			h2_greedy(g, Q, lc, cur, curd, lane, evals);
+		const int	top = min(level, entry_level);
+
+		for (int lc = top; lc >= 0; lc--)
+		{
+			const size_t so = ((size_t) sel_off[i] + (size_t) (top - lc)) * g.m;
+
+			h2_search_layer(g, Q, cur, curd, lc, W, V, lane, evals);
+			V.clear(lane);
+			h2_sort(W, sid, sd, lane);
+			const int	n = h2_select(g, sid, sd, (int) W.nw, g.m, select, s_selid, s_seld, lane);
+
+			if (lane == 0)
+			{
+				sel_n[sel_off[i] + (uint32_t) (top - lc)] = n;
+				g.ncount[(size_t) x * NDBHIP_HNSW_MAX_LEVEL + lc] = (int16_t) n;
+			}
+			for (int j = lane; j < n; j += 64)
+			{
+				sel_ids[so + j] = s_selid[j];
+				sel_d2[so + j] = s_seld[j];
+				g.nbrs[(size_t) x * g.stride + (size_t) lc * 2 * g.m + j] = s_selid[j];
+			}
+			cur = sid[0];
+			curd = sd[0];
+			__threadfence_block();
+		}
+	}
+}
+
+/* one target (node, level) and its back-link requests req[r0 .. r1), in insertion order */
+struct H2Group
+{
+	uint32_t	node;
+	int			level;
+	uint32_t	r0, r1;
+};
+struct H2Req
+{
+	uint32_t	x;
+	uint32_t	pad;
+	double		d2;				/* d2(x, target) */
+};
+
+/*
+ * Apply phase: every target replays its requests in order — appended while the list has room, else the list becomes
+ * what the selection rule keeps of (list + x) around the target, ascending by (d2 to the target, id).  One wave per
+ * target; scratch in LDS: cid / cd / kid / kd [2m + 1].
+ */
+__global__ __launch_bounds__(64) void
+k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups, const H2Req *__restrict__ req, int select)
+{
+	__shared__ uint32_t cid[260], kid[260];
+	__shared__ double cd[260], kd[260];
+	const int	lane = threadIdx.x;
+
+	for (uint32_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x)
+	{
+		const H2Group gr = groups[gi];
+		const int	cap = gr.level == 0 ? 2 * g.m : g.m;
+		uint32_t   *nb = g.nbrs + (size_t) gr.node * g.stride + (size_t) gr.level * 2 * g.m;
+		int16_t    *pc = &g.ncount[(size_t) gr.node * NDBHIP_HNSW_MAX_LEVEL + gr.level];
+		int			cnt = *pc;
+		const float *ev = g.vecs + (size_t) gr.node * g.dim;
+
+		for (uint32_t r = gr.r0; r < gr.r1; r++)
+		{
+			const uint32_t x = req[r].x;
+			const double dxe = req[r].d2;
+
+			if (cnt < cap)
+			{
+				if (lane == 0)
+					nb[cnt] = x;
+				cnt++;
+				__threadfence_block();
+				continue;
+			}
+			/* candidates = the list + x with their distances to the target ... */
+			for (int i0 = 0; i0 <= cnt; i0++)
+			{
+				const uint32_t id = i0 < cnt ? nb[i0] : x;
+				const double d = i0 < cnt ? h2_dist2_rows(ev, g.vecs + (size_t) id * g.dim, g.dim, lane) : dxe;
+
+				if (lane == 0)
+				{
+					kid[i0] = id;
+					kd[i0] = d;
+				}
+			}
+			__threadfence_block();
+			/* ... ascending by (d2, id) ... */
+			for (int i0 = lane; i0 <= cnt; i0 += 64)
+			{
+				const double d = kd[i0];
+				const uint32_t id = kid[i0];
+				int			rank = 0;
+
+				for (int j = 0; j <= cnt; j++)
+					rank += h2_less(kd[j], kid[j], d, id) ? 1 : 0;
+				cid[rank] = id;
+				cd[rank] = d;
+			}
+			__threadfence_block();
+			/* ... and what the rule keeps of them */
+			const int	n = h2_select(g, cid, cd, cnt + 1, cap, select, kid, kd, lane);
+
+			for (int j = lane; j < 2 * g.m; j += 64)
+				nb[j] = j < n ? kid[j] : NDBHIP_INVALID_BLOCK;
+			cnt = n;
+			__threadfence_block();
+		}
+		if (lane == 0)
+			*pc = (int16_t) cnt;
+	}
+}
+
+#endif							/* NDBHIP_HNSW2_H */

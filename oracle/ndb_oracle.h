@@ -131,6 +131,16 @@ int			ndbo_ivf_collect_candidates(const ndbo_ivf *ix, const float *query, int st
 int			ndbo_ivf_search(const ndbo_ivf *ix, const float *query, int strategy, int nprobe, int k,
 							int64_t max_candidates, ndbo_tid *out_tids, float *out_dist, int64_t *n_scored);
 
+/* ndb_oracle_mt.c: the same single-query functions on one thread per host core (CPU baseline only: no arithmetic of
+ * its own).  ndbo_mt_spread_copy: a copy whose pages are first touched by the workers, 2 MiB stripes round-robin (a
+ * row array filled by one thread sits on one NUMA node).  The batch drivers return the parallel section's wall time. */
+void	   *ndbo_mt_spread_copy(const void *src, size_t bytes, int nthreads);
+double		ndbo_mt_ivf_search_batch(const ndbo_ivf *ix, const float *queries, int nq, int strategy, int nprobe, int k,
+									 int64_t max_candidates, int nthreads, ndbo_tid *out_tids, float *out_dist,
+									 int *out_count, int64_t *n_scored);
+double		ndbo_mt_ivf_assign_batch(const float *rows, int64_t n, int dim, const float *cents, int k, int nthreads,
+									 int *out);
+
 /* k-means: src/index/ivf_am.c:2070-2294.  data = first n sample rows
  * (row-major [n*dim]); centroids out [k*dim]; assignments out [n]; counts out [k].
  * Returns the number of Lloyd iterations executed. */
@@ -203,6 +213,17 @@ uint32_t	ndbo_hnsw_insert(ndbo_hnsw *g, const float *vec, ndbo_tid heap_tid, int
  * Nothing else changes: links INTO the dead node from other nodes stay, and hnswSearch does not test the dead
  * flag, so the node can still be walked and returned.  Returns tuples_removed. */
 int64_t		ndbo_hnsw_bulkdelete(ndbo_hnsw *g, const ndbo_tid *tids, int64_t n);
+
+/* ndb_oracle_hnsw2.c — the `intended` HNSW (its header says what it keeps of the reference and what it
+ * repairs): squared L2 in fp64 summed by a fixed 64-way tree, best-first layer search, links pruned to the nearest
+ * `cap`, batch-synchronous build schedule.  parity unpinned (nothing in the reference pins it). */
+double		ndbo_h2_dist2(const float *a, const float *b, int dim);
+int			ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
+								 int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited);
+int			ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, const int *levels,
+						  int batch_div, int batch_max, int select);
+int			ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
+						   int64_t *evals);
 
 /* level = (int)(-log(r) * ml), clamped [0, 15]: src/index/hnsw_am.c:1143-1161 */
 int			ndbo_hnsw_level_from_uniform(double r, float ml);

@@ -1,0 +1,495 @@
+/*
+ * ndb_oracle_hnsw2.c — TEST INFRASTRUCTURE (see ndb_oracle.h).  The `intended` HNSW: what SURVEY 8f-2 asks for next
+ * to the bug-compatible hnswInsertNode / hnswSearch of ndb_oracle.c.  parity unpinned: the reference holds no test,
+ * fixture or caller for this algorithm — it is the textbook one its dead file sketches.
+ *
+ * What it keeps from the reference: the page-level data model (node = block, `levels`, dense 16-level neighbour
+ * arrays of 2m slots, entry point / entry level in the meta page: src/index/hnsw_am.c:108-181), the injected level
+ * draws (hnswGetRandomLevel, :1143-1161), L2 for every build-time comparison (hnswInsertNode always passes strategy
+ * 1, :2360-2520) and the best-first layer search of src/scan/hnsw_scan.c:379-483, 645-844 as the specification of
+ * the search: a candidate set ordered by distance, a result set of at most ef, expansion of the nearest unexpanded
+ * candidate until none is nearer than the worst result.
+ * What it repairs (each one is a reason recall@10 of the reference's graph is 0.0: DESIGN.md section 7):
+ *   - the greedy descent's result is USED as the next level's entry point (hnsw_am.c:2155-2286 computes and drops it);
+ *   - every level is searched on ITS OWN links (the reference reruns the level-0 walk for every level);
+ *   - a full neighbour list is PRUNED to its nearest `cap` entries when a back-link arrives (hnsw_am.c:2503-2513 is
+ *     the unreachable branch; the reference drops the link);
+ *   - hnsw_scan.c's quirks (the bound read from an unsorted slot, inserts into a full heap dropped, the entry point
+ *     entered at distance 0) are not reproduced.
+ *
+ * Arithmetic (one definition for host and device, so that a graph can be compared slot for slot): the squared L2
+ * distance in fp64, every term (double) fl32(a_i - b_i) squared, summed by a FIXED tree — 64 strided partial sums
+ * (element i goes to partial i mod 64, in increasing i) folded by the butterfly 32, 16, 8, 4, 2, 1 — which is what a
+ * 64-lane wave computes with one lane per partial; no fused multiply-add (-ffp-contract=off on both sides).
+ * Every comparison is on the pair (d2, block number): no ties anywhere.
+ *
+ * Build schedule (part of the definition, so that the device can run a batch's searches in parallel and still
+ * produce THIS graph): inserts are taken in batches of clamp(nodes so far / batch_div, 1, batch_max); every member of
+ * a batch searches the graph as it stood when the batch began (members do not see one another), then the members'
+ * links are applied one after the other in insertion order.  batch_max = 1 is the sequential textbook insert.
+ */
+#include "ndb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define H2_MAXLEV NDBO_HNSW_MAX_LEVEL
+
+double
+ndbo_h2_dist2(const float *a, const float *b, int dim)
+{
+	double		p[64];
+	int			i,
+				off;
+
+	for (i = 0; i < 64; i++)
+		p[i] = 0.0;
+	for (i = 0; i < dim; i++)
+	{
+		const float d = a[i] - b[i];
+		const double dd = (double) d;
+
+		p[i & 63] += dd * dd;
+	}
+	for (off = 32; off > 0; off >>= 1)
+		for (i = 0; i < off; i++)
+			p[i] = p[i] + p[i + off];	/* lane i and lane i ^ off compute the same sum: the butterfly's value */
+	return p[0];
+}
+
+static inline const float *
+h2_vec(const ndbo_hnsw *g, uint32_t b)
+{
+	return g->vecs + (size_t) b * g->dim;
+}
+
+static inline uint32_t *
+h2_nbrs(const ndbo_hnsw *g, uint32_t b, int level)
+{
+	return g->nbrs + ((size_t) b * H2_MAXLEV + level) * 2 * (size_t) g->m;
+}
+
+static inline int
+h2_cap(const ndbo_hnsw *g, int level)
+{
+	return level == 0 ? 2 * g->m : g->m;
+}
+
+/* (d2, id) < (e2, jd) */
+static inline int
+h2_less(double d2, uint32_t id, double e2, uint32_t jd)
+{
+	return d2 < e2 || (d2 == e2 && id < jd);
+}
+
+/*
+ * Best-first search of one layer.  Entry points ep[0..nep) with distances; results: the (at most ef) nearest found,
+ * ascending by (d2, id).  `visited`: nblocks bytes, all zero on entry and on return.
+ * The candidate set is the result set's unexpanded part: an element pushed out of the results is farther than
+ * everything left in them, so the textbook loop would stop before expanding it.
+ */
+int
+ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
+					 int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited)
+{
+	uint32_t   *wid = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) (ef + 1));
+	double	   *wd = (double *) malloc(sizeof(double) * (size_t) (ef + 1));
+	uint8_t    *wx = (uint8_t *) malloc((size_t) (ef + 1));
+	uint32_t   *log = NULL;
+	size_t		nlog = 0,
+				caplog = 0;
+	int			nw = 0,
+				i;
+
+#define H2_MARK(b) do { if (nlog == caplog) { caplog = caplog ? 2 * caplog : 1024; \
+		log = (uint32_t *) realloc(log, caplog * sizeof(uint32_t)); } log[nlog++] = (b); visited[b] = 1; } while (0)
+	for (i = 0; i < nep && nw < ef; i++)
+	{
+		if (visited[ep[i]])
+			continue;
+		H2_MARK(ep[i]);
+		wid[nw] = ep[i];
+		wd[nw] = epd[i];
+		wx[nw] = 0;
+		nw++;
+	}
+	for (;;)
+	{
+		int			best = -1,
+					j;
+		uint32_t	c;
+		const uint32_t *nb;
+		int			cnt;
+
+		for (i = 0; i < nw; i++)
+			if (!wx[i] && (best < 0 || h2_less(wd[i], wid[i], wd[best], wid[best])))
+				best = i;
+		if (best < 0)
+			break;
+		wx[best] = 1;
+		c = wid[best];
+		nb = h2_nbrs(g, c, level);
+		cnt = g->ncount[(size_t) c * H2_MAXLEV + level];
+		for (j = 0; j < cnt; j++)
+		{
+			const uint32_t e = nb[j];
+			double		d;
+			int			worst = 0;
+
+			if (e == NDBO_INVALID_BLOCK || e >= g->nblocks || visited[e])
+				continue;
+			H2_MARK(e);
+			d = ndbo_h2_dist2(q, h2_vec(g, e), g->dim);
+			if (evals)
+				(*evals)++;
+			if (nw < ef)
+			{
+				wid[nw] = e;
+				wd[nw] = d;
+				wx[nw] = 0;
+				nw++;
+				continue;
+			}
+			for (i = 1; i < nw; i++)
+				if (h2_less(wd[worst], wid[worst], wd[i], wid[i]))
+					worst = i;
+			if (h2_less(d, e, wd[worst], wid[worst]))
+			{
+				wid[worst] = e;
+				wd[worst] = d;
+				wx[worst] = 0;
+			}
+		}
+	}
+	/* ascending (d2, id): insertion sort (ef <= a few hundred) */
+	for (i = 0; i < nw; i++)
+	{
+		int			j = i;
+		const uint32_t id = wid[i];
+		const double d = wd[i];
+
+		while (j > 0 && h2_less(d, id, out_d2[j - 1], out_ids[j - 1]))
+		{
+			out_d2[j] = out_d2[j - 1];
+			out_ids[j] = out_ids[j - 1];
+			j--;
+		}
+		out_d2[j] = d;
+		out_ids[j] = id;
+	}
+	for (i = 0; i < (int) nlog; i++)
+		visited[log[i]] = 0;
+	free(log);
+	free(wid);
+	free(wd);
+	free(wx);
+	return nw;
+#undef H2_MARK
+}
+
+/* greedy step of the upper layers: from `cur`, move to the nearest neighbour at `level` while one is nearer */
+static void
+h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
+{
+	for (;;)
+	{
+		const uint32_t *nb = h2_nbrs(g, *cur, level);
+		const int	cnt = g->ncount[(size_t) (*cur) * H2_MAXLEV + level];
+		uint32_t	bid = *cur;
+		double		bd = *curd;
+		int			j;
+
+		for (j = 0; j < cnt; j++)
+		{
+			const uint32_t e = nb[j];
+			double		d;
+
+			if (e == NDBO_INVALID_BLOCK || e >= g->nblocks)
+				continue;
+			d = ndbo_h2_dist2(q, h2_vec(g, e), g->dim);
+			if (evals)
+				(*evals)++;
+			if (h2_less(d, e, bd, bid))
+			{
+				bd = d;
+				bid = e;
+			}
+		}
+		if (bid == *cur)
+			return;
+		*cur = bid;
+		*curd = bd;
+	}
+}
+
+/* kNN query: greedy descent to level 1, best-first search with ef at level 0, the k nearest ascending.  Distances
+ * come back as (float) sqrt(d2).  Returns the count. */
+int
+ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
+			   int64_t *evals)
+{
+	uint8_t    *visited;
+	uint32_t   *ids;
+	double	   *d2;
+	uint32_t	cur;
+	double		curd;
+	int			lc,
+				n,
+				i;
+
+	if (g->entry_point == NDBO_INVALID_BLOCK || k < 1)
+		return 0;
+	if (ef < k)
+		ef = k;
+	cur = g->entry_point;
+	curd = ndbo_h2_dist2(query, h2_vec(g, cur), g->dim);
+	if (evals)
+		(*evals)++;
+	for (lc = g->entry_level; lc >= 1; lc--)
+		h2_greedy(g, query, lc, &cur, &curd, evals);
+	visited = (uint8_t *) calloc(g->nblocks, 1);
+	ids = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) ef);
+	d2 = (double *) malloc(sizeof(double) * (size_t) ef);
+	n = ndbo_h2_search_layer(g, query, &cur, &curd, 1, ef, 0, ids, d2, evals, visited);
+	if (n > k)
+		n = k;
+	for (i = 0; i < n; i++)
+	{
+		out_blocks[i] = ids[i];
+		out_dist[i] = (float) sqrt(d2[i]);
+	}
+	free(visited);
+	free(ids);
+	free(d2);
+	return n;
+}
+
+/* what the search phase of one insert leaves: per level lc <= min(level, entry level at that time) the selected
+ * neighbours, ascending by (d2, id) */
+typedef struct h2_sel
+{
+	int			top;			/* highest level with a selection (-1: the graph was empty) */
+	int			n[H2_MAXLEV];
+	uint32_t   *ids;			/* [H2_MAXLEV][m] */
+	double	   *d2;
+}			h2_sel;
+
+/* the m the new node links to out of the layer search's results (ascending): select 0 = the nearest m; 1 = the
+ * textbook heuristic — a candidate is taken unless it is nearer to one already taken than to the new node */
+static int
+h2_select(const ndbo_hnsw *g, const float *base, const uint32_t *cid, const double *cd2, int nc, int M, int select,
+		  uint32_t *out, double *outd)
+{
+	int			n = 0,
+				i,
+				j;
+
+	for (i = 0; i < nc && n < M; i++)
+	{
+		int			ok = 1;
+
+		if (select)
+			for (j = 0; j < n; j++)
+				if (ndbo_h2_dist2(h2_vec(g, cid[i]), h2_vec(g, out[j]), g->dim) < cd2[i])
+				{
+					ok = 0;
+					break;
+				}
+		if (ok)
+		{
+			out[n] = cid[i];
+			outd[n] = cd2[i];
+			n++;
+		}
+	}
+	(void) base;
+	return n;
+}
+
+static void
+h2_insert_search(const ndbo_hnsw *g, const float *vec, int level, int select, h2_sel *s, uint8_t *visited)
+{
+	const int	efc = g->ef_construction, m = g->m;
+	uint32_t	cur;
+	double		curd;
+	uint32_t   *wid;
+	double	   *wd;
+	int			lc;
+
+	memset(s->n, 0, sizeof(s->n));
+	s->top = -1;
+	if (g->entry_point == NDBO_INVALID_BLOCK)
+		return;
+	cur = g->entry_point;
+	curd = ndbo_h2_dist2(vec, h2_vec(g, cur), g->dim);
+	for (lc = g->entry_level; lc > level; lc--)
+		h2_greedy(g, vec, lc, &cur, &curd, NULL);
+	wid = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) efc);
+	wd = (double *) malloc(sizeof(double) * (size_t) efc);
+	s->top = level < g->entry_level ? level : g->entry_level;
+	for (lc = s->top; lc >= 0; lc--)
+	{
+		const int	nw = ndbo_h2_search_layer(g, vec, &cur, &curd, 1, efc, lc, wid, wd, NULL, visited);
+
+		s->n[lc] = h2_select(g, vec, wid, wd, nw, m, select, s->ids + (size_t) lc * m, s->d2 + (size_t) lc * m);
+		cur = wid[0];			/* the nearest found is the next level's entry point */
+		curd = wd[0];
+	}
+	free(wid);
+	free(wd);
+}
+
+/* a back-link x -> into e's list at `level`: appended while there is room, else the list becomes the `cap` entries
+ * of (list + x) chosen by the same rule as above around e, ascending by (d2 to e, id) */
+static void
+h2_backlink(ndbo_hnsw *g, uint32_t e, int level, uint32_t x, double dxe, int select)
+{
+	const int	cap = h2_cap(g, level);
+	uint32_t   *nb = h2_nbrs(g, e, level);
+	int16_t    *pc = &g->ncount[(size_t) e * H2_MAXLEV + level];
+	uint32_t	cid[2 * 64 + 1],
+				kid[2 * 64 + 1];
+	double		cd[2 * 64 + 1],
+				kd[2 * 64 + 1];
+	int			cnt = *pc,
+				i,
+				n;
+
+	if (cnt < cap)
+	{
+		nb[cnt] = x;
+		*pc = (int16_t) (cnt + 1);
+		return;
+	}
+	/* candidates ascending by (d2 to e, id) */
+	n = 0;
+	for (i = 0; i <= cnt; i++)
+	{
+		const uint32_t id = i < cnt ? nb[i] : x;
+		const double d = i < cnt ? ndbo_h2_dist2(h2_vec(g, e), h2_vec(g, id), g->dim) : dxe;
+		int			j = n;
+
+		while (j > 0 && h2_less(d, id, cd[j - 1], cid[j - 1]))
+		{
+			cd[j] = cd[j - 1];
+			cid[j] = cid[j - 1];
+			j--;
+		}
+		cd[j] = d;
+		cid[j] = id;
+		n++;
+	}
+	n = h2_select(g, h2_vec(g, e), cid, cd, n, cap, select, kid, kd);
+	for (i = 0; i < 2 * g->m; i++)
+		nb[i] = i < n ? kid[i] : NDBO_INVALID_BLOCK;
+	*pc = (int16_t) n;
+}
+
+static void
+h2_insert_apply(ndbo_hnsw *g, uint32_t x, int level, const h2_sel *s, int select)
+{
+	const int	m = g->m;
+	int			lc,
+				i;
+
+	for (lc = s->top; lc >= 0; lc--)
+	{
+		uint32_t   *nb = h2_nbrs(g, x, lc);
+
+		for (i = 0; i < s->n[lc]; i++)
+			nb[i] = s->ids[(size_t) lc * m + i];
+		g->ncount[(size_t) x * H2_MAXLEV + lc] = (int16_t) s->n[lc];
+		for (i = 0; i < s->n[lc]; i++)
+			h2_backlink(g, s->ids[(size_t) lc * m + i], lc, x, s->d2[(size_t) lc * m + i], select);
+	}
+	if (g->entry_point == NDBO_INVALID_BLOCK || level > g->entry_level)
+	{
+		g->entry_point = x;
+		g->entry_level = level;
+		if (level > g->max_level)
+			g->max_level = level;
+	}
+}
+
+/*
+ * Build over n rows (row i becomes block i + 1), levels injected, the batch schedule of the header.  select: 0 = the
+ * nearest m, 1 = the heuristic.  Returns the number of batches.
+ */
+int
+ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, const int *levels, int batch_div,
+			  int batch_max, int select)
+{
+	const int	m = g->m;
+	int64_t		done = 0;
+	int			nbatches = 0;
+	uint8_t    *visited = (uint8_t *) calloc((size_t) n + 2, 1);
+	h2_sel	   *sel = NULL;
+	int64_t		capsel = 0;
+
+	if (batch_div < 1)
+		batch_div = 1;
+	if (batch_max < 1)
+		batch_max = 1;
+	while (done < n)
+	{
+		int64_t		b = (int64_t) g->inserted / batch_div,
+					i;
+
+		if (b < 1)
+			b = 1;
+		if (b > batch_max)
+			b = batch_max;
+		if (b > n - done)
+			b = n - done;
+		if (b > capsel)
+		{
+			sel = (h2_sel *) realloc(sel, sizeof(h2_sel) * (size_t) b);
+			for (i = capsel; i < b; i++)
+			{
+				sel[i].ids = (uint32_t *) malloc(sizeof(uint32_t) * H2_MAXLEV * (size_t) m);
+				sel[i].d2 = (double *) malloc(sizeof(double) * H2_MAXLEV * (size_t) m);
+			}
+			capsel = b;
+		}
+		/* the members' vectors are in place before anyone searches (a member is not reachable until it is linked) */
+		for (i = 0; i < b; i++)
+		{
+			const uint32_t x = (uint32_t) (done + i + 1);
+			int			lev = levels[done + i];
+
+			if (lev < 0)
+				lev = 0;
+			if (lev > H2_MAXLEV - 1)
+				lev = H2_MAXLEV - 1;
+			memcpy(g->vecs + (size_t) x * g->dim, vecs + (size_t) (done + i) * g->dim, sizeof(float) * (size_t) g->dim);
+			if (tids)
+				g->heap_tids[x] = tids[done + i];
+			g->levels[x] = lev;
+		}
+		for (i = 0; i < b; i++)
+			h2_insert_search(g, vecs + (size_t) (done + i) * g->dim, g->levels[done + i + 1], select, &sel[i], visited);
+		for (i = 0; i < b; i++)
+		{
+			const uint32_t x = (uint32_t) (done + i + 1);
+
+			g->nblocks = x + 1;		/* (visible to validity checks only once it can be named) */
+			h2_insert_apply(g, x, g->levels[x], &sel[i], select);
+			g->inserted++;
+		}
+		done += b;
+		nbatches++;
+	}
+	{
+		int64_t		i;
+
+		for (i = 0; i < capsel; i++)
+		{
+			free(sel[i].ids);
+			free(sel[i].d2);
+		}
+	}
+	free(sel);
+	free(visited);
+	return nbatches;
+}

@@ -108,6 +108,13 @@ def lib(native: bool = False):
         "ndbo_hnsw_insert": (C.c_uint32, [C.POINTER(NdboHnsw), f32p, NdboTid, i]),
         "ndbo_hnsw_level_from_uniform": (i, [C.c_double, f]),
         "ndbo_selection_topk": (i, [f32p, C.c_int64, i, i64p]),
+        "ndbo_h2_dist2": (C.c_double, [f32p, f32p, i]),
+        "ndbo_h2_build": (i, [C.POINTER(NdboHnsw), f32p, C.c_void_p, C.c_int64, i32p, i, i, i]),
+        "ndbo_h2_search": (i, [C.POINTER(NdboHnsw), f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
+        "ndbo_mt_spread_copy": (C.c_void_p, [C.c_void_p, C.c_size_t, i]),
+        "ndbo_mt_ivf_search_batch": (C.c_double, [C.POINTER(NdboIvf), f32p, i, i, i, i, C.c_int64, i, C.c_void_p, f32p,
+                                                  i32p, C.POINTER(C.c_int64)]),
+        "ndbo_mt_ivf_assign_batch": (C.c_double, [C.c_void_p, C.c_int64, i, f32p, i, i, i32p]),
         "ndbo_extract_vector": (i, [i, u8p, f32p, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
@@ -144,6 +151,40 @@ class IvfImage:
         s.tids = self.tids.ctypes.data if self.tids.size else None
         s.live = None if self.live is None else self.live.ctypes.data
         self.c = s
+
+    def search_batch_mt(self, queries, strategy=1, nprobe=10, k=10, max_candidates=0, nthreads=1, native=False,
+                        spread=True):
+        """ndbo_mt_ivf_search_batch: the queries through ndbo_ivf_search on `nthreads` pthreads (one backend per core).
+        spread: the rows are first copied into memory whose pages the worker threads touch first (2 MiB stripes
+        round-robin), so a many-socket host reads them from all its memory controllers.
+        Returns (tids [nq, k] structured, dist [nq, k], count [nq], wall seconds of the parallel section)."""
+        import ctypes.util
+        L = lib(native)
+        q = _f32(queries)
+        nq = len(q)
+        c = self.c
+        if spread and self.vecs.size and getattr(self, "_spread_threads", 0) != nthreads:
+            self.free_spread()
+            self._spread_ptr = L.ndbo_mt_spread_copy(self.vecs.ctypes.data, self.vecs.nbytes, nthreads)
+            self._spread_threads = nthreads if self._spread_ptr else 0
+        if spread and getattr(self, "_spread_ptr", None):
+            c = NdboIvf()
+            for f, _ in NdboIvf._fields_:
+                setattr(c, f, getattr(self.c, f))
+            c.vecs = self._spread_ptr
+        out_t = np.zeros((nq, max(k, 1)), dtype=TID_DTYPE)
+        out_d = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        out_c = np.zeros(nq, dtype=np.int32)
+        ns = C.c_int64(0)
+        wall = L.ndbo_mt_ivf_search_batch(C.byref(c), q, nq, strategy, nprobe, k, int(max_candidates), int(nthreads),
+                                          out_t.ctypes.data, out_d, out_c, C.byref(ns))
+        return out_t, out_d, out_c, float(wall)
+
+    def free_spread(self):
+        if getattr(self, "_spread_ptr", None):
+            C.CDLL(None).free(C.c_void_p(self._spread_ptr))
+            self._spread_ptr = None
+            self._spread_threads = 0
 
     def select_clusters(self, query, nprobe, native=False):
         sel = np.zeros(max(nprobe, 1), dtype=np.int32)
@@ -266,6 +307,21 @@ class HnswGraph:
         """hnswbulkdelete with callback = membership in `tids` (structured TID array); returns tuples_removed."""
         t = np.ascontiguousarray(tids)
         return int(self.L.ndbo_hnsw_bulkdelete(self.g, t.ctypes.data, len(t)))
+
+    def build_intended(self, vecs, levels, tids=None, batch_div=64, batch_max=1024, select=0):
+        """ndbo_h2_build (oracle/ndb_oracle_hnsw2.c): the `intended` graph over all rows at once, batch schedule
+        clamp(nodes so far / batch_div, 1, batch_max); returns the number of batches"""
+        v = _f32(vecs)
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        t = None if tids is None else np.ascontiguousarray(tids).ctypes.data
+        return int(self.L.ndbo_h2_build(self.g, v, t, len(v), lv, int(batch_div), int(batch_max), int(select)))
+
+    def search_intended(self, query, ef=64, k=10):
+        ob = np.zeros(max(k, 1), dtype=np.uint32)
+        od = np.zeros(max(k, 1), dtype=np.float32)
+        ns = C.c_int64(0)
+        n = self.L.ndbo_h2_search(self.g, _f32(query), ef, k, ob, od, C.byref(ns))
+        return ob[:n], od[:n], ns.value
 
     def search(self, query, strategy=1, ef=64, k=10):
         ob = np.zeros(max(k, 1), dtype=np.uint32)

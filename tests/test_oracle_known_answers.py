@@ -123,3 +123,26 @@ def test_ivf_distance_matches_numpy_sequential_fp32():
             d = float(np.float32(a[i] - b[i]))
             s64 += d * d
         assert np.float32(L.ndbo_hnsw_distance(a, b, dim, 1, None)) == np.float32(math.sqrt(s64))
+
+
+def test_pthread_driver_returns_what_single_calls_return():
+    """oracle/ndb_oracle_mt.c adds no arithmetic: the batch on 4 threads (rows in the spread copy) = the loop."""
+    import numpy as np
+    from oracle import ndbo
+    from tests.util import make_ivf_arrays, oracle_image
+    a = make_ivf_arrays(3000, 48, 12, seed=5, dup_frac=0.1, integer=True)
+    img = oracle_image(a)
+    q = np.random.default_rng(6).integers(-3, 4, size=(37, 48)).astype(np.float32)
+    t, d, c, wall = img.search_batch_mt(q, 1, 5, 10, 0, nthreads=4)
+    assert wall > 0
+    for i in range(len(q)):
+        et, ed, _ = img.search(q[i], 1, 5, 10, 0)
+        assert c[i] == len(et) and np.array_equal(ndbo.tids_to_u64(t[i, :c[i]]), ndbo.tids_to_u64(et))
+        assert np.array_equal(d[i, :c[i]].view(np.uint32), ed.view(np.uint32))
+    img.free_spread()
+    cent = a["centroids"]
+    out = np.zeros(len(a["rows"]), dtype=np.int32)
+    ndbo.lib().ndbo_mt_ivf_assign_batch(a["rows"].ctypes.data, len(out), 48, cent, len(cent), 3, out)
+    L = ndbo.lib()
+    for r in range(0, len(out), 97):
+        assert out[r] == L.ndbo_ivf_assign(cent, None, len(cent), len(cent), 48, a["rows"][r], None)
