@@ -849,10 +849,7 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 3), "build_schedule": ix.build_stats(),
             "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
             "evaluations_per_query": round(evals, 1), "bytes_per_query": int(bytes_q),
-            "roofline": dict({"bound": "hbm", "achieved": round(nq / ts * bytes_q / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                              "unit": "GB/s", "frac": round(nq / ts * bytes_q / 1e9 / HBM_PEAK_GBPS, 4),
-                              "note": "dependent graph walk: latency-bound, as SURVEY 8d expects"},
-                             **hnsw_pmc_traffic(n, dim, m, ef, nq, ts)),
+            "roofline": hnsw_roofline(n, dim, m, ef, nq, ts, bytes_q),
             "recall_at_10": round(recall, 4),
             "recall_note": "the reference's level-0 walk is BFS-until-ef (quirk Q10); the oracle returns the same ids",
             "oracle_parity": {"queries": sample, "mismatches": int(bad),
@@ -861,7 +858,135 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             "cpu_baseline": {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                              "sample": f"{ncpu} of the same queries through oracle/ndb_oracle.c ndbo_hnsw_search on the "
                                        "exported graph, one thread per core"},
-            "search_layer": layer}
+            "search_layer": layer,
+            "intended": hnsw_intended_leg(args, dev)}
+
+
+def hnsw_roofline(n, dim, m, ef, nq, ts, bytes_q):
+    """The reference-compatible walk is a chain of dependent fetches around the entry point: what reaches HBM is the
+    PMC traffic of a committed pass (frac = that over this run's batch time over 8 TB/s, about 0.01), the rest is
+    served from L2; the algorithmic bytes SURVEY 8d defines (evaluations x node bytes) are kept beside it."""
+    t = hnsw_pmc_traffic(n, dim, m, ef, nq, ts)
+    tr = t.get("traffic")
+    return {"bound": "latency", "achieved": None if not tr else round(tr / ts / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": t.get("traffic_frac"), "traffic": tr, "traffic_source": t.get("traffic_source"),
+            "algorithmic": {"bytes_per_query": int(bytes_q), "gb_per_s": round(nq / ts * bytes_q / 1e9, 1),
+                            "note": "evaluations x (node header + vector + level-0 slots), SURVEY 8d; every query walks the "
+                                    "same ~100 nodes around the entry point, so these bytes come from L2, not HBM"},
+            "note": "dependent graph walk, latency-bound; frac = HBM-side PMC bytes per launch / batch time / 8 TB/s"}
+
+
+def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
+    """BASELINE config C3 in the `intended` mode (include/ndbhip.h ndbhip_hnsw_build_intended_device,
+    oracle/ndb_oracle_hnsw2.c): build and search in HBM, recall@10 against a float64 brute force, a sample replayed by
+    the oracle on the exported graph (blocks, float4 distance bits, evaluation counts).  Table: the headline's clustered
+    generator, rows normalised (cosine order = L2 order); the i.i.d. N(0,1) table is measured beside it at 100 000
+    rows — in 768 dimensions its nearest neighbours are barely nearer than the rest and no graph walk of ef = 64
+    finds them, which is a property of the data, not of the graph."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from neurondb_amd import HnswIndex
+    from neurondb_amd._lib import check, lib
+    from oracle import ndbo
+    n, dim, k = args.hnsw_nvec, args.dim, args.k
+
+    def table(kind, rows, seed):
+        x = make_data(rows, dim, kind, args.components, args.sigma, seed, 0x5EEDC0DE, dev)
+        return x / x.norm(dim=1, keepdim=True)
+
+    def recall_of(ix, base, q, efs, nr=200):
+        sims = q[:nr].double() @ base.double().T
+        gt = torch.topk(sims, k, dim=1).indices.cpu().numpy() + 1
+        out = {}
+        for e in efs:
+            ob, od, oc, oe = ix.search_intended(q[:max(nr, 256)], e, k)
+            out[e] = round(float(np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / k for i in range(nr)])), 4)
+        return out
+
+    try:
+        base = table("clustered", n, 0x5EED0003)
+        q = table("clustered", nq, 0x5EED0004)
+        r = np.random.default_rng(11).uniform(1e-12, 1.0, n)
+        levels = np.clip((-np.log(r) * np.float32(0.36)).astype(np.int32), 0, 15)      # hnsw_am.c:1143-1161
+        ix = HnswIndex(dim, m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix.build_intended(base, torch.arange(n, device=dev, dtype=torch.int64), levels, efc)
+        tb = time.perf_counter() - t0
+        sched = ix.build_stats()
+        ix.search_intended(q[:512], ef, k)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ob, od, oc, oe = ix.search_intended(q, ef, k)
+        ts = (time.perf_counter() - t0) / reps
+        evals = float(oe.mean())
+        rec = recall_of(ix, base, q, [ef])[ef]
+        # oracle replay on the exported graph
+        e = ix.export()
+        vecs = np.zeros((n + 1, dim), np.float32)
+        vecs[1:] = base.cpu().numpy()
+        og = ndbo.HnswGraph.from_arrays(vecs, e["levels"], e["ncount"], e["nbrs"], None, e["entry_point"], e["entry_level"], m, efc)
+        del vecs
+        sample, bad = 32, 0
+        qh = q[:max(sample, 1)].cpu().numpy()
+        t0 = time.perf_counter()
+        for i in range(sample):
+            eb, ed, ns = og.search_intended(qh[i], ef, k)
+            bad += not (oc[i] == len(eb) and np.array_equal(ob[i, :len(eb)], eb) and
+                        np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns)
+        tc = (time.perf_counter() - t0) / sample
+        cores = os.cpu_count() or 1
+        ncpu = int(min(nq, max(cores * 4, min(args.cpu_seconds, 10.0) * cores / max(tc, 1e-6)))) if args.cpu_seconds > 0 else 0
+        cpu = None
+        if ncpu > 0:
+            qall = q[:ncpu].cpu().numpy()
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                list(ex.map(lambda lo: [og.search_intended(qall[i], ef, k) for i in range(lo, min(ncpu, lo + 8))], range(0, ncpu, 8)))
+            cpu = {"value": round(ncpu / (time.perf_counter() - t0), 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                   "sample": f"{ncpu} of the same queries through oracle/ndb_oracle_hnsw2.c ndbo_h2_search on the exported "
+                             "graph, one thread per core"}
+        del og, e
+        ix.close()
+        bytes_q = evals * (4 * dim) + (evals / (2 * m)) * (4 * 2 * m + 2)
+        out = {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k}, cosine order on unit-norm "
+                           f"rows, {nq}-query batches (BASELINE config C3), intended mode; table: mixture of {args.components} "
+                           f"Gaussians sigma={args.sigma}, normalised",
+               "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 2),
+               "build_schedule": {"batches": int(sched.get("batches", 0)), "largest_batch": int(sched.get("max_batch", 0))},
+               "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
+               "evaluations_per_query": round(evals, 1), "recall_at_10": rec,
+               "roofline": {"bound": "hbm", "achieved": round(nq / ts * bytes_q / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(nq / ts * bytes_q / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                            "bytes_per_query": int(bytes_q),
+                            "note": "bytes = distance evaluations (counted per query by the kernel) x row bytes + the "
+                                    "neighbour lists read; a best-first walk re-reads little, so these are close to what "
+                                    "reaches HBM; no PMC pass of this kernel is committed yet"},
+               "oracle_parity": {"queries": sample, "mismatches": int(bad),
+                                 "checked": "blocks, float4 distance bits, evaluation counts (graph equality: "
+                                            "tests/test_gpu_hnsw2.py)"},
+               "cpu_oracle_ms_per_query_single_thread": round(tc * 1e3, 3), "cpu_baseline": cpu}
+        del base
+        torch.cuda.empty_cache()
+        # the i.i.d. table, small: what the data does to any graph walk
+        n2 = min(100_000, n)
+        b2 = table("gauss", n2, 0x5EED0003)
+        q2 = table("gauss", 512, 0x5EED0004)
+        ix2 = HnswIndex(dim, m)
+        r2 = np.random.default_rng(12).uniform(1e-12, 1.0, n2)
+        t0 = time.perf_counter()
+        ix2.build_intended(b2, torch.arange(n2, device=dev, dtype=torch.int64),
+                           np.clip((-np.log(r2) * np.float32(0.36)).astype(np.int32), 0, 15), efc)
+        tb2 = time.perf_counter() - t0
+        out["iid_gauss_unit"] = {"rows": n2, "build_vectors_per_s": round(n2 / tb2, 1),
+                                 "recall_at_10_by_ef": recall_of(ix2, b2, q2, [ef, 4 * ef, 16 * ef]),
+                                 "note": "i.i.d. N(0,1) rows, normalised (BASELINE.md section 2): distances concentrate in 768 "
+                                         "dimensions (the 10th neighbour is a few per cent nearer than the median row)"}
+        ix2.close()
+        return out
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def hnsw_pmc_traffic(n, dim, m, ef, nq, seconds):

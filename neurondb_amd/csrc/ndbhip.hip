@@ -1499,6 +1499,14 @@ struct ndbhip_ivf
 	_Float16   *w_qcplanes = nullptr; size_t w_qcplanes_n = 0;
 	float	   *w_qcn2 = nullptr;	size_t w_qcn2_n = 0;
 	int		   *w_qcexp = nullptr;	size_t w_qcexp_n = 0;
+	/* ... its planes take appends in place: rows / capacity of every bucket (list or sublist), the bucket of every list
+	 * that takes its appends, first padded plane row (32 x first block) of every bucket, a row's index in its list */
+	std::vector<uint32_t> s16_blen, s16_bcap;
+	std::vector<int> s16_tail;
+	std::vector<int64_t> s16_prow;
+	int64_t    *d_prow_off = nullptr;	size_t d_prow_off_n = 0;
+	uint32_t   *d_pposof = nullptr;	size_t d_pposof_n = 0;
+	bool		s16_cen_layout = false;
 	uint32_t   *w_pslot = nullptr;	size_t w_pslot_n = 0;	/* [3][qc_cap] per pair slot: query, first candidate position, visible rows */
 	float	   *w_amat = nullptr;	size_t w_amat_n = 0;	/* [nq][astride] the sweep's |q - centroid|^2 (k_cent_select) */
 	uint8_t    *w_cfull = nullptr;	size_t w_cfull_n = 0;	/* [nq] queries k_cent_select left to k_probe_select */
@@ -1532,6 +1540,9 @@ struct ndbhip_ivf
 	int64_t    *w_stotal = nullptr;	size_t w_stotal_n = 0;
 };
 
+
+struct ndbhip_ivf;
+static int	ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vector<int64_t> &new_own);
 
 /* temporaries of one call: freed on every way out of the scope unless keep() hands one over (the
  * HIP_TRY early returns of ivf_flush / ndbhip_ivf_delete leaked their device buffers) */
@@ -1620,7 +1631,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2086,7 +2097,11 @@ ivf_flush(ndbhip_ivf *ix)
 		ix->own_rows = true;
 	}
 	ix->nrows = nown;
-	ix->norm_valid = false; ix->s16_valid = false;
+	ix->norm_valid = false;
+	/* the centred planes take the new rows in the spare blocks of their lists (ndbhip_screen16c.h); anything else —
+	 * other layouts, a list that has outgrown its spare blocks — is laid out again by the next screened batch */
+	if (ix->s16_valid && ivf_s16c_append(ix, add, new_own) != 0)
+		ix->s16_valid = false;
 	ix->pend_list.clear();
 	ix->pend_rows.clear();
 	ix->pend_tids.clear();
@@ -2395,6 +2410,7 @@ static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - 
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
 static int	g_s16_cen = 1;		/* L2 on float4 rows: the centred one-plane sweep (ndbhip_screen16c.h; "screen16_centered", 0: the two-plane sweep) */
 static int	g_s16c_qb = 0;		/* pairs per tile of the centred sweep / 32: 4 or 1; 0 = from the previous batch's pairs per bucket ("screen16c_qb") */
+static int	g_s16_slack = 1;	/* the centred planes keep spare blocks and take appends in place ("screen16_slack", 0: every append lays the planes out again) */
 static int	g_s16c_seeds = 0;	/* rows whose upper bounds give a query its first threshold, 0 = 32 (k <= 20) or 64 ("screen16c_seeds") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
@@ -2414,7 +2430,7 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 	return true;
 }
 
-static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host);	/* ndbhip_build.h */
+static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host, bool slack);	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
 static int	s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim);	/* ndbhip_build.h */
 static int	s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr,
@@ -2462,19 +2478,28 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		if (sub_cfg != 0 && !ix->f16)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
-			const int	rc = ivf_s16_build_sublists(ix, bo);
+			const int	rc = ivf_s16_build_sublists(ix, bo, cen && g_s16_slack != 0);
 
 			if (rc)
 				return rc;
 		}
 		if (!ix->s16_sub)
 		{
-			/* every list starts a new 32-row block of the blocked planes */
+			/* every list starts a new 32-row block of the blocked planes (the centred planes: with spare blocks
+			 * behind it, for the rows inserted later) */
 			bo.assign((size_t) nc + 1, 0);
+			ix->s16_tail.assign((size_t) nc, -1);
+			ix->s16_blen.assign((size_t) nc, 0);
 			for (int c = 0; c < nc; c++)
 			{
 				bo[c] = (uint32_t) nb;
 				nb += (uint64_t) ((ix->own_len[c] + 31) / 32);
+				ix->s16_blen[(size_t) c] = (uint32_t) ix->own_len[c];
+				if (cen && g_s16_slack)
+				{
+					nb += std::max<uint64_t>(2, (uint64_t) ix->own_len[c] / 256);
+					ix->s16_tail[(size_t) c] = c;
+				}
 			}
 			bo[nc] = (uint32_t) nb;
 			if (nb + 8 > 0xFFFFFFFFull)
@@ -2484,10 +2509,30 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			HIP_TRY(hipStreamSynchronize(g.stream));		/* bo is a local */
 		}
 		nb = bo.back();
+		const size_t nbk = bo.size() - 1;			/* buckets */
+
+		ix->s16_cen_layout = cen;
+		ix->s16_bcap.assign(nbk, 0);
+		for (size_t b2 = 0; b2 < nbk; b2++)
+			ix->s16_bcap[b2] = (bo[b2 + 1] - bo[b2]) * 32u;
+		if (cen)
+		{
+			/* the centred path indexes norms / exponents / list positions by PADDED plane row (32 x block + row) */
+			std::vector<int64_t> po(nbk + 1);
+
+			for (size_t b2 = 0; b2 <= nbk; b2++)
+				po[b2] = (int64_t) bo[b2] * 32;
+			ix->s16_prow = po;
+			if (grow(ix->d_prow_off, ix->d_prow_off_n, nbk + 1)) return NDBHIP_ERR_HIP;
+			if (grow(ix->d_pposof, ix->d_pposof_n, (size_t) (nb + 8) * 32)) return NDBHIP_ERR_HIP;
+			HIP_TRY(hipMemcpyAsync(ix->d_prow_off, po.data(), (nbk + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipMemsetAsync(ix->d_pposof, 0xFF, (size_t) (nb + 8) * 32 * sizeof(uint32_t), g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));		/* po is a local */
+		}
 		const size_t blk_bytes = cen ? (size_t) (dimp / S16C_CH) * 4096 : (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
 
-		if (grow(ix->d_rn2, ix->d_rn2_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
-		if (grow(ix->d_rexp, ix->d_rexp_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_rn2, ix->d_rn2_n, cen ? (size_t) (nb + 8) * 32 : (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
+		if (grow(ix->d_rexp, ix->d_rexp_n, cen ? (size_t) (nb + 8) * 32 : (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
 		if (grow(ix->d_planes, ix->d_planes_n, (size_t) (nb + 8) * blk_bytes)) return NDBHIP_ERR_HIP;
 		HIP_TRY(hipMemsetAsync(ix->d_planes, 0, (size_t) (nb + 8) * blk_bytes, g.stream));
 		if (!ix->d_xmax16)
@@ -2508,7 +2553,9 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 							   ix->s16_sub ? ix->nsub : nc, (const float *) ix->d_centroids,
 							   ix->s16_sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
 							   ix->d_planes, ix->d_rn2, ix->d_rexp,
-							   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr);
+							   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr,
+							   (const int64_t *) ix->d_prow_off, ix->s16_sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr,
+							   ix->d_pposof);
 		else if (!ix->f16)
 			S16_PREP_L(0);
 		else if (ix->f16_sub)
@@ -2532,6 +2579,76 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		HIP_TRY(hipGetLastError());
 		ix->s16_valid = true;
 	}
+	return 0;
+}
+
+/*
+ * Rows appended since the planes were laid out (ivf_flush has just put them behind their lists in the mirror): the
+ * centred layout keeps spare 32-row blocks behind the bucket of every list that takes appends — the list itself, or
+ * the extra sublist around the centroid of a regrouped list — so the new rows' planes, norms, exponents and list
+ * positions are written there (k_s16c_row_append), the bucket's and the list's radius grow by a max, and nothing
+ * else moves.  Returns 0 when done, 1 when the layout cannot take them (the caller invalidates it: the next
+ * screened batch lays everything out again, with fresh spare blocks), negative on error.
+ */
+static int
+ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vector<int64_t> &new_own)
+{
+	const int	nc = ix->ncent, dim = ix->dim, dimp = (dim + 63) & ~63;
+
+	if (!ix->s16_cen_layout || !g_s16_slack || ix->f16 || (int) ix->s16_tail.size() != nc)
+		return 1;
+	std::vector<S16CApp> recs;
+	std::vector<uint32_t> bidx, bval;
+
+	for (int c = 0; c < nc; c++)
+	{
+		if (add[c] <= 0 || !ix->owned[c])
+			continue;
+		const int	b = ix->s16_tail[(size_t) c];
+
+		if (b < 0 || (int64_t) ix->s16_blen[(size_t) b] + add[c] > (int64_t) ix->s16_bcap[(size_t) b])
+			return 1;
+		const int64_t old_own = new_own[c] - add[c];
+
+		for (int64_t i = 0; i < add[c]; i++)
+		{
+			S16CApp		a;
+
+			a.pos = (uint32_t) (old_own + i);
+			a.row = ix->loc_off[c] + old_own + i;
+			a.pp = ix->s16_prow[(size_t) b] + (int64_t) ix->s16_blen[(size_t) b] + i;
+			a.bucket = (uint32_t) b;
+			a.list = (uint32_t) c;
+			a.pad = 0;
+			recs.push_back(a);
+		}
+		ix->s16_blen[(size_t) b] += (uint32_t) add[c];
+		bidx.push_back((uint32_t) b);
+		bval.push_back(ix->s16_blen[(size_t) b]);
+	}
+	if (recs.empty())
+		return 0;
+	DevGuard	tmp;
+	S16CApp    *d_recs = nullptr;
+	uint32_t   *d_bidx = nullptr, *d_bval = nullptr;
+
+	if (tmp.alloc(d_recs, recs.size() * sizeof(S16CApp))) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_bidx, bidx.size() * 4)) return NDBHIP_ERR_HIP;
+	if (tmp.alloc(d_bval, bval.size() * 4)) return NDBHIP_ERR_HIP;
+	HIP_TRY(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(S16CApp), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_bidx, bidx.data(), bidx.size() * 4, hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_bval, bval.data(), bval.size() * 4, hipMemcpyHostToDevice, g.stream));
+	hipLaunchKernelGGL(k_s16c_row_append, dim3((unsigned) ((recs.size() + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
+					   dim, dimp, (const S16CApp *) d_recs, (uint32_t) recs.size(), (const float *) ix->d_centroids,
+					   ix->s16_sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr, ix->d_planes,
+					   ix->d_rn2, ix->d_rexp, ix->d_pposof, ix->s16_sub ? ix->d_sub_rad : (uint32_t *) nullptr, ix->d_lrad);
+	if (ix->s16_sub)
+		/* the sweep sees the sublists as its lists: their lengths are its own table */
+		hipLaunchKernelGGL(k_s16c_set_u32, dim3((unsigned) ((bidx.size() + 255) / 256)), dim3(256), 0, g.stream, ix->d_sub_len,
+						   (const uint32_t *) d_bidx, (const uint32_t *) d_bval, (uint32_t) bidx.size());
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(g.stream));		/* the host arrays are locals */
+	g.stats.prepare_updates++;
 	return 0;
 }
 
@@ -2597,7 +2714,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	if (!seed_by_sublist && cen)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<false>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 						   (uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
-						   (const int64_t *) nullptr, (const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
+						   (const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
 						   0u, (const float *) nullptr, (const float *) nullptr, 0u, ix->w_qthr);
 	else if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
@@ -2734,8 +2851,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				if (cen)
 					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<true>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 									   (uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
-									   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
+									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
+									   (const uint32_t *) ix->d_pposof,
 									   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
 				else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_L2>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
@@ -2815,7 +2932,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 #define S16C_SWEEP_L(QB, NB, DB)                                                                                     \
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB == 1 || NB == 2) ? 2 : 1)), dim3(256), 0, g.stream, \
-							   dim, ncs, (const int64_t *) ds.loc_off, (const uint32_t *) ds.own_len,                         \
+							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
 							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (const uint32_t *) ix->w_pslot,            \
@@ -2823,7 +2940,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
-							   sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr, cE, qc_cap)
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap)
 			if (g_s16_debug == 1)
 				S16C_SWEEP_L(4, 2, 1);
 			else if (g_s16_debug == 2)
@@ -2852,13 +2969,6 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
 			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr);
-		if (round == 0)
-		{
-			hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
-							   g.d_counters + 3);
-			hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
-							   g.d_counters + 4);
-		}
 		HIP_TRY(hipGetLastError());
 		{
 			unsigned int f[8];
@@ -2874,6 +2984,11 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (!over)
 			break;
 	}
+	/* statistics: survivors given the reference's arithmetic, records emitted (as the last round left them) */
+	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
+					   g.d_counters + 3);
+	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
+					   g.d_counters + 4);
 	if (cen && fl8[5] > 0)
 		ix->s16c_density = (float) fl8[4] / (float) fl8[5];		/* pairs per bucket with pairs: the next batch's tile size */
 	if (g_debug_s16)
@@ -3065,6 +3180,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_qb must be 0 (auto), 1 or 4");
 		g_s16c_qb = value;
 	}
+	else if (!strcmp(name, "screen16_slack"))
+		g_s16_slack = value != 0;
 	else if (!strcmp(name, "screen16c_seeds"))
 	{
 		if (value != 0 && value != 32 && value != 64)

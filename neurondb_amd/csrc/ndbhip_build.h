@@ -1841,7 +1841,7 @@ k_s16_mid_sort(const MidDesc *__restrict__ md, const uint32_t *__restrict__ mrow
  * sublist.  Leaves ix->s16_sub false when no list is long enough.
  */
 static int
-ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
+ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 {
 	const int	nc = ix->ncent, dim = ix->dim;
 	std::vector<int> giant, midl;
@@ -2085,10 +2085,17 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 	size_t		nsub = 0;
 	const size_t nsub_g = cbase;
 
+	/* slack (the centred planes take appends in place): a regrouped list gets one more, empty sublist around its own
+	 * centroid — the rows inserted later land there, in insertion order — and every bucket that takes appends has
+	 * spare 32-row blocks behind it */
+	std::vector<uint32_t> nsub_eff(nsub_of);
+
 	for (int c = 0; c < nc; c++)
 	{
+		if (slack && nsub_of[(size_t) c] > 1)
+			nsub_eff[(size_t) c]++;
 		first[(size_t) c] = (uint32_t) nsub;
-		nsub += nsub_of[(size_t) c];
+		nsub += nsub_eff[(size_t) c];
 	}
 	first[(size_t) nc] = (uint32_t) nsub;
 	if (grow(ix->d_perm, ix->d_perm_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
@@ -2121,17 +2128,28 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo)
 	uint64_t	nb = 0;
 
 	bo.assign(nsub + 1, 0);
-	for (size_t s2 = 0; s2 < nsub; s2++)
-	{
-		sub_loc[s2 + 1] = sub_loc[s2] + (int64_t) sub_len[s2];
-		bo[s2] = (uint32_t) nb;
-		nb += (uint64_t) ((sub_len[s2] + 31) / 32);
-	}
+	ix->s16_tail.assign((size_t) nc, -1);
+	for (int c = 0; c < nc; c++)
+		for (uint32_t j = 0; j < nsub_eff[(size_t) c]; j++)
+		{
+			const size_t s2 = first[(size_t) c] + j;
+			const bool	tail = j + 1 == nsub_eff[(size_t) c];
+
+			sub_loc[s2 + 1] = sub_loc[s2] + (int64_t) sub_len[s2];
+			bo[s2] = (uint32_t) nb;
+			nb += (uint64_t) ((sub_len[s2] + 31) / 32);
+			if (slack && tail)
+			{
+				nb += std::max<uint64_t>(2, (uint64_t) ix->own_len[c] / 256);
+				ix->s16_tail[(size_t) c] = (int) s2;
+			}
+		}
 	bo[nsub] = (uint32_t) nb;
+	ix->s16_blen.assign(sub_len.begin(), sub_len.end());
 	if (nb + 8 > 0xFFFFFFFFull)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 row blocks");
 	for (int c = 0; c < nc; c++)
-		for (uint32_t j = 0; j < nsub_of[(size_t) c]; j++)
+		for (uint32_t j = 0; j < nsub_eff[(size_t) c]; j++)
 		{
 			const size_t s2 = first[(size_t) c] + j;
 

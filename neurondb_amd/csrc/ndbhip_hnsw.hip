@@ -3373,8 +3373,8 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	if (batch_div < 1) batch_div = 1;
 	if (batch_max < 1) batch_max = 1;
 	const uint32_t nb = n + 1;
-	const int	m = h->m;
-	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * m;
+	const int	m = 2 * h->m;		/* row width of the selections: a level-0 row may hold 2m */
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
 	std::vector<int> lev(n);
 
 	for (uint32_t i = 0; i < n; i++)
@@ -3574,8 +3574,8 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
 extern "C" int
 ndbhip_hnsw_set_intended_select(int select)
 {
-	if (select != 0 && select != 1)
-		return fail(NDBHIP_ERR_INVALID, "select must be 0 (the nearest m) or 1 (the heuristic)");
+	if (select < 0 || select > 3)
+		return fail(NDBHIP_ERR_INVALID, "select: bit 0 = the heuristic (else the nearest), bit 1 = up to 2m links for a new node at level 0");
 	g_h2_select = select;
 	return NDBHIP_OK;
 }

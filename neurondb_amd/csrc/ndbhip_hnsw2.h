@@ -578,12 +578,12 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 
 		for (int lc = top; lc >= 0; lc--)
 		{
-			const size_t so = ((size_t) sel_off[i] + (size_t) (top - lc)) * g.m;
+			const size_t so = ((size_t) sel_off[i] + (size_t) (top - lc)) * 2 * g.m;	/* rows of 2m: level 0 may take that many */
 
 			h2_search_layer(g, Q, cur, curd, lc, W, V, lane, evals);
 			V.clear(lane);
 			h2_sort(W, sid, sd, lane);
-			const int	n = h2_select(g, sid, sd, (int) W.nw, g.m, select, s_selid, s_seld, lane);
+			const int	n = h2_select(g, sid, sd, (int) W.nw, (lc == 0 && (select & 2)) ? 2 * g.m : g.m, select & 1, s_selid, s_seld, lane);
 
 			if (lane == 0)
 			{
@@ -678,7 +678,7 @@ k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups, cons
 			}
 			__threadfence_block();
 			/* ... and what the rule keeps of them */
-			const int	n = h2_select(g, cid, cd, cnt + 1, cap, select, kid, kd, lane);
+			const int	n = h2_select(g, cid, cd, cnt + 1, cap, select & 1, kid, kd, lane);
 
 			for (int j = lane; j < 2 * g.m; j += 64)
 				nb[j] = j < n ? kid[j] : NDBHIP_INVALID_BLOCK;

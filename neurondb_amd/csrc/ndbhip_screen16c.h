@@ -40,14 +40,17 @@ s16c_t_from_ub(float ub, int dim)
  * One wave per plane row.  planes[(blk * nchunk + c) * 4096 + image]: the 32 rows of block blk for the 64-dimension
  * chunk c, [r][8 slots of 16 bytes], logical slot s = elements 8 s .. 8 s + 7 of the chunk (s = 2 kstep + khalf),
  * stored at slot s ^ ((r >> 1) & 7) — the geometry of k_s16_row_prep's image with the second plane's slots
- * holding the chunk's next 32 dimensions instead.  rn2[prow] = |x - c|^2 as computed (NaN: not a finite fp32,
- * the row's elements are always emitted), rexp[prow] its scale exponent.
+ * holding the chunk's next 32 dimensions instead.  rn2[padded row] = |x - c|^2 as computed (NaN: not a finite fp32,
+ * the row's elements are always emitted), rexp[..] its scale exponent, pposof[..] the row's index in its list.
  */
 __global__ __launch_bounds__(256) void
 k_s16c_row_prep(const float *__restrict__ vecs, int64_t nrows, int dim, int dimp, const int64_t *__restrict__ loc_off,
 				const uint32_t *__restrict__ blk_off, int nb, const float *__restrict__ cents /* [nb][dim], or ... */,
 				const float *const *__restrict__ cptr /* ... a pointer per bucket */, unsigned char *__restrict__ planes,
-				float *__restrict__ rn2, int16_t *__restrict__ rexp, const int64_t *__restrict__ perm)
+				float *__restrict__ rn2, int16_t *__restrict__ rexp, const int64_t *__restrict__ perm,
+				const int64_t *__restrict__ prow_off /* [nb + 1] first PADDED plane row (32 x first block) of every bucket */,
+				const uint32_t *__restrict__ pos_of /* dense plane row -> index in its list, or NULL (= place in the bucket) */,
+				uint32_t *__restrict__ pposof /* padded plane row -> index in its list */ )
 {
 	const int	lane = threadIdx.x & 63;
 	const int64_t prow = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -82,12 +85,18 @@ k_s16c_row_prep(const float *__restrict__ vecs, int64_t nrows, int dim, int dimp
 	const bool	ok = s <= 3.0e38;
 	const int	e = ok ? s16_exponent(s) : 0;
 
+	const uint32_t pos = (uint32_t) (prow - loc_off[lo]);
+
 	if (lane == 0)
 	{
-		rn2[prow] = ok ? (float) s : __uint_as_float(0x7FC00000u);
-		rexp[prow] = (int16_t) e;
+		/* norms, exponents and list positions are indexed by padded plane row: a bucket's rows stay where they are
+		 * when rows are added behind them */
+		const int64_t pp = prow_off[lo] + pos;
+
+		rn2[pp] = ok ? (float) s : __uint_as_float(0x7FC00000u);
+		rexp[pp] = (int16_t) e;
+		pposof[pp] = pos_of ? pos_of[prow] : pos;
 	}
-	const uint32_t pos = (uint32_t) (prow - loc_off[lo]);
 	const size_t blk = (size_t) blk_off[lo] + (pos >> 5);
 	const int	rr = (int) (pos & 31u);
 	const int	nchunk = dimp / S16C_CH;
@@ -107,6 +116,88 @@ k_s16c_row_prep(const float *__restrict__ vecs, int64_t nrows, int dim, int dimp
 		h.x = h0; h.y = h1;
 		*reinterpret_cast<ndb_h2 *>(img + (size_t) ch * 4096 + 16 * ((j >> 2) ^ ((rr >> 1) & 7)) + 4 * (j & 3)) = h;
 	}
+}
+
+/* a row inserted after the planes were laid out: where it sits in the mirror and where it goes in the planes */
+struct S16CApp
+{
+	int64_t		row;			/* mirror row */
+	int64_t		pp;				/* padded plane row (in the spare blocks of its bucket) */
+	uint32_t	bucket;
+	uint32_t	list;
+	uint32_t	pos;			/* index in its list */
+	uint32_t	pad;
+};
+
+/* k_s16c_row_prep for those rows (one wave each), plus what the bounds need: the bucket's and the list's radius grow
+ * by atomicMax (float bits of |x - c| rounded up; +inf for a row that is not a finite fp32) */
+__global__ __launch_bounds__(256) void
+k_s16c_row_append(const float *__restrict__ vecs, int dim, int dimp, const S16CApp *__restrict__ recs, uint32_t n,
+				  const float *__restrict__ cents, const float *const *__restrict__ cptr, unsigned char *__restrict__ planes,
+				  float *__restrict__ rn2, int16_t *__restrict__ rexp, uint32_t *__restrict__ pposof,
+				  uint32_t *__restrict__ sub_rad /* per bucket, or NULL */, uint32_t *__restrict__ lrad /* per list */ )
+{
+	const int	lane = threadIdx.x & 63;
+	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (i >= n)
+		return;
+	const S16CApp a = recs[i];
+	const float *x = vecs + (size_t) a.row * dim;
+	const float *c = cptr ? cptr[a.bucket] : cents + (size_t) a.bucket * dim;
+	double		s = 0.0;
+
+	for (int j = lane; j < dim; j += 64)
+	{
+		const float d = x[j] - c[j];
+
+		s += (double) d * (double) d;
+	}
+	s = wave_sum_f64(s);
+	const bool	ok = s <= 3.0e38;
+	const int	e = ok ? s16_exponent(s) : 0;
+
+	if (lane == 0)
+	{
+		const double r = __builtin_sqrt(s) * (1.0 + 9.5367431640625e-7);
+		const uint32_t bits = (r <= 3.0e38) ? __float_as_uint(__double2float_ru(r)) : 0x7F800000u;
+
+		rn2[a.pp] = ok ? (float) s : __uint_as_float(0x7FC00000u);
+		rexp[a.pp] = (int16_t) e;
+		pposof[a.pp] = a.pos;
+		if (sub_rad)
+			atomicMax(&sub_rad[a.bucket], bits);
+		atomicMax(&lrad[a.list], bits);
+	}
+	const size_t blk = (size_t) (a.pp >> 5);
+	const int	rr = (int) (a.pp & 31);
+	const int	nchunk = dimp / S16C_CH;
+	unsigned char *img = planes + blk * (size_t) nchunk * 4096 + (size_t) rr * 128;
+
+	for (int p = lane; p < dimp / 2; p += 64)
+	{
+		const int	k2 = 2 * p, ch = k2 >> 6, j = (k2 & 63) >> 1;
+		_Float16	h0 = 0, h1 = 0;
+
+		if (ok && k2 < dim)
+			h0 = (_Float16) (float) ldexp((double) (x[k2] - c[k2]), 14 - e);
+		if (ok && k2 + 1 < dim)
+			h1 = (_Float16) (float) ldexp((double) (x[k2 + 1] - c[k2 + 1]), 14 - e);
+		ndb_h2		h;
+
+		h.x = h0; h.y = h1;
+		*reinterpret_cast<ndb_h2 *>(img + (size_t) ch * 4096 + 16 * ((j >> 2) ^ ((rr >> 1) & 7)) + 4 * (j & 3)) = h;
+	}
+}
+
+/* dst[idx[i]] = val[i] */
+__global__ void
+k_s16c_set_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ val, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i < n)
+		dst[idx[i]] = val[i];
 }
 
 /*
@@ -225,7 +316,8 @@ __global__ __launch_bounds__(64) void
 k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 			const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, uint32_t ns,
 			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
-			const int64_t *__restrict__ sub_loc, const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of,
+			const int64_t *__restrict__ prow_off /* first padded plane row of every sublist */,
+			const uint32_t *__restrict__ pposof /* padded plane row -> index in its list */,
 			const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
 			const float *__restrict__ cdist, uint32_t cstride, float2 *__restrict__ qthr)
 {
@@ -286,10 +378,10 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 
 			if ((uint32_t) lane < min(sub_len[bs], ns))
 			{
-				const int64_t prow = sub_loc[bs] + lane;
+				const uint32_t pos = pposof[prow_off[bs] + lane];
 
-				ok = pos_of[prow] < vis;			/* a candidate of this (query, probe) under the candidate cap */
-				row = perm[prow];
+				ok = pos < vis;			/* a candidate of this (query, probe) under the candidate cap */
+				row = ix.loc_off[probes[(size_t) q * npr + bp]] + pos;
 			}
 		}
 	}

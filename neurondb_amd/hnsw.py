@@ -73,6 +73,41 @@ class HnswIndex:
                                              _ptr(lv), int(ef_construction)))
         self.nblocks = len(lv) + 1
 
+    def build_intended(self, rows, tids, levels, ef_construction=200, batch_div=16, batch_max=8192):
+        """The `intended` graph (ndbhip_hnsw_build_intended_device; oracle/ndb_oracle_hnsw2.c defines it): rows as a
+        numpy array or a CUDA tensor, node i + 1 = row i."""
+        import torch
+        r = rows if isinstance(rows, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
+        if isinstance(tids, torch.Tensor):
+            tt = tids
+        else:
+            t = np.ascontiguousarray(tids)
+            t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
+            t8 = np.zeros((t6.shape[0], 8), dtype=np.uint8)
+            t8[:, :6] = t6
+            tt = torch.from_numpy(t8.view(np.int64).reshape(-1)).cuda()
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        check(lib().ndbhip_hnsw_build_intended_device(self._h, C.c_void_p(r.data_ptr()), C.c_void_p(tt.data_ptr()), len(lv),
+                                                      _ptr(lv), int(ef_construction), int(batch_div), int(batch_max)))
+        check(lib().ndbhip_synchronize())
+        self.nblocks = len(lv) + 1
+
+    def search_intended(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K):
+        """kNN of the `intended` mode: (blocks [nq, k], dist [nq, k] = sqrt of the squared L2, count [nq], evaluations [nq])"""
+        import torch
+        q = queries if isinstance(queries, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)).cuda()
+        nq = q.shape[0]
+        ob = torch.zeros((nq, k), dtype=torch.int32, device=q.device)
+        od = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
+        oc = torch.zeros(nq, dtype=torch.int32, device=q.device)
+        oe = torch.zeros(nq, dtype=torch.int64, device=q.device)
+        check(lib().ndbhip_hnsw_search_intended_device(self._h, C.c_void_p(q.data_ptr()), nq, int(ef), int(k),
+                                                       C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
+                                                       C.c_void_p(oc.data_ptr()), None, C.c_void_p(oe.data_ptr())))
+        check(lib().ndbhip_synchronize())
+        return ob.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy(), oe.cpu().numpy()
+
     @classmethod
     def load_pages(cls, pages):
         """Mirror of an hnsw relation image (bytes / uint8 array of 8 KB blocks): ndbhip_hnsw_load_pages."""

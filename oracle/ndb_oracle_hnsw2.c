@@ -271,7 +271,7 @@ typedef struct h2_sel
 {
 	int			top;			/* highest level with a selection (-1: the graph was empty) */
 	int			n[H2_MAXLEV];
-	uint32_t   *ids;			/* [H2_MAXLEV][m] */
+	uint32_t   *ids;			/* [H2_MAXLEV][2m] */
 	double	   *d2;
 }			h2_sel;
 
@@ -310,7 +310,9 @@ h2_select(const ndbo_hnsw *g, const float *base, const uint32_t *cid, const doub
 static void
 h2_insert_search(const ndbo_hnsw *g, const float *vec, int level, int select, h2_sel *s, uint8_t *visited)
 {
-	const int	efc = g->ef_construction, m = g->m;
+	const int	efc = g->ef_construction, m = g->m, w = 2 * g->m;
+	/* bit 1 of `select`: a new node takes up to 2m links at level 0 (the list's capacity there) instead of m */
+	const int	m0 = (select & 2) ? 2 * m : m;
 	uint32_t	cur;
 	double		curd;
 	uint32_t   *wid;
@@ -332,7 +334,7 @@ h2_insert_search(const ndbo_hnsw *g, const float *vec, int level, int select, h2
 	{
 		const int	nw = ndbo_h2_search_layer(g, vec, &cur, &curd, 1, efc, lc, wid, wd, NULL, visited);
 
-		s->n[lc] = h2_select(g, vec, wid, wd, nw, m, select, s->ids + (size_t) lc * m, s->d2 + (size_t) lc * m);
+		s->n[lc] = h2_select(g, vec, wid, wd, nw, lc == 0 ? m0 : m, select & 1, s->ids + (size_t) lc * w, s->d2 + (size_t) lc * w);
 		cur = wid[0];			/* the nearest found is the next level's entry point */
 		curd = wd[0];
 	}
@@ -380,7 +382,7 @@ h2_backlink(ndbo_hnsw *g, uint32_t e, int level, uint32_t x, double dxe, int sel
 		cid[j] = id;
 		n++;
 	}
-	n = h2_select(g, h2_vec(g, e), cid, cd, n, cap, select, kid, kd);
+	n = h2_select(g, h2_vec(g, e), cid, cd, n, cap, select & 1, kid, kd);
 	for (i = 0; i < 2 * g->m; i++)
 		nb[i] = i < n ? kid[i] : NDBO_INVALID_BLOCK;
 	*pc = (int16_t) n;
@@ -389,7 +391,7 @@ h2_backlink(ndbo_hnsw *g, uint32_t e, int level, uint32_t x, double dxe, int sel
 static void
 h2_insert_apply(ndbo_hnsw *g, uint32_t x, int level, const h2_sel *s, int select)
 {
-	const int	m = g->m;
+	const int	m = 2 * g->m;		/* row width of the selections */
 	int			lc,
 				i;
 
@@ -413,8 +415,8 @@ h2_insert_apply(ndbo_hnsw *g, uint32_t x, int level, const h2_sel *s, int select
 }
 
 /*
- * Build over n rows (row i becomes block i + 1), levels injected, the batch schedule of the header.  select: 0 = the
- * nearest m, 1 = the heuristic.  Returns the number of batches.
+ * Build over n rows (row i becomes block i + 1), levels injected, the batch schedule of the header.  select: bit 0: 0 = the
+ * nearest, 1 = the heuristic; bit 1: a new node takes up to 2m links at level 0 instead of m.  Returns the number of batches.
  */
 int
 ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, const int *levels, int batch_div,
@@ -447,8 +449,8 @@ ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, 
 			sel = (h2_sel *) realloc(sel, sizeof(h2_sel) * (size_t) b);
 			for (i = capsel; i < b; i++)
 			{
-				sel[i].ids = (uint32_t *) malloc(sizeof(uint32_t) * H2_MAXLEV * (size_t) m);
-				sel[i].d2 = (double *) malloc(sizeof(double) * H2_MAXLEV * (size_t) m);
+				sel[i].ids = (uint32_t *) malloc(sizeof(uint32_t) * H2_MAXLEV * 2 * (size_t) m);
+				sel[i].d2 = (double *) malloc(sizeof(double) * H2_MAXLEV * 2 * (size_t) m);
 			}
 			capsel = b;
 		}

@@ -1,0 +1,84 @@
+"""The `intended` HNSW on the device (csrc/ndbhip_hnsw2.h) against its sequential definition, oracle/ndb_oracle_hnsw2.c:
+the device-built graph equals the oracle's slot for slot under the same batch schedule, the device search returns
+the oracle's blocks, float4 distances and evaluation counts, and the graph finds neighbours (recall@10 against a
+float64 brute force) where the reference-compatible one does not."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels(rng, n):
+    r = rng.uniform(1e-12, 1.0, n)
+    return np.clip((-np.log(r) * np.float32(0.36)).astype(np.int32), 0, 15)      # hnsw_am.c:1143-1161
+
+
+def _data(kind, n, dim, nq, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "clustered":
+        cen = rng.standard_normal((32, dim)).astype(np.float32)
+        base = (cen[rng.integers(0, 32, n)] + 0.1 * rng.standard_normal((n, dim))).astype(np.float32)
+        q = (cen[rng.integers(0, 32, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+    elif kind == "integer":
+        base = rng.integers(-2, 3, size=(n, dim)).astype(np.float32)             # equal distances everywhere
+        q = rng.integers(-2, 3, size=(nq, dim)).astype(np.float32)
+    else:
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+    return base, q, _levels(rng, n)
+
+
+@pytest.mark.parametrize("kind,n,dim,m,efc,bdiv,bmax,select", [
+    ("normal", 1500, 48, 8, 40, 64, 1024, 1), ("clustered", 2500, 64, 16, 64, 16, 256, 1),
+    ("integer", 1200, 40, 6, 32, 8, 64, 1), ("normal", 900, 100, 16, 200, 1, 1, 1),
+    ("clustered", 2000, 64, 16, 64, 32, 512, 0), ("normal", 1100, 1100, 8, 24, 64, 1024, 1),
+    ("clustered", 2500, 64, 16, 64, 16, 256, 3), ("normal", 1300, 48, 8, 40, 64, 1024, 2)])
+def test_intended_build_and_search_equal_the_oracle(kind, n, dim, m, efc, bdiv, bmax, select):
+    from neurondb_amd import HnswIndex, _lib
+    from oracle import ndbo
+    base, q, levels = _data(kind, n, dim, 40, seed=n + dim)
+    og = ndbo.HnswGraph(dim, m, efc, cap_nodes=n + 1)
+    nb = og.build_intended(base, levels, batch_div=bdiv, batch_max=bmax, select=select)
+    e = og.arrays()
+    _lib.ensure_init()
+    _lib.check(_lib.lib().ndbhip_hnsw_set_intended_select(select))
+    try:
+        ix = HnswIndex(dim, m)
+        ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, efc, batch_div=bdiv, batch_max=bmax)
+    finally:
+        _lib.check(_lib.lib().ndbhip_hnsw_set_intended_select(1))
+    d = ix.export()
+    assert d["nblocks"] == n + 1 and d["entry_point"] == e["entry_point"] and d["entry_level"] == e["entry_level"]
+    assert np.array_equal(d["levels"][1:], e["levels"][1:])
+    assert np.array_equal(d["ncount"][1:], e["ncount"][1:]), np.argwhere(d["ncount"] != e["ncount"])[:5]
+    assert np.array_equal(d["nbrs"][1:], e["nbrs"][1:]), np.argwhere(d["nbrs"] != e["nbrs"])[:5]
+    if bmax == 1:
+        assert nb == n
+    for ef, k in ((64, 10), (8, 8), (200, 37)):
+        ob, od, oc, oe = ix.search_intended(q, ef, k)
+        for i in range(len(q)):
+            eb, ed, ns = og.search_intended(q[i], ef, k)
+            assert oc[i] == len(eb) and np.array_equal(ob[i, :oc[i]], eb), (i, ob[i], eb)
+            assert np.array_equal(od[i, :oc[i]].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns, (i, oe[i], ns)
+    ix.close()
+
+
+@pytest.mark.parametrize("kind", ["normal", "clustered"])
+def test_intended_graph_finds_the_neighbours(kind):
+    """recall@10 against a float64 brute force at ef_search = 64 (m = 16, ef_construction = 200)"""
+    from neurondb_amd import HnswIndex
+    from oracle import ndbo
+    n, dim, nq = 20000, 64, 200
+    base, q, levels = _data(kind, n, dim, nq, seed=5)
+    ix = HnswIndex(dim, 16)
+    ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, 200)
+    ob, od, oc, oe = ix.search_intended(q, 64, 10)
+    d2 = ((q[:, None, :].astype(np.float64) - base[None].astype(np.float64)) ** 2).sum(-1)
+    gt = np.argsort(d2, axis=1, kind="stable")[:, :10] + 1
+    recall = np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nq)])
+    assert recall >= (0.95 if kind == "clustered" else 0.7), recall
+    # the distances are the L2 distances of the blocks returned
+    i = 3
+    ex = np.sqrt(d2[i, ob[i, :oc[i]].astype(np.int64) - 1])
+    assert np.allclose(od[i, :oc[i]], ex, rtol=1e-6)
+    ix.close()

@@ -403,3 +403,60 @@ def test_centroid_scan_on_the_matrix_cores_selects_like_the_reference(dim, nlist
             et, ed, ec, _ = oracle_search_batch(img, q[:130], 1, nprobe, 10, 0)
             assert_same_results(t, d, c, et, ed, ec)
     ix.close()
+
+
+@pytest.mark.parametrize("sublists", [1, 0])
+def test_appends_go_into_the_planes_spare_blocks_without_a_new_layout(sublists, lib):
+    """aminsert between batches (ivf_am.c:954-1157): the centred planes keep spare blocks behind every list (behind an
+    extra sublist around the centroid where the list is regrouped), so 1000 rows appended 25 at a time between
+    130-query batches cost 40 small updates (stats.prepare_updates) and at most a couple of full layouts
+    (stats.prepares: one at the start, one more only when a list outgrows its spare blocks) — and every batch is the
+    oracle's, rows far from everything and duplicates of existing rows included."""
+    from oracle import ndbo
+    rng = np.random.default_rng(404 + sublists)
+    dim, nlists, n0 = 64, 12, 20000
+    cen = rng.standard_normal((40, dim)).astype(np.float32) * 3
+    base = (cen[rng.integers(0, 40, n0)] + 0.1 * rng.standard_normal((n0, dim))).astype(np.float32)
+    cent = base[rng.choice(n0, nlists, replace=False)].copy()
+    asg = ((base[:, None, :].astype(np.float64) - cent[None]) ** 2).sum(-1).argmin(1)
+    lists = [list(np.flatnonzero(asg == c)) for c in range(nlists)]
+    rows_all = [base[i] for i in range(n0)]
+
+    def arrays():
+        order = np.concatenate([np.asarray(l, np.int64) for l in lists])
+        return dict(centroids=cent, list_len=np.asarray([len(l) for l in lists], np.int64),
+                    rows=np.ascontiguousarray(np.stack([rows_all[i] for i in order])), tids=ndbo.tids_from_rows(order))
+
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", sublists))
+    try:
+        a = arrays()
+        ix = _index(a)
+        lib.check(lib.lib().ndbhip_stats_reset())
+        nq, k, nprobe = 130, 10, 5
+        for rnd in range(40):
+            for _ in range(25):
+                c = int(rng.integers(0, nlists))
+                kind = rng.random()
+                if kind < 0.8:
+                    v = (cen[rng.integers(0, 40)] + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+                elif kind < 0.9:
+                    v = rows_all[int(rng.integers(0, len(rows_all)))].copy()            # a duplicate
+                else:
+                    v = (rng.standard_normal(dim) * 30).astype(np.float32)              # far from everything
+                rid = len(rows_all)
+                rows_all.append(v)
+                lists[c].append(rid)
+                ix.append(c, v, ndbo.tids_from_rows(np.asarray([rid]))[0])
+            q = (cen[rng.integers(0, 40, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+            q[:20] = np.stack([rows_all[i] for i in rng.integers(0, len(rows_all), 20)])
+            t, d, c_ = ix.search(q, 1, nprobe, k, 0)
+            if rnd % 8 == 7 or rnd < 2:
+                et, ed, ec, _ = oracle_search_batch(oracle_image(arrays()), q, 1, nprobe, k, 0)
+                assert_same_results(t, d, c_, et, ed, ec)
+        st = lib.stats()
+        assert st["screen16_batches"] + st["screen16_fallbacks"] == 40, st
+        assert st["prepares"] <= 3 and st["prepare_updates"] >= 37, st
+        ix.close()
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", 1))
