@@ -712,7 +712,7 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
     off[1:] = np.cumsum(list_len)
     img = ndbo.IvfImage(cent_h, off, rows_h, tid_h)
     q_h = qs[:nparity].cpu().numpy()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         res = list(ex.map(lambda i: img.search(q_h[i], 1, nprobe, k, 0), range(nparity)))
@@ -810,7 +810,7 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
     tc = (time.perf_counter() - t0) / sample
     # all host cores (one thread per core; the ctypes call releases the GIL): the CPU baseline of C3 in queries/s
     from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     ncpu = int(min(nq, max(cores * 8, min(args.cpu_seconds, 10.0) * cores / max(tc, 1e-6))))
     qall = q[:ncpu].cpu().numpy()
     t0 = time.perf_counter()
@@ -936,7 +936,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             bad += not (oc[i] == len(eb) and np.array_equal(ob[i, :len(eb)], eb) and
                         np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns)
         tc = (time.perf_counter() - t0) / sample
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         ncpu = int(min(nq, max(cores * 4, min(args.cpu_seconds, 10.0) * cores / max(tc, 1e-6)))) if args.cpu_seconds > 0 else 0
         cpu = None
         if ncpu > 0:
@@ -1030,6 +1030,30 @@ def pmc_traffic(args, world, kernel="k_ivf_scan", data=None, want_busy=False):
     return none
 
 
+def host_cores():
+    """Cores this process may really use: the smaller of the affinity mask and the cgroup's CPU quota (a container can
+    see 256 CPUs and be allowed 8); os.cpu_count() alone overstates the CPU baseline's denominator."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g2:
+                q, p2 = int(f.read()), int(g2.read())
+            if q > 0:
+                n = max(1, min(n, q // p2))
+        except Exception:
+            pass
+    return n
+
+
 def sweep_roofline(args, st, nq, steps, ms_per_step, data_kind, world):
     """Roofline of k_s16c_sweep (csrc/ndbhip_screen16c.h), the dominant kernel of a screened L2 batch over float4
     rows, on the work it DOES — every number recomputable from library_stats and profiles/:
@@ -1086,7 +1110,7 @@ def build_cpu_baseline(args, base, cent_h, iters):
     (iterations x sample + N) rows at that rate (centroid updates are negligible next to it)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ndbo
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     L = ndbo.lib()
     nl, dim = cent_h.shape
     cent = np.ascontiguousarray(cent_h, np.float32)
@@ -1115,7 +1139,7 @@ def run_cpu_baseline(args, cent_h, list_len, rows_h, tid_h, qs, out_t, out_d, ou
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ndbo
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     tid_h = np.ascontiguousarray(tid_h).view(ndbo.TID_DTYPE).reshape(-1)
     off = np.zeros(len(list_len) + 1, dtype=np.int64)
     off[1:] = np.cumsum(list_len)
@@ -1163,7 +1187,7 @@ def run_cpu_baseline(args, cent_h, list_len, rows_h, tid_h, qs, out_t, out_d, ou
             n0, bad = nsample, vbad
     img.free_spread()
     best = max(variants.values(), key=lambda v: v["queries_per_s"])
-    return {"value": best["queries_per_s"], "unit": "queries/s", "cores": cores, "kind": "port",
+    return {"value": best["queries_per_s"], "unit": "queries/s", "cores": cores, "cpus_visible": os.cpu_count(), "kind": "port",
             "sample": f"{n0} queries of the same workload through oracle/ndb_oracle.c (-ffp-contract=off) on one pthread per "
                       "core (oracle/ndb_oracle_mt.c; the rows in memory first touched by the workers, 2 MiB stripes "
                       "round-robin over their NUMA nodes); both builds in `variants`, `value` = the faster",

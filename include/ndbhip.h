@@ -366,6 +366,10 @@ int			ndbhip_ivf_search_sharded(ndbhip_ivf *shard, const float *d_queries, int n
 /* Personalised exchange (csrc/ndbhip_comm.cpp): bytes [send_off[p], send_off[p + 1]) of d_send go to rank p and
  * land at [recv_off[r], recv_off[r + 1]) of p's d_recv (r = the sender); host arrays of world + 1 byte offsets. */
 int			ndbhip_comm_alltoallv(const void *d_send, const size_t *send_off, void *d_recv, const size_t *recv_off);
+/* In-place element-wise minimum of n floats over the ranks (device pointer, the library's stream): what a sharded
+ * screened scan does to its queries' first thresholds between the seeds and the sweep, so that a rank that does not
+ * hold a query's own list still sweeps against the bound of the rank that does.  RCCL: ncclAllReduce(ncclMin). */
+int			ndbhip_comm_allreduce_min_f32(float *d_buf, size_t n);
 /*
  * ivfbuild over the communicator's ranks, each holding a contiguous slice of the table in heap order (rank 0 the
  * first rows, rank 1 the next ...): rank 0 runs the k-means on the sample (the table's first min(10000, 100 lists)

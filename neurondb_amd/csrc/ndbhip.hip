@@ -2410,6 +2410,16 @@ static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - 
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
 static int	g_s16_cen = 1;		/* L2 on float4 rows: the centred one-plane sweep (ndbhip_screen16c.h; "screen16_centered", 0: the two-plane sweep) */
 static int	g_s16c_qb = 0;		/* pairs per tile of the centred sweep / 32: 4 or 1; 0 = from the previous batch's pairs per bucket ("screen16c_qb") */
+/* a sharded search (ndbhip_comm.cpp) exchanges the queries' first thresholds between the seeds and the sweep: the
+ * minimum over the ranks, in place, of the (threshold, unused) pairs — every rank must call it once per sub-batch */
+static int	(*g_thr_hook) (float *, size_t) = nullptr;
+
+extern "C" void
+ndbhip_internal_set_thr_hook(int (*fn) (float *, size_t))
+{
+	g_thr_hook = fn;
+}
+
 static int	g_s16_slack = 1;	/* the centred planes keep spare blocks and take appends in place ("screen16_slack", 0: every append lays the planes out again) */
 static int	g_s16c_seeds = 0;	/* rows whose upper bounds give a query its first threshold, 0 = 32 (k <= 20) or 64 ("screen16c_seeds") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
@@ -2719,6 +2729,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	else if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
 				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr, cen ? 1 : 0);
+	if (g_thr_hook && !seed_by_sublist)
+	{
+		/* sharded search: the smallest threshold any rank found for a query serves all of them */
+		const int	rc = g_thr_hook((float *) ix->w_qthr, (size_t) 2 * nq);
+
+		if (rc)
+			return rc;
+	}
 
 	/* the (query, probe) pairs bucketed by list — by sublist when the planes are regrouped (`ncs` buckets) —; items
 	 * of 128 rows x 128 queries */
@@ -2861,6 +2879,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
 								   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
 								   (const uint32_t *) ix->d_xmax16, ix->w_qthr, cen ? 1 : 0);
+				if (g_thr_hook)
+				{
+					const int	rc2 = g_thr_hook((float *) ix->w_qthr, (size_t) 2 * nq);
+
+					if (rc2)
+						return rc2;
+				}
 			}
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -3309,6 +3334,17 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 		hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, ix->dim, dimp,
 						   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
+	}
+	if (g_thr_hook && !s16_here && full && allow_s16)
+	{
+		/* a sharded search whose other ranks exchange thresholds while this one serves the sub-batch another way
+		 * (no rows here, a recipe the screen does not take): it joins the exchange with +inf */
+		if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) ix->w_qthr, 0x7F800000, (size_t) 2 * nq, g.stream));
+		const int	rc = g_thr_hook((float *) ix->w_qthr, (size_t) 2 * nq);
+
+		if (rc)
+			return rc;
 	}
 	if (!d_probes_in && s16_here && g_cent_s16 && ncmp >= 256 && ncmp <= 4096 && npr <= NDBHIP_MAX_NPROBE)
 	{

@@ -30,6 +30,7 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -42,6 +43,7 @@
 #include "../../include/ndbhip.h"
 
 extern "C" int ndbhip_internal_fail(int code, const char *fmt, ...);
+extern "C" void ndbhip_internal_set_thr_hook(int (*fn) (float *, size_t));
 
 namespace
 {
@@ -66,6 +68,8 @@ struct RcclApi
 	ncclResult_t (*Recv) (void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*GroupStart) (void) = nullptr;
 	ncclResult_t (*GroupEnd) (void) = nullptr;
+	/* the per-query thresholds' minimum over the ranks (ndbhip_comm_allreduce_min_f32) */
+	ncclResult_t (*AllReduce) (const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 };
 
 struct Comm
@@ -121,6 +125,7 @@ load_rccl()
 	SYM(Recv, "ncclRecv");
 	SYM(GroupStart, "ncclGroupStart");
 	SYM(GroupEnd, "ncclGroupEnd");
+	SYM(AllReduce, "ncclAllReduce");
 #undef SYM
 	return 0;
 }
@@ -362,6 +367,66 @@ ndbhip_comm_allgather(const void *d_send, void *d_recv, size_t bytes)
 }
 
 /*
+ * In-place element-wise minimum of n floats over the ranks (device pointer, the library's stream).  One use: the
+ * per-query thresholds of a sharded screened scan — a rank that does not hold a query's own list would otherwise
+ * sweep its rows against a threshold nothing has tightened.  RCCL: ncclAllReduce(ncclMin); SHM: through the slots.
+ */
+extern "C" int
+ndbhip_comm_allreduce_min_f32(float *d_buf, size_t n)
+{
+	void	   *sv = nullptr;
+
+	if (ndbhip_get_stream(&sv))
+		return NDBHIP_ERR_NODEVICE;
+	hipStream_t stream = (hipStream_t) sv;
+
+	if (n == 0 || comm.kind == 0 || comm.world == 1)
+		return NDBHIP_OK;
+	if (!d_buf)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "NULL device pointer");
+	if (comm.kind == 1)
+	{
+		const ncclResult_t r = rccl.AllReduce(d_buf, d_buf, n, ncclFloat, ncclMin, comm.nccl, stream);
+
+		if (r != ncclSuccess)
+			return ndbhip_internal_fail(NDBHIP_ERR_HIP, "ncclAllReduce: %s", rccl.GetErrorString(r));
+		return NDBHIP_OK;
+	}
+	const size_t bytes = n * sizeof(float);
+
+	if (bytes > comm.slot_bytes)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "all-reduce of %zu bytes exceeds the segment's slots (%zu)", bytes,
+									comm.slot_bytes);
+	float	   *mine = (float *) (comm.slots + (size_t) comm.rank * comm.slot_bytes);
+
+	if (hipMemcpyAsync(mine, d_buf, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+		hipStreamSynchronize(stream) != hipSuccess)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "device-to-host copy failed");
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot is written */
+	float	   *red = (float *) malloc(bytes);
+
+	if (!red)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	memcpy(red, comm.slots, bytes);
+	for (int r = 1; r < comm.world; r++)
+	{
+		const float *o = (const float *) (comm.slots + (size_t) r * comm.slot_bytes);
+
+		for (size_t i = 0; i < n; i++)
+			if (o[i] < red[i])
+				red[i] = o[i];
+	}
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot has been read: it may be overwritten */
+	const bool	ok = hipMemcpyAsync(d_buf, red, bytes, hipMemcpyHostToDevice, stream) == hipSuccess &&
+		hipStreamSynchronize(stream) == hipSuccess;
+
+	free(red);
+	if (!ok)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "host-to-device copy failed");
+	return NDBHIP_OK;
+}
+
+/*
  * Personalised exchange: bytes [send_off[p], send_off[p + 1]) of this rank's d_send go to rank p and arrive at
  * [recv_off[r], recv_off[r + 1]) of p's d_recv (r = this rank); host arrays of world + 1 byte offsets, the sizes
  * agreed by the caller (rank r's piece for p is as long as p expects from r).  Device pointers, ordered on the
@@ -492,9 +557,12 @@ ndbhip_ivf_search_sharded(ndbhip_ivf *shard, const float *d_queries, int nq, int
 	rc = ndbhip_comm_allgather(comm.probes_mine, comm.probes_all, (size_t) s * nprobe * sizeof(int));
 	if (rc)
 		return rc;
-	/* 2. this shard's lists for all queries */
+	/* 2. this shard's lists for all queries; the queries' first thresholds are exchanged on the way (minimum over the
+	 * ranks: every rank then sweeps against the bound of the rank that holds the query's own list) */
+	ndbhip_internal_set_thr_hook(world > 1 ? ndbhip_comm_allreduce_min_f32 : nullptr);
 	rc = ndbhip_ivf_search_partial_probes_device(shard, d_queries, nq, strategy, nprobe, k, max_candidates,
 												 comm.probes_all, comm.cand, comm.ncand, comm.total);
+	ndbhip_internal_set_thr_hook(nullptr);
 	if (rc)
 		return rc;
 	/* 3. records of every rank, then the replay merge */

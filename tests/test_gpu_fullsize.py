@@ -321,4 +321,30 @@ def test_c4_c5_single_gpu_share_properties(cfg):
         assert len(et) == cnt[i] and np.array_equal(erow, rows[i, :len(et)]), (cfg, i)
         assert np.array_equal(ed.view(np.uint32), dist[i, :len(et)].view(np.uint32)), (cfg, i)
     assert len(picks) >= 4
+
+    # The 8-rank execution of this config, one rank after the other on this device: the index cut into
+    # work-balanced list slices (the 900 k-row list every query probes goes to all eight), every shard's partial
+    # records, the replay merge — equal to the unsharded result for the whole batch.
+    from neurondb_amd.dist import ShardedSearchBuffers, partition_slices
+    world = 8
+    probes = torch.zeros((nq, PROBES), dtype=torch.int32, device=dev)
+    ix.select_clusters_device(q, probes, PROBES)
+    check(lib.ndbhip_synchronize())
+    pc = probes.cpu().numpy()
+    slo, sln, stl = partition_slices(ll, world, np.bincount(pc[pc >= 0].ravel(), minlength=lists)[:lists])
+    assert ((sln > 0).sum(0) > 1).any()
+    buf = ShardedSearchBuffers(nq, K, world, dev, nprobe=PROBES)
+    for w in range(world):
+        sh = ix.shard_slices(slo[w], sln[w], stl[w])
+        sh.search_partial_probes_device(q, probes, buf.cand, buf.ncand, buf.total, strategy, PROBES, K, 0)
+        check(lib.ndbhip_synchronize())
+        buf.cand_all[w].copy_(buf.cand)
+        buf.ncand_all[w].copy_(buf.ncand)
+        sh.close()
+    check(lib.ndbhip_merge_topk_device(buf.cand_all.data_ptr(), buf.ncand_all.data_ptr(), buf.total.data_ptr(), world, nq, K,
+                                       buf.cap, buf.out_tids.data_ptr(), buf.out_dist.data_ptr(), buf.out_count.data_ptr()))
+    check(lib.ndbhip_synchronize())
+    assert np.array_equal(unpack_tids(buf.out_tids).cpu().numpy(), rows), cfg
+    assert np.array_equal(buf.out_dist.cpu().numpy().view(np.uint32), dist.view(np.uint32)), cfg
+    assert np.array_equal(buf.out_count.cpu().numpy(), cnt), cfg
     ix.close()

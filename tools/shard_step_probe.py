@@ -31,9 +31,12 @@ def main():
     dev = torch.device("cuda", 0)
     _lib.ensure_init(0)
     _lib.use_torch_stream()
-    n, dim, nlists, nprobe, k, nq = 1_000_000, 768, 1024, 32, 10, int(os.environ.get("NQ", 4096))
-    base = make_data(n, dim, "clustered", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
-    q = make_data(nq, dim, "clustered", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    n, dim, nlists, nprobe, k, nq = int(os.environ.get("NVEC", 1_000_000)), 768, int(os.environ.get("LISTS", 1024)), 32, 10, \
+        int(os.environ.get("NQ", 4096))
+    comp = int(os.environ.get("COMPONENTS", nlists))
+    print(f"table {n} x {dim}, lists {nlists}, {comp} components, {nq} queries per step")
+    base = make_data(n, dim, "clustered", comp, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
+    q = make_data(nq, dim, "clustered", comp, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
     full = IvfIndex(dim, nlists)
     full.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
     _, ll, _, _ = full.export(rows=False)
@@ -43,7 +46,8 @@ def main():
     oc = torch.zeros(nq, dtype=torch.int32, device=dev)
     t1 = timed(lambda: full.search_device(q, ot, od, oc, 1, nprobe, k, 0), sync)
     print(f"N=1: full step {t1:.3f} ms ({nq / t1 * 1e3:.0f} q/s)")
-    qcal = make_data(nq, dim, "clustered", 1024, 0.1, 0x5EED0007, 0x5EEDC0DE, dev)     # calibration batch
+    qcal = make_data(nq, dim, "clustered", comp, 0.1, 0x5EED0007, 0x5EEDC0DE, dev)     # calibration batch
+    del base
     pc = torch.zeros((nq, nprobe), dtype=torch.int32, device=dev)
     full.select_clusters_device(qcal, pc, nprobe)
     sync()
