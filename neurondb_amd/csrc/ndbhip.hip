@@ -2780,10 +2780,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4) ? g_s16c_qb :
 		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : 4) : (ix->s16_sub ? 1 : 4));
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
-	/* rows of the pair planes: every pair there can be, up to 4 x (queries x probes) (at least 65 536) — sublists
+	/* rows of the pair planes: every pair there can be, up to 16 x (queries x probes) (at least 65 536) — sublists
 	 * multiply the pairs of a probed list, the exclusion bounds remove most again; a batch with more than that goes to
 	 * the older path (flags[2]) */
-	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, std::max<size_t>((size_t) 4 * nq * npr + 1024, (size_t) 1 << 16)),
+	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, std::max<size_t>((size_t) 16 * nq * npr + 1024, (size_t) 1 << 16)),
 														   0x7FFFFFFFu);
 	const uint32_t qcrowbytes = (uint32_t) dimp * 2u;
 
@@ -2814,7 +2814,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	 */
 	unsigned int *active = ix->w_ecount + 2 * (size_t) nq;
 
-	const size_t fsmem = topk_smem_bytes(S16_SURV_CAP, (uint32_t) k);
+	/* a shard's finalize decides with the k-th LOCAL bound, looser than the whole index's: four times the room */
+	const uint32_t surv_cap = partial ? 4u * S16_SURV_CAP : (uint32_t) S16_SURV_CAP;
+	const size_t fsmem = topk_smem_bytes(surv_cap, (uint32_t) k);
 	unsigned int over = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 	for (int round = 0; round < 2; round++)
@@ -2993,7 +2995,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 #define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__)
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
-			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr);
+			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr,
+			  surv_cap);
 		HIP_TRY(hipGetLastError());
 		{
 			unsigned int f[8];
@@ -3037,6 +3040,23 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				nact, nover, mxs, h[3 * (size_t) nq], h[3 * (size_t) nq + 1]);
 		fprintf(stderr, "s16 debug: cen %d qb %d flags %u %u %u %u pairs %u buckets-with-pairs %u qc_cap %u\n", (int) cen, c_qb, fl8[0], fl8[1],
 				fl8[2], fl8[3], fl8[4], fl8[5], qc_cap);
+		{
+			float		tmin = 3e38f, tmax = 0.0f;
+			int			ninf = 0;
+
+			for (int q = 0; q < nq; q++)
+			{
+				if (!(th[q].x < 3e38f))
+					ninf++;
+				else
+				{
+					tmin = std::min(tmin, th[q].x);
+					tmax = std::max(tmax, th[q].x);
+				}
+			}
+			fprintf(stderr, "s16 debug: thresholds after the batch: min %g max %g, %d infinite; hook %s, seeds by sublist %d\n", tmin, tmax, ninf,
+					g_thr_hook ? "set" : "none", (int) seed_by_sublist);
+		}
 	}
 	if (over)
 	{

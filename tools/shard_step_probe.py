@@ -76,8 +76,44 @@ def main():
         full.select_clusters_device(q, probes, nprobe)
         sync()
         t_sel = timed(lambda: ix.select_clusters_device(q[lo:hi], buf.probes_mine[:hi - lo], nprobe), sync)
+        # The ranks of a real run exchange the queries' first thresholds between seeds and sweep (minimum over the ranks:
+        # ndbhip_comm_allreduce_min_f32).  Emulated here: every rank's shard is searched once with a hook that records
+        # its thresholds, then the heaviest shard is timed with a hook that hands it the minimum over all of them.
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+        thr = torch.full((world, 2 * nq), float("inf"), dtype=torch.float32, device=dev)
+        state = {"w": 0}
+
+        def record(ptr, cnt_):
+            lib().ndbhip_synchronize()      # (the library's stream is its own: the seeds must have run)
+            hip.hipMemcpy(C.c_void_p(thr[state["w"]].data_ptr()), C.c_void_p(ptr), C.c_size_t(cnt_ * 4), 3)
+            return 0
+        rec_cb = HOOK(record)
+        shards = []
+        for w in range(world):
+            if how == "slices":
+                sh = ix if w == worst else full.shard_slices(slo[w], sln[w], stl[w])
+            else:
+                sh = ix if w == worst else full.shard((owner == w).astype(np.uint8))
+            state["w"] = w
+            lib().ndbhip_internal_set_thr_hook(rec_cb)
+            sh.search_partial_probes_device(q, probes, buf.cand, buf.ncand, buf.total, 1, nprobe, k, 0)
+            sync()
+            lib().ndbhip_internal_set_thr_hook(None)
+            if w != worst:
+                sh.close()
+        thr_min = thr.min(dim=0).values.contiguous()
+
+        def give(ptr, cnt_):
+            lib().ndbhip_synchronize()
+            hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(thr_min.data_ptr()), C.c_size_t(cnt_ * 4), 3)
+            return 0
+        give_cb = HOOK(give)
+        lib().ndbhip_internal_set_thr_hook(give_cb)
         t_scan = timed(lambda: ix.search_partial_probes_device(q, probes, buf.cand, buf.ncand, buf.total, 1, nprobe, k, 0),
                        sync)
+        lib().ndbhip_internal_set_thr_hook(None)
         for w in range(world):
             buf.cand_all[w].copy_(buf.cand)
             buf.ncand_all[w].copy_(buf.ncand)
