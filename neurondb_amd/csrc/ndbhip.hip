@@ -1510,6 +1510,7 @@ struct ndbhip_ivf
 	uint32_t   *w_pslot = nullptr;	size_t w_pslot_n = 0;	/* [3][qc_cap] per pair slot: query, first candidate position, visible rows */
 	float	   *w_amat = nullptr;	size_t w_amat_n = 0;	/* [nq][astride] the sweep's |q - centroid|^2 (k_cent_select) */
 	uint8_t    *w_cfull = nullptr;	size_t w_cfull_n = 0;	/* [nq] queries k_cent_select left to k_probe_select */
+	int			qc_mult = 4;			/* rows of the pair planes / (queries x probes) */
 	float		s16c_density = -1.0f;	/* pairs per bucket that had any, previous batch (-1: none yet) */
 	/* sublists (ndbhip_screen16.h): the planes' own grouping of the rows of long lists */
 	bool		s16_sub = false;
@@ -2780,10 +2781,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4) ? g_s16c_qb :
 		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : 4) : (ix->s16_sub ? 1 : 4));
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
-	/* rows of the pair planes: every pair there can be, up to 16 x (queries x probes) (at least 65 536) — sublists
+	/* rows of the pair planes: every pair there can be, up to qc_mult x (queries x probes) (at least 65 536; qc_mult starts at 4 and doubles, up to 16, after a batch that did not fit) — sublists
 	 * multiply the pairs of a probed list, the exclusion bounds remove most again; a batch with more than that goes to
 	 * the older path (flags[2]) */
-	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, std::max<size_t>((size_t) 16 * nq * npr + 1024, (size_t) 1 << 16)),
+	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, std::max<size_t>((size_t) ix->qc_mult * nq * npr + 1024, (size_t) 1 << 16)),
 														   0x7FFFFFFFu);
 	const uint32_t qcrowbytes = (uint32_t) dimp * 2u;
 
@@ -3007,7 +3008,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			if (round == 0)
 				memcpy(fl8, f, sizeof(fl8));
 			if (f[2])
-				break;			/* more pairs than the pair planes hold: nothing was swept, the older path serves the batch */
+			{
+				/* more pairs than the pair planes hold: nothing was swept, the older path serves the batch — and
+				 * the next batch gets planes twice as large */
+				if (ix->qc_mult < 16)
+					ix->qc_mult *= 2;
+				break;
+			}
 		}
 		if (!over)
 			break;
