@@ -153,7 +153,7 @@ def main():
         from neurondb_amd.dist import init_library_comm
         try:
             init_library_comm(device=dev)
-        except Exception as e:              # (a collective: it fails on every rank or on none)
+        except Exception as e:              # (init_library_comm agrees on the outcome: every rank raises or none does)
             comm_error = f"{type(e).__name__}: {e}"
             args.dist_impl = "torch"        # the same exchange through torch.distributed (neurondb_amd/dist.py)
 

@@ -67,12 +67,17 @@ typedef struct ndb_index_scan
 int			ndb_am_set_guc(const char *name, int value);
 int			ndb_am_get_guc(const char *name, int *value);
 /* GUC neurondb.device_service (a string: the shared-memory name of the device-owner process, include/ndb_service.h;
- * NULL or "" detaches).  While set, an ivf scan opened with index == NULL is answered by that process: the
- * backend itself never initialises HIP and holds no mirror.  Connect failure = NDBHIP_ERR_NODEVICE. */
+ * NULL or "" detaches).  While set, an ivf scan opened with ndb_ivfbeginscan_service (or index == NULL) is
+ * answered by that process: the backend itself never initialises HIP and holds no mirror.  Connect failure =
+ * NDBHIP_ERR_NODEVICE.  hnsw scans are not served: ndb_hnswbeginscan(NULL, ..) fails. */
 int			ndb_am_use_service(const char *name);
 
 /* ivf: src/index/ivf_am.c:1412-1437 / 1439-1545 / 1911-2027 / 2029-2048 */
 ndb_index_scan *ndb_ivfbeginscan(ndbhip_ivf *index, int nkeys, int norderbys);
+/* a scan the device-owner process answers (ndb_am_use_service), on the index with key `index_key` at generation
+ * `index_version` (include/ndb_service.h: ndb_gen_get): a service holding another index or another generation is
+ * NDBHIP_ERR_NODEVICE from ndb_ivfgettuple.  ndb_ivfbeginscan(NULL, ..) is the unkeyed form (key 0, generation 0). */
+ndb_index_scan *ndb_ivfbeginscan_service(uint64_t index_key, uint64_t index_version, int nkeys, int norderbys);
 int			ndb_ivfrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys,
 						  const ndb_scan_key *orderbys, int norderbys);
 /* 1 = a tuple is in xs_heaptid / xs_orderbyval, 0 = no more tuples, < 0 = the reference's ERROR */

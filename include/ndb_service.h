@@ -5,7 +5,7 @@
  * (src/index/ivf_am.c:1439-1545; the work happens in the first amgettuple, :1911-2027), and a backend is a
  * single-threaded process.  Called from each backend on its own, the device path costs ~0.2 ms per query
  * (~5 k queries/s per backend) and every backend would upload its own copy of the index (3 GB at 1M x 768).
- * The batched kernels need >= 128 queries per launch to run at their rate.  So the backends do not touch the
+ * The batched kernels need tens to hundreds of queries per launch to run at their rate.  So the backends do not touch the
  * device: they hand their query to a shared-memory ring, ONE process owns the device and the mirror, coalesces
  * whatever is waiting into one launch of ndbhip_ivf_search and writes every backend's rows back.  This is the
  * reference's own lazy, per-process GPU initialisation contract (src/gpu/common/gpu_core.c:240-310:
@@ -61,6 +61,16 @@ int			ndb_service_complete(ndb_service *s, int n, const int *slot_ids, const uin
  * max_batches launches (0 = unbounded).  Needs ndbhip_init() in this process. */
 int			ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_us, int64_t max_batches,
 								  ndb_service_stats *stats);
+/* Which index the owner's mirror is (key: its relfilenode / OID; 0 = unkeyed, for a single-index deployment and
+ * the tests) and at which generation (ndb_gen_get at the time the pages were read), plus the index's own nprobe
+ * (reloptions / meta page, ivf_am.c:1487-1513) for backends in neurondb.ref_compat.  A request whose key or
+ * generation differs is refused with NDBHIP_ERR_NODEVICE — the backend runs its CPU scan — and a newer generation
+ * makes ndb_service_serve_ivf return so that the owner can reload: while (!stopped) { load; publish; serve; }. */
+int			ndb_service_publish(ndb_service *s, uint64_t index_key, uint64_t index_version, int meta_nprobe);
+int			ndb_service_reload_wanted(const ndb_service *s, uint64_t *version);	/* 1: a backend has seen *version > the published one */
+/* slots of backends that died mid-request go back to FREE (the poll loop does this once a second by itself);
+ * returns how many */
+int			ndb_service_reclaim(ndb_service *s);
 int			ndb_service_stop(ndb_service *s);		/* callable from another thread / a signal handler of the owner */
 int			ndb_service_stopped(const ndb_service *s);
 
@@ -76,6 +86,26 @@ int			ndb_client_submit(ndb_client *c, const float *query, int strategy, int npr
 int			ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *count, int timeout_ms);
 int			ndb_client_search(ndb_client *c, const float *query, int strategy, int nprobe, int k, int64_t max_candidates,
 							  uint8_t *tids6, float *dist, int *count, int timeout_ms);
+/* the same for a scan on index `index_key` at generation `index_version` (the plain forms above are key 0,
+ * generation 0 and are only answered by an owner that published exactly that) */
+int			ndb_client_submit_index(ndb_client *c, uint64_t index_key, uint64_t index_version, const float *query,
+									int strategy, int nprobe, int k, int64_t max_candidates, int *ticket);
+int			ndb_client_search_index(ndb_client *c, uint64_t index_key, uint64_t index_version, const float *query,
+									int strategy, int nprobe, int k, int64_t max_candidates, uint8_t *tids6, float *dist,
+									int *count, int timeout_ms);
+int			ndb_client_index(const ndb_client *c, uint64_t *index_key, uint64_t *index_version);	/* what the owner serves */
+int			ndb_client_meta_nprobe(const ndb_client *c);	/* the served index's own nprobe (0: not published) */
+
+/* ---- index generations: the version stamp of every device mirror (backends' own and the owner's) ----
+ * A shared table (POSIX shm `name`, created by whoever attaches first; ncells a power of two) of one counter per
+ * index.  Every aminsert / ambulkdelete bumps its index's counter after changing the pages; a scan compares the
+ * counter with the generation its mirror was loaded at.  Counters only grow, so a stamp never comes back (the
+ * reference's meta->insertedVectors does: +1 by ivfinsert, -n by ivfbulkdelete, ivf_am.c:1346). */
+typedef struct ndb_gen ndb_gen;
+int			ndb_gen_attach(const char *name, int ncells, ndb_gen **out);
+int			ndb_gen_detach(ndb_gen *g, const char *unlink_name);	/* unlink_name != NULL also removes the segment */
+uint64_t	ndb_gen_get(ndb_gen *g, uint64_t key);		/* >= 1; 0 for key 0 / NULL */
+uint64_t	ndb_gen_bump(ndb_gen *g, uint64_t key);	/* the new generation; 0 = table full */
 
 #ifdef __cplusplus
 }

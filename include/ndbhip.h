@@ -144,6 +144,8 @@ int			ndbhip_set_scan_mode(int mode);
  *                             0: the two-plane sweep over the rows as they are
  *   "screen16c_qb"      0     (query, list) pairs per tile of the centred sweep / 32: 4 | 1, 0 = chosen from the previous batch's pairs per list
  *   "screen16c_seeds"   0     rows per query whose upper bounds make its first threshold: 32 | 64, 0 = 32 for k <= 20, else 64
+ *   "screen16_slack"    1     the centred planes keep spare 32-row blocks per bucket and take appends in place (0: every append lays them out again)
+ *   "screen_min_nq"     32    batches of at least this many queries take the screened (matrix-core) scan; smaller ones the exact grouped scan
  *   "screen16c_nbuf"    0     ring depth of the centred sweep: 2 | 3, 0 = the tile geometry's default
  *   "build_screen16"    1     build / ndbhip_ivf_assign_device (>= 4096 rows): the assignment is screened on the matrix cores (0: exact kernels)
  *   "block_cache"       1     keep up to 4 freed packed-row blocks (>= 64 MiB) for the next build (0: release them now, stop caching)

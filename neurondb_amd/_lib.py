@@ -129,6 +129,7 @@ def lib():
         pass
     L = C.CDLL(_LIB)
     vp, i, i64, f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    u64 = C.c_uint64
     sig = {
         "ndbhip_abi_version": (i, []),
         "ndbhip_device_count": (i, []),
@@ -191,6 +192,7 @@ def lib():
         "ndbhip_kmeans_device": (i, [vp, i, i, i, i, f, vp, vp, vp, C.POINTER(i), C.POINTER(f)]),
         "ndbhip_ivf_build_sharded": (i, [vp, vp, vp, i64, i, vp, vp]),
         "ndbhip_comm_alltoallv": (i, [vp, vp, vp, vp]),
+        "ndbhip_comm_allreduce_min_f32": (i, [vp, C.c_size_t]),
         "ndbhip_ivf_assign_device": (i, [vp, i, i, vp, i64, vp]),
         "ndbhip_ivf_build_device": (i, [vp, vp, vp, i64, i, C.POINTER(i)]),
         "ndbhip_ivf_prepare": (i, [vp, i]),
@@ -243,6 +245,18 @@ def lib():
         "ndb_client_submit": (i, [vp, vp, i, i, i, i64, C.POINTER(i)]),
         "ndb_client_wait": (i, [vp, i, vp, vp, C.POINTER(i), i]),
         "ndb_client_search": (i, [vp, vp, i, i, i, i64, vp, vp, C.POINTER(i), i]),
+        "ndb_client_submit_index": (i, [vp, u64, u64, vp, i, i, i, i64, C.POINTER(i)]),
+        "ndb_client_search_index": (i, [vp, u64, u64, vp, i, i, i, i64, vp, vp, C.POINTER(i), i]),
+        "ndb_client_index": (i, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "ndb_client_meta_nprobe": (i, [vp]),
+        "ndb_service_publish": (i, [vp, u64, u64, i]),
+        "ndb_service_reload_wanted": (i, [vp, C.POINTER(u64)]),
+        "ndb_service_reclaim": (i, [vp]),
+        "ndb_gen_attach": (i, [C.c_char_p, i, C.POINTER(vp)]),
+        "ndb_gen_detach": (i, [vp, C.c_char_p]),
+        "ndb_gen_get": (u64, [vp, u64]),
+        "ndb_gen_bump": (u64, [vp, u64]),
+        "ndb_ivfbeginscan_service": (C.POINTER(NdbIndexScan), [u64, u64, i, i]),
         "ndb_am_use_service": (i, [C.c_char_p]),
         "ndb_am_set_guc": (i, [C.c_char_p, i]),
         "ndb_am_get_guc": (i, [C.c_char_p, C.POINTER(i)]),

@@ -96,12 +96,14 @@ struct ScanOpaque
 	std::vector<float> queryVector;
 	std::vector<uint8_t> results;			/* heapPtrs, 6 bytes each */
 	std::vector<float> distances;
+	uint64_t	serviceKey = 0;				/* a scan answered by the device-owner process: which index it is on, */
+	uint64_t	serviceVersion = 0;			/* and the generation the backend read for it (include/ndb_service.h) */
 };
 
 static ndb_index_scan *
-begin_scan(void *index, int nkeys, int norderbys)
+begin_scan(void *index, int nkeys, int norderbys, bool service_ok)
 {
-	if (!index && !am_client)	/* (a NULL index is the device-owner process's: ndb_am_use_service) */
+	if (!index && !(am_client && service_ok))	/* (a NULL ivf index is the device-owner process's: ndb_am_use_service) */
 	{
 		ndbhip_pages_fail(NDBHIP_ERR_INVALID, "index is NULL");
 		return nullptr;
@@ -157,7 +159,24 @@ end_scan(ndb_index_scan *scan)
 extern "C" ndb_index_scan *
 ndb_ivfbeginscan(ndbhip_ivf *index, int nkeys, int norderbys)
 {
-	return begin_scan(index, nkeys, norderbys);
+	return begin_scan(index, nkeys, norderbys, true);
+}
+
+/* the same for a backend without a mirror: the scan is on index `index_key` (relfilenode / OID) whose generation
+ * the backend read as `index_version` (ndb_gen_get); the device-owner process answers only if that is the index
+ * and the generation it holds, otherwise ndb_ivfgettuple returns NDBHIP_ERR_NODEVICE and the backend runs its
+ * CPU scan */
+extern "C" ndb_index_scan *
+ndb_ivfbeginscan_service(uint64_t index_key, uint64_t index_version, int nkeys, int norderbys)
+{
+	ndb_index_scan *scan = begin_scan(nullptr, nkeys, norderbys, true);
+
+	if (scan)
+	{
+		((ScanOpaque *) scan->opaque)->serviceKey = index_key;
+		((ScanOpaque *) scan->opaque)->serviceVersion = index_version;
+	}
+	return scan;
 }
 
 /* ivfrescan: src/index/ivf_am.c:1439-1545 */
@@ -185,7 +204,15 @@ ndb_ivfrescan(ndb_index_scan *scan, const ndb_scan_key *keys, int nkeys, const n
 	{
 		int			np = IVF_DEFAULT_NPROBE;
 
-		(void) ndbhip_ivf_get_nprobe((ndbhip_ivf *) scan->indexRelation, &np);	/* reloptions / meta->nprobe */
+		if (!scan->indexRelation && am_client)
+		{
+			const int	snp = ndb_client_meta_nprobe(am_client);	/* the owner published its index's reloptions / meta->nprobe */
+
+			if (snp > 0)
+				np = snp;
+		}
+		else
+			(void) ndbhip_ivf_get_nprobe((ndbhip_ivf *) scan->indexRelation, &np);	/* reloptions / meta->nprobe */
 		so->strategy = 1;
 		so->nprobe = np > 0 ? np : IVF_DEFAULT_NPROBE;	/* :1512-1513 */
 		so->k = IVF_DEFAULT_K;
@@ -223,9 +250,9 @@ ndb_ivfgettuple(ndb_index_scan *scan, int direction)
 			return 0;
 		so->results.assign((size_t) so->k * 6, 0);
 		so->distances.assign((size_t) so->k, 0.0f);
-		const int	rc = ndb_client_search(am_client, so->queryVector.data(), so->strategy, so->nprobe, so->k,
-										   guc_ref_compat ? (int64_t) so->k * 10 : 0, so->results.data(),
-										   so->distances.data(), &count, 30000);
+		const int	rc = ndb_client_search_index(am_client, so->serviceKey, so->serviceVersion, so->queryVector.data(),
+												 so->strategy, so->nprobe, so->k, guc_ref_compat ? (int64_t) so->k * 10 : 0,
+												 so->results.data(), so->distances.data(), &count, 30000);
 
 		if (rc)
 			return rc;			/* NDBHIP_ERR_NODEVICE: the caller applies neurondb.compute_mode (CPU scan or ERROR) */
@@ -286,7 +313,7 @@ ndb_ivfendscan(ndb_index_scan *scan)
 extern "C" ndb_index_scan *
 ndb_hnswbeginscan(ndbhip_hnsw *index, int nkeys, int norderbys)
 {
-	return begin_scan(index, nkeys, norderbys);
+	return begin_scan(index, nkeys, norderbys, false);	/* (the device service answers ivf scans only) */
 }
 
 /* hnswrescan: src/index/hnsw_am.c:904-976 */

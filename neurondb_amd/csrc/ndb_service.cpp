@@ -3,6 +3,7 @@
  * (clients) and the one process that owns the device and the index mirror.
  */
 #include <errno.h>
+#include <signal.h>
 #include <fcntl.h>
 #include <linux/futex.h>
 #include <stdio.h>
@@ -37,7 +38,27 @@ struct Header
 	std::atomic<uint32_t> stop;
 	std::atomic<uint32_t> cursor;		/* where clients start looking for a free slot */
 	std::atomic<uint64_t> seq;			/* arrival order */
+	/* which index the owner's mirror is, and at which generation of it (ndb_service_publish); a request for
+	 * another key or a newer generation is refused with NDBHIP_ERR_NODEVICE instead of being answered from the
+	 * wrong rows */
+	std::atomic<uint64_t> index_key, index_version;
+	std::atomic<uint64_t> wanted_version;	/* newest generation a backend has asked for (> index_version: reload) */
+	std::atomic<int32_t> meta_nprobe;		/* the served index's reloptions / meta-page nprobe (ivf_am.c:1487-1513) */
+	std::atomic<int32_t> owner_pid;
 };
+static_assert(sizeof(Header) <= 4096, "the header has one page");
+
+bool
+pid_gone(int32_t pid)
+{
+	return pid > 0 && kill((pid_t) pid, 0) != 0 && errno == ESRCH;
+}
+
+uint64_t
+now_ms()
+{
+	return (uint64_t) std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct Slot
 {
@@ -46,6 +67,10 @@ struct Slot
 	int32_t		strategy, nprobe, k, count;
 	int64_t		max_candidates;
 	uint64_t	seq;
+	uint64_t	index_key, index_version;	/* what the backend's scan is on (0, 0: whatever the owner serves — only
+											 * accepted while the owner itself publishes key 0) */
+	int32_t		client_pid;					/* so that the owner can take back the slot of a backend that died */
+	uint64_t	t_ms;						/* when the slot was claimed / finished (steady clock) */
 	/* followed by: float query[dim]; float dist[max_k]; uint8_t tids6[max_k][6] */
 };
 
@@ -127,6 +152,8 @@ ndb_service_create(const char *name, int dim, int max_k, int nslots, ndb_service
 	s->m.h->max_k = (uint32_t) max_k;
 	s->m.h->nslots = (uint32_t) nslots;
 	s->m.h->slot_bytes = sb;
+	s->m.h->owner_pid.store((int32_t) getpid());
+	s->m.h->meta_nprobe.store(0);
 	s->m.h->magic.store(MAGIC, std::memory_order_release);
 	*out = s;
 	return NDBHIP_OK;
@@ -163,6 +190,63 @@ ndb_service_stopped(const ndb_service *s)
 }
 
 extern "C" int
+ndb_service_publish(ndb_service *s, uint64_t index_key, uint64_t index_version, int meta_nprobe)
+{
+	if (!s)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "service is NULL");
+	Header	   *h = s->m.h;
+
+	h->meta_nprobe.store(meta_nprobe);
+	h->index_key.store(index_key, std::memory_order_release);
+	h->index_version.store(index_version, std::memory_order_release);
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_service_reload_wanted(const ndb_service *s, uint64_t *version)
+{
+	if (!s)
+		return 0;
+	const uint64_t w = s->m.h->wanted_version.load(std::memory_order_acquire);
+
+	if (version)
+		*version = w;
+	return w > s->m.h->index_version.load(std::memory_order_acquire) ? 1 : 0;
+}
+
+/* Slots whose backend is gone (SIGKILLed between claim and read, or gave up on a RUNNING ticket and exited):
+ * CLAIMED / DONE slots of a dead pid, and DONE slots nobody read for a minute, go back to FREE.  Owner only. */
+static int
+reclaim_slots(ndb_service *s)
+{
+	Header	   *h = s->m.h;
+	const uint64_t t = now_ms();
+	int			n = 0;
+
+	for (uint32_t i = 0; i < h->nslots; i++)
+	{
+		Slot	   *sl = s->m.slot(i);
+		uint32_t	st = sl->state.load(std::memory_order_acquire);
+
+		if (st != S_CLAIMED && st != S_DONE && st != S_READY)
+			continue;
+		if (!(pid_gone(sl->client_pid) || (st == S_DONE && t - sl->t_ms > 60000)))
+			continue;
+		if (sl->state.compare_exchange_strong(st, S_FREE, std::memory_order_acq_rel))
+			n++;
+	}
+	return n;
+}
+
+extern "C" int
+ndb_service_reclaim(ndb_service *s)
+{
+	if (!s)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "service is NULL");
+	return reclaim_slots(s);
+}
+
+extern "C" int
 ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int *slot_ids, float *queries,
 				 int *strategy, int *nprobe, int *k, int64_t *max_candidates)
 {
@@ -176,12 +260,48 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 	int			n = 0;
 	bool		have_key = false;
 	auto		last_gain = t0;
+	static thread_local uint64_t last_reclaim = 0;
 
+	if (now_ms() - last_reclaim > 1000)
+	{
+		last_reclaim = now_ms();
+		(void) reclaim_slots(s);
+	}
 	for (;;)
 	{
 		if (h->stop.load(std::memory_order_acquire) && n == 0)
 			return 0;
 		const uint32_t seen = h->submitted.load(std::memory_order_acquire);
+		const uint64_t skey = h->index_key.load(std::memory_order_acquire), sver = h->index_version.load(std::memory_order_acquire);
+
+		/* requests on another index, or on a generation of this one the mirror does not hold: refused now
+		 * (the backend runs its CPU scan, as after a failed ndb_gpu_init_if_needed), never answered from the
+		 * wrong rows */
+		for (uint32_t i = 0; i < h->nslots; i++)
+		{
+			Slot	   *sl = s->m.slot(i);
+			uint32_t	st = S_READY;
+
+			if (sl->state.load(std::memory_order_acquire) != S_READY || (sl->index_key == skey && sl->index_version == sver))
+				continue;
+			const uint64_t want = sl->index_version;
+			const bool	same_key = sl->index_key == skey;
+
+			if (!sl->state.compare_exchange_strong(st, S_RUNNING, std::memory_order_acq_rel))
+				continue;
+			if (same_key)
+			{
+				uint64_t	w = h->wanted_version.load();
+
+				while (want > w && !h->wanted_version.compare_exchange_weak(w, want))
+					;
+			}
+			sl->status = NDBHIP_ERR_NODEVICE;
+			sl->count = 0;
+			sl->t_ms = now_ms();
+			sl->state.store(S_DONE, std::memory_order_release);
+			futex(&sl->state, FUTEX_WAKE, 1 << 30, nullptr);
+		}
 		/* oldest first: a backend must not starve behind newer arrivals with another parameter set */
 		if (!have_key)
 		{
@@ -226,6 +346,8 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 			}
 		if (gained)
 			last_gain = std::chrono::steady_clock::now();
+		else if (n == 0)
+			have_key = false;	/* the slot the parameters came from was withdrawn: look again */
 		if (n >= max_batch)
 			return n;
 		if (n > 0)
@@ -270,6 +392,7 @@ ndb_service_complete(ndb_service *s, int n, const int *slot_ids, const uint8_t *
 			memcpy(s->m.dist(sl), dist + (size_t) i * k, (size_t) c * 4);
 			memcpy(s->m.tids(sl), tids6 + (size_t) i * k * 6, (size_t) c * 6);
 		}
+		sl->t_ms = now_ms();
 		sl->state.store(S_DONE, std::memory_order_release);
 		futex(&sl->state, FUTEX_WAKE, 1 << 30, nullptr);
 	}
@@ -294,6 +417,8 @@ ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_
 
 	while (!h->stop.load(std::memory_order_acquire) && (max_batches <= 0 || (int64_t) st.batches < max_batches))
 	{
+		if (h->wanted_version.load(std::memory_order_acquire) > h->index_version.load(std::memory_order_acquire))
+			break;				/* the index has moved on: the owner reloads its mirror, publishes, and serves again */
 		int			strategy, nprobe, k;
 		int64_t		cap;
 		const int	n = ndb_service_poll(s, max_batch, 50 * 1000, linger_us, ids.data(), q.data(), &strategy, &nprobe, &k, &cap);
@@ -379,6 +504,24 @@ ndb_client_dim(const ndb_client *c)
 }
 
 extern "C" int
+ndb_client_meta_nprobe(const ndb_client *c)
+{
+	return c ? (int) c->m.h->meta_nprobe.load() : NDBHIP_ERR_INVALID;
+}
+
+extern "C" int
+ndb_client_index(const ndb_client *c, uint64_t *index_key, uint64_t *index_version)
+{
+	if (!c)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "client is NULL");
+	if (index_key)
+		*index_key = c->m.h->index_key.load(std::memory_order_acquire);
+	if (index_version)
+		*index_version = c->m.h->index_version.load(std::memory_order_acquire);
+	return NDBHIP_OK;
+}
+
+extern "C" int
 ndb_client_stop_service(ndb_client *c)
 {
 	if (!c)
@@ -392,12 +535,34 @@ ndb_client_stop_service(ndb_client *c)
 extern "C" int
 ndb_client_submit(ndb_client *c, const float *query, int strategy, int nprobe, int k, int64_t max_candidates, int *ticket)
 {
+	return ndb_client_submit_index(c, 0, 0, query, strategy, nprobe, k, max_candidates, ticket);
+}
+
+extern "C" int
+ndb_client_submit_index(ndb_client *c, uint64_t index_key, uint64_t index_version, const float *query, int strategy,
+						int nprobe, int k, int64_t max_candidates, int *ticket)
+{
 	if (!c || !query || !ticket)
 		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad submit arguments");
 	Header	   *h = c->m.h;
 
-	if (h->magic.load(std::memory_order_acquire) != MAGIC || h->stop.load())
+	if (h->magic.load(std::memory_order_acquire) != MAGIC || h->stop.load() || pid_gone(h->owner_pid.load()))
 		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service is gone");
+	if (h->index_key.load(std::memory_order_acquire) != index_key)
+		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service holds another index (key %llu, this scan is on %llu)",
+									(unsigned long long) h->index_key.load(), (unsigned long long) index_key);
+	if (h->index_version.load(std::memory_order_acquire) != index_version)
+	{
+		/* tell the owner (its serve loop returns for a reload); this scan runs on the CPU */
+		uint64_t	w = h->wanted_version.load();
+
+		while (index_version > w && !h->wanted_version.compare_exchange_weak(w, index_version))
+			;
+		h->submitted.fetch_add(1, std::memory_order_release);
+		futex(&h->submitted, FUTEX_WAKE, 1, nullptr);
+		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service holds generation %llu of the index, this scan needs %llu",
+									(unsigned long long) h->index_version.load(), (unsigned long long) index_version);
+	}
 	if (k < 1 || k > (int) h->max_k)
 		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "k %d beyond the service's max_k %u", k, h->max_k);
 	/* a free slot: start at the shared cursor, bounded number of rounds */
@@ -419,6 +584,10 @@ ndb_client_submit(ndb_client *c, const float *query, int strategy, int nprobe, i
 			sl->nprobe = nprobe;
 			sl->k = k;
 			sl->max_candidates = max_candidates;
+			sl->index_key = index_key;
+			sl->index_version = index_version;
+			sl->client_pid = (int32_t) getpid();
+			sl->t_ms = now_ms();
 			sl->status = 0;
 			sl->count = 0;
 			sl->seq = h->seq.fetch_add(1, std::memory_order_relaxed);
@@ -464,6 +633,14 @@ ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *cou
 			if (timeout_ms >= 0 && waited >= 4 * (int64_t) timeout_ms + 1000)
 				return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service took the request and never finished it");
 		}
+		if ((spins & 63) == 63 && pid_gone(h->owner_pid.load()))
+		{
+			/* the owner was killed: nobody will finish (or reclaim) this slot; a new owner starts from a fresh segment */
+			uint32_t	exp = st;
+
+			(void) sl->state.compare_exchange_strong(exp, S_FREE);
+			return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service's process is gone");
+		}
 		if (spins < 200)
 			continue;			/* a batch returns within a fraction of a millisecond: spin first */
 		struct timespec ts = {0, 2 * 1000 * 1000};
@@ -491,10 +668,194 @@ extern "C" int
 ndb_client_search(ndb_client *c, const float *query, int strategy, int nprobe, int k, int64_t max_candidates,
 				  uint8_t *tids6, float *dist, int *count, int timeout_ms)
 {
+	return ndb_client_search_index(c, 0, 0, query, strategy, nprobe, k, max_candidates, tids6, dist, count, timeout_ms);
+}
+
+extern "C" int
+ndb_client_search_index(ndb_client *c, uint64_t index_key, uint64_t index_version, const float *query, int strategy,
+						int nprobe, int k, int64_t max_candidates, uint8_t *tids6, float *dist, int *count, int timeout_ms)
+{
 	int			ticket = -1;
-	const int	rc = ndb_client_submit(c, query, strategy, nprobe, k, max_candidates, &ticket);
+	const int	rc = ndb_client_submit_index(c, index_key, index_version, query, strategy, nprobe, k, max_candidates, &ticket);
 
 	if (rc)
 		return rc;
 	return ndb_client_wait(c, ticket, tids6, dist, count, timeout_ms);
+}
+
+/* ------------------------------------------------------------------ */
+/* index generations                                                   */
+/* ------------------------------------------------------------------ */
+/*
+ * A counter per index that every aminsert / ambulkdelete of every backend bumps and every scan reads: the
+ * version stamp of the device mirrors.  It never repeats (the reference's meta->insertedVectors goes down again
+ * in ivfbulkdelete, ivf_am.c:1346, and its pages carry no LSN — every change is MarkBufferDirty without WAL,
+ * ivf_am.c:1137-1156 — so nothing on the pages can serve).  A POSIX shm segment with an open-addressing table of
+ * (key, generation) pairs; lock-free: a key is claimed by CAS on an empty cell and never removed.
+ */
+namespace
+{
+const uint32_t GEN_MAGIC = 0x4E444753u;	/* "NDGS" */
+
+struct GenHeader
+{
+	std::atomic<uint32_t> magic;
+	uint32_t	ncells;
+};
+
+struct GenCell
+{
+	std::atomic<uint64_t> key;		/* 0 = empty */
+	std::atomic<uint64_t> gen;
+};
+}
+
+struct ndb_gen
+{
+	void	   *base = nullptr;
+	size_t		bytes = 0;
+	GenHeader  *h = nullptr;
+	GenCell    *cells = nullptr;
+};
+
+extern "C" int
+ndb_gen_attach(const char *name, int ncells, ndb_gen **out)
+{
+	if (!name || name[0] != '/' || !out || ncells < 16 || ncells > (1 << 24) || (ncells & (ncells - 1)))
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad generation-table arguments (name \"/...\", ncells a power of two >= 16)");
+	const size_t bytes = 4096 + sizeof(GenCell) * (size_t) ncells;
+	bool		creator = true;
+	int			fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+
+	if (fd < 0 && errno == EEXIST)
+	{
+		creator = false;
+		fd = shm_open(name, O_RDWR, 0600);
+	}
+	if (fd < 0)
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "shm_open(%s): %s", name, strerror(errno));
+	if (creator && ftruncate(fd, (off_t) bytes) != 0)
+	{
+		close(fd);
+		(void) shm_unlink(name);
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "ftruncate(%s): %s", name, strerror(errno));
+	}
+	struct stat st;
+
+	/* a late attacher may see the segment before the creator has sized it */
+	for (int tries = 0; tries < 2000; tries++)
+	{
+		if (fstat(fd, &st) == 0 && (size_t) st.st_size >= 4096 + sizeof(GenCell) * 16)
+			break;
+		struct timespec ts = {0, 1000 * 1000};
+
+		nanosleep(&ts, nullptr);
+	}
+	if (fstat(fd, &st) != 0 || (size_t) st.st_size < 4096 + sizeof(GenCell) * 16)
+	{
+		close(fd);
+		return ndbhip_internal_fail(NDBHIP_ERR_STATE, "generation table %s was never sized", name);
+	}
+	void	   *p = mmap(nullptr, (size_t) st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+
+	close(fd);
+	if (p == MAP_FAILED)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "mmap(%s): %s", name, strerror(errno));
+	GenHeader  *h = (GenHeader *) p;
+
+	if (creator)
+	{
+		h->ncells = (uint32_t) ncells;	/* (the segment is zero-filled: every cell empty) */
+		h->magic.store(GEN_MAGIC, std::memory_order_release);
+	}
+	else
+	{
+		for (int tries = 0; tries < 2000 && h->magic.load(std::memory_order_acquire) != GEN_MAGIC; tries++)
+		{
+			struct timespec ts = {0, 1000 * 1000};
+
+			nanosleep(&ts, nullptr);
+		}
+		if (h->magic.load(std::memory_order_acquire) != GEN_MAGIC ||
+			4096 + sizeof(GenCell) * (size_t) h->ncells > (size_t) st.st_size)
+		{
+			munmap(p, (size_t) st.st_size);
+			return ndbhip_internal_fail(NDBHIP_ERR_STATE, "generation table %s is not initialised", name);
+		}
+	}
+	ndb_gen    *g = new (std::nothrow) ndb_gen();
+
+	if (!g)
+	{
+		munmap(p, (size_t) st.st_size);
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	}
+	g->base = p;
+	g->bytes = (size_t) st.st_size;
+	g->h = h;
+	g->cells = (GenCell *) ((unsigned char *) p + 4096);
+	*out = g;
+	return NDBHIP_OK;
+}
+
+extern "C" int
+ndb_gen_detach(ndb_gen *g, const char *unlink_name)
+{
+	if (g)
+	{
+		munmap(g->base, g->bytes);
+		delete g;
+	}
+	if (unlink_name)
+		(void) shm_unlink(unlink_name);
+	return NDBHIP_OK;
+}
+
+static GenCell *
+gen_cell(ndb_gen *g, uint64_t key, bool create)
+{
+	const uint32_t mask = g->h->ncells - 1;
+	uint64_t	x = key * 0x9E3779B97F4A7C15ull;
+	uint32_t	i = (uint32_t) (x >> 32) & mask;
+
+	for (uint32_t probe = 0; probe <= mask; probe++, i = (i + 1) & mask)
+	{
+		GenCell    *c = &g->cells[i];
+		uint64_t	k = c->key.load(std::memory_order_acquire);
+
+		if (k == key)
+			return c;
+		if (k == 0)
+		{
+			if (!create)
+				return nullptr;
+			if (c->key.compare_exchange_strong(k, key, std::memory_order_acq_rel) || k == key)
+				return c;
+		}
+	}
+	return nullptr;
+}
+
+/* generation of `key` (an index's relfilenode / OID, != 0); 1 for an index nobody has changed since the table
+ * was created */
+extern "C" uint64_t
+ndb_gen_get(ndb_gen *g, uint64_t key)
+{
+	if (!g || key == 0)
+		return 0;
+	GenCell    *c = gen_cell(g, key, false);
+
+	return c ? c->gen.load(std::memory_order_acquire) + 1 : 1;
+}
+
+/* one more change to `key`: returns the new generation (0: the table is full — callers then treat every scan
+ * as stale, i.e. rebuild their mirror each time) */
+extern "C" uint64_t
+ndb_gen_bump(ndb_gen *g, uint64_t key)
+{
+	if (!g || key == 0)
+		return 0;
+	GenCell    *c = gen_cell(g, key, true);
+
+	return c ? c->gen.fetch_add(1, std::memory_order_acq_rel) + 2 : 0;
 }

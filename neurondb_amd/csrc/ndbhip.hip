@@ -29,7 +29,8 @@ static int	g_scan_mode = 0;
 /* screened L2 scan in auto mode (ndbhip_set_option("screen", 0) turns it off); batches below this many queries keep the
  * exact scan (the two extra passes cost more than they save there) */
 static bool g_screen_auto = true;
-#define NDB_SCREEN_MIN_NQ 128
+#define NDB_SCREEN_MIN_NQ 32
+static int	g_screen_min_nq = NDB_SCREEN_MIN_NQ;	/* batches of at least this many queries take the screened path ("screen_min_nq") */
 /* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32): the grouped path costs 0.38 ms for 1..16
  * queries, the per-query path 0.18 / 0.24 / 0.35 / 0.50 ms for 1 / 2 / 4 / 7 */
 #define NDB_GROUPED_MIN_NQ 5
@@ -736,19 +737,22 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
 			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv, uint32_t rt,
 			   int exact_runs = 0 /* runs of exactly nitems / 8 items (a list may straddle two runs): for a sweep whose blocks
-								   * walk their XCD's run at a fixed stride and cannot help another run out */ )
+								   * walk their XCD's run at a fixed stride and cannot help another run out */,
+			   unsigned long long *__restrict__ swept = nullptr /* statistics: += sum of pairs x rows over the lists */ )
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
 	const int	per = (ncent + 1023) / 1024;
 	const int	l0 = t * per, l1 = min(ncent, l0 + per);
 	uint32_t	a = 0, b = 0, c2 = 0;
+	unsigned long long sw = 0;
 
 	for (int L = l0; L < l1; L++)
 	{
 		const uint32_t c = cnt[L];
 		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
 
+		sw += (unsigned long long) c * glob_len[L];
 		a += c;
 		b += ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
 		c2 += ng;
@@ -783,6 +787,19 @@ k_pair_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gl
 		a += c;
 		b += ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
 		c2 += ng;
+	}
+	if (swept)
+	{
+		/* (one wave-level sum, then 16 atomics) */
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) sw, off, 64);
+			const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (sw >> 32), off, 64);
+
+			sw += ((unsigned long long) hi << 32) | lo;
+		}
+		if ((t & 63) == 0 && sw != 0)
+			atomicAdd(swept, sw);
 	}
 	if (t == 1023)
 	{
@@ -2856,9 +2873,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			drop = ix->w_drop;
 			pdist = sub ? ix->w_pdist : nullptr;
 		}
-		if (round == 0)
-			hipLaunchKernelGGL(k_s16_prune_stats, dim3((nq + 255) / 256), dim3(256), 0, g.stream, sub ? (const uint8_t *) nullptr : drop,
-							   lco, (uint32_t) nq, npr, g.d_counters + 5, sub ? 0 : 1);
+		if (round == 0 && !sub)
+			hipLaunchKernelGGL(k_s16_prune_stats, dim3((nq + 255) / 256), dim3(256), 0, g.stream, drop,
+							   lco, (uint32_t) nq, npr, g.d_counters + 5, 1);
 		if (sub)
 		{
 			/* distances of every query to the centres of the regrouped lists (once per batch), then the expansion */
@@ -2900,11 +2917,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, cnt, act, drop);
-		if (sub && round == 0)
-			hipLaunchKernelGGL(k_s16_swept_rows, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) cnt,
-							   (const uint32_t *) ix->d_sub_len, ncs, g.d_counters + 6);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
-						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0);
+						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0,
+						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr);
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -3234,6 +3249,12 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_slack"))
 		g_s16_slack = value != 0;
+	else if (!strcmp(name, "screen_min_nq"))
+	{
+		if (value < 1 || value > 65536)
+			return fail(NDBHIP_ERR_INVALID, "screen_min_nq must be 1 .. 65536");
+		g_screen_min_nq = value;
+	}
 	else if (!strcmp(name, "screen16c_seeds"))
 	{
 		if (value != 0 && value != 32 && value != 64)
@@ -3312,7 +3333,7 @@ ivf_grow_scan_buffers(ndbhip_ivf *ix, int qb, uint32_t stride, int nprobe)
 static bool
 ivf_s16_wanted(const ndbhip_ivf *ix, int nq, int R, int k)
 {
-	return (g_scan_mode == 5 || (g_scan_mode == 0 && g_screen_auto && g_s16_auto && nq >= NDB_SCREEN_MIN_NQ)) &&
+	return (g_scan_mode == 5 || (g_scan_mode == 0 && g_screen_auto && g_s16_auto && nq >= g_screen_min_nq)) &&
 		ivf_s16_eligible(ix, nq, R, k);
 }
 
@@ -3524,7 +3545,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * are screened by the two-tile kernel only (its pass is the plain dot product; the norms come from
 			 * the per-row norms) */
 			const int	scr_coop = g_scr_coop;
-			const bool	want = g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= NDB_SCREEN_MIN_NQ);
+			const bool	want = g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= g_screen_min_nq);
 			const bool	two_tile = scr_coop == 2 && (ix->dim % 16) == 0;
 
 			/* fp16 rows (decoded when the tile is staged), inner product and cosine: the two-tile kernel only */

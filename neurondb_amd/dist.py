@@ -83,15 +83,38 @@ def init_library_comm(group=None, device=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu")
-    ident = torch.zeros(128, dtype=torch.uint8)
+    # Every rank takes the same number of collectives whether or not a step fails: rank 0 always broadcasts (a
+    # status byte in front of the id), and the outcome of ndbhip_comm_init is all-reduced, so that the ranks agree
+    # on success or failure and a caller's fallback runs on all of them or on none.
+    msg = torch.zeros(129, dtype=torch.uint8)
+    err = None
     if rank == 0:
         buf = (C.c_ubyte * 128)()
-        check(lib().ndbhip_comm_unique_id(C.byref(buf)))
-        ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
-    ident = ident.to(dev)
-    dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    raw = bytes(ident.cpu().numpy().tobytes())
-    check(lib().ndbhip_comm_init(C.c_char_p(raw), rank, world))
+        try:
+            check(lib().ndbhip_comm_unique_id(C.byref(buf)))
+            msg[0] = 1
+            msg[1:] = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+        except Exception as e:                                # noqa: BLE001 — reported below, after the broadcast
+            err = e
+    msg = msg.to(dev)
+    dist.broadcast(msg, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    host = msg.cpu()
+    ok = torch.zeros(1, dtype=torch.int32)
+    if int(host[0]) == 1:
+        try:
+            check(lib().ndbhip_comm_init(C.c_char_p(bytes(host[1:].numpy().tobytes())), rank, world))
+            ok[0] = 1
+        except Exception as e:                                # noqa: BLE001
+            err = e
+    ok = ok.to(dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.cpu()[0]) != 1:
+        try:
+            lib().ndbhip_comm_destroy()                       # ranks that did get a communicator give it back
+        except Exception:                                     # noqa: BLE001
+            pass
+        raise RuntimeError(f"the library's communicator could not be created on every rank"
+                           + (f" (this rank: {type(err).__name__}: {err})" if err else " (another rank failed)"))
     return rank, world
 
 

@@ -9,7 +9,9 @@
  *   GUCs            neurondb.ivf_probes / ivf_k / hnsw_ef_search / hnsw_k / ref_compat -> ndb_am_set_guc
  *                   neurondb.device_service (string)                                   -> ndb_am_use_service
  *   lazy init       ndb_hip_ready(): the contract of ndb_gpu_init_if_needed (src/gpu/common/gpu_core.c:240-310)
- *   mirror cache    ndb_hip_ivf_mirror(Relation): index pages -> ndbhip_ivf_load_pages, keyed by (relid, stamp)
+ *   mirror cache    ndb_hip_ivf_mirror(Relation): index pages -> ndbhip_ivf_load_pages, keyed by (relid, stamp);
+ *                   the stamp is the index's generation in a shared counter table (ndb_gen_*, include/ndb_service.h)
+ *                   that every backend's aminsert / ambulkdelete bumps — it never repeats
  *   AM callbacks    ndbhip_ivfrescan / ndbhip_ivfgettuple / ndbhip_ivfendscan (and hnsw): called from the
  *                   handlers of src/index/ivf_am.c:385-435 / hnsw_am.c:287-338 (pgext/reference.patch)
  *   plugin vtable   ndbhip_register_backend(): memcpy of the prefix image + ndb_gpu_register_backend
@@ -115,7 +117,7 @@ ndb_hip_ready(void)
 typedef struct MirrorEntry
 {
 	Oid			relid;
-	uint64		stamp;			/* meta->insertedVectors + block count: changes with every insert / vacuum */
+	uint64		stamp;			/* the index's generation (ivf_stamp) when the pages were read */
 	ndbhip_ivf *ivf;
 	ndbhip_hnsw *hnsw;
 } MirrorEntry;
@@ -240,20 +242,48 @@ guc_device_service_set(void)
 	return guc_device_service && guc_device_service[0];
 }
 
-/* version stamp of an ivf index: the meta page's insertedVectors (ivf_am.c:75-89, bumped by every ivfinsert,
- * :1122-1157) and the relation's size (VACUUM never shrinks it, bulkdelete only kills line pointers: the
- * delete hook below drops the mirror explicitly) */
+/*
+ * Version stamp of an index's pages: its generation in the cluster-wide counter table.  Nothing ON the pages can
+ * serve: meta->insertedVectors goes up in ivfinsert (ivf_am.c:1122-1157) and down again in ivfbulkdelete
+ * (:1346), so an UPDATE + VACUUM elsewhere brings an old value back, and the reference changes its pages with
+ * MarkBufferDirty alone (no WAL record, ivf_am.c:1137-1156), so their LSNs never move.  The table lives in POSIX
+ * shared memory named after the postmaster's port (one per cluster); a backend attaches on first use.  Keys are
+ * (database OID << 32 | index relfilenumber): a REINDEX gives the index a new key and with it generation 1, and
+ * every mirror of the old file is stale by key.
+ */
+static ndb_gen *gen_table = NULL;
+
+static uint64
+index_key(Relation index)
+{
+	return ((uint64) MyDatabaseId << 32) | (uint64) RelationGetSmgr(index)->smgr_rlocator.locator.relNumber;
+}
+
+static ndb_gen *
+generations(void)
+{
+	if (!gen_table)
+	{
+		char		name[64];
+
+		snprintf(name, sizeof(name), "/ndbhip_gen_%d", PostPortNumber);
+		if (ndb_gen_attach(name, 4096, &gen_table) != NDBHIP_OK)
+			ereport(ERROR, (errmsg("neurondb: %s", ndbhip_last_error())));
+	}
+	return gen_table;
+}
+
 uint64
 ivf_stamp(Relation index)
 {
-	Buffer		buf = ReadBuffer(index, 0);
-	uint64		stamp;
+	return ndb_gen_get(generations(), index_key(index));
+}
 
-	LockBuffer(buf, BUFFER_LOCK_SHARE);
-	/* IvfMetaPageData: magic, version, nlists, nprobe, dim, centroidsBlock, int64 insertedVectors (offset 24) */
-	memcpy(&stamp, (char *) PageGetContents(BufferGetPage(buf)) + 24, sizeof(stamp));
-	UnlockReleaseBuffer(buf);
-	return stamp ^ ((uint64) RelationGetNumberOfBlocks(index) << 40);
+/* the scan of a backend without a mirror of its own (neurondb.device_service): which index, which generation */
+ndb_index_scan *
+ndb_hip_ivf_service_scan(Relation index, int nkeys, int norderbys)
+{
+	return ndb_ivfbeginscan_service(index_key(index), ivf_stamp(index), nkeys, norderbys);
 }
 
 /* aminsert: keep a cached mirror in step instead of rebuilding it (ivf_am.c:954-1157 appended the entry to
@@ -261,11 +291,17 @@ ivf_stamp(Relation index)
 void
 ndb_hip_ivf_note_insert(Relation index, int list_id, const float *vec, ItemPointer heap_tid)
 {
+	/* every backend's mirror of this index (and the device-owner process's) is now one change behind */
+	const uint64 gen = ndb_gen_bump(generations(), index_key(index));
+
 	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
 		if (mirrors[i].relid == RelationGetRelid(index) && mirrors[i].ivf)
 		{
-			if (ndbhip_ivf_append(mirrors[i].ivf, list_id, vec, (const uint8_t *) heap_tid) == NDBHIP_OK)
-				mirrors[i].stamp = ivf_stamp(index);	/* the page append has bumped insertedVectors */
+			/* this backend's own mirror follows along — only if nobody else changed the index in between
+			 * (gen is exactly one past the generation the mirror holds) and the append itself worked */
+			if (gen == mirrors[i].stamp + 1 &&
+				ndbhip_ivf_append(mirrors[i].ivf, list_id, vec, (const uint8_t *) heap_tid) == NDBHIP_OK)
+				mirrors[i].stamp = gen;
 			else
 			{
 				ndbhip_ivf_destroy(mirrors[i].ivf);		/* out of step: rebuild on the next scan */
@@ -279,6 +315,7 @@ ndb_hip_ivf_note_insert(Relation index, int list_id, const float *vec, ItemPoint
 void
 ndb_hip_ivf_note_delete(Relation index)
 {
+	(void) ndb_gen_bump(generations(), index_key(index));	/* other backends and the owner: reload before the next scan */
 	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
 		if (mirrors[i].relid == RelationGetRelid(index))
 		{

@@ -135,3 +135,34 @@ def test_partition_slices_covers_every_list_once_and_balances_work():
         assert work.max() / work.sum() < 1.0 / world + 0.01
         if world == 8:
             assert (ln[:, 5] > 0).all()                   # the 28 k-row list is shared by all ranks
+
+
+def _comm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neurondb_amd.dist import init_library_comm
+    try:
+        init_library_comm()
+        outcome = "ok"
+    except RuntimeError as e:
+        outcome = "raised: " + str(e)[:60]
+    # the ranks are still in step: one more collective pairs up and carries the right values
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)
+    ret[rank] = (outcome, int(t))
+    dist.destroy_process_group()
+
+
+def test_library_communicator_setup_fails_on_every_rank_or_on_none():
+    """init_library_comm without a device: rank 0 cannot draw an RCCL unique id.  It must still take part in the
+    broadcast and the agreement round, so that every rank raises (bench.py then falls back to the torch exchange on
+    all of them) instead of rank 1 waiting in a broadcast rank 0 never joins."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_comm_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    outcomes = {ret[r][0].split(":")[0] for r in range(world)}
+    assert len(outcomes) == 1                       # the same branch everywhere
+    assert all(ret[r][1] == 3 for r in range(world))

@@ -1,4 +1,4 @@
-"""The screened scan on fp16 matrix cores (csrc/ndbhip_screen16.h; scan mode 5, and auto mode from 128 queries):
+"""The screened scan on fp16 matrix cores (csrc/ndbhip_screen16.h; scan mode 5, and auto mode from 32 queries):
 results must be the oracle's bit for bit — ivfCollectCandidates, /root/reference/NeuronDB/src/index/ivf_am.c:1722-1909 —
 and the statistics must show that this path (not a fallback) produced them."""
 import numpy as np
@@ -31,7 +31,7 @@ def lib():
                                                (128, 20000, 40, 300), (1536, 2500, 6, 128)])
 def test_screen16_matches_oracle_and_really_runs(dim, n, nlists, nq, lib):
     """Any dim (the planes are padded to 32), ragged lists and query tiles, k up to 64, candidate cap, L2 and
-    inner product; auto mode picks this path from 128 queries."""
+    inner product; auto mode picks this path from 32 queries."""
     a = make_ivf_arrays(n, dim, nlists, seed=dim + 11, dup_frac=0.05, zero_rows=2, empty_lists=(1,))
     ix = _index(a)
     img = oracle_image(a)

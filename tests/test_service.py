@@ -179,3 +179,183 @@ def test_device_owner_serves_concurrent_backends_faster_than_one_backend_alone()
     assert one["mismatches"] == 0 and many["mismatches"] == 0
     assert many["avg_batch"] >= 32
     assert many["aggregate_queries_per_s"] >= 10 * one["aggregate_queries_per_s"], (one, many)
+
+
+def _poll_once(L, s, dim, wait_us=20000):
+    ids = (C.c_int * 8)()
+    qbuf = np.zeros((8, dim), np.float32)
+    st, npb, kk, cap = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    n = L.ndb_service_poll(s, 8, wait_us, 0, ids, qbuf.ctypes.data_as(C.c_void_p), C.byref(st), C.byref(npb), C.byref(kk),
+                           C.byref(cap))
+    _last_nprobe[0] = npb.value
+    return n, ids, kk.value
+
+
+_last_nprobe = [None]
+
+
+def test_a_scan_on_another_index_or_another_generation_is_refused_not_answered():
+    """The request carries (index key, generation); the owner publishes what its mirror is.  Another key, or a
+    generation the mirror does not hold, is NDBHIP_ERR_NODEVICE for the backend (its CPU scan takes over) and a
+    newer generation asks the owner to reload — never rows from the wrong index (csrc/ndb_service.cpp)."""
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    dim = 8
+    name = f"/ndb_service_ident_{os.getpid()}"
+    s, c = C.c_void_p(), C.c_void_p()
+    _lib.check(L.ndb_service_create(name.encode(), dim, 16, 4, C.byref(s)))
+    try:
+        _lib.check(L.ndb_service_publish(s, 16385, 7, 12))
+        _lib.check(L.ndb_client_connect(name.encode(), C.byref(c)))
+        k_, v_ = C.c_uint64(), C.c_uint64()
+        _lib.check(L.ndb_client_index(c, C.byref(k_), C.byref(v_)))
+        assert (k_.value, v_.value, L.ndb_client_meta_nprobe(c)) == (16385, 7, 12)
+        q = np.ones(dim, np.float32)
+        t = C.c_int(-1)
+        nodev = -2
+        assert L.ndb_client_submit_index(c, 999, 7, q.ctypes.data_as(C.c_void_p), 1, 2, 3, 0, C.byref(t)) == nodev
+        assert b"another index" in L.ndbhip_last_error()
+        assert L.ndb_client_submit(c, q.ctypes.data_as(C.c_void_p), 1, 2, 3, 0, C.byref(t)) == nodev   # unkeyed: key 0
+        assert L.ndb_service_reload_wanted(s, None) == 0
+        assert L.ndb_client_submit_index(c, 16385, 9, q.ctypes.data_as(C.c_void_p), 1, 2, 3, 0, C.byref(t)) == nodev
+        w = C.c_uint64()
+        assert L.ndb_service_reload_wanted(s, C.byref(w)) == 1 and w.value == 9
+        # the matching request goes through ...
+        _lib.check(L.ndb_client_submit_index(c, 16385, 7, q.ctypes.data_as(C.c_void_p), 1, 2, 3, 0, C.byref(t)))
+        n, ids, kk = _poll_once(L, s, dim)
+        assert n == 1 and kk == 3
+        tids = np.zeros((1, 3, 6), np.uint8)
+        dist = np.zeros((1, 3), np.float32)
+        cnt = np.array([0], np.int32)
+        _lib.check(L.ndb_service_complete(s, 1, ids, tids.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p),
+                                          cnt.ctypes.data_as(C.c_void_p), 3, 0))
+        got = C.c_int(-1)
+        _lib.check(L.ndb_client_wait(c, t.value, None, None, C.byref(got), 1000))
+        # ... and one submitted just before the owner moved to generation 9 is refused by the owner itself
+        _lib.check(L.ndb_client_submit_index(c, 16385, 7, q.ctypes.data_as(C.c_void_p), 1, 2, 3, 0, C.byref(t)))
+        _lib.check(L.ndb_service_publish(s, 16385, 9, 12))
+        assert L.ndb_service_reload_wanted(s, None) == 0
+        n, _, _ = _poll_once(L, s, dim, 1000)
+        assert n == 0
+        assert L.ndb_client_wait(c, t.value, None, None, C.byref(got), 1000) == nodev
+        # the AM callback passes the scan's identity along
+        _lib.check(L.ndb_am_use_service(name.encode()))
+        assert not L.ndb_hnswbeginscan(None, 0, 1)               # hnsw scans are not served
+        scan = L.ndb_ivfbeginscan_service(4242, 1, 0, 1)
+        assert scan
+        from tests.test_extract_vector import vector_datum
+        from tests.test_gpu_am import VECTOR
+        datum = vector_datum(q)
+        buf = C.create_string_buffer(datum, len(datum))
+        key = _lib.NdbScanKey(1, VECTOR, C.cast(buf, C.c_void_p), len(datum))
+        _lib.check(L.ndb_ivfrescan(scan, None, 0, C.byref(key), 1))
+        assert L.ndb_ivfgettuple(scan, 1) == nodev
+        L.ndb_ivfendscan(scan)
+        # ref_compat: the index's own nprobe comes from the owner, not the default 10
+        _lib.check(L.ndb_am_set_guc(b"neurondb.ref_compat", 1))
+        scan = L.ndb_ivfbeginscan_service(16385, 9, 0, 1)
+        _lib.check(L.ndb_ivfrescan(scan, None, 0, C.byref(key), 1))
+
+        def one_poll():
+            n, ids, kk = _poll_once(L, s, dim, 2_000_000)
+            seen.append((n, kk))
+            L.ndb_service_complete(s, n, ids, None, None, None, kk, 0)
+        seen = []
+        th = threading.Thread(target=one_poll)
+        th.start()
+        rc = L.ndb_ivfgettuple(scan, 1)
+        assert rc == 0, L.ndbhip_last_error()
+        th.join(10)
+        L.ndb_ivfendscan(scan)
+        assert seen == [(1, 10)] and _last_nprobe[0] == 12
+    finally:
+        L.ndb_am_set_guc(b"neurondb.ref_compat", 0)
+        L.ndb_am_use_service(None)
+        L.ndb_client_disconnect(c)
+        L.ndb_service_destroy(s)
+
+
+def _bump(name, key, times, q):
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    g = C.c_void_p()
+    _lib.check(L.ndb_gen_attach(name.encode(), 64, C.byref(g)))
+    seen = [L.ndb_gen_bump(g, key) for _ in range(times)]
+    L.ndb_gen_detach(g, None)
+    q.put(seen)
+
+
+def test_index_generations_only_grow_and_are_shared_between_processes():
+    """The mirrors' version stamp (include/ndb_service.h: ndb_gen_*): an insert followed by a vacuum must not bring
+    an old stamp back (the reference's insertedVectors does, ivf_am.c:1346), and every backend must see every
+    other backend's bump."""
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    name = f"/ndb_gen_test_{os.getpid()}"
+    g = C.c_void_p()
+    _lib.check(L.ndb_gen_attach(name.encode(), 64, C.byref(g)))
+    try:
+        assert L.ndb_gen_get(g, 0) == 0 and L.ndb_gen_bump(g, 0) == 0
+        assert L.ndb_gen_get(g, 777) == 1                       # untouched index
+        assert L.ndb_gen_bump(g, 777) == 2 and L.ndb_gen_get(g, 777) == 2
+        assert L.ndb_gen_bump(g, 777) == 3                      # "insert, then vacuum": 2 -> 3, never back to 1
+        assert L.ndb_gen_get(g, 778) == 1                       # another index is another counter
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_bump, args=(name, 900 + (r % 2), 500, q)) for r in range(4)]
+        for p in procs:
+            p.start()
+        seen = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(60)
+        for sq in seen:
+            assert all(b > a for a, b in zip(sq, sq[1:]))        # each process sees its index's stamp move forward only
+        assert L.ndb_gen_get(g, 900) == 1001 and L.ndb_gen_get(g, 901) == 1001   # no bump lost
+        allv = sorted(v for sq in seen for v in sq)
+        assert len(set(allv)) == 1000                            # the 2 x 1000 bumps: each value handed out once per key
+        # a table that fills up says so instead of aliasing two indexes
+        full = [L.ndb_gen_bump(g, 10_000 + i) for i in range(80)]
+        assert full.count(0) >= 80 - 64 + 3 and all(v in (0, 2) for v in full)
+    finally:
+        L.ndb_gen_detach(g, name.encode())
+
+
+def _claim_and_die(name, dim):
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    c = C.c_void_p()
+    _lib.check(L.ndb_client_connect(name.encode(), C.byref(c)))
+    q = np.zeros(dim, np.float32)
+    t = C.c_int()
+    for _ in range(3):
+        _lib.check(L.ndb_client_submit(c, q.ctypes.data_as(C.c_void_p), 1, 1, 1, 0, C.byref(t)))
+    os._exit(0)                                                  # a backend killed with requests in flight
+
+
+def test_slots_of_dead_backends_are_reclaimed_and_a_dead_owner_is_noticed():
+    from neurondb_amd import _lib
+    L = _lib.lib()
+    dim = 4
+    name = f"/ndb_service_leak_{os.getpid()}"
+    s, c = C.c_void_p(), C.c_void_p()
+    _lib.check(L.ndb_service_create(name.encode(), dim, 2, 4, C.byref(s)))
+    try:
+        ctx = mp.get_context("spawn")
+        p = ctx.Process(target=_claim_and_die, args=(name, dim))
+        p.start()
+        p.join(60)
+        _lib.check(L.ndb_client_connect(name.encode(), C.byref(c)))
+        q = np.zeros(dim, np.float32)
+        t = C.c_int()
+        # 3 of 4 slots are READY for a dead pid: a 2nd live request would find no room ...
+        _lib.check(L.ndb_client_submit(c, q.ctypes.data_as(C.c_void_p), 1, 1, 1, 0, C.byref(t)))   # the 4th slot
+        # ... until the owner takes them back (its poll loop does so once a second; here directly)
+        assert L.ndb_service_reclaim(s) == 3
+        t2 = C.c_int()
+        _lib.check(L.ndb_client_submit(c, q.ctypes.data_as(C.c_void_p), 1, 1, 1, 0, C.byref(t2)))
+        n, ids, kk = _poll_once(L, s, dim)
+        assert n == 2                                            # the dead backend's requests are not run
+        assert t2.value != t.value
+    finally:
+        L.ndb_client_disconnect(c)
+        L.ndb_service_destroy(s)

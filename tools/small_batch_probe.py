@@ -27,27 +27,33 @@ def main():
     ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
     if os.environ.get("SCAN_MODE"):
         check(lib().ndbhip_set_scan_mode(int(os.environ["SCAN_MODE"])))      # 1 per-query scan, 2 grouped scan
-    for nq in [int(x) for x in os.environ.get("NQS", "1,2,4,7,8,9,16,32,64,128,256,512").split(",")]:
-        ot = torch.zeros((nq, 10), dtype=torch.int64, device=dev)
-        od = torch.zeros((nq, 10), dtype=torch.float32, device=dev)
-        oc = torch.zeros(nq, dtype=torch.int32, device=dev)
-        res = []
-        for host in (True, False):
-            def run(i):
-                if host:
-                    ix.search(q[i * nq:(i + 1) * nq], 1, 32, 10)
-                else:
-                    ix.search_device(qd[i * nq:(i + 1) * nq], ot, od, oc, 1, 32, 10, 0)
-                    check(lib().ndbhip_synchronize())
-            for i in range(3):
-                run(i)
-            ts = []
-            for i in range(3, 8):
-                t0 = time.perf_counter()
-                run(i % (4096 // nq))
-                ts.append(time.perf_counter() - t0)
-            res.append(np.median(ts) * 1e3)
-        print(f"nq={nq:4d}  host pointers {res[0]:7.3f} ms   device pointers {res[1]:7.3f} ms", flush=True)
+    for kv in [x for x in os.environ.get("OPTS", "").split(",") if x]:
+        check(lib().ndbhip_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
+        print("option", kv, flush=True)
+    for minnq in [int(x) for x in os.environ.get("MINNQS", "128").split(",")]:
+      check(lib().ndbhip_set_option(b"screen_min_nq", minnq))
+      print("screen_min_nq", minnq, flush=True)
+      for nq in [int(x) for x in os.environ.get("NQS", "1,2,4,7,8,9,16,32,64,128,256,512").split(",")]:
+          ot = torch.zeros((nq, 10), dtype=torch.int64, device=dev)
+          od = torch.zeros((nq, 10), dtype=torch.float32, device=dev)
+          oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+          res = []
+          for host in (True, False):
+              def run(i):
+                  if host:
+                      ix.search(q[i * nq:(i + 1) * nq], 1, 32, 10)
+                  else:
+                      ix.search_device(qd[i * nq:(i + 1) * nq], ot, od, oc, 1, 32, 10, 0)
+                      check(lib().ndbhip_synchronize())
+              for i in range(3):
+                  run(i)
+              ts = []
+              for i in range(3, 8):
+                  t0 = time.perf_counter()
+                  run(i % (4096 // nq))
+                  ts.append(time.perf_counter() - t0)
+              res.append(np.median(ts) * 1e3)
+          print(f"nq={nq:4d}  host pointers {res[0]:7.3f} ms   device pointers {res[1]:7.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
