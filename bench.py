@@ -37,6 +37,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s meas
 UNFUSED_FP32_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 4 x 256 CUs x 2.4 GHz
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16, dense (MI355X_MICROARCH.md: ~2.5 PF; AMD's 5 PF is 2:1 sparse)
+PCIE_PEAK_GBPS = 64.0                # host link: PCIe 5.0 x16 per direction (raw); measured pageable hipMemcpy: 56 GB/s
 
 
 def parse():
@@ -51,6 +52,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--build-from-host", type=int, default=1, help="also time ndbhip_ivf_build from host memory (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=200)
     ap.add_argument("--data", choices=["clustered", "gauss"], default="clustered",
                     help="clustered: mixture of --components Gaussians (sigma --sigma); gauss: i.i.d. N(0,1)")
@@ -200,6 +202,40 @@ def main():
     check(lib().ndbhip_synchronize())
     t_prepare = time.perf_counter() - t0
     cent_h, list_len, _, _ = ix_full.export(rows=False)
+    # ... and the same build from where a CREATE INDEX finds its table: host memory (pageable, like a backend's
+    # palloc'd tuples).  ndbhip_ivf_build uploads through its pinned lanes while the k-means runs; the rate includes
+    # PCIe, the build and the prepare — what the reference's ivfbuild is timed as, whole (rank 0, one GPU)
+    from_host = None
+    if rank == 0 and world == 1 and args.build_from_host:
+        host_rows = base.cpu().numpy()
+        host_tids = tids_all.cpu().numpy()
+        hx = IvfIndex(dim, nlists, device=local_rank)
+        hx.build(host_rows[:max(nlists * 100, 20000)], host_tids[:max(nlists * 100, 20000)], 50)   # pins the lanes (once per process)
+        hx.close()
+        hx = IvfIndex(dim, nlists, device=local_rank)
+        t0 = time.perf_counter()
+        hx.build(host_rows, host_tids, 50)
+        t_hb = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        hx.prepare({"l2": 1, "cosine": 2, "ip": 3}[args.strategy])
+        check(lib().ndbhip_synchronize())
+        t_hp = time.perf_counter() - t0
+        _, hl, _, _ = hx.export(rows=False)
+        from_host = {"vectors_per_s": round(n / t_hb, 1), "searchable_vectors_per_s": round(n / (t_hb + t_hp), 1),
+                     "build_seconds": round(t_hb, 4), "prepare_seconds": round(t_hp, 4), "host_bytes": int(n) * dim * 4,
+                     "same_lists_as_device_build": bool(np.array_equal(hl, list_len)),
+                     "roofline": {"bound": "pcie", "achieved": round(n * dim * 4 / t_hb / 1e9, 2), "peak": PCIE_PEAK_GBPS,
+                                  "unit": "GB/s", "frac": round(n * dim * 4 / t_hb / 1e9 / PCIE_PEAK_GBPS, 4),
+                                  "note": "table bytes / build_seconds against the host link (PCIe 5.0 x16, 64 GB/s raw; "
+                                          "a bare hipMemcpy of the same pageable table reaches 56 GB/s on this box: "
+                                          "profiles/r03_host_build_timeline.txt): the rows arrive in heap order while "
+                                          "the k-means and the assignment of the slabs already there run, so the build "
+                                          "adds only its last slab and the list packing to the transfer"},
+                     "note": "ndbhip_ivf_build(host rows, pageable) then ndbhip_ivf_prepare: wall time from the call to "
+                             "an index that answers (vectors_per_s) and one that answers at full speed "
+                             "(searchable_vectors_per_s)"}
+        hx.close()
+        del host_rows, host_tids
     build = None
     if rank == 0:
         # SURVEY 8d "IVF build roofline": the assignment of all N rows is 2 N lists dim flops (a dense contraction;
@@ -227,6 +263,8 @@ def main():
                  "first_build_seconds": round(t_first_build, 4),
                  "prepare_seconds": round(t_prepare, 4),
                  "searchable_vectors_per_s": round(n / (t_build + t_prepare), 1),
+                 "from_host": from_host,
+                 "from_host_vectors_per_s": from_host["vectors_per_s"] if from_host else None,
                  "lists_identical_to_exact_assignment": same and counts_ok,
                  "roofline": {"bound": "mfma", "achieved": round(flops / t_build / 1e12, 2), "peak": FP16_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(flops / t_build / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),

@@ -16,6 +16,8 @@
 
 
 #include "ndbhip_internal.h"
+#include <atomic>
+#include <thread>
 
 /* ================================================================== */
 /* context / errors                                                    */
@@ -30,6 +32,7 @@ static int	g_scan_mode = 0;
  * exact scan (the two extra passes cost more than they save there) */
 static bool g_screen_auto = true;
 #define NDB_SCREEN_MIN_NQ 32
+static int	g_build_prepare = 0;	/* "build_prepare": strategy (1 .. 3) a build prepares the index for before it returns, 0 = the first batched scan or ndbhip_ivf_prepare does */
 static int	g_screen_min_nq = NDB_SCREEN_MIN_NQ;	/* batches of at least this many queries take the screened path ("screen_min_nq") */
 /* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32): the grouped path costs 0.38 ms for 1..16
  * queries, the per-query path 0.18 / 0.24 / 0.35 / 0.50 ms for 1 / 2 / 4 / 7 */
@@ -103,10 +106,14 @@ ndbhip_init(int device)
 	g.stream = g.own_stream;
 	HIP_TRY(hipMalloc((void **) &g.d_counters, 8 * sizeof(unsigned long long)));
 	HIP_TRY(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+	HIP_TRY(hipHostMalloc((void **) &g.pin_words, 4096, hipHostMallocDefault));
+	memset(g.pin_words, 0, 4096);
 	g.device = device;
 	g.inited = true;
 	return set_kernel_attributes();
 }
+
+static void upload_release(void);
 
 extern "C" int
 ndbhip_shutdown(void)
@@ -124,10 +131,98 @@ ndbhip_shutdown(void)
 		(void) hipFree(g.d_counters);
 	if (g.asg_arena)
 		(void) hipFree(g.asg_arena);
+	if (g.pin_words)
+		(void) hipHostFree(g.pin_words);
 	big_cache_flush();
+	upload_release();
 	g = Ctx();
 	return NDBHIP_OK;
 }
+
+/*
+ * Host rows -> device.  Measured on the MI355X box (tools/host_build_probe.py): the runtime's own hipMemcpy from
+ * pageable memory carries 3 GB at 56 GB/s — the link's rate — while a pinned-staging copy of this library's own
+ * (CPU memcpy into pinned buffers + DMA, 1 .. 8 threads) reached 20 .. 39 GB/s, bounded by the CPU copies, and
+ * pinning the caller's pages first (hipHostRegister) + asynchronous pieces was no faster than the runtime.  So
+ * the upload is the runtime's, cut into NDB_UP_CHUNK pieces on a side stream by a thread of its own, and what
+ * this adds is ORDER: the pieces go in row order and `done` says how far they have got, so that device work on
+ * the first rows (the k-means of a build, then the assignment slab by slab) runs while the rest is on the wire.
+ */
+#define NDB_UP_CHUNK ((size_t) 32 << 20)
+static hipStream_t g_up_stream = nullptr;
+static std::mutex g_up_mutex;		/* one upload at a time */
+
+static void
+upload_release(void)
+{
+	if (g_up_stream)
+		(void) hipStreamDestroy(g_up_stream);
+	g_up_stream = nullptr;
+}
+
+/* bytes of host memory at src -> device memory at d_dst in chunks; *done (nullable) = bytes that have arrived */
+static int
+upload_rows(void *d_dst, const void *src, size_t bytes, std::atomic<size_t> *done = nullptr)
+{
+	std::lock_guard<std::mutex> hold(g_up_mutex);
+
+	if (!g_up_stream && hipStreamCreateWithFlags(&g_up_stream, hipStreamNonBlocking) != hipSuccess)
+		return fail(NDBHIP_ERR_HIP, "no stream for the upload");
+	for (size_t off = 0; off < bytes; off += NDB_UP_CHUNK)
+	{
+		const size_t n = std::min(NDB_UP_CHUNK, bytes - off);
+
+		if (hipMemcpyAsync((char *) d_dst + off, (const char *) src + off, n, hipMemcpyHostToDevice, g_up_stream) != hipSuccess ||
+			hipStreamSynchronize(g_up_stream) != hipSuccess)
+			return fail(NDBHIP_ERR_HIP, "upload of %zu bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+		if (done)
+			done->store(off + n, std::memory_order_release);
+	}
+	return 0;
+}
+
+/* upload_rows on a thread of its own */
+struct UploadJob
+{
+	std::thread th;
+	std::atomic<size_t> done{0};
+	std::atomic<int> finished{0};
+	size_t		total = 0;
+	int			rc = 0;
+	bool		running = false;
+	void start(void *d_dst, const void *src, size_t bytes)
+	{
+		int			dev = 0;
+
+		(void) hipGetDevice(&dev);
+		total = bytes;
+		running = true;
+		th = std::thread([=]() {
+			(void) hipSetDevice(dev);
+			rc = upload_rows(d_dst, src, bytes, &done);
+			finished.store(1, std::memory_order_release);
+		});
+	}
+	/* blocks until the first `bytes` bytes have arrived (or the upload has failed) */
+	int wait_for(size_t bytes)
+	{
+		if (bytes > total)
+			bytes = total;
+		while (running && done.load(std::memory_order_acquire) < bytes && !finished.load(std::memory_order_acquire))
+			std::this_thread::sleep_for(std::chrono::microseconds(50));
+		return finished.load(std::memory_order_acquire) ? rc : 0;
+	}
+	int wait()
+	{
+		if (running)
+		{
+			th.join();
+			running = false;
+		}
+		return rc;
+	}
+	~UploadJob() { (void) wait(); }
+};
 
 /*
  * Allocation of an index's large device blocks.  hipMalloc of a few GB costs between 0.3 and 60 ms on this runtime
@@ -3249,6 +3344,12 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_slack"))
 		g_s16_slack = value != 0;
+	else if (!strcmp(name, "build_prepare"))
+	{
+		if (value < 0 || value > 3)
+			return fail(NDBHIP_ERR_INVALID, "build_prepare must be 0 (off) or a strategy 1 .. 3");
+		g_build_prepare = value;
+	}
 	else if (!strcmp(name, "screen_min_nq"))
 	{
 		if (value < 1 || value > 65536)

@@ -434,6 +434,35 @@ set_kernel_attributes_build()
 	return set_kernel_attributes_hnsw();
 }
 
+/*
+ * hipFree waits for every stream of the device — including the one a table is still arriving on (ndbhip_ivf_build):
+ * one small free after the k-means would hold the build up until the last byte of the upload.  While
+ * g_defer_frees is set, the build's temporaries are parked here and released together at its end.
+ */
+static bool g_defer_frees = false;
+static std::vector<void *> g_deferred;
+
+static hipError_t
+free_or_defer(void *p)
+{
+	if (!p)
+		return hipSuccess;
+	if (g_defer_frees)
+	{
+		g_deferred.push_back(p);
+		return hipSuccess;
+	}
+	return hipFree(p);
+}
+
+static void
+flush_deferred(void)
+{
+	for (void *p : g_deferred)
+		(void) hipFree(p);
+	g_deferred.clear();
+}
+
 /* scratch of assign_rows, reusable across calls (the k-means loop calls it once per iteration) */
 struct AssignWs
 {
@@ -443,9 +472,9 @@ struct AssignWs
 	size_t		pn = 0, cn = 0;
 	int release()
 	{
-		if (pd) HIP_TRY(hipFree(pd));
-		if (pi) HIP_TRY(hipFree(pi));
-		if (cblock) HIP_TRY(hipFree(cblock));
+		if (pd) HIP_TRY(free_or_defer(pd));
+		if (pi) HIP_TRY(free_or_defer(pi));
+		if (cblock) HIP_TRY(free_or_defer(cblock));
 		pd = nullptr; pi = nullptr; cblock = nullptr; pn = cn = 0;
 		return 0;
 	}
@@ -540,7 +569,8 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 }
 
 static int	assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int k, int *d_out_list,
-							unsigned long long *stats, const std::function<int()> &while_running);
+							unsigned long long *stats, const std::function<int()> &while_running,
+							const std::function<int(int64_t)> &rows_until = nullptr);
 
 extern "C" int
 ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, const float *d_rows,
@@ -600,13 +630,18 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if ((size_t) n * 4 + 64 > NDB_TOPK_MAX_SMEM)	/* the reference samples at most 10000 rows (ivf_am.c:580) */
 		return fail(NDBHIP_ERR_UNSUPPORTED, "k-means sample of %d rows exceeds the LDS-resident limit", n);
-	float	   *d_pc = nullptr, *d_cost = nullptr;
+	float	   *d_pc = nullptr;
+	/* the iteration's cost lands in pinned host memory straight from the kernel: no copy engine in the loop */
+	float	   *d_cost = g.pin_words;
 	float		prevCost = FLT_MAX, cost = 0.0f;
 	int			iters = 0;
 	AssignWs	ws;
 
+	const auto	tk0 = std::chrono::steady_clock::now();
+
 	HIP_TRY(hipMalloc((void **) &d_pc, (size_t) n * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &d_cost, sizeof(float)));
+	if (g_debug_build & 2)
+		fprintf(stderr, "k-means: scratch allocated at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count());
 	hipLaunchKernelGGL(k_kmeans_init, dim3((unsigned) (((size_t) k * dim + 255) / 256)), dim3(256), 0, g.stream,
 					   d_samples, n, dim, k, d_centroids);
 	for (int iter = 0; iter < max_iter; iter++)
@@ -622,16 +657,17 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 		hipLaunchKernelGGL(k_kmeans_point_cost, dim3((n + 255) / 256), dim3(256), 0, g.stream, d_samples, n, dim,
 						   (const int *) d_assign, (const float *) d_centroids, d_pc);
 		hipLaunchKernelGGL(k_seq_sum, dim3(1), dim3(256), (size_t) n * 4, g.stream, (const float *) d_pc, n, d_cost);
-		HIP_TRY(hipMemcpyAsync(&cost, d_cost, sizeof(float), hipMemcpyDeviceToHost, g.stream));
 		HIP_TRY(hipStreamSynchronize(g.stream));
+		cost = *(volatile float *) d_cost;
+		if (g_debug_build & 2)
+			fprintf(stderr, "k-means: iteration %d done at %.2f ms\n", iter, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count());
 		iters = iter + 1;
 		/* fabs(prevCost - cost) < threshold, float difference widened (ivf_am.c:2141) */
 		if (fabs((double) (float) (prevCost - cost)) < (double) threshold)
 			break;
 		prevCost = cost;
 	}
-	HIP_TRY(hipFree(d_pc));
-	HIP_TRY(hipFree(d_cost));
+	HIP_TRY(free_or_defer(d_pc));
 	if (ws.release())
 		return NDBHIP_ERR_HIP;
 	if (out_iters)
@@ -967,7 +1003,8 @@ k_assign_tables(const unsigned char *__restrict__ dup, int k, uint32_t rows_a, u
 static int
 assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int k, int *d_out_list,
 				unsigned long long *stats /* host [2] or NULL: rows decided among several candidates, rows sent to the exact assignment */ ,
-				const std::function<int()> &while_running /* host work done while the kernels run */ )
+				const std::function<int()> &while_running /* host work done while the kernels run */ ,
+				const std::function<int(int64_t)> &rows_until /* nullable: returns once rows [0, n) are on the device (a table still arriving) */ )
 {
 	const int	dimp = (dim + 63) & ~63;
 	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
@@ -1086,6 +1123,16 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 		dv.dim = dim;
 		dv.ncent = 1;
 		dv.nlists = 1;
+		if (rows_until)
+		{
+			const int	urc = rows_until(s0 + ns);
+
+			if (urc != 0)
+			{
+				(void) hipStreamSynchronize(g.stream);
+				return urc;
+			}
+		}
 		if (s0 > 0)
 			HIP_TRY(hipMemsetAsync(heads, 0, 2 * 8 * NDB_QHEAD_STRIDE * 4, g.stream));
 		HIP_TRY(hipMemsetAsync(rowmin, 0xFF, (size_t) ns * 4, g.stream));
@@ -1152,10 +1199,16 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 	return 0;
 }
 
-extern "C" int ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
-									   int max_iter, int *out_iters);
+static int	ivf_build_rows(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows, int max_iter,
+						   int *out_iters, const std::function<int(int64_t)> &rows_until, const std::function<int()> &tids_ready);
 
-/* ivfbuild (src/index/ivf_am.c:501-745) for host rows in heap order: staged H2D, then ndbhip_ivf_build_device */
+/*
+ * ivfbuild (src/index/ivf_am.c:501-745) for host rows in heap order.  The table is the input of a CREATE INDEX:
+ * it arrives over PCIe, and the arrival is most of the wall time (3 GB at 1M x 768 against ~25 ms of device
+ * work).  So: the k-means sample (the first min(10000, 100 lists) rows, ivf_am.c:580) goes first, the rest
+ * follows on the upload lanes (ndbhip.hip: upload_rows) WHILE the k-means runs, and only the assignment of every
+ * row waits for the last byte.
+ */
 extern "C" int
 ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_t nrows, int max_iter, int *out_iters)
 {
@@ -1164,28 +1217,75 @@ ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	float	   *d_rows = nullptr;
 	uint64_t   *d_tids = nullptr;
-	std::vector<uint64_t> t64((size_t) nrows);
+	const size_t row_bytes = (size_t) ix->dim * sizeof(float);
+	const int64_t ns = std::min<int64_t>(std::min<int64_t>(10000, (int64_t) ix->nlists * 100), nrows);
+	std::vector<uint64_t> t64;
+	UploadJob	rest;
+	int			rc;
 
-	for (int64_t i = 0; i < nrows; i++)
-		t64[(size_t) i] = ndb_tid_pack(tids6 + (size_t) i * 6);
-	HIP_TRY(hipMalloc((void **) &d_rows, (size_t) nrows * ix->dim * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &d_tids, (size_t) nrows * sizeof(uint64_t)));
-	HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t) nrows * ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
-	HIP_TRY(hipMemcpyAsync(d_tids, t64.data(), (size_t) nrows * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-	const int	rc = ndbhip_ivf_build_device(ix, d_rows, d_tids, nrows, max_iter, out_iters);
+	const auto	tb0 = std::chrono::steady_clock::now();
+	auto		since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
+	const bool	tl = (g_debug_build & 2) != 0;
 
+	if (big_alloc((void **) &d_rows, (size_t) nrows * row_bytes)) return NDBHIP_ERR_HIP;
+	if (big_alloc((void **) &d_tids, (size_t) nrows * sizeof(uint64_t)))
+	{
+		big_free(d_rows);
+		return NDBHIP_ERR_HIP;
+	}
+	/* the rows in heap order on a thread of their own; the build asks for as many as its next step reads: the
+	 * sample for the k-means, then the assignment slab by slab — the device works on what has arrived while the
+	 * rest is on the wire; the TIDs (packed on this thread meanwhile) follow the last row */
+	if (tl) fprintf(stderr, "host build: %.2f ms device blocks allocated\n", since());
+	g_defer_frees = true;
+	rest.start(d_rows, rows, (size_t) nrows * row_bytes);
+	rc = ivf_build_rows(ix, d_rows, d_tids, nrows, max_iter, out_iters,
+						[&](int64_t upto) -> int {
+							if (tl) fprintf(stderr, "host build: %.2f ms waiting for rows up to %lld\n", since(), (long long) upto);
+							const int	r = rest.wait_for((size_t) upto * row_bytes);
+
+							if (tl) fprintf(stderr, "host build: %.2f ms   ... arrived\n", since());
+							return r;
+						},
+						[&]() -> int {
+							if (tl) fprintf(stderr, "host build: %.2f ms assignment launched; packing TIDs\n", since());
+							t64.resize((size_t) nrows);
+							for (int64_t i = 0; i < nrows; i++)
+								t64[(size_t) i] = ndb_tid_pack(tids6 + (size_t) i * 6);
+							int			r = rest.wait();
+
+							if (tl) fprintf(stderr, "host build: %.2f ms TIDs packed\n", since());
+							if (r == 0)
+								r = upload_rows(d_tids, t64.data(), (size_t) nrows * sizeof(uint64_t));
+							if (tl) fprintf(stderr, "host build: %.2f ms TIDs uploaded\n", since());
+							return r;
+						});
+	(void) ns;
+	(void) rest.wait();
+	g_defer_frees = false;
+	flush_deferred();
+	if (tl) fprintf(stderr, "host build: %.2f ms index built\n", since());
 	(void) hipStreamSynchronize(g.stream);
-	(void) hipFree(d_rows);
-	(void) hipFree(d_tids);
+	big_free(d_rows);
+	big_free(d_tids);
 	return rc;
+}
+
+extern "C" int
+ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
+						int max_iter, int *out_iters)
+{
+	return ivf_build_rows(ix, d_rows, d_tids, nrows, max_iter, out_iters, nullptr, nullptr);
 }
 
 static int	pack_by_list(const int *d_list, int64_t nrows, int dim, int k, const float *d_rows, const uint64_t *d_tids,
 						 float *d_prow, uint64_t *d_ptid, std::vector<int64_t> &list_len);
 
-extern "C" int
-ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
-						int max_iter, int *out_iters)
+/* rows_until(n) (nullable): returns once rows [0, n) are on the device; tids_ready() (nullable): once all TIDs are —
+ * for a table that is still arriving (ndbhip_ivf_build) */
+static int
+ivf_build_rows(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows, int max_iter, int *out_iters,
+			   const std::function<int(int64_t)> &rows_until, const std::function<int()> &tids_ready)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!ix || !d_rows || !d_tids || nrows < 1)
@@ -1203,7 +1303,7 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	float	   *d_cent = nullptr;
 	int		   *d_sasg = nullptr, *d_scnt = nullptr, *d_list = nullptr;
 	int			iters = 0, rc;
-	const bool	dbg = g_debug_build != 0;
+	const bool	dbg = (g_debug_build & 1) != 0;
 	auto		now = [&]() { if (dbg) (void) hipStreamSynchronize(g.stream); return std::chrono::steady_clock::now(); };
 	auto		t_start = now();
 	auto		lap = [&](const char *what) {
@@ -1216,12 +1316,14 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	HIP_TRY(hipMalloc((void **) &d_cent, (size_t) k * dim * sizeof(float)));
 	HIP_TRY(hipMalloc((void **) &d_sasg, (size_t) ns * sizeof(int)));
 	HIP_TRY(hipMalloc((void **) &d_scnt, (size_t) k * sizeof(int)));
+	if (rows_until && (rc = rows_until(ns)) != 0)
+		return rc;
 	rc = ndbhip_kmeans_device(d_rows, ns, dim, k, max_iter, 0.001f, d_cent, d_sasg, d_scnt, &iters, nullptr);
 	if (rc)
 		return rc;
 	lap("k-means on the sample");
-	HIP_TRY(hipFree(d_sasg));
-	HIP_TRY(hipFree(d_scnt));
+	HIP_TRY(free_or_defer(d_sasg));
+	HIP_TRY(free_or_defer(d_scnt));
 
 	/* every row goes to the list ivfinsert would choose (Q5: the reference leaves this to later INSERTs) */
 	HIP_TRY(hipMalloc((void **) &d_list, (size_t) nrows * sizeof(int)));
@@ -1241,12 +1343,18 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 		return 0;
 	};
 
-	rc = g_build_s16 ? assign_rows_s16(d_rows, nrows, dim, d_cent, k, d_list, nullptr, alloc_mirror) : 1;
+	rc = g_build_s16 ? assign_rows_s16(d_rows, nrows, dim, d_cent, k, d_list, nullptr, alloc_mirror, rows_until) : 1;
 	if (rc < 0)
 		return rc;
 	if (rc == 1)				/* a shape the sweep does not take: the exact assignment on the vector ALU */
+	{
+		if (rows_until && (rc = rows_until(nrows)) != 0)
+			return rc;
 		rc = assign_rows(d_rows, nrows, dim, d_cent, k, true, d_list, nullptr, &aws);
+	}
 	if (rc)
+		return rc;
+	if (tids_ready && (rc = tids_ready()) != 0)
 		return rc;
 	rc = alloc_mirror();
 	if (rc)
@@ -1283,6 +1391,13 @@ ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_t
 	lap("adopt (layout upload, old rows freed)");
 	if (out_iters)
 		*out_iters = iters;
+	if (g_build_prepare)
+	{
+		rc = ndbhip_ivf_prepare(ix, g_build_prepare);	/* so that the first query does not pay for it */
+		lap("prepare (sublists, planes, norms, radii)");
+		if (rc)
+			return rc;
+	}
 	return NDBHIP_OK;
 }
 

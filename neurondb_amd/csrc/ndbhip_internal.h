@@ -70,6 +70,8 @@ struct Ctx
 	 * multi-GB hipMalloc costs anything from 0.3 to 60 ms on this runtime, which is as much as a whole build */
 	unsigned char *asg_arena = nullptr;
 	size_t		asg_arena_cap = 0;
+	float	   *pin_words = nullptr;	/* 1024 words of pinned, device-visible host memory: kernels leave single results here
+									 * (a copy engine busy with a table upload would hold a 4-byte readback up for its whole queue) */
 	/* large device blocks (an index's packed rows and TIDs) handed back by a destroyed or rebuilt index, kept for
 	 * the next build of similar size for the same reason (big_alloc / big_free in ndbhip.hip) */
 	std::vector<std::pair<void *, size_t>> big_live, big_cached;

@@ -116,17 +116,18 @@ class IvfIndex:
         return iters.value, owned
 
     def build(self, rows, tids, max_iter=50):
-        """Host-array form of build_device (stages through torch device tensors)."""
-        import torch
-        r = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
+        """ndbhip_ivf_build: ivfbuild for a table in host memory (heap order); the library uploads it through its
+        pinned lanes while the k-means on the sample runs.  tids: ndbo.TID_DTYPE / (n, 6) uint8 / uint64 images."""
+        r = np.ascontiguousarray(rows, dtype=np.float32)
         t = np.ascontiguousarray(tids)
-        t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
-        t8 = np.zeros((t6.shape[0], 8), dtype=np.uint8)
-        t8[:, :6] = t6
-        tt = torch.from_numpy(t8.view(np.int64).reshape(-1)).cuda()
-        it = self.build_device(r, tt, max_iter)
+        if t.dtype in (np.uint64, np.int64):
+            t6 = np.ascontiguousarray(t.view(np.uint8).reshape(-1, 8)[:, :6])
+        else:
+            t6 = t.view(np.uint8).reshape(-1, 6) if t.dtype != np.uint8 else t.reshape(-1, 6)
+        it = C.c_int(0)
+        check(lib().ndbhip_ivf_build(self._h, _ptr(r), _ptr(t6), r.shape[0], max_iter, C.byref(it)))
         check(lib().ndbhip_synchronize())
-        return it
+        return it.value
 
     def shard(self, owned):
         """New IvfIndex holding only the lists with owned[L] != 0 (multi-GPU: one process per GPU)."""

@@ -201,3 +201,48 @@ def test_host_pointer_build_is_the_device_build():
     assert np.array_equal(ll, np.diff(img.list_off))
     assert np.array_equal(ndbo.tids_to_u64(tids), ndbo.tids_to_u64(img.tids))
     assert np.array_equal(rows.view(np.uint32), img.vecs.view(np.uint32))
+
+
+def test_build_from_host_memory_equals_build_from_device_memory_and_can_leave_the_index_prepared():
+    """ndbhip_ivf_build uploads the table in heap order while the k-means and the assignment of the slabs that have
+    arrived already run (csrc/ndbhip_build.h); 200k x 768 is several upload pieces and two assignment slabs.  The
+    index must be the one ndbhip_ivf_build_device makes from the same rows; with option build_prepare the sublists /
+    planes are made inside the build, not by the first batch of queries."""
+    import torch
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import Stats, check, lib
+    from bench import make_data, pack_tids
+    _lib.ensure_init()
+    n, dim, nlists = 200_000, 768, 64
+    dev = torch.device("cuda", 0)
+    base = make_data(n, dim, "clustered", 64, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
+    tids = pack_tids(torch.arange(n, device=dev))
+    a = IvfIndex(dim, nlists)
+    ita = a.build_device(base, tids, 50)
+    check(lib().ndbhip_synchronize())
+    ca, la, ra, ta = a.export()
+    host = base.cpu().numpy()
+    st = Stats()
+    try:
+        check(lib().ndbhip_set_option(b"build_prepare", 1))
+        check(lib().ndbhip_stats_reset())
+        b = IvfIndex(dim, nlists)
+        itb = b.build(host, tids.cpu().numpy(), 50)
+        check(lib().ndbhip_stats_get(C.byref(st)))
+        prepared_in_build = st.prepares
+    finally:
+        check(lib().ndbhip_set_option(b"build_prepare", 0))
+    cb, lb, rb, tb = b.export()
+    assert ita == itb
+    assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
+    assert np.array_equal(la, lb)
+    assert np.array_equal(ndbo.tids_to_u64(ta), ndbo.tids_to_u64(tb))
+    assert np.array_equal(ra.view(np.uint32), rb.view(np.uint32))
+    assert prepared_in_build == 1
+    q = make_data(256, dim, "clustered", 64, 0.1, 0x5EED0002, 0x5EEDC0DE, dev).cpu().numpy()
+    t1, d1, c1 = a.search(q, 1, 8, 10)
+    t2, d2, c2 = b.search(q, 1, 8, 10)
+    check(lib().ndbhip_stats_get(C.byref(st)))
+    assert st.prepares == 2                     # a's first batch prepared a; b was ready
+    assert np.array_equal(c1, c2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    assert np.array_equal(ndbo.tids_to_u64(t1.reshape(-1)), ndbo.tids_to_u64(t2.reshape(-1)))
