@@ -11,17 +11,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_pmc_traffic_json_is_what_the_summaries_say(tmp_path):
     out = tmp_path / "t.json"
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"),
-                           os.path.join(ROOT, "profiles", "r02_pmc"), str(out), "3",
-                           "--hnsw", os.path.join(ROOT, "profiles", "r02_pmc_hnsw"), "8192"], stdout=subprocess.DEVNULL)
+    P = os.path.join(ROOT, "profiles")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"), str(out), "3",
+                           "--ivf", "clustered", os.path.join(P, "r03_pmc_clustered"),
+                           "--ivf", "gauss", os.path.join(P, "r03_pmc_gauss"),
+                           "--h2", os.path.join(P, "r03_pmc_h2"), "8192"], stdout=subprocess.DEVNULL)
     fresh = json.load(open(out))["kernels"]
-    kept = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
-    for kern, sub in (("k_s16_sweep", "clustered"), ("k_s16_finalize", "clustered"), ("k_hnsw_search_fast", "gauss_unit")):
+    kept = json.load(open(os.path.join(P, "r03_pmc_traffic.json")))["kernels"]
+    for kern, sub in (("k_s16c_sweep", "clustered"), ("k_s16c_sweep", "gauss"), ("k_s16_finalize", "clustered")):
         assert fresh[kern][sub]["traffic_bytes_per_launch"] == kept[kern][sub]["traffic_bytes_per_launch"]
-    e = kept["k_s16_sweep"]["clustered"]
+    assert fresh["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"] == kept["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"]
+    e = kept["k_s16c_sweep"]["clustered"]
     # 2 x FETCH_SIZE + WRITE_SIZE (KiB per step) is the per-step traffic the file reports
     assert abs((2 * e["fetch_kib_per_step"] + e["write_kib_per_step"]) * 1024 - e["traffic_bytes_per_step"]) < 4096
-    assert 1e9 < e["traffic_bytes_per_launch"] < 2e10
+    assert 1e9 < e["traffic_bytes_per_launch"] < 4e9
+    g = kept["k_s16c_sweep"]["gauss"]
+    # the matrix pipe's busy share is MFMA_BUSY / (1024 SIMDs x launch cycles); never above 1, and the dense table's
+    # is the larger one
+    assert 0.0 < e["mfma_busy"] < g["mfma_busy"] < 1.0
 
 
 def test_bench_finds_the_committed_traffic_for_its_default_workload():
@@ -29,17 +36,19 @@ def test_bench_finds_the_committed_traffic_for_its_default_workload():
     import bench
     args = types.SimpleNamespace(data="clustered", nvec=1_000_000, dim=768, lists=1024, probes=32, batch=4096, k=10,
                                  rows="f32", strategy="l2")
-    traffic, source = bench.pmc_traffic(args, 1, "k_s16_sweep")
-    assert traffic and "profiles/r" in source
-    assert bench.pmc_traffic(args, 8, "k_s16_sweep") == (None, None)          # a PMC pass describes one GPU
+    traffic, source = bench.pmc_traffic(args, 1, "k_s16c_sweep")
+    assert traffic and "profiles/r03" in source
+    t2, s2, busy = bench.pmc_traffic(args, 1, "k_s16c_sweep", "gauss", want_busy=True)
+    assert t2 > traffic and busy and "profiles/r03" in s2
+    assert bench.pmc_traffic(args, 8, "k_s16c_sweep") == (None, None)          # a PMC pass describes one GPU
     args.strategy = "ip"
-    assert bench.pmc_traffic(args, 1, "k_s16_sweep") == (None, None)          # ... and one workload
-    hn = bench.hnsw_pmc_traffic(1_000_000, 768, 16, 64, 8192, 1e-3)
-    assert hn["traffic"] and hn["traffic_source"]
+    assert bench.pmc_traffic(args, 1, "k_s16c_sweep") == (None, None)          # ... and one workload
+    h = bench.h2_roofline(1_000_000, 768, 16, 64, 8192, 16.3e-3, 2.6e6)
+    assert h["traffic"] and h["traffic_source"] and 0 < h["traffic_frac"] < 1 and 0 < h["frac"] < 1
 
 
 def test_the_committed_bench_line_is_one_json_object_with_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -49,5 +58,11 @@ def test_the_committed_bench_line_is_one_json_object_with_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # every fraction of a roof in the line is a fraction
+    assert 0 < r["frac"] <= 1 and 0 < r["hbm"]["frac"] <= 1 and 0 < r["mfma"]["frac"] <= 1 and 0 < r["hbm"]["step_frac"] <= r["hbm"]["frac"]
+    g = d["iid_gauss"]
+    assert 0 < g["roofline"]["frac"] <= 1 and g["cpu_baseline"]["value"] > 0 and g["oracle_parity"]["mismatches"] == 0
     assert c["gpu_parity_on_sample"]["mismatches"] == 0 and d["recall_at_10"] == 1.0
     assert "workload" in d["config"] and "model" not in d["config"]
+    b = d["build"]
+    assert b["searchable_vectors_per_s"] < b["vectors_per_s"] and b["lists_identical_to_exact_assignment"]

@@ -2,15 +2,14 @@
 """Turns the PMC summaries of one state of the library (tools/pmc_all.sh TAG -> gpurun_out/pmc_TAG_{fetch,write,tcc}.txt,
 or copies of them under profiles/) into profiles/<round>_pmc_traffic.json, the file bench.py's roofline.traffic reads.
 
-usage: tools/pmc_traffic_json.py PREFIX OUT.json STEPS [--hnsw PREFIX_HNSW]
-  PREFIX       e.g. profiles/r02_pmc   (reads PREFIX_fetch.txt, PREFIX_write.txt, PREFIX_tcc.txt)
+usage: tools/pmc_traffic_json.py OUT.json STEPS [--ivf DATA PREFIX]... [--h2 PREFIX NQ]
+  PREFIX       e.g. profiles/r03_pmc_clustered   (reads PREFIX_fetch.txt, PREFIX_write.txt, PREFIX_tcc.txt, PREFIX_sq.txt)
   STEPS        search steps the profiled bench.py ran in total (steps + warmup; tools/pmc_pass.sh: 3)
 
 Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are KiB per dispatch;
 on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced streams as 64 bytes, so read bytes =
-2 x FETCH_SIZE x 1024.  The sweep runs twice a step (all queries, then the queries whose record buffer overflowed):
-`traffic_bytes_per_launch` is the FIRST sweep's share, estimated as the step's traffic x (first sweep's time / both),
-and `traffic_bytes_per_step` the sum of both."""
+2 x FETCH_SIZE x 1024.  The centred sweep runs once a step (a second round only for queries whose record buffer
+overflowed, none on the bench tables): `traffic_bytes_per_launch` = the pass's traffic / its dispatches."""
 import json
 import re
 import sys
@@ -77,30 +76,57 @@ def entry(prefix, needle, steps, workload, two_rounds):
     return e
 
 
+def busy(prefix, needle, nsimd=1024, nxcd=8):
+    """share of the launch during which the matrix pipe of an average SIMD was busy: SQ_VALU_MFMA_BUSY_CYCLES (shader
+    cycles, summed over the chip's 1024 SIMDs: 32 per v_mfma_f32_32x32x16_f16 — it equals 32 x SQ_INSTS_MFMA in the sq2
+    pass) / (SIMDs x cycles of the launch).  GRBM_GUI_ACTIVE of the same pass is the launch's cycles summed over the 8
+    XCDs (7.34 M for a 0.39 ms launch = 8 x 2.35 GHz x 0.39 ms), so cycles of the launch = GRBM_GUI_ACTIVE / 8."""
+    try:
+        c = pick(counters(prefix + "_sq.txt"), needle)
+    except OSError:
+        return None
+    if not c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c or c["GRBM_GUI_ACTIVE"][0] <= 0:
+        return None
+    return round(c["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (nsimd * c["GRBM_GUI_ACTIVE"][0] / nxcd), 4)
+
+
 def main():
-    prefix, out, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    wl = {"data": "clustered", "nvec": 1000000, "dim": 768, "lists": 1024, "probes": 32, "batch": 4096,
-          "rows": "f32", "strategy": "l2"}
+    """usage: tools/pmc_traffic_json.py OUT.json STEPS [--ivf DATA PREFIX]... [--h2 PREFIX NQ]
+       e.g.   tools/pmc_traffic_json.py profiles/r03_pmc_traffic.json 3 --ivf clustered profiles/r03_pmc_clustered \
+                  --ivf gauss profiles/r03_pmc_gauss --h2 profiles/r03_pmc_h2 8192"""
+    out, steps = sys.argv[1], int(sys.argv[2])
     doc = {"_comment": __doc__, "kernels": {}}
-    e = entry(prefix, "k_s16_sweep<0, 0, 4, 2, 0, 0>", steps, wl, True)
-    if e:
-        doc["kernels"]["k_s16_sweep"] = {"clustered": e}
-    e = entry(prefix, "k_s16_finalize", steps, wl, False)
-    if e:
-        doc["kernels"]["k_s16_finalize"] = {"clustered": e}
-    if "--hnsw" in sys.argv:
-        hp = sys.argv[sys.argv.index("--hnsw") + 1]
-        nq = int(sys.argv[sys.argv.index("--hnsw") + 2])
-        f = pick(counters(hp + "_fetch.txt"), "k_hnsw_search_fast")
-        w = pick(counters(hp + "_write.txt"), "k_hnsw_search_fast")
-        if f and w:
-            fk, n = f["FETCH_SIZE"]
-            wk, _ = w["WRITE_SIZE"]
-            doc["kernels"]["k_hnsw_search_fast"] = {"gauss_unit": {
-                "dispatches": n, "queries_per_dispatch": nq,
-                "traffic_bytes_per_launch": int((2.0 * fk + wk) * 1024.0 / n),
-                "traffic_bytes_per_query": int((2.0 * fk + wk) * 1024.0 / n / nq),
-                "source": f"{hp}_{{fetch,write}}.txt"}}
+    a = sys.argv[3:]
+    while a:
+        if a[0] == "--ivf":
+            data, prefix = a[1], a[2]
+            a = a[3:]
+            wl = {"data": data, "nvec": 1000000, "dim": 768, "lists": 1024, "probes": 32, "batch": 4096,
+                  "rows": "f32", "strategy": "l2"}
+            for needle, name in (("k_s16c_sweep", "k_s16c_sweep"), ("k_s16_finalize", "k_s16_finalize"),
+                                 ("k_s16c_seed", "k_s16c_seed")):
+                e = entry(prefix, needle, steps, wl, False)
+                if e:
+                    b = busy(prefix, needle)
+                    if b is not None and name == "k_s16c_sweep":
+                        e["mfma_busy"] = b
+                    doc["kernels"].setdefault(name, {})[data] = e
+        elif a[0] == "--h2":
+            hp, nq = a[1], int(a[2])
+            a = a[3:]
+            f = pick(counters(hp + "_fetch.txt"), "k_h2_search")
+            w = pick(counters(hp + "_write.txt"), "k_h2_search")
+            if f and w:
+                fk, n = f["FETCH_SIZE"]
+                wk, _ = w["WRITE_SIZE"]
+                # (tools/h2_bench.py: one 256-query warm-up launch + one of NQ per ef; traffic is per query over both)
+                doc["kernels"]["k_h2_search"] = {"clustered_unit": {
+                    "dispatches": n, "queries_profiled": nq + 256,
+                    "traffic_bytes_per_query": int((2.0 * fk + wk) * 1024.0 / (nq + 256)),
+                    "workload": {"nvec": 1000000, "dim": 768, "m": 16, "ef": 64},
+                    "source": f"{hp}_{{fetch,write}}.txt"}}
+        else:
+            raise SystemExit("unknown argument " + a[0])
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc["kernels"], indent=1))
 
