@@ -142,7 +142,7 @@ int			ndbhip_set_scan_mode(int mode);
  *                             ONE fp16 plane of each (2 bytes per row element instead of 4); the error term scales with the distances
  *                             to the centre instead of the vectors' norms (csrc/ndbhip_screen16c.h, csrc/ndbhip_common.h (8));
  *                             0: the two-plane sweep over the rows as they are
- *   "screen16c_qb"      0     (query, list) pairs per tile of the centred sweep / 32: 4 | 1, 0 = chosen from the previous batch's pairs per list
+ *   "screen16c_qb"      0     (query, list) pairs per tile of the centred sweep / 32: 8 (256 pairs x 256 rows, 8 waves) | 4 | 1, 0 = chosen from the previous batch's pairs per list
  *   "screen16c_seeds"   0     rows per query whose upper bounds make its first threshold: 32 | 64, 0 = 32 for k <= 20, else 64
  *   "build_prepare"     0     ndbhip_ivf_build / _build_device end with ndbhip_ivf_prepare(ix, this strategy 1 .. 3): the index leaves the
  *                             build searchable at full speed (0: the first batched scan, or an explicit ndbhip_ivf_prepare, pays for it)

@@ -2887,11 +2887,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	/* tile geometry: 8 waves, 256 rows x 128 queries, ring of 3 chunk buffers, one block per CU (default), or
 	 * 4 waves, 128 x 128, ring of 2, two blocks per CU (ndbhip_set_option("screen16_waves", 4)) */
-	const int	s16_rt = cen ? 128 : (g_s16_waves == 8 ? 256 : 128);
-	/* the centred sweep's tile holds 128 pairs, or 32 where the buckets are probed by a handful of queries each (what
-	 * the previous batch on this mirror looked like; before any: regrouped planes mean clustered rows, i.e. few) */
-	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4) ? g_s16c_qb :
-		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : 4) : (ix->s16_sub ? 1 : 4));
+	/* the centred sweep's tile holds 128 pairs; 32 where the buckets are probed by a handful of queries each; 256 pairs
+	 * x 256 rows where they are probed by hundreds and are whole lists (what the previous batch on this mirror looked
+	 * like; before any: regrouped planes mean clustered rows, i.e. few) */
+	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4 || g_s16c_qb == 8) ? g_s16c_qb :
+		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : (ix->s16c_density >= 320.0f && !sub && dimp / S16C_CH >= 2) ? 8 : 4)
+		 : (ix->s16_sub ? 1 : 4));
+	const int	s16_rt = cen ? (c_qb == 8 ? 256 : 128) : (g_s16_waves == 8 ? 256 : 128);
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
 	/* rows of the pair planes: every pair there can be, up to qc_mult x (queries x probes) (at least 65 536; qc_mult starts at 4 and doubles, up to 16, after a batch that did not fit) — sublists
 	 * multiply the pairs of a probed list, the exclusion bounds remove most again; a batch with more than that goes to
@@ -3069,7 +3071,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			const int	nbuf = dimp / S16C_CH < 2 ? 2 : (g_s16c_nbuf ? g_s16c_nbuf : (c_qb == 1 ? 3 : 2));
 
 #define S16C_SWEEP_L(QB, NB, DB)                                                                                     \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB == 1 || NB == 2) ? 2 : 1)), dim3(256), 0, g.stream, \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB != 8 && (QB == 1 || NB == 2)) ? 2 : 1)), dim3(QB == 8 ? 512 : 256), 0, g.stream, \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
@@ -3079,10 +3081,16 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap)
-			if (g_s16_debug == 1)
+			if (g_s16_debug == 1 && c_qb == 8)
+				S16C_SWEEP_L(8, 2, 1);
+			else if (g_s16_debug == 2 && c_qb == 8)
+				S16C_SWEEP_L(8, 2, 2);
+			else if (g_s16_debug == 1)
 				S16C_SWEEP_L(4, 2, 1);
 			else if (g_s16_debug == 2)
 				S16C_SWEEP_L(4, 2, 2);
+			else if (c_qb == 8)
+				S16C_SWEEP_L(8, 2, 0);
 			else if (c_qb == 1 && nbuf == 2)
 				S16C_SWEEP_L(1, 2, 0);
 			else if (c_qb == 1)
@@ -3338,8 +3346,8 @@ ndbhip_set_option(const char *name, int value)
 		g_cent_s16 = value != 0;
 	else if (!strcmp(name, "screen16c_qb"))
 	{
-		if (value != 0 && value != 1 && value != 4)
-			return fail(NDBHIP_ERR_INVALID, "screen16c_qb must be 0 (auto), 1 or 4");
+		if (value != 0 && value != 1 && value != 4 && value != 8)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_qb must be 0 (auto), 1, 4 or 8");
 		g_s16c_qb = value;
 	}
 	else if (!strcmp(name, "screen16_slack"))

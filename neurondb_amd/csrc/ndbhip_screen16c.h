@@ -473,24 +473,35 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 }
 
 /*
- * Geometry.  QB = 32-pair blocks per tile (4: 128 pairs, the dense form; 1: 32 pairs, for batches whose buckets are
- * probed by a handful of queries each — most of a 128-pair tile would be padding, and the LDS it reserves is
- * better spent on a deeper ring, because that regime is bound by the rows' bytes).  4 waves, 128 rows per tile.
+ * Geometry.  QB = 32-pair blocks per tile (4: 128 pairs; 1: 32 pairs, for batches whose buckets are probed by a
+ * handful of queries each — most of a 128-pair tile would be padding, and the LDS it reserves is better spent on a
+ * deeper ring, because that regime is bound by the rows' bytes); 4 waves, 128 rows per tile.  QB = 8 is the dense
+ * form, for buckets with hundreds of pairs AND hundreds of rows (an i.i.d. table: every product is needed, the sweep
+ * is a dense contraction): 8 waves, 256 pairs x 256 rows per tile, a wave owns 64 pairs x 128 rows — per 16 dims 6
+ * ds_read_b128 feed 8 MFMAs (4 feed 4 in the 128 x 128 tile, which ran into the LDS's 128 B/clk: profiles/r03_pmc_gauss_sq),
+ * and a tile's operands (2 x 393 KB) serve 4 x the products of a 128 x 128 tile's (2 x 196 KB): half the bytes per
+ * product through L2 and HBM, which at 4.4 TB/s were the other limit.
  * Wave w = (wq, wr) = (w % NWQ, w / NWQ) owns AQ pair blocks x BR row blocks.
  */
 template <int QB> struct S16CGeom
 {
-	static constexpr int NW = 4;
-	static constexpr int RT = 128;
-	static constexpr int NWQ = QB >= 2 ? 2 : 1;
+	static constexpr int NW = QB == 8 ? 8 : 4;	/* waves per block */
+	static constexpr int RB = QB == 8 ? 8 : 4;	/* 32-row blocks per tile: one per wave and chunk to fetch */
+	static constexpr int RT = 32 * RB;
+	static constexpr int NWQ = QB == 8 ? 4 : (QB >= 2 ? 2 : 1);
 	static constexpr int NWR = NW / NWQ;
 	static constexpr int AQ = QB / NWQ;
-	static constexpr int BR = 4 / NWR;
-	static constexpr int Q_OFF = 4 * 4096;
+	static constexpr int BR = RB / NWR;
+	static constexpr int Q_OFF = RB * 4096;
 	static constexpr int BUF = Q_OFF + QB * 4096;
-	static constexpr int Q_DMA = QB;			/* 1 KiB pieces of the pair area per wave and chunk (4 QB pieces, 4 waves) */
+	static constexpr int Q_DMA = 4 * QB / NW;	/* 1 KiB pieces of the pair area per wave and chunk (4 QB pieces in all) */
 	static constexpr int PER = 4 + Q_DMA;
 	static constexpr int QT = 32 * QB;
+	/* the epilogue keeps one bit per accumulator element in a 64-bit mask: BG row blocks (x AQ pair blocks x 16
+	 * registers) at a time, NG times */
+	static constexpr int BG = 64 / (AQ * 16) < BR ? 64 / (AQ * 16) : BR;
+	static constexpr int NG = (BR + BG - 1) / BG;
+	static_assert(BR % BG == 0, "the epilogue walks the row blocks BG at a time");
 };
 
 /* a 4-byte-per-lane LDS DMA: lane i of the wave copies the dword at base + voff to LDS address la + 4 i */
@@ -517,7 +528,7 @@ s16_dma4(const void *base, uint32_t voff, uint32_t la)
  * g + NBUF - 1 into the buffer everybody has finished reading, 16 ds_read_b128 + 4 AQ BR MFMAs.
  */
 template <int QB, int NBUF, int DBG = 0>
-__global__ __launch_bounds__(256, ((S16CGeom<QB>::BUF * NBUF + 8192) * 2 <= 160 * 1024) ? 2 : 1) void
+__global__ __launch_bounds__(64 * S16CGeom<QB>::NW, ((S16CGeom<QB>::BUF * NBUF + 8192) * 2 <= 160 * 1024) ? 2 : 1) void
 k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
 			 const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
 			 const float *__restrict__ rn2, const int16_t *__restrict__ rexp,
@@ -578,7 +589,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		const S16Desc d = desc[it];			/* uniform address: scalar loads */
 		const uint32_t L = d.L, nmem = min((uint32_t) G::QT, cnt[L] - d.qt * G::QT);
 		const uint32_t nbk = blk_off[L + 1] - blk_off[L];
-		const uint32_t b = min(d.t2 * 4u + (uint32_t) wave, nbk - 1u);
+		const uint32_t b = min(d.t2 * (uint32_t) G::RB + (uint32_t) wave, nbk - 1u);
 		const uint32_t slot0 = pair_off[L] + d.qt * G::QT;
 
 #pragma unroll
@@ -713,6 +724,13 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 							acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
 					}
 				}
+				/* the dense tile's 128 accumulator registers leave room for the operands of two k-steps, not four:
+				 * keep the compiler from hoisting every ds_read of the chunk to its top (it spilled) */
+				if constexpr (QB == 8)
+				{
+					if (s & 1)
+						__builtin_amdgcn_sched_barrier(0);
+				}
 			}
 		};
 
@@ -800,12 +818,17 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		 * right-hand side never exceeds the real one.  NaN anywhere: the comparison is false, the element emitted.
 		 */
 		const float K = (1.0f - cE) * 0.99999905f;
-		/* pass 1: which elements cannot be left out — one bit each, bit (b AQ + a) 16 + reg, no memory traffic */
+		/* (a generic lambda per group of row blocks, not a loop: the group's index must be a compile-time constant for
+		 * the accumulators to stay in registers, and the body is too large for the unroller to be trusted with) */
+		auto		epilogue = [&](auto bgc) {
+		constexpr int bg = decltype(bgc)::value;
+		/* pass 1: which elements cannot be left out — one bit each, bit ((b - BG bg) AQ + a) 16 + reg, no memory traffic */
 		unsigned long long emask = 0;
 
 #pragma unroll
-		for (int b = 0; b < G::BR; b++)
+		for (int bb = 0; bb < G::BG; bb++)
 		{
+			const int	b = bg * G::BG + bb;	/* (BR is a multiple of BG) */
 			const bool	rok = rokr[b];
 
 #pragma unroll
@@ -822,7 +845,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					const float rhs = __builtin_fmaf(n, K, -s_t2[m]);
 
 					if ((DBG ? t1 == 1234.5f : !(t1 < rhs)) && rok && (uint32_t) m < nmem_cur && porr[b] < s_nrow[c_par][m])
-						emask |= 1ull << ((b * G::AQ + a) * 16 + reg);
+						emask |= 1ull << ((bb * G::AQ + a) * 16 + reg);
 				}
 			}
 		}
@@ -865,14 +888,15 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			if (mycnt != 0)
 				base = atomicAdd(&ecount[s_qid[c_par][mym % G::QT]], mycnt);
 #pragma unroll
-			for (int b = 0; b < G::BR; b++)
+			for (int bb = 0; bb < G::BG; bb++)
 #pragma unroll
 			for (int a = 0; a < G::AQ; a++)
 #pragma unroll
 			for (int reg = 0; reg < 16; reg++)
 			{
 				/* (unrolled: the accumulators are registers, an index known only at run time would send them to scratch) */
-				const int	e = (b * G::AQ + a) * 16 + reg;
+				const int	b = bg * G::BG + bb;
+				const int	e = (bb * G::AQ + a) * 16 + reg;
 
 				if (!((anym >> e) & 1ull))
 					continue;			/* uniform */
@@ -923,6 +947,16 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					base += nhi;
 			}
 		}
+		};
+		epilogue(std::integral_constant<int, 0>{});
+		if constexpr (G::NG > 1)
+			epilogue(std::integral_constant<int, 1>{});
+		if constexpr (G::NG > 2)
+		{
+			epilogue(std::integral_constant<int, 2>{});
+			epilogue(std::integral_constant<int, 3>{});
+		}
+		static_assert(G::NG == 1 || G::NG == 2 || G::NG == 4, "groups of row blocks in the epilogue");
 		if constexpr (DBG == 0)
 		{
 			/* a query that keeps emitting has a loose threshold: the k-th smallest bucket minimum bounds its k-th

@@ -111,6 +111,8 @@ def one_case(rng, lib, IvfIndex, check):
     check(lib.ndbhip_set_option(b"screen16_sublists", int(rng.random() < 0.8)))
     check(lib.ndbhip_set_option(b"screen16_prune", int(rng.random() < 0.8)))
     check(lib.ndbhip_set_option(b"screen16_tighten", int(rng.random() < 0.8)))
+    # the centred sweep's tile: chosen by the library, or forced to 32 / 128 pairs x 128 rows, or 256 x 256
+    check(lib.ndbhip_set_option(b"screen16c_qb", int(rng.choice([0, 0, 1, 4, 8, 8]))))
     if os.environ.get("FUZZ_TRACE"):
         print("CASE", dict(dim=dim, n=n, nlists=nlists, nq=nq, kind=kind, k=k, nprobe=nprobe, cap=cap, strategy=strategy,
                            lens=a["list_len"].tolist()), flush=True)
