@@ -701,7 +701,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			na += nmem_cur > (uint32_t) (32 * (G::AQ * wq + a)) ? 1 : 0;
 
 		auto		compute = [&](const unsigned char *buf) {
-			if (na == 0)
+			if (QB != 8 && na == 0)
 				return;
 #pragma unroll
 			for (int s = 0; s < 4; s++)
@@ -717,19 +717,14 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 #pragma unroll
 				for (int a = 0; a < G::AQ; a++)
 				{
-					if (a < na)
+					/* (the dense tile multiplies its empty pair blocks too: without the test the k-steps are straight-line
+					 * code and the next one's ds_reads are issued under this one's MFMAs) */
+					if (QB == 8 || a < na)
 					{
 #pragma unroll
 						for (int b = 0; b < G::BR; b++)
 							acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
 					}
-				}
-				/* the dense tile's 128 accumulator registers leave room for the operands of two k-steps, not four:
-				 * keep the compiler from hoisting every ds_read of the chunk to its top (it spilled) */
-				if constexpr (QB == 8)
-				{
-					if (s & 1)
-						__builtin_amdgcn_sched_barrier(0);
 				}
 			}
 		};
