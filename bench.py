@@ -932,7 +932,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         x = make_data(rows, dim, kind, args.components, args.sigma, seed, 0x5EEDC0DE, dev)
         return x / x.norm(dim=1, keepdim=True)
 
-    def recall_of(ix, base, q, efs, nr=200):
+    def recall_of(ix, base, q, efs, nr=1000):    # (200 queries put the same graph anywhere in 0.88 .. 0.92: profiles/r03_h2_variants.txt)
         sims = q[:nr].double() @ base.double().T
         gt = torch.topk(sims, k, dim=1).indices.cpu().numpy() + 1
         out = {}

@@ -519,7 +519,8 @@ int			ndbhip_hnsw_build_intended_device(ndbhip_hnsw *g, const float *d_rows, con
 int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
 											   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 											   uint64_t *d_out_tids, int64_t *d_out_evals);
-/* bit 0: the heuristic (else the nearest); bit 1: a new node takes up to 2m links at level 0 instead of m.  Default 1. */
+/* bit 0: the heuristic (else the nearest); bit 1: a new node takes up to 2m links at level 0 instead of m; bit 2 (with
+ * bit 0): the places the heuristic leaves empty go to the nearest candidates it passed over (keepPrunedConnections). */
 int			ndbhip_hnsw_set_intended_select(int select);
 
 /* ------------------------------------------------------------------ */

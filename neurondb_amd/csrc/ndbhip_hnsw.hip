@@ -3574,8 +3574,9 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
 extern "C" int
 ndbhip_hnsw_set_intended_select(int select)
 {
-	if (select < 0 || select > 3)
-		return fail(NDBHIP_ERR_INVALID, "select: bit 0 = the heuristic (else the nearest), bit 1 = up to 2m links for a new node at level 0");
+	if (select < 0 || select > 7 || (select & 5) == 4)
+		return fail(NDBHIP_ERR_INVALID, "select: bit 0 = the heuristic (else the nearest), bit 1 = up to 2m links for a new node at level 0, "
+					"bit 2 (with bit 0) = places the heuristic leaves empty go to the nearest candidates it passed over");
 	g_h2_select = select;
 	return NDBHIP_OK;
 }

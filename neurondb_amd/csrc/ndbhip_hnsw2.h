@@ -448,7 +448,7 @@ h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M
 		const double dc = cd[i];
 		bool		ok = true;
 
-		if (select)
+		if (select & 1)
 			for (int j = 0; j < n && ok; j++)
 				if (h2_dist2_rows(g.vecs + (size_t) c * g.dim, g.vecs + (size_t) out[j] * g.dim, g.dim, lane) < dc)
 					ok = false;
@@ -461,6 +461,30 @@ h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M
 			}
 			n++;
 			__threadfence_block();
+		}
+	}
+	if ((select & 5) == 5)
+	{
+		/* keepPrunedConnections: the places left go to the nearest candidates the heuristic passed over, in order */
+		const int	n0 = n;
+
+		for (int i = 0; i < nc && n < M; i++)
+		{
+			const uint32_t c = cid[i];
+			bool		taken = false;
+
+			for (int j = 0; j < n0; j++)
+				taken = taken || out[j] == c;		/* (uniform: every lane reads the same LDS words) */
+			if (!taken)
+			{
+				if (lane == 0)
+				{
+					out[n] = c;
+					outd[n] = cd[i];
+				}
+				n++;
+				__threadfence_block();
+			}
 		}
 	}
 	return n;
@@ -583,7 +607,7 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 			h2_search_layer(g, Q, cur, curd, lc, W, V, lane, evals);
 			V.clear(lane);
 			h2_sort(W, sid, sd, lane);
-			const int	n = h2_select(g, sid, sd, (int) W.nw, (lc == 0 && (select & 2)) ? 2 * g.m : g.m, select & 1, s_selid, s_seld, lane);
+			const int	n = h2_select(g, sid, sd, (int) W.nw, (lc == 0 && (select & 2)) ? 2 * g.m : g.m, select & 5, s_selid, s_seld, lane);
 
 			if (lane == 0)
 			{
@@ -678,7 +702,7 @@ k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups, cons
 			}
 			__threadfence_block();
 			/* ... and what the rule keeps of them */
-			const int	n = h2_select(g, cid, cd, cnt + 1, cap, select & 1, kid, kd, lane);
+			const int	n = h2_select(g, cid, cd, cnt + 1, cap, select & 5, kid, kd, lane);
 
 			for (int j = lane; j < 2 * g.m; j += 64)
 				nb[j] = j < n ? kid[j] : NDBHIP_INVALID_BLOCK;

@@ -275,8 +275,10 @@ typedef struct h2_sel
 	double	   *d2;
 }			h2_sel;
 
-/* the m the new node links to out of the layer search's results (ascending): select 0 = the nearest m; 1 = the
- * textbook heuristic — a candidate is taken unless it is nearer to one already taken than to the new node */
+/* the m the new node links to out of the layer search's results (ascending): select bit 0 clear = the nearest m;
+ * set = the textbook heuristic — a candidate is taken unless it is nearer to one already taken than to the new node;
+ * bit 2 (with bit 0): the places the heuristic leaves empty go to the nearest candidates it passed over, in order
+ * (the paper's keepPrunedConnections: a node inside a tight cluster keeps m links instead of a handful) */
 static int
 h2_select(const ndbo_hnsw *g, const float *base, const uint32_t *cid, const double *cd2, int nc, int M, int select,
 		  uint32_t *out, double *outd)
@@ -289,7 +291,7 @@ h2_select(const ndbo_hnsw *g, const float *base, const uint32_t *cid, const doub
 	{
 		int			ok = 1;
 
-		if (select)
+		if (select & 1)
 			for (j = 0; j < n; j++)
 				if (ndbo_h2_dist2(h2_vec(g, cid[i]), h2_vec(g, out[j]), g->dim) < cd2[i])
 				{
@@ -301,6 +303,25 @@ h2_select(const ndbo_hnsw *g, const float *base, const uint32_t *cid, const doub
 			out[n] = cid[i];
 			outd[n] = cd2[i];
 			n++;
+		}
+	}
+	if ((select & 5) == 5)
+	{
+		const int	n0 = n;
+
+		for (i = 0; i < nc && n < M; i++)
+		{
+			int			taken = 0;
+
+			for (j = 0; j < n0; j++)
+				if (out[j] == cid[i])
+					taken = 1;
+			if (!taken)
+			{
+				out[n] = cid[i];
+				outd[n] = cd2[i];
+				n++;
+			}
 		}
 	}
 	(void) base;
@@ -334,7 +355,7 @@ h2_insert_search(const ndbo_hnsw *g, const float *vec, int level, int select, h2
 	{
 		const int	nw = ndbo_h2_search_layer(g, vec, &cur, &curd, 1, efc, lc, wid, wd, NULL, visited);
 
-		s->n[lc] = h2_select(g, vec, wid, wd, nw, lc == 0 ? m0 : m, select & 1, s->ids + (size_t) lc * w, s->d2 + (size_t) lc * w);
+		s->n[lc] = h2_select(g, vec, wid, wd, nw, lc == 0 ? m0 : m, select & 5, s->ids + (size_t) lc * w, s->d2 + (size_t) lc * w);
 		cur = wid[0];			/* the nearest found is the next level's entry point */
 		curd = wd[0];
 	}
@@ -382,7 +403,7 @@ h2_backlink(ndbo_hnsw *g, uint32_t e, int level, uint32_t x, double dxe, int sel
 		cid[j] = id;
 		n++;
 	}
-	n = h2_select(g, h2_vec(g, e), cid, cd, n, cap, select & 1, kid, kd);
+	n = h2_select(g, h2_vec(g, e), cid, cd, n, cap, select & 5, kid, kd);
 	for (i = 0; i < 2 * g->m; i++)
 		nb[i] = i < n ? kid[i] : NDBO_INVALID_BLOCK;
 	*pc = (int16_t) n;

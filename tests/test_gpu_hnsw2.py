@@ -32,7 +32,9 @@ def _data(kind, n, dim, nq, seed):
     ("normal", 1500, 48, 8, 40, 64, 1024, 1), ("clustered", 2500, 64, 16, 64, 16, 256, 1),
     ("integer", 1200, 40, 6, 32, 8, 64, 1), ("normal", 900, 100, 16, 200, 1, 1, 1),
     ("clustered", 2000, 64, 16, 64, 32, 512, 0), ("normal", 1100, 1100, 8, 24, 64, 1024, 1),
-    ("clustered", 2500, 64, 16, 64, 16, 256, 3), ("normal", 1300, 48, 8, 40, 64, 1024, 2)])
+    ("clustered", 2500, 64, 16, 64, 16, 256, 3), ("normal", 1300, 48, 8, 40, 64, 1024, 2),
+    ("clustered", 2500, 64, 16, 64, 16, 256, 5), ("clustered", 2200, 64, 8, 48, 32, 512, 7),
+    ("integer", 1200, 40, 6, 32, 8, 64, 7)])
 def test_intended_build_and_search_equal_the_oracle(kind, n, dim, m, efc, bdiv, bmax, select):
     from neurondb_amd import HnswIndex, _lib
     from oracle import ndbo
