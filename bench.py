@@ -933,6 +933,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         return x / x.norm(dim=1, keepdim=True)
 
     def recall_of(ix, base, q, efs, nr=1000):    # (200 queries put the same graph anywhere in 0.88 .. 0.92: profiles/r03_h2_variants.txt)
+        nr = min(nr, len(q))
         sims = q[:nr].double() @ base.double().T
         gt = torch.topk(sims, k, dim=1).indices.cpu().numpy() + 1
         out = {}
