@@ -1644,6 +1644,7 @@ struct ndbhip_ivf
 	bool		dm_cent_valid = false;
 	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
+	float	   *d_cn2 = nullptr;	size_t d_cn2_n = 0;		/* [ncent] |centroid|^2 (the inner product's sublist bound) */
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
 	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
@@ -1744,7 +1745,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2582,7 +2583,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 	const int	nc = ix->ncent;
 	/* sublists only pay where a bound can exclude them: L2 (an index has one operator class, hence one strategy;
 	 * a caller that alternates strategies on one mirror has its planes laid out again at every change) */
-	const int	sub_cfg = (g_s16_sublists && g_s16_prune && R == R_IVF_L2) ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
+	const int	sub_cfg = (g_s16_sublists && g_s16_prune && (R == R_IVF_L2 || R == R_IVF_IP)) ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
 
 	/* L2 on float4 rows: the planes hold the rows minus their bucket's centre, one fp16 plane (ndbhip_screen16c.h) */
 	const bool	cen = ivf_s16_centered(ix, R);
@@ -2699,6 +2700,9 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		else
 			hipLaunchKernelGGL(k_s16_list_radius<2>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim,
 							   (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
+		/* |centroid|^2: the inner product's sublist bound turns |q - c|^2 into q.c with it */
+		if (grow(ix->d_cn2, ix->d_cn2_n, (size_t) nc)) return NDBHIP_ERR_HIP;
+		hipLaunchKernelGGL(k_vec_norm2, dim3((nc + 3) / 4), dim3(256), 0, g.stream, (const float *) ix->d_centroids, nc, dim, ix->d_cn2);
 		HIP_TRY(hipGetLastError());
 		ix->s16_valid = true;
 	}
@@ -2829,7 +2833,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	} while (0)
 #define S16_SEED_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
 	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
-	const bool	seed_by_sublist = ix->s16_sub && R == R_IVF_L2 && g_s16_prune && ix->nsub_g > 0;
+	const bool	seed_by_sublist = ix->s16_sub && (R == R_IVF_L2 || (R == R_IVF_IP && cdist)) && g_s16_prune && ix->nsub_g > 0;
 
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
@@ -2956,7 +2960,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		const uint8_t *drop = nullptr;
 		const float *pdist = nullptr;
 
-		const bool	prune = R == R_IVF_L2 && g_s16_prune;
+		/* inner product: sublists are excluded by -(q.c) - |q| rad (k_sub_pairs); that needs the centroid scan's
+		 * distances of this call */
+		const bool	prune = g_s16_prune && (R == R_IVF_L2 || (R == R_IVF_IP && sub && cdist));
+		const int	ipb = R == R_IVF_IP ? 1 : 0;
 
 		if (prune && !(sub && cdist))
 		{
@@ -2989,6 +2996,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
 									   (const uint32_t *) ix->d_pposof,
 									   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
+				else if (ipb)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_IP>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
+								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
+								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
+								   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
+								   (const uint32_t *) ix->d_xmax16, ix->w_qthr, 0, (const float *) ix->dm_sub.rn2,
+								   (const float *) ix->d_cn2);
 				else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_L2>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
 								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -3004,12 +3019,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 						return rc2;
 				}
 			}
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
-							   (PairRec *) nullptr);
+							   (PairRec *) nullptr, ipb, (const float *) ix->dm_sub.rn2, (const float *) ix->d_cn2);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -3018,11 +3033,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0,
 						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr);
 		if (sub)
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3((nq + 3) / 4), dim3(256), 0, g.stream, w_probes, lco,
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs);
+							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs,
+							   ipb, (const float *) ix->dm_sub.rn2, (const float *) ix->d_cn2);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);

@@ -512,6 +512,40 @@ s16_sub_excluded(float d, uint32_t rad_bits, float te)
 	return lb > 0.0 && lb * lb * (1.0 - 1e-9) > (double) te && te >= 0.0f;	/* NaN / inf: false */
 }
 
+/* Inner product: the reference's value of a row is -(q.x) and -(q.x) = -(q.c) - q.(x - c) >= -(q.c) - |q| rad for every row
+ * of a sublist with centre c and radius rad, where q.c = (|q|^2 + |c|^2 - |q - c|^2) / 2.  alo = a lower bound of
+ * |q - c|^2 (the matrix-core sweep's a - e, or the centroid scan's float4 distance squared and shaved), q2 and c2 the
+ * norms as stored (fp64 sums rounded to fp32: relative 2^-24 each).  The sublist is left out when that lower bound
+ * exceeds thrE = thr + e, the reference value bounding the k-th from above plus the query's error term (which covers
+ * the reference's own rounding gamma |q||x|: a row with true value > thrE has a reference value > thr). */
+__device__ __forceinline__ bool
+s16_sub_excluded_ip(double alo, float q2, float c2, uint32_t rad_bits, float thrE)
+{
+	const double lbdot = 0.5 * (alo - ((double) q2 + (double) c2) * (1.0 + 3e-7));
+	const double qn = __builtin_sqrt((double) q2) * (1.0 + 1e-7);
+	const double lb = lbdot - qn * (double) __uint_as_float(rad_bits);
+
+	return lb - __builtin_fabs(lb) * 1e-9 - 1e-30 > (double) thrE;	/* NaN / inf anywhere: false */
+}
+
+/* vectors' squared norms (fp64 sums, stored as fp32): one wave each */
+__global__ __launch_bounds__(256) void
+k_vec_norm2(const float *__restrict__ v, int n, int dim, float *__restrict__ out)
+{
+	const int	lane = threadIdx.x & 63;
+	const int	i = blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (i >= n)
+		return;
+	double		s = 0.0;
+
+	for (int j = lane; j < dim; j += 64)
+		s += (double) v[(size_t) i * dim + j] * (double) v[(size_t) i * dim + j];
+	s = wave_sum_f64(s);
+	if (lane == 0)
+		out[i] = s <= 3.0e38 ? (float) s : __uint_as_float(0x7FC00000u);
+}
+
 /* (query, probe) -> the sublists of the probed list that stay.  The distance of the query to the sublist's centre is
  * the centroid scan's own value (cdist, the reference's float4 distance, shaved by 1e-3) or pdist[q][p]
  * (k_s16_pair_prune, when the probes came from elsewhere) for a list that is its own single sublist; for the sublists of a
@@ -528,11 +562,21 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			uint32_t cstride, const float *__restrict__ qn2, const uint32_t *__restrict__ cxmax_bits, int dim,
 			const unsigned int *__restrict__ active,
 			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
-			PairRec *__restrict__ pairs)
+			PairRec *__restrict__ pairs, int ip = 0 /* inner product: s16_sub_excluded_ip, with ... */,
+			const float *__restrict__ cn2_sub = nullptr /* ... |c|^2 of the regrouped lists' centres (by gidx) */,
+			const float *__restrict__ cn2_list = nullptr /* ... and of the lists' centroids */ )
 {
-	/* one wave per query; its probes one after the other, a list's sublists spread over the lanes */
-	const int	lane = threadIdx.x & 63;
-	const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+	/* One block (4 waves) per query.  The (probe, sublist) tests of 64 probes at a time are laid end to end and dealt to
+	 * the block's 256 lanes (every wave works the same prefix out for itself: lane p learns where probe p's sublists
+	 * start and how many there are, a prefix sum over the lanes gives every test its number, and a test finds its probe
+	 * by bisection over the 64 starts in LDS).  The kernel is a chain of dependent loads per test (sublist -> centre
+	 * index -> distance) and every wave of a 4096-query batch is resident at once, so its time is the LONGEST WAVE's:
+	 * one wave per query walking its probes one after the other took 89 + 77 us (count + fill), 64 lanes over the
+	 * flattened tests 71 + 66 us, 256 lanes what is measured now. */
+	__shared__ uint32_t s_off[4][65], s_s0[4][64];
+	__shared__ float s_pd[4][64], s_c2[4][64];
+	const int	lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t q = blockIdx.x;
 
 	if (q >= nq || (active && !active[q]))
 		return;
@@ -541,34 +585,87 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	/* error of the centre distances: the sweep's own bound with the largest centre norm in the rows' place */
 	const float ec = prune ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
 
-	for (int p = 0; p < npr; p++)
+	for (int p0 = 0; p0 < npr; p0 += 64)
 	{
-		if (co[p + 1] == co[p])
-			continue;
-		const int	L = probes[(size_t) q * npr + p];
-		const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
-		const float pd = !prune ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
+		const int	p = p0 + lane;
+		uint32_t	n = 0, s0 = 0;
+		float		pd = 0.0f, c2l = 0.0f;
 
-		for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
+		if (p < npr && co[p + 1] != co[p])
 		{
+			const int	L = probes[(size_t) q * npr + p];
+
+			s0 = sub_first[L];
+			n = sub_first[L + 1] - s0;
+			pd = !prune ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
+			if (ip && prune)
+				c2l = cn2_list[L];
+		}
+		/* inclusive prefix sum of n over the lanes */
+		uint32_t	inc = n;
+
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t v = (uint32_t) __shfl_up((int) inc, off, 64);
+
+			if (lane >= off)
+				inc += v;
+		}
+		s_off[w][lane] = inc - n;
+		s_s0[w][lane] = s0;
+		s_pd[w][lane] = pd;
+		s_c2[w][lane] = c2l;
+		const uint32_t T = (uint32_t) __shfl((int) inc, 63, 64);
+
+		if (lane == 0)
+			s_off[w][64] = T;
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t t = (uint32_t) threadIdx.x; t < T; t += 256)
+		{
+			/* the probe whose tests include number t: the last lane pl with s_off[pl] <= t (empty probes share their
+			 * successor's start and are skipped by "last") */
+			int			lo = 0, hi = 64;
+
+			while (hi - lo > 1)
+			{
+				const int	mid = (lo + hi) >> 1;
+
+				if (s_off[w][mid] <= t)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			const uint32_t s = s_s0[w][lo] + (t - s_off[w][lo]);
+
 			if (sub_len[s] == 0)
 				continue;
 			const int	gi = sub_gidx[s];
 
-			if (prune && (gi < 0 ? s16_sub_excluded(pd, sub_rad[s], te)
-						  : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
+			if (prune && ip)
+			{
+				const double pdl = (double) s_pd[w][lo];
+				const double alo = gi < 0 ? pdl * pdl * (1.0 - 1e-4)
+					: (double) subdist[(size_t) q * sstride + gi] - (double) ec * (1.0 + 1e-6);
+
+				if (s16_sub_excluded_ip(alo, qn2[q], gi < 0 ? s_c2[w][lo] : cn2_sub[gi], sub_rad[s], te))
+					continue;
+			}
+			else if (prune && (gi < 0 ? s16_sub_excluded(s_pd[w][lo], sub_rad[s], te)
+							   : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
 				continue;
 			if (FILL)
 			{
 				PairRec		r;
 
 				r.q = q;
-				r.p = (uint32_t) p;
+				r.p = (uint32_t) (p0 + lo);
 				pairs[pair_off[s] + atomicAdd(&fill[s], 1u)] = r;
 			}
 			else
 				atomicAdd(&cnt[s], 1u);
 		}
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -916,7 +1013,7 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of, const float *__restrict__ subdist,
 			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ cdist, uint32_t cstride,
 			   const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr,
-			   int cen = 0)
+			   int cen = 0, const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr)
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x;
@@ -943,7 +1040,12 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			if (sub_len[s] < k)
 				continue;
 			const int	gi = sub_gidx[s];
-			const float dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+			float		dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+
+			/* inner product: "nearest" = the largest q.c = (|q|^2 + |c|^2 - |q - c|^2) / 2 (any choice is valid;
+			 * this one finds the query's own neighbourhood) */
+			if (R == R_IVF_IP && cn2_sub)
+				dd = dd - (gi < 0 ? cn2_list[L] : cn2_sub[gi]);
 
 			if (dd < bd)
 			{

@@ -10,4 +10,4 @@ f=$(find /tmp/prof_$tag -name "*.db" | head -1)
 if [ -z "$f" ]; then echo "no db for $tag"; grep -v amdgpu /tmp/prof_$tag.log | tail -8; exit 0; fi
 python3 $GRAFT_REPO_ROOT/tools/rocpd_summary.py $f 40 > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.txt </dev/null
 cp /tmp/prof_$tag.json $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_bench_line.json
-head -30 $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.txt | cut -c1-150
+head -${PROF_LINES:-30} $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.txt | cut -c1-150
