@@ -2599,7 +2599,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		g.stats.prepares++;
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = lay_cfg;
-		if (sub_cfg != 0 && !ix->f16)
+		if (sub_cfg != 0)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
 			const int	rc = ivf_s16_build_sublists(ix, bo, cen && g_s16_slack != 0);
@@ -2996,21 +2996,17 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
 									   (const uint32_t *) ix->d_pposof,
 									   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
-				else if (ipb)
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_IP>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
-								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
-								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
-								   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-								   (const uint32_t *) ix->d_xmax16, ix->w_qthr, 0, (const float *) ix->dm_sub.rn2,
-								   (const float *) ix->d_cn2);
 				else
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<R_IVF_L2>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco,
-								   npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-								   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
-								   (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
-								   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-								   (const uint32_t *) ix->d_xmax16, ix->w_qthr, cen ? 1 : 0);
+				{
+#define S16_SEEDSUB_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
+					S16_BY_RH(S16_SEEDSUB_L, d, d_q, w_probes, lco,
+							  npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+							  (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
+							  (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
+							  (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
+							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, 0, ipb ? (const float *) ix->dm_sub.rn2 : (const float *) nullptr,
+							  ipb ? (const float *) ix->d_cn2 : (const float *) nullptr, H == 1 ? 1 : 0);
+				}
 				if (g_thr_hook)
 				{
 					const int	rc2 = g_thr_hook((float *) ix->w_qthr, (size_t) 2 * nq);

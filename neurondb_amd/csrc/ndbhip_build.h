@@ -1955,11 +1955,42 @@ k_s16_mid_sort(const MidDesc *__restrict__ md, const uint32_t *__restrict__ mrow
  * (row-weighted mean sublist radius < 0.6 x the list's own).  Outputs the d_sub_* tables, the planes' order (d_perm, d_posof) and bo = first 32-row block of every
  * sublist.  Leaves ix->s16_sub false when no list is long enough.
  */
+/* an fp16 mirror's rows as the reference decodes them (fp16_to_float, quirk Q20 for subnormals): the values the
+ * exact arithmetic sees, so radii measured on them are radii of what is scored */
+__global__ void
+k_rows_decode_f16(const uint16_t *__restrict__ src, size_t n, float *__restrict__ out)
+{
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (i < n)
+		out[i] = h2f_ref(src[i]);
+}
+
 static int
 ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 {
 	const int	nc = ix->ncent, dim = ix->dim;
 	std::vector<int> giant, midl;
+	/* an fp16 mirror is regrouped on a transient fp32 copy of its decoded rows (the copy goes when this returns;
+	 * the planes, the seeds and the exact re-score read the fp16 rows themselves) */
+	struct Rows32
+	{
+		float	   *p = nullptr;
+		~Rows32() { if (p) big_free(p); }
+	}			dec;
+	const float *vecs32 = (const float *) ix->d_vecs;
+
+	if (ix->f16)
+	{
+		const size_t ne = (size_t) ix->nrows * dim;
+
+		if (ne == 0)
+			return 0;
+		if (big_alloc((void **) &dec.p, ne * sizeof(float))) return NDBHIP_ERR_HIP;
+		hipLaunchKernelGGL(k_rows_decode_f16, dim3((unsigned) ((ne + 255) / 256)), dim3(256), 0, g.stream,
+						   (const uint16_t *) ix->d_vecs, ne, dec.p);
+		vecs32 = dec.p;
+	}
 
 	for (int c = 0; c < nc; c++)
 		if (ix->own_len[c] > (int64_t) g_s16_sub_min)
@@ -1975,7 +2006,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 	/* the lists' own radii (around their centroids): what regrouping has to beat */
 	if (grow(ix->d_lrad, ix->d_lrad_n, (size_t) nc)) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipMemsetAsync(ix->d_lrad, 0, (size_t) nc * sizeof(uint32_t), g.stream));
-	hipLaunchKernelGGL(k_s16_list_radius<0>, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const void *) ix->d_vecs,
+	hipLaunchKernelGGL(k_s16_list_radius<0>, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const void *) vecs32,
 					   ix->nrows, dim, (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
 	std::vector<float> lrad((size_t) nc);
 
@@ -2081,9 +2112,9 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 		HIP_TRY(hipMemcpyAsync(d_mwhich, which.data(), mid_cents * 8, hipMemcpyHostToDevice, g.stream));
 		HIP_TRY(hipMemsetAsync(d_mrad, 0, mid_cents * 4, g.stream));
 		HIP_TRY(hipMemsetAsync(d_mcnt, 0, mid_cents * 4, g.stream));
-		hipLaunchKernelGGL(k_rows_gather, dim3((unsigned) mid_cents), dim3(256), 0, g.stream, (const float *) ix->d_vecs, dim,
+		hipLaunchKernelGGL(k_rows_gather, dim3((unsigned) mid_cents), dim3(256), 0, g.stream, vecs32, dim,
 						   (const int64_t *) d_mwhich, d_mcents);
-		hipLaunchKernelGGL(k_s16_mid_assign, dim3((unsigned) ((mid_rows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
+		hipLaunchKernelGGL(k_s16_mid_assign, dim3((unsigned) ((mid_rows + 3) / 4)), dim3(256), 0, g.stream, vecs32,
 						   dim, (const MidDesc *) d_md, (const uint32_t *) d_mro, nmid, (const float *) d_mcents, d_msid, d_mrad, d_mcnt);
 		hipLaunchKernelGGL(k_s16_mid_sort, dim3((unsigned) nmid), dim3(256), 0, g.stream, (const MidDesc *) d_md,
 						   (const uint32_t *) d_mro, (const uint8_t *) d_msid, d_msorted);
@@ -2140,7 +2171,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 	{
 		const int64_t len = ix->own_len[c], row0 = ix->loc_off[c];
 		const int	S = (int) nsub_of[(size_t) c];
-		const float *lrows = ix->d_vecs + (size_t) row0 * dim;
+		const float *lrows = vecs32 + (size_t) row0 * dim;
 		float	   *cents = d_cents + cbase * (size_t) dim;
 		std::vector<int64_t> which((size_t) S);
 		std::vector<uint32_t> rad((size_t) S);
@@ -2284,7 +2315,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 	HIP_TRY(hipMemcpyAsync(ix->d_sub_gidx, sub_gidx.data(), nsub * 4, hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemcpyAsync(ix->d_sub_cptr, cptr.data(), nsub * sizeof(const float *), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemsetAsync(ix->d_sub_rad, 0, nsub * 4, g.stream));
-	hipLaunchKernelGGL(k_s16_sub_radius, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
+	hipLaunchKernelGGL(k_s16_sub_radius, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, vecs32,
 					   ix->nrows, dim, (const int64_t *) ix->d_sub_loc, (int) nsub, (const int64_t *) ix->d_perm,
 					   (const float *const *) ix->d_sub_cptr, ix->d_sub_rad);
 	/* the centres of the regrouped lists as one list of the matrix-core sweep: planes, norms, exponents */

@@ -1005,7 +1005,7 @@ k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
  * rule (the k-th smallest of distinct candidates bounds the k-th distance); without such a sublist, k_s16_seed's
  * own candidates.  One wave per query.
  */
-template <int R>
+template <int R, int H16 = 0>
 __global__ __launch_bounds__(64) void
 k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 			   const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, const uint32_t *__restrict__ sub_first,
@@ -1013,13 +1013,14 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   const int64_t *__restrict__ perm, const uint32_t *__restrict__ pos_of, const float *__restrict__ subdist,
 			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ cdist, uint32_t cstride,
 			   const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr,
-			   int cen = 0, const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr)
+			   int cen = 0, const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr,
+			   int e_sub = 0 /* the mirror holds fp16 subnormals (s16_e) */ )
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x;
 	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
 	const int	dim = ix.dim;
-	const float e = s16_e<R>(dim, qn2[q], __uint_as_float(*xmax_bits), false);
+	const float e = s16_e<R>(dim, qn2[q], __uint_as_float(*xmax_bits), e_sub != 0);
 	float		bd = __uint_as_float(0x7F800000u);
 	uint32_t	bs = 0xFFFFFFFFu, bp = 0;
 
@@ -1084,7 +1085,12 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 
 			ok = pos_of[prow] < vis;			/* a candidate of this (query, probe) under the candidate cap */
 			if (ok)
-				v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + (size_t) perm[prow] * (size_t) dim, dim);
+			{
+				if (H16)
+					v = scr_exact_h<R, H16 == 1>(queries + (size_t) q * dim, (const uint16_t *) ix.vecs + (size_t) perm[prow] * (size_t) dim, dim);
+				else
+					v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + (size_t) perm[prow] * (size_t) dim, dim);
+			}
 		}
 	}
 	if (__ballot(ok) == 0 || (uint32_t) __popcll(__ballot(ok)) < k)
@@ -1101,7 +1107,10 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			const int	L = probes[(size_t) q * npr + p];
 			const size_t row = (size_t) ix.loc_off[L] + ((uint32_t) lane - lco[p]);
 
-			v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + row * (size_t) dim, dim);
+			if (H16)
+				v = scr_exact_h<R, H16 == 1>(queries + (size_t) q * dim, (const uint16_t *) ix.vecs + row * (size_t) dim, dim);
+			else
+				v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + row * (size_t) dim, dim);
 		}
 	}
 	const uint32_t key = ok ? ndb_key_from_bits(__float_as_uint(v)) : 0xFFFFFFFFu;

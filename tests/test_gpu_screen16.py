@@ -243,9 +243,11 @@ def test_list_level_pruning_drops_pairs_and_changes_nothing(lib):
     ix.close()
 
 
-@pytest.mark.parametrize("strategy,cap,nprobe,dim", [(1, 0, 6, 64), (1, 40, 6, 64), (3, 0, 4, 64), (1, 0, 14, 64),
-                                                      (1, 0, 6, 100), (1, 0, 5, 33), (3, 40, 6, 64), (3, 0, 14, 100)])
-def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, dim, lib):
+@pytest.mark.parametrize("strategy,cap,nprobe,dim,rowtype", [
+    (1, 0, 6, 64, "f32"), (1, 40, 6, 64, "f32"), (3, 0, 4, 64, "f32"), (1, 0, 14, 64, "f32"), (1, 0, 6, 100, "f32"),
+    (1, 0, 5, 33, "f32"), (3, 40, 6, 64, "f32"), (3, 0, 14, 100, "f32"),
+    (3, 0, 4, 64, "f16"), (1, 0, 6, 64, "f16"), (3, 40, 6, 128, "f16"), (3, 0, 5, 64, "f16sub")])
+def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, dim, rowtype, lib):
     """screen16_sublists with the threshold lowered to 300 rows: lists that mix several tight clusters are regrouped
     inside the planes (and a list of unstructured rows is not), (query, probe) pairs expand to sublists, seeds come
     from the nearest sublist.  Results must be the oracle's with and without it: positions, the k*10 candidate cap
@@ -266,11 +268,31 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
         rows.append(r)
         lens.append(len(r))
     rows = np.concatenate(rows)
-    cents = np.stack([rows[sum(lens[:L]):sum(lens[:L + 1])].mean(0) for L in range(nlists)]).astype(np.float32)
     from oracle import ndbo
+    half = None
+    if rowtype != "f32":
+        # a halfvec column: the rows ARE fp16 values (f16sub: some of them fp16 subnormals, which the reference decodes
+        # 2^-10 too small, quirk Q20); the oracle sees them as the reference decodes them
+        if rowtype == "f16sub":
+            rows[::7, 3] = np.float32(3e-6)
+        half = rows.astype(np.float16).view(np.uint16)
+        Lo = ndbo.lib()
+        lut = np.array([Lo.ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+        rows = lut[half]
+    cents = np.stack([rows[sum(lens[:L]):sum(lens[:L + 1])].mean(0) for L in range(nlists)]).astype(np.float32)
     a = dict(centroids=cents, list_len=np.asarray(lens, np.int64), rows=rows, tids=ndbo.tids_from_rows(np.arange(len(rows))))
     img = oracle_image(a)
     nq, k = 180, 10
+
+    def make_index():
+        if half is None:
+            return _index(a)
+        from neurondb_amd import IvfIndex
+        ix = IvfIndex(dim, nlists)
+        ix.set_centroids(cents)
+        ix.load_f16(a["list_len"], half, a["tids"])
+        return ix
+
     q = (rows[rng.integers(0, len(rows), nq)] + 0.02 * rng.standard_normal((nq, dim))).astype(np.float32)
     et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
     lib.check(lib.lib().ndbhip_set_scan_mode(5))
@@ -278,7 +300,7 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
         for sublists in (1, 0):
             lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", sublists))
             lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 300))
-            ix = _index(a)
+            ix = make_index()
             lib.check(lib.lib().ndbhip_stats_reset())
             t, d, c = ix.search(q, strategy, nprobe, k, cap)
             st = lib.stats()
@@ -287,6 +309,9 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
             if sublists and cap == 0 and dim == 64:
                 # many sublists of the probed lists are excluded: |q - c| - radius (L2), -(q.c) - |q| radius (inner product)
                 assert st["rows_swept"] < st["rows_scored"] * 2 // 3, st
+            if half is not None:
+                ix.close()
+                continue
             # the mirror changes: an append invalidates the planes, the next batch regroups again
             ix.append(2, rows[5] + np.float32(0.001), ndbo.tids_from_rows(np.asarray([len(rows)]))[0])
             t2, d2, c2 = ix.search(q[:140], strategy, nprobe, k, cap)
