@@ -131,7 +131,7 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen16"          1   ... on the fp16 matrix cores (0 = the fp32 bound pass)
  *   "screen16_records"  8192  candidates a query may emit before it is swept again / its batch falls back
  *   "screen16_prune"    1     L2: a (query, list) pair whose |q - centroid| - list radius already exceeds the query's threshold is not swept
- *   "screen16_sublists" 1     L2, float4 rows: lists longer than "screen16_sub_min" (256) rows are regrouped, inside the library's
+ *   "screen16_sublists" 1     L2 and inner product, float4 and fp16 rows: lists longer than "screen16_sub_min" (256) rows are regrouped, inside the library's
  *                             own copy of the rows, into sublists of about "screen16_sub_rows" (128) rows — kept per list only
  *                             where that shrinks the radius — and a (query, probe) pair expands only to the sublists the
  *                             triangle inequality cannot exclude (csrc/ndbhip_screen16.h, "Sublists")
