@@ -1645,6 +1645,11 @@ struct ndbhip_ivf
 	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	float	   *d_cn2 = nullptr;	size_t d_cn2_n = 0;		/* [ncent] |centroid|^2 (the inner product's sublist bound) */
+	/* centred planes: rows of every bucket IN THE PLANES (holes of deleted rows included: the list's own length shrinks,
+	 * the bucket's does not) when the buckets are the lists themselves (regrouped planes keep that in d_sub_len), and the
+	 * list every bucket belongs to */
+	uint32_t   *d_plen = nullptr;	size_t d_plen_n = 0;
+	uint32_t   *d_bucket_list = nullptr;	size_t d_bucket_list_n = 0;
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
 	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
@@ -1745,7 +1750,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2354,6 +2359,43 @@ k_delete_list_len(const uint32_t *__restrict__ pref, const int64_t *__restrict__
 		new_len[L] = (int64_t) pref[loc_off[L + 1]] - (int64_t) pref[loc_off[L]];
 }
 
+/* Centred planes after a delete: the planes keep the deleted rows as HOLES (position 0xFFFFFFFF: no candidate cap
+ * reaches it, so the sweep never emits it and the seeds skip it) and every surviving row learns its new index in its
+ * list — old index minus the deleted rows before it, which the compaction's own prefix sums give: pref[r] = new mirror
+ * row of old row r.  One thread per padded plane row. */
+__global__ void
+k_s16c_delete_fix(const int64_t *__restrict__ prow_off, int nb, const uint32_t *__restrict__ plen,
+				  const uint32_t *__restrict__ bucket_list, const int64_t *__restrict__ loc_off_old,
+				  const uint8_t *__restrict__ keep, const uint32_t *__restrict__ pref, uint32_t *__restrict__ pposof)
+{
+	const int64_t pp = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (pp >= prow_off[nb])
+		return;
+	int			lo = 0, hi = nb;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (prow_off[mid] <= pp)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < nb && prow_off[lo + 1] <= pp)
+		lo++;
+	if (pp - prow_off[lo] >= (int64_t) plen[lo])
+		return;					/* spare rows */
+	const uint32_t p = pposof[pp];
+
+	if (p == 0xFFFFFFFFu)
+		return;					/* a hole already */
+	const int64_t l0 = loc_off_old[bucket_list[lo]], r = l0 + p;
+
+	pposof[pp] = keep[r] ? pref[r] - pref[l0] : 0xFFFFFFFFu;
+}
+
 extern "C" int
 ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *removed)
 {
@@ -2426,6 +2468,23 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 		hipLaunchKernelGGL(k_delete_move, dim3((unsigned) std::min<int64_t>(nrows, 1 << 23)), dim3(256), 0, g.stream,
 						   (const uint8_t *) d_keep, (const uint32_t *) d_pref, (const uint32_t *) ix->d_vecs,
 						   (const uint64_t *) ix->d_tids, (uint32_t *) nv, nt, row_words, (size_t) nrows);
+		/* centred planes stay: holes for the deleted rows, new list positions for the others (the lists' radii remain
+		 * upper bounds; a bucket emptied of live rows simply emits nothing) */
+		const bool	planes_stay = ix->s16_valid && ix->s16_cen_layout && ix->d_plen && ix->d_bucket_list &&
+			!ix->s16_prow.empty();
+
+		if (planes_stay)
+		{
+			const int	nbk = (int) ix->s16_prow.size() - 1;
+			const int64_t npp = ix->s16_prow.back();
+
+			if (npp > 0)
+				hipLaunchKernelGGL(k_s16c_delete_fix, dim3((unsigned) ((npp + 255) / 256)), dim3(256), 0, g.stream,
+								   (const int64_t *) ix->d_prow_off, nbk,
+								   ix->s16_sub ? (const uint32_t *) ix->d_sub_len : (const uint32_t *) ix->d_plen,
+								   (const uint32_t *) ix->d_bucket_list, (const int64_t *) ix->d_loc_off, (const uint8_t *) d_keep,
+								   (const uint32_t *) d_pref, ix->d_pposof);
+		}
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(g.stream));
 		ivf_free_rows(ix);
@@ -2436,7 +2495,10 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 		ix->own_rows = true;
 		ix->cap_rows = cap;
 		ix->nrows = (int64_t) total;
-		ix->norm_valid = false; ix->s16_valid = false;
+		ix->norm_valid = false;
+		ix->s16_valid = planes_stay;	/* (ivf_free_rows has just cleared it) */
+		if (planes_stay)
+			g.stats.prepare_updates++;
 		rc = ivf_set_layout(ix, newlen.data(), nullptr, (int64_t) total);
 	}
 	if (removed)
@@ -2651,7 +2713,27 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			if (grow(ix->d_pposof, ix->d_pposof_n, (size_t) (nb + 8) * 32)) return NDBHIP_ERR_HIP;
 			HIP_TRY(hipMemcpyAsync(ix->d_prow_off, po.data(), (nbk + 1) * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
 			HIP_TRY(hipMemsetAsync(ix->d_pposof, 0xFF, (size_t) (nb + 8) * 32 * sizeof(uint32_t), g.stream));
-			HIP_TRY(hipStreamSynchronize(g.stream));		/* po is a local */
+			/* bucket -> list, and the buckets' row counts in the planes (what a delete must not shrink) */
+			std::vector<uint32_t> blist(nbk);
+
+			if (ix->s16_sub)
+			{
+				std::vector<uint32_t> first((size_t) nc + 1);
+
+				HIP_TRY(hipMemcpyAsync(first.data(), ix->d_sub_first, ((size_t) nc + 1) * 4, hipMemcpyDeviceToHost, g.stream));
+				HIP_TRY(hipStreamSynchronize(g.stream));
+				for (int c = 0; c < nc; c++)
+					for (uint32_t b2 = first[(size_t) c]; b2 < first[(size_t) c + 1] && b2 < nbk; b2++)
+						blist[b2] = (uint32_t) c;
+			}
+			else
+				for (size_t b2 = 0; b2 < nbk; b2++)
+					blist[b2] = (uint32_t) b2;
+			if (grow(ix->d_bucket_list, ix->d_bucket_list_n, nbk)) return NDBHIP_ERR_HIP;
+			if (grow(ix->d_plen, ix->d_plen_n, nbk)) return NDBHIP_ERR_HIP;
+			HIP_TRY(hipMemcpyAsync(ix->d_bucket_list, blist.data(), nbk * 4, hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipMemcpyAsync(ix->d_plen, ix->s16_blen.data(), nbk * 4, hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));		/* po, blist are locals */
 		}
 		const size_t blk_bytes = cen ? (size_t) (dimp / S16C_CH) * 4096 : (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
 
@@ -2769,10 +2851,10 @@ ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vect
 					   dim, dimp, (const S16CApp *) d_recs, (uint32_t) recs.size(), (const float *) ix->d_centroids,
 					   ix->s16_sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr, ix->d_planes,
 					   ix->d_rn2, ix->d_rexp, ix->d_pposof, ix->s16_sub ? ix->d_sub_rad : (uint32_t *) nullptr, ix->d_lrad);
-	if (ix->s16_sub)
-		/* the sweep sees the sublists as its lists: their lengths are its own table */
-		hipLaunchKernelGGL(k_s16c_set_u32, dim3((unsigned) ((bidx.size() + 255) / 256)), dim3(256), 0, g.stream, ix->d_sub_len,
-						   (const uint32_t *) d_bidx, (const uint32_t *) d_bval, (uint32_t) bidx.size());
+	/* the sweep's own table of bucket lengths: the sublists' (regrouped planes), or the lists' rows in the planes */
+	hipLaunchKernelGGL(k_s16c_set_u32, dim3((unsigned) ((bidx.size() + 255) / 256)), dim3(256), 0, g.stream,
+					   ix->s16_sub ? ix->d_sub_len : ix->d_plen,
+					   (const uint32_t *) d_bidx, (const uint32_t *) d_bval, (uint32_t) bidx.size());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(g.stream));		/* the host arrays are locals */
 	g.stats.prepare_updates++;
@@ -2888,6 +2970,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		ds.own_len = ix->d_sub_len;
 		ds.ncent = ncs;
 	}
+	else if (cen)
+		ds.own_len = ix->d_plen;	/* the lists' rows in the planes, holes of deleted rows included */
 
 	/* tile geometry: 8 waves, 256 rows x 128 queries, ring of 3 chunk buffers, one block per CU (default), or
 	 * 4 waves, 128 x 128, ring of 2, two blocks per CU (ndbhip_set_option("screen16_waves", 4)) */

@@ -486,3 +486,69 @@ def test_appends_go_into_the_planes_spare_blocks_without_a_new_layout(sublists, 
         ix.close()
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", 1))
+
+
+@pytest.mark.parametrize("sublists", [1, 0])
+def test_deletes_leave_holes_in_the_planes_without_a_new_layout(sublists, lib):
+    """ambulkdelete between batches (ivf_am.c:1172-1357): the mirror is compacted (survivors keep list and order), the
+    centred planes keep the deleted rows as holes and every surviving row's index in its list is renumbered from the
+    compaction's own prefix sums — no new layout (stats.prepares stays 1), every batch the oracle's over the pruned
+    arrays; VACUUMs that empty a whole list, hit duplicates' first copy, and appends in between included."""
+    from oracle import ndbo
+    rng = np.random.default_rng(505 + sublists)
+    dim, nlists, n0 = 64, 10, 16000
+    cen = rng.standard_normal((30, dim)).astype(np.float32) * 3
+    base = (cen[rng.integers(0, 30, n0)] + 0.1 * rng.standard_normal((n0, dim))).astype(np.float32)
+    base[101] = base[100]                                                              # duplicates: ties by position
+    base[205] = base[100]
+    cent = base[rng.choice(n0, nlists, replace=False)].copy()
+    asg = ((base[:, None, :].astype(np.float64) - cent[None]) ** 2).sum(-1).argmin(1)
+    asg[101] = asg[205] = asg[100]
+    lists = [list(np.flatnonzero(asg == c)) for c in range(nlists)]
+    rows_all = [base[i] for i in range(n0)]
+
+    def arrays():
+        order = np.concatenate([np.asarray(l, np.int64) for l in lists])
+        return dict(centroids=cent, list_len=np.asarray([len(l) for l in lists], np.int64),
+                    rows=np.ascontiguousarray(np.stack([rows_all[i] for i in order])), tids=ndbo.tids_from_rows(order))
+
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", sublists))
+    try:
+        ix = _index(arrays())
+        lib.check(lib.lib().ndbhip_stats_reset())
+        nq, k, nprobe = 130, 10, 5
+        smallest = int(np.argmin([len(l) for l in lists]))
+        for rnd in range(12):
+            if rnd > 0:
+                live = [i for l in lists for i in l]
+                if rnd == 3:
+                    dead = list(lists[smallest])                                       # a VACUUM that empties a list
+                elif rnd == 5:
+                    dead = [100] if 100 in live else []                                # the first of three equal rows
+                else:
+                    dead = [int(i) for i in rng.choice(live, size=min(len(live) // 20, 700), replace=False)]
+                dset = set(dead)
+                for c in range(nlists):
+                    lists[c] = [i for i in lists[c] if i not in dset]
+                removed = ix.delete(ndbo.tids_from_rows(np.asarray(dead + [10 ** 7], np.int64)))   # (one TID that is not there)
+                assert removed == len(dead)
+                for _ in range(10):                                                    # ... and a few inserts behind them
+                    c = int(rng.integers(0, nlists))
+                    v = (cen[rng.integers(0, 30)] + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+                    rid = len(rows_all)
+                    rows_all.append(v)
+                    lists[c].append(rid)
+                    ix.append(c, v, ndbo.tids_from_rows(np.asarray([rid]))[0])
+            q = (cen[rng.integers(0, 30, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+            q[:20] = np.stack([rows_all[i] for i in rng.integers(0, n0, 20)])           # deleted rows among the queries
+            q[20] = rows_all[100]
+            t, d, c_ = ix.search(q, 1, nprobe, k, 0)
+            et, ed, ec, _ = oracle_search_batch(oracle_image(arrays()), q, 1, nprobe, k, 0)
+            assert_same_results(t, d, c_, et, ed, ec)
+        st = lib.stats()
+        assert st["screen16_batches"] + st["screen16_fallbacks"] == 12, st
+        assert st["prepares"] == 1 and st["prepare_updates"] >= 20, st
+        ix.close()
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", 1))
