@@ -1648,6 +1648,8 @@ struct ndbhip_ivf
 	/* centred planes: rows of every bucket IN THE PLANES (holes of deleted rows included: the list's own length shrinks,
 	 * the bucket's does not) when the buckets are the lists themselves (regrouped planes keep that in d_sub_len), and the
 	 * list every bucket belongs to */
+	bool		s16_planes_f32 = true;	/* the planes hold two-plane float4-style rows (always, except an fp16 mirror's own plane) */
+	float	   *w_qhat = nullptr;	size_t w_qhat_n = 0;	/* cosine: the batch's queries divided by their norms */
 	uint32_t   *d_plen = nullptr;	size_t d_plen_n = 0;
 	uint32_t   *d_bucket_list = nullptr;	size_t d_bucket_list_n = 0;
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
@@ -1750,7 +1752,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2600,12 +2602,14 @@ static int	g_s16_slack = 1;	/* the centred planes keep spare blocks and take app
 static int	g_s16c_seeds = 0;	/* rows whose upper bounds give a query its first threshold, 0 = 32 (k <= 20) or 64 ("screen16c_seeds") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
+static int	g_s16_cos = 1;		/* cosine on the matrix-core sweep, as the inner product of normalised planes ("screen16_cosine") */
+
 static bool
 ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 {
 	const size_t dimp = (size_t) ((ix->dim + 63) & ~63);
 
-	if (R != R_IVF_L2 && R != R_IVF_IP)
+	if (R != R_IVF_L2 && R != R_IVF_IP && !(R == R_IVF_COS && g_s16_cos))
 		return false;
 	if (k > NDB_TOPK_FAST_MAXK || ix->nrows < 1)
 		return false;
@@ -2616,7 +2620,8 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 	return true;
 }
 
-static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host, bool slack);	/* ndbhip_build.h */
+static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host, bool slack,
+								   const float *rows32 = nullptr /* the rows to regroup (cosine: their normalised copy) */ );	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
 static int	s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim);	/* ndbhip_build.h */
 static int	s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr,
@@ -2645,11 +2650,13 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 	const int	nc = ix->ncent;
 	/* sublists only pay where a bound can exclude them: L2 (an index has one operator class, hence one strategy;
 	 * a caller that alternates strategies on one mirror has its planes laid out again at every change) */
-	const int	sub_cfg = (g_s16_sublists && g_s16_prune && (R == R_IVF_L2 || R == R_IVF_IP)) ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
+	const int	sub_cfg = (g_s16_sublists && g_s16_prune && (R == R_IVF_L2 || R == R_IVF_IP || R == R_IVF_COS)) ? (g_s16_sub_min * 131 + g_s16_sub_rows) : 0;
+	/* cosine: the planes (and the sublists) are those of the rows divided by their norms */
+	const bool	cosn = R == R_IVF_COS;
 
 	/* L2 on float4 rows: the planes hold the rows minus their bucket's centre, one fp16 plane (ndbhip_screen16c.h) */
 	const bool	cen = ivf_s16_centered(ix, R);
-	const int	lay_cfg = sub_cfg * 2 + (cen ? 1 : 0);
+	const int	lay_cfg = (sub_cfg * 2 + (cen ? 1 : 0)) * 2 + (cosn ? 1 : 0);
 
 	if (ix->s16_valid && ix->s16_sub_cfg != lay_cfg)
 		ix->s16_valid = false;	/* the planes were laid out under other settings */
@@ -2661,10 +2668,31 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		g.stats.prepares++;
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = lay_cfg;
+		ix->s16_planes_f32 = cosn || !ix->f16;
+		/* cosine: a transient fp32 copy of the rows divided by their norms (decoded like the reference decodes an fp16
+		 * mirror) — what is regrouped and what the planes are made of; released when this returns */
+		struct Hat
+		{
+			float	   *p = nullptr;
+			~Hat() { if (p) big_free(p); }
+		}			hat;
+
+		if (cosn)
+		{
+			if (big_alloc((void **) &hat.p, (size_t) ix->nrows * dim * sizeof(float))) return NDBHIP_ERR_HIP;
+			const dim3	gn((unsigned) ((ix->nrows + 3) / 4));
+
+			if (!ix->f16)
+				hipLaunchKernelGGL(k_rows_normalise<0>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p);
+			else if (ix->f16_sub)
+				hipLaunchKernelGGL(k_rows_normalise<1>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p);
+			else
+				hipLaunchKernelGGL(k_rows_normalise<2>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p);
+		}
 		if (sub_cfg != 0)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
-			const int	rc = ivf_s16_build_sublists(ix, bo, cen && g_s16_slack != 0);
+			const int	rc = ivf_s16_build_sublists(ix, bo, cen && g_s16_slack != 0, hat.p);
 
 			if (rc)
 				return rc;
@@ -2735,7 +2763,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			HIP_TRY(hipMemcpyAsync(ix->d_plen, ix->s16_blen.data(), nbk * 4, hipMemcpyHostToDevice, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));		/* po, blist are locals */
 		}
-		const size_t blk_bytes = cen ? (size_t) (dimp / S16C_CH) * 4096 : (size_t) (dimp / S16_CH) * (ix->f16 ? 2048 : 4096);
+		const size_t blk_bytes = cen ? (size_t) (dimp / S16C_CH) * 4096 : (size_t) (dimp / S16_CH) * (ix->s16_planes_f32 ? 4096 : 2048);
 
 		if (grow(ix->d_rn2, ix->d_rn2_n, cen ? (size_t) (nb + 8) * 32 : (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
 		if (grow(ix->d_rexp, ix->d_rexp_n, cen ? (size_t) (nb + 8) * 32 : (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
@@ -2747,7 +2775,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		const dim3	gp((unsigned) ((ix->nrows + 3) / 4));
 
 #define S16_PREP_L(HH)                                                                                          \
-		hipLaunchKernelGGL(k_s16_row_prep<HH>, gp, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, dimp, \
+		hipLaunchKernelGGL(k_s16_row_prep<HH>, gp, dim3(256), 0, g.stream, cosn ? (const void *) hat.p : (const void *) ix->d_vecs, ix->nrows, dim, dimp, \
 						   ix->s16_sub ? (const int64_t *) ix->d_sub_loc : (const int64_t *) ix->d_loc_off,              \
 						   ix->s16_sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,            \
 						   ix->s16_sub ? ix->nsub : nc, ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16,               \
@@ -2762,7 +2790,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 							   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr,
 							   (const int64_t *) ix->d_prow_off, ix->s16_sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr,
 							   ix->d_pposof);
-		else if (!ix->f16)
+		else if (ix->s16_planes_f32)
 			S16_PREP_L(0);
 		else if (ix->f16_sub)
 			S16_PREP_L(1);
@@ -2786,6 +2814,8 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		if (grow(ix->d_cn2, ix->d_cn2_n, (size_t) nc)) return NDBHIP_ERR_HIP;
 		hipLaunchKernelGGL(k_vec_norm2, dim3((nc + 3) / 4), dim3(256), 0, g.stream, (const float *) ix->d_centroids, nc, dim, ix->d_cn2);
 		HIP_TRY(hipGetLastError());
+		if (cosn)
+			HIP_TRY(hipStreamSynchronize(g.stream));	/* the normalised copy goes with this scope */
 		ix->s16_valid = true;
 	}
 	return 0;
@@ -2900,7 +2930,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	 * already have needed them for the centroid scan) */
 #define S16_BY_RH(KERNEL, ...)                                                                  \
 	do {                                                                                        \
-		if (R == R_IVF_IP)                                                                      \
+		if (R == R_IVF_COS)                                                                     \
+		{                                                                                       \
+			if (H == 0) KERNEL(R_IVF_COS, 0, __VA_ARGS__);                                       \
+			else if (H == 1) KERNEL(R_IVF_COS, 1, __VA_ARGS__);                                  \
+			else KERNEL(R_IVF_COS, 2, __VA_ARGS__);                                              \
+		}                                                                                       \
+		else if (R == R_IVF_IP)                                                                 \
 		{                                                                                       \
 			if (H == 0) KERNEL(R_IVF_IP, 0, __VA_ARGS__);                                        \
 			else if (H == 1) KERNEL(R_IVF_IP, 1, __VA_ARGS__);                                   \
@@ -2915,7 +2951,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	} while (0)
 #define S16_SEED_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
 	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
-	const bool	seed_by_sublist = ix->s16_sub && (R == R_IVF_L2 || (R == R_IVF_IP && cdist)) && g_s16_prune && ix->nsub_g > 0;
+	const bool	seed_by_sublist = ix->s16_sub && (R == R_IVF_L2 || (R == R_IVF_IP && cdist) || R == R_IVF_COS) && g_s16_prune && ix->nsub_g > 0;
 
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
@@ -3003,10 +3039,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 1>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
 		else if (g_s16_debug == 2 && HH == 0 && RR == R_IVF_L2)                                                    \
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
+		else if (RR == R_IVF_COS)		/* (the inner product of the normalised planes, which are float4-style whatever the mirror holds) */ \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_IP, 0, 4, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
 		else if (g_s16_waves == 8)                                                                                \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<RR, HH, 8, 3>), dim3(g.num_cus), dim3(512), 0, g.stream, __VA_ARGS__); \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<(RR == R_IVF_COS ? R_IVF_IP : RR), HH, 8, 3>), dim3(g.num_cus), dim3(512), 0, g.stream, __VA_ARGS__); \
 		else                                                                                                      \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<RR, HH, 4, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<(RR == R_IVF_COS ? R_IVF_IP : RR), HH, 4, 2>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, __VA_ARGS__); \
 	} while (0)
 	/*
 	 * Round 0 sweeps every (query, probe) pair against the seed threshold.  A query that emits more than its
@@ -3033,7 +3071,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			 * against the threshold its first records give — rare enough that its nine launches are not worth
 			 * queueing for every batch */
 			HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned int), g.stream));
-			if (R == R_IVF_IP)
+			if (R == R_IVF_IP || R == R_IVF_COS)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_IP>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 0);
 			else
@@ -3046,8 +3084,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 		/* inner product: sublists are excluded by -(q.c) - |q| rad (k_sub_pairs); that needs the centroid scan's
 		 * distances of this call */
-		const bool	prune = g_s16_prune && (R == R_IVF_L2 || (R == R_IVF_IP && sub && cdist));
-		const int	ipb = R == R_IVF_IP ? 1 : 0;
+		const bool	prune = g_s16_prune && (R == R_IVF_L2 || (R == R_IVF_IP && sub && cdist) || (R == R_IVF_COS && sub));
+		const int	ipb = R == R_IVF_IP ? 1 : (R == R_IVF_COS ? 2 : 0);
 
 		if (prune && !(sub && cdist))
 		{
@@ -3135,7 +3173,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) item_off, (const uint32_t *) cnt, ds.own_len, ncs, (uint32_t) s16_rt,
 							   (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu), (S16Desc *) ix->w_s16desc, flags, s16_qt,
 							   round == 0 ? g.d_counters + 7 : (unsigned long long *) nullptr,
-							   (uint32_t) (cen ? (dimp / S16C_CH) * 4096 : (dimp / S16_CH) * (ix->f16 ? 2048 : 4096)));
+							   (uint32_t) (cen ? (dimp / S16C_CH) * 4096 : (dimp / S16_CH) * (ix->s16_planes_f32 ? 4096 : 2048)));
 			desc_cap = (uint32_t) std::min<size_t>(cap_items, 0xFFFFFFFFu);
 		}
 		if (cen)
@@ -3448,6 +3486,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_slack"))
 		g_s16_slack = value != 0;
+	else if (!strcmp(name, "screen16_cosine"))
+		g_s16_cos = value != 0;
 	else if (!strcmp(name, "build_prepare"))
 	{
 		if (value < 0 || value > 3)
@@ -3585,7 +3625,16 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (grow(ix->w_qn2, ix->w_qn2_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qexp, ix->w_qexp_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
-		hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, ix->dim, dimp,
+		const float *qsrc = d_q;
+
+		if (ivf_recipe(strategy) == R_IVF_COS)
+		{
+			/* cosine: the planes are those of q / |q| (the exact arithmetic keeps reading d_q itself) */
+			if (grow(ix->w_qhat, ix->w_qhat_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_rows_normalise<0>, dim3((nq + 3) / 4), dim3(256), 0, g.stream, (const void *) d_q, (int64_t) nq, ix->dim, ix->w_qhat);
+			qsrc = ix->w_qhat;
+		}
+		hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, qsrc, (uint32_t) nq, ix->dim, dimp,
 						   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
 	}
 	if (g_thr_hook && !s16_here && full && allow_s16)
@@ -3599,7 +3648,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (rc)
 			return rc;
 	}
-	if (!d_probes_in && s16_here && g_cent_s16 && ncmp >= 256 && ncmp <= 4096 && npr <= NDBHIP_MAX_NPROBE)
+	if (!d_probes_in && s16_here && g_cent_s16 && ncmp >= 256 && ncmp <= 4096 && npr <= NDBHIP_MAX_NPROBE &&
+		ivf_recipe(strategy) != R_IVF_COS /* (its query planes are the normalised queries') */ )
 	{
 		/* HOT LOOP 1 for a screened batch: |q - centroid|^2 of every pair from the two-plane sweep (MODE 3), the
 		 * reference's arithmetic for the centroids near the nprobe-th only (k_cent_select) */

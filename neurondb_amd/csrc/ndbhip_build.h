@@ -1967,7 +1967,7 @@ k_rows_decode_f16(const uint16_t *__restrict__ src, size_t n, float *__restrict_
 }
 
 static int
-ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
+ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, const float *rows32)
 {
 	const int	nc = ix->ncent, dim = ix->dim;
 	std::vector<int> giant, midl;
@@ -1980,7 +1980,9 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack)
 	}			dec;
 	const float *vecs32 = (const float *) ix->d_vecs;
 
-	if (ix->f16)
+	if (rows32)
+		vecs32 = rows32;
+	else if (ix->f16)
 	{
 		const size_t ne = (size_t) ix->nrows * dim;
 

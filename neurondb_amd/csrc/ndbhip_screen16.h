@@ -528,6 +528,46 @@ s16_sub_excluded_ip(double alo, float q2, float c2, uint32_t rad_bits, float thr
 	return lb - __builtin_fabs(lb) * 1e-9 - 1e-30 > (double) thrE;	/* NaN / inf anywhere: false */
 }
 
+/* rows (float4, or fp16 as the reference decodes them: H16 1 = with quirk Q20, 2 = no subnormals in the mirror) divided
+ * by their norm, as fp32: out = fl32(x_i / sqrt(sum x_i^2)) with the sum and the quotient in fp64.  A zero row stays zero
+ * (the reference's cosine distance of a zero vector is exactly 1 = 1 - 0); a row whose norm is outside the range the error
+ * model covers becomes NaN (its plane row is marked, every candidate of it is emitted).  One wave per row. */
+template <int H16>
+__global__ __launch_bounds__(256) void
+k_rows_normalise(const void *__restrict__ src, int64_t n, int dim, float *__restrict__ out)
+{
+	const int	lane = threadIdx.x & 63;
+	const int64_t r = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (r >= n)
+		return;
+	auto		at = [&](int i) -> float {
+		if constexpr (H16 == 0)
+			return ((const float *) src)[(size_t) r * dim + i];
+		else if constexpr (H16 == 1)
+			return h2f_ref(((const uint16_t *) src)[(size_t) r * dim + i]);
+		else
+			return __half2float(__ushort_as_half(((const uint16_t *) src)[(size_t) r * dim + i]));
+	};
+	double		s = 0.0;
+
+	for (int i = lane; i < dim; i += 64)
+	{
+		const double v = (double) at(i);
+
+		s += v * v;
+	}
+	s = wave_sum_f64(s);
+	/* the error model of s16_e<R_IVF_COS> assumes the reference's fp32 sums neither overflow nor lose their terms to
+	 * underflow: |x|^2 within [1e-28, 1e37] (terms below 2^-126 then add up to < 1e-7 of the sum), or exactly zero;
+	 * anything else is left to the exact arithmetic (NaN marks the row / the query) */
+	const bool	ok = s == 0.0 || (s >= 1.0e-28 && s <= 1.0e37);
+	const double inv = (ok && s > 0.0) ? 1.0 / __builtin_sqrt(s) : 0.0;
+
+	for (int i = lane; i < dim; i += 64)
+		out[(size_t) r * dim + i] = ok ? (float) ((double) at(i) * inv) : __uint_as_float(0x7FC00000u);
+}
+
 /* vectors' squared norms (fp64 sums, stored as fp32): one wave each */
 __global__ __launch_bounds__(256) void
 k_vec_norm2(const float *__restrict__ v, int n, int dim, float *__restrict__ out)
@@ -597,8 +637,8 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 
 			s0 = sub_first[L];
 			n = sub_first[L + 1] - s0;
-			pd = !prune ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
-			if (ip && prune)
+			pd = (!prune || ip == 2) ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
+			if (ip == 1 && prune)
 				c2l = cn2_list[L];
 		}
 		/* inclusive prefix sum of n over the lanes */
@@ -642,7 +682,9 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 				continue;
 			const int	gi = sub_gidx[s];
 
-			if (prune && ip)
+			if (prune && ip == 2 && gi < 0)
+				;				/* cosine: a list that is its own sublist has no centre in the normalised space: kept */
+			else if (prune && ip)
 			{
 				const double pdl = (double) s_pd[w][lo];
 				const double alo = gi < 0 ? pdl * pdl * (1.0 - 1e-4)
@@ -728,6 +770,16 @@ s16_e(int dim, float q2, float x2max, bool sub)
 {
 	float		e;
 
+	if (R == R_IVF_COS)
+	{
+		/* COSINE runs as the inner product of NORMALISED rows and queries (k_rows_normalise: q^ = fl32(q / |q|), norms
+		 * within 1 +- 4u): a = -(q^.x^) as the sweep computes it is within cdot |q^||x^| of the fp32 vectors' product,
+		 * that within 6u of the real cosine, and the reference's 1 - dot / (sqrt(n1) sqrt(n2)) (three sequential fp32
+		 * sums, two roots, a quotient, a difference) within 4 gamma_(dim + 8) of 1 - cosine: |(1 + a) - reference| <= e.
+		 * The norms and the subnormal term play no part: the planes hold decoded, normalised values. */
+		e = ndb_s16_cdot(dim) * 1.00001f + 4.0f * ndb_s16_gamma(dim + 8) + 16.0f * NDB_S16_U;
+		return s16_up(e * 1.00001f) + NDB_S16_ABS;
+	}
 	if (R == R_IVF_L2)
 		e = (ndb_s16_cdot(dim) + NDB_S16_NORMS) * (q2 + x2max);
 	else
@@ -744,6 +796,8 @@ s16_thr_from_ref(float thr, float e, int dim)
 {
 	if (R == R_IVF_L2)
 		return s16_up(s16_up(thr * thr) * (1.0f + ndb_s16_refslack(dim)) + e);
+	if (R == R_IVF_COS)
+		return s16_up(s16_up(thr - 1.0f) + e);	/* the sweep's a = -(q^.x^) = (cosine distance) - 1 */
 	return s16_up(thr + e);
 }
 
@@ -1034,18 +1088,21 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		if (vis < k || L < 0 || L >= ix.ncent)
 			continue;
 		const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
-		const float pd = cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p];
+		const float pd = R == R_IVF_COS ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
 
 		for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
 		{
 			if (sub_len[s] < k)
 				continue;
 			const int	gi = sub_gidx[s];
+
+			if (R == R_IVF_COS && gi < 0)
+				continue;			/* (the distances to such a list's centroid are in the rows' own space) */
 			float		dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
 
 			/* inner product: "nearest" = the largest q.c = (|q|^2 + |c|^2 - |q - c|^2) / 2 (any choice is valid;
 			 * this one finds the query's own neighbourhood) */
-			if (R == R_IVF_IP && cn2_sub)
+			if ((R == R_IVF_IP || R == R_IVF_COS) && cn2_sub)
 				dd = dd - (gi < 0 ? cn2_list[L] : cn2_sub[gi]);
 
 			if (dd < bd)

@@ -403,12 +403,19 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 	float		v = 0.0f;
 	const bool	vec4 = (dim & 3) == 0;
 
-	for (int j0 = 0; j0 < n; j0 += 4)
+	/* SG seed rows at a time: their loads are in flight together (a row is 3 KB: 12 coalesced loads per lane) */
+	constexpr int SG = 8;
+
+	for (int j0 = 0; j0 < n; j0 += SG)
 	{
-		float		part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+		float		part[SG];
 
 #pragma unroll
-		for (int u = 0; u < 4; u++)
+		for (int u = 0; u < SG; u++)
+			part[u] = 0.0f;
+
+#pragma unroll
+		for (int u = 0; u < SG; u++)
 		{
 			const int	j = j0 + u;
 
@@ -440,7 +447,7 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			part[u] = a;
 		}
 #pragma unroll
-		for (int u = 0; u < 4; u++)
+		for (int u = 0; u < SG; u++)
 		{
 			float		a = part[u];
 

@@ -246,7 +246,8 @@ def test_list_level_pruning_drops_pairs_and_changes_nothing(lib):
 @pytest.mark.parametrize("strategy,cap,nprobe,dim,rowtype", [
     (1, 0, 6, 64, "f32"), (1, 40, 6, 64, "f32"), (3, 0, 4, 64, "f32"), (1, 0, 14, 64, "f32"), (1, 0, 6, 100, "f32"),
     (1, 0, 5, 33, "f32"), (3, 40, 6, 64, "f32"), (3, 0, 14, 100, "f32"),
-    (3, 0, 4, 64, "f16"), (1, 0, 6, 64, "f16"), (3, 40, 6, 128, "f16"), (3, 0, 5, 64, "f16sub")])
+    (3, 0, 4, 64, "f16"), (1, 0, 6, 64, "f16"), (3, 40, 6, 128, "f16"), (3, 0, 5, 64, "f16sub"),
+    (2, 0, 6, 64, "f32"), (2, 40, 5, 100, "f32"), (2, 0, 14, 33, "f32"), (2, 0, 6, 64, "f16"), (2, 0, 5, 128, "f16sub")])
 def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, dim, rowtype, lib):
     """screen16_sublists with the threshold lowered to 300 rows: lists that mix several tight clusters are regrouped
     inside the planes (and a list of unstructured rows is not), (query, probe) pairs expand to sublists, seeds come
