@@ -1642,6 +1642,14 @@ struct ndbhip_ivf
 	S16Mat		dm_sub;				/* the centres of the regrouped lists: every query's squared distance to every one of them */
 	S16Mat		dm_cent;			/* the index's centroids: the batch centroid scan on the matrix cores (ndbhip_screen16.h) */
 	bool		dm_cent_valid = false;
+	/* centroids AND the regrouped lists' centres as one matrix (columns 0 .. ncmp - 1, then the centres): a screened
+	 * batch that needs both gets them from one launch instead of two of the same fixed latency */
+	S16Mat		dm_all;
+	float	   *d_allcent = nullptr;	size_t d_allcent_n = 0;
+	bool		dm_all_valid = false;
+	int			dm_all_ncmp = 0;
+	const float *bat_subdist = nullptr;	/* this batch's distances to the centres, when dm_all served (else NULL) */
+	uint32_t	bat_sstride = 0;
 	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	float	   *d_cn2 = nullptr;	size_t d_cn2_n = 0;		/* [ncent] |centroid|^2 (the inner product's sublist bound) */
@@ -1752,12 +1760,13 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
 		ix->dm_sub.release();
 		ix->dm_cent.release();
+		ix->dm_all.release();
 		if (ix->pin) (void) hipHostFree(ix->pin);
 	}
 	delete ix;
@@ -1770,7 +1779,7 @@ ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncent)
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!ix || !centroids || ncent < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
-	ix->dm_cent_valid = false;
+	ix->dm_cent_valid = false; ix->dm_all_valid = false;
 	if (ix->d_centroids)
 		HIP_TRY(hipFree(ix->d_centroids));
 	ix->d_centroids = nullptr;
@@ -2592,6 +2601,48 @@ static int	g_s16c_qb = 0;		/* pairs per tile of the centred sweep / 32: 4 or 1; 
  * minimum over the ranks, in place, of the (threshold, unused) pairs — every rank must call it once per sub-batch */
 static int	(*g_thr_hook) (float *, size_t) = nullptr;
 
+/*
+ * The exchange is an element-wise MINIMUM over the ranks.  A threshold (x = thr + e, y = e: the reference bound plus
+ * this rank's error term, which grows with the largest row norm IT holds) cannot simply be min'd: rank B would sweep
+ * against thr_A + e_A with e_A < e_B.  Packed as (x, -y) the minimum gives x* = the smallest thr + e and e_max = the
+ * largest error term; x* + e_max >= thr_r* + e_B for every rank B, so (x* + e_max, e_max) is valid everywhere (looser
+ * than the best possible by at most the smallest e).  The centred path's thresholds carry y = 0 and pass unchanged.
+ */
+__global__ void
+k_thr_pack(float2 *__restrict__ qthr, uint32_t nq)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (q < nq)
+		qthr[q].y = -qthr[q].y;
+}
+
+__global__ void
+k_thr_unpack(float2 *__restrict__ qthr, uint32_t nq)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (q >= nq)
+		return;
+	const float2 v = qthr[q];
+	const float e = -v.y;
+
+	qthr[q] = make_float2(e > 0.0f ? s16_up(v.x + e) : v.x, e);
+}
+
+/* the queries' thresholds through the hook (a sharded search: ndbhip_comm.cpp) */
+static int
+ivf_exchange_thresholds(float2 *qthr, int nq)
+{
+	hipLaunchKernelGGL(k_thr_pack, dim3((nq + 255) / 256), dim3(256), 0, g.stream, qthr, (uint32_t) nq);
+	const int	rc = g_thr_hook((float *) qthr, (size_t) 2 * nq);
+
+	if (rc)
+		return rc;
+	hipLaunchKernelGGL(k_thr_unpack, dim3((nq + 255) / 256), dim3(256), 0, g.stream, qthr, (uint32_t) nq);
+	return 0;
+}
+
 extern "C" void
 ndbhip_internal_set_thr_hook(int (*fn) (float *, size_t))
 {
@@ -2816,6 +2867,26 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		HIP_TRY(hipGetLastError());
 		if (cosn)
 			HIP_TRY(hipStreamSynchronize(g.stream));	/* the normalised copy goes with this scope */
+		ix->dm_all_valid = false;
+		{
+			const int	ncmp = std::min(ix->nlists, ix->ncent);
+
+			if (ix->s16_sub && ix->nsub_g > 0 && !cosn && g_cent_s16 && ncmp >= 256 && ncmp <= 4096)
+			{
+				const size_t nall = (size_t) ncmp + (size_t) ix->nsub_g;
+
+				if (grow(ix->d_allcent, ix->d_allcent_n, nall * (size_t) dim)) return NDBHIP_ERR_HIP;
+				HIP_TRY(hipMemcpyAsync(ix->d_allcent, ix->d_centroids, (size_t) ncmp * dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+				HIP_TRY(hipMemcpyAsync(ix->d_allcent + (size_t) ncmp * dim, ix->d_subcent, (size_t) ix->nsub_g * dim * sizeof(float),
+									   hipMemcpyDeviceToDevice, g.stream));
+				const int	rc = s16mat_prepare(ix->dm_all, ix->d_allcent, (int) nall, dim);
+
+				if (rc)
+					return rc;
+				ix->dm_all_valid = true;
+				ix->dm_all_ncmp = ncmp;
+			}
+		}
 		ix->s16_valid = true;
 	}
 	return 0;
@@ -2967,7 +3038,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	if (g_thr_hook && !seed_by_sublist)
 	{
 		/* sharded search: the smallest threshold any rank found for a query serves all of them */
-		const int	rc = g_thr_hook((float *) ix->w_qthr, (size_t) 2 * nq);
+		const int	rc = ivf_exchange_thresholds(ix->w_qthr, nq);
 
 		if (rc)
 			return rc;
@@ -2999,6 +3070,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* the sweep sees the sublists as its lists */
 	IvfDev		ds = d;
 	uint32_t	sstride = 0;
+	/* distances of the batch's queries to the regrouped lists' centres: the centroid scan's matrix when it covered them
+	 * (ix->bat_subdist), else a MODE 3 run of their own */
+	const float *subdist = ix->w_subdist, *sub_rn2 = ix->dm_sub.rn2;
+	const uint32_t *sub_xmax = ix->dm_sub.xmax;
 
 	if (sub)
 	{
@@ -3107,17 +3182,31 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			/* distances of every query to the centres of the regrouped lists (once per batch), then the expansion */
 			if (round == 0 && prune && ix->nsub_g > 0)
 			{
-				const int	rc = ivf_s16_sub_distances(ix, d_q, nq, &sstride);
+				if (ix->bat_subdist && cdist)
+				{
+					/* the centroid scan of this call multiplied the centres along with the centroids */
+					subdist = ix->bat_subdist;
+					sstride = ix->bat_sstride;
+					sub_xmax = ix->dm_all.xmax;
+					sub_rn2 = ix->dm_all.rn2 + ix->dm_all_ncmp;
+				}
+				else
+				{
+					const int	rc = ivf_s16_sub_distances(ix, d_q, nq, &sstride);
 
-				if (rc)
-					return rc;
+					if (rc)
+						return rc;
+					subdist = ix->w_subdist;
+					sub_xmax = ix->dm_sub.xmax;
+					sub_rn2 = ix->dm_sub.rn2;
+				}
 				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
 				if (cen)
 					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<true>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 									   (uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
 									   (const uint32_t *) ix->d_pposof,
-									   (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
+									   subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
 				else
 				{
 #define S16_SEEDSUB_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
@@ -3125,13 +3214,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							  npr, (uint32_t) k, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 							  (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
 							  (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
-							  (const float *) ix->w_subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, 0, ipb ? (const float *) ix->dm_sub.rn2 : (const float *) nullptr,
+							  subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
+							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, 0, ipb ? sub_rn2 : (const float *) nullptr,
 							  ipb ? (const float *) ix->d_cn2 : (const float *) nullptr, H == 1 ? 1 : 0);
 				}
 				if (g_thr_hook)
 				{
-					const int	rc2 = g_thr_hook((float *) ix->w_qthr, (size_t) 2 * nq);
+					const int	rc2 = ivf_exchange_thresholds(ix->w_qthr, nq);
 
 					if (rc2)
 						return rc2;
@@ -3139,10 +3228,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			}
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<0>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
+							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
-							   (PairRec *) nullptr, ipb, (const float *) ix->dm_sub.rn2, (const float *) ix->d_cn2);
+							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
+							   (PairRec *) nullptr, ipb, sub_rn2, (const float *) ix->d_cn2);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -3153,10 +3242,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, (const float *) ix->w_subdist,
+							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							   (const uint32_t *) ix->dm_sub.xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs,
-							   ipb, (const float *) ix->dm_sub.rn2, (const float *) ix->d_cn2);
+							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs,
+							   ipb, sub_rn2, (const float *) ix->d_cn2);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
@@ -3617,6 +3706,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const bool	s16_here = full && allow_s16 && ivf_s16_wanted(ix, nq, ivf_recipe(strategy), k);
 	bool		cent_done = false;
 
+	ix->bat_subdist = nullptr;
+
 	if (s16_here)
 	{
 		const int	dimp = (ix->dim + 63) & ~63;
@@ -3653,9 +3744,14 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	{
 		/* HOT LOOP 1 for a screened batch: |q - centroid|^2 of every pair from the two-plane sweep (MODE 3), the
 		 * reference's arithmetic for the centroids near the nprobe-th only (k_cent_select) */
-		const uint32_t astride = (uint32_t) ((ncmp + 63) & ~63);
+		/* the planes laid out and their centres known: the centroids and the regrouped lists' centres are one matrix
+		 * (dm_all), the sweep's sublist code reads its columns past the centroids' */
+		const bool	both = ix->s16_valid && ix->s16_sub && ix->dm_all_valid && ix->dm_all_ncmp == ncmp && ix->nsub_g > 0 &&
+			ix->dm_all.n == ncmp + ix->nsub_g && g_s16_prune;
+		S16Mat	   &cm = both ? ix->dm_all : ix->dm_cent;
+		const uint32_t astride = (uint32_t) (((both ? ncmp + ix->nsub_g : ncmp) + 63) & ~63);
 
-		if (!ix->dm_cent_valid || ix->dm_cent.n != ncmp || ix->dm_cent.src != ix->d_centroids)
+		if (!both && (!ix->dm_cent_valid || ix->dm_cent.n != ncmp || ix->dm_cent.src != ix->d_centroids))
 		{
 			const int	rc = s16mat_prepare(ix->dm_cent, ix->d_centroids, ncmp, ix->dim);
 
@@ -3666,14 +3762,19 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (grow(ix->w_amat, ix->w_amat_n, (size_t) nq * astride)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_cfull, ix->w_cfull_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 		{
-			const int	rc = s16mat_run(ix->dm_cent, ix->dim, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq, ix->w_amat, astride);
+			const int	rc = s16mat_run(cm, ix->dim, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq, ix->w_amat, astride);
 
 			if (rc)
 				return rc;
 		}
+		if (both)
+		{
+			ix->bat_subdist = ix->w_amat + ncmp;
+			ix->bat_sstride = astride;
+		}
 #define CENT_SELECT_L(PER)                                                                                          \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cent_select<PER>), dim3(nq), dim3(64), 0, g.stream, (const float *) ix->w_amat, astride, \
-						   (const float *) ix->w_qn2, (const uint32_t *) ix->dm_cent.xmax, d_q, (const float *) d.centroids, ix->dim, \
+						   (const float *) ix->w_qn2, (const uint32_t *) cm.xmax, d_q, (const float *) d.centroids, ix->dim, \
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,                          \
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->w_cdist, cstride, w_probes, ix->w_candoff, \
 						   lco_w, ix->w_cfull)

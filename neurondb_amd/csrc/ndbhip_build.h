@@ -1372,7 +1372,7 @@ ivf_build_rows(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int6
 	lap("frees");
 
 	/* adopt: centroids + packed lists become the index */
-	ix->dm_cent_valid = false;
+	ix->dm_cent_valid = false; ix->dm_all_valid = false;
 	if (ix->d_centroids)
 		HIP_TRY(hipFree(ix->d_centroids));
 	ix->d_centroids = d_cent;
@@ -1692,7 +1692,7 @@ ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_
 
 	for (int L = 0; L < k; L++)
 		owned[(size_t) L] = owner[(size_t) L] == me;
-	ix->dm_cent_valid = false;
+	ix->dm_cent_valid = false; ix->dm_all_valid = false;
 	if (ix->d_centroids)
 		(void) hipFree(ix->d_centroids);
 	ix->d_centroids = d_cent;

@@ -333,31 +333,76 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 	{
 		float		bd = __uint_as_float(0x7F800000u);
 		uint32_t	bs = 0xFFFFFFFFu, bp = 0;
+		/* the (probe, sublist) candidates of 64 probes at a time laid end to end and dealt to the lanes (as in
+		 * k_sub_pairs: walking the probes one after the other was 32 dependent trips of mostly idle lanes) */
+		__shared__ uint32_t s_off[65], s_s0[64];
+		__shared__ float s_pd[64];
 
-		for (int p = 0; p < npr; p++)
+		for (int p0 = 0; p0 < npr; p0 += 64)
 		{
-			const uint32_t vis = lco[p + 1] - lco[p];
-			const int	L = probes[(size_t) q * npr + p];
+			const int	p = p0 + lane;
+			uint32_t	n = 0, s0 = 0;
+			float		pd = 0.0f;
 
-			if (vis < k || L < 0 || L >= ix.ncent)
-				continue;
-			const uint32_t s0 = sub_first[L], s1 = sub_first[L + 1];
-			const float pd = cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p];
-
-			for (uint32_t s = s0 + (uint32_t) lane; s < s1; s += 64)
+			if (p < npr)
 			{
-				if (sub_len[s] < k)
-					continue;
-				const int	gi = sub_gidx[s];
-				const float dd = gi < 0 ? pd * pd : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+				const uint32_t vis = lco[p + 1] - lco[p];
+				const int	L = probes[(size_t) q * npr + p];
 
-				if (dd < bd)
+				if (vis >= k && L >= 0 && L < ix.ncent)
 				{
-					bd = dd;
-					bs = s;
-					bp = (uint32_t) p;
+					s0 = sub_first[L];
+					n = sub_first[L + 1] - s0;
+					pd = cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p];
 				}
 			}
+			uint32_t	inc = n;
+
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1)
+			{
+				const uint32_t v = (uint32_t) __shfl_up((int) inc, off, 64);
+
+				if (lane >= off)
+					inc += v;
+			}
+			s_off[lane] = inc - n;
+			s_s0[lane] = s0;
+			s_pd[lane] = pd;
+			const uint32_t T = (uint32_t) __shfl((int) inc, 63, 64);
+
+			if (lane == 0)
+				s_off[64] = T;
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t t = (uint32_t) lane; t < T; t += 64)
+			{
+				int			lo = 0, hi = 64;
+
+				while (hi - lo > 1)
+				{
+					const int	mid = (lo + hi) >> 1;
+
+					if (s_off[mid] <= t)
+						lo = mid;
+					else
+						hi = mid;
+				}
+				const uint32_t sx = s_s0[lo] + (t - s_off[lo]);
+
+				if (sub_len[sx] < k)
+					continue;
+				const int	gi = sub_gidx[sx];
+				const float pdl = s_pd[lo];
+				const float dd = gi < 0 ? pdl * pdl : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+
+				if (dd < bd || (dd == bd && sx < bs))
+				{
+					bd = dd;
+					bs = sx;
+					bp = (uint32_t) (p0 + lo);
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
 		}
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1)

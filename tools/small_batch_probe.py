@@ -30,7 +30,7 @@ def main():
     for kv in [x for x in os.environ.get("OPTS", "").split(",") if x]:
         check(lib().ndbhip_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
         print("option", kv, flush=True)
-    for minnq in [int(x) for x in os.environ.get("MINNQS", "128").split(",")]:
+    for minnq in [int(x) for x in os.environ.get("MINNQS", "32").split(",")]:
       check(lib().ndbhip_set_option(b"screen_min_nq", minnq))
       print("screen_min_nq", minnq, flush=True)
       for nq in [int(x) for x in os.environ.get("NQS", "1,2,4,7,8,9,16,32,64,128,256,512").split(",")]:
