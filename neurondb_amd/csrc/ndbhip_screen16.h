@@ -687,7 +687,8 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			else if (prune && ip)
 			{
 				const double pdl = (double) s_pd[w][lo];
-				const double alo = gi < 0 ? pdl * pdl * (1.0 - 1e-4)
+				/* (the centroid scan's float4 distance is within (dim + 3) 2^-24 of the real one, relatively; squared: twice that) */
+				const double alo = gi < 0 ? pdl * pdl * (1.0 - 2.2 * (double) (dim + 8) * 5.9604645e-8)
 					: (double) subdist[(size_t) q * sstride + gi] - (double) ec * (1.0 + 1e-6);
 
 				if (s16_sub_excluded_ip(alo, qn2[q], gi < 0 ? s_c2[w][lo] : cn2_sub[gi], sub_rad[s], te))
