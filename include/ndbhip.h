@@ -146,6 +146,7 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen16c_seeds"   0     rows per query whose upper bounds make its first threshold: 32 | 64, 0 = 32 for k <= 20, else 64
  *   "build_prepare"     0     ndbhip_ivf_build / _build_device end with ndbhip_ivf_prepare(ix, this strategy 1 .. 3): the index leaves the
  *                             build searchable at full speed (0: the first batched scan, or an explicit ndbhip_ivf_prepare, pays for it)
+ *   "hnsw_intended_waves" 16  waves per CU walking the intended HNSW (build and search); each owns a visited bitmap of one bit per node
  *   "screen16_cosine"   1     cosine batches run the same sweep as the inner product of NORMALISED planes (rows and queries divided by
  *                             their norms; sublists regrouped in that space); 0: the round-1 fp32 screen
  *   "screen16_slack"    1     the centred planes keep spare 32-row blocks per bucket and take appends in place (0: every append lays them out again)

@@ -3619,6 +3619,12 @@ ndbhip_set_option(const char *name, int value)
 		g_debug_s16 = value;
 	else if (!strcmp(name, "debug_build"))
 		g_debug_build = value;
+	else if (!strcmp(name, "hnsw_intended_waves"))
+	{
+		if (value < 1 || value > 32)
+			return fail(NDBHIP_ERR_INVALID, "hnsw_intended_waves must be 1 .. 32 (waves per CU)");
+		g_h2_waves = value;
+	}
 	else if (!strcmp(name, "hnsw_trace"))
 		g_hnsw_trace = value;
 	else if (!strcmp(name, "hnsw_nofast"))

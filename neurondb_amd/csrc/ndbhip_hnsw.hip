@@ -8,6 +8,7 @@
 #include "ndbhip_internal.h"
 
 int			g_hnsw_trace = 0, g_hnsw_nofast = 0;	/* ndbhip_set_option("hnsw_trace" / "hnsw_nofast") */
+int			g_h2_waves = 16;		/* waves per CU of the intended HNSW's walk kernels ("hnsw_intended_waves"): each owns a visited bitmap */
 
 /* hnswbuild: 0 the one-wave sequential kernel, 1 optimistic batches with the chunked block-wide commit (hashed
  * when m <= 16, else sorted), 2 optimistic batches with the one-wave commit, 3 optimistic batches with the
@@ -3399,7 +3400,7 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	h->nblocks = nb;
 	h->ef_construction = ef_construction;
 
-	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * 8, std::max(1, batch_max));
+	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * g_h2_waves, std::max(1, batch_max));
 	uint32_t	nwords = 0;
 
 	if (h2_workspace(h, nwaves, nb, &nwords)) return NDBHIP_ERR_HIP;
@@ -3557,7 +3558,7 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
 	if (rc)
 		return rc;
 	const uint32_t efe = (uint32_t) std::max(ef, k);
-	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * 8, nq);
+	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * g_h2_waves, nq);
 	uint32_t	nwords = 0;
 
 	if (h2_workspace(h, nwaves, h->nblocks, &nwords)) return NDBHIP_ERR_HIP;

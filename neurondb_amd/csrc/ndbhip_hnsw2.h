@@ -96,11 +96,18 @@ h2_dist2(const H2Query &Q, const float *__restrict__ x, int lane)
 	return h2_wave_fold(p);
 }
 
-/* four rows at a time: the loads of all four are in flight before the first sum is folded */
+/* H2_NR rows at a time: the loads of all of them are in flight before the first sum is folded (a walk is a chain of
+ * dependent fetches: what it can overlap is the rows of ONE expansion — up to 2m unvisited neighbours, offered to the
+ * set in any order with the same result) */
+#define H2_NR 8
 __device__ __forceinline__ void
-h2_dist2x4(const H2Query &Q, const float *const x[4], int n, int lane, double out[4])
+h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, double out[H2_NR])
 {
-	double		p[4] = {0.0, 0.0, 0.0, 0.0};
+	double		p[H2_NR];
+
+#pragma unroll
+	for (int u = 0; u < H2_NR; u++)
+		p[u] = 0.0;
 
 	if (Q.dim <= 64 * H2_QREG)
 	{
@@ -108,13 +115,13 @@ h2_dist2x4(const H2Query &Q, const float *const x[4], int n, int lane, double ou
 		for (int j = 0; j < H2_QREG; j++)
 			if (lane + 64 * j < Q.dim)
 			{
-				float		v[4];
+				float		v[H2_NR];
 
 #pragma unroll
-				for (int u = 0; u < 4; u++)
+				for (int u = 0; u < H2_NR; u++)
 					v[u] = u < n ? x[u][lane + 64 * j] : 0.0f;
 #pragma unroll
-				for (int u = 0; u < 4; u++)
+				for (int u = 0; u < H2_NR; u++)
 				{
 					const float d = Q.r[j] - v[u];
 
@@ -128,7 +135,7 @@ h2_dist2x4(const H2Query &Q, const float *const x[4], int n, int lane, double ou
 			const float qv = Q.q[i];
 
 #pragma unroll
-			for (int u = 0; u < 4; u++)
+			for (int u = 0; u < H2_NR; u++)
 				if (u < n)
 				{
 					const float d = qv - x[u][i];
@@ -137,7 +144,7 @@ h2_dist2x4(const H2Query &Q, const float *const x[4], int n, int lane, double ou
 				}
 		}
 #pragma unroll
-	for (int u = 0; u < 4; u++)
+	for (int u = 0; u < H2_NR; u++)
 		out[u] = h2_wave_fold(p[u]);
 }
 
@@ -334,13 +341,13 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 
 		while (todo)
 		{
-			const float *x[4];
-			uint32_t	ids[4];
-			double		d[4];
+			const float *x[H2_NR];
+			uint32_t	ids[H2_NR];
+			double		d[H2_NR];
 			int			n = 0;
 
 #pragma unroll
-			for (int u = 0; u < 4; u++)
+			for (int u = 0; u < H2_NR; u++)
 			{
 				ids[u] = 0;
 				x[u] = g.vecs;
@@ -377,13 +384,13 @@ h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &
 
 		while (todo)
 		{
-			const float *x[4];
-			uint32_t	ids[4];
-			double		d[4];
+			const float *x[H2_NR];
+			uint32_t	ids[H2_NR];
+			double		d[H2_NR];
 			int			n = 0;
 
 #pragma unroll
-			for (int u = 0; u < 4; u++)
+			for (int u = 0; u < H2_NR; u++)
 			{
 				ids[u] = 0;
 				x[u] = g.vecs;

@@ -36,6 +36,8 @@ def main():
     tids = torch.arange(n, device=dev, dtype=torch.int64)
     ix = HnswIndex(dim, 16)
     check(lib().ndbhip_hnsw_set_intended_select(int(os.environ.get("H2_SELECT", "1"))))
+    if os.environ.get("H2_WAVES"):
+        check(lib().ndbhip_set_option(b"hnsw_intended_waves", int(os.environ["H2_WAVES"])))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ix.build_intended(x, tids, levels, 200, batch_div=int(os.environ.get("H2_BDIV", "16")), batch_max=int(os.environ.get("H2_BMAX", "8192")))
