@@ -1656,6 +1656,12 @@ struct ndbhip_ivf
 	/* centred planes: rows of every bucket IN THE PLANES (holes of deleted rows included: the list's own length shrinks,
 	 * the bucket's does not) when the buckets are the lists themselves (regrouped planes keep that in d_sub_len), and the
 	 * list every bucket belongs to */
+	uint32_t   *w_overq = nullptr;	size_t w_overq_n = 0;	/* queries of the last batch whose records / survivors overflowed */
+	std::vector<uint32_t> redo;		/* ... on the host: ivf_s16_run returned 2, these go to the exact path one sub-batch */
+	float	   *w_redo_q = nullptr;	size_t w_redo_q_n = 0;
+	int		   *w_redo_p = nullptr;	size_t w_redo_p_n = 0;
+	unsigned char *w_redo_out = nullptr;	size_t w_redo_out_n = 0;
+	int64_t    *w_redo_idx = nullptr;	size_t w_redo_idx_n = 0;
 	bool		s16_planes_f32 = true;	/* the planes hold two-plane float4-style rows (always, except an fp16 mirror's own plane) */
 	float	   *w_qhat = nullptr;	size_t w_qhat_n = 0;	/* cosine: the batch's queries divided by their norms */
 	uint32_t   *d_plen = nullptr;	size_t d_plen_n = 0;
@@ -1760,7 +1766,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2653,6 +2659,7 @@ static int	g_s16_slack = 1;	/* the centred planes keep spare blocks and take app
 static int	g_s16c_seeds = 0;	/* rows whose upper bounds give a query its first threshold, 0 = 32 (k <= 20) or 64 ("screen16c_seeds") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
+static int	g_s16_redo = 1;		/* queries whose records / survivors overflow go to the exact path alone ("screen16_redo"; 0: the whole batch does) */
 static int	g_s16_cos = 1;		/* cosine on the matrix-core sweep, as the inner product of normalised planes ("screen16_cosine") */
 
 static bool
@@ -3133,7 +3140,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* a shard's finalize decides with the k-th LOCAL bound, looser than the whole index's: four times the room */
 	const uint32_t surv_cap = partial ? 4u * S16_SURV_CAP : (uint32_t) S16_SURV_CAP;
 	const size_t fsmem = topk_smem_bytes(surv_cap, (uint32_t) k);
-	unsigned int over = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned int over = 0, over_n = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	bool		over_pairs = false;
+
+	if (grow(ix->w_overq, ix->w_overq_n, (size_t) S16_OVER_CAP)) return NDBHIP_ERR_HIP;
 
 	for (int round = 0; round < 2; round++)
 	{
@@ -3338,7 +3348,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
 			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr,
-			  surv_cap);
+			  surv_cap, ix->w_overq);
 		HIP_TRY(hipGetLastError());
 		{
 			unsigned int f[8];
@@ -3346,6 +3356,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			HIP_TRY(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
 			over = f[0] | f[2];
+			over_n = f[0];
+			over_pairs = f[2] != 0;
+			if (g_debug_s16)
+				fprintf(stderr, "s16 debug: round %d flags %u %u %u\n", round, f[0], f[1], f[2]);
 			if (round == 0)
 				memcpy(fl8, f, sizeof(fl8));
 			if (f[2])
@@ -3408,6 +3422,16 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	}
 	if (over)
 	{
+		/* a handful of queries with more records or survivors than their buffers hold (a dense neighbourhood in a
+		 * bucket the centring serves badly): they alone go to the exact path, the others' results stand */
+		if (g_s16_redo && over_n > 0 && over_n <= (unsigned int) S16_OVER_CAP && over_n <= (unsigned int) std::max(1, nq / 8) && !over_pairs)
+		{
+			ix->redo.resize(over_n);
+			HIP_TRY(hipMemcpyAsync(ix->redo.data(), ix->w_overq, (size_t) over_n * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			g.stats.screen16_batches++;
+			return 2;
+		}
 		g.stats.screen16_fallbacks++;
 		return 1;
 	}
@@ -3575,6 +3599,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_slack"))
 		g_s16_slack = value != 0;
+	else if (!strcmp(name, "screen16_redo"))
+		g_s16_redo = value != 0;
 	else if (!strcmp(name, "screen16_cosine"))
 		g_s16_cos = value != 0;
 	else if (!strcmp(name, "build_prepare"))
@@ -3662,7 +3688,8 @@ ivf_grow_scan_buffers(ndbhip_ivf *ix, int qb, uint32_t stride, int nprobe)
 	if (grow(ix->w_dist, ix->w_dist_n, (size_t) qb * stride)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_tmin, ix->w_tmin_n, (size_t) qb * ((((stride >> 6) + (size_t) nprobe + 2) + 63) & ~(size_t) 63)))
 		return NDBHIP_ERR_HIP;
-	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode == 2))
+	/* (the same predicate as `grouped` in ivf_search_chunk: modes 2 .. 5 run the grouped scan for any batch size) */
+	if ((ix->dim % NDB_CHUNK) == 0 && g_scan_mode != 1 && (qb >= NDB_GROUPED_MIN_NQ || g_scan_mode >= 2))
 		if (grow(ix->w_qblock, ix->w_qblock_n,
 				 ((size_t) qb * nprobe / NDB_QG + (size_t) ix->ncent) * (size_t) ix->dim * NDB_QG))
 			return NDBHIP_ERR_HIP;
@@ -3675,6 +3702,28 @@ ivf_s16_wanted(const ndbhip_ivf *ix, int nq, int R, int k)
 {
 	return (g_scan_mode == 5 || (g_scan_mode == 0 && g_screen_auto && g_s16_auto && nq >= g_screen_min_nq)) &&
 		ivf_s16_eligible(ix, nq, R, k);
+}
+
+/* row which[i] of src (words dwords each) -> row i of dst */
+__global__ void
+k_rows_pick(const uint32_t *__restrict__ src, uint32_t words, const int64_t *__restrict__ which, uint32_t *__restrict__ dst)
+{
+	const uint32_t *s = src + (size_t) which[blockIdx.x] * words;
+	uint32_t   *d = dst + (size_t) blockIdx.x * words;
+
+	for (uint32_t j = threadIdx.x; j < words; j += blockDim.x)
+		d[j] = s[j];
+}
+
+/* row i of src (words dwords each) -> row which[i] of dst */
+__global__ void
+k_rows_scatter(const uint32_t *__restrict__ src, uint32_t words, const int64_t *__restrict__ which, uint32_t *__restrict__ dst)
+{
+	const uint32_t *s = src + (size_t) blockIdx.x * words;
+	uint32_t   *d = dst + (size_t) which[blockIdx.x] * words;
+
+	for (uint32_t j = threadIdx.x; j < words; j += blockDim.x)
+		d[j] = s[j];
 }
 
 /* queries already on the device; runs select (+ scan + topk when `full`) for one sub-batch */
@@ -3853,6 +3902,75 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 
 		if (rc <= 0)
 			return rc;
+		if (rc == 2)
+		{
+			/* the sweep served the batch but for ix->redo (a few queries whose records or survivors overflowed): those
+			 * alone through the paths below, as a sub-batch of their own, their rows put back where they belong */
+			const std::vector<uint32_t> redo = ix->redo;
+			const int	nr = (int) redo.size();
+
+			if (g_debug_s16)
+				fprintf(stderr, "s16 debug: %d queries go to the exact path alone (first %u), stride %u, partial %d\n", nr, redo[0], stride, partial);
+			const uint32_t cap3 = 3u * (uint32_t) k;
+			const size_t ob_t = (size_t) nr * k * sizeof(uint64_t), ob_d = (size_t) nr * k * sizeof(float), ob_c = (size_t) nr * sizeof(int),
+				ob_cand = (size_t) nr * cap3 * sizeof(ndbhip_cand), ob_tot = (size_t) nr * sizeof(int64_t);
+			std::vector<int64_t> idx(redo.begin(), redo.end());
+
+			if (grow(ix->w_redo_q, ix->w_redo_q_n, (size_t) nr * ix->dim)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_redo_idx, ix->w_redo_idx_n, (size_t) nr)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_redo_out, ix->w_redo_out_n, ob_t + ob_d + ob_c + ob_cand + ob_tot + 64)) return NDBHIP_ERR_HIP;
+			if (d_probes_in && grow(ix->w_redo_p, ix->w_redo_p_n, (size_t) nr * npr)) return NDBHIP_ERR_HIP;
+			HIP_TRY(hipMemcpyAsync(ix->w_redo_idx, idx.data(), (size_t) nr * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+			hipLaunchKernelGGL(k_rows_pick, dim3(nr), dim3(256), 0, g.stream, (const uint32_t *) d_q, (uint32_t) ix->dim,
+							   (const int64_t *) ix->w_redo_idx, (uint32_t *) ix->w_redo_q);
+			if (d_probes_in)
+				hipLaunchKernelGGL(k_rows_pick, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) d_probes_in, (uint32_t) npr,
+								   (const int64_t *) ix->w_redo_idx, (uint32_t *) ix->w_redo_p);
+			HIP_TRY(hipStreamSynchronize(g.stream));		/* idx is a local */
+			if (g_debug_s16) fprintf(stderr, "s16 debug: redo queries gathered\n");
+			/* (8-byte pieces first: every piece's offset is a multiple of its alignment) */
+			unsigned char *ob = ix->w_redo_out;
+			uint64_t   *r_tid = (uint64_t *) ob;
+			ndbhip_cand *r_cand = (ndbhip_cand *) (ob + ob_t);
+			int64_t    *r_tot = (int64_t *) (ob + ob_t + ob_cand);
+			float	   *r_dist = (float *) (ob + ob_t + ob_cand + ob_tot);
+			int		   *r_cnt = (int *) (ob + ob_t + ob_cand + ob_tot + ob_d);
+			/* the buffers above are the mirror's: the recursion must not run into this branch again (allow_s16 = false) */
+			const float *rq = ix->w_redo_q;
+			const int  *rp = d_probes_in ? (const int *) ix->w_redo_p : (const int *) nullptr;
+			const int	rc2 = ivf_search_chunk(ix, rq, nr, strategy, npr, k, max_candidates, stride, full, partial,
+											   partial ? r_cand : (ndbhip_cand *) nullptr, partial ? r_cnt : (int *) nullptr,
+											   partial ? r_tot : (int64_t *) nullptr, partial ? (uint64_t *) nullptr : r_tid,
+											   partial ? (float *) nullptr : r_dist, partial ? (int *) nullptr : r_cnt, rp,
+											   (int *) nullptr, false);
+
+			if (rc2)
+				return rc2;
+			if (g_debug_s16) { (void) hipStreamSynchronize(g.stream); fprintf(stderr, "s16 debug: redo sub-batch done\n"); }
+			if (grow(ix->w_redo_idx, ix->w_redo_idx_n, (size_t) nr)) return NDBHIP_ERR_HIP;
+			HIP_TRY(hipMemcpyAsync(ix->w_redo_idx, idx.data(), (size_t) nr * sizeof(int64_t), hipMemcpyHostToDevice, g.stream));
+			if (partial)
+			{
+				hipLaunchKernelGGL(k_rows_scatter, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) r_cand,
+								   (uint32_t) (cap3 * sizeof(ndbhip_cand) / 4), (const int64_t *) ix->w_redo_idx, (uint32_t *) d_cand);
+				hipLaunchKernelGGL(k_rows_scatter, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) r_cnt, 1u,
+								   (const int64_t *) ix->w_redo_idx, (uint32_t *) d_ncand);
+				hipLaunchKernelGGL(k_rows_scatter, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) r_tot, 2u,
+								   (const int64_t *) ix->w_redo_idx, (uint32_t *) d_total);
+			}
+			else
+			{
+				hipLaunchKernelGGL(k_rows_scatter, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) r_tid, (uint32_t) (2 * k),
+								   (const int64_t *) ix->w_redo_idx, (uint32_t *) d_otid);
+				hipLaunchKernelGGL(k_rows_scatter, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) r_dist, (uint32_t) k,
+								   (const int64_t *) ix->w_redo_idx, (uint32_t *) d_odist);
+				hipLaunchKernelGGL(k_rows_scatter, dim3(nr), dim3(64), 0, g.stream, (const uint32_t *) r_cnt, 1u,
+								   (const int64_t *) ix->w_redo_idx, (uint32_t *) d_ocnt);
+			}
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(g.stream));		/* idx */
+			return 0;
+		}
 		/* some query emitted more than its record capacity: the older path has none */
 	}
 	/* The paths below keep a [queries x candidates] distance array, which the caller did not size when it expected

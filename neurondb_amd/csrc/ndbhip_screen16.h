@@ -775,10 +775,14 @@ s16_e(int dim, float q2, float x2max, bool sub)
 	{
 		/* COSINE runs as the inner product of NORMALISED rows and queries (k_rows_normalise: q^ = fl32(q / |q|), norms
 		 * within 1 +- 4u): a = -(q^.x^) as the sweep computes it is within cdot |q^||x^| of the fp32 vectors' product,
-		 * that within 6u of the real cosine, and the reference's 1 - dot / (sqrt(n1) sqrt(n2)) (three sequential fp32
-		 * sums, two roots, a quotient, a difference) within 4 gamma_(dim + 8) of 1 - cosine: |(1 + a) - reference| <= e.
-		 * The norms and the subnormal term play no part: the planes hold decoded, normalised values. */
-		e = ndb_s16_cdot(dim) * 1.00001f + 4.0f * ndb_s16_gamma(dim + 8) + 16.0f * NDB_S16_U;
+		 * that within 6u of the real cosine.  The reference's 1 - dot / (sqrt(n1) sqrt(n2)): the dot product's sequential
+		 * fp32 sum is within gamma_dim |q||x| of the real one; n1 and n2 (sums of non-negative terms) within gamma_dim
+		 * relatively, their roots within gamma_dim / 2 + u each, the product of the roots within gamma_dim + 3u; so the
+		 * quotient is within (gamma_dim |q||x| + |dot| (gamma_dim + 3u)) / (|q||x|) (1 + ..) + u <= 2 gamma_dim + 5u of the
+		 * real cosine (|dot| <= |q||x|), and the difference adds 2u: 2.01 gamma_(dim + 8) + 16u covers it with the second-
+		 * order terms.  |(1 + a) - reference| <= e.  The norms and the subnormal term play no part: the planes hold
+		 * decoded, normalised values. */
+		e = ndb_s16_cdot(dim) * 1.00001f + 2.01f * ndb_s16_gamma(dim + 8) + 16.0f * NDB_S16_U;
 		return s16_up(e * 1.00001f) + NDB_S16_ABS;
 	}
 	if (R == R_IVF_L2)
@@ -830,6 +834,7 @@ s16_thr_from_a(float ak, float e, int dim)
  * One wave per query; PER = centroids per lane.
  */
 #define NDB_CSEL_CAP 256
+#define S16_OVER_CAP 512		/* queries of a batch that may go to the exact path on their own (more: the whole batch does) */
 
 template <int PER>
 __global__ __launch_bounds__(64) void
@@ -2114,7 +2119,9 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 														 * candidate's LOWER bound, eub its upper bound, and the
 														 * threshold carries no error term */,
 			   uint32_t surv_cap = S16_SURV_CAP /* survivors the block's LDS holds (a shard's k-th local bound is looser
-												 * than the index's: it gets more room) */ )
+												 * than the index's: it gets more room) */,
+			   uint32_t *__restrict__ over_q = nullptr /* [S16_OVER_CAP] the queries counted in flags[0]: what the host
+														* hands to the exact path one by one instead of the whole batch */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	TopkSmem	s = carve_topk_smem(smem_raw, surv_cap, k);
@@ -2130,7 +2137,10 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	{
 		if (tid == 0)
 		{
-			atomicAdd(&flags[0], 1u);
+			const uint32_t sl = atomicAdd(&flags[0], 1u);
+
+			if (over_q && sl < S16_OVER_CAP)
+				over_q[sl] = q;
 			rec_counts[q] = 0;
 		}
 		return;					/* uniform */
@@ -2185,7 +2195,10 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	{
 		if (tid == 0)
 		{
-			atomicAdd(&flags[0], 1u);
+			const uint32_t sl = atomicAdd(&flags[0], 1u);
+
+			if (over_q && sl < S16_OVER_CAP)
+				over_q[sl] = q;
 			rec_counts[q] = 0;
 		}
 		return;

@@ -309,7 +309,8 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
             assert st["screen16_batches"] + st["screen16_fallbacks"] == 1, st
             if sublists and cap == 0 and dim == 64:
                 # many sublists of the probed lists are excluded: |q - c| - radius (L2), -(q.c) - |q| radius (inner product)
-                assert st["rows_swept"] < st["rows_scored"] * 2 // 3, st
+                # (cosine cannot exclude a list that is its own sublist — list 3 here —: its centre lives in the rows' space)
+                assert st["rows_swept"] < st["rows_scored"] * (4 if strategy == 2 else 2) // (5 if strategy == 2 else 3), st
             if half is not None:
                 ix.close()
                 continue
@@ -553,3 +554,36 @@ def test_deletes_leave_holes_in_the_planes_without_a_new_layout(sublists, lib):
         ix.close()
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_sublists", 1))
+
+
+@pytest.mark.parametrize("strategy", [1, 3, 2])
+def test_a_few_queries_with_too_many_ties_go_to_the_exact_path_alone(strategy, lib):
+    """400 identical rows: a query next to them has 400 candidates no bound can separate — more survivors than the
+    finalize stage holds.  Such queries (a handful per batch) are served by the exact path as a sub-batch of their own
+    and put back; the other queries' results from the sweep stand, and the batch does not count as a fallback."""
+    from oracle import ndbo
+    rng = np.random.default_rng(77 + strategy)
+    dim, nlists = 64, 8
+    cen = (rng.standard_normal((24, dim)) * 4).astype(np.float32)
+    base = (cen[rng.integers(0, 24, 6000)] + 0.05 * rng.standard_normal((6000, dim))).astype(np.float32)
+    dup = (cen[5] + 0.05 * rng.standard_normal(dim)).astype(np.float32)
+    base[1000:1400] = dup                                                            # 400 equal rows, one list
+    cent = base[rng.choice(6000, nlists, replace=False)].copy()
+    asg = ((base[:, None, :].astype(np.float64) - cent[None]) ** 2).sum(-1).argmin(1)
+    order = np.argsort(asg, kind="stable")
+    a = dict(centroids=cent, list_len=np.bincount(asg, minlength=nlists).astype(np.int64), rows=np.ascontiguousarray(base[order]),
+             tids=ndbo.tids_from_rows(order))
+    img = oracle_image(a)
+    nq, k, nprobe = 160, 10, 4
+    q = (cen[rng.integers(0, 24, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float32)
+    q[[3, 50, 51, 120]] = dup + np.float32(0.001) * rng.standard_normal((4, dim)).astype(np.float32)
+    q[77] = dup
+    et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, 0)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    ix = _index(a)
+    lib.check(lib.lib().ndbhip_stats_reset())
+    t, d, c = ix.search(q, strategy, nprobe, k, 0)
+    st = lib.stats()
+    assert_same_results(t, d, c, et, ed, ec)
+    assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
+    ix.close()
