@@ -1664,6 +1664,10 @@ struct ndbhip_ivf
 	int64_t    *w_redo_idx = nullptr;	size_t w_redo_idx_n = 0;
 	bool		s16_planes_f32 = true;	/* the planes hold two-plane float4-style rows (always, except an fp16 mirror's own plane) */
 	float	   *w_qhat = nullptr;	size_t w_qhat_n = 0;	/* cosine: the batch's queries divided by their norms */
+	/* cosine: planes / norms / exponents of the queries AS THEY ARE, for the centroid scan (always L2 on the rows' own space) */
+	unsigned char *w_qplanes_o = nullptr;	size_t w_qplanes_o_n = 0;
+	float	   *w_qn2_o = nullptr;	size_t w_qn2_o_n = 0;
+	int		   *w_qexp_o = nullptr;	size_t w_qexp_o_n = 0;
 	uint32_t   *d_plen = nullptr;	size_t d_plen_n = 0;
 	uint32_t   *d_bucket_list = nullptr;	size_t d_bucket_list_n = 0;
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
@@ -1766,7 +1770,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3760,6 +3764,10 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	 * sweep both multiply them) */
 	const bool	s16_here = full && allow_s16 && ivf_s16_wanted(ix, nq, ivf_recipe(strategy), k);
 	bool		cent_done = false;
+	/* the query planes the centroid scan multiplies (cosine: not the sweep's) */
+	const unsigned char *cq_planes = nullptr;
+	const float *cq_n2 = nullptr;
+	const int  *cq_exp = nullptr;
 
 	ix->bat_subdist = nullptr;
 
@@ -3773,12 +3781,24 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (grow(ix->w_qthr, ix->w_qthr_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 		const float *qsrc = d_q;
 
+		cq_planes = ix->w_qplanes;
+		cq_n2 = ix->w_qn2;
+		cq_exp = ix->w_qexp;
 		if (ivf_recipe(strategy) == R_IVF_COS)
 		{
 			/* cosine: the planes are those of q / |q| (the exact arithmetic keeps reading d_q itself) */
 			if (grow(ix->w_qhat, ix->w_qhat_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_rows_normalise<0>, dim3((nq + 3) / 4), dim3(256), 0, g.stream, (const void *) d_q, (int64_t) nq, ix->dim, ix->w_qhat);
 			qsrc = ix->w_qhat;
+			/* ... and the centroid scan, which is L2 in the rows' own space, multiplies planes of the queries as they are */
+			if (grow(ix->w_qplanes_o, ix->w_qplanes_o_n, (size_t) nq * dimp * 4)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_qn2_o, ix->w_qn2_o_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_qexp_o, ix->w_qexp_o_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, d_q, (uint32_t) nq, ix->dim, dimp,
+							   (ndb_h2 *) ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o);
+			cq_planes = ix->w_qplanes_o;
+			cq_n2 = ix->w_qn2_o;
+			cq_exp = ix->w_qexp_o;
 		}
 		hipLaunchKernelGGL(k_s16_qprep, dim3((nq + 3) / 4), dim3(256), 0, g.stream, qsrc, (uint32_t) nq, ix->dim, dimp,
 						   (ndb_h2 *) ix->w_qplanes, ix->w_qn2, ix->w_qexp);
@@ -3794,15 +3814,14 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (rc)
 			return rc;
 	}
-	if (!d_probes_in && s16_here && g_cent_s16 && ncmp >= 256 && ncmp <= 4096 && npr <= NDBHIP_MAX_NPROBE &&
-		ivf_recipe(strategy) != R_IVF_COS /* (its query planes are the normalised queries') */ )
+	if (!d_probes_in && s16_here && g_cent_s16 && ncmp >= 256 && ncmp <= 4096 && npr <= NDBHIP_MAX_NPROBE)
 	{
 		/* HOT LOOP 1 for a screened batch: |q - centroid|^2 of every pair from the two-plane sweep (MODE 3), the
 		 * reference's arithmetic for the centroids near the nprobe-th only (k_cent_select) */
 		/* the planes laid out and their centres known: the centroids and the regrouped lists' centres are one matrix
 		 * (dm_all), the sweep's sublist code reads its columns past the centroids' */
 		const bool	both = ix->s16_valid && ix->s16_sub && ix->dm_all_valid && ix->dm_all_ncmp == ncmp && ix->nsub_g > 0 &&
-			ix->dm_all.n == ncmp + ix->nsub_g && g_s16_prune;
+			ix->dm_all.n == ncmp + ix->nsub_g && g_s16_prune && ivf_recipe(strategy) != R_IVF_COS;
 		S16Mat	   &cm = both ? ix->dm_all : ix->dm_cent;
 		const uint32_t astride = (uint32_t) (((both ? ncmp + ix->nsub_g : ncmp) + 63) & ~63);
 
@@ -3817,7 +3836,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (grow(ix->w_amat, ix->w_amat_n, (size_t) nq * astride)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_cfull, ix->w_cfull_n, (size_t) nq)) return NDBHIP_ERR_HIP;
 		{
-			const int	rc = s16mat_run(cm, ix->dim, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq, ix->w_amat, astride);
+			const int	rc = s16mat_run(cm, ix->dim, cq_planes, cq_n2, cq_exp, ix->w_qthr, nq, ix->w_amat, astride);
 
 			if (rc)
 				return rc;
@@ -3829,7 +3848,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		}
 #define CENT_SELECT_L(PER)                                                                                          \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cent_select<PER>), dim3(nq), dim3(64), 0, g.stream, (const float *) ix->w_amat, astride, \
-						   (const float *) ix->w_qn2, (const uint32_t *) cm.xmax, d_q, (const float *) d.centroids, ix->dim, \
+						   cq_n2, (const uint32_t *) cm.xmax, d_q, (const float *) d.centroids, ix->dim, \
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,                          \
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->w_cdist, cstride, w_probes, ix->w_candoff, \
 						   lco_w, ix->w_cfull)
