@@ -147,8 +147,11 @@ int			ndbhip_set_scan_mode(int mode);
  *   "build_prepare"     0     ndbhip_ivf_build / _build_device end with ndbhip_ivf_prepare(ix, this strategy 1 .. 3): the index leaves the
  *                             build searchable at full speed (0: the first batched scan, or an explicit ndbhip_ivf_prepare, pays for it)
  *   "hnsw_intended_waves" 16  waves per CU walking the intended HNSW (build and search); each owns a visited bitmap of one bit per node
- *   "screen16_cosine"   1     cosine batches run the same sweep as the inner product of NORMALISED planes (rows and queries divided by
- *                             their norms; sublists regrouped in that space); 0: the round-1 fp32 screen
+ *   "screen16_cosine"   1     cosine batches run the matrix-core sweep over NORMALISED planes (rows and queries divided by their
+ *                             norms; sublists regrouped in that space); 0: the round-1 fp32 screen
+ *   "screen16_cosine_centered" 1  ... as the centred L2 sweep (|q^ - x^|^2 = 2 x cosine distance); 0: as the inner product of
+ *                             two-plane normalised rows
+ *   "screen16_redo"     1     queries whose records / survivors overflow go to the exact path alone (0: their whole batch does)
  *   "screen16_slack"    1     the centred planes keep spare 32-row blocks per bucket and take appends in place (0: every append lays them out again)
  *   "screen_min_nq"     32    batches of at least this many queries take the screened (matrix-core) scan; smaller ones the exact grouped scan
  *   "screen16c_nbuf"    0     ring depth of the centred sweep: 2 | 3, 0 = the tile geometry's default

@@ -1664,6 +1664,8 @@ struct ndbhip_ivf
 	int64_t    *w_redo_idx = nullptr;	size_t w_redo_idx_n = 0;
 	bool		s16_planes_f32 = true;	/* the planes hold two-plane float4-style rows (always, except an fp16 mirror's own plane) */
 	float	   *w_qhat = nullptr;	size_t w_qhat_n = 0;	/* cosine: the batch's queries divided by their norms */
+	float	   *d_cent_hat = nullptr;	size_t d_cent_hat_n = 0;	/* cosine: the centroids divided by their norms (bucket centres of lists that are their own sublist) */
+	bool		s16_cos_layout = false;		/* the planes are the normalised rows' */
 	/* cosine: planes / norms / exponents of the queries AS THEY ARE, for the centroid scan (always L2 on the rows' own space) */
 	unsigned char *w_qplanes_o = nullptr;	size_t w_qplanes_o_n = 0;
 	float	   *w_qn2_o = nullptr;	size_t w_qn2_o_n = 0;
@@ -1770,7 +1772,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2491,7 +2493,7 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 						   (const uint64_t *) ix->d_tids, (uint32_t *) nv, nt, row_words, (size_t) nrows);
 		/* centred planes stay: holes for the deleted rows, new list positions for the others (the lists' radii remain
 		 * upper bounds; a bucket emptied of live rows simply emits nothing) */
-		const bool	planes_stay = ix->s16_valid && ix->s16_cen_layout && ix->d_plen && ix->d_bucket_list &&
+		const bool	planes_stay = ix->s16_valid && ix->s16_cen_layout && !ix->s16_cos_layout && ix->d_plen && ix->d_bucket_list &&
 			!ix->s16_prow.empty();
 
 		if (planes_stay)
@@ -2683,7 +2685,8 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 }
 
 static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off_host, bool slack,
-								   const float *rows32 = nullptr /* the rows to regroup (cosine: their normalised copy) */ );	/* ndbhip_build.h */
+								   const float *rows32 = nullptr /* the rows to regroup (cosine: their normalised copy) */,
+								   const float *list_centres = nullptr /* (cosine: the normalised centroids) */ );	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
 static int	s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim);	/* ndbhip_build.h */
 static int	s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr,
@@ -2694,10 +2697,13 @@ static int	g_s16_sub_min = 256;	/* lists longer than this are regrouped where th
 static int	g_s16_sub_rows = 128;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
 
 /* does the centred one-plane sweep (ndbhip_screen16c.h) serve this recipe on this mirror */
+static int	g_s16_cos_cen = 1;	/* cosine on the CENTRED sweep: |q^ - x^|^2 = 2 x cosine distance ("screen16_cosine_centered") */
+
 static bool
 ivf_s16_centered(const ndbhip_ivf *ix, int R)
 {
-	return R == R_IVF_L2 && !ix->f16 && g_s16_cen != 0;
+	/* (cosine: the planes come from a normalised fp32 copy whatever the mirror holds) */
+	return g_s16_cen != 0 && ((R == R_IVF_L2 && !ix->f16) || (R == R_IVF_COS && g_s16_cos && g_s16_cos_cen));
 }
 
 /*
@@ -2745,16 +2751,23 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			const dim3	gn((unsigned) ((ix->nrows + 3) / 4));
 
 			if (!ix->f16)
-				hipLaunchKernelGGL(k_rows_normalise<0>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p);
+				hipLaunchKernelGGL(k_rows_normalise<0>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p, cen ? 1 : 0);
 			else if (ix->f16_sub)
-				hipLaunchKernelGGL(k_rows_normalise<1>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p);
+				hipLaunchKernelGGL(k_rows_normalise<1>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p, cen ? 1 : 0);
 			else
-				hipLaunchKernelGGL(k_rows_normalise<2>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p);
+				hipLaunchKernelGGL(k_rows_normalise<2>, gn, dim3(256), 0, g.stream, (const void *) ix->d_vecs, ix->nrows, dim, hat.p, cen ? 1 : 0);
+		}
+		ix->s16_cos_layout = cosn;
+		if (cosn)
+		{
+			if (grow(ix->d_cent_hat, ix->d_cent_hat_n, (size_t) nc * dim)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_rows_normalise<0>, dim3((nc + 3) / 4), dim3(256), 0, g.stream, (const void *) ix->d_centroids,
+							   (int64_t) nc, dim, ix->d_cent_hat);
 		}
 		if (sub_cfg != 0)
 		{
 			/* long lists regrouped into sublists: sets ix->s16_sub and the d_sub_* tables, bo = their block offsets */
-			const int	rc = ivf_s16_build_sublists(ix, bo, cen && g_s16_slack != 0, hat.p);
+			const int	rc = ivf_s16_build_sublists(ix, bo, cen && g_s16_slack != 0, hat.p, cosn ? ix->d_cent_hat : (const float *) nullptr);
 
 			if (rc)
 				return rc;
@@ -2843,10 +2856,10 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 						   ix->s16_sub ? ix->nsub : nc, ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16,               \
 						   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr)
 		if (cen)
-			hipLaunchKernelGGL(k_s16c_row_prep, gp, dim3(256), 0, g.stream, (const float *) ix->d_vecs, ix->nrows, dim, dimp,
+			hipLaunchKernelGGL(k_s16c_row_prep, gp, dim3(256), 0, g.stream, cosn ? (const float *) hat.p : (const float *) ix->d_vecs, ix->nrows, dim, dimp,
 							   ix->s16_sub ? (const int64_t *) ix->d_sub_loc : (const int64_t *) ix->d_loc_off,
 							   ix->s16_sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,
-							   ix->s16_sub ? ix->nsub : nc, (const float *) ix->d_centroids,
+							   ix->s16_sub ? ix->nsub : nc, cosn ? (const float *) ix->d_cent_hat : (const float *) ix->d_centroids,
 							   ix->s16_sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
 							   ix->d_planes, ix->d_rn2, ix->d_rexp,
 							   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr,
@@ -2916,8 +2929,8 @@ ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vect
 {
 	const int	nc = ix->ncent, dim = ix->dim, dimp = (dim + 63) & ~63;
 
-	if (!ix->s16_cen_layout || !g_s16_slack || ix->f16 || (int) ix->s16_tail.size() != nc)
-		return 1;
+	if (!ix->s16_cen_layout || ix->s16_cos_layout || !g_s16_slack || ix->f16 || (int) ix->s16_tail.size() != nc)
+		return 1;				/* (the cosine layout's planes are normalised rows: laid out again) */
 	std::vector<S16CApp> recs;
 	std::vector<uint32_t> bidx, bval;
 
@@ -2990,6 +3003,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const uint32_t ecap = std::max<uint32_t>(std::min<uint32_t>(g_s16_ecap, (uint32_t) ((((size_t) 1 << 30) / 8) / (size_t) nq)), 64u);
 
 	const bool	cen = ivf_s16_centered(ix, R);
+	const bool	cosb = cen && R == R_IVF_COS;	/* cosine on the centred sweep: normalised planes, thresholds in their squared-L2 domain */
 	{
 		const int	rc = ivf_s16_prepare(ix, R);
 
@@ -3038,7 +3052,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
 
-	if (!seed_by_sublist && cen)
+	if (!seed_by_sublist && cen && !cosb)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<false>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 						   (uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
 						   (const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
@@ -3160,7 +3174,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			 * against the threshold its first records give — rare enough that its nine launches are not worth
 			 * queueing for every batch */
 			HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned int), g.stream));
-			if (R == R_IVF_IP || R == R_IVF_COS)
+			if (cosb)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_COS>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
+								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 1);
+			else if (R == R_IVF_IP || R == R_IVF_COS)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_IP>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 0);
 			else
@@ -3174,9 +3191,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		/* inner product: sublists are excluded by -(q.c) - |q| rad (k_sub_pairs); that needs the centroid scan's
 		 * distances of this call */
 		const bool	prune = g_s16_prune && (R == R_IVF_L2 || (R == R_IVF_IP && sub && cdist) || (R == R_IVF_COS && sub));
-		const int	ipb = R == R_IVF_IP ? 1 : (R == R_IVF_COS ? 2 : 0);
+		const int	ipb = R == R_IVF_IP ? 1 : (R == R_IVF_COS ? (cosb ? 3 : 2) : 0);
 
-		if (prune && !(sub && cdist))
+		if (prune && !(sub && cdist) && R == R_IVF_L2)
 		{
 			/* (query, list) pairs whose every row lies beyond the query's current threshold: |q - c| - radius
 			 * (with sublists and the centroid scan's distances at hand, k_sub_pairs applies the same test itself) */
@@ -3215,7 +3232,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 					sub_rn2 = ix->dm_sub.rn2;
 				}
 				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
-				if (cen)
+				if (cen && !cosb)
 					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<true>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 									   (uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
@@ -3229,7 +3246,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							  (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
 							  (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
 							  subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, 0, ipb ? sub_rn2 : (const float *) nullptr,
+							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, cosb ? 1 : 0, ipb ? sub_rn2 : (const float *) nullptr,
 							  ipb ? (const float *) ix->d_cn2 : (const float *) nullptr, H == 1 ? 1 : 0);
 				}
 				if (g_thr_hook)
@@ -3283,8 +3300,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		{
 			/* q - c of every pair that is left, in the pair tables' order (more pairs than the planes hold: flags[0],
 			 * the batch goes to the older path and the sweep below returns at once) */
-			hipLaunchKernelGGL(k_s16c_qcprep, dim3(g.num_cus * 8), dim3(256), 0, g.stream, d_q, dim, dimp,
-							   (const PairRec *) ix->w_pairs, (const uint32_t *) pair_off, ncs, (const float *) ix->d_centroids,
+			hipLaunchKernelGGL(k_s16c_qcprep, dim3(g.num_cus * 8), dim3(256), 0, g.stream, cosb ? (const float *) ix->w_qhat : d_q, dim, dimp,
+							   (const PairRec *) ix->w_pairs, (const uint32_t *) pair_off, ncs,
+							   cosb ? (const float *) ix->d_cent_hat : (const float *) ix->d_centroids,
 							   sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
 							   ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_pslot, ix->w_pslot + qc_cap, ix->w_pslot + 2 * (size_t) qc_cap,
 							   lco, npr, qc_cap, flags + 2, round == 0 ? flags + 4 : (unsigned int *) nullptr,
@@ -3317,7 +3335,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
-							   (const uint32_t *) ix->d_pposof, cE, qc_cap)
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0)
 			if (g_s16_debug == 1 && c_qb == 8)
 				S16C_SWEEP_L(8, 2, 1);
 			else if (g_s16_debug == 2 && c_qb == 8)
@@ -3603,6 +3621,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16_slack"))
 		g_s16_slack = value != 0;
+	else if (!strcmp(name, "screen16_cosine_centered"))
+		g_s16_cos_cen = value != 0;
 	else if (!strcmp(name, "screen16_redo"))
 		g_s16_redo = value != 0;
 	else if (!strcmp(name, "screen16_cosine"))
@@ -3788,7 +3808,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		{
 			/* cosine: the planes are those of q / |q| (the exact arithmetic keeps reading d_q itself) */
 			if (grow(ix->w_qhat, ix->w_qhat_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
-			hipLaunchKernelGGL(k_rows_normalise<0>, dim3((nq + 3) / 4), dim3(256), 0, g.stream, (const void *) d_q, (int64_t) nq, ix->dim, ix->w_qhat);
+			hipLaunchKernelGGL(k_rows_normalise<0>, dim3((nq + 3) / 4), dim3(256), 0, g.stream, (const void *) d_q, (int64_t) nq, ix->dim, ix->w_qhat,
+							   ivf_s16_centered(ix, R_IVF_COS) ? 1 : 0);
 			qsrc = ix->w_qhat;
 			/* ... and the centroid scan, which is L2 in the rows' own space, multiplies planes of the queries as they are */
 			if (grow(ix->w_qplanes_o, ix->w_qplanes_o_n, (size_t) nq * dimp * 4)) return NDBHIP_ERR_HIP;

@@ -1967,8 +1967,11 @@ k_rows_decode_f16(const uint16_t *__restrict__ src, size_t n, float *__restrict_
 }
 
 static int
-ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, const float *rows32)
+ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, const float *rows32, const float *list_centres)
 {
+	/* the lists' own centres: their centroids, or (cosine) the centroids divided by their norms — the space rows32 is in */
+	const float *lcent = list_centres ? list_centres : (const float *) ix->d_centroids;
+
 	const int	nc = ix->ncent, dim = ix->dim;
 	std::vector<int> giant, midl;
 	/* an fp16 mirror is regrouped on a transient fp32 copy of its decoded rows (the copy goes when this returns;
@@ -2009,7 +2012,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, co
 	if (grow(ix->d_lrad, ix->d_lrad_n, (size_t) nc)) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipMemsetAsync(ix->d_lrad, 0, (size_t) nc * sizeof(uint32_t), g.stream));
 	hipLaunchKernelGGL(k_s16_list_radius<0>, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const void *) vecs32,
-					   ix->nrows, dim, (const int64_t *) ix->d_loc_off, nc, (const float *) ix->d_centroids, ix->d_lrad);
+					   ix->nrows, dim, (const int64_t *) ix->d_loc_off, nc, lcent, ix->d_lrad);
 	std::vector<float> lrad((size_t) nc);
 
 	HIP_TRY(hipMemcpyAsync(lrad.data(), ix->d_lrad, (size_t) nc * 4, hipMemcpyDeviceToHost, g.stream));
@@ -2248,8 +2251,15 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, co
 	first[(size_t) nc] = (uint32_t) nsub;
 	if (grow(ix->d_perm, ix->d_perm_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
 	if (grow(ix->d_posof, ix->d_posof_n, (size_t) ix->nrows)) return NDBHIP_ERR_HIP;
-	if (grow(ix->d_subcent, ix->d_subcent_n, nsub_g * (size_t) dim)) return NDBHIP_ERR_HIP;
+	/* cosine (list_centres given): the lists' own normalised centres join the matrix of centres, so that a list that is its
+	 * own sublist has a distance in the normalised space too (the centroid scan's is in the rows' own space) */
+	const size_t ncol = nsub_g + (list_centres ? (size_t) nc : 0);
+
+	if (grow(ix->d_subcent, ix->d_subcent_n, ncol * (size_t) dim)) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipMemcpyAsync(ix->d_subcent, d_cents, nsub_g * (size_t) dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+	if (list_centres)
+		HIP_TRY(hipMemcpyAsync(ix->d_subcent + nsub_g * (size_t) dim, list_centres, (size_t) nc * dim * sizeof(float),
+							   hipMemcpyDeviceToDevice, g.stream));
 	hipLaunchKernelGGL(k_s16_identity_perm, dim3((unsigned) ((ix->nrows + 255) / 256)), dim3(256), 0, g.stream, ix->nrows,
 					   (const int64_t *) ix->d_loc_off, nc, ix->d_perm, ix->d_posof);
 	std::vector<uint32_t> sub_len(nsub, 0);
@@ -2270,6 +2280,11 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, co
 	for (int c = 0; c < nc; c++)
 		if (nsub_of[(size_t) c] == 1)
 			sub_len[first[(size_t) c]] = (uint32_t) ix->own_len[c];
+	if (list_centres)
+		for (int c = 0; c < nc; c++)
+			for (uint32_t s2 = first[(size_t) c]; s2 < first[(size_t) c + 1]; s2++)
+				if (sub_gidx[s2] < 0)
+					sub_gidx[s2] = (int) (nsub_g + (size_t) c);		/* (whole lists and the tail buckets: the list's own centre) */
 	/* offsets: sublists are consecutive in the planes, every one starts a new 32-row block */
 	std::vector<int64_t> sub_loc(nsub + 1, 0);
 	std::vector<const float *> cptr(nsub);
@@ -2301,7 +2316,7 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, co
 		{
 			const size_t s2 = first[(size_t) c] + j;
 
-			cptr[s2] = sub_gidx[s2] >= 0 ? ix->d_subcent + (size_t) sub_gidx[s2] * dim : ix->d_centroids + (size_t) c * dim;
+			cptr[s2] = sub_gidx[s2] >= 0 ? ix->d_subcent + (size_t) sub_gidx[s2] * dim : lcent + (size_t) c * dim;
 		}
 	if (grow(ix->d_sub_first, ix->d_sub_first_n, (size_t) nc + 1)) return NDBHIP_ERR_HIP;
 	if (grow(ix->d_sub_len, ix->d_sub_len_n, nsub)) return NDBHIP_ERR_HIP;
@@ -2322,14 +2337,14 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, co
 					   (const float *const *) ix->d_sub_cptr, ix->d_sub_rad);
 	/* the centres of the regrouped lists as one list of the matrix-core sweep: planes, norms, exponents */
 	{
-		const int	rc = s16mat_prepare(ix->dm_sub, ix->d_subcent, (int) nsub_g, dim);
+		const int	rc = s16mat_prepare(ix->dm_sub, ix->d_subcent, (int) ncol, dim);
 
 		if (rc)
 			return rc;
 	}
 	HIP_TRY(hipStreamSynchronize(g.stream));			/* the host tables are locals */
 	ix->nsub = (int) nsub;
-	ix->nsub_g = (int) nsub_g;
+	ix->nsub_g = (int) ncol;
 	ix->s16_sub = true;
 	if (g_debug_s16)
 		fprintf(stderr, "s16 sublists: %zu lists regrouped into %zu sublists (%zu in all), %llu row blocks\n", kept.size(), nsub_g,

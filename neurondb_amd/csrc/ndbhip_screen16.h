@@ -534,7 +534,10 @@ s16_sub_excluded_ip(double alo, float q2, float c2, uint32_t rad_bits, float thr
  * model covers becomes NaN (its plane row is marked, every candidate of it is emitted).  One wave per row. */
 template <int H16>
 __global__ __launch_bounds__(256) void
-k_rows_normalise(const void *__restrict__ src, int64_t n, int dim, float *__restrict__ out)
+k_rows_normalise(const void *__restrict__ src, int64_t n, int dim, float *__restrict__ out,
+				 int zero_is_nan = 0 /* the centred form (|q^ - x^|^2 = 2 x cosine distance) holds for UNIT vectors only: a zero
+									  * vector, whose reference distance is exactly 1, must not pass for one at squared
+									  * distance 1 = "cosine distance 0.5" — it is marked like a vector out of range */ )
 {
 	const int	lane = threadIdx.x & 63;
 	const int64_t r = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -561,7 +564,7 @@ k_rows_normalise(const void *__restrict__ src, int64_t n, int dim, float *__rest
 	/* the error model of s16_e<R_IVF_COS> assumes the reference's fp32 sums neither overflow nor lose their terms to
 	 * underflow: |x|^2 within [1e-28, 1e37] (terms below 2^-126 then add up to < 1e-7 of the sum), or exactly zero;
 	 * anything else is left to the exact arithmetic (NaN marks the row / the query) */
-	const bool	ok = s == 0.0 || (s >= 1.0e-28 && s <= 1.0e37);
+	const bool	ok = (s == 0.0 && !zero_is_nan) || (s >= 1.0e-28 && s <= 1.0e37);
 	const double inv = (ok && s > 0.0) ? 1.0 / __builtin_sqrt(s) : 0.0;
 
 	for (int i = lane; i < dim; i += 64)
@@ -637,7 +640,7 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 
 			s0 = sub_first[L];
 			n = sub_first[L + 1] - s0;
-			pd = (!prune || ip == 2) ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
+			pd = (!prune || ip >= 2) ? 0.0f : (cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p]);
 			if (ip == 1 && prune)
 				c2l = cn2_list[L];
 		}
@@ -682,8 +685,14 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 				continue;
 			const int	gi = sub_gidx[s];
 
-			if (prune && ip == 2 && gi < 0)
-				;				/* cosine: a list that is its own sublist has no centre in the normalised space: kept */
+			if (prune && ip >= 2 && gi < 0)
+				;				/* cosine: the centroid scan's distance to a list that is its own sublist is in the rows' own space: kept */
+			else if (prune && ip == 3)
+			{
+				/* cosine on the centred sweep: the L2 test in the normalised space */
+				if (s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te))
+					continue;
+			}
 			else if (prune && ip)
 			{
 				const double pdl = (double) s_pd[w][lo];
@@ -818,6 +827,33 @@ s16_thr_from_a(float ak, float e, int dim)
 		return s16_up(s16_up(t) + e);
 	}
 	return s16_up(s16_up(ak + e) + e);
+}
+
+/*
+ * COSINE ON THE CENTRED SWEEP (ndbhip_screen16c.h): |q^ - x^|^2 = 2 (1 - q^.x^) = 2 x (cosine distance) for the normalised
+ * vectors, so the centred one-plane L2 sweep over the NORMALISED planes bounds the cosine distance; its thresholds T live
+ * in that squared-L2 domain.  e_ref = what separates the reference's 1 - dot / (sqrt(n1) sqrt(n2)) from the real cosine
+ * distance (s16_e<R_IVF_COS>: 2.01 gamma_(dim + 8) + 16u) plus the normalisation's roundings (|q^_f|, |x^_f| within 4u of 1:
+ * 32u on the squared distance).
+ *   from a reference value thr that bounds the k-th from above: a row can be among the k only if its reference value is
+ *     <= thr, i.e. its real cosine distance <= thr + e_ref, i.e. |q^ - x^|^2 <= 2 (thr + e_ref):  T = 2 (thr + e_ref);
+ *   from the k-th smallest upper bound U of |q^ - x^|^2 over distinct candidates: those k rows have reference values
+ *     <= U / 2 + e_ref, which is such a thr:  T = U + 4 e_ref.
+ */
+__device__ __forceinline__ float
+s16c_cos_eref(int dim)
+{
+	return (2.01f * ndb_s16_gamma(dim + 8) + 48.0f * NDB_S16_U) * 1.0001f;
+}
+__device__ __forceinline__ float
+s16c_cos_t_from_ref(float thr, int dim)
+{
+	return s16_up(s16_up(2.0f * (fmaxf(thr, 0.0f) + s16c_cos_eref(dim))) * 1.000001f);
+}
+__device__ __forceinline__ float
+s16c_cos_t_from_ub(float ub, int dim)
+{
+	return s16_up(s16_up(fmaxf(ub, 0.0f)) * 1.000001f + 4.0f * s16c_cos_eref(dim));
 }
 
 /*
@@ -1051,7 +1087,7 @@ k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
 
 		if (thr == thr)			/* a NaN distance bounds nothing */
-			thrE = s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
+			thrE = (R == R_IVF_COS && cen) ? s16c_cos_t_from_ref(thr, dim) : s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
 	}
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
@@ -1194,7 +1230,7 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
 
 		if (thr == thr)			/* a NaN distance bounds nothing */
-			thrE = s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
+			thrE = (R == R_IVF_COS && cen) ? s16c_cos_t_from_ref(thr, dim) : s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
 	}
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
@@ -2090,7 +2126,9 @@ k_s16_retarget(int dim, uint32_t k, float2 *__restrict__ qthr, unsigned int *__r
 		const float2 o = qthr[q];
 
 		const float ak = __uint_as_float(tb);
-		const float nt = cen ? s16_up(s16_up(fmaxf(ak, 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))) : s16_thr_from_a<R>(ak, o.y, dim);
+		const float nt = cen ? (R == R_IVF_COS ? s16c_cos_t_from_ub(ak, dim)
+								: s16_up(s16_up(fmaxf(ak, 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))))
+			: s16_thr_from_a<R>(ak, o.y, dim);
 
 		qthr[q] = make_float2(fminf(o.x, nt), o.y);
 	}
@@ -2166,7 +2204,9 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			/* T = order key of the k-th smallest a: back to the float */
 			const uint32_t tb = (T & 0x80000000u) ? (T & 0x7FFFFFFFu) : ~T;
 
-			if (ubq)
+			if (ubq && R == R_IVF_COS)
+				thrE = fminf(thrE, s16c_cos_t_from_ub(__uint_as_float(tb), dim));
+			else if (ubq)
 				thrE = fminf(thrE, s16_up(s16_up(fmaxf(__uint_as_float(tb), 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))));
 			else
 				thrE = fminf(thrE, s16_thr_from_a<R>(__uint_as_float(tb), e, dim));

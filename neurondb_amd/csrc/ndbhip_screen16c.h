@@ -591,7 +591,8 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			 const uint32_t *__restrict__ runs, unsigned int *__restrict__ ecount, uint2 *__restrict__ erec,
 			 float *__restrict__ eub, uint32_t ecap, uint32_t *__restrict__ bmin, int nchunk,
 			 uint32_t desc_cap, uint32_t topk, const uint32_t *__restrict__ pos_of, float cE,
-			 uint32_t qc_cap /* rows of qcplanes: more pairs than that and nothing is swept (k_s16c_qcprep raised the flag) */ )
+			 uint32_t qc_cap /* rows of qcplanes: more pairs than that and nothing is swept (k_s16c_qcprep raised the flag) */,
+			 int cosine = 0 /* the planes are normalised vectors' and the thresholds bound cosine distances (s16c_cos_t_from_ub) */ )
 {
 	typedef S16CGeom<QB> G;
 	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];
@@ -1035,7 +1036,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					if (topk != 0 && rank == topk - 1 && mine != 0xFFFFFFFFu)
 					{
 						const uint32_t tb = (mine & 0x80000000u) ? (mine & 0x7FFFFFFFu) : ~mine;
-						const float nt = s16c_t_from_ub(__uint_as_float(tb), dim);
+						const float nt = cosine ? s16c_cos_t_from_ub(__uint_as_float(tb), dim) : s16c_t_from_ub(__uint_as_float(tb), dim);
 
 						/* T >= 0 (or +inf): its bits order like the values */
 						atomicMin(reinterpret_cast<unsigned int *>(&qthr[q].x), __float_as_uint(nt));

@@ -78,6 +78,12 @@ def one_case(rng, lib, IvfIndex, check):
         base[rng.integers(0, n, n // 10)] = base[rng.integers(0, n, n // 10)]       # duplicates
     if rng.random() < 0.2:
         q[0] = base[0]
+    if rng.random() < 0.25:
+        # zero vectors: the reference's cosine distance of one is exactly 1, its inner product 0 — and a bound that took
+        # it for a unit vector would be wrong (round 3's centred cosine did, once)
+        base[rng.integers(0, n, 3)] = 0.0
+        if rng.random() < 0.5:
+            q[nq - 1] = 0.0
     cent = base[rng.choice(n, nlists, replace=False)].copy()
     asg = rng.integers(0, nlists, n) if rng.random() < 0.3 else \
         (((base[:, None, :64].astype(np.float64) - cent[None, :, :64]) ** 2).sum(-1)).argmin(1)
