@@ -45,7 +45,7 @@ def main():
     st = (C.c_int64 * 6)()
     check(lib().ndbhip_hnsw_build_stats(ix._h, st))
     print(f"build {n} x {dim} {kind}: {tb:.2f} s = {n / tb:.0f} vectors/s, {st[4]} batches (largest {st[5]}), {st[0]} back-links")
-    nr = int(os.environ.get("H2_NR", "200"))
+    nr = int(os.environ.get("H2_NR", "1000"))
     sims = q[:nr].double() @ x.double().T
     gt = torch.topk(sims, 10, dim=1).indices.cpu().numpy() + 1
     for ef in efs:
