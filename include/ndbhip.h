@@ -103,7 +103,8 @@ typedef struct ndbhip_stats
 	uint64_t	plane_bytes;		/* bytes of row planes the sweeps had to read: every touched 128-row tile once per batch */
 	uint64_t	cent_screen_batches;	/* sub-batches whose centroid scan ran on the matrix cores (k_cent_select) */
 	uint64_t	prepares;			/* full layouts of the sweep's operands (planes, sublists, radii): once per mirror unless ... */
-	uint64_t	prepare_updates;	/* ... appends were folded into the existing layout instead (rows added in place) */
+	uint64_t	prepare_updates;	/* ... appends / deletes were folded into the existing layout instead (rows added in spare blocks,
+									 * deleted rows left as holes and the survivors renumbered) */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);
