@@ -92,11 +92,14 @@ def _worker_c(rank, world, name, slices, ret):
         torch.cuda.set_device(dev)
         _lib.use_torch_stream()
         a = make_ivf_arrays(6000, 96, 20, seed=61, dup_frac=0.1)
+        a["rows"][100:420] = a["rows"][100]              # 320 equal rows: more ties than a query's survivor buffer holds
         img = oracle_image(a)
         rng = np.random.default_rng(62)
         nq, k, nprobe = 157, 10, 5                      # ragged query slices; >= 128 queries: the fp16 matrix-core screen
         q = a["rows"][rng.integers(0, len(a["rows"]), nq)] + rng.standard_normal((nq, 96)).astype(np.float32) * 0.05
         q = np.ascontiguousarray(q, dtype=np.float32)
+        q[5] = q[6] = a["rows"][100]                    # ... for these queries: they go to the exact path alone, on each rank
+        q[7] = 0.0                                      # a zero query (cosine distance exactly 1 to everything)
         full = IvfIndex(96, 20)
         full.set_centroids(a["centroids"])
         full.load(a["list_len"], a["rows"], a["tids"])
@@ -114,7 +117,7 @@ def _worker_c(rank, world, name, slices, ret):
         od = torch.zeros((nq, k), dtype=torch.float32, device=dev)
         oc = torch.zeros(nq, dtype=torch.int32, device=dev)
         ok = True
-        for strategy in (1, 3):
+        for strategy in (1, 3, 2):
             ix.search_sharded_device(dq, ot, od, oc, strategy, nprobe, k, 0)
             _lib.check(_lib.lib().ndbhip_synchronize())
             et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k)
