@@ -2493,7 +2493,7 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 						   (const uint64_t *) ix->d_tids, (uint32_t *) nv, nt, row_words, (size_t) nrows);
 		/* centred planes stay: holes for the deleted rows, new list positions for the others (the lists' radii remain
 		 * upper bounds; a bucket emptied of live rows simply emits nothing) */
-		const bool	planes_stay = ix->s16_valid && ix->s16_cen_layout && !ix->s16_cos_layout && ix->d_plen && ix->d_bucket_list &&
+		const bool	planes_stay = ix->s16_valid && ix->s16_cen_layout && !ix->s16_cos_layout && !ix->f16 && ix->d_plen && ix->d_bucket_list &&
 			!ix->s16_prow.empty();
 
 		if (planes_stay)
@@ -2689,6 +2689,7 @@ static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off
 								   const float *list_centres = nullptr /* (cosine: the normalised centroids) */ );	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
 static int	s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim);	/* ndbhip_build.h */
+__global__ void k_rows_decode_f16(const uint16_t *__restrict__ src, size_t n, float *__restrict__ out);	/* ndbhip_build.h */
 static int	s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr,
 					   int nq, float *out, uint32_t stride);
 static int	g_cent_s16 = 1;		/* screened batches: the centroid scan on the matrix cores + exact arithmetic near the nprobe-th ("cent_screen16") */
@@ -2702,8 +2703,10 @@ static int	g_s16_cos_cen = 1;	/* cosine on the CENTRED sweep: |q^ - x^|^2 = 2 x 
 static bool
 ivf_s16_centered(const ndbhip_ivf *ix, int R)
 {
-	/* (cosine: the planes come from a normalised fp32 copy whatever the mirror holds) */
-	return g_s16_cen != 0 && ((R == R_IVF_L2 && !ix->f16) || (R == R_IVF_COS && g_s16_cos && g_s16_cos_cen));
+	/* (cosine: the planes come from a normalised fp32 copy whatever the mirror holds; L2 on an fp16 mirror: from a
+	 * transient copy of the rows as the reference decodes them) */
+	(void) ix;
+	return g_s16_cen != 0 && (R == R_IVF_L2 || (R == R_IVF_COS && g_s16_cos && g_s16_cos_cen));
 }
 
 /*
@@ -2745,6 +2748,16 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			~Hat() { if (p) big_free(p); }
 		}			hat;
 
+		const bool	dech = !cosn && cen && ix->f16;		/* the centred planes of an fp16 mirror: made from its decoded rows */
+
+		if (dech)
+		{
+			const size_t ne = (size_t) ix->nrows * dim;
+
+			if (big_alloc((void **) &hat.p, ne * sizeof(float))) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_rows_decode_f16, dim3((unsigned) ((ne + 255) / 256)), dim3(256), 0, g.stream,
+							   (const uint16_t *) ix->d_vecs, ne, hat.p);
+		}
 		if (cosn)
 		{
 			if (big_alloc((void **) &hat.p, (size_t) ix->nrows * dim * sizeof(float))) return NDBHIP_ERR_HIP;
@@ -2856,7 +2869,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 						   ix->s16_sub ? ix->nsub : nc, ix->d_planes, ix->d_rn2, ix->d_rexp, ix->d_xmax16,               \
 						   ix->s16_sub ? (const int64_t *) ix->d_perm : (const int64_t *) nullptr)
 		if (cen)
-			hipLaunchKernelGGL(k_s16c_row_prep, gp, dim3(256), 0, g.stream, cosn ? (const float *) hat.p : (const float *) ix->d_vecs, ix->nrows, dim, dimp,
+			hipLaunchKernelGGL(k_s16c_row_prep, gp, dim3(256), 0, g.stream, hat.p ? (const float *) hat.p : (const float *) ix->d_vecs, ix->nrows, dim, dimp,
 							   ix->s16_sub ? (const int64_t *) ix->d_sub_loc : (const int64_t *) ix->d_loc_off,
 							   ix->s16_sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff,
 							   ix->s16_sub ? ix->nsub : nc, cosn ? (const float *) ix->d_cent_hat : (const float *) ix->d_centroids,
@@ -2889,8 +2902,8 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		if (grow(ix->d_cn2, ix->d_cn2_n, (size_t) nc)) return NDBHIP_ERR_HIP;
 		hipLaunchKernelGGL(k_vec_norm2, dim3((nc + 3) / 4), dim3(256), 0, g.stream, (const float *) ix->d_centroids, nc, dim, ix->d_cn2);
 		HIP_TRY(hipGetLastError());
-		if (cosn)
-			HIP_TRY(hipStreamSynchronize(g.stream));	/* the normalised copy goes with this scope */
+		if (hat.p)
+			HIP_TRY(hipStreamSynchronize(g.stream));	/* the transient copy goes with this scope */
 		ix->dm_all_valid = false;
 		{
 			const int	ncmp = std::min(ix->nlists, ix->ncent);
@@ -3004,6 +3017,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	const bool	cen = ivf_s16_centered(ix, R);
 	const bool	cosb = cen && R == R_IVF_COS;	/* cosine on the centred sweep: normalised planes, thresholds in their squared-L2 domain */
+	/* seeds by the exact-arithmetic kernels (k_s16_seed / k_s16_seed_sub with the centred thresholds) instead of
+	 * k_s16c_seed, which reads float4 rows: cosine (the reference's cosine values), fp16 mirrors */
+	const bool	xseed = cosb || (cen && ix->f16);
 	{
 		const int	rc = ivf_s16_prepare(ix, R);
 
@@ -3052,7 +3068,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
 
-	if (!seed_by_sublist && cen && !cosb)
+	if (!seed_by_sublist && cen && !xseed)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<false>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 						   (uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
 						   (const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
@@ -3232,7 +3248,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 					sub_rn2 = ix->dm_sub.rn2;
 				}
 				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
-				if (cen && !cosb)
+				if (cen && !xseed)
 					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<true>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
 									   (uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
 									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
@@ -3246,7 +3262,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							  (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
 							  (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
 							  subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, cosb ? 1 : 0, ipb ? sub_rn2 : (const float *) nullptr,
+							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, xseed ? 1 : 0, ipb ? sub_rn2 : (const float *) nullptr,
 							  ipb ? (const float *) ix->d_cn2 : (const float *) nullptr, H == 1 ? 1 : 0);
 				}
 				if (g_thr_hook)
