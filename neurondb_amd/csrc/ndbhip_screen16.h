@@ -1110,7 +1110,9 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   uint32_t sstride, const float *__restrict__ pdist, const float *__restrict__ cdist, uint32_t cstride,
 			   const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, float2 *__restrict__ qthr,
 			   int cen = 0, const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr,
-			   int e_sub = 0 /* the mirror holds fp16 subnormals (s16_e) */ )
+			   int e_sub = 0 /* the mirror holds fp16 subnormals (s16_e) */,
+			   uint32_t nseed = S16_SEED /* rows scored (<= S16_SEED): any subset of a query's candidates gives a valid threshold;
+										  * 32 halve this kernel's row traffic where k leaves room (k <= 20) */ )
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x;
@@ -1176,7 +1178,7 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	if (bs != 0xFFFFFFFFu)		/* uniform */
 	{
 		const uint32_t vis = lco[bp + 1] - lco[bp];
-		const uint32_t n = min(sub_len[bs], (uint32_t) S16_SEED);
+		const uint32_t n = min(sub_len[bs], min(nseed, (uint32_t) S16_SEED));
 
 		if ((uint32_t) lane < n)
 		{
@@ -1196,7 +1198,7 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	{
 		/* no sublist holds k visible rows (short lists, a tight candidate cap): k_s16_seed's rule, the query's
 		 * first 64 candidates */
-		const uint32_t n = min(lco[npr], (uint32_t) S16_SEED);
+		const uint32_t n = min(lco[npr], min(nseed, (uint32_t) S16_SEED));
 
 		ok = (uint32_t) lane < n;
 		v = 0.0f;
