@@ -1656,6 +1656,8 @@ struct ndbhip_ivf
 	/* centred planes: rows of every bucket IN THE PLANES (holes of deleted rows included: the list's own length shrinks,
 	 * the bucket's does not) when the buckets are the lists themselves (regrouped planes keep that in d_sub_len), and the
 	 * list every bucket belongs to */
+	uint4	   *w_qpairs = nullptr;	size_t w_qpairs_n = 0;	/* k_sub_pairs: what the count pass kept, per query */
+	uint32_t   *w_qpn = nullptr;	size_t w_qpn_n = 0;
 	uint32_t   *w_overq = nullptr;	size_t w_overq_n = 0;	/* queries of the last batch whose records / survivors overflowed */
 	std::vector<uint32_t> redo;		/* ... on the host: ivf_s16_run returned 2, these go to the exact path one sub-batch */
 	float	   *w_redo_q = nullptr;	size_t w_redo_q_n = 0;
@@ -1772,7 +1774,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3178,6 +3180,11 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	bool		over_pairs = false;
 
 	if (grow(ix->w_overq, ix->w_overq_n, (size_t) S16_OVER_CAP)) return NDBHIP_ERR_HIP;
+	if (ix->s16_sub)
+	{
+		if (grow(ix->w_qpairs, ix->w_qpairs_n, (size_t) nq * S16_QP_CAP)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_qpn, ix->w_qpn_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+	}
 
 	for (int round = 0; round < 2; round++)
 	{
@@ -3200,7 +3207,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_L2>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, cen ? 1 : 0);
 		}
-		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE) * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE + 1) * sizeof(uint32_t), g.stream));	/* + k_sub_pairs' overflow flag */
 		const uint8_t *drop = nullptr;
 		const float *pdist = nullptr;
 
@@ -3280,7 +3287,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
-							   (PairRec *) nullptr, ipb, sub_rn2, (const float *) ix->d_cn2);
+							   (PairRec *) nullptr, ipb, sub_rn2, (const float *) ix->d_cn2, ix->w_qpairs, ix->w_qpn, ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -3294,7 +3301,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) ix->d_sub_len, (const uint32_t *) ix->d_sub_rad, subdist,
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs,
-							   ipb, sub_rn2, (const float *) ix->d_cn2);
+							   ipb, sub_rn2, (const float *) ix->d_cn2, ix->w_qpairs, ix->w_qpn, ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);

@@ -594,6 +594,7 @@ k_vec_norm2(const float *__restrict__ v, int n, int dim, float *__restrict__ out
  * (k_s16_pair_prune, when the probes came from elsewhere) for a list that is its own single sublist; for the sublists of a
  * regrouped one, subdist[q][gidx] holds the SQUARED distance as the matrix-core sweep computes it (MODE 3, every
  * query against every such centre, within the sweep's own error bound).  FILL = 0: count. */
+#define S16_QP_CAP 256			/* (query, sublist) pairs per query the count pass of k_sub_pairs remembers for the fill pass */
 template <int FILL>
 __global__ __launch_bounds__(256) void
 k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t nq,
@@ -607,8 +608,42 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pair_off, uint32_t *__restrict__ fill,
 			PairRec *__restrict__ pairs, int ip = 0 /* inner product: s16_sub_excluded_ip, with ... */,
 			const float *__restrict__ cn2_sub = nullptr /* ... |c|^2 of the regrouped lists' centres (by gidx) */,
-			const float *__restrict__ cn2_list = nullptr /* ... and of the lists' centroids */ )
+			const float *__restrict__ cn2_list = nullptr /* ... and of the lists' centroids */,
+			uint4 *__restrict__ qpairs = nullptr /* [nq][S16_QP_CAP] (sublist, probe, rank in the sublist's run) of the pairs the
+												  * count pass kept: the fill pass replays them instead of testing everything
+												  * again and needs no atomics ... */,
+			uint32_t *__restrict__ qpn = nullptr /* ... (their number per query) ... */,
+			uint32_t *__restrict__ qovf = nullptr /* ... unless some query of the batch kept more than S16_QP_CAP (set here; the
+												   * fill pass then places every pair with its own counter, as it used to) */ )
 {
+	__shared__ uint32_t s_np;
+
+	if (qpairs && FILL)
+	{
+		/* (uniform per block) */
+		const uint32_t q0 = blockIdx.x;
+
+		if (q0 >= nq || (active && !active[q0]))
+			return;
+		if (*qovf == 0)
+		{
+			const uint32_t n0 = qpn[q0];
+
+			for (uint32_t i = threadIdx.x; i < n0; i += blockDim.x)
+			{
+				const uint4 sp = qpairs[(size_t) q0 * S16_QP_CAP + i];
+				PairRec		r;
+
+				r.q = q0;
+				r.p = sp.y;
+				pairs[pair_off[sp.x] + sp.z] = r;
+			}
+			return;
+		}
+	}
+	if (threadIdx.x == 0)
+		s_np = 0;
+	__syncthreads();
 	/* One block (4 waves) per query.  The (probe, sublist) tests of 64 probes at a time are laid end to end and dealt to
 	 * the block's 256 lanes (every wave works the same prefix out for itself: lane p learns where probe p's sublists
 	 * start and how many there are, a prefix sum over the lanes gives every test its number, and a test finds its probe
@@ -715,9 +750,29 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 				pairs[pair_off[s] + atomicAdd(&fill[s], 1u)] = r;
 			}
 			else
-				atomicAdd(&cnt[s], 1u);
+			{
+				const uint32_t rank = atomicAdd(&cnt[s], 1u);
+
+				if (qpairs)
+				{
+					const uint32_t i = atomicAdd(&s_np, 1u);
+
+					if (i < S16_QP_CAP)
+						qpairs[(size_t) q * S16_QP_CAP + i] = make_uint4(s, (uint32_t) (p0 + lo), rank, 0u);
+				}
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
+	}
+	if (qpairs && !FILL)
+	{
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			qpn[q] = s_np;
+			if (s_np > S16_QP_CAP)
+				*qovf = 1u;
+		}
 	}
 }
 

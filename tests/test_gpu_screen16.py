@@ -331,6 +331,45 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
         lib.check(lib.lib().ndbhip_set_option(b"screen16_sub_min", 256))
 
 
+@pytest.mark.parametrize("strategy", [1, 2])
+def test_a_query_that_keeps_more_sublists_than_the_count_pass_remembers(strategy, lib):
+    """k_sub_pairs' count pass remembers up to 256 (sublist, probe) pairs per query for the fill pass to replay; a
+    query that keeps more (40 probes x ~13 sublists here, nothing excluded with screen16_prune 0) switches the whole
+    batch back to the fill pass that tests everything again.  Same results either way, and with pruning on."""
+    dim, nlists, nprobe, nq, k = 32, 40, 40, 48, 10
+    rng = np.random.default_rng(77)
+    comp = (rng.standard_normal((nlists * 13, dim)) * 4).astype(np.float32)
+    rows, lens = [], []
+    for L in range(nlists):
+        mine = np.arange(L * 13, L * 13 + 13)
+        n = 1700
+        rows.append((comp[mine[rng.integers(0, 13, n)]] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32))
+        lens.append(n)
+    rows = np.concatenate(rows)
+    from oracle import ndbo
+    cents = np.stack([rows[sum(lens[:L]):sum(lens[:L + 1])].mean(0) for L in range(nlists)]).astype(np.float32)
+    a = dict(centroids=cents, list_len=np.asarray(lens, np.int64), rows=rows, tids=ndbo.tids_from_rows(np.arange(len(rows))))
+    img = oracle_image(a)
+    q = (rows[rng.integers(0, len(rows), nq)] + 0.02 * rng.standard_normal((nq, dim))).astype(np.float32)
+    et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, 0)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    try:
+        swept = []
+        for prune in (0, 1):
+            lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", prune))
+            ix = _index(a)
+            lib.check(lib.lib().ndbhip_stats_reset())
+            t, d, c = ix.search(q, strategy, nprobe, k, 0)
+            st = lib.stats()
+            assert_same_results(t, d, c, et, ed, ec)
+            assert st["screen16_batches"] == 1, st
+            swept.append(st["rows_swept"])
+            ix.close()
+        assert swept[0] == nq * len(rows) and swept[1] < swept[0] * 3 // 4, swept   # every (query, sublist) pair kept / some excluded
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", 1))
+
+
 def test_sublists_on_slice_shards_merge_to_the_unsharded_result(lib):
     import torch
     from neurondb_amd.dist import ShardedSearchBuffers
