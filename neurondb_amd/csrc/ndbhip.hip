@@ -479,12 +479,14 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			   const uint32_t *__restrict__ own_len, uint64_t cap,
 			   int dim, int *__restrict__ probes, uint32_t *__restrict__ cand_off,
 			   uint32_t *__restrict__ loc_cand_off, unsigned long long *__restrict__ counters, int full_sort = 1,
-			   const uint8_t *__restrict__ only = nullptr /* serve just the queries marked here (k_cent_select's leftovers) */ )
+			   const uint8_t *__restrict__ only = nullptr /* serve just the queries marked here (k_cent_select's leftovers) */,
+			   int sum_here = 0 /* add this query's candidate counts to counters[0..2] (dim = bytes per row) */ )
 {
 	__shared__ uint32_t hist[256];
 	__shared__ uint32_t sh[16];
-	__shared__ uint64_t comp[NDBHIP_MAX_NPROBE];
+	__shared__ uint64_t comp[NDBHIP_MAX_NPROBE + 2];
 	__shared__ uint64_t full[2048];
+	__shared__ uint64_t s_bound;
 	__shared__ uint32_t perm[NDBHIP_MAX_NPROBE];
 	__shared__ uint32_t lens[NDBHIP_MAX_NPROBE];
 	__shared__ int selc[NDBHIP_MAX_NPROBE];
@@ -518,15 +520,74 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 		if (tid == 0)
 			sh[0] = 0;
 		__syncthreads();
-		for (uint32_t j = tid; j < np2; j += blockDim.x)
+		uint32_t	nok = 0;
+
+		for (uint32_t j0 = 0; j0 < np2; j0 += blockDim.x)
 		{
+			const uint32_t j = j0 + tid;
 			uint32_t	bits = 0;
 			const bool	ok = j < (uint32_t) ncmp && ld(j, bits);
 
-			full[j] = ok ? (((uint64_t) ndb_key_from_bits(bits) << 32) | j) : ~0ull;
-			if (ok)
-				atomicAdd(&sh[0], 1u);
+			if (j < np2)
+				full[j] = ok ? (((uint64_t) ndb_key_from_bits(bits) << 32) | j) : ~0ull;
+			nok += (uint32_t) __popcll(__ballot(ok));	/* (one LDS atomic per key on one word serialises: 1024 of them cost ~10 us) */
 		}
+		if ((tid & 63u) == 0 && nok)
+			atomicAdd(&sh[0], nok);
+		__syncthreads();
+		/*
+		 * The head of that order without the sort (a single query spent 30 of its 176 us in the 55 barrier-separated
+		 * stages of the 1024-key network): the kk-th smallest of the threads' minima over their strided shares bounds the
+		 * kk-th smallest key (the kk smallest minima are kk distinct keys), at most kk threads hold keys at or below it,
+		 * so at most kk x (keys per thread) keys are gathered — and both "the kk-th smallest of the minima" and "the
+		 * order of the gathered" are ranks by counting, a loop of broadcast LDS reads with no barrier inside.
+		 */
+		const uint32_t per = (np2 + blockDim.x - 1) / blockDim.x;
+		const uint32_t want = min((uint32_t) npr_eff, sh[0]);
+		uint64_t	mymin = ~0ull;
+
+		for (uint32_t j = tid; j < np2; j += blockDim.x)
+			mymin = min(mymin, full[j]);
+		const uint32_t nth = (uint32_t) __syncthreads_count(mymin != ~0ull);
+		const bool	by_rank = want > 0 && nth >= want && want * per <= 512u && blockDim.x <= NDBHIP_MAX_NPROBE;
+
+		if (by_rank)
+		{
+			comp[tid] = mymin;
+			if (tid == 0)
+				sh[1] = 0;
+			__syncthreads();
+			const uint32_t r = lds_rank_u64(comp, blockDim.x, mymin);
+
+			if (r == want - 1)
+				s_bound = mymin;
+			__syncthreads();
+			const uint64_t U = s_bound;
+
+			/* (every thread finished reading comp[] before that barrier: it can be reused) */
+			for (uint32_t j = tid; j < np2; j += blockDim.x)
+			{
+				const uint64_t v = full[j];
+
+				if (v <= U && v != ~0ull)
+					comp[atomicAdd(&sh[1], 1u)] = v;
+			}
+			__syncthreads();
+			const uint32_t m = sh[1];
+
+			for (uint32_t c = tid; c < m; c += blockDim.x)
+			{
+				const uint64_t v = comp[c];
+				const uint32_t r = lds_rank_u64(comp, m, v);
+
+				if (r < want)
+					perm[r] = (uint32_t) v;
+			}
+			__syncthreads();
+			kk = want;
+		}
+		else
+		{
 		for (uint32_t size = 2; size <= np2; size <<= 1)
 			for (uint32_t sd = size >> 1; sd > 0; sd >>= 1)
 			{
@@ -550,6 +611,7 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 		for (uint32_t j = tid; j < kk; j += blockDim.x)
 			perm[j] = (uint32_t) full[j];
 		__syncthreads();
+		}
 	}
 	else
 	{
@@ -578,6 +640,10 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 	}
 	__syncthreads();
 	}
+	/* the selection is done with full[] and comp[]: the probes' own-row ranges and the running sums live there now */
+	uint32_t   *olo = (uint32_t *) full, *olen = olo + NDBHIP_MAX_NPROBE;
+	uint32_t   *pa = (uint32_t *) comp, *pm = pa + (NDBHIP_MAX_NPROBE + 1);
+
 	for (uint32_t i = tid; i < (uint32_t) npr; i += blockDim.x)
 	{
 		int			c;
@@ -590,18 +656,20 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 			c = 0;
 		probes[(size_t) q * npr + i] = c;
 		selc[i] = c;
-		lens[i] = (c >= 0 && c < ncent) ? glob_len[c] : 0u;	/* ivf_am.c:1768-1779 */
+		const bool	held = c >= 0 && c < ncent;
+
+		lens[i] = held ? glob_len[c] : 0u;	/* ivf_am.c:1768-1779 */
+		olo[i] = held ? own_lo[c] : 0u;		/* (read here, by all threads: thread 0's running sums below then touch LDS only —
+											 * 32 dependent pairs of global loads were 15 of a single query's 176 us) */
+		olen[i] = held ? own_len[c] : 0u;
 	}
 	__syncthreads();
 	if (tid == 0)
 	{
 		uint64_t	acc = 0, mine = 0;
-		uint32_t   *co = cand_off + (size_t) q * (npr + 1);
-		uint32_t   *lco = loc_cand_off ? loc_cand_off + (size_t) q * (npr + 1) : nullptr;
 
-		co[0] = 0;
-		if (lco)
-			lco[0] = 0;
+		pa[0] = 0;
+		pm[0] = 0;
 		for (int i = 0; i < npr; i++)
 		{
 			uint64_t	l = lens[i];
@@ -610,13 +678,37 @@ k_probe_select(const float *__restrict__ cdist, uint32_t cstride, int ncmp, int 
 				l = cap - acc;	/* candidateCount < maxCandidates guards: ivf_am.c:1764, 1793, 1811 */
 			acc += l;
 			if (l > 0)
-				mine += ndb_local_part(l, own_lo, own_len, selc[i]);
-			co[i + 1] = (uint32_t) acc;
-			if (lco)			/* positions of the rows THIS rank holds (sharded mirrors) */
-				lco[i + 1] = (uint32_t) mine;
+			{
+				/* of the first l positions of the list, how many does this mirror hold (ndb_local_part) */
+				const uint64_t lo = olo[i], hi = lo + olen[i];
+
+				mine += l > lo ? ((l < hi ? l : hi) - lo) : 0;
+			}
+			pa[i + 1] = (uint32_t) acc;
+			pm[i + 1] = (uint32_t) mine;
 		}
-		(void) counters;		/* summed by k_sum_candidates: three atomics per query on one line serialise */
-		(void) dim;
+		/* (batches: summed by k_sum_candidates — three atomics per query on one line serialise; a handful of queries
+		 * add their own and save the launch) */
+		if (counters && sum_here)
+		{
+			const uint64_t m = loc_cand_off ? mine : acc;
+
+			atomicAdd(&counters[0], (unsigned long long) acc);
+			atomicAdd(&counters[1], (unsigned long long) m);
+			atomicAdd(&counters[2], (unsigned long long) m * (unsigned long long) dim);
+		}
+	}
+	__syncthreads();
+	{
+		uint32_t   *co = cand_off + (size_t) q * (npr + 1);
+		uint32_t   *lco = loc_cand_off ? loc_cand_off + (size_t) q * (npr + 1) : nullptr;
+
+		for (uint32_t i = tid; i <= (uint32_t) npr; i += blockDim.x)
+		{
+			co[i] = pa[i];
+			if (lco)
+				lco[i] = pm[i];
+		}
 	}
 }
 
@@ -3795,6 +3887,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const uint32_t *lco = ix->sharded ? lco_w : ix->w_candoff;
 
 	int		   *w_probes = d_probes_out ? d_probes_out : ix->w_probes;
+	bool		summed = false;	/* k_probe_select added the candidate counts itself */
 
 	if (d_probes_in)
 	{
@@ -3947,11 +4040,13 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
 						   w_probes, ix->w_candoff, lco_w, full ? g.d_counters : (unsigned long long *) nullptr,
-						   (nq >= 512 && g_probe_sel_radix) ? 0 : 1);
+						   (nq >= 512 && g_probe_sel_radix) ? 0 : 1, (const uint8_t *) nullptr, (full && nq <= 16) ? 1 : 0);
+		summed = full && nq <= 16;
 	}
 	HIP_TRY(hipGetLastError());
 	if (!full)
 		return 0;
+	if (!summed)
 	hipLaunchKernelGGL(k_sum_candidates, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) ix->w_candoff,
 					   (const uint32_t *) lco_w, (uint32_t) nq, npr, ix->dim * (ix->f16 ? 2 : 4), g.d_counters);
 

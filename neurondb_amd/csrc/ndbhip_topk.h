@@ -23,6 +23,22 @@
  *
  * partial != 0: emit the tie-complete subset for the shard merge instead of results.
  */
+/* the k-th smallest of the 256 threads' values mn (all threads get it; `otherwise` when fewer than k threads hold
+ * one): the thread whose (value, thread) pair has rank k - 1 publishes it — no sort.  Ends with a barrier. */
+static __device__ uint32_t
+block_kth_of_minima(uint64_t *comp, uint32_t *slot, uint32_t mn, uint32_t k, uint32_t nth, uint32_t otherwise)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint64_t mine = ((uint64_t) mn << 32) | tid;
+
+	comp[tid] = mine;
+	__syncthreads();
+	if (nth >= k && lds_rank_u64(comp, 256, mine) == k - 1)
+		*slot = mn;
+	__syncthreads();
+	return nth >= k ? *slot : otherwise;
+}
+
 __global__ __launch_bounds__(256) void
 k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict__ cand_off,
 		   const uint32_t *__restrict__ loc_cand_off, int npr, const float *__restrict__ dist, uint32_t stride, uint32_t k, int partial,
@@ -58,14 +74,25 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		return true;
 	};
 	/* local position (inside this block's range) -> (TID, position in candidates[]) */
+	/* the fast paths search a copy of the probes' offsets in LDS (the histogram area, which only the radix path uses):
+	 * the binary search is five dependent reads, and from memory each of them is a trip to L2 */
+	const uint32_t *lcs = lco;
 	auto		tid_of = [&](uint32_t i0, uint32_t &gpos) -> uint64_t {
 		const uint32_t i = i0 + lo;
-		const uint32_t p = find_probe(lco, npr, i);
+		const uint32_t p = find_probe(lcs, npr, i);
 		const int	L = probes[(size_t) q * npr + p];
+		const uint32_t at = i - lcs[p];
 
-		gpos = co[p] + ix.own_lo[L] + (i - lco[p]);	/* a split list: this mirror starts at position own_lo */
-		return ix.tids[ix.loc_off[L] + (i - lco[p])];
+		gpos = co[p] + ix.own_lo[L] + at;	/* a split list: this mirror starts at position own_lo */
+		return ix.tids[ix.loc_off[L] + at];
 	};
+
+	if (npr + 1 <= 256 && k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
+	{
+		for (uint32_t i = tid; i <= (uint32_t) npr; i += 256)
+			s.hist[i] = lco[i];
+		lcs = s.hist;			/* (every use is behind a barrier of the fast paths) */
+	}
 
 	if (tmin && gridDim.y == 1 && k <= NDB_TOPK_FAST_MAXK && ecap == NDB_TOPK_FAST_CAP)
 	{
@@ -83,10 +110,7 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 			mn = min(mn, tm[sidx]);
 		const uint32_t nth = (uint32_t) __syncthreads_count(mn != 0xFFFFFFFFu);
 
-		s.fs.comp[tid] = ((uint64_t) mn << 32) | tid;
-		s.fs.perm[tid] = tid;
-		block_bitonic_sort(s.fs.comp, s.fs.perm, 256);
-		const uint32_t U = (nth >= k) ? (uint32_t) (s.fs.comp[k - 1] >> 32) : 0xFFFFFFFEu;	/* 0xFFFFFFFF = empty slot */
+		const uint32_t U = block_kth_of_minima(s.fs.comp, s.sh + 8, mn, k, nth, 0xFFFFFFFEu);	/* 0xFFFFFFFF = empty slot */
 		uint32_t   *tlist = s.fs.curpos;	/* tiles to open (curpos is replay scratch, free until then) */
 
 		__syncthreads();
@@ -121,15 +145,15 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 				{
 					const uint32_t mid = (lo2 + hi2) >> 1;
 
-					if ((lco[mid] >> 6) + mid <= sidx)
+					if ((lcs[mid] >> 6) + mid <= sidx)
 						lo2 = mid;
 					else
 						hi2 = mid;
 				}
-				const uint32_t base = lco[lo2] + ((sidx - ((lco[lo2] >> 6) + lo2)) << 6);
+				const uint32_t base = lcs[lo2] + ((sidx - ((lcs[lo2] >> 6) + lo2)) << 6);
 				const uint32_t i = base + lane;
 
-				if (base < lco[lo2 + 1] && i < lco[lo2 + 1])
+				if (base < lcs[lo2 + 1] && i < lcs[lo2 + 1])
 				{
 					const uint32_t b0 = __float_as_uint(d[i]);
 
@@ -190,22 +214,15 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 		/* sort the 256 minima; threads without a candidate carry 0xFFFFFFFF and sort last */
 		const uint32_t nth = (uint32_t) __syncthreads_count(nvalid > 0);
 
-		s.fs.comp[tid] = ((uint64_t) mn << 32) | tid;
-		s.fs.perm[tid] = tid;
-		block_bitonic_sort(s.fs.comp, s.fs.perm, 256);
 		/* U: the k-th smallest thread minimum bounds the k-th smallest candidate (the k smallest
 		 * minima are k distinct candidates <= U); with fewer than k non-empty threads gather all */
-		const uint32_t U = (nth >= k) ? (uint32_t) (s.fs.comp[k - 1] >> 32) : 0xFFFFFFFFu;
-		__syncthreads();
+		const uint32_t U = block_kth_of_minima(s.fs.comp, s.sh + 8, mn, k, nth, 0xFFFFFFFFu);
 
 		/* pass 2: gather every candidate with key <= U */
 		if (tid == 0)
 			s.sh[0] = 0;
 		__syncthreads();
-		for (i = tid; i < total; i += 256)
-		{
-			const uint32_t b0 = __float_as_uint(d[i]);
-
+		auto		keep = [&](uint32_t b0, uint32_t at) {
 			if (ndb_key_from_bits(b0) <= U)
 			{
 				const uint32_t slot = atomicAdd(&s.sh[0], 1u);
@@ -213,10 +230,23 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 				if (slot < NDB_TOPK_FAST_CAP)
 				{
 					s.e_bits[slot] = b0;
-					s.e_pos[slot] = i;
+					s.e_pos[slot] = at;
 				}
 			}
+		};
+		/* (four loads in flight per thread, like pass 1: with the LDS atomic between them the loads would go out one by one) */
+		for (i = tid; i + 3 * 256 < total; i += 4 * 256)
+		{
+			const uint32_t b0 = __float_as_uint(d[i]), b1 = __float_as_uint(d[i + 256]);
+			const uint32_t b2 = __float_as_uint(d[i + 512]), b3 = __float_as_uint(d[i + 768]);
+
+			keep(b0, i);
+			keep(b1, i + 256);
+			keep(b2, i + 512);
+			keep(b3, i + 768);
 		}
+		for (; i < total; i += 256)
+			keep(__float_as_uint(d[i]), i);
 		__syncthreads();
 		const uint32_t got = s.sh[0];
 
@@ -239,6 +269,8 @@ k_ivf_topk(IvfDev ix, const int *__restrict__ probes, const uint32_t *__restrict
 	if (!have)
 	{
 		uint32_t	T, m_less, kk0, cnt_eq;
+
+		lcs = lco;
 
 		block_radix_select(ld, total, k, s.hist, s.sh, T, m_less, kk0, cnt_eq);
 		const uint32_t n_eq = cnt_eq < 2 * k ? cnt_eq : 2 * k;
@@ -304,32 +336,47 @@ k_merge_topk(const ndbhip_cand *__restrict__ cand, const int *__restrict__ ncand
 	const uint32_t q = blockIdx.x;
 	uint32_t   *woff = s.hist;		/* 65 words: the histogram area is unused in the merge */
 
-	if (threadIdx.x == 0)
-	{
-		uint32_t	acc = 0;
+	/* (the counts are read by as many threads as there are ranks or ranges: one thread reading them in turn pays the
+	 * memory latency `world` times — 16 ranges were ~10 us of a single query) */
+	uint32_t   *wcnt = s.hist + 80;
 
-		for (int w = 0; w < world; w++)
+	for (int w0 = 0; w0 < world; w0 += 64)
+	{
+		const int	w = w0 + (int) threadIdx.x;
+
+		__syncthreads();
+		if (threadIdx.x < 64 && w < world)
 		{
 			/* a count from a peer is data, not a promise: more than `cap` records (or a negative count) would
 			 * overrun the LDS arrays sized for world x cap */
 			const int	nc_w = ncand[(size_t) w * nq + q];
 
-			woff[w] = acc;
-			acc += (uint32_t) (nc_w < 0 ? 0 : (nc_w > (int) cap ? (int) cap : nc_w));
+			wcnt[threadIdx.x] = (uint32_t) (nc_w < 0 ? 0 : (nc_w > (int) cap ? (int) cap : nc_w));
 		}
-		woff[world] = acc;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			uint32_t	acc = w0 ? woff[w0] : 0;
+
+			for (int i = 0; i < 64 && w0 + i < world; i++)
+			{
+				woff[w0 + i] = acc;
+				acc += wcnt[i];
+			}
+			woff[w0 + (world - w0 < 64 ? world - w0 : 64)] = acc;
+		}
 	}
 	__syncthreads();
 	const uint32_t n = woff[world];
 
-	for (int w = 0; w < world; w++)
+	/* (one flat loop over ranks x records: a loop per rank would wait for memory once per rank) */
+	for (uint32_t idx = threadIdx.x; idx < capall; idx += blockDim.x)
 	{
-		const uint32_t cnt = woff[w + 1] - woff[w];
-		const ndbhip_cand *src = cand + ((size_t) w * nq + q) * cap;
+		const uint32_t w = idx / cap, j = idx - w * cap;
 
-		for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x)
+		if (j < woff[w + 1] - woff[w])
 		{
-			const ndbhip_cand c = src[j];
+			const ndbhip_cand c = cand[((size_t) w * nq + q) * cap + j];
 
 			s.e_bits[woff[w] + j] = c.key;
 			s.e_pos[woff[w] + j] = c.pos;

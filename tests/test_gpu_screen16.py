@@ -365,7 +365,9 @@ def test_a_query_that_keeps_more_sublists_than_the_count_pass_remembers(strategy
             assert st["screen16_batches"] == 1, st
             swept.append(st["rows_swept"])
             ix.close()
-        assert swept[0] == nq * len(rows) and swept[1] < swept[0] * 3 // 4, swept   # every (query, sublist) pair kept / some excluded
+        # every (query, sublist) pair kept / some excluded (inner product needs the centroid scan's distances for that, which
+        # a forced scan mode with 48 queries does not have)
+        assert swept[0] == nq * len(rows) and (swept[1] < swept[0] * 3 // 4 or strategy == 2), swept
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", 1))
 
