@@ -614,7 +614,10 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 												  * again and needs no atomics ... */,
 			uint32_t *__restrict__ qpn = nullptr /* ... (their number per query) ... */,
 			uint32_t *__restrict__ qovf = nullptr /* ... unless some query of the batch kept more than S16_QP_CAP (set here; the
-												   * fill pass then places every pair with its own counter, as it used to) */ )
+												   * fill pass then places every pair with its own counter, as it used to) */,
+			int dbg = 0 /* timing experiments, WRONG results: 4 no counter atomics, 8 no reads of subdist, 16 no table reads */,
+			uint32_t *__restrict__ cntx = nullptr /* [8][ncs] the count pass's counters, one set per XCD (see below) */,
+			uint32_t ncs = 0 )
 {
 	__shared__ uint32_t s_np;
 
@@ -636,7 +639,8 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 
 				r.q = q0;
 				r.p = sp.y;
-				pairs[pair_off[sp.x] + sp.z] = r;
+				/* (k_pair_offsets turned cntx[x][s] into the start of XCD x's pairs inside sublist s's run) */
+				pairs[pair_off[sp.x] + (cntx ? cntx[(size_t) sp.w * ncs + sp.x] : 0u) + sp.z] = r;
 			}
 			return;
 		}
@@ -644,6 +648,13 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	if (threadIdx.x == 0)
 		s_np = 0;
 	__syncthreads();
+	uint32_t	xcd = 0;
+
+	if (cntx && !FILL)
+	{
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcd));
+		xcd &= 7u;
+	}
 	/* One block (4 waves) per query.  The (probe, sublist) tests of 64 probes at a time are laid end to end and dealt to
 	 * the block's 256 lanes (every wave works the same prefix out for itself: lane p learns where probe p's sublists
 	 * start and how many there are, a prefix sum over the lanes gives every test its number, and a test finds its probe
@@ -715,17 +726,20 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 					hi = mid;
 			}
 			const uint32_t s = s_s0[w][lo] + (t - s_off[w][lo]);
+			/* (the three table reads go out together: behind the `continue` they would be three round trips) */
+			const uint32_t slen = (dbg & 16) ? 100u : sub_len[s];
+			const int	gi = (dbg & 16) ? (int) (s & 1023u) : sub_gidx[s];
+			const uint32_t srad = (dbg & 16) ? 0u : sub_rad[s];
 
-			if (sub_len[s] == 0)
+			if (slen == 0)
 				continue;
-			const int	gi = sub_gidx[s];
 
 			if (prune && ip >= 2 && gi < 0)
 				;				/* cosine: the centroid scan's distance to a list that is its own sublist is in the rows' own space: kept */
 			else if (prune && ip == 3)
 			{
 				/* cosine on the centred sweep: the L2 test in the normalised space */
-				if (s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te))
+				if (s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, srad, te))
 					continue;
 			}
 			else if (prune && ip)
@@ -735,11 +749,11 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 				const double alo = gi < 0 ? pdl * pdl * (1.0 - 2.2 * (double) (dim + 8) * 5.9604645e-8)
 					: (double) subdist[(size_t) q * sstride + gi] - (double) ec * (1.0 + 1e-6);
 
-				if (s16_sub_excluded_ip(alo, qn2[q], gi < 0 ? s_c2[w][lo] : cn2_sub[gi], sub_rad[s], te))
+				if (s16_sub_excluded_ip(alo, qn2[q], gi < 0 ? s_c2[w][lo] : cn2_sub[gi], srad, te))
 					continue;
 			}
-			else if (prune && (gi < 0 ? s16_sub_excluded(s_pd[w][lo], sub_rad[s], te)
-							   : s16_sub_excluded_a(subdist[(size_t) q * sstride + gi], ec, sub_rad[s], te)))
+			else if (prune && (gi < 0 ? s16_sub_excluded(s_pd[w][lo], srad, te)
+							   : s16_sub_excluded_a((dbg & 8) ? (float) (s & 255u) * te * 0.02f : subdist[(size_t) q * sstride + gi], ec, srad, te)))
 				continue;
 			if (FILL)
 			{
@@ -751,14 +765,24 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 			}
 			else
 			{
-				const uint32_t rank = atomicAdd(&cnt[s], 1u);
+				/*
+				 * One counter per (XCD, sublist), bumped where this block runs: 50 k device-scope atomics with a return
+				 * value — they execute at the memory side, for every XCD — were half of this kernel (64 -> 32 us without
+				 * them); an atomic that only has to be coherent among the blocks of ONE XCD executes in that XCD's L2.
+				 * The scope is `workgroup` to get exactly that instruction (no sc1); what makes it correct is that every
+				 * block that touches cntx[x][.] runs on XCD x (it asked the hardware which one it is on), and that the
+				 * next kernel reads the counters after this one's end-of-kernel write-back.
+				 */
+				const uint32_t rank = (dbg & 4) ? 0u
+					: (cntx ? __hip_atomic_fetch_add(&cntx[(size_t) xcd * ncs + s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+					   : atomicAdd(&cnt[s], 1u));
 
 				if (qpairs)
 				{
 					const uint32_t i = atomicAdd(&s_np, 1u);
 
 					if (i < S16_QP_CAP)
-						qpairs[(size_t) q * S16_QP_CAP + i] = make_uint4(s, (uint32_t) (p0 + lo), rank, 0u);
+						qpairs[(size_t) q * S16_QP_CAP + i] = make_uint4(s, (uint32_t) (p0 + lo), rank, xcd);
 				}
 			}
 		}
