@@ -926,8 +926,9 @@ k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len
 			   int exact_runs = 0 /* runs of exactly nitems / 8 items (a list may straddle two runs): for a sweep whose blocks
 								   * walk their XCD's run at a fixed stride and cannot help another run out */,
 			   unsigned long long *__restrict__ swept = nullptr /* statistics: += sum of pairs x rows over the lists */,
-			   uint32_t *__restrict__ cntx = nullptr /* [8][ncent] counts per XCD (k_sub_pairs): summed into cnt[] here and
-													  * replaced by each XCD's start inside the list's run of pairs */ )
+			   uint32_t *__restrict__ cntx = nullptr /* [8][xstride] counts per XCD (k_sub_pairs): summed into cnt[] here and
+													  * replaced by each XCD's start inside the list's run of pairs */,
+			   uint32_t xstride = 0 )
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
@@ -945,11 +946,11 @@ k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len
 
 #pragma unroll
 			for (int x = 0; x < 8; x++)
-				v[x] = cntx[(size_t) x * ncent + L];
+				v[x] = cntx[(size_t) x * xstride + L];
 #pragma unroll
 			for (int x = 0; x < 8; x++)
 			{
-				cntx[(size_t) x * ncent + L] = run;
+				cntx[(size_t) x * xstride + L] = run;
 				run += v[x];
 			}
 			cnt[L] = run;
@@ -3216,13 +3217,16 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	if (sub)
 	{
-		if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ncs + 8 * NDB_QHEAD_STRIDE + 16 + (size_t) 8 * ncs)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_gcnt, ix->w_gcnt_n, (size_t) 2 * ncs + 8 * NDB_QHEAD_STRIDE + 48 + (size_t) 8 * ((ncs + 31) & ~31))) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_goff, ix->w_goff_n, (size_t) 3 * (ncs + 1) + 80)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_pairs, ix->w_pairs_n, pairs_cap)) return NDBHIP_ERR_HIP;
 	}
 	uint32_t   *cnt = ix->w_gcnt, *fill = ix->w_gcnt + ncs;
 	unsigned int *next_item = ix->w_gcnt + 2 * ncs;
-	uint32_t   *cntx = ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE + 16;	/* [8][ncs]: k_sub_pairs counts per XCD */
+	/* [8][ncsx]: k_sub_pairs counts per XCD; every XCD's row starts on a 128-byte line and is whole lines long, so no line
+	 * is ever dirty in two L2s */
+	const int	ncsx = (ncs + 31) & ~31;
+	uint32_t   *cntx = ix->w_gcnt + (((size_t) 2 * ncs + 8 * NDB_QHEAD_STRIDE + 16 + 31) & ~(size_t) 31);
 	uint32_t   *pair_off = ix->w_goff, *item_off = ix->w_goff + (ncs + 1), *grp_off = ix->w_goff + 2 * (ncs + 1);
 	uint32_t   *runs = ix->w_goff + 3 * (ncs + 1) + 32;
 	const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
@@ -3324,7 +3328,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_L2>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, cen ? 1 : 0);
 		}
-		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE + 16 + (sub ? 8 * ncs : 0)) * sizeof(uint32_t), g.stream));	/* + k_sub_pairs' overflow flag and per-XCD counts */
+		HIP_TRY(hipMemsetAsync(ix->w_gcnt, 0, (size_t) (2 * ncs + 8 * NDB_QHEAD_STRIDE + (sub ? 48 + 8 * ncsx : 16)) * sizeof(uint32_t), g.stream));	/* + k_sub_pairs' overflow flag and per-XCD counts */
 		const uint8_t *drop = nullptr;
 		const float *pdist = nullptr;
 
@@ -3405,14 +3409,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
 							   (PairRec *) nullptr, ipb, sub_rn2, (const float *) ix->d_cn2, ix->w_qpairs, ix->w_qpn, ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE,
-							   g_s16_debug & 28, cntx, (uint32_t) ncs);
+							   g_s16_debug & 28, cntx, (uint32_t) ncsx);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, cnt, act, drop);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, cnt, ds.own_len, ncs,
 						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0,
-						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr, sub ? cntx : (uint32_t *) nullptr);
+						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr, sub ? cntx : (uint32_t *) nullptr, (uint32_t) ncsx);
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -3420,7 +3424,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs,
 							   ipb, sub_rn2, (const float *) ix->d_cn2, ix->w_qpairs, ix->w_qpn, ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE,
-							   0, cntx, (uint32_t) ncs);
+							   0, cntx, (uint32_t) ncsx);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);

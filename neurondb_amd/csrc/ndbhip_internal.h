@@ -189,42 +189,54 @@ block_radix_select(F f, uint32_t n, uint32_t k_want, uint32_t *hist, uint32_t *s
 			}
 		}
 		__syncthreads();
-		if (tid == 0)
+		/*
+		 * Which bin holds the rem-th smallest: the first wave, four bins a lane — the lanes' sums, a prefix over the
+		 * lanes, and the one lane whose range contains rem walks its four bins.  (One thread walking the 256 bins,
+		 * a dependent LDS read each and twice in the first pass, was ~8 us a pass: five of those were a third of
+		 * k_s16_finalize, whose 4096 one-wave blocks have nothing else to run meanwhile.)
+		 */
+		if (tid < 64)
 		{
-			uint32_t	rem;
-			uint32_t	cum = 0;
+			const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+			const uint32_t mine = c0 + c1 + c2 + c3;
+			uint32_t	inc = mine;
 
-			if (pass == 0)
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1)
 			{
-				uint32_t	nv = 0;
+				const uint32_t v = (uint32_t) __shfl_up((int) inc, off, 64);
 
-				for (int b = 0; b < 256; b++)
-					nv += hist[b];
-				sh[3] = (k_want < nv) ? k_want : nv;	/* kk */
-				rem = sh[3];
+				if (tid >= (uint32_t) off)
+					inc += v;
 			}
-			else
-				rem = sh[1];
-			sh[0] = 0;
-			sh[2] = 0;
-			if (rem > 0)
-			{
-				for (int b = 0; b < 256; b++)
-				{
-					const uint32_t c = hist[b];
+			const uint32_t nv = (uint32_t) __shfl((int) inc, 63, 64);
+			const uint32_t kkv = (k_want < nv) ? k_want : nv;
+			const uint32_t rem = (pass == 0) ? kkv : sh[1];		/* (sh[1] is rewritten below by the lane that finds the bin: all lanes have read it) */
+			const uint32_t excl = inc - mine;
 
-					if (cum + c >= rem)
-					{
-						sh[0] = (uint32_t) b;
-						sh[1] = rem - cum;	/* rank inside this bin, 1-based */
-						sh[2] = c;
-						break;
-					}
-					cum += c;
+			__builtin_amdgcn_wave_barrier();
+			if (pass == 0 && tid == 0)
+				sh[3] = kkv;		/* kk */
+			if (rem == 0)
+			{
+				if (tid == 0)
+				{
+					sh[0] = 0;
+					sh[1] = 0;
+					sh[2] = 0;
 				}
 			}
-			else
-				sh[1] = 0;
+			else if (excl < rem && rem <= inc)
+			{
+				uint32_t	cum = excl, b = 4 * tid, c = c0;
+
+				if (cum + c < rem) { cum += c; b++; c = c1; }
+				if (cum + c < rem) { cum += c; b++; c = c2; }
+				if (cum + c < rem) { cum += c; b++; c = c3; }
+				sh[0] = b;
+				sh[1] = rem - cum;	/* rank inside this bin, 1-based */
+				sh[2] = c;
+			}
 		}
 		__syncthreads();
 		prefix |= sh[0] << shift;

