@@ -759,7 +759,7 @@ k_sum_candidates(const uint32_t *__restrict__ cand_off, const uint32_t *__restri
 	__shared__ unsigned long long pa[4], pm[4];
 	unsigned long long a = 0, m = 0;
 
-	for (uint32_t q = threadIdx.x; q < nq; q += 256)
+	for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256)
 	{
 		a += cand_off[(size_t) q * (npr + 1) + npr];
 		m += (loc_cand_off ? loc_cand_off : cand_off)[(size_t) q * (npr + 1) + npr];
@@ -3545,9 +3545,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			break;
 	}
 	/* statistics: survivors given the reference's arithmetic, records emitted (as the last round left them) */
-	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
+	hipLaunchKernelGGL(k_sum_u32, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, g.stream, (const unsigned int *) surv, (uint32_t) nq,
 					   g.d_counters + 3);
-	hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
+	hipLaunchKernelGGL(k_sum_u32, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, g.stream, (const unsigned int *) ecount, (uint32_t) nq,
 					   g.d_counters + 4);
 	if (cen && fl8[5] > 0)
 		ix->s16c_density = (float) fl8[4] / (float) fl8[5];		/* pairs per bucket with pairs: the next batch's tile size */
@@ -4078,7 +4078,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	if (!full)
 		return 0;
 	if (!summed)
-	hipLaunchKernelGGL(k_sum_candidates, dim3(1), dim3(256), 0, g.stream, (const uint32_t *) ix->w_candoff,
+	hipLaunchKernelGGL(k_sum_candidates, dim3(std::min(64, (nq + 255) / 256)), dim3(256), 0, g.stream, (const uint32_t *) ix->w_candoff,
 					   (const uint32_t *) lco_w, (uint32_t) nq, npr, ix->dim * (ix->f16 ? 2 : 4), g.d_counters);
 
 	/* HOT LOOP 2 */

@@ -280,14 +280,15 @@ k_ivf_survivors(IvfDev ix, const float *__restrict__ queries, const int *__restr
 
 /* one lane per listed candidate: the reference's arithmetic, the value into the distance buffer and into its
  * tile's minimum */
-/* counters[3] += sum of v[0..n): one block */
+/* counters[3] += sum of v[0..n): any number of blocks, one atomic each (a single block of 256 threads read 4096 values
+ * in 16 dependent trips: 6 us of a 1 ms step for a statistic) */
 __global__ __launch_bounds__(256) void
 k_sum_u32(const unsigned int *__restrict__ v, uint32_t n, unsigned long long *__restrict__ out)
 {
 	__shared__ unsigned long long part[4];
 	unsigned long long s = 0;
 
-	for (uint32_t i = threadIdx.x; i < n; i += 256)
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
 		s += v[i];
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1)
