@@ -183,6 +183,10 @@ int			ndbhip_gen_rows_host(int kind, uint64_t seed, uint64_t center_seed, int64_
  * C, D [ntiles][32][32] floats, all device pointers; asynchronous on the library's stream. */
 int			ndbhip_mfma_probe(const uint16_t *d_a, const uint16_t *d_b, const float *d_c, float *d_d,
 							  int ntiles, int chain);
+/* The fp32 matrix instruction that screens the centred sweep's accumulator blocks (v_mfma_f32_32x32x2_f32,
+ * csrc/ndbhip_screen16c.h "pass 0"): per tile t, D = C + A.B with A [ntiles][32][2], B [ntiles][2][32],
+ * C, D [ntiles][32][32] floats. */
+int			ndbhip_mfma_probe_f32(const float *d_a, const float *d_b, const float *d_c, float *d_d, int ntiles);
 
 /* ------------------------------------------------------------------ */
 /* IVF mirror lifecycle.  Replaces the page walk of ivfSelectClusters /

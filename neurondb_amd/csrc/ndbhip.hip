@@ -1762,6 +1762,14 @@ struct ndbhip_ivf
 	/* centroids AND the regrouped lists' centres as one matrix (columns 0 .. ncmp - 1, then the centres): a screened
 	 * batch that needs both gets them from one launch instead of two of the same fixed latency */
 	S16Mat		dm_all;
+	/* a sample of the mirror's rows as a matrix of their own: first thresholds of a dense batch (k_s16c_seed_sample) */
+	S16Mat		dm_seed;
+	bool		seed_valid = false;
+	int			seed_n = 0;
+	float	   *d_seedrows = nullptr; size_t d_seedrows_n = 0;
+	int		   *d_seed_list = nullptr; size_t d_seed_list_n = 0;
+	uint32_t   *d_seed_pos = nullptr; size_t d_seed_pos_n = 0;
+	float	   *w_seedmat = nullptr; size_t w_seedmat_n = 0;
 	float	   *d_allcent = nullptr;	size_t d_allcent_n = 0;
 	bool		dm_all_valid = false;
 	int			dm_all_ncmp = 0;
@@ -1870,7 +1878,7 @@ ivf_free_rows(ndbhip_ivf *ix)
 	ix->d_tids = nullptr;
 	ix->own_rows = false;
 	ix->nrows = 0;
-	ix->norm_valid = false; ix->s16_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
 	ix->cap_rows = 0;
 }
 
@@ -1891,13 +1899,14 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
 		ix->dm_sub.release();
 		ix->dm_cent.release();
 		ix->dm_all.release();
+		ix->dm_seed.release();
 		if (ix->pin) (void) hipHostFree(ix->pin);
 	}
 	delete ix;
@@ -2029,7 +2038,7 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
-	ix->norm_valid = false; ix->s16_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
 	ix->loaded = true;
 	return NDBHIP_OK;
 }
@@ -2108,7 +2117,7 @@ ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owne
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
-	ix->norm_valid = false; ix->s16_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
 	ix->f16 = true;
 	ix->loaded = true;
 	return ivf_note_f16_subnormals(ix);
@@ -2133,7 +2142,7 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 	ix->own_rows = false;
 	ix->f16 = false;
 	ix->nrows = nrows;
-	ix->norm_valid = false; ix->s16_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
 	return NDBHIP_OK;
@@ -2359,6 +2368,7 @@ ivf_flush(ndbhip_ivf *ix)
 	}
 	ix->nrows = nown;
 	ix->norm_valid = false;
+	ix->seed_valid = false;
 	/* the centred planes take the new rows in the spare blocks of their lists (ndbhip_screen16c.h); anything else —
 	 * other layouts, a list that has outgrown its spare blocks — is laid out again by the next screened batch */
 	if (ix->s16_valid && ivf_s16c_append(ix, add, new_own) != 0)
@@ -2713,6 +2723,7 @@ ivf_recipe(int strategy)
 /* defined with the build kernels below; the batch centroid scan of the search reuses them */
 #include "ndbhip_screen16.h"
 #include "ndbhip_screen16c.h"
+#include "ndbhip_screen16d.h"
 
 /* the fp16-MFMA screened scan in auto mode (ndbhip_set_option("screen16", 0) turns it off: the older fp32 bound
  * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
@@ -2782,6 +2793,12 @@ ndbhip_internal_set_thr_hook(int (*fn) (float *, size_t))
 
 static int	g_s16_slack = 1;	/* the centred planes keep spare blocks and take appends in place ("screen16_slack", 0: every append lays the planes out again) */
 static int	g_s16c_seeds = 0;	/* rows whose upper bounds give a query its first threshold, 0 = 32 (k <= 20) or 64 ("screen16c_seeds") */
+static int	g_s16c_epi = 1;		/* 1: the sweep's matrix pipe screens its own accumulator blocks before the per-element test; 0: every element tested (A/B, "screen16c_epi") */
+static int	g_s16c_pf = 0;		/* variants of k_s16c_sweep<8, 2> for A/B: 3 = an in-wave L2 prefetch, 16 / 32 / 48 = non-temporal rows / pairs / both ("screen16c_pf") */
+static int	g_s16c_dense = 1;	/* dense buckets (tile of 256 x 256) run k_s16c_dense (ndbhip_screen16d.h: loader and prefetcher waves); 0: k_s16c_sweep<8, 2> ("screen16c_dense") */
+static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch's first thresholds, 0 = none ("screen16c_sample") */
+static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
+static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
 static int	g_s16_redo = 1;		/* queries whose records / survivors overflow go to the exact path alone ("screen16_redo"; 0: the whole batch does) */
@@ -3195,6 +3212,38 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	else if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
 				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr, cen ? 1 : 0);
+	/* a table without cluster structure (what the previous batch's pairs per bucket say, as for the tile size below):
+	 * thresholds from a sample of the mirror's rows (k_s16c_seed_sample) on top of the seeds' */
+	if (!seed_by_sublist && cen && !xseed && R == R_IVF_L2 && !ix->s16_sub && g_s16c_sample > 0 && k <= 64 && npr <= 512 &&
+		ix->nrows >= 16 * (int64_t) g_s16c_sample &&
+		(g_s16c_qb == 8 || (g_s16c_qb == 0 && ix->s16c_density >= 320.0f)))
+	{
+		const uint32_t ns = (uint32_t) g_s16c_sample, sstr = (ns + 63u) & ~63u;
+
+		if (!ix->seed_valid || ix->seed_n != (int) ns)
+		{
+			if (grow(ix->d_seedrows, ix->d_seedrows_n, (size_t) ns * dim)) return NDBHIP_ERR_HIP;
+			if (grow(ix->d_seed_list, ix->d_seed_list_n, (size_t) ns)) return NDBHIP_ERR_HIP;
+			if (grow(ix->d_seed_pos, ix->d_seed_pos_n, (size_t) ns)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_seed_gather, dim3(ns), dim3(256), 0, g.stream, (const float *) ix->d_vecs, (int64_t) ix->nrows, dim,
+							   d.loc_off, nc, ns, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos);
+			const int	rc = s16mat_prepare(ix->dm_seed, ix->d_seedrows, (int) ns, dim);
+
+			if (rc)
+				return rc;
+			ix->seed_valid = true;
+			ix->seed_n = (int) ns;
+		}
+		if (grow(ix->w_seedmat, ix->w_seedmat_n, (size_t) nq * sstr)) return NDBHIP_ERR_HIP;
+		const int	rc = s16mat_run(ix->dm_seed, dim, (const unsigned char *) ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq,
+									ix->w_seedmat, sstr);
+
+		if (rc)
+			return rc;
+		hipLaunchKernelGGL(k_s16c_seed_sample, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_seedmat, sstr, ns,
+						   (const int *) ix->d_seed_list, (const uint32_t *) ix->d_seed_pos, w_probes, lco, npr, (uint32_t) k,
+						   (const float *) ix->w_qn2, (const uint32_t *) ix->dm_seed.xmax, dim, ix->w_qthr);
+	}
 	if (g_thr_hook && !seed_by_sublist)
 	{
 		/* sharded search: the smallest threshold any rank found for a query serves all of them */
@@ -3264,10 +3313,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const uint32_t qc_cap = (uint32_t) std::min<size_t>(std::min<size_t>(pairs_cap, std::max<size_t>((size_t) ix->qc_mult * nq * npr + 1024, (size_t) 1 << 16)),
 														   0x7FFFFFFFu);
 	const uint32_t qcrowbytes = (uint32_t) dimp * 2u;
+	/* the dense tile's kernel (ndbhip_screen16d.h) reads chunk-major pair planes: [64-dim chunk][pair][64 halfs] */
+	const bool	dense_k = cen && c_qb == 8 && g_s16c_dense;
+	const size_t qc_plane = ((size_t) qc_cap + 256) * 64;		/* halfs per chunk plane */
 
 	if (cen)
 	{
-		if (grow(ix->w_qcplanes, ix->w_qcplanes_n, (size_t) qc_cap * dimp)) return NDBHIP_ERR_HIP;
+		/* (+ 256 rows: the dense sweep's loaders fetch whole 8-row pieces of a tile's last, partly filled pair block) */
+		if (grow(ix->w_qcplanes, ix->w_qcplanes_n, ((size_t) qc_cap + 256) * dimp)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qcn2, ix->w_qcn2_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qcexp, ix->w_qcexp_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_pslot, ix->w_pslot_n, (size_t) 3 * qc_cap)) return NDBHIP_ERR_HIP;
@@ -3452,7 +3505,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const PairRec *) ix->w_pairs, (const uint32_t *) pair_off, ncs,
 							   cosb ? (const float *) ix->d_cent_hat : (const float *) ix->d_centroids,
 							   sub ? (const float *const *) ix->d_sub_cptr : (const float *const *) nullptr,
-							   ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_pslot, ix->w_pslot + qc_cap, ix->w_pslot + 2 * (size_t) qc_cap,
+							   ix->w_qcplanes, dense_k ? qc_plane : (size_t) 0, ix->w_qcn2, ix->w_qcexp, ix->w_pslot, ix->w_pslot + qc_cap, ix->w_pslot + 2 * (size_t) qc_cap,
 							   lco, npr, qc_cap, flags + 2, round == 0 ? flags + 4 : (unsigned int *) nullptr,
 							   (const uint32_t *) cnt);
 		}
@@ -3473,8 +3526,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			/* (a ring of 3 looks two chunks ahead, which must not reach past the NEXT item: dims <= 64 are one chunk) */
 			const int	nbuf = dimp / S16C_CH < 2 ? 2 : (g_s16c_nbuf ? g_s16c_nbuf : (c_qb == 1 ? 3 : 2));
 
-#define S16C_SWEEP_L(QB, NB, DB)                                                                                     \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB>), dim3(g.num_cus * ((QB != 8 && (QB == 1 || NB == 2)) ? 2 : 1)), dim3(QB == 8 ? 512 : 256), 0, g.stream, \
+#define S16C_SWEEP_L(QB, NB, DB) S16C_SWEEP_LP(QB, NB, DB, 1, 0)
+#define S16C_SWEEP_LE(QB, NB, DB, EP) S16C_SWEEP_LP(QB, NB, DB, EP, 0)
+#define S16C_SWEEP_LP(QB, NB, DB, EP, PFD)                                                                           \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_sweep<QB, NB, DB, EP, PFD>), dim3(g.num_cus * ((QB != 8 && (QB == 1 || NB == 2)) ? 2 : 1)), dim3(QB == 8 ? 512 : 256), 0, g.stream, \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
@@ -3484,16 +3539,57 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0)
-			if (g_s16_debug == 1 && c_qb == 8)
+#define S16C_DENSE_L(DB)                                                                                             \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_dense<DB>), dim3(g.num_cus), dim3(512), 0, g.stream,                  \
+							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
+							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
+							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qc_plane * 2, \
+							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (const uint32_t *) ix->w_pslot,            \
+							   (const uint32_t *) (ix->w_pslot + qc_cap), (const uint32_t *) (ix->w_pslot + 2 * (size_t) qc_cap), \
+							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
+							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
+							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot)
+			if (dense_k && g_s16_debug == 6)
+				S16C_DENSE_L(6);
+			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4))
+				S16C_DENSE_L(0);
+			else if (dense_k && g_s16_debug == 1)
+				S16C_DENSE_L(1);
+			else if (dense_k && g_s16_debug == 2)
+				S16C_DENSE_L(2);
+			else if (dense_k && g_s16_debug == 3)
+				S16C_DENSE_L(3);
+			else if (dense_k && g_s16_debug == 4)
+				S16C_DENSE_L(4);
+			else if (g_s16_debug == 1 && c_qb == 8)
 				S16C_SWEEP_L(8, 2, 1);
 			else if (g_s16_debug == 2 && c_qb == 8)
 				S16C_SWEEP_L(8, 2, 2);
+			else if (g_s16_debug == 3 && c_qb == 8)
+				S16C_SWEEP_L(8, 2, 3);
+			else if (g_s16_debug == 4 && c_qb == 8)
+				S16C_SWEEP_L(8, 2, 4);
 			else if (g_s16_debug == 1)
 				S16C_SWEEP_L(4, 2, 1);
 			else if (g_s16_debug == 2)
 				S16C_SWEEP_L(4, 2, 2);
+			else if (c_qb == 8 && !g_s16c_epi)
+				S16C_SWEEP_LE(8, 2, 0, 0);
+			else if (c_qb == 8 && g_s16c_pf == 3)
+				S16C_SWEEP_LP(8, 2, 0, 1, 3);
+			else if (c_qb == 8 && g_s16c_pf == 16)
+				S16C_SWEEP_LP(8, 2, 0, 1, 16);
+			else if (c_qb == 8 && g_s16c_pf == 32)
+				S16C_SWEEP_LP(8, 2, 0, 1, 32);
+			else if (c_qb == 8 && g_s16c_pf == 48)
+				S16C_SWEEP_LP(8, 2, 0, 1, 48);
 			else if (c_qb == 8)
 				S16C_SWEEP_L(8, 2, 0);
+			else if (c_qb == 1 && nbuf == 3 && !g_s16c_epi)
+				S16C_SWEEP_LE(1, 3, 0, 0);
+			else if (c_qb == 4 && nbuf == 2 && !g_s16c_epi)
+				S16C_SWEEP_LE(4, 2, 0, 0);
 			else if (c_qb == 1 && nbuf == 2)
 				S16C_SWEEP_L(1, 2, 0);
 			else if (c_qb == 1)
@@ -3699,6 +3795,19 @@ ndbhip_mfma_probe(const uint16_t *d_a, const uint16_t *d_b, const float *d_c, fl
 }
 
 extern "C" int
+ndbhip_mfma_probe_f32(const float *d_a, const float *d_b, const float *d_c, float *d_d, int ntiles)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ntiles < 0 || (ntiles > 0 && (!d_a || !d_b || !d_c || !d_d)))
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ntiles == 0)
+		return NDBHIP_OK;
+	hipLaunchKernelGGL(k_s16_mfma_probe_f32, dim3(ntiles), dim3(64), 0, g.stream, d_a, d_b, d_c, d_d);
+	HIP_TRY(hipGetLastError());
+	return NDBHIP_OK;
+}
+
+extern "C" int
 ndbhip_set_option(const char *name, int value)
 {
 	if (!name)
@@ -3793,6 +3902,30 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_seeds must be 0 (default), 32 or 64");
 		g_s16c_seeds = value;
 	}
+	else if (!strcmp(name, "screen16c_sample"))
+	{
+		if (value != 0 && (value < 256 || value > 2048))
+			return fail(NDBHIP_ERR_INVALID, "screen16c_sample must be 0 or 256..2048");
+		g_s16c_sample = value;
+	}
+	else if (!strcmp(name, "screen16c_rot"))
+		g_s16c_rot = value != 0;
+	else if (!strcmp(name, "screen16c_dense"))
+		g_s16c_dense = value != 0;
+	else if (!strcmp(name, "screen16c_pfd"))
+	{
+		if (value < 0 || value > 10)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_pfd must be 0..10");
+		g_s16c_pfd = value;
+	}
+	else if (!strcmp(name, "screen16c_pf"))
+	{
+		if (value != 0 && value != 3 && value != 16 && value != 32 && value != 48)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_pf must be 0, 3, 16, 32 or 48");
+		g_s16c_pf = value;
+	}
+	else if (!strcmp(name, "screen16c_epi"))
+		g_s16c_epi = value != 0;
 	else if (!strcmp(name, "screen16c_nbuf"))
 	{
 		if (value != 0 && value != 2 && value != 3)

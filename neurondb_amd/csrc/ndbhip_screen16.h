@@ -1383,20 +1383,32 @@ typedef const __attribute__((address_space(1))) void *ndb_glb_ptr;
  * register hipcc does not model as a clobber, so the guarantee has to come from the generated code); one wait
  * state between the SALU write of M0 and its use.
  */
+template <bool NT = false>
 __device__ __forceinline__ void
 s16_dma16(const unsigned char *base, uint32_t voff, uint32_t la)
 {
-	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-				 :: "s"(la), "v"(voff), "s"(base) : "memory");
+	if constexpr (NT)
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+					 :: "s"(la), "v"(voff), "s"(base) : "memory");
+	else
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+					 :: "s"(la), "v"(voff), "s"(base) : "memory");
 }
 
 /* the same for a piece that is contiguous on both sides: N instructions, lane i of instruction j copies the 16
  * bytes at base + 1024 j + 16 i to la + 1024 j + 16 i (the instruction offset applies to both addresses) */
-template <int N>
+template <int N, bool NT = false>
 __device__ __forceinline__ void
 s16_dma_linear(const unsigned char *base, uint32_t lane16, uint32_t la)
 {
-	if constexpr (N == 4)
+	if constexpr (N == 4 && NT)
+		/* non-temporal: a stream that is read once (by the blocks sharing it now) should not push out of the L2 what
+		 * is read again */
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+					 "global_load_lds_dwordx4 %1, %2 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+					 "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 nt"
+					 :: "s"(la), "v"(lane16), "s"(base) : "memory");
+	else if constexpr (N == 4)
 		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
 					 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
 					 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
@@ -2496,6 +2508,24 @@ k_s16_mfma_probe(const uint16_t *__restrict__ A, const uint16_t *__restrict__ B,
 		acc[r] = C[(t * 32 + ((r & 3) + 8 * (r >> 2) + 4 * kh)) * 32 + i];
 	for (int c = 0; c < chain; c++)
 		acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		D[(t * 32 + ((r & 3) + 8 * (r >> 2) + 4 * kh)) * 32 + i] = acc[r];
+}
+
+/* the same for the fp32 instruction of the centred sweep's pass 0 (ndbhip_mfma_probe_f32): A [nt][32][2], B [nt][2][32] */
+__global__ __launch_bounds__(64) void
+k_s16_mfma_probe_f32(const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ C,
+					 float *__restrict__ D)
+{
+	const size_t t = blockIdx.x;
+	const int	lane = threadIdx.x, i = lane & 31, kh = lane >> 5;
+	ndb_f16acc	acc;
+
+#pragma unroll
+	for (int r = 0; r < 16; r++)
+		acc[r] = C[(t * 32 + ((r & 3) + 8 * (r >> 2) + 4 * kh)) * 32 + i];
+	acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(t * 32 + i) * 2 + kh], B[(t * 2 + kh) * 32 + i], acc, 0, 0, 0);
 #pragma unroll
 	for (int r = 0; r < 16; r++)
 		D[(t * 32 + ((r & 3) + 8 * (r >> 2) + 4 * kh)) * 32 + i] = acc[r];

@@ -209,7 +209,9 @@ k_s16c_set_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ idx, con
 __global__ __launch_bounds__(256) void
 k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRec *__restrict__ pairs,
 			  const uint32_t *__restrict__ pair_off, int nb, const float *__restrict__ cents,
-			  const float *const *__restrict__ cptr, _Float16 *__restrict__ qcplanes, float *__restrict__ qcn2,
+			  const float *const *__restrict__ cptr, _Float16 *__restrict__ qcplanes,
+			  size_t chunk_plane /* 0: [pair][dimp]; else the dense sweep's layout, [64-dim chunk][pair][64] with this many halfs per chunk plane */,
+			  float *__restrict__ qcn2,
 			  int *__restrict__ qcexp, uint32_t *__restrict__ pqid, uint32_t *__restrict__ pla, uint32_t *__restrict__ pnrow,
 			  const uint32_t *__restrict__ loc_cand_off, int npr,
 			  uint32_t cap, unsigned int *__restrict__ flags /* [0]++ when the pairs exceed cap */,
@@ -281,7 +283,7 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 			pla[j] = lq[pr.p];
 			pnrow[j] = lq[pr.p + 1] - lq[pr.p];
 		}
-		ndb_h2	   *out = reinterpret_cast<ndb_h2 *>(qcplanes + (size_t) j * dimp);
+		ndb_h2	   *out = reinterpret_cast<ndb_h2 *>(qcplanes + (chunk_plane ? (size_t) j * 64 : (size_t) j * dimp));
 
 		for (int p = lane; p < dimp / 2; p += 64)
 		{
@@ -295,7 +297,10 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 			ndb_h2		h;
 
 			h.x = h0; h.y = h1;
-			out[p] = h;
+			if (chunk_plane)
+				*reinterpret_cast<ndb_h2 *>(reinterpret_cast<_Float16 *>(out) + (size_t) (i >> 6) * chunk_plane + (i & 63)) = h;
+			else
+				out[p] = h;
 		}
 	}
 }
@@ -525,6 +530,135 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 }
 
 /*
+ * Thresholds for tables WITHOUT cluster structure (the i.i.d. table of BASELINE.md: whole lists as buckets, every query
+ * probing most of the table).  k_s16c_seed's 32 seed rows are 32 arbitrary rows there — their k-th smallest distance is
+ * about the median of all distances — and a query's first tiles, multiplied by 32 blocks at a time before any tightening
+ * can reach them, emitted half of their rows: 2 100 records per query for 13 survivors, 2.7 of the sweep's 7.4 ms
+ * (profiles/r04_dense_probe.txt).  A threshold taken from n0 of the query's candidates passes 1 / n0-th of the rest as
+ * the sweep begins, so: a fixed SAMPLE of the mirror's rows (`ns`, every nrows / ns-th row: k_seed_gather, once per
+ * version of the mirror), all queries against all of them as one dense matrix on the matrix cores (s16mat_run: the
+ * two-plane sweep's MODE 3, as the centroid scan runs), and per query the k-th smallest UPPER bound a + E of its own
+ * candidates among them — a sample row counts for a query that probes its list and sees its position under the candidate
+ * cap, exactly what makes a row a seed in k_s16c_seed.
+ */
+__global__ __launch_bounds__(256) void
+k_seed_gather(const float *__restrict__ vecs, int64_t nrows, int dim, const int64_t *__restrict__ loc_off, int ncent,
+			  uint32_t ns, float *__restrict__ out, int *__restrict__ slist, uint32_t *__restrict__ spos)
+{
+	const uint32_t i = blockIdx.x;
+	const int64_t row = (int64_t) (((uint64_t) i * (uint64_t) nrows) / ns);
+	int			lo = 0, hi = ncent;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (loc_off[mid] <= row)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < ncent && loc_off[lo + 1] <= row)
+		lo++;
+	if (threadIdx.x == 0)
+	{
+		slist[i] = lo;
+		spos[i] = (uint32_t) (row - loc_off[lo]);
+	}
+	for (int j = threadIdx.x; j < dim; j += 256)
+		out[(size_t) i * dim + j] = vecs[(size_t) row * dim + j];
+}
+
+/* one block per query; amat[q][0 .. ns) = a ~ |q - sample|^2 within E = s16_e(dim, |q|^2, largest sample norm) */
+__global__ __launch_bounds__(256) void
+k_s16c_seed_sample(const float *__restrict__ amat, uint32_t astride, uint32_t ns, const int *__restrict__ slist,
+				   const uint32_t *__restrict__ spos, const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off,
+				   int npr, uint32_t k, const float *__restrict__ qn2, const uint32_t *__restrict__ xmax_bits, int dim,
+				   float2 *__restrict__ qthr)
+{
+	constexpr int PER = 8;			/* ns <= 2048 */
+	__shared__ int s_pl[512];
+	__shared__ uint32_t s_vis[512];
+	__shared__ unsigned long long s_red[4];
+	const uint32_t q = blockIdx.x;
+	const int	tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
+
+	for (int p = tid; p < npr; p += 256)
+	{
+		s_pl[p] = probes[(size_t) q * npr + p];
+		s_vis[p] = lco[p + 1] - lco[p];
+	}
+	__syncthreads();
+	const float e = s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*xmax_bits), false);
+	unsigned long long key[PER];
+
+#pragma unroll
+	for (int u = 0; u < PER; u++)
+	{
+		const uint32_t i = (uint32_t) tid + 256u * (uint32_t) u;
+
+		key[u] = ~0ull;
+		if (i < ns)
+		{
+			const int	L = slist[i];
+			const uint32_t pos = spos[i];
+			bool		ok = false;
+
+			/* (a list can be probed more than once — ivf_am.c:1978 —: any probe that sees the row will do) */
+			for (int p = 0; p < npr; p++)
+				ok = ok || (s_pl[p] == L && pos < s_vis[p]);
+			const float ub = s16_up(fmaxf(amat[(size_t) q * astride + i] + e, 0.0f));
+
+			if (ok && ub == ub && ub < 3.0e38f)
+				key[u] = ((unsigned long long) __float_as_uint(ub) << 32) | i;		/* ub >= 0: the bits order like the values */
+		}
+	}
+	/* the k-th smallest by k rounds of "take the minimum out" (k <= 64, distinct keys) */
+	unsigned long long kth = ~0ull;
+
+	for (uint32_t r = 0; r < k; r++)
+	{
+		unsigned long long m = key[0];
+
+#pragma unroll
+		for (int u = 1; u < PER; u++)
+			m = key[u] < m ? key[u] : m;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) m, off, 64);
+			const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (m >> 32), off, 64);
+			const unsigned long long o = ((unsigned long long) hi << 32) | lo;
+
+			m = o < m ? o : m;
+		}
+		if (lane == 0)
+			s_red[w] = m;
+		__syncthreads();
+		m = s_red[0];
+#pragma unroll
+		for (int j = 1; j < 4; j++)
+			m = s_red[j] < m ? s_red[j] : m;
+		__syncthreads();
+		kth = m;
+		if (m == ~0ull)
+			break;				/* fewer than k candidates in the sample: no threshold from it (uniform) */
+#pragma unroll
+		for (int u = 0; u < PER; u++)
+			if (key[u] == m)
+				key[u] = ~0ull;
+	}
+	if (tid == 0 && kth != ~0ull)
+	{
+		const float t = s16c_t_from_ub(__uint_as_float((uint32_t) (kth >> 32)), dim);
+
+		/* T >= 0 (or +inf): its bits order like the values */
+		atomicMin(reinterpret_cast<unsigned int *>(&qthr[q].x), __float_as_uint(t));
+	}
+}
+
+/*
  * Geometry.  QB = 32-pair blocks per tile (4: 128 pairs; 1: 32 pairs, for batches whose buckets are probed by a
  * handful of queries each — most of a 128-pair tile would be padding, and the LDS it reserves is better spent on a
  * deeper ring, because that regime is bound by the rows' bytes); 4 waves, 128 rows per tile.  QB = 8 is the dense
@@ -579,7 +713,7 @@ s16_dma4(const void *base, uint32_t voff, uint32_t la)
  * chunk's own DMA has landed (s_waitcnt vmcnt leaves the later chunks' requests in flight), barrier, request chunk
  * g + NBUF - 1 into the buffer everybody has finished reading, 16 ds_read_b128 + 4 AQ BR MFMAs.
  */
-template <int QB, int NBUF, int DBG = 0>
+template <int QB, int NBUF, int DBG = 0, int EPI = 1, int VAR = 0>
 __global__ __launch_bounds__(64 * S16CGeom<QB>::NW, ((S16CGeom<QB>::BUF * NBUF + 8192) * 2 <= 160 * 1024) ? 2 : 1) void
 k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
 			 const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
@@ -595,6 +729,9 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			 int cosine = 0 /* the planes are normalised vectors' and the thresholds bound cosine distances (s16c_cos_t_from_ub) */ )
 {
 	typedef S16CGeom<QB> G;
+	/* VAR: bits 0-3 = chunks an L2 prefetch runs ahead (0: none), bit 4 = the rows' stream is non-temporal, bit 5 = the pairs' */
+	constexpr int PF = VAR & 15;
+	constexpr bool RNT = (VAR & 16) != 0, QNT = (VAR & 32) != 0;
 	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];
 	__shared__ __attribute__((aligned(1024))) unsigned char ring[NBUF * G::BUF];
 	/* per member of the two items in flight (by the item's parity): DMA'd from the pair-ordered arrays */
@@ -603,6 +740,13 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	__shared__ __attribute__((aligned(256))) uint32_t s_la[2][64 * ((G::QT + 63) / 64)], s_nrow[2][64 * ((G::QT + 63) / 64)],
 		s_qid[2][64 * ((G::QT + 63) / 64)];
 	__shared__ float s_t2[G::QT];
+	/* EPI: the members' two operands of the test instruction (k = 0: -v, k = 1: -u, below), and whether some exponent
+	 * of the item (by the item's parity) lies outside the range the test instruction is proved for */
+	__shared__ float s_nuv[2][G::QT];
+	__shared__ uint32_t s_wild[2];
+	/* PF: where the L2 prefetch's 4-byte-per-lane LDS DMA lands (nobody reads it) */
+	__shared__ __attribute__((aligned(256))) uint32_t s_sink[PF ? 64 : 1];
+	static_assert(PF == 0 || (NBUF == 2 && G::Q_DMA == 4), "the L2 prefetch is written for the ring of two and 32 pair rows per wave");
 	const int	tid = threadIdx.x;
 	const int	lane = tid & 63;
 	const int	wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -611,6 +755,8 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 	if (pair_off[nbuckets] > qc_cap)
 		return;					/* uniform */
+	if (tid < 2)
+		s_wild[tid] = 0;		/* (the first chunk's barrier comes before anybody looks) */
 	/* this block's items: those of run (block % 8) at stride (blocks in that XCD) */
 	const uint32_t xq = blockIdx.x & 7u;
 	const uint32_t stride = (gridDim.x - xq + 7u) >> 3;
@@ -673,16 +819,17 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	auto		issue = [&](uint32_t c, uint32_t bufi) {
 		if constexpr (DBG == 1)
 			return;
-		const unsigned char *rb = s16_uniform_ptr(DBG == 2 ? planes : rbase + (size_t) c * 4096);
-		const unsigned char *qb = s16_uniform_ptr(DBG == 2 ? qcplanes : qbase + (size_t) c * 128);
+		/* (DBG 3 / 4: only the rows' / only the pairs' operands come from where they are) */
+		const unsigned char *rb = s16_uniform_ptr((DBG == 2 || DBG == 4) ? planes : rbase + (size_t) c * 4096);
+		const unsigned char *qb = s16_uniform_ptr((DBG == 2 || DBG == 3) ? qcplanes : qbase + (size_t) c * 128);
 		const uint32_t la = ring_la + bufi * G::BUF;
 
-		s16_dma_linear<4>(rb, lane16, la + wave * 4096);
+		s16_dma_linear<4, RNT>(rb, lane16, la + wave * 4096);
 		if (qdma)
 		{
 #pragma unroll
 			for (int j = 0; j < G::Q_DMA; j++)
-				s16_dma16(qb, voff_q[j], la + G::Q_OFF + (wave * G::Q_DMA + j) * 1024);
+				s16_dma16<QNT>(qb, voff_q[j], la + G::Q_OFF + (wave * G::Q_DMA + j) * 1024);
 		}
 	};
 	/* request the next chunk of the stream (none left: nothing); returns whether this wave's request included pair
@@ -711,6 +858,48 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		return had_q;
 	};
 
+	/*
+	 * PF > 0: an L2 prefetch runs PF chunks ahead of the operand stream.  The ring holds one chunk in flight (64 KiB a
+	 * block: all the LDS there is), which covers an L2 hit's latency and not a miss's; two thirds of the requests hit
+	 * (the blocks of an XCD share row and pair tiles), but a chunk is as late as its latest line, so nearly every chunk
+	 * waited for HBM: 8.2 ms a batch on the i.i.d. table against 3.6 ms with every request a hit, at 1.9 TB/s — a
+	 * quarter of what HBM delivers.  So every wave touches, with one 4-byte-per-lane LDS DMA for the row block and one
+	 * for the pair rows (a line per lane; the data lands in a sink nobody reads), the 64 lines it will ask for PF chunks
+	 * later: by then they are in this XCD's L2.  The cursor (it_p, p_c) walks the same static schedule as the stream.
+	 */
+	uint32_t	it_p = it_c, p_c = 0, voff_qp = 0;
+	const unsigned char *rbase_p = planes, *qbase_p = qcplanes;
+	const uint32_t sink_la = (uint32_t) (uintptr_t) (ndb_lds_ptr) s_sink;
+	auto		enter_p = [&](uint32_t it) {
+		const S16Desc d = desc[it];			/* uniform address: scalar loads */
+		const uint32_t L = d.L, nmem = min((uint32_t) G::QT, cnt[L] - d.qt * G::QT);
+		const uint32_t nbk = blk_off[L + 1] - blk_off[L];
+		const uint32_t b = min(d.t2 * (uint32_t) G::RB + (uint32_t) wave, nbk - 1u);
+
+		rbase_p = planes + ((size_t) blk_off[L] + b) * (size_t) nchunk * 4096;
+		qbase_p = qcplanes + (size_t) (pair_off[L] + d.qt * G::QT) * qrowbytes;
+		voff_qp = min((uint32_t) (32 * wave + r32), nmem - 1u) * qrowbytes;
+	};
+	auto		prefetch_next = [&]() -> bool {
+		if constexpr (PF == 0)
+			return false;
+		if (it_p == S16_NOITEM)
+			return false;
+		if (p_c == (uint32_t) nchunk)
+		{
+			p_c = 0;
+			it_p = it_p + stride < run_hi ? it_p + stride : S16_NOITEM;
+			if (it_p == S16_NOITEM)
+				return false;
+			enter_p(it_p);
+		}
+		s16_dma4(s16_uniform_ptr(rbase_p + (size_t) p_c * 4096), (uint32_t) r32 * 128u, sink_la);
+		s16_dma4(s16_uniform_ptr(qbase_p + (size_t) p_c * 128), voff_qp, sink_la);
+		p_c++;
+		return true;
+	};
+	bool		pf_last = false;		/* the newest two requests of this wave are a prefetch (they may stay in flight across the chunk's wait) */
+
 	const int	sw = (r32 >> 1) & 7;
 	const int	qfrag = G::Q_OFF + (G::AQ * wq) * 4096 + r32 * 128;
 	const int	rfrag = (G::BR * wr) * 4096 + r32 * 128;
@@ -719,6 +908,13 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	 * pair rows: one bit per ring slot */
 	uint32_t	qbits = 0;
 
+	if constexpr (PF > 0)
+	{
+		/* (the first PF + NBUF - 1 chunks are touched too: the stream asks for the first of them right behind) */
+		enter_p(it_c);
+		for (int p = 0; p < PF + NBUF - 1; p++)
+			(void) prefetch_next();
+	}
 	enter(it_c, 0);
 #pragma unroll
 	for (int p = 0; p < NBUF - 1; p++)
@@ -787,7 +983,15 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			/* chunk g_c must have landed; the requests for the NBUF - 2 chunks after it may stay in flight: 4 row
 			 * pieces each, plus Q_DMA pair pieces where the request had them (anything else the wave has asked for —
 			 * member constants — is older than those and is waited for along with the chunk) */
-			if constexpr (NBUF == 2)
+			if constexpr (NBUF == 2 && PF > 0)
+			{
+				/* (requests retire in order: leaving the newest two — the prefetch — leaves nothing of the chunk) */
+				if (pf_last)
+					s16_wait_vm<2>();
+				else
+					s16_wait_vm<0>();
+			}
+			else if constexpr (NBUF == 2)
 				s16_wait_vm<0>();
 			else
 			{
@@ -808,6 +1012,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 				qbits = (qbits & ~(1u << slot)) | ((hq ? 1u : 0u) << slot);
 			}
+			pf_last = prefetch_next();
 			compute(ring + (g_c % NBUF) * G::BUF);
 			g_c++;
 		};
@@ -851,8 +1056,45 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			exr[b] -= 27;
 		}
 		if (tid < G::QT)
+		{
 			/* what the test subtracts: T rounded up with the slack its fused form needs (see below) */
 			s_t2[tid] = s16_up(tfresh * 1.000001f) + NDB_S16_ABS;
+			if constexpr (EPI != 0)
+			{
+				/* (an index the compiler cannot see through: the dense tile runs at the register file's limit, and an
+				 * LDS address computed in the prologue for this block would live — in scratch — across the whole sweep) */
+				int			tix = tid;
+
+				asm volatile("" : "+v"(tix));
+				/* the member's operands of the test instruction (see "pass 0" below): u = (KB Q2 - TB) 2^(27 - eq) and
+				 * v = KB 2^(27 - eq), negated.  A member the tile does not have never emits (u = +inf); a NaN — a norm
+				 * that is not a finite fp32, a threshold that is +inf — always does (u = -inf). */
+				const bool	valid = (uint32_t) tix < nmem_cur;
+				const int	eq = s_eq[c_par][tix];
+				const float KB = (1.0f - cE) * 0.9999962f;
+				const float TB = s16_up(tfresh * 1.000004f) + NDB_S16_ABS;
+				float		cm = __builtin_fmaf(s_q2[c_par][tix], KB, -TB);
+
+				if (!(cm == cm))
+					cm = -__builtin_inff();
+				s_nuv[0][tix] = -ldexpf(KB, 27 - eq);
+				s_nuv[1][tix] = valid ? -ldexpf(cm, 27 - eq) : -__builtin_inff();
+				if (valid && (eq < -20 || eq > 20))
+					s_wild[c_par] = 1u;
+			}
+		}
+		if constexpr (EPI != 0)
+		{
+			bool		w = false;
+
+#pragma unroll
+			for (int b = 0; b < G::BR; b++)
+				w = w || (rokr[b] && (exr[b] + 27 < -20 || exr[b] + 27 > 20));
+			if (w)
+				s_wild[c_par] = 1u;
+			if (tid == 0)
+				s_wild[c_par ^ 1u] = 0;		/* read by the item before this one, set next by the item after it */
+		}
 		__syncthreads();
 
 		/*
@@ -996,13 +1238,82 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			}
 		}
 		};
-		epilogue(std::integral_constant<int, 0>{});
+		/*
+		 * Pass 0 (EPI): the test above costs a dozen vector instructions per accumulator element — at 128 elements a
+		 * lane and two waves a SIMD as much time as the item's matrix instructions —, and all but a few in a million
+		 * elements are left out.  So the matrix pipe evaluates the test itself: one v_mfma_f32_32x32x2_f32 per 32 x 32
+		 * block (fp32 operands, D = fma(a1, b1, fma(a0, b0, C)): 4 % of the block's 4 nchunk fp16 instructions) with
+		 *     A[member][k] = (-v, -u),   v = KB 2^(27 - eq),  u = (KB Q2 - TB) 2^(27 - eq)          (per member, LDS)
+		 *     B[k][row]    = (w, s),     w = X2 2^-ex,        s = 2^-ex                               (per row)
+		 *     C            = the block's accumulators = t1 P / 2... = dot 2^(28 - eq - ex) = t1 P,  P = 2^(27 - eq - ex)
+		 * leaves fin = (t1 - (KB (Q2 + X2) - TB)) P up to two fp32 roundings, into registers of its own (the
+		 * accumulators stay as they are), and the element may be left out when fin < 0:
+		 *   - every scaling is by a power of two and exact while |eq|, |ex| <= 20 (u, v, w, s normal or zero, no
+		 *     overflow: |u| < 2^(27 + eq) when it is positive); an item with an exponent outside that range
+		 *     (`s_wild`) does not use the instruction's verdict at all;
+		 *   - KB = (1 - cE)(1 - 2^-18) and TB = T (1 + 2^-18) (+ up) + ABS give away (1 - cE) n 2^-18 + T 2^-18
+		 *     >= (32 n + 64 T) u of the real right-hand side n (1 - cE) - ABS - T  (n = Q2 + X2, cE < 1/2), while
+		 *     everything that is rounded moves the computed one by less: KB itself 2 u n, the fma that makes
+		 *     KB Q2 - TB u (Q2 + TB), the instruction's two steps — taken at 2 u each of |C| + |a0 b0| + |a1 b1|
+		 *     <= (2 n + TB) P, twice what a correctly rounded fma chain costs — 4 u (2 n + TB) P: (11 n + 5 T) u P in all.
+		 *     Hence fin < 0 implies t1 < n (1 - cE) - ABS - T in real numbers: what pass 1 tests;
+		 *   - a row the tile does not have, or a hole, never emits (w = +inf: fin = -inf), a row whose norm is not a
+		 *     finite fp32 always does (w = -inf); where the two kinds of infinity meet (NaN), one side is a member or
+		 *     row that pass 1 throws out anyway.
+		 * "Some fin >= 0 or NaN" = the largest of the 16 AQ BG bit patterns, taken as integers, is >= 0 (the part
+		 * makes +NaN; a -NaN can only come from the meeting of infinities above).  Only then — a few times per
+		 * thousand blocks — the group goes through passes 1 and 2, which decide as they always did.
+		 */
+		auto		screen = [&](auto bgc) -> bool {
+			constexpr int bg = decltype(bgc)::value;
+
+			if constexpr (EPI == 0)
+				return true;
+			else
+			{
+				int			mx = (int) 0x80000000;
+
+#pragma unroll
+				for (int bb = 0; bb < G::BG; bb++)
+				{
+					const int	b = bg * G::BG + bb;
+					/* (exr is the row's exponent - 27) */
+					const bool	nan = !(x2r[b] == x2r[b]);
+					const bool	dead = !rokr[b] || porr[b] == 0xFFFFFFFFu;
+					const float w = dead ? __builtin_inff() : (nan ? -__builtin_inff() : ldexpf(x2r[b], -(exr[b] + 27)));
+					const float wb = kh ? ldexpf(1.0f, -(exr[b] + 27)) : w;
+
+#pragma unroll
+					for (int a = 0; a < G::AQ; a++)
+					{
+						if (a >= na)
+							continue;
+						const float ua = s_nuv[kh][32 * (G::AQ * wq + a) + r32];
+						const ndb_f16acc fin = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, wb, acc[a][b], 0, 0, 0);
+
+#pragma unroll
+						for (int reg = 0; reg < 16; reg++)
+							mx = max(mx, __float_as_int(fin[reg]));
+					}
+				}
+				const bool	hit = DBG ? mx == 0x12345678 : (mx >= 0 || s_wild[c_par] != 0);
+
+				return __ballot(hit) != 0ull;
+			}
+		};
+		if (screen(std::integral_constant<int, 0>{}))
+			epilogue(std::integral_constant<int, 0>{});
 		if constexpr (G::NG > 1)
-			epilogue(std::integral_constant<int, 1>{});
+		{
+			if (screen(std::integral_constant<int, 1>{}))
+				epilogue(std::integral_constant<int, 1>{});
+		}
 		if constexpr (G::NG > 2)
 		{
-			epilogue(std::integral_constant<int, 2>{});
-			epilogue(std::integral_constant<int, 3>{});
+			if (screen(std::integral_constant<int, 2>{}))
+				epilogue(std::integral_constant<int, 2>{});
+			if (screen(std::integral_constant<int, 3>{}))
+				epilogue(std::integral_constant<int, 3>{});
 		}
 		static_assert(G::NG == 1 || G::NG == 2 || G::NG == 4, "groups of row blocks in the epilogue");
 		if constexpr (DBG == 0)

@@ -100,3 +100,69 @@ def test_fp16_subnormal_inputs_are_not_flushed():
     got = _run(A, B, C, 1)
     assert got[0, 0, 0] == np.float32(2.0 ** -24)
     assert got[0, 1, 1] == np.float32(3.0 * 2.0 ** -15)
+
+
+def _run_f32(A, B, C):
+    import torch
+    from neurondb_amd import _lib
+    _lib.ensure_init()
+    dA, dB, dC = (torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda() for x in (A, B, C))
+    dD = torch.zeros_like(dC)
+    _lib.check(_lib.lib().ndbhip_mfma_probe_f32(dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dD.data_ptr(), A.shape[0]))
+    _lib.check(_lib.lib().ndbhip_synchronize())
+    return dD.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "spread", "cancel", "screen_shape"])
+def test_mfma_f32_screen_instruction_stays_inside_its_model(kind):
+    """Pass 0 of the centred sweep (csrc/ndbhip_screen16c.h) lets v_mfma_f32_32x32x2_f32 evaluate the exclusion test and
+    allows each of its two steps an error of 2 u of |C| + |a0 b0| + |a1 b1| (twice what a correctly rounded fma chain
+    costs): 4 u in all.  Checked against float64 (products of two floats are exact there)."""
+    rng = np.random.default_rng(["uniform", "spread", "cancel", "screen_shape"].index(kind))
+    nt = 512
+    A = rng.uniform(-1, 1, (nt, 32, 2))
+    B = rng.uniform(-1, 1, (nt, 2, 32))
+    C = rng.uniform(-1, 1, (nt, 32, 32))
+    if kind == "spread":
+        A *= 2.0 ** rng.integers(-30, 31, A.shape)
+        B *= 2.0 ** rng.integers(-30, 31, B.shape)
+        C *= 2.0 ** rng.integers(-30, 31, C.shape)
+    elif kind == "cancel":
+        C = -(A[:, :, 0:1] * B[:, 0:1, :] + A[:, :, 1:2] * B[:, 1:2, :]) * (1 + rng.uniform(-1e-6, 1e-6, (nt, 32, 32)))
+    elif kind == "screen_shape":
+        # what the sweep feeds it: C = t1 P, a = (-v, -u), b = (w, s) with the terms nearly cancelling
+        A = -np.abs(A) * 2.0 ** rng.integers(0, 40, A.shape)
+        B = np.abs(B) * 2.0 ** rng.integers(-20, 21, B.shape)
+        C = (np.abs(A[:, :, 0:1] * B[:, 0:1, :]) + np.abs(A[:, :, 1:2] * B[:, 1:2, :])) * rng.uniform(0.99, 1.01, (nt, 32, 32))
+    A, B, C = A.astype(np.float32), B.astype(np.float32), C.astype(np.float32)
+    got = _run_f32(A, B, C).astype(np.float64)
+    a, b, c = A.astype(np.float64), B.astype(np.float64), C.astype(np.float64)
+    exact = c + np.einsum("tik,tkj->tij", a, b)
+    mag = np.abs(c) + np.einsum("tik,tkj->tij", np.abs(a), np.abs(b))
+    err = np.abs(got - exact)
+    worst = float(np.max(err / np.maximum(mag, 2.0 ** -120)))
+    assert np.all(err <= 4 * U * mag + 2.0 ** -149), (kind, worst / U)
+    print(f"f32 {kind}: max err / (|C| + sum|ab|) = {worst / U:.2f} u, allowed 4 u")
+
+
+def test_mfma_f32_screen_instruction_and_infinities():
+    """The flags pass 0 plants: w = +inf (a row the tile does not have: never emitted), w = -inf or u = -inf (always
+    emitted); an integer maximum over the results' bit patterns must see the first as negative, the others as not."""
+    A = np.zeros((1, 32, 2), np.float32)
+    B = np.zeros((1, 2, 32), np.float32)
+    C = np.full((1, 32, 32), 3.5, np.float32)
+    A[0, :, 0] = -0.75                                 # -v
+    A[0, :, 1] = -2.0                                  # -u
+    A[0, 5, 1] = np.inf                                # u = -inf: member 5 always emits
+    A[0, 6, 1] = -np.inf                               # u = +inf: member 6 never does
+    B[0, 0, :] = 1.0                                   # w
+    B[0, 1, :] = 1.0                                   # s
+    B[0, 0, 3] = np.inf                                # row 3 is not there
+    B[0, 0, 4] = -np.inf                               # row 4's norm is not a finite fp32
+    got = _run_f32(A, B, C)[0]
+    bits = got.view(np.int32)
+    assert got[0, 0] == np.float32(3.5 - 0.75 - 2.0)
+    assert np.all(got[:, 3][np.arange(32) != 5] == -np.inf) and np.all(bits[:, 3][np.arange(32) != 5] < 0)
+    assert np.all(got[:, 4][np.arange(32) != 6] == np.inf)
+    assert np.all(got[5, :][np.arange(32) != 3] == np.inf) and np.all(got[6, :][np.arange(32) != 4] == -np.inf)
+    assert np.isnan(got[5, 3]) and np.isnan(got[6, 4])      # either verdict is fine there: pass 1 throws both out

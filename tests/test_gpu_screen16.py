@@ -629,3 +629,47 @@ def test_a_few_queries_with_too_many_ties_go_to_the_exact_path_alone(strategy, l
     assert_same_results(t, d, c, et, ed, ec)
     assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
     ix.close()
+
+
+@pytest.mark.parametrize("dim,n,nlists,nq", [(768, 9000, 12, 700), (100, 12000, 7, 300), (33, 5000, 3, 530), (64, 3000, 2, 260)])
+@pytest.mark.parametrize("variant", ["dense pfd=3", "dense pfd=0", "dense pfd=7", "sweep<8,2>"])
+def test_dense_tile_of_the_centred_sweep_matches_the_oracle(dim, n, nlists, nq, variant, lib):
+    """The 256 x 256 tile (csrc/ndbhip_screen16d.h: loader and prefetcher waves, the matrix pipe's own screen of its
+    accumulator blocks) on buckets probed by hundreds of queries: ragged row and pair tiles, exact hits and duplicates,
+    zero rows, a list whose rows sit 2^40 and one whose rows sit 2^-40 from its centre next to ordinary ones
+    (exponents outside the range the screen instruction is proved for: those items must take the per-element test),
+    the candidate cap.  ids, ranks and float4 bits of ivfCollectCandidates (ivf_am.c:1722-1909)."""
+    a = make_ivf_arrays(n, dim, nlists, seed=dim + 5, dup_frac=0.05, zero_rows=2)
+    off = np.zeros(nlists + 1, dtype=np.int64)
+    off[1:] = np.cumsum(a["list_len"])
+    rows = a["rows"]
+    if nlists >= 7:
+        # list 1: every row 2^40 x its offset from the centroid; list 2: 2^-40 x (rows AT the centre, up to rounding)
+        for L, f in ((1, 2.0 ** 40), (2, 2.0 ** -40)):
+            c = a["centroids"][L]
+            rows[off[L]:off[L + 1]] = (c + f * (rows[off[L]:off[L + 1]] - c)).astype(np.float32)
+    ix = _index(a)
+    img = oracle_image(a)
+    rng = np.random.default_rng(dim + 1)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[: nq // 4] = rows[rng.integers(0, n, nq // 4)]
+    q[nq // 4: nq // 2] = (rows[rng.integers(off[nlists - 1], n, nq // 2 - nq // 4)] +
+                           0.01 * rng.standard_normal((nq // 2 - nq // 4, dim))).astype(np.float32)
+    q[-1] = 0.0
+    L = lib.lib()
+    lib.check(L.ndbhip_set_option(b"screen16c_qb", 8))
+    lib.check(L.ndbhip_set_option(b"screen16c_dense", 0 if variant.startswith("sweep") else 1))
+    lib.check(L.ndbhip_set_option(b"screen16c_pfd", int(variant.split("=")[1]) if "pfd" in variant else 0))
+    try:
+        for nprobe, k, cap in ((nlists, 10, 0), (max(1, nlists // 2), 64, 0), (nlists, 10, 100)):
+            lib.check(L.ndbhip_stats_reset())
+            t, d, c = ix.search(q, 1, nprobe, k, cap)
+            st = lib.stats()
+            et, ed, ec, _ = oracle_search_batch(img, q, 1, nprobe, k, cap)
+            assert_same_results(t, d, c, et, ed, ec)
+            assert st["screen16_batches"] + st["screen16_fallbacks"] == 1, st
+    finally:
+        lib.check(L.ndbhip_set_option(b"screen16c_qb", 0))
+        lib.check(L.ndbhip_set_option(b"screen16c_dense", 1))
+        lib.check(L.ndbhip_set_option(b"screen16c_pfd", 0))
+        ix.close()
