@@ -2797,6 +2797,7 @@ static int	g_s16c_epi = 1;		/* 1: the sweep's matrix pipe screens its own accumu
 static int	g_s16c_pf = 0;		/* variants of k_s16c_sweep<8, 2> for A/B: 3 = an in-wave L2 prefetch, 16 / 32 / 48 = non-temporal rows / pairs / both ("screen16c_pf") */
 static int	g_s16c_dense = 1;	/* dense buckets (tile of 256 x 256) run k_s16c_dense (ndbhip_screen16d.h: loader and prefetcher waves); 0: k_s16c_sweep<8, 2> ("screen16c_dense") */
 static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch's first thresholds, 0 = none ("screen16c_sample") */
+static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
@@ -3549,9 +3550,11 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
-							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot)
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight)
 			if (dense_k && g_s16_debug == 6)
 				S16C_DENSE_L(6);
+			else if (dense_k && g_s16_debug == 7)
+				S16C_DENSE_L(7);
 			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4))
 				S16C_DENSE_L(0);
 			else if (dense_k && g_s16_debug == 1)
@@ -3907,6 +3910,12 @@ ndbhip_set_option(const char *name, int value)
 		if (value != 0 && (value < 256 || value > 2048))
 			return fail(NDBHIP_ERR_INVALID, "screen16c_sample must be 0 or 256..2048");
 		g_s16c_sample = value;
+	}
+	else if (!strcmp(name, "screen16c_tight"))
+	{
+		if (value < 8 || value > 1024 || (value & (value - 1)))
+			return fail(NDBHIP_ERR_INVALID, "screen16c_tight must be a power of two, 8..1024");
+		g_s16c_tight = value;
 	}
 	else if (!strcmp(name, "screen16c_rot"))
 		g_s16c_rot = value != 0;

@@ -241,19 +241,28 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 		}
 	}
 
-	for (uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < total; j += nw)
+	/* every wave takes a contiguous run of the pair records: one bisection for the run's first bucket, then the buckets are
+	 * walked along with the records (a bisection per record — ten dependent loads — was most of this kernel's time) */
+	const uint32_t per = (total + nw - 1) / nw;
+	const uint32_t j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * per, j1 = min(total, j0 + per);
+	uint32_t	lo = 0;
+
+	if (j0 < j1)
 	{
-		uint32_t	lo = 0, hi = (uint32_t) nb;
+		uint32_t	hi = (uint32_t) nb;
 
 		while (hi - lo > 1)
 		{
 			const uint32_t mid = (lo + hi) >> 1;
 
-			if (pair_off[mid] <= j)
+			if (pair_off[mid] <= j0)
 				lo = mid;
 			else
 				hi = mid;
 		}
+	}
+	for (uint32_t j = j0; j < j1; j++)
+	{
 		while (lo + 1 < (uint32_t) nb && pair_off[lo + 1] <= j)
 			lo++;
 		const PairRec pr = pairs[j];
@@ -284,6 +293,9 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 			pnrow[j] = lq[pr.p + 1] - lq[pr.p];
 		}
 		ndb_h2	   *out = reinterpret_cast<ndb_h2 *>(qcplanes + (chunk_plane ? (size_t) j * 64 : (size_t) j * dimp));
+		/* (q - c) 2^(14 - e): the scale is a power of two between 2^-126 and 2^127 for every exponent an fp32 vector's norm
+		 * can have, the product exact (below 2^-126 it is flushed: inside the 2^-25 the error model allows an element) */
+		const float sc = ldexpf(1.0f, 14 - e);
 
 		for (int p = lane; p < dimp / 2; p += 64)
 		{
@@ -291,9 +303,9 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 			_Float16	h0 = 0, h1 = 0;
 
 			if (ok && i < dim)
-				h0 = (_Float16) (float) ldexp((double) (q[i] - c[i]), 14 - e);
+				h0 = (_Float16) ((q[i] - c[i]) * sc);
 			if (ok && i + 1 < dim)
-				h1 = (_Float16) (float) ldexp((double) (q[i + 1] - c[i + 1]), 14 - e);
+				h1 = (_Float16) ((q[i + 1] - c[i + 1]) * sc);
 			ndb_h2		h;
 
 			h.x = h0; h.y = h1;
@@ -592,7 +604,30 @@ k_s16c_seed_sample(const float *__restrict__ amat, uint32_t astride, uint32_t ns
 	__syncthreads();
 	const float e = s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*xmax_bits), false);
 	unsigned long long key[PER];
+	int			sl[PER];
+	uint32_t	sp[PER];
+	bool		ok[PER];
 
+#pragma unroll
+	for (int u = 0; u < PER; u++)
+	{
+		const uint32_t i = (uint32_t) tid + 256u * (uint32_t) u;
+
+		sl[u] = i < ns ? slist[i] : -1;
+		sp[u] = i < ns ? spos[i] : 0xFFFFFFFFu;
+		ok[u] = false;
+	}
+	/* (probes outermost: one broadcast read of a probe serves the thread's PER samples; a list can be probed more than
+	 * once — ivf_am.c:1978 —: any probe that sees the row will do) */
+	for (int p = 0; p < npr; p++)
+	{
+		const int	L = s_pl[p];
+		const uint32_t vis = s_vis[p];
+
+#pragma unroll
+		for (int u = 0; u < PER; u++)
+			ok[u] = ok[u] || (sl[u] == L && sp[u] < vis);
+	}
 #pragma unroll
 	for (int u = 0; u < PER; u++)
 	{
@@ -601,21 +636,16 @@ k_s16c_seed_sample(const float *__restrict__ amat, uint32_t astride, uint32_t ns
 		key[u] = ~0ull;
 		if (i < ns)
 		{
-			const int	L = slist[i];
-			const uint32_t pos = spos[i];
-			bool		ok = false;
-
-			/* (a list can be probed more than once — ivf_am.c:1978 —: any probe that sees the row will do) */
-			for (int p = 0; p < npr; p++)
-				ok = ok || (s_pl[p] == L && pos < s_vis[p]);
 			const float ub = s16_up(fmaxf(amat[(size_t) q * astride + i] + e, 0.0f));
 
-			if (ok && ub == ub && ub < 3.0e38f)
+			if (ok[u] && ub == ub && ub < 3.0e38f)
 				key[u] = ((unsigned long long) __float_as_uint(ub) << 32) | i;		/* ub >= 0: the bits order like the values */
 		}
 	}
-	/* the k-th smallest by k rounds of "take the minimum out" (k <= 64, distinct keys) */
-	unsigned long long kth = ~0ull;
+	/* the k-th smallest (k <= 64, distinct keys): every wave takes its own k smallest out one at a time (no barrier), the
+	 * 4 k keys that leaves are ranked by counting */
+	__shared__ unsigned long long s_top[4 * 64];
+	unsigned long long kth;
 
 	for (uint32_t r = 0; r < k; r++)
 	{
@@ -634,21 +664,28 @@ k_s16c_seed_sample(const float *__restrict__ amat, uint32_t astride, uint32_t ns
 			m = o < m ? o : m;
 		}
 		if (lane == 0)
-			s_red[w] = m;
-		__syncthreads();
-		m = s_red[0];
-#pragma unroll
-		for (int j = 1; j < 4; j++)
-			m = s_red[j] < m ? s_red[j] : m;
-		__syncthreads();
-		kth = m;
-		if (m == ~0ull)
-			break;				/* fewer than k candidates in the sample: no threshold from it (uniform) */
+			s_top[w * 64 + r] = m;
 #pragma unroll
 		for (int u = 0; u < PER; u++)
-			if (key[u] == m)
+			if (key[u] == m && m != ~0ull)
 				key[u] = ~0ull;
 	}
+	if (tid == 0)
+		s_red[0] = ~0ull;
+	__syncthreads();
+	{
+		/* thread t < 4 k (<= 256): the rank of its key among the 4 k (keys are distinct but for the "none" value) */
+		const uint32_t nt = 4u * k;
+		const unsigned long long mine = (uint32_t) tid < nt ? s_top[((uint32_t) tid / k) * 64 + ((uint32_t) tid % k)] : ~0ull;
+		uint32_t	rank = 0;
+
+		for (uint32_t o = 0; o < nt; o++)
+			rank += s_top[(o / k) * 64 + (o % k)] < mine ? 1u : 0u;
+		if ((uint32_t) tid < nt && mine != ~0ull && rank == k - 1)
+			s_red[0] = mine;
+	}
+	__syncthreads();
+	kth = s_red[0];			/* "none": fewer than k candidates in the sample, no threshold from it */
 	if (tid == 0 && kth != ~0ull)
 	{
 		const float t = s16c_t_from_ub(__uint_as_float((uint32_t) (kth >> 32)), dim);

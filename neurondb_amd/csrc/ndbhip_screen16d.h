@@ -47,7 +47,8 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			 float *__restrict__ eub, uint32_t ecap, uint32_t *__restrict__ bmin, int nchunk,
 			 uint32_t desc_cap, uint32_t topk, const uint32_t *__restrict__ pos_of, float cE,
 			 uint32_t qc_cap, int cosine, int pfd /* chunks the prefetch runs ahead of the operand stream (0: none) */,
-			 int rot /* 1: an item's chunks start at a rotation given by its row tile (see `enter`) */ )
+			 int rot /* 1: an item's chunks start at a rotation given by its row tile (see `enter`) */,
+			 uint32_t tight /* a query's threshold is tightened every time it has emitted this many more records (a power of two) */ )
 {
 	constexpr int T = S16D_T;
 	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];
@@ -183,7 +184,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	};
 	/* prefetcher: touch the lines of chunk c of its item */
 	auto		touch = [&](uint32_t c) {
-		if constexpr (DBG != 0 && DBG != 6)
+		if constexpr (DBG != 0 && DBG != 6 && DBG != 7)
 			return;
 		s16_dma4(s16_uniform_ptr(sb0 + (size_t) c * 4096), voff_rp, sink_la);
 		s16_dma4(s16_uniform_ptr(sq + (size_t) c * qplane), voff_qp, sink_la);
@@ -372,7 +373,8 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				if (keep)
 				{
 					const uint32_t q = s_qid[c_par][m];
-					uint32_t	slot = atomicAdd(&ecount[q], 1u);
+					/* (DBG 7: timing only — the records without the returning atomic's round trip) */
+					uint32_t	slot = DBG == 7 ? (uint32_t) lane : atomicAdd(&ecount[q], 1u);
 
 					/* (looked at here: a returning atomic still pending at the loop's edge would put the compiler's wait for
 					 * the vector-memory counter into every item's first chunk) */
@@ -393,7 +395,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					if ((ub_bits & 0x7FFFFFFFu) < 0x7F800000u)
 						atomicMin(&bmin[(size_t) q * S16_NB + ((pos * 2654435761u) >> (32 - S16_NB_LOG2))],
 								  ndb_key_from_bits(ub_bits));
-					if ((slot & (S16_TIGHT - 1)) == S16_TIGHT - 1)
+					if ((slot & (tight - 1u)) == tight - 1u)
 					{
 						const uint32_t ti = atomicAdd(&s_tn, 1u);
 
@@ -424,7 +426,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 #pragma unroll
 			for (int reg = 0; reg < 16; reg++)
 				mx = max(mx, __float_as_int(fin[reg]));
-			if constexpr (DBG != 0)
+			if constexpr (DBG != 0 && DBG != 7)
 			{
 				if (mx != 0x12345678)
 					return;

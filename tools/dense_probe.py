@@ -37,7 +37,7 @@ def main():
     ref = None
     variants = sys.argv[1:] or [""]
     defaults = {}
-    default_of = {"screen16c_epi": 1, "screen16c_rot": 0, "screen16c_dense": 1, "screen16c_pfd": 0, "screen16c_sample": 2048}
+    default_of = {"screen16c_epi": 1, "screen16c_rot": 0, "screen16c_dense": 1, "screen16c_pfd": 0, "screen16c_sample": 2048, "screen16c_tight": 128}
     for v in variants:
         opts = dict(kv.split("=") for kv in v.split(",") if kv)
         for k in list(defaults):
