@@ -105,6 +105,8 @@ typedef struct ndbhip_stats
 	uint64_t	prepares;			/* full layouts of the sweep's operands (planes, sublists, radii): once per mirror unless ... */
 	uint64_t	prepare_updates;	/* ... appends / deletes were folded into the existing layout instead (rows added in spare blocks,
 									 * deleted rows left as holes and the survivors renumbered) */
+	uint64_t	dense_sweeps;		/* sweeps that ran the dense tile's kernel (256 pairs x 256 rows: buckets probed by hundreds of
+									 * queries — a table without cluster structure; csrc/ndbhip_screen16d.h) */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);

@@ -3551,6 +3551,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight)
+			if (dense_k)
+				g.stats.dense_sweeps++;
 			if (dense_k && g_s16_debug == 6)
 				S16C_DENSE_L(6);
 			else if (dense_k && g_s16_debug == 7)

@@ -348,3 +348,47 @@ def test_c4_c5_single_gpu_share_properties(cfg):
     assert np.array_equal(buf.out_dist.cpu().numpy().view(np.uint32), dist.view(np.uint32)), cfg
     assert np.array_equal(buf.out_count.cpu().numpy(), cnt), cfg
     ix.close()
+
+
+def test_c2_on_the_iid_table_at_full_size():
+    """BASELINE.md's own C2 data — i.i.d. N(0,1) rows — at full size: the reference's build rule (k-means on the first
+    10 000 rows, ivf_am.c:580) leaves most rows in a few dozen lists there, a query's 32 probes cover four fifths of the table, and
+    from the second batch on the sweep runs the dense tile's kernel (csrc/ndbhip_screen16d.h; asserted from the
+    statistics).  16 queries replayed in full by the CPU oracle on the exported index (ids, ranks, float4 bits), the
+    batch's properties, and independence of the batch a query travels in."""
+    from concurrent.futures import ThreadPoolExecutor
+    from neurondb_amd import IvfIndex, _lib
+    dev = torch.device("cuda", 0)
+    _lib.ensure_init(0)
+    base = make_data(N, DIM, "gauss", 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
+    q = make_data(4096, DIM, "gauss", 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    ix = IvfIndex(DIM, LISTS)
+    ix.build_device(base, pack_tids(torch.arange(N, device=dev)), 50)
+    del base
+    try:
+        _search(ix, q)                                        # the first batch measures the pairs per bucket
+        _lib.check(_lib.lib().ndbhip_stats_reset())
+        rows, dist, cnt = _search(ix, q)
+        st = _lib.stats()
+        assert st["dense_sweeps"] == 1 and st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
+        assert (cnt == K).all() and (np.diff(dist, axis=1) >= 0).all()
+        assert all(len(set(r.tolist())) == K for r in rows[:512])
+        # the batch a query travels in does not matter (other tiles, other thresholds, the exact path for one query)
+        for lo, n in ((3, 1), (100, 40), (1000, 700)):
+            r, d, c = _search(ix, q[lo:lo + n])
+            assert np.array_equal(r, rows[lo:lo + n]) and np.array_equal(d.view(np.uint32), dist[lo:lo + n].view(np.uint32))
+        cent, list_len, rows_h, tid_h = ix.export(rows=True)
+        off = np.zeros(LISTS + 1, np.int64)
+        off[1:] = np.cumsum(list_len)
+        assert np.sort(list_len)[-64:].sum() > 0.5 * N        # the degenerate index the reference's rule builds here
+        img = ndbo.IvfImage(cent, off, rows_h, np.ascontiguousarray(tid_h).view(ndbo.TID_DTYPE).reshape(-1))
+        pick = list(range(0, 4096, 256))                      # 16 queries
+        qh = q.cpu().numpy()
+        ndbo.lib()
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            res = list(ex.map(lambda i: img.search(qh[i], 1, PROBES, K, 0), pick))
+        for i, (et, ed, _) in zip(pick, res):
+            er = (((et["bi_hi"].astype(np.int64) << 16) | et["bi_lo"]) * 64 + et["posid"] - 1)
+            assert np.array_equal(er, rows[i]) and np.array_equal(ed.view(np.uint32), dist[i].view(np.uint32)), i
+    finally:
+        ix.close()
