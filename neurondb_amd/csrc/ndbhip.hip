@@ -3920,7 +3920,11 @@ ndbhip_set_option(const char *name, int value)
 		g_s16c_tight = value;
 	}
 	else if (!strcmp(name, "screen16c_rot"))
-		g_s16c_rot = value != 0;
+	{
+		if (value < 0 || value > 2)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_rot must be 0, 1 or 2");
+		g_s16c_rot = value;
+	}
 	else if (!strcmp(name, "screen16c_dense"))
 		g_s16c_dense = value != 0;
 	else if (!strcmp(name, "screen16c_pfd"))

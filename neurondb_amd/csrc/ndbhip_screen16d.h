@@ -130,7 +130,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		 * start rotated by the row tile (the 4 blocks that share a pair tile have 4 consecutive row tiles), a pair line is
 		 * touched every nchunk / 4 steps: it stays, and what the cache drops is the rows' dead lines.
 		 */
-		f_rot = rot ? ((d.t2 & 3u) * (uint32_t) nchunk) >> 2 : 0u;
+		f_rot = rot == 1 ? ((d.t2 & 3u) * (uint32_t) nchunk) >> 2 : (rot == 2 ? ((d.qt & 7u) * (uint32_t) nchunk) >> 3 : 0u);
 		sb0 = planes + ((size_t) blk_off[L] + b0) * (size_t) nchunk * 4096;
 		if (!loader)
 		{
