@@ -104,7 +104,8 @@ int			ndb_client_meta_nprobe(const ndb_client *c);	/* the served index's own npr
 typedef struct ndb_gen ndb_gen;
 int			ndb_gen_attach(const char *name, int ncells, ndb_gen **out);
 int			ndb_gen_detach(ndb_gen *g, const char *unlink_name);	/* unlink_name != NULL also removes the segment */
-uint64_t	ndb_gen_get(ndb_gen *g, uint64_t key);		/* >= 1; 0 for key 0 / NULL */
+uint64_t	ndb_gen_get(ndb_gen *g, uint64_t key);		/* >= 1; 0 = unknown (key 0, no table, or no cell for the key in a FULL
+													 * table): the caller reloads for every scan and never treats 0 as a match */
 uint64_t	ndb_gen_bump(ndb_gen *g, uint64_t key);	/* the new generation; 0 = table full */
 
 #ifdef __cplusplus

@@ -27,6 +27,14 @@ extern "C" int ndbhip_internal_fail(int code, const char *fmt, ...);
 namespace
 {
 enum : uint32_t { S_FREE = 0, S_CLAIMED = 1, S_READY = 2, S_RUNNING = 3, S_DONE = 4 };
+/* A slot's state word is (pid of the backend that holds it << 3) | state, 0 = free.  Every transition is a compare-
+ * and-swap (or a store by whoever owns the slot in that state) on the WHOLE word, so that nobody can act on a slot
+ * that has changed hands since it was looked at: a backend whose half-filled slot was taken back (its pid looked dead,
+ * or it was slow) fails to publish it and claims another, instead of publishing into a slot a third backend has
+ * claimed meanwhile; the owner's once-a-second sweep frees exactly the holder it examined. */
+inline uint32_t st_of(uint32_t w) { return w & 7u; }
+inline int32_t pid_of(uint32_t w) { return (int32_t) (w >> 3); }
+inline uint32_t word_of(int32_t pid, uint32_t st) { return ((uint32_t) pid << 3) | st; }
 const uint32_t MAGIC = 0x4E445356u;		/* "NDSV" */
 
 struct Header
@@ -226,13 +234,16 @@ reclaim_slots(ndb_service *s)
 	for (uint32_t i = 0; i < h->nslots; i++)
 	{
 		Slot	   *sl = s->m.slot(i);
-		uint32_t	st = sl->state.load(std::memory_order_acquire);
+		uint32_t	w = sl->state.load(std::memory_order_acquire);
+		const uint32_t st = st_of(w);
 
 		if (st != S_CLAIMED && st != S_DONE && st != S_READY)
 			continue;
-		if (!(pid_gone(sl->client_pid) || (st == S_DONE && t - sl->t_ms > 60000)))
+		/* (t_ms of a DONE slot is the owner's own stamp; a CLAIMED slot's holder is judged by its pid alone — the pid
+		 * is part of the word, so it is the holder's, not a predecessor's) */
+		if (!(pid_gone(pid_of(w)) || (st == S_DONE && t - sl->t_ms > 60000)))
 			continue;
-		if (sl->state.compare_exchange_strong(st, S_FREE, std::memory_order_acq_rel))
+		if (sl->state.compare_exchange_strong(w, S_FREE, std::memory_order_acq_rel))
 			n++;
 	}
 	return n;
@@ -280,14 +291,16 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 		for (uint32_t i = 0; i < h->nslots; i++)
 		{
 			Slot	   *sl = s->m.slot(i);
-			uint32_t	st = S_READY;
+			uint32_t	w = sl->state.load(std::memory_order_acquire);
 
-			if (sl->state.load(std::memory_order_acquire) != S_READY || (sl->index_key == skey && sl->index_version == sver))
+			/* (generation 0 of a named index = its backend could not learn the generation, ndb_gen_get: never served) */
+			if (st_of(w) != S_READY || (sl->index_key == skey && sl->index_version == sver && !(sl->index_key != 0 && sl->index_version == 0)))
 				continue;
 			const uint64_t want = sl->index_version;
 			const bool	same_key = sl->index_key == skey;
+			const int32_t holder = pid_of(w);
 
-			if (!sl->state.compare_exchange_strong(st, S_RUNNING, std::memory_order_acq_rel))
+			if (!sl->state.compare_exchange_strong(w, word_of(holder, S_RUNNING), std::memory_order_acq_rel))
 				continue;
 			if (same_key)
 			{
@@ -299,7 +312,7 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 			sl->status = NDBHIP_ERR_NODEVICE;
 			sl->count = 0;
 			sl->t_ms = now_ms();
-			sl->state.store(S_DONE, std::memory_order_release);
+			sl->state.store(word_of(holder, S_DONE), std::memory_order_release);
 			futex(&sl->state, FUTEX_WAKE, 1 << 30, nullptr);
 		}
 		/* oldest first: a backend must not starve behind newer arrivals with another parameter set */
@@ -312,7 +325,7 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 			{
 				Slot	   *sl = s->m.slot(i);
 
-				if (sl->state.load(std::memory_order_acquire) == S_READY && sl->seq < best)
+				if (st_of(sl->state.load(std::memory_order_acquire)) == S_READY && sl->seq < best)
 				{
 					best = sl->seq;
 					bi = (int) i;
@@ -332,13 +345,13 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 			for (uint32_t i = 0; i < h->nslots && n < max_batch; i++)
 			{
 				Slot	   *sl = s->m.slot(i);
-				uint32_t	st = S_READY;
+				uint32_t	w = sl->state.load(std::memory_order_acquire);
 
-				if (sl->state.load(std::memory_order_acquire) != S_READY)
+				if (st_of(w) != S_READY)
 					continue;
 				if (sl->strategy != *strategy || sl->nprobe != *nprobe || sl->k != *k || sl->max_candidates != *max_candidates)
 					continue;
-				if (!sl->state.compare_exchange_strong(st, S_RUNNING, std::memory_order_acq_rel))
+				if (!sl->state.compare_exchange_strong(w, word_of(pid_of(w), S_RUNNING), std::memory_order_acq_rel))
 					continue;
 				memcpy(queries + (size_t) n * h->dim, s->m.query(sl), (size_t) h->dim * 4);
 				slot_ids[n++] = (int) i;
@@ -393,7 +406,8 @@ ndb_service_complete(ndb_service *s, int n, const int *slot_ids, const uint8_t *
 			memcpy(s->m.tids(sl), tids6 + (size_t) i * k * 6, (size_t) c * 6);
 		}
 		sl->t_ms = now_ms();
-		sl->state.store(S_DONE, std::memory_order_release);
+		/* (RUNNING slots are the owner's: the holder's pid stays in the word) */
+		sl->state.store(word_of(pid_of(sl->state.load(std::memory_order_relaxed)), S_DONE), std::memory_order_release);
 		futex(&sl->state, FUTEX_WAKE, 1 << 30, nullptr);
 	}
 	return NDBHIP_OK;
@@ -575,9 +589,10 @@ ndb_client_submit_index(ndb_client *c, uint64_t index_key, uint64_t index_versio
 			const uint32_t i = (start + j) % h->nslots;
 			Slot	   *sl = c->m.slot(i);
 			uint32_t	st = S_FREE;
+			const int32_t me = (int32_t) getpid();
 
 			if (sl->state.load(std::memory_order_relaxed) != S_FREE ||
-				!sl->state.compare_exchange_strong(st, S_CLAIMED, std::memory_order_acq_rel))
+				!sl->state.compare_exchange_strong(st, word_of(me, S_CLAIMED), std::memory_order_acq_rel))
 				continue;
 			memcpy(c->m.query(sl), query, (size_t) h->dim * 4);
 			sl->strategy = strategy;
@@ -591,7 +606,14 @@ ndb_client_submit_index(ndb_client *c, uint64_t index_key, uint64_t index_versio
 			sl->status = 0;
 			sl->count = 0;
 			sl->seq = h->seq.fetch_add(1, std::memory_order_relaxed);
-			sl->state.store(S_READY, std::memory_order_release);
+			{
+				/* published only if the slot is still this backend's claim: the owner may have taken it back (this
+				 * process looked dead to it, e.g. across a pid namespace) and somebody else may hold it now */
+				uint32_t	mine = word_of(me, S_CLAIMED);
+
+				if (!sl->state.compare_exchange_strong(mine, word_of(me, S_READY), std::memory_order_acq_rel))
+					continue;
+			}
 			h->submitted.fetch_add(1, std::memory_order_release);
 			futex(&h->submitted, FUTEX_WAKE, 1, nullptr);
 			*ticket = (int) i;
@@ -615,8 +637,11 @@ ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *cou
 
 	for (int spins = 0;; spins++)
 	{
-		const uint32_t st = sl->state.load(std::memory_order_acquire);
+		const uint32_t w = sl->state.load(std::memory_order_acquire);
+		const uint32_t st = st_of(w);
 
+		if (pid_of(w) != (int32_t) getpid() && w != S_FREE)
+			return ndbhip_internal_fail(NDBHIP_ERR_STATE, "ticket %d belongs to another backend now", ticket);
 		if (st == S_DONE)
 			break;
 		if (st != S_READY && st != S_RUNNING)
@@ -626,7 +651,7 @@ ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *cou
 		if ((timeout_ms >= 0 && waited >= timeout_ms) || (h->stop.load() && st == S_READY))
 		{
 			/* give the slot back only if the owner has not taken it; a RUNNING slot is the owner's */
-			uint32_t	exp = S_READY;
+			uint32_t	exp = word_of((int32_t) getpid(), S_READY);
 
 			if (sl->state.compare_exchange_strong(exp, S_FREE))
 				return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service did not answer");
@@ -636,7 +661,7 @@ ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *cou
 		if ((spins & 63) == 63 && pid_gone(h->owner_pid.load()))
 		{
 			/* the owner was killed: nobody will finish (or reclaim) this slot; a new owner starts from a fresh segment */
-			uint32_t	exp = st;
+			uint32_t	exp = w;
 
 			(void) sl->state.compare_exchange_strong(exp, S_FREE);
 			return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service's process is gone");
@@ -645,7 +670,7 @@ ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *cou
 			continue;			/* a batch returns within a fraction of a millisecond: spin first */
 		struct timespec ts = {0, 2 * 1000 * 1000};
 
-		futex(&sl->state, FUTEX_WAIT, st, &ts);
+		futex(&sl->state, FUTEX_WAIT, w, &ts);
 	}
 	const int	rc = sl->status;
 	const int	n = sl->count;
@@ -658,7 +683,14 @@ ndb_client_wait(ndb_client *c, int ticket, uint8_t *tids6, float *dist, int *cou
 		if (tids6)
 			memcpy(tids6, c->m.tids(sl), (size_t) n * 6);
 	}
-	sl->state.store(S_FREE, std::memory_order_release);
+	{
+		/* given back only if it is still this backend's finished request: the owner takes DONE slots back after a minute
+		 * (a backend stopped in a debugger, say), and then what was copied above may be somebody else's */
+		uint32_t	mine = word_of((int32_t) getpid(), S_DONE);
+
+		if (!sl->state.compare_exchange_strong(mine, S_FREE, std::memory_order_acq_rel))
+			return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "the device service took ticket %d back before its answer was read", ticket);
+	}
 	if (rc)
 		return ndbhip_internal_fail(rc, "the device service reported error %d for this query", rc);
 	return NDBHIP_OK;
@@ -811,9 +843,13 @@ ndb_gen_detach(ndb_gen *g, const char *unlink_name)
 	return NDBHIP_OK;
 }
 
+/* the cell of `key`; NULL when it has none — *full says whether that is because the table has no empty cell left (the
+ * key may have been changed without anybody being able to count it) */
 static GenCell *
-gen_cell(ndb_gen *g, uint64_t key, bool create)
+gen_cell(ndb_gen *g, uint64_t key, bool create, bool *full = nullptr)
 {
+	if (full)
+		*full = false;
 	const uint32_t mask = g->h->ncells - 1;
 	uint64_t	x = key * 0x9E3779B97F4A7C15ull;
 	uint32_t	i = (uint32_t) (x >> 32) & mask;
@@ -833,19 +869,25 @@ gen_cell(ndb_gen *g, uint64_t key, bool create)
 				return c;
 		}
 	}
+	if (full)
+		*full = true;
 	return nullptr;
 }
 
 /* generation of `key` (an index's relfilenode / OID, != 0); 1 for an index nobody has changed since the table
- * was created */
+ * was created; 0 = UNKNOWN — no table, or the key has no cell and the table is full, so its changes could not be
+ * counted: a caller must treat every mirror of it as stale (reload for every scan), never compare 0 with 0 */
 extern "C" uint64_t
 ndb_gen_get(ndb_gen *g, uint64_t key)
 {
 	if (!g || key == 0)
 		return 0;
-	GenCell    *c = gen_cell(g, key, false);
+	bool		full = false;
+	GenCell    *c = gen_cell(g, key, false, &full);
 
-	return c ? c->gen.load(std::memory_order_acquire) + 1 : 1;
+	if (c)
+		return c->gen.load(std::memory_order_acquire) + 1;
+	return full ? 0 : 1;
 }
 
 /* one more change to `key`: returns the new generation (0: the table is full — callers then treat every scan

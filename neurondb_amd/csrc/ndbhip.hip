@@ -3157,6 +3157,35 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* seeds by the exact-arithmetic kernels (k_s16_seed / k_s16_seed_sub with the centred thresholds) instead of
 	 * k_s16c_seed, which reads float4 rows: cosine (the reference's cosine values), fp16 mirrors */
 	const bool	xseed = cosb || (cen && ix->f16);
+	/* A sharded search exchanges thresholds between the seeds and the sweep (g_thr_hook): a collective.  A rank that
+	 * fails before it gets there (an allocation, the preparation) must still take part — with +inf, the identity of the
+	 * minimum — or its peers wait for it forever; it reports its error afterwards. */
+	struct ThrJoin
+	{
+		ndbhip_ivf *ix; int nq; bool done;
+		~ThrJoin()
+		{
+			if (done || !g_thr_hook)
+				return;
+			float	   *buf = nullptr;
+			bool		own = false;
+
+			if (ix->w_qthr && ix->w_qthr_n >= (size_t) nq)
+				buf = (float *) ix->w_qthr;
+			else if (hipMalloc((void **) &buf, (size_t) 2 * nq * sizeof(float)) == hipSuccess)
+				own = true;
+			if (buf)
+			{
+				(void) hipMemsetD32Async((hipDeviceptr_t) buf, 0x7F800000, (size_t) 2 * nq, g.stream);
+				(void) g_thr_hook(buf, (size_t) 2 * nq);
+				if (own)
+				{
+					(void) hipStreamSynchronize(g.stream);
+					(void) hipFree(buf);
+				}
+			}
+		}
+	} thr_join = {ix, nq, false};
 	{
 		const int	rc = ivf_s16_prepare(ix, R);
 
@@ -3248,6 +3277,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	if (g_thr_hook && !seed_by_sublist)
 	{
 		/* sharded search: the smallest threshold any rank found for a query serves all of them */
+		thr_join.done = true;
 		const int	rc = ivf_exchange_thresholds(ix->w_qthr, nq);
 
 		if (rc)
@@ -3451,6 +3481,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				}
 				if (g_thr_hook)
 				{
+					thr_join.done = true;
 					const int	rc2 = ivf_exchange_thresholds(ix->w_qthr, nq);
 
 					if (rc2)

@@ -398,31 +398,40 @@ ndbhip_comm_allreduce_min_f32(float *d_buf, size_t n)
 		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "all-reduce of %zu bytes exceeds the segment's slots (%zu)", bytes,
 									comm.slot_bytes);
 	float	   *mine = (float *) (comm.slots + (size_t) comm.rank * comm.slot_bytes);
+	/* A collective: whatever goes wrong on this rank, it passes BOTH barriers — its peers are waiting in them — and
+	 * reports afterwards.  So everything that can fail is done before the first barrier, and a rank that could not
+	 * produce its slot contributes +inf (the identity of min: the others' bound stands). */
+	float	   *red = (float *) malloc(bytes);
+	bool		ok = red != nullptr;
 
 	if (hipMemcpyAsync(mine, d_buf, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
 		hipStreamSynchronize(stream) != hipSuccess)
-		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "device-to-host copy failed");
-	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot is written */
-	float	   *red = (float *) malloc(bytes);
-
-	if (!red)
-		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
-	memcpy(red, comm.slots, bytes);
-	for (int r = 1; r < comm.world; r++)
 	{
-		const float *o = (const float *) (comm.slots + (size_t) r * comm.slot_bytes);
-
+		ok = false;
 		for (size_t i = 0; i < n; i++)
-			if (o[i] < red[i])
-				red[i] = o[i];
+			mine[i] = __builtin_inff();
+	}
+	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot is written */
+	if (red)
+	{
+		memcpy(red, comm.slots, bytes);
+		for (int r = 1; r < comm.world; r++)
+		{
+			const float *o = (const float *) (comm.slots + (size_t) r * comm.slot_bytes);
+
+			for (size_t i = 0; i < n; i++)
+				if (o[i] < red[i])
+					red[i] = o[i];
+		}
 	}
 	pthread_barrier_wait(&comm.hdr->barrier);		/* every slot has been read: it may be overwritten */
-	const bool	ok = hipMemcpyAsync(d_buf, red, bytes, hipMemcpyHostToDevice, stream) == hipSuccess &&
+	if (!red)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	ok = ok && hipMemcpyAsync(d_buf, red, bytes, hipMemcpyHostToDevice, stream) == hipSuccess &&
 		hipStreamSynchronize(stream) == hipSuccess;
-
 	free(red);
 	if (!ok)
-		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "host-to-device copy failed");
+		return ndbhip_internal_fail(NDBHIP_ERR_HIP, "a copy between the device and the exchange segment failed");
 	return NDBHIP_OK;
 }
 

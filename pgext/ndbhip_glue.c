@@ -86,6 +86,9 @@ ndbhip_define_gucs(void)
 							NULL, assign_hnsw_k, NULL);
 	DefineCustomBoolVariable("neurondb.ref_compat", "keep the reference's quirks (k = 10, candidate cap k * 10, L2 for "
 							 "every opclass)", NULL, &guc_ref_compat, false, PGC_USERSET, 0, NULL, assign_ref_compat, NULL);
+	DefineCustomIntVariable("neurondb.generation_cells", "indexes the cluster-wide generation table can hold (a power of two; "
+							"read when the first backend creates the table)", NULL, &guc_gen_cells, 65536, 1024, 1 << 24,
+							PGC_POSTMASTER, 0, NULL, NULL, NULL);
 	DefineCustomStringVariable("neurondb.device_service", "shared-memory name of the device-owner process "
 							   "(include/ndb_service.h); empty = this backend drives the device itself", NULL,
 							   &guc_device_service, "", PGC_SUSET, 0, NULL, assign_device_service, NULL);
@@ -117,13 +120,90 @@ ndb_hip_ready(void)
 typedef struct MirrorEntry
 {
 	Oid			relid;
-	uint64		stamp;			/* the index's generation (ivf_stamp) when the pages were read */
+	uint64		key;			/* (database, relfilenumber) of the file the pages were read from: index_key() */
+	uint64		stamp;			/* that key's generation (ivf_stamp) when the pages were read; 0 = unknown, never fresh */
 	ndbhip_ivf *ivf;
 	ndbhip_hnsw *hnsw;
+	int			pins;			/* open scans of this backend that hold `ivf` / `hnsw` (ndb_hip_mirror_pin / _unpin) */
 } MirrorEntry;
 
 #define NDB_MAX_MIRRORS 32
 static MirrorEntry mirrors[NDB_MAX_MIRRORS];
+
+/* mirrors that went stale while a scan node of this backend still held them (two kNN scan nodes on one index with a
+ * lateral rescan, and an insert from anywhere in between): destroyed when their last scan ends */
+typedef struct Retired
+{
+	ndbhip_ivf *ivf;
+	ndbhip_hnsw *hnsw;
+	int			pins;
+} Retired;
+static Retired retired[NDB_MAX_MIRRORS];
+
+static uint64 index_key(Relation index);
+
+static void
+mirror_drop(MirrorEntry *e)
+{
+	if (e->pins > 0 && (e->ivf || e->hnsw))
+	{
+		for (int i = 0; i < NDB_MAX_MIRRORS; i++)
+			if (!retired[i].ivf && !retired[i].hnsw)
+			{
+				retired[i].ivf = e->ivf;
+				retired[i].hnsw = e->hnsw;
+				retired[i].pins = e->pins;
+				e->ivf = NULL;
+				e->hnsw = NULL;
+				e->pins = 0;
+				return;
+			}
+		ereport(ERROR, (errmsg("neurondb: too many stale device mirrors still held by open scans")));
+	}
+	if (e->ivf) ndbhip_ivf_destroy(e->ivf);
+	if (e->hnsw) ndbhip_hnsw_destroy(e->hnsw);
+	e->ivf = NULL;
+	e->hnsw = NULL;
+	e->pins = 0;
+}
+
+/* ambeginscan / amendscan: a scan holds the raw mirror pointer from its first rescan to its end */
+void
+ndb_hip_mirror_pin(const void *mirror)
+{
+	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
+		if (mirror && ((const void *) mirrors[i].ivf == mirror || (const void *) mirrors[i].hnsw == mirror))
+		{
+			mirrors[i].pins++;
+			return;
+		}
+}
+
+void
+ndb_hip_mirror_unpin(const void *mirror)
+{
+	if (!mirror)
+		return;
+	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
+	{
+		if ((const void *) mirrors[i].ivf == mirror || (const void *) mirrors[i].hnsw == mirror)
+		{
+			if (mirrors[i].pins > 0)
+				mirrors[i].pins--;
+			return;
+		}
+		if ((const void *) retired[i].ivf == mirror || (const void *) retired[i].hnsw == mirror)
+		{
+			if (--retired[i].pins <= 0)
+			{
+				if (retired[i].ivf) ndbhip_ivf_destroy(retired[i].ivf);
+				if (retired[i].hnsw) ndbhip_hnsw_destroy(retired[i].hnsw);
+				memset(&retired[i], 0, sizeof(retired[i]));
+			}
+			return;
+		}
+	}
+}
 
 static void
 mirror_reset(void *arg)			/* MemoryContextCallback on CacheMemoryContext: ERROR unwinds by longjmp */
@@ -133,6 +213,9 @@ mirror_reset(void *arg)			/* MemoryContextCallback on CacheMemoryContext: ERROR 
 		if (mirrors[i].ivf) ndbhip_ivf_destroy(mirrors[i].ivf);
 		if (mirrors[i].hnsw) ndbhip_hnsw_destroy(mirrors[i].hnsw);
 		memset(&mirrors[i], 0, sizeof(mirrors[i]));
+		if (retired[i].ivf) ndbhip_ivf_destroy(retired[i].ivf);
+		if (retired[i].hnsw) ndbhip_hnsw_destroy(retired[i].hnsw);
+		memset(&retired[i], 0, sizeof(retired[i]));
 	}
 }
 
@@ -160,6 +243,7 @@ mirror_slot(Relation index, uint64 stamp)
 {
 	static bool registered = false;
 	MirrorEntry *free_slot = NULL;
+	const uint64 key = index_key(index);
 
 	if (!registered)
 	{
@@ -174,12 +258,13 @@ mirror_slot(Relation index, uint64 stamp)
 	{
 		if (mirrors[i].relid == RelationGetRelid(index))
 		{
-			if (mirrors[i].stamp != stamp)
+			/* fresh only for the SAME file at the SAME generation: a new relfilenode (TRUNCATE, VACUUM FULL, CLUSTER,
+			 * REINDEX) starts its own counter at 1 again, so the stamp alone would keep the old file's mirror — and its
+			 * heap TIDs — alive.  Generation 0 = the counter table could not say (full, or not attachable): never fresh. */
+			if (mirrors[i].key != key || mirrors[i].stamp != stamp || stamp == 0)
 			{
-				if (mirrors[i].ivf) ndbhip_ivf_destroy(mirrors[i].ivf);
-				if (mirrors[i].hnsw) ndbhip_hnsw_destroy(mirrors[i].hnsw);
-				mirrors[i].ivf = NULL;
-				mirrors[i].hnsw = NULL;
+				mirror_drop(&mirrors[i]);
+				mirrors[i].key = key;
 				mirrors[i].stamp = stamp;
 			}
 			return &mirrors[i];
@@ -190,6 +275,7 @@ mirror_slot(Relation index, uint64 stamp)
 	if (!free_slot)
 		ereport(ERROR, (errmsg("neurondb: more than %d device-mirrored indexes in one backend", NDB_MAX_MIRRORS)));
 	free_slot->relid = RelationGetRelid(index);
+	free_slot->key = key;
 	free_slot->stamp = stamp;
 	return free_slot;
 }
@@ -252,6 +338,7 @@ guc_device_service_set(void)
  * every mirror of the old file is stale by key.
  */
 static ndb_gen *gen_table = NULL;
+static int	guc_gen_cells = 65536;		/* neurondb.generation_cells: indexes (relfilenodes) the counter table can hold */
 
 static uint64
 index_key(Relation index)
@@ -267,8 +354,17 @@ generations(void)
 		char		name[64];
 
 		snprintf(name, sizeof(name), "/ndbhip_gen_%d", PostPortNumber);
-		if (ndb_gen_attach(name, 4096, &gen_table) != NDBHIP_OK)
-			ereport(ERROR, (errmsg("neurondb: %s", ndbhip_last_error())));
+		/* never an ERROR: this runs inside aminsert and ambulkdelete of backends that may not use the accelerator at
+		 * all.  Without the table every stamp is 0 = "unknown": mirrors are rebuilt for every scan, nothing is stale. */
+		if (ndb_gen_attach(name, guc_gen_cells, &gen_table) != NDBHIP_OK)
+		{
+			static bool warned = false;
+
+			if (!warned)
+				ereport(WARNING, (errmsg("neurondb: %s; device mirrors will be rebuilt for every scan", ndbhip_last_error())));
+			warned = true;
+			gen_table = NULL;
+		}
 	}
 	return gen_table;
 }
@@ -276,6 +372,7 @@ generations(void)
 uint64
 ivf_stamp(Relation index)
 {
+	/* (ndb_gen_get: 0 for a NULL table, and 0 for a key that has no cell in a table that is full) */
 	return ndb_gen_get(generations(), index_key(index));
 }
 
@@ -299,14 +396,11 @@ ndb_hip_ivf_note_insert(Relation index, int list_id, const float *vec, ItemPoint
 		{
 			/* this backend's own mirror follows along — only if nobody else changed the index in between
 			 * (gen is exactly one past the generation the mirror holds) and the append itself worked */
-			if (gen == mirrors[i].stamp + 1 &&
+			if (gen != 0 && gen == mirrors[i].stamp + 1 && mirrors[i].key == index_key(index) &&
 				ndbhip_ivf_append(mirrors[i].ivf, list_id, vec, (const uint8_t *) heap_tid) == NDBHIP_OK)
 				mirrors[i].stamp = gen;
 			else
-			{
-				ndbhip_ivf_destroy(mirrors[i].ivf);		/* out of step: rebuild on the next scan */
-				mirrors[i].ivf = NULL;
-			}
+				mirror_drop(&mirrors[i]);		/* out of step: rebuild on the next scan (an open scan keeps its copy until it ends) */
 		}
 }
 
@@ -319,8 +413,7 @@ ndb_hip_ivf_note_delete(Relation index)
 	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
 		if (mirrors[i].relid == RelationGetRelid(index))
 		{
-			if (mirrors[i].ivf) ndbhip_ivf_destroy(mirrors[i].ivf);
-			if (mirrors[i].hnsw) ndbhip_hnsw_destroy(mirrors[i].hnsw);
+			mirror_drop(&mirrors[i]);
 			memset(&mirrors[i], 0, sizeof(mirrors[i]));
 		}
 }

@@ -316,6 +316,12 @@ def test_index_generations_only_grow_and_are_shared_between_processes():
         # a table that fills up says so instead of aliasing two indexes
         full = [L.ndb_gen_bump(g, 10_000 + i) for i in range(80)]
         assert full.count(0) >= 80 - 64 + 3 and all(v in (0, 2) for v in full)
+        # ... and an index it could not take is of UNKNOWN generation (0: "reload for every scan"), not of generation 1 —
+        # its changes can no longer be counted, so a mirror stamped 1 must never look fresh again; the indexes that got a
+        # cell keep counting
+        lost = [10_000 + i for i, v in enumerate(full) if v == 0]
+        assert all(L.ndb_gen_get(g, k) == 0 for k in lost)
+        assert L.ndb_gen_get(g, 777) == 3 and L.ndb_gen_bump(g, 777) == 4
     finally:
         L.ndb_gen_detach(g, name.encode())
 
