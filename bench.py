@@ -515,6 +515,7 @@ def main():
 
         # ---------------- CPU baseline: the oracle on the host cores (bounded sample) ----------------
         if args.cpu_seconds > 0 and world == 1:
+            trace("cpu_baseline")
             cpu_baseline = run_cpu_baseline(args, cent_h, list_len, rows_h, tids_h, qs, out_t, out_d, out_c)
 
     dist_parity = None
@@ -569,12 +570,14 @@ def main():
             ix.close()
             ix = None
             torch.cuda.empty_cache()
+            trace("iid_gauss leg")
             gauss = gauss_leg(args, dev, steps=args.gauss_steps)
         except Exception as e:
             gauss = {"error": f"{type(e).__name__}: {e}"}
         if args.components == args.lists:
             try:
                 torch.cuda.empty_cache()
+                trace("balanced_index leg")
                 balanced = gauss_leg(args, dev, steps=args.gauss_steps, kind="balanced")
             except Exception as e:
                 balanced = {"error": f"{type(e).__name__}: {e}"}
@@ -582,6 +585,7 @@ def main():
     hnsw = None
     if rank == 0 and world == 1 and args.hnsw_nvec > 0:
         try:
+            trace("hnsw leg (ref_compat)")
             hnsw = hnsw_leg(args, dev)
         except Exception as e:                      # the IVF line must not depend on this leg
             hnsw = {"error": f"{type(e).__name__}: {e}"}
@@ -619,6 +623,10 @@ def main():
                                       (None if not gauss or "queries_per_s" not in gauss else
                                        f"{gauss['queries_per_s']:.0f} queries/s, recall@10 {gauss['recall_at_10']}")}},
             "recall_at_10": None if recall is None else round(recall, 4),
+            # the same step on BASELINE.md's own data (i.i.d. N(0,1) rows; the whole leg: `iid_gauss`), at the top level
+            # next to `value`: both tables, each with its recall
+            "value_iid": None if not gauss or "queries_per_s" not in gauss else gauss["queries_per_s"],
+            "recall_at_10_iid": None if not gauss or "recall_at_10" not in gauss else gauss["recall_at_10"],
             "build_vectors_per_s": None if build_vps is None else round(build_vps, 1),
             "build": build,
             "bytes_per_query": int(st["bytes_scored"] / max(1, nq * args.steps)) + nlists * dim * 4,
@@ -882,10 +890,13 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
              "evaluations_per_query": round(float(gs_l.mean()), 1), "recall_at_10": round(recall_l, 4),
              "oracle_parity": {"queries": sample, "mismatches": int(bad_l),
                                "checked": "blocks in slot order, float4 bits, evaluation counts"}}
-    return {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k} cosine, "
-                        f"{nq}-query batches (BASELINE config C3)",
-            "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 3), "build_schedule": ix.build_stats(),
-            "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
+    trace("hnsw leg (intended)")
+    intended = hnsw_intended_leg(args, dev)
+    ref_compat = {"what": "hnswSearch as the reference runs it (hnsw_am.c:1545-2080: greedy descent, BFS-until-ef at level 0, "
+                          "quirks Q10 / Q12): PARITY evidence — blocks, ranks, float4 bits and evaluation counts equal the "
+                          "oracle's — not a search result anybody wants (recall ~ 0 by the reference's own algorithm)",
+                  "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 3), "build_schedule": ix.build_stats(),
+                  "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
             "evaluations_per_query": round(evals, 1), "bytes_per_query": int(bytes_q),
             "roofline": hnsw_roofline(n, dim, m, ef, nq, ts, bytes_q),
             "recall_at_10": round(recall, 4),
@@ -896,8 +907,19 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             "cpu_baseline": {"value": round(cpu_qps, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                              "sample": f"{ncpu} of the same queries through oracle/ndb_oracle.c ndbo_hnsw_search on the "
                                        "exported graph, one thread per core"},
-            "search_layer": layer,
-            "intended": hnsw_intended_leg(args, dev)}
+            "search_layer": layer}
+    # C3's figure is the `intended` index (the layer search src/scan/hnsw_scan.c specifies, on a graph
+    # built with the links hnswInsertNode drops): queries_per_s / recall_at_10 at the top are ITS
+    top = {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k} cosine, "
+                       f"{nq}-query batches (BASELINE config C3)"}
+    if intended and "queries_per_s" in intended:
+        for key in ("queries_per_s", "recall_at_10", "build_vectors_per_s", "ms_per_batch", "evaluations_per_query", "roofline"):
+            if key in intended:
+                top[key] = intended[key]
+        top["mode"] = "intended (details: `intended`); the reference-compatible walk: `ref_compat`"
+    top["intended"] = intended
+    top["ref_compat"] = ref_compat
+    return top
 
 
 def hnsw_roofline(n, dim, m, ef, nq, ts, bytes_q):
@@ -1087,6 +1109,12 @@ def pmc_traffic(args, world, kernel="k_ivf_scan", data=None, want_busy=False):
     return none
 
 
+def trace(what):
+    """Progress on stderr (the JSON line is the only thing on stdout): which leg a run that dies was in."""
+    sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] {what}\n")
+    sys.stderr.flush()
+
+
 def host_cores():
     """Cores this process may really use: the smaller of the affinity mask and the cgroup's CPU quota (a container can
     see 256 CPUs and be allowed 8); os.cpu_count() alone overstates the CPU baseline's denominator."""
@@ -1135,11 +1163,14 @@ def sweep_roofline(args, st, nq, steps, ms_per_step, data_kind, world):
     hbm = plane / (ms * 1e-3) / 1e9
     mf = issued / (ms * 1e-3) / 1e12
     hf, mfr = hbm / HBM_PEAK_GBPS, mf / FP16_MFMA_PEAK_TFLOPS
-    tr, src, busy = pmc_traffic(args, world, "k_s16c_sweep", data_kind, want_busy=True)
+    dense = st.get("dense_sweeps", 0) > 0
+    tr, src, busy = pmc_traffic(args, world, "k_s16c_dense" if dense else "k_s16c_sweep", data_kind, want_busy=True)
     alg = st["bytes_scored"] / launches
     r = {"bound": "hbm" if hf >= mfr else "mfma",
-         "kernel": "k_s16c_sweep (centred one-plane sweep: fp16 planes of row - centre and query - centre, "
-                   "v_mfma_f32_32x32x16_f16, operands by LDS DMA)",
+         "kernel": ("k_s16c_dense (the centred one-plane sweep's dense tile, 256 pairs x 256 rows: loader / prefetcher waves, "
+                    "the matrix pipe screens its own accumulator blocks, queued records; csrc/ndbhip_screen16d.h)" if dense else
+                    "k_s16c_sweep (centred one-plane sweep: fp16 planes of row - centre and query - centre, "
+                    "v_mfma_f32_32x32x16_f16, operands by LDS DMA)"),
          "achieved": round(hbm if hf >= mfr else mf, 1), "peak": HBM_PEAK_GBPS if hf >= mfr else FP16_MFMA_PEAK_TFLOPS,
          "unit": "GB/s" if hf >= mfr else "TFLOP/s", "frac": round(max(hf, mfr), 4),
          "traffic": tr, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": int(launches),

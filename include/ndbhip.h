@@ -158,6 +158,16 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen16_slack"    1     the centred planes keep spare 32-row blocks per bucket and take appends in place (0: every append lays them out again)
  *   "screen_min_nq"     32    batches of at least this many queries take the screened (matrix-core) scan; smaller ones the exact grouped scan
  *   "screen16c_nbuf"    0     ring depth of the centred sweep: 2 | 3, 0 = the tile geometry's default
+ *   "screen16c_dense"   1     the dense tile (256 pairs x 256 rows) runs k_s16c_dense (csrc/ndbhip_screen16d.h: loader and prefetcher
+ *                             waves, chunk-major pair planes, the matrix pipe screens its own accumulator blocks, queued records);
+ *                             0 = k_s16c_sweep<8, 2> (A/B)
+ *   "screen16c_sample"  2048  rows of the mirror sampled for the first thresholds of a batch on a table without cluster structure
+ *                             (k_s16c_seed_sample: all queries x the sample as one matrix on the matrix cores); 0 = seeds only, 256..2048
+ *   "screen16c_tight"   128   k_s16c_dense tightens a query's threshold every this many records (power of two, 8..1024)
+ *   "screen16c_pfd"     0     chunks k_s16c_dense's prefetcher waves touch ahead of its loaders (0 = none: measured slower on MI355X), 0..10
+ *   "screen16c_rot"     0     k_s16c_dense takes an item's chunks in an order rotated by its row tile (1) / pair tile (2); 0 = in order
+ *   "screen16c_epi"     1     k_s16c_sweep: the matrix pipe screens accumulator blocks before the per-element test; 0 = every element (A/B)
+ *   "screen16c_pf"      0     timing variants of k_s16c_sweep<8, 2>: 3 = in-wave L2 prefetch, 16 / 32 / 48 = non-temporal rows / pairs / both
  *   "build_screen16"    1     build / ndbhip_ivf_assign_device (>= 4096 rows): the assignment is screened on the matrix cores (0: exact kernels)
  *   "block_cache"       1     keep up to 4 freed packed-row blocks (>= 64 MiB) for the next build (0: release them now, stop caching)
  *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
