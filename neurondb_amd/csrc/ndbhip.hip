@@ -1762,6 +1762,12 @@ struct ndbhip_ivf
 	/* centroids AND the regrouped lists' centres as one matrix (columns 0 .. ncmp - 1, then the centres): a screened
 	 * batch that needs both gets them from one launch instead of two of the same fixed latency */
 	S16Mat		dm_all;
+	/* inner product on the centred sweep: M^2 (device word + host copy), M^2 - |x|^2 per padded plane row, ev per query */
+	bool		ipc_valid = false;
+	float		ipc_m2 = 0.0f;
+	uint32_t   *d_ipc_m2 = nullptr; size_t d_ipc_m2_n = 0;
+	float	   *d_rnx = nullptr; size_t d_rnx_n = 0;
+	float	   *w_qev = nullptr; size_t w_qev_n = 0;
 	/* a sample of the mirror's rows as a matrix of their own: first thresholds of a dense batch (k_s16c_seed_sample) */
 	S16Mat		dm_seed;
 	bool		seed_valid = false;
@@ -1878,7 +1884,7 @@ ivf_free_rows(ndbhip_ivf *ix)
 	ix->d_tids = nullptr;
 	ix->own_rows = false;
 	ix->nrows = 0;
-	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false; ix->ipc_valid = false;
 	ix->cap_rows = 0;
 }
 
@@ -1899,7 +1905,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -2038,7 +2044,7 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
-	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false; ix->ipc_valid = false;
 	ix->loaded = true;
 	return NDBHIP_OK;
 }
@@ -2117,7 +2123,7 @@ ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owne
 		HIP_TRY(hipStreamSynchronize(g.stream));
 	}
 	ix->nrows = nrows;
-	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false; ix->ipc_valid = false;
 	ix->f16 = true;
 	ix->loaded = true;
 	return ivf_note_f16_subnormals(ix);
@@ -2142,7 +2148,7 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 	ix->own_rows = false;
 	ix->f16 = false;
 	ix->nrows = nrows;
-	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false;
+	ix->norm_valid = false; ix->s16_valid = false; ix->seed_valid = false; ix->ipc_valid = false;
 	ix->cap_rows = nrows;
 	ix->loaded = true;
 	return NDBHIP_OK;
@@ -2369,6 +2375,7 @@ ivf_flush(ndbhip_ivf *ix)
 	ix->nrows = nown;
 	ix->norm_valid = false;
 	ix->seed_valid = false;
+	ix->ipc_valid = false;
 	/* the centred planes take the new rows in the spare blocks of their lists (ndbhip_screen16c.h); anything else —
 	 * other layouts, a list that has outgrown its spare blocks — is laid out again by the next screened batch */
 	if (ix->s16_valid && ivf_s16c_append(ix, add, new_own) != 0)
@@ -2725,6 +2732,80 @@ ivf_recipe(int strategy)
 #include "ndbhip_screen16c.h"
 #include "ndbhip_screen16d.h"
 
+/* ---- inner product on the centred sweep (ndbhip_screen16.h: s16c_ip_*): M^2 and the rows' constants M^2 - |x|^2 ---- */
+/* one wave per mirror row: |x|^2 (fp64 sum, rounded to fp32), and the largest of them (float bits; NaN / inf rows are
+ * not counted: their plane rows are marked and always emitted) */
+__global__ __launch_bounds__(256) void
+k_ipc_norms(const float *__restrict__ vecs, int64_t nrows, int dim, float *__restrict__ x2, uint32_t *__restrict__ m2_bits)
+{
+	const int	lane = threadIdx.x & 63;
+	const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+
+	if (row >= nrows)
+		return;
+	const float *x = vecs + (size_t) row * dim;
+	double		s = 0.0;
+
+	for (int i = lane; i < dim; i += 64)
+		s += (double) x[i] * (double) x[i];
+	s = wave_sum_f64(s);
+	if (lane == 0)
+	{
+		const bool	ok = s <= 3.0e38;
+		const float v = ok ? __double2float_ru(s) : __uint_as_float(0x7FC00000u);
+
+		x2[row] = v;
+		if (ok && __float_as_uint(v) > __atomic_load_n(m2_bits, __ATOMIC_RELAXED))
+			atomicMax(m2_bits, __float_as_uint(v));
+	}
+}
+
+/* one thread per padded plane row: which mirror row sits there (bucket -> list, index in the list), its constant */
+__global__ __launch_bounds__(256) void
+k_ipc_fill(const float *__restrict__ x2, const uint32_t *__restrict__ m2_bits, const int64_t *__restrict__ prow_off, int nb,
+		   const uint32_t *__restrict__ bucket_list, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
+		   const uint32_t *__restrict__ pposof, float *__restrict__ rnx)
+{
+	const int64_t pp = (int64_t) blockIdx.x * 256 + threadIdx.x;
+
+	if (pp >= prow_off[nb])
+		return;
+	int			lo = 0, hi = nb;
+
+	while (hi - lo > 1)
+	{
+		const int	mid = (lo + hi) >> 1;
+
+		if (prow_off[mid] <= pp)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	while (lo + 1 < nb && prow_off[lo + 1] <= pp)
+		lo++;
+	const uint32_t L = bucket_list[lo], pos = pposof[pp];
+	float		r = 0.0f;
+
+	if (pos < own_len[L])
+	{
+		const float v = x2[(size_t) loc_off[L] + pos];
+
+		/* (rounded down; the sweep takes it another 2^-20 down or up as the bound needs) */
+		r = v == v ? __double2float_rd((double) __uint_as_float(*m2_bits) - (double) v) : __uint_as_float(0x7FC00000u);
+		r = r < 0.0f ? 0.0f : r;
+	}
+	rnx[pp] = r;
+}
+
+__global__ void
+k_ipc_qev(const float *__restrict__ qn2, const uint32_t *__restrict__ m2_bits, int dim, uint32_t nq, float *__restrict__ qev)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+	if (q < nq)
+		qev[q] = s16c_ip_ev(dim, qn2[q], __uint_as_float(*m2_bits));
+}
+
 /* the fp16-MFMA screened scan in auto mode (ndbhip_set_option("screen16", 0) turns it off: the older fp32 bound
  * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
 static int	g_s16_auto = 1;
@@ -2835,6 +2916,7 @@ static int	g_s16_sub_min = 256;	/* lists longer than this are regrouped where th
 static int	g_s16_sub_rows = 128;	/* ... into sublists of about this many rows ("screen16_sub_rows") */
 
 /* does the centred one-plane sweep (ndbhip_screen16c.h) serve this recipe on this mirror */
+static int	g_s16_ip_cen = 1;	/* inner product on the CENTRED sweep: |q - x|^2 + M^2 - |x|^2 ("screen16_ip_centered") */
 static int	g_s16_cos_cen = 1;	/* cosine on the CENTRED sweep: |q^ - x^|^2 = 2 x cosine distance ("screen16_cosine_centered") */
 
 static bool
@@ -2842,8 +2924,10 @@ ivf_s16_centered(const ndbhip_ivf *ix, int R)
 {
 	/* (cosine: the planes come from a normalised fp32 copy whatever the mirror holds; L2 on an fp16 mirror: from a
 	 * transient copy of the rows as the reference decodes them) */
-	(void) ix;
-	return g_s16_cen != 0 && (R == R_IVF_L2 || (R == R_IVF_COS && g_s16_cos && g_s16_cos_cen));
+	/* (inner product: on the L2 layout's own planes, every bound shifted by the row's M^2 - |x|^2 (s16c_ip_*); float4 rows,
+	 * and not on a shard — the thresholds carry M^2, which every rank has its own of) */
+	return g_s16_cen != 0 && (R == R_IVF_L2 || (R == R_IVF_COS && g_s16_cos && g_s16_cos_cen) ||
+							  (R == R_IVF_IP && g_s16_ip_cen && !ix->f16 && !g_thr_hook));
 }
 
 /*
@@ -2874,6 +2958,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		uint64_t	nb = 0;
 
 		g.stats.prepares++;
+		ix->ipc_valid = false;		/* (the rows' constants are indexed by padded plane row) */
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = lay_cfg;
 		ix->s16_planes_f32 = cosn || !ix->f16;
@@ -3156,7 +3241,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const bool	cosb = cen && R == R_IVF_COS;	/* cosine on the centred sweep: normalised planes, thresholds in their squared-L2 domain */
 	/* seeds by the exact-arithmetic kernels (k_s16_seed / k_s16_seed_sub with the centred thresholds) instead of
 	 * k_s16c_seed, which reads float4 rows: cosine (the reference's cosine values), fp16 mirrors */
-	const bool	xseed = cosb || (cen && ix->f16);
+	const bool	ipc = cen && R == R_IVF_IP;		/* inner product on the centred sweep: the L2 planes, bounds and thresholds in b's domain */
+	const bool	xseed = cosb || ipc || (cen && ix->f16);
 	/* A sharded search exchanges thresholds between the seeds and the sweep (g_thr_hook): a collective.  A rank that
 	 * fails before it gets there (an allocation, the preparation) must still take part — with +inf, the identity of the
 	 * minimum — or its peers wait for it forever; it reports its error afterwards. */
@@ -3191,6 +3277,34 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 		if (rc)
 			return rc;
+	}
+	if (ipc)
+	{
+		if (!ix->ipc_valid)
+		{
+			/* once per version of the mirror / layout of the planes: M^2 and every plane row's M^2 - |x|^2 */
+			const size_t npp = (size_t) ix->s16_prow.back() + 8 * 32;
+			float	   *x2 = nullptr;
+
+			if (grow(ix->d_ipc_m2, ix->d_ipc_m2_n, (size_t) 1)) return NDBHIP_ERR_HIP;
+			if (grow(ix->d_rnx, ix->d_rnx_n, npp)) return NDBHIP_ERR_HIP;
+			if (big_alloc((void **) &x2, (size_t) ix->nrows * sizeof(float))) return NDBHIP_ERR_HIP;
+			HIP_TRY(hipMemsetAsync(ix->d_ipc_m2, 0, sizeof(uint32_t), g.stream));
+			HIP_TRY(hipMemsetAsync(ix->d_rnx, 0, npp * sizeof(float), g.stream));
+			hipLaunchKernelGGL(k_ipc_norms, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
+							   ix->nrows, dim, x2, ix->d_ipc_m2);
+			hipLaunchKernelGGL(k_ipc_fill, dim3((unsigned) ((ix->s16_prow.back() + 255) / 256)), dim3(256), 0, g.stream, (const float *) x2,
+							   (const uint32_t *) ix->d_ipc_m2, (const int64_t *) ix->d_prow_off, (int) ix->s16_prow.size() - 1,
+							   (const uint32_t *) ix->d_bucket_list, (const int64_t *) d.loc_off, d.own_len,
+							   (const uint32_t *) ix->d_pposof, ix->d_rnx);
+			HIP_TRY(hipMemcpyAsync(&ix->ipc_m2, ix->d_ipc_m2, sizeof(float), hipMemcpyDeviceToHost, g.stream));
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			big_free(x2);
+			ix->ipc_valid = true;
+		}
+		if (grow(ix->w_qev, ix->w_qev_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		hipLaunchKernelGGL(k_ipc_qev, dim3((nq + 255) / 256), dim3(256), 0, g.stream, (const float *) ix->w_qn2,
+						   (const uint32_t *) ix->d_ipc_m2, dim, (uint32_t) nq, ix->w_qev);
 	}
 	if (grow(ix->w_qplanes, ix->w_qplanes_n, (size_t) nq * qrowbytes)) return NDBHIP_ERR_HIP;
 	if (grow(ix->w_qn2, ix->w_qn2_n, (size_t) nq)) return NDBHIP_ERR_HIP;
@@ -3241,7 +3355,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 						   0u, (const float *) nullptr, (const float *) nullptr, 0u, ix->w_qthr);
 	else if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
-				  (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr, cen ? 1 : 0);
+				  ipc ? (const uint32_t *) ix->d_ipc_m2 : (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr,
+				  ipc ? 2 : (cen ? 1 : 0));
 	/* a table without cluster structure (what the previous batch's pairs per bucket say, as for the tile size below):
 	 * thresholds from a sample of the mirror's rows (k_s16c_seed_sample) on top of the seeds' */
 	if (!seed_by_sublist && cen && !xseed && R == R_IVF_L2 && !ix->s16_sub && g_s16c_sample > 0 && k <= 64 && npr <= 512 &&
@@ -3345,7 +3460,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 														   0x7FFFFFFFu);
 	const uint32_t qcrowbytes = (uint32_t) dimp * 2u;
 	/* the dense tile's kernel (ndbhip_screen16d.h) reads chunk-major pair planes: [64-dim chunk][pair][64 halfs] */
-	const bool	dense_k = cen && c_qb == 8 && g_s16c_dense;
+	const bool	dense_k = cen && c_qb == 8 && g_s16c_dense && !ipc;	/* (inner product: k_s16c_sweep<8, 2>, which takes the rows' constants) */
 	const size_t qc_plane = ((size_t) qc_cap + 256) * 64;		/* halfs per chunk plane */
 
 	if (cen)
@@ -3407,7 +3522,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 1);
 			else if (R == R_IVF_IP || R == R_IVF_COS)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_IP>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
-								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, 0);
+								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, ipc ? 1 : 0,
+								   ipc ? (const float *) ix->w_qev : (const float *) nullptr);
 			else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_retarget<R_IVF_L2>), dim3(nq), dim3(S16_NB), 0, g.stream, dim, (uint32_t) k,
 								   ix->w_qthr, ecount, ecap, (const uint32_t *) ix->w_bmin, active, flags + 1, cen ? 1 : 0);
@@ -3474,7 +3590,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							  (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_sub_loc,
 							  (const int64_t *) ix->d_perm, (const uint32_t *) ix->d_posof,
 							  subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2,
-							  (const uint32_t *) ix->d_xmax16, ix->w_qthr, xseed ? 1 : 0, ipb ? sub_rn2 : (const float *) nullptr,
+							  ipc ? (const uint32_t *) ix->d_ipc_m2 : (const uint32_t *) ix->d_xmax16, ix->w_qthr, ipc ? 2 : (xseed ? 1 : 0),
+							  ipb ? sub_rn2 : (const float *) nullptr,
 							  ipb ? (const float *) ix->d_cn2 : (const float *) nullptr, H == 1 ? 1 : 0,
 							  /* (the two-plane sweep pays for a looser threshold with emissions: measured 2.66 -> 2.59 M q/s at 32) */
 							  xseed ? cseeds : (uint32_t) S16_SEED);
@@ -3494,7 +3611,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) nullptr, (uint32_t *) nullptr,
 							   (PairRec *) nullptr, ipb, sub_rn2, (const float *) ix->d_cn2, ix->w_qpairs, ix->w_qpn, ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE,
-							   g_s16_debug & 28, cntx, (uint32_t) ncsx);
+							   g_s16_debug & 28, cntx, (uint32_t) ncsx, ipc ? ix->ipc_m2 : -1.0f);
 		}
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
@@ -3509,7 +3626,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   sstride, (const float2 *) ix->w_qthr, prune ? 1 : 0, pdist, cdist, cstride, (const float *) ix->w_qn2,
 							   (const uint32_t *) sub_xmax, dim, act, cnt, (const uint32_t *) pair_off, fill, ix->w_pairs,
 							   ipb, sub_rn2, (const float *) ix->d_cn2, ix->w_qpairs, ix->w_qpn, ix->w_gcnt + 2 * ncs + 8 * NDB_QHEAD_STRIDE,
-							   0, cntx, (uint32_t) ncsx);
+							   0, cntx, (uint32_t) ncsx, ipc ? ix->ipc_m2 : -1.0f);
 		else
 			hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, (const uint32_t *) pair_off, fill, ix->w_pairs, act, drop);
@@ -3570,7 +3687,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
-							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0)
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0,                                       \
+							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, ipc ? (const float *) ix->w_qev : (const float *) nullptr)
 #define S16C_DENSE_L(DB)                                                                                             \
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_dense<DB>), dim3(g.num_cus), dim3(512), 0, g.stream,                  \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
@@ -3650,7 +3768,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
 			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr,
-			  surv_cap, ix->w_overq);
+			  surv_cap, ix->w_overq, ipc ? (const float *) ix->w_qev : (const float *) nullptr);
 		HIP_TRY(hipGetLastError());
 		{
 			unsigned int f[8];
@@ -3938,6 +4056,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_seeds must be 0 (default), 32 or 64");
 		g_s16c_seeds = value;
 	}
+	else if (!strcmp(name, "screen16_ip_centered"))
+		g_s16_ip_cen = value != 0;
 	else if (!strcmp(name, "screen16c_sample"))
 	{
 		if (value != 0 && (value < 256 || value > 2048))

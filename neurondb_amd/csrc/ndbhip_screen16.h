@@ -617,7 +617,8 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 												   * fill pass then places every pair with its own counter, as it used to) */,
 			int dbg = 0 /* timing experiments, WRONG results: 4 no counter atomics, 8 no reads of subdist, 16 no table reads */,
 			uint32_t *__restrict__ cntx = nullptr /* [8][ncs] the count pass's counters, one set per XCD (see below) */,
-			uint32_t ncs = 0 )
+			uint32_t ncs = 0,
+			float ipc_m2 = -1.0f /* >= 0: inner product on the centred sweep — the thresholds are in b's domain (s16c_ip_*), this is M^2 */ )
 {
 	__shared__ uint32_t s_np;
 
@@ -670,7 +671,16 @@ k_sub_pairs(const int *__restrict__ probes, const uint32_t *__restrict__ loc_can
 	if (q >= nq || (active && !active[q]))
 		return;
 	const uint32_t *co = loc_cand_off + (size_t) q * (npr + 1);
-	const float te = qthr[q].x;
+	float		te = qthr[q].x;
+
+	if (ipc_m2 >= 0.0f)
+	{
+		/* T = |q|^2 + M^2 + 2 (thr + ev) back to the reference's domain, upwards: the value a row's real -q.x must exceed
+		 * for the row to be out (what s16_sub_excluded_ip compares with) */
+		const double tv = 0.5 * ((double) te - (double) qn2[q] * (1.0 - 3e-7) - (double) ipc_m2 * (1.0 - 3e-7));
+
+		te = (float) (tv + __builtin_fabs(tv) * 1e-6 + 1e-30);
+	}
 	/* error of the centre distances: the sweep's own bound with the largest centre norm in the rows' place */
 	const float ec = prune ? s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false) : 0.0f;
 
@@ -936,6 +946,39 @@ s16c_cos_t_from_ub(float ub, int dim)
 }
 
 /*
+ * INNER PRODUCT ON THE CENTRED SWEEP (ndbhip_screen16c.h; quantization.c:2075-2116 / hnsw_am.c:1334-1337 are where the
+ * reference's -sum q_i x_i comes from).  With M^2 = the largest |x|^2 of the mirror,
+ *     b(q, x) = |q - x|^2 + (M^2 - |x|^2) = |q|^2 + M^2 - 2 q.x  >= 0
+ * orders the rows of a query like -q.x does, and its first term is what the centred L2 sweep bounds (a - E <= |q - x|^2
+ * <= a + E) from the SAME planes an L2 search uses; the second is a constant of the row (`rnx`, per padded plane row).  The
+ * thresholds T of such a batch live in b's domain.  ev = gamma_dim |q| M (+) bounds what separates the reference's
+ * sequential fp32 sum from the real -q.x for every row (|x| <= M).
+ *   from a reference value thr that bounds the k-th from above: a row can be among the k only if its reference value is
+ *     <= thr, i.e. -q.x <= thr + ev, i.e. b <= |q|^2 + M^2 + 2 (thr + ev):  T = that (|q|^2, M^2 as stored: fp64 sums
+ *     rounded to fp32, taken 2^-21 up);
+ *   from the k-th smallest upper bound U of b over distinct candidates: those k rows have -q.x <= (U - |q|^2 - M^2) / 2,
+ *     hence reference values <= that + ev, which is such a thr:  T = U + 4 ev  (|q|^2 and M^2 cancel).
+ * T >= 0 always (b is), so its bits order like its values, as the sweep's atomicMin wants.
+ */
+__device__ __forceinline__ float
+s16c_ip_ev(int dim, float q2, float m2)
+{
+	return s16_up(ndb_s16_gamma(dim) * __builtin_sqrtf(q2) * __builtin_sqrtf(m2) * 1.00001f) + NDB_S16_ABS;
+}
+__device__ __forceinline__ float
+s16c_ip_t_from_ref(float thr, float q2, float m2, int dim)
+{
+	const float t = s16_up(s16_up(q2 * 1.0000005f) + s16_up(m2 * 1.0000005f) + 2.0f * s16_up(thr + s16c_ip_ev(dim, q2, m2)));
+
+	return t == t ? fmaxf(t, 0.0f) : __uint_as_float(0x7F800000u);
+}
+__device__ __forceinline__ float
+s16c_ip_t_from_ub(float ub, float ev)
+{
+	return s16_up(s16_up(fmaxf(ub, 0.0f)) + 4.0f * ev);
+}
+
+/*
  * ivfSelectClusters (src/index/ivf_am.c:1597-1717) for a batch, screened: amat[q][c] = a ~ |q - centroid c|^2 from
  * the two-plane sweep's MODE 3 (s16mat_run over the centroids' planes; |a - D| <= E = s16_e(dim, |q|^2, largest
  * centroid norm)).  The reference's float4 distance d of a centroid satisfies (a - E)(1 - m) <= d^2 <= (a + E)(1 + m)
@@ -1183,7 +1226,10 @@ k_s16_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__
 		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
 
 		if (thr == thr)			/* a NaN distance bounds nothing */
-			thrE = (R == R_IVF_COS && cen) ? s16c_cos_t_from_ref(thr, dim) : s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
+			/* (cen == 2, inner product on the centred sweep: xmax_bits holds M^2, the threshold goes to b's domain) */
+			thrE = (R == R_IVF_COS && cen) ? s16c_cos_t_from_ref(thr, dim)
+				: (R == R_IVF_IP && cen == 2) ? s16c_ip_t_from_ref(thr, qn2[q], __uint_as_float(*xmax_bits), dim)
+				: s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
 	}
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
@@ -1328,7 +1374,10 @@ k_s16_seed_sub(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		const float thr = __shfl(v, __ffsll((long long) pick) - 1, 64);
 
 		if (thr == thr)			/* a NaN distance bounds nothing */
-			thrE = (R == R_IVF_COS && cen) ? s16c_cos_t_from_ref(thr, dim) : s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
+			/* (cen == 2, inner product on the centred sweep: xmax_bits holds M^2, the threshold goes to b's domain) */
+			thrE = (R == R_IVF_COS && cen) ? s16c_cos_t_from_ref(thr, dim)
+				: (R == R_IVF_IP && cen == 2) ? s16c_ip_t_from_ref(thr, qn2[q], __uint_as_float(*xmax_bits), dim)
+				: s16_thr_from_ref<R>(thr, cen ? 0.0f : e, dim);
 	}
 	if (lane == 0)
 		qthr[q] = make_float2(thrE, e);
@@ -2205,7 +2254,8 @@ template <int R>
 __global__ __launch_bounds__(S16_NB) void
 k_s16_retarget(int dim, uint32_t k, float2 *__restrict__ qthr, unsigned int *__restrict__ ecount, uint32_t ecap,
 			   const uint32_t *__restrict__ bmin, unsigned int *__restrict__ active,
-			   unsigned int *__restrict__ flags, int cen = 0 /* bmin holds upper bounds, the threshold no error term */ )
+			   unsigned int *__restrict__ flags, int cen = 0 /* bmin holds upper bounds, the threshold no error term */,
+			   const float *__restrict__ qev = nullptr /* inner product on the centred sweep: ev per query (s16c_ip_ev) */ )
 {
 	__shared__ uint32_t keys[S16_NB];
 	const uint32_t q = blockIdx.x;
@@ -2237,6 +2287,7 @@ k_s16_retarget(int dim, uint32_t k, float2 *__restrict__ qthr, unsigned int *__r
 
 		const float ak = __uint_as_float(tb);
 		const float nt = cen ? (R == R_IVF_COS ? s16c_cos_t_from_ub(ak, dim)
+								: (R == R_IVF_IP && qev) ? s16c_ip_t_from_ub(ak, qev[q])
 								: s16_up(s16_up(fmaxf(ak, 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))))
 			: s16_thr_from_a<R>(ak, o.y, dim);
 
@@ -2269,7 +2320,9 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   uint32_t surv_cap = S16_SURV_CAP /* survivors the block's LDS holds (a shard's k-th local bound is looser
 												 * than the index's: it gets more room) */,
 			   uint32_t *__restrict__ over_q = nullptr /* [S16_OVER_CAP] the queries counted in flags[0]: what the host
-														* hands to the exact path one by one instead of the whole batch */ )
+														* hands to the exact path one by one instead of the whole batch */,
+			   const float *__restrict__ qev = nullptr /* inner product on the centred sweep: ev per query (s16c_ip_ev); the
+														 * records' bounds and the threshold are in b's domain */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	TopkSmem	s = carve_topk_smem(smem_raw, surv_cap, k);
@@ -2316,6 +2369,8 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 
 			if (ubq && R == R_IVF_COS)
 				thrE = fminf(thrE, s16c_cos_t_from_ub(__uint_as_float(tb), dim));
+			else if (ubq && R == R_IVF_IP && qev)
+				thrE = fminf(thrE, s16c_ip_t_from_ub(__uint_as_float(tb), qev[q]));
 			else if (ubq)
 				thrE = fminf(thrE, s16_up(s16_up(fmaxf(__uint_as_float(tb), 0.0f)) * (1.0f + 2.5f * ndb_s16_refslack(dim))));
 			else

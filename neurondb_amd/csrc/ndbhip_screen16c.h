@@ -763,7 +763,10 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			 float *__restrict__ eub, uint32_t ecap, uint32_t *__restrict__ bmin, int nchunk,
 			 uint32_t desc_cap, uint32_t topk, const uint32_t *__restrict__ pos_of, float cE,
 			 uint32_t qc_cap /* rows of qcplanes: more pairs than that and nothing is swept (k_s16c_qcprep raised the flag) */,
-			 int cosine = 0 /* the planes are normalised vectors' and the thresholds bound cosine distances (s16c_cos_t_from_ub) */ )
+			 int cosine = 0 /* the planes are normalised vectors' and the thresholds bound cosine distances (s16c_cos_t_from_ub) */,
+			 const float *__restrict__ rnx = nullptr /* inner product (ndbhip_screen16.h: s16c_ip_*): M^2 - |x|^2 per padded plane
+													  * row, added to every bound of the row; the thresholds are in b's domain */,
+			 const float *__restrict__ qev = nullptr /* ... and ev per query, for the tightening */ )
 {
 	typedef S16CGeom<QB> G;
 	/* VAR: bits 0-3 = chunks an L2 prefetch runs ahead (0: none), bit 4 = the rows' stream is non-temporal, bit 5 = the pairs' */
@@ -1065,7 +1068,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		 * Requested here, these loads are older than the stream and cost nothing; the empty asm statements behind
 		 * the loop pin their first use there, so that no arithmetic on them (and no wait) is hoisted into the loop.
 		 */
-		float		tfresh = 0.0f, x2r[G::BR];
+		float		tfresh = 0.0f, x2r[G::BR], rxr[G::BR];
 		int			exr[G::BR];
 		uint32_t	porr[G::BR];
 		bool		rokr[G::BR];
@@ -1080,6 +1083,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 			rokr[b] = ridx < len;
 			x2r[b] = rn2[grow];
+			rxr[b] = rnx ? rnx[grow] : 0.0f;
 			exr[b] = (int) rexp[grow];
 			porr[b] = pos_of ? pos_of[grow] : ridx;
 		}
@@ -1089,7 +1093,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 #pragma unroll
 		for (int b = 0; b < G::BR; b++)
 		{
-			asm volatile("" : "+v"(x2r[b]), "+v"(exr[b]), "+v"(porr[b]));
+			asm volatile("" : "+v"(x2r[b]), "+v"(exr[b]), "+v"(porr[b]), "+v"(rxr[b]));
 			exr[b] -= 27;
 		}
 		if (tid < G::QT)
@@ -1126,7 +1130,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 #pragma unroll
 			for (int b = 0; b < G::BR; b++)
-				w = w || (rokr[b] && (exr[b] + 27 < -20 || exr[b] + 27 > 20));
+				w = w || (rokr[b] && (exr[b] + 27 < -20 || exr[b] + 27 > 20 || rxr[b] > 1.0e30f));
 			if (w)
 				s_wild[c_par] = 1u;
 			if (tid == 0)
@@ -1169,7 +1173,8 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					const int	m = 32 * (G::AQ * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
 					const float t1 = ldexpf(acc[a][b][reg], s_eq[c_par][m] + exr[b]);
 					const float n = s_q2[c_par][m] + x2r[b];
-					const float rhs = __builtin_fmaf(n, K, -s_t2[m]);
+					/* (inner product: the row's constant joins the bound, 2^-20 down: that covers the one more rounding) */
+					const float rhs = __builtin_fmaf(n, K, -s_t2[m]) + rxr[b] * 0.99999905f;
 
 					if ((DBG ? t1 == 1234.5f : !(t1 < rhs)) && rok && (uint32_t) m < nmem_cur && porr[b] < s_nrow[c_par][m])
 						emask |= 1ull << ((bb * G::AQ + a) * 16 + reg);
@@ -1242,7 +1247,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					const float n = s_q2[c_par][m] + x2r[b];
 					const float av = n - t1;
 					const float er = s16_up(s16_up(cE * n) + NDB_S16_ABS);
-					const float lbv = av - er, ubv = s16_up(av + er);
+					const float lbv = (av - er) + rxr[b] * 0.99999905f, ubv = s16_up(s16_up(av + er) + rxr[b] * 1.000001f);
 					const float lb = lbv - fabsf(lbv) * 4.8e-7f - 1e-37f;
 					const uint32_t pos = s_la[c_par][m] + porr[b], ub_bits = __float_as_uint(ubv);
 
@@ -1315,9 +1320,12 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				{
 					const int	b = bg * G::BG + bb;
 					/* (exr is the row's exponent - 27) */
-					const bool	nan = !(x2r[b] == x2r[b]);
+					const bool	nan = !(x2r[b] == x2r[b]) || !(rxr[b] == rxr[b]);
 					const bool	dead = !rokr[b] || porr[b] == 0xFFFFFFFFu;
-					const float w = dead ? __builtin_inff() : (nan ? -__builtin_inff() : ldexpf(x2r[b], -(exr[b] + 27)));
+					/* (inner product: KB (X2 + rx' / KB) = KB X2 + rx' with rx' = the row's constant 2^-18 down — the quotient's
+					 * and the sum's roundings and the instruction's own on one more term are inside that) */
+					const float xw = rnx ? x2r[b] + rxr[b] * 0.999996f / ((1.0f - cE) * 0.9999962f) : x2r[b];
+					const float w = dead ? __builtin_inff() : (nan ? -__builtin_inff() : ldexpf(xw, -(exr[b] + 27)));
 					const float wb = kh ? ldexpf(1.0f, -(exr[b] + 27)) : w;
 
 #pragma unroll
@@ -1384,7 +1392,8 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					if (topk != 0 && rank == topk - 1 && mine != 0xFFFFFFFFu)
 					{
 						const uint32_t tb = (mine & 0x80000000u) ? (mine & 0x7FFFFFFFu) : ~mine;
-						const float nt = cosine ? s16c_cos_t_from_ub(__uint_as_float(tb), dim) : s16c_t_from_ub(__uint_as_float(tb), dim);
+						const float nt = qev ? s16c_ip_t_from_ub(__uint_as_float(tb), qev[q])
+							: cosine ? s16c_cos_t_from_ub(__uint_as_float(tb), dim) : s16c_t_from_ub(__uint_as_float(tb), dim);
 
 						/* T >= 0 (or +inf): its bits order like the values */
 						atomicMin(reinterpret_cast<unsigned int *>(&qthr[q].x), __float_as_uint(nt));
