@@ -2735,19 +2735,23 @@ ivf_recipe(int strategy)
 /* ---- inner product on the centred sweep (ndbhip_screen16.h: s16c_ip_*): M^2 and the rows' constants M^2 - |x|^2 ---- */
 /* one wave per mirror row: |x|^2 (fp64 sum, rounded to fp32), and the largest of them (float bits; NaN / inf rows are
  * not counted: their plane rows are marked and always emitted) */
+template <bool F16>		/* the mirror holds fp16 rows: as the reference decodes them (fp16_to_float, quantization.c:170-218) */
 __global__ __launch_bounds__(256) void
-k_ipc_norms(const float *__restrict__ vecs, int64_t nrows, int dim, float *__restrict__ x2, uint32_t *__restrict__ m2_bits)
+k_ipc_norms(const void *__restrict__ vecs, int64_t nrows, int dim, float *__restrict__ x2, uint32_t *__restrict__ m2_bits)
 {
 	const int	lane = threadIdx.x & 63;
 	const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
 
 	if (row >= nrows)
 		return;
-	const float *x = vecs + (size_t) row * dim;
 	double		s = 0.0;
 
 	for (int i = lane; i < dim; i += 64)
-		s += (double) x[i] * (double) x[i];
+	{
+		const float v = F16 ? h2f_ref(((const uint16_t *) vecs)[(size_t) row * dim + i]) : ((const float *) vecs)[(size_t) row * dim + i];
+
+		s += (double) v * (double) v;
+	}
 	s = wave_sum_f64(s);
 	if (lane == 0)
 	{
@@ -2924,10 +2928,10 @@ ivf_s16_centered(const ndbhip_ivf *ix, int R)
 {
 	/* (cosine: the planes come from a normalised fp32 copy whatever the mirror holds; L2 on an fp16 mirror: from a
 	 * transient copy of the rows as the reference decodes them) */
-	/* (inner product: on the L2 layout's own planes, every bound shifted by the row's M^2 - |x|^2 (s16c_ip_*); float4 rows,
-	 * and not on a shard — the thresholds carry M^2, which every rank has its own of) */
+	/* (inner product: on the L2 layout's own planes, every bound shifted by the row's M^2 - |x|^2 (s16c_ip_*); an fp16 mirror's planes come
+	 * from its decoded rows as for L2; not on a shard — the thresholds carry M^2, which every rank has its own of) */
 	return g_s16_cen != 0 && (R == R_IVF_L2 || (R == R_IVF_COS && g_s16_cos && g_s16_cos_cen) ||
-							  (R == R_IVF_IP && g_s16_ip_cen && !ix->f16 && !g_thr_hook));
+							  (R == R_IVF_IP && g_s16_ip_cen && !g_thr_hook));
 }
 
 /*
@@ -3291,8 +3295,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			if (big_alloc((void **) &x2, (size_t) ix->nrows * sizeof(float))) return NDBHIP_ERR_HIP;
 			HIP_TRY(hipMemsetAsync(ix->d_ipc_m2, 0, sizeof(uint32_t), g.stream));
 			HIP_TRY(hipMemsetAsync(ix->d_rnx, 0, npp * sizeof(float), g.stream));
-			hipLaunchKernelGGL(k_ipc_norms, dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream, (const float *) ix->d_vecs,
-							   ix->nrows, dim, x2, ix->d_ipc_m2);
+			if (ix->f16)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ipc_norms<true>), dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream,
+								   (const void *) ix->d_vecs, ix->nrows, dim, x2, ix->d_ipc_m2);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ipc_norms<false>), dim3((unsigned) ((ix->nrows + 3) / 4)), dim3(256), 0, g.stream,
+								   (const void *) ix->d_vecs, ix->nrows, dim, x2, ix->d_ipc_m2);
 			hipLaunchKernelGGL(k_ipc_fill, dim3((unsigned) ((ix->s16_prow.back() + 255) / 256)), dim3(256), 0, g.stream, (const float *) x2,
 							   (const uint32_t *) ix->d_ipc_m2, (const int64_t *) ix->d_prow_off, (int) ix->s16_prow.size() - 1,
 							   (const uint32_t *) ix->d_bucket_list, (const int64_t *) d.loc_off, d.own_len,
