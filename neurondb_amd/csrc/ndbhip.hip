@@ -918,6 +918,30 @@ k_pair_count(const int *__restrict__ probes, const uint32_t *__restrict__ loc_ca
 	atomicAdd(&cnt[probes[(size_t) q * npr + p]], 1u);
 }
 
+/* k_sub_pairs' per-XCD counts summed per list and turned into each XCD's start inside the list's run of pairs — what
+ * k_pair_offsets does itself for a few thousand lists; with the tens of thousands of buckets of a 10 M-row index that is
+ * megabytes through ONE compute unit (154 us of a 1.4 ms step at C5), so there it runs here, over the whole device */
+__global__ __launch_bounds__(256) void
+k_pair_xsum(uint32_t *__restrict__ cntx, uint32_t xstride, int ncent, uint32_t *__restrict__ cnt)
+{
+	const int	L = blockIdx.x * 256 + threadIdx.x;
+
+	if (L >= ncent)
+		return;
+	uint32_t	v[8], run = 0;
+
+#pragma unroll
+	for (int x = 0; x < 8; x++)
+		v[x] = cntx[(size_t) x * xstride + L];
+#pragma unroll
+	for (int x = 0; x < 8; x++)
+	{
+		cntx[(size_t) x * xstride + L] = run;
+		run += v[x];
+	}
+	cnt[L] = run;
+}
+
 /* pass 2 (one block of 1024 threads): per-list pair / work-item / group offsets */
 __global__ __launch_bounds__(1024) void
 k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
@@ -1047,6 +1071,154 @@ k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len
 			r = __hip_atomic_load(&item_off[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		runs[t] = r;
+	}
+}
+
+/*
+ * The same for the tens of thousands of buckets a 10 M-row index has (one block walking them all was 130 us of a 1.4 ms
+ * step at C5: one compute unit's address path): two launches over ncent / 1024 blocks, a list per thread.
+ * k_pair_part leaves every block's three totals; k_pair_scan adds up the totals of the blocks before its own, scans its
+ * 1024 lists and writes their offsets; the last block writes the grand totals and the eight runs (exact runs only: the
+ * centred sweep's static schedule).
+ */
+__device__ __forceinline__ void
+pair_triple(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int L, int ncent, uint32_t gdiv, uint32_t rt,
+			uint32_t &a, uint32_t &b, uint32_t &c2)
+{
+	a = b = c2 = 0;
+	if (L < ncent)
+	{
+		const uint32_t c = cnt[L];
+		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
+
+		a = c;
+		b = ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
+		c2 = ng;
+	}
+}
+
+__global__ __launch_bounds__(1024) void
+k_pair_part(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent, uint32_t gdiv, uint32_t rt,
+			uint32_t *__restrict__ part /* [blocks][4] */, unsigned long long *__restrict__ swept)
+{
+	__shared__ uint32_t sa[16], sb[16], sc[16];
+	const int	t = threadIdx.x, L = blockIdx.x * 1024 + t;
+	uint32_t	a, b, c2;
+	unsigned long long sw = 0;
+
+	pair_triple(cnt, glob_len, L, ncent, gdiv, rt, a, b, c2);
+	if (swept && L < ncent)
+		sw = (unsigned long long) a * glob_len[L];
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		a += (uint32_t) __shfl_xor((int) a, off, 64);
+		b += (uint32_t) __shfl_xor((int) b, off, 64);
+		c2 += (uint32_t) __shfl_xor((int) c2, off, 64);
+		if (swept)
+		{
+			const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) sw, off, 64);
+			const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (sw >> 32), off, 64);
+
+			sw += ((unsigned long long) hi << 32) | lo;
+		}
+	}
+	if ((t & 63) == 0)
+	{
+		sa[t >> 6] = a;
+		sb[t >> 6] = b;
+		sc[t >> 6] = c2;
+		if (swept && sw != 0)
+			atomicAdd(swept, sw);
+	}
+	__syncthreads();
+	if (t == 0)
+	{
+		uint32_t	A = 0, B = 0, C = 0;
+
+		for (int w = 0; w < 16; w++)
+		{
+			A += sa[w];
+			B += sb[w];
+			C += sc[w];
+		}
+		part[4 * blockIdx.x] = A;
+		part[4 * blockIdx.x + 1] = B;
+		part[4 * blockIdx.x + 2] = C;
+	}
+}
+
+__global__ __launch_bounds__(1024) void
+k_pair_scan(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent, uint32_t gdiv, uint32_t rt,
+			const uint32_t *__restrict__ part, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
+			uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs)
+{
+	__shared__ uint32_t sa[1024], sb[1024], sc[1024], base[3];
+	const int	t = threadIdx.x, L = blockIdx.x * 1024 + t;
+	uint32_t	a, b, c2;
+
+	/* the totals of the blocks before this one (a few dozen) */
+	{
+		uint32_t	pa = 0, pb = 0, pc = 0;
+
+		for (int j = t; j < (int) blockIdx.x; j += 1024)
+		{
+			pa += part[4 * j];
+			pb += part[4 * j + 1];
+			pc += part[4 * j + 2];
+		}
+		sa[t] = pa;
+		sb[t] = pb;
+		sc[t] = pc;
+		__syncthreads();
+		if (t == 0)
+		{
+			uint32_t	A = 0, B = 0, C = 0;
+			const int	nn = min((int) blockIdx.x, 1024);
+
+			for (int j = 0; j < nn; j++)
+			{
+				A += sa[j];
+				B += sb[j];
+				C += sc[j];
+			}
+			base[0] = A;
+			base[1] = B;
+			base[2] = C;
+		}
+		__syncthreads();
+	}
+	pair_triple(cnt, glob_len, L, ncent, gdiv, rt, a, b, c2);
+	sa[t] = a;
+	sb[t] = b;
+	sc[t] = c2;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1)
+	{
+		const uint32_t va = (t >= off) ? sa[t - off] : 0u;
+		const uint32_t vb = (t >= off) ? sb[t - off] : 0u;
+		const uint32_t vc = (t >= off) ? sc[t - off] : 0u;
+
+		__syncthreads();
+		sa[t] += va;
+		sb[t] += vb;
+		sc[t] += vc;
+		__syncthreads();
+	}
+	if (L < ncent)
+	{
+		pair_off[L] = base[0] + sa[t] - a;
+		item_off[L] = base[1] + sb[t] - b;
+		grp_off[L] = base[2] + sc[t] - c2;
+	}
+	if (blockIdx.x == gridDim.x - 1 && t == 1023)
+	{
+		const uint32_t nitems = base[1] + sb[1023];
+
+		pair_off[ncent] = base[0] + sa[1023];
+		item_off[ncent] = nitems;
+		grp_off[ncent] = base[2] + sc[1023];
+		for (uint32_t x = 0; x <= 8; x++)
+			runs[x] = x == 0 ? 0u : (x == 8 ? nitems : (uint32_t) (((uint64_t) nitems * x) >> 3));
 	}
 }
 
@@ -1768,6 +1940,7 @@ struct ndbhip_ivf
 	uint32_t   *d_ipc_m2 = nullptr; size_t d_ipc_m2_n = 0;
 	float	   *d_rnx = nullptr; size_t d_rnx_n = 0;
 	float	   *w_qev = nullptr; size_t w_qev_n = 0;
+	uint32_t   *w_ppart = nullptr; size_t w_ppart_n = 0;	/* k_pair_part's block totals */
 	/* a sample of the mirror's rows as a matrix of their own: first thresholds of a dense batch (k_s16c_seed_sample) */
 	S16Mat		dm_seed;
 	bool		seed_valid = false;
@@ -1905,7 +2078,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev, ix->w_ppart};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3246,7 +3419,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* seeds by the exact-arithmetic kernels (k_s16_seed / k_s16_seed_sub with the centred thresholds) instead of
 	 * k_s16c_seed, which reads float4 rows: cosine (the reference's cosine values), fp16 mirrors */
 	const bool	ipc = cen && R == R_IVF_IP;		/* inner product on the centred sweep: the L2 planes, bounds and thresholds in b's domain */
-	const bool	xseed = cosb || ipc || (cen && ix->f16);
+	/* (inner product and fp16 mirrors take k_s16c_seed's wave-wide sums too: its IP / H16 forms) */
+	const bool	xseed = cosb;
 	/* A sharded search exchanges thresholds between the seeds and the sweep (g_thr_hook): a collective.  A rank that
 	 * fails before it gets there (an allocation, the preparation) must still take part — with +inf, the identity of the
 	 * minimum — or its peers wait for it forever; it reports its error afterwards. */
@@ -3356,11 +3530,21 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
 
+#define S16C_SEED_L(SUBB, ...)                                                                                          \
+	do {                                                                                                                \
+		if (ipc && H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 1>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
+		else if (ipc && H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 2>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
+		else if (ipc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 0>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__);     \
+		else if (H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 1>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
+		else if (H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 2>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 0>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__);             \
+	} while (0)
 	if (!seed_by_sublist && cen && !xseed)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<false>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
-						   (uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
-						   (const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
-						   0u, (const float *) nullptr, (const float *) nullptr, 0u, ix->w_qthr);
+		S16C_SEED_L(false, d, d_q, w_probes, lco, npr,
+					(uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
+					(const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
+					0u, (const float *) nullptr, (const float *) nullptr, 0u, ix->w_qthr,
+					(const float *) ix->w_qn2, (const uint32_t *) ix->d_ipc_m2, (const float *) nullptr, (const float *) nullptr);
 	else if (!seed_by_sublist)
 		S16_BY_RH(S16_SEED_L, d, d_q, w_probes, lco, npr, (uint32_t) k, (const float *) ix->w_qn2,
 				  ipc ? (const uint32_t *) ix->d_ipc_m2 : (const uint32_t *) ix->d_xmax16, (int) (ix->f16 && ix->f16_sub), ix->w_qthr,
@@ -3585,11 +3769,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				}
 				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
 				if (cen && !xseed)
-					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<true>), dim3(nq), dim3(64), 0, g.stream, d, d_q, w_probes, lco, npr,
-									   (uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-									   (const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
-									   (const uint32_t *) ix->d_pposof,
-									   subdist, sstride, pdist, cdist, cstride, ix->w_qthr);
+					S16C_SEED_L(true, d, d_q, w_probes, lco, npr,
+								(uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
+								(const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
+								(const uint32_t *) ix->d_pposof,
+								subdist, sstride, pdist, cdist, cstride, ix->w_qthr,
+								(const float *) ix->w_qn2, (const uint32_t *) ix->d_ipc_m2, sub_rn2, (const float *) ix->d_cn2);
 				else
 				{
 #define S16_SEEDSUB_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
@@ -3624,9 +3809,27 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, cnt, act, drop);
+		const bool	xsum_apart = sub && ncs > 8192;
+
+		if (xsum_apart)
+			hipLaunchKernelGGL(k_pair_xsum, dim3((ncs + 255) / 256), dim3(256), 0, g.stream, cntx, (uint32_t) ncsx, ncs, cnt);
+		if (xsum_apart && cen)
+		{
+			const unsigned nblk = (unsigned) ((ncs + 1023) / 1024);
+
+			if (grow(ix->w_ppart, ix->w_ppart_n, (size_t) 4 * nblk)) return NDBHIP_ERR_HIP;
+			hipLaunchKernelGGL(k_pair_part, dim3(nblk), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
+							   (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), ix->w_ppart,
+							   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr);
+			hipLaunchKernelGGL(k_pair_scan, dim3(nblk), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
+							   (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), (const uint32_t *) ix->w_ppart,
+							   pair_off, item_off, grp_off, runs);
+		}
+		else
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, cnt, ds.own_len, ncs,
 						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0,
-						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr, sub ? cntx : (uint32_t *) nullptr, (uint32_t) ncsx);
+						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr,
+						   (sub && !xsum_apart) ? cntx : (uint32_t *) nullptr, (uint32_t) ncsx);
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,

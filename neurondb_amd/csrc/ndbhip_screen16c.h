@@ -328,7 +328,15 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
  * lists that hold at least k visible rows (SUB; k_s16_seed_sub's rule); without one, the query's first `ns` candidates.
  * One wave per query.
  */
-template <bool SUB>
+/*
+ * IP (inner product, thresholds in b's domain: ndbhip_screen16.h s16c_ip_*): the wave sums -q_i x_i instead; a sum of dim
+ * rounded products in any order is within gamma_(dim + 1) |q||x| <= 1.01 ev of the real -q.x, the reference's own value
+ * within ev of it, so v + 2.02 ev bounds the reference's value of the row from above and the k-th smallest of those is a
+ * reference bound: T = s16c_ip_t_from_ref.  The nearest sublist is the one with the largest q.c = (|q|^2 + |c|^2 -
+ * |q - c|^2) / 2 (cn2_sub / cn2_list: the centres' norms).  H16: the mirror's rows are fp16 (decoded like the reference
+ * decodes them).
+ */
+template <bool SUB, bool IP = false, int H16 = 0 /* 0: float4 rows; 1: fp16 decoded like the reference (quirk Q20); 2: fp16 without subnormals (the plain conversion is the reference's) */>
 __global__ __launch_bounds__(64) void
 k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 			const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, uint32_t ns,
@@ -336,7 +344,9 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			const int64_t *__restrict__ prow_off /* first padded plane row of every sublist */,
 			const uint32_t *__restrict__ pposof /* padded plane row -> index in its list */,
 			const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
-			const float *__restrict__ cdist, uint32_t cstride, float2 *__restrict__ qthr)
+			const float *__restrict__ cdist, uint32_t cstride, float2 *__restrict__ qthr,
+			const float *__restrict__ qn2 = nullptr, const uint32_t *__restrict__ m2_bits = nullptr /* IP: |q|^2, M^2 */,
+			const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr /* IP: |c|^2 */ )
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x;
@@ -410,7 +420,11 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 					continue;
 				const int	gi = sub_gidx[sx];
 				const float pdl = s_pd[lo];
-				const float dd = gi < 0 ? pdl * pdl : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+				float		dd = gi < 0 ? pdl * pdl : fmaxf(subdist[(size_t) q * sstride + gi], 0.0f);	/* both squared */
+
+				if constexpr (IP)
+					/* (|q - c|^2 - |c|^2 orders the centres like -q.c does; any choice of seed rows is a valid one) */
+					dd -= gi < 0 ? (cn2_list ? cn2_list[probes[(size_t) q * npr + p0 + lo]] : 0.0f) : (cn2_sub ? cn2_sub[gi] : 0.0f);
 
 				if (dd < bd || (dd == bd && sx < bs))
 				{
@@ -485,26 +499,61 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				continue;			/* uniform */
 			const uint32_t rlo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) row, j);
 			const uint32_t rhi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (row >> 32), j);
-			const float *x = ix.vecs + (size_t) (((uint64_t) rhi << 32) | rlo) * (size_t) dim;
+			const size_t ro = (size_t) (((uint64_t) rhi << 32) | rlo) * (size_t) dim;
+			const float *x = ix.vecs + ro;
+			const uint16_t *xh = (const uint16_t *) ix.vecs + ro;
 			float		a = 0.0f;
 
 			if (vec4)
 				for (int i = lane * 4; i < dim; i += 256)
 				{
-					const float4 xv = *reinterpret_cast<const float4 *>(x + i), qv = *reinterpret_cast<const float4 *>(qq + i);
-					const float d0 = qv.x - xv.x, d1 = qv.y - xv.y, d2 = qv.z - xv.z, d3 = qv.w - xv.w;
+					float4		xv;
+					const float4 qv = *reinterpret_cast<const float4 *>(qq + i);
 
-					a += d0 * d0;
-					a += d1 * d1;
-					a += d2 * d2;
-					a += d3 * d3;
+					if constexpr (H16 == 1)
+					{
+						const uint2 hb = *reinterpret_cast<const uint2 *>(xh + i);
+
+						xv = make_float4(h2f_ref(hb.x & 0xFFFFu), h2f_ref(hb.x >> 16), h2f_ref(hb.y & 0xFFFFu), h2f_ref(hb.y >> 16));
+					}
+					else if constexpr (H16 == 2)
+					{
+						const ndb_h2 h01 = *reinterpret_cast<const ndb_h2 *>(xh + i), h23 = *reinterpret_cast<const ndb_h2 *>(xh + i + 2);
+
+						xv = make_float4((float) h01.x, (float) h01.y, (float) h23.x, (float) h23.y);
+					}
+					else
+						xv = *reinterpret_cast<const float4 *>(x + i);
+					if constexpr (IP)
+					{
+						a -= qv.x * xv.x;
+						a -= qv.y * xv.y;
+						a -= qv.z * xv.z;
+						a -= qv.w * xv.w;
+					}
+					else
+					{
+						const float d0 = qv.x - xv.x, d1 = qv.y - xv.y, d2 = qv.z - xv.z, d3 = qv.w - xv.w;
+
+						a += d0 * d0;
+						a += d1 * d1;
+						a += d2 * d2;
+						a += d3 * d3;
+					}
 				}
 			else
 				for (int i = lane; i < dim; i += 64)
 				{
-					const float d0 = qq[i] - x[i];
+					const float xv = H16 == 1 ? h2f_ref(xh[i]) : (H16 == 2 ? (float) reinterpret_cast<const _Float16 *>(xh)[i] : x[i]);
 
-					a += d0 * d0;
+					if constexpr (IP)
+						a -= qq[i] * xv;
+					else
+					{
+						const float d0 = qq[i] - xv;
+
+						a += d0 * d0;
+					}
 				}
 			part[u] = a;
 		}
@@ -520,10 +569,16 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				v = a;
 		}
 	}
-	/* upper bound of the real squared distance; NaN (a row or query beyond fp32) bounds nothing */
-	const float ub = s16_up(v * (1.0f + ndb_s16_refslack(dim)));
-	const bool	good = ok && ub == ub;
-	const uint32_t key = good ? __float_as_uint(ub) : 0xFFFFFFFFu;	/* (ub >= 0: the bits order like the values) */
+	/* upper bound of the real squared distance (IP: of the reference's value); NaN (a row or query beyond fp32) bounds nothing */
+	float		ub;
+
+	if constexpr (IP)
+		ub = s16_up(v + 2.02f * s16c_ip_ev(dim, qn2[q], __uint_as_float(*m2_bits)));
+	else
+		ub = s16_up(v * (1.0f + ndb_s16_refslack(dim)));
+	const bool	good = ok && ub == ub && (!IP || (ub - ub) == 0.0f);
+	/* (L2: ub >= 0, its bits order like the values; IP: the order-preserving key of any float) */
+	const uint32_t key = good ? (IP ? ndb_key_from_bits(__float_as_uint(ub)) : __float_as_uint(ub)) : 0xFFFFFFFFu;
 	uint32_t	rank = 0;
 
 	for (int j = 0; j < 64; j++)
@@ -536,7 +591,11 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 	float		t = __uint_as_float(0x7F800000u);	/* +inf: fewer than k seeds */
 
 	if (pick)
-		t = s16c_t_from_ub(__shfl(ub, __ffsll((long long) pick) - 1, 64), dim);
+	{
+		const float uk = __shfl(ub, __ffsll((long long) pick) - 1, 64);
+
+		t = IP ? s16c_ip_t_from_ref(uk, qn2[q], __uint_as_float(*m2_bits), dim) : s16c_t_from_ub(uk, dim);
+	}
 	if (lane == 0)
 		qthr[q] = make_float2(t, 0.0f);
 }

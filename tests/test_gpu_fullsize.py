@@ -365,12 +365,14 @@ def test_c2_on_the_iid_table_at_full_size():
     ix = IvfIndex(DIM, LISTS)
     ix.build_device(base, pack_tids(torch.arange(N, device=dev)), 50)
     del base
+    _lib.check(_lib.lib().ndbhip_set_scan_mode(0))
     try:
         _search(ix, q)                                        # the first batch measures the pairs per bucket
         _lib.check(_lib.lib().ndbhip_stats_reset())
         rows, dist, cnt = _search(ix, q)
         st = _lib.stats()
-        assert st["dense_sweeps"] == 1 and st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
+        assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, st
+        assert st["dense_sweeps"] >= 1, {k: st[k] for k in ("dense_sweeps", "screen16_batches", "pairs_pruned", "rows_swept", "rows_emitted")}
         assert (cnt == K).all() and (np.diff(dist, axis=1) >= 0).all()
         assert all(len(set(r.tolist())) == K for r in rows[:512])
         # the batch a query travels in does not matter (other tiles, other thresholds, the exact path for one query)
