@@ -354,6 +354,14 @@ def main():
     elapsed = time.perf_counter() - t0
     check(lib().ndbhip_profile(0))
     st = _lib.stats()
+    if os.environ.get("NDB_PHASES"):
+        # a profiling build of the library (make EXTRA=-DNDB_PHASES): block 0's clock stamps of the last step's kernels
+        import ctypes as _C
+        ph = (_C.c_ulonglong * 64)()
+        check(lib().ndbhip_debug_phases(ph))
+        ph = list(ph)
+        sys.stderr.write("[phases] cent_select us: " + " ".join(f"{(ph[i + 1] - ph[i]) / 100:.1f}" for i in range(0, 7)) +
+                         "   finalize us: " + " ".join(f"{(ph[i + 1] - ph[i]) / 100:.1f}" for i in range(16, 21)) + "\n")
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -154,9 +154,14 @@ int			ndbhip_set_scan_mode(int mode);
  *                             norms; sublists regrouped in that space); 0: the round-1 fp32 screen
  *   "screen16_cosine_centered" 1  ... as the centred L2 sweep (|q^ - x^|^2 = 2 x cosine distance); 0: as the inner product of
  *                             two-plane normalised rows
+ *   "screen16_ip_centered" 1  inner-product batches run the centred one-plane sweep over the L2 layout's planes (b = |q - x|^2 + M^2 - |x|^2
+ *                             orders a query's rows like -q.x; fp32 and fp16 mirrors); 0: the two-plane sweep of round 2
  *   "screen16_redo"     1     queries whose records / survivors overflow go to the exact path alone (0: their whole batch does)
  *   "screen16_slack"    1     the centred planes keep spare 32-row blocks per bucket and take appends in place (0: every append lays them out again)
  *   "screen_min_nq"     32    batches of at least this many queries take the screened (matrix-core) scan; smaller ones the exact grouped scan
+ *   "screen16_stage"    1     k_s16_finalize's survivors and k_cent_select's candidate centroids get the reference's sequential sum from rows
+ *                             streamed through LDS by DMA (s16_exact_staged: a chunk of 256 bytes per row, several chunks ahead) instead of
+ *                             rows loaded 16 bytes at a time by the lane that sums them; 0 = off, 2..13 = that ring depth (1: by batch size)
  *   "screen16c_nbuf"    0     ring depth of the centred sweep: 2 | 3, 0 = the tile geometry's default
  *   "screen16c_dense"   1     the dense tile (256 pairs x 256 rows) runs k_s16c_dense (csrc/ndbhip_screen16d.h: loader and prefetcher
  *                             waves, chunk-major pair planes, the matrix pipe screens its own accumulator blocks, queued records);
@@ -199,6 +204,9 @@ int			ndbhip_mfma_probe(const uint16_t *d_a, const uint16_t *d_b, const float *d
  * csrc/ndbhip_screen16c.h "pass 0"): per tile t, D = C + A.B with A [ntiles][32][2], B [ntiles][2][32],
  * C, D [ntiles][32][32] floats. */
 int			ndbhip_mfma_probe_f32(const float *d_a, const float *d_b, const float *d_c, float *d_d, int ntiles);
+/* Profiling builds of the library (make PHASES=1: -DNDB_PHASES) stamp a 100 MHz clock at marked places of the per-batch
+ * kernels (block 0 only); this copies the 64 stamps to out (zeros from an ordinary build).  tools/phase_probe.py */
+int			ndbhip_debug_phases(unsigned long long *out);
 
 /* ------------------------------------------------------------------ */
 /* IVF mirror lifecycle.  Replaces the page walk of ivfSelectClusters /

@@ -156,6 +156,7 @@ def lib():
         "ndbhip_set_option": (i, [C.c_char_p, i]),
         "ndbhip_mfma_probe": (i, [vp, vp, vp, vp, i, i]),
         "ndbhip_mfma_probe_f32": (i, [vp, vp, vp, vp, i]),
+        "ndbhip_debug_phases": (i, [vp]),
         "ndbhip_gen_rows_device": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),
         "ndbhip_gen_rows_host": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),
         "ndbhip_ivf_create": (i, [i, i, C.POINTER(vp)]),

@@ -2992,6 +2992,8 @@ static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sw
 static uint32_t g_s16_ecap = 8192;
 static int	g_probe_sel_radix = 0;	/* batches of >= 512 queries: radix select instead of the full LDS sort ("probe_select_radix") */
 static int	g_probe_sel_threads = 256;	/* threads of a k_probe_select block for batches of >= 512 queries ("probe_select_threads") */
+static int	g_s16_stage = 1;		/* "screen16_stage": 0 = every lane loads the row it sums (k_s16_finalize, k_cent_select); 1 = rows
+									 * streamed through LDS (s16_exact_staged), ring depth by batch size; n >= 2 = that depth */
 static int	g_s16_fin_threads = 64;	/* threads of a k_s16_finalize block (one block per query; "screen16_fin_threads": 64 / 128 / 256) */
 static int	g_s16_prune = 1;	/* (query, list) pairs excluded by |q - centroid| - list radius before the sweep ("screen16_prune") */
 static int	g_s16_tighten = 1;	/* thresholds tightened inside the sweep (ndbhip_set_option("screen16_tighten", 0): only between the rounds) */
@@ -3532,12 +3534,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 #define S16C_SEED_L(SUBB, ...)                                                                                          \
 	do {                                                                                                                \
-		if (ipc && H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 1>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
-		else if (ipc && H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 2>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
-		else if (ipc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 0>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__);     \
-		else if (H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 1>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
-		else if (H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 2>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__); \
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 0>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__);             \
+		if (ipc && H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 1>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else if (ipc && H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 2>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else if (ipc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 0>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);     \
+		else if (H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 1>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else if (H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 2>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 0>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);             \
 	} while (0)
 	if (!seed_by_sublist && cen && !xseed)
 		S16C_SEED_L(false, d, d_q, w_probes, lco, npr,
@@ -3687,7 +3689,21 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 	/* a shard's finalize decides with the k-th LOCAL bound, looser than the whole index's: four times the room */
 	const uint32_t surv_cap = partial ? 4u * S16_SURV_CAP : (uint32_t) S16_SURV_CAP;
-	const size_t fsmem = topk_smem_bytes(surv_cap, (uint32_t) k);
+	/* the survivors' rows through LDS (s16_exact_staged) for a small batch, which has a CU to itself: 8 chunks deep for up to
+	 * 16 survivors, 64-row slots for more.  A large batch lives on 16 blocks per CU overlapping each other's phases, and the
+	 * ring's LDS would halve them (measured at 4096 queries: 128 us with a 10 KB ring, 103 us without) */
+	const size_t fsmem0 = (topk_smem_bytes(surv_cap, (uint32_t) k) + 15) & ~(size_t) 15;
+	const size_t fin_room = fsmem0 < 65536 ? 65536 - fsmem0 : 0;	/* (within the 64 KB a kernel gets unasked) */
+	const bool	fin_ok = g_s16_stage && s16_staged_ok(ix->dim, ix->f16 ? 1 : 0);
+	const bool	fin_small = nq <= 512;
+	int			fin_nbuf = (fin_ok && (fin_small || g_s16_stage >= 2)) ? s16_staged_nbuf(1, g_s16_stage >= 2 ? g_s16_stage : 8) : 0;
+	int			fin_nbuf4 = (fin_ok && fin_small) ? s16_staged_nbuf(4, g_s16_stage >= 2 ? g_s16_stage : 3) : 0;
+
+	fin_nbuf = std::min(fin_nbuf, (int) (fin_room / S16X_SLOT(1)));
+	fin_nbuf4 = std::min(fin_nbuf4, (int) (fin_room / S16X_SLOT(4)));
+	if (fin_nbuf < 2) fin_nbuf = 0;
+	if (fin_nbuf4 < 2) fin_nbuf4 = 0;
+	const size_t fsmem = fsmem0 + std::max((size_t) fin_nbuf * S16X_SLOT(1), (size_t) fin_nbuf4 * S16X_SLOT(4));
 	unsigned int over = 0, over_n = 0, fl8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool		over_pairs = false;
 
@@ -3975,11 +3991,17 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				  sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
 
-#define S16_FIN_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__)
+#define S16_FIN_L(RR, HH, ...)                                                                                                      \
+	do {                                                                                                                            \
+		if (fin_nbuf || fin_nbuf4)                                                                                                  \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH, true>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__); \
+		else                                                                                                                        \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_finalize<RR, HH, false>), dim3(nq), dim3(g_s16_fin_threads), fsmem, g.stream, __VA_ARGS__); \
+	} while (0)
 	S16_BY_RH(S16_FIN_L, d, d_q, w_probes, (const uint32_t *) ix->w_candoff, lco, npr, (uint32_t) k,
 			  (const float2 *) ix->w_qthr, (const unsigned int *) ecount, (const uint2 *) ix->w_erec, ecap, partial,
 			  d_cand, d_ncand, d_total, d_otid, d_odist, d_ocnt, surv, flags, cen ? (const float *) ix->w_eub : (const float *) nullptr,
-			  surv_cap, ix->w_overq, ipc ? (const float *) ix->w_qev : (const float *) nullptr);
+			  surv_cap, ix->w_overq, ipc ? (const float *) ix->w_qev : (const float *) nullptr, fin_nbuf, fin_nbuf4);
 		HIP_TRY(hipGetLastError());
 		{
 			unsigned int f[8];
@@ -4172,6 +4194,22 @@ ndbhip_mfma_probe_f32(const float *d_a, const float *d_b, const float *d_c, floa
 	return NDBHIP_OK;
 }
 
+/* profiling builds (-DNDB_PHASES): the 64 clock stamps of block 0 (100 MHz); otherwise zeros */
+extern "C" int
+ndbhip_debug_phases(unsigned long long *out)
+{
+	if (!out)
+		return fail(NDBHIP_ERR_INVALID, "ndbhip_debug_phases: out is NULL");
+#ifdef NDB_PHASES
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phases), 64 * sizeof(unsigned long long)));
+#else
+	memset(out, 0, 64 * sizeof(unsigned long long));
+#endif
+	return NDBHIP_OK;
+}
+
+
 extern "C" int
 ndbhip_set_option(const char *name, int value)
 {
@@ -4218,6 +4256,12 @@ ndbhip_set_option(const char *name, int value)
 		if (value != 64 && value != 128 && value != 256)
 			return fail(NDBHIP_ERR_INVALID, "screen16_fin_threads must be 64, 128 or 256");
 		g_s16_fin_threads = value;
+	}
+	else if (!strcmp(name, "screen16_stage"))
+	{
+		if (value < 0 || value > 13)
+			return fail(NDBHIP_ERR_INVALID, "screen16_stage must be 0 .. 13");
+		g_s16_stage = value;
 	}
 	else if (!strcmp(name, "screen16_prune"))
 		g_s16_prune = value != 0;
@@ -4526,18 +4570,43 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			ix->bat_subdist = ix->w_amat + ncmp;
 			ix->bat_sstride = astride;
 		}
-#define CENT_SELECT_L(PER)                                                                                          \
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cent_select<PER>), dim3(nq), dim3(64), 0, g.stream, (const float *) ix->w_amat, astride, \
+#define CENT_SELECT_L(PER, ST)                                                                                      \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cent_select<PER, ST>), dim3(nq), dim3(64), (size_t) cs_nbuf * S16X_SLOT(4), g.stream, (const float *) ix->w_amat, astride, \
 						   cq_n2, (const uint32_t *) cm.xmax, d_q, (const float *) d.centroids, ix->dim, \
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,                          \
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->w_cdist, cstride, w_probes, ix->w_candoff, \
-						   lco_w, ix->w_cfull)
-		if (ncmp <= 1024)
-			CENT_SELECT_L(16);
+						   lco_w, ix->w_cfull, cs_nbuf)
+		/* the candidates' centroids through LDS while a CU has few queries to work on (4 chunks deep: 68 KB a block); a large
+		 * batch keeps its 16 blocks per CU (measured: 3 staged blocks a CU took 238 us where 16 lane-per-row ones take 84) */
+		const int	cs_nbuf = (g_s16_stage && s16_staged_ok(ix->dim, 0) && (nq <= 512 || g_s16_stage >= 2))
+			? s16_staged_nbuf(4, g_s16_stage >= 2 ? g_s16_stage : 4) : 0;
+
+		{
+			static bool cs_attr = false;	/* static + dynamic LDS beyond 64 KB has to be asked for */
+
+			if (!cs_attr)
+			{
+				HIP_TRY(hipFuncSetAttribute((const void *) k_cent_select<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * S16X_SLOT(4)));
+				HIP_TRY(hipFuncSetAttribute((const void *) k_cent_select<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * S16X_SLOT(4)));
+				HIP_TRY(hipFuncSetAttribute((const void *) k_cent_select<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * S16X_SLOT(4)));
+				cs_attr = true;
+			}
+		}
+		if (cs_nbuf)
+		{
+			if (ncmp <= 1024)
+				CENT_SELECT_L(16, true);
+			else if (ncmp <= 2048)
+				CENT_SELECT_L(32, true);
+			else
+				CENT_SELECT_L(64, true);
+		}
+		else if (ncmp <= 1024)
+			CENT_SELECT_L(16, false);
 		else if (ncmp <= 2048)
-			CENT_SELECT_L(32);
+			CENT_SELECT_L(32, false);
 		else
-			CENT_SELECT_L(64);
+			CENT_SELECT_L(64, false);
 		/* (a query with too many near-ties, or fewer than nprobe finite bounds, had all its distances computed
 		 * exactly and is selected the old way) */
 		hipLaunchKernelGGL(k_probe_select, dim3(nq), dim3(256), 0, g.stream, (const float *) ix->w_cdist, cstride,

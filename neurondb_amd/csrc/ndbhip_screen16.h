@@ -978,6 +978,216 @@ s16c_ip_t_from_ub(float ub, float ev)
 	return s16_up(s16_up(fmaxf(ub, 0.0f)) + 4.0f * ev);
 }
 
+typedef __attribute__((address_space(3))) void *ndb_lds_ptr;
+
+/* -DNDB_PHASES (profiling builds only): block 0's first lane stamps the 100 MHz clock at marked places of the per-batch
+ * kernels; ndbhip_debug_phases() reads the stamps (tools/phase_probe.py) */
+#ifdef NDB_PHASES
+__device__ unsigned long long g_phases[64];
+#define NDB_PHASE(I) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phases[I] = wall_clock64(); } while (0)
+#else
+#define NDB_PHASE(I) ((void) 0)
+#endif
+
+template <int N> __device__ __forceinline__ void
+s16_wait_vm()
+{
+	static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+/* wait until all but the newest `ahead` chunks' requests (IPC instructions each) have landed; ahead * IPC <= 63 */
+template <int IPC, int K> __device__ __forceinline__ void
+s16_wait_vm_k()
+{
+	if constexpr (K * IPC < 64)
+		s16_wait_vm<K * IPC>();
+	else
+		s16_wait_vm<0>();
+}
+template <int IPC> __device__ __forceinline__ void
+s16_wait_vm_chunks(int ahead)
+{
+	switch (ahead)
+	{
+		case 1: s16_wait_vm_k<IPC, 1>(); break;
+		case 2: s16_wait_vm_k<IPC, 2>(); break;
+		case 3: s16_wait_vm_k<IPC, 3>(); break;
+		case 4: s16_wait_vm_k<IPC, 4>(); break;
+		case 5: s16_wait_vm_k<IPC, 5>(); break;
+		case 6: s16_wait_vm_k<IPC, 6>(); break;
+		case 7: s16_wait_vm_k<IPC, 7>(); break;
+		case 8: s16_wait_vm_k<IPC, 8>(); break;
+		case 9: s16_wait_vm_k<IPC, 9>(); break;
+		case 10: s16_wait_vm_k<IPC, 10>(); break;
+		case 11: s16_wait_vm_k<IPC, 11>(); break;
+		case 12: s16_wait_vm_k<IPC, 12>(); break;
+		default: s16_wait_vm<0>(); break;
+	}
+}
+
+/* 16 bytes per lane from 64 unrelated addresses to la + 16 lane */
+__device__ __forceinline__ void
+s16_dma16_at(const unsigned char *p, uint32_t la)
+{
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+				 :: "s"(la), "v"(p) : "memory");
+}
+
+/*
+ * The reference's sequential arithmetic for up to 16 NG rows per wave, one lane per row, with the rows STREAMED through
+ * LDS instead of loaded by the lane that sums them.  A lane that reads its own row asks for 16 bytes of 64 different
+ * lines per instruction and then waits for them before its next 4 (fp16: 8) steps: a batch of 256 queries spent 0.12 ms
+ * in k_s16_finalize and 0.095 ms in k_cent_select on 1536 dimensions — a chain of ~200 memory round trips — and a
+ * batch of 4096 is bound by the 16-byte requests themselves.  Here the wave copies a CHUNK (256 bytes of every row: 64
+ * floats or 128 halves) per step by LDS DMA, 4 lanes per row and instruction (64 contiguous bytes of 16 rows), nbuf - 1
+ * chunks ahead of the one being summed, and the query's chunk with it; the lanes then read their row from LDS
+ * (16-byte units, swizzled by the row so that the 16 rows of a group fall into different banks).
+ *   rowp  this lane's row (lanes without one: any readable row, e.g. the wave's first; their result means nothing)
+ *   qq    the query (wave-uniform), dim floats
+ *   row bytes must be a multiple of 16 (dim % 4 == 0; fp16: dim % 8 == 0) and rows 16-byte aligned: s16_staged_ok
+ *   ring  the wave's LDS ring, nbuf * S16X_SLOT(NG) bytes, 16-byte aligned; nbuf >= 2, (nbuf - 1) * (4 NG + 1) <= 63
+ * Every lane of the wave calls it (uniform control flow).  The sum is Acc<R>'s: the same steps in the same order as
+ * scr_exact / scr_exact_h, bit for bit.
+ */
+#define S16X_SLOT(NG) ((4 * (NG) + 1) * 1024)
+__host__ __device__ __forceinline__ bool
+s16_staged_ok(int dim, int h16)
+{
+	return h16 ? (dim % 8) == 0 : (dim % 4) == 0;
+}
+__host__ __device__ __forceinline__ int
+s16_staged_nbuf(int ng, int want)
+{
+	const int	most = 63 / (4 * ng + 1) + 1;
+
+	return want < 2 ? 2 : (want > most ? most : want);
+}
+
+template <int R, int H16, int NG>
+__device__ __forceinline__ float
+s16_exact_staged(const float *__restrict__ qq, const unsigned char *rowp, int dim, unsigned char *ring, int nbuf)
+{
+	constexpr int IPC = 4 * NG + 1;				/* DMA instructions per chunk */
+	constexpr int CD = H16 ? 128 : 64;			/* dimensions per chunk */
+	constexpr int UD = H16 ? 8 : 4;				/* ... per 16-byte unit of a row */
+	const int	lane = threadIdx.x & 63;
+	const uint32_t ring_la = (uint32_t) (uintptr_t) (ndb_lds_ptr) ring;
+	const uint32_t rowbytes = (uint32_t) dim * (H16 ? 2u : 4u);
+	const int	nchunk = (dim + CD - 1) / CD;
+	/* the rows this lane copies from: row 16 g + lane / 4 for g = 0 .. NG - 1, unit (lane & 3) ^ swizzle of every piece */
+	const unsigned char *src[NG];
+	const uint32_t cu16 = (uint32_t) ((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+
+#pragma unroll
+	for (int g = 0; g < NG; g++)
+	{
+		const uint64_t v = (uint64_t) rowp;
+		const int	from = 16 * g + (lane >> 2);
+		const uint32_t lo = (uint32_t) __shfl((int) (uint32_t) v, from, 64), hi = (uint32_t) __shfl((int) (uint32_t) (v >> 32), from, 64);
+
+		src[g] = (const unsigned char *) (((uint64_t) hi << 32) | lo);
+	}
+	const unsigned char *qb = (const unsigned char *) qq;
+	const uint32_t qbytes = (uint32_t) dim * 4u;
+
+	int			si = 0;					/* ring slot of the next chunk to request */
+	auto		issue = [&](int c) {
+		const uint32_t la = ring_la + (uint32_t) si * (uint32_t) S16X_SLOT(NG);
+
+		si = si + 1 == nbuf ? 0 : si + 1;
+
+#pragma unroll
+		for (int g = 0; g < NG; g++)
+#pragma unroll
+			for (int p = 0; p < 4; p++)
+			{
+				uint32_t	off = (uint32_t) c * 256u + (uint32_t) p * 64u + cu16;
+
+				off = off < rowbytes ? off : 0u;		/* beyond the row: anything readable, never looked at */
+				s16_dma16_at(src[g] + off, la + (uint32_t) (g * 4 + p) * 1024u);
+			}
+		{
+			uint32_t	off = (uint32_t) c * (uint32_t) (CD * 4) + (uint32_t) lane * 16u;
+
+			off = ((uint32_t) lane * 16u < (uint32_t) (CD * 4) && off < qbytes) ? off : 0u;
+			s16_dma16_at(qb + off, la + (uint32_t) NG * 4096u);
+		}
+	};
+
+	for (int c = 0; c < nbuf - 1 && c < nchunk; c++)
+		issue(c);
+	Acc<R>		acc;
+	const int	g_me = lane >> 4, rr = lane & 15, sw = (rr >> 2) & 3;
+	int			sc = 0;					/* ring slot of chunk c */
+
+	for (int c = 0; c < nchunk; c++)
+	{
+		if (c + nbuf - 1 < nchunk)
+		{
+			issue(c + nbuf - 1);			/* into the slot of chunk c - 1: its reads were consumed by the sums above */
+			s16_wait_vm_chunks<IPC>(nbuf - 1);
+		}
+		else
+			s16_wait_vm<0>();
+		const unsigned char *slot = ring + (size_t) sc * S16X_SLOT(NG);
+
+		sc = sc + 1 == nbuf ? 0 : sc + 1;
+		const unsigned char *mine = slot + (NG > 1 ? g_me * 4096 : 0) + rr * 64;
+		const unsigned char *qs = slot + NG * 4096;
+		const int	d0 = c * CD;
+
+		/* (a whole chunk inside the row: no test between the units, so that their LDS reads are issued together) */
+		auto		sum_chunk = [&](auto whole) {
+#pragma unroll
+			for (int p = 0; p < 4; p++)
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					const int	d = d0 + (p * 4 + u) * UD;
+
+					if (!decltype(whole)::value && d >= dim)		/* uniform */
+						continue;
+					const float4 raw = *reinterpret_cast<const float4 *>(mine + p * 1024 + ((u ^ sw) * 16));
+
+					if constexpr (H16 != 0)
+					{
+						const float4 q0 = *reinterpret_cast<const float4 *>(qs + (p * 4 + u) * 32);
+						const float4 q1 = *reinterpret_cast<const float4 *>(qs + (p * 4 + u) * 32 + 16);
+						float		v[8];
+
+						decode8<H16 == 1>(raw, v);
+						acc.step(q0.x, v[0]);
+						acc.step(q0.y, v[1]);
+						acc.step(q0.z, v[2]);
+						acc.step(q0.w, v[3]);
+						acc.step(q1.x, v[4]);
+						acc.step(q1.y, v[5]);
+						acc.step(q1.z, v[6]);
+						acc.step(q1.w, v[7]);
+					}
+					else
+					{
+						const float4 q0 = *reinterpret_cast<const float4 *>(qs + (p * 4 + u) * 16);
+
+						acc.step(q0.x, raw.x);
+						acc.step(q0.y, raw.y);
+						acc.step(q0.z, raw.z);
+						acc.step(q0.w, raw.w);
+					}
+				}
+		};
+
+		if (d0 + CD <= dim)
+			sum_chunk(std::true_type{});
+		else
+			sum_chunk(std::false_type{});
+		/* (the compiler must not start the next chunk's reads before the wait, nor hold this chunk's past the refill) */
+		asm volatile("" ::: "memory");
+	}
+	return acc.fin();
+}
+
 /*
  * ivfSelectClusters (src/index/ivf_am.c:1597-1717) for a batch, screened: amat[q][c] = a ~ |q - centroid c|^2 from
  * the two-plane sweep's MODE 3 (s16mat_run over the centroids' planes; |a - D| <= E = s16_e(dim, |q|^2, largest
@@ -994,14 +1204,16 @@ s16c_ip_t_from_ub(float ub, float ev)
 #define NDB_CSEL_CAP 256
 #define S16_OVER_CAP 512		/* queries of a batch that may go to the exact path on their own (more: the whole batch does) */
 
-template <int PER>
+template <int PER, bool STAGED = false /* the candidates' centroids come through LDS (dynamic: stage_nbuf slots, NG = 4) */>
 __global__ __launch_bounds__(64) void
 k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__restrict__ qn2, const uint32_t *__restrict__ cmax_bits,
 			  const float *__restrict__ queries, const float *__restrict__ cents, int dim, int ncmp, int ncent, int npr,
 			  const uint32_t *__restrict__ glob_len, const uint32_t *__restrict__ own_lo, const uint32_t *__restrict__ own_len,
 			  uint64_t cap, float *__restrict__ cdist, uint32_t cstride, int *__restrict__ probes,
-			  uint32_t *__restrict__ cand_off, uint32_t *__restrict__ loc_cand_off, uint8_t *__restrict__ full)
+			  uint32_t *__restrict__ cand_off, uint32_t *__restrict__ loc_cand_off, uint8_t *__restrict__ full,
+			  int stage_nbuf = 0 /* STAGED: slots of the ring */ )
 {
+	extern __shared__ __attribute__((aligned(16))) unsigned char csel_ring[];
 	__shared__ uint32_t s_idx[NDB_CSEL_CAP], s_key[NDB_CSEL_CAP];
 	__shared__ int s_sel[NDBHIP_MAX_NPROBE];
 	__shared__ uint32_t s_len[NDBHIP_MAX_NPROBE];
@@ -1013,6 +1225,8 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 	const float e = s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cmax_bits), false);
 	const float m = ndb_s16_refslack(dim);
 	uint32_t	ub[PER], lb[PER];
+
+	NDB_PHASE(0);
 
 #pragma unroll
 	for (int j = 0; j < PER; j++)
@@ -1034,25 +1248,31 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 	 * with #(ub < v) < npr_eff */
 	uint32_t	U = 0;
 
+	NDB_PHASE(1);
+
 	if (npr_eff > 0)
 	{
 		for (int bit = 30; bit >= 0; bit--)
 		{
 			const uint32_t t = U | (1u << bit);
-			uint32_t	n = 0;
+			uint32_t	mine = 0, n = 0;
 
 #pragma unroll
 			for (int j = 0; j < PER; j++)
-				n += ub[j] < t ? 1u : 0u;
+				mine += ub[j] < t ? 1u : 0u;
+			/* the wave's total, bit by bit on the scalar side (mine <= PER <= 64: 7 independent ballots instead of six
+			 * dependent cross-lane steps) */
 #pragma unroll
-			for (int off = 32; off > 0; off >>= 1)
-				n += (uint32_t) __shfl_xor((int) n, off, 64);
+			for (int b = 0; b < 7; b++)
+				n += (uint32_t) __popcll(__ballot((mine >> b) & 1u)) << b;
 			if (n < (uint32_t) npr_eff)
 				U = t;
 		}
 	}
 	/* the candidates, in index order */
 	uint32_t	total = 0;
+
+	NDB_PHASE(2);
 
 #pragma unroll
 	for (int j = 0; j < PER; j++)
@@ -1079,11 +1299,20 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 		return;
 	}
 	__syncthreads();
-	for (uint32_t i = lane; i < total; i += 64)
+	NDB_PHASE(3);
+	for (uint32_t i0 = 0; i0 < total; i0 += 64)		/* uniform */
 	{
-		const uint32_t c = s_idx[i];
-		const float v = scr_exact<R_IVF_L2>(qq, cents + (size_t) c * dim, dim);
+		const uint32_t i = i0 + lane;
+		const uint32_t c = s_idx[i < total ? i : 0];
+		float		v = 0.0f;
 
+		if constexpr (STAGED)
+			v = s16_exact_staged<R_IVF_L2, 0, 4>(qq, (const unsigned char *) (cents + (size_t) c * dim), dim, csel_ring, stage_nbuf);
+		else if (i < total)
+			v = scr_exact<R_IVF_L2>(qq, cents + (size_t) c * dim, dim);
+
+		if (i >= total)
+			continue;
 		cdist[(size_t) q * cstride + c] = v;
 		/* valid = strictly below FLT_MAX (bestDist starts at FLT_MAX: ivf_am.c:1689, 1706); the others never win */
 		s_key[i] = v < FLT_MAX ? ndb_key_from_bits(__float_as_uint(v)) : 0xFFFFFFFFu;
@@ -1091,6 +1320,8 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 	__syncthreads();
 	/* rank of every valid candidate by (distance, index); the list is in index order, so ties go to the earlier slot */
 	uint32_t	nvalid = 0;
+
+	NDB_PHASE(4);
 
 	for (uint32_t i = lane; i < total; i += 64)
 		nvalid += s_key[i] != 0xFFFFFFFFu ? 1u : 0u;
@@ -1117,6 +1348,7 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 			s_sel[rank] = (int) s_idx[i];
 	}
 	__syncthreads();
+	NDB_PHASE(5);
 	const bool	in_lds = npr <= NDB_CSEL_CAP;
 
 	for (int i = lane; i < npr; i += 64)
@@ -1143,6 +1375,7 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 		}
 	}
 	__syncthreads();
+	NDB_PHASE(6);
 	if (lane == 0)
 	{
 		uint64_t	acc = 0, mine = 0;
@@ -1173,6 +1406,7 @@ k_cent_select(const float *__restrict__ amat, uint32_t astride, const float *__r
 				lco[i + 1] = (uint32_t) mine;
 		}
 	}
+	NDB_PHASE(7);
 }
 
 /*
@@ -1417,7 +1651,6 @@ template <int H16, int NW> struct S16Geom
 	static constexpr int PER = ROW_DMA + Q_DMA;
 };
 
-typedef __attribute__((address_space(3))) void *ndb_lds_ptr;
 typedef const __attribute__((address_space(1))) void *ndb_glb_ptr;
 
 /*
@@ -1477,12 +1710,6 @@ s16_uniform_ptr(const unsigned char *p)
 	return (const unsigned char *) (((uint64_t) hi << 32) | lo);
 }
 
-template <int N> __device__ __forceinline__ void
-s16_wait_vm()
-{
-	static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-	asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
 
 /* one work item of the sweep, expanded once per batch (k_s16_items) so that a block finds its next item with one
  * load instead of a binary search over the lists */
@@ -2305,7 +2532,7 @@ k_s16_retarget(int dim, uint32_t k, float2 *__restrict__ qthr, unsigned int *__r
  * Finalize: one block per query.  rec_counts[q] = survivors rescored (statistics); flags[0] != 0 when some query
  * overflowed its records or its survivor list (the host then reruns the batch on the older path).
  */
-template <int R, int H16>
+template <int R, int H16, bool STAGED = false /* small batches: the survivors' rows come through LDS (stage_nbuf, stage_nbuf4) */>
 __global__ __launch_bounds__(256) void
 k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 			   const uint32_t *__restrict__ cand_off, const uint32_t *__restrict__ loc_cand_off, int npr,
@@ -2322,10 +2549,14 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 			   uint32_t *__restrict__ over_q = nullptr /* [S16_OVER_CAP] the queries counted in flags[0]: what the host
 														* hands to the exact path one by one instead of the whole batch */,
 			   const float *__restrict__ qev = nullptr /* inner product on the centred sweep: ev per query (s16c_ip_ev); the
-														 * records' bounds and the threshold are in b's domain */ )
+														 * records' bounds and the threshold are in b's domain */,
+			   int stage_nbuf = 0 /* > 0: up to 16 survivors' rows are streamed through a ring of that many chunk slots behind
+								   * the top-k arrays (s16_exact_staged, NG = 1; the host checked s16_staged_ok) */,
+			   int stage_nbuf4 = 0 /* > 0: more than 16 go 64 at a time through that many 64-row slots (NG = 4) */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	TopkSmem	s = carve_topk_smem(smem_raw, surv_cap, k);
+	unsigned char *stage_ring = smem_raw + ((topk_smem_bytes(surv_cap, k) + 15) & ~(size_t) 15);
 	const uint32_t q = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t *co = cand_off + (size_t) q * (npr + 1);
@@ -2346,6 +2577,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 		}
 		return;					/* uniform */
 	}
+	NDB_PHASE(16);
 	const uint2 *rec = erec + (size_t) q * ecap;	/* a few hundred records, read from L2 as often as needed */
 	const float *ubq = eub ? eub + (size_t) q * ecap : nullptr;
 	float		thrE = qthr[q].x;
@@ -2377,6 +2609,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 				thrE = fminf(thrE, s16_thr_from_a<R>(__uint_as_float(tb), e, dim));
 		}
 	}
+	NDB_PHASE(17);
 	if (tid == 0)
 		s.sh[0] = 0;
 	__syncthreads();
@@ -2410,27 +2643,75 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	}
 	if (tid == 0)
 		rec_counts[q] = ns;
+	NDB_PHASE(18);
 	/* the reference's arithmetic for every survivor: one lane per candidate */
-	for (uint32_t j = tid; j < ns; j += blockDim.x)
-	{
-		const uint32_t i = s.e_pos[j];
-		const uint32_t p = find_probe(lco, npr, i);
-		const int	L = probes[(size_t) q * npr + p];
-		const size_t row = (size_t) ix.loc_off[L] + (i - lco[p]);
-		float		v;
+	/* ... their rows streamed through LDS (first wave): up to 16 with 4 lanes copying per row and the deep ring, up to 64
+	 * in one pass when the ring has room for 64-row slots (small batches: LDS is free); otherwise every lane loads the row
+	 * it sums, below */
+	const bool	st1 = STAGED && stage_nbuf > 0 && ns <= 16, st4 = STAGED && stage_nbuf4 > 0 && !st1;
 
-		if constexpr (H16 != 0)
-			v = scr_exact_h<R, H16 == 1>(queries + (size_t) q * dim, (const uint16_t *) ix.vecs + row * (size_t) dim, dim);
-		else
-			v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + row * (size_t) dim, dim);
-		s.e_bits[j] = __float_as_uint(v);
-		s.e_id[j] = ix.tids[row];
-		s.e_pos[j] = co[p] + ix.own_lo[L] + (i - lco[p]);
+	if (st1 || st4)
+	{
+		const uint32_t per = st1 ? 16u : 64u;
+
+		if (tid < 64)
+			for (uint32_t j0 = 0; j0 < ns; j0 += per)		/* uniform */
+			{
+				const uint32_t j = j0 + tid;
+				const bool	mine = tid < per && j < ns;
+				uint32_t	i = 0, p = 0;
+				int			L = 0;
+				size_t		row = 0;
+
+				if (mine)
+				{
+					i = s.e_pos[j];
+					p = find_probe(lco, npr, i);
+					L = probes[(size_t) q * npr + p];
+					row = (size_t) ix.loc_off[L] + (i - lco[p]);
+				}
+				/* (lane 0 always has a row here: the others' copies read it again) */
+				const uint32_t r0lo = (uint32_t) __shfl((int) (uint32_t) row, 0, 64), r0hi = (uint32_t) __shfl((int) (uint32_t) ((uint64_t) row >> 32), 0, 64);
+				const size_t rsrc = mine ? row : (size_t) (((uint64_t) r0hi << 32) | r0lo);
+				const unsigned char *rp = (const unsigned char *) ix.vecs + rsrc * (size_t) dim * (H16 != 0 ? 2 : 4);
+				float		v = 0.0f;
+
+				if constexpr (STAGED)
+					v = st1 ? s16_exact_staged<R, H16, 1>(queries + (size_t) q * dim, rp, dim, stage_ring, stage_nbuf)
+						: s16_exact_staged<R, H16, 4>(queries + (size_t) q * dim, rp, dim, stage_ring, stage_nbuf4);
+
+				if (mine)
+				{
+					s.e_bits[j] = __float_as_uint(v);
+					s.e_id[j] = ix.tids[row];
+					s.e_pos[j] = co[p] + ix.own_lo[L] + (i - lco[p]);
+				}
+			}
 	}
+	else
+		for (uint32_t j = tid; j < ns; j += blockDim.x)
+		{
+			const uint32_t i = s.e_pos[j];
+			const uint32_t p = find_probe(lco, npr, i);
+			const int	L = probes[(size_t) q * npr + p];
+			const size_t row = (size_t) ix.loc_off[L] + (i - lco[p]);
+			float		v;
+
+			if constexpr (H16 != 0)
+				v = scr_exact_h<R, H16 == 1>(queries + (size_t) q * dim, (const uint16_t *) ix.vecs + row * (size_t) dim, dim);
+			else
+				v = scr_exact<R>(queries + (size_t) q * dim, ix.vecs + row * (size_t) dim, dim);
+			s.e_bits[j] = __float_as_uint(v);
+			s.e_id[j] = ix.tids[row];
+			s.e_pos[j] = co[p] + ix.own_lo[L] + (i - lco[p]);
+		}
 	__syncthreads();
+	NDB_PHASE(19);
 	uint32_t	kk;
 	const uint32_t npad = next_pow2(ns > 0 ? ns : 1);
 	const uint32_t cut = block_sort_cut(s.e_bits, s.e_pos, ns, npad, k, partial ? (uint64_t) ns : (uint64_t) gtotal, s.fs, kk);
+
+	NDB_PHASE(20);
 
 	if (partial)
 	{
@@ -2453,6 +2734,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
 	}
 	block_replay_emit(s.e_bits, s.e_id, cut, kk, s.fs, out_tids + (size_t) q * k, out_dist + (size_t) q * k,
 					  out_count + q);
+	NDB_PHASE(21);
 }
 
 /*

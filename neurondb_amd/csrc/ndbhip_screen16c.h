@@ -336,8 +336,9 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
  * |q - c|^2) / 2 (cn2_sub / cn2_list: the centres' norms).  H16: the mirror's rows are fp16 (decoded like the reference
  * decodes them).
  */
+#define S16C_SEED_THREADS 256	/* 4 waves a query: one wave alone was 0.33 ms of dependent loads for 256 queries on 10M rows */
 template <bool SUB, bool IP = false, int H16 = 0 /* 0: float4 rows; 1: fp16 decoded like the reference (quirk Q20); 2: fp16 without subnormals (the plain conversion is the reference's) */>
-__global__ __launch_bounds__(64) void
+__global__ __launch_bounds__(S16C_SEED_THREADS) void
 k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 			const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, uint32_t ns,
 			const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
@@ -349,7 +350,8 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr /* IP: |c|^2 */ )
 {
 	const uint32_t q = blockIdx.x;
-	const int	lane = threadIdx.x;
+	const int	lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	constexpr int NW = S16C_SEED_THREADS / 64;
 	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
 	const int	dim = ix.dim;
 	const float *qq = queries + (size_t) q * dim;
@@ -362,8 +364,8 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 		uint32_t	bs = 0xFFFFFFFFu, bp = 0;
 		/* the (probe, sublist) candidates of 64 probes at a time laid end to end and dealt to the lanes (as in
 		 * k_sub_pairs: walking the probes one after the other was 32 dependent trips of mostly idle lanes) */
-		__shared__ uint32_t s_off[65], s_s0[64];
-		__shared__ float s_pd[64];
+		__shared__ uint32_t s_off[65], s_s0[64], s_bs[NW], s_bp[NW];
+		__shared__ float s_pd[64], s_bd[NW];
 
 		for (int p0 = 0; p0 < npr; p0 += 64)
 		{
@@ -393,15 +395,18 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				if (lane >= off)
 					inc += v;
 			}
-			s_off[lane] = inc - n;
-			s_s0[lane] = s0;
-			s_pd[lane] = pd;
 			const uint32_t T = (uint32_t) __shfl((int) inc, 63, 64);
 
-			if (lane == 0)
-				s_off[64] = T;
-			__builtin_amdgcn_wave_barrier();
-			for (uint32_t t = (uint32_t) lane; t < T; t += 64)
+			if (wv == 0)			/* (every wave holds the same values) */
+			{
+				s_off[lane] = inc - n;
+				s_s0[lane] = s0;
+				s_pd[lane] = pd;
+				if (lane == 0)
+					s_off[64] = T;
+			}
+			__syncthreads();
+			for (uint32_t t = threadIdx.x; t < T; t += S16C_SEED_THREADS)
 			{
 				int			lo = 0, hi = 64;
 
@@ -433,7 +438,7 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 					bp = (uint32_t) (p0 + lo);
 				}
 			}
-			__builtin_amdgcn_wave_barrier();
+			__syncthreads();
 		}
 #pragma unroll
 		for (int off = 32; off > 0; off >>= 1)
@@ -448,7 +453,27 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				bp = op;
 			}
 		}
-		if (bs != 0xFFFFFFFFu)		/* uniform */
+		if (lane == 0)
+		{
+			s_bd[wv] = bd;
+			s_bs[wv] = bs;
+			s_bp[wv] = bp;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int w = 0; w < NW; w++)
+		{
+			const float od = s_bd[w];
+			const uint32_t os = s_bs[w], op = s_bp[w];
+
+			if (od < bd || (od == bd && os < bs))
+			{
+				bd = od;
+				bs = os;
+				bp = op;
+			}
+		}
+		if (bs != 0xFFFFFFFFu)		/* uniform over the block */
 		{
 			const uint32_t vis = lco[bp + 1] - lco[bp];
 
@@ -479,10 +504,11 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 	float		v = 0.0f;
 	const bool	vec4 = (dim & 3) == 0;
 
-	/* SG seed rows at a time: their loads are in flight together (a row is 3 KB: 12 coalesced loads per lane) */
+	/* SG seed rows at a time per wave: their loads are in flight together (a row is 3 KB: 12 coalesced loads per lane) */
 	constexpr int SG = 8;
+	__shared__ float s_v[64];
 
-	for (int j0 = 0; j0 < n; j0 += SG)
+	for (int j0 = wv * SG; j0 < n; j0 += NW * SG)
 	{
 		float		part[SG];
 
@@ -566,9 +592,13 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			for (int off = 32; off > 0; off >>= 1)
 				a += __shfl_xor(a, off, 64);
 			if (lane == j0 + u)
-				v = a;
+				s_v[lane] = a;
 		}
 	}
+	__syncthreads();
+	if (wv)
+		return;
+	v = lane < n ? s_v[lane] : 0.0f;		/* (slots without a seed were never written: `ok` masks them below) */
 	/* upper bound of the real squared distance (IP: of the reference's value); NaN (a row or query beyond fp32) bounds nothing */
 	float		ub;
 

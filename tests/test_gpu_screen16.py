@@ -673,3 +673,50 @@ def test_dense_tile_of_the_centred_sweep_matches_the_oracle(dim, n, nlists, nq, 
         lib.check(L.ndbhip_set_option(b"screen16c_dense", 1))
         lib.check(L.ndbhip_set_option(b"screen16c_pfd", 0))
         ix.close()
+
+
+@pytest.mark.parametrize("dim,rowtype,strategy", [(100, "f32", 1), (768, "f32", 1), (68, "f32", 3), (1536, "f32", 2),
+                                                   (64, "f16", 1), (192, "f16sub", 3), (1536, "f16", 3), (320, "f16", 2)])
+def test_rows_streamed_through_lds_sum_like_rows_read_by_their_lane(dim, rowtype, strategy, lib):
+    """screen16_stage: k_s16_finalize's survivors and k_cent_select's candidate centroids take the reference's sequential
+    arithmetic from rows copied chunk by chunk into LDS (s16_exact_staged) instead of loaded by the lane that sums them.
+    Same steps, same order: the oracle's results at every ring depth (2 = one chunk ahead, 13 = the deepest), with dims
+    that end inside a chunk (fp16 mirrors: dim % 64 == 0, a chunk is 128), fp16 rows (with subnormals: quirk Q20), more survivors than one pass of 16 holds (k = 40),
+    and more candidate centroids than one pass of 64."""
+    rng = np.random.default_rng(dim + strategy)
+    n, nlists, nq = 6000, 300, 96
+    a = make_ivf_arrays(n, dim, nlists, seed=dim + 5, dup_frac=0.05, zero_rows=2)
+    from oracle import ndbo
+    half = None
+    if rowtype != "f32":
+        rows = a["rows"]
+        if rowtype == "f16sub":
+            rows[::7, 3] = np.float32(3e-6)
+        half = rows.astype(np.float16).view(np.uint16)
+        Lo = ndbo.lib()
+        lut = np.array([Lo.ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+        a["rows"] = lut[half]
+    img = oracle_image(a)
+    if half is None:
+        ix = _index(a)
+    else:
+        from neurondb_amd import IvfIndex
+        ix = IvfIndex(dim, nlists)
+        ix.set_centroids(a["centroids"])
+        ix.load_f16(a["list_len"], half, a["tids"])
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[: nq // 2] = (a["rows"][rng.integers(0, n, nq // 2)] + 0.01 * rng.standard_normal((nq // 2, dim))).astype(np.float32)
+    lib.check(lib.lib().ndbhip_set_scan_mode(5))
+    try:
+        for nprobe, k in ((8, 10), (150, 40)):
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, 0)
+            for stage in (0, 1, 2, 13):
+                lib.check(lib.lib().ndbhip_set_option(b"screen16_stage", stage))
+                lib.check(lib.lib().ndbhip_stats_reset())
+                t, d, c = ix.search(q, strategy, nprobe, k, 0)
+                st = lib.stats()
+                assert_same_results(t, d, c, et, ed, ec)
+                assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0 and st["cent_screen_batches"] == 1, (stage, st)
+    finally:
+        lib.check(lib.lib().ndbhip_set_option(b"screen16_stage", 1))
+    ix.close()
