@@ -72,6 +72,9 @@ def parse():
                          "path is still run and checked after the timed region (`sharded_leg`)")
     ap.add_argument("--gauss-steps", type=int, default=3,
                     help="N=1, default workload: also run this many steps on i.i.d. N(0,1) data (0 = skip)")
+    ap.add_argument("--c5-nvec", type=int, default=10_000_000,
+                    help="N=1, default workload: also run BASELINE.md's C5 (halfvec x 1536, inner product, lists 4096, batches "
+                         "of 256) on this many rows on the one GPU (0 = skip)")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
     ap.add_argument("--dist-parity-queries", type=int, default=128,
@@ -443,7 +446,8 @@ def main():
                                                 "traffic is `traffic`"}}
 
     s16 = st.get("screen16_batches", 0) > 0 and st.get("screen16_fallbacks", 0) == 0
-    centred = s16 and st.get("plane_bytes", 0) > 0 and args.strategy == "l2" and args.rows == "f32" and \
+    # (plane_bytes is counted by the centred one-plane sweep only: L2, and inner product / cosine on the same planes)
+    centred = s16 and st.get("plane_bytes", 0) > 0 and \
         dict(o.split("=") for o in args.opt).get("screen16_centered", "1") != "0"
     if centred:
         roofline = sweep_roofline(args, st, nq, args.steps, elapsed / args.steps * 1e3, args.data, world) or roofline
@@ -590,6 +594,20 @@ def main():
             except Exception as e:
                 balanced = {"error": f"{type(e).__name__}: {e}"}
 
+    c5 = None
+    if rank == 0 and world == 1 and args.c5_nvec > 0 and args.data == "clustered" and args.rows == "f32" and \
+            args.strategy == "l2":
+        try:
+            if ix is not None:
+                ix.close()
+                ix = None
+            torch.cuda.empty_cache()
+            trace("c5 leg")
+            c5 = c5_leg(args, dev, args.c5_nvec)
+        except Exception as e:
+            c5 = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
     hnsw = None
     if rank == 0 and world == 1 and args.hnsw_nvec > 0:
         try:
@@ -647,6 +665,7 @@ def main():
             "sharded_leg": sharded_leg,
             "iid_gauss": gauss,
             "balanced_index": balanced,
+            "c5": c5,
             "hnsw": hnsw,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -795,6 +814,107 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
                              "sample": f"{nparity} of the step's queries through the C oracle (gcc -O2, the reference's "
                                        f"default flags), one thread per host core; the same sample checks the GPU results"},
             "oracle_parity": {"queries": nparity, "mismatches": int(bad)}}
+
+
+def c5_leg(args, dev, n, steps=20, warm=3, nreplay=8):
+    """BASELINE.md's C5 on one GPU: 10M x 1536 halfvec rows, inner product, lists 4096, probes 32, k 10, batches of 256
+    queries (the clustered generator with one component per list).  Build on the device, halfvec twin (round to
+    nearest even), timed batches on the screened path, then parity two ways: the whole last batch against the library's
+    exact scan (scan mode 3: the kernels the small-size oracle tests pin), and `nreplay` of its queries against the C
+    oracle over their probed lists (the other lists emptied: the oracle then collects exactly the candidates the full
+    image would give it, without 61 GB of rows crossing to the host)."""
+    import copy
+    import ctypes as C
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import check, lib
+    from oracle import ndbo
+    dim, lists, nq, K, P, strategy = 1536, 4096, 256, 10, 32, 3
+    base = make_data(n, dim, "clustered", lists, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
+    q = make_data(nq * (steps + warm + 1), dim, "clustered", lists, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    ix = IvfIndex(dim, lists, device=dev.index or 0)
+    t0 = time.perf_counter()
+    iters = ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
+    check(lib().ndbhip_synchronize())
+    tb = time.perf_counter() - t0
+    twin = ix.to_f16(False)
+    ix.close()
+    ix = twin
+    ot = torch.zeros((nq, K), dtype=torch.int64, device=dev)
+    od = torch.zeros((nq, K), dtype=torch.float32, device=dev)
+    oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+    for w in range(warm):
+        ix.search_device(q[w * nq:(w + 1) * nq], ot, od, oc, strategy, P, K, 0)
+    torch.cuda.synchronize()
+    check(lib().ndbhip_stats_reset())
+    check(lib().ndbhip_profile(1))
+    t0 = time.perf_counter()
+    for sidx in range(steps):
+        ix.search_device(q[(warm + sidx) * nq:(warm + sidx + 1) * nq], ot, od, oc, strategy, P, K, 0)
+    torch.cuda.synchronize()
+    ts = (time.perf_counter() - t0) / steps
+    check(lib().ndbhip_profile(0))
+    st = _lib.stats()
+    # parity 1: the last batch again, screened vs the exact scan
+    qs = q[(warm + steps) * nq:(warm + steps + 1) * nq]
+    ix.search_device(qs, ot, od, oc, strategy, P, K, 0)
+    torch.cuda.synchronize()
+    got = (ot.cpu().numpy().copy(), od.cpu().numpy().view(np.uint32).copy(), oc.cpu().numpy().copy())
+    check(lib().ndbhip_set_scan_mode(3))
+    try:
+        ix.search_device(qs, ot, od, oc, strategy, P, K, 0)
+        torch.cuda.synchronize()
+    finally:
+        check(lib().ndbhip_set_scan_mode(0))
+    exact = (ot.cpu().numpy(), od.cpu().numpy().view(np.uint32), oc.cpu().numpy())
+    bad_exact = int(sum(not (got[2][i] == exact[2][i] and np.array_equal(got[0][i], exact[0][i]) and
+                             np.array_equal(got[1][i], exact[1][i])) for i in range(nq)))
+    # parity 2: the oracle over the probed lists of a few queries (rows as the reference decodes the halfvec values)
+    cent_h, ll, _, _ = ix.export(rows=False)
+    t6 = np.zeros((n, 6), np.uint8)
+    check(lib().ndbhip_ivf_export(ix._h, None, None, None, t6.ctypes.data_as(C.c_void_p)))
+    tid_all = t6.view(ndbo.TID_DTYPE).reshape(n)
+    order = (((tid_all["bi_hi"].astype(np.int64) << 16) | tid_all["bi_lo"]) * 64 + tid_all["posid"] - 1)
+    off = np.zeros(len(ll) + 1, np.int64)
+    off[1:] = np.cumsum(ll)
+    qh = qs.cpu().numpy()
+    gtid = ndbo.tids_from_device_u64(got[0])
+    bad_oracle = 0
+    cores = host_cores()
+    t_cpu = 0.0
+    for i in range(nreplay):
+        pr = sorted(int(x) for x in ix.select_clusters(qh[i:i + 1], P)[0] if x >= 0)
+        keep = np.zeros(len(ll), bool)
+        keep[pr] = True
+        off2 = np.zeros(len(ll) + 1, np.int64)
+        off2[1:] = np.cumsum(np.where(keep, ll, 0))
+        sel = np.concatenate([np.arange(off[L], off[L + 1]) for L in pr])
+        h = base[torch.from_numpy(order[sel]).to(dev)].to(torch.float16)
+        f = h.to(torch.float32)
+        rows_img = torch.where((h.abs() < 2.0 ** -14) & (h != 0), f * 2.0 ** -10, f).cpu().numpy()     # quirk Q20
+        img = ndbo.IvfImage(cent_h, off2, rows_img, np.ascontiguousarray(tid_all[sel]))
+        t0 = time.perf_counter()
+        et, ed, _ = img.search(qh[i], strategy, P, K, 0)
+        t_cpu += time.perf_counter() - t0
+        bad_oracle += not (got[2][i] == len(et) and np.array_equal(gtid[i, :len(et)], ndbo.tids_to_u64(et)) and
+                           np.array_equal(got[1][i, :len(et)], ed.view(np.uint32)))
+    ix.close()
+    a5 = copy.copy(args)
+    a5.dim, a5.strategy, a5.rows, a5.nvec, a5.lists = dim, "ip", "f16", n, lists
+    return {"workload": f"IVFFlat {n}x{dim} halfvec lists={lists} probes={P} k={K} inner product, {nq} queries/step, "
+                        f"clustered ({lists} components, sigma 0.1), one GPU (BASELINE.md C5 names 8)",
+            "queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3), "steps": steps,
+            "build_vectors_per_s": round(n / tb, 1), "kmeans_iterations": int(iters),
+            "list_len_min_mean_max": [int(ll.min()), float(ll.mean()), int(ll.max())],
+            "screen16": {"batches": int(st.get("screen16_batches", 0)), "fallbacks": int(st.get("screen16_fallbacks", 0)),
+                         "rows_swept_frac": round(st.get("rows_swept", 0) / max(1, st.get("rows_scored", 1)), 4)},
+            "roofline": sweep_roofline(a5, st, nq, steps, ts * 1e3, "c5", 1) if st.get("plane_bytes", 0) > 0 else None,
+            "exact_scan_parity": {"queries": nq, "mismatches": bad_exact,
+                                  "note": "the screened batch against scan mode 3 (exact kernels) on the same mirror: TIDs, "
+                                          "float4 bits, counts"},
+            "oracle_parity": {"queries": nreplay, "mismatches": int(bad_oracle),
+                              "note": "the C oracle over each query's probed lists (rows decoded like fp16_to_float)"},
+            "cpu_baseline": {"value": round(nreplay / t_cpu, 2) if t_cpu > 0 else None, "unit": "queries/s", "cores": 1,
+                             "kind": "port", "sample": f"the {nreplay} replayed queries, one at a time on one core"}}
 
 
 def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
@@ -1174,11 +1294,14 @@ def sweep_roofline(args, st, nq, steps, ms_per_step, data_kind, world):
     dense = st.get("dense_sweeps", 0) > 0
     tr, src, busy = pmc_traffic(args, world, "k_s16c_dense" if dense else "k_s16c_sweep", data_kind, want_busy=True)
     alg = st["bytes_scored"] / launches
+    how = {"ip": "; inner product: b = |q - x|^2 + M^2 - |x|^2 on the L2 layout's planes, thresholds in b's domain",
+           "cosine": "; cosine: |q^ - x^|^2 over normalised planes"}.get(args.strategy, "") + \
+        ("; fp16 mirror rows" if args.rows == "f16" else "")
     r = {"bound": "hbm" if hf >= mfr else "mfma",
          "kernel": ("k_s16c_dense (the centred one-plane sweep's dense tile, 256 pairs x 256 rows: loader / prefetcher waves, "
                     "the matrix pipe screens its own accumulator blocks, queued records; csrc/ndbhip_screen16d.h)" if dense else
                     "k_s16c_sweep (centred one-plane sweep: fp16 planes of row - centre and query - centre, "
-                    "v_mfma_f32_32x32x16_f16, operands by LDS DMA)"),
+                    "v_mfma_f32_32x32x16_f16, operands by LDS DMA)") + how,
          "achieved": round(hbm if hf >= mfr else mf, 1), "peak": HBM_PEAK_GBPS if hf >= mfr else FP16_MFMA_PEAK_TFLOPS,
          "unit": "GB/s" if hf >= mfr else "TFLOP/s", "frac": round(max(hf, mfr), 4),
          "traffic": tr, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": int(launches),
