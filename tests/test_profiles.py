@@ -13,22 +13,23 @@ def test_pmc_traffic_json_is_what_the_summaries_say(tmp_path):
     out = tmp_path / "t.json"
     P = os.path.join(ROOT, "profiles")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"), str(out), "3",
-                           "--ivf", "clustered", os.path.join(P, "r03_pmc_clustered"),
-                           "--ivf", "gauss", os.path.join(P, "r03_pmc_gauss"),
-                           "--h2", os.path.join(P, "r03_pmc_h2"), "8192"], stdout=subprocess.DEVNULL)
+                           "--ivf", "clustered", os.path.join(P, "r04_pmc_clustered"),
+                           "--ivf", "gauss", os.path.join(P, "r04_pmc_gauss"),
+                           "--h2", os.path.join(P, "r04_pmc_h2"), "8192"], stdout=subprocess.DEVNULL)
     fresh = json.load(open(out))["kernels"]
-    kept = json.load(open(os.path.join(P, "r03_pmc_traffic.json")))["kernels"]
-    for kern, sub in (("k_s16c_sweep", "clustered"), ("k_s16c_sweep", "gauss"), ("k_s16_finalize", "clustered")):
+    kept = json.load(open(os.path.join(P, "r04_pmc_traffic.json")))["kernels"]
+    for kern, sub in (("k_s16c_sweep", "clustered"), ("k_s16c_dense", "gauss"), ("k_s16_finalize", "clustered")):
         assert fresh[kern][sub]["traffic_bytes_per_launch"] == kept[kern][sub]["traffic_bytes_per_launch"]
     assert fresh["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"] == kept["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"]
     e = kept["k_s16c_sweep"]["clustered"]
     # 2 x FETCH_SIZE + WRITE_SIZE (KiB per step) is the per-step traffic the file reports
     assert abs((2 * e["fetch_kib_per_step"] + e["write_kib_per_step"]) * 1024 - e["traffic_bytes_per_step"]) < 4096
     assert 1e9 < e["traffic_bytes_per_launch"] < 4e9
-    g = kept["k_s16c_sweep"]["gauss"]
+    g = kept["k_s16c_dense"]["gauss"]
     # the matrix pipe's busy share is MFMA_BUSY / (1024 SIMDs x launch cycles); never above 1, and the dense table's
-    # is the larger one
+    # is the larger one (k_s16c_dense: the fp16 products and the fp32 screening instruction of its pass 0)
     assert 0.0 < e["mfma_busy"] < g["mfma_busy"] < 1.0
+    assert 5e9 < g["traffic_bytes_per_launch"] < 3e10
 
 
 def test_bench_finds_the_committed_traffic_for_its_default_workload():
@@ -37,9 +38,9 @@ def test_bench_finds_the_committed_traffic_for_its_default_workload():
     args = types.SimpleNamespace(data="clustered", nvec=1_000_000, dim=768, lists=1024, probes=32, batch=4096, k=10,
                                  rows="f32", strategy="l2")
     traffic, source = bench.pmc_traffic(args, 1, "k_s16c_sweep")
-    assert traffic and "profiles/r03" in source
-    t2, s2, busy = bench.pmc_traffic(args, 1, "k_s16c_sweep", "gauss", want_busy=True)
-    assert t2 > traffic and busy and "profiles/r03" in s2
+    assert traffic and "profiles/r04" in source
+    t2, s2, busy = bench.pmc_traffic(args, 1, "k_s16c_dense", "gauss", want_busy=True)
+    assert t2 > traffic and busy and "profiles/r04" in s2
     assert bench.pmc_traffic(args, 8, "k_s16c_sweep") == (None, None)          # a PMC pass describes one GPU
     args.strategy = "ip"
     assert bench.pmc_traffic(args, 1, "k_s16c_sweep") == (None, None)          # ... and one workload
@@ -48,7 +49,7 @@ def test_bench_finds_the_committed_traffic_for_its_default_workload():
 
 
 def test_the_committed_bench_line_is_one_json_object_with_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key

@@ -103,12 +103,12 @@ def main():
             a = a[3:]
             wl = {"data": data, "nvec": 1000000, "dim": 768, "lists": 1024, "probes": 32, "batch": 4096,
                   "rows": "f32", "strategy": "l2"}
-            for needle, name in (("k_s16c_sweep", "k_s16c_sweep"), ("k_s16_finalize", "k_s16_finalize"),
-                                 ("k_s16c_seed", "k_s16c_seed")):
+            for needle, name in (("k_s16c_sweep", "k_s16c_sweep"), ("k_s16c_dense", "k_s16c_dense"),
+                                 ("k_s16_finalize", "k_s16_finalize"), ("k_s16c_seed", "k_s16c_seed")):
                 e = entry(prefix, needle, steps, wl, False)
                 if e:
                     b = busy(prefix, needle)
-                    if b is not None and name == "k_s16c_sweep":
+                    if b is not None and name in ("k_s16c_sweep", "k_s16c_dense"):
                         e["mfma_busy"] = b
                     doc["kernels"].setdefault(name, {})[data] = e
         elif a[0] == "--h2":
