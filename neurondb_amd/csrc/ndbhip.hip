@@ -3553,7 +3553,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				  ipc ? 2 : (cen ? 1 : 0));
 	/* a table without cluster structure (what the previous batch's pairs per bucket say, as for the tile size below):
 	 * thresholds from a sample of the mirror's rows (k_s16c_seed_sample) on top of the seeds' */
-	if (!seed_by_sublist && cen && !xseed && R == R_IVF_L2 && !ix->s16_sub && g_s16c_sample > 0 && k <= 64 && npr <= 512 &&
+	/* (float4 mirrors: k_seed_gather copies fp32 rows) */
+	if (!seed_by_sublist && cen && !xseed && !ix->f16 && R == R_IVF_L2 && !ix->s16_sub && g_s16c_sample > 0 && k <= 64 && npr <= 512 &&
 		ix->nrows >= 16 * (int64_t) g_s16c_sample &&
 		(g_s16c_qb == 8 || (g_s16c_qb == 0 && ix->s16c_density >= 320.0f)))
 	{

@@ -720,3 +720,38 @@ def test_rows_streamed_through_lds_sum_like_rows_read_by_their_lane(dim, rowtype
     finally:
         lib.check(lib.lib().ndbhip_set_option(b"screen16_stage", 1))
     ix.close()
+
+
+@pytest.mark.parametrize("strategy", [1, 3])
+def test_dense_tile_on_a_halfvec_mirror(strategy, lib):
+    """A halfvec mirror under the 256 x 256 tile with the sample-seeded thresholds switched on: the sample is gathered from
+    float4 rows only (a fuzz campaign found the gather reading fp16 rows as floats, past the end of the mirror), so an
+    fp16 mirror must take the plain seeds — and give the oracle's results."""
+    from neurondb_amd import IvfIndex
+    from oracle import ndbo
+    dim, n, nlists, nq = 64, 5200, 6, 300
+    a = make_ivf_arrays(n, dim, nlists, seed=77, dup_frac=0.05, zero_rows=2)
+    half = a["rows"].astype(np.float16).view(np.uint16)
+    Lo = ndbo.lib()
+    lut = np.array([Lo.ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+    a["rows"] = lut[half]
+    img = oracle_image(a)
+    ix = IvfIndex(dim, nlists)
+    ix.set_centroids(a["centroids"])
+    ix.load_f16(a["list_len"], half, a["tids"])
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[: nq // 2] = (a["rows"][rng.integers(0, n, nq // 2)] + 0.01 * rng.standard_normal((nq // 2, dim))).astype(np.float32)
+    L = lib.lib()
+    lib.check(L.ndbhip_set_scan_mode(5))
+    lib.check(L.ndbhip_set_option(b"screen16c_qb", 8))
+    lib.check(L.ndbhip_set_option(b"screen16c_sample", 256))
+    try:
+        for nprobe, k in ((nlists, 10), (3, 37)):
+            t, d, c = ix.search(q, strategy, nprobe, k, 0)
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, 0)
+            assert_same_results(t, d, c, et, ed, ec)
+    finally:
+        lib.check(L.ndbhip_set_option(b"screen16c_qb", 0))
+        lib.check(L.ndbhip_set_option(b"screen16c_sample", 2048))
+        ix.close()

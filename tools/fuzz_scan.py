@@ -119,6 +119,15 @@ def one_case(rng, lib, IvfIndex, check):
     check(lib.ndbhip_set_option(b"screen16_tighten", int(rng.random() < 0.8)))
     # the centred sweep's tile: chosen by the library, or forced to 32 / 128 pairs x 128 rows, or 256 x 256
     check(lib.ndbhip_set_option(b"screen16c_qb", int(rng.choice([0, 0, 1, 4, 8, 8]))))
+    # round 4: the dense tile's own kernel or the older 8-wave sweep, sample-seeded thresholds on or off, how often the
+    # dense kernel tightens, inner product on the centred planes or on two planes, rows streamed through LDS (ring depth)
+    r4 = {"screen16c_dense": int(rng.random() < 0.75), "screen16c_sample": int(rng.choice([0, 256, 2048])),
+          "screen16c_tight": int(rng.choice([8, 128, 1024])), "screen16_ip_centered": int(rng.random() < 0.75),
+          "screen16_stage": int(rng.choice([0, 1, 1, 2, 5, 13]))}
+    for name, value in r4.items():
+        check(lib.ndbhip_set_option(name.encode(), value))
+    if os.environ.get("FUZZ_TRACE"):
+        print("OPTS", r4, flush=True)
     if os.environ.get("FUZZ_TRACE"):
         print("CASE", dict(dim=dim, n=n, nlists=nlists, nq=nq, kind=kind, k=k, nprobe=nprobe, cap=cap, strategy=strategy,
                            lens=a["list_len"].tolist()), flush=True)
