@@ -9,7 +9,7 @@ One "step" = one pass of the hot path (centroid scan -> probe select -> list sca
 over one batch of --batch synthetic queries, inputs resident in HBM.  N > 1 (--shard): a table
 that fits one device several times over is REPLICATED and every rank answers its own batches —
 queries are the independent units of this path, a step costs 1.8 ms and most of it is per-query
-work that list sharding cannot divide (DESIGN.md 6) — so `value` = N batches per step, weak
+work that list sharding cannot divide (DESIGN.md 7) — so `value` = N batches per step, weak
 scaling, no data-path collective; the SHARDED path (lists cut over the ranks, every batch merged
 over the library's RCCL communicator: what a table too large for one device needs) then runs
 after the timed region and is checked against the oracle (`sharded_leg`).  --shard slices|lists

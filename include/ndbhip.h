@@ -177,9 +177,9 @@ int			ndbhip_set_scan_mode(int mode);
  *   "block_cache"       1     keep up to 4 freed packed-row blocks (>= 64 MiB) for the next build (0: release them now, stop caching)
  *   "screen16_waves"    4   tile geometry of the fp16 sweep: 4 waves, 128 x 128, ring of 2 (measured faster) | 8 waves, 256 x 128, ring of 3
  *   "screen16_debug"    0   timing experiments of the sweep (1 no DMA, 2 DMA of cache-hot lines; 4 / 8 / 16: k_sub_pairs without its counter atomics / centre distances / table reads — all WRONG results)
- *   "scr_coop" 2, "scr_ch" 16, "scr_mfma" 1, "gchunk" 32   A/B switches of the fp32 screened / grouped kernels
+ *   "scr_coop" 2, "scr_ch" 16, "scr_mfma" 1, "gchunk" 32   A/B switches of the fp32 screened / grouped kernels (docs/DESIGN_rounds_1_3.md 3b, 3c)
  *   "screen16_fin_threads" 64 threads of a k_s16_finalize block (one block per query; 64 / 128 / 256), "probe_select_threads" 256,
- *   "probe_select_radix" 0    launch shapes kept for A/B (DESIGN.md 3e has the measurements)
+ *   "probe_select_radix" 0    launch shapes kept for A/B (docs/DESIGN_rounds_1_3.md 3e has the measurements)
  *   "debug_s16", "debug_build", "hnsw_trace"  0   progress / timing lines on stderr
  *   "hnsw_nofast"       0   hnsw build walks score rows in the reference's own summation order only */
 int			ndbhip_set_option(const char *name, int value);

@@ -4094,7 +4094,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 }
 
 /* ambuild's last step (optional): everything the first batched scan would otherwise prepare lazily — sublists of
- * the long lists, the rows' fp16 planes, norms and radii (DESIGN.md 3d-3f) — for the operator class `strategy` */
+ * the long lists, the rows' fp16 planes, norms and radii (DESIGN.md 3, 4) — for the operator class `strategy` */
 extern "C" int
 ndbhip_ivf_prepare(ndbhip_ivf *ix, int strategy)
 {

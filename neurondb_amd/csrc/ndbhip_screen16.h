@@ -20,7 +20,7 @@
  *                    reference's own sequential arithmetic (one lane per candidate), and replay the
  *                    reference's selection sort over them (block_sort_cut / block_replay_emit).
  *
- * For L2, two cheaper bounds run first: k_s16_pair_prune drops a (query, probe) pair whose list lies
+ * For L2, two cheaper bounds run first (docs/DESIGN_rounds_1_3.md 3e): k_s16_pair_prune drops a (query, probe) pair whose list lies
  * wholly beyond the threshold (|q - centroid| - list radius), and on mirrors whose long lists were regrouped into
  * sublists (ivf_s16_build_sublists: rows reordered inside the planes only, pos_of = their place in the list) the
  * pair expands just to the sublists that survive the same test against the sublist centres (k_sub_pairs; the

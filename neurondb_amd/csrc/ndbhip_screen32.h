@@ -3,7 +3,7 @@
  * bound pass over (list, row tile, query groups) items — on the vector ALU (k_ivf_bound_coop / _coop2) or on fp32
  * MFMA (k_ivf_bound_mfma) — into the [nq x candidates] distance buffer, k_ivf_survivors / k_ivf_rescore_list for
  * the candidates that can still matter.  Serves cosine, k > 64 and the batches the fp16 matrix-core screen
- * (ndbhip_screen16.h) hands back; DESIGN.md 3c.
+ * (ndbhip_screen16.h) hands back; docs/DESIGN_rounds_1_3.md 3c.
  */
 #ifndef NDBHIP_SCREEN32_H
 #define NDBHIP_SCREEN32_H

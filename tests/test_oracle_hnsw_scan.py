@@ -1,6 +1,6 @@
 """oracle/ndbo_hnsw_search_layer (restatement of src/scan/hnsw_scan.c) against a second,
 independent restatement written in plain Python from the same reference lines — the reference has no test,
-fixture or caller for this file, so nothing of its own pins it (parity unpinned; see DESIGN.md §8)."""
+fixture or caller for this file, so nothing of its own pins it (parity unpinned; see DESIGN.md §9)."""
 import numpy as np
 
 from oracle import ndbo
