@@ -50,9 +50,14 @@ int			ndb_service_create(const char *name, int dim, int max_k, int nslots, ndb_s
 int			ndb_service_destroy(ndb_service *s);
 /* Gather up to max_batch READY requests that share (strategy, nprobe, k, max_candidates) with the oldest one:
  * waits up to wait_us for the first, then lingers up to linger_us while more keep arriving.  Returns the number
- * gathered (0 = nothing within wait_us, or stopped); fills slot_ids[], queries [n][dim] and the four parameters. */
+ * gathered (0 = nothing within wait_us, or stopped); fills slot_ids[], queries [n][dim] and the four parameters.
+ * queries == NULL: the queries are not copied — an executor that can read the ring itself takes them from
+ * ndb_service_query_offset(s, slot_ids[i]) (ndb_service_serve_ivf does: the device gathers them). */
 int			ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int *slot_ids, float *queries,
 							 int *strategy, int *nprobe, int *k, int64_t *max_candidates);
+/* where slot `slot_id`'s query lies in the segment (bytes from its start); ndb_service_segment: the owner's mapping */
+int64_t		ndb_service_query_offset(const ndb_service *s, int slot_id);
+int			ndb_service_segment(const ndb_service *s, void **base, size_t *bytes);
 /* rows of a gathered batch (tids6 [n][k][6], dist [n][k], count [n]); status != 0 is handed to the backends
  * as the error of their wait */
 int			ndb_service_complete(ndb_service *s, int n, const int *slot_ids, const uint8_t *tids6, const float *dist,

@@ -328,6 +328,13 @@ int			ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strate
 							  int nprobe, int k, int64_t max_candidates,
 							  uint8_t *out_tids6, float *out_dist, int *out_count);
 /* Device-pointer form (inputs and outputs in HBM, asynchronous on the stream). */
+/* ndbhip_ivf_search for queries scattered in host memory the device can read (hipHostRegister'd / hipHostMalloc'd):
+ * query i = the dim floats at d_base + offsets[i] (bytes; d_base = the DEVICE pointer of that memory, offsets a host
+ * array).  A kernel gathers them over PCIe: no CPU copy of the queries.  The device-owner service serves its request
+ * ring this way (csrc/ndb_service.cpp). */
+int			ndbhip_ivf_search_mapped(ndbhip_ivf *ix, const void *d_base, const int64_t *offsets, int nq, int strategy,
+									 int nprobe, int k, int64_t max_candidates, uint8_t *out_tids6, float *out_dist,
+									 int *out_count);
 int			ndbhip_ivf_search_device(ndbhip_ivf *ix, const float *d_queries, int nq, int strategy,
 									 int nprobe, int k, int64_t max_candidates,
 									 uint64_t *d_out_tids, float *d_out_dist, int *d_out_count);

@@ -157,6 +157,7 @@ def lib():
         "ndbhip_mfma_probe": (i, [vp, vp, vp, vp, i, i]),
         "ndbhip_mfma_probe_f32": (i, [vp, vp, vp, vp, i]),
         "ndbhip_debug_phases": (i, [vp]),
+        "ndbhip_ivf_search_mapped": (i, [vp, vp, vp, i, i, i, i, i64, vp, vp, vp]),
         "ndbhip_gen_rows_device": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),
         "ndbhip_gen_rows_host": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),
         "ndbhip_ivf_create": (i, [i, i, C.POINTER(vp)]),
@@ -237,6 +238,8 @@ def lib():
         "ndb_service_create": (i, [C.c_char_p, i, i, i, C.POINTER(vp)]),
         "ndb_service_destroy": (i, [vp]),
         "ndb_service_poll": (i, [vp, i, i, i, vp, vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i64)]),
+        "ndb_service_query_offset": (i64, [vp, i]),
+        "ndb_service_segment": (i, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ndb_service_complete": (i, [vp, i, vp, vp, vp, vp, i, i]),
         "ndb_service_serve_ivf": (i, [vp, vp, i, i, i64, C.POINTER(ServiceStats)]),
         "ndb_service_stop": (i, [vp]),

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <time.h>
@@ -19,6 +20,8 @@
 #include <new>
 #include <string>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../include/ndb_service.h"
 
@@ -109,6 +112,11 @@ struct Map
 	Header	   *h = nullptr;
 	unsigned char *slots = nullptr;
 	Slot *slot(uint32_t i) const { return (Slot *) (slots + (size_t) i * h->slot_bytes); }
+	/* one byte per slot behind the slots: "this slot may hold a request" — set by the backend after it published the slot,
+	 * cleared by the owner when it takes it.  The owner's scans walk these bytes (nslots / 64 cache lines) instead of one
+	 * line per slot, 3.5 KB apart and last written by another core: at 8192 slots the three scans of a poll cost more than
+	 * the device's work on the batch.  Only a hint: the state word decides */
+	std::atomic<uint8_t> *hint(uint32_t i) const { return (std::atomic<uint8_t> *) (slots + (size_t) h->nslots * h->slot_bytes) + i; }
 	float *query(Slot *s) const { return (float *) (s + 1); }
 	float *dist(Slot *s) const { return query(s) + h->dim; }
 	uint8_t *tids(Slot *s) const { return (uint8_t *) (dist(s) + h->max_k); }
@@ -132,7 +140,7 @@ ndb_service_create(const char *name, int dim, int max_k, int nslots, ndb_service
 	if (!name || name[0] != '/' || !out || dim < 1 || dim > 32767 || max_k < 1 || max_k > NDBHIP_MAX_K || nslots < 1 || nslots > (1 << 20))
 		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad service arguments (name must start with '/')");
 	const size_t sb = slot_bytes_for(dim, max_k);
-	const size_t bytes = 4096 + sb * (size_t) nslots;
+	const size_t bytes = 4096 + sb * (size_t) nslots + (((size_t) nslots + 63) & ~(size_t) 63);	/* header, slots, hints */
 
 	(void) shm_unlink(name);
 	const int	fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -265,7 +273,7 @@ extern "C" int
 ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int *slot_ids, float *queries,
 				 int *strategy, int *nprobe, int *k, int64_t *max_candidates)
 {
-	if (!s || max_batch < 1 || !slot_ids || !queries || !strategy || !nprobe || !k || !max_candidates)
+	if (!s || max_batch < 1 || !slot_ids || !strategy || !nprobe || !k || !max_candidates)
 		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad poll arguments");
 	Header	   *h = s->m.h;
 	const auto	t0 = std::chrono::steady_clock::now();
@@ -294,9 +302,20 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 		 * wrong rows */
 		for (uint32_t i = 0; i < h->nslots; i++)
 		{
+			if (!s->m.hint(i)->load(std::memory_order_acquire))
+				continue;
 			Slot	   *sl = s->m.slot(i);
 			uint32_t	w = sl->state.load(std::memory_order_acquire);
 
+			if (st_of(w) != S_READY)
+			{
+				/* a stale hint (the backend withdrew its request): cleared — and set again should the slot have been
+				 * published in between (the backend stores the state first, the hint second) */
+				s->m.hint(i)->store(0, std::memory_order_release);
+				if (st_of(sl->state.load(std::memory_order_acquire)) == S_READY)
+					s->m.hint(i)->store(1, std::memory_order_release);
+				continue;
+			}
 			/* (generation 0 of a named index = its backend could not learn the generation, ndb_gen_get: never served) */
 			if (st_of(w) != S_READY || (sl->index_key == skey && sl->index_version == sver && !(sl->index_key != 0 && sl->index_version == 0)))
 				continue;
@@ -306,6 +325,7 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 
 			if (!sl->state.compare_exchange_strong(w, word_of(holder, S_RUNNING), std::memory_order_acq_rel))
 				continue;
+			s->m.hint(i)->store(0, std::memory_order_release);
 			if (same_key)
 			{
 				uint64_t	w = h->wanted_version.load();
@@ -328,6 +348,8 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 
 			for (uint32_t i = 0; i < h->nslots; i++)
 			{
+				if (!s->m.hint(i)->load(std::memory_order_acquire))
+					continue;
 				Slot	   *sl = s->m.slot(i);
 
 				if (st_of(sl->state.load(std::memory_order_acquire)) == S_READY && sl->seq < best)
@@ -349,6 +371,8 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 		if (have_key)
 			for (uint32_t i = 0; i < h->nslots && n < max_batch; i++)
 			{
+				if (!s->m.hint(i)->load(std::memory_order_acquire))
+					continue;
 				Slot	   *sl = s->m.slot(i);
 				uint32_t	w = sl->state.load(std::memory_order_acquire);
 
@@ -358,7 +382,9 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 					continue;
 				if (!sl->state.compare_exchange_strong(w, word_of(pid_of(w), S_RUNNING), std::memory_order_acq_rel))
 					continue;
-				memcpy(queries + (size_t) n * h->dim, s->m.query(sl), (size_t) h->dim * 4);
+				s->m.hint(i)->store(0, std::memory_order_release);
+				if (queries)
+					memcpy(queries + (size_t) n * h->dim, s->m.query(sl), (size_t) h->dim * 4);
 				slot_ids[n++] = (int) i;
 				gained++;
 			}
@@ -386,6 +412,24 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 
 		futex(&h->submitted, FUTEX_WAIT, seen, &ts);	/* returns at once if something was submitted meanwhile */
 	}
+}
+
+extern "C" int64_t
+ndb_service_query_offset(const ndb_service *s, int slot_id)
+{
+	if (!s || slot_id < 0 || (uint32_t) slot_id >= s->m.h->nslots)
+		return -1;
+	return (int64_t) ((unsigned char *) s->m.query(s->m.slot((uint32_t) slot_id)) - (unsigned char *) s->m.base);
+}
+
+extern "C" int
+ndb_service_segment(const ndb_service *s, void **base, size_t *bytes)
+{
+	if (!s || !base || !bytes)
+		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "bad arguments");
+	*base = s->m.base;
+	*bytes = s->m.bytes;
+	return NDBHIP_OK;
 }
 
 extern "C" int
@@ -432,11 +476,52 @@ ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_
 
 	if (ndbhip_ivf_dim(ix) != (int) h->dim)
 		return ndbhip_internal_fail(NDBHIP_ERR_INVALID, "service dim %u != index dim %d", h->dim, ndbhip_ivf_dim(ix));
-	std::vector<int> ids((size_t) max_batch), cnt((size_t) max_batch);
-	std::vector<float> q((size_t) max_batch * h->dim), dist((size_t) max_batch * h->max_k);
-	std::vector<uint8_t> tids((size_t) max_batch * h->max_k * 6);
+	/* the batch's queries and results in PINNED host memory: ndbhip_ivf_search's copies are then one DMA each instead of the
+	 * runtime's staged copy of pageable memory (3 MB of queries per 1024-query batch) */
+	struct Pinned
+	{
+		void	   *p = nullptr;
+		bool		pinned = false;
+		explicit Pinned(size_t bytes)
+		{
+			if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess)
+				pinned = true;
+			else
+			{
+				(void) hipGetLastError();
+				p = malloc(bytes ? bytes : 1);
+			}
+		}
+		~Pinned() { if (pinned) (void) hipHostFree(p); else free(p); }
+	};
+	std::vector<int> ids((size_t) max_batch);
+	Pinned		q_mem((size_t) max_batch * h->dim * 4), dist_mem((size_t) max_batch * h->max_k * 4),
+		tids_mem((size_t) max_batch * h->max_k * 6), cnt_mem((size_t) max_batch * 4);
+
+	if (!q_mem.p || !dist_mem.p || !tids_mem.p || !cnt_mem.p)
+		return ndbhip_internal_fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	struct { void *p; float *data() { return (float *) p; } } q{q_mem.p}, dist{dist_mem.p};
+	struct { void *p; uint8_t *data() { return (uint8_t *) p; } } tids{tids_mem.p};
+	struct { void *p; int *data() { return (int *) p; } } cnt{cnt_mem.p};
 	ndb_service_stats st = {0, 0, 0, 0.0};
 	int			rc_last = NDBHIP_OK;
+	/* the ring registered with the device: a batch's queries are gathered by a kernel straight out of the slots (3 MB per
+	 * 1024 queries that no CPU copies twice on the critical path); where that fails the queries are copied as before */
+	void	   *d_ring = nullptr;
+	bool		ring_reg = false;
+
+	/* (the poll's linger sleeps 5 us at a time: with the default 50 us timer slack each of those is ten times as long) */
+	(void) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+	std::vector<int64_t> offs((size_t) max_batch);
+
+	if (hipHostRegister(s->m.base, s->m.bytes, hipHostRegisterMapped) == hipSuccess)
+	{
+		ring_reg = true;
+		if (hipHostGetDevicePointer(&d_ring, s->m.base, 0) != hipSuccess)
+			d_ring = nullptr;
+	}
+	if (!d_ring)
+		(void) hipGetLastError();
 
 	while (!h->stop.load(std::memory_order_acquire) && (max_batches <= 0 || (int64_t) st.batches < max_batches))
 	{
@@ -444,13 +529,23 @@ ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_
 			break;				/* the index has moved on: the owner reloads its mirror, publishes, and serves again */
 		int			strategy, nprobe, k;
 		int64_t		cap;
-		const int	n = ndb_service_poll(s, max_batch, 50 * 1000, linger_us, ids.data(), q.data(), &strategy, &nprobe, &k, &cap);
+		const int	n = ndb_service_poll(s, max_batch, 50 * 1000, linger_us, ids.data(), d_ring ? nullptr : q.data(), &strategy, &nprobe, &k, &cap);
 
 		if (n <= 0)
 			continue;
 		const auto	t0 = std::chrono::steady_clock::now();
-		int			rc = (k < 1 || k > (int) h->max_k) ? ndbhip_internal_fail(NDBHIP_ERR_INVALID, "k %d beyond the service's max_k %u", k, h->max_k)
-			: ndbhip_ivf_search(ix, q.data(), n, strategy, nprobe, k, cap, tids.data(), dist.data(), cnt.data());
+		int			rc;
+
+		if (k < 1 || k > (int) h->max_k)
+			rc = ndbhip_internal_fail(NDBHIP_ERR_INVALID, "k %d beyond the service's max_k %u", k, h->max_k);
+		else if (d_ring)
+		{
+			for (int i = 0; i < n; i++)
+				offs[(size_t) i] = ndb_service_query_offset(s, ids[(size_t) i]);
+			rc = ndbhip_ivf_search_mapped(ix, d_ring, offs.data(), n, strategy, nprobe, k, cap, tids.data(), dist.data(), cnt.data());
+		}
+		else
+			rc = ndbhip_ivf_search(ix, q.data(), n, strategy, nprobe, k, cap, tids.data(), dist.data(), cnt.data());
 
 		ndb_service_complete(s, n, ids.data(), tids.data(), dist.data(), cnt.data(), k, rc);
 		st.busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -461,6 +556,8 @@ ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_
 		if (rc)
 			rc_last = rc;
 	}
+	if (ring_reg)
+		(void) hipHostUnregister(s->m.base);
 	if (stats)
 		*stats = st;
 	return rc_last;
@@ -490,7 +587,7 @@ ndb_client_connect(const char *name, ndb_client **out)
 	Header	   *h = (Header *) p;
 
 	if (h->magic.load(std::memory_order_acquire) != MAGIC ||
-		4096 + h->slot_bytes * (size_t) h->nslots > (size_t) st.st_size)
+		4096 + h->slot_bytes * (size_t) h->nslots + (size_t) h->nslots > (size_t) st.st_size)
 	{
 		munmap(p, (size_t) st.st_size);
 		return ndbhip_internal_fail(NDBHIP_ERR_NODEVICE, "service segment %s is not initialised", name);
@@ -623,6 +720,7 @@ ndb_client_submit_index(ndb_client *c, uint64_t index_key, uint64_t index_versio
 				if (!sl->state.compare_exchange_strong(mine, word_of(me, S_READY), std::memory_order_acq_rel))
 					continue;
 			}
+			c->m.hint(i)->store(1, std::memory_order_release);
 			h->submitted.fetch_add(1, std::memory_order_release);
 			futex(&h->submitted, FUTEX_WAKE, 1, nullptr);
 			*ticket = (int) i;

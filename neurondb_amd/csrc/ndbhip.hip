@@ -1909,6 +1909,7 @@ struct ndbhip_ivf
 	uint32_t   *d_pposof = nullptr;	size_t d_pposof_n = 0;
 	bool		s16_cen_layout = false;
 	uint32_t   *w_pslot = nullptr;	size_t w_pslot_n = 0;	/* [3][qc_cap] per pair slot: query, first candidate position, visible rows */
+	int64_t    *w_qoffs = nullptr;	size_t w_qoffs_n = 0;	/* [nq] byte offsets of scattered queries (ndbhip_ivf_search_mapped) */
 	float	   *w_amat = nullptr;	size_t w_amat_n = 0;	/* [nq][astride] the sweep's |q - centroid|^2 (k_cent_select) */
 	uint8_t    *w_cfull = nullptr;	size_t w_cfull_n = 0;	/* [nq] queries k_cent_select left to k_probe_select */
 	int			qc_mult = 4;			/* rows of the pair planes / (queries x probes) */
@@ -2078,7 +2079,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev, ix->w_ppart};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev, ix->w_ppart, ix->w_qoffs};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -5243,9 +5244,27 @@ ndbhip_ivf_select_clusters_device(ndbhip_ivf *ix, const float *d_queries, int nq
 	return NDBHIP_OK;
 }
 
-extern "C" int
-ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, int nprobe, int k,
-				  int64_t max_candidates, uint8_t *out_tids6, float *out_dist, int *out_count)
+/* row i of out = the dim floats at base + off[i] (bytes): the device-owner service's queries straight out of its request
+ * ring (host memory registered with the device: the reads cross PCIe once, no CPU copy) */
+__global__ void
+k_gather_mapped(const unsigned char *__restrict__ base, const int64_t *__restrict__ off, int dim, float *__restrict__ out)
+{
+	const float *src = (const float *) (base + off[blockIdx.x]);
+	float	   *dst = out + (size_t) blockIdx.x * dim;
+
+	if ((dim & 3) == 0 && (((uintptr_t) src) & 15) == 0)
+		for (int i = threadIdx.x * 4; i < dim; i += blockDim.x * 4)
+			*reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(src + i);
+	else
+		for (int i = threadIdx.x; i < dim; i += blockDim.x)
+			dst[i] = src[i];
+}
+
+/* ndbhip_ivf_search with the queries either in one host array (queries) or scattered in device-visible host memory
+ * (d_base + offsets[i]) */
+static int
+ivf_search_host(ndbhip_ivf *ix, const float *queries, const void *d_base, const int64_t *offsets, int nq, int strategy,
+				int nprobe, int k, int64_t max_candidates, uint8_t *out_tids6, float *out_dist, int *out_count)
 {
 	int			rc = ivf_check_search_args(ix, nq, nprobe, k);
 
@@ -5253,7 +5272,7 @@ ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, in
 		return rc;
 	if (nq == 0)
 		return NDBHIP_OK;
-	if (!queries || !out_tids6 || !out_dist || !out_count)
+	if ((!queries && (!d_base || !offsets)) || !out_tids6 || !out_dist || !out_count)
 		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
 	if (grow(ix->w_q, ix->w_q_n, (size_t) nq * ix->dim)) return NDBHIP_ERR_HIP;
 	/* one device block for the results — [TIDs | distances | counts] — and one pinned host block for the query
@@ -5266,7 +5285,8 @@ ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, in
 	uint64_t   *d_tid = ix->w_otid;
 	float	   *d_dist = (float *) (ix->w_otid + nk);
 	int		   *d_cnt = (int *) (d_dist + nk);
-	const size_t pin_bytes = (size_t) nq * ix->dim * sizeof(float) + 8 + out_words * 4;
+	const size_t in_bytes = queries ? (size_t) nq * ix->dim * sizeof(float) : (size_t) nq * sizeof(int64_t);
+	const size_t pin_bytes = in_bytes + 8 + out_words * 4;
 
 	if (pin_bytes > ix->pin_n)
 	{
@@ -5276,11 +5296,24 @@ ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, in
 		HIP_TRY(hipHostMalloc((void **) &ix->pin, pin_bytes, hipHostMallocDefault));
 		ix->pin_n = pin_bytes;
 	}
-	float	   *h_q = (float *) ix->pin;
-	unsigned char *h_out = (unsigned char *) ix->pin + (((size_t) nq * ix->dim * sizeof(float) + 7) & ~(size_t) 7);
+	unsigned char *h_out = (unsigned char *) ix->pin + ((in_bytes + 7) & ~(size_t) 7);
 
-	memcpy(h_q, queries, (size_t) nq * ix->dim * sizeof(float));
-	HIP_TRY(hipMemcpyAsync(ix->w_q, h_q, (size_t) nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	if (queries)
+	{
+		float	   *h_q = (float *) ix->pin;
+
+		memcpy(h_q, queries, in_bytes);
+		HIP_TRY(hipMemcpyAsync(ix->w_q, h_q, in_bytes, hipMemcpyHostToDevice, g.stream));
+	}
+	else
+	{
+		if (grow(ix->w_qoffs, ix->w_qoffs_n, (size_t) nq)) return NDBHIP_ERR_HIP;
+		memcpy(ix->pin, offsets, in_bytes);
+		HIP_TRY(hipMemcpyAsync(ix->w_qoffs, ix->pin, in_bytes, hipMemcpyHostToDevice, g.stream));
+		hipLaunchKernelGGL(k_gather_mapped, dim3(nq), dim3(256), 0, g.stream, (const unsigned char *) d_base,
+						   (const int64_t *) ix->w_qoffs, ix->dim, ix->w_q);
+		HIP_TRY(hipGetLastError());
+	}
 	rc = ivf_search_device_impl(ix, ix->w_q, nq, strategy, nprobe, k, max_candidates, 0, nullptr, nullptr,
 								nullptr, d_tid, d_dist, d_cnt);
 	if (rc)
@@ -5303,6 +5336,24 @@ ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, in
 			}
 		}
 	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_ivf_search(ndbhip_ivf *ix, const float *queries, int nq, int strategy, int nprobe, int k,
+				  int64_t max_candidates, uint8_t *out_tids6, float *out_dist, int *out_count)
+{
+	if (nq > 0 && !queries)
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	return ivf_search_host(ix, queries, nullptr, nullptr, nq, strategy, nprobe, k, max_candidates, out_tids6, out_dist, out_count);
+}
+
+extern "C" int
+ndbhip_ivf_search_mapped(ndbhip_ivf *ix, const void *d_base, const int64_t *offsets, int nq, int strategy, int nprobe, int k,
+						 int64_t max_candidates, uint8_t *out_tids6, float *out_dist, int *out_count)
+{
+	if (nq > 0 && (!d_base || !offsets))
+		return fail(NDBHIP_ERR_INVALID, "NULL pointer");
+	return ivf_search_host(ix, nullptr, d_base, offsets, nq, strategy, nprobe, k, max_candidates, out_tids6, out_dist, out_count);
 }
 
 extern "C" int
