@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 900 python3 -m pytest tests/test_gpu_screen16.py -x -q -m gpu -k "dense" 2>&1 | tail -2
+timeout 900 python3 tools/dense_probe.py "" "screen16c_dense=0" "screen16_debug=1" "screen16_debug=2" 2>&1 | grep -v amdgpu
