@@ -158,7 +158,8 @@ int			ndbhip_set_scan_mode(int mode);
  *                             orders a query's rows like -q.x; fp32 and fp16 mirrors); 0: the two-plane sweep of round 2
  *   "screen16_redo"     1     queries whose records / survivors overflow go to the exact path alone (0: their whole batch does)
  *   "screen16_slack"    1     the centred planes keep spare 32-row blocks per bucket and take appends in place (0: every append lays them out again)
- *   "screen_min_nq"     32    batches of at least this many queries take the screened (matrix-core) scan; smaller ones the exact grouped scan
+ *   "screen_min_nq"     5     batches of at least this many queries take the screened (matrix-core) scan; smaller ones the exact scans
+ *                             (measured crossover, profiles/r04_small_batch.txt; the first such batch on an index pays its preparation once)
  *   "screen16_stage"    1     k_s16_finalize's survivors and k_cent_select's candidate centroids get the reference's sequential sum from rows
  *                             streamed through LDS by DMA (s16_exact_staged: a chunk of 256 bytes per row, several chunks ahead) instead of
  *                             rows loaded 16 bytes at a time by the lane that sums them; 0 = off, 2..13 = that ring depth (1: by batch size)

@@ -31,7 +31,10 @@ static int	g_scan_mode = 0;
 /* screened L2 scan in auto mode (ndbhip_set_option("screen", 0) turns it off); batches below this many queries keep the
  * exact scan (the two extra passes cost more than they save there) */
 static bool g_screen_auto = true;
-#define NDB_SCREEN_MIN_NQ 32
+/* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32; profiles/r04_small_batch.txt): the
+ * exact scans cost 0.17 / 0.25 / 0.35 / 0.34 / 0.39 ms for 2 / 4 / 8 / 16 / 24 queries, the matrix-core screen 0.25-0.27 ms
+ * for anything from 2 to 32 — it wins from 5 queries up (32 until round 4: the per-batch chain was twice as long) */
+#define NDB_SCREEN_MIN_NQ 5
 static int	g_build_prepare = 0;	/* "build_prepare": strategy (1 .. 3) a build prepares the index for before it returns, 0 = the first batched scan or ndbhip_ivf_prepare does */
 static int	g_screen_min_nq = NDB_SCREEN_MIN_NQ;	/* batches of at least this many queries take the screened path ("screen_min_nq") */
 /* measured crossover on MI355X (tools/small_batch_probe.py, 1M x 768, probes 32): the grouped path costs 0.38 ms for 1..16
@@ -4797,7 +4800,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			 * are screened by the two-tile kernel only (its pass is the plain dot product; the norms come from
 			 * the per-row norms) */
 			const int	scr_coop = g_scr_coop;
-			const bool	want = g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= g_screen_min_nq);
+			/* (the fp32 screen — what serves k > 64 — pays from 32 queries up, as measured in round 1) */
+			const bool	want = g_scan_mode == 3 || (g_scan_mode == 0 && g_screen_auto && nq >= std::max(g_screen_min_nq, 32));
 			const bool	two_tile = scr_coop == 2 && (ix->dim % 16) == 0;
 
 			/* fp16 rows (decoded when the tile is staged), inner product and cosine: the two-tile kernel only */

@@ -64,7 +64,7 @@ def test_every_documented_option_is_accepted_and_bad_ones_are_refused():
     defaults = {"screen16": 1, "screen16_records": 8192, "screen16_tighten": 1, "screen16_prune": 1, "screen16_sublists": 1,
                 "screen16_sub_min": 256, "screen16_sub_rows": 128, "screen16_centered": 1, "cent_screen16": 1, "screen16_fin_threads": 64, "screen16_waves": 4,
                 "probe_select_threads": 256, "probe_select_radix": 0, "build_screen16": 1, "block_cache": 1, "gchunk": 32,
-                "scr_coop": 2, "scr_mfma": 1, "screen": 1, "screen16_slack": 1, "screen_min_nq": 32, "screen16_cosine": 1, "hnsw_intended_waves": 16, "screen16_cosine_centered": 1, "screen16_redo": 1,
+                "scr_coop": 2, "scr_mfma": 1, "screen": 1, "screen16_slack": 1, "screen_min_nq": 5, "screen16_cosine": 1, "hnsw_intended_waves": 16, "screen16_cosine_centered": 1, "screen16_redo": 1,
                 "screen16c_dense": 1, "screen16c_sample": 2048, "screen16c_tight": 128, "screen16c_epi": 1, "screen16_stage": 1, "screen16_ip_centered": 1}
     for n in sorted(names):
         rc = L.ndbhip_set_option(n.encode(), defaults.get(n, 0))

