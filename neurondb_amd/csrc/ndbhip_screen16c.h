@@ -269,6 +269,33 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 		const float *q = queries + (size_t) pr.q * dim;
 		const float *c = cptr ? cptr[lo] : cents + (size_t) lo * dim;
 		double		s = 0.0;
+		/* dims up to 2048 in multiples of 4 (the usual case): 16 bytes per lane and load, every q_i - c_i kept in registers
+		 * for the plane below (the second pass over q and c, a dependent round trip per pair, was a third of this kernel's
+		 * time at 1536 dimensions) */
+		const bool	vec = (dim & 3) == 0 && dim <= 2048;
+		float4		dv[8];
+
+		if (vec)
+		{
+#pragma unroll
+			for (int t = 0; t < 8; t++)
+			{
+				const int	i = t * 256 + lane * 4;
+
+				dv[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (i < dim)
+				{
+					const float4 qv = *reinterpret_cast<const float4 *>(q + i), cv = *reinterpret_cast<const float4 *>(c + i);
+
+					dv[t] = make_float4(qv.x - cv.x, qv.y - cv.y, qv.z - cv.z, qv.w - cv.w);
+				}
+			}
+#pragma unroll
+			for (int t = 0; t < 8; t++)
+				s += (double) dv[t].x * (double) dv[t].x + (double) dv[t].y * (double) dv[t].y +
+					(double) dv[t].z * (double) dv[t].z + (double) dv[t].w * (double) dv[t].w;
+		}
+		else
 
 		for (int i = lane; i < dim; i += 64)
 		{
@@ -297,6 +324,29 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 		 * can have, the product exact (below 2^-126 it is flushed: inside the 2^-25 the error model allows an element) */
 		const float sc = ldexpf(1.0f, 14 - e);
 
+		if (vec)
+		{
+#pragma unroll
+			for (int t = 0; t < 8; t++)
+			{
+				const int	i = t * 256 + lane * 4;
+
+				if (i >= dimp)
+					continue;
+				ndb_h2		h01, h23;
+
+				h01.x = ok ? (_Float16) (dv[t].x * sc) : (_Float16) 0;
+				h01.y = ok ? (_Float16) (dv[t].y * sc) : (_Float16) 0;
+				h23.x = ok ? (_Float16) (dv[t].z * sc) : (_Float16) 0;
+				h23.y = ok ? (_Float16) (dv[t].w * sc) : (_Float16) 0;
+				_Float16   *o = chunk_plane ? reinterpret_cast<_Float16 *>(out) + (size_t) (i >> 6) * chunk_plane + (i & 63)
+					: reinterpret_cast<_Float16 *>(out) + i;
+				ndb_h2		pk[2] = {h01, h23};
+
+				*reinterpret_cast<uint2 *>(o) = *reinterpret_cast<const uint2 *>(pk);
+			}
+			continue;
+		}
 		for (int p = lane; p < dimp / 2; p += 64)
 		{
 			const int	i = 2 * p;
