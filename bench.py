@@ -899,7 +899,7 @@ def c5_leg(args, dev, n, steps=20, warm=3, nreplay=8):
                            np.array_equal(got[1][i, :len(et)], ed.view(np.uint32)))
     ix.close()
     a5 = copy.copy(args)
-    a5.dim, a5.strategy, a5.rows, a5.nvec, a5.lists = dim, "ip", "f16", n, lists
+    a5.dim, a5.strategy, a5.rows, a5.nvec, a5.lists, a5.batch, a5.probes, a5.k = dim, "ip", "f16", n, lists, nq, P, K
     return {"workload": f"IVFFlat {n}x{dim} halfvec lists={lists} probes={P} k={K} inner product, {nq} queries/step, "
                         f"clustered ({lists} components, sigma 0.1), one GPU (BASELINE.md C5 names 8)",
             "queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3), "steps": steps,

@@ -15,10 +15,12 @@ def test_pmc_traffic_json_is_what_the_summaries_say(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"), str(out), "3",
                            "--ivf", "clustered", os.path.join(P, "r04_pmc_clustered"),
                            "--ivf", "gauss", os.path.join(P, "r04_pmc_gauss"),
+                           "--c5", os.path.join(P, "r04_pmc_c5"),
                            "--h2", os.path.join(P, "r04_pmc_h2"), "8192"], stdout=subprocess.DEVNULL)
     fresh = json.load(open(out))["kernels"]
     kept = json.load(open(os.path.join(P, "r04_pmc_traffic.json")))["kernels"]
-    for kern, sub in (("k_s16c_sweep", "clustered"), ("k_s16c_dense", "gauss"), ("k_s16_finalize", "clustered")):
+    for kern, sub in (("k_s16c_sweep", "clustered"), ("k_s16c_dense", "gauss"), ("k_s16_finalize", "clustered"),
+                      ("k_s16c_sweep", "c5")):
         assert fresh[kern][sub]["traffic_bytes_per_launch"] == kept[kern][sub]["traffic_bytes_per_launch"]
     assert fresh["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"] == kept["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"]
     e = kept["k_s16c_sweep"]["clustered"]
@@ -44,6 +46,10 @@ def test_bench_finds_the_committed_traffic_for_its_default_workload():
     assert bench.pmc_traffic(args, 8, "k_s16c_sweep") == (None, None)          # a PMC pass describes one GPU
     args.strategy = "ip"
     assert bench.pmc_traffic(args, 1, "k_s16c_sweep") == (None, None)          # ... and one workload
+    a5 = types.SimpleNamespace(data="clustered", nvec=10_000_000, dim=1536, lists=4096, probes=32, batch=256, k=10,
+                               rows="f16", strategy="ip")
+    t5, s5 = bench.pmc_traffic(a5, 1, "k_s16c_sweep", "c5")              # what bench.py's c5 leg looks up
+    assert 1e9 < t5 < 4e9 and "profiles/r04" in s5
     h = bench.h2_roofline(1_000_000, 768, 16, 64, 8192, 16.3e-3, 2.6e6)
     assert h["traffic"] and h["traffic_source"] and 0 < h["traffic_frac"] < 1 and 0 < h["frac"] < 1
 

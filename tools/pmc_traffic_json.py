@@ -2,7 +2,7 @@
 """Turns the PMC summaries of one state of the library (tools/pmc_all.sh TAG -> gpurun_out/pmc_TAG_{fetch,write,tcc}.txt,
 or copies of them under profiles/) into profiles/<round>_pmc_traffic.json, the file bench.py's roofline.traffic reads.
 
-usage: tools/pmc_traffic_json.py OUT.json STEPS [--ivf DATA PREFIX]... [--h2 PREFIX NQ]
+usage: tools/pmc_traffic_json.py OUT.json STEPS [--ivf DATA PREFIX]... [--c5 PREFIX] [--h2 PREFIX NQ]
   PREFIX       e.g. profiles/r03_pmc_clustered   (reads PREFIX_fetch.txt, PREFIX_write.txt, PREFIX_tcc.txt, PREFIX_sq.txt)
   STEPS        search steps the profiled bench.py ran in total (steps + warmup; tools/pmc_pass.sh: 3)
 
@@ -111,6 +111,16 @@ def main():
                     if b is not None and name in ("k_s16c_sweep", "k_s16c_dense"):
                         e["mfma_busy"] = b
                     doc["kernels"].setdefault(name, {})[data] = e
+        elif a[0] == "--c5":
+            # BASELINE.md's C5 on one GPU (bench.py's c5 leg: tools/pmc_pass.sh with C5's arguments)
+            prefix = a[1]
+            a = a[2:]
+            wl = {"data": "c5", "nvec": 10000000, "dim": 1536, "lists": 4096, "probes": 32, "batch": 256,
+                  "rows": "f16", "strategy": "ip"}
+            for needle, name in (("k_s16c_sweep", "k_s16c_sweep"), ("k_s16_finalize", "k_s16_finalize")):
+                e = entry(prefix, needle, steps, wl, False)
+                if e:
+                    doc["kernels"].setdefault(name, {})["c5"] = e
         elif a[0] == "--h2":
             hp, nq = a[1], int(a[2])
             a = a[3:]
