@@ -215,7 +215,45 @@ struct H2Set
 	uint8_t    *wx;
 	uint32_t	ef;
 	uint32_t	nw;				/* uniform */
+	/* the farthest entry of a FULL set, remembered between offers (worst_i < 0: not known) — most offers to a full set
+	 * lose against it and need nothing else */
+	double		worst_d;
+	uint32_t	worst_id;
+	int			worst_i;
 };
+
+/*
+ * The best of the lanes' (d, id, index) triples under the total order h2_less (FAR: its reverse), index < 0 = the lane has
+ * none; wave-uniform result.  (d2, block) is a total order, so the pairing of the reduction is free: four steps inside the
+ * rows of 16 lanes and two broadcasts across them by data-parallel-primitive moves (no LDS round trip) — the xor
+ * butterfly over ds_bpermute this replaces was 24 dependent round trips per call, once per distance evaluation.
+ */
+template <bool FAR>
+__device__ __forceinline__ int
+h2_best_lane(double bd, uint32_t bid, int bi)
+{
+#define H2_DPP_STEP(CTRL, RMASK)                                                                                              \
+	{                                                                                                                         \
+		const int	lo = __builtin_amdgcn_update_dpp((int) __double2loint(bd), (int) __double2loint(bd), CTRL, RMASK, 0xF, false); \
+		const int	hi = __builtin_amdgcn_update_dpp((int) __double2hiint(bd), (int) __double2hiint(bd), CTRL, RMASK, 0xF, false); \
+		const uint32_t oid = (uint32_t) __builtin_amdgcn_update_dpp((int) bid, (int) bid, CTRL, RMASK, 0xF, false);             \
+		const int	oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, RMASK, 0xF, false);                                         \
+		const double od = __hiloint2double(hi, lo);                                                                            \
+		const bool	take = oi >= 0 && (bi < 0 || (FAR ? h2_less(bd, bid, od, oid) : h2_less(od, oid, bd, bid)));               \
+                                                                                                                              \
+		bd = take ? od : bd;                                                                                                   \
+		bid = take ? oid : bid;                                                                                                \
+		bi = take ? oi : bi;                                                                                                   \
+	}
+	H2_DPP_STEP(0xB1, 0xF)		/* quad_perm [1, 0, 3, 2] */
+	H2_DPP_STEP(0x4E, 0xF)		/* quad_perm [2, 3, 0, 1] */
+	H2_DPP_STEP(0x141, 0xF)		/* row_half_mirror */
+	H2_DPP_STEP(0x140, 0xF)		/* row_mirror: every lane of a row holds the row's best */
+	H2_DPP_STEP(0x142, 0xA)		/* row_bcast:15 into rows 1 and 3 */
+	H2_DPP_STEP(0x143, 0xC)		/* row_bcast:31 into rows 2 and 3: lane 63 holds the wave's best */
+#undef H2_DPP_STEP
+	return __builtin_amdgcn_readlane(bi, 63);
+}
 
 /* nearest unexpanded entry (index, or -1), wave-uniform */
 __device__ __forceinline__ int
@@ -232,21 +270,7 @@ h2_pick(const H2Set &W, int lane)
 			bid = W.wid[i];
 			bi = (int) i;
 		}
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
-	{
-		const double od = __shfl_xor(bd, off, 64);
-		const uint32_t oid = (uint32_t) __shfl_xor((int) bid, off, 64);
-		const int	oi = __shfl_xor(bi, off, 64);
-
-		if (oi >= 0 && (bi < 0 || h2_less(od, oid, bd, bid)))
-		{
-			bd = od;
-			bid = oid;
-			bi = oi;
-		}
-	}
-	return bi;
+	return h2_best_lane<false>(bd, bid, bi);
 }
 
 /* farthest entry (index), wave-uniform; nw >= 1 */
@@ -264,21 +288,7 @@ h2_worst(const H2Set &W, int lane)
 			bid = W.wid[i];
 			bi = (int) i;
 		}
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
-	{
-		const double od = __shfl_xor(bd, off, 64);
-		const uint32_t oid = (uint32_t) __shfl_xor((int) bid, off, 64);
-		const int	oi = __shfl_xor(bi, off, 64);
-
-		if (oi >= 0 && (bi < 0 || h2_less(bd, bid, od, oid)))
-		{
-			bd = od;
-			bid = oid;
-			bi = oi;
-		}
-	}
-	return bi;
+	return h2_best_lane<true>(bd, bid, bi);
 }
 
 /* offer (d, id) to the set: appended while there is room, else it replaces the farthest entry it beats (uniform args) */
@@ -294,19 +304,27 @@ h2_offer(H2Set &W, double d, uint32_t id, int lane)
 			W.wx[W.nw] = 0;
 		}
 		W.nw++;
+		W.worst_i = -1;
 		__threadfence_block();
 		return;
 	}
-	const int	w = h2_worst(W, lane);
+	if (W.worst_i < 0)
+	{
+		const int	w = h2_worst(W, lane);
 
-	if (h2_less(d, id, W.wd[w], W.wid[w]))
+		W.worst_i = w;
+		W.worst_d = W.wd[w];
+		W.worst_id = W.wid[w];
+	}
+	if (h2_less(d, id, W.worst_d, W.worst_id))
 	{
 		if (lane == 0)
 		{
-			W.wd[w] = d;
-			W.wid[w] = id;
-			W.wx[w] = 0;
+			W.wd[W.worst_i] = d;
+			W.wid[W.worst_i] = id;
+			W.wx[W.worst_i] = 0;
 		}
+		W.worst_i = -1;
 		__threadfence_block();
 	}
 }
@@ -321,6 +339,7 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 				long long &evals)
 {
 	W.nw = 0;
+	W.worst_i = -1;
 	(void) V.mark(lane == 0, ep, lane);
 	h2_offer(W, epd, ep, lane);
 	for (;;)
