@@ -208,6 +208,7 @@ int			ndbhip_mfma_probe_f32(const float *d_a, const float *d_b, const float *d_c
 /* Profiling builds of the library (make PHASES=1: -DNDB_PHASES) stamp a 100 MHz clock at marked places of the per-batch
  * kernels (block 0 only); this copies the 64 stamps to out (zeros from an ordinary build).  tools/phase_probe.py */
 int			ndbhip_debug_phases(unsigned long long *out);
+int			ndbhip_debug_h2_phases(unsigned long long *out);	/* [8]: the intended HNSW search's phase clocks (csrc/ndbhip_hnsw2.h), read and reset */
 
 /* ------------------------------------------------------------------ */
 /* IVF mirror lifecycle.  Replaces the page walk of ivfSelectClusters /

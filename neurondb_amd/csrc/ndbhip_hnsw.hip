@@ -3581,3 +3581,22 @@ ndbhip_hnsw_set_intended_select(int select)
 	g_h2_select = select;
 	return NDBHIP_OK;
 }
+
+/* profiling builds (-DNDB_PHASES): the intended search's phase clocks (ndbhip_hnsw2.h), read and reset; otherwise zeros */
+extern "C" int
+ndbhip_debug_h2_phases(unsigned long long *out)
+{
+	if (!out)
+		return NDBHIP_ERR_INVALID;
+#ifdef NDB_PHASES
+	unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_phases), sizeof(zero)));
+	HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_h2_phases), zero, sizeof(zero)));
+#else
+	memset(out, 0, 8 * sizeof(unsigned long long));
+#endif
+	return NDBHIP_OK;
+}
+

@@ -22,6 +22,24 @@
 #ifndef NDBHIP_HNSW2_H
 #define NDBHIP_HNSW2_H
 
+/* profiling builds (make EXTRA=-DNDB_PHASES): 100 MHz clock ticks block 0's wave spends in the parts of a layer search,
+ * summed over the launch — [0] pick, [1] neighbour list + visited marks, [2] row distances, [3] offers, [4] expansions */
+#ifdef NDB_PHASES
+__device__ unsigned long long g_h2_phases[8];
+#define H2_PH_DECL unsigned long long h2_ph_t = wall_clock64(), h2_ph_acc[5] = {0, 0, 0, 0, 0}
+#define H2_PH(I) do { const unsigned long long h2_now = wall_clock64(); h2_ph_acc[I] += h2_now - h2_ph_t; h2_ph_t = h2_now; } while (0)
+#define H2_PH_COUNT(I) (h2_ph_acc[I]++)
+#define H2_PH_FLUSH do { if (blockIdx.x == 0 && lane == 0) for (int h2_i = 0; h2_i < 5; h2_i++) atomicAdd(&g_h2_phases[h2_i], h2_ph_acc[h2_i]); } while (0)
+#else
+#define H2_PH_DECL ((void) 0)
+#define H2_PH(I) ((void) 0)
+#define H2_PH_COUNT(I) ((void) 0)
+#define H2_PH_FLUSH ((void) 0)
+#endif
+
+#ifndef H2_JG_DEF
+#define H2_JG_DEF 6			/* strides of a row batch requested together (h2_dist2x4) */
+#endif
 #define H2_QREG 16				/* query elements a lane keeps in registers (dim <= 1024); beyond: re-read (L1 / L2) */
 #define H2_LOG_CAP 8192			/* visited blocks a wave logs for clearing its bitmap; more: the whole map is cleared */
 
@@ -111,23 +129,41 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 
 	if (Q.dim <= 64 * H2_QREG)
 	{
-#pragma unroll
-		for (int j = 0; j < H2_QREG; j++)
-			if (lane + 64 * j < Q.dim)
-			{
-				float		v[H2_NR];
+		/* H2_JG strides of all the rows requested together: 12 strides one after the other, each waiting for its loads, were
+		 * twelve memory round trips per expansion — 20 of its 28 us (phase clocks, tools/h2_bench.py on a profiling build).
+		 * A lane still adds its elements lane, lane + 64, ... in that order. */
+		constexpr int H2_JG = H2_JG_DEF;
 
 #pragma unroll
-				for (int u = 0; u < H2_NR; u++)
-					v[u] = u < n ? x[u][lane + 64 * j] : 0.0f;
+		for (int j0 = 0; j0 < H2_QREG; j0 += H2_JG)
+		{
+			if (64 * j0 >= Q.dim)		/* uniform */
+				break;
+			float		v[H2_NR][H2_JG];
+
 #pragma unroll
-				for (int u = 0; u < H2_NR; u++)
+			for (int u = 0; u < H2_NR; u++)
+#pragma unroll
+				for (int jj = 0; jj < H2_JG; jj++)
 				{
-					const float d = Q.r[j] - v[u];
+					const int	i = lane + 64 * (j0 + jj);
 
-					p[u] += (double) d * (double) d;
+					/* (beyond the row: 0 against the query's 0 — a term +0.0 that leaves the sum as it is) */
+					v[u][jj] = (u < n && j0 + jj < H2_QREG && i < Q.dim) ? x[u][i] : 0.0f;
 				}
-			}
+#pragma unroll
+			for (int jj = 0; jj < H2_JG; jj++)
+				if (j0 + jj < H2_QREG && lane + 64 * (j0 + jj) < Q.dim)
+				{
+#pragma unroll
+					for (int u = 0; u < H2_NR; u++)
+					{
+						const float d = Q.r[j0 + jj] - v[u][jj];
+
+						p[u] += (double) d * (double) d;
+					}
+				}
+		}
 	}
 	else
 		for (int i = lane; i < Q.dim; i += 64)
@@ -220,7 +256,40 @@ struct H2Set
 	double		worst_d;
 	uint32_t	worst_id;
 	int			worst_i;
+	/* ef <= 64 (uniform `inreg`): while a layer is searched entry i lives in lane i's registers — no LDS round trip per
+	 * offer or pick — and is written to wd / wid / wx when the search ends (h2_set_spill) */
+	bool		inreg;
+	double		rd;
+	uint32_t	rid;
+	uint32_t	rx;
 };
+
+__device__ __forceinline__ double
+h2_readlane_f64(double v, int l)
+{
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+/* block number of entry i (uniform i) */
+__device__ __forceinline__ uint32_t
+h2_id_at(const H2Set &W, int i)
+{
+	return W.inreg ? (uint32_t) __builtin_amdgcn_readlane((int) W.rid, i) : W.wid[i];
+}
+
+__device__ __forceinline__ void
+h2_set_spill(const H2Set &W, int lane)
+{
+	if (!W.inreg)
+		return;
+	if ((uint32_t) lane < W.nw)
+	{
+		W.wd[lane] = W.rd;
+		W.wid[lane] = W.rid;
+		W.wx[lane] = (uint8_t) W.rx;
+	}
+	__threadfence_block();
+}
 
 /*
  * The best of the lanes' (d, id, index) triples under the total order h2_less (FAR: its reverse), index < 0 = the lane has
@@ -263,6 +332,13 @@ h2_pick(const H2Set &W, int lane)
 	uint32_t	bid = 0;
 	int			bi = -1;
 
+	if (W.inreg)
+	{
+		/* (the lanes hold the entries in ascending order: the nearest unexpanded one is the first) */
+		const unsigned long long m = __ballot((uint32_t) lane < W.nw && !W.rx);
+
+		return m ? (int) __builtin_ctzll(m) : -1;
+	}
 	for (uint32_t i = lane; i < W.nw; i += 64)
 		if (!W.wx[i] && (bi < 0 || h2_less(W.wd[i], W.wid[i], bd, bid)))
 		{
@@ -281,6 +357,16 @@ h2_worst(const H2Set &W, int lane)
 	uint32_t	bid = 0;
 	int			bi = -1;
 
+	if (W.inreg)
+	{
+		if ((uint32_t) lane < W.nw)
+		{
+			bd = W.rd;
+			bid = W.rid;
+			bi = lane;
+		}
+		return h2_best_lane<true>(bd, bid, bi);
+	}
 	for (uint32_t i = lane; i < W.nw; i += 64)
 		if (bi < 0 || h2_less(bd, bid, W.wd[i], W.wid[i]))
 		{
@@ -295,6 +381,36 @@ h2_worst(const H2Set &W, int lane)
 __device__ __forceinline__ void
 h2_offer(H2Set &W, double d, uint32_t id, int lane)
 {
+	if (W.inreg)
+	{
+		/* lanes 0 .. nw - 1 hold the entries in ascending (d2, block) order: the new one goes where the entries before it are
+		 * the nearer ones, everything behind moves up a lane (one whole-wave shift; the farthest falls off a full set).  An
+		 * arg-max over the set per accepted offer, however it is reduced, was a third of a search's instructions. */
+		const int	pos = (int) __popcll(__ballot((uint32_t) lane < W.nw && h2_less(W.rd, W.rid, d, id)));
+
+		if (W.nw >= W.ef && pos >= (int) W.ef)
+			return;
+		const int	slo = __builtin_amdgcn_update_dpp(0, (int) __double2loint(W.rd), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+		const int	shi = __builtin_amdgcn_update_dpp(0, (int) __double2hiint(W.rd), 0x138, 0xF, 0xF, false);
+		const int	sid = __builtin_amdgcn_update_dpp(0, (int) W.rid, 0x138, 0xF, 0xF, false);
+		const int	sx = __builtin_amdgcn_update_dpp(0, (int) W.rx, 0x138, 0xF, 0xF, false);
+
+		if (lane > pos)
+		{
+			W.rd = __hiloint2double(shi, slo);
+			W.rid = (uint32_t) sid;
+			W.rx = (uint32_t) sx;
+		}
+		else if (lane == pos)
+		{
+			W.rd = d;
+			W.rid = id;
+			W.rx = 0;
+		}
+		if (W.nw < W.ef)
+			W.nw++;
+		return;
+	}
 	if (W.nw < W.ef)
 	{
 		if (lane == 0)
@@ -340,24 +456,42 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 {
 	W.nw = 0;
 	W.worst_i = -1;
+	W.inreg = W.ef <= 64;
+	W.rd = 0.0;
+	W.rid = 0;
+	W.rx = 0;
 	(void) V.mark(lane == 0, ep, lane);
 	h2_offer(W, epd, ep, lane);
+	H2_PH_DECL;
 	for (;;)
 	{
 		const int	bi = h2_pick(W, lane);
 
+		H2_PH(0);
 		if (bi < 0)
 			break;
-		if (lane == 0)
-			W.wx[bi] = 1;
-		__threadfence_block();
-		const uint32_t c = W.wid[bi];
-		const int	cnt = min((int) g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		H2_PH_COUNT(4);
+		if (W.inreg)
+		{
+			if (lane == bi)
+				W.rx = 1;
+		}
+		else
+		{
+			if (lane == 0)
+				W.wx[bi] = 1;
+			__threadfence_block();
+		}
+		const uint32_t c = h2_id_at(W, bi);
+		/* (the slot is read whatever the count says — every list has 2m slots — so that both loads are in flight together) */
 		const uint32_t *nb = g.nbrs + (size_t) c * g.stride + (size_t) level * 2 * g.m;
-		const uint32_t e = lane < cnt ? nb[lane] : NDBHIP_INVALID_BLOCK;
+		const uint32_t e0 = lane < 2 * g.m ? nb[lane] : NDBHIP_INVALID_BLOCK;
+		const int	cnt = min((int) g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		const uint32_t e = lane < cnt ? e0 : NDBHIP_INVALID_BLOCK;
 		const bool	fresh = V.mark(e != NDBHIP_INVALID_BLOCK && e < g.nvisible && e != 0, e, lane);
 		unsigned long long todo = __ballot(fresh);
 
+		H2_PH(1);
 		while (todo)
 		{
 			const float *x[H2_NR];
@@ -382,10 +516,14 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 			}
 			h2_dist2x4(Q, x, n, lane, d);
 			evals += n;
+			H2_PH(2);
 			for (int u = 0; u < n; u++)
 				h2_offer(W, d[u], ids[u], lane);
+			H2_PH(3);
 		}
 	}
+	h2_set_spill(W, lane);
+	H2_PH_FLUSH;
 }
 
 /* greedy step of the upper layers: from (cur, curd) move to the nearest neighbour at `level` while one is nearer */

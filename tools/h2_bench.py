@@ -50,12 +50,20 @@ def main():
     gt = torch.topk(sims, 10, dim=1).indices.cpu().numpy() + 1
     for ef in efs:
         ix.search_intended(q[:256], ef, 10)
+        ph = (C.c_ulonglong * 8)()
+        check(lib().ndbhip_debug_h2_phases(ph))               # (reset: what follows is the timed search alone)
         t0 = time.perf_counter()
         ob, od, oc, oe = ix.search_intended(q, ef, 10)
         ts = time.perf_counter() - t0
         rec = float(np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nr)]))
         print(f"search ef={ef}: {nq / ts:.0f} queries/s ({ts * 1e3:.1f} ms per {nq}), recall@10 {rec:.3f}, "
               f"{oe.mean():.0f} evaluations/query")
+        check(lib().ndbhip_debug_h2_phases(ph))
+        if ph[4]:
+            # a profiling build (make EXTRA=-DNDB_PHASES): block 0's wave, microseconds per expansion
+            print("  phases of block 0's wave, us per expansion: " + ", ".join(
+                f"{name} {ph[i] / 100 / ph[4]:.2f}" for i, name in enumerate(("pick", "neighbours + marks", "rows", "offers"))) +
+                f"; {ph[4]} expansions")
 
 
 if __name__ == "__main__":
