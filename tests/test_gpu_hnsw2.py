@@ -56,7 +56,8 @@ def test_intended_build_and_search_equal_the_oracle(kind, n, dim, m, efc, bdiv, 
     assert np.array_equal(d["nbrs"][1:], e["nbrs"][1:]), np.argwhere(d["nbrs"] != e["nbrs"])[:5]
     if bmax == 1:
         assert nb == n
-    for ef, k in ((64, 10), (8, 8), (200, 37)):
+    # (ef <= 64: the result set lives sorted in the lanes' registers; above: in LDS — 1, 2, 63 / 64 / 65 are its edges)
+    for ef, k in ((64, 10), (8, 8), (200, 37), (1, 1), (2, 2), (63, 10), (65, 10)):
         ob, od, oc, oe = ix.search_intended(q, ef, k)
         for i in range(len(q)):
             eb, ed, ns = og.search_intended(q[i], ef, k)
