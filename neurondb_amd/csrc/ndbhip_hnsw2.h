@@ -200,16 +200,83 @@ h2_dist2_rows(const float *__restrict__ a, const float *__restrict__ b, int dim,
 }
 
 /* a wave's visited set: one bit per block in global memory (all zero at rest), the blocks it set logged for clearing */
+#define H2_HV 2048				/* slots of the LDS visited table of a search; three quarters full = it moves to the bitmap */
+#define H2_HV_MAX_EF 256			/* searches up to this ef start on the table (8 KB of LDS a walker) */
 struct H2Visited
 {
 	uint32_t   *bits;
 	uint32_t   *log;
 	uint32_t	nwords;
 	uint32_t	nlog;			/* uniform */
+	/* hv != NULL: the visited blocks of this search are an open-addressing table in LDS instead (block numbers are >= 1:
+	 * 0 = empty slot) — a search at ef 64 meets ~850 nodes, and marking 32 neighbours per expansion in a bitmap of one
+	 * bit per node (0.5 GB over the walkers) was 32 atomics on 32 random lines of HBM, a sixth of the walk's traffic.
+	 * More than 3/4 H2_HV marks: `over` is set, and before its next expansion the search moves the table's blocks into the
+	 * bitmap and carries on there (migrate). */
+	uint32_t   *hv;
+	uint32_t	nhv;			/* uniform */
+	bool		over;			/* uniform */
+
+	__device__ __forceinline__ bool mark_lds(bool act, uint32_t b)
+	{
+		bool		fresh = false;
+
+		if (act)
+		{
+			uint32_t	h = (b * 2654435761u) >> (32 - 11);		/* H2_HV = 2^11 */
+
+			for (;;)
+			{
+				const uint32_t old = atomicCAS(&hv[h], 0u, b);
+
+				if (old == 0u)
+				{
+					fresh = true;
+					break;
+				}
+				if (old == b)
+					break;
+				h = (h + 1u) & (H2_HV - 1u);
+			}
+		}
+		nhv += (uint32_t) __popcll(__ballot(fresh));
+		if (nhv > (H2_HV / 4u) * 3u)
+			over = true;
+		return fresh;
+	}
+	__device__ __forceinline__ void clear_lds(int lane)
+	{
+		for (uint32_t i = lane; i < H2_HV; i += 64)
+			hv[i] = 0u;
+		nhv = 0;
+		over = false;
+		__threadfence_block();
+	}
+
+	/* the table is three quarters full: its blocks go into the wave's bitmap and the search carries on there (same set of
+	 * visited blocks: nothing observable changes) */
+	__device__ __forceinline__ void migrate(int lane)
+	{
+		uint32_t   *const t = hv;
+
+		hv = nullptr;
+		for (uint32_t i0 = 0; i0 < H2_HV; i0 += 64)
+		{
+			const uint32_t b = t[i0 + lane];
+
+			(void) mark(b != 0u, b, lane);
+			t[i0 + lane] = 0u;
+		}
+		nhv = 0;
+		over = false;
+		__threadfence_block();
+	}
 
 	/* lanes with act: was block b unvisited (and now marked)?  One lane wins where several name the same block. */
 	__device__ __forceinline__ bool mark(bool act, uint32_t b, int lane)
 	{
+		if (hv)
+			return mark_lds(act, b);
 		bool		fresh = false;
 
 		if (act)
@@ -232,6 +299,11 @@ struct H2Visited
 	}
 	__device__ __forceinline__ void clear(int lane)
 	{
+		if (hv)
+		{
+			clear_lds(lane);
+			return;
+		}
 		if (nlog <= H2_LOG_CAP)
 			for (uint32_t i = lane; i < nlog; i += 64)
 				bits[log[i] >> 5] = 0;
@@ -470,6 +542,8 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 		H2_PH(0);
 		if (bi < 0)
 			break;
+		if (V.hv && V.over)			/* uniform */
+			V.migrate(lane);
 		H2_PH_COUNT(4);
 		if (W.inreg)
 		{
@@ -657,7 +731,7 @@ h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M
 __host__ __device__ static inline size_t
 h2_smem_bytes(uint32_t ef)
 {
-	return (size_t) ef * (8 + 4 + 1 + 8 + 4) + 64;
+	return (((size_t) ef * (8 + 4 + 1 + 8 + 4) + 64 + 15) & ~(size_t) 15) + (ef <= H2_HV_MAX_EF ? (size_t) H2_HV * 4 : 0);
 }
 
 /* kNN queries: greedy descent to level 1, layer search with ef at level 0, the k nearest ascending, distances as
@@ -683,6 +757,14 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 	V.log = vlog + (size_t) blockIdx.x * H2_LOG_CAP;
 	V.nwords = nwords;
 	V.nlog = 0;
+	/* the LDS visited table behind the set's arrays (h2_smem_bytes) */
+	uint32_t   *const hv_lds = ef <= H2_HV_MAX_EF ? (uint32_t *) (smem + (((size_t) ef * (8 + 4 + 1 + 8 + 4) + 64 + 15) & ~(size_t) 15)) : nullptr;
+
+	V.hv = hv_lds;
+	V.nhv = 0;
+	V.over = false;
+	if (hv_lds)
+		V.clear_lds(lane);
 	for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x)
 	{
 		H2Query		Q;
@@ -699,7 +781,8 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 			for (int lc = entry_level; lc >= 1; lc--)
 				h2_greedy(g, Q, lc, cur, curd, lane, evals);
 			h2_search_layer(g, Q, cur, curd, 0, W, V, lane, evals);
-			V.clear(lane);
+			V.clear(lane);			/* (the LDS table, or — after a migration — the bitmap) */
+			V.hv = hv_lds;
 			h2_sort(W, sid, sd, lane);
 			n = min(W.nw, k);
 			for (uint32_t i = lane; i < n; i += 64)
@@ -747,6 +830,9 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 	V.log = vlog + (size_t) blockIdx.x * H2_LOG_CAP;
 	V.nwords = nwords;
 	V.nlog = 0;
+	V.hv = nullptr;			/* (ef_construction walks meet thousands of nodes: the bitmap) */
+	V.nhv = 0;
+	V.over = false;
 	for (uint32_t i = blockIdx.x; i < nmem; i += gridDim.x)
 	{
 		const uint32_t x = first + i;
