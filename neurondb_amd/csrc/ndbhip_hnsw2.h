@@ -686,10 +686,31 @@ h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M
 		const double dc = cd[i];
 		bool		ok = true;
 
-		if (select & 1)
-			for (int j = 0; j < n && ok; j++)
-				if (h2_dist2_rows(g.vecs + (size_t) c * g.dim, g.vecs + (size_t) out[j] * g.dim, g.dim, lane) < dc)
-					ok = false;
+		if ((select & 1) && n > 0)
+		{
+			/* the candidate against everything taken so far, H2_NR rows at a time with their loads in flight together (one
+			 * row pair after the other, stopping at the first that is nearer, was up to 16 dependent round trips per
+			 * candidate — most of a build).  Same arithmetic (the candidate in the query's place: h2_dist2x4 = h2_dist2_rows
+			 * term for term), and whether ANY taken row is nearer does not depend on the order they are looked at. */
+			H2Query		C;
+
+			C.load(g.vecs + (size_t) c * g.dim, g.dim, lane);
+			for (int j0 = 0; j0 < n && ok; j0 += H2_NR)
+			{
+				const float *x[H2_NR];
+				double		d[H2_NR];
+				const int	nn = min(H2_NR, n - j0);
+
+#pragma unroll
+				for (int u = 0; u < H2_NR; u++)
+					x[u] = g.vecs + (size_t) (u < nn ? out[j0 + u] : c) * g.dim;
+				h2_dist2x4(C, x, nn, lane, d);
+#pragma unroll
+				for (int u = 0; u < H2_NR; u++)
+					if (u < nn && d[u] < dc)
+						ok = false;
+			}
+		}
 		if (ok)
 		{
 			if (lane == 0)

@@ -45,6 +45,12 @@ def main():
     st = (C.c_int64 * 6)()
     check(lib().ndbhip_hnsw_build_stats(ix._h, st))
     print(f"build {n} x {dim} {kind}: {tb:.2f} s = {n / tb:.0f} vectors/s, {st[4]} batches (largest {st[5]}), {st[0]} back-links")
+    ph = (C.c_ulonglong * 8)()
+    check(lib().ndbhip_debug_h2_phases(ph))
+    if ph[4]:
+        print("  build, phases of block 0's wave, us per expansion: " + ", ".join(
+            f"{name} {ph[i] / 100 / ph[4]:.2f}" for i, name in enumerate(("pick", "neighbours + marks", "rows", "offers"))) +
+            f"; {ph[4]} expansions, {sum(ph[:4]) / 100 / 1e6:.2f} s of the build in layer searches")
     nr = int(os.environ.get("H2_NR", "1000"))
     sims = q[:nr].double() @ x.double().T
     gt = torch.topk(sims, 10, dim=1).indices.cpu().numpy() + 1
