@@ -3404,7 +3404,7 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	uint32_t	nwords = 0;
 
 	if (h2_workspace(h, nwaves, nb, &nwords)) return NDBHIP_ERR_HIP;
-	const size_t smem = h2_smem_bytes((uint32_t) ef_construction);
+	const size_t smem = h2_smem_bytes((uint32_t) ef_construction, false);
 
 	HIP_TRY(hipFuncSetAttribute((const void *) k_h2_insert_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
 	/* per-batch scratch: selections (compact: a member has min(level, entry level) + 1 levels), groups, requests */

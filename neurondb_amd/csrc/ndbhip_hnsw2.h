@@ -750,9 +750,10 @@ h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M
 }
 
 __host__ __device__ static inline size_t
-h2_smem_bytes(uint32_t ef)
+h2_smem_bytes(uint32_t ef, bool table = true /* with the LDS visited table (the search; the build's walks outgrow it at once,
+											   * and its 8 KB a wave would cost the build a third of its walkers) */ )
 {
-	return (((size_t) ef * (8 + 4 + 1 + 8 + 4) + 64 + 15) & ~(size_t) 15) + (ef <= H2_HV_MAX_EF ? (size_t) H2_HV * 4 : 0);
+	return (((size_t) ef * (8 + 4 + 1 + 8 + 4) + 64 + 15) & ~(size_t) 15) + ((table && ef <= H2_HV_MAX_EF) ? (size_t) H2_HV * 4 : 0);
 }
 
 /* kNN queries: greedy descent to level 1, layer search with ef at level 0, the k nearest ascending, distances as
@@ -851,15 +852,9 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 	V.log = vlog + (size_t) blockIdx.x * H2_LOG_CAP;
 	V.nwords = nwords;
 	V.nlog = 0;
-	/* the LDS visited table behind the set's arrays (h2_smem_bytes); a level-0 walk at ef_construction 200 that outgrows it
-	 * moves on to the bitmap (H2Visited::migrate) */
-	uint32_t   *const hv_lds = efc <= H2_HV_MAX_EF ? (uint32_t *) (smem + (((size_t) efc * (8 + 4 + 1 + 8 + 4) + 64 + 15) & ~(size_t) 15)) : nullptr;
-
-	V.hv = hv_lds;
+	V.hv = nullptr;			/* (ef_construction walks meet thousands of nodes: the bitmap from the start) */
 	V.nhv = 0;
 	V.over = false;
-	if (hv_lds)
-		V.clear_lds(lane);
 	for (uint32_t i = blockIdx.x; i < nmem; i += gridDim.x)
 	{
 		const uint32_t x = first + i;
@@ -883,7 +878,6 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 
 			h2_search_layer(g, Q, cur, curd, lc, W, V, lane, evals);
 			V.clear(lane);
-			V.hv = hv_lds;
 			h2_sort(W, sid, sd, lane);
 			const int	n = h2_select(g, sid, sd, (int) W.nw, (lc == 0 && (select & 2)) ? 2 * g.m : g.m, select & 5, s_selid, s_seld, lane);
 
