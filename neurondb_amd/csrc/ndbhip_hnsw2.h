@@ -876,10 +876,28 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 		{
 			const size_t so = ((size_t) sel_off[i] + (size_t) (top - lc)) * 2 * g.m;	/* rows of 2m: level 0 may take that many */
 
+#ifdef NDB_PHASES
+			const unsigned long long ph_t0 = wall_clock64();
+#endif
 			h2_search_layer(g, Q, cur, curd, lc, W, V, lane, evals);
 			V.clear(lane);
+#ifdef NDB_PHASES
+			const unsigned long long ph_t1 = wall_clock64();
+#endif
 			h2_sort(W, sid, sd, lane);
+#ifdef NDB_PHASES
+			const unsigned long long ph_t2 = wall_clock64();
+#endif
 			const int	n = h2_select(g, sid, sd, (int) W.nw, (lc == 0 && (select & 2)) ? 2 * g.m : g.m, select & 5, s_selid, s_seld, lane);
+#ifdef NDB_PHASES
+			if (blockIdx.x == 0 && lane == 0)
+			{
+				/* [5] layer search + clearing, [6] sort, [7] selection: block 0's wave, all its members and levels */
+				atomicAdd(&g_h2_phases[5], ph_t1 - ph_t0);
+				atomicAdd(&g_h2_phases[6], ph_t2 - ph_t1);
+				atomicAdd(&g_h2_phases[7], wall_clock64() - ph_t2);
+			}
+#endif
 
 			if (lane == 0)
 			{

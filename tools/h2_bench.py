@@ -51,6 +51,7 @@ def main():
         print("  build, phases of block 0's wave, us per expansion: " + ", ".join(
             f"{name} {ph[i] / 100 / ph[4]:.2f}" for i, name in enumerate(("pick", "neighbours + marks", "rows", "offers"))) +
             f"; {ph[4]} expansions, {sum(ph[:4]) / 100 / 1e6:.2f} s of the build in layer searches")
+        print(f"  build, block 0's wave: layer searches + clearing {ph[5] / 1e8:.2f} s, sorts {ph[6] / 1e8:.2f} s, selections {ph[7] / 1e8:.2f} s")
     nr = int(os.environ.get("H2_NR", "1000"))
     sims = q[:nr].double() @ x.double().T
     gt = torch.topk(sims, 10, dim=1).indices.cpu().numpy() + 1
