@@ -3416,6 +3416,9 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	H2Req	   *d_req = nullptr;
 	const size_t bm = (size_t) batch_max, lvcap = bm * NDBHIP_HNSW_MAX_LEVEL;
 
+	uint32_t   *d_next = nullptr;	/* the batch's next unassigned member (k_h2_insert_search deals them to whichever wave is free) */
+
+	if (tmp.alloc(d_next, 16)) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_off, bm * 4)) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_sid, lvcap * m * 4)) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_sd2, lvcap * m * 8)) return NDBHIP_ERR_HIP;
@@ -3453,9 +3456,10 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 				nlev += (uint32_t) std::min(lev[done + i], entry_level) + 1u;
 			}
 			HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t) b * 4, hipMemcpyHostToDevice, g.stream));
+			HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
 			hipLaunchKernelGGL(k_h2_insert_search, dim3(std::min(b, nwaves)), dim3(64), smem, g.stream, h2_graph(h, first), first, b,
 							   (uint32_t) ef_construction, g_h2_select, entry, entry_level, (const uint32_t *) d_off, d_sid, d_sd2,
-							   d_sn, h->w_vbits, h->w_vlog, nwords);
+							   d_sn, h->w_vbits, h->w_vlog, nwords, d_next);
 			HIP_TRY(hipGetLastError());
 			sid.resize((size_t) nlev * m);
 			sd2.resize((size_t) nlev * m);

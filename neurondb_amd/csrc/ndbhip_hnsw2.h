@@ -833,7 +833,10 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 __global__ __launch_bounds__(64) void
 k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int select, uint32_t entry, int entry_level,
 				   const uint32_t *__restrict__ sel_off, uint32_t *__restrict__ sel_ids, double *__restrict__ sel_d2,
-				   int *__restrict__ sel_n, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords)
+				   int *__restrict__ sel_n, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords,
+				   uint32_t *__restrict__ next /* zero at launch: members are dealt to the waves as they come free — a member
+												 * costs 2 .. 10 ms, and with two a wave in a fixed order the batch waited
+												 * for the wave that drew two expensive ones */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	__shared__ uint32_t s_selid[128];
@@ -855,8 +858,15 @@ k_h2_insert_search(H2Graph g, uint32_t first, uint32_t nmem, uint32_t efc, int s
 	V.hv = nullptr;			/* (ef_construction walks meet thousands of nodes: the bitmap from the start) */
 	V.nhv = 0;
 	V.over = false;
-	for (uint32_t i = blockIdx.x; i < nmem; i += gridDim.x)
+	for (;;)
 	{
+		uint32_t	i = 0;
+
+		if (lane == 0)
+			i = atomicAdd(next, 1u);
+		i = (uint32_t) __builtin_amdgcn_readfirstlane((int) i);
+		if (i >= nmem)
+			break;
 		const uint32_t x = first + i;
 		const int	level = g.levels[x];
 		H2Query		Q;
