@@ -3331,7 +3331,8 @@ h2_workspace(ndbhip_hnsw *h, uint32_t nwaves, uint32_t nblocks, uint32_t *nwords
 		if (grow(h->w_vbits, h->w_vbits_n, (size_t) nwaves * nwords)) return NDBHIP_ERR_HIP;
 		HIP_TRY(hipMemsetAsync(h->w_vbits, 0, h->w_vbits_n * sizeof(uint32_t), g.stream));	/* all zero at rest */
 	}
-	if (grow(h->w_vlog, h->w_vlog_n, (size_t) nwaves * H2_LOG_CAP)) return NDBHIP_ERR_HIP;
+	/* (+ 64 words behind the logs: the "next query" counter of a search launch) */
+	if (grow(h->w_vlog, h->w_vlog_n, (size_t) nwaves * H2_LOG_CAP + 64)) return NDBHIP_ERR_HIP;
 	*nwords_out = nwords;
 	return 0;
 }
@@ -3592,10 +3593,13 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
 	if (h2_workspace(h, nwaves, h->nblocks, &nwords)) return NDBHIP_ERR_HIP;
 	const size_t smem = h2_smem_bytes(efe);
 
+	uint32_t   *d_next = h->w_vlog + (size_t) nwaves * H2_LOG_CAP;
+
+	HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
 	HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
 	hipLaunchKernelGGL(k_h2_search, dim3(nwaves), dim3(64), smem, g.stream, h2_graph(h, h->nblocks), d_queries, (uint32_t) nq, efe,
 					   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
-					   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals);
+					   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next);
 	HIP_TRY(hipGetLastError());
 	return NDBHIP_OK;
 }

@@ -762,7 +762,10 @@ __global__ __launch_bounds__(64) void
 k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level,
 			const uint64_t *__restrict__ tids, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords,
 			uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
-			uint64_t *__restrict__ out_tids, long long *__restrict__ out_evals)
+			uint64_t *__restrict__ out_tids, long long *__restrict__ out_evals,
+			uint32_t *__restrict__ next /* zero at launch: queries are dealt to the waves as they come free (a query costs
+										  * 400 .. 2500 evaluations: two a wave in a fixed order left the batch waiting for the
+										  * unluckiest wave) */ )
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int	lane = threadIdx.x;
@@ -787,8 +790,15 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 	V.over = false;
 	if (hv_lds)
 		V.clear_lds(lane);
-	for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x)
+	for (;;)
 	{
+		uint32_t	q = 0;
+
+		if (lane == 0)
+			q = atomicAdd(next, 1u);
+		q = (uint32_t) __builtin_amdgcn_readfirstlane((int) q);
+		if (q >= nq)
+			break;
 		H2Query		Q;
 		long long	evals = 0;
 		uint32_t	n = 0;
