@@ -4312,8 +4312,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16c_seeds"))
 	{
-		if (value != 0 && value != 32 && value != 64)
-			return fail(NDBHIP_ERR_INVALID, "screen16c_seeds must be 0 (default), 32 or 64");
+		if (value != 0 && value != 16 && value != 24 && value != 32 && value != 48 && value != 64)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_seeds must be 0 (default), 16, 24, 32, 48 or 64");
 		g_s16c_seeds = value;
 	}
 	else if (!strcmp(name, "screen16_ip_centered"))

@@ -7,4 +7,4 @@ print(sys.argv[1], d['value'], d['ms_per_step'], r.get('avg_launch_ms'), r.get('
 run --steps 30
 run --steps 30 --opt screen16c_seeds=16
 run --steps 30 --opt screen16c_seeds=24
-run --steps 30 --opt screen16c_seeds=64
+run --steps 30 --opt screen16c_seeds=48
