@@ -34,6 +34,20 @@
 #define S16D_BUF 65536			/* a chunk in the ring: 8 row blocks, then 8 pair blocks, 4 KiB each */
 #define S16D_QOFF 32768
 
+/* profiling builds (-DNDB_PHASES): 100 MHz clock ticks wave 0 and wave 4 of block 0 spend in the parts of the sweep, summed
+ * over the launch: g_phases[32 + 8 w + i], w = 0 (a loader) / 1 (a multiplier), i = 0 waiting for the chunk's DMA, 1 at
+ * the chunk's barrier, 2 requesting the next chunk, 3 multiplying, 4 the item's results (pass 0, records), 5 tightening,
+ * 6 items */
+#ifdef NDB_PHASES
+#define S16D_PH_DECL unsigned long long d_ph_t = wall_clock64(), d_ph[7] = {0, 0, 0, 0, 0, 0, 0}
+#define S16D_PH(I) do { const unsigned long long d_now = wall_clock64(); d_ph[I] += d_now - d_ph_t; d_ph_t = d_now; } while (0)
+#define S16D_PH_FLUSH do { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) for (int d_i = 0; d_i < 7; d_i++) atomicAdd(&g_phases[32 + 8 * (wave >> 2) + d_i], d_ph[d_i]); } while (0)
+#else
+#define S16D_PH_DECL ((void) 0)
+#define S16D_PH(I) ((void) 0)
+#define S16D_PH_FLUSH ((void) 0)
+#endif
+
 template <int DBG = 0>
 __global__ __launch_bounds__(512, 1) void
 k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
@@ -223,6 +237,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	const int	rfrag = (4 * wr) * 4096 + r32 * 128;
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
 
+	S16D_PH_DECL;
 	enter(it_c, 0);
 	if (loader)
 		step();
@@ -274,10 +289,14 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		auto		chunk = [&]() {
 			if (loader)
 				s16_wait_vm<0>();
+			S16D_PH(0);
 			__syncthreads();
+			S16D_PH(1);
 			if (loader || pfd > 0)
 				step();
+			S16D_PH(2);
 			compute(ring + (g_c & 1u) * S16D_BUF);
+			S16D_PH(3);
 			g_c++;
 		};
 
@@ -479,6 +498,10 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 #undef S16D_BLK
 		if (hq_n != 0)
 			flush();
+		S16D_PH(4);
+#ifdef NDB_PHASES
+		d_ph[6]++;
+#endif
 		if constexpr (DBG == 0)
 		{
 			/* a query that keeps emitting has a loose threshold: the k-th smallest bucket minimum bounds its k-th
@@ -521,6 +544,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			if (tid == 0 && s_tn != 0)
 				s_tn = 0;
 		}
+		S16D_PH(5);
 		it_c += stride;
 		if (it_c >= run_hi)
 			break;
@@ -528,6 +552,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		/* (no barrier: the next item's first chunk starts with one, and the per-item arrays of parity c_par ^ 1 are
 		 * requested again only by an `enter` behind that barrier) */
 	}
+	S16D_PH_FLUSH;
 }
 
 #endif							/* NDBHIP_SCREEN16D_H */

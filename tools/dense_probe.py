@@ -74,6 +74,16 @@ def main():
         fb = s1["screen16_fallbacks"] - s0["screen16_fallbacks"]
         em = (s1["rows_emitted"] - s0["rows_emitted"]) / steps / nq
         rs = (s1["rows_rescored"] - s0["rows_rescored"]) / steps / nq
+        import ctypes as _C
+        ph = (_C.c_ulonglong * 64)()
+        check(lib().ndbhip_debug_phases(ph))
+        if ph[32 + 6]:
+            # a profiling build (make EXTRA=-DNDB_PHASES): block 0's wave 0 (a loader) and wave 4 (a multiplier), the last launch
+            names = ("DMA wait", "barrier", "request", "multiply", "results", "tighten")
+            for w, who in ((0, "loader"), (1, "multiplier")):
+                items = max(1, ph[32 + 8 * w + 6])
+                print("    " + who + ", us per item: " + ", ".join(f"{nm} {ph[32 + 8 * w + i] / 100 / items:.2f}" for i, nm in enumerate(names)) +
+                      f"; {items} items", flush=True)
         print(f"{v or 'defaults':48s} step {dt * 1e3:8.3f} ms  sweep {kms:8.3f} ms  issued {tf:7.1f} TFLOP/s  "
               f"launches/step {launches / steps:.1f} fallbacks {fb} emitted/q {em:.0f} rescored/q {rs:.1f} {same}", flush=True)
 
