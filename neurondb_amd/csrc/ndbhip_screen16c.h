@@ -201,6 +201,104 @@ k_s16c_set_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ idx, con
 }
 
 /*
+ * k_s16c_qcprep's work for G consecutive pair records j .. j + G - 1 of one wave (dims in multiples of 4, up to 256 NT):
+ * 16 bytes per lane and load, the loads of all G pairs in flight together and their fp64 sums folded side by side — one
+ * pair after the other was two memory round trips and twelve cross-lane steps per pair, 0.47 ms of a 4096-query batch on
+ * 10 M rows —, every q_i - c_i kept in registers for the plane.  `lo` = the bucket of pair j - 1 on entry, of the last
+ * pair on return.
+ */
+template <int NT, int G>
+__device__ __forceinline__ void
+s16c_qc_group(const float *__restrict__ queries, int dim, int dimp, const PairRec *__restrict__ pairs,
+			  const uint32_t *__restrict__ pair_off, int nb, const float *__restrict__ cents,
+			  const float *const *__restrict__ cptr, _Float16 *__restrict__ qcplanes, size_t chunk_plane,
+			  float *__restrict__ qcn2, int *__restrict__ qcexp, uint32_t *__restrict__ pqid, uint32_t *__restrict__ pla,
+			  uint32_t *__restrict__ pnrow, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t j, uint32_t &lo,
+			  int lane)
+{
+	PairRec		pr[G];
+	const float *q[G], *c[G];
+	float4		dv[G][NT];
+	double		s[G];
+
+#pragma unroll
+	for (int g = 0; g < G; g++)
+	{
+		while (lo + 1 < (uint32_t) nb && pair_off[lo + 1] <= j + (uint32_t) g)
+			lo++;
+		pr[g] = pairs[j + g];
+		q[g] = queries + (size_t) pr[g].q * dim;
+		c[g] = cptr ? cptr[lo] : cents + (size_t) lo * dim;
+	}
+#pragma unroll
+	for (int g = 0; g < G; g++)
+#pragma unroll
+		for (int t = 0; t < NT; t++)
+		{
+			const int	i = t * 256 + lane * 4;
+
+			dv[g][t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (i < dim)
+			{
+				const float4 qv = *reinterpret_cast<const float4 *>(q[g] + i), cv = *reinterpret_cast<const float4 *>(c[g] + i);
+
+				dv[g][t] = make_float4(qv.x - cv.x, qv.y - cv.y, qv.z - cv.z, qv.w - cv.w);
+			}
+		}
+#pragma unroll
+	for (int g = 0; g < G; g++)
+	{
+		s[g] = 0.0;
+#pragma unroll
+		for (int t = 0; t < NT; t++)
+			s[g] += (double) dv[g][t].x * (double) dv[g][t].x + (double) dv[g][t].y * (double) dv[g][t].y +
+				(double) dv[g][t].z * (double) dv[g][t].z + (double) dv[g][t].w * (double) dv[g][t].w;
+	}
+#pragma unroll
+	for (int g = 0; g < G; g++)
+		s[g] = wave_sum_f64(s[g]);
+#pragma unroll
+	for (int g = 0; g < G; g++)
+	{
+		const uint32_t jj = j + (uint32_t) g;
+		const bool	ok = s[g] <= 3.0e38;
+		const int	e = ok ? s16_exponent(s[g]) : 0;
+
+		if (lane == 0)
+		{
+			const uint32_t *lq = loc_cand_off + (size_t) pr[g].q * (npr + 1);
+
+			qcn2[jj] = ok ? (float) s[g] : __uint_as_float(0x7FC00000u);
+			qcexp[jj] = e;
+			pqid[jj] = pr[g].q;
+			pla[jj] = lq[pr[g].p];
+			pnrow[jj] = lq[pr[g].p + 1] - lq[pr[g].p];
+		}
+		_Float16   *out = qcplanes + (chunk_plane ? (size_t) jj * 64 : (size_t) jj * dimp);
+		const float sc = ldexpf(1.0f, 14 - e);
+
+#pragma unroll
+		for (int t = 0; t < NT; t++)
+		{
+			const int	i = t * 256 + lane * 4;
+
+			if (i >= dimp)
+				continue;
+			ndb_h2		h01, h23;
+
+			h01.x = ok ? (_Float16) (dv[g][t].x * sc) : (_Float16) 0;
+			h01.y = ok ? (_Float16) (dv[g][t].y * sc) : (_Float16) 0;
+			h23.x = ok ? (_Float16) (dv[g][t].z * sc) : (_Float16) 0;
+			h23.y = ok ? (_Float16) (dv[g][t].w * sc) : (_Float16) 0;
+			_Float16   *o = chunk_plane ? out + (size_t) (i >> 6) * chunk_plane + (i & 63) : out + i;
+			ndb_h2		pk[2] = {h01, h23};
+
+			*reinterpret_cast<uint2 *>(o) = *reinterpret_cast<const uint2 *>(pk);
+		}
+	}
+}
+
+/*
  * One wave per (query, bucket) pair record, in the pair tables' order (slot j = pair_off[bucket] + i): the plane of
  * q - c in natural element order (the sweep's DMA applies the LDS swizzle), qcn2[j] = |q - c|^2 as computed (NaN:
  * not a finite fp32 — every element of the pair is emitted), qcexp[j], and the pair's query / first candidate
@@ -261,7 +359,28 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 				hi = mid;
 		}
 	}
-	for (uint32_t j = j0; j < j1; j++)
+	uint32_t	jv = j0;
+
+	if ((dim & 3) == 0 && dim <= 2048)
+	{
+#define S16C_QC_ARGS queries, dim, dimp, pairs, pair_off, nb, cents, cptr, qcplanes, chunk_plane, qcn2, qcexp, pqid, pla, pnrow, loc_cand_off, npr
+		if (dim <= 1024)
+		{
+			for (; jv + 4 <= j1; jv += 4)
+				s16c_qc_group<4, 4>(S16C_QC_ARGS, jv, lo, lane);
+			for (; jv < j1; jv++)
+				s16c_qc_group<4, 1>(S16C_QC_ARGS, jv, lo, lane);
+		}
+		else
+		{
+			for (; jv + 2 <= j1; jv += 2)
+				s16c_qc_group<8, 2>(S16C_QC_ARGS, jv, lo, lane);
+			for (; jv < j1; jv++)
+				s16c_qc_group<8, 1>(S16C_QC_ARGS, jv, lo, lane);
+		}
+#undef S16C_QC_ARGS
+	}
+	for (uint32_t j = jv; j < j1; j++)
 	{
 		while (lo + 1 < (uint32_t) nb && pair_off[lo + 1] <= j)
 			lo++;
@@ -269,34 +388,6 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 		const float *q = queries + (size_t) pr.q * dim;
 		const float *c = cptr ? cptr[lo] : cents + (size_t) lo * dim;
 		double		s = 0.0;
-		/* dims up to 2048 in multiples of 4 (the usual case): 16 bytes per lane and load, every q_i - c_i kept in registers
-		 * for the plane below (the second pass over q and c, a dependent round trip per pair, was a third of this kernel's
-		 * time at 1536 dimensions) */
-		const bool	vec = (dim & 3) == 0 && dim <= 2048;
-		float4		dv[8];
-
-		if (vec)
-		{
-#pragma unroll
-			for (int t = 0; t < 8; t++)
-			{
-				const int	i = t * 256 + lane * 4;
-
-				dv[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-				if (i < dim)
-				{
-					const float4 qv = *reinterpret_cast<const float4 *>(q + i), cv = *reinterpret_cast<const float4 *>(c + i);
-
-					dv[t] = make_float4(qv.x - cv.x, qv.y - cv.y, qv.z - cv.z, qv.w - cv.w);
-				}
-			}
-#pragma unroll
-			for (int t = 0; t < 8; t++)
-				s += (double) dv[t].x * (double) dv[t].x + (double) dv[t].y * (double) dv[t].y +
-					(double) dv[t].z * (double) dv[t].z + (double) dv[t].w * (double) dv[t].w;
-		}
-		else
-
 		for (int i = lane; i < dim; i += 64)
 		{
 			const float d = q[i] - c[i];
@@ -324,29 +415,6 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
 		 * can have, the product exact (below 2^-126 it is flushed: inside the 2^-25 the error model allows an element) */
 		const float sc = ldexpf(1.0f, 14 - e);
 
-		if (vec)
-		{
-#pragma unroll
-			for (int t = 0; t < 8; t++)
-			{
-				const int	i = t * 256 + lane * 4;
-
-				if (i >= dimp)
-					continue;
-				ndb_h2		h01, h23;
-
-				h01.x = ok ? (_Float16) (dv[t].x * sc) : (_Float16) 0;
-				h01.y = ok ? (_Float16) (dv[t].y * sc) : (_Float16) 0;
-				h23.x = ok ? (_Float16) (dv[t].z * sc) : (_Float16) 0;
-				h23.y = ok ? (_Float16) (dv[t].w * sc) : (_Float16) 0;
-				_Float16   *o = chunk_plane ? reinterpret_cast<_Float16 *>(out) + (size_t) (i >> 6) * chunk_plane + (i & 63)
-					: reinterpret_cast<_Float16 *>(out) + i;
-				ndb_h2		pk[2] = {h01, h23};
-
-				*reinterpret_cast<uint2 *>(o) = *reinterpret_cast<const uint2 *>(pk);
-			}
-			continue;
-		}
 		for (int p = lane; p < dimp / 2; p += 64)
 		{
 			const int	i = 2 * p;
