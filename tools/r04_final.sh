@@ -23,7 +23,7 @@ PY
 NQS=1,8,16,32,64,128,256,512,1024 timeout 600 python3 tools/small_batch_probe.py 2>&1 | grep -E "nq=" > gpurun_out/r04_final_small_batch.txt; cat gpurun_out/r04_final_small_batch.txt
 timeout 300 python3 tools/latency.py 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/r04_final_latency.txt; cat gpurun_out/r04_final_latency.txt
 : > gpurun_out/r04_fuzz_scan.txt
-for seed in 51 52 53; do
+for seed in 61 62; do
   timeout 420 python3 tools/fuzz_scan.py 300 $seed 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-700 >> gpurun_out/r04_fuzz_scan.txt
 done
 cat gpurun_out/r04_fuzz_scan.txt
