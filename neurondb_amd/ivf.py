@@ -200,6 +200,19 @@ class IvfIndex:
                                       _ptr(t6), _ptr(d), _ptr(cnt)))
         return t6.view(TID_DTYPE).reshape(nq, k), d, cnt
 
+    def search_mapped(self, base_ptr, offsets, strategy=1, nprobe=IVF_DEFAULT_NPROBE, k=IVF_DEFAULT_K, max_candidates=0):
+        """Queries scattered in device-visible host memory: query i = the dim floats at base_ptr + offsets[i] (bytes);
+        base_ptr = the DEVICE pointer of that memory (ndbhip_ivf_search_mapped: what the device-owner service does with
+        its request ring).  Returns like search()."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        nq = len(off)
+        t6 = np.zeros((nq, k, 6), dtype=np.uint8)
+        d = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.int32)
+        check(lib().ndbhip_ivf_search_mapped(self._h, C.c_void_p(int(base_ptr)), _ptr(off), nq, strategy, nprobe, k,
+                                             int(max_candidates), _ptr(t6), _ptr(d), _ptr(cnt)))
+        return t6.view(TID_DTYPE).reshape(nq, k), d, cnt
+
     def search_device(self, d_queries, out_tids, out_dist, out_count, strategy=1, nprobe=IVF_DEFAULT_NPROBE,
                       k=IVF_DEFAULT_K, max_candidates=0):
         """torch device tensors in/out; asynchronous on the current ndbhip stream."""

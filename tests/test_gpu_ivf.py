@@ -771,3 +771,33 @@ def test_randomised_parity_campaign_all_scan_modes():
     finally:
         _lib.check(_lib.lib().ndbhip_set_scan_mode(0))
     assert n >= 20
+
+
+@pytest.mark.parametrize("dim,nq", [(64, 300), (100, 37), (33, 9)])
+def test_queries_gathered_from_mapped_host_memory_give_the_same_answers(dim, nq):
+    """ndbhip_ivf_search_mapped (what the device-owner service serves its ring with): the queries lie scattered in pinned
+    host memory — other bytes between them, not in order, some of them not 16-byte aligned — and a kernel gathers them;
+    the answers are ndbhip_ivf_search's, hence the oracle's."""
+    import torch
+    from neurondb_amd import IvfIndex, _lib
+    _lib.ensure_init()
+    n, nlists = 4000, 12
+    a = make_ivf_arrays(n, dim, nlists, seed=dim + 3, dup_frac=0.05)
+    ix = IvfIndex(dim, nlists)
+    ix.set_centroids(a["centroids"])
+    ix.load(a["list_len"], a["rows"], a["tids"])
+    rng = np.random.default_rng(dim)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[: nq // 2] = a["rows"][rng.integers(0, n, nq // 2)]
+    stride = dim * 4 + 4 * int(rng.integers(1, 40))            # a slot: the query and some bytes of something else
+    ring = torch.zeros(nq * stride + 64, dtype=torch.uint8).pin_memory()
+    order = rng.permutation(nq)                                 # query i lives in slot order[i]
+    offs = (order * stride + 4).astype(np.int64)                # (+ 4: every other slot start is not 16-byte aligned)
+    host = ring.numpy()
+    for i in range(nq):
+        host[offs[i]: offs[i] + dim * 4] = q[i].view(np.uint8)
+    for strategy, nprobe, k in ((1, 5, 10), (3, nlists, 7), (2, 3, 1)):
+        et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, strategy, nprobe, k, 0)
+        t, d, c = ix.search_mapped(ring.data_ptr(), offs, strategy, nprobe, k)
+        assert_same_results(t, d, c, et, ed, ec)
+    ix.close()
