@@ -2908,6 +2908,7 @@ ivf_recipe(int strategy)
 #include "ndbhip_screen16.h"
 #include "ndbhip_screen16c.h"
 #include "ndbhip_screen16d.h"
+#include "ndbhip_screen16w.h"
 
 /* ---- inner product on the centred sweep (ndbhip_screen16.h: s16c_ip_*): M^2 and the rows' constants M^2 - |x|^2 ---- */
 /* one wave per mirror row: |x|^2 (fp64 sum, rounded to fp32), and the largest of them (float bits; NaN / inf rows are
@@ -3064,6 +3065,7 @@ static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch
 static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
+static int	g_s16c_wave = 5;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 5; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
 static int	g_s16_redo = 1;		/* queries whose records / survivors overflow go to the exact path alone ("screen16_redo"; 0: the whole batch does) */
@@ -3932,9 +3934,33 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight)
+			/* chunks in flight per wave of the register-streaming sweep: the option's value if it divides the item's chunks */
+			const int	nchk = dimp / S16C_CH;
+			const int	wd = (c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk < 2) ? 0 : std::min(g_s16c_wave, nchk);
+#define S16C_WSWEEP_L(DD, IPXX)                                                                                        \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_wsweep<DD, IPXX>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, \
+							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
+							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
+							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
+							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (const uint32_t *) ix->w_pslot,            \
+							   (const uint32_t *) (ix->w_pslot + qc_cap), (const uint32_t *) (ix->w_pslot + 2 * (size_t) qc_cap), \
+							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
+							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
+							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0,                                       \
+							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, ipc ? (const float *) ix->w_qev : (const float *) nullptr)
+#define S16C_WSWEEP_D(DD) do { if (ipc) S16C_WSWEEP_L(DD, true); else S16C_WSWEEP_L(DD, false); } while (0)
 			if (dense_k)
 				g.stats.dense_sweeps++;
-			if (dense_k && g_s16_debug == 6)
+			if (wd == 2)
+				S16C_WSWEEP_D(2);
+			else if (wd == 3)
+				S16C_WSWEEP_D(3);
+			else if (wd == 4)
+				S16C_WSWEEP_D(4);
+			else if (wd == 5)
+				S16C_WSWEEP_D(5);
+			else if (dense_k && g_s16_debug == 6)
 				S16C_DENSE_L(6);
 			else if (dense_k && g_s16_debug == 7)
 				S16C_DENSE_L(7);
@@ -4352,6 +4378,12 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16c_epi"))
 		g_s16c_epi = value != 0;
+	else if (!strcmp(name, "screen16c_wave"))
+	{
+		if (value != 0 && (value < 2 || value > 5))
+			return fail(NDBHIP_ERR_INVALID, "screen16c_wave must be 0 (the LDS ring) or 2 .. 5 chunks in flight");
+		g_s16c_wave = value;
+	}
 	else if (!strcmp(name, "screen16c_nbuf"))
 	{
 		if (value != 0 && value != 2 && value != 3)

@@ -23,6 +23,13 @@
 
 #define S16C_CH 64				/* dimensions per staged chunk (four MFMA k-steps) */
 
+/* byte offset, inside a chunk's 4 KiB image of a 32-row block, of the 16-byte unit (row rr, logical slot t = 2 kstep + khalf) */
+__device__ __forceinline__ uint32_t
+s16c_unit(int rr, int t)
+{
+	return (uint32_t) (t >> 1) * 1024u + (uint32_t) (((t & 1) << 5) + rr) * 16u;
+}
+
 /* T from a float4 reference distance that bounds the k-th distance from above / from the k-th smallest upper
  * bound `ub` of distinct candidates (ndbhip_common.h (7), (8)) */
 __device__ __forceinline__ float
@@ -38,9 +45,12 @@ s16c_t_from_ub(float ub, int dim)
 
 /*
  * One wave per plane row.  planes[(blk * nchunk + c) * 4096 + image]: the 32 rows of block blk for the 64-dimension
- * chunk c, [r][8 slots of 16 bytes], logical slot s = elements 8 s .. 8 s + 7 of the chunk (s = 2 kstep + khalf),
- * stored at slot s ^ ((r >> 1) & 7) — the geometry of k_s16_row_prep's image with the second plane's slots
- * holding the chunk's next 32 dimensions instead.  rn2[padded row] = |x - c|^2 as computed (NaN: not a finite fp32,
+ * chunk c in FRAGMENT-MAJOR order (r5): the 16-byte unit of row r, logical slot t = elements 8 t .. 8 t + 7 of the
+ * chunk (t = 2 kstep + khalf), sits at s16c_unit(r, t) = kstep * 1024 + (32 khalf + r) * 16 — lane (r, khalf) of a
+ * wave finds its operand of k-step `kstep` at image + 1024 kstep + 16 lane, so that a wave reads a k-step's 1 KiB with
+ * ONE fully coalesced 16-byte-per-lane load straight into the registers the matrix instruction takes
+ * (k_s16c_wsweep, ndbhip_screen16w.h), and the LDS-staged sweeps (a straight 4 KiB DMA, then ds_read_b128 at
+ * 1024 kstep + 16 lane: consecutive lanes, consecutive banks) need no swizzle.  rn2[padded row] = |x - c|^2 as computed (NaN: not a finite fp32,
  * the row's elements are always emitted), rexp[..] its scale exponent, pposof[..] the row's index in its list.
  */
 __global__ __launch_bounds__(256) void
@@ -100,7 +110,7 @@ k_s16c_row_prep(const float *__restrict__ vecs, int64_t nrows, int dim, int dimp
 	const size_t blk = (size_t) blk_off[lo] + (pos >> 5);
 	const int	rr = (int) (pos & 31u);
 	const int	nchunk = dimp / S16C_CH;
-	unsigned char *img = planes + blk * (size_t) nchunk * 4096 + (size_t) rr * 128;
+	unsigned char *img = planes + blk * (size_t) nchunk * 4096;
 
 	for (int p = lane; p < dimp / 2; p += 64)
 	{
@@ -114,7 +124,7 @@ k_s16c_row_prep(const float *__restrict__ vecs, int64_t nrows, int dim, int dimp
 		ndb_h2		h;
 
 		h.x = h0; h.y = h1;
-		*reinterpret_cast<ndb_h2 *>(img + (size_t) ch * 4096 + 16 * ((j >> 2) ^ ((rr >> 1) & 7)) + 4 * (j & 3)) = h;
+		*reinterpret_cast<ndb_h2 *>(img + (size_t) ch * 4096 + s16c_unit(rr, j >> 2) + 4 * (j & 3)) = h;
 	}
 }
 
@@ -172,7 +182,7 @@ k_s16c_row_append(const float *__restrict__ vecs, int dim, int dimp, const S16CA
 	const size_t blk = (size_t) (a.pp >> 5);
 	const int	rr = (int) (a.pp & 31);
 	const int	nchunk = dimp / S16C_CH;
-	unsigned char *img = planes + blk * (size_t) nchunk * 4096 + (size_t) rr * 128;
+	unsigned char *img = planes + blk * (size_t) nchunk * 4096;
 
 	for (int p = lane; p < dimp / 2; p += 64)
 	{
@@ -186,7 +196,7 @@ k_s16c_row_append(const float *__restrict__ vecs, int dim, int dimp, const S16CA
 		ndb_h2		h;
 
 		h.x = h0; h.y = h1;
-		*reinterpret_cast<ndb_h2 *>(img + (size_t) ch * 4096 + 16 * ((j >> 2) ^ ((rr >> 1) & 7)) + 4 * (j & 3)) = h;
+		*reinterpret_cast<ndb_h2 *>(img + (size_t) ch * 4096 + s16c_unit(rr, j >> 2) + 4 * (j & 3)) = h;
 	}
 }
 
@@ -1149,7 +1159,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 	const int	sw = (r32 >> 1) & 7;
 	const int	qfrag = G::Q_OFF + (G::AQ * wq) * 4096 + r32 * 128;
-	const int	rfrag = (G::BR * wr) * 4096 + r32 * 128;
+	const int	rfrag = (G::BR * wr) * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
 	/* did the request for chunk g (g = g_c + 1 .. g_c + NBUF - 2, the ones that stay in flight across a wait) include
 	 * pair rows: one bit per ring slot */
@@ -1209,7 +1219,7 @@ k_s16c_sweep(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					ah[a] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + a * 4096 + (((2 * s + kh) ^ sw) * 16));
 #pragma unroll
 				for (int b = 0; b < G::BR; b++)
-					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + (((2 * s + kh) ^ sw) * 16));
+					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + s * 1024);
 #pragma unroll
 				for (int a = 0; a < G::AQ; a++)
 				{

@@ -234,7 +234,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 	const int	sw = (r32 >> 1) & 7;
 	const int	qfrag = S16D_QOFF + (2 * wq) * 4096 + r32 * 128;
-	const int	rfrag = (4 * wr) * 4096 + r32 * 128;
+	const int	rfrag = (4 * wr) * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
 
 	S16D_PH_DECL;
@@ -277,7 +277,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 					ah[a] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + a * 4096 + (((2 * s + kh) ^ sw) * 16));
 #pragma unroll
 				for (int b = 0; b < 4; b++)
-					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + (((2 * s + kh) ^ sw) * 16));
+					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + s * 1024);
 #pragma unroll
 				for (int a = 0; a < 2; a++)
 #pragma unroll

@@ -123,7 +123,9 @@ def one_case(rng, lib, IvfIndex, check):
     # dense kernel tightens, inner product on the centred planes or on two planes, rows streamed through LDS (ring depth)
     r4 = {"screen16c_dense": int(rng.random() < 0.75), "screen16c_sample": int(rng.choice([0, 256, 2048])),
           "screen16c_tight": int(rng.choice([8, 128, 1024])), "screen16_ip_centered": int(rng.random() < 0.75),
-          "screen16_stage": int(rng.choice([0, 1, 1, 2, 5, 13]))}
+          "screen16_stage": int(rng.choice([0, 1, 1, 2, 5, 13])),
+          # round 5: the 32-pair tile as wave-autonomous register streams (chunks in flight per wave) or the LDS ring
+          "screen16c_wave": int(rng.choice([0, 2, 3, 4, 5, 5]))}
     for name, value in r4.items():
         check(lib.ndbhip_set_option(name.encode(), value))
     if os.environ.get("FUZZ_TRACE"):
