@@ -365,6 +365,33 @@ def main():
         ph = list(ph)
         sys.stderr.write("[phases] cent_select us: " + " ".join(f"{(ph[i + 1] - ph[i]) / 100:.1f}" for i in range(0, 7)) +
                          "   finalize us: " + " ".join(f"{(ph[i + 1] - ph[i]) / 100:.1f}" for i in range(16, 21)) + "\n")
+    if os.environ.get("NDB_TRACE"):
+        # a profiling build (make EXTRA=-DNDB_PHASES): the register-streaming sweep's per-wave trace of the last step
+        import ctypes as _C
+        nw = 24576
+        tr = (_C.c_ulonglong * nw)()
+        check(lib().ndbhip_debug_trace(tr, nw))
+        tr = np.array(list(tr), dtype=np.int64).reshape(-1, 12)
+        tr = tr[tr[:, 1] > 0]
+        if len(tr):
+            t0w, t1w = tr[:, 0].min(), tr[:, 1].max()
+            span = (t1w - t0w) / 100.0
+            ends = (tr[:, 1] - t0w) / 100.0
+            starts = (tr[:, 0] - t0w) / 100.0
+            busy = (tr[:, 1] - tr[:, 0]) / 100.0
+            sys.stderr.write(f"[trace] waves {len(tr)} span {span:.1f} us; start p50/p99/max {np.percentile(starts, 50):.1f}/"
+                             f"{np.percentile(starts, 99):.1f}/{starts.max():.1f}; end min/p10/p50/p90/max {ends.min():.1f}/"
+                             f"{np.percentile(ends, 10):.1f}/{np.percentile(ends, 50):.1f}/{np.percentile(ends, 90):.1f}/{ends.max():.1f}; "
+                             f"busy mean {busy.mean():.1f}; wait share {tr[:, 3].sum() / max(1, (tr[:, 1] - tr[:, 0]).sum()):.3f}; "
+                             f"items/wave min/mean/max {tr[:, 2].min()}/{tr[:, 2].mean():.2f}/{tr[:, 2].max()}; "
+                             f"us per item {busy.sum() / max(1, tr[:, 2].sum()):.2f}; emission path: share {tr[:, 4].sum() / max(1, (tr[:, 1] - tr[:, 0]).sum()):.3f}, "
+                             f"items taking it {tr[:, 5].sum() / max(1, tr[:, 2].sum()):.3f}, us each {tr[:, 4].sum() / 100.0 / max(1, tr[:, 5].sum()):.2f}; "
+                             f"looking for work elsewhere: share {tr[:, 6].sum() / max(1, (tr[:, 1] - tr[:, 0]).sum()):.3f}; "
+                             f"emission path us per taking item: members' constants {tr[:, 8].sum() / 100.0 / max(1, tr[:, 5].sum()):.2f}, "
+                             f"per-element test {tr[:, 9].sum() / 100.0 / max(1, tr[:, 5].sum()):.2f}, counts + slots {tr[:, 10].sum() / 100.0 / max(1, tr[:, 5].sum()):.2f}, "
+                             f"records {tr[:, 11].sum() / 100.0 / max(1, tr[:, 5].sum()):.2f}; a wave's longest item us p50/p90/p99/max "
+                             f"{np.percentile(tr[:, 7], 50) / 100.0:.1f}/{np.percentile(tr[:, 7], 90) / 100.0:.1f}/{np.percentile(tr[:, 7], 99) / 100.0:.1f}/{tr[:, 7].max() / 100.0:.1f}\n")
+            np.save(os.environ["NDB_TRACE"], tr)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

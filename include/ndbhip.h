@@ -83,6 +83,11 @@ const char *ndbhip_last_error(void);
  * synchronise with the legacy default stream (handle 0) either — a caller that produces or consumes device
  * buffers on another stream passes that stream here (neurondb_amd/_lib.py: use_torch_stream). */
 int			ndbhip_set_stream(void *hip_stream);
+/* The CALLING THREAD's stream: every entry point this thread calls afterwards launches on it instead of the process-wide
+ * one (NULL: back to that).  Two host threads, each with a stream and a mirror of its own, keep two batches in flight:
+ * the per-query chains of one batch (round trips to memory) run under the other batch's sweep (profiles/r05_overlap.txt).
+ * Handles are not shared between threads that search at the same time. */
+int			ndbhip_set_thread_stream(void *hip_stream);
 int			ndbhip_get_stream(void **out_hip_stream);	/* the stream every asynchronous entry point is ordered on */
 int			ndbhip_synchronize(void);
 
@@ -208,6 +213,9 @@ int			ndbhip_mfma_probe_f32(const float *d_a, const float *d_b, const float *d_c
 /* Profiling builds of the library (make PHASES=1: -DNDB_PHASES) stamp a 100 MHz clock at marked places of the per-batch
  * kernels (block 0 only); this copies the 64 stamps to out (zeros from an ordinary build).  tools/phase_probe.py */
 int			ndbhip_debug_phases(unsigned long long *out);
+/* profiling builds: per-wave trace of the last register-streaming sweep (4 words a wave: first request, end — 100 MHz
+ * clock —, items, ticks inside the stream's waits), n words; zeros in a release build */
+int			ndbhip_debug_trace(unsigned long long *out, int n);
 int			ndbhip_debug_h2_phases(unsigned long long *out);	/* [8]: the intended HNSW search's phase clocks (csrc/ndbhip_hnsw2.h), read and reset */
 
 /* ------------------------------------------------------------------ */

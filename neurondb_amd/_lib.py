@@ -154,9 +154,11 @@ def lib():
         "ndbhip_profile": (i, [i]),
         "ndbhip_set_scan_mode": (i, [i]),
         "ndbhip_set_option": (i, [C.c_char_p, i]),
+        "ndbhip_set_thread_stream": (i, [vp]),
         "ndbhip_mfma_probe": (i, [vp, vp, vp, vp, i, i]),
         "ndbhip_mfma_probe_f32": (i, [vp, vp, vp, vp, i]),
         "ndbhip_debug_phases": (i, [vp]),
+        "ndbhip_debug_trace": (i, [vp, i]),
         "ndbhip_debug_h2_phases": (i, [vp]),
         "ndbhip_ivf_search_mapped": (i, [vp, vp, vp, i, i, i, i, i64, vp, vp, vp]),
         "ndbhip_gen_rows_device": (i, [i, C.c_uint64, C.c_uint64, i64, i64, i, i, C.c_float, vp]),

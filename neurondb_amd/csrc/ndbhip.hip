@@ -24,6 +24,8 @@
 /* ================================================================== */
 
 thread_local char ndbhip_g_err[512];
+thread_local hipStream_t ndbhip_tl_stream = nullptr;
+std::mutex	ndbhip_g_mtx;
 
 /* list-scan kernel choice: 0 auto (grouped for batches >= NDB_GROUPED_MIN_NQ queries and dim % 64 == 0),
  * 1 always per-query (k_ivf_scan), 2 always grouped (k_ivf_scan_grouped) */
@@ -240,6 +242,8 @@ struct UploadJob
 int
 big_alloc(void **out, size_t bytes)
 {
+	std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
 	*out = nullptr;
 	if (bytes == 0)
 		bytes = 16;
@@ -258,7 +262,9 @@ big_alloc(void **out, size_t bytes)
 	if (hipMalloc(out, bytes) != hipSuccess)
 	{
 		(void) hipGetLastError();
-		big_cache_flush();		/* the cache must never be the reason an allocation fails */
+		for (auto &b : g.big_cached)		/* the cache must never be the reason an allocation fails */
+			(void) hipFree(b.first);
+		g.big_cached.clear();
 		HIP_TRY(hipMalloc(out, bytes));
 	}
 	if (bytes >= NDB_BIG_CACHE_MIN)
@@ -271,6 +277,8 @@ big_free(void *p)
 {
 	if (!p)
 		return;
+	std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
 	for (size_t i = 0; i < g.big_live.size(); i++)
 		if (g.big_live[i].first == p)
 		{
@@ -293,6 +301,8 @@ big_free(void *p)
 void
 big_cache_flush(void)
 {
+	std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
 	for (auto &b : g.big_cached)
 		(void) hipFree(b.first);
 	g.big_cached.clear();
@@ -307,12 +317,20 @@ ndbhip_set_stream(void *s)
 }
 
 extern "C" int
+ndbhip_set_thread_stream(void *s)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	ndbhip_tl_stream = (hipStream_t) s;
+	return NDBHIP_OK;
+}
+
+extern "C" int
 ndbhip_get_stream(void **out_hip_stream)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!out_hip_stream)
 		return fail(NDBHIP_ERR_INVALID, "out is NULL");
-	*out_hip_stream = (void *) g.stream;
+	*out_hip_stream = (void *) (hipStream_t) g.stream;
 	return NDBHIP_OK;
 }
 
@@ -339,6 +357,8 @@ ndbhip_synchronize(void)
 static int
 drain_profile_events()
 {
+	std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
 	for (auto &p : g.pending)
 	{
 		float		ms = 0.f;
@@ -949,13 +969,16 @@ k_pair_xsum(uint32_t *__restrict__ cntx, uint32_t xstride, int ncent, uint32_t *
 __global__ __launch_bounds__(1024) void
 k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent,
 			   uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
-			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv, uint32_t rt,
+			   uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, uint32_t gdiv, uint32_t rt /* rows per item / 32 */,
 			   int exact_runs = 0 /* runs of exactly nitems / 8 items (a list may straddle two runs): for a sweep whose blocks
 								   * walk their XCD's run at a fixed stride and cannot help another run out */,
 			   unsigned long long *__restrict__ swept = nullptr /* statistics: += sum of pairs x rows over the lists */,
 			   uint32_t *__restrict__ cntx = nullptr /* [8][xstride] counts per XCD (k_sub_pairs): summed into cnt[] here and
 													  * replaced by each XCD's start inside the list's run of pairs */,
-			   uint32_t xstride = 0 )
+			   uint32_t xstride = 0,
+			   int wmode = 0 /* 1: grp_off[] = the list's first (pair, 32-row block) word instead — pairs before it x their
+							  * lists' blocks: where the register-streaming sweep leaves a pair's row masks and bounds
+							  * (ndbhip_screen16w.h) */ )
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024];
 	const int	t = threadIdx.x;
@@ -993,8 +1016,8 @@ k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len
 
 		sw += (unsigned long long) c * glob_len[L];
 		a += c;
-		b += ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
-		c2 += ng;
+		b += ((((glob_len[L] + 31u) >> 5) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
+		c2 += wmode ? c * ((glob_len[L] + 31u) >> 5) : ng;
 	}
 	sa[t] = a;
 	sb[t] = b;
@@ -1024,8 +1047,8 @@ k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len
 		item_off[L] = b;
 		grp_off[L] = c2;
 		a += c;
-		b += ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
-		c2 += ng;
+		b += ((((glob_len[L] + 31u) >> 5) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
+		c2 += wmode ? c * ((glob_len[L] + 31u) >> 5) : ng;
 	}
 	if (swept)
 	{
@@ -1086,7 +1109,7 @@ k_pair_offsets(uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len
  */
 __device__ __forceinline__ void
 pair_triple(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int L, int ncent, uint32_t gdiv, uint32_t rt,
-			uint32_t &a, uint32_t &b, uint32_t &c2)
+			uint32_t &a, uint32_t &b, uint32_t &c2, int wmode)
 {
 	a = b = c2 = 0;
 	if (L < ncent)
@@ -1095,21 +1118,21 @@ pair_triple(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_
 		const uint32_t ng = (c + NDB_QG - 1) / NDB_QG;
 
 		a = c;
-		b = ((((glob_len[L] + 63u) >> 6) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
-		c2 = ng;
+		b = ((((glob_len[L] + 31u) >> 5) + rt - 1u) / rt) * ((ng + gdiv - 1u) / gdiv);
+		c2 = wmode ? c * ((glob_len[L] + 31u) >> 5) : ng;
 	}
 }
 
 __global__ __launch_bounds__(1024) void
 k_pair_part(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent, uint32_t gdiv, uint32_t rt,
-			uint32_t *__restrict__ part /* [blocks][4] */, unsigned long long *__restrict__ swept)
+			uint32_t *__restrict__ part /* [blocks][4] */, unsigned long long *__restrict__ swept, int wmode = 0)
 {
 	__shared__ uint32_t sa[16], sb[16], sc[16];
 	const int	t = threadIdx.x, L = blockIdx.x * 1024 + t;
 	uint32_t	a, b, c2;
 	unsigned long long sw = 0;
 
-	pair_triple(cnt, glob_len, L, ncent, gdiv, rt, a, b, c2);
+	pair_triple(cnt, glob_len, L, ncent, gdiv, rt, a, b, c2, wmode);
 	if (swept && L < ncent)
 		sw = (unsigned long long) a * glob_len[L];
 	for (int off = 32; off > 0; off >>= 1)
@@ -1153,7 +1176,7 @@ k_pair_part(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_
 __global__ __launch_bounds__(1024) void
 k_pair_scan(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_len, int ncent, uint32_t gdiv, uint32_t rt,
 			const uint32_t *__restrict__ part, uint32_t *__restrict__ pair_off, uint32_t *__restrict__ item_off,
-			uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs)
+			uint32_t *__restrict__ grp_off, uint32_t *__restrict__ runs, int wmode = 0)
 {
 	__shared__ uint32_t sa[1024], sb[1024], sc[1024], base[3];
 	const int	t = threadIdx.x, L = blockIdx.x * 1024 + t;
@@ -1190,7 +1213,7 @@ k_pair_scan(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ glob_
 		}
 		__syncthreads();
 	}
-	pair_triple(cnt, glob_len, L, ncent, gdiv, rt, a, b, c2);
+	pair_triple(cnt, glob_len, L, ncent, gdiv, rt, a, b, c2, wmode);
 	sa[t] = a;
 	sb[t] = b;
 	sc[t] = c2;
@@ -1966,6 +1989,14 @@ struct ndbhip_ivf
 	 * list every bucket belongs to */
 	uint4	   *w_qpairs = nullptr;	size_t w_qpairs_n = 0;	/* k_sub_pairs: what the count pass kept, per query */
 	uint32_t   *w_qpn = nullptr;	size_t w_qpn_n = 0;
+	/* the register-streaming sweep (ndbhip_screen16w.h): per query the slots of its pairs (+ how many), per (pair, 32-row
+	 * block) word the rows that stay, per row of a word its two bounds */
+	uint32_t   *w_qslot = nullptr;	size_t w_qslot_n = 0;
+	uint32_t   *w_wmask = nullptr;	size_t w_wmask_n = 0;
+	float2	   *w_wrec = nullptr;	size_t w_wrec_n = 0;
+	bool		s16w_off = false;	/* a query of some batch had more pairs than its list holds: the LDS ring from then on */
+	uint32_t	s16w_maxlw = 1;		/* the most (pair, block) words a (query, probe) pair can need: blocks of the fullest list's buckets */
+	uint32_t	wc_mult = 2;		/* words per (query, probe) pair the word arrays start with; doubles after a batch that did not fit */
 	uint32_t   *w_overq = nullptr;	size_t w_overq_n = 0;	/* queries of the last batch whose records / survivors overflowed */
 	std::vector<uint32_t> redo;		/* ... on the host: ivf_s16_run returned 2, these go to the exact path one sub-batch */
 	float	   *w_redo_q = nullptr;	size_t w_redo_q_n = 0;
@@ -2082,7 +2113,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev, ix->w_ppart, ix->w_qoffs};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev, ix->w_ppart, ix->w_qoffs, ix->w_qslot, ix->w_wmask, ix->w_wrec};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3065,7 +3096,8 @@ static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch
 static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
-static int	g_s16c_wave = 5;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 5; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
+static int	g_s16c_wave = 3;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
+static int	g_s16c_wblk = 2;	/* blocks of 4 waves per compute unit that k_s16c_wsweep is launched with (1, 2, or 3 when two chunks are in flight per wave: the registers of that form allow three; "screen16c_wave_blocks") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
 static int	g_s16_redo = 1;		/* queries whose records / survivors overflow go to the exact path alone ("screen16_redo"; 0: the whole batch does) */
@@ -3252,6 +3284,19 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			else
 				for (size_t b2 = 0; b2 < nbk; b2++)
 					blist[b2] = (uint32_t) b2;
+			{
+				/* the most 32-row blocks the buckets of ONE list have (spare blocks included): what a (query, probe)
+				 * pair can need of (pair, block) words at most (ndbhip_screen16w.h) */
+				std::vector<uint64_t> lw((size_t) nc, 0);
+				uint64_t	mx = 1;
+
+				for (size_t b2 = 0; b2 < nbk; b2++)
+					if (blist[b2] < (uint32_t) nc)
+						lw[blist[b2]] += ix->s16_bcap[b2] / 32u;
+				for (int c = 0; c < nc; c++)
+					mx = std::max(mx, lw[(size_t) c]);
+				ix->s16w_maxlw = (uint32_t) std::min<uint64_t>(mx, 0xFFFFFFu);
+			}
 			if (grow(ix->d_bucket_list, ix->d_bucket_list_n, nbk)) return NDBHIP_ERR_HIP;
 			if (grow(ix->d_plen, ix->d_plen_n, nbk)) return NDBHIP_ERR_HIP;
 			HIP_TRY(hipMemcpyAsync(ix->d_bucket_list, blist.data(), nbk * 4, hipMemcpyHostToDevice, g.stream));
@@ -3652,7 +3697,12 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4 || g_s16c_qb == 8) ? g_s16c_qb :
 		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : (ix->s16c_density >= 320.0f && !sub && dimp / S16C_CH >= 2) ? 8 : 4)
 		 : (ix->s16_sub ? 1 : 4));
-	const int	s16_rt = cen ? (c_qb == 8 ? 256 : 128) : (g_s16_waves == 8 ? 256 : 128);
+	/* the register-streaming sweep (ndbhip_screen16w.h: sparse pair tables) takes items of ONE 32-row block — a wave each,
+	 * dealt round-robin: the sweep is as long as its busiest wave, and tiles of 128 rows over sublists of 40 to 200
+	 * left waves with 6 to 20 items (profiles/r05_wave_trace.txt) */
+	const int	nchk_w = dimp / S16C_CH;
+	const int	wd = (!cen || c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk_w < 2 || ix->s16w_off) ? 0 : std::min(g_s16c_wave, nchk_w);
+	const int	s16_rt = cen ? (wd ? 32 : (c_qb == 8 ? 256 : 128)) : (g_s16_waves == 8 ? 256 : 128);
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
 	/* rows of the pair planes: every pair there can be, up to qc_mult x (queries x probes) (at least 65 536; qc_mult starts at 4 and doubles, up to 16, after a batch that did not fit) — sublists
 	 * multiply the pairs of a probed list, the exclusion bounds remove most again; a batch with more than that goes to
@@ -3670,7 +3720,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		if (grow(ix->w_qcplanes, ix->w_qcplanes_n, ((size_t) qc_cap + 256) * dimp)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qcn2, ix->w_qcn2_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
 		if (grow(ix->w_qcexp, ix->w_qcexp_n, (size_t) qc_cap)) return NDBHIP_ERR_HIP;
-		if (grow(ix->w_pslot, ix->w_pslot_n, (size_t) 3 * qc_cap)) return NDBHIP_ERR_HIP;
+		if (grow(ix->w_pslot, ix->w_pslot_n, (size_t) 5 * qc_cap)) return NDBHIP_ERR_HIP;		/* query, first position, visible rows | first word, bucket */
 	}
 #define S16_SWEEP_L(RR, HH, ...)                                                                                  \
 	do {                                                                                                          \
@@ -3842,17 +3892,17 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 			if (grow(ix->w_ppart, ix->w_ppart_n, (size_t) 4 * nblk)) return NDBHIP_ERR_HIP;
 			hipLaunchKernelGGL(k_pair_part, dim3(nblk), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
-							   (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), ix->w_ppart,
-							   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr);
+							   (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 32), ix->w_ppart,
+							   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr, wd ? 1 : 0);
 			hipLaunchKernelGGL(k_pair_scan, dim3(nblk), dim3(1024), 0, g.stream, (const uint32_t *) cnt, ds.own_len, ncs,
-							   (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), (const uint32_t *) ix->w_ppart,
-							   pair_off, item_off, grp_off, runs);
+							   (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 32), (const uint32_t *) ix->w_ppart,
+							   pair_off, item_off, grp_off, runs, wd ? 1 : 0);
 		}
 		else
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, cnt, ds.own_len, ncs,
-						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 64), cen ? 1 : 0,
+						   pair_off, item_off, grp_off, runs, (uint32_t) (s16_qt / NDB_QG), (uint32_t) (s16_rt / 32), cen ? 1 : 0,
 						   (sub && round == 0) ? g.d_counters + 6 : (unsigned long long *) nullptr,
-						   (sub && !xsum_apart) ? cntx : (uint32_t *) nullptr, (uint32_t) ncsx);
+						   (sub && !xsum_apart) ? cntx : (uint32_t *) nullptr, (uint32_t) ncsx, wd ? 1 : 0);
 		if (sub)
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub_pairs<1>), dim3(nq), dim3(256), 0, g.stream, w_probes, lco,
 							   npr, (uint32_t) nq, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
@@ -3891,6 +3941,27 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   ix->w_qcplanes, dense_k ? qc_plane : (size_t) 0, ix->w_qcn2, ix->w_qcexp, ix->w_pslot, ix->w_pslot + qc_cap, ix->w_pslot + 2 * (size_t) qc_cap,
 							   lco, npr, qc_cap, flags + 2, round == 0 ? flags + 4 : (unsigned int *) nullptr,
 							   (const uint32_t *) cnt);
+		}
+		/* the register-streaming sweep leaves its results per (pair, 32-row block) word (ndbhip_screen16w.h): the words'
+		 * places (grp_off is their per-bucket start with wmode = 1), and every query's list of its pairs */
+		/* at most every (query, probe) pair x the fullest list's blocks; to start with, wc_mult words a pair (a clustered
+		 * table keeps a handful of sublists per query: 1 word a (query, probe) pair at C2), twice that after a batch that
+		 * needed more */
+		const size_t wbound = (size_t) nq * ((size_t) npr + dup0) * (size_t) ix->s16w_maxlw;
+		const uint32_t wcap = (uint32_t) std::min<size_t>(std::min<size_t>(wbound, std::max<size_t>((size_t) ix->wc_mult * nq * npr, (size_t) 1 << 16)), 0x07FFFFFFu);
+
+		if (wd)
+		{
+			if (grow(ix->w_wmask, ix->w_wmask_n, (size_t) wcap)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_wrec, ix->w_wrec_n, (size_t) 32 * wcap)) return NDBHIP_ERR_HIP;
+			if (grow(ix->w_qslot, ix->w_qslot_n, (size_t) nq * S16_QP_CAP + (size_t) nq)) return NDBHIP_ERR_HIP;
+			uint32_t   *qsn = ix->w_qslot + (size_t) nq * S16_QP_CAP;
+
+			HIP_TRY(hipMemsetAsync(qsn, 0, (size_t) nq * sizeof(uint32_t), g.stream));
+			hipLaunchKernelGGL(k_s16w_pairinfo, dim3((qc_cap + 255) / 256), dim3(256), 0, g.stream, (const PairRec *) ix->w_pairs,
+							   (const uint32_t *) pair_off, ncs, (const uint32_t *) grp_off, (const uint32_t *) ds.own_len, qc_cap, wcap,
+							   ix->w_pslot + 3 * (size_t) qc_cap, ix->w_pslot + 4 * (size_t) qc_cap, ix->w_qslot, qsn,
+							   (uint32_t) S16_QP_CAP, flags + 2, flags + 6);
 		}
 		if (g_debug_s16 && round == 0)
 		{
@@ -3935,31 +4006,28 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight)
 			/* chunks in flight per wave of the register-streaming sweep: the option's value if it divides the item's chunks */
-			const int	nchk = dimp / S16C_CH;
-			const int	wd = (c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk < 2) ? 0 : std::min(g_s16c_wave, nchk);
-#define S16C_WSWEEP_L(DD, IPXX)                                                                                        \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_wsweep<DD, IPXX>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, \
+#define S16C_WSWEEP_L(DD, IPXX, BLKK)                                                                                   \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_wsweep<DD, IPXX, BLKK>), dim3(g.num_cus * (BLKK == 3 ? 3 : g_s16c_wblk)), dim3(256), 0, g.stream, \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
 							   (const float *) ix->w_qcn2, (const int *) ix->w_qcexp, (const uint32_t *) ix->w_pslot,            \
-							   (const uint32_t *) (ix->w_pslot + qc_cap), (const uint32_t *) (ix->w_pslot + 2 * (size_t) qc_cap), \
-							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
-							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
-							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
-							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0,                                       \
-							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, ipc ? (const float *) ix->w_qev : (const float *) nullptr)
-#define S16C_WSWEEP_D(DD) do { if (ipc) S16C_WSWEEP_L(DD, true); else S16C_WSWEEP_L(DD, false); } while (0)
+							   (const uint32_t *) (ix->w_pslot + 3 * (size_t) qc_cap), (const uint32_t *) (ix->w_pslot + 2 * (size_t) qc_cap), \
+							   (const float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,               \
+							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ix->w_wmask, ix->w_wrec, wcap,        \
+							   (const uint32_t *) (grp_off + ncs), dimp / S16C_CH, desc_cap, (const uint32_t *) ix->d_pposof, cE, qc_cap, \
+							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, next_item)
+#define S16C_WSWEEP_D(DD, BLKK) do { if (ipc) S16C_WSWEEP_L(DD, true, BLKK); else S16C_WSWEEP_L(DD, false, BLKK); } while (0)
 			if (dense_k)
 				g.stats.dense_sweeps++;
-			if (wd == 2)
-				S16C_WSWEEP_D(2);
+			if (wd == 2 && g_s16c_wblk == 3)
+				S16C_WSWEEP_D(2, 3);
+			else if (wd == 2)
+				S16C_WSWEEP_D(2, 2);
 			else if (wd == 3)
-				S16C_WSWEEP_D(3);
+				S16C_WSWEEP_D(3, 2);
 			else if (wd == 4)
-				S16C_WSWEEP_D(4);
-			else if (wd == 5)
-				S16C_WSWEEP_D(5);
+				S16C_WSWEEP_D(4, 2);
 			else if (dense_k && g_s16_debug == 6)
 				S16C_DENSE_L(6);
 			else if (dense_k && g_s16_debug == 7)
@@ -4021,6 +4089,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,
 				  sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
+		if (wd)
+			hipLaunchKernelGGL(k_s16w_collect, dim3(nq), dim3(64), 0, g.stream, (uint32_t) nq, (const uint32_t *) ix->w_qslot,
+							   (const uint32_t *) (ix->w_qslot + (size_t) nq * S16_QP_CAP), (uint32_t) S16_QP_CAP,
+							   (const uint32_t *) (ix->w_pslot + 4 * (size_t) qc_cap), (const uint32_t *) (ix->w_pslot + 3 * (size_t) qc_cap),
+							   (const uint32_t *) (ix->w_pslot + qc_cap), (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,
+							   (const uint32_t *) ix->d_pposof, (const uint32_t *) ix->w_wmask, (const float2 *) ix->w_wrec, ecount,
+							   ix->w_erec, ix->w_eub, ecap, act, (const uint32_t *) pair_off, ncs, qc_cap,
+							   (const uint32_t *) (grp_off + ncs), wcap);
 
 #define S16_FIN_L(RR, HH, ...)                                                                                                      \
 	do {                                                                                                                            \
@@ -4039,6 +4115,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 			HIP_TRY(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
+			if (f[6])
+			{
+				/* a query with more pairs than its list holds (ndbhip_screen16w.h): this mirror's batches take the LDS ring
+				 * from now on; this one goes to the older path */
+				ix->s16w_off = true;
+				f[2] = 1;
+			}
 			over = f[0] | f[2];
 			over_n = f[0];
 			over_pairs = f[2] != 0;
@@ -4052,6 +4135,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				 * the next batch gets planes twice as large */
 				if (ix->qc_mult < 16)
 					ix->qc_mult *= 2;
+				if (wd && ix->wc_mult < 4096)
+					ix->wc_mult *= 4;
 				break;
 			}
 		}
@@ -4241,6 +4326,21 @@ ndbhip_debug_phases(unsigned long long *out)
 }
 
 
+/* profiling builds (-DNDB_PHASES): the register-streaming sweep's per-wave trace of its last launch — n words of
+ * {first request, end (100 MHz clock), items, ticks inside the stream's waits} per wave; otherwise zeros */
+extern "C" int
+ndbhip_debug_trace(unsigned long long *out, int n)
+{
+	if (!out || n < 0)
+		return fail(NDBHIP_ERR_INVALID, "ndbhip_debug_trace: bad arguments");
+	memset(out, 0, (size_t) n * sizeof(unsigned long long));
+#ifdef NDB_PHASES
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), (size_t) std::min(n, S16W_TRACE_N) * sizeof(unsigned long long)));
+#endif
+	return NDBHIP_OK;
+}
+
 extern "C" int
 ndbhip_set_option(const char *name, int value)
 {
@@ -4380,9 +4480,15 @@ ndbhip_set_option(const char *name, int value)
 		g_s16c_epi = value != 0;
 	else if (!strcmp(name, "screen16c_wave"))
 	{
-		if (value != 0 && (value < 2 || value > 5))
-			return fail(NDBHIP_ERR_INVALID, "screen16c_wave must be 0 (the LDS ring) or 2 .. 5 chunks in flight");
+		if (value != 0 && (value < 2 || value > 4))
+			return fail(NDBHIP_ERR_INVALID, "screen16c_wave must be 0 (the LDS ring) or 2 .. 4 chunks in flight");
 		g_s16c_wave = value;
+	}
+	else if (!strcmp(name, "screen16c_wave_blocks"))
+	{
+		if (value < 1 || value > 3)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_wave_blocks must be 1, 2 or 3 (3: with screen16c_wave = 2)");
+		g_s16c_wblk = value;
 	}
 	else if (!strcmp(name, "screen16c_nbuf"))
 	{
@@ -4845,7 +4951,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, cnt);
 		hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(1024), 0, g.stream, cnt,
-						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u, coop == 2 ? 2u : 1u);
+						   d.own_len, nc, pair_off, item_off, grp_off, runs, coop ? 4u : 1u, coop == 2 ? 4u : 2u);		/* (items of 128 or 64 rows) */
 		hipLaunchKernelGGL(k_pair_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream,
 						   (const int *) w_probes, lco, npr, (uint32_t) nq, (const uint32_t *) pair_off, fill,
 						   ix->w_pairs);

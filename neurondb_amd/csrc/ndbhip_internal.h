@@ -53,12 +53,26 @@ fail(int code, const char *fmt, ...)
 						hipGetErrorString(_e), __FILE__, __LINE__);                \
 	} while (0)
 
+/*
+ * The stream everything is launched on.  Process-wide (ndbhip_set_stream), unless the CALLING THREAD has given itself a
+ * stream of its own (ndbhip_set_thread_stream): two host threads, each with its own stream and its own mirror, keep two
+ * batches in flight, and the per-query chains of one batch (selection, seeds, pair tables, finalize: waves waiting for
+ * memory round trips) run under the other batch's sweep.  `g.stream` reads as the calling thread's stream everywhere.
+ */
+extern thread_local hipStream_t ndbhip_tl_stream;
+struct StreamRef
+{
+	hipStream_t dflt = nullptr;
+	operator hipStream_t() const { return ndbhip_tl_stream ? ndbhip_tl_stream : dflt; }
+	StreamRef &operator=(hipStream_t s) { dflt = s; return *this; }
+};
+
 struct Ctx
 {
 	bool		inited = false;
 	int			device = -1;
 	hipStream_t own_stream = nullptr;
-	hipStream_t stream = nullptr;
+	StreamRef	stream;
 	bool		profile = false;
 	int			num_cus = 256;
 	ndbhip_stats stats = {};
@@ -78,6 +92,7 @@ struct Ctx
 	bool		big_cache_on = true;
 };
 extern Ctx	g;
+extern std::mutex ndbhip_g_mtx;		/* g's event pools and block cache, when several threads search at once */
 int			big_alloc(void **out, size_t bytes);
 void		big_free(void *p);
 void		big_cache_flush(void);
@@ -103,6 +118,8 @@ struct ScanTimer
 	bool		on = false;
 	int start()
 	{
+		std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
 		g.stats.scan_launches++;
 		if (!g.profile)
 			return 0;
@@ -121,6 +138,8 @@ struct ScanTimer
 		if (!on)
 			return 0;
 		HIP_TRY(hipEventRecord(ev.second, g.stream));
+		std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
 		g.pending.push_back(ev);
 		return 0;
 	}

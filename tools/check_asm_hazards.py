@@ -104,11 +104,51 @@ def check_m0(path, want=("k_s16_sweep",)):
     return seen, bad
 
 
+def check_reserved(path, want=("k_s16c_wsweep",), first=88):
+    """k_s16c_wsweep (csrc/ndbhip_screen16w.h) keeps its register stream in v88 .. v255, which only its own asm
+    statements may name: the kernel is compiled with amdgpu_num_vgpr(44) (= v0 .. v87 for the compiler on gfx950).
+    That is a promise of the register allocator, not of the language: every instruction OUTSIDE an asm block that
+    names a register >= v88, and any scratch access at all (a spill would go through the in-order memory counter the
+    stream's waits count on), is reported."""
+    s = open(path).read()
+    bad, seen = [], 0
+    for m in re.finditer(r"^(_Z\w+):\s*; @", s, re.M):
+        sym = m.group(1)
+        if not any(w in sym for w in want):
+            continue
+        end = s.index(".end_amdhsa_kernel", m.end())
+        body = s[m.end():end]
+        code = body[:body.index(".amdhsa_kernel")] if ".amdhsa_kernel" in body else body
+        in_asm = False
+        for line in code.split("\n"):
+            t = line.strip()
+            if t.startswith(";;#ASMSTART") or t.startswith(";APP"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND") or t.startswith(";NO_APP"):
+                in_asm = False
+                continue
+            ins = t.split(";")[0].strip()
+            if not ins or ins.startswith("."):
+                continue
+            if "scratch_" in ins:
+                bad.append((sym[:48], ins, "scratch access"))
+                continue
+            high = [r for r in regs(ins) if r[0] == "v" and r[1] >= first]
+            if in_asm:
+                seen += 1 if high else 0
+            elif high:
+                bad.append((sym[:48], ins, "compiler code names the stream's registers"))
+    return seen, bad
+
+
 if __name__ == "__main__":
     seen, bad = check(sys.argv[1])
     seen_m0, bad_m0 = check_m0(sys.argv[1])
     print(f"{seen_m0} M0 writes inside asm, {len(bad_m0)} uses of M0 by compiler-generated code")
-    bad = bad + bad_m0
+    seen_r, bad_r = check_reserved(sys.argv[1])
+    print(f"{seen_r} asm instructions on the register stream's own registers, {len(bad_r)} trespasses by compiler-generated code")
+    bad = bad + bad_m0 + bad_r
     print(f"{seen} asm loads checked, {len(bad)} hazards")
     for b in bad[:20]:
         print("  ", b)
