@@ -26,6 +26,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# steps in flight on streams of their own (--inflight) must not share a hardware queue, where they would run one after
+# the other: the HIP runtime maps a process's streams onto 4 queues unless told otherwise (read when it initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -51,6 +54,11 @@ def parse():
     ap.add_argument("--probes", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="N = 1, unsharded: steps in flight at once — that many mirrors of the index, each driven by a host thread "
+                         "with a stream of its own (ndbhip_set_thread_stream): a step's per-query chains (selection, seeds, pair "
+                         "tables, finalize: waves waiting for memory) run under another step's sweep; the sweeps themselves queue "
+                         "up.  1 = one step after the other (reported either way as `serial`)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--build-from-host", type=int, default=1, help="also time ndbhip_ivf_build from host memory (0 = skip)")
     ap.add_argument("--recall-queries", type=int, default=200)
@@ -344,19 +352,94 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        step(queries[w * nq:(w + 1) * nq])
+    inflight = max(1, args.inflight) if (not use_dist and args.rows == "f32") else 1
+    mirrors, lanes = [ix], []
+    if inflight > 1:
+        # the other steps in flight search mirrors of their own (built like the first: the build is deterministic)
+        import threading
+        base2 = make_data(n, dim, args.data, args.components, args.sigma, 0x5EED0001, 0x5EEDC0DE, dev)
+        for _ in range(inflight - 1):
+            m = IvfIndex(dim, nlists, device=local_rank)
+            m.build_device(base2, tids_all, 50)
+            m.prepare(strategy)
+            mirrors.append(m)
+        check(lib().ndbhip_synchronize())
+        del base2
+        for w in range(inflight):
+            _dummy = [torch.cuda.Stream() for _ in range(int(os.environ.get("NDB_LANE_STREAM_SKIP", "0")))]
+            lanes.append({"stream": torch.cuda.Stream(), "t": torch.zeros_like(out_t), "d": torch.zeros_like(out_d),
+                          "c": torch.zeros_like(out_c)})
+        torch.cuda.synchronize()
+
+    def run_steps(first, count):
+        """steps first .. first + count - 1, `inflight` at a time (step s on mirror s % inflight)"""
+        if inflight == 1:
+            for s in range(first, first + count):
+                step(queries[s * nq:(s + 1) * nq])
+            return
+        err = []
+
+        def lane(w):
+            try:
+                ln = lanes[w]
+                check(lib().ndbhip_set_thread_stream(C.c_void_p(ln["stream"].cuda_stream)))
+                for s in range(first + w, first + count, inflight):
+                    mirrors[w].search_device(queries[s * nq:(s + 1) * nq], ln["t"], ln["d"], ln["c"], strategy, nprobe, k, 0)
+                check(lib().ndbhip_synchronize())
+                check(lib().ndbhip_set_thread_stream(None))
+            except Exception as e:              # (surfaced by the caller: a lane must not die silently)
+                err.append(e)
+        th = [threading.Thread(target=lane, args=(w,)) for w in range(inflight)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+
+    import ctypes as C
+    run_steps(0, args.warmup)
     barrier()
     check(lib().ndbhip_stats_reset())
     check(lib().ndbhip_profile(1))
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        i = args.warmup + s
-        step(queries[i * nq:(i + 1) * nq])
+    run_steps(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     check(lib().ndbhip_profile(0))
     st = _lib.stats()
+    serial = None
+    if inflight > 1:
+        # the same steps one after the other on the first mirror: what rounds 1-4 timed; its results are the reference the
+        # lanes' last steps are compared with
+        save = inflight
+        lane_out = [(lanes[w]["t"].clone(), lanes[w]["d"].clone(), lanes[w]["c"].clone()) for w in range(inflight)]
+        inflight = 1
+        run_steps(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.warmup, args.steps)
+        barrier()
+        el1 = time.perf_counter() - t0
+        inflight = save
+        # lane w's last step was step warmup + last index congruent to w; rerun those serially and compare
+        same = True
+        for w in range(inflight):
+            last = max(s for s in range(args.warmup, args.warmup + args.steps) if (s - args.warmup) % inflight == w) \
+                if args.steps > w else None
+            if last is None:
+                continue
+            step(queries[last * nq:(last + 1) * nq])
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(out_t, lane_out[w][0]) and torch.equal(out_d.view(torch.int32), lane_out[w][1].view(torch.int32))
+                                 and torch.equal(out_c, lane_out[w][2]))
+        serial = {"queries_per_s": round(nq * args.steps / el1, 1), "ms_per_step": round(el1 / args.steps * 1e3, 4),
+                  "lanes_identical_to_serial": same,
+                  "note": "the same steps one after the other on one stream and one mirror (what rounds 1-4 reported as `value`)"}
+        for m in mirrors[1:]:
+            m.close()
+        mirrors, lanes, lane_out = [ix], [], None
+        torch.cuda.empty_cache()
     if os.environ.get("NDB_PHASES"):
         # a profiling build of the library (make EXTRA=-DNDB_PHASES): block 0's clock stamps of the last step's kernels
         import ctypes as _C
@@ -656,6 +739,9 @@ def main():
             "config": {"workload": f"IVFFlat {n}x{dim} {'fp32' if esz == 4 else 'fp16'} lists={nlists} probes={nprobe} "
                                    f"k={k} {args.strategy.upper()}, "
                                    f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
+                       "steps_in_flight": (f"{inflight}: {inflight} mirrors of the index, each driven by a host thread on a stream of its "
+                                           f"own (ndbhip_set_thread_stream) — a step's per-query chains run under another step's sweep, "
+                                           f"the sweeps queue up; `serial` = one step after the other" if inflight > 1 else "1"),
                        "sharding": "none" if not use_dist else
                                    (f"replicas: each of the {world} ranks holds the whole index and answers its own "
                                     f"{nq}-query batches (value = {world} batches per step; no data-path collective); the "
@@ -686,6 +772,7 @@ def main():
             "note": None if (args.rows == "f32" and args.strategy == "l2") else
             "recall / CPU legs run for the default fp32 L2 workload only; parity of this variant: tests/test_gpu_ivf.py",
             "roofline": roofline,
+            "serial": serial,
             "library_stats": {k2: (round(v2, 3) if isinstance(v2, float) else int(v2)) for k2, v2 in st.items()},
             "cpu_baseline": cpu_baseline,
             "dist_parity_on_sample": dist_parity,

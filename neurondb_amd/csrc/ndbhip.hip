@@ -3096,7 +3096,7 @@ static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch
 static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
-static int	g_s16c_wave = 3;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
+static int	g_s16c_wave = 2;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
 static int	g_s16c_wblk = 2;	/* blocks of 4 waves per compute unit that k_s16c_wsweep is launched with (1, 2, or 3 when two chunks are in flight per wave: the registers of that form allow three; "screen16c_wave_blocks") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
@@ -3450,6 +3450,50 @@ ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vect
 	g.stats.prepare_updates++;
 	return 0;
 }
+
+/*
+ * Batches in flight on several streams (ndbhip_set_thread_stream): the point is that one batch's per-query chains run
+ * under ANOTHER batch's sweep — not that two sweeps share the device, each then taking twice as long with nothing
+ * gained.  So the sweeps queue up: a sweep is launched behind the event that ends the sweep launched before it,
+ * whichever stream that was on (a ring of events; the mutex only orders the launches, nobody waits on the host).
+ * "screen16_sweep_queue" 0 turns that off.
+ */
+static int	g_s16_sweepq = 1;
+static std::mutex g_sweepq_mtx;
+static hipEvent_t g_sweepq_ev[8];
+static unsigned g_sweepq_n = 0;
+static hipStream_t g_sweepq_last = nullptr;
+
+struct SweepTurn
+{
+	std::unique_lock<std::mutex> lk;
+	bool		on = false;
+	int begin()
+	{
+		if (!g_s16_sweepq || !ndbhip_tl_stream)
+			return 0;			/* one stream: nothing to queue behind */
+		lk = std::unique_lock<std::mutex>(g_sweepq_mtx);
+		on = true;
+		if (g_sweepq_n > 0 && g_sweepq_last != (hipStream_t) g.stream)
+			HIP_TRY(hipStreamWaitEvent(g.stream, g_sweepq_ev[(g_sweepq_n - 1) & 7u], 0));
+		return 0;
+	}
+	int end()
+	{
+		if (!on)
+			return 0;
+		hipEvent_t &e = g_sweepq_ev[g_sweepq_n & 7u];
+
+		if (!e)
+			HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(e, g.stream));
+		g_sweepq_last = (hipStream_t) g.stream;
+		g_sweepq_n++;
+		lk.unlock();
+		on = false;
+		return 0;
+	}
+};
 
 /* Runs the sweep + finalize for one sub-batch whose probes / candidate offsets are already on the device.
  * Returns 0, a negative error, or 1 when some query overflowed (nothing usable was written: rerun on the older path). */
@@ -3973,6 +4017,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			fprintf(stderr, "s16 debug: %u (query, probe, %s) triples in %u items of %d x %d, %d buckets\n", np,
 					sub ? "sublist" : "list", ni, s16_rt, S16_QT, ncs);
 		}
+		SweepTurn	turn;
+
+		if (turn.begin()) return NDBHIP_ERR_HIP;
 		if (round == 0 && t.start()) return NDBHIP_ERR_HIP;
 		if (cen)
 		{
@@ -4007,7 +4054,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight)
 			/* chunks in flight per wave of the register-streaming sweep: the option's value if it divides the item's chunks */
 #define S16C_WSWEEP_L(DD, IPXX, BLKK)                                                                                   \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_wsweep<DD, IPXX, BLKK>), dim3(g.num_cus * (BLKK == 3 ? 3 : g_s16c_wblk)), dim3(256), 0, g.stream, \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_wsweep<DD, IPXX, BLKK>), dim3(g.num_cus * g_s16c_wblk), dim3(256), 0, g.stream, \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qcrowbytes, \
@@ -4020,10 +4067,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 #define S16C_WSWEEP_D(DD, BLKK) do { if (ipc) S16C_WSWEEP_L(DD, true, BLKK); else S16C_WSWEEP_L(DD, false, BLKK); } while (0)
 			if (dense_k)
 				g.stats.dense_sweeps++;
-			if (wd == 2 && g_s16c_wblk == 3)
+			/* (two chunks in flight: the 168-register form whatever the blocks — at two blocks a compute unit it leaves a
+			 * third of the register file to the other steps' kernels, see --inflight) */
+			if (wd == 2)
 				S16C_WSWEEP_D(2, 3);
-			else if (wd == 2)
-				S16C_WSWEEP_D(2, 2);
 			else if (wd == 3)
 				S16C_WSWEEP_D(3, 2);
 			else if (wd == 4)
@@ -4089,6 +4136,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				  ix->w_bmin, nq < 1024 ? 1 : 0, dimp / S16_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,
 				  sub ? (const uint32_t *) ix->d_posof : (const uint32_t *) nullptr);
 		if (round == 0 && t.stop()) return NDBHIP_ERR_HIP;
+		if (turn.end()) return NDBHIP_ERR_HIP;
 		if (wd)
 			hipLaunchKernelGGL(k_s16w_collect, dim3(nq), dim3(64), 0, g.stream, (uint32_t) nq, (const uint32_t *) ix->w_qslot,
 							   (const uint32_t *) (ix->w_qslot + (size_t) nq * S16_QP_CAP), (uint32_t) S16_QP_CAP,
@@ -4484,6 +4532,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_wave must be 0 (the LDS ring) or 2 .. 4 chunks in flight");
 		g_s16c_wave = value;
 	}
+	else if (!strcmp(name, "screen16_sweep_queue"))
+		g_s16_sweepq = value != 0;
 	else if (!strcmp(name, "screen16c_wave_blocks"))
 	{
 		if (value < 1 || value > 3)

@@ -8,6 +8,8 @@ own mirror of the same table, and drives them from two host threads (ctypes rele
 
   serial      one copy answers all the batches, one after the other (what bench.py times)
   overlapped  the two copies answer alternate batches concurrently
+  threads     ONE copy of the library, two mirrors, two host threads that each gave themselves a stream
+              (ndbhip_set_thread_stream): what bench.py --inflight 2 does
 
 Same table, same queries, same results either way (checked); the only thing that changes is whether kernels of two
 batches may share the device.  Prints queries/s of both and the kernels' own time per batch.
@@ -31,6 +33,7 @@ def load(path):
     vp, i, i64 = C.c_void_p, C.c_int, C.c_int64
     L.ndbhip_init.argtypes = [i]
     L.ndbhip_set_stream.argtypes = [vp]
+    L.ndbhip_set_thread_stream.argtypes = [vp]
     L.ndbhip_ivf_create.argtypes = [i, i, C.POINTER(vp)]
     L.ndbhip_ivf_build_device.argtypes = [vp, vp, vp, i64, i, C.POINTER(i)]
     L.ndbhip_ivf_prepare.argtypes = [vp, i]
@@ -114,12 +117,50 @@ def main():
     t_over = time.perf_counter() - t0
     torch.cuda.synchronize()
     same = all(bool(torch.equal(outs[0][j][:steps], outs[1][j][:steps])) for j in range(3))
+    # one copy of the library, a second mirror of its own, per-thread streams
+    L = libs[0]
+    h2 = C.c_void_p()
+    it = C.c_int(0)
+    with torch.cuda.stream(streams[0]):
+        base = torch.empty((n, dim), dtype=torch.float32, device=dev)
+        check(L, L.ndbhip_gen_rows_device(1, 0x5EED0001, 0x5EEDC0DE, 0, n, dim, 1024, 0.1, C.c_void_p(base.data_ptr())))
+    check(L, L.ndbhip_ivf_create(dim, nlists, C.byref(h2)))
+    check(L, L.ndbhip_ivf_build_device(h2, C.c_void_p(base.data_ptr()), C.c_void_p(tids.data_ptr()), n, 50, C.byref(it)))
+    check(L, L.ndbhip_ivf_prepare(h2, 1))
+    check(L, L.ndbhip_synchronize())
+    del base
+    hs = [handles[0], h2]
+    s3 = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out3 = (torch.zeros_like(outs[0][0]), torch.zeros_like(outs[0][1]), torch.zeros_like(outs[0][2]))
+
+    def run_t(which, batches):
+        check(L, L.ndbhip_set_thread_stream(C.c_void_p(s3[which].cuda_stream)))
+        for b in batches:
+            q = queries[b * nq:(b + 1) * nq]
+            check(L, L.ndbhip_ivf_search_device(hs[which], C.c_void_p(q.data_ptr()), nq, 1, nprobe, k, 0, C.c_void_p(out3[0][b].data_ptr()),
+                                                C.c_void_p(out3[1][b].data_ptr()), C.c_void_p(out3[2][b].data_ptr())))
+        check(L, L.ndbhip_synchronize())
+        check(L, L.ndbhip_set_thread_stream(None))
+
+    th = [threading.Thread(target=run_t, args=(w, [steps + w, steps + 2 + w])) for w in (0, 1)]      # warm-up
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run_t, args=(w, all_b[w::2])) for w in (0, 1)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    t_thr = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    same3 = all(bool(torch.equal(outs[0][j][:steps], out3[j][:steps])) for j in range(3))
     print(f"overlap_probe: {n} x {dim}, lists {nlists}, probes {nprobe}, k {k}, {steps} batches of {nq} queries"
           f"{' (' + os.environ['NDB_OPTS'] + ')' if opts else ''}")
     print(f"  serial      {t_serial / steps * 1e3:.3f} ms per batch   {nq * steps / t_serial / 1e6:.3f} M q/s")
     print(f"  overlapped  {t_over / steps * 1e3:.3f} ms per batch   {nq * steps / t_over / 1e6:.3f} M q/s   "
           f"(two batches in flight: two copies of the library, two streams, two host threads)")
-    print(f"  ratio {t_serial / t_over:.3f}; results identical: {same}")
+    print(f"  threads     {t_thr / steps * 1e3:.3f} ms per batch   {nq * steps / t_thr / 1e6:.3f} M q/s   "
+          f"(one copy of the library, two mirrors, per-thread streams)")
+    print(f"  ratio {t_serial / t_over:.3f} / {t_serial / t_thr:.3f}; results identical: {same} / {same3}")
 
 
 if __name__ == "__main__":
