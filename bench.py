@@ -82,7 +82,8 @@ def parse():
                     help="N=1, default workload: also run this many steps on i.i.d. N(0,1) data (0 = skip)")
     ap.add_argument("--c5-nvec", type=int, default=10_000_000,
                     help="N=1, default workload: also run BASELINE.md's C5 (halfvec x 1536, inner product, lists 4096, batches "
-                         "of 256) on this many rows on the one GPU (0 = skip)")
+                         "of 256) on this many rows on the one GPU (0 = skip; skipped with a note when the device has less "
+                         "free memory than 4.5 x the table: the leg holds the fp32 rows, their fp16 twin and the planes at once)")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
     ap.add_argument("--dist-parity-queries", type=int, default=128,
@@ -713,7 +714,12 @@ def main():
                 ix = None
             torch.cuda.empty_cache()
             trace("c5 leg")
-            c5 = c5_leg(args, dev, args.c5_nvec)
+            free_b, _tot = torch.cuda.mem_get_info(dev)
+            need_b = 4.5 * args.c5_nvec * 1536 * 4
+            if free_b < need_b:
+                c5 = {"skipped": f"{free_b / 2**30:.0f} GiB free on the device, the leg needs about {need_b / 2**30:.0f} GiB"}
+            else:
+                c5 = c5_leg(args, dev, args.c5_nvec)
         except Exception as e:
             c5 = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()

@@ -310,10 +310,14 @@ ndb_service_poll(ndb_service *s, int max_batch, int wait_us, int linger_us, int 
 			if (st_of(w) != S_READY)
 			{
 				/* a stale hint (the backend withdrew its request): cleared — and set again should the slot have been
-				 * published in between (the backend stores the state first, the hint second) */
-				s->m.hint(i)->store(0, std::memory_order_release);
-				if (st_of(sl->state.load(std::memory_order_acquire)) == S_READY)
-					s->m.hint(i)->store(1, std::memory_order_release);
+				 * published in between (the backend stores the state first, the hint second).  The clear and the re-read
+				 * are sequentially consistent (as are the backend's publish and its hint): with release / acquire alone
+				 * the re-read may be satisfied BEFORE the clear becomes visible (store -> load reordering, legal and real
+				 * on x86), the backend's state = READY, hint = 1 slip in between, and the clear then lands on top of the
+				 * fresh hint — a READY slot no scan would ever look at again */
+				s->m.hint(i)->exchange(0, std::memory_order_seq_cst);
+				if (st_of(sl->state.load(std::memory_order_seq_cst)) == S_READY)
+					s->m.hint(i)->store(1, std::memory_order_seq_cst);
 				continue;
 			}
 			/* (generation 0 of a named index = its backend could not learn the generation, ndb_gen_get: never served) */
@@ -511,6 +515,9 @@ ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_
 	bool		ring_reg = false;
 
 	/* (the poll's linger sleeps 5 us at a time: with the default 50 us timer slack each of those is ten times as long) */
+	/* (the calling thread's own setting is put back before this returns: a library call leaves no process-visible change) */
+	const int	old_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+
 	(void) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
 	std::vector<int64_t> offs((size_t) max_batch);
 
@@ -558,6 +565,8 @@ ndb_service_serve_ivf(ndb_service *s, ndbhip_ivf *ix, int max_batch, int linger_
 	}
 	if (ring_reg)
 		(void) hipHostUnregister(s->m.base);
+	if (old_slack > 0)
+		(void) prctl(PR_SET_TIMERSLACK, (unsigned long) old_slack, 0, 0, 0);
 	if (stats)
 		*stats = st;
 	return rc_last;
@@ -717,10 +726,10 @@ ndb_client_submit_index(ndb_client *c, uint64_t index_key, uint64_t index_versio
 				 * process looked dead to it, e.g. across a pid namespace) and somebody else may hold it now */
 				uint32_t	mine = word_of(me, S_CLAIMED);
 
-				if (!sl->state.compare_exchange_strong(mine, word_of(me, S_READY), std::memory_order_acq_rel))
+				if (!sl->state.compare_exchange_strong(mine, word_of(me, S_READY), std::memory_order_seq_cst))
 					continue;
 			}
-			c->m.hint(i)->store(1, std::memory_order_release);
+			c->m.hint(i)->store(1, std::memory_order_seq_cst);		/* (seq_cst with the owner's stale-hint repair: see there) */
 			h->submitted.fetch_add(1, std::memory_order_release);
 			futex(&h->submitted, FUTEX_WAKE, 1, nullptr);
 			*ticket = (int) i;

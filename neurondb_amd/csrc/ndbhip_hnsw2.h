@@ -200,7 +200,11 @@ h2_dist2_rows(const float *__restrict__ a, const float *__restrict__ b, int dim,
 }
 
 /* a wave's visited set: one bit per block in global memory (all zero at rest), the blocks it set logged for clearing */
-#define H2_HV 2048				/* slots of the LDS visited table of a search; three quarters full = it moves to the bitmap */
+#define H2_HV_LOG2 11
+#define H2_HV (1u << H2_HV_LOG2)	/* slots of the LDS visited table of a search; three quarters full = it moves to the bitmap */
+/* (an expansion marks at most 2 m = 64 blocks between two checks of the fill: 3/4 of the table + 64 stays below its size,
+ * so the probe loop always finds a free slot) */
+static_assert(H2_HV == 2048u && (H2_HV / 4u) * 3u + 64u < H2_HV, "the visited table's hash shift and its fill bound go with H2_HV_LOG2");
 #define H2_HV_MAX_EF 256			/* searches up to this ef start on the table (8 KB of LDS a walker) */
 struct H2Visited
 {
@@ -223,7 +227,7 @@ struct H2Visited
 
 		if (act)
 		{
-			uint32_t	h = (b * 2654435761u) >> (32 - 11);		/* H2_HV = 2^11 */
+			uint32_t	h = (b * 2654435761u) >> (32 - H2_HV_LOG2);
 
 			for (;;)
 			{

@@ -158,7 +158,12 @@ mirror_drop(MirrorEntry *e)
 				e->pins = 0;
 				return;
 			}
-		ereport(ERROR, (errmsg("neurondb: too many stale device mirrors still held by open scans")));
+		/* Every retired slot is held by an open scan too.  Never an ERROR from here (this runs inside aminsert,
+		 * ambulkdelete and every scan's lookup): the entry stays where it is, marked "never fresh" (stamp 0 matches no
+		 * lookup), and is dropped for good by a later call once its scans have ended — pins come down on endscan and on
+		 * abort alike (ndb_hip_mirror_pin_scoped), so that moment always comes. */
+		e->stamp = 0;
+		return;
 	}
 	if (e->ivf) ndbhip_ivf_destroy(e->ivf);
 	if (e->hnsw) ndbhip_hnsw_destroy(e->hnsw);
@@ -203,6 +208,55 @@ ndb_hip_mirror_unpin(const void *mirror)
 			return;
 		}
 	}
+}
+
+/*
+ * A pin that cannot leak.  amendscan is not called when a query is cancelled or an ereport(ERROR) unwinds through the
+ * executor, and a rescan (LATERAL, nested loop) must not pin a second time: the scan takes ONE scoped pin when it first
+ * takes the mirror (ivfrescan / hnswrescan, inside `if (!so->ndb)`), tied to the memory context the scan's opaque state
+ * lives in.  The pin is released exactly once — by ndb_hip_mirror_unpin_scoped from amendscan or the fallback path, or
+ * by the context's reset callback when the query's memory goes away on abort, whichever comes first.
+ */
+typedef struct ScopedPin
+{
+	MemoryContextCallback cb;
+	const void *mirror;
+	bool		released;
+} ScopedPin;
+
+static void
+scoped_pin_release(void *arg)
+{
+	ScopedPin  *p = (ScopedPin *) arg;
+
+	if (!p->released)
+	{
+		p->released = true;
+		ndb_hip_mirror_unpin(p->mirror);
+	}
+}
+
+void *
+ndb_hip_mirror_pin_scoped(const void *mirror, MemoryContext scan_context)
+{
+	ScopedPin  *p;
+
+	if (!mirror)
+		return NULL;
+	p = (ScopedPin *) MemoryContextAllocZero(scan_context, sizeof(ScopedPin));
+	p->mirror = mirror;
+	p->cb.func = scoped_pin_release;
+	p->cb.arg = p;
+	MemoryContextRegisterResetCallback(scan_context, &p->cb);	/* before the pin: nothing may throw between the two */
+	ndb_hip_mirror_pin(mirror);
+	return p;
+}
+
+void
+ndb_hip_mirror_unpin_scoped(void *pin)
+{
+	if (pin)
+		scoped_pin_release(pin);
 }
 
 static void
