@@ -48,9 +48,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nvec", type=int, default=1_000_000)
+    ap.add_argument("--nvec", type=int, default=None,
+                    help="rows of the table.  Default: 1 000 000 (BASELINE.json configs[1], the workload `metric` is quoted on) at "
+                         "--gpus 1; at --gpus N > 1, 10 000 000 with --lists 4096 (configs[3]: the table north_star shards over the "
+                         "ranks, lists cut into slices, every batch merged over RCCL inside the timed region)")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--lists", type=int, default=1024)
+    ap.add_argument("--lists", type=int, default=None, help="default 1024 (N = 1) / 4096 (N > 1), see --nvec")
     ap.add_argument("--probes", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
@@ -64,7 +67,7 @@ def parse():
     ap.add_argument("--recall-queries", type=int, default=200)
     ap.add_argument("--data", choices=["clustered", "gauss"], default="clustered",
                     help="clustered: mixture of --components Gaussians (sigma --sigma); gauss: i.i.d. N(0,1)")
-    ap.add_argument("--components", type=int, default=1024)
+    ap.add_argument("--components", type=int, default=None, help="default: one per list")
     ap.add_argument("--sigma", type=float, default=0.1)
     ap.add_argument("--rows", choices=["f32", "f16"], default="f32",
                     help="f16: search a halfvec twin of the index (rows narrowed round-to-nearest-even on the device)")
@@ -84,6 +87,11 @@ def parse():
                     help="N=1, default workload: also run BASELINE.md's C5 (halfvec x 1536, inner product, lists 4096, batches "
                          "of 256) on this many rows on the one GPU (0 = skip; skipped with a note when the device has less "
                          "free memory than 4.5 x the table: the leg holds the fp32 rows, their fp16 twin and the planes at once)")
+    ap.add_argument("--c4-nvec", type=int, default=10_000_000,
+                    help="N=1, default workload: also run BASELINE.md's C4 shape (x 768 fp32, lists 4096, L2, 4096 queries a step) "
+                         "on this many rows on the one GPU (0 = skip)")
+    ap.add_argument("--sigma-sweep", type=int, default=1,
+                    help="N=1, default workload: the headline shape at sigma 0.1 ... 1.0 and one anisotropic table (0 = skip)")
     ap.add_argument("--hnsw-nvec", type=int, default=1_000_000,
                     help="also measure HNSW build + search (BASELINE config C3) on this many rows at N=1 (0 = skip)")
     ap.add_argument("--dist-parity-queries", type=int, default=128,
@@ -171,11 +179,21 @@ def main():
             comm_error = f"{type(e).__name__}: {e}"
             args.dist_impl = "torch"        # the same exchange through torch.distributed (neurondb_amd/dist.py)
 
+    # the workload: N = 1 -> C2 (what `metric` is quoted on); N > 1 -> C4, SHARDED (north_star: "IVFFlat list scans shard
+    # naturally across the 8 GPUs of one node with RCCL top-k merge"): the collective is inside the timed region, N = 1 of the
+    # same table is the `c4` key of the N = 1 line, and the replicated number (no collective) is a sub-key
+    c4_default = world > 1 and args.nvec is None and args.lists is None and not args.force_dist
+    if args.nvec is None:
+        args.nvec = 10_000_000 if world > 1 else 1_000_000
+    if args.lists is None:
+        args.lists = 4096 if c4_default else 1024
+    if args.components is None:
+        args.components = args.lists
     n, dim, nlists, nprobe, k, nq = args.nvec, args.dim, args.lists, args.probes, args.k, args.batch
     shard_mode = args.shard
     if shard_mode == "auto":
         fits = 4.0 * n * dim * 4 < 0.5 * torch.cuda.get_device_properties(dev).total_memory
-        shard_mode = "replicas" if fits else "slices"
+        shard_mode = "slices" if (c4_default or not fits) else "replicas"
     sharded = use_dist and shard_mode in ("slices", "lists")       # the timed step is the RCCL-merged sharded search
     replicas = use_dist and not sharded                              # the timed step is each rank's own batch on a full copy
 
@@ -328,8 +346,33 @@ def main():
         return sh, info
 
     shard_info = None
+    replicated = None
     if sharded:
         ix, shard_info = make_shard(ix_full, shard_mode)
+        if world > 1:
+            # the sub-key: the same table REPLICATED (every rank the whole index, its own batches, no data-path collective) —
+            # what the ranks can do when the table fits each of them; the timed step below is the sharded one
+            rq_ = make_data(nq * (args.warmup + args.steps), dim, args.data, args.components, args.sigma,
+                            0x5EED0002 + 0x100000 * rank, 0x5EEDC0DE, dev)
+            rt_, rd_, rc_ = (torch.zeros((nq, k), dtype=torch.int64, device=dev), torch.zeros((nq, k), dtype=torch.float32, device=dev),
+                             torch.zeros(nq, dtype=torch.int32, device=dev))
+            for w in range(args.warmup):
+                ix_full.search_device(rq_[w * nq:(w + 1) * nq], rt_, rd_, rc_, strategy, nprobe, k, 0)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s_ in range(args.steps):
+                i_ = args.warmup + s_
+                ix_full.search_device(rq_[i_ * nq:(i_ + 1) * nq], rt_, rd_, rc_, strategy, nprobe, k, 0)
+            dist.barrier()
+            torch.cuda.synchronize()
+            tt_ = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            replicated = {"queries_per_s": round(world * nq * args.steps / float(tt_.item()), 1),
+                          "ms_per_step": round(float(tt_.item()) / args.steps * 1e3, 3),
+                          "note": f"every rank holds the whole table and answers its own {nq}-query batches: {world} batches a step, "
+                                  f"no data-path collective (weak scaling); `value` is the SHARDED step"}
+            del rq_, rt_, rd_, rc_
         ix_full.close()
         ix_full = None
         torch.cuda.empty_cache()
@@ -706,6 +749,8 @@ def main():
                 balanced = {"error": f"{type(e).__name__}: {e}"}
 
     c5 = None
+    c4 = None
+    sigma_sweep = None
     if rank == 0 and world == 1 and args.c5_nvec > 0 and args.data == "clustered" and args.rows == "f32" and \
             args.strategy == "l2":
         try:
@@ -723,6 +768,30 @@ def main():
         except Exception as e:
             c5 = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
+    default_wl = rank == 0 and world == 1 and args.data == "clustered" and args.rows == "f32" and args.strategy == "l2"
+    if default_wl and (args.c4_nvec > 0 or args.sigma_sweep):
+        if ix is not None:
+            ix.close()
+            ix = None
+        torch.cuda.empty_cache()
+    if default_wl and args.c4_nvec > 0:
+        try:
+            trace("c4 leg")
+            free_b, _tot = torch.cuda.mem_get_info(dev)
+            need_b = 3.0 * args.c4_nvec * 768 * 4
+            if free_b < need_b:
+                c4 = {"skipped": f"{free_b / 2**30:.0f} GiB free on the device, the leg needs about {need_b / 2**30:.0f} GiB"}
+            else:
+                # BASELINE.md C4's table on ONE GPU (it names 8: `--gpus N` shards this same table, and N = 1 of that is this)
+                c4 = l2_table_leg(args, dev, args.c4_nvec, 768, 4096, 32, 10, 4096, 4096, 0.1, steps=5, warm=2, nreplay=4, recall_q=32,
+                                  label=f"IVFFlat {args.c4_nvec}x768 fp32 lists=4096 probes=32 k=10 L2, 4096 queries/step, clustered "
+                                        f"(4096 components, sigma 0.1), one GPU (BASELINE.md C4 names 8)")
+        except Exception as e:
+            c4 = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if default_wl and args.sigma_sweep:
+        trace("sigma sweep")
+        sigma_sweep = sigma_sweep_leg(args, dev)
 
     hnsw = None
     if rank == 0 and world == 1 and args.hnsw_nvec > 0:
@@ -756,6 +825,12 @@ def main():
                                    f"balanced by calibration-batch work; RCCL all-gather of probes and records + merge "
                                    f"({'inside the C library: ndbhip_ivf_search_sharded' if args.dist_impl == 'c' else 'torch.distributed calls'})",
                        "shard": shard_info,
+                       "collectives": (None if not sharded else
+                                       {"rccl_ranks": int(lib().ndbhip_comm_world()) if args.dist_impl == "c" else world,
+                                        "per_step": 3,
+                                        "what": "all-gather of the probes (the selection is split over the ranks' query ranges), all-reduce "
+                                                "(min) of the first thresholds, all-gather of each rank's <= 3k candidates per query",
+                                        "bytes_per_step_per_rank": int(nq * nprobe * 4 // world + 2 * nq * 4 + nq * (3 * k * 16 + 12))}),
                        "data": (f"mixture of {args.components} Gaussians, sigma={args.sigma}" if args.data == "clustered"
                                 else "i.i.d. N(0,1)"),
                        "index_build": f"ndbhip_ivf_build_device: first-10000-row sample, {kmeans_iters} Lloyd iterations "
@@ -779,6 +854,7 @@ def main():
             "recall / CPU legs run for the default fp32 L2 workload only; parity of this variant: tests/test_gpu_ivf.py",
             "roofline": roofline,
             "serial": serial,
+            "replicated": replicated,
             "library_stats": {k2: (round(v2, 3) if isinstance(v2, float) else int(v2)) for k2, v2 in st.items()},
             "cpu_baseline": cpu_baseline,
             "dist_parity_on_sample": dist_parity,
@@ -786,6 +862,8 @@ def main():
             "iid_gauss": gauss,
             "balanced_index": balanced,
             "c5": c5,
+            "c4": c4,
+            "sigma_sweep": sigma_sweep,
             "hnsw": hnsw,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -934,6 +1012,133 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
                              "sample": f"{nparity} of the step's queries through the C oracle (gcc -O2, the reference's "
                                        f"default flags), one thread per host core; the same sample checks the GPU results"},
             "oracle_parity": {"queries": nparity, "mismatches": int(bad)}}
+
+
+def l2_table_leg(args, dev, n, dim, lists, P, K, nq, components, sigma, steps=5, warm=2, nreplay=8, recall_q=64, aniso=False,
+                 kind="clustered", label=""):
+    """One float4 L2 table of another shape or another spread through the same timed step: build on the device, prepare,
+    `steps` batches of `nq` queries, then recall@K of `recall_q` queries against a float64 brute force over the rows, which
+    sweep ran, how many (row, pair) elements the bounds excluded, and the CPU oracle's answers for `nreplay` queries over
+    their probed lists (ids + float4 bits).  aniso: every dimension d of rows and queries scaled by (d + 1)^-0.5
+    (a power-law spectrum: what learned embeddings look like next to an isotropic Gaussian)."""
+    import ctypes as C
+    from neurondb_amd import IvfIndex, _lib
+    from neurondb_amd._lib import check, lib
+    from oracle import ndbo
+    base = make_data(n, dim, kind, components, sigma, 0x5EED0001, 0x5EEDC0DE, dev)
+    q = make_data(nq * (steps + warm + 1), dim, kind, components, sigma, 0x5EED0002, 0x5EEDC0DE, dev)
+    if aniso:
+        w = (torch.arange(1, dim + 1, device=dev, dtype=torch.float32) ** -0.5)[None, :]
+        base.mul_(w)
+        q.mul_(w)
+    ix = IvfIndex(dim, lists, device=dev.index or 0)
+    t0 = time.perf_counter()
+    iters = ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
+    ix.prepare(1)
+    check(lib().ndbhip_synchronize())
+    tb = time.perf_counter() - t0
+    ot = torch.zeros((nq, K), dtype=torch.int64, device=dev)
+    od = torch.zeros((nq, K), dtype=torch.float32, device=dev)
+    oc = torch.zeros(nq, dtype=torch.int32, device=dev)
+    for w_ in range(warm):
+        ix.search_device(q[w_ * nq:(w_ + 1) * nq], ot, od, oc, 1, P, K, 0)
+    torch.cuda.synchronize()
+    check(lib().ndbhip_stats_reset())
+    check(lib().ndbhip_profile(1))
+    t0 = time.perf_counter()
+    for sidx in range(steps):
+        ix.search_device(q[(warm + sidx) * nq:(warm + sidx + 1) * nq], ot, od, oc, 1, P, K, 0)
+    torch.cuda.synchronize()
+    ts = (time.perf_counter() - t0) / steps
+    check(lib().ndbhip_profile(0))
+    st = _lib.stats()
+    qs = q[(warm + steps) * nq:(warm + steps + 1) * nq]
+    ix.search_device(qs, ot, od, oc, 1, P, K, 0)
+    torch.cuda.synchronize()
+    got_t, got_d, got_c = ot.cpu().numpy().copy(), od.cpu().numpy().view(np.uint32).copy(), oc.cpu().numpy().copy()
+    # recall@K: float64 brute force over the table as it lies in `base` (row r has TID r)
+    rq = min(recall_q, nq)
+    q64 = qs[:rq].double()
+    best_d = torch.full((rq, K), float("inf"), dtype=torch.float64, device=dev)
+    best_i = torch.zeros((rq, K), dtype=torch.int64, device=dev)
+    for s0 in range(0, n, 131072):
+        x = base[s0:s0 + 131072].double()
+        d2 = (q64 * q64).sum(1)[:, None] + (x * x).sum(1)[None, :] - 2.0 * (q64 @ x.T)
+        dd = torch.cat([best_d, d2], 1)
+        ii = torch.cat([best_i, torch.arange(s0, s0 + x.shape[0], device=dev)[None, :].expand(rq, -1)], 1)
+        sel = torch.topk(dd, K, dim=1, largest=False)
+        best_d, best_i = sel.values, torch.gather(ii, 1, sel.indices)
+    gt = best_i.cpu().numpy()
+    got_rows = unpack_tids(ot[:rq]).cpu().numpy()
+    recall = float(np.mean([len(set(got_rows[i][:got_c[i]]) & set(gt[i])) / K for i in range(rq)]))
+    # the CPU oracle over the probed lists of a few queries
+    cent_h, ll, _, _ = ix.export(rows=False)
+    t6 = np.zeros((n, 6), np.uint8)
+    check(lib().ndbhip_ivf_export(ix._h, None, None, None, t6.ctypes.data_as(C.c_void_p)))
+    tid_all = t6.view(ndbo.TID_DTYPE).reshape(n)
+    order = (((tid_all["bi_hi"].astype(np.int64) << 16) | tid_all["bi_lo"]) * 64 + tid_all["posid"] - 1)
+    off = np.zeros(len(ll) + 1, np.int64)
+    off[1:] = np.cumsum(ll)
+    qh = qs.cpu().numpy()
+    gtid = ndbo.tids_from_device_u64(got_t)
+    bad_oracle = 0
+    for i in range(nreplay):
+        pr = sorted(int(x) for x in ix.select_clusters(qh[i:i + 1], P)[0] if x >= 0)
+        keep = np.zeros(len(ll), bool)
+        keep[pr] = True
+        off2 = np.zeros(len(ll) + 1, np.int64)
+        off2[1:] = np.cumsum(np.where(keep, ll, 0))
+        sel = np.concatenate([np.arange(off[L], off[L + 1]) for L in pr]) if pr else np.zeros(0, np.int64)
+        rows_img = base[torch.from_numpy(order[sel]).to(dev)].cpu().numpy()
+        img = ndbo.IvfImage(cent_h, off2, rows_img, np.ascontiguousarray(tid_all[sel]))
+        et, ed, _ = img.search(qh[i], 1, P, K, 0)
+        bad_oracle += not (got_c[i] == len(et) and np.array_equal(gtid[i, :len(et)], ndbo.tids_to_u64(et)) and
+                           np.array_equal(got_d[i, :len(et)], ed.view(np.uint32)))
+    ix.close()
+    del base, q
+    torch.cuda.empty_cache()
+    launches = max(1, st["scan_launches"])
+    which = ("k_s16c_dense" if st.get("dense_sweeps", 0) > 0 else
+             ("centred sweep (k_s16c_wsweep / k_s16c_sweep)" if st.get("plane_bytes", 0) > 0 else
+              ("k_s16_sweep" if st.get("screen16_batches", 0) > 0 else "exact / fp32-screened scans")))
+    import copy
+    a2 = copy.copy(args)
+    a2.dim, a2.nvec, a2.lists, a2.batch, a2.probes, a2.k = dim, n, lists, nq, P, K
+    return {"workload": label or f"IVFFlat {n}x{dim} fp32 lists={lists} probes={P} k={K} L2, {nq} queries/step",
+            "queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3), "steps": steps,
+            "recall_at_10": round(recall, 4), "kmeans_iterations": int(iters), "build_and_prepare_s": round(tb, 3),
+            "lists_nonempty": int((ll > 0).sum()), "list_len_max": int(ll.max()),
+            "sweep": which, "sweep_ms": round(st["scan_kernel_ms"] / launches, 4),
+            "pairs_pruned_frac": round(1.0 - st.get("rows_swept", 0) / max(1, st.get("rows_scored", 1)), 4),
+            "screen16": {"batches": int(st.get("screen16_batches", 0)), "fallbacks": int(st.get("screen16_fallbacks", 0))},
+            "rows_emitted_per_query": round(st.get("rows_emitted", 0) / max(1, nq * steps), 1),
+            "rows_rescored_per_query": round(st.get("rows_rescored", 0) / max(1, nq * steps), 1),
+            "roofline": sweep_roofline(a2, st, nq, steps, ts * 1e3, "leg", 1) if st.get("plane_bytes", 0) > 0 else None,
+            "oracle_parity": {"queries": nreplay, "mismatches": int(bad_oracle),
+                              "note": "oracle/ndb_oracle.c over each query's probed lists: TIDs, float4 bits, counts"}}
+
+
+def sigma_sweep_leg(args, dev):
+    """the regime between the two tables of the line.  The headline shape (1M x 768, lists 1024, probes 32,
+    k 10, 4096 queries a step) with the mixture's spread sigma from 0.1 (components apart: the headline) to 1.0 (components
+    as wide as their centres are apart: nothing left of them in 768 dimensions), plus one anisotropic table (sigma 0.3, every
+    dimension d scaled by (d + 1)^-0.5).  Per table: queries/s, recall@10, the share of (row, pair) elements the bounds
+    excluded, which sweep ran, oracle parity."""
+    out = {}
+    for sg in (0.1, 0.2, 0.3, 0.5, 1.0):
+        try:
+            out[f"sigma_{sg}"] = l2_table_leg(args, dev, args.nvec, args.dim, args.lists, args.probes, args.k, args.batch,
+                                              args.components, sg, steps=3, warm=2, nreplay=4, recall_q=32,
+                                              label=f"mixture of {args.components} Gaussians, sigma {sg}")
+        except Exception as e:
+            out[f"sigma_{sg}"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        out["anisotropic_sigma_0.3"] = l2_table_leg(args, dev, args.nvec, args.dim, args.lists, args.probes, args.k, args.batch,
+                                                    args.components, 0.3, steps=3, warm=2, nreplay=4, recall_q=32, aniso=True,
+                                                    label=f"mixture of {args.components} Gaussians, sigma 0.3, dimension d scaled by (d+1)^-0.5")
+    except Exception as e:
+        out["anisotropic_sigma_0.3"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def c5_leg(args, dev, n, steps=20, warm=3, nreplay=8):

@@ -1996,7 +1996,9 @@ struct ndbhip_ivf
 	float2	   *w_wrec = nullptr;	size_t w_wrec_n = 0;
 	bool		s16w_off = false;	/* a query of some batch had more pairs than its list holds: the LDS ring from then on */
 	uint32_t	s16w_maxlw = 1;		/* the most (pair, block) words a (query, probe) pair can need: blocks of the fullest list's buckets */
-	uint32_t	wc_mult = 2;		/* words per (query, probe) pair the word arrays start with; doubles after a batch that did not fit */
+	uint32_t	s16w_avgblk = 4;	/* 32-row blocks of a bucket on average (rounded up) */
+	uint32_t	wc_mult = 4;		/* buckets per (query, probe) pair the word arrays are sized for to start with; x 4 after a batch that did not fit */
+	uint32_t	wc_words = 0;		/* the most words a batch of this mirror has needed so far (read back with the batch's flags) */
 	uint32_t   *w_overq = nullptr;	size_t w_overq_n = 0;	/* queries of the last batch whose records / survivors overflowed */
 	std::vector<uint32_t> redo;		/* ... on the host: ivf_s16_run returned 2, these go to the exact path one sub-batch */
 	float	   *w_redo_q = nullptr;	size_t w_redo_q_n = 0;
@@ -3296,6 +3298,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 				for (int c = 0; c < nc; c++)
 					mx = std::max(mx, lw[(size_t) c]);
 				ix->s16w_maxlw = (uint32_t) std::min<uint64_t>(mx, 0xFFFFFFu);
+				ix->s16w_avgblk = (uint32_t) std::max<uint64_t>(1, ((uint64_t) nb + nbk - 1) / std::max<size_t>(nbk, 1));
 			}
 			if (grow(ix->d_bucket_list, ix->d_bucket_list_n, nbk)) return NDBHIP_ERR_HIP;
 			if (grow(ix->d_plen, ix->d_plen_n, nbk)) return NDBHIP_ERR_HIP;
@@ -3745,7 +3748,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	 * dealt round-robin: the sweep is as long as its busiest wave, and tiles of 128 rows over sublists of 40 to 200
 	 * left waves with 6 to 20 items (profiles/r05_wave_trace.txt) */
 	const int	nchk_w = dimp / S16C_CH;
-	const int	wd = (!cen || c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk_w < 2 || ix->s16w_off) ? 0 : std::min(g_s16c_wave, nchk_w);
+	/* (buckets of 16 blocks on average at most: a pair has a word per block of its bucket, and whole lists of thousands of
+	 * rows that happen to be probed by few queries — a small batch on an unclustered table — are the LDS ring's) */
+	const int	wd = (!cen || c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk_w < 2 || ix->s16w_off || ix->s16w_avgblk > 16) ? 0
+		: std::min(g_s16c_wave, nchk_w);
 	const int	s16_rt = cen ? (wd ? 32 : (c_qb == 8 ? 256 : 128)) : (g_s16_waves == 8 ? 256 : 128);
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
 	/* rows of the pair planes: every pair there can be, up to qc_mult x (queries x probes) (at least 65 536; qc_mult starts at 4 and doubles, up to 16, after a batch that did not fit) — sublists
@@ -3988,11 +3994,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		}
 		/* the register-streaming sweep leaves its results per (pair, 32-row block) word (ndbhip_screen16w.h): the words'
 		 * places (grp_off is their per-bucket start with wmode = 1), and every query's list of its pairs */
-		/* at most every (query, probe) pair x the fullest list's blocks; to start with, wc_mult words a pair (a clustered
-		 * table keeps a handful of sublists per query: 1 word a (query, probe) pair at C2), twice that after a batch that
-		 * needed more */
+		/* at most every (query, probe) pair x the fullest list's blocks; to start with, wc_mult buckets of average size a
+		 * (query, probe) pair (C2 needs 1 word a pair, C4 — 19 sublists a list, 2.3 of them kept per probe — 9), then half
+		 * as much again as the fullest batch so far needed; four times the start after a batch that did not fit */
 		const size_t wbound = (size_t) nq * ((size_t) npr + dup0) * (size_t) ix->s16w_maxlw;
-		const uint32_t wcap = (uint32_t) std::min<size_t>(std::min<size_t>(wbound, std::max<size_t>((size_t) ix->wc_mult * nq * npr, (size_t) 1 << 16)), 0x07FFFFFFu);
+		const size_t wwant = std::max<size_t>(std::max<size_t>((size_t) ix->wc_mult * nq * npr * ix->s16w_avgblk, (size_t) ix->wc_words + ix->wc_words / 2),
+											  (size_t) 1 << 16);
+		const uint32_t wcap = (uint32_t) std::min<size_t>(std::min<size_t>(wbound, wwant), 0x07FFFFFFu);
 
 		if (wd)
 		{
@@ -4005,7 +4013,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			hipLaunchKernelGGL(k_s16w_pairinfo, dim3((qc_cap + 255) / 256), dim3(256), 0, g.stream, (const PairRec *) ix->w_pairs,
 							   (const uint32_t *) pair_off, ncs, (const uint32_t *) grp_off, (const uint32_t *) ds.own_len, qc_cap, wcap,
 							   ix->w_pslot + 3 * (size_t) qc_cap, ix->w_pslot + 4 * (size_t) qc_cap, ix->w_qslot, qsn,
-							   (uint32_t) S16_QP_CAP, flags + 2, flags + 6);
+							   (uint32_t) S16_QP_CAP, flags + 2, flags + 6, flags + 7);
 		}
 		if (g_debug_s16 && round == 0)
 		{
@@ -4163,6 +4171,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 			HIP_TRY(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
+			if (wd && f[7] > ix->wc_words)
+				ix->wc_words = f[7];
 			if (f[6])
 			{
 				/* a query with more pairs than its list holds (ndbhip_screen16w.h): this mirror's batches take the LDS ring

@@ -521,13 +521,18 @@ __global__ __launch_bounds__(256) void
 k_s16w_pairinfo(const PairRec *__restrict__ pairs, const uint32_t *__restrict__ pair_off, int nb,
 				const uint32_t *__restrict__ wbase /* [nb + 1] */, const uint32_t *__restrict__ own_len, uint32_t qc_cap,
 				uint32_t wcap, uint32_t *__restrict__ pebase, uint32_t *__restrict__ pbkt, uint32_t *__restrict__ qslot,
-				uint32_t *__restrict__ qsn, uint32_t qcap, unsigned int *__restrict__ flag_words, unsigned int *__restrict__ flag_list)
+				uint32_t *__restrict__ qsn, uint32_t qcap, unsigned int *__restrict__ flag_words, unsigned int *__restrict__ flag_list,
+				unsigned int *__restrict__ words_needed /* = the batch's words (the host sizes the next batch's arrays by it) */ )
 {
 	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t total = pair_off[nb];
 
-	if (j == 0 && wbase[nb] > wcap)
-		atomicAdd(flag_words, 1u);
+	if (j == 0)
+	{
+		*words_needed = wbase[nb];
+		if (wbase[nb] > wcap)
+			atomicAdd(flag_words, 1u);
+	}
 	if (j >= total || total > qc_cap || wbase[nb] > wcap)
 		return;
 	uint32_t	lo = 0, hi = (uint32_t) nb;
@@ -559,10 +564,10 @@ k_s16w_pairinfo(const PairRec *__restrict__ pairs, const uint32_t *__restrict__ 
  * position, lower bound), eub[q][i] = upper bound, ecount[q]; the positions and bounds the sweep's own slots held, in
  * another order).  Three steps, each with all its loads in flight together: the pairs (bucket, first word, blocks), the
  * words (row mask -> count, running sums over the wave), the records (record r -> its word by bisection over the sums
- * -> the set bit of its rank -> bounds and list position).  Records beyond ecap are counted and not written (the
- * query overflows: k_s16_finalize hands it to the exact path, as ever).
+ * -> the set bit of its rank -> bounds and list position; words and records S16W_COLLECT_WORDS words at a time).  Records
+ * beyond ecap are counted and not written (the query overflows: k_s16_finalize hands it to the exact path, as ever).
  */
-#define S16W_COLLECT_WORDS 512		/* (pair, block) words a query may have (more: it overflows); 9 KB of LDS a wave with the pairs' arrays: 17 waves a compute unit, the batch's 4096 in one go */
+#define S16W_COLLECT_WORDS 512		/* (pair, block) words a query's wave keeps at a time (more: in several goes); 9 KB of LDS a wave with the pairs' arrays: 17 waves a compute unit, the batch's 4096 in one go */
 __global__ __launch_bounds__(64) void
 k_s16w_collect(uint32_t nq, const uint32_t *__restrict__ qslot, const uint32_t *__restrict__ qsn, uint32_t qcap,
 			   const uint32_t *__restrict__ pbkt, const uint32_t *__restrict__ pebase, const uint32_t *__restrict__ pla,
@@ -616,94 +621,93 @@ k_s16w_collect(uint32_t nq, const uint32_t *__restrict__ qslot, const uint32_t *
 		s_first[n] = run;
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t nwords = run;
-
-	if (nwords > S16W_COLLECT_WORDS)
-	{
-		if (lane == 0)
-			ecount[q] = 0xFFFFFFFFu;		/* more words than this wave keeps: the query overflows */
-		return;
-	}
-	/* the words: masks, and where each word's records start */
+	/* the words, S16W_COLLECT_WORDS at a time: masks and where each word's records start, then the records */
 	uint32_t	nrec = 0;
 
-	for (uint32_t w0 = 0; w0 < nwords; w0 += 64)
+	for (uint32_t c0 = 0; c0 < nwords; c0 += S16W_COLLECT_WORDS)
 	{
-		const uint32_t w = w0 + (uint32_t) lane;
-		uint32_t	mk = 0, pi = 0;
+		const uint32_t cw = min((uint32_t) S16W_COLLECT_WORDS, nwords - c0);
+		const uint32_t rec0 = nrec;
 
-		if (w < nwords)
+		for (uint32_t w0 = 0; w0 < cw; w0 += 64)
 		{
-			uint32_t	lo = 0, hi = n;
+			const uint32_t wl = w0 + (uint32_t) lane, w = c0 + wl;
+			uint32_t	mk = 0, pi = 0;
+
+			if (wl < cw)
+			{
+				uint32_t	lo = 0, hi = n;
+
+				while (hi - lo > 1)
+				{
+					const uint32_t mid = (lo + hi) >> 1;
+
+					if (s_first[mid] <= w)
+						lo = mid;
+					else
+						hi = mid;
+				}
+				while (lo + 1 < n && s_first[lo + 1] <= w)
+					lo++;
+				pi = lo;
+				mk = wmask[s_word[pi] + (w - s_first[pi])];
+			}
+			const uint32_t c = (uint32_t) __popc(mk);
+			uint32_t	inc = c;
+
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1)
+			{
+				const uint32_t v = (uint32_t) __shfl_up((int) inc, off, 64);
+
+				if (lane >= off)
+					inc += v;
+			}
+			if (wl < cw)
+			{
+				s_off[wl] = nrec + inc - c;
+				s_mask[wl] = mk;
+				s_pair[wl] = (uint16_t) pi;
+			}
+			nrec += (uint32_t) __shfl((int) inc, 63, 64);
+		}
+		if (lane == 0)
+			s_off[cw] = nrec;
+		__builtin_amdgcn_wave_barrier();
+		/* the chunk's records */
+		const uint32_t rend = min(nrec, ecap);
+
+		for (uint32_t r = rec0 + (uint32_t) lane; r < rend; r += 64)
+		{
+			uint32_t	lo = 0, hi = cw;
 
 			while (hi - lo > 1)
 			{
 				const uint32_t mid = (lo + hi) >> 1;
 
-				if (s_first[mid] <= w)
+				if (s_off[mid] <= r)
 					lo = mid;
 				else
 					hi = mid;
 			}
-			while (lo + 1 < n && s_first[lo + 1] <= w)
+			while (lo + 1 < cw && s_off[lo + 1] <= r)
 				lo++;
-			pi = lo;
-			mk = wmask[s_word[pi] + (w - s_first[pi])];
-		}
-		const uint32_t c = (uint32_t) __popc(mk);
-		uint32_t	inc = c;
+			uint32_t	mk = s_mask[lo];
 
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1)
-		{
-			const uint32_t v = (uint32_t) __shfl_up((int) inc, off, 64);
+			for (uint32_t t = r - s_off[lo]; t > 0; t--)
+				mk &= mk - 1u;
+			const uint32_t bit = (uint32_t) __builtin_ctz(mk);
+			const uint32_t pi = s_pair[lo], blk = c0 + lo - s_first[pi];
+			const float2 lu = wrec[(size_t) 32u * (s_word[pi] + blk) + bit];
+			const uint32_t por = pos_of[(size_t) s_prow[pi] + 32u * blk + bit];
 
-			if (lane >= off)
-				inc += v;
+			erec[(size_t) q * ecap + r] = make_uint2(s_la[pi] + por, __float_as_uint(lu.x));
+			eub[(size_t) q * ecap + r] = lu.y;
 		}
-		if (w < nwords)
-		{
-			s_off[w] = nrec + inc - c;
-			s_mask[w] = mk;
-			s_pair[w] = (uint16_t) pi;
-		}
-		nrec += (uint32_t) __shfl((int) inc, 63, 64);
+		__builtin_amdgcn_wave_barrier();
 	}
 	if (lane == 0)
-	{
-		s_off[nwords] = nrec;
 		ecount[q] = nrec;
-	}
-	__builtin_amdgcn_wave_barrier();
-	/* the records */
-	const uint32_t nout = min(nrec, ecap);
-
-	for (uint32_t r = (uint32_t) lane; r < nout; r += 64)
-	{
-		uint32_t	lo = 0, hi = nwords;
-
-		while (hi - lo > 1)
-		{
-			const uint32_t mid = (lo + hi) >> 1;
-
-			if (s_off[mid] <= r)
-				lo = mid;
-			else
-				hi = mid;
-		}
-		while (lo + 1 < nwords && s_off[lo + 1] <= r)
-			lo++;
-		uint32_t	mk = s_mask[lo];
-
-		for (uint32_t t = r - s_off[lo]; t > 0; t--)
-			mk &= mk - 1u;
-		const uint32_t bit = (uint32_t) __builtin_ctz(mk);
-		const uint32_t pi = s_pair[lo], blk = lo - s_first[pi];
-		const float2 lu = wrec[(size_t) 32u * (s_word[pi] + blk) + bit];
-		const uint32_t por = pos_of[(size_t) s_prow[pi] + 32u * blk + bit];
-
-		erec[(size_t) q * ecap + r] = make_uint2(s_la[pi] + por, __float_as_uint(lu.x));
-		eub[(size_t) q * ecap + r] = lu.y;
-	}
 }
 
 #endif							/* NDBHIP_SCREEN16W_H */

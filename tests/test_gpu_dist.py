@@ -82,13 +82,16 @@ def test_two_ranks_one_device_sharded_search_equals_oracle(slices):
     assert all(ret.get(r) is True for r in range(world)), dict(ret)
 
 
-def _worker_c(rank, world, name, slices, ret):
+def _worker_c(rank, world, name, slices, ret, rccl_id=None):
+    """rccl_id None: both ranks on cuda:0 over the shared-memory transport; else a Manager dict through which rank 0 hands
+    the other ranks RCCL's unique id: rank r on cuda:r, the communicator bench.py --gpus N uses."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         from neurondb_amd import IvfIndex, _lib
         from neurondb_amd.dist import partition_lists, partition_slices
-        _lib.ensure_init(0)
-        dev = torch.device("cuda", 0)
+        di = rank if rccl_id is not None else 0
+        _lib.ensure_init(di)
+        dev = torch.device("cuda", di)
         torch.cuda.set_device(dev)
         _lib.use_torch_stream()
         a = make_ivf_arrays(6000, 96, 20, seed=61, dup_frac=0.1)
@@ -110,7 +113,23 @@ def _worker_c(rank, world, name, slices, ret):
             owner = partition_lists(a["list_len"], world)
             ix = full.shard((owner == rank).astype(np.uint8))
         full.close()
-        _lib.check(_lib.lib().ndbhip_comm_init_shm(name.encode(), rank, world, 1 << 20))
+        if rccl_id is None:
+            _lib.check(_lib.lib().ndbhip_comm_init_shm(name.encode(), rank, world, 1 << 20))
+        else:
+            import ctypes as C
+            import time as _t
+            ident = (C.c_ubyte * 128)()
+            if rank == 0:
+                _lib.check(_lib.lib().ndbhip_comm_unique_id(C.byref(ident)))
+                rccl_id["id"] = bytes(ident)
+            else:
+                t0 = _t.time()
+                while "id" not in rccl_id:
+                    if _t.time() - t0 > 120:
+                        raise TimeoutError("rank 0 never published the RCCL id")
+                    _t.sleep(0.01)
+                C.memmove(ident, rccl_id["id"], 128)
+            _lib.check(_lib.lib().ndbhip_comm_init(C.byref(ident), rank, world))
         assert _lib.lib().ndbhip_comm_world() == world and _lib.lib().ndbhip_comm_rank() == rank
         dq = torch.from_numpy(q).to(dev)
         ot = torch.zeros((nq, k), dtype=torch.int64, device=dev)
@@ -136,6 +155,20 @@ def test_c_abi_sharded_search_two_ranks_over_shared_memory(slices):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_c, args=(world, f"/ndbhip_test_{os.getpid()}_{int(slices)}", slices, ret), nprocs=world, join=True)
+    assert all(ret.get(r) is True for r in range(world)), dict(ret)
+
+
+@pytest.mark.parametrize("slices", [False, True])
+def test_c_abi_sharded_search_two_ranks_over_rccl_on_two_devices(slices):
+    """The same two-rank search with one rank per DEVICE over RCCL (ncclCommInitRank with two ranks, the all-gathers and the
+    all-reduce(min) of ndbhip_comm.cpp between two GPUs): what bench.py --gpus N times.  Needs two devices: skipped on the
+    one-GPU boxes the round's tests run on, there for the day a multi-GPU box runs them."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"{torch.cuda.device_count()} device(s): two ranks over RCCL need two")
+    world = 2
+    mgr = mp.Manager()
+    ret, rid = mgr.dict(), mgr.dict()
+    mp.spawn(_worker_c, args=(world, "", slices, ret, rid), nprocs=world, join=True)
     assert all(ret.get(r) is True for r in range(world)), dict(ret)
 
 
