@@ -1617,7 +1617,8 @@ def sweep_roofline(args, st, nq, steps, ms_per_step, data_kind, world):
     mf = issued / (ms * 1e-3) / 1e12
     hf, mfr = hbm / HBM_PEAK_GBPS, mf / FP16_MFMA_PEAK_TFLOPS
     dense = st.get("dense_sweeps", 0) > 0
-    tr, src, busy = pmc_traffic(args, world, "k_s16c_dense" if dense else "k_s16c_sweep", data_kind, want_busy=True)
+    wave = st.get("wave_sweeps", 0) > 0
+    tr, src, busy = pmc_traffic(args, world, "k_s16c_dense" if dense else ("k_s16c_wsweep" if wave else "k_s16c_sweep"), data_kind, want_busy=True)
     alg = st["bytes_scored"] / launches
     how = {"ip": "; inner product: b = |q - x|^2 + M^2 - |x|^2 on the L2 layout's planes, thresholds in b's domain",
            "cosine": "; cosine: |q^ - x^|^2 over normalised planes"}.get(args.strategy, "") + \
@@ -1625,8 +1626,12 @@ def sweep_roofline(args, st, nq, steps, ms_per_step, data_kind, world):
     r = {"bound": "hbm" if hf >= mfr else "mfma",
          "kernel": ("k_s16c_dense (the centred one-plane sweep's dense tile, 256 pairs x 256 rows: loader / prefetcher waves, "
                     "the matrix pipe screens its own accumulator blocks, queued records; csrc/ndbhip_screen16d.h)" if dense else
-                    "k_s16c_sweep (centred one-plane sweep: fp16 planes of row - centre and query - centre, "
-                    "v_mfma_f32_32x32x16_f16, operands by LDS DMA)") + how,
+                    ("k_s16c_wsweep (centred one-plane sweep as wave-autonomous register streams: fragment-major fp16 planes of "
+                     "row - centre, a 32-row block x 32 pairs per wave, operands by coalesced 16-byte-per-lane loads straight into "
+                     "the registers v_mfma_f32_32x32x16_f16 reads, items from per-XCD queues, every element's bounds in a place of "
+                     "its own; csrc/ndbhip_screen16w.h)" if wave else
+                     "k_s16c_sweep (centred one-plane sweep: fp16 planes of row - centre and query - centre, "
+                     "v_mfma_f32_32x32x16_f16, operands by LDS DMA)")) + how,
          "achieved": round(hbm if hf >= mfr else mf, 1), "peak": HBM_PEAK_GBPS if hf >= mfr else FP16_MFMA_PEAK_TFLOPS,
          "unit": "GB/s" if hf >= mfr else "TFLOP/s", "frac": round(max(hf, mfr), 4),
          "traffic": tr, "traffic_source": src, "avg_launch_ms": round(ms, 4), "launches": int(launches),

@@ -112,6 +112,8 @@ typedef struct ndbhip_stats
 									 * deleted rows left as holes and the survivors renumbered) */
 	uint64_t	dense_sweeps;		/* sweeps that ran the dense tile's kernel (256 pairs x 256 rows: buckets probed by hundreds of
 									 * queries — a table without cluster structure; csrc/ndbhip_screen16d.h) */
+	uint64_t	wave_sweeps;		/* sweeps that ran as wave-autonomous register streams (k_s16c_wsweep, csrc/ndbhip_screen16w.h: sparse pair
+								 * tables — a bucket probed by a handful of queries) */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);

@@ -3099,6 +3099,7 @@ static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold ever
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_wave = 2;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
+static int	g_s16c_wave_min_nq = 1024;	/* batches from this many queries up take k_s16c_wsweep ("screen16c_wave_min_nq") */
 static int	g_s16c_wblk = 2;	/* blocks of 4 waves per compute unit that k_s16c_wsweep is launched with (1, 2, or 3 when two chunks are in flight per wave: the registers of that form allow three; "screen16c_wave_blocks") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
@@ -3750,7 +3751,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	const int	nchk_w = dimp / S16C_CH;
 	/* (buckets of 16 blocks on average at most: a pair has a word per block of its bucket, and whole lists of thousands of
 	 * rows that happen to be probed by few queries — a small batch on an unclustered table — are the LDS ring's) */
-	const int	wd = (!cen || c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk_w < 2 || ix->s16w_off || ix->s16w_avgblk > 16) ? 0
+	/* (and batches of a thousand queries at least: below that the ring is as fast — 0.156 against 0.163-0.177 ms at C5's
+	 * 256 — and needs no pair lists and no collect behind it) */
+	const int	wd = (!cen || c_qb != 1 || !g_s16c_wave || !g_s16c_epi || g_s16_debug != 0 || nchk_w < 2 || ix->s16w_off || ix->s16w_avgblk > 16 ||
+					  nq < g_s16c_wave_min_nq) ? 0
 		: std::min(g_s16c_wave, nchk_w);
 	const int	s16_rt = cen ? (wd ? 32 : (c_qb == 8 ? 256 : 128)) : (g_s16_waves == 8 ? 256 : 128);
 	const uint32_t s16_qt = (uint32_t) (32 * c_qb);
@@ -4077,6 +4081,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				g.stats.dense_sweeps++;
 			/* (two chunks in flight: the 168-register form whatever the blocks — at two blocks a compute unit it leaves a
 			 * third of the register file to the other steps' kernels, see --inflight) */
+			if (wd)
+				g.stats.wave_sweeps++;
 			if (wd == 2)
 				S16C_WSWEEP_D(2, 3);
 			else if (wd == 3)
@@ -4541,6 +4547,12 @@ ndbhip_set_option(const char *name, int value)
 		if (value != 0 && (value < 2 || value > 4))
 			return fail(NDBHIP_ERR_INVALID, "screen16c_wave must be 0 (the LDS ring) or 2 .. 4 chunks in flight");
 		g_s16c_wave = value;
+	}
+	else if (!strcmp(name, "screen16c_wave_min_nq"))
+	{
+		if (value < 1)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_wave_min_nq must be >= 1");
+		g_s16c_wave_min_nq = value;
 	}
 	else if (!strcmp(name, "screen16_sweep_queue"))
 		g_s16_sweepq = value != 0;

@@ -103,12 +103,12 @@ def main():
             a = a[3:]
             wl = {"data": data, "nvec": 1000000, "dim": 768, "lists": 1024, "probes": 32, "batch": 4096,
                   "rows": "f32", "strategy": "l2"}
-            for needle, name in (("k_s16c_sweep", "k_s16c_sweep"), ("k_s16c_dense", "k_s16c_dense"),
-                                 ("k_s16_finalize", "k_s16_finalize"), ("k_s16c_seed", "k_s16c_seed")):
+            for needle, name in (("k_s16c_wsweep", "k_s16c_wsweep"), ("k_s16c_sweep", "k_s16c_sweep"), ("k_s16c_dense", "k_s16c_dense"),
+                                 ("k_s16_finalize", "k_s16_finalize"), ("k_s16c_seed", "k_s16c_seed"), ("k_s16w_collect", "k_s16w_collect")):
                 e = entry(prefix, needle, steps, wl, False)
                 if e:
                     b = busy(prefix, needle)
-                    if b is not None and name in ("k_s16c_sweep", "k_s16c_dense"):
+                    if b is not None and name in ("k_s16c_sweep", "k_s16c_dense", "k_s16c_wsweep"):
                         e["mfma_busy"] = b
                     doc["kernels"].setdefault(name, {})[data] = e
         elif a[0] == "--c5":
@@ -117,7 +117,7 @@ def main():
             a = a[2:]
             wl = {"data": "c5", "nvec": 10000000, "dim": 1536, "lists": 4096, "probes": 32, "batch": 256,
                   "rows": "f16", "strategy": "ip"}
-            for needle, name in (("k_s16c_sweep", "k_s16c_sweep"), ("k_s16_finalize", "k_s16_finalize")):
+            for needle, name in (("k_s16c_wsweep", "k_s16c_wsweep"), ("k_s16c_sweep", "k_s16c_sweep"), ("k_s16_finalize", "k_s16_finalize")):
                 e = entry(prefix, needle, steps, wl, False)
                 if e:
                     doc["kernels"].setdefault(name, {})["c5"] = e
