@@ -3099,6 +3099,7 @@ static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold ever
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_wave = 2;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
+static int	g_s16c_plseed = 1;	/* first thresholds from the sweep's own planes (block 0 of the nearest sublist) instead of float4 rows ("screen16c_plane_seeds") */
 static int	g_s16c_wave_min_nq = 1024;	/* batches from this many queries up take k_s16c_wsweep ("screen16c_wave_min_nq") */
 static int	g_s16c_wblk = 2;	/* blocks of 4 waves per compute unit that k_s16c_wsweep is launched with (1, 2, or 3 when two chunks are in flight per wave: the registers of that form allow three; "screen16c_wave_blocks") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
@@ -3631,17 +3632,17 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
 
-#define S16C_SEED_L(SUBB, ...)                                                                                          \
+#define S16C_SEED_L(SUBB, PLL, ...)                                                                                     \
 	do {                                                                                                                \
 		if (ipc && H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 1>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
 		else if (ipc && H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 2>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
 		else if (ipc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 0>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);     \
-		else if (H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 1>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
-		else if (H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 2>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 0>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);             \
+		else if (H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 1, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else if (H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 2, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 0, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);             \
 	} while (0)
 	if (!seed_by_sublist && cen && !xseed)
-		S16C_SEED_L(false, d, d_q, w_probes, lco, npr,
+		S16C_SEED_L(false, false, d, d_q, w_probes, lco, npr,
 					(uint32_t) k, cseeds, (const uint32_t *) nullptr, (const int *) nullptr, (const uint32_t *) nullptr,
 					(const int64_t *) nullptr, (const uint32_t *) nullptr, (const float *) nullptr,
 					0u, (const float *) nullptr, (const float *) nullptr, 0u, ix->w_qthr,
@@ -3896,12 +3897,22 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				}
 				/* ... which also say where the query's own neighbourhood is: seeds from the nearest sublist */
 				if (cen && !xseed)
-					S16C_SEED_L(true, d, d_q, w_probes, lco, npr,
-								(uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,
-								(const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,
-								(const uint32_t *) ix->d_pposof,
-								subdist, sstride, pdist, cdist, cstride, ix->w_qthr,
-								(const float *) ix->w_qn2, (const uint32_t *) ix->d_ipc_m2, sub_rn2, (const float *) ix->d_cn2);
+					{
+#define S16C_SEED_SUB_ARGS d, d_q, w_probes, lco, npr,                                                               \
+								(uint32_t) k, cseeds, (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx,       \
+								(const uint32_t *) ix->d_sub_len, (const int64_t *) ix->d_prow_off,                          \
+								(const uint32_t *) ix->d_pposof,                                                            \
+								subdist, sstride, pdist, cdist, cstride, ix->w_qthr,                                         \
+								(const float *) ix->w_qn2, (const uint32_t *) ix->d_ipc_m2, sub_rn2, (const float *) ix->d_cn2, \
+								(const unsigned char *) ix->d_planes, (const uint32_t *) ix->d_sub_blk, (const float *) ix->d_rn2, \
+								(const int16_t *) ix->d_rexp, (const float *const *) ix->d_sub_cptr, ndb_s16c_ce(dim)
+						/* (L2 on the centred planes: the seeds' bounds from block 0 of the nearest sublist's planes) */
+						if (g_s16c_plseed && !ipc && !cosb)
+							S16C_SEED_L(true, true, S16C_SEED_SUB_ARGS);
+						else
+							S16C_SEED_L(true, false, S16C_SEED_SUB_ARGS);
+#undef S16C_SEED_SUB_ARGS
+					}
 				else
 				{
 #define S16_SEEDSUB_L(RR, HH, ...) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_seed_sub<RR, HH>), dim3(nq), dim3(64), 0, g.stream, __VA_ARGS__)
@@ -4548,6 +4559,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_wave must be 0 (the LDS ring) or 2 .. 4 chunks in flight");
 		g_s16c_wave = value;
 	}
+	else if (!strcmp(name, "screen16c_plane_seeds"))
+		g_s16c_plseed = value != 0;
 	else if (!strcmp(name, "screen16c_wave_min_nq"))
 	{
 		if (value < 1)

@@ -465,7 +465,8 @@ k_s16c_qcprep(const float *__restrict__ queries, int dim, int dimp, const PairRe
  * decodes them).
  */
 #define S16C_SEED_THREADS 256	/* 4 waves a query: one wave alone was 0.33 ms of dependent loads for 256 queries on 10M rows */
-template <bool SUB, bool IP = false, int H16 = 0 /* 0: float4 rows; 1: fp16 decoded like the reference (quirk Q20); 2: fp16 without subnormals (the plain conversion is the reference's) */>
+template <bool SUB, bool IP = false, int H16 = 0 /* 0: float4 rows; 1: fp16 decoded like the reference (quirk Q20); 2: fp16 without subnormals (the plain conversion is the reference's) */,
+		  bool PL = false /* the seeds' bounds from the sweep's own fp16 planes (SUB, L2): see "plane seeds" below */>
 __global__ __launch_bounds__(S16C_SEED_THREADS) void
 k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict__ probes,
 			const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k, uint32_t ns,
@@ -475,7 +476,11 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
 			const float *__restrict__ cdist, uint32_t cstride, float2 *__restrict__ qthr,
 			const float *__restrict__ qn2 = nullptr, const uint32_t *__restrict__ m2_bits = nullptr /* IP: |q|^2, M^2 */,
-			const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr /* IP: |c|^2 */ )
+			const float *__restrict__ cn2_sub = nullptr, const float *__restrict__ cn2_list = nullptr /* IP: |c|^2 */,
+			/* PL: the centred planes and what goes with them (k_s16c_row_prep), the buckets' centres, c_E */
+			const unsigned char *__restrict__ planes = nullptr, const uint32_t *__restrict__ blk_off = nullptr,
+			const float *__restrict__ rn2 = nullptr, const int16_t *__restrict__ rexp = nullptr,
+			const float *const *__restrict__ cptr = nullptr, float cE = 0.0f)
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -611,6 +616,135 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 
 				ok = pos < vis;			/* a candidate of this (query, probe) under the candidate cap */
 				row = ix.loc_off[probes[(size_t) q * npr + bp]] + pos;
+			}
+		}
+		if constexpr (PL && !IP)
+		{
+			/*
+			 * Plane seeds (r5).  The seed rows are the first rows of the nearest sublist: block 0 of that bucket's planes.
+			 * Summing (q_i - x_i)^2 over their float4 rows read 32 x 3 KB a query — 440 MB a batch of 4096, 85 us at C2 —
+			 * for a number that only has to BOUND the k-th distance from above; the sweep's own arithmetic gives such a
+			 * bound from half the bytes: a = Q2 + X2 - 2 (q - c).(x - c) from the block's fp16 image (one
+			 * v_mfma_f32_32x32x16_f16 per 16 dimensions in ONE accumulator chain, the query's q - c as the only member of
+			 * the pair operand: the very chain k_s16c_sweep runs), |a - |q - x|^2| <= E = c_E (Q2 + X2) + ABS
+			 * (ndbhip_common.h (8)), so a + E bounds the real squared distance from above — what s16c_t_from_ub takes.
+			 * q - c, its norm and its exponent are made exactly as k_s16c_qcprep makes them (fp64 sum, 2^(14 - e), round
+			 * to nearest fp16).
+			 */
+			const int	dimp = (dim + 63) & ~63;
+			const bool	enough = (uint32_t) __popcll(__ballot(ok)) >= k;		/* (every wave holds the same `ok`) */
+
+			if (bs != 0xFFFFFFFFu && enough && ns <= 32u && dimp <= 2048 && (dim & 3) == 0)		/* uniform over the block */
+			{
+				__shared__ double s_sum[NW];
+				__shared__ __attribute__((aligned(16))) _Float16 s_qc[2048];
+				const float *c = cptr[bs];
+				const int	i0 = (int) threadIdx.x * 4;
+				float4		dv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+				double		sm = 0.0;
+
+#pragma unroll
+				for (int t = 0; t < 2; t++)
+				{
+					const int	i = i0 + t * 4 * S16C_SEED_THREADS;
+
+					if (i < dim)
+					{
+						const float4 qv = *reinterpret_cast<const float4 *>(qq + i), cv = *reinterpret_cast<const float4 *>(c + i);
+
+						dv[t] = make_float4(qv.x - cv.x, qv.y - cv.y, qv.z - cv.z, qv.w - cv.w);
+						sm += (double) dv[t].x * (double) dv[t].x + (double) dv[t].y * (double) dv[t].y +
+							(double) dv[t].z * (double) dv[t].z + (double) dv[t].w * (double) dv[t].w;
+					}
+				}
+				sm = wave_sum_f64(sm);
+				if (lane == 0)
+					s_sum[wv] = sm;
+				__syncthreads();
+				double		tot = 0.0;
+
+#pragma unroll
+				for (int w = 0; w < NW; w++)
+					tot += s_sum[w];
+				const bool	qok = tot <= 3.0e38;
+				const int	eq = qok ? s16_exponent(tot) : 0;
+				const float Q2 = qok ? (float) tot : __uint_as_float(0x7FC00000u);
+				const float sc = ldexpf(1.0f, 14 - eq);
+
+#pragma unroll
+				for (int t = 0; t < 2; t++)
+				{
+					const int	i = i0 + t * 4 * S16C_SEED_THREADS;
+
+					if (i < dimp)
+					{
+						ndb_h2		h01, h23;
+
+						h01.x = qok ? (_Float16) (dv[t].x * sc) : (_Float16) 0;
+						h01.y = qok ? (_Float16) (dv[t].y * sc) : (_Float16) 0;
+						h23.x = qok ? (_Float16) (dv[t].z * sc) : (_Float16) 0;
+						h23.y = qok ? (_Float16) (dv[t].w * sc) : (_Float16) 0;
+						ndb_h2		pk[2] = {h01, h23};
+
+						*reinterpret_cast<uint2 *>(s_qc + i) = *reinterpret_cast<const uint2 *>(pk);
+					}
+				}
+				__syncthreads();
+				if (wv)
+					return;
+				/* one wave, one chain: block 0 of the bucket, chunk by chunk, k-step by k-step */
+				const int	nchunk = dimp / S16C_CH, r32 = lane & 31, kh = lane >> 5;
+				const unsigned char *blk = planes + (size_t) blk_off[bs] * (size_t) nchunk * 4096;
+				ndb_f16acc	acc;
+				ndb_h8		zero;
+
+#pragma unroll
+				for (int i = 0; i < 16; i++)
+					acc[i] = 0.0f;
+#pragma unroll
+				for (int i = 0; i < 8; i++)
+					zero[i] = (_Float16) 0;
+				for (int ch = 0; ch < nchunk; ch++)
+				{
+					ndb_h8		bh[4], ah[4];
+
+#pragma unroll
+					for (int st = 0; st < 4; st++)
+					{
+						bh[st] = *reinterpret_cast<const ndb_h8 *>(blk + (size_t) ch * 4096 + st * 1024 + lane * 16);
+						ah[st] = r32 == 0 ? *reinterpret_cast<const ndb_h8 *>(s_qc + ch * 64 + st * 16 + kh * 8) : zero;
+					}
+#pragma unroll
+					for (int st = 0; st < 4; st++)
+						acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st], bh[st], acc, 0, 0, 0);
+				}
+				/* element (reg 0, lane r < 32) = member 0, row r of the block */
+				const int64_t pp = prow_off[bs] + (lane & 31);
+				const float X2 = rn2[pp];
+				const int	ex = (int) rexp[pp];
+				const float t1 = ldexpf(acc[0], eq + ex - 27);
+				const float nn = Q2 + X2;
+				const float av = nn - t1;
+				const float er = s16_up(s16_up(cE * nn) + NDB_S16_ABS);
+				const float ub = fmaxf(s16_up(s16_up(av + er)), 0.0f);
+				const bool	good = ok && lane < 32 && ub == ub && (ub - ub) == 0.0f;
+				const uint32_t key = good ? __float_as_uint(ub) : 0xFFFFFFFFu;
+				uint32_t	rank = 0;
+
+				for (int j = 0; j < 64; j++)
+				{
+					const uint32_t kj = (uint32_t) __shfl((int) key, j, 64);
+
+					rank += (kj < key || (kj == key && j < lane)) ? 1u : 0u;
+				}
+				const unsigned long long pick = __ballot(good && rank == k - 1);
+				float		t = __uint_as_float(0x7F800000u);	/* +inf: fewer than k usable seeds */
+
+				if (pick)
+					t = s16c_t_from_ub(__shfl(ub, __ffsll((long long) pick) - 1, 64), dim);
+				if (lane == 0)
+					qthr[q] = make_float2(t, 0.0f);
+				return;
 			}
 		}
 	}

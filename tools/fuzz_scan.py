@@ -126,7 +126,8 @@ def one_case(rng, lib, IvfIndex, check):
           "screen16_stage": int(rng.choice([0, 1, 1, 2, 5, 13])),
           # round 5: the 32-pair tile as wave-autonomous register streams (chunks in flight per wave) or the LDS ring
           "screen16c_wave": int(rng.choice([0, 2, 2, 3, 4])),
-          "screen16c_wave_blocks": int(rng.choice([1, 2, 3, 3])), "screen16c_wave_min_nq": 1}
+          "screen16c_wave_blocks": int(rng.choice([1, 2, 3, 3])), "screen16c_wave_min_nq": 1,
+          "screen16c_plane_seeds": int(rng.random() < 0.7)}
     for name, value in r4.items():
         check(lib.ndbhip_set_option(name.encode(), value))
     if os.environ.get("FUZZ_TRACE"):
