@@ -296,16 +296,19 @@ def main():
                  "from_host": from_host,
                  "from_host_vectors_per_s": from_host["vectors_per_s"] if from_host else None,
                  "lists_identical_to_exact_assignment": same and counts_ok,
-                 "roofline": {"bound": "mfma", "achieved": round(flops / t_build / 1e12, 2), "peak": FP16_MFMA_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(flops / t_build / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),
-                              "flops": int(flops),
-                              "executed_flops": int(6.0 * 2.0 * n * nlists * dim + flops - 2.0 * n * nlists * dim),
-                              "note": "whole build (sample k-means, assignment of every row, list packing) over the "
-                                      "algorithmic flops SURVEY 8d assigns to it (2 N lists dim), against the dense fp16 "
-                                      "matrix-core peak: the assignment runs as two sweeps of k_s16_sweep (row minimum, "
-                                      "then the centroids within the error bound of it), each 3 fp16 products per "
-                                      "multiply (split operands) = executed_flops; the reference's fp32 arithmetic decides "
-                                      "only among the centroids the bound leaves (about 1 % of the rows have more than one)"},
+                 "roofline": (lambda exe: {
+                     "bound": "mfma", "achieved": round(exe / t_build / 1e12, 2), "peak": FP16_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(exe / t_build / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),
+                     "executed_flops": int(exe),
+                     "algorithmic": {"flops": int(flops), "achieved": round(flops / t_build / 1e12, 2),
+                                     "frac": round(flops / t_build / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4)},
+                     "note": "whole build (sample k-means, assignment of every row, list packing) over the flops it EXECUTES, "
+                             "against the dense fp16 matrix-core peak: the assignment runs as two sweeps of k_s16_sweep "
+                             "(row minimum, then the centroids within the error bound of it), each 3 fp16 products per "
+                             "multiply (split operands) = 12 N lists dim, plus the k-means iterations; `algorithmic` = "
+                             "SURVEY 8d's 2 N lists dim.  The reference's fp32 arithmetic decides only among the "
+                             "centroids the bound leaves (about 1 % of the rows have more than one)"})(
+                     6.0 * 2.0 * n * nlists * dim + flops - 2.0 * n * nlists * dim),
                  "cpu_baseline": (build_cpu_baseline(args, base, cent_h, kmeans_iters) if args.cpu_seconds > 0 and world == 1
                                   else None)}
     del base
@@ -410,7 +413,6 @@ def main():
         check(lib().ndbhip_synchronize())
         del base2
         for w in range(inflight):
-            _dummy = [torch.cuda.Stream() for _ in range(int(os.environ.get("NDB_LANE_STREAM_SKIP", "0")))]
             lanes.append({"stream": torch.cuda.Stream(), "t": torch.zeros_like(out_t), "d": torch.zeros_like(out_d),
                           "c": torch.zeros_like(out_c)})
         torch.cuda.synchronize()
@@ -452,7 +454,7 @@ def main():
     elapsed = time.perf_counter() - t0
     check(lib().ndbhip_profile(0))
     st = _lib.stats()
-    serial = None
+    serial, st_serial = None, None
     if inflight > 1:
         # the same steps one after the other on the first mirror: what rounds 1-4 timed; its results are the reference the
         # lanes' last steps are compared with
@@ -461,10 +463,14 @@ def main():
         inflight = 1
         run_steps(0, args.warmup)
         barrier()
+        check(lib().ndbhip_stats_reset())
+        check(lib().ndbhip_profile(1))
         t0 = time.perf_counter()
         run_steps(args.warmup, args.steps)
         barrier()
         el1 = time.perf_counter() - t0
+        check(lib().ndbhip_profile(0))
+        st_serial = _lib.stats()
         inflight = save
         # lane w's last step was step warmup + last index congruent to w; rerun those serially and compare
         same = True
@@ -605,6 +611,13 @@ def main():
         dict(o.split("=") for o in args.opt).get("screen16_centered", "1") != "0"
     if centred:
         roofline = sweep_roofline(args, st, nq, args.steps, elapsed / args.steps * 1e3, args.data, world) or roofline
+        if st_serial is not None and st_serial.get("plane_bytes", 0) > 0 and "hbm" in roofline:
+            # the same kernel with nothing beside it (the serial pass): what the kernel itself reaches; the figures above are
+            # its launches INSIDE the timed region, where the other steps' chains take compute units and bandwidth
+            al = sweep_roofline(args, st_serial, nq, args.steps, serial["ms_per_step"], args.data, world)
+            if al:
+                roofline["alone"] = {k: al[k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}
+                roofline["alone"]["note"] = "the same launches in the `serial` pass (one step at a time, HIP events on the library's stream)"
     elif s16:
         # The bound pass ran on the fp16 matrix cores (k_s16_sweep, csrc/ndbhip_screen16.h).  Algorithmic flops:
         # SURVEY 8d's per-unit figure, 3 x dim per scored (row, query) pair (subtract, multiply, add), x the pairs

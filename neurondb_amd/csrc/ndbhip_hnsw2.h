@@ -46,6 +46,7 @@ __device__ unsigned long long g_h2_phases[8];
 struct H2Graph
 {
 	const float *vecs;
+	const uint16_t *vecs16;		/* walk rows (round 5): float4_to_fp16 of every element of vecs, same stride; nullptr = none */
 	const int  *levels;
 	int16_t    *ncount;
 	uint32_t   *nbrs;
@@ -84,6 +85,21 @@ struct H2Query
 #pragma unroll
 		for (int j = 0; j < H2_QREG; j++)
 			r[j] = lane + 64 * j < d ? qq[lane + 64 * j] : 0.0f;
+	}
+
+	/* for walk rows: the lane's GROUPS of four elements, group lane, lane + 64, ... (d % 4 == 0, d <= 64 * H2_QREG) */
+	__device__ __forceinline__ void load16(const float *qq, int d, int lane)
+	{
+		q = qq;
+		dim = d;
+#pragma unroll
+		for (int j = 0; j < H2_QREG / 4; j++)
+		{
+			const int	i = (lane + 64 * j) * 4;
+#pragma unroll
+			for (int t = 0; t < 4; t++)
+				r[4 * j + t] = i < d ? qq[i + t] : 0.0f;
+		}
 	}
 };
 
@@ -182,6 +198,81 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
 		out[u] = h2_wave_fold(p[u]);
+}
+
+/*
+ * The same on WALK ROWS (oracle/ndb_oracle_hnsw2.c "WALK ROWS", ndbo_h2_dist2_w16): fp16 images of the rows, a lane
+ * asks for 8 bytes — the four halves of group lane + 64 j — per request (a 768-dim row is three requests of 512
+ * contiguous bytes instead of twelve of 256), decodes them (the reference's fp16_to_float; the encoder leaves no
+ * subnormal, so the hardware conversion is that function) and adds the four terms in increasing element order to its
+ * fp64 partial: element i goes to partial (i / 4) mod 64.  Query registers in load16's order.
+ */
+__device__ __forceinline__ void
+h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, double out[H2_NR])
+{
+	constexpr int NG = H2_QREG / 4;
+	double		p[H2_NR];
+	uint2		v[H2_NR][NG];
+
+#pragma unroll
+	for (int u = 0; u < H2_NR; u++)
+	{
+		p[u] = 0.0;
+#pragma unroll
+		for (int j = 0; j < NG; j++)
+		{
+			const int	i = (lane + 64 * j) * 4;
+
+			v[u][j] = (u < n && i < Q.dim) ? *(const uint2 *) (x[u] + i) : make_uint2(0u, 0u);
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < NG; j++)
+		if ((lane + 64 * j) * 4 < Q.dim)
+		{
+#pragma unroll
+			for (int u = 0; u < H2_NR; u++)
+			{
+				const uint32_t w[2] = {v[u][j].x, v[u][j].y};
+
+#pragma unroll
+				for (int t = 0; t < 4; t++)
+				{
+					const unsigned short h = (unsigned short) ((t & 1) ? (w[t >> 1] >> 16) : (w[t >> 1] & 0xFFFFu));
+					const float d = Q.r[4 * j + t] - __half2float(__ushort_as_half(h));
+
+					p[u] += (double) d * (double) d;
+				}
+			}
+		}
+#pragma unroll
+	for (int u = 0; u < H2_NR; u++)
+		out[u] = h2_wave_fold(p[u]);
+}
+
+/* d2(query, node ids[u]) for u < n: on the walk rows (W16; Q loaded by load16) or on the float4 rows (Q loaded by load) */
+template <bool W16>
+__device__ __forceinline__ void
+h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, int lane, double d[H2_NR])
+{
+	if (W16)
+	{
+		const uint16_t *x[H2_NR];
+
+#pragma unroll
+		for (int u = 0; u < H2_NR; u++)
+			x[u] = g.vecs16 + (size_t) ids[u] * g.dim;
+		h2w_dist2x(Q, x, n, lane, d);
+	}
+	else
+	{
+		const float *x[H2_NR];
+
+#pragma unroll
+		for (int u = 0; u < H2_NR; u++)
+			x[u] = g.vecs + (size_t) ids[u] * g.dim;
+		h2_dist2x4(Q, x, n, lane, d);
+	}
 }
 
 /* d2 of two rows of the graph */
@@ -526,6 +617,7 @@ h2_offer(H2Set &W, double d, uint32_t id, int lane)
  * `evals` counts distance evaluations.  A node's neighbour list is read one slot per lane, the unvisited ones are
  * scored four rows at a time and offered to the set.
  */
+template <bool W16 = false>
 __device__ __forceinline__ void
 h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int level, H2Set &W, H2Visited &V, int lane,
 				long long &evals)
@@ -572,7 +664,6 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 		H2_PH(1);
 		while (todo)
 		{
-			const float *x[H2_NR];
 			uint32_t	ids[H2_NR];
 			double		d[H2_NR];
 			int			n = 0;
@@ -581,18 +672,16 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 			for (int u = 0; u < H2_NR; u++)
 			{
 				ids[u] = 0;
-				x[u] = g.vecs;
 				if (todo)
 				{
 					const int	l = __builtin_ctzll(todo);
 
 					todo &= todo - 1;
 					ids[u] = (uint32_t) __builtin_amdgcn_readlane((int) e, l);
-					x[u] = g.vecs + (size_t) ids[u] * g.dim;
 					n = u + 1;
 				}
 			}
-			h2_dist2x4(Q, x, n, lane, d);
+			h2_ids_d2<W16>(g, Q, ids, n, lane, d);
 			evals += n;
 			H2_PH(2);
 			for (int u = 0; u < n; u++)
@@ -605,6 +694,7 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 }
 
 /* greedy step of the upper layers: from (cur, curd) move to the nearest neighbour at `level` while one is nearer */
+template <bool W16 = false>
 __device__ __forceinline__ void
 h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &curd, int lane, long long &evals)
 {
@@ -619,7 +709,6 @@ h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &
 
 		while (todo)
 		{
-			const float *x[H2_NR];
 			uint32_t	ids[H2_NR];
 			double		d[H2_NR];
 			int			n = 0;
@@ -628,18 +717,16 @@ h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &
 			for (int u = 0; u < H2_NR; u++)
 			{
 				ids[u] = 0;
-				x[u] = g.vecs;
 				if (todo)
 				{
 					const int	l = __builtin_ctzll(todo);
 
 					todo &= todo - 1;
 					ids[u] = (uint32_t) __builtin_amdgcn_readlane((int) e, l);
-					x[u] = g.vecs + (size_t) ids[u] * g.dim;
 					n = u + 1;
 				}
 			}
-			h2_dist2x4(Q, x, n, lane, d);
+			h2_ids_d2<W16>(g, Q, ids, n, lane, d);
 			evals += n;
 			for (int u = 0; u < n; u++)
 				if (h2_less(d[u], ids[u], bd, bid))

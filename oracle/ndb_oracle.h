@@ -224,6 +224,12 @@ int			ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64
 						  int batch_div, int batch_max, int select);
 int			ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
 						   int64_t *evals);
+/* the same search with the walk on fp16 WALK ROWS (the reference's float4_to_fp16 of every element, groups-of-four
+ * summation tree) and the final result set re-scored on the float4 rows: ndb_oracle_hnsw2.c "WALK ROWS" */
+void		ndbo_h2_walk_rows(const float *vecs, int64_t nel, uint16_t *out);
+double		ndbo_h2_dist2_w16(const float *q, const uint16_t *w, int dim);
+int			ndbo_h2_search_w16(const ndbo_hnsw *g, const uint16_t *w16, const float *query, int ef, int k,
+							   uint32_t *out_blocks, float *out_dist, int64_t *evals);
 
 /* level = (int)(-log(r) * ml), clamped [0, 15]: src/index/hnsw_am.c:1143-1161 */
 int			ndbo_hnsw_level_from_uniform(double r, float ml);

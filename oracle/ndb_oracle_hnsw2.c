@@ -64,6 +64,55 @@ h2_vec(const ndbo_hnsw *g, uint32_t b)
 	return g->vecs + (size_t) b * g->dim;
 }
 
+/*
+ * WALK ROWS (round 5; SURVEY 8f-4: fp16 node storage).  A walk is bound by the bytes of the rows it fetches at random;
+ * it can run on what a halfvec column of the same rows would hold — every element through the reference's own
+ * float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal results flushed to signed zero)
+ * and back through fp16_to_float (:170-218) — as long as the rows it RETURNS are ordered by the definition's distance
+ * to the float4 rows: ndbo_h2_search_w16 walks on the halves and re-scores the ef entries of the final result set.
+ * Arithmetic on the halves (again one definition for host and device): the squared L2 distance in fp64, every term
+ * (double) fl32(q_i - w_i) squared, summed by a fixed tree whose 64 partial sums take the elements in GROUPS OF FOUR —
+ * element i goes to partial (i / 4) mod 64, in increasing i — folded by the same butterfly: what a 64-lane wave computes
+ * when every lane loads 8 bytes (four halves) of the row per request.
+ */
+void
+ndbo_h2_walk_rows(const float *vecs, int64_t nel, uint16_t *out)
+{
+	int64_t		i;
+
+	for (i = 0; i < nel; i++)
+		out[i] = ndbo_float4_to_fp16(vecs[i]);
+}
+
+double
+ndbo_h2_dist2_w16(const float *q, const uint16_t *w, int dim)
+{
+	double		p[64];
+	int			i,
+				off;
+
+	for (i = 0; i < 64; i++)
+		p[i] = 0.0;
+	for (i = 0; i < dim; i++)
+	{
+		const float d = q[i] - ndbo_fp16_to_float(w[i]);
+		const double dd = (double) d;
+
+		p[(i >> 2) & 63] += dd * dd;
+	}
+	for (off = 32; off > 0; off >>= 1)
+		for (i = 0; i < off; i++)
+			p[i] = p[i] + p[i + off];
+	return p[0];
+}
+
+/* d2(q, node e) as a walk sees it: on the walk rows when there are any, else the definition's */
+static inline double
+h2_walk_d2(const ndbo_hnsw *g, const uint16_t *w16, const float *q, uint32_t e)
+{
+	return w16 ? ndbo_h2_dist2_w16(q, w16 + (size_t) e * g->dim, g->dim) : ndbo_h2_dist2(q, h2_vec(g, e), g->dim);
+}
+
 static inline uint32_t *
 h2_nbrs(const ndbo_hnsw *g, uint32_t b, int level)
 {
@@ -89,9 +138,9 @@ h2_less(double d2, uint32_t id, double e2, uint32_t jd)
  * The candidate set is the result set's unexpanded part: an element pushed out of the results is farther than
  * everything left in them, so the textbook loop would stop before expanding it.
  */
-int
-ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
-					 int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited)
+static int
+h2_search_layer_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
+				  int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited)
 {
 	uint32_t   *wid = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) (ef + 1));
 	double	   *wd = (double *) malloc(sizeof(double) * (size_t) (ef + 1));
@@ -140,7 +189,7 @@ ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, con
 			if (e == NDBO_INVALID_BLOCK || e >= g->nblocks || visited[e])
 				continue;
 			H2_MARK(e);
-			d = ndbo_h2_dist2(q, h2_vec(g, e), g->dim);
+			d = h2_walk_d2(g, w16, q, e);
 			if (evals)
 				(*evals)++;
 			if (nw < ef)
@@ -188,9 +237,16 @@ ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, con
 #undef H2_MARK
 }
 
+int
+ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
+					 int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited)
+{
+	return h2_search_layer_w(g, NULL, q, ep, epd, nep, ef, level, out_ids, out_d2, evals, visited);
+}
+
 /* greedy step of the upper layers: from `cur`, move to the nearest neighbour at `level` while one is nearer */
 static void
-h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
+h2_greedy_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
 {
 	for (;;)
 	{
@@ -207,7 +263,7 @@ h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *
 
 			if (e == NDBO_INVALID_BLOCK || e >= g->nblocks)
 				continue;
-			d = ndbo_h2_dist2(q, h2_vec(g, e), g->dim);
+			d = h2_walk_d2(g, w16, q, e);
 			if (evals)
 				(*evals)++;
 			if (h2_less(d, e, bd, bid))
@@ -223,11 +279,20 @@ h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *
 	}
 }
 
+static void
+h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
+{
+	h2_greedy_w(g, NULL, q, level, cur, curd, evals);
+}
+
 /* kNN query: greedy descent to level 1, best-first search with ef at level 0, the k nearest ascending.  Distances
- * come back as (float) sqrt(d2).  Returns the count. */
-int
-ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
-			   int64_t *evals)
+ * come back as (float) sqrt(d2).  Returns the count.
+ * w16 != NULL (ndbo_h2_search_w16): descent and layer search on the walk rows; the result set's (at most ef) entries
+ * are then scored against the float4 rows with the definition's arithmetic (ndbo_h2_dist2), ordered by that
+ * (d2, block), and the k nearest returned with THOSE distances — an evaluation each, counted. */
+static int
+h2_search_w(const ndbo_hnsw *g, const uint16_t *w16, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
+			int64_t *evals)
 {
 	uint8_t    *visited;
 	uint32_t   *ids;
@@ -243,15 +308,38 @@ ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *
 	if (ef < k)
 		ef = k;
 	cur = g->entry_point;
-	curd = ndbo_h2_dist2(query, h2_vec(g, cur), g->dim);
+	curd = h2_walk_d2(g, w16, query, cur);
 	if (evals)
 		(*evals)++;
 	for (lc = g->entry_level; lc >= 1; lc--)
-		h2_greedy(g, query, lc, &cur, &curd, evals);
+		h2_greedy_w(g, w16, query, lc, &cur, &curd, evals);
 	visited = (uint8_t *) calloc(g->nblocks, 1);
 	ids = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) ef);
 	d2 = (double *) malloc(sizeof(double) * (size_t) ef);
-	n = ndbo_h2_search_layer(g, query, &cur, &curd, 1, ef, 0, ids, d2, evals, visited);
+	n = h2_search_layer_w(g, w16, query, &cur, &curd, 1, ef, 0, ids, d2, evals, visited);
+	if (w16)
+	{
+		/* re-score on the float4 rows, then ascending (d2, id) again (insertion sort) */
+		for (i = 0; i < n; i++)
+			d2[i] = ndbo_h2_dist2(query, h2_vec(g, ids[i]), g->dim);
+		if (evals)
+			*evals += n;
+		for (i = 1; i < n; i++)
+		{
+			const uint32_t id = ids[i];
+			const double d = d2[i];
+			int			j = i;
+
+			while (j > 0 && h2_less(d, id, d2[j - 1], ids[j - 1]))
+			{
+				d2[j] = d2[j - 1];
+				ids[j] = ids[j - 1];
+				j--;
+			}
+			d2[j] = d;
+			ids[j] = id;
+		}
+	}
 	if (n > k)
 		n = k;
 	for (i = 0; i < n; i++)
@@ -263,6 +351,23 @@ ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *
 	free(ids);
 	free(d2);
 	return n;
+}
+
+int
+ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
+			   int64_t *evals)
+{
+	return h2_search_w(g, NULL, query, ef, k, out_blocks, out_dist, evals);
+}
+
+/* w16: [nblocks][dim] walk rows of g's vectors (ndbo_h2_walk_rows over g->vecs) */
+int
+ndbo_h2_search_w16(const ndbo_hnsw *g, const uint16_t *w16, const float *query, int ef, int k, uint32_t *out_blocks,
+				   float *out_dist, int64_t *evals)
+{
+	if (!w16)
+		return -1;
+	return h2_search_w(g, w16, query, ef, k, out_blocks, out_dist, evals);
 }
 
 /* what the search phase of one insert leaves: per level lc <= min(level, entry level at that time) the selected

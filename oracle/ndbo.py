@@ -111,6 +111,9 @@ def lib(native: bool = False):
         "ndbo_h2_dist2": (C.c_double, [f32p, f32p, i]),
         "ndbo_h2_build": (i, [C.POINTER(NdboHnsw), f32p, C.c_void_p, C.c_int64, i32p, i, i, i]),
         "ndbo_h2_search": (i, [C.POINTER(NdboHnsw), f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
+        "ndbo_h2_walk_rows": (None, [f32p, C.c_int64, u16p]),
+        "ndbo_h2_dist2_w16": (C.c_double, [f32p, u16p, i]),
+        "ndbo_h2_search_w16": (i, [C.POINTER(NdboHnsw), u16p, f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
         "ndbo_mt_spread_copy": (C.c_void_p, [C.c_void_p, C.c_size_t, i]),
         "ndbo_mt_ivf_search_batch": (C.c_double, [C.POINTER(NdboIvf), f32p, i, i, i, i, C.c_int64, i, C.c_void_p, f32p,
                                                   i32p, C.POINTER(C.c_int64)]),
@@ -321,6 +324,23 @@ class HnswGraph:
         od = np.zeros(max(k, 1), dtype=np.float32)
         ns = C.c_int64(0)
         n = self.L.ndbo_h2_search(self.g, _f32(query), ef, k, ob, od, C.byref(ns))
+        return ob[:n], od[:n], ns.value
+
+    def walk_rows(self):
+        """ndbo_h2_walk_rows over the graph's vectors: [nblocks, dim] uint16 (the reference's float4_to_fp16 of every element)"""
+        nb, dim = int(self.g.contents.nblocks), int(self.g.contents.dim)
+        v = np.ctypeslib.as_array(self.g.contents.vecs, shape=(nb * dim,))
+        out = np.zeros(nb * dim, dtype=np.uint16)
+        self.L.ndbo_h2_walk_rows(np.ascontiguousarray(v, dtype=np.float32), nb * dim, out)
+        return out.reshape(nb, dim)
+
+    def search_intended_w16(self, w16, query, ef=64, k=10):
+        """ndbo_h2_search_w16: walk on the fp16 walk rows, the final result set re-scored on the float4 rows"""
+        ob = np.zeros(max(k, 1), dtype=np.uint32)
+        od = np.zeros(max(k, 1), dtype=np.float32)
+        ns = C.c_int64(0)
+        w = np.ascontiguousarray(w16, dtype=np.uint16)
+        n = self.L.ndbo_h2_search_w16(self.g, w.reshape(-1), _f32(query), ef, k, ob, od, C.byref(ns))
         return ob[:n], od[:n], ns.value
 
     def search(self, query, strategy=1, ef=64, k=10):

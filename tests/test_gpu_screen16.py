@@ -112,6 +112,57 @@ def test_a_nan_row_only_affects_the_queries_that_probe_it(lib):
     ix.close()
 
 
+@pytest.mark.parametrize("strategy", [1, 3])
+def test_rows_whose_norm_overflows_go_to_the_reference_arithmetic_and_equal_the_oracle(strategy, lib):
+    """vector_in rejects NaN and Inf (/root/reference/NeuronDB/src/core/neurondb.c:396,427) but not 1e20: a finite row
+    whose sum of squares overflows float4.  Its L2 distance is +inf for every query (ivf_am.c:1562-1568: sum += diff*diff
+    overflows, sqrtf(inf)) — it orders after every finite candidate and is returned when a query has fewer than k of
+    those; its inner product is finite and huge — it is the FIRST or the LAST neighbour of every query that probes its
+    list.  The screens cannot bound such a row (its plane norm is not finite): it must be handed to the reference's
+    arithmetic and the results must be the oracle's for EVERY query, in every scan mode."""
+    a = make_ivf_arrays(6000, 64, 12, seed=177)
+    rng = np.random.default_rng(178)
+    nq, nprobe, k = 160, 3, 10
+    q = (a["base"][rng.integers(0, 6000, nq)] + 0.01 * rng.standard_normal((nq, 64))).astype(np.float32)
+    probes = np.stack([oracle_image(a).select_clusters(qq, nprobe) for qq in q])
+    counts = np.bincount(probes.ravel(), minlength=12)
+    busiest = int(np.argmax(counts))
+    off = np.concatenate([[0], np.cumsum(a["list_len"])])
+    rows = a["rows"].copy()
+    rows[off[busiest] + 4, 5] = np.float32(1e20)
+    rows[off[busiest] + 9, :] = np.float32(-3e19)
+    b = dict(a, rows=rows)
+    img = oracle_image(b)
+    et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k)
+    hit = (probes == busiest).any(1)
+    assert hit.sum() >= 30
+    if strategy == 3:
+        big = np.abs(ed) > 1e18
+        assert big[hit].any(), "the overflowing rows must show up among the inner-product neighbours"
+    ix = _index(b)
+    for mode in (5, 3, 2, 1, 0):
+        lib.check(lib.lib().ndbhip_set_scan_mode(mode))
+        t, d, c = ix.search(q, strategy, nprobe, k)
+        assert_same_results(t, d, c, et, ed, ec)
+    # every probed row a candidate (k beyond the lists' lengths): the +inf distances are part of the answer
+    kk = 64
+    small = dict(b)
+    lens = np.asarray(b["list_len"]).copy()
+    keep = np.concatenate([np.arange(off[L], off[L] + min(int(lens[L]), 15)) for L in range(12)])
+    small["rows"], small["tids"] = b["rows"][keep], b["tids"][keep]
+    small["list_len"] = np.minimum(lens, 15)
+    et, ed, ec, _ = oracle_search_batch(oracle_image(small), q, strategy, nprobe, kk)
+    if strategy == 1:
+        assert np.isinf(ed[hit]).any()
+    ix2 = _index(small)
+    for mode in (5, 0):
+        lib.check(lib.lib().ndbhip_set_scan_mode(mode))
+        t, d, c = ix2.search(q, strategy, nprobe, kk)
+        assert_same_results(t, d, c, et, ed, ec)
+    ix.close()
+    ix2.close()
+
+
 @pytest.mark.parametrize("centered", [0, 1])
 def test_overflowing_queries_fall_back_and_stay_exact(lib, centered):
     """centered = 0 (the two-plane sweep over the rows as they are): rows 300 from the origin and 0.01 apart —
