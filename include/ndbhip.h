@@ -569,6 +569,16 @@ int			ndbhip_hnsw_build_intended_device(ndbhip_hnsw *g, const float *d_rows, con
 int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
 											   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 											   uint64_t *d_out_tids, int64_t *d_out_evals);
+/* The same search with the walk on fp16 WALK ROWS (round 5; SURVEY 8f-4, src/index/hnsw_am.c:1436-1451 reads halfvec node
+ * vectors): every element of the graph's rows through the reference's float4_to_fp16 (src/types/quantization.c:141-168) —
+ * what a halfvec column of the same data holds; the twin is made on the device at the first call and again after rows were
+ * appended (+ 0.5 x the rows' bytes).  Descent and layer search run on the halves (half the bytes per evaluated row); the
+ * result set's ef entries are then scored against the float4 rows with the definition's arithmetic, ordered by that, and
+ * the k nearest returned with those distances: oracle/ndb_oracle_hnsw2.c ndbo_h2_search_w16, equal id for id and bit for
+ * bit.  dim % 4 == 0 and dim <= 1024, else NDBHIP_ERR_UNSUPPORTED (use the float4 walk). */
+int			ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
+												   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
+												   uint64_t *d_out_tids, int64_t *d_out_evals);
 /* bit 0: the heuristic (else the nearest); bit 1: a new node takes up to 2m links at level 0 instead of m; bit 2 (with
  * bit 0): the places the heuristic leaves empty go to the nearest candidates it passed over (keepPrunedConnections). */
 int			ndbhip_hnsw_set_intended_select(int select);

@@ -2239,6 +2239,8 @@ struct ndbhip_hnsw
 	uint32_t	entry_point = NDBHIP_INVALID_BLOCK;
 	int			entry_level = -1;
 	float	   *d_vecs = nullptr;
+	uint16_t   *d_vecs16 = nullptr;		/* walk rows of the intended search (made on first use, ndbhip_hnsw2.h) */
+	uint32_t	w16_blocks = 0;			/* blocks they cover: fewer than nblocks = stale (rows were appended) */
 	int		   *d_levels = nullptr;
 	int16_t    *d_ncount = nullptr;
 	int64_t    *d_nbr_off = nullptr;
@@ -2287,6 +2289,9 @@ hnsw_free_dev(ndbhip_hnsw *h)
 
 	for (void *p : ptrs)
 		if (p) (void) hipFree(p);
+	if (h->d_vecs16) (void) hipFree(h->d_vecs16);
+	h->d_vecs16 = nullptr;
+	h->w16_blocks = 0;
 	h->d_dead = nullptr;
 	h->cap_blocks = 0;
 	h->d_vecs = nullptr; h->d_levels = nullptr; h->d_ncount = nullptr;
@@ -3343,6 +3348,7 @@ h2_graph(const ndbhip_hnsw *h, uint32_t nvisible)
 	H2Graph		gr;
 
 	gr.vecs = h->d_vecs;
+	gr.vecs16 = h->d_vecs16;
 	gr.levels = h->d_levels;
 	gr.ncount = h->d_ncount;
 	gr.nbrs = h->d_nbrs;
@@ -3569,9 +3575,9 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 /* kNN search of the `intended` mode on a dense mirror (built by ndbhip_hnsw_build_intended_device, or any graph):
  * greedy descent, best-first layer search with ef at level 0, the k nearest ascending; distances (float) sqrt(d2)
  * (L2 whatever the operator class: on unit-norm rows the order is the cosine order).  Device pointers, asynchronous. */
-extern "C" int
-ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
-								   float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
+static int
+h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+			  float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!h || !h->loaded)
@@ -3586,6 +3592,23 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
 
 	if (rc)
 		return rc;
+	if (w16)
+	{
+		if (h->dim % 4 != 0 || h->dim > 64 * H2_QREG)
+			return fail(NDBHIP_ERR_UNSUPPORTED, "walk rows need dim %% 4 == 0 and dim <= %d (dim = %d)", 64 * H2_QREG, h->dim);
+		if (!h->d_vecs16 || h->w16_blocks != h->nblocks)
+		{
+			/* (rows are only ever appended: a twin that covers fewer blocks than the graph is stale as a whole — made again) */
+			const size_t nel = (size_t) h->nblocks * h->dim;
+
+			if (h->d_vecs16) { HIP_TRY(hipStreamSynchronize(g.stream)); HIP_TRY(hipFree(h->d_vecs16)); h->d_vecs16 = nullptr; }
+			HIP_TRY(hipMalloc((void **) &h->d_vecs16, nel * sizeof(uint16_t)));
+			hipLaunchKernelGGL(k_h2_walk_rows, dim3((unsigned) std::min<size_t>((nel + 255) / 256, (size_t) 1 << 20)), dim3(256), 0, g.stream,
+							   (const float *) h->d_vecs, h->d_vecs16, nel);
+			HIP_TRY(hipGetLastError());
+			h->w16_blocks = h->nblocks;
+		}
+	}
 	const uint32_t efe = (uint32_t) std::max(ef, k);
 	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * g_h2_waves, nq);
 	uint32_t	nwords = 0;
@@ -3596,12 +3619,43 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
 	uint32_t   *d_next = h->w_vlog + (size_t) nwaves * H2_LOG_CAP;
 
 	HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
-	HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
-	hipLaunchKernelGGL(k_h2_search, dim3(nwaves), dim3(64), smem, g.stream, h2_graph(h, h->nblocks), d_queries, (uint32_t) nq, efe,
-					   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
-					   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next);
+	H2Graph		gr = h2_graph(h, h->nblocks);
+
+	if (w16)
+	{
+		HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+		hipLaunchKernelGGL(k_h2_search<true>, dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe,
+						   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
+						   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next);
+	}
+	else
+	{
+		HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+		hipLaunchKernelGGL(k_h2_search<false>, dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe,
+						   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
+						   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next);
+	}
 	HIP_TRY(hipGetLastError());
 	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+								   float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
+{
+	return h2_search_run(h, false, d_queries, nq, ef, k, d_out_blocks, d_out_dist, d_out_count, d_out_tids, d_out_evals);
+}
+
+/* The same search with the WALK on fp16 walk rows — every element of the graph's rows through the reference's own
+ * float4_to_fp16 (src/types/quantization.c:141-168), what a halfvec column of the same data holds; made on the device at
+ * the first call and again after rows were appended (+ 0.5 x the rows' bytes) — and the result set's ef entries scored
+ * against the float4 rows with the definition's arithmetic: oracle/ndb_oracle_hnsw2.c ndbo_h2_search_w16, equal id for id
+ * and bit for bit.  A walk fetches half the bytes per evaluated row. */
+extern "C" int
+ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *h, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+									   float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
+{
+	return h2_search_run(h, true, d_queries, nq, ef, k, d_out_blocks, d_out_dist, d_out_count, d_out_tids, d_out_evals);
 }
 
 extern "C" int

@@ -840,6 +840,21 @@ h2_select(const H2Graph &g, const uint32_t *cid, const double *cd, int nc, int M
 	return n;
 }
 
+/* walk rows of rows [first, first + n) x dim: the reference's float4_to_fp16 (src/types/quantization.c:141-168: mantissa
+ * truncated, subnormal results flushed to signed zero, overflow and NaN -> infinity) */
+__global__ __launch_bounds__(256) void
+k_h2_walk_rows(const float *__restrict__ src, uint16_t *__restrict__ dst, size_t nel)
+{
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < nel; i += (size_t) gridDim.x * 256)
+	{
+		const uint32_t u = __float_as_uint(src[i]);
+		const uint16_t sign = (uint16_t) ((u >> 16) & 0x8000u);
+		const int	e = (int) ((u >> 23) & 0xffu) - 127 + 15;
+
+		dst[i] = e <= 0 ? sign : (e >= 31 ? (uint16_t) (sign | 0x7c00u) : (uint16_t) (sign | ((uint32_t) e << 10) | ((u & 0x7fffffu) >> 13)));
+	}
+}
+
 __host__ __device__ static inline size_t
 h2_smem_bytes(uint32_t ef, bool table = true /* with the LDS visited table (the search; the build's walks outgrow it at once,
 											   * and its 8 KB a wave would cost the build a third of its walkers) */ )
@@ -848,7 +863,10 @@ h2_smem_bytes(uint32_t ef, bool table = true /* with the LDS visited table (the 
 }
 
 /* kNN queries: greedy descent to level 1, layer search with ef at level 0, the k nearest ascending, distances as
- * (float) sqrt(d2).  Persistent grid of one-wave blocks; block b owns visited map b. */
+ * (float) sqrt(d2).  Persistent grid of one-wave blocks; block b owns visited map b.
+ * W16 (ndbo_h2_search_w16): descent and layer search on the fp16 walk rows (g.vecs16), then the result set's entries
+ * scored against the float4 rows with the definition's arithmetic and ordered by that. */
+template <bool W16>
 __global__ __launch_bounds__(64) void
 k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level,
 			const uint64_t *__restrict__ tids, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords,
@@ -894,18 +912,56 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 		long long	evals = 0;
 		uint32_t	n = 0;
 
-		Q.load(queries + (size_t) q * g.dim, g.dim, lane);
+		if (W16)
+			Q.load16(queries + (size_t) q * g.dim, g.dim, lane);
+		else
+			Q.load(queries + (size_t) q * g.dim, g.dim, lane);
 		if (entry != NDBHIP_INVALID_BLOCK)
 		{
 			uint32_t	cur = entry;
-			double		curd = h2_dist2(Q, g.vecs + (size_t) cur * g.dim, lane);
+			double		curd;
 
+			if (W16)
+			{
+				uint32_t	ids[H2_NR];
+				double		d[H2_NR];
+
+#pragma unroll
+				for (int u = 0; u < H2_NR; u++)
+					ids[u] = u == 0 ? cur : 0u;
+				h2_ids_d2<true>(g, Q, ids, 1, lane, d);
+				curd = d[0];
+			}
+			else
+				curd = h2_dist2(Q, g.vecs + (size_t) cur * g.dim, lane);
 			evals = 1;
 			for (int lc = entry_level; lc >= 1; lc--)
-				h2_greedy(g, Q, lc, cur, curd, lane, evals);
-			h2_search_layer(g, Q, cur, curd, 0, W, V, lane, evals);
+				h2_greedy<W16>(g, Q, lc, cur, curd, lane, evals);
+			h2_search_layer<W16>(g, Q, cur, curd, 0, W, V, lane, evals);
 			V.clear(lane);			/* (the LDS table, or — after a migration — the bitmap) */
 			V.hv = hv_lds;
+			if (W16)
+			{
+				/* the result set against the float4 rows, H2_NR at a time (one evaluation each, counted) */
+				Q.load(queries + (size_t) q * g.dim, g.dim, lane);
+				for (uint32_t i0 = 0; i0 < W.nw; i0 += H2_NR)
+				{
+					uint32_t	ids[H2_NR];
+					double		d[H2_NR];
+					const int	n2 = (int) min((uint32_t) H2_NR, W.nw - i0);
+
+#pragma unroll
+					for (int u = 0; u < H2_NR; u++)
+						ids[u] = u < n2 ? W.wid[i0 + u] : 0u;
+					h2_ids_d2<false>(g, Q, ids, n2, lane, d);
+#pragma unroll
+					for (int u = 0; u < H2_NR; u++)
+						if (lane == u && u < n2)
+							W.wd[i0 + u] = d[u];
+				}
+				evals += W.nw;
+				__threadfence_block();
+			}
 			h2_sort(W, sid, sd, lane);
 			n = min(W.nw, k);
 			for (uint32_t i = lane; i < n; i += 64)

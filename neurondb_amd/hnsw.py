@@ -92,8 +92,10 @@ class HnswIndex:
         check(lib().ndbhip_synchronize())
         self.nblocks = len(lv) + 1
 
-    def search_intended(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K):
-        """kNN of the `intended` mode: (blocks [nq, k], dist [nq, k] = sqrt of the squared L2, count [nq], evaluations [nq])"""
+    def search_intended(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K, walk16=False):
+        """kNN of the `intended` mode: (blocks [nq, k], dist [nq, k] = sqrt of the squared L2, count [nq], evaluations [nq]).
+        walk16: descent and layer search on fp16 walk rows, the result set re-scored on the float4 rows
+        (ndbhip_hnsw_search_intended_w16_device)"""
         import torch
         q = queries if isinstance(queries, torch.Tensor) else \
             torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)).cuda()
@@ -102,9 +104,9 @@ class HnswIndex:
         od = torch.zeros((nq, k), dtype=torch.float32, device=q.device)
         oc = torch.zeros(nq, dtype=torch.int32, device=q.device)
         oe = torch.zeros(nq, dtype=torch.int64, device=q.device)
-        check(lib().ndbhip_hnsw_search_intended_device(self._h, C.c_void_p(q.data_ptr()), nq, int(ef), int(k),
-                                                       C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
-                                                       C.c_void_p(oc.data_ptr()), None, C.c_void_p(oe.data_ptr())))
+        fn = lib().ndbhip_hnsw_search_intended_w16_device if walk16 else lib().ndbhip_hnsw_search_intended_device
+        check(fn(self._h, C.c_void_p(q.data_ptr()), nq, int(ef), int(k), C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
+                 C.c_void_p(oc.data_ptr()), None, C.c_void_p(oe.data_ptr())))
         check(lib().ndbhip_synchronize())
         return ob.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy(), oe.cpu().numpy()
 

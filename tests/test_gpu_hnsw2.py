@@ -22,6 +22,10 @@ def _data(kind, n, dim, nq, seed):
     elif kind == "integer":
         base = rng.integers(-2, 3, size=(n, dim)).astype(np.float32)             # equal distances everywhere
         q = rng.integers(-2, 3, size=(nq, dim)).astype(np.float32)
+    elif kind == "offset":
+        # values around 100, where halves are 1/16 apart: the fp16 image of a row is a different point
+        base = (100.0 + 0.1 * rng.standard_normal((n, dim))).astype(np.float32)
+        q = (100.0 + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
     else:
         base = rng.standard_normal((n, dim)).astype(np.float32)
         q = rng.standard_normal((nq, dim)).astype(np.float32)
@@ -66,6 +70,40 @@ def test_intended_build_and_search_equal_the_oracle(kind, n, dim, m, efc, bdiv, 
     ix.close()
 
 
+@pytest.mark.parametrize("kind,n,dim,m,efc", [("clustered", 3000, 96, 8, 64), ("normal", 2500, 768, 16, 100), ("clustered", 4000, 128, 16, 200),
+                                              ("normal", 1500, 1024, 8, 40), ("clustered", 2000, 20, 4, 32), ("offset", 2500, 64, 8, 48)])
+def test_walk_on_fp16_rows_rescored_on_float4_equals_the_oracle(kind, n, dim, m, efc):
+    """ndbhip_hnsw_search_intended_w16_device == ndbo_h2_search_w16 (oracle/ndb_oracle_hnsw2.c "WALK ROWS"): descent and
+    layer search on the reference's float4_to_fp16 image of the rows (src/types/quantization.c:141-168; what
+    hnsw_am.c:1436-1451 would read from a halfvec column), groups-of-four summation tree, the result set re-scored on the
+    float4 rows — same blocks, same float4 distance bits, same evaluation counts; rows with values the encoder flushes
+    (below 2^-14) or saturates (beyond 65504) included; the twin follows appended rows."""
+    from neurondb_amd import HnswIndex, _lib
+    from oracle import ndbo
+    base, q, levels = _data(kind, n, dim, 40, seed=3 * n + dim)
+    base[5, :4] = np.float32(3e-6)          # flushed to zero by the encoder
+    base[9, 1] = np.float32(1e5)            # beyond the halves' range: +inf on the walk rows, finite on the float4 rows
+    base[11] = base[10]                     # equal rows: ties broken by block number on both sides
+    og = ndbo.HnswGraph(dim, m, efc, cap_nodes=n + 1)
+    og.build_intended(base, levels, batch_div=16, batch_max=512, select=1)
+    w16 = og.walk_rows()
+    _lib.ensure_init()
+    ix = HnswIndex(dim, m)
+    ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, efc, batch_div=16, batch_max=512)
+    differs = 0
+    for ef, k in ((64, 10), (8, 8), (200, 37), (1, 1), (63, 10), (65, 10)):
+        ob, od, oc, oe = ix.search_intended(q, ef, k, walk16=True)
+        pb, pd, pc, pe = ix.search_intended(q, ef, k)
+        for i in range(len(q)):
+            eb, ed, ns = og.search_intended_w16(w16, q[i], ef, k)
+            assert oc[i] == len(eb) and np.array_equal(ob[i, :oc[i]], eb), (ef, i, ob[i], eb)
+            assert np.array_equal(od[i, :oc[i]].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns, (ef, i, oe[i], ns)
+            differs += int(oe[i] - max(ef, k) != pe[i] or not np.array_equal(ob[i], pb[i]))
+    # where the halves are coarse the two walks are different walks (else this test could not tell them apart)
+    assert differs > 0 or kind != "offset"
+    ix.close()
+
+
 @pytest.mark.parametrize("kind", ["normal", "clustered"])
 def test_intended_graph_finds_the_neighbours(kind):
     """recall@10 against a float64 brute force at ef_search = 64 (m = 16, ef_construction = 200)"""
@@ -80,6 +118,11 @@ def test_intended_graph_finds_the_neighbours(kind):
     gt = np.argsort(d2, axis=1, kind="stable")[:, :10] + 1
     recall = np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nq)])
     assert recall >= (0.95 if kind == "clustered" else 0.7), recall
+    # the walk on fp16 rows loses next to nothing (the returned distances are the float4 rows' either way)
+    wb, wd, wc, we = ix.search_intended(q, 64, 10, walk16=True)
+    recall16 = np.mean([len(set(wb[i, :wc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nq)])
+    assert recall16 >= recall - 0.01, (recall, recall16)
+    assert np.allclose(wd[3, :wc[3]], np.sqrt(d2[3, wb[3, :wc[3]].astype(np.int64) - 1]), rtol=1e-6)
     # the distances are the L2 distances of the blocks returned
     i = 3
     ex = np.sqrt(d2[i, ob[i, :oc[i]].astype(np.int64) - 1])

@@ -65,6 +65,16 @@ def main():
         rec = float(np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nr)]))
         print(f"search ef={ef}: {nq / ts:.0f} queries/s ({ts * 1e3:.1f} ms per {nq}), recall@10 {rec:.3f}, "
               f"{oe.mean():.0f} evaluations/query")
+        if dim % 4 == 0 and dim <= 1024:
+            # the same with the walk on fp16 walk rows (ndbhip_hnsw_search_intended_w16_device)
+            ix.search_intended(q[:256], ef, 10, walk16=True)
+            t0 = time.perf_counter()
+            wb, wd, wc, we = ix.search_intended(q, ef, 10, walk16=True)
+            tw = time.perf_counter() - t0
+            rec = float(np.mean([len(set(wb[i, :wc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nr)]))
+            same = float(np.mean([np.array_equal(wb[i], ob[i]) for i in range(nq)]))
+            print(f"   walk on fp16 rows: {nq / tw:.0f} queries/s ({tw * 1e3:.1f} ms per {nq}), recall@10 {rec:.3f}, "
+                  f"{we.mean():.0f} evaluations/query (the re-score's {ef} included), {same:.3f} of the queries return the float4 walk's blocks")
         check(lib().ndbhip_debug_h2_phases(ph))
         if ph[4]:
             # a profiling build (make EXTRA=-DNDB_PHASES): block 0's wave, microseconds per expansion
