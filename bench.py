@@ -1420,13 +1420,13 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         x = make_data(rows, dim, kind, args.components, args.sigma, seed, 0x5EEDC0DE, dev)
         return x / x.norm(dim=1, keepdim=True)
 
-    def recall_of(ix, base, q, efs, nr=1000):    # (200 queries put the same graph anywhere in 0.88 .. 0.92: profiles/r03_h2_variants.txt)
+    def recall_of(ix, base, q, efs, nr=1000, w16=False):    # (200 queries put the same graph anywhere in 0.88 .. 0.92: profiles/r03_h2_variants.txt)
         nr = min(nr, len(q))
         sims = q[:nr].double() @ base.double().T
         gt = torch.topk(sims, k, dim=1).indices.cpu().numpy() + 1
         out = {}
         for e in efs:
-            ob, od, oc, oe = ix.search_intended(q[:max(nr, 256)], e, k)
+            ob, od, oc, oe = ix.search_intended(q[:max(nr, 256)], e, k, walk16=w16)
             out[e] = round(float(np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / k for i in range(nr)])), 4)
         return out
 
@@ -1441,28 +1441,61 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         ix.build_intended(base, torch.arange(n, device=dev, dtype=torch.int64), levels, efc)
         tb = time.perf_counter() - t0
         sched = ix.build_stats()
-        ix.search_intended(q[:512], ef, k)
+        walk16 = dim % 4 == 0 and dim <= 1024       # the walk on fp16 walk rows (ndbhip_hnsw_search_intended_w16_device)
         reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            ob, od, oc, oe = ix.search_intended(q, ef, k)
-        ts = (time.perf_counter() - t0) / reps
+
+        def timed(qq, w16):
+            ix.search_intended(qq[:512], ef, k, walk16=w16)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = ix.search_intended(qq, ef, k, walk16=w16)
+            return (time.perf_counter() - t0) / reps, r
+
+        ts32, (pb, pd, pc, pe) = timed(q, False)
+        if walk16:
+            ts, (ob, od, oc, oe) = timed(q, True)
+        else:
+            ts, (ob, od, oc, oe) = ts32, (pb, pd, pc, pe)
         evals = float(oe.mean())
-        rec = recall_of(ix, base, q, [ef])[ef]
+        rec = recall_of(ix, base, q, [ef], w16=walk16)[ef]
+        rec32 = recall_of(ix, base, q, [ef])[ef] if walk16 else rec
+        # steady state: four times the queries (a query is 400 .. 2500 evaluations and the device holds 3000 .. 4000 walks at a
+        # time: a batch of 8192 is two or three rounds, as long as its unluckiest walker)
+        big = {}
+        try:
+            qb = table("clustered", 4 * nq, 0x5EED0005)
+            tb32, rb32 = timed(qb, False)
+            big = {"queries": 4 * nq, "float4_walk_queries_per_s": round(4 * nq / tb32, 1)}
+            if walk16:
+                tb16, rb16 = timed(qb, True)
+                big["queries_per_s"] = round(4 * nq / tb16, 1)
+            del qb
+        except Exception as e2:                      # noqa: BLE001
+            big = {"error": f"{type(e2).__name__}: {e2}"}
         # oracle replay on the exported graph
         e = ix.export()
         vecs = np.zeros((n + 1, dim), np.float32)
         vecs[1:] = base.cpu().numpy()
         og = ndbo.HnswGraph.from_arrays(vecs, e["levels"], e["ncount"], e["nbrs"], None, e["entry_point"], e["entry_level"], m, efc)
         del vecs
-        sample, bad = 32, 0
+        sample, bad, bad32 = 32, 0, 0
         qh = q[:max(sample, 1)].cpu().numpy()
+        w16rows = og.walk_rows() if walk16 else None
         t0 = time.perf_counter()
         for i in range(sample):
             eb, ed, ns = og.search_intended(qh[i], ef, k)
-            bad += not (oc[i] == len(eb) and np.array_equal(ob[i, :len(eb)], eb) and
-                        np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns)
+            bad32 += not (pc[i] == len(eb) and np.array_equal(pb[i, :len(eb)], eb) and
+                          np.array_equal(pd[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and pe[i] == ns)
         tc = (time.perf_counter() - t0) / sample
+        if walk16:
+            for i in range(sample):
+                eb, ed, ns = og.search_intended_w16(w16rows, qh[i], ef, k)
+                bad += not (oc[i] == len(eb) and np.array_equal(ob[i, :len(eb)], eb) and
+                            np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns)
+        else:
+            bad = bad32
+        del w16rows
         cores = host_cores()
         ncpu = int(min(nq, max(cores * 4, min(args.cpu_seconds, 10.0) * cores / max(tc, 1e-6)))) if args.cpu_seconds > 0 else 0
         cpu = None
@@ -1476,15 +1509,27 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
                              "graph, one thread per core"}
         del og, e
         ix.close()
-        bytes_q = evals * (4 * dim) + (evals / (2 * m)) * (4 * 2 * m + 2)
+        evals32 = float(pe.mean())
+        lists_b = lambda ev: (ev / (2 * m)) * (4 * 2 * m + 2)                      # noqa: E731
+        bytes32 = evals32 * (4 * dim) + lists_b(evals32)
+        # (walk rows: 2 bytes an element for the walk's evaluations, 4 for the ef re-scored entries)
+        bytes_q = ((evals - ef) * (2 * dim) + ef * (4 * dim) + lists_b(evals - ef)) if walk16 else bytes32
         out = {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k}, cosine order on unit-norm "
                            f"rows, {nq}-query batches (BASELINE config C3), intended mode; table: mixture of {args.components} "
                            f"Gaussians sigma={args.sigma}, normalised",
+               "search": ("walk on fp16 walk rows (the reference's float4_to_fp16 image of the rows), the ef result entries re-scored "
+                          "on the float4 rows: ndbhip_hnsw_search_intended_w16_device == oracle ndbo_h2_search_w16; `float4_walk` = "
+                          "the walk on the float4 rows (ndbhip_hnsw_search_intended_device, what rounds 3-4 reported)") if walk16
+               else "walk on the float4 rows",
                "build_vectors_per_s": round(n / tb, 1), "build_s": round(tb, 2),
                "build_schedule": {"batches": int(sched.get("batches", 0)), "largest_batch": int(sched.get("max_batch", 0))},
                "queries_per_s": round(nq / ts, 1), "ms_per_batch": round(ts * 1e3, 3),
                "evaluations_per_query": round(evals, 1), "recall_at_10": rec,
-               "roofline": h2_roofline(n, dim, m, ef, nq, ts, bytes_q),
+               "float4_walk": {"queries_per_s": round(nq / ts32, 1), "ms_per_batch": round(ts32 * 1e3, 3),
+                               "evaluations_per_query": round(evals32, 1), "recall_at_10": rec32,
+                               "oracle_mismatches": int(bad32), "bytes_per_query": int(bytes32)},
+               "steady_state": big,
+               "roofline": h2_roofline(n, dim, m, ef, nq, ts, bytes_q, "k_h2_search_w16" if walk16 else "k_h2_search"),
                "oracle_parity": {"queries": sample, "mismatches": int(bad),
                                  "checked": "blocks, float4 distance bits, evaluation counts (graph equality: "
                                             "tests/test_gpu_hnsw2.py)"},
@@ -1511,7 +1556,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def h2_roofline(n, dim, m, ef, nq, ts, bytes_q):
+def h2_roofline(n, dim, m, ef, nq, ts, bytes_q, kernel="k_h2_search"):
     """k_h2_search (csrc/ndbhip_hnsw2.h): one wave per query walks the graph best-first; every step is a dependent
     fetch of ~2m rows, so the kernel is bound by HBM latency x the waves in flight, not by bandwidth.  `achieved` =
     algorithmic bytes (distance evaluations counted by the kernel x row bytes + neighbour lists) / batch time; `traffic`
@@ -1520,7 +1565,7 @@ def h2_roofline(n, dim, m, ef, nq, ts, bytes_q):
     tr = src = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         with open(path) as f:
-            e = json.load(f)["kernels"].get("k_h2_search", {}).get("clustered_unit")
+            e = json.load(f)["kernels"].get(kernel, {}).get("clustered_unit")
         if e and (e["workload"]["nvec"], e["workload"]["dim"], e["workload"]["m"], e["workload"]["ef"]) == (n, dim, m, ef):
             tr, src = int(e["traffic_bytes_per_query"]) * nq, "committed PMC pass " + os.path.relpath(path, ROOT)
             break

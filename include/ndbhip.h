@@ -157,6 +157,8 @@ int			ndbhip_set_scan_mode(int mode);
  *   "build_prepare"     0     ndbhip_ivf_build / _build_device end with ndbhip_ivf_prepare(ix, this strategy 1 .. 3): the index leaves the
  *                             build searchable at full speed (0: the first batched scan, or an explicit ndbhip_ivf_prepare, pays for it)
  *   "hnsw_intended_waves" 16  waves per CU walking the intended HNSW (build and search); each owns a visited bitmap of one bit per node
+ *   "hnsw_intended_host_groups" 0  1 = the back-links of an intended build batch are grouped by target on the host (rounds 3-4) instead of on the device
+ *   "hnsw_intended_occ4"   0  the intended search held to 128 registers (four walkers a SIMD): 1 = where that costs no scratch (walk rows, dim <= 768), 2 = everywhere, 0 = nowhere
  *   "screen16_cosine"   1     cosine batches run the matrix-core sweep over NORMALISED planes (rows and queries divided by their
  *                             norms; sublists regrouped in that space); 0: the round-1 fp32 screen
  *   "screen16_cosine_centered" 1  ... as the centred L2 sweep (|q^ - x^|^2 = 2 x cosine distance); 0: as the inner product of

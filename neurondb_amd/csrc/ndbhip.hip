@@ -4605,6 +4605,14 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "hnsw_intended_waves must be 1 .. 32 (waves per CU)");
 		g_h2_waves = value;
 	}
+	else if (!strcmp(name, "hnsw_intended_host_groups"))
+		g_h2_host_groups = value != 0;
+	else if (!strcmp(name, "hnsw_intended_occ4"))
+	{
+		if (value < 0 || value > 2)
+			return fail(NDBHIP_ERR_INVALID, "hnsw_intended_occ4 must be 0 (three walkers a SIMD), 1 (four where that costs no scratch) or 2 (four everywhere)");
+		g_h2_occ4 = value;
+	}
 	else if (!strcmp(name, "hnsw_trace"))
 		g_hnsw_trace = value;
 	else if (!strcmp(name, "hnsw_nofast"))

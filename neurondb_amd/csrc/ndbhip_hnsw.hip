@@ -3303,8 +3303,11 @@ ndbhip_hnsw_search_layer(ndbhip_hnsw *h, const float *queries, int nq, int strat
 /* ================================================================== */
 /* the `intended` HNSW (ndbhip_hnsw2.h; oracle/ndb_oracle_hnsw2.c is its sequential definition)                   */
 /* ================================================================== */
+#include <hipcub/hipcub.hpp>
 #include "ndbhip_hnsw2.h"
 
+int			g_h2_host_groups = 0;	/* option hnsw_intended_host_groups: 1 = a build batch's back-links grouped on the host (rounds 3-4) */
+int			g_h2_occ4 = 0;			/* option hnsw_intended_occ4 (measured: more walkers a SIMD buy nothing) */
 static int	g_h2_select = 1;		/* 1: the heuristic (ndbhip_hnsw_set_intended_select(0): the nearest m) */
 
 /* device temporaries of one call, freed on every way out */
@@ -3432,6 +3435,66 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	if (tmp.alloc(d_sn, lvcap * 4)) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_grp, lvcap * m * sizeof(H2Group))) return NDBHIP_ERR_HIP;
 	if (tmp.alloc(d_req, lvcap * m * sizeof(H2Req))) return NDBHIP_ERR_HIP;
+	/* back-links grouped on the device (ndbhip_hnsw2.h k_h2_bl_*): every member's first selection row for the whole build
+	 * (the schedule and the entry level at every batch follow from the level draws alone), sort and scan scratch */
+	const bool	devgrp = g_h2_host_groups == 0;
+	uint32_t   *d_offall = nullptr, *d_rowmem = nullptr, *d_vals = nullptr, *d_vals2 = nullptr, *d_flags = nullptr, *d_gpos = nullptr,
+			   *d_counts = nullptr;
+	int		   *d_rowlc = nullptr;
+	unsigned long long *d_keys = nullptr, *d_keys2 = nullptr, *d_total = nullptr;
+	void	   *d_cub = nullptr;
+	size_t		cub_bytes = 0;
+	const unsigned long long padkey = ((unsigned long long) nb << 8) | 0xFFull;
+	int			end_bit = 1;
+
+	while (end_bit < 64 && (padkey >> end_bit) != 0)
+		end_bit++;
+	if (devgrp)
+	{
+		const size_t maxitems = lvcap * (size_t) m;
+		size_t		b1 = 0, b2 = 0;
+		std::vector<uint32_t> off_all(n);
+		uint32_t	e = NDBHIP_INVALID_BLOCK, dn = 0;
+		int			el = -1;
+
+		while (dn < n)
+		{
+			uint32_t	b = (uint32_t) std::min<int64_t>(std::max<int64_t>((int64_t) dn / batch_div, 1), batch_max);
+			uint32_t	nlev = 0;
+
+			b = std::min(b, n - dn);
+			for (uint32_t i = 0; i < b; i++)
+			{
+				off_all[dn + i] = nlev;
+				nlev += (uint32_t) std::min(lev[dn + i], std::max(el, 0)) + 1u;
+			}
+			/* (the entry point changes AFTER the batch: its members see the entry of its start) */
+			for (uint32_t i = 0; i < b; i++)
+				if (e == NDBHIP_INVALID_BLOCK || lev[dn + i] > el)
+				{
+					e = dn + 1 + i;
+					el = lev[dn + i];
+				}
+			dn += b;
+		}
+		if (tmp.alloc(d_offall, (size_t) n * 4)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemcpy(d_offall, off_all.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+		if (tmp.alloc(d_rowmem, lvcap * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_rowlc, lvcap * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_keys, maxitems * 8)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_keys2, maxitems * 8)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_vals, maxitems * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_vals2, maxitems * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_flags, maxitems * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_gpos, maxitems * 4)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_counts, 16)) return NDBHIP_ERR_HIP;
+		if (tmp.alloc(d_total, 16)) return NDBHIP_ERR_HIP;
+		HIP_TRY(hipMemsetAsync(d_total, 0, 8, g.stream));
+		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, d_keys, d_keys2, d_vals, d_vals2, (int) maxitems, 0, end_bit, (hipStream_t) g.stream));
+		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, d_flags, d_gpos, (int) maxitems, (hipStream_t) g.stream));
+		cub_bytes = std::max(b1, b2);
+		if (tmp.alloc(d_cub, cub_bytes)) return NDBHIP_ERR_HIP;
+	}
 	std::vector<uint32_t> off(bm), sid;
 	std::vector<double> sd2;
 	std::vector<int> sn;
@@ -3462,12 +3525,39 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 				off[i] = nlev;
 				nlev += (uint32_t) std::min(lev[done + i], entry_level) + 1u;
 			}
-			HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t) b * 4, hipMemcpyHostToDevice, g.stream));
+			const uint32_t *d_off_b = devgrp ? d_offall + done : d_off;
+
+			if (!devgrp)
+				HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t) b * 4, hipMemcpyHostToDevice, g.stream));
 			HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
 			hipLaunchKernelGGL(k_h2_insert_search, dim3(std::min(b, nwaves)), dim3(64), smem, g.stream, h2_graph(h, first), first, b,
-							   (uint32_t) ef_construction, g_h2_select, entry, entry_level, (const uint32_t *) d_off, d_sid, d_sd2,
+							   (uint32_t) ef_construction, g_h2_select, entry, entry_level, d_off_b, d_sid, d_sd2,
 							   d_sn, h->w_vbits, h->w_vlog, nwords, d_next);
 			HIP_TRY(hipGetLastError());
+			if (devgrp)
+			{
+				const uint32_t nitems = nlev * (uint32_t) m;
+				size_t		cb = cub_bytes;
+
+				hipLaunchKernelGGL(k_h2_bl_rows, dim3((b + 255) / 256), dim3(256), 0, g.stream, b, d_off_b, (const int *) h->d_levels + first,
+								   entry_level, d_rowmem, d_rowlc);
+				hipLaunchKernelGGL(k_h2_bl_keys, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, nitems, (uint32_t) m, (const int *) d_sn,
+								   (const uint32_t *) d_sid, (const int *) d_rowlc, padkey, d_keys, d_vals);
+				HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_cub, cb, d_keys, d_keys2, d_vals, d_vals2, (int) nitems, 0, end_bit, (hipStream_t) g.stream));
+				hipLaunchKernelGGL(k_h2_bl_heads, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, nitems, (const unsigned long long *) d_keys2,
+								   padkey, d_flags);
+				cb = cub_bytes;
+				HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_cub, cb, d_flags, d_gpos, (int) nitems, (hipStream_t) g.stream));
+				HIP_TRY(hipMemsetAsync(d_counts, 0, 8, g.stream));
+				hipLaunchKernelGGL(k_h2_bl_groups, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, nitems, (uint32_t) m, first,
+								   (const unsigned long long *) d_keys2, (const uint32_t *) d_vals2, padkey, (const uint32_t *) d_flags,
+								   (const uint32_t *) d_gpos, (const uint32_t *) d_rowmem, (const double *) d_sd2, d_grp, d_req, d_counts, d_total);
+				hipLaunchKernelGGL(k_h2_apply, dim3((unsigned) std::min<size_t>((size_t) nitems, (size_t) g.num_cus * 16)), dim3(64), 0, g.stream,
+								   h2_graph(h, first + b), (const H2Group *) d_grp, 0u, (const uint32_t *) d_counts, (const H2Req *) d_req, g_h2_select);
+				HIP_TRY(hipGetLastError());
+			}
+			else
+			{
 			sid.resize((size_t) nlev * m);
 			sd2.resize((size_t) nlev * m);
 			sn.resize(nlev);
@@ -3545,12 +3635,13 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 				HIP_TRY(hipMemcpyAsync(d_grp, grp.data(), grp.size() * sizeof(H2Group), hipMemcpyHostToDevice, g.stream));
 				HIP_TRY(hipMemcpyAsync(d_req, req.data(), req.size() * sizeof(H2Req), hipMemcpyHostToDevice, g.stream));
 				hipLaunchKernelGGL(k_h2_apply, dim3((unsigned) std::min<size_t>(grp.size(), (size_t) g.num_cus * 16)), dim3(64), 0, g.stream,
-								   h2_graph(h, first + b), (const H2Group *) d_grp, (uint32_t) grp.size(), (const H2Req *) d_req,
-								   g_h2_select);
+								   h2_graph(h, first + b), (const H2Group *) d_grp, (uint32_t) grp.size(), (const uint32_t *) nullptr,
+								   (const H2Req *) d_req, g_h2_select);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamSynchronize(g.stream));		/* grp / req are reused by the next batch */
 			}
 			nprunes += (int64_t) keys.size();
+			}
 		}
 		/* the entry point: the first node of every new top level, in insertion order */
 		for (uint32_t i = 0; i < b; i++)
@@ -3562,6 +3653,14 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 		done += b;
 		nbatches++;
 		maxbatch = std::max<int64_t>(maxbatch, b);
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));		/* (the scratch above is freed on return) */
+	if (devgrp)
+	{
+		unsigned long long tot = 0;
+
+		HIP_TRY(hipMemcpy(&tot, d_total, 8, hipMemcpyDeviceToHost));
+		nprunes = (int64_t) tot;
 	}
 	h->entry_point = entry;
 	h->entry_level = entry_level;
@@ -3621,20 +3720,33 @@ h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int ef, 
 	HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
 	H2Graph		gr = h2_graph(h, h->nblocks);
 
-	if (w16)
+#define H2_SEARCH_L(KK, NGG) do { \
+		HIP_TRY(hipFuncSetAttribute((const void *) KK<NGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem)); \
+		hipLaunchKernelGGL(KK<NGG>, dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe, \
+						   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords, \
+						   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next); } while (0)
+	/* (g_h2_occ4: 1 = four walkers a SIMD where that costs no scratch — walk rows of dim <= 768; 2 = everywhere; 0 = nowhere) */
+	if (!w16)
 	{
-		HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
-		hipLaunchKernelGGL(k_h2_search<true>, dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe,
-						   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
-						   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next);
+		if (g_h2_occ4 >= 2) H2_SEARCH_L(k_h2_search4, 0); else H2_SEARCH_L(k_h2_search, 0);
+	}
+	else if (h->dim <= 256)
+	{
+		if (g_h2_occ4 >= 1) H2_SEARCH_L(k_h2_search4, 1); else H2_SEARCH_L(k_h2_search, 1);
+	}
+	else if (h->dim <= 512)
+	{
+		if (g_h2_occ4 >= 1) H2_SEARCH_L(k_h2_search4, 2); else H2_SEARCH_L(k_h2_search, 2);
+	}
+	else if (h->dim <= 768)
+	{
+		if (g_h2_occ4 >= 1) H2_SEARCH_L(k_h2_search4, 3); else H2_SEARCH_L(k_h2_search, 3);
 	}
 	else
 	{
-		HIP_TRY(hipFuncSetAttribute((const void *) k_h2_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
-		hipLaunchKernelGGL(k_h2_search<false>, dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe,
-						   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords,
-						   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next);
+		if (g_h2_occ4 >= 2) H2_SEARCH_L(k_h2_search4, 4); else H2_SEARCH_L(k_h2_search, 4);
 	}
+#undef H2_SEARCH_L
 	HIP_TRY(hipGetLastError());
 	return NDBHIP_OK;
 }

@@ -207,10 +207,10 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
  * subnormal, so the hardware conversion is that function) and adds the four terms in increasing element order to its
  * fp64 partial: element i goes to partial (i / 4) mod 64.  Query registers in load16's order.
  */
+template <int NG>
 __device__ __forceinline__ void
 h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, double out[H2_NR])
 {
-	constexpr int NG = H2_QREG / 4;
 	double		p[H2_NR];
 	uint2		v[H2_NR][NG];
 
@@ -251,18 +251,18 @@ h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, do
 }
 
 /* d2(query, node ids[u]) for u < n: on the walk rows (W16; Q loaded by load16) or on the float4 rows (Q loaded by load) */
-template <bool W16>
+template <int W16>		/* 0: float4 rows; NG = 1 .. 4: walk rows of dim <= 256 NG (groups of four a lane holds) */
 __device__ __forceinline__ void
 h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, int lane, double d[H2_NR])
 {
-	if (W16)
+	if constexpr (W16 != 0)
 	{
 		const uint16_t *x[H2_NR];
 
 #pragma unroll
 		for (int u = 0; u < H2_NR; u++)
 			x[u] = g.vecs16 + (size_t) ids[u] * g.dim;
-		h2w_dist2x(Q, x, n, lane, d);
+		h2w_dist2x<W16>(Q, x, n, lane, d);
 	}
 	else
 	{
@@ -617,7 +617,7 @@ h2_offer(H2Set &W, double d, uint32_t id, int lane)
  * `evals` counts distance evaluations.  A node's neighbour list is read one slot per lane, the unvisited ones are
  * scored four rows at a time and offered to the set.
  */
-template <bool W16 = false>
+template <int W16 = 0>
 __device__ __forceinline__ void
 h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int level, H2Set &W, H2Visited &V, int lane,
 				long long &evals)
@@ -631,6 +631,9 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 	(void) V.mark(lane == 0, ep, lane);
 	h2_offer(W, epd, ep, lane);
 	H2_PH_DECL;
+	uint32_t	pf_id = NDBHIP_INVALID_BLOCK, pf_e0 = NDBHIP_INVALID_BLOCK;
+	int			pf_cnt = 0;
+
 	for (;;)
 	{
 		const int	bi = h2_pick(W, lane);
@@ -653,14 +656,44 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 			__threadfence_block();
 		}
 		const uint32_t c = h2_id_at(W, bi);
-		/* (the slot is read whatever the count says — every list has 2m slots — so that both loads are in flight together) */
-		const uint32_t *nb = g.nbrs + (size_t) c * g.stride + (size_t) level * 2 * g.m;
-		const uint32_t e0 = lane < 2 * g.m ? nb[lane] : NDBHIP_INVALID_BLOCK;
-		const int	cnt = min((int) g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		uint32_t	e0;
+		int			cnt;
+
+		if (W.inreg && c == pf_id)		/* uniform: the list asked for during the previous expansion's rows */
+		{
+			e0 = pf_e0;
+			cnt = pf_cnt;
+		}
+		else
+		{
+			/* (the slot is read whatever the count says — every list has 2m slots — so that both loads are in flight together) */
+			const uint32_t *nb = g.nbrs + (size_t) c * g.stride + (size_t) level * 2 * g.m;
+
+			e0 = lane < 2 * g.m ? nb[lane] : NDBHIP_INVALID_BLOCK;
+			cnt = min((int) g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		}
 		const uint32_t e = lane < cnt ? e0 : NDBHIP_INVALID_BLOCK;
 		const bool	fresh = V.mark(e != NDBHIP_INVALID_BLOCK && e < g.nvisible && e != 0, e, lane);
 		unsigned long long todo = __ballot(fresh);
 
+		if (W.inreg)
+		{
+			/* An expansion is two dependent round trips — the node's list, then its neighbours' rows.  The list of the node
+			 * that is next in line NOW (the nearest unexpanded entry; c is marked) is asked for before this expansion's rows:
+			 * unless one of these rows turns out nearer, the next expansion finds its list in registers.  A frozen graph: the
+			 * list read now is the list read then. */
+			const unsigned long long m2 = __ballot((uint32_t) lane < W.nw && !W.rx);
+
+			pf_id = NDBHIP_INVALID_BLOCK;
+			if (m2)
+			{
+				pf_id = (uint32_t) __builtin_amdgcn_readlane((int) W.rid, (int) __builtin_ctzll(m2));
+				const uint32_t *nb2 = g.nbrs + (size_t) pf_id * g.stride + (size_t) level * 2 * g.m;
+
+				pf_e0 = lane < 2 * g.m ? nb2[lane] : NDBHIP_INVALID_BLOCK;
+				pf_cnt = min((int) g.ncount[(size_t) pf_id * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+			}
+		}
 		H2_PH(1);
 		while (todo)
 		{
@@ -694,7 +727,7 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 }
 
 /* greedy step of the upper layers: from (cur, curd) move to the nearest neighbour at `level` while one is nearer */
-template <bool W16 = false>
+template <int W16 = 0>
 __device__ __forceinline__ void
 h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &curd, int lane, long long &evals)
 {
@@ -866,9 +899,9 @@ h2_smem_bytes(uint32_t ef, bool table = true /* with the LDS visited table (the 
  * (float) sqrt(d2).  Persistent grid of one-wave blocks; block b owns visited map b.
  * W16 (ndbo_h2_search_w16): descent and layer search on the fp16 walk rows (g.vecs16), then the result set's entries
  * scored against the float4 rows with the definition's arithmetic and ordered by that. */
-template <bool W16>
-__global__ __launch_bounds__(64) void
-k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level,
+template <int W16>		/* 0, or the walk rows' groups a lane (dim <= 256 W16) */
+__device__ __forceinline__ void
+h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level,
 			const uint64_t *__restrict__ tids, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords,
 			uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count,
 			uint64_t *__restrict__ out_tids, long long *__restrict__ out_evals,
@@ -929,7 +962,7 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 #pragma unroll
 				for (int u = 0; u < H2_NR; u++)
 					ids[u] = u == 0 ? cur : 0u;
-				h2_ids_d2<true>(g, Q, ids, 1, lane, d);
+				h2_ids_d2<W16>(g, Q, ids, 1, lane, d);
 				curd = d[0];
 			}
 			else
@@ -953,7 +986,7 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 #pragma unroll
 					for (int u = 0; u < H2_NR; u++)
 						ids[u] = u < n2 ? W.wid[i0 + u] : 0u;
-					h2_ids_d2<false>(g, Q, ids, n2, lane, d);
+					h2_ids_d2<0>(g, Q, ids, n2, lane, d);
 #pragma unroll
 					for (int u = 0; u < H2_NR; u++)
 						if (lane == u && u < n2)
@@ -980,6 +1013,27 @@ k_h2_search(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t 
 		}
 		__threadfence_block();
 	}
+}
+
+#define H2_SEARCH_PARAMS H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level, \
+	const uint64_t *__restrict__ tids, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords, \
+	uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count, uint64_t *__restrict__ out_tids, \
+	long long *__restrict__ out_evals, uint32_t *__restrict__ next
+#define H2_SEARCH_ARGS g, queries, nq, ef, k, entry, entry_level, tids, vbits, vlog, nwords, out_blocks, out_dist, out_count, out_tids, out_evals, next
+template <int W16>
+__global__ __launch_bounds__(64) void
+k_h2_search(H2_SEARCH_PARAMS)
+{
+	h2_search_body<W16>(H2_SEARCH_ARGS);
+}
+
+/* the same held to 128 registers: four walkers a SIMD instead of three (a walk waits on memory most of its time; what a
+ * compute unit gets done scales with the walks it holds).  Walk rows of dim <= 768 fit without scratch. */
+template <int W16>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
+k_h2_search4(H2_SEARCH_PARAMS)
+{
+	h2_search_body<W16>(H2_SEARCH_ARGS);
 }
 
 /*
@@ -1104,11 +1158,13 @@ struct H2Req
  * target; scratch in LDS: cid / cd / kid / kd [2m + 1].
  */
 __global__ __launch_bounds__(64) void
-k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups, const H2Req *__restrict__ req, int select)
+k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups_host, const uint32_t *__restrict__ ngroups_dev,
+		   const H2Req *__restrict__ req, int select)
 {
 	__shared__ uint32_t cid[260], kid[260];
 	__shared__ double cd[260], kd[260];
 	const int	lane = threadIdx.x;
+	const uint32_t ngroups = ngroups_dev ? *ngroups_dev : ngroups_host;		/* (grouped on the device: the count lives there) */
 
 	for (uint32_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x)
 	{
@@ -1168,6 +1224,99 @@ k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups, cons
 		}
 		if (lane == 0)
 			*pc = (int16_t) cnt;
+	}
+}
+
+/*
+ * A batch's back-links grouped by target ON THE DEVICE (round 5; the host did this between the search and the apply
+ * kernel of every batch — selections down, 140 k keys built and radix-sorted, groups and requests up — with the device
+ * waiting: a third of a build).  The selections of a batch lie as rows [off[i] + (top - lc)][m] in insertion order —
+ * member i ascending, level descending, slot ascending — so the item index row * m + j IS the insertion order:
+ *   k_h2_bl_rows    row -> (member, level)
+ *   k_h2_bl_keys    key[idx] = target << 8 | level (a slot beyond the row's count: `pad`, which sorts behind every key)
+ *   a STABLE radix sort of (key, idx) (hipcub::DeviceRadixSort) = by (target, insertion order): the host's order
+ *   k_h2_bl_heads   flags the first request of every target; an exclusive sum numbers the groups
+ *   k_h2_bl_groups  requests (x, d2) in sorted order, groups (target, level, r0, r1), the counts k_h2_apply reads
+ * Nothing comes back to the host: a build is one queue of launches.
+ */
+__global__ __launch_bounds__(256) void
+k_h2_bl_rows(uint32_t b, const uint32_t *__restrict__ off, const int *__restrict__ levels, int entry_level,
+			 uint32_t *__restrict__ rowmem, int *__restrict__ rowlc)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+
+	if (i >= b)
+		return;
+	const int	top = min(levels[i], entry_level);
+
+	for (int t = 0; t <= top; t++)
+	{
+		rowmem[off[i] + t] = i;
+		rowlc[off[i] + t] = top - t;
+	}
+}
+
+__global__ __launch_bounds__(256) void
+k_h2_bl_keys(uint32_t nitems, uint32_t m, const int *__restrict__ sn, const uint32_t *__restrict__ sid, const int *__restrict__ rowlc,
+			 unsigned long long pad, unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+	const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+
+	if (idx >= nitems)
+		return;
+	const uint32_t row = idx / m, j = idx - row * m;
+
+	keys[idx] = (int) j < sn[row] ? (((unsigned long long) sid[idx] << 8) | (unsigned long long) rowlc[row]) : pad;
+	vals[idx] = idx;
+}
+
+__global__ __launch_bounds__(256) void
+k_h2_bl_heads(uint32_t nitems, const unsigned long long *__restrict__ keys, unsigned long long pad, uint32_t *__restrict__ flags)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+
+	if (r < nitems)
+		flags[r] = (keys[r] != pad && (r == 0 || keys[r] != keys[r - 1])) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void
+k_h2_bl_groups(uint32_t nitems, uint32_t m, uint32_t first, const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+			   unsigned long long pad, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ gpos,
+			   const uint32_t *__restrict__ rowmem, const double *__restrict__ sd2, H2Group *__restrict__ grp, H2Req *__restrict__ req,
+			   uint32_t *__restrict__ counts /* [0] groups, [1] requests of this batch (zeroed before) */ ,
+			   unsigned long long *__restrict__ total)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+
+	if (r >= nitems)
+		return;
+	const unsigned long long key = keys[r];
+
+	if (key == pad)
+		return;
+	const uint32_t idx = vals[r];
+	const uint32_t gi = gpos[r] + flags[r] - 1u;
+	H2Req		rq;
+
+	rq.x = first + rowmem[idx / m];
+	rq.pad = 0;
+	rq.d2 = sd2[idx];
+	req[r] = rq;
+	if (flags[r])
+	{
+		grp[gi].node = (uint32_t) (key >> 8);
+		grp[gi].level = (int) (key & 0xFFull);
+		grp[gi].r0 = r;
+	}
+	const unsigned long long nextkey = r + 1 < nitems ? keys[r + 1] : pad;
+
+	if (nextkey != key)
+		grp[gi].r1 = r + 1;
+	if (nextkey == pad)
+	{
+		counts[0] = gi + 1;
+		counts[1] = r + 1;
+		atomicAdd(total, (unsigned long long) (r + 1));
 	}
 }
 

@@ -660,6 +660,6 @@ topk_entry_cap(uint32_t k)
 #define NDB_TOPK_MAX_SMEM (150 * 1024)
 
 int			set_kernel_attributes_hnsw();
-extern int	g_hnsw_trace, g_hnsw_nofast, g_h2_waves;
+extern int	g_hnsw_trace, g_hnsw_nofast, g_h2_waves, g_h2_occ4, g_h2_host_groups;
 
 #endif							/* NDBHIP_INTERNAL_H */

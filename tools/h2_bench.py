@@ -22,7 +22,7 @@ def main():
     _lib.ensure_init(0)
     _lib.use_torch_stream()
     import ctypes as C
-    nq = 8192
+    nq = int(os.environ.get("H2_NQ", "8192"))
     x = torch.empty((n, dim), dtype=torch.float32, device=dev)
     q = torch.empty((nq, dim), dtype=torch.float32, device=dev)
     k1 = 1 if kind == "clustered" else 0
@@ -38,6 +38,8 @@ def main():
     check(lib().ndbhip_hnsw_set_intended_select(int(os.environ.get("H2_SELECT", "1"))))
     if os.environ.get("H2_WAVES"):
         check(lib().ndbhip_set_option(b"hnsw_intended_waves", int(os.environ["H2_WAVES"])))
+    if os.environ.get("H2_OCC4"):
+        check(lib().ndbhip_set_option(b"hnsw_intended_occ4", int(os.environ["H2_OCC4"])))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ix.build_intended(x, tids, levels, 200, batch_div=int(os.environ.get("H2_BDIV", "16")), batch_max=int(os.environ.get("H2_BMAX", "8192")))
