@@ -1174,7 +1174,11 @@ k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups_host,
 		int16_t    *pc = &g.ncount[(size_t) gr.node * NDBHIP_HNSW_MAX_LEVEL + gr.level];
 		int			cnt = *pc;
 		const float *ev = g.vecs + (size_t) gr.node * g.dim;
+		H2Query		C;
+		bool		Cloaded = false;
 
+		C.q = ev;
+		C.dim = g.dim;
 		for (uint32_t r = gr.r0; r < gr.r1; r++)
 		{
 			const uint32_t x = req[r].x;
@@ -1188,17 +1192,36 @@ k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups_host,
 				__threadfence_block();
 				continue;
 			}
-			/* candidates = the list + x with their distances to the target ... */
-			for (int i0 = 0; i0 <= cnt; i0++)
+			/* candidates = the list + x with their distances to the target: the list's rows H2_NR at a time, their loads in
+			 * flight together (one row pair after the other was cnt dependent round trips per request — most of this
+			 * kernel); the target in the query's place: h2_dist2x4 = h2_dist2_rows term for term */
+			if (!Cloaded)
 			{
-				const uint32_t id = i0 < cnt ? nb[i0] : x;
-				const double d = i0 < cnt ? h2_dist2_rows(ev, g.vecs + (size_t) id * g.dim, g.dim, lane) : dxe;
+				C.load(ev, g.dim, lane);
+				Cloaded = true;
+			}
+			for (int i0 = 0; i0 < cnt; i0 += H2_NR)
+			{
+				uint32_t	ids[H2_NR];
+				double		d[H2_NR];
+				const int	n2 = min(H2_NR, cnt - i0);
 
-				if (lane == 0)
-				{
-					kid[i0] = id;
-					kd[i0] = d;
-				}
+#pragma unroll
+				for (int u = 0; u < H2_NR; u++)
+					ids[u] = u < n2 ? nb[i0 + u] : 0u;
+				h2_ids_d2<0>(g, C, ids, n2, lane, d);
+#pragma unroll
+				for (int u = 0; u < H2_NR; u++)
+					if (lane == u && u < n2)
+					{
+						kid[i0 + u] = ids[u];
+						kd[i0 + u] = d[u];
+					}
+			}
+			if (lane == 0)
+			{
+				kid[cnt] = x;
+				kd[cnt] = dxe;
 			}
 			__threadfence_block();
 			/* ... ascending by (d2, id) ... */
