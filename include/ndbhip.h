@@ -176,6 +176,7 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen16c_dense"   1     the dense tile (256 pairs x 256 rows) runs k_s16c_dense (csrc/ndbhip_screen16d.h: loader and prefetcher
  *                             waves, chunk-major pair planes, the matrix pipe screens its own accumulator blocks, queued records);
  *                             0 = k_s16c_sweep<8, 2> (A/B)
+ *   "screen16c_bigk"    1     64 < k <= 256 on the centred fp16 screen (L2, sublists): thresholds from the buckets' radii (k_s16c_thr_radius); 0: the fp32 screen serves k > 64
  *   "screen16c_sample"  2048  rows of the mirror sampled for the first thresholds of a batch on a table without cluster structure
  *                             (k_s16c_seed_sample: all queries x the sample as one matrix on the matrix cores); 0 = seeds only, 256..2048
  *   "screen16c_tight"   128   k_s16c_dense tightens a query's threshold every this many records (power of two, 8..1024)

@@ -2017,6 +2017,7 @@ struct ndbhip_ivf
 	uint32_t   *d_bucket_list = nullptr;	size_t d_bucket_list_n = 0;
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
+	bool		s16_bigk_off = false;	/* this mirror's layout cannot serve k > 64 on the fp16 screen (no sublists, not centred): found out once */
 	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
 	/* split top-k of small batches: per-range records, counts, totals */
 	ndbhip_cand *w_scand = nullptr;	size_t w_scand_n = 0;
@@ -3104,6 +3105,7 @@ static int	g_s16c_wave_min_nq = 1024;	/* batches from this many queries up take 
 static int	g_s16c_wblk = 2;	/* blocks of 4 waves per compute unit that k_s16c_wsweep is launched with (1, 2, or 3 when two chunks are in flight per wave: the registers of that form allow three; "screen16c_wave_blocks") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
+static int	g_s16c_bigk = 1;	/* 64 < k <= 256 on the centred fp16 screen ("screen16c_bigk"; 0: the fp32 screen, as before round 5) */
 static int	g_s16_redo = 1;		/* queries whose records / survivors overflow go to the exact path alone ("screen16_redo"; 0: the whole batch does) */
 static int	g_s16_cos = 1;		/* cosine on the matrix-core sweep, as the inner product of normalised planes ("screen16_cosine") */
 
@@ -3114,7 +3116,10 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 
 	if (R != R_IVF_L2 && R != R_IVF_IP && !(R == R_IVF_COS && g_s16_cos))
 		return false;
-	if (k > NDB_TOPK_FAST_MAXK || ix->nrows < 1)
+	if (ix->nrows < 1)
+		return false;
+	/* (64 < k <= 256: L2 on the centred planes over sublists only — ivf_s16_run sends anything else back) */
+	if (k > NDB_TOPK_FAST_MAXK && !(g_s16c_bigk && k <= NDB_S16_MAXK && R == R_IVF_L2 && !ix->s16_bigk_off))
 		return false;
 	if (ix->f16 && (ix->dim % 64) != 0)
 		return false;
@@ -3382,6 +3387,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 			}
 		}
 		ix->s16_valid = true;
+		ix->s16_bigk_off = false;		/* (a new layout: k > 64 gets another try) */
 	}
 	return 0;
 }
@@ -3629,6 +3635,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
 	const bool	seed_by_sublist = ix->s16_sub && (R == R_IVF_L2 || (R == R_IVF_IP && cdist) || R == R_IVF_COS) && g_s16_prune && ix->nsub_g > 0;
 
+	if (k > NDB_TOPK_FAST_MAXK && !(cen && !xseed && !ipc && seed_by_sublist && R == R_IVF_L2))
+	{
+		/* 64 < k: thresholds come from the sublists' radii (k_s16c_thr_radius) — a layout without sublists, or not centred,
+		 * has nothing to take them from: this mirror's batches with k > 64 go to the fp32 screen, this one included */
+		ix->s16_bigk_off = true;
+		g.stats.screen16_fallbacks++;
+		return 1;
+	}
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
 	const uint32_t cseeds = g_s16c_seeds ? (uint32_t) g_s16c_seeds : (k <= 20 ? 32u : 64u);
 
@@ -3800,7 +3814,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	unsigned int *active = ix->w_ecount + 2 * (size_t) nq;
 
 	/* a shard's finalize decides with the k-th LOCAL bound, looser than the whole index's: four times the room */
-	const uint32_t surv_cap = partial ? 4u * S16_SURV_CAP : (uint32_t) S16_SURV_CAP;
+	/* (k > 64: the cut at the k-th upper bound leaves k survivors and those inside the bounds' error) */
+	const uint32_t surv_cap = std::max(partial ? 4u * S16_SURV_CAP : (uint32_t) S16_SURV_CAP, k > NDB_TOPK_FAST_MAXK ? std::min(6u * (uint32_t) k, 1280u) : 0u);
 	/* the survivors' rows through LDS (s16_exact_staged) for a small batch, which has a CU to itself: 8 chunks deep for up to
 	 * 16 survivors, 64-row slots for more.  A large batch lives on 16 blocks per CU overlapping each other's phases, and the
 	 * ring's LDS would halve them (measured at 4096 queries: 128 us with a 10 KB ring, 103 us without) */
@@ -3912,6 +3927,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 						else
 							S16C_SEED_L(true, false, S16C_SEED_SUB_ARGS);
 #undef S16C_SEED_SUB_ARGS
+						/* k > 64: no seed kernel holds k rows; the threshold comes from the buckets' radii */
+						if (k > NDB_TOPK_FAST_MAXK && !ipc && !cosb)
+							hipLaunchKernelGGL(k_s16c_thr_radius, dim3(nq), dim3(256), 0, g.stream, w_probes, lco, npr, (uint32_t) k,
+											   (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx, (const uint32_t *) ix->d_sub_len,
+											   (const uint32_t *) ix->d_sub_rad, (const int64_t *) ix->d_prow_off, (const uint32_t *) ix->d_pposof,
+											   subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2, (const uint32_t *) sub_xmax, dim,
+											   ix->w_qthr);
 					}
 				else
 				{
@@ -4561,6 +4583,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16c_plane_seeds"))
 		g_s16c_plseed = value != 0;
+	else if (!strcmp(name, "screen16c_bigk"))
+		g_s16c_bigk = value != 0;
 	else if (!strcmp(name, "screen16c_wave_min_nq"))
 	{
 		if (value < 1)

@@ -649,6 +649,7 @@ carve_topk_smem(unsigned char *base, uint32_t cap, uint32_t k)
 }
 
 #define NDB_TOPK_FAST_MAXK 64		/* fast path: k <= 64 (256 thread minima bound the k-th value) */
+#define NDB_S16_MAXK 256			/* the centred fp16 screen serves k up to this (L2 over sublists: thresholds from the buckets' radii, k_s16c_thr_radius) */
 #define NDB_TOPK_FAST_CAP 1024		/* candidates <= U the fast path can hold before falling back */
 
 __host__ __device__ static inline uint32_t

@@ -1047,6 +1047,182 @@ k_s16c_seed_sample(const float *__restrict__ amat, uint32_t astride, uint32_t ns
 }
 
 /*
+ * Thresholds for 64 < k <= NDB_S16_MAXK (round 5).  The seed kernels bound the k-th distance by the k-th smallest of at
+ * most 64 rows' distances — nothing for k > 64, and without a finite first threshold every pair survives and every
+ * query overflows its record buffer.  What bounds the k-th distance of a larger k needs no row at
+ * all: EVERY row of a bucket with centre c and radius rad lies within |q - c| + rad of the query, so with the buckets of
+ * the query's probed lists in ascending order of U = (|q - c| + rad)^2, the first U at which the buckets so far hold k
+ * of the query's candidates (live rows, visible under the candidate cap: counted from pposof, a bucket at a time) is an
+ * upper bound of its k-th smallest REAL squared distance — what s16c_t_from_ub takes.  |q - c|: from the matrix-core
+ * centre distances (a + their error bound, the one k_sub_pairs prunes with), or the centroid scan's float4 distance for
+ * a list that is its own bucket (within 1e-3 of the real one, as s16_sub_excluded takes it).  k = 100 on a clustered
+ * table: U of the query's own sublist, a few times its real k-th distance; the emissions that costs (the rows of the
+ * neighbouring sublists) are cut by k_s16_finalize's k-th UPPER bound as ever.
+ * One block per query; up to S16C_RAD_CAP buckets (more: the threshold stays where it was).  L2 only.
+ */
+#define S16C_RAD_CAP 1024
+#define S16C_RAD_STEPS 32		/* buckets taken in order before giving up (k <= 256 needs a handful of ~128-row sublists) */
+__global__ __launch_bounds__(256) void
+k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ loc_cand_off, int npr, uint32_t k,
+				  const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx, const uint32_t *__restrict__ sub_len,
+				  const uint32_t *__restrict__ sub_rad, const int64_t *__restrict__ prow_off, const uint32_t *__restrict__ pposof,
+				  const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
+				  const float *__restrict__ cdist, uint32_t cstride, const float *__restrict__ qn2,
+				  const uint32_t *__restrict__ cxmax_bits, int dim, float2 *__restrict__ qthr)
+{
+	__shared__ uint32_t s_off[65], s_s0[64];
+	__shared__ float s_pd[64];
+	__shared__ uint32_t s_key[S16C_RAD_CAP], s_sx[S16C_RAD_CAP];
+	__shared__ uint16_t s_pr[S16C_RAD_CAP];
+	__shared__ unsigned long long s_best[4];
+	__shared__ uint32_t s_cnt[4];
+	const uint32_t q = blockIdx.x;
+	const int	tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t *lco = loc_cand_off + (size_t) q * (npr + 1);
+	const float ec = s16_e<R_IVF_L2>(dim, qn2[q], __uint_as_float(*cxmax_bits), false);
+	uint32_t	nb = 0;
+	bool		toomany = false;
+
+	for (int p0 = 0; p0 < npr; p0 += 64)
+	{
+		const int	p = p0 + lane;
+		uint32_t	n = 0, s0 = 0;
+		float		pd = 0.0f;
+
+		if (p < npr && lco[p + 1] != lco[p])
+		{
+			const int	L = probes[(size_t) q * npr + p];
+
+			s0 = sub_first[L];
+			n = sub_first[L + 1] - s0;
+			pd = cdist ? cdist[(size_t) q * cstride + L] : pdist[(size_t) q * npr + p];
+		}
+		uint32_t	inc = n;
+
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t v = (uint32_t) __shfl_up((int) inc, off, 64);
+
+			if (lane >= off)
+				inc += v;
+		}
+		const uint32_t T = (uint32_t) __shfl((int) inc, 63, 64);
+
+		__syncthreads();			/* (the previous round's readers are done with the tables) */
+		if (wv == 0)
+		{
+			s_off[lane] = inc - n;
+			s_s0[lane] = s0;
+			s_pd[lane] = pd;
+			if (lane == 0)
+				s_off[64] = T;
+		}
+		__syncthreads();
+		if (nb + T > (uint32_t) S16C_RAD_CAP)
+		{
+			toomany = true;			/* uniform */
+			break;
+		}
+		for (uint32_t t = (uint32_t) tid; t < T; t += 256)
+		{
+			int			lo = 0, hi = 64;
+
+			while (hi - lo > 1)
+			{
+				const int	mid = (lo + hi) >> 1;
+
+				if (s_off[mid] <= t)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			const uint32_t sx = s_s0[lo] + (t - s_off[lo]);
+			const int	gi = sub_gidx[sx];
+			const double rad = (double) __uint_as_float(sub_rad[sx]);
+			double		du;
+
+			if (gi < 0)
+				du = (double) s_pd[lo] * (1.0 + 1e-3);
+			else
+				du = __builtin_sqrt((double) fmaxf(subdist[(size_t) q * sstride + gi], 0.0f) + (double) ec * (1.0 + 1e-6)) * (1.0 + 1e-9);
+			const double u = (du + rad) * (du + rad) * (1.0 + 1e-9);
+			const float uf = s16_up((float) u);
+			/* (a centre or a radius beyond fp32, an empty bucket: never taken) */
+			const bool	good = sub_len[sx] > 0 && uf == uf && uf < 3.0e38f && uf >= 0.0f;
+
+			s_key[nb + t] = good ? __float_as_uint(uf) : 0xFFFFFFFFu;		/* uf >= 0: the bits order like the values */
+			s_sx[nb + t] = sx;
+			s_pr[nb + t] = (uint16_t) (p0 + lo);
+		}
+		nb += T;
+	}
+	__syncthreads();
+	if (toomany || nb == 0)
+		return;
+	uint32_t	have = 0;
+
+	for (int step = 0; step < S16C_RAD_STEPS; step++)
+	{
+		/* the nearest bucket not taken yet: (key, index) minimum over the block */
+		unsigned long long m = ~0ull;
+
+		for (uint32_t i = (uint32_t) tid; i < nb; i += 256)
+		{
+			const unsigned long long v = ((unsigned long long) s_key[i] << 32) | i;
+
+			m = v < m ? v : m;
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) m, off, 64);
+			const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (m >> 32), off, 64);
+			const unsigned long long o = ((unsigned long long) hi << 32) | lo;
+
+			m = o < m ? o : m;
+		}
+		if (lane == 0)
+			s_best[wv] = m;
+		__syncthreads();
+		m = s_best[0];
+#pragma unroll
+		for (int w = 1; w < 4; w++)
+			m = s_best[w] < m ? s_best[w] : m;
+		if ((uint32_t) (m >> 32) == 0xFFFFFFFFu)
+			return;					/* nothing usable left (uniform) */
+		const uint32_t bi = (uint32_t) m, sx = s_sx[bi], pr = s_pr[bi];
+		const uint32_t vis = lco[pr + 1] - lco[pr], len = sub_len[sx];
+		const int64_t r0 = prow_off[sx];
+		uint32_t	c = 0;
+
+		for (uint32_t i = (uint32_t) tid; i < len; i += 256)
+			c += pposof[r0 + i] < vis ? 1u : 0u;		/* (a deleted row's hole: 0xFFFFFFFF) */
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+			c += (uint32_t) __shfl_xor((int) c, off, 64);
+		if (lane == 0)
+			s_cnt[wv] = c;
+		__syncthreads();
+		have += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+		if (tid == 0)
+			s_key[bi] = 0xFFFFFFFFu;		/* taken */
+		if (have >= k)
+		{
+			if (tid == 0)
+			{
+				const float t = s16c_t_from_ub(__uint_as_float((uint32_t) (m >> 32)), dim);
+				const float2 o = qthr[q];
+
+				qthr[q] = make_float2(fminf(o.x, t), o.y);
+			}
+			return;
+		}
+		__syncthreads();
+	}
+}
+
+/*
  * Geometry.  QB = 32-pair blocks per tile (4: 128 pairs; 1: 32 pairs, for batches whose buckets are probed by a
  * handful of queries each — most of a 128-pair tile would be padding, and the LDS it reserves is better spent on a
  * deeper ring, because that regime is bound by the rows' bytes); 4 waves, 128 rows per tile.  QB = 8 is the dense

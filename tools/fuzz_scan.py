@@ -105,7 +105,7 @@ def one_case(rng, lib, IvfIndex, check):
     else:
         ix.load(a["list_len"], a["rows"], a["tids"])
     img = oracle_image(a)
-    k = int(rng.choice([1, 10, 37, 100]))
+    k = int(rng.choice([1, 10, 37, 100, 65, 160, 256]))     # (64 < k <= 256: the fp16 screen's radius thresholds, round 5)
     nprobe = int(rng.integers(1, nlists + 3))
     cap = int(rng.choice([0, 0, k * 10, 500]))
     strategy = int(rng.choice([1, 1, 1, 2, 3]))
@@ -127,7 +127,7 @@ def one_case(rng, lib, IvfIndex, check):
           # round 5: the 32-pair tile as wave-autonomous register streams (chunks in flight per wave) or the LDS ring
           "screen16c_wave": int(rng.choice([0, 2, 2, 3, 4])),
           "screen16c_wave_blocks": int(rng.choice([1, 2, 3, 3])), "screen16c_wave_min_nq": 1,
-          "screen16c_plane_seeds": int(rng.random() < 0.7)}
+          "screen16c_plane_seeds": int(rng.random() < 0.7), "screen16c_bigk": int(rng.random() < 0.85)}
     for name, value in r4.items():
         check(lib.ndbhip_set_option(name.encode(), value))
     if os.environ.get("FUZZ_TRACE"):
