@@ -3105,6 +3105,7 @@ static int	g_s16c_wave_min_nq = 1024;	/* batches from this many queries up take 
 static int	g_s16c_wblk = 2;	/* blocks of 4 waves per compute unit that k_s16c_wsweep is launched with (1, 2, or 3 when two chunks are in flight per wave: the registers of that form allow three; "screen16c_wave_blocks") */
 static int	g_s16c_nbuf = 0;	/* ring depth of the centred sweep, 0 = the geometry's default ("screen16c_nbuf") */
 
+static long	g_slow_call_us = 0;	/* "slow_call_log": host-pointer searches slower than this many microseconds report their phases on stderr */
 static int	g_s16c_bigk = 1;	/* 64 < k <= 256 on the centred fp16 screen ("screen16c_bigk"; 0: the fp32 screen, as before round 5) */
 static int	g_s16_redo = 1;		/* queries whose records / survivors overflow go to the exact path alone ("screen16_redo"; 0: the whole batch does) */
 static int	g_s16_cos = 1;		/* cosine on the matrix-core sweep, as the inner product of normalised planes ("screen16_cosine") */
@@ -4585,6 +4586,8 @@ ndbhip_set_option(const char *name, int value)
 		g_s16c_plseed = value != 0;
 	else if (!strcmp(name, "screen16c_bigk"))
 		g_s16c_bigk = value != 0;
+	else if (!strcmp(name, "slow_call_log"))
+		g_slow_call_us = value;
 	else if (!strcmp(name, "screen16c_wave_min_nq"))
 	{
 		if (value < 1)
@@ -5556,6 +5559,8 @@ ivf_search_host(ndbhip_ivf *ix, const float *queries, const void *d_base, const 
 		ix->pin_n = pin_bytes;
 	}
 	unsigned char *h_out = (unsigned char *) ix->pin + ((in_bytes + 7) & ~(size_t) 7);
+	/* ("slow_call_log" = microseconds: a call that takes longer says where the time went — host-side phases, stderr) */
+	const auto	lt0 = std::chrono::steady_clock::now();
 
 	if (queries)
 	{
@@ -5573,12 +5578,29 @@ ivf_search_host(ndbhip_ivf *ix, const float *queries, const void *d_base, const 
 						   (const int64_t *) ix->w_qoffs, ix->dim, ix->w_q);
 		HIP_TRY(hipGetLastError());
 	}
+	const auto	lt1 = std::chrono::steady_clock::now();
+
 	rc = ivf_search_device_impl(ix, ix->w_q, nq, strategy, nprobe, k, max_candidates, 0, nullptr, nullptr,
 								nullptr, d_tid, d_dist, d_cnt);
 	if (rc)
 		return rc;
+	const auto	lt2 = std::chrono::steady_clock::now();
+
 	HIP_TRY(hipMemcpyAsync(h_out, d_tid, out_words * 4, hipMemcpyDeviceToHost, g.stream));
+	const auto	lt3 = std::chrono::steady_clock::now();
+
 	HIP_TRY(hipStreamSynchronize(g.stream));
+	if (g_slow_call_us > 0)
+	{
+		const auto	lt4 = std::chrono::steady_clock::now();
+		auto		us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+			return (long) std::chrono::duration_cast<std::chrono::microseconds>(b - a).count();
+		};
+
+		if (us(lt0, lt4) > g_slow_call_us)
+			fprintf(stderr, "ndbhip slow call: %ld us for %d queries: copy in %ld, launches %ld, copy out %ld, wait %ld\n", us(lt0, lt4), nq,
+					us(lt0, lt1), us(lt1, lt2), us(lt2, lt3), us(lt3, lt4));
+	}
 	const uint64_t *t64 = (const uint64_t *) h_out;
 
 	memcpy(out_dist, h_out + nk * 8, nk * 4);

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--lists", type=int, default=1024)
     ap.add_argument("--probes", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--n", type=int, default=300)
+    ap.add_argument("--n", type=int, default=1000)
     a = ap.parse_args()
     from neurondb_amd import IvfIndex, _lib
     dev = torch.device("cuda", 0)
@@ -34,12 +34,20 @@ def main():
     ix.build_device(base, pack_tids(torch.arange(a.nvec, device=dev)), 50)
     for i in range(20):
         ix.search(q[i:i + 1], 1, a.probes, a.k)
+    _lib.check(_lib.lib().ndbhip_set_option(b"slow_call_log", 1000))      # calls over 1 ms say where the time went (stderr)
+    import gc
+    gc.collect()
+    if os.environ.get("LAT_NOGC"):
+        gc.disable()
     ts = []
     for i in range(20, 20 + a.n):
         t0 = time.perf_counter()
         ix.search(q[i:i + 1], 1, a.probes, a.k)
         ts.append(time.perf_counter() - t0)
     ts = np.array(ts) * 1e6
+    slow = np.argsort(ts)[-5:][::-1]
+    print("  slowest calls (index: us): " + ", ".join(f"{int(i)}: {ts[i]:.0f}" for i in slow) +
+          f"; calls over 1 ms: {int((ts > 1000).sum())} of {len(ts)}")
     print(f"single-query ndbhip_ivf_search latency over {a.n} queries: p50 {np.percentile(ts, 50):.0f} us, "
           f"p90 {np.percentile(ts, 90):.0f} us, p99 {np.percentile(ts, 99):.0f} us, mean {ts.mean():.0f} us "
           f"({a.nvec}x{a.dim}, lists={a.lists}, probes={a.probes}, k={a.k})")
