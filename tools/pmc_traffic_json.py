@@ -124,17 +124,19 @@ def main():
         elif a[0] == "--h2":
             hp, nq = a[1], int(a[2])
             a = a[3:]
-            f = pick(counters(hp + "_fetch.txt"), "k_h2_search")
-            w = pick(counters(hp + "_write.txt"), "k_h2_search")
-            if f and w:
-                fk, n = f["FETCH_SIZE"]
-                wk, _ = w["WRITE_SIZE"]
-                # (tools/h2_bench.py: one 256-query warm-up launch + one of NQ per ef; traffic is per query over both)
-                doc["kernels"]["k_h2_search"] = {"clustered_unit": {
-                    "dispatches": n, "queries_profiled": nq + 256,
-                    "traffic_bytes_per_query": int((2.0 * fk + wk) * 1024.0 / (nq + 256)),
-                    "workload": {"nvec": 1000000, "dim": 768, "m": 16, "ef": 64},
-                    "source": f"{hp}_{{fetch,write}}.txt"}}
+            cf, cw = counters(hp + "_fetch.txt"), counters(hp + "_write.txt")
+            # (round 5: k_h2_search<0> walks the float4 rows, k_h2_search<NG> the fp16 walk rows; older files: one kernel)
+            for needle, name in (("k_h2_search<0>", "k_h2_search"), ("k_h2_search<3>", "k_h2_search_w16"), ("k_h2_search(", "k_h2_search")):
+                f, w = pick(cf, needle), pick(cw, needle)
+                if f and w and name not in doc["kernels"]:
+                    fk, n = f["FETCH_SIZE"]
+                    wk, _ = w["WRITE_SIZE"]
+                    # (tools/h2_bench.py: one 256-query warm-up launch + one of NQ per ef and walk; traffic is per query over both)
+                    doc["kernels"][name] = {"clustered_unit": {
+                        "dispatches": n, "queries_profiled": nq + 256,
+                        "traffic_bytes_per_query": int((2.0 * fk + wk) * 1024.0 / (nq + 256)),
+                        "workload": {"nvec": 1000000, "dim": 768, "m": 16, "ef": 64},
+                        "source": f"{hp}_{{fetch,write}}.txt"}}
         else:
             raise SystemExit("unknown argument " + a[0])
     json.dump(doc, open(out, "w"), indent=1)

@@ -25,3 +25,8 @@ if [ -f neurondb_amd/lib_ph/libndbhip.so ]; then
   unset NDBHIP_LIB
 fi
 python3 tools/overlap_probe.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_overlap.txt
+# the intended HNSW (build + both walks at ef 64): kernel stats, FETCH_SIZE / WRITE_SIZE of the search kernels
+rm -rf /tmp/ks_h2; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks_h2 -o p -- python3 $GRAFT_REPO_ROOT/tools/h2_bench.py 1000000 768 clustered 64 > /tmp/ks_h2.log 2>&1)
+f=$(find /tmp/ks_h2 -name "*.db" | head -1); [ -n "$f" ] && python3 tools/rocpd_summary.py $f 30 > gpurun_out/${R}_h2_kernel_stats.txt; grep -E "k_h2_" gpurun_out/${R}_h2_kernel_stats.txt | cut -c1-60,76-130
+export KERNELS="k_h2_search"
+PROG="tools/h2_bench.py 1000000 768 clustered 64" PASSES="fetch write" bash tools/pmc_all.sh ${R}_h2 2>&1 | tail -8
