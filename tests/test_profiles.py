@@ -73,3 +73,49 @@ def test_the_committed_bench_line_is_one_json_object_with_the_contract_fields():
     assert "workload" in d["config"] and "model" not in d["config"]
     b = d["build"]
     assert b["searchable_vectors_per_s"] < b["vectors_per_s"] and b["lists_identical_to_exact_assignment"]
+
+
+def test_round_5_artefacts_agree_with_each_other():
+    """profiles/r05_*: the PMC traffic file is what the committed summaries say, the committed line carries the contract's
+    fields plus the round's keys (serial, roofline.alone, c4, sigma_sweep, the HNSW walks), and bench.py finds the
+    round's traffic for the kernel it runs now."""
+    P = os.path.join(ROOT, "profiles")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "t.json")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"), out, "3",
+                               "--ivf", "clustered", os.path.join(P, "r05_pmc_clustered"),
+                               "--h2", os.path.join(P, "r05_pmc_h2"), "8192"], stdout=subprocess.DEVNULL)
+        fresh = json.load(open(out))["kernels"]
+    kept = json.load(open(os.path.join(P, "r05_pmc_traffic.json")))["kernels"]
+    for kern in ("k_s16c_wsweep", "k_s16w_collect", "k_s16_finalize", "k_s16c_seed"):
+        assert fresh[kern]["clustered"]["traffic_bytes_per_launch"] == kept[kern]["clustered"]["traffic_bytes_per_launch"]
+    w = kept["k_s16c_wsweep"]["clustered"]
+    assert 1.5e9 < w["traffic_bytes_per_launch"] < 2.0e9 and 0 < w["l2_hit_rate"] < 0.5
+    f32, w16 = kept["k_h2_search"]["clustered_unit"], kept["k_h2_search_w16"]["clustered_unit"]
+    assert fresh["k_h2_search_w16"]["clustered_unit"]["traffic_bytes_per_query"] == w16["traffic_bytes_per_query"]
+    # the walk on fp16 rows moves a little more than half of the float4 walk's bytes (the re-score reads float4 rows)
+    assert 0.5 < w16["traffic_bytes_per_query"] / f32["traffic_bytes_per_query"] < 0.7
+    d = json.load(open(os.path.join(P, "r05_bench_line.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "serial", "c4", "c5", "sigma_sweep", "hnsw"):
+        assert key in d, key
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= r["alone"]["frac"] <= 1
+    assert r["traffic"] == w["traffic_bytes_per_launch"] and 1.0 <= r["hbm"]["traffic_over_bytes"] <= 1.15
+    assert d["serial"]["lanes_identical_to_serial"] and d["serial"]["ms_per_step"] > d["ms_per_step"]
+    assert d["cpu_baseline"]["gpu_parity_on_sample"]["mismatches"] == 0 and d["recall_at_10"] == 1.0
+    for name, leg in d["sigma_sweep"].items():
+        if isinstance(leg, dict) and "queries_per_s" in leg:
+            assert leg["recall_at_10"] >= 0.99 and leg["oracle_parity"]["mismatches"] == 0, name
+    h = d["hnsw"]["intended"]
+    assert h["oracle_parity"]["mismatches"] == 0 and h["float4_walk"]["oracle_mismatches"] == 0
+    assert h["queries_per_s"] > h["float4_walk"]["queries_per_s"] and h["recall_at_10"] >= 0.90
+    assert h["roofline"]["traffic_source"] and "r05" in h["roofline"]["traffic_source"]
+    sys.path.insert(0, ROOT)
+    import bench
+    args = types.SimpleNamespace(data="clustered", nvec=1_000_000, dim=768, lists=1024, probes=32, batch=4096, k=10,
+                                 rows="f32", strategy="l2")
+    traffic, source = bench.pmc_traffic(args, 1, "k_s16c_wsweep")
+    assert traffic == w["traffic_bytes_per_launch"] and "profiles/r05" in source
+
