@@ -321,6 +321,14 @@ int			ndbhip_ivf_shard(const ndbhip_ivf *src, const uint8_t *owned, ndbhip_ivf *
  * tail page); NULL = the rank holding the list's last row, and nobody for an empty list. */
 int			ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const int64_t *len, const uint8_t *tail,
 									ndbhip_ivf **out);
+/* A second HANDLE on the same mirror (round 5): rows, TIDs, planes, sublists and matrices — everything a search reads —
+ * are the source's own arrays; everything a batch writes (per-batch scratch, the pinned result block) is the new
+ * handle's.  What several batches in flight need — a host thread, a stream (ndbhip_set_thread_stream) and a handle each —
+ * without a second copy of a mirror that is 1.55 x its table.  While a share lives both handles are FROZEN: loads,
+ * appends, deletes, builds and anything that would lay the planes out again return NDBHIP_ERR_STATE, so run
+ * ndbhip_ivf_prepare (or one batch of every kind the shares will serve) on the source first; ndbhip_ivf_destroy of the
+ * source is refused until its shares are destroyed. */
+int			ndbhip_ivf_share(ndbhip_ivf *src, ndbhip_ivf **out);
 /* A halfvec twin of a float4 mirror (same centroids, lists, TIDs): rows narrowed on the device with the
  * reference's own encoder float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal
  * results flushed to zero) when reference_encoder != 0 — what a halfvec column cast by the reference holds —

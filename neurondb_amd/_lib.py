@@ -174,6 +174,7 @@ def lib():
         "ndbhip_ivf_ncentroids": (i, [vp]),
         "ndbhip_ivf_delete": (i, [vp, vp, i64, C.POINTER(i64)]),
         "ndbhip_ivf_to_f16": (i, [vp, i, C.POINTER(vp)]),
+        "ndbhip_ivf_share": (i, [vp, C.POINTER(vp)]),
         "ndbhip_ivf_get_nprobe": (i, [vp, C.POINTER(i)]),
         "ndbhip_ivf_set_nprobe": (i, [vp, i]),
         "ndbhip_ivf_shard_slices": (i, [vp, vp, vp, vp, C.POINTER(vp)]),

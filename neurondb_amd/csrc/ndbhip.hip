@@ -2017,6 +2017,11 @@ struct ndbhip_ivf
 	uint32_t   *d_bucket_list = nullptr;	size_t d_bucket_list_n = 0;
 	uint8_t    *w_drop = nullptr;	size_t w_drop_n = 0;	/* [nq][npr] pairs excluded before the sweep */
 	uint32_t   *w_s16desc = nullptr; size_t w_s16desc_n = 0;	/* S16Desc per work item of the sweep */
+	/* ndbhip_ivf_share: a second handle on the same rows, planes and tables with scratch of its own (two batches in flight on
+	 * two streams without a second copy of the mirror).  shared_of: this handle borrows everything persistent from that one;
+	 * nshares: handles borrowing from this one.  Either way the persistent state is frozen (ivf_frozen). */
+	ndbhip_ivf *shared_of = nullptr;
+	int			nshares = 0;
 	bool		s16_bigk_off = false;	/* this mirror's layout cannot serve k > 64 on the fp16 screen (no sublists, not centred): found out once */
 	uint32_t   *w_bmin = nullptr;	size_t w_bmin_n = 0;	/* [nq][S16_NB] smallest emitted a per hash bucket of positions */
 	/* split top-k of small batches: per-range records, counts, totals */
@@ -2025,6 +2030,32 @@ struct ndbhip_ivf
 	int64_t    *w_stotal = nullptr;	size_t w_stotal_n = 0;
 };
 
+
+/* every per-batch scratch array of a handle (pointer + element count `_n`): what ndbhip_ivf_share gives a new handle afresh
+ * and the only device memory such a handle frees.  (w_rnorm is not among them: the rows' norms, made once while norm_valid
+ * is false, are read by every later batch of the fp32 screen — persistent whatever its name says.) */
+#define NDB_IVF_SCRATCH(F) \
+	F(w_cdist) F(w_probes) F(w_candoff) F(w_dist) F(w_q) F(w_otid) F(w_odist) F(w_ocnt) \
+	F(w_gcnt) F(w_goff) F(w_pairs) F(w_qblock) F(w_qnorm) F(w_scrt) F(w_scrd) \
+	F(w_scrc) F(w_screc) F(w_cblock) F(w_tmin) F(w_qplanes) F(w_qn2) F(w_qexp) F(w_qthr) \
+	F(w_ecount) F(w_erec) F(w_eub) F(w_qcplanes) F(w_qcn2) F(w_qcexp) F(w_pslot) F(w_qoffs) \
+	F(w_amat) F(w_cfull) F(w_subdist) F(w_qev) F(w_ppart) F(w_seedmat) F(w_pdist) F(w_qpairs) \
+	F(w_qpn) F(w_qslot) F(w_wmask) F(w_wrec) F(w_overq) F(w_redo_q) F(w_redo_p) F(w_redo_out) \
+	F(w_redo_idx) F(w_qhat) F(w_qplanes_o) F(w_qn2_o) F(w_qexp_o) F(w_drop) F(w_s16desc) F(w_bmin) \
+	F(w_scand) F(w_sncand) F(w_stotal)
+
+/* a handle whose persistent state other handles read, or which reads another's: nothing may change or be built in it */
+static inline bool
+ivf_frozen(const ndbhip_ivf *ix)
+{
+	return ix->shared_of != nullptr || ix->nshares > 0;
+}
+#define IVF_NOT_FROZEN(ix, what)                                                                                        \
+	do {                                                                                                                \
+		if (ivf_frozen(ix))                                                                                             \
+			return fail(NDBHIP_ERR_STATE, "%s: the mirror is shared (ndbhip_ivf_share): destroy the shares first%s", what, \
+						(ix)->shared_of ? ", and do this on the handle they were made from" : "");                       \
+	} while (0)
 
 struct ndbhip_ivf;
 static int	ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vector<int64_t> &new_own);
@@ -2104,6 +2135,30 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 {
 	if (!ix)
 		return NDBHIP_OK;
+	if (ix->nshares > 0)
+		return fail(NDBHIP_ERR_STATE, "ndbhip_ivf_destroy: %d shares of this mirror are alive (ndbhip_ivf_share): destroy them first", ix->nshares);
+	if (ix->shared_of)
+	{
+		/* a share: its scratch, the matrices' per-batch tables, its pinned block — nothing persistent is its own */
+		if (g.inited)
+		{
+			(void) hipStreamSynchronize(g.stream);
+#define F(name) if (ix->name) (void) hipFree((void *) ix->name);
+			NDB_IVF_SCRATCH(F)
+#undef F
+			for (S16Mat *m : {&ix->dm_sub, &ix->dm_cent, &ix->dm_all, &ix->dm_seed})
+			{
+				void	   *ptrs[] = {m->meta, m->pairs, m->desc, m->heads, m->zero};
+
+				for (void *p : ptrs)
+					if (p) (void) hipFree(p);
+			}
+			if (ix->pin) (void) hipHostFree(ix->pin);
+		}
+		ix->shared_of->nshares--;
+		delete ix;
+		return NDBHIP_OK;
+	}
 	if (g.inited)
 	{
 		(void) hipStreamSynchronize(g.stream);
@@ -2130,12 +2185,63 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 	return NDBHIP_OK;
 }
 
+/* A second handle on the same mirror: rows, TIDs, planes, sublists, matrices — everything a search READS — are the
+ * source's own arrays; everything a batch WRITES (the NDB_IVF_SCRATCH arrays, the matrices' per-batch tables, the pinned
+ * result block, the heuristics' memory of earlier batches) is the new handle's.  What two batches in flight need
+ * (ndbhip_set_thread_stream: a thread, a stream and a handle each) without a second copy of a mirror that is 1.55 x its
+ * table.  Both handles are frozen while the share lives: loads, appends, deletes, builds and anything that would lay
+ * the planes out again return NDBHIP_ERR_STATE — run a batch of every kind the shares will serve on the source first
+ * (ndbhip_ivf_prepare, or one search), so that nothing is left to build. */
+extern "C" int
+ndbhip_ivf_share(ndbhip_ivf *src, ndbhip_ivf **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!src || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!src->loaded)
+		return fail(NDBHIP_ERR_STATE, "index not loaded");
+	if (src->shared_of)
+		return fail(NDBHIP_ERR_STATE, "ndbhip_ivf_share: make shares from the handle that owns the mirror");
+	if (!src->pend_list.empty())
+		return fail(NDBHIP_ERR_STATE, "source index has pending appends: search or export it first");
+	HIP_TRY(hipStreamSynchronize(g.stream));		/* (whatever the source still has in flight has written its tables) */
+	ndbhip_ivf *ix = new (std::nothrow) ndbhip_ivf(*src);
+
+	if (!ix)
+		return fail(NDBHIP_ERR_NOMEM, "out of host memory");
+#define F(name) ix->name = nullptr; ix->name##_n = 0;
+	NDB_IVF_SCRATCH(F)
+#undef F
+	for (S16Mat *m : {&ix->dm_sub, &ix->dm_cent, &ix->dm_all, &ix->dm_seed})
+	{
+		m->meta = nullptr; m->meta_n = 0;
+		m->pairs = nullptr; m->pairs_n = 0;
+		m->desc = nullptr; m->desc_n = 0;
+		m->heads = nullptr; m->heads_n = 0;
+		m->zero = nullptr; m->zero_n = 0;
+		m->nq = -1;
+	}
+	ix->pin = nullptr;
+	ix->pin_n = 0;
+	ix->d_vecs_alt = nullptr;		/* (the appends' second row buffer: a share takes no appends) */
+	ix->d_tids_alt = nullptr;
+	ix->alt_cap = 0;
+	ix->redo.clear();
+	ix->bat_subdist = nullptr;
+	ix->shared_of = src;
+	ix->nshares = 0;
+	src->nshares++;
+	*out = ix;
+	return NDBHIP_OK;
+}
+
 extern "C" int
 ndbhip_ivf_set_centroids(ndbhip_ivf *ix, const float *centroids, int ncent)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	if (!ix || !centroids || ncent < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	IVF_NOT_FROZEN(ix, "ndbhip_ivf_set_centroids");
 	ix->dm_cent_valid = false; ix->dm_all_valid = false;
 	if (ix->d_centroids)
 		HIP_TRY(hipFree(ix->d_centroids));
@@ -2228,6 +2334,7 @@ ndbhip_ivf_load(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owned,
 				const float *rows, const uint8_t *tids6, int64_t nrows)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_load");
 	if (!ix || !list_len || nrows < 0 || (nrows > 0 && (!rows || !tids6)))
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	int			rc = ivf_set_layout(ix, list_len, owned, nrows);
@@ -2306,6 +2413,7 @@ ndbhip_ivf_load_f16(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *owne
 					const uint16_t *rows_f16, const uint8_t *tids6, int64_t nrows)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_load_f16");
 	if (!ix || !list_len || nrows < 0 || (nrows > 0 && (!rows_f16 || !tids6)))
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (ix->dim % 64 != 0)
@@ -2345,6 +2453,7 @@ ndbhip_ivf_load_device(ndbhip_ivf *ix, const int64_t *list_len, const uint8_t *o
 					   const float *d_rows, const uint64_t *d_tids, int64_t nrows)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_load_device");
 	if (!ix || !list_len || nrows < 0 || (nrows > 0 && (!d_rows || !d_tids)))
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (((uintptr_t) d_rows & 15) != 0)
@@ -2770,6 +2879,7 @@ extern "C" int
 ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *removed)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_delete");
 	if (!ix || n < 0 || (n > 0 && !tids6))
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!ix->loaded)
@@ -2880,6 +2990,7 @@ extern "C" int
 ndbhip_ivf_append(ndbhip_ivf *ix, int list_id, const float *vec, const uint8_t *tid6)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_append");
 	if (!ix || !vec || !tid6)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!ix->loaded)
@@ -3177,8 +3288,12 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 	const bool	cen = ivf_s16_centered(ix, R);
 	const int	lay_cfg = (sub_cfg * 2 + (cen ? 1 : 0)) * 2 + (cosn ? 1 : 0);
 
-	if (ix->s16_valid && ix->s16_sub_cfg != lay_cfg)
+	if (ix->s16_valid && ix->s16_sub_cfg != lay_cfg && !ivf_frozen(ix))
 		ix->s16_valid = false;	/* the planes were laid out under other settings */
+	if (ix->s16_valid && ix->s16_sub_cfg != lay_cfg)
+		return fail(NDBHIP_ERR_STATE, "the mirror is shared (ndbhip_ivf_share) and its planes were laid out for another kind of search or under other settings");
+	if (!ix->s16_valid && ivf_frozen(ix))
+		return fail(NDBHIP_ERR_STATE, "the mirror is shared (ndbhip_ivf_share) and has no planes yet: ndbhip_ivf_prepare on the source before sharing");
 	if (!ix->s16_valid)
 	{
 		std::vector<uint32_t> bo;
@@ -3567,6 +3682,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	}
 	if (ipc)
 	{
+		if (!ix->ipc_valid && ivf_frozen(ix))
+			return fail(NDBHIP_ERR_STATE, "the mirror is shared (ndbhip_ivf_share): run an inner-product batch on the source before sharing");
 		if (!ix->ipc_valid)
 		{
 			/* once per version of the mirror / layout of the planes: M^2 and every plane row's M^2 - |x|^2 */
@@ -3675,6 +3792,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	{
 		const uint32_t ns = (uint32_t) g_s16c_sample, sstr = (ns + 63u) & ~63u;
 
+		if ((!ix->seed_valid || ix->seed_n != (int) ns) && ivf_frozen(ix))
+			return fail(NDBHIP_ERR_STATE, "the mirror is shared (ndbhip_ivf_share): run a batch on the source before sharing (its row sample is not there yet)");
 		if (!ix->seed_valid || ix->seed_n != (int) ns)
 		{
 			if (grow(ix->d_seedrows, ix->d_seedrows_n, (size_t) ns * dim)) return NDBHIP_ERR_HIP;
@@ -4812,6 +4931,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		S16Mat	   &cm = both ? ix->dm_all : ix->dm_cent;
 		const uint32_t astride = (uint32_t) (((both ? ncmp + ix->nsub_g : ncmp) + 63) & ~63);
 
+		if (!both && (!ix->dm_cent_valid || ix->dm_cent.n != ncmp || ix->dm_cent.src != ix->d_centroids) && ivf_frozen(ix))
+			return fail(NDBHIP_ERR_STATE, "the mirror is shared (ndbhip_ivf_share): run a batch on the source before sharing (the centroid matrix is not there yet)");
 		if (!both && (!ix->dm_cent_valid || ix->dm_cent.n != ncmp || ix->dm_cent.src != ix->d_centroids))
 		{
 			const int	rc = s16mat_prepare(ix->dm_cent, ix->d_centroids, ncmp, ix->dim);
@@ -5086,6 +5207,8 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		if (screen)
 		{
 			/* the largest row norm of the rows held here, once per version of the mirror */
+			if (!ix->norm_valid && ivf_frozen(ix))
+				return fail(NDBHIP_ERR_STATE, "the mirror is shared (ndbhip_ivf_share): run a batch of this kind on the source before sharing (the row norms are not there yet)");
 			if (!ix->norm_valid)
 			{
 				if (!ix->d_xxmax)

@@ -598,6 +598,7 @@ extern "C" int
 ndbhip_ivf_insert(ndbhip_ivf *ix, const float *vec, const uint8_t *tid6, int *list_out)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_insert");
 	if (!ix || !vec || !tid6)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!ix->loaded || ix->ncent < 1)
@@ -1213,6 +1214,7 @@ extern "C" int
 ndbhip_ivf_build(ndbhip_ivf *ix, const float *rows, const uint8_t *tids6, int64_t nrows, int max_iter, int *out_iters)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_build");
 	if (!ix || !rows || !tids6 || nrows < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	float	   *d_rows = nullptr;
@@ -1275,6 +1277,7 @@ extern "C" int
 ndbhip_ivf_build_device(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_tids, int64_t nrows,
 						int max_iter, int *out_iters)
 {
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_build_device");
 	return ivf_build_rows(ix, d_rows, d_tids, nrows, max_iter, out_iters, nullptr, nullptr);
 }
 
@@ -1453,6 +1456,7 @@ ndbhip_ivf_build_sharded(ndbhip_ivf *ix, const float *d_rows, const uint64_t *d_
 						 int max_iter, int *out_iters, uint8_t *out_owned)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (ix) IVF_NOT_FROZEN(ix, "ndbhip_ivf_build_sharded");
 	const int	W = ndbhip_comm_world(), me = ndbhip_comm_rank();
 
 	if (W <= 1)

@@ -37,7 +37,7 @@ class IvfIndex:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().ndbhip_ivf_destroy(self._h)
+            check(lib().ndbhip_ivf_destroy(self._h))      # (refused while shares of this mirror are alive: close them first)
             self._h = None
 
     def __del__(self):
@@ -147,6 +147,17 @@ class IvfIndex:
         removed = C.c_int64(0)
         check(lib().ndbhip_ivf_delete(self._h, _ptr(t6), t6.shape[0], C.byref(removed)))
         return int(removed.value)
+
+    def share(self):
+        """A second handle on this mirror with scratch of its own (ndbhip_ivf_share): for a second batch in flight on another
+        thread and stream.  Both handles are frozen (no loads, appends, deletes, builds) until the share is closed; close
+        the shares before this index."""
+        h = C.c_void_p()
+        check(lib().ndbhip_ivf_share(self._h, C.byref(h)))
+        sub = IvfIndex.__new__(IvfIndex)
+        sub.dim, sub.nlists, sub._h, sub._keep = self.dim, self.nlists, h, [self]
+        sub.ncent = getattr(self, "ncent", self.nlists)
+        return sub
 
     def to_f16(self, reference_encoder=True):
         """Halfvec twin of this float4 mirror (rows narrowed on the device; ndbhip_ivf_to_f16)."""
