@@ -399,19 +399,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    inflight = max(1, args.inflight) if (not use_dist and args.rows == "f32") else 1
+    inflight = max(1, args.inflight) if not use_dist else 1
     mirrors, lanes = [ix], []
     if inflight > 1:
-        # the other steps in flight search mirrors of their own (built like the first: the build is deterministic)
+        # the other steps in flight search SHARES of the mirror (ndbhip_ivf_share: the same rows, planes and tables, scratch
+        # of their own); a share builds nothing, so the source runs one batch first (matrices, samples, constants)
         import threading
-        base2 = make_data(n, dim, args.data, args.components, args.sigma, 0x5EED0001, 0x5EEDC0DE, dev)
+        step(queries[:nq])
+        torch.cuda.synchronize()
         for _ in range(inflight - 1):
-            m = IvfIndex(dim, nlists, device=local_rank)
-            m.build_device(base2, tids_all, 50)
-            m.prepare(strategy)
-            mirrors.append(m)
-        check(lib().ndbhip_synchronize())
-        del base2
+            mirrors.append(ix.share())
         for w in range(inflight):
             lanes.append({"stream": torch.cuda.Stream(), "t": torch.zeros_like(out_t), "d": torch.zeros_like(out_d),
                           "c": torch.zeros_like(out_c)})
@@ -796,7 +793,7 @@ def main():
                 c4 = {"skipped": f"{free_b / 2**30:.0f} GiB free on the device, the leg needs about {need_b / 2**30:.0f} GiB"}
             else:
                 # BASELINE.md C4's table on ONE GPU (it names 8: `--gpus N` shards this same table, and N = 1 of that is this)
-                c4 = l2_table_leg(args, dev, args.c4_nvec, 768, 4096, 32, 10, 4096, 4096, 0.1, steps=5, warm=2, nreplay=4, recall_q=32,
+                c4 = l2_table_leg(args, dev, args.c4_nvec, 768, 4096, 32, 10, 4096, 4096, 0.1, steps=9, warm=2, nreplay=4, recall_q=32, inflight=max(1, args.inflight),
                                   label=f"IVFFlat {args.c4_nvec}x768 fp32 lists=4096 probes=32 k=10 L2, 4096 queries/step, clustered "
                                         f"(4096 components, sigma 0.1), one GPU (BASELINE.md C4 names 8)")
         except Exception as e:
@@ -827,7 +824,7 @@ def main():
             "config": {"workload": f"IVFFlat {n}x{dim} {'fp32' if esz == 4 else 'fp16'} lists={nlists} probes={nprobe} "
                                    f"k={k} {args.strategy.upper()}, "
                                    f"{nq} queries/step, exact fp32-sequential arithmetic (bit-identical to the CPU path)",
-                       "steps_in_flight": (f"{inflight}: {inflight} mirrors of the index, each driven by a host thread on a stream of its "
+                       "steps_in_flight": (f"{inflight}: {inflight} handles on ONE mirror of the index (ndbhip_ivf_share), each driven by a host thread on a stream of its "
                                            f"own (ndbhip_set_thread_stream) — a step's per-query chains run under another step's sweep, "
                                            f"the sweeps queue up; `serial` = one step after the other" if inflight > 1 else "1"),
                        "sharding": "none" if not use_dist else
@@ -1027,8 +1024,55 @@ def gauss_leg(args, dev, steps=3, nrecall=100, nparity=128, kind="gauss"):
             "oracle_parity": {"queries": nparity, "mismatches": int(bad)}}
 
 
+def steps_in_flight(ix, nlanes, q, nq, first, count, strategy, P, K, dev, warm=2):
+    """`count` batches (q[(first + s) * nq : ...], s = 0 .. count - 1) with `nlanes` of them in flight: the source handle and
+    nlanes - 1 shares of it (ndbhip_ivf_share: the same rows, planes and tables, scratch of their own), a host thread and a
+    stream each (ndbhip_set_thread_stream).  Returns (seconds per step, the last batch's results per lane as
+    [(step, tids, dist bits, counts)]).  The source must have run a batch of this kind already (a share builds nothing)."""
+    import threading
+    from neurondb_amd._lib import check, lib
+    handles = [ix] + [ix.share() for _ in range(nlanes - 1)]
+    streams = [torch.cuda.Stream() for _ in range(nlanes)]
+    bufs = [(torch.zeros((nq, K), dtype=torch.int64, device=dev), torch.zeros((nq, K), dtype=torch.float32, device=dev),
+             torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in range(nlanes)]
+    err, last = [], [None] * nlanes
+
+    def run(lo, n_):
+        def lane(w):
+            try:
+                check(lib().ndbhip_set_thread_stream(streams[w].cuda_stream))
+                for s_ in range(lo + w, lo + n_, nlanes):
+                    handles[w].search_device(q[s_ * nq:(s_ + 1) * nq], *bufs[w], strategy, P, K, 0)
+                    last[w] = s_
+                check(lib().ndbhip_synchronize())
+                check(lib().ndbhip_set_thread_stream(None))
+            except Exception as e:          # noqa: BLE001
+                err.append(e)
+        th = [threading.Thread(target=lane, args=(w,)) for w in range(nlanes)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if err:
+            raise err[0]
+
+    try:
+        run(first - warm * nlanes if first >= warm * nlanes else first, min(warm * nlanes, count))      # (each lane's scratch grows here)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(first, count)
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - t0) / count
+        out = [(last[w], bufs[w][0].cpu().numpy().copy(), bufs[w][1].cpu().numpy().view(np.uint32).copy(), bufs[w][2].cpu().numpy().copy())
+               for w in range(nlanes) if last[w] is not None]
+    finally:
+        for h in handles[1:]:
+            h.close()
+    return ts, out
+
+
 def l2_table_leg(args, dev, n, dim, lists, P, K, nq, components, sigma, steps=5, warm=2, nreplay=8, recall_q=64, aniso=False,
-                 kind="clustered", label=""):
+                 kind="clustered", label="", inflight=1):
     """One float4 L2 table of another shape or another spread through the same timed step: build on the device, prepare,
     `steps` batches of `nq` queries, then recall@K of `recall_q` queries against a float64 brute force over the rows, which
     sweep ran, how many (row, pair) elements the bounds excluded, and the CPU oracle's answers for `nreplay` queries over
@@ -1065,6 +1109,20 @@ def l2_table_leg(args, dev, n, dim, lists, P, K, nq, components, sigma, steps=5,
     ts = (time.perf_counter() - t0) / steps
     check(lib().ndbhip_profile(0))
     st = _lib.stats()
+    flight = None
+    if inflight > 1:
+        # the same steps with `inflight` of them in flight on shares of this mirror; every lane's last batch must be what
+        # the serial loop gives for that batch
+        tf, lasts = steps_in_flight(ix, inflight, q, nq, warm, steps, 1, P, K, dev)
+        same = True
+        for s_, lt, ld, lc in lasts:
+            ix.search_device(q[s_ * nq:(s_ + 1) * nq], ot, od, oc, 1, P, K, 0)
+            torch.cuda.synchronize()
+            same = same and np.array_equal(ot.cpu().numpy(), lt) and np.array_equal(od.cpu().numpy().view(np.uint32), ld) and \
+                np.array_equal(oc.cpu().numpy(), lc)
+        flight = {"steps_in_flight": inflight, "queries_per_s": round(nq / tf, 1), "ms_per_step": round(tf * 1e3, 3),
+                  "identical_to_serial": bool(same),
+                  "how": "ndbhip_ivf_share: handles on ONE mirror, a host thread and a stream each"}
     qs = q[(warm + steps) * nq:(warm + steps + 1) * nq]
     ix.search_device(qs, ot, od, oc, 1, P, K, 0)
     torch.cuda.synchronize()
@@ -1118,7 +1176,10 @@ def l2_table_leg(args, dev, n, dim, lists, P, K, nq, components, sigma, steps=5,
     a2 = copy.copy(args)
     a2.dim, a2.nvec, a2.lists, a2.batch, a2.probes, a2.k = dim, n, lists, nq, P, K
     return {"workload": label or f"IVFFlat {n}x{dim} fp32 lists={lists} probes={P} k={K} L2, {nq} queries/step",
-            "queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3), "steps": steps,
+            "queries_per_s": flight["queries_per_s"] if flight else round(nq / ts, 1),
+            "ms_per_step": flight["ms_per_step"] if flight else round(ts * 1e3, 3), "steps": steps,
+            "in_flight": flight,
+            "serial": {"queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3)} if flight else None,
             "recall_at_10": round(recall, 4), "kmeans_iterations": int(iters), "build_and_prepare_s": round(tb, 3),
             "lists_nonempty": int((ll > 0).sum()), "list_len_max": int(ll.max()),
             "sweep": which, "sweep_ms": round(st["scan_kernel_ms"] / launches, 4),
@@ -1192,6 +1253,20 @@ def c5_leg(args, dev, n, steps=20, warm=3, nreplay=8):
     ts = (time.perf_counter() - t0) / steps
     check(lib().ndbhip_profile(0))
     st = _lib.stats()
+    flight = None
+    # (batches of 256: a step is a chain of small kernels at their latency floor — twice the lanes of the 4096-query steps)
+    nfl = 2 * max(1, getattr(args, "inflight", 1)) if getattr(args, "inflight", 1) > 1 else 1
+    if nfl > 1:
+        tf, lasts = steps_in_flight(ix, nfl, q, nq, warm, steps, strategy, P, K, dev)
+        same = True
+        for s_, lt, ld, lc in lasts:
+            ix.search_device(q[s_ * nq:(s_ + 1) * nq], ot, od, oc, strategy, P, K, 0)
+            torch.cuda.synchronize()
+            same = same and np.array_equal(ot.cpu().numpy(), lt) and np.array_equal(od.cpu().numpy().view(np.uint32), ld) and \
+                np.array_equal(oc.cpu().numpy(), lc)
+        flight = {"steps_in_flight": nfl, "queries_per_s": round(nq / tf, 1), "ms_per_step": round(tf * 1e3, 3),
+                  "identical_to_serial": bool(same),
+                  "how": "ndbhip_ivf_share: handles on ONE mirror, a host thread and a stream each"}
     # parity 1: the last batch again, screened vs the exact scan
     qs = q[(warm + steps) * nq:(warm + steps + 1) * nq]
     ix.search_device(qs, ot, od, oc, strategy, P, K, 0)
@@ -1240,7 +1315,10 @@ def c5_leg(args, dev, n, steps=20, warm=3, nreplay=8):
     a5.dim, a5.strategy, a5.rows, a5.nvec, a5.lists, a5.batch, a5.probes, a5.k = dim, "ip", "f16", n, lists, nq, P, K
     return {"workload": f"IVFFlat {n}x{dim} halfvec lists={lists} probes={P} k={K} inner product, {nq} queries/step, "
                         f"clustered ({lists} components, sigma 0.1), one GPU (BASELINE.md C5 names 8)",
-            "queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3), "steps": steps,
+            "queries_per_s": flight["queries_per_s"] if flight else round(nq / ts, 1),
+            "ms_per_step": flight["ms_per_step"] if flight else round(ts * 1e3, 3), "steps": steps,
+            "in_flight": flight,
+            "serial": {"queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3)} if flight else None,
             "build_vectors_per_s": round(n / tb, 1), "kmeans_iterations": int(iters),
             "list_len_min_mean_max": [int(ll.min()), float(ll.mean()), int(ll.max())],
             "screen16": {"batches": int(st.get("screen16_batches", 0)), "fallbacks": int(st.get("screen16_fallbacks", 0)),
