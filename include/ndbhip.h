@@ -590,6 +590,12 @@ int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries,
 int			ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
 												   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 												   uint64_t *d_out_tids, int64_t *d_out_evals);
+/* A second HANDLE on the same graph (rows, levels, neighbour lists, TIDs, walk rows) with a workspace of its own — visited
+ * maps, result blocks —: two batches of searches in flight, a host thread, a stream (ndbhip_set_thread_stream) and a handle
+ * each (a batch ends with its longest walks; the next one's fill the device meanwhile).  Both handles are frozen while the
+ * share lives (loads, inserts, builds, deletes: NDBHIP_ERR_STATE); ndbhip_hnsw_destroy of the source is refused until its
+ * shares are gone.  Walk rows are made by the source's first ndbhip_hnsw_search_intended_w16_device, before sharing. */
+int			ndbhip_hnsw_share(ndbhip_hnsw *src, ndbhip_hnsw **out);
 /* bit 0: the heuristic (else the nearest); bit 1: a new node takes up to 2m links at level 0 instead of m; bit 2 (with
  * bit 0): the places the heuristic leaves empty go to the nearest candidates it passed over (keepPrunedConnections). */
 int			ndbhip_hnsw_set_intended_select(int select);

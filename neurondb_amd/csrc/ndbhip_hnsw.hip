@@ -2262,7 +2262,22 @@ struct ndbhip_hnsw
 	uint32_t   *w_vbits = nullptr;	size_t w_vbits_n = 0;	/* hnsw_search_layer: per-block visited bitmaps, all-zero at rest */
 	uint32_t   *w_vlog = nullptr;	size_t w_vlog_n = 0;
 	void	   *pin = nullptr;		size_t pin_n = 0;		/* pinned host block of the host-pointer search: queries + results */
+	/* ndbhip_hnsw_share: a second handle on the same graph with a workspace of its own (see ndbhip_ivf_share) */
+	ndbhip_hnsw *shared_of = nullptr;
+	int			nshares = 0;
 };
+
+static inline bool
+hnsw_frozen(const ndbhip_hnsw *h)
+{
+	return h->shared_of != nullptr || h->nshares > 0;
+}
+#define HNSW_NOT_FROZEN(h, what)                                                                                        \
+	do {                                                                                                                \
+		if ((h) && hnsw_frozen(h))                                                                                      \
+			return fail(NDBHIP_ERR_STATE, "%s: the graph is shared (ndbhip_hnsw_share): destroy the shares first%s", what, \
+						(h)->shared_of ? ", and do this on the handle they were made from" : "");                        \
+	} while (0)
 
 extern "C" int
 ndbhip_hnsw_create(int dim, int m, ndbhip_hnsw **out)
@@ -2304,6 +2319,23 @@ ndbhip_hnsw_destroy(ndbhip_hnsw *h)
 {
 	if (!h)
 		return NDBHIP_OK;
+	if (h->nshares > 0)
+		return fail(NDBHIP_ERR_STATE, "ndbhip_hnsw_destroy: %d shares of this graph are alive (ndbhip_hnsw_share): destroy them first", h->nshares);
+	if (h->shared_of)
+	{
+		if (g.inited)
+		{
+			(void) hipStreamSynchronize(g.stream);
+			void	   *ptrs[] = {h->w_q, h->w_ob, h->w_od, h->w_oc, h->w_ot, h->w_os, h->w_vbits, h->w_vlog};
+
+			for (void *p : ptrs)
+				if (p) (void) hipFree(p);
+			if (h->pin) (void) hipHostFree(h->pin);
+		}
+		h->shared_of->nshares--;
+		delete h;
+		return NDBHIP_OK;
+	}
 	if (g.inited)
 	{
 		(void) hipStreamSynchronize(g.stream);
@@ -2318,12 +2350,58 @@ ndbhip_hnsw_destroy(ndbhip_hnsw *h)
 	return NDBHIP_OK;
 }
 
+static int hnsw_densify(ndbhip_hnsw *h);
+
+/* A second handle on the same graph (node rows, levels, neighbour lists, TIDs, the fp16 walk rows if they exist): a
+ * workspace of its own — visited maps, result blocks — and nothing else.  Two batches of searches in flight (a host
+ * thread, a stream — ndbhip_set_thread_stream — and a handle each): a batch ends with its longest walks, the next one's
+ * fill the device meanwhile.  Both handles are frozen while the share lives (NDBHIP_ERR_STATE from loads, inserts, builds,
+ * deletes); walk rows are made on the source by its first ndbhip_hnsw_search_intended_w16_device, before sharing. */
+extern "C" int
+ndbhip_hnsw_share(ndbhip_hnsw *src, ndbhip_hnsw **out)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!src || !out)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (!src->loaded)
+		return fail(NDBHIP_ERR_STATE, "graph not loaded");
+	if (src->shared_of)
+		return fail(NDBHIP_ERR_STATE, "ndbhip_hnsw_share: make shares from the handle that owns the graph");
+	if (!src->nshares)
+	{
+		const int	rc = hnsw_densify(src);		/* (the layout every search reads: made once, here, not under a share) */
+
+		if (rc)
+			return rc;
+	}
+	HIP_TRY(hipStreamSynchronize(g.stream));
+	ndbhip_hnsw *h = new (std::nothrow) ndbhip_hnsw(*src);
+
+	if (!h)
+		return fail(NDBHIP_ERR_NOMEM, "out of host memory");
+	h->w_q = nullptr; h->w_q_n = 0;
+	h->w_ob = nullptr; h->w_ob_n = 0;
+	h->w_od = nullptr; h->w_od_n = 0;
+	h->w_oc = nullptr; h->w_oc_n = 0;
+	h->w_ot = nullptr; h->w_ot_n = 0;
+	h->w_os = nullptr; h->w_os_n = 0;
+	h->w_vbits = nullptr; h->w_vbits_n = 0;
+	h->w_vlog = nullptr; h->w_vlog_n = 0;
+	h->pin = nullptr; h->pin_n = 0;
+	h->shared_of = src;
+	h->nshares = 0;
+	src->nshares++;
+	*out = h;
+	return NDBHIP_OK;
+}
+
 extern "C" int
 ndbhip_hnsw_load(ndbhip_hnsw *h, uint32_t nblocks, const float *vecs, const int32_t *levels,
 				 const int16_t *ncount, const int64_t *nbr_off, const uint32_t *nbrs, const uint8_t *tids6,
 				 uint32_t entry_point, int entry_level)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_load");
 	if (!h || nblocks < 1 || !vecs || !levels || !ncount || !nbr_off || !tids6)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	const int64_t nn = nbr_off[nblocks];
@@ -2641,6 +2719,7 @@ extern "C" int
 ndbhip_hnsw_build_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 						 const int32_t *levels, int ef_construction)
 {
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_build_device");
 	return hnsw_insert_rows(h, d_rows, d_tids, n, levels, ef_construction, 0);
 }
 
@@ -2649,6 +2728,7 @@ extern "C" int
 ndbhip_hnsw_insert_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 						  const int32_t *levels, int ef_construction)
 {
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_insert_device");
 	if (!h)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!h->loaded || h->nblocks < 1)
@@ -2662,6 +2742,7 @@ ndbhip_hnsw_insert(ndbhip_hnsw *h, const float *rows, const uint8_t *tids6, uint
 				   int ef_construction)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_insert");
 	if (!h || !rows || !tids6 || !levels || n < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	float	   *d_rows = nullptr;
@@ -2860,6 +2941,8 @@ hnsw_densify(ndbhip_hnsw *h)
 {
 	if (h->dense)
 		return 0;
+	if (hnsw_frozen(h))
+		return fail(NDBHIP_ERR_STATE, "the graph is shared (ndbhip_hnsw_share) and its neighbour lists are not in the dense layout");
 	const uint32_t nb = h->nblocks;
 	const int	m2 = 2 * h->m;
 	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * m2;
@@ -2882,6 +2965,7 @@ extern "C" int
 ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *removed)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_delete");
 	if (!h || n < 0 || (n > 0 && !tids6))
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!h->loaded)
@@ -3024,6 +3108,7 @@ extern "C" int
 ndbhip_hnsw_set_dead_flags(ndbhip_hnsw *h, const uint8_t *dead)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_set_dead_flags");
 	if (!h || !h->loaded || !dead)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!h->d_dead)
@@ -3373,6 +3458,7 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 								  const int32_t *levels, int ef_construction, int batch_div, int batch_max)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_build_intended_device");
 	if (!h || !d_rows || !d_tids || !levels || n < 1)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (ef_construction < 4 || ef_construction > NDBHIP_MAX_EF)
@@ -3695,6 +3781,8 @@ h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int ef, 
 	{
 		if (h->dim % 4 != 0 || h->dim > 64 * H2_QREG)
 			return fail(NDBHIP_ERR_UNSUPPORTED, "walk rows need dim %% 4 == 0 and dim <= %d (dim = %d)", 64 * H2_QREG, h->dim);
+		if ((!h->d_vecs16 || h->w16_blocks != h->nblocks) && hnsw_frozen(h))
+			return fail(NDBHIP_ERR_STATE, "the graph is shared (ndbhip_hnsw_share) and has no walk rows: run ndbhip_hnsw_search_intended_w16_device on the source before sharing");
 		if (!h->d_vecs16 || h->w16_blocks != h->nblocks)
 		{
 			/* (rows are only ever appended: a twin that covers fewer blocks than the graph is stale as a whole — made again) */

@@ -29,8 +29,18 @@ class HnswIndex:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().ndbhip_hnsw_destroy(self._h)
+            check(lib().ndbhip_hnsw_destroy(self._h))     # (refused while shares of this graph are alive: close them first)
             self._h = None
+
+    def share(self):
+        """A second handle on this graph with a workspace of its own (ndbhip_hnsw_share): for a second batch of searches in
+        flight on another thread and stream.  Both handles are frozen until the share is closed; close it before this one."""
+        h = C.c_void_p()
+        check(lib().ndbhip_hnsw_share(self._h, C.byref(h)))
+        sub = HnswIndex.__new__(HnswIndex)
+        sub.dim, sub.m, sub._h, sub._src = self.dim, self.m, h, self
+        sub.nblocks = getattr(self, "nblocks", None)
+        return sub
 
     def __del__(self):
         try:

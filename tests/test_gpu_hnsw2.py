@@ -128,3 +128,52 @@ def test_intended_graph_finds_the_neighbours(kind):
     ex = np.sqrt(d2[i, ob[i, :oc[i]].astype(np.int64) - 1])
     assert np.allclose(od[i, :oc[i]], ex, rtol=1e-6)
     ix.close()
+
+
+def test_two_batches_of_walks_in_flight_on_shares_of_one_graph():
+    """ndbhip_hnsw_share: handles on the same graph with workspaces of their own, a thread and a stream each; what the
+    lanes return is what the same batches return one after the other (and the oracle's, by the tests above); a shared graph
+    is frozen."""
+    import threading
+    import torch
+    from neurondb_amd import HnswIndex, _lib
+    from neurondb_amd._lib import NdbHipError
+    from oracle import ndbo
+    n, dim, m = 6000, 96, 8
+    base, q, levels = _data("clustered", n, dim, 600, seed=12)
+    ix = HnswIndex(dim, m)
+    ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, 64)
+    batches = [q[i * 100:(i + 1) * 100] for i in range(6)]
+    for w16 in (False, True):
+        want = [ix.search_intended(b, 48, 10, walk16=w16) for b in batches]
+        handles = [ix, ix.share()]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got, err = [None] * len(batches), []
+
+        def lane(w):
+            try:
+                _lib.check(_lib.lib().ndbhip_set_thread_stream(streams[w].cuda_stream))
+                with torch.cuda.stream(streams[w]):          # (the wrapper's own tensor work goes to the lane's stream too)
+                    for rep in range(3):
+                        for b in range(w, len(batches), 2):
+                            got[b] = handles[w].search_intended(batches[b], 48, 10, walk16=w16)
+                _lib.check(_lib.lib().ndbhip_set_thread_stream(None))
+            except Exception as e:          # noqa: BLE001
+                err.append(e)
+
+        th = [threading.Thread(target=lane, args=(w,)) for w in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not err, err
+        for g_, w_ in zip(got, want):
+            for x, y in zip(g_, w_):
+                assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+        with pytest.raises(NdbHipError):
+            ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, 64)      # frozen
+        with pytest.raises(NdbHipError):
+            ix.close()                                                                   # a share is alive
+        handles[1].close()
+    ix.close()
+
