@@ -1215,7 +1215,7 @@ def sigma_sweep_leg(args, dev):
     return out
 
 
-def c5_leg(args, dev, n, steps=20, warm=3, nreplay=8):
+def c5_leg(args, dev, n, steps=24, warm=3, nreplay=8):
     """BASELINE.md's C5 on one GPU: 10M x 1536 halfvec rows, inner product, lists 4096, probes 32, k 10, batches of 256
     queries (the clustered generator with one component per list).  Build on the device, halfvec twin (round to
     nearest even), timed batches on the screened path, then parity two ways: the whole last batch against the library's
