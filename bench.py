@@ -1196,19 +1196,19 @@ def sigma_sweep_leg(args, dev):
     """the regime between the two tables of the line.  The headline shape (1M x 768, lists 1024, probes 32,
     k 10, 4096 queries a step) with the mixture's spread sigma from 0.1 (components apart: the headline) to 1.0 (components
     as wide as their centres are apart: nothing left of them in 768 dimensions), plus one anisotropic table (sigma 0.3, every
-    dimension d scaled by (d + 1)^-0.5).  Per table: queries/s, recall@10, the share of (row, pair) elements the bounds
-    excluded, which sweep ran, oracle parity."""
+    dimension d scaled by (d + 1)^-0.5).  Per table: queries/s (steps in flight like the line's `value`; `serial` beside it),
+    recall@10, the share of (row, pair) elements the bounds excluded, which sweep ran, oracle parity."""
     out = {}
     for sg in (0.1, 0.2, 0.3, 0.5, 1.0):
         try:
             out[f"sigma_{sg}"] = l2_table_leg(args, dev, args.nvec, args.dim, args.lists, args.probes, args.k, args.batch,
-                                              args.components, sg, steps=3, warm=2, nreplay=4, recall_q=32,
+                                              args.components, sg, steps=6, warm=2, nreplay=4, recall_q=32, inflight=max(1, args.inflight),
                                               label=f"mixture of {args.components} Gaussians, sigma {sg}")
         except Exception as e:
             out[f"sigma_{sg}"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         out["anisotropic_sigma_0.3"] = l2_table_leg(args, dev, args.nvec, args.dim, args.lists, args.probes, args.k, args.batch,
-                                                    args.components, 0.3, steps=3, warm=2, nreplay=4, recall_q=32, aniso=True,
+                                                    args.components, 0.3, steps=6, warm=2, nreplay=4, recall_q=32, aniso=True, inflight=max(1, args.inflight),
                                                     label=f"mixture of {args.components} Gaussians, sigma 0.3, dimension d scaled by (d+1)^-0.5")
     except Exception as e:
         out["anisotropic_sigma_0.3"] = {"error": f"{type(e).__name__}: {e}"}

@@ -2155,7 +2155,11 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			}
 			if (ix->pin) (void) hipHostFree(ix->pin);
 		}
-		ix->shared_of->nshares--;
+		{
+			std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
+			ix->shared_of->nshares--;
+		}
 		delete ix;
 		return NDBHIP_OK;
 	}
@@ -2230,7 +2234,11 @@ ndbhip_ivf_share(ndbhip_ivf *src, ndbhip_ivf **out)
 	ix->bat_subdist = nullptr;
 	ix->shared_of = src;
 	ix->nshares = 0;
-	src->nshares++;
+	{
+		std::lock_guard<std::mutex> lk(ndbhip_g_mtx);		/* (shares may be made and destroyed by different threads) */
+
+		src->nshares++;
+	}
 	*out = ix;
 	return NDBHIP_OK;
 }
@@ -3231,7 +3239,7 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 	if (ix->nrows < 1)
 		return false;
 	/* (64 < k <= 256: L2 on the centred planes over sublists only — ivf_s16_run sends anything else back) */
-	if (k > NDB_TOPK_FAST_MAXK && !(g_s16c_bigk && k <= NDB_S16_MAXK && R == R_IVF_L2 && !ix->s16_bigk_off))
+	if (k > NDB_TOPK_FAST_MAXK && !(g_s16c_bigk && k <= NDB_S16_MAXK && (R == R_IVF_L2 || (R == R_IVF_COS && g_s16_cos)) && !ix->s16_bigk_off))
 		return false;
 	if (ix->f16 && (ix->dim % 64) != 0)
 		return false;
@@ -3753,7 +3761,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
 	const bool	seed_by_sublist = ix->s16_sub && (R == R_IVF_L2 || (R == R_IVF_IP && cdist) || R == R_IVF_COS) && g_s16_prune && ix->nsub_g > 0;
 
-	if (k > NDB_TOPK_FAST_MAXK && !(cen && !xseed && !ipc && seed_by_sublist && R == R_IVF_L2))
+	if (k > NDB_TOPK_FAST_MAXK && !(cen && !ipc && seed_by_sublist && (R == R_IVF_L2 || cosb)))
 	{
 		/* 64 < k: thresholds come from the sublists' radii (k_s16c_thr_radius) — a layout without sublists, or not centred,
 		 * has nothing to take them from: this mirror's batches with k > 64 go to the fp32 screen, this one included */
@@ -4047,13 +4055,6 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 						else
 							S16C_SEED_L(true, false, S16C_SEED_SUB_ARGS);
 #undef S16C_SEED_SUB_ARGS
-						/* k > 64: no seed kernel holds k rows; the threshold comes from the buckets' radii */
-						if (k > NDB_TOPK_FAST_MAXK && !ipc && !cosb)
-							hipLaunchKernelGGL(k_s16c_thr_radius, dim3(nq), dim3(256), 0, g.stream, w_probes, lco, npr, (uint32_t) k,
-											   (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx, (const uint32_t *) ix->d_sub_len,
-											   (const uint32_t *) ix->d_sub_rad, (const int64_t *) ix->d_prow_off, (const uint32_t *) ix->d_pposof,
-											   subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2, (const uint32_t *) sub_xmax, dim,
-											   ix->w_qthr);
 					}
 				else
 				{
@@ -4069,6 +4070,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							  /* (the two-plane sweep pays for a looser threshold with emissions: measured 2.66 -> 2.59 M q/s at 32) */
 							  xseed ? cseeds : (uint32_t) S16_SEED);
 				}
+				/* k > 64: no seed kernel holds k rows; the threshold comes from the buckets' radii (L2, and cosine in the
+				 * normalised rows' space) */
+				if (k > NDB_TOPK_FAST_MAXK && cen && !ipc)
+					hipLaunchKernelGGL(k_s16c_thr_radius, dim3(nq), dim3(256), 0, g.stream, w_probes, lco, npr, (uint32_t) k,
+									   (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx, (const uint32_t *) ix->d_sub_len,
+									   (const uint32_t *) ix->d_sub_rad, (const int64_t *) ix->d_prow_off, (const uint32_t *) ix->d_pposof,
+									   subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2, (const uint32_t *) sub_xmax, dim,
+									   ix->w_qthr, cosb ? 1 : 0);
 				if (g_thr_hook)
 				{
 					thr_join.done = true;

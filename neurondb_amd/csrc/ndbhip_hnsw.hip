@@ -2332,7 +2332,11 @@ ndbhip_hnsw_destroy(ndbhip_hnsw *h)
 				if (p) (void) hipFree(p);
 			if (h->pin) (void) hipHostFree(h->pin);
 		}
-		h->shared_of->nshares--;
+		{
+			std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
+
+			h->shared_of->nshares--;
+		}
 		delete h;
 		return NDBHIP_OK;
 	}
@@ -2390,7 +2394,11 @@ ndbhip_hnsw_share(ndbhip_hnsw *src, ndbhip_hnsw **out)
 	h->pin = nullptr; h->pin_n = 0;
 	h->shared_of = src;
 	h->nshares = 0;
-	src->nshares++;
+	{
+		std::lock_guard<std::mutex> lk(ndbhip_g_mtx);		/* (shares may be made and destroyed by different threads) */
+
+		src->nshares++;
+	}
 	*out = h;
 	return NDBHIP_OK;
 }

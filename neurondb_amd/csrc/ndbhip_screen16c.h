@@ -1068,7 +1068,11 @@ k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ l
 				  const uint32_t *__restrict__ sub_rad, const int64_t *__restrict__ prow_off, const uint32_t *__restrict__ pposof,
 				  const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
 				  const float *__restrict__ cdist, uint32_t cstride, const float *__restrict__ qn2,
-				  const uint32_t *__restrict__ cxmax_bits, int dim, float2 *__restrict__ qthr)
+				  const uint32_t *__restrict__ cxmax_bits, int dim, float2 *__restrict__ qthr,
+				  int cos = 0 /* cosine on the centred sweep: centres, radii and distances are those of the NORMALISED rows and
+							   * queries (|q^ - x^|^2 = 2 x the cosine distance), the threshold converts with s16c_cos_t_from_ub; a
+							   * list that is its own bucket has no centre distance in that space (the centroid scan's is in the
+							   * rows' own): it is not taken */ )
 {
 	__shared__ uint32_t s_off[65], s_s0[64];
 	__shared__ float s_pd[64];
@@ -1149,7 +1153,7 @@ k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ l
 			const double u = (du + rad) * (du + rad) * (1.0 + 1e-9);
 			const float uf = s16_up((float) u);
 			/* (a centre or a radius beyond fp32, an empty bucket: never taken) */
-			const bool	good = sub_len[sx] > 0 && uf == uf && uf < 3.0e38f && uf >= 0.0f;
+			const bool	good = sub_len[sx] > 0 && uf == uf && uf < 3.0e38f && uf >= 0.0f && !(cos && gi < 0);
 
 			s_key[nb + t] = good ? __float_as_uint(uf) : 0xFFFFFFFFu;		/* uf >= 0: the bits order like the values */
 			s_sx[nb + t] = sx;
@@ -1211,7 +1215,8 @@ k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ l
 		{
 			if (tid == 0)
 			{
-				const float t = s16c_t_from_ub(__uint_as_float((uint32_t) (m >> 32)), dim);
+				const float ubk = __uint_as_float((uint32_t) (m >> 32));
+				const float t = cos ? s16c_cos_t_from_ub(ubk, dim) : s16c_t_from_ub(ubk, dim);
 				const float2 o = qthr[q];
 
 				qthr[q] = make_float2(fminf(o.x, t), o.y);

@@ -132,7 +132,7 @@ def test_a_mirror_without_sublists_sends_k_100_to_the_older_path_once(lib):
         assert_same_results(t, d, c, et, ed, ec)
         seen.append((st["screen16_batches"], st["screen16_fallbacks"]))
     assert seen[0] == (0, 1) and seen[1] == (0, 0), seen
-    for strategy in (2, 3):
+    for strategy in (3,):                # (inner product never tries; cosine does — and finds no sublists either)
         et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, strategy, nprobe, k)
         lib.check(lib.lib().ndbhip_stats_reset())
         t, d, c = ix.search(q, strategy, nprobe, k)
@@ -140,3 +140,35 @@ def test_a_mirror_without_sublists_sends_k_100_to_the_older_path_once(lib):
         assert_same_results(t, d, c, et, ed, ec)
         assert st["screen16_batches"] == 0 and st["screen16_fallbacks"] == 0, st
     ix.close()
+
+
+@pytest.mark.parametrize("wave", [False, True])
+@pytest.mark.parametrize("k,nprobe,dim", [(100, 6, 128), (256, 9, 64), (70, 5, 192)])
+def test_cosine_k_beyond_64(wave, k, nprobe, dim, lib):
+    """cosine on the centred planes of the normalised rows: the radius rule in that space (a list that is its own bucket has
+    no centre distance there and is not taken).  Wider clusters than `clustered` makes: rows that are near-copies of one
+    another leave more candidates inside the cosine bound's error than a query's buffer holds, k or no k."""
+    rng = np.random.default_rng(300 + k + dim)
+    comp = (rng.standard_normal((40, dim)) * 2).astype(np.float32)
+    rows, lens = [], []
+    for L in range(12):
+        mine = rng.choice(40, 1 + L % 4, replace=False)
+        n = 200 + 200 * len(mine)
+        r = (comp[mine[rng.integers(0, len(mine), n)]] * (1.0 + 0.5 * rng.random((n, 1))) + 0.4 * rng.standard_normal((n, dim))).astype(np.float32)
+        r[9] = r[4]
+        rows.append(r)
+        lens.append(n)
+    rows = np.concatenate(rows)
+    a = image(rows, lens)
+    nq = 150
+    q = (rows[rng.integers(0, len(rows), nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(np.float32)
+    et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, 2, nprobe, k)
+    _wave(lib, wave)
+    ix = index_of(a)
+    lib.check(lib.lib().ndbhip_stats_reset())
+    t, d, c = ix.search(q, 2, nprobe, k)
+    st = lib.stats()
+    assert_same_results(t, d, c, et, ed, ec)
+    assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, str({kk: v for kk, v in st.items() if v})
+    ix.close()
+
