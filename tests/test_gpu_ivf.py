@@ -761,7 +761,7 @@ def test_randomised_parity_campaign_all_scan_modes():
     grouped / per-query / auto) — the long runs are in profiles/r01l_fuzz_scan.txt."""
     import time
     from neurondb_amd import IvfIndex, _lib
-    from tools.fuzz_scan import one_case
+    from tools.fuzz_scan import one_case, reset_options
     rng = np.random.default_rng(12345)
     t0, n = time.time(), 0
     try:
@@ -769,7 +769,7 @@ def test_randomised_parity_campaign_all_scan_modes():
             one_case(rng, _lib.lib(), IvfIndex, _lib.check)
             n += 1
     finally:
-        _lib.check(_lib.lib().ndbhip_set_scan_mode(0))
+        reset_options(_lib.lib(), _lib.check)        # (one_case draws a dozen options: whatever the last case drew must not stay)
     assert n >= 20
 
 

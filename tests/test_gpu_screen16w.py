@@ -100,7 +100,8 @@ def test_wave_sweep_matches_the_oracle_in_every_form(wave, blocks, strategy, cap
     assert_same_results(t, d, c, et, ed, ec)
     # (cosine over rows that are near-copies of one another: more candidates inside the bound's error than a query's
     # survivor buffer holds, for the ring as for this kernel — the batch then goes to the older path, which is the design)
-    assert st["screen16_batches"] + st["screen16_fallbacks"] == 1 and (strategy == 2 or st["screen16_fallbacks"] == 0), st
+    assert st["screen16_batches"] + st["screen16_fallbacks"] == 1 and (strategy == 2 or st["screen16_fallbacks"] == 0), \
+        str({kk: v for kk, v in st.items() if v})
     # (a chunk = 64 dimensions: rows of one chunk have nothing to keep in flight and take the ring; the cosine plane of a
     # halfvec mirror is the older two-plane sweep's)
     if (dim + 63) // 64 >= 2 and not (strategy == 2 and half is not None):

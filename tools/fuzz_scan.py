@@ -50,6 +50,20 @@ def sharded_case(rng, ix, img, q, strategy, nprobe, k, cap, et, ed, ec):
         sh.close()
 
 
+# every option one_case draws, at the library's default: a campaign must leave the process as it found it (the `-m gpu`
+# suite runs a few seconds of this in the middle of everything else)
+DEFAULT_OPTIONS = {"screen16_sub_min": 256, "screen16_sub_rows": 128, "screen16_sublists": 1, "screen16_prune": 1,
+                   "screen16_tighten": 1, "screen16c_qb": 0, "screen16c_dense": 1, "screen16c_sample": 2048,
+                   "screen16c_tight": 128, "screen16_ip_centered": 1, "screen16_stage": 1, "screen16c_wave": 2,
+                   "screen16c_wave_blocks": 2, "screen16c_wave_min_nq": 1024, "screen16c_plane_seeds": 1, "screen16c_bigk": 1}
+
+
+def reset_options(lib, check):
+    for name, value in DEFAULT_OPTIONS.items():
+        check(lib.ndbhip_set_option(name.encode(), value))
+    check(lib.ndbhip_set_scan_mode(0))
+
+
 def one_case(rng, lib, IvfIndex, check):
     dim = int(rng.choice([64, 128, 192, 256, 768]))
     n = int(rng.integers(200, 5000))
