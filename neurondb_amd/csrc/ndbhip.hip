@@ -1966,6 +1966,7 @@ struct ndbhip_ivf
 	float		ipc_m2 = 0.0f;
 	uint32_t   *d_ipc_m2 = nullptr; size_t d_ipc_m2_n = 0;
 	float	   *d_rnx = nullptr; size_t d_rnx_n = 0;
+	float	   *d_bkt_rnxmax = nullptr; size_t d_bkt_rnxmax_n = 0;	/* [buckets] the largest of them per bucket (k > 64: k_s16c_thr_radius) */
 	float	   *w_qev = nullptr; size_t w_qev_n = 0;
 	uint32_t   *w_ppart = nullptr; size_t w_ppart_n = 0;	/* k_pair_part's block totals */
 	/* a sample of the mirror's rows as a matrix of their own: first thresholds of a dense batch (k_s16c_seed_sample) */
@@ -2175,7 +2176,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->w_qev, ix->w_ppart, ix->w_qoffs, ix->w_qslot, ix->w_wmask, ix->w_wrec};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->d_bkt_rnxmax, ix->w_qev, ix->w_ppart, ix->w_qoffs, ix->w_qslot, ix->w_wmask, ix->w_wrec};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3239,7 +3240,7 @@ ivf_s16_eligible(const ndbhip_ivf *ix, int nq, int R, int k)
 	if (ix->nrows < 1)
 		return false;
 	/* (64 < k <= 256: L2 on the centred planes over sublists only — ivf_s16_run sends anything else back) */
-	if (k > NDB_TOPK_FAST_MAXK && !(g_s16c_bigk && k <= NDB_S16_MAXK && (R == R_IVF_L2 || (R == R_IVF_COS && g_s16_cos)) && !ix->s16_bigk_off))
+	if (k > NDB_TOPK_FAST_MAXK && !(g_s16c_bigk && k <= NDB_S16_MAXK && (R == R_IVF_L2 || R == R_IVF_IP || (R == R_IVF_COS && g_s16_cos)) && !ix->s16_bigk_off))
 		return false;
 	if (ix->f16 && (ix->dim % 64) != 0)
 		return false;
@@ -3713,6 +3714,14 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) ix->d_ipc_m2, (const int64_t *) ix->d_prow_off, (int) ix->s16_prow.size() - 1,
 							   (const uint32_t *) ix->d_bucket_list, (const int64_t *) d.loc_off, d.own_len,
 							   (const uint32_t *) ix->d_pposof, ix->d_rnx);
+			{
+				const int	nbk = (int) ix->s16_prow.size() - 1;
+
+				if (grow(ix->d_bkt_rnxmax, ix->d_bkt_rnxmax_n, (size_t) std::max(nbk, 1))) return NDBHIP_ERR_HIP;
+				hipLaunchKernelGGL(k_ipc_bucket_max, dim3((unsigned) std::max(nbk, 1)), dim3(64), 0, g.stream, (const float *) ix->d_rnx,
+								   (const int64_t *) ix->d_prow_off, ix->s16_sub ? (const uint32_t *) ix->d_sub_len : (const uint32_t *) ix->d_plen,
+								   nbk, ix->d_bkt_rnxmax);
+			}
 			HIP_TRY(hipMemcpyAsync(&ix->ipc_m2, ix->d_ipc_m2, sizeof(float), hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
 			big_free(x2);
@@ -3761,7 +3770,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (with regrouped planes and L2 the seeds come from the nearest sublist instead: k_s16_seed_sub, below) */
 	const bool	seed_by_sublist = ix->s16_sub && (R == R_IVF_L2 || (R == R_IVF_IP && cdist) || R == R_IVF_COS) && g_s16_prune && ix->nsub_g > 0;
 
-	if (k > NDB_TOPK_FAST_MAXK && !(cen && !ipc && seed_by_sublist && (R == R_IVF_L2 || cosb)))
+	if (k > NDB_TOPK_FAST_MAXK && !(cen && seed_by_sublist && (R == R_IVF_L2 || cosb || ipc)))
 	{
 		/* 64 < k: thresholds come from the sublists' radii (k_s16c_thr_radius) — a layout without sublists, or not centred,
 		 * has nothing to take them from: this mirror's batches with k > 64 go to the fp32 screen, this one included */
@@ -4072,12 +4081,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				}
 				/* k > 64: no seed kernel holds k rows; the threshold comes from the buckets' radii (L2, and cosine in the
 				 * normalised rows' space) */
-				if (k > NDB_TOPK_FAST_MAXK && cen && !ipc)
+				if (k > NDB_TOPK_FAST_MAXK && cen)
 					hipLaunchKernelGGL(k_s16c_thr_radius, dim3(nq), dim3(256), 0, g.stream, w_probes, lco, npr, (uint32_t) k,
 									   (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx, (const uint32_t *) ix->d_sub_len,
 									   (const uint32_t *) ix->d_sub_rad, (const int64_t *) ix->d_prow_off, (const uint32_t *) ix->d_pposof,
 									   subdist, sstride, pdist, cdist, cstride, (const float *) ix->w_qn2, (const uint32_t *) sub_xmax, dim,
-									   ix->w_qthr, cosb ? 1 : 0);
+									   ix->w_qthr, ipc ? (const float *) ix->d_bkt_rnxmax : (const float *) nullptr,
+									   ipc ? (const float *) ix->w_qev : (const float *) nullptr, cosb ? 1 : 0);
 				if (g_thr_hook)
 				{
 					thr_join.done = true;

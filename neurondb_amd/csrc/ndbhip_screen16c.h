@@ -1060,6 +1060,36 @@ k_s16c_seed_sample(const float *__restrict__ amat, uint32_t astride, uint32_t ns
  * neighbouring sublists) are cut by k_s16_finalize's k-th UPPER bound as ever.
  * One block per query; up to S16C_RAD_CAP buckets (more: the threshold stays where it was).  L2 only.
  */
+/* inner product: the largest M^2 - |x|^2 of every bucket's plane rows (holes and padding hold 0, which M^2 - |x|^2 never
+ * falls below); one wave a bucket */
+__global__ __launch_bounds__(64) void
+k_ipc_bucket_max(const float *__restrict__ rnx, const int64_t *__restrict__ prow_off, const uint32_t *__restrict__ blen, int nb,
+				 float *__restrict__ out)
+{
+	const int	b = blockIdx.x, lane = threadIdx.x;
+
+	if (b >= nb)
+		return;
+	const int64_t r0 = prow_off[b];
+	float		m = 0.0f;
+
+	for (uint32_t i = (uint32_t) lane; i < blen[b]; i += 64)
+	{
+		const float v = rnx[r0 + i];
+
+		m = v > m ? v : m;			/* (a NaN — a row beyond fp32 — never wins: its bucket's radius is +inf and rules it out) */
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const float o = __shfl_xor(m, off, 64);
+
+		m = o > m ? o : m;
+	}
+	if (lane == 0)
+		out[b] = m;
+}
+
 #define S16C_RAD_CAP 1024
 #define S16C_RAD_STEPS 32		/* buckets taken in order before giving up (k <= 256 needs a handful of ~128-row sublists) */
 __global__ __launch_bounds__(256) void
@@ -1069,6 +1099,10 @@ k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ l
 				  const float *__restrict__ subdist, uint32_t sstride, const float *__restrict__ pdist,
 				  const float *__restrict__ cdist, uint32_t cstride, const float *__restrict__ qn2,
 				  const uint32_t *__restrict__ cxmax_bits, int dim, float2 *__restrict__ qthr,
+				  const float *__restrict__ rnxmax = nullptr /* inner product on the centred sweep (thresholds in b's domain,
+															  * b = |q - x|^2 + M^2 - |x|^2): every bucket's largest M^2 - |x|^2
+															  * (k_ipc_bucket_max) goes on top of (|q - c| + rad)^2 ... */,
+				  const float *__restrict__ qev = nullptr /* ... and the threshold converts with s16c_ip_t_from_ub (ev per query) */,
 				  int cos = 0 /* cosine on the centred sweep: centres, radii and distances are those of the NORMALISED rows and
 							   * queries (|q^ - x^|^2 = 2 x the cosine distance), the threshold converts with s16c_cos_t_from_ub; a
 							   * list that is its own bucket has no centre distance in that space (the centroid scan's is in the
@@ -1150,7 +1184,7 @@ k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ l
 				du = (double) s_pd[lo] * (1.0 + 1e-3);
 			else
 				du = __builtin_sqrt((double) fmaxf(subdist[(size_t) q * sstride + gi], 0.0f) + (double) ec * (1.0 + 1e-6)) * (1.0 + 1e-9);
-			const double u = (du + rad) * (du + rad) * (1.0 + 1e-9);
+			const double u = ((du + rad) * (du + rad) + (rnxmax ? (double) rnxmax[sx] * (1.0 + 1e-6) : 0.0)) * (1.0 + 1e-9);
 			const float uf = s16_up((float) u);
 			/* (a centre or a radius beyond fp32, an empty bucket: never taken) */
 			const bool	good = sub_len[sx] > 0 && uf == uf && uf < 3.0e38f && uf >= 0.0f && !(cos && gi < 0);
@@ -1216,7 +1250,7 @@ k_s16c_thr_radius(const int *__restrict__ probes, const uint32_t *__restrict__ l
 			if (tid == 0)
 			{
 				const float ubk = __uint_as_float((uint32_t) (m >> 32));
-				const float t = cos ? s16c_cos_t_from_ub(ubk, dim) : s16c_t_from_ub(ubk, dim);
+				const float t = cos ? s16c_cos_t_from_ub(ubk, dim) : (rnxmax ? s16c_ip_t_from_ub(ubk, qev[q]) : s16c_t_from_ub(ubk, dim));
 				const float2 o = qthr[q];
 
 				qthr[q] = make_float2(fminf(o.x, t), o.y);

@@ -132,7 +132,7 @@ def test_a_mirror_without_sublists_sends_k_100_to_the_older_path_once(lib):
         assert_same_results(t, d, c, et, ed, ec)
         seen.append((st["screen16_batches"], st["screen16_fallbacks"]))
     assert seen[0] == (0, 1) and seen[1] == (0, 0), seen
-    for strategy in (3,):                # (inner product never tries; cosine does — and finds no sublists either)
+    for strategy in (3, 2):              # (the mirror is marked: inner product and cosine do not try either)
         et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, strategy, nprobe, k)
         lib.check(lib.lib().ndbhip_stats_reset())
         t, d, c = ix.search(q, strategy, nprobe, k)
@@ -170,5 +170,33 @@ def test_cosine_k_beyond_64(wave, k, nprobe, dim, lib):
     st = lib.stats()
     assert_same_results(t, d, c, et, ed, ec)
     assert st["screen16_batches"] == 1 and st["screen16_fallbacks"] == 0, str({kk: v for kk, v in st.items() if v})
+    ix.close()
+
+
+@pytest.mark.parametrize("wave", [False, True])
+@pytest.mark.parametrize("k,nprobe,dim,rowtype", [(100, 6, 128, "f32"), (256, 10, 64, "f32"), (128, 7, 128, "f16"), (65, 5, 192, "f32")])
+def test_inner_product_k_beyond_64(wave, k, nprobe, dim, rowtype, lib):
+    """inner product on the centred planes (thresholds in b's domain, b = |q - x|^2 + M^2 - |x|^2): the radius rule with every
+    bucket's largest M^2 - |x|^2 on top (k_ipc_bucket_max); float4 and halfvec rows"""
+    from oracle import ndbo
+    rng = np.random.default_rng(700 + k + dim)
+    rows, lens = clustered(rng, dim)
+    half = None
+    if rowtype == "f16":
+        half = rows.astype(np.float16).view(np.uint16)
+        lut = np.array([ndbo.lib().ndbo_fp16_to_float(int(v)) for v in range(65536)], np.float32)
+        rows = lut[half]
+    a = image(rows, lens)
+    nq = 150
+    q = (rows[rng.integers(0, len(rows), nq)] + 0.02 * rng.standard_normal((nq, dim))).astype(np.float32)
+    et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, 3, nprobe, k)
+    _wave(lib, wave)
+    ix = index_of(a, half)
+    lib.check(lib.lib().ndbhip_stats_reset())
+    t, d, c = ix.search(q, 3, nprobe, k)
+    st = lib.stats()
+    assert_same_results(t, d, c, et, ed, ec)
+    assert st["screen16_batches"] + st["screen16_fallbacks"] == 1 and (k < 100 or st["screen16_fallbacks"] == 0), \
+        str({kk: v for kk, v in st.items() if v})
     ix.close()
 
