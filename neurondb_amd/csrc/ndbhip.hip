@@ -2143,7 +2143,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 		/* a share: its scratch, the matrices' per-batch tables, its pinned block — nothing persistent is its own */
 		if (g.inited)
 		{
-			(void) hipStreamSynchronize(g.stream);
+			(void) hipDeviceSynchronize();		/* (its last batch may have run on another thread's stream) */
 #define F(name) if (ix->name) (void) hipFree((void *) ix->name);
 			NDB_IVF_SCRATCH(F)
 #undef F

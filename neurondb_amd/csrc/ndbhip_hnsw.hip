@@ -2325,7 +2325,7 @@ ndbhip_hnsw_destroy(ndbhip_hnsw *h)
 	{
 		if (g.inited)
 		{
-			(void) hipStreamSynchronize(g.stream);
+			(void) hipDeviceSynchronize();		/* (its last batch may have run on another thread's stream) */
 			void	   *ptrs[] = {h->w_q, h->w_ob, h->w_od, h->w_oc, h->w_ot, h->w_os, h->w_vbits, h->w_vlog};
 
 			for (void *p : ptrs)
