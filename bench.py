@@ -1123,6 +1123,9 @@ def l2_table_leg(args, dev, n, dim, lists, P, K, nq, components, sigma, steps=5,
         flight = {"steps_in_flight": inflight, "queries_per_s": round(nq / tf, 1), "ms_per_step": round(tf * 1e3, 3),
                   "identical_to_serial": bool(same),
                   "how": "ndbhip_ivf_share: handles on ONE mirror, a host thread and a stream each"}
+    # (what the leg reports is the faster of the two ways to run it: where the sweep is bound by the matrix cores and fills
+    # the device — the tables whose clusters have blurred — steps in flight only get in each other's way)
+    use_flight = bool(flight) and flight["ms_per_step"] < ts * 1e3
     qs = q[(warm + steps) * nq:(warm + steps + 1) * nq]
     ix.search_device(qs, ot, od, oc, 1, P, K, 0)
     torch.cuda.synchronize()
@@ -1176,8 +1179,9 @@ def l2_table_leg(args, dev, n, dim, lists, P, K, nq, components, sigma, steps=5,
     a2 = copy.copy(args)
     a2.dim, a2.nvec, a2.lists, a2.batch, a2.probes, a2.k = dim, n, lists, nq, P, K
     return {"workload": label or f"IVFFlat {n}x{dim} fp32 lists={lists} probes={P} k={K} L2, {nq} queries/step",
-            "queries_per_s": flight["queries_per_s"] if flight else round(nq / ts, 1),
-            "ms_per_step": flight["ms_per_step"] if flight else round(ts * 1e3, 3), "steps": steps,
+            "queries_per_s": flight["queries_per_s"] if use_flight else round(nq / ts, 1),
+            "ms_per_step": flight["ms_per_step"] if use_flight else round(ts * 1e3, 3), "steps": steps,
+            "mode": "steps in flight" if use_flight else "one step at a time",
             "in_flight": flight,
             "serial": {"queries_per_s": round(nq / ts, 1), "ms_per_step": round(ts * 1e3, 3)} if flight else None,
             "recall_at_10": round(recall, 4), "kmeans_iterations": int(iters), "build_and_prepare_s": round(tb, 3),
