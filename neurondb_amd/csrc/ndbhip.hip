@@ -3783,9 +3783,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 #define S16C_SEED_L(SUBB, PLL, ...)                                                                                     \
 	do {                                                                                                                \
-		if (ipc && H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 1>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
-		else if (ipc && H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 2>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
-		else if (ipc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 0>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);     \
+		if (ipc && H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 1, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else if (ipc && H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 2, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
+		else if (ipc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, true, 0, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);     \
 		else if (H == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 1, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
 		else if (H == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 2, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__); \
 		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_seed<SUBB, false, 0, PLL>), dim3(nq), dim3(S16C_SEED_THREADS), 0, g.stream, __VA_ARGS__);             \
@@ -4057,9 +4057,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 								subdist, sstride, pdist, cdist, cstride, ix->w_qthr,                                         \
 								(const float *) ix->w_qn2, (const uint32_t *) ix->d_ipc_m2, sub_rn2, (const float *) ix->d_cn2, \
 								(const unsigned char *) ix->d_planes, (const uint32_t *) ix->d_sub_blk, (const float *) ix->d_rn2, \
-								(const int16_t *) ix->d_rexp, (const float *const *) ix->d_sub_cptr, ndb_s16c_ce(dim)
-						/* (L2 on the centred planes: the seeds' bounds from block 0 of the nearest sublist's planes) */
-						if (g_s16c_plseed && !ipc && !cosb)
+								(const int16_t *) ix->d_rexp, (const float *const *) ix->d_sub_cptr, ndb_s16c_ce(dim),             \
+								ipc ? (const float *) ix->d_rnx : (const float *) nullptr
+						/* (L2 and inner product on the centred planes: the seeds' bounds from block 0 of the nearest sublist's planes) */
+						if (g_s16c_plseed && !cosb)
 							S16C_SEED_L(true, true, S16C_SEED_SUB_ARGS);
 						else
 							S16C_SEED_L(true, false, S16C_SEED_SUB_ARGS);

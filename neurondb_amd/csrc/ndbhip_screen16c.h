@@ -480,7 +480,8 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			/* PL: the centred planes and what goes with them (k_s16c_row_prep), the buckets' centres, c_E */
 			const unsigned char *__restrict__ planes = nullptr, const uint32_t *__restrict__ blk_off = nullptr,
 			const float *__restrict__ rn2 = nullptr, const int16_t *__restrict__ rexp = nullptr,
-			const float *const *__restrict__ cptr = nullptr, float cE = 0.0f)
+			const float *const *__restrict__ cptr = nullptr, float cE = 0.0f,
+			const float *__restrict__ rnx = nullptr /* PL with IP: M^2 - |x|^2 per padded plane row */ )
 {
 	const uint32_t q = blockIdx.x;
 	const int	lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -618,7 +619,7 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				row = ix.loc_off[probes[(size_t) q * npr + bp]] + pos;
 			}
 		}
-		if constexpr (PL && !IP)
+		if constexpr (PL)
 		{
 			/*
 			 * Plane seeds (r5).  The seed rows are the first rows of the nearest sublist: block 0 of that bucket's planes.
@@ -726,7 +727,9 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				const float nn = Q2 + X2;
 				const float av = nn - t1;
 				const float er = s16_up(s16_up(cE * nn) + NDB_S16_ABS);
-				const float ub = fmaxf(s16_up(s16_up(av + er)), 0.0f);
+				/* (inner product: the bound of b = |q - x|^2 + M^2 - |x|^2, the row's constant on top as the sweep's epilogue
+				 * puts it there; the threshold converts as k_s16_finalize's k-th upper bound does) */
+				const float ub = IP ? fmaxf(s16_up(s16_up(s16_up(av + er)) + rnx[pp] * 1.000001f), 0.0f) : fmaxf(s16_up(s16_up(av + er)), 0.0f);
 				const bool	good = ok && lane < 32 && ub == ub && (ub - ub) == 0.0f;
 				const uint32_t key = good ? __float_as_uint(ub) : 0xFFFFFFFFu;
 				uint32_t	rank = 0;
@@ -741,7 +744,11 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 				float		t = __uint_as_float(0x7F800000u);	/* +inf: fewer than k usable seeds */
 
 				if (pick)
-					t = s16c_t_from_ub(__shfl(ub, __ffsll((long long) pick) - 1, 64), dim);
+				{
+					const float ubk = __shfl(ub, __ffsll((long long) pick) - 1, 64);
+
+					t = IP ? s16c_ip_t_from_ub(ubk, s16c_ip_ev(dim, qn2[q], __uint_as_float(*m2_bits))) : s16c_t_from_ub(ubk, dim);
+				}
 				if (lane == 0)
 					qthr[q] = make_float2(t, 0.0f);
 				return;
