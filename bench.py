@@ -415,19 +415,27 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(first, count):
-        """steps first .. first + count - 1, `inflight` at a time (step s on mirror s % inflight)"""
+        """steps first .. first + count - 1, `inflight` at a time: every lane takes the next step that nobody has taken yet
+        (a lane that falls behind does not leave its share of the steps for the end)"""
         if inflight == 1:
             for s in range(first, first + count):
                 step(queries[s * nq:(s + 1) * nq])
             return
         err = []
+        nxt, nxt_lock = [first], threading.Lock()
 
         def lane(w):
             try:
                 ln = lanes[w]
                 check(lib().ndbhip_set_thread_stream(C.c_void_p(ln["stream"].cuda_stream)))
-                for s in range(first + w, first + count, inflight):
+                while True:
+                    with nxt_lock:
+                        s = nxt[0]
+                        nxt[0] += 1
+                    if s >= first + count:
+                        break
                     mirrors[w].search_device(queries[s * nq:(s + 1) * nq], ln["t"], ln["d"], ln["c"], strategy, nprobe, k, 0)
+                    ln["last"] = s
                 check(lib().ndbhip_synchronize())
                 check(lib().ndbhip_set_thread_stream(None))
             except Exception as e:              # (surfaced by the caller: a lane must not die silently)
@@ -457,6 +465,7 @@ def main():
         # lanes' last steps are compared with
         save = inflight
         lane_out = [(lanes[w]["t"].clone(), lanes[w]["d"].clone(), lanes[w]["c"].clone()) for w in range(inflight)]
+        lane_last = [lanes[w].get("last") for w in range(inflight)]
         inflight = 1
         run_steps(0, args.warmup)
         barrier()
@@ -469,12 +478,11 @@ def main():
         check(lib().ndbhip_profile(0))
         st_serial = _lib.stats()
         inflight = save
-        # lane w's last step was step warmup + last index congruent to w; rerun those serially and compare
+        # every lane's last step of the timed region, rerun one at a time and compared
         same = True
         for w in range(inflight):
-            last = max(s for s in range(args.warmup, args.warmup + args.steps) if (s - args.warmup) % inflight == w) \
-                if args.steps > w else None
-            if last is None:
+            last = lane_last[w]
+            if last is None or last < args.warmup:
                 continue
             step(queries[last * nq:(last + 1) * nq])
             torch.cuda.synchronize()
