@@ -113,6 +113,98 @@ h2_walk_d2(const ndbo_hnsw *g, const uint16_t *w16, const float *q, uint32_t e)
 	return w16 ? ndbo_h2_dist2_w16(q, w16 + (size_t) e * g->dim, g->dim) : ndbo_h2_dist2(q, h2_vec(g, e), g->dim);
 }
 
+/*
+ * THE OPERATOR CLASS'S METRIC (round 6; SURVEY Q1: "metric comes from the opclass", hnsw_am.c:918-921 hands sk_strategy to
+ * hnswSearch, neurondb--1.0.sql:2941-2965 binds <-> / <=> / <#> to strategies 1 / 2 / 3).  The graph's links stay L2 (Q12:
+ * hnswInsertNode always passes strategy 1); what the strategy decides is the ORDER a search walks and returns in:
+ *   walk key (descent, layer search; fp64, the fixed 64-partial tree of ndbo_h2_dist2 / _w16 — element i to partial i mod 64 on
+ *   float4 rows, (i / 4) mod 64 on walk rows — products of two float4 values are exact in fp64):
+ *     1  sum (double) fl32(q_i - x_i) squared                                   (ndbo_h2_dist2[_w16]; unchanged)
+ *     2  1 - dot / (sqrt(nq) sqrt(nx)), 2.0 when nq or nx is zero, with dot = sum q_i x_i, nx = sum x_i x_i, nq = sum q_i q_i
+ *        by that tree (hnswComputeDistance case 2 at fp64: hnsw_am.c:1321-1332)
+ *     3  -dot                                                                   (case 3, :1334-1337)
+ *   every comparison on (key, block), as before;
+ *   returned distances: strategy 1 as before ((float) sqrt(d2) of the float4 rows); strategies 2 and 3: the (at most ef) entries
+ *   of the final result set are scored with hnswComputeDistance's OWN arithmetic on the float4 rows (ndbo_hnsw_distance:
+ *   sequential, fp32 products widened and summed in fp64, hnsw_am.c:1301-1345), ordered by (that float4, block), and the k
+ *   nearest returned with those values — what `ORDER BY v <=> $q` compares.  One evaluation each, counted.
+ */
+static void
+h2_dot_nx(const float *q, const float *x, const uint16_t *w, int dim, double *dot, double *nx)
+{
+	double		pd[64],
+				pn[64];
+	int			i,
+				off;
+
+	for (i = 0; i < 64; i++)
+		pd[i] = pn[i] = 0.0;
+	for (i = 0; i < dim; i++)
+	{
+		const double xv = (double) (w ? ndbo_fp16_to_float(w[i]) : x[i]);
+		const int	p = w ? ((i >> 2) & 63) : (i & 63);
+
+		pd[p] += (double) q[i] * xv;
+		pn[p] += xv * xv;
+	}
+	for (off = 32; off > 0; off >>= 1)
+		for (i = 0; i < off; i++)
+		{
+			pd[i] = pd[i] + pd[i + off];
+			pn[i] = pn[i] + pn[i + off];
+		}
+	*dot = pd[0];
+	*nx = pn[0];
+}
+
+/* the query's own sum of squares by the tree of the rows the walk runs on (group4: walk rows) */
+double
+ndbo_h2_query_norm2(const float *q, int dim, int group4)
+{
+	double		pn[64];
+	int			i,
+				off;
+
+	for (i = 0; i < 64; i++)
+		pn[i] = 0.0;
+	for (i = 0; i < dim; i++)
+		pn[group4 ? ((i >> 2) & 63) : (i & 63)] += (double) q[i] * (double) q[i];
+	for (off = 32; off > 0; off >>= 1)
+		for (i = 0; i < off; i++)
+			pn[i] = pn[i] + pn[i + off];
+	return pn[0];
+}
+
+/* the walk key of (query, node e) under `strategy`; nq = ndbo_h2_query_norm2(q, dim, w16 != NULL) (strategy 2 only) */
+double
+ndbo_h2_walk_key(const ndbo_hnsw *g, const uint16_t *w16, const float *q, uint32_t e, int strategy, double nq)
+{
+	double		dot,
+				nx;
+
+	if (strategy == 1)
+		return h2_walk_d2(g, w16, q, e);
+	h2_dot_nx(q, w16 ? NULL : h2_vec(g, e), w16 ? w16 + (size_t) e * g->dim : NULL, g->dim, &dot, &nx);
+	if (strategy == 3)
+		return -dot;
+	if (nq == 0.0 || nx == 0.0)
+		return 2.0;
+	return 1.0 - dot / (sqrt(nq) * sqrt(nx));
+}
+
+/* (strategy, query norm) of the walk in progress: the layer search and the greedy step below score through this */
+typedef struct h2_metric
+{
+	int			strategy;
+	double		nq;
+}			h2_metric;
+
+static inline double
+h2_key(const ndbo_hnsw *g, const uint16_t *w16, const float *q, uint32_t e, const h2_metric *mt)
+{
+	return mt ? ndbo_h2_walk_key(g, w16, q, e, mt->strategy, mt->nq) : h2_walk_d2(g, w16, q, e);
+}
+
 static inline uint32_t *
 h2_nbrs(const ndbo_hnsw *g, uint32_t b, int level)
 {
@@ -139,7 +231,7 @@ h2_less(double d2, uint32_t id, double e2, uint32_t jd)
  * everything left in them, so the textbook loop would stop before expanding it.
  */
 static int
-h2_search_layer_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
+h2_search_layer_w(const ndbo_hnsw *g, const uint16_t *w16, const h2_metric *mt, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
 				  int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited)
 {
 	uint32_t   *wid = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) (ef + 1));
@@ -189,7 +281,7 @@ h2_search_layer_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, const
 			if (e == NDBO_INVALID_BLOCK || e >= g->nblocks || visited[e])
 				continue;
 			H2_MARK(e);
-			d = h2_walk_d2(g, w16, q, e);
+			d = h2_key(g, w16, q, e, mt);
 			if (evals)
 				(*evals)++;
 			if (nw < ef)
@@ -241,12 +333,12 @@ int
 ndbo_h2_search_layer(const ndbo_hnsw *g, const float *q, const uint32_t *ep, const double *epd, int nep, int ef,
 					 int level, uint32_t *out_ids, double *out_d2, int64_t *evals, uint8_t *visited)
 {
-	return h2_search_layer_w(g, NULL, q, ep, epd, nep, ef, level, out_ids, out_d2, evals, visited);
+	return h2_search_layer_w(g, NULL, NULL, q, ep, epd, nep, ef, level, out_ids, out_d2, evals, visited);
 }
 
 /* greedy step of the upper layers: from `cur`, move to the nearest neighbour at `level` while one is nearer */
 static void
-h2_greedy_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
+h2_greedy_w(const ndbo_hnsw *g, const uint16_t *w16, const h2_metric *mt, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
 {
 	for (;;)
 	{
@@ -263,7 +355,7 @@ h2_greedy_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, int level, 
 
 			if (e == NDBO_INVALID_BLOCK || e >= g->nblocks)
 				continue;
-			d = h2_walk_d2(g, w16, q, e);
+			d = h2_key(g, w16, q, e, mt);
 			if (evals)
 				(*evals)++;
 			if (h2_less(d, e, bd, bid))
@@ -282,7 +374,7 @@ h2_greedy_w(const ndbo_hnsw *g, const uint16_t *w16, const float *q, int level, 
 static void
 h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *curd, int64_t *evals)
 {
-	h2_greedy_w(g, NULL, q, level, cur, curd, evals);
+	h2_greedy_w(g, NULL, NULL, q, level, cur, curd, evals);
 }
 
 /* kNN query: greedy descent to level 1, best-first search with ef at level 0, the k nearest ascending.  Distances
@@ -291,9 +383,11 @@ h2_greedy(const ndbo_hnsw *g, const float *q, int level, uint32_t *cur, double *
  * are then scored against the float4 rows with the definition's arithmetic (ndbo_h2_dist2), ordered by that
  * (d2, block), and the k nearest returned with THOSE distances — an evaluation each, counted. */
 static int
-h2_search_w(const ndbo_hnsw *g, const uint16_t *w16, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
+h2_search_w(const ndbo_hnsw *g, const uint16_t *w16, int strategy, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
 			int64_t *evals)
 {
+	h2_metric	mtv;
+	const h2_metric *mt = NULL;
 	uint8_t    *visited;
 	uint32_t   *ids;
 	double	   *d2;
@@ -307,16 +401,59 @@ h2_search_w(const ndbo_hnsw *g, const uint16_t *w16, const float *query, int ef,
 		return 0;
 	if (ef < k)
 		ef = k;
+	if (strategy != 1)
+	{
+		mtv.strategy = strategy;
+		mtv.nq = strategy == 2 ? ndbo_h2_query_norm2(query, g->dim, w16 != NULL) : 0.0;
+		mt = &mtv;
+	}
 	cur = g->entry_point;
-	curd = h2_walk_d2(g, w16, query, cur);
+	curd = h2_key(g, w16, query, cur, mt);
 	if (evals)
 		(*evals)++;
 	for (lc = g->entry_level; lc >= 1; lc--)
-		h2_greedy_w(g, w16, query, lc, &cur, &curd, evals);
+		h2_greedy_w(g, w16, mt, query, lc, &cur, &curd, evals);
 	visited = (uint8_t *) calloc(g->nblocks, 1);
 	ids = (uint32_t *) malloc(sizeof(uint32_t) * (size_t) ef);
 	d2 = (double *) malloc(sizeof(double) * (size_t) ef);
-	n = h2_search_layer_w(g, w16, query, &cur, &curd, 1, ef, 0, ids, d2, evals, visited);
+	n = h2_search_layer_w(g, w16, mt, query, &cur, &curd, 1, ef, 0, ids, d2, evals, visited);
+	if (mt)
+	{
+		/* the result set under hnswComputeDistance's arithmetic (float4 rows), ascending (that float4, block) */
+		float	   *fd = (float *) malloc(sizeof(float) * (size_t) (n > 0 ? n : 1));
+
+		for (i = 0; i < n; i++)
+			fd[i] = ndbo_hnsw_distance(query, h2_vec(g, ids[i]), g->dim, strategy, NULL);
+		if (evals)
+			*evals += n;
+		for (i = 1; i < n; i++)
+		{
+			const uint32_t id = ids[i];
+			const float d = fd[i];
+			int			j = i;
+
+			while (j > 0 && (d < fd[j - 1] || (d == fd[j - 1] && id < ids[j - 1])))
+			{
+				fd[j] = fd[j - 1];
+				ids[j] = ids[j - 1];
+				j--;
+			}
+			fd[j] = d;
+			ids[j] = id;
+		}
+		if (n > k)
+			n = k;
+		for (i = 0; i < n; i++)
+		{
+			out_blocks[i] = ids[i];
+			out_dist[i] = fd[i];
+		}
+		free(fd);
+		free(visited);
+		free(ids);
+		free(d2);
+		return n;
+	}
 	if (w16)
 	{
 		/* re-score on the float4 rows, then ascending (d2, id) again (insertion sort) */
@@ -357,7 +494,18 @@ int
 ndbo_h2_search(const ndbo_hnsw *g, const float *query, int ef, int k, uint32_t *out_blocks, float *out_dist,
 			   int64_t *evals)
 {
-	return h2_search_w(g, NULL, query, ef, k, out_blocks, out_dist, evals);
+	return h2_search_w(g, NULL, 1, query, ef, k, out_blocks, out_dist, evals);
+}
+
+/* the same under the operator class's strategy (1 L2 = ndbo_h2_search, 2 cosine, 3 negative inner product; see
+ * "THE OPERATOR CLASS'S METRIC" above); w16 NULL = walk on the float4 rows.  -1: unknown strategy (the reference's ERROR) */
+int
+ndbo_h2_search_s(const ndbo_hnsw *g, const uint16_t *w16, int strategy, const float *query, int ef, int k, uint32_t *out_blocks,
+				 float *out_dist, int64_t *evals)
+{
+	if (strategy < 1 || strategy > 3)
+		return -1;
+	return h2_search_w(g, w16, strategy, query, ef, k, out_blocks, out_dist, evals);
 }
 
 /* w16: [nblocks][dim] walk rows of g's vectors (ndbo_h2_walk_rows over g->vecs) */
@@ -367,7 +515,7 @@ ndbo_h2_search_w16(const ndbo_hnsw *g, const uint16_t *w16, const float *query, 
 {
 	if (!w16)
 		return -1;
-	return h2_search_w(g, w16, query, ef, k, out_blocks, out_dist, evals);
+	return h2_search_w(g, w16, 1, query, ef, k, out_blocks, out_dist, evals);
 }
 
 /* what the search phase of one insert leaves: per level lc <= min(level, entry level at that time) the selected

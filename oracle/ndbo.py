@@ -114,6 +114,9 @@ def lib(native: bool = False):
         "ndbo_h2_walk_rows": (None, [f32p, C.c_int64, u16p]),
         "ndbo_h2_dist2_w16": (C.c_double, [f32p, u16p, i]),
         "ndbo_h2_search_w16": (i, [C.POINTER(NdboHnsw), u16p, f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
+        "ndbo_h2_search_s": (i, [C.POINTER(NdboHnsw), C.c_void_p, i, f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
+        "ndbo_h2_query_norm2": (C.c_double, [f32p, i, i]),
+        "ndbo_h2_walk_key": (C.c_double, [C.POINTER(NdboHnsw), C.c_void_p, f32p, C.c_uint32, i, C.c_double]),
         "ndbo_mt_spread_copy": (C.c_void_p, [C.c_void_p, C.c_size_t, i]),
         "ndbo_mt_ivf_search_batch": (C.c_double, [C.POINTER(NdboIvf), f32p, i, i, i, i, C.c_int64, i, C.c_void_p, f32p,
                                                   i32p, C.POINTER(C.c_int64)]),
@@ -341,6 +344,18 @@ class HnswGraph:
         ns = C.c_int64(0)
         w = np.ascontiguousarray(w16, dtype=np.uint16)
         n = self.L.ndbo_h2_search_w16(self.g, w.reshape(-1), _f32(query), ef, k, ob, od, C.byref(ns))
+        return ob[:n], od[:n], ns.value
+
+    def search_intended_s(self, query, strategy, ef=64, k=10, w16=None):
+        """ndbo_h2_search_s: the intended search under the operator class's strategy (1 L2, 2 cosine, 3 negative inner
+        product); w16 (walk_rows()) = walk on the fp16 walk rows"""
+        ob = np.zeros(max(k, 1), dtype=np.uint32)
+        od = np.zeros(max(k, 1), dtype=np.float32)
+        ns = C.c_int64(0)
+        w = None if w16 is None else np.ascontiguousarray(w16, dtype=np.uint16)
+        n = self.L.ndbo_h2_search_s(self.g, None if w is None else w.ctypes.data, int(strategy), _f32(query), ef, k, ob, od, C.byref(ns))
+        if n < 0:
+            raise ValueError(f"hnsw: unsupported distance strategy {strategy}")
         return ob[:n], od[:n], ns.value
 
     def search(self, query, strategy=1, ef=64, k=10):
