@@ -573,11 +573,17 @@ int			ndbhip_hnsw_search_layer_device(ndbhip_hnsw *g, const float *d_queries, in
  * point), same level draws; every build-time comparison is L2 like hnswInsertNode's.  The build is batch-synchronous
  * (batches of clamp(nodes so far / batch_div, 1, batch_max): the members search the graph as it stood when their
  * batch began, their links are applied in insertion order), which is part of the definition:
- * oracle/ndb_oracle_hnsw2.c states it sequentially and the device graph equals it slot for slot.  Distances are
- * squared L2 in fp64 (a fixed 64-way summation tree), returned as (float) sqrt. */
+ * oracle/ndb_oracle_hnsw2.c states it sequentially and the device graph equals it slot for slot.  Build-time distances
+ * are squared L2 in fp64 (a fixed 64-way summation tree).
+ * The SEARCH takes the operator class's strategy like hnswSearch does (src/index/hnsw_am.c:918-921 hands sk_strategy down;
+ * neurondb--1.0.sql:2941-2965: <-> 1, <=> 2, <#> 3): 1 = L2, distances (float) sqrt(d2); 2 = cosine, 3 = negative inner
+ * product: descent and layer search order by that metric's fp64 key (1 - dot / (|q| |x|), -dot: the same summation tree),
+ * the result set's (at most ef) entries are then scored with hnswComputeDistance's own arithmetic (hnsw_am.c:1321-1337,
+ * bit for bit what ndbhip_hnsw_search returns for the same pair), ordered by (that float4, block), and the k nearest
+ * returned with those values.  Any other strategy: NDBHIP_ERR_INVALID (the reference's ERROR, :1339-1343). */
 int			ndbhip_hnsw_build_intended_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 											  const int32_t *levels, int ef_construction, int batch_div, int batch_max);
-int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
+int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries, int nq, int strategy, int ef, int k,
 											   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 											   uint64_t *d_out_tids, int64_t *d_out_evals);
 /* The same search with the walk on fp16 WALK ROWS (round 5; SURVEY 8f-4, src/index/hnsw_am.c:1436-1451 reads halfvec node
@@ -587,9 +593,15 @@ int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries,
  * result set's ef entries are then scored against the float4 rows with the definition's arithmetic, ordered by that, and
  * the k nearest returned with those distances: oracle/ndb_oracle_hnsw2.c ndbo_h2_search_w16, equal id for id and bit for
  * bit.  dim % 4 == 0 and dim <= 1024, else NDBHIP_ERR_UNSUPPORTED (use the float4 walk). */
-int			ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *g, const float *d_queries, int nq, int ef, int k,
+int			ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *g, const float *d_queries, int nq, int strategy, int ef, int k,
 												   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 												   uint64_t *d_out_tids, int64_t *d_out_evals);
+/* The intended search from HOST pointers (replaces the body of hnswgettuple's hnswSearch call, src/index/hnsw_am.c:998-1001,
+ * when neurondb.ref_compat is off): queries [nq x dim] are copied in, results copied out before return; out_tids6 nullable =
+ * node->heapPtr of every result (:1009-1053); out_evals nullable [nq].  walk16 != 0: the walk on fp16 walk rows. */
+int			ndbhip_hnsw_search_intended(ndbhip_hnsw *g, const float *queries, int nq, int strategy, int ef, int k, int walk16,
+										uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6,
+										int64_t *out_evals);
 /* A second HANDLE on the same graph (rows, levels, neighbour lists, TIDs, walk rows) with a workspace of its own — visited
  * maps, result blocks —: two batches of searches in flight, a host thread, a stream (ndbhip_set_thread_stream) and a handle
  * each (a batch ends with its longest walks; the next one's fill the device meanwhile).  Both handles are frozen while the

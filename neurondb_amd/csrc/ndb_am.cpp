@@ -370,9 +370,16 @@ ndb_hnswgettuple(ndb_index_scan *scan, int direction)
 		so->results.assign((size_t) so->k * 6, 0);
 		so->distances.assign((size_t) so->k, 0.0f);
 		/* hnswSearch (:998-1001); a strategy outside 1..3 is the ERROR of hnswComputeDistance (:1339-1343).
-		 * The heapPtr of every result comes back with it: saves the node re-read of :1009-1053. */
-		int			rc = ndbhip_hnsw_search(g, so->queryVector.data(), 1, so->strategy, so->efSearch, so->k,
-											blocks.data(), so->distances.data(), &count, so->results.data(), nullptr);
+		 * The heapPtr of every result comes back with it: saves the node re-read of :1009-1053.
+		 * neurondb.ref_compat = 1: the reference's walk as it stands (BFS-until-ef at level 0, Q10: recall ~ 0 beyond a few
+		 * thousand nodes); 0 (default): the `intended` search — greedy descent kept, best-first layer search of
+		 * src/scan/hnsw_scan.c:379-483 — ordered by the operator class's metric like hnswSearch's strategy argument
+		 * (:918-921), distances of strategies 2 / 3 in hnswComputeDistance's arithmetic. */
+		int			rc = guc_ref_compat
+			? ndbhip_hnsw_search(g, so->queryVector.data(), 1, so->strategy, so->efSearch, so->k,
+								 blocks.data(), so->distances.data(), &count, so->results.data(), nullptr)
+			: ndbhip_hnsw_search_intended(g, so->queryVector.data(), 1, so->strategy, so->efSearch, so->k, 0,
+										  blocks.data(), so->distances.data(), &count, so->results.data(), nullptr);
 
 		if (rc)
 			return rc;

@@ -306,8 +306,18 @@ ndb_hnsw_knn_search_gpu(ndbhip_hnsw *index, int strategy, const void *const *que
 	std::vector<float> dist(n * k);
 	std::vector<int> count(n);
 
-	rc = ndbhip_hnsw_search(index, packed.data(), (int) n, strategy, ef_search, k, blocks.data(), dist.data(),
-							count.data(), tids.data(), nullptr);
+	/* the access method's search for every query: neurondb.ref_compat = 1 the reference's walk, else the `intended`
+	 * search under the same strategy — the choice ndb_hnswgettuple makes, on the same (float4) rows, so that the rows
+	 * equal an index scan's */
+	int			compat = 0;
+
+	(void) ndb_am_get_guc("neurondb.ref_compat", &compat);
+	if (compat)
+		rc = ndbhip_hnsw_search(index, packed.data(), (int) n, strategy, ef_search, k, blocks.data(), dist.data(),
+								count.data(), tids.data(), nullptr);
+	else
+		rc = ndbhip_hnsw_search_intended(index, packed.data(), (int) n, strategy, ef_search, k, 0, blocks.data(), dist.data(),
+										 count.data(), tids.data(), nullptr);
 	if (rc)
 		return rc;
 	emit_rows(which, k, tids.data(), dist.data(), count.data(), rows, nrows);

@@ -3308,10 +3308,12 @@ ndbhip_hnsw_search_layer_device(ndbhip_hnsw *h, const float *d_queries, int nq, 
 	return NDBHIP_OK;
 }
 
+/* mode: 0 hnswSearch, 1 hnsw_search_layer, 2 / 3 the `intended` search on float4 / fp16 walk rows */
 static int
-hnsw_search_host(ndbhip_hnsw *h, bool scan_layer, const float *queries, int nq, int strategy, int ef, int k,
+hnsw_search_host(ndbhip_hnsw *h, int mode, const float *queries, int nq, int strategy, int ef, int k,
 				 uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_scored)
 {
+	const bool	scan_layer = mode == 1;
 	int			rc = hnsw_check(h, nq, scan_layer ? 1 : strategy, ef, k);
 
 	if (rc)
@@ -3347,7 +3349,9 @@ hnsw_search_host(ndbhip_hnsw *h, bool scan_layer, const float *queries, int nq, 
 	memcpy(h->pin, queries, (size_t) nq * h->dim * sizeof(float));
 	HIP_TRY(hipMemcpyAsync(h->w_q, h->pin, (size_t) nq * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipMemsetAsync(d_tid, 0, out_bytes, g.stream));
-	rc = scan_layer
+	rc = mode == 3 ? ndbhip_hnsw_search_intended_w16_device(h, h->w_q, nq, strategy, ef, k, d_blk, d_dist, d_cnt, d_tid, (int64_t *) d_sc)
+		: mode == 2 ? ndbhip_hnsw_search_intended_device(h, h->w_q, nq, strategy, ef, k, d_blk, d_dist, d_cnt, d_tid, (int64_t *) d_sc)
+		: scan_layer
 		? ndbhip_hnsw_search_layer_device(h, h->w_q, nq, strategy, ef, k, d_blk, d_dist, d_cnt, d_tid, (int64_t *) d_sc)
 		: ndbhip_hnsw_search_device(h, h->w_q, nq, strategy, ef, k, d_blk, d_dist, d_cnt, d_tid, (int64_t *) d_sc);
 	if (rc)
@@ -3380,7 +3384,7 @@ extern "C" int
 ndbhip_hnsw_search(ndbhip_hnsw *h, const float *queries, int nq, int strategy, int ef, int k,
 				   uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_scored)
 {
-	return hnsw_search_host(h, false, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
+	return hnsw_search_host(h, 0, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
 							out_scored);
 }
 
@@ -3389,8 +3393,18 @@ ndbhip_hnsw_search_layer(ndbhip_hnsw *h, const float *queries, int nq, int strat
 						 uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6,
 						 int64_t *out_scored)
 {
-	return hnsw_search_host(h, true, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
+	return hnsw_search_host(h, 1, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
 							out_scored);
+}
+
+/* the `intended` search from host pointers (what ndb_hnswgettuple calls when neurondb.ref_compat is off): one upload, the
+ * walk, one download; heap TIDs come back with the blocks like ndbhip_hnsw_search's */
+extern "C" int
+ndbhip_hnsw_search_intended(ndbhip_hnsw *h, const float *queries, int nq, int strategy, int ef, int k, int walk16,
+							uint32_t *out_blocks, float *out_dist, int *out_count, uint8_t *out_tids6, int64_t *out_evals)
+{
+	return hnsw_search_host(h, walk16 ? 3 : 2, queries, nq, strategy, ef, k, out_blocks, out_dist, out_count, out_tids6,
+							out_evals);
 }
 
 /* ================================================================== */
@@ -3766,10 +3780,12 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 }
 
 /* kNN search of the `intended` mode on a dense mirror (built by ndbhip_hnsw_build_intended_device, or any graph):
- * greedy descent, best-first layer search with ef at level 0, the k nearest ascending; distances (float) sqrt(d2)
- * (L2 whatever the operator class: on unit-norm rows the order is the cosine order).  Device pointers, asynchronous. */
+ * greedy descent, best-first layer search with ef at level 0, the k nearest ascending.  strategy = the operator class's
+ * (hnsw_am.c:918-921: 1 L2 — distances (float) sqrt(d2) —, 2 cosine, 3 negative inner product: the walk orders by that
+ * metric's fp64 key, the result set is scored with hnswComputeDistance's own arithmetic, :1321-1337, and ordered by
+ * that float4; oracle/ndb_oracle_hnsw2.c "THE OPERATOR CLASS'S METRIC").  Device pointers, asynchronous. */
 static int
-h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int strategy, int ef, int k, uint32_t *d_out_blocks,
 			  float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
@@ -3779,6 +3795,8 @@ h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int ef, 
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (k < 1 || k > NDBHIP_MAX_K || ef < 1 || ef > NDBHIP_MAX_EF)
 		return fail(NDBHIP_ERR_INVALID, "k or ef out of range");
+	if (strategy < 1 || strategy > 3)
+		return fail(NDBHIP_ERR_INVALID, "hnsw: unsupported distance strategy %d", strategy);		/* hnsw_am.c:1339-1343 */
 	if (nq == 0)
 		return NDBHIP_OK;
 	int			rc = hnsw_densify(h);
@@ -3816,42 +3834,39 @@ h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int ef, 
 	HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
 	H2Graph		gr = h2_graph(h, h->nblocks);
 
-#define H2_SEARCH_L(KK, NGG) do { \
-		HIP_TRY(hipFuncSetAttribute((const void *) KK<NGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem)); \
-		hipLaunchKernelGGL(KK<NGG>, dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe, \
+#define H2_SEARCH_L(KK, ...) do { \
+		HIP_TRY(hipFuncSetAttribute((const void *) KK<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem)); \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(KK<__VA_ARGS__>), dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe, \
 						   (uint32_t) k, h->entry_point, h->entry_level, (const uint64_t *) h->d_tids, h->w_vbits, h->w_vlog, nwords, \
 						   d_out_blocks, d_out_dist, d_out_count, d_out_tids, (long long *) d_out_evals, d_next); } while (0)
-	/* (g_h2_occ4: 1 = four walkers a SIMD where that costs no scratch — walk rows of dim <= 768; 2 = everywhere; 0 = nowhere) */
-	if (!w16)
+	/* (g_h2_occ4: 1 = four walkers a SIMD where that costs no scratch — walk rows of dim <= 768; 2 = everywhere; 0 = nowhere;
+	 * L2 only: the other strategies' walks hold a second partial sum per row) */
+	const int	ng = !w16 ? 0 : (h->dim <= 256 ? 1 : (h->dim <= 512 ? 2 : (h->dim <= 768 ? 3 : 4)));
+
+#define H2_SEARCH_S(NGG) do { \
+		if (strategy == 2) H2_SEARCH_L(k_h2_search, NGG, 2); \
+		else if (strategy == 3) H2_SEARCH_L(k_h2_search, NGG, 3); \
+		else if (g_h2_occ4 >= ((NGG) >= 1 && (NGG) <= 3 ? 1 : 2)) H2_SEARCH_L(k_h2_search4, NGG); \
+		else H2_SEARCH_L(k_h2_search, NGG, 1); } while (0)
+	switch (ng)
 	{
-		if (g_h2_occ4 >= 2) H2_SEARCH_L(k_h2_search4, 0); else H2_SEARCH_L(k_h2_search, 0);
+		case 0: H2_SEARCH_S(0); break;
+		case 1: H2_SEARCH_S(1); break;
+		case 2: H2_SEARCH_S(2); break;
+		case 3: H2_SEARCH_S(3); break;
+		default: H2_SEARCH_S(4); break;
 	}
-	else if (h->dim <= 256)
-	{
-		if (g_h2_occ4 >= 1) H2_SEARCH_L(k_h2_search4, 1); else H2_SEARCH_L(k_h2_search, 1);
-	}
-	else if (h->dim <= 512)
-	{
-		if (g_h2_occ4 >= 1) H2_SEARCH_L(k_h2_search4, 2); else H2_SEARCH_L(k_h2_search, 2);
-	}
-	else if (h->dim <= 768)
-	{
-		if (g_h2_occ4 >= 1) H2_SEARCH_L(k_h2_search4, 3); else H2_SEARCH_L(k_h2_search, 3);
-	}
-	else
-	{
-		if (g_h2_occ4 >= 2) H2_SEARCH_L(k_h2_search4, 4); else H2_SEARCH_L(k_h2_search, 4);
-	}
+#undef H2_SEARCH_S
 #undef H2_SEARCH_L
 	HIP_TRY(hipGetLastError());
 	return NDBHIP_OK;
 }
 
 extern "C" int
-ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int nq, int strategy, int ef, int k, uint32_t *d_out_blocks,
 								   float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
 {
-	return h2_search_run(h, false, d_queries, nq, ef, k, d_out_blocks, d_out_dist, d_out_count, d_out_tids, d_out_evals);
+	return h2_search_run(h, false, d_queries, nq, strategy, ef, k, d_out_blocks, d_out_dist, d_out_count, d_out_tids, d_out_evals);
 }
 
 /* The same search with the WALK on fp16 walk rows — every element of the graph's rows through the reference's own
@@ -3860,10 +3875,10 @@ ndbhip_hnsw_search_intended_device(ndbhip_hnsw *h, const float *d_queries, int n
  * against the float4 rows with the definition's arithmetic: oracle/ndb_oracle_hnsw2.c ndbo_h2_search_w16, equal id for id
  * and bit for bit.  A walk fetches half the bytes per evaluated row. */
 extern "C" int
-ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *h, const float *d_queries, int nq, int ef, int k, uint32_t *d_out_blocks,
+ndbhip_hnsw_search_intended_w16_device(ndbhip_hnsw *h, const float *d_queries, int nq, int strategy, int ef, int k, uint32_t *d_out_blocks,
 									   float *d_out_dist, int *d_out_count, uint64_t *d_out_tids, int64_t *d_out_evals)
 {
-	return h2_search_run(h, true, d_queries, nq, ef, k, d_out_blocks, d_out_dist, d_out_count, d_out_tids, d_out_evals);
+	return h2_search_run(h, true, d_queries, nq, strategy, ef, k, d_out_blocks, d_out_dist, d_out_count, d_out_tids, d_out_evals);
 }
 
 extern "C" int

@@ -77,6 +77,8 @@ struct H2Query
 	const float *q;
 	float		r[H2_QREG];
 	int			dim;
+	/* strategy 2 (norm2()): the query's own sum of squares by the tree of the rows the walk runs on, and its root */
+	double		nq, sq;
 
 	__device__ __forceinline__ void load(const float *qq, int d, int lane)
 	{
@@ -85,6 +87,29 @@ struct H2Query
 #pragma unroll
 		for (int j = 0; j < H2_QREG; j++)
 			r[j] = lane + 64 * j < d ? qq[lane + 64 * j] : 0.0f;
+	}
+
+	/* oracle ndbo_h2_query_norm2: a lane's elements in increasing order into its fp64 partial, the butterfly; group4 = the
+	 * registers are in load16's order.  (Products of two float4 values are exact in fp64.) */
+	__device__ __forceinline__ void norm2(bool group4, int lane)
+	{
+		double		p = 0.0;
+
+		if (dim <= 64 * H2_QREG)
+		{
+#pragma unroll
+			for (int j = 0; j < H2_QREG; j++)
+				p += (double) r[j] * (double) r[j];		/* (beyond the row: + 0.0) */
+		}
+		else
+			for (int i = lane; i < dim; i += 64)
+				p += (double) q[i] * (double) q[i];
+		(void) group4;		/* (load16 keeps group lane + 64 j at r[4 j .. 4 j + 3]: the same loop walks it in increasing element order) */
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+			p = p + __shfl_xor(p, off, 64);
+		nq = p;
+		sq = __builtin_sqrt(p);
 	}
 
 	/* for walk rows: the lane's GROUPS of four elements, group lane, lane + 64, ... (d % 4 == 0, d <= 64 * H2_QREG) */
@@ -102,6 +127,47 @@ struct H2Query
 		}
 	}
 };
+
+/*
+ * The walk key under the operator class's strategy (oracle/ndb_oracle_hnsw2.c "THE OPERATOR CLASS'S METRIC"; S = 1 L2 — the
+ * definition's d2, what every build-time comparison uses —, 2 cosine, 3 negative inner product): a lane's term per element
+ * and the wave's key out of the folded partial sums.
+ */
+template <int S>
+__device__ __forceinline__ void
+h2_term(double &p, double &pn, float qv, float xv)
+{
+	if constexpr (S == 1)
+	{
+		const float d = qv - xv;
+
+		p += (double) d * (double) d;
+	}
+	else
+	{
+		p += (double) qv * (double) xv;
+		if constexpr (S == 2)
+			pn += (double) xv * (double) xv;
+	}
+}
+
+template <int S>
+__device__ __forceinline__ double
+h2_key_of(const H2Query &Q, double p, double pn)
+{
+	if constexpr (S == 1)
+		return h2_wave_fold(p);
+	else if constexpr (S == 3)
+		return -h2_wave_fold(p);
+	else
+	{
+		const double dot = h2_wave_fold(p), nx = h2_wave_fold(pn);
+
+		if (Q.nq == 0.0 || nx == 0.0)
+			return 2.0;
+		return 1.0 - dot / (Q.sq * __builtin_sqrt(nx));
+	}
+}
 
 /* d2(query, row x) by the whole wave (every lane returns it) */
 __device__ __forceinline__ double
@@ -134,14 +200,18 @@ h2_dist2(const H2Query &Q, const float *__restrict__ x, int lane)
  * dependent fetches: what it can overlap is the rows of ONE expansion — up to 2m unvisited neighbours, offered to the
  * set in any order with the same result) */
 #define H2_NR 8
+template <int S = 1>
 __device__ __forceinline__ void
 h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, double out[H2_NR])
 {
-	double		p[H2_NR];
+	double		p[H2_NR], pn[S == 2 ? H2_NR : 1];
 
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
+	{
 		p[u] = 0.0;
+		pn[S == 2 ? u : 0] = 0.0;
+	}
 
 	if (Q.dim <= 64 * H2_QREG)
 	{
@@ -173,11 +243,7 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 				{
 #pragma unroll
 					for (int u = 0; u < H2_NR; u++)
-					{
-						const float d = Q.r[j0 + jj] - v[u][jj];
-
-						p[u] += (double) d * (double) d;
-					}
+						h2_term<S>(p[u], pn[S == 2 ? u : 0], Q.r[j0 + jj], v[u][jj]);
 				}
 		}
 	}
@@ -189,15 +255,11 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 #pragma unroll
 			for (int u = 0; u < H2_NR; u++)
 				if (u < n)
-				{
-					const float d = qv - x[u][i];
-
-					p[u] += (double) d * (double) d;
-				}
+					h2_term<S>(p[u], pn[S == 2 ? u : 0], qv, x[u][i]);
 		}
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
-		out[u] = h2_wave_fold(p[u]);
+		out[u] = h2_key_of<S>(Q, p[u], pn[S == 2 ? u : 0]);
 }
 
 /*
@@ -207,17 +269,18 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
  * subnormal, so the hardware conversion is that function) and adds the four terms in increasing element order to its
  * fp64 partial: element i goes to partial (i / 4) mod 64.  Query registers in load16's order.
  */
-template <int NG>
+template <int NG, int S = 1>
 __device__ __forceinline__ void
 h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, double out[H2_NR])
 {
-	double		p[H2_NR];
+	double		p[H2_NR], pn[S == 2 ? H2_NR : 1];
 	uint2		v[H2_NR][NG];
 
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
 	{
 		p[u] = 0.0;
+		pn[S == 2 ? u : 0] = 0.0;
 #pragma unroll
 		for (int j = 0; j < NG; j++)
 		{
@@ -239,19 +302,18 @@ h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, do
 				for (int t = 0; t < 4; t++)
 				{
 					const unsigned short h = (unsigned short) ((t & 1) ? (w[t >> 1] >> 16) : (w[t >> 1] & 0xFFFFu));
-					const float d = Q.r[4 * j + t] - __half2float(__ushort_as_half(h));
 
-					p[u] += (double) d * (double) d;
+					h2_term<S>(p[u], pn[S == 2 ? u : 0], Q.r[4 * j + t], __half2float(__ushort_as_half(h)));
 				}
 			}
 		}
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
-		out[u] = h2_wave_fold(p[u]);
+		out[u] = h2_key_of<S>(Q, p[u], pn[S == 2 ? u : 0]);
 }
 
 /* d2(query, node ids[u]) for u < n: on the walk rows (W16; Q loaded by load16) or on the float4 rows (Q loaded by load) */
-template <int W16>		/* 0: float4 rows; NG = 1 .. 4: walk rows of dim <= 256 NG (groups of four a lane holds) */
+template <int W16, int S = 1>		/* 0: float4 rows; NG = 1 .. 4: walk rows of dim <= 256 NG (groups of four a lane holds) */
 __device__ __forceinline__ void
 h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, int lane, double d[H2_NR])
 {
@@ -262,7 +324,7 @@ h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, 
 #pragma unroll
 		for (int u = 0; u < H2_NR; u++)
 			x[u] = g.vecs16 + (size_t) ids[u] * g.dim;
-		h2w_dist2x<W16>(Q, x, n, lane, d);
+		h2w_dist2x<W16, S>(Q, x, n, lane, d);
 	}
 	else
 	{
@@ -271,7 +333,7 @@ h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, 
 #pragma unroll
 		for (int u = 0; u < H2_NR; u++)
 			x[u] = g.vecs + (size_t) ids[u] * g.dim;
-		h2_dist2x4(Q, x, n, lane, d);
+		h2_dist2x4<S>(Q, x, n, lane, d);
 	}
 }
 
@@ -617,7 +679,7 @@ h2_offer(H2Set &W, double d, uint32_t id, int lane)
  * `evals` counts distance evaluations.  A node's neighbour list is read one slot per lane, the unvisited ones are
  * scored four rows at a time and offered to the set.
  */
-template <int W16 = 0>
+template <int W16 = 0, int S = 1>
 __device__ __forceinline__ void
 h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int level, H2Set &W, H2Visited &V, int lane,
 				long long &evals)
@@ -671,6 +733,10 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 
 			e0 = lane < 2 * g.m ? nb[lane] : NDBHIP_INVALID_BLOCK;
 			cnt = min((int) g.ncount[(size_t) c * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+			/* a node page holds lists for levels 0 .. its own only (hnsw_am.c:124-181); the dense layout a reference-compatible
+			 * build leaves has the out-of-item writes of Q12 / Q21 above that: not part of the index */
+			if (level > 0 && g.levels[c] < level)
+				cnt = 0;
 		}
 		const uint32_t e = lane < cnt ? e0 : NDBHIP_INVALID_BLOCK;
 		const bool	fresh = V.mark(e != NDBHIP_INVALID_BLOCK && e < g.nvisible && e != 0, e, lane);
@@ -692,6 +758,8 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 
 				pf_e0 = lane < 2 * g.m ? nb2[lane] : NDBHIP_INVALID_BLOCK;
 				pf_cnt = min((int) g.ncount[(size_t) pf_id * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+				if (level > 0 && g.levels[pf_id] < level)
+					pf_cnt = 0;
 			}
 		}
 		H2_PH(1);
@@ -714,7 +782,7 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 					n = u + 1;
 				}
 			}
-			h2_ids_d2<W16>(g, Q, ids, n, lane, d);
+			h2_ids_d2<W16, S>(g, Q, ids, n, lane, d);
 			evals += n;
 			H2_PH(2);
 			for (int u = 0; u < n; u++)
@@ -727,13 +795,14 @@ h2_search_layer(const H2Graph &g, const H2Query &Q, uint32_t ep, double epd, int
 }
 
 /* greedy step of the upper layers: from (cur, curd) move to the nearest neighbour at `level` while one is nearer */
-template <int W16 = 0>
+template <int W16 = 0, int S = 1>
 __device__ __forceinline__ void
 h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &curd, int lane, long long &evals)
 {
 	for (;;)
 	{
-		const int	cnt = min((int) g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		const int	cnt0 = min((int) g.ncount[(size_t) cur * NDBHIP_HNSW_MAX_LEVEL + level], 2 * g.m);
+		const int	cnt = g.levels[cur] >= level ? cnt0 : 0;	/* (lists exist up to the node's own level: see h2_search_layer) */
 		const uint32_t *nb = g.nbrs + (size_t) cur * g.stride + (size_t) level * 2 * g.m;
 		const uint32_t e = lane < cnt ? nb[lane] : NDBHIP_INVALID_BLOCK;
 		unsigned long long todo = __ballot(e != NDBHIP_INVALID_BLOCK && e < g.nvisible && e != 0);
@@ -759,7 +828,7 @@ h2_greedy(const H2Graph &g, const H2Query &Q, int level, uint32_t &cur, double &
 					n = u + 1;
 				}
 			}
-			h2_ids_d2<W16>(g, Q, ids, n, lane, d);
+			h2_ids_d2<W16, S>(g, Q, ids, n, lane, d);
 			evals += n;
 			for (int u = 0; u < n; u++)
 				if (h2_less(d[u], ids[u], bd, bid))
@@ -899,7 +968,7 @@ h2_smem_bytes(uint32_t ef, bool table = true /* with the LDS visited table (the 
  * (float) sqrt(d2).  Persistent grid of one-wave blocks; block b owns visited map b.
  * W16 (ndbo_h2_search_w16): descent and layer search on the fp16 walk rows (g.vecs16), then the result set's entries
  * scored against the float4 rows with the definition's arithmetic and ordered by that. */
-template <int W16>		/* 0, or the walk rows' groups a lane (dim <= 256 W16) */
+template <int W16, int S>		/* W16: 0, or the walk rows' groups a lane (dim <= 256 W16); S: the operator class's strategy */
 __device__ __forceinline__ void
 h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32_t ef, uint32_t k, uint32_t entry, int entry_level,
 			const uint64_t *__restrict__ tids, uint32_t *__restrict__ vbits, uint32_t *__restrict__ vlog, uint32_t nwords,
@@ -949,12 +1018,14 @@ h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32
 			Q.load16(queries + (size_t) q * g.dim, g.dim, lane);
 		else
 			Q.load(queries + (size_t) q * g.dim, g.dim, lane);
+		if constexpr (S == 2)
+			Q.norm2(W16 != 0, lane);
 		if (entry != NDBHIP_INVALID_BLOCK)
 		{
 			uint32_t	cur = entry;
 			double		curd;
 
-			if (W16)
+			if (W16 || S != 1)
 			{
 				uint32_t	ids[H2_NR];
 				double		d[H2_NR];
@@ -962,18 +1033,48 @@ h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32
 #pragma unroll
 				for (int u = 0; u < H2_NR; u++)
 					ids[u] = u == 0 ? cur : 0u;
-				h2_ids_d2<W16>(g, Q, ids, 1, lane, d);
+				h2_ids_d2<W16, S>(g, Q, ids, 1, lane, d);
 				curd = d[0];
 			}
 			else
 				curd = h2_dist2(Q, g.vecs + (size_t) cur * g.dim, lane);
 			evals = 1;
 			for (int lc = entry_level; lc >= 1; lc--)
-				h2_greedy<W16>(g, Q, lc, cur, curd, lane, evals);
-			h2_search_layer<W16>(g, Q, cur, curd, 0, W, V, lane, evals);
+				h2_greedy<W16, S>(g, Q, lc, cur, curd, lane, evals);
+			h2_search_layer<W16, S>(g, Q, cur, curd, 0, W, V, lane, evals);
 			V.clear(lane);			/* (the LDS table, or — after a migration — the bitmap) */
 			V.hv = hv_lds;
-			if (W16)
+			if constexpr (S != 1)
+			{
+				/* strategies 2, 3: the result set under hnswComputeDistance's own arithmetic on the float4 rows (hnsw_am.c:1321-1337:
+				 * sequential, fp32 products widened, fp64 sums) — a lane per entry, its row 16 bytes at a time —, kept as the
+				 * float4's fp64 image (exact, same order, same ties) so that the sort below orders (that float4, block) */
+				const float *qq = queries + (size_t) q * g.dim;
+
+				for (uint32_t i = lane; i < W.nw; i += 64)
+				{
+					const float *x = g.vecs + (size_t) W.wid[i] * g.dim;
+					Acc<S == 2 ? R_HNSW_COS : R_HNSW_IP> a;
+					int			t = 0;
+
+					if ((g.dim & 3) == 0)
+						for (; t < g.dim; t += 4)
+						{
+							const float4 xv = *(const float4 *) (x + t);		/* (rows of dim % 4 == 0 are 16-byte aligned; the query may not be) */
+
+							a.step(qq[t], xv.x);
+							a.step(qq[t + 1], xv.y);
+							a.step(qq[t + 2], xv.z);
+							a.step(qq[t + 3], xv.w);
+						}
+					for (; t < g.dim; t++)
+						a.step(qq[t], x[t]);
+					W.wd[i] = (double) a.fin();
+				}
+				evals += W.nw;
+				__threadfence_block();
+			}
+			else if (W16)
 			{
 				/* the result set against the float4 rows, H2_NR at a time (one evaluation each, counted) */
 				Q.load(queries + (size_t) q * g.dim, g.dim, lane);
@@ -1000,7 +1101,7 @@ h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32
 			for (uint32_t i = lane; i < n; i += 64)
 			{
 				out_blocks[(size_t) q * k + i] = sid[i];
-				out_dist[(size_t) q * k + i] = (float) __builtin_sqrt(sd[i]);
+				out_dist[(size_t) q * k + i] = S != 1 ? (float) sd[i] : (float) __builtin_sqrt(sd[i]);
 				if (out_tids)
 					out_tids[(size_t) q * k + i] = tids[sid[i]];
 			}
@@ -1020,11 +1121,11 @@ h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32
 	uint32_t *__restrict__ out_blocks, float *__restrict__ out_dist, int *__restrict__ out_count, uint64_t *__restrict__ out_tids, \
 	long long *__restrict__ out_evals, uint32_t *__restrict__ next
 #define H2_SEARCH_ARGS g, queries, nq, ef, k, entry, entry_level, tids, vbits, vlog, nwords, out_blocks, out_dist, out_count, out_tids, out_evals, next
-template <int W16>
+template <int W16, int S = 1>
 __global__ __launch_bounds__(64) void
 k_h2_search(H2_SEARCH_PARAMS)
 {
-	h2_search_body<W16>(H2_SEARCH_ARGS);
+	h2_search_body<W16, S>(H2_SEARCH_ARGS);
 }
 
 /* the same held to 128 registers: four walkers a SIMD instead of three (a walk waits on memory most of its time; what a
@@ -1033,7 +1134,7 @@ template <int W16>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 k_h2_search4(H2_SEARCH_PARAMS)
 {
-	h2_search_body<W16>(H2_SEARCH_ARGS);
+	h2_search_body<W16, 1>(H2_SEARCH_ARGS);
 }
 
 /*

@@ -102,8 +102,9 @@ class HnswIndex:
         check(lib().ndbhip_synchronize())
         self.nblocks = len(lv) + 1
 
-    def search_intended(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K, walk16=False):
-        """kNN of the `intended` mode: (blocks [nq, k], dist [nq, k] = sqrt of the squared L2, count [nq], evaluations [nq]).
+    def search_intended(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K, walk16=False, strategy=1):
+        """kNN of the `intended` mode: (blocks [nq, k], dist [nq, k], count [nq], evaluations [nq]).  strategy = the operator
+        class's (1 L2: sqrt of the squared L2; 2 cosine, 3 negative inner product: hnswComputeDistance's float4 values).
         walk16: descent and layer search on fp16 walk rows, the result set re-scored on the float4 rows
         (ndbhip_hnsw_search_intended_w16_device)"""
         import torch
@@ -115,7 +116,7 @@ class HnswIndex:
         oc = torch.zeros(nq, dtype=torch.int32, device=q.device)
         oe = torch.zeros(nq, dtype=torch.int64, device=q.device)
         fn = lib().ndbhip_hnsw_search_intended_w16_device if walk16 else lib().ndbhip_hnsw_search_intended_device
-        check(fn(self._h, C.c_void_p(q.data_ptr()), nq, int(ef), int(k), C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
+        check(fn(self._h, C.c_void_p(q.data_ptr()), nq, int(strategy), int(ef), int(k), C.c_void_p(ob.data_ptr()), C.c_void_p(od.data_ptr()),
                  C.c_void_p(oc.data_ptr()), None, C.c_void_p(oe.data_ptr())))
         check(lib().ndbhip_synchronize())
         return ob.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy(), oe.cpu().numpy()

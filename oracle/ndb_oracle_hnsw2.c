@@ -271,7 +271,9 @@ h2_search_layer_w(const ndbo_hnsw *g, const uint16_t *w16, const h2_metric *mt, 
 		wx[best] = 1;
 		c = wid[best];
 		nb = h2_nbrs(g, c, level);
-		cnt = g->ncount[(size_t) c * H2_MAXLEV + level];
+		/* a node page holds lists for levels 0 .. its own only (hnsw_am.c:124-181: neighbors[level + 1][2m]); what the
+		 * reference's inserts wrote beyond that (Q12 / Q21) is not part of the index */
+		cnt = g->levels[c] >= level ? g->ncount[(size_t) c * H2_MAXLEV + level] : 0;
 		for (j = 0; j < cnt; j++)
 		{
 			const uint32_t e = nb[j];
@@ -343,7 +345,7 @@ h2_greedy_w(const ndbo_hnsw *g, const uint16_t *w16, const h2_metric *mt, const 
 	for (;;)
 	{
 		const uint32_t *nb = h2_nbrs(g, *cur, level);
-		const int	cnt = g->ncount[(size_t) (*cur) * H2_MAXLEV + level];
+		const int	cnt = g->levels[*cur] >= level ? g->ncount[(size_t) (*cur) * H2_MAXLEV + level] : 0;
 		uint32_t	bid = *cur;
 		double		bd = *curd;
 		int			j;

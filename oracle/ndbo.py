@@ -207,6 +207,16 @@ class IvfImage:
         return out_t[:n], out_d[:n], ns.value
 
 
+def hnsw_distance(a, b, strategy):
+    """ndbo_hnsw_distance = hnswComputeDistance (hnsw_am.c:1301-1345) of two float4 vectors"""
+    a, b = _f32(a), _f32(b)
+    err = C.c_int(0)
+    d = lib().ndbo_hnsw_distance(a, b, len(a), int(strategy), C.byref(err))
+    if err.value:
+        raise ValueError(f"hnsw: unsupported distance strategy {strategy}")
+    return np.float32(d)
+
+
 def tids_from_rows(rows):
     """Synthetic heap TIDs for row numbers: block = row // 64, offset = row % 64 + 1."""
     rows = np.asarray(rows, dtype=np.int64)

@@ -107,11 +107,15 @@ def test_ivf_scan_callbacks(gucs):
     L.ndb_ivfendscan(scan)
 
 
-def test_hnsw_scan_callbacks(gucs):
+@pytest.mark.parametrize("compat", [1, 0], ids=["ref_compat", "intended"])
+def test_hnsw_scan_callbacks(gucs, compat):
+    """neurondb.ref_compat = 1: hnswgettuple's results are hnswSearch's (the reference's walk); 0 (the default): the
+    `intended` search under the ORDER BY operator's strategy (oracle ndbo_h2_search_s) — same callbacks, same GUCs"""
     from neurondb_amd import _lib
     L = _lib.lib()
     g, vecs = build_graph(800, 32, 8, 40, seed=63)
     ix, a = load(g)
+    gucs("neurondb.ref_compat", compat)
     rng = np.random.default_rng(64)
     q = rng.standard_normal(32).astype(np.float32)
     scan = L.ndb_hnswbeginscan(ix._h, 0, 1)
@@ -124,7 +128,7 @@ def test_hnsw_scan_callbacks(gucs):
         return key, keep
 
     def expect(query, strategy, ef, k):
-        eb, ed, _ = g.search(query, strategy, ef, k)
+        eb, ed, _ = g.search(query, strategy, ef, k) if compat else g.search_intended_s(query, strategy, ef, k)
         t = a["tids"][eb]
         return [tuple(int(x) for x in row) for row in np.asarray(t).reshape(len(eb), -1)]
 

@@ -177,3 +177,78 @@ def test_two_batches_of_walks_in_flight_on_shares_of_one_graph():
         handles[1].close()
     ix.close()
 
+
+
+@pytest.mark.parametrize("kind,n,dim,m,efc", [("normal", 2500, 64, 8, 48), ("clustered", 3000, 96, 16, 64), ("scaled", 2500, 768, 16, 100),
+                                              ("scaled", 1500, 1100, 8, 40), ("integer", 1500, 40, 6, 32), ("zeros", 1200, 32, 8, 40)])
+def test_intended_search_under_the_operator_class_strategy_equals_the_oracle(kind, n, dim, m, efc):
+    """ndbhip_hnsw_search_intended[_w16]_device(..., strategy, ...) == ndbo_h2_search_s for <-> / <=> / <#>
+    (strategies 1 / 2 / 3) on rows that are NOT unit vectors — where L2 order, cosine order and inner-product order are three
+    different orders ("scaled": every row times its own factor in 0.2 .. 5) — blocks, float4 distance bits (strategies 2, 3:
+    hnswComputeDistance's own values, hnsw_am.c:1321-1337) and evaluation counts, on float4 rows and on fp16 walk rows."""
+    from neurondb_amd import HnswIndex, _lib
+    from oracle import ndbo
+    src = {"scaled": "normal", "zeros": "normal"}.get(kind, kind)
+    base, q, levels = _data(src, n, dim, 48, seed=3 * n + dim)
+    rng = np.random.default_rng(n)
+    if kind == "scaled":
+        base = (base * rng.uniform(0.2, 5.0, (n, 1))).astype(np.float32)
+        q = (q * rng.uniform(0.2, 5.0, (len(q), 1))).astype(np.float32)
+    if kind == "zeros":                                                     # zero-norm rows and a zero query: cosine's 2.0 branch
+        base[rng.integers(0, n, 40)] = 0.0
+        q[5] = 0.0
+    og = ndbo.HnswGraph(dim, m, efc, cap_nodes=n + 1)
+    og.build_intended(base, levels, batch_div=16, batch_max=256, select=1)
+    w16 = og.walk_rows() if dim % 4 == 0 and dim <= 1024 else None
+    ix = HnswIndex(dim, m)
+    ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, efc, batch_div=16, batch_max=256)
+    differ = 0
+    for strategy in (1, 2, 3):
+        for ef, k in ((64, 10), (16, 16), (100, 20), (1, 1)):
+            for walk16 in ([False, True] if w16 is not None else [False]):
+                ob, od, oc, oe = ix.search_intended(q, ef, k, walk16=walk16, strategy=strategy)
+                for i in range(len(q)):
+                    eb, ed, ns = og.search_intended_s(q[i], strategy, ef, k, w16=w16 if walk16 else None)
+                    assert oc[i] == len(eb) and np.array_equal(ob[i, :oc[i]], eb), (strategy, ef, walk16, i, ob[i], eb)
+                    assert np.array_equal(od[i, :oc[i]].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns, (strategy, ef, i, oe[i], ns)
+                    # the returned values are hnswComputeDistance's for that pair
+                    if strategy != 1 and oc[i]:
+                        ref = np.array([ndbo.hnsw_distance(q[i], base[b - 1], strategy) for b in eb], np.float32)
+                        assert np.array_equal(ref.view(np.uint32), od[i, :oc[i]].view(np.uint32))
+        if strategy != 1 and kind == "scaled":
+            b1 = ix.search_intended(q, 64, 10, strategy=1)[0]
+            bs = ix.search_intended(q, 64, 10, strategy=strategy)[0]
+            differ += int((b1 != bs).any(axis=1).sum())
+    if kind == "scaled":
+        assert differ > len(q)               # the three orders really are different orders here
+    # strategy 1 through the new argument is the old entry point's answer
+    a1 = ix.search_intended(q, 64, 10)
+    a2 = ix.search_intended(q, 64, 10, strategy=1)
+    assert all(np.array_equal(x, y) for x, y in zip(a1, a2))
+    with pytest.raises(Exception):
+        ix.search_intended(q, 64, 10, strategy=4)          # hnswComputeDistance's ERROR (:1339-1343)
+    ix.close()
+
+
+def test_device_fp64_sqrt_and_divide_are_correctly_rounded():
+    """The cosine walk key is 1 - dot / (sqrt(nq) sqrt(nx)) in fp64 on both sides: the device's fp64 sqrt and divide must be the
+    IEEE results (they are expansions on gfx950, not instructions).  2^20 random operands through torch's kernels would not
+    prove the library's; so the search itself is the witness: a table whose rows differ in the last bits of their norms."""
+    from neurondb_amd import HnswIndex
+    from oracle import ndbo
+    rng = np.random.default_rng(5)
+    n, dim = 3000, 32
+    d0 = rng.standard_normal(dim).astype(np.float32)
+    # rows = one direction at 3000 lengths one float32 ulp apart + tiny noise: cosine keys differ in their last fp64 bits
+    base = np.stack([(d0 * np.float32(1.0 + i * 2.0 ** -20) + np.float32(1e-6) * rng.standard_normal(dim)).astype(np.float32) for i in range(n)])
+    q = (d0[None, :] + 1e-3 * rng.standard_normal((32, dim))).astype(np.float32)
+    levels = _levels(rng, n)
+    og = ndbo.HnswGraph(dim, 8, 40, cap_nodes=n + 1)
+    og.build_intended(base, levels, batch_div=16, batch_max=256, select=1)
+    ix = HnswIndex(dim, 8)
+    ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, 40, batch_div=16, batch_max=256)
+    ob, od, oc, oe = ix.search_intended(q, 64, 10, strategy=2)
+    for i in range(len(q)):
+        eb, ed, ns = og.search_intended_s(q[i], 2, 64, 10)
+        assert np.array_equal(ob[i, :oc[i]], eb) and oe[i] == ns
+    ix.close()

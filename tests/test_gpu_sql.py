@@ -130,12 +130,21 @@ def test_ivf_knn_search_gpu_rows_equal_the_index_scan():
     assert L.ndb_ivf_knn_search_gpu(None, 1, ptrs, lens, len(datums), 1, 5, buf, C.byref(n)) < 0
 
 
-def test_hnsw_knn_search_gpu_rows_equal_the_index_scan():
+@pytest.mark.parametrize("compat", [1, 0], ids=["ref_compat", "intended"])
+def test_hnsw_knn_search_gpu_rows_equal_the_index_scan(compat):
     from neurondb_amd import _lib
     from neurondb_amd._lib import NdbKnnRow
     L = _lib.lib()
     g, vecs = build_graph(900, 32, 8, 40, seed=73)
     ix, a = load(g)
+    _lib.check(L.ndb_am_set_guc(b"neurondb.ref_compat", compat))
+    try:
+        _hnsw_knn_rows(L, _lib, NdbKnnRow, g, ix, a, compat)
+    finally:
+        _lib.check(L.ndb_am_set_guc(b"neurondb.ref_compat", 0))
+
+
+def _hnsw_knn_rows(L, _lib, NdbKnnRow, g, ix, a, compat):
     rng = np.random.default_rng(74)
     qs = [rng.standard_normal(32).astype(np.float32) for _ in range(6)]
     datums = [vector_datum(q) for q in qs]
@@ -149,7 +158,7 @@ def test_hnsw_knn_search_gpu_rows_equal_the_index_scan():
         for i, q in enumerate(qs):
             if i == 2:
                 continue
-            eb, ed, _ = g.search(q, strategy, ef, k)
+            eb, ed, _ = g.search(q, strategy, ef, k) if compat else g.search_intended_s(q, strategy, ef, k)
             t = np.asarray(a["tids"][eb])
             exp += [(i, tuple(int(x) for x in np.asarray(row).reshape(-1)), np.float32(d))
                     for row, d in zip(t.reshape(len(eb), -1), ed)]
