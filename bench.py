@@ -1672,7 +1672,7 @@ def hnsw_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
                        f"{nq}-query batches (BASELINE config C3)"}
     if intended and "queries_per_s" in intended:
         for key in ("queries_per_s", "recall_at_10", "build_vectors_per_s", "ms_per_batch", "evaluations_per_query", "roofline",
-                    "in_flight", "one_batch_at_a_time"):
+                    "in_flight", "one_batch_at_a_time", "strategy"):
             if key in intended:
                 top[key] = intended[key]
         top["mode"] = "intended (details: `intended`); the reference-compatible walk: `ref_compat`"
@@ -1695,7 +1695,7 @@ def hnsw_roofline(n, dim, m, ef, nq, ts, bytes_q):
             "note": "dependent graph walk, latency-bound; frac = HBM-side PMC bytes per launch / batch time / 8 TB/s"}
 
 
-def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
+def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192, strategy=2):
     """BASELINE config C3 in the `intended` mode (include/ndbhip.h ndbhip_hnsw_build_intended_device,
     oracle/ndb_oracle_hnsw2.c): build and search in HBM, recall@10 against a float64 brute force, a sample replayed by
     the oracle on the exported graph (blocks, float4 distance bits, evaluation counts).  Table: the headline's clustered
@@ -1719,7 +1719,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         gt = torch.topk(sims, k, dim=1).indices.cpu().numpy() + 1
         out = {}
         for e in efs:
-            ob, od, oc, oe = ix.search_intended(q[:max(nr, 256)], e, k, walk16=w16)
+            ob, od, oc, oe = ix.search_intended(q[:max(nr, 256)], e, k, walk16=w16, strategy=strategy)
             out[e] = round(float(np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / k for i in range(nr)])), 4)
         return out
 
@@ -1738,11 +1738,11 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         reps = 3
 
         def timed(qq, w16):
-            ix.search_intended(qq[:512], ef, k, walk16=w16)
+            ix.search_intended(qq[:512], ef, k, walk16=w16, strategy=strategy)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
-                r = ix.search_intended(qq, ef, k, walk16=w16)
+                r = ix.search_intended(qq, ef, k, walk16=w16, strategy=strategy)
             return (time.perf_counter() - t0) / reps, r
 
         ts32, (pb, pd, pc, pe) = timed(q, False)
@@ -1781,7 +1781,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
                     check(lib().ndbhip_set_thread_stream(C.c_void_p(streams[w].cuda_stream)))
                     with torch.cuda.stream(streams[w]):
                         for _ in range(rp):
-                            lastres[w] = handles[w].search_intended(q, ef, k, walk16=walk16)
+                            lastres[w] = handles[w].search_intended(q, ef, k, walk16=walk16, strategy=strategy)
                     check(lib().ndbhip_set_thread_stream(None))
                 except Exception as ex:          # noqa: BLE001
                     errs.append(ex)
@@ -1821,13 +1821,13 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         w16rows = og.walk_rows() if walk16 else None
         t0 = time.perf_counter()
         for i in range(sample):
-            eb, ed, ns = og.search_intended(qh[i], ef, k)
+            eb, ed, ns = og.search_intended_s(qh[i], strategy, ef, k)
             bad32 += not (pc[i] == len(eb) and np.array_equal(pb[i, :len(eb)], eb) and
                           np.array_equal(pd[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and pe[i] == ns)
         tc = (time.perf_counter() - t0) / sample
         if walk16:
             for i in range(sample):
-                eb, ed, ns = og.search_intended_w16(w16rows, qh[i], ef, k)
+                eb, ed, ns = og.search_intended_s(qh[i], strategy, ef, k, w16=w16rows)
                 bad += not (oc[i] == len(eb) and np.array_equal(ob[i, :len(eb)], eb) and
                             np.array_equal(od[i, :len(eb)].view(np.uint32), ed.view(np.uint32)) and oe[i] == ns)
         else:
@@ -1840,7 +1840,7 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             qall = q[:ncpu].cpu().numpy()
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=cores) as ex:
-                list(ex.map(lambda lo: [og.search_intended(qall[i], ef, k) for i in range(lo, min(ncpu, lo + 8))], range(0, ncpu, 8)))
+                list(ex.map(lambda lo: [og.search_intended_s(qall[i], strategy, ef, k) for i in range(lo, min(ncpu, lo + 8))], range(0, ncpu, 8)))
             cpu = {"value": round(ncpu / (time.perf_counter() - t0), 1), "unit": "queries/s", "cores": cores, "kind": "port",
                    "sample": f"{ncpu} of the same queries through oracle/ndb_oracle_hnsw2.c ndbo_h2_search on the exported "
                              "graph, one thread per core"}
@@ -1851,9 +1851,11 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
         bytes32 = evals32 * (4 * dim) + lists_b(evals32)
         # (walk rows: 2 bytes an element for the walk's evaluations, 4 for the ef re-scored entries)
         bytes_q = ((evals - ef) * (2 * dim) + ef * (4 * dim) + lists_b(evals - ef)) if walk16 else bytes32
-        out = {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k}, cosine order on unit-norm "
-                           f"rows, {nq}-query batches (BASELINE config C3), intended mode; table: mixture of {args.components} "
+        out = {"workload": f"HNSW {n}x{dim} fp32 m={m} ef_construction={efc} ef_search={ef} k={k}, "
+                           f"{ {1: 'L2 (<->)', 2: 'cosine (<=>)', 3: 'inner product (<#>)'}[strategy]}: strategy {strategy} of the operator class, "
+                           f"unit-norm rows, {nq}-query batches (BASELINE config C3), intended mode; table: mixture of {args.components} "
                            f"Gaussians sigma={args.sigma}, normalised",
+               "strategy": strategy,
                "search": ("walk on fp16 walk rows (the reference's float4_to_fp16 image of the rows), the ef result entries re-scored "
                           "on the float4 rows: ndbhip_hnsw_search_intended_w16_device == oracle ndbo_h2_search_w16; `float4_walk` = "
                           "the walk on the float4 rows (ndbhip_hnsw_search_intended_device, what rounds 3-4 reported)") if walk16
@@ -1884,11 +1886,11 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192):
             ix3.build_intended(base, torch.arange(n, device=dev, dtype=torch.int64), levels, efc, batch_max=32768)
             tb3 = time.perf_counter() - t0
             sched3 = ix3.build_stats()
-            ix3.search_intended(q[:512], ef, k, walk16=walk16)
+            ix3.search_intended(q[:512], ef, k, walk16=walk16, strategy=strategy)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
-                ix3.search_intended(q, ef, k, walk16=walk16)
+                ix3.search_intended(q, ef, k, walk16=walk16, strategy=strategy)
             ts3 = (time.perf_counter() - t0) / reps
             out["batch_max_32768"] = {"build_vectors_per_s": round(n / tb3, 1), "build_s": round(tb3, 2),
                                       "build_schedule": {"batches": int(sched3.get("batches", 0)), "largest_batch": int(sched3.get("max_batch", 0))},

@@ -583,6 +583,14 @@ int			ndbhip_hnsw_search_layer_device(ndbhip_hnsw *g, const float *d_queries, in
  * returned with those values.  Any other strategy: NDBHIP_ERR_INVALID (the reference's ERROR, :1339-1343). */
 int			ndbhip_hnsw_build_intended_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
 											  const int32_t *levels, int ef_construction, int batch_div, int batch_max);
+/* hnswinsert under `intended` (src/index/hnsw_am.c:478-538 / hnswInsertNode :2091-2670 with the repairs above): n MORE rows on
+ * top of the graph the mirror holds (built here in either mode, or loaded): node nblocks + i = row i; the batch schedule goes
+ * on from the relation's size (one row = one batch = the sequential textbook insert).  oracle: ndbo_h2_build on a graph that
+ * is not empty.  The _device form takes rows and packed heapPtrs in HBM; the other stages host rows / 6-byte heapPtrs. */
+int			ndbhip_hnsw_insert_intended_device(ndbhip_hnsw *g, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+											   const int32_t *levels, int ef_construction, int batch_div, int batch_max);
+int			ndbhip_hnsw_insert_intended(ndbhip_hnsw *g, const float *rows, const uint8_t *tids6, uint32_t n,
+										const int32_t *levels, int ef_construction, int batch_div, int batch_max);
 int			ndbhip_hnsw_search_intended_device(ndbhip_hnsw *g, const float *d_queries, int nq, int strategy, int ef, int k,
 											   uint32_t *d_out_blocks, float *d_out_dist, int *d_out_count,
 											   uint64_t *d_out_tids, int64_t *d_out_evals);

@@ -209,6 +209,8 @@ def lib():
         "ndbhip_hnsw_load": (i, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, i]),
         "ndbhip_hnsw_build_device": (i, [vp, vp, vp, C.c_uint32, vp, i]),
         "ndbhip_hnsw_build_intended_device": (i, [vp, vp, vp, C.c_uint32, vp, i, i, i]),
+        "ndbhip_hnsw_insert_intended_device": (i, [vp, vp, vp, C.c_uint32, vp, i, i, i]),
+        "ndbhip_hnsw_insert_intended": (i, [vp, vp, vp, C.c_uint32, vp, i, i, i]),
         "ndbhip_hnsw_search_intended_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_hnsw_search_intended_w16_device": (i, [vp, vp, i, i, i, i, vp, vp, vp, vp, vp]),
         "ndbhip_hnsw_search_intended": (i, [vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]),

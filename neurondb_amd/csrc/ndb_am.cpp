@@ -479,7 +479,11 @@ ndb_hnswinsert(ndbhip_hnsw *index, const void *value, size_t value_len, int valu
 	int			efc = 200;		/* HNSW_DEFAULT_EF_CONSTRUCTION; the mirror carries meta->efConstruction (:2369-2378) */
 
 	(void) ndbhip_hnsw_get_meta(index, &efc, nullptr);
-	rc = ndbhip_hnsw_insert(index, row.data(), (const uint8_t *) ht_ctid, 1, &lv, efc);
+	/* neurondb.ref_compat = 1: hnswInsertNode as it stands (:2091-2670); 0: the `intended` insert — one row = one batch of the
+	 * definition's schedule, i.e. the sequential textbook insert (descent kept, every level on its own links, pruning) */
+	rc = guc_ref_compat
+		? ndbhip_hnsw_insert(index, row.data(), (const uint8_t *) ht_ctid, 1, &lv, efc)
+		: ndbhip_hnsw_insert_intended(index, row.data(), (const uint8_t *) ht_ctid, 1, &lv, efc, 64, 1024);
 	return rc ? rc : 1;
 }
 

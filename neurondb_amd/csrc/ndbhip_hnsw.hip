@@ -2453,44 +2453,12 @@ ndbhip_hnsw_load(ndbhip_hnsw *h, uint32_t nblocks, const float *vecs, const int3
 
 static int hnsw_densify(ndbhip_hnsw *h);
 
-/* hnswInsertNode for rows 0..n-1 on top of the `base` nodes the mirror already holds (0: build from nothing) */
+/* room for nb blocks in the dense arrays of a mirror that holds base nodes (blocks 0 .. base): the relation grows by pages;
+ * the arrays grow geometrically so that a stream of single-row hnswinsert calls does not copy the graph every time */
 static int
-hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n, const int32_t *levels,
-				 int ef_construction, uint32_t base)
+hnsw_grow_dense(ndbhip_hnsw *h, uint32_t base, uint32_t nb)
 {
-	if (need_init()) return NDBHIP_ERR_NODEVICE;
-	if (!h || !d_rows || !d_tids || !levels || n < 1)
-		return fail(NDBHIP_ERR_INVALID, "bad arguments");
-	if (ef_construction < 4 || ef_construction > NDBHIP_MAX_EF)	/* HNSW_MIN_EF_CONSTRUCTION: hnsw_am.c:92 */
-		return fail(NDBHIP_ERR_INVALID, "ef_construction %d out of range 4..%d", ef_construction, NDBHIP_MAX_EF);
-	const size_t smem = hnsw_smem_bytes((uint32_t) ef_construction, (uint32_t) ef_construction, (uint32_t) h->m);
-
-	if (smem > NDB_TOPK_MAX_SMEM)
-		return fail(NDBHIP_ERR_UNSUPPORTED, "ef_construction too large for the LDS-resident candidate set");
-	if ((uint64_t) base + n + 1 > 0xFFFFFFF0ull)
-		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 blocks");
-	const uint32_t nb = base + n + 1;
 	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
-	int		   *d_lv_in = nullptr;
-	uint32_t   *d_entry = nullptr;
-	uint32_t	entry[2] = {NDBHIP_INVALID_BLOCK, (uint32_t) -1};
-
-	if (base == 0)
-	{
-		hnsw_free_dev(h);
-		HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
-		HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
-		HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
-		HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
-		HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
-		HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));	/* row 0 = meta page */
-		HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
-		HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
-		HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
-		HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
-		h->cap_blocks = nb;
-	}
-	else
 	{
 		/* the relation grows by n pages; the arrays grow geometrically so that a stream of single-row
 		 * hnswinsert calls does not copy the graph every time */
@@ -2537,6 +2505,53 @@ hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, ui
 			h->d_vecs = nv; h->d_levels = nl; h->d_ncount = nc; h->d_nbrs = nn; h->d_tids = nt;
 			h->cap_blocks = cap;
 		}
+	}
+	return 0;
+}
+
+/* hnswInsertNode for rows 0..n-1 on top of the `base` nodes the mirror already holds (0: build from nothing) */
+static int
+hnsw_insert_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n, const int32_t *levels,
+				 int ef_construction, uint32_t base)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	if (!h || !d_rows || !d_tids || !levels || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	if (ef_construction < 4 || ef_construction > NDBHIP_MAX_EF)	/* HNSW_MIN_EF_CONSTRUCTION: hnsw_am.c:92 */
+		return fail(NDBHIP_ERR_INVALID, "ef_construction %d out of range 4..%d", ef_construction, NDBHIP_MAX_EF);
+	const size_t smem = hnsw_smem_bytes((uint32_t) ef_construction, (uint32_t) ef_construction, (uint32_t) h->m);
+
+	if (smem > NDB_TOPK_MAX_SMEM)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "ef_construction too large for the LDS-resident candidate set");
+	if ((uint64_t) base + n + 1 > 0xFFFFFFF0ull)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 blocks");
+	const uint32_t nb = base + n + 1;
+	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
+	int		   *d_lv_in = nullptr;
+	uint32_t   *d_entry = nullptr;
+	uint32_t	entry[2] = {NDBHIP_INVALID_BLOCK, (uint32_t) -1};
+
+	if (base == 0)
+	{
+		hnsw_free_dev(h);
+		HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
+		HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
+		HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
+		HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));	/* row 0 = meta page */
+		HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
+		h->cap_blocks = nb;
+	}
+	else
+	{
+		int			rc = hnsw_grow_dense(h, base, nb);
+
+		if (rc)
+			return rc;
 		entry[0] = h->entry_point;
 		entry[1] = (uint32_t) h->entry_level;
 	}
@@ -2994,8 +3009,11 @@ ndbhip_hnsw_delete(ndbhip_hnsw *h, const uint8_t *tids6, int64_t n, int64_t *rem
 	}
 	if (!h->d_dead)
 	{
-		HIP_TRY(hipMalloc((void **) &h->d_dead, (size_t) nb));
-		HIP_TRY(hipMemsetAsync(h->d_dead, 0, (size_t) nb, g.stream));
+		/* (as long as the other arrays: later inserts fill blocks below cap_blocks without reallocating) */
+		const size_t dcap = std::max<size_t>(nb, h->cap_blocks);
+
+		HIP_TRY(hipMalloc((void **) &h->d_dead, dcap));
+		HIP_TRY(hipMemsetAsync(h->d_dead, 0, dcap, g.stream));
 	}
 	std::vector<uint64_t> set((size_t) n);
 
@@ -3120,7 +3138,12 @@ ndbhip_hnsw_set_dead_flags(ndbhip_hnsw *h, const uint8_t *dead)
 	if (!h || !h->loaded || !dead)
 		return fail(NDBHIP_ERR_INVALID, "bad arguments");
 	if (!h->d_dead)
-		HIP_TRY(hipMalloc((void **) &h->d_dead, (size_t) h->nblocks));
+	{
+		const size_t dcap = std::max<size_t>(h->nblocks, h->cap_blocks);
+
+		HIP_TRY(hipMalloc((void **) &h->d_dead, dcap));
+		HIP_TRY(hipMemsetAsync(h->d_dead, 0, dcap, g.stream));
+	}
 	HIP_TRY(hipMemcpyAsync(h->d_dead, dead, (size_t) h->nblocks, hipMemcpyHostToDevice, g.stream));
 	HIP_TRY(hipStreamSynchronize(g.stream));
 	return NDBHIP_OK;
@@ -3475,9 +3498,12 @@ h2_graph(const ndbhip_hnsw *h, uint32_t nvisible)
  * batch began (k_h2_insert_search), the host groups their back-links by target, every target replays its requests in
  * insertion order (k_h2_apply).  The graph is the one ndbo_h2_build leaves, slot for slot.
  */
-extern "C" int
-ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
-								  const int32_t *levels, int ef_construction, int batch_div, int batch_max)
+/* base = nodes the mirror holds already (0: hnswbuild from nothing; > 0: round 6, rows appended — hnswinsert under `intended`:
+ * row i becomes block base + 1 + i and the schedule goes on from the relation's size: oracle ndbo_h2_build on a graph that is
+ * not empty) */
+static int
+h2_build_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+			  const int32_t *levels, int ef_construction, int batch_div, int batch_max, uint32_t base)
 {
 	if (need_init()) return NDBHIP_ERR_NODEVICE;
 	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_build_intended_device");
@@ -3487,33 +3513,49 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 		return fail(NDBHIP_ERR_INVALID, "ef_construction %d out of range 4..%d", ef_construction, NDBHIP_MAX_EF);
 	if (h->m > 64)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "intended build: m <= 64");
-	if ((uint64_t) n + 1 > 0xFFFFFFF0ull)
+	if ((uint64_t) base + n + 1 > 0xFFFFFFF0ull)
 		return fail(NDBHIP_ERR_UNSUPPORTED, "more than 2^32 blocks");
 	if (batch_div < 1) batch_div = 1;
 	if (batch_max < 1) batch_max = 1;
-	const uint32_t nb = n + 1;
+	const uint32_t nb = base + n + 1;
 	const int	m = 2 * h->m;		/* row width of the selections: a level-0 row may hold 2m */
 	const size_t stride = (size_t) NDBHIP_HNSW_MAX_LEVEL * 2 * h->m;
 	std::vector<int> lev(n);
 
 	for (uint32_t i = 0; i < n; i++)
 		lev[i] = levels[i] < 0 ? 0 : (levels[i] > NDBHIP_HNSW_MAX_LEVEL - 1 ? NDBHIP_HNSW_MAX_LEVEL - 1 : levels[i]);
-	hnsw_free_dev(h);
-	HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
-	HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
-	HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
-	HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
-	h->cap_blocks = nb;
+	if (base == 0)
+	{
+		hnsw_free_dev(h);
+		HIP_TRY(hipMalloc((void **) &h->d_vecs, (size_t) nb * h->dim * sizeof(float)));
+		HIP_TRY(hipMalloc((void **) &h->d_levels, (size_t) nb * sizeof(int)));
+		HIP_TRY(hipMalloc((void **) &h->d_ncount, (size_t) nb * 16 * sizeof(int16_t)));
+		HIP_TRY(hipMalloc((void **) &h->d_nbrs, (size_t) nb * stride * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &h->d_tids, (size_t) nb * sizeof(uint64_t)));
+		h->cap_blocks = nb;
+		HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_ncount, 0, 16 * sizeof(int16_t), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, stride * sizeof(uint32_t), g.stream));
+		HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
+	}
+	else
+	{
+		int			rc = hnsw_grow_dense(h, base, nb);
+
+		if (rc)
+			return rc;
+	}
 	/* every page is laid out before anything is linked: a node is unreachable until its own insert links it */
-	HIP_TRY(hipMemsetAsync(h->d_vecs, 0, (size_t) h->dim * sizeof(float), g.stream));
-	HIP_TRY(hipMemcpyAsync(h->d_vecs + h->dim, d_rows, (size_t) n * h->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_levels, 0, sizeof(int), g.stream));
-	HIP_TRY(hipMemcpyAsync(h->d_levels + 1, lev.data(), (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_ncount, 0, (size_t) nb * 16 * sizeof(int16_t), g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_nbrs, 0xFF, (size_t) nb * stride * sizeof(uint32_t), g.stream));
-	HIP_TRY(hipMemsetAsync(h->d_tids, 0, sizeof(uint64_t), g.stream));
-	HIP_TRY(hipMemcpyAsync(h->d_tids + 1, d_tids, (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+	const size_t b1 = (size_t) base + 1;
+
+	HIP_TRY(hipMemcpyAsync(h->d_vecs + b1 * h->dim, d_rows, (size_t) n * h->dim * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_levels + b1, lev.data(), (size_t) n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_ncount + b1 * 16, 0, (size_t) n * 16 * sizeof(int16_t), g.stream));
+	HIP_TRY(hipMemsetAsync(h->d_nbrs + b1 * stride, 0xFF, (size_t) n * stride * sizeof(uint32_t), g.stream));
+	HIP_TRY(hipMemcpyAsync(h->d_tids + b1, d_tids, (size_t) n * sizeof(uint64_t), hipMemcpyDeviceToDevice, g.stream));
+	if (h->d_dead)
+		HIP_TRY(hipMemsetAsync(h->d_dead + b1, 0, (size_t) n, g.stream));
 	h->dense = true;
 	h->nblocks = nb;
 	h->ef_construction = ef_construction;
@@ -3562,12 +3604,12 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 		const size_t maxitems = lvcap * (size_t) m;
 		size_t		b1 = 0, b2 = 0;
 		std::vector<uint32_t> off_all(n);
-		uint32_t	e = NDBHIP_INVALID_BLOCK, dn = 0;
-		int			el = -1;
+		uint32_t	e = base ? h->entry_point : NDBHIP_INVALID_BLOCK, dn = 0;
+		int			el = base ? h->entry_level : -1;
 
 		while (dn < n)
 		{
-			uint32_t	b = (uint32_t) std::min<int64_t>(std::max<int64_t>((int64_t) dn / batch_div, 1), batch_max);
+			uint32_t	b = (uint32_t) std::min<int64_t>(std::max<int64_t>(((int64_t) base + dn) / batch_div, 1), batch_max);
 			uint32_t	nlev = 0;
 
 			b = std::min(b, n - dn);
@@ -3580,7 +3622,7 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 			for (uint32_t i = 0; i < b; i++)
 				if (e == NDBHIP_INVALID_BLOCK || lev[dn + i] > el)
 				{
-					e = dn + 1 + i;
+					e = base + dn + 1 + i;
 					el = lev[dn + i];
 				}
 			dn += b;
@@ -3611,18 +3653,18 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	struct Key { uint64_t key; uint32_t seq; uint32_t x; double d2; };
 	std::vector<Key> keys, keys2;
 	std::vector<uint32_t> radix_cnt(65537);
-	uint32_t	entry = NDBHIP_INVALID_BLOCK;
-	int			entry_level = -1;
+	uint32_t	entry = base ? h->entry_point : NDBHIP_INVALID_BLOCK;
+	int			entry_level = base ? h->entry_level : -1;
 	uint32_t	done = 0;
 	int64_t		nbatches = 0, maxbatch = 0, nprunes = 0;
 
 	memset(h->build_stats, 0, sizeof(h->build_stats));
 	while (done < n)
 	{
-		uint32_t	b = (uint32_t) std::min<int64_t>(std::max<int64_t>((int64_t) done / batch_div, 1), batch_max);
+		uint32_t	b = (uint32_t) std::min<int64_t>(std::max<int64_t>(((int64_t) base + done) / batch_div, 1), batch_max);
 
 		b = std::min(b, n - done);
-		const uint32_t first = done + 1;
+		const uint32_t first = base + done + 1;
 
 		if (entry != NDBHIP_INVALID_BLOCK)
 		{
@@ -3777,6 +3819,54 @@ ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uin
 	h->build_stats[5] = maxbatch;
 	h->build_stats[0] = nprunes;
 	return NDBHIP_OK;
+}
+
+extern "C" int
+ndbhip_hnsw_build_intended_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+								  const int32_t *levels, int ef_construction, int batch_div, int batch_max)
+{
+	return h2_build_rows(h, d_rows, d_tids, n, levels, ef_construction, batch_div, batch_max, 0);
+}
+
+/* hnswinsert under `intended` (src/index/hnsw_am.c:478-538): n MORE rows on top of the graph the mirror holds — built here in
+ * either mode, or loaded (a loaded graph is first given the dense layout): node nblocks + i = row i, the batch schedule goes
+ * on from the relation's size.  On an empty mirror this is ndbhip_hnsw_build_intended_device. */
+extern "C" int
+ndbhip_hnsw_insert_intended_device(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint32_t n,
+								   const int32_t *levels, int ef_construction, int batch_div, int batch_max)
+{
+	if (!h)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	return h2_build_rows(h, d_rows, d_tids, n, levels, ef_construction, batch_div, batch_max,
+						 (!h->loaded || h->nblocks < 1) ? 0u : h->nblocks - 1);
+}
+
+/* ... and for host rows / heapPtrs (6 bytes each), staged by the library: what ndb_hnswinsert calls when neurondb.ref_compat
+ * is off */
+extern "C" int
+ndbhip_hnsw_insert_intended(ndbhip_hnsw *h, const float *rows, const uint8_t *tids6, uint32_t n, const int32_t *levels,
+							int ef_construction, int batch_div, int batch_max)
+{
+	if (need_init()) return NDBHIP_ERR_NODEVICE;
+	HNSW_NOT_FROZEN(h, "ndbhip_hnsw_insert_intended");
+	if (!h || !rows || !tids6 || !levels || n < 1)
+		return fail(NDBHIP_ERR_INVALID, "bad arguments");
+	float	   *d_rows = nullptr;
+	uint64_t   *d_tids = nullptr;
+	std::vector<uint64_t> t64(n);
+
+	for (uint32_t i = 0; i < n; i++)
+		t64[i] = ndb_tid_pack(tids6 + (size_t) i * 6);
+	HIP_TRY(hipMalloc((void **) &d_rows, (size_t) n * h->dim * sizeof(float)));
+	HIP_TRY(hipMalloc((void **) &d_tids, (size_t) n * sizeof(uint64_t)));
+	HIP_TRY(hipMemcpyAsync(d_rows, rows, (size_t) n * h->dim * sizeof(float), hipMemcpyHostToDevice, g.stream));
+	HIP_TRY(hipMemcpyAsync(d_tids, t64.data(), (size_t) n * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+	const int	rc = ndbhip_hnsw_insert_intended_device(h, d_rows, d_tids, n, levels, ef_construction, batch_div, batch_max);
+
+	(void) hipStreamSynchronize(g.stream);
+	(void) hipFree(d_rows);
+	(void) hipFree(d_tids);
+	return rc;
 }
 
 /* kNN search of the `intended` mode on a dense mirror (built by ndbhip_hnsw_build_intended_device, or any graph):

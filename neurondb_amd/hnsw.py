@@ -83,9 +83,10 @@ class HnswIndex:
                                              _ptr(lv), int(ef_construction)))
         self.nblocks = len(lv) + 1
 
-    def build_intended(self, rows, tids, levels, ef_construction=200, batch_div=16, batch_max=8192):
+    def build_intended(self, rows, tids, levels, ef_construction=200, batch_div=16, batch_max=8192, append=False):
         """The `intended` graph (ndbhip_hnsw_build_intended_device; oracle/ndb_oracle_hnsw2.c defines it): rows as a
-        numpy array or a CUDA tensor, node i + 1 = row i."""
+        numpy array or a CUDA tensor, node i + 1 = row i.  append: the rows go on top of the graph the mirror holds
+        (ndbhip_hnsw_insert_intended_device: hnswinsert under `intended`), node nblocks + i = row i."""
         import torch
         r = rows if isinstance(rows, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).cuda()
         if isinstance(tids, torch.Tensor):
@@ -97,10 +98,11 @@ class HnswIndex:
             t8[:, :6] = t6
             tt = torch.from_numpy(t8.view(np.int64).reshape(-1)).cuda()
         lv = np.ascontiguousarray(levels, dtype=np.int32)
-        check(lib().ndbhip_hnsw_build_intended_device(self._h, C.c_void_p(r.data_ptr()), C.c_void_p(tt.data_ptr()), len(lv),
-                                                      _ptr(lv), int(ef_construction), int(batch_div), int(batch_max)))
+        fn = lib().ndbhip_hnsw_insert_intended_device if append else lib().ndbhip_hnsw_build_intended_device
+        check(fn(self._h, C.c_void_p(r.data_ptr()), C.c_void_p(tt.data_ptr()), len(lv),
+                 _ptr(lv), int(ef_construction), int(batch_div), int(batch_max)))
         check(lib().ndbhip_synchronize())
-        self.nblocks = len(lv) + 1
+        self.nblocks = (self.nblocks if append and getattr(self, "nblocks", 0) else 1) + len(lv)
 
     def search_intended(self, queries, ef=HNSW_DEFAULT_EF_SEARCH, k=HNSW_DEFAULT_K, walk16=False, strategy=1):
         """kNN of the `intended` mode: (blocks [nq, k], dist [nq, k], count [nq], evaluations [nq]).  strategy = the operator

@@ -691,19 +691,27 @@ h2_insert_apply(ndbo_hnsw *g, uint32_t x, int level, const h2_sel *s, int select
 }
 
 /*
- * Build over n rows (row i becomes block i + 1), levels injected, the batch schedule of the header.  select: bit 0: 0 = the
- * nearest, 1 = the heuristic; bit 1: a new node takes up to 2m links at level 0 instead of m.  Returns the number of batches.
+ * Build over n rows, levels injected, the batch schedule of the header.  On an empty graph row i becomes block i + 1; on a graph
+ * that holds nodes already (round 6: hnswinsert under `intended`, src/index/hnsw_am.c:478-538 — one row, one batch — and bulk
+ * appends) row i becomes block nblocks + i and the schedule goes on from the nodes inserted so far.  select: bit 0: 0 = the
+ * nearest, 1 = the heuristic; bit 1: a new node takes up to 2m links at level 0 instead of m.  Returns the number of
+ * batches, -1 when the graph's arrays cannot hold the rows.
  */
 int
 ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, const int *levels, int batch_div,
 			  int batch_max, int select)
 {
 	const int	m = g->m;
+	const int64_t base = g->nblocks > 0 ? (int64_t) g->nblocks - 1 : 0;	/* nodes there already: blocks 1 .. base */
 	int64_t		done = 0;
 	int			nbatches = 0;
-	uint8_t    *visited = (uint8_t *) calloc((size_t) n + 2, 1);
+	uint8_t    *visited;
 	h2_sel	   *sel = NULL;
 	int64_t		capsel = 0;
+
+	if (base + n + 1 > (int64_t) g->cap_blocks)
+		return -1;
+	visited = (uint8_t *) calloc((size_t) (base + n) + 2, 1);
 
 	if (batch_div < 1)
 		batch_div = 1;
@@ -711,7 +719,7 @@ ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, 
 		batch_max = 1;
 	while (done < n)
 	{
-		int64_t		b = (int64_t) g->inserted / batch_div,
+		int64_t		b = (base + done) / batch_div,	/* (nodes the relation holds: = g->inserted on a graph nothing was deleted from) */
 					i;
 
 		if (b < 1)
@@ -733,7 +741,7 @@ ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, 
 		/* the members' vectors are in place before anyone searches (a member is not reachable until it is linked) */
 		for (i = 0; i < b; i++)
 		{
-			const uint32_t x = (uint32_t) (done + i + 1);
+			const uint32_t x = (uint32_t) (base + done + i + 1);
 			int			lev = levels[done + i];
 
 			if (lev < 0)
@@ -746,10 +754,10 @@ ndbo_h2_build(ndbo_hnsw *g, const float *vecs, const ndbo_tid *tids, int64_t n, 
 			g->levels[x] = lev;
 		}
 		for (i = 0; i < b; i++)
-			h2_insert_search(g, vecs + (size_t) (done + i) * g->dim, g->levels[done + i + 1], select, &sel[i], visited);
+			h2_insert_search(g, vecs + (size_t) (done + i) * g->dim, g->levels[base + done + i + 1], select, &sel[i], visited);
 		for (i = 0; i < b; i++)
 		{
-			const uint32_t x = (uint32_t) (done + i + 1);
+			const uint32_t x = (uint32_t) (base + done + i + 1);
 
 			g->nblocks = x + 1;		/* (visible to validity checks only once it can be named) */
 			h2_insert_apply(g, x, g->levels[x], &sel[i], select);

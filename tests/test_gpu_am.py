@@ -197,10 +197,15 @@ def test_ivf_insert_and_bulkdelete_callbacks():
     assert [tuple(t) for t in ix.export()[3].tolist()] == [tuple(t) for t in np.array(kept).tolist()]
 
 
-def test_hnsw_insert_and_bulkdelete_callbacks():
+@pytest.mark.parametrize("compat", [1, 0], ids=["ref_compat", "intended"])
+def test_hnsw_insert_and_bulkdelete_callbacks(gucs, compat):
+    """neurondb.ref_compat = 1: ndb_hnswinsert is hnswInsertNode (oracle ndbo_hnsw_insert); 0: the `intended` insert — one row,
+    one batch of the definition's schedule (oracle ndbo_h2_build on the graph as it stands) — on top of a graph the
+    reference's own insert built: the mirror equals the model slot for slot either way"""
     from neurondb_amd import HnswIndex, _lib
     from neurondb_amd._lib import BULKDELETE_CALLBACK, NdbItemPointer
     L = _lib.lib()
+    gucs("neurondb.ref_compat", compat)
     g, vecs = build_graph(400, 16, 5, 200, seed=73)           # ef_construction 200: what ndb_hnswinsert uses
     ix, a = load(g)
     # model = the oracle over what the loaded (packed) mirror holds
@@ -214,12 +219,32 @@ def test_hnsw_insert_and_bulkdelete_callbacks():
         t = ndbo.tids_from_rows(np.array([400 + i]))[0]
         tid = NdbItemPointer(int(t["bi_hi"]), int(t["bi_lo"]), int(t["posid"]))
         assert L.ndb_hnswinsert(ix._h, vector_datum(more[i]), 8 + 4 * 16, VECTOR, C.byref(tid), lv) == 1
-        model.insert(more[i], 400 + i, lv)
+        if compat:
+            model.insert(more[i], 400 + i, lv)
+        else:
+            assert model.build_intended(more[i:i + 1], [lv], tids=ndbo.tids_from_rows(np.array([400 + i])), batch_div=64,
+                                        batch_max=1024, select=1) == 1
     q = rng.standard_normal((8, 16)).astype(np.float32)
     from tests.test_gpu_hnsw import check
     ix.nblocks = 431
+    d, e2 = ix.export(), model.arrays()
+    assert d["nblocks"] == 431 and (d["entry_point"], d["entry_level"]) == (e2["entry_point"], e2["entry_level"])
+    assert np.array_equal(d["levels"][1:], e2["levels"][1:])
+    if not compat:
+        # (the reference's inserts write lists above a node's own level, Q12 / Q21 — kept by the dense layouts, not part of the
+        # index: compared up to every node's level)
+        for b_ in range(1, 431):
+            top = int(d["levels"][b_]) + 1
+            assert np.array_equal(d["ncount"][b_, :top], e2["ncount"][b_, :top]), b_
+            assert np.array_equal(d["nbrs"][b_, :top], e2["nbrs"][b_, :top]), b_
     for strategy in (1, 2):
         check(model, ix, q, strategy, 32, 10)
+    # ... and the scan the same GUC selects finds the same rows as its oracle
+    for strategy in (1, 2, 3):
+        ob = ix.search_intended(q, 32, 10, strategy=strategy)
+        for i in range(len(q)):
+            eb, ed, ns = model.search_intended_s(q[i], strategy, 32, 10)
+            assert np.array_equal(ob[0][i, :ob[2][i]], eb) and np.array_equal(ob[1][i, :ob[2][i]].view(np.uint32), ed.view(np.uint32))
 
     def cb(ip, state):
         return 1 if ip.contents.posid % 9 == 0 else 0

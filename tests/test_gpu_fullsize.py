@@ -223,6 +223,66 @@ def test_c3_hnsw_at_full_size():
     ix2.close()
 
 
+def test_c3_intended_hnsw_at_full_size():
+    """the search a drop-in `ORDER BY v <=> $q` on an hnsw index runs (neurondb.ref_compat off) at C3's full size.
+    1M-node `intended` graph built on the device over the bench's clustered unit rows; strategy 2 (cosine) on float4 rows
+    and on fp16 walk rows: k results, ascending, every distance hnswComputeDistance(query, that node) bit for bit
+    (hnsw_am.c:1321-1332), a query's answer the same alone and in a batch of 2048, recall@10 against a float64 brute
+    force, and 32 queries replayed by the oracle on the exported graph for BOTH walks (blocks, float4 bits, evaluation
+    counts); strategies 1 and 3: 8 queries each replayed the same way."""
+    import ctypes as C
+    from neurondb_amd import HnswIndex, _lib
+    dev = torch.device("cuda", 0)
+    _lib.ensure_init(0)
+    n, m, efc, ef = N, 16, 200, 64
+    base = make_data(n, DIM, "clustered", 1024, 0.1, 0x5EED0003, 0x5EEDC0DE, dev)
+    base = base / base.norm(dim=1, keepdim=True)
+    q = make_data(2048, DIM, "clustered", 1024, 0.1, 0x5EED0004, 0x5EEDC0DE, dev)
+    q = q / q.norm(dim=1, keepdim=True)
+    r = np.random.default_rng(11).uniform(1e-12, 1.0, n)
+    levels = np.clip((-np.log(r) * np.float32(0.36)).astype(np.int32), 0, 15)
+    ix = HnswIndex(DIM, m)
+    ix.build_intended(base, torch.arange(n, device=dev, dtype=torch.int64), levels, efc)
+    res = {w: ix.search_intended(q, ef, K, walk16=w, strategy=2) for w in (False, True)}
+    L = ndbo.lib()
+    bh, qh = base.cpu().numpy(), q.cpu().numpy()
+    err = C.c_int(0)
+    sims = q[:256].double() @ base.double().T
+    gt = torch.topk(sims, K, dim=1).indices.cpu().numpy() + 1
+    del sims
+    for w, (ob, od, oc, oe) in res.items():
+        assert (oc == K).all() and (np.diff(od, axis=1) >= 0).all() and (oe > ef).all()
+        assert all(len(set(row.tolist())) == K for row in ob[:512])
+        for i in range(0, 2048, 97):
+            exp = np.array([L.ndbo_hnsw_distance(qh[i], bh[b - 1], DIM, 2, C.byref(err)) for b in ob[i]], np.float32)
+            assert np.array_equal(exp.view(np.uint32), od[i].view(np.uint32)), (w, i)
+        b1, d1, c1, e1 = ix.search_intended(q[9:10], ef, K, walk16=w, strategy=2)
+        assert np.array_equal(b1[0], ob[9]) and np.array_equal(d1[0].view(np.uint32), od[9].view(np.uint32)) and e1[0] == oe[9]
+        rec = float(np.mean([len(set(ob[i].tolist()) & set(gt[i].tolist())) / K for i in range(256)]))
+        assert rec > 0.85, (w, rec)
+    # the two walks agree on almost every query (they differ where halves round a row across a neighbour)
+    assert (res[False][0] == res[True][0]).all(axis=1).mean() > 0.97
+    e = ix.export()
+    vecs = np.zeros((n + 1, DIM), np.float32)
+    vecs[1:] = bh
+    og = ndbo.HnswGraph.from_arrays(vecs, e["levels"], e["ncount"], e["nbrs"], None, e["entry_point"], e["entry_level"], m, efc)
+    del vecs
+    w16 = og.walk_rows()
+    for w, (ob, od, oc, oe) in res.items():
+        for i in range(32):
+            eb, ed, ns = og.search_intended_s(qh[i], 2, ef, K, w16=w16 if w else None)
+            assert np.array_equal(eb, ob[i, :oc[i]]) and ns == oe[i], (w, i)
+            assert np.array_equal(ed.view(np.uint32), od[i, :oc[i]].view(np.uint32)), (w, i)
+    for strategy in (1, 3):
+        for w in (False, True):
+            ob, od, oc, oe = ix.search_intended(q[:8], ef, K, walk16=w, strategy=strategy)
+            for i in range(8):
+                eb, ed, ns = og.search_intended_s(qh[i], strategy, ef, K, w16=w16 if w else None)
+                assert np.array_equal(eb, ob[i, :oc[i]]) and ns == oe[i], (strategy, w, i)
+                assert np.array_equal(ed.view(np.uint32), od[i, :oc[i]].view(np.uint32)), (strategy, w, i)
+    ix.close()
+
+
 def _free_gib():
     free, _ = torch.cuda.mem_get_info(0)
     return free / 2 ** 30

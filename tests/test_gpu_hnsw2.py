@@ -252,3 +252,43 @@ def test_device_fp64_sqrt_and_divide_are_correctly_rounded():
         eb, ed, ns = og.search_intended_s(q[i], 2, 64, 10)
         assert np.array_equal(ob[i, :oc[i]], eb) and oe[i] == ns
     ix.close()
+
+
+@pytest.mark.parametrize("kind,n0,dim,m,efc,select", [("clustered", 1500, 64, 8, 48, 1), ("normal", 0, 48, 8, 40, 1), ("integer", 900, 40, 6, 32, 7)])
+def test_rows_appended_to_an_intended_graph_equal_the_oracle(kind, n0, dim, m, efc, select):
+    """hnswinsert under `intended` (ndbhip_hnsw_insert_intended_device == ndbo_h2_build on a graph that is not empty): calls
+    of 1, 7, 300 rows and the rest on top of n0 built rows, the schedule going on from the relation's size — graph slot for
+    slot after every call, searches equal at the end; walk rows follow the appended rows."""
+    from neurondb_amd import HnswIndex, _lib
+    from oracle import ndbo
+    n = n0 + 1 + 7 + 300 + 400
+    base, q, levels = _data(kind, n, dim, 24, seed=n + dim)
+    tids = ndbo.tids_from_rows(np.arange(n))
+    og = ndbo.HnswGraph(dim, m, efc, cap_nodes=n + 1)
+    _lib.ensure_init()
+    _lib.check(_lib.lib().ndbhip_hnsw_set_intended_select(select))
+    try:
+        ix = HnswIndex(dim, m)
+        lo = 0
+        for cnt in ([n0] if n0 else []) + [1, 7, 300, 400]:
+            og.build_intended(base[lo:lo + cnt], levels[lo:lo + cnt], tids=tids[lo:lo + cnt], batch_div=16, batch_max=256, select=select)
+            ix.build_intended(base[lo:lo + cnt], tids[lo:lo + cnt], levels[lo:lo + cnt], efc, batch_div=16, batch_max=256, append=lo > 0)
+            lo += cnt
+            d, e = ix.export(), og.arrays()
+            assert d["nblocks"] == lo + 1 == e["nblocks"] and (d["entry_point"], d["entry_level"]) == (e["entry_point"], e["entry_level"])
+            assert np.array_equal(d["levels"][1:], e["levels"][1:])
+            assert np.array_equal(d["ncount"][1:], e["ncount"][1:]), (lo, np.argwhere(d["ncount"] != e["ncount"])[:5])
+            assert np.array_equal(d["nbrs"][1:], e["nbrs"][1:]), (lo, np.argwhere(d["nbrs"] != e["nbrs"])[:5])
+            if lo == n0 + 8 and dim % 4 == 0:
+                ix.search_intended(q, 32, 5, walk16=True)            # walk rows made here must be made again after the next append
+    finally:
+        _lib.check(_lib.lib().ndbhip_hnsw_set_intended_select(1))
+    w16 = og.walk_rows() if dim % 4 == 0 else None
+    for strategy in (1, 2):
+        for walk16 in ([False, True] if w16 is not None else [False]):
+            ob, od, oc, oe = ix.search_intended(q, 48, 10, walk16=walk16, strategy=strategy)
+            for i in range(len(q)):
+                eb, ed, ns = og.search_intended_s(q[i], strategy, 48, 10, w16=w16 if walk16 else None)
+                assert oc[i] == len(eb) and np.array_equal(ob[i, :oc[i]], eb) and oe[i] == ns
+                assert np.array_equal(od[i, :oc[i]].view(np.uint32), ed.view(np.uint32))
+    ix.close()
