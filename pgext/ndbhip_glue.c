@@ -116,98 +116,24 @@ ndb_hip_ready(void)
 	return state == 1;
 }
 
-/* ---- mirror cache: one mirror per index and per version of its pages ---- */
-typedef struct MirrorEntry
-{
-	Oid			relid;
-	uint64		key;			/* (database, relfilenumber) of the file the pages were read from: index_key() */
-	uint64		stamp;			/* that key's generation (ivf_stamp) when the pages were read; 0 = unknown, never fresh */
-	ndbhip_ivf *ivf;
-	ndbhip_hnsw *hnsw;
-	int			pins;			/* open scans of this backend that hold `ivf` / `hnsw` (ndb_hip_mirror_pin / _unpin) */
-} MirrorEntry;
-
-#define NDB_MAX_MIRRORS 32
-static MirrorEntry mirrors[NDB_MAX_MIRRORS];
-
-/* mirrors that went stale while a scan node of this backend still held them (two kNN scan nodes on one index with a
- * lateral rescan, and an insert from anywhere in between): destroyed when their last scan ends */
-typedef struct Retired
-{
-	ndbhip_ivf *ivf;
-	ndbhip_hnsw *hnsw;
-	int			pins;
-} Retired;
-static Retired retired[NDB_MAX_MIRRORS];
+/* ---- mirror cache: one mirror per index and per version of its pages (rules and tests: ndb_mirror_cache.h) ---- */
+#define NDB_MC_DESTROY_IVF(p) ndbhip_ivf_destroy((ndbhip_ivf *) (p))
+#define NDB_MC_DESTROY_HNSW(p) ndbhip_hnsw_destroy((ndbhip_hnsw *) (p))
+#include "ndb_mirror_cache.h"
 
 static uint64 index_key(Relation index);
-
-static void
-mirror_drop(MirrorEntry *e)
-{
-	if (e->pins > 0 && (e->ivf || e->hnsw))
-	{
-		for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-			if (!retired[i].ivf && !retired[i].hnsw)
-			{
-				retired[i].ivf = e->ivf;
-				retired[i].hnsw = e->hnsw;
-				retired[i].pins = e->pins;
-				e->ivf = NULL;
-				e->hnsw = NULL;
-				e->pins = 0;
-				return;
-			}
-		/* Every retired slot is held by an open scan too.  Never an ERROR from here (this runs inside aminsert,
-		 * ambulkdelete and every scan's lookup): the entry stays where it is, marked "never fresh" (stamp 0 matches no
-		 * lookup), and is dropped for good by a later call once its scans have ended — pins come down on endscan and on
-		 * abort alike (ndb_hip_mirror_pin_scoped), so that moment always comes. */
-		e->stamp = 0;
-		return;
-	}
-	if (e->ivf) ndbhip_ivf_destroy(e->ivf);
-	if (e->hnsw) ndbhip_hnsw_destroy(e->hnsw);
-	e->ivf = NULL;
-	e->hnsw = NULL;
-	e->pins = 0;
-}
 
 /* ambeginscan / amendscan: a scan holds the raw mirror pointer from its first rescan to its end */
 void
 ndb_hip_mirror_pin(const void *mirror)
 {
-	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-		if (mirror && ((const void *) mirrors[i].ivf == mirror || (const void *) mirrors[i].hnsw == mirror))
-		{
-			mirrors[i].pins++;
-			return;
-		}
+	ndb_mc_pin(mirror);
 }
 
 void
 ndb_hip_mirror_unpin(const void *mirror)
 {
-	if (!mirror)
-		return;
-	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-	{
-		if ((const void *) mirrors[i].ivf == mirror || (const void *) mirrors[i].hnsw == mirror)
-		{
-			if (mirrors[i].pins > 0)
-				mirrors[i].pins--;
-			return;
-		}
-		if ((const void *) retired[i].ivf == mirror || (const void *) retired[i].hnsw == mirror)
-		{
-			if (--retired[i].pins <= 0)
-			{
-				if (retired[i].ivf) ndbhip_ivf_destroy(retired[i].ivf);
-				if (retired[i].hnsw) ndbhip_hnsw_destroy(retired[i].hnsw);
-				memset(&retired[i], 0, sizeof(retired[i]));
-			}
-			return;
-		}
-	}
+	ndb_mc_unpin(mirror);
 }
 
 /*
@@ -262,15 +188,8 @@ ndb_hip_mirror_unpin_scoped(void *pin)
 static void
 mirror_reset(void *arg)			/* MemoryContextCallback on CacheMemoryContext: ERROR unwinds by longjmp */
 {
-	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-	{
-		if (mirrors[i].ivf) ndbhip_ivf_destroy(mirrors[i].ivf);
-		if (mirrors[i].hnsw) ndbhip_hnsw_destroy(mirrors[i].hnsw);
-		memset(&mirrors[i], 0, sizeof(mirrors[i]));
-		if (retired[i].ivf) ndbhip_ivf_destroy(retired[i].ivf);
-		if (retired[i].hnsw) ndbhip_hnsw_destroy(retired[i].hnsw);
-		memset(&retired[i], 0, sizeof(retired[i]));
-	}
+	(void) arg;
+	ndb_mc_reset();
 }
 
 /* the relation's blocks, copied under SHARE locks: no pointer into a buffer page outlives its lock */
@@ -292,12 +211,14 @@ copy_relation_pages(Relation index, BlockNumber *nblocks)
 	return pages;
 }
 
-static MirrorEntry *
+/* NULL: the index's stale mirror is still pinned by scans of this backend and no retired slot is free — the caller does
+ * not search a device mirror for this call (neurondb.compute_mode decides: CPU path or ERROR) */
+static NdbMirrorEntry *
 mirror_slot(Relation index, uint64 stamp)
 {
 	static bool registered = false;
-	MirrorEntry *free_slot = NULL;
-	const uint64 key = index_key(index);
+	NdbMirrorEntry *e;
+	int			full = 0;
 
 	if (!registered)
 	{
@@ -308,42 +229,24 @@ mirror_slot(Relation index, uint64 stamp)
 		MemoryContextRegisterResetCallback(CacheMemoryContext, cb);
 		registered = true;
 	}
-	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-	{
-		if (mirrors[i].relid == RelationGetRelid(index))
-		{
-			/* fresh only for the SAME file at the SAME generation: a new relfilenode (TRUNCATE, VACUUM FULL, CLUSTER,
-			 * REINDEX) starts its own counter at 1 again, so the stamp alone would keep the old file's mirror — and its
-			 * heap TIDs — alive.  Generation 0 = the counter table could not say (full, or not attachable): never fresh. */
-			if (mirrors[i].key != key || mirrors[i].stamp != stamp || stamp == 0)
-			{
-				mirror_drop(&mirrors[i]);
-				mirrors[i].key = key;
-				mirrors[i].stamp = stamp;
-			}
-			return &mirrors[i];
-		}
-		if (!free_slot && mirrors[i].relid == InvalidOid)
-			free_slot = &mirrors[i];
-	}
-	if (!free_slot)
+	e = ndb_mc_slot((uint32_t) RelationGetRelid(index), index_key(index), stamp, &full);
+	if (!e && full)
 		ereport(ERROR, (errmsg("neurondb: more than %d device-mirrored indexes in one backend", NDB_MAX_MIRRORS)));
-	free_slot->relid = RelationGetRelid(index);
-	free_slot->key = key;
-	free_slot->stamp = stamp;
-	return free_slot;
+	return e;
 }
 
 ndbhip_ivf *
 ndb_hip_ivf_mirror(Relation index, uint64 stamp)
 {
-	MirrorEntry *e = mirror_slot(index, stamp);
+	NdbMirrorEntry *e = mirror_slot(index, stamp);
 
+	if (!e)
+		return NULL;			/* a stale mirror that cannot be dropped yet is never served: the caller applies neurondb.compute_mode */
 	if (!e->ivf)
 	{
 		BlockNumber n;
 		uint8	   *pages = copy_relation_pages(index, &n);
-		int			rc = ndbhip_ivf_load_pages(&e->ivf, pages, (uint32) n);
+		int			rc = ndbhip_ivf_load_pages((ndbhip_ivf **) &e->ivf, pages, (uint32) n);
 
 		pfree(pages);
 		if (rc != NDBHIP_OK)
@@ -352,19 +255,21 @@ ndb_hip_ivf_mirror(Relation index, uint64 stamp)
 			return NULL;		/* the caller applies neurondb.compute_mode */
 		}
 	}
-	return e->ivf;
+	return (ndbhip_ivf *) e->ivf;
 }
 
 ndbhip_hnsw *
 ndb_hip_hnsw_mirror(Relation index, uint64 stamp)
 {
-	MirrorEntry *e = mirror_slot(index, stamp);
+	NdbMirrorEntry *e = mirror_slot(index, stamp);
 
+	if (!e)
+		return NULL;
 	if (!e->hnsw)
 	{
 		BlockNumber n;
 		uint8	   *pages = copy_relation_pages(index, &n);
-		int			rc = ndbhip_hnsw_load_pages(&e->hnsw, pages, (uint32) n);
+		int			rc = ndbhip_hnsw_load_pages((ndbhip_hnsw **) &e->hnsw, pages, (uint32) n);
 
 		pfree(pages);
 		if (rc != NDBHIP_OK)
@@ -373,7 +278,7 @@ ndb_hip_hnsw_mirror(Relation index, uint64 stamp)
 			return NULL;
 		}
 	}
-	return e->hnsw;
+	return (ndbhip_hnsw *) e->hnsw;
 }
 
 bool
@@ -446,15 +351,18 @@ ndb_hip_ivf_note_insert(Relation index, int list_id, const float *vec, ItemPoint
 	const uint64 gen = ndb_gen_bump(generations(), index_key(index));
 
 	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-		if (mirrors[i].relid == RelationGetRelid(index) && mirrors[i].ivf)
+		if (ndb_mc_mirrors[i].relid == (uint32_t) RelationGetRelid(index) && ndb_mc_mirrors[i].ivf)
 		{
 			/* this backend's own mirror follows along — only if nobody else changed the index in between
-			 * (gen is exactly one past the generation the mirror holds) and the append itself worked */
-			if (gen != 0 && gen == mirrors[i].stamp + 1 && mirrors[i].key == index_key(index) &&
-				ndbhip_ivf_append(mirrors[i].ivf, list_id, vec, (const uint8_t *) heap_tid) == NDBHIP_OK)
-				mirrors[i].stamp = gen;
+			 * (gen is exactly one past the generation the mirror holds; a never-fresh entry, stamp 0, does not follow) and
+			 * the append itself worked */
+			if (gen != 0 && ndb_mc_mirrors[i].stamp != 0 && gen == ndb_mc_mirrors[i].stamp + 1 &&
+				ndb_mc_mirrors[i].key == index_key(index) &&
+				ndbhip_ivf_append((ndbhip_ivf *) ndb_mc_mirrors[i].ivf, list_id, vec, (const uint8_t *) heap_tid) == NDBHIP_OK)
+				ndb_mc_mirrors[i].stamp = gen;
 			else
-				mirror_drop(&mirrors[i]);		/* out of step: rebuild on the next scan (an open scan keeps its copy until it ends) */
+				(void) ndb_mc_drop(&ndb_mc_mirrors[i]);	/* out of step: rebuild on the next scan (an open scan keeps its copy until it
+															 * ends; a mirror that cannot be retired stays, never fresh) */
 		}
 }
 
@@ -464,12 +372,7 @@ void
 ndb_hip_ivf_note_delete(Relation index)
 {
 	(void) ndb_gen_bump(generations(), index_key(index));	/* other backends and the owner: reload before the next scan */
-	for (int i = 0; i < NDB_MAX_MIRRORS; i++)
-		if (mirrors[i].relid == RelationGetRelid(index))
-		{
-			mirror_drop(&mirrors[i]);
-			memset(&mirrors[i], 0, sizeof(mirrors[i]));
-		}
+	ndb_mc_invalidate((uint32_t) RelationGetRelid(index));
 }
 
 /* ---- the scan callbacks: IndexScanDesc <-> ndb_index_scan ---- */
