@@ -3216,6 +3216,14 @@ static int	g_s16c_epi = 1;		/* 1: the sweep's matrix pipe screens its own accumu
 static int	g_s16c_pf = 0;		/* variants of k_s16c_sweep<8, 2> for A/B: 3 = an in-wave L2 prefetch, 16 / 32 / 48 = non-temporal rows / pairs / both ("screen16c_pf") */
 static int	g_s16c_dense = 1;	/* dense buckets (tile of 256 x 256) run k_s16c_dense (ndbhip_screen16d.h: loader and prefetcher waves); 0: k_s16c_sweep<8, 2> ("screen16c_dense") */
 static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch's first thresholds, 0 = none ("screen16c_sample") */
+/* The dense tile's kernel (ndbhip_screen16d.h) from this many pairs per bucket with pairs (the previous batch's): round 6,
+ * measured on 1M x 768 at 512 .. 4096 queries a batch (tools/dense_probe.py, SIGMA = 0.5 / 1.0): whole lists 47 pairs a bucket
+ * 0.82 against the ring's 0.86 ms, 74: 1.30 / 1.58, 133: 2.14 / 2.90 (25: 0.56 / 0.48 — the ring's); layouts with sublists
+ * (buckets of ~128 rows fill half a row tile) 131: 1.56 / 1.79, 72: 1.04 / 1.01, 45: 0.76 / 0.59.  Until round 5 the rule
+ * was 320 and whole lists only: a balanced table at 4096 queries (128 pairs a list) stayed on the 128 x 128 ring at 0.2 of
+ * the matrix peak. */
+static int	g_s16c_dense_min = 48;		/* "screen16c_dense_min" */
+static int	g_s16c_dense_min_sub = 100;	/* "screen16c_dense_min_sub": the same for regrouped planes (sublists); 0 = never */
 static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
@@ -3805,7 +3813,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	/* (float4 mirrors: k_seed_gather copies fp32 rows) */
 	if (!seed_by_sublist && cen && !xseed && !ix->f16 && R == R_IVF_L2 && !ix->s16_sub && g_s16c_sample > 0 && k <= 64 && npr <= 512 &&
 		ix->nrows >= 16 * (int64_t) g_s16c_sample &&
-		(g_s16c_qb == 8 || (g_s16c_qb == 0 && ix->s16c_density >= 320.0f)))
+		(g_s16c_qb == 8 || (g_s16c_qb == 0 && ix->s16c_density >= (float) g_s16c_dense_min)))
 	{
 		const uint32_t ns = (uint32_t) g_s16c_sample, sstr = (ns + 63u) & ~63u;
 
@@ -3895,7 +3903,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 	 * x 256 rows where they are probed by hundreds and are whole lists (what the previous batch on this mirror looked
 	 * like; before any: regrouped planes mean clustered rows, i.e. few) */
 	const int	c_qb = !cen ? 4 : (g_s16c_qb == 1 || g_s16c_qb == 4 || g_s16c_qb == 8) ? g_s16c_qb :
-		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 : (ix->s16c_density >= 320.0f && !sub && dimp / S16C_CH >= 2) ? 8 : 4)
+		(ix->s16c_density >= 0.0f ? (ix->s16c_density < 24.0f ? 1 :
+									(dimp / S16C_CH >= 2 && (sub ? (g_s16c_dense_min_sub > 0 && ix->s16c_density >= (float) g_s16c_dense_min_sub)
+											 : ix->s16c_density >= (float) g_s16c_dense_min)) ? 8 : 4)
 		 : (ix->s16_sub ? 1 : 4));
 	/* the register-streaming sweep (ndbhip_screen16w.h: sparse pair tables) takes items of ONE 32-row block — a wave each,
 	 * dealt round-robin: the sweep is as long as its busiest wave, and tiles of 128 rows over sublists of 40 to 200
@@ -4387,6 +4397,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 					   g.d_counters + 4);
 	if (cen && fl8[5] > 0)
 		ix->s16c_density = (float) fl8[4] / (float) fl8[5];		/* pairs per bucket with pairs: the next batch's tile size */
+		if (getenv("NDB_DENSITY"))
+			fprintf(stderr, "[ndbhip] pairs %llu buckets with pairs %llu density %.1f sub %d\n", (unsigned long long) fl8[4], (unsigned long long) fl8[5], ix->s16c_density, (int) ix->s16_sub);
 	if (g_debug_s16)
 	{
 		std::vector<unsigned int> h((size_t) 3 * nq + 4);
@@ -4686,6 +4698,18 @@ ndbhip_set_option(const char *name, int value)
 		if (value != 0 && (value < 256 || value > 2048))
 			return fail(NDBHIP_ERR_INVALID, "screen16c_sample must be 0 or 256..2048");
 		g_s16c_sample = value;
+	}
+	else if (!strcmp(name, "screen16c_dense_min_sub"))
+	{
+		if (value != 0 && (value < 24 || value > 100000))
+			return fail(NDBHIP_ERR_INVALID, "screen16c_dense_min_sub must be 0 (never) or 24 .. 100000 pairs per bucket");
+		g_s16c_dense_min_sub = value;
+	}
+	else if (!strcmp(name, "screen16c_dense_min"))
+	{
+		if (value < 24 || value > 100000)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_dense_min must be 24 .. 100000 pairs per bucket");
+		g_s16c_dense_min = value;
 	}
 	else if (!strcmp(name, "screen16c_tight"))
 	{

@@ -26,8 +26,9 @@ def main():
     kind = os.environ.get("DATA", "gauss")
     nq = int(os.environ.get("NQ", 4096))
     steps = int(os.environ.get("STEPS", 6))
-    base = make_data(n, dim, kind, 1024, 0.1, 0x5EED0001, 0x5EEDC0DE, dev)
-    qd = make_data(nq * 4, dim, kind, 1024, 0.1, 0x5EED0002, 0x5EEDC0DE, dev)
+    sigma = float(os.environ.get("SIGMA", 0.1))
+    base = make_data(n, dim, kind, 1024, sigma, 0x5EED0001, 0x5EEDC0DE, dev)
+    qd = make_data(nq * 4, dim, kind, 1024, sigma, 0x5EED0002, 0x5EEDC0DE, dev)
     ix = IvfIndex(dim, int(os.environ.get("LISTS", 1024)))
     ix.build_device(base, pack_tids(torch.arange(n, device=dev)), 50)
     ot = torch.zeros((nq, 10), dtype=torch.int64, device=dev)
@@ -83,7 +84,8 @@ def main():
             for w, who in ((0, "loader"), (1, "multiplier")):
                 items = max(1, ph[32 + 8 * w + 6])
                 print("    " + who + ", us per item: " + ", ".join(f"{nm} {ph[32 + 8 * w + i] / 100 / items:.2f}" for i, nm in enumerate(names)) +
-                      f"; {items} items", flush=True)
+                      f"; {items} items; results = constants {ph[48 + 8 * w] / 100 / items:.2f}, barrier {ph[49 + 8 * w] / 100 / items:.2f}, "
+                      f"pass 0 + queue {ph[50 + 8 * w] / 100 / items:.2f}, issue {ph[51 + 8 * w] / 100 / items:.2f}", flush=True)
         print(f"{v or 'defaults':48s} step {dt * 1e3:8.3f} ms  sweep {kms:8.3f} ms  issued {tf:7.1f} TFLOP/s  "
               f"launches/step {launches / steps:.1f} fallbacks {fb} emitted/q {em:.0f} rescored/q {rs:.1f} {same}", flush=True)
 
