@@ -3433,7 +3433,10 @@ ndbhip_hnsw_search_intended(ndbhip_hnsw *h, const float *queries, int nq, int st
 /* ================================================================== */
 /* the `intended` HNSW (ndbhip_hnsw2.h; oracle/ndb_oracle_hnsw2.c is its sequential definition)                   */
 /* ================================================================== */
-#include <hipcub/hipcub.hpp>
+/* rocPRIM, AMD's own device-primitive library (header-only, wave64-tuned radix sort and scan: /opt/rocm/include/rocprim) —
+ * called directly; round 5 went through hipCUB, the CUB-compatibility wrapper around the same kernels.  Used by the intended
+ * build only (back-links grouped on the device), never on a search path. */
+#include <rocprim/rocprim.hpp>
 #include "ndbhip_hnsw2.h"
 
 int			g_h2_host_groups = 0;	/* option hnsw_intended_host_groups: 1 = a build batch's back-links grouped on the host (rounds 3-4) */
@@ -3640,8 +3643,8 @@ h2_build_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint3
 		if (tmp.alloc(d_counts, 16)) return NDBHIP_ERR_HIP;
 		if (tmp.alloc(d_total, 16)) return NDBHIP_ERR_HIP;
 		HIP_TRY(hipMemsetAsync(d_total, 0, 8, g.stream));
-		HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, d_keys, d_keys2, d_vals, d_vals2, (int) maxitems, 0, end_bit, (hipStream_t) g.stream));
-		HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, d_flags, d_gpos, (int) maxitems, (hipStream_t) g.stream));
+		HIP_TRY(rocprim::radix_sort_pairs(nullptr, b1, d_keys, d_keys2, d_vals, d_vals2, (size_t) maxitems, 0u, (unsigned int) end_bit, (hipStream_t) g.stream));
+		HIP_TRY(rocprim::exclusive_scan(nullptr, b2, d_flags, d_gpos, 0u, (size_t) maxitems, rocprim::plus<uint32_t>(), (hipStream_t) g.stream));
 		cub_bytes = std::max(b1, b2);
 		if (tmp.alloc(d_cub, cub_bytes)) return NDBHIP_ERR_HIP;
 	}
@@ -3693,11 +3696,11 @@ h2_build_rows(ndbhip_hnsw *h, const float *d_rows, const uint64_t *d_tids, uint3
 								   entry_level, d_rowmem, d_rowlc);
 				hipLaunchKernelGGL(k_h2_bl_keys, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, nitems, (uint32_t) m, (const int *) d_sn,
 								   (const uint32_t *) d_sid, (const int *) d_rowlc, padkey, d_keys, d_vals);
-				HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_cub, cb, d_keys, d_keys2, d_vals, d_vals2, (int) nitems, 0, end_bit, (hipStream_t) g.stream));
+				HIP_TRY(rocprim::radix_sort_pairs(d_cub, cb, d_keys, d_keys2, d_vals, d_vals2, (size_t) nitems, 0u, (unsigned int) end_bit, (hipStream_t) g.stream));
 				hipLaunchKernelGGL(k_h2_bl_heads, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, nitems, (const unsigned long long *) d_keys2,
 								   padkey, d_flags);
 				cb = cub_bytes;
-				HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_cub, cb, d_flags, d_gpos, (int) nitems, (hipStream_t) g.stream));
+				HIP_TRY(rocprim::exclusive_scan(d_cub, cb, d_flags, d_gpos, 0u, (size_t) nitems, rocprim::plus<uint32_t>(), (hipStream_t) g.stream));
 				HIP_TRY(hipMemsetAsync(d_counts, 0, 8, g.stream));
 				hipLaunchKernelGGL(k_h2_bl_groups, dim3((nitems + 255) / 256), dim3(256), 0, g.stream, nitems, (uint32_t) m, first,
 								   (const unsigned long long *) d_keys2, (const uint32_t *) d_vals2, padkey, (const uint32_t *) d_flags,

@@ -1358,7 +1358,7 @@ k_h2_apply(H2Graph g, const H2Group *__restrict__ groups, uint32_t ngroups_host,
  * member i ascending, level descending, slot ascending — so the item index row * m + j IS the insertion order:
  *   k_h2_bl_rows    row -> (member, level)
  *   k_h2_bl_keys    key[idx] = target << 8 | level (a slot beyond the row's count: `pad`, which sorts behind every key)
- *   a STABLE radix sort of (key, idx) (hipcub::DeviceRadixSort) = by (target, insertion order): the host's order
+ *   a STABLE radix sort of (key, idx) (rocprim::radix_sort_pairs) = by (target, insertion order): the host's order
  *   k_h2_bl_heads   flags the first request of every target; an exclusive sum numbers the groups
  *   k_h2_bl_groups  requests (x, d2) in sorted order, groups (target, level, r0, r1), the counts k_h2_apply reads
  * Nothing comes back to the host: a build is one queue of launches.
