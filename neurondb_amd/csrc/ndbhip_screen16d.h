@@ -39,18 +39,12 @@
  * the chunk's barrier, 2 requesting the next chunk, 3 multiplying, 4 the item's results (pass 0, records), 5 tightening,
  * 6 items */
 #ifdef NDB_PHASES
-#define S16D_PH_DECL unsigned long long d_ph_t = wall_clock64(), d_ph[7] = {0, 0, 0, 0, 0, 0, 0}, e_ph_t = 0, e_ph[4] = {0, 0, 0, 0}
+#define S16D_PH_DECL unsigned long long d_ph_t = wall_clock64(), d_ph[7] = {0, 0, 0, 0, 0, 0, 0}
 #define S16D_PH(I) do { const unsigned long long d_now = wall_clock64(); d_ph[I] += d_now - d_ph_t; d_ph_t = d_now; } while (0)
-/* the parts of "results" (g_phases[48 + 8 w + i]): 0 the members' and rows' constants, 1 the barrier behind them, 2 pass 0 and the queue, 3 issue_records */
-#define S16D_EPH0 do { e_ph_t = wall_clock64(); } while (0)
-#define S16D_EPH(I) do { const unsigned long long e_now = wall_clock64(); e_ph[I] += e_now - e_ph_t; e_ph_t = e_now; } while (0)
-#define S16D_PH_FLUSH do { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) { for (int d_i = 0; d_i < 7; d_i++) atomicAdd(&g_phases[32 + 8 * (wave >> 2) + d_i], d_ph[d_i]); \
-	for (int d_i = 0; d_i < 4; d_i++) atomicAdd(&g_phases[48 + 8 * (wave >> 2) + d_i], e_ph[d_i]); } } while (0)
+#define S16D_PH_FLUSH do { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) for (int d_i = 0; d_i < 7; d_i++) atomicAdd(&g_phases[32 + 8 * (wave >> 2) + d_i], d_ph[d_i]); } while (0)
 #else
 #define S16D_PH_DECL ((void) 0)
 #define S16D_PH(I) ((void) 0)
-#define S16D_EPH0 ((void) 0)
-#define S16D_EPH(I) ((void) 0)
 #define S16D_PH_FLUSH ((void) 0)
 #endif
 
@@ -84,9 +78,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	__shared__ float s_nuv[2][T];
 	__shared__ uint32_t s_wild[2];
 	__shared__ __attribute__((aligned(256))) uint32_t s_sink[64];
-	/* per wave: the elements that stay — (member | row << 8, accumulator) while they are queued, (position, lower bound, upper
-	 * bound, query) once their record slots have been asked for (`issue_records`), until the wave writes the records */
-	__shared__ uint4 s_hq[8][64];
+	__shared__ uint2 s_hq[8][64];			/* per wave: the elements that stay, until the wave writes their records */
 	__shared__ __attribute__((aligned(256))) float s_tf[T];			/* the members' thresholds as the item's first chunk found them */
 	const int	tid = threadIdx.x;
 	const int	lane = tid & 63;
@@ -241,46 +233,9 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	};
 
 	const int	sw = (r32 >> 1) & 7;
+	const int	qfrag = S16D_QOFF + (2 * wq) * 4096 + r32 * 128;
 	const int	rfrag = (4 * wr) * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
-
-	/*
-	 * Records in two steps (round 6).  An element that stays needs a slot in its query's record list: one returning atomic,
-	 * a round trip of a microsecond or more to the L2 with the device loaded — and with the slot awaited where it was asked
-	 * for, every wave of the block stood at the end of every item for that long with the matrix pipe idle (results +
-	 * tightening: 6 of an item's 26 us, profiles/r04_dense_phases.txt).  Now the end of an item only ASKS
-	 * (`issue_records`: validity, bounds, the atomic; what the record will hold goes back into the wave's queue entry) and
-	 * the records are WRITTEN behind the first chunk of the next item (`commit`, at the chunk's top: the loaders have just
-	 * waited for everything they asked for, the multipliers have nothing else in flight), by when the slots are back.
-	 */
-	uint32_t	pend_n = 0;			/* uniform: entries of s_hq[wave] that await their slots */
-	uint32_t	pend_slot = 0;		/* this lane's slot, once it is back */
-	bool		pend_keep = false;	/* this lane's entry is a record */
-	auto		commit = [&]() {
-		if (pend_n == 0)		/* uniform */
-			return;
-		if (pend_keep)
-		{
-			const uint4 r = s_hq[wave][lane];
-			const uint32_t slot = pend_slot;
-
-			if (slot < ecap)
-			{
-				erec[(size_t) r.w * ecap + slot] = make_uint2(r.x, r.y);
-				eub[(size_t) r.w * ecap + slot] = __uint_as_float(r.z);
-			}
-			if ((slot & (tight - 1u)) == tight - 1u)
-			{
-				const uint32_t ti = atomicAdd(&s_tn, 1u);
-
-				if (ti < S16_TIGHT_Q)
-					s_tq[ti] = r.w;
-			}
-		}
-		pend_n = 0;
-		pend_keep = false;
-		__builtin_amdgcn_wave_barrier();
-	};
 
 	S16D_PH_DECL;
 	enter(it_c, 0);
@@ -307,51 +262,33 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				for (int i = 0; i < 16; i++)
 					acc[a][b][i] = 0.0f;
 
-		/*
-		 * A SMALL tile (round 6): at most 128 members — what a balanced table gives a list at 4096 queries a batch (128 pairs a
-		 * list on average), and every list's last tile.  With the wave -> block map of the full tile (member blocks 2 wq,
-		 * 2 wq + 1) half the waves of such a tile hold no member and multiply 8 empty blocks all the same.  There the map is
-		 * member block wq x row blocks 4 wr .. 4 wr + 3 instead: every wave has work, and half of it — acc[0][*] only.
-		 * (Tile-uniform.  The operands lie in the ring where they always do: member block p at S16D_QOFF + 4096 p.)
-		 */
-		const bool	small = nmem_cur <= 128u;
-		const int	mblk0 = small ? wq : 2 * wq;		/* the member block of acc[0][*] (acc[1][*]: the next one; unused in a small tile) */
-		/* member blocks of this wave that hold a member (wave-uniform; in a full tile the empty ones are multiplied all the same:
-		 * without the test the k-steps are straight-line code, the next one's ds_reads issued under this one's MFMAs) */
-		const int	na = small ? (nmem_cur > (uint32_t) (32 * wq) ? 1 : 0)
-			: (nmem_cur > (uint32_t) (32 * (2 * wq)) ? 1 : 0) + (nmem_cur > (uint32_t) (32 * (2 * wq + 1)) ? 1 : 0);
+		/* pair blocks of this wave that hold a member (wave-uniform; the empty ones are multiplied all the same: without
+		 * the test the k-steps are straight-line code, the next one's ds_reads issued under this one's MFMAs) */
+		const int	na = (nmem_cur > (uint32_t) (32 * (2 * wq)) ? 1 : 0) + (nmem_cur > (uint32_t) (32 * (2 * wq + 1)) ? 1 : 0);
 
-		/* (one address for both maps: member block mblk0 of the ring's pair half) */
-		const int	qf = S16D_QOFF + mblk0 * 4096 + r32 * 128;
 		auto		compute = [&](const unsigned char *buf) {
 #pragma unroll
 			for (int s = 0; s < 4; s++)
 			{
 				ndb_h8		ah[2], bh[4];
 
-				ah[0] = *reinterpret_cast<const ndb_h8 *>(buf + qf + (((2 * s + kh) ^ sw) * 16));
+#pragma unroll
+				for (int a = 0; a < 2; a++)
+					ah[a] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + a * 4096 + (((2 * s + kh) ^ sw) * 16));
 #pragma unroll
 				for (int b = 0; b < 4; b++)
 					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + s * 1024);
-				if (!small)			/* uniform */
-					ah[1] = *reinterpret_cast<const ndb_h8 *>(buf + qf + 4096 + (((2 * s + kh) ^ sw) * 16));
 #pragma unroll
-				for (int b = 0; b < 4; b++)
-					acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh[b], acc[0][b], 0, 0, 0);
-				if (!small)
-				{
+				for (int a = 0; a < 2; a++)
 #pragma unroll
 					for (int b = 0; b < 4; b++)
-						acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh[b], acc[1][b], 0, 0, 0);
-				}
+						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
 			}
 		};
 		/* one chunk of the stream: (loaders) wait for it, barrier, hand out the next one, multiply */
-		auto		chunk = [&](bool commit_now) {
+		auto		chunk = [&]() {
 			if (loader)
 				s16_wait_vm<0>();
-			if (commit_now)
-				commit();			/* the slots asked for at the end of the item before this one have come back meanwhile */
 			S16D_PH(0);
 			__syncthreads();
 			S16D_PH(1);
@@ -363,22 +300,19 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			g_c++;
 		};
 
-		/* (one copy of the chunk's code: the commit goes with the second chunk, or the only one) */
-		for (int c = 0; c < nchunk; c++)
-		{
-			chunk(c == (nchunk == 1 ? 0 : 1));
-			/* the members' thresholds as they stand now (in-sweep tightening; a stale value is a valid, looser bound): the one
-			 * ordinary vector-memory read of an item, by the loaders' threads, behind the first chunk's barrier (the member
-			 * arrays have landed) and looked at after the last chunk */
-			if (c == 0 && loader)
-				/* (thread = member: the loaders' 256 threads; a gather by LDS DMA like everything else — an ordinary load
-				 * would bring the compiler's own waits on the vector-memory counter into paths the prefetchers take too) */
-				s16_dma4(s16_uniform_ptr((const unsigned char *) qthr), 8u * s_qid[c_par][tid], tf_la + (uint32_t) lw * 256u);
-		}
+		chunk();
+		/* the members' thresholds as they stand now (in-sweep tightening; a stale value is a valid, looser bound): the one
+		 * ordinary vector-memory read of an item, by the loaders' threads, behind the first chunk's barrier (the member
+		 * arrays have landed) and looked at after the last chunk */
+		if (loader)
+			/* (thread = member: the loaders' 256 threads; a gather by LDS DMA like everything else — an ordinary load
+			 * would bring the compiler's own waits on the vector-memory counter into paths the prefetchers take too) */
+			s16_dma4(s16_uniform_ptr((const unsigned char *) qthr), 8u * s_qid[c_par][tid], tf_la + (uint32_t) lw * 256u);
+		for (int c = 1; c < nchunk; c++)
+			chunk();
 		if (nchunk == 1 && loader)
 			s16_wait_vm<0>();		/* (otherwise the later chunks' waits have covered the gather) */
 
-		S16D_EPH0;
 		/* does one of this lane's four rows (row 32 (4 wr + b) + r32 of the tile) have an exponent outside pass 0's range */
 		bool		wildrow = false;
 
@@ -420,9 +354,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			s_wild[c_par] = 1u;
 		if (tid == 0)
 			s_wild[c_par ^ 1u] = 0;		/* read by the item before this one, set next by the item after it */
-		S16D_EPH(0);
 		__syncthreads();
-		S16D_EPH(1);
 
 		const float K = (1.0f - cE) * 0.99999905f;
 		const bool	wild = s_wild[c_par] != 0;		/* uniform */
@@ -441,15 +373,11 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		 * range every element is queued and the flush applies that test itself.
 		 */
 		uint32_t	hq_n = 0;			/* entries in this wave's queue (uniform) */
-		/* the queue's entries become records that await their slots (see `commit`) */
-		auto		issue_records = [&]() {
-			commit();				/* (a queue that overflowed inside this item: the entries are about to be overwritten) */
+		auto		flush = [&]() {
 			__builtin_amdgcn_wave_barrier();
-			bool		keep = false;
-
 			if ((uint32_t) lane < hq_n)
 			{
-				const uint4 h = s_hq[wave][lane];
+				const uint2 h = s_hq[wave][lane];
 				const int	m = (int) (h.x & 255u), ri = (int) ((h.x >> 8) & 255u);
 				const float accv = __uint_as_float(h.y);
 				const int	ex = (int) reinterpret_cast<const int16_t *>(&s_exw[c_par][0])[(ri >> 6) * 128 + (ri & 63)];
@@ -457,37 +385,46 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				const uint32_t por = s_por[c_par][ri];
 				const float t1 = ldexpf(accv, s_eq[c_par][m] + ex - 27);
 				const float n = s_q2[c_par][m] + x2;
+				bool		keep = t2 * T + (uint32_t) ri < len && (uint32_t) m < nmem_cur && por < s_nrow[c_par][m];
 
-				keep = t2 * T + (uint32_t) ri < len && (uint32_t) m < nmem_cur && por < s_nrow[c_par][m];
 				if (wild)
 					keep = keep && !(t1 < __builtin_fmaf(n, K, -s_t2[m]));
 				if (keep)
 				{
 					const uint32_t q = s_qid[c_par][m];
+					/* (DBG 7: timing only — the records without the returning atomic's round trip) */
+					uint32_t	slot = DBG == 7 ? (uint32_t) lane : atomicAdd(&ecount[q], 1u);
+
+					/* (looked at here: a returning atomic still pending at the loop's edge would put the compiler's wait for
+					 * the vector-memory counter into every item's first chunk) */
+					asm volatile("" : "+v"(slot));
 					const float av = n - t1;
 					const float er = s16_up(s16_up(cE * n) + NDB_S16_ABS);
 					const float lbv = av - er, ubv = s16_up(av + er);
 					const float lb = lbv - fabsf(lbv) * 4.8e-7f - 1e-37f;
 					const uint32_t pos = s_la[c_par][m] + por, ub_bits = __float_as_uint(ubv);
 
-					/* (DBG 7: timing only — the records without the returning atomic) */
-					pend_slot = DBG == 7 ? (uint32_t) lane : atomicAdd(&ecount[q], 1u);
-					/* the smallest upper bound of every hash bucket of positions (kept whether or not the record will fit):
+					if (slot < ecap)
+					{
+						erec[(size_t) q * ecap + slot] = make_uint2(pos, __float_as_uint(lb));
+						eub[(size_t) q * ecap + slot] = ubv;
+					}
+					/* the smallest upper bound of every hash bucket of positions (kept whether or not the record fit):
 					 * k non-empty buckets are k distinct candidates */
 					if ((ub_bits & 0x7FFFFFFFu) < 0x7F800000u)
 						atomicMin(&bmin[(size_t) q * S16_NB + ((pos * 2654435761u) >> (32 - S16_NB_LOG2))],
 								  ndb_key_from_bits(ub_bits));
-					s_hq[wave][lane] = make_uint4(pos, __float_as_uint(lb), ub_bits, q);
+					if ((slot & (tight - 1u)) == tight - 1u)
+					{
+						const uint32_t ti = atomicAdd(&s_tn, 1u);
+
+						if (ti < S16_TIGHT_Q)
+							s_tq[ti] = q;
+					}
 				}
 			}
-			pend_keep = keep;
-			pend_n = hq_n;
-			hq_n = 0;
 			__builtin_amdgcn_wave_barrier();
-		};
-		auto		flush = [&]() {		/* inside an item (the queue is full): asked and written at once */
-			issue_records();
-			commit();
+			hq_n = 0;
 		};
 		auto		block = [&](auto ac, auto bc) {
 			constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
@@ -501,7 +438,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			const bool	dead = !(t2 * T + (uint32_t) ri < len) || s_por[c_par][ri] == 0xFFFFFFFFu;
 			const float w = dead ? __builtin_inff() : (nan ? -__builtin_inff() : ldexpf(x2, -ex));
 			const float wb = kh ? ldexpf(1.0f, -ex) : w;
-			const float ua = s_nuv[kh][32 * (mblk0 + a) + r32];
+			const float ua = s_nuv[kh][32 * (2 * wq + a) + r32];
 			const ndb_f16acc fin = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, wb, acc[a][b], 0, 0, 0);
 			int			mx = (int) 0x80000000;
 
@@ -547,10 +484,10 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 #pragma unroll
 					for (int r = 1; r < 16; r++)
 						v = reg == r ? acc[a][b][r] : v;
-					const int	m = 32 * (mblk0 + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+					const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
 					const uint32_t idx = hq_n + (uint32_t) __popcll(bal & ((1ull << lane) - 1ull));
 
-					s_hq[wave][idx] = make_uint4((uint32_t) m | ((uint32_t) ri << 8), __float_as_uint(v), 0u, 0u);
+					s_hq[wave][idx] = make_uint2((uint32_t) m | ((uint32_t) ri << 8), __float_as_uint(v));
 				}
 				hq_n += cnt;
 			}
@@ -559,10 +496,8 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		S16D_BLK(0, 0); S16D_BLK(1, 0); S16D_BLK(0, 1); S16D_BLK(1, 1);
 		S16D_BLK(0, 2); S16D_BLK(1, 2); S16D_BLK(0, 3); S16D_BLK(1, 3);
 #undef S16D_BLK
-		S16D_EPH(2);
 		if (hq_n != 0)
-			issue_records();
-		S16D_EPH(3);
+			flush();
 		S16D_PH(4);
 #ifdef NDB_PHASES
 		d_ph[6]++;
@@ -617,7 +552,6 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		/* (no barrier: the next item's first chunk starts with one, and the per-item arrays of parity c_par ^ 1 are
 		 * requested again only by an `enter` behind that barrier) */
 	}
-	commit();					/* the last item's records */
 	S16D_PH_FLUSH;
 }
 

@@ -84,8 +84,7 @@ def main():
             for w, who in ((0, "loader"), (1, "multiplier")):
                 items = max(1, ph[32 + 8 * w + 6])
                 print("    " + who + ", us per item: " + ", ".join(f"{nm} {ph[32 + 8 * w + i] / 100 / items:.2f}" for i, nm in enumerate(names)) +
-                      f"; {items} items; results = constants {ph[48 + 8 * w] / 100 / items:.2f}, barrier {ph[49 + 8 * w] / 100 / items:.2f}, "
-                      f"pass 0 + queue {ph[50 + 8 * w] / 100 / items:.2f}, issue {ph[51 + 8 * w] / 100 / items:.2f}", flush=True)
+                      f"; {items} items", flush=True)
         print(f"{v or 'defaults':48s} step {dt * 1e3:8.3f} ms  sweep {kms:8.3f} ms  issued {tf:7.1f} TFLOP/s  "
               f"launches/step {launches / steps:.1f} fallbacks {fb} emitted/q {em:.0f} rescored/q {rs:.1f} {same}", flush=True)
 
