@@ -2241,6 +2241,10 @@ struct ndbhip_hnsw
 	float	   *d_vecs = nullptr;
 	uint16_t   *d_vecs16 = nullptr;		/* walk rows of the intended search (made on first use, ndbhip_hnsw2.h) */
 	uint32_t	w16_blocks = 0;			/* blocks they cover: fewer than nblocks = stale (rows were appended) */
+	/* the intended search under strategy 2 (cosine): 1 / |row| of every node, for the float4 rows [0] and the walk rows [1]
+	 * (made on first use; stale like the walk rows) */
+	double	   *d_rinv[2] = {nullptr, nullptr};
+	uint32_t	rinv_blocks[2] = {0, 0};
 	int		   *d_levels = nullptr;
 	int16_t    *d_ncount = nullptr;
 	int64_t    *d_nbr_off = nullptr;
@@ -2307,6 +2311,12 @@ hnsw_free_dev(ndbhip_hnsw *h)
 	if (h->d_vecs16) (void) hipFree(h->d_vecs16);
 	h->d_vecs16 = nullptr;
 	h->w16_blocks = 0;
+	for (int r = 0; r < 2; r++)
+	{
+		if (h->d_rinv[r]) (void) hipFree(h->d_rinv[r]);
+		h->d_rinv[r] = nullptr;
+		h->rinv_blocks[r] = 0;
+	}
 	h->d_dead = nullptr;
 	h->cap_blocks = 0;
 	h->d_vecs = nullptr; h->d_levels = nullptr; h->d_ncount = nullptr;
@@ -3485,6 +3495,7 @@ h2_graph(const ndbhip_hnsw *h, uint32_t nvisible)
 
 	gr.vecs = h->d_vecs;
 	gr.vecs16 = h->d_vecs16;
+	gr.rinv = nullptr;
 	gr.levels = h->d_levels;
 	gr.ncount = h->d_ncount;
 	gr.nbrs = h->d_nbrs;
@@ -3915,6 +3926,24 @@ h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int stra
 			h->w16_blocks = h->nblocks;
 		}
 	}
+	const int	rv = w16 ? 1 : 0;
+
+	if (strategy == 2 && (!h->d_rinv[rv] || h->rinv_blocks[rv] != h->nblocks))
+	{
+		/* the nodes' factors of the cosine walk key: 1 / |row| of the rows this walk reads */
+		if (hnsw_frozen(h))
+			return fail(NDBHIP_ERR_STATE, "the graph is shared (ndbhip_hnsw_share) and has no row norms for this walk: run a cosine search of the same kind on the source before sharing");
+		if (h->d_rinv[rv]) { HIP_TRY(hipStreamSynchronize(g.stream)); HIP_TRY(hipFree(h->d_rinv[rv])); h->d_rinv[rv] = nullptr; }
+		HIP_TRY(hipMalloc((void **) &h->d_rinv[rv], (size_t) h->nblocks * sizeof(double)));
+		const unsigned nb4 = (unsigned) std::min<uint32_t>((h->nblocks + 3u) / 4u, 1u << 16);
+
+		if (w16)
+			hipLaunchKernelGGL(k_h2_rinv<1>, dim3(nb4), dim3(256), 0, g.stream, (const float *) h->d_vecs, (const uint16_t *) h->d_vecs16, h->dim, h->nblocks, h->d_rinv[rv]);
+		else
+			hipLaunchKernelGGL(k_h2_rinv<0>, dim3(nb4), dim3(256), 0, g.stream, (const float *) h->d_vecs, (const uint16_t *) nullptr, h->dim, h->nblocks, h->d_rinv[rv]);
+		HIP_TRY(hipGetLastError());
+		h->rinv_blocks[rv] = h->nblocks;
+	}
 	const uint32_t efe = (uint32_t) std::max(ef, k);
 	const uint32_t nwaves = (uint32_t) std::min<int64_t>((int64_t) g.num_cus * g_h2_waves, nq);
 	uint32_t	nwords = 0;
@@ -3927,6 +3956,8 @@ h2_search_run(ndbhip_hnsw *h, bool w16, const float *d_queries, int nq, int stra
 	HIP_TRY(hipMemsetAsync(d_next, 0, 4, g.stream));
 	H2Graph		gr = h2_graph(h, h->nblocks);
 
+	if (strategy == 2)
+		gr.rinv = h->d_rinv[rv];
 #define H2_SEARCH_L(KK, ...) do { \
 		HIP_TRY(hipFuncSetAttribute((const void *) KK<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem)); \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(KK<__VA_ARGS__>), dim3(nwaves), dim3(64), smem, g.stream, gr, d_queries, (uint32_t) nq, efe, \

@@ -47,6 +47,8 @@ struct H2Graph
 {
 	const float *vecs;
 	const uint16_t *vecs16;		/* walk rows (round 5): float4_to_fp16 of every element of vecs, same stride; nullptr = none */
+	const double *rinv;			/* strategy 2 (round 6): 1 / sqrt(sum of squares) of the rows THIS walk reads (vecs, or vecs16), 0 for a
+								 * row of zeros; nullptr for the other strategies */
 	const int  *levels;
 	int16_t    *ncount;
 	uint32_t   *nbrs;
@@ -77,9 +79,6 @@ struct H2Query
 	const float *q;
 	float		r[H2_QREG];
 	int			dim;
-	/* strategy 2 (norm2()): the query's own sum of squares by the tree of the rows the walk runs on, and its root */
-	double		nq, sq;
-
 	__device__ __forceinline__ void load(const float *qq, int d, int lane)
 	{
 		q = qq;
@@ -87,29 +86,6 @@ struct H2Query
 #pragma unroll
 		for (int j = 0; j < H2_QREG; j++)
 			r[j] = lane + 64 * j < d ? qq[lane + 64 * j] : 0.0f;
-	}
-
-	/* oracle ndbo_h2_query_norm2: a lane's elements in increasing order into its fp64 partial, the butterfly; group4 = the
-	 * registers are in load16's order.  (Products of two float4 values are exact in fp64.) */
-	__device__ __forceinline__ void norm2(bool group4, int lane)
-	{
-		double		p = 0.0;
-
-		if (dim <= 64 * H2_QREG)
-		{
-#pragma unroll
-			for (int j = 0; j < H2_QREG; j++)
-				p += (double) r[j] * (double) r[j];		/* (beyond the row: + 0.0) */
-		}
-		else
-			for (int i = lane; i < dim; i += 64)
-				p += (double) q[i] * (double) q[i];
-		(void) group4;		/* (load16 keeps group lane + 64 j at r[4 j .. 4 j + 3]: the same loop walks it in increasing element order) */
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1)
-			p = p + __shfl_xor(p, off, 64);
-		nq = p;
-		sq = __builtin_sqrt(p);
 	}
 
 	/* for walk rows: the lane's GROUPS of four elements, group lane, lane + 64, ... (d % 4 == 0, d <= 64 * H2_QREG) */
@@ -135,7 +111,7 @@ struct H2Query
  */
 template <int S>
 __device__ __forceinline__ void
-h2_term(double &p, double &pn, float qv, float xv)
+h2_term(double &p, float qv, float xv)
 {
 	if constexpr (S == 1)
 	{
@@ -144,29 +120,18 @@ h2_term(double &p, double &pn, float qv, float xv)
 		p += (double) d * (double) d;
 	}
 	else
-	{
-		p += (double) qv * (double) xv;
-		if constexpr (S == 2)
-			pn += (double) xv * (double) xv;
-	}
+		p += (double) qv * (double) xv;		/* (a product of two float4 values is exact in fp64) */
 }
 
+/* S = 1: d2; 3: -dot; 2: -dot as well — the node's factor rinv is multiplied in by h2_ids_d2, which knows the node */
 template <int S>
 __device__ __forceinline__ double
-h2_key_of(const H2Query &Q, double p, double pn)
+h2_key_of(double p)
 {
 	if constexpr (S == 1)
 		return h2_wave_fold(p);
-	else if constexpr (S == 3)
-		return -h2_wave_fold(p);
 	else
-	{
-		const double dot = h2_wave_fold(p), nx = h2_wave_fold(pn);
-
-		if (Q.nq == 0.0 || nx == 0.0)
-			return 2.0;
-		return 1.0 - dot / (Q.sq * __builtin_sqrt(nx));
-	}
+		return -h2_wave_fold(p);
 }
 
 /* d2(query, row x) by the whole wave (every lane returns it) */
@@ -204,14 +169,11 @@ template <int S = 1>
 __device__ __forceinline__ void
 h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, double out[H2_NR])
 {
-	double		p[H2_NR], pn[S == 2 ? H2_NR : 1];
+	double		p[H2_NR];
 
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
-	{
 		p[u] = 0.0;
-		pn[S == 2 ? u : 0] = 0.0;
-	}
 
 	if (Q.dim <= 64 * H2_QREG)
 	{
@@ -235,7 +197,19 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 					const int	i = lane + 64 * (j0 + jj);
 
 					/* (beyond the row: 0 against the query's 0 — a term +0.0 that leaves the sum as it is) */
-					v[u][jj] = (u < n && j0 + jj < H2_QREG && i < Q.dim) ? x[u][i] : 0.0f;
+					if constexpr (S == 1)
+						v[u][jj] = (u < n && j0 + jj < H2_QREG && i < Q.dim) ? x[u][i] : 0.0f;
+					else
+					{
+						/* (the other strategies widen the loaded value at once, and the compiler then puts every guarded load in a
+						 * branch of its own with a full wait behind it — 326 waits in the kernel against 88, the float4 walk at a
+						 * quarter of its rate —: the load is made unconditional (a row the wave does not need reads row 0, an element
+						 * beyond the row its first stride), the guard picks the value) */
+						const bool	ok = u < n && j0 + jj < H2_QREG && i < Q.dim;
+						const float raw = x[u][i < Q.dim ? i : lane];
+
+						v[u][jj] = ok ? raw : 0.0f;
+					}
 				}
 #pragma unroll
 			for (int jj = 0; jj < H2_JG; jj++)
@@ -243,7 +217,7 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 				{
 #pragma unroll
 					for (int u = 0; u < H2_NR; u++)
-						h2_term<S>(p[u], pn[S == 2 ? u : 0], Q.r[j0 + jj], v[u][jj]);
+						h2_term<S>(p[u], Q.r[j0 + jj], v[u][jj]);
 				}
 		}
 	}
@@ -255,11 +229,11 @@ h2_dist2x4(const H2Query &Q, const float *const x[H2_NR], int n, int lane, doubl
 #pragma unroll
 			for (int u = 0; u < H2_NR; u++)
 				if (u < n)
-					h2_term<S>(p[u], pn[S == 2 ? u : 0], qv, x[u][i]);
+					h2_term<S>(p[u], qv, x[u][i]);
 		}
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
-		out[u] = h2_key_of<S>(Q, p[u], pn[S == 2 ? u : 0]);
+		out[u] = h2_key_of<S>(p[u]);
 }
 
 /*
@@ -273,14 +247,13 @@ template <int NG, int S = 1>
 __device__ __forceinline__ void
 h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, double out[H2_NR])
 {
-	double		p[H2_NR], pn[S == 2 ? H2_NR : 1];
+	double		p[H2_NR];
 	uint2		v[H2_NR][NG];
 
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
 	{
 		p[u] = 0.0;
-		pn[S == 2 ? u : 0] = 0.0;
 #pragma unroll
 		for (int j = 0; j < NG; j++)
 		{
@@ -303,13 +276,13 @@ h2w_dist2x(const H2Query &Q, const uint16_t *const x[H2_NR], int n, int lane, do
 				{
 					const unsigned short h = (unsigned short) ((t & 1) ? (w[t >> 1] >> 16) : (w[t >> 1] & 0xFFFFu));
 
-					h2_term<S>(p[u], pn[S == 2 ? u : 0], Q.r[4 * j + t], __half2float(__ushort_as_half(h)));
+					h2_term<S>(p[u], Q.r[4 * j + t], __half2float(__ushort_as_half(h)));
 				}
 			}
 		}
 #pragma unroll
 	for (int u = 0; u < H2_NR; u++)
-		out[u] = h2_key_of<S>(Q, p[u], pn[S == 2 ? u : 0]);
+		out[u] = h2_key_of<S>(p[u]);
 }
 
 /* d2(query, node ids[u]) for u < n: on the walk rows (W16; Q loaded by load16) or on the float4 rows (Q loaded by load) */
@@ -317,6 +290,15 @@ template <int W16, int S = 1>		/* 0: float4 rows; NG = 1 .. 4: walk rows of dim 
 __device__ __forceinline__ void
 h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, int lane, double d[H2_NR])
 {
+	double		ri[S == 2 ? H2_NR : 1];
+
+	if constexpr (S == 2)
+	{
+		/* the nodes' factors (wave-uniform addresses: they travel with the rows' loads) */
+#pragma unroll
+		for (int u = 0; u < H2_NR; u++)
+			ri[u] = u < n ? g.rinv[ids[u]] : 0.0;
+	}
 	if constexpr (W16 != 0)
 	{
 		const uint16_t *x[H2_NR];
@@ -334,6 +316,12 @@ h2_ids_d2(const H2Graph &g, const H2Query &Q, const uint32_t ids[H2_NR], int n, 
 		for (int u = 0; u < H2_NR; u++)
 			x[u] = g.vecs + (size_t) ids[u] * g.dim;
 		h2_dist2x4<S>(Q, x, n, lane, d);
+	}
+	if constexpr (S == 2)
+	{
+#pragma unroll
+		for (int u = 0; u < H2_NR; u++)
+			d[u] = d[u] * ri[u];		/* (-dot) * rinv: oracle ndbo_h2_walk_key */
 	}
 }
 
@@ -957,6 +945,46 @@ k_h2_walk_rows(const float *__restrict__ src, uint16_t *__restrict__ dst, size_t
 	}
 }
 
+/* rinv of rows [0, nblocks): a wave per row; the tree of ndbo_h2_dist2 / _w16 — element i into partial i mod 64 (float4 rows)
+ * or (i / 4) mod 64 (walk rows), a lane's elements in increasing order, the butterfly — then 1 / sqrt, 0 for a row of zeros
+ * (oracle ndbo_h2_rinv; fp64 sqrt and divide are the IEEE results on gfx950: tests/test_gpu_hnsw2.py) */
+template <int W16>
+__global__ __launch_bounds__(256) void
+k_h2_rinv(const float *__restrict__ vecs, const uint16_t *__restrict__ vecs16, int dim, uint32_t nblocks, double *__restrict__ out)
+{
+	const int	lane = threadIdx.x & 63;
+
+	for (uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nblocks; b += gridDim.x * 4u)
+	{
+		double		p = 0.0;
+
+		if (W16)
+		{
+			const uint16_t *w = vecs16 + (size_t) b * dim;
+
+			for (int g0 = lane; g0 * 4 < dim; g0 += 64)
+#pragma unroll
+				for (int t = 0; t < 4; t++)
+					if (g0 * 4 + t < dim)
+					{
+						const double xv = (double) __half2float(__ushort_as_half(w[g0 * 4 + t]));
+
+						p += xv * xv;
+					}
+		}
+		else
+		{
+			const float *x = vecs + (size_t) b * dim;
+
+			for (int i = lane; i < dim; i += 64)
+				p += (double) x[i] * (double) x[i];
+		}
+		p = h2_wave_fold(p);
+		if (lane == 0)
+			out[b] = p > 0.0 ? 1.0 / __builtin_sqrt(p) : 0.0;
+	}
+}
+
 __host__ __device__ static inline size_t
 h2_smem_bytes(uint32_t ef, bool table = true /* with the LDS visited table (the search; the build's walks outgrow it at once,
 											   * and its 8 KB a wave would cost the build a third of its walkers) */ )
@@ -1018,8 +1046,6 @@ h2_search_body(H2Graph g, const float *__restrict__ queries, uint32_t nq, uint32
 			Q.load16(queries + (size_t) q * g.dim, g.dim, lane);
 		else
 			Q.load(queries + (size_t) q * g.dim, g.dim, lane);
-		if constexpr (S == 2)
-			Q.norm2(W16 != 0, lane);
 		if (entry != NDBHIP_INVALID_BLOCK)
 		{
 			uint32_t	cur = entry;

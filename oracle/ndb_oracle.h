@@ -232,8 +232,8 @@ int			ndbo_h2_search_w16(const ndbo_hnsw *g, const uint16_t *w16, const float *q
 							   uint32_t *out_blocks, float *out_dist, int64_t *evals);
 /* round 6: the intended search under the operator class's strategy (1 L2, 2 cosine, 3 negative inner product); w16 NULL = walk
  * on the float4 rows */
-double		ndbo_h2_query_norm2(const float *q, int dim, int group4);
-double		ndbo_h2_walk_key(const ndbo_hnsw *g, const uint16_t *w16, const float *q, uint32_t e, int strategy, double nq);
+double		ndbo_h2_rinv(const ndbo_hnsw *g, const uint16_t *w16, uint32_t e);
+double		ndbo_h2_walk_key(const ndbo_hnsw *g, const uint16_t *w16, const float *q, uint32_t e, int strategy);
 int			ndbo_h2_search_s(const ndbo_hnsw *g, const uint16_t *w16, int strategy, const float *query, int ef, int k,
 							 uint32_t *out_blocks, float *out_dist, int64_t *evals);
 

@@ -115,8 +115,8 @@ def lib(native: bool = False):
         "ndbo_h2_dist2_w16": (C.c_double, [f32p, u16p, i]),
         "ndbo_h2_search_w16": (i, [C.POINTER(NdboHnsw), u16p, f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
         "ndbo_h2_search_s": (i, [C.POINTER(NdboHnsw), C.c_void_p, i, f32p, i, i, u32p, f32p, C.POINTER(C.c_int64)]),
-        "ndbo_h2_query_norm2": (C.c_double, [f32p, i, i]),
-        "ndbo_h2_walk_key": (C.c_double, [C.POINTER(NdboHnsw), C.c_void_p, f32p, C.c_uint32, i, C.c_double]),
+        "ndbo_h2_rinv": (C.c_double, [C.POINTER(NdboHnsw), C.c_void_p, C.c_uint32]),
+        "ndbo_h2_walk_key": (C.c_double, [C.POINTER(NdboHnsw), C.c_void_p, f32p, C.c_uint32, i]),
         "ndbo_mt_spread_copy": (C.c_void_p, [C.c_void_p, C.c_size_t, i]),
         "ndbo_mt_ivf_search_batch": (C.c_double, [C.POINTER(NdboIvf), f32p, i, i, i, i, C.c_int64, i, C.c_void_p, f32p,
                                                   i32p, C.POINTER(C.c_int64)]),

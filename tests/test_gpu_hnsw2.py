@@ -231,9 +231,10 @@ def test_intended_search_under_the_operator_class_strategy_equals_the_oracle(kin
 
 
 def test_device_fp64_sqrt_and_divide_are_correctly_rounded():
-    """The cosine walk key is 1 - dot / (sqrt(nq) sqrt(nx)) in fp64 on both sides: the device's fp64 sqrt and divide must be the
-    IEEE results (they are expansions on gfx950, not instructions).  2^20 random operands through torch's kernels would not
-    prove the library's; so the search itself is the witness: a table whose rows differ in the last bits of their norms."""
+    """The cosine walk key is -dot * rinv(node) with rinv = 1 / sqrt(sum of squares) in fp64 on both sides (the device keeps
+    it per node: k_h2_rinv): the device's fp64 sqrt and divide must be the IEEE results (they are expansions on gfx950, not
+    instructions).  2^20 random operands through torch's kernels would not prove the library's; so the search itself is the
+    witness: a table whose rows differ in the last bits of their norms."""
     from neurondb_amd import HnswIndex
     from oracle import ndbo
     rng = np.random.default_rng(5)

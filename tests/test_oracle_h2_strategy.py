@@ -1,5 +1,5 @@
 """The `intended` search under the operator class's strategy (oracle/ndb_oracle_hnsw2.c "THE OPERATOR CLASS'S METRIC",
-ndbo_h2_search_s) against a second, independent statement of the same definition in Python: the fp64 walk keys by the fixed
+ndbo_h2_search_s) against a second, independent statement of the same definition in Python: the fp64 walk keys (L2: the squared distance; cosine: -dot * 1 / sqrt(|x|^2); inner product: -dot) by the fixed
 64-partial tree (float4 rows: element i -> partial i mod 64; walk rows: (i / 4) mod 64), a best-first layer search over a
 plain sorted list, the greedy descent, and the re-score of the result set with hnswComputeDistance's arithmetic
 (src/index/hnsw_am.c:1301-1345, restated in tests/test_oracle_hnsw_restatement.py).  CPU only."""
@@ -35,7 +35,7 @@ def _half_image(x):
     return out.view(np.float16).astype(np.float32).reshape(x.shape)
 
 
-def walk_key(q, x, strategy, group4, nq):
+def walk_key(q, x, strategy, group4):
     q64, x64 = q.astype(np.float64), x.astype(np.float64)
     if strategy == 1:
         d = (q - x).astype(np.float32).astype(np.float64)            # fl32(q_i - x_i), widened
@@ -44,9 +44,8 @@ def walk_key(q, x, strategy, group4, nq):
     if strategy == 3:
         return -dot
     nx = _tree(list(x64 * x64), group4)
-    if nq == 0.0 or nx == 0.0:
-        return 2.0
-    return 1.0 - dot / (math.sqrt(nq) * math.sqrt(nx))
+    rinv = 1.0 / math.sqrt(nx) if nx > 0.0 else 0.0                  # a constant of the node (the device keeps it)
+    return -dot * rinv
 
 
 def search_py(a, rows, q, strategy, ef, k, group4):
@@ -55,12 +54,10 @@ def search_py(a, rows, q, strategy, ef, k, group4):
     if a["entry_point"] == INVALID or k < 1:
         return [], [], 0
     ef = max(ef, k)
-    nq = _tree(list(q.astype(np.float64) ** 2), group4) if strategy == 2 else 0.0
-
     def key(b):
         nonlocal evals
         evals += 1
-        return walk_key(q, rows[b], strategy, group4, nq)
+        return walk_key(q, rows[b], strategy, group4)
 
     def nbrs(b, level):
         cnt = int(a["ncount"][b, level]) if a["levels"][b] >= level else 0      # lists exist up to the node's own level
@@ -100,7 +97,7 @@ def search_py(a, rows, q, strategy, ef, k, group4):
         return [b for _, b in out], [np.float32(math.sqrt(d)) for d, _ in out], evals
     if strategy == 1:
         # walk rows: re-score on the float4 rows with the definition's d2, ascending again
-        rs = sorted((walk_key(q, a["vecs"][b], 1, False, 0.0), b) for _, b in res)
+        rs = sorted((walk_key(q, a["vecs"][b], 1, False), b) for _, b in res)
         evals += len(res)
         return [b for _, b in rs[:k]], [np.float32(math.sqrt(d)) for d, _ in rs[:k]], evals
     rs = sorted((float(ref_distance(q, a["vecs"][b], strategy)), b) for _, b in res)
