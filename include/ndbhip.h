@@ -114,6 +114,8 @@ typedef struct ndbhip_stats
 									 * queries — a table without cluster structure; csrc/ndbhip_screen16d.h) */
 	uint64_t	wave_sweeps;		/* sweeps that ran as wave-autonomous register streams (k_s16c_wsweep, csrc/ndbhip_screen16w.h: sparse pair
 								 * tables — a bucket probed by a handful of queries) */
+	uint64_t	sub_restricted;		/* batches that scored the regrouped lists' centres for the PROBED lists only (round 6, k_subdist_lists:
+								 * tables with tens of thousands of sublists) instead of multiplying every query by every centre */
 }			ndbhip_stats;
 int			ndbhip_stats_get(ndbhip_stats *out);
 int			ndbhip_stats_reset(void);

@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("rows_emitted", C.c_uint64), ("screen16_batches", C.c_uint64), ("screen16_fallbacks", C.c_uint64),
                 ("pairs_pruned", C.c_uint64), ("rows_swept", C.c_uint64), ("plane_bytes", C.c_uint64),
                 ("cent_screen_batches", C.c_uint64), ("prepares", C.c_uint64), ("prepare_updates", C.c_uint64),
-                ("dense_sweeps", C.c_uint64), ("wave_sweeps", C.c_uint64)]
+                ("dense_sweeps", C.c_uint64), ("wave_sweeps", C.c_uint64), ("sub_restricted", C.c_uint64)]
 
 
 class ServiceStats(C.Structure):

@@ -1955,6 +1955,13 @@ struct ndbhip_ivf
 	int64_t    *d_perm = nullptr;		size_t d_perm_n = 0;		/* [nrows] plane row -> mirror row */
 	uint32_t   *d_posof = nullptr;		size_t d_posof_n = 0;		/* [nrows] plane row -> index in its list */
 	float	   *w_subdist = nullptr;	size_t w_subdist_n = 0;		/* [nq][sstride] squared distances to the centres (sweep MODE 3) */
+	/* round 6, the centres of PROBED lists only (ivf_s16_sub_distances_probed): the batch's (query, probe) pairs by list */
+	uint32_t   *w_lqoff = nullptr;	size_t w_lqoff_n = 0;		/* [2 (nlists + 1)] first pair of every list | fill cursors */
+	uint32_t   *w_lq = nullptr;		size_t w_lq_n = 0;			/* [nq npr] the queries, list by list */
+	uint32_t   *w_uoff = nullptr;	size_t w_uoff_n = 0;		/* [nunits + 2] first work item of every unit (a unit's queries 256 at a time) | the work counter */
+	/* ... and, per layout: the regrouped lists' sublists sixteen (dim > 1024: eight) at a time — a UNIT (list, first sublist) */
+	uint2	   *d_sub_units = nullptr;	size_t d_sub_units_n = 0;
+	uint32_t	nsub_units = 0, sub_unit_c = 16;
 	S16Mat		dm_sub;				/* the centres of the regrouped lists: every query's squared distance to every one of them */
 	S16Mat		dm_cent;			/* the index's centroids: the batch centroid scan on the matrix cores (ndbhip_screen16.h) */
 	bool		dm_cent_valid = false;
@@ -1982,6 +1989,8 @@ struct ndbhip_ivf
 	int			dm_all_ncmp = 0;
 	const float *bat_subdist = nullptr;	/* this batch's distances to the centres, when dm_all served (else NULL) */
 	uint32_t	bat_sstride = 0;
+	bool		bat_restrict = false;	/* this batch: the centroid scan multiplied the centroids alone; the regrouped lists' centres are
+									 * scored for the probed lists only (ivf_s16_sub_distances_probed) */
 	float	   *w_pdist = nullptr;		size_t w_pdist_n = 0;		/* [nq][npr] |q - centroid of the probed list| */
 	uint32_t   *d_lrad = nullptr;	size_t d_lrad_n = 0;	/* [ncent] list radius around its centroid (float bits, rounded up) */
 	float	   *d_cn2 = nullptr;	size_t d_cn2_n = 0;		/* [ncent] |centroid|^2 (the inner product's sublist bound) */
@@ -2043,7 +2052,7 @@ struct ndbhip_ivf
 	F(w_amat) F(w_cfull) F(w_subdist) F(w_qev) F(w_ppart) F(w_seedmat) F(w_pdist) F(w_qpairs) \
 	F(w_qpn) F(w_qslot) F(w_wmask) F(w_wrec) F(w_overq) F(w_redo_q) F(w_redo_p) F(w_redo_out) \
 	F(w_redo_idx) F(w_qhat) F(w_qplanes_o) F(w_qn2_o) F(w_qexp_o) F(w_drop) F(w_s16desc) F(w_bmin) \
-	F(w_scand) F(w_sncand) F(w_stotal)
+	F(w_scand) F(w_sncand) F(w_stotal) F(w_lqoff) F(w_lq) F(w_uoff)
 
 /* a handle whose persistent state other handles read, or which reads another's: nothing may change or be built in it */
 static inline bool
@@ -2176,7 +2185,7 @@ ndbhip_ivf_destroy(ndbhip_ivf *ix)
 			ix->w_ecount, ix->w_erec, ix->w_bmin, ix->w_s16desc, ix->d_blkoff, ix->d_lrad, ix->w_drop,
 			ix->d_sub_first, ix->d_sub_len, ix->d_sub_loc, ix->d_sub_blk, ix->d_sub_rad, ix->d_sub_gidx, ix->d_subcent,
 			(void *) ix->d_sub_cptr, ix->d_perm, ix->d_posof, ix->w_subdist, ix->w_pdist,
-			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->d_bkt_rnxmax, ix->w_qev, ix->w_ppart, ix->w_qoffs, ix->w_qslot, ix->w_wmask, ix->w_wrec};
+			ix->w_eub, ix->w_qcplanes, ix->w_qcn2, ix->w_qcexp, ix->w_amat, ix->w_cfull, ix->w_pslot, ix->d_prow_off, ix->d_pposof, ix->d_cn2, ix->d_plen, ix->d_bucket_list, ix->w_qhat, ix->d_allcent, ix->w_overq, ix->w_redo_q, ix->w_redo_p, ix->w_redo_out, ix->w_redo_idx, ix->w_qplanes_o, ix->w_qn2_o, ix->w_qexp_o, ix->d_cent_hat, ix->w_qpairs, ix->w_qpn, ix->d_seedrows, ix->d_seed_list, ix->d_seed_pos, ix->w_seedmat, ix->d_ipc_m2, ix->d_rnx, ix->d_bkt_rnxmax, ix->w_qev, ix->w_ppart, ix->w_qoffs, ix->w_qslot, ix->w_wmask, ix->w_wrec, ix->w_lqoff, ix->w_lq, ix->w_uoff, (void *) ix->d_sub_units};
 
 		for (void *p : ptrs)
 			if (p) (void) hipFree(p);
@@ -3224,6 +3233,15 @@ static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch
  * the matrix peak. */
 static int	g_s16c_dense_min = 48;		/* "screen16c_dense_min" */
 static int	g_s16c_dense_min_sub = 100;	/* "screen16c_dense_min_sub": the same for regrouped planes (sublists); 0 = never */
+/* "screen16_sub_restrict": from this many regrouped-list centres on, a batch scores the centres of its PROBED lists only
+ * (k_subdist_lists, list-major, fp32 vector ALU) instead of multiplying every query by every centre along with the
+ * centroids: 0 = never, the default.  MEASURED (round 6, 10M x 768, lists 4096 = C4: 78 k centres, the full matrix 0.79 of a
+ * 4.3 ms step): the step went from 4.67 to 22.3 ms.  The reference's build rule leaves that table a few lists of hundreds
+ * of thousands of rows, every query probes them, and they are the lists with thousands of sublists: the (query, centre)
+ * pairs a batch needs are a quarter of the full matrix, not the 1 % that 32 probes x 19 sublists of a BALANCED index
+ * would be, and the vector ALU multiplies at a twentieth of the matrix cores' rate.  Same results either way
+ * (tests/test_gpu_screen16.py); kept for tables whose lists are balanced. */
+static int	g_sub_restrict = 0;
 static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
@@ -3261,6 +3279,7 @@ static int	ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &blk_off
 								   const float *rows32 = nullptr /* the rows to regroup (cosine: their normalised copy) */,
 								   const float *list_centres = nullptr /* (cosine: the normalised centroids) */ );	/* ndbhip_build.h */
 static int	ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstride);
+static int	ivf_s16_sub_distances_probed(ndbhip_ivf *ix, const float *d_q, int nq, const int *w_probes, int npr, uint32_t *sstride);
 static int	s16mat_prepare(S16Mat &M, const float *d_src, int n, int dim);	/* ndbhip_build.h */
 __global__ void k_rows_decode_f16(const uint16_t *__restrict__ src, size_t n, float *__restrict__ out);	/* ndbhip_build.h */
 static int	s16mat_run(S16Mat &M, int dim, const unsigned char *qplanes, const float *qn2, const int *qexp, float2 *qthr,
@@ -4039,7 +4058,19 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			/* distances of every query to the centres of the regrouped lists (once per batch), then the expansion */
 			if (round == 0 && prune && ix->nsub_g > 0)
 			{
-				if (ix->bat_subdist && cdist)
+				if (ix->bat_restrict && cdist)
+				{
+					/* the centroid scan multiplied the centroids alone: the centres of the probed lists, list by list */
+					const int	rc = ivf_s16_sub_distances_probed(ix, d_q, nq, w_probes, npr, &sstride);
+
+					if (rc)
+						return rc;
+					g.stats.sub_restricted++;
+					subdist = ix->w_subdist;
+					sub_xmax = ix->dm_all.xmax;
+					sub_rn2 = ix->dm_all.rn2 + ix->dm_all_ncmp;
+				}
+				else if (ix->bat_subdist && cdist)
 				{
 					/* the centroid scan of this call multiplied the centres along with the centroids */
 					subdist = ix->bat_subdist;
@@ -4711,6 +4742,12 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_dense_min must be 24 .. 100000 pairs per bucket");
 		g_s16c_dense_min = value;
 	}
+	else if (!strcmp(name, "screen16_sub_restrict"))
+	{
+		if (value < 0)
+			return fail(NDBHIP_ERR_INVALID, "screen16_sub_restrict must be 0 (never) or a number of centres");
+		g_sub_restrict = value;
+	}
 	else if (!strcmp(name, "screen16c_tight"))
 	{
 		if (value < 8 || value > 1024 || (value & (value - 1)))
@@ -4919,6 +4956,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 	const int  *cq_exp = nullptr;
 
 	ix->bat_subdist = nullptr;
+	ix->bat_restrict = false;
 
 	if (s16_here)
 	{
@@ -4970,8 +5008,12 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 		 * reference's arithmetic for the centroids near the nprobe-th only (k_cent_select) */
 		/* the planes laid out and their centres known: the centroids and the regrouped lists' centres are one matrix
 		 * (dm_all), the sweep's sublist code reads its columns past the centroids' */
-		const bool	both = ix->s16_valid && ix->s16_sub && ix->dm_all_valid && ix->dm_all_ncmp == ncmp && ix->nsub_g > 0 &&
+		const bool	both0 = ix->s16_valid && ix->s16_sub && ix->dm_all_valid && ix->dm_all_ncmp == ncmp && ix->nsub_g > 0 &&
 			ix->dm_all.n == ncmp + ix->nsub_g && g_s16_prune && ivf_recipe(strategy) != R_IVF_COS;
+		/* many centres: the matrix is the centroids' alone and the centres of the probed lists follow once the probes are
+		 * known (float4 queries; the norms and the error bound stay dm_all's) */
+		const bool	restr = both0 && g_sub_restrict > 0 && ix->nsub_g >= g_sub_restrict && !ix->f16;
+		const bool	both = both0 && !restr;
 		S16Mat	   &cm = both ? ix->dm_all : ix->dm_cent;
 		const uint32_t astride = (uint32_t) (((both ? ncmp + ix->nsub_g : ncmp) + 63) & ~63);
 
@@ -4998,6 +5040,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 			ix->bat_subdist = ix->w_amat + ncmp;
 			ix->bat_sstride = astride;
 		}
+		ix->bat_restrict = restr;
 #define CENT_SELECT_L(PER, ST)                                                                                      \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cent_select<PER, ST>), dim3(nq), dim3(64), (size_t) cs_nbuf * S16X_SLOT(4), g.stream, (const float *) ix->w_amat, astride, \
 						   cq_n2, (const uint32_t *) cm.xmax, d_q, (const float *) d.centroids, ix->dim, \

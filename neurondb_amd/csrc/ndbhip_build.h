@@ -2322,6 +2322,30 @@ ivf_s16_build_sublists(ndbhip_ivf *ix, std::vector<uint32_t> &bo, bool slack, co
 
 			cptr[s2] = sub_gidx[s2] >= 0 ? ix->d_subcent + (size_t) sub_gidx[s2] * dim : lcent + (size_t) c * dim;
 		}
+	{
+		/* the units of ivf_s16_sub_distances_probed: a regrouped list's sublists (those with a centre of their own) sixteen at
+		 * a time, eight beyond 1024 dimensions (the tile of centres lives in LDS) */
+		std::vector<uint2> units;
+		const uint32_t uc = dim > 1024 ? 8u : 16u;
+
+		for (int c = 0; c < nc; c++)
+		{
+			uint32_t	s2 = first[(size_t) c];
+			const uint32_t s3 = first[(size_t) c + 1];
+
+			while (s2 < s3 && sub_gidx[s2] >= 0)
+			{
+				units.push_back(make_uint2((uint32_t) c, s2));
+				s2 += uc;
+			}
+		}
+		if (grow(ix->d_sub_units, ix->d_sub_units_n, units.size() + 1)) return NDBHIP_ERR_HIP;
+		if (!units.empty())
+			HIP_TRY(hipMemcpyAsync(ix->d_sub_units, units.data(), units.size() * sizeof(uint2), hipMemcpyHostToDevice, g.stream));
+		ix->nsub_units = (uint32_t) units.size();
+		ix->sub_unit_c = uc;
+		HIP_TRY(hipStreamSynchronize(g.stream));		/* (units is a local) */
+	}
 	if (grow(ix->d_sub_first, ix->d_sub_first_n, (size_t) nc + 1)) return NDBHIP_ERR_HIP;
 	if (grow(ix->d_sub_len, ix->d_sub_len_n, nsub)) return NDBHIP_ERR_HIP;
 	if (grow(ix->d_sub_loc, ix->d_sub_loc_n, nsub + 1)) return NDBHIP_ERR_HIP;
@@ -2368,6 +2392,257 @@ ivf_s16_sub_distances(ndbhip_ivf *ix, const float *d_q, int nq, uint32_t *sstrid
 	if (grow(ix->w_subdist, ix->w_subdist_n, (size_t) nq * st)) return NDBHIP_ERR_HIP;
 	*sstride = st;
 	return s16mat_run(ix->dm_sub, ix->dim, ix->w_qplanes, ix->w_qn2, ix->w_qexp, ix->w_qthr, nq, ix->w_subdist, st);
+}
+
+/*
+ * Round 6: the same distances for the centres of each query's PROBED lists only (10M x 768, lists 4096 has
+ * 78 k centres — every query x every centre was 0.79 of a 4.3 ms step, on every rank of a sharded search — while a query can
+ * use the 32 x ~19 of its probed lists).  List-major, so that a tile of centres is read once for all the queries that probe
+ * its list: the batch's (query, probe) pairs bucketed by list (k_lq_count / k_lq_scan / k_lq_fill), then k_subdist_lists —
+ * a work item = (a UNIT of <= 16 sublists of one list, 256 of the list's queries); the tile of centres in LDS, a wave per
+ * query, every lane the elements lane, lane + 64, ... of (q - c)^2 in fp32, the wave's sum by the xor butterfly:
+ * |a - |q - c|^2| <= (dim / 64 + 8) 2^-24 a, far inside the s16_e bound the consumers (k_sub_pairs, the seeds,
+ * k_s16c_thr_radius) assume for the matrix-core sweep's values.  Entries of lists a query does not probe are never read
+ * (the consumers walk sub_first[L] .. sub_first[L + 1] of probed lists) and are left as they are.
+ */
+__global__ __launch_bounds__(256) void
+k_lq_count(const int *__restrict__ probes, uint32_t n, int nlists, uint32_t *__restrict__ cnt)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+
+	if (i < n)
+	{
+		const int	L = probes[i];
+
+		if (L >= 0 && L < nlists)
+			atomicAdd(&cnt[L], 1u);
+	}
+}
+
+/* one block: off[0 .. nlists] = exclusive sums of cnt (cursor = a copy), then uoff[0 .. nunits] = exclusive sums of the units'
+ * work items (ceil(queries of the unit's list / 256)); uoff[nunits + 1] = the work counter, zeroed */
+__global__ __launch_bounds__(1024) void
+k_lq_scan(const uint32_t *__restrict__ cnt, int nlists, uint32_t *__restrict__ off, uint32_t *__restrict__ cursor,
+		  const uint2 *__restrict__ units, uint32_t nunits, uint32_t *__restrict__ uoff)
+{
+	__shared__ uint32_t s_w[16], s_run;
+	const int	tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+	for (int pass = 0; pass < 2; pass++)
+	{
+		const uint32_t n = pass == 0 ? (uint32_t) nlists : nunits;
+
+		if (tid == 0)
+			s_run = 0;
+		__syncthreads();
+		for (uint32_t i0 = 0; i0 < n; i0 += 1024)
+		{
+			const uint32_t i = i0 + (uint32_t) tid;
+			uint32_t	v = 0;
+
+			if (i < n)
+			{
+				if (pass == 0)
+					v = cnt[i];
+				else
+				{
+					const uint32_t L = units[i].x;
+
+					v = (off[L + 1] - off[L] + 255u) >> 8;
+				}
+			}
+			uint32_t	inc = v;
+
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1)
+			{
+				const uint32_t t = (uint32_t) __shfl_up((int) inc, o, 64);
+
+				if (lane >= o)
+					inc += t;
+			}
+			if (lane == 63)
+				s_w[w] = inc;
+			__syncthreads();
+			uint32_t	base = s_run;
+
+			for (int k2 = 0; k2 < w; k2++)
+				base += s_w[k2];
+			if (i < n)
+			{
+				if (pass == 0)
+				{
+					off[i] = base + inc - v;
+					cursor[i] = base + inc - v;
+				}
+				else
+					uoff[i] = base + inc - v;
+			}
+			__syncthreads();
+			if (tid == 1023)
+				s_run = base + inc;
+			__syncthreads();
+		}
+		if (tid == 0)
+		{
+			if (pass == 0)
+				off[nlists] = s_run;
+			else
+			{
+				uoff[nunits] = s_run;
+				uoff[nunits + 1] = 0;
+			}
+		}
+		__syncthreads();		/* (pass 1 reads off[]) */
+	}
+}
+
+__global__ __launch_bounds__(256) void
+k_lq_fill(const int *__restrict__ probes, uint32_t n, int npr, int nlists, uint32_t *__restrict__ cursor, uint32_t *__restrict__ lq)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+
+	if (i < n)
+	{
+		const int	L = probes[i];
+
+		if (L >= 0 && L < nlists)
+			lq[atomicAdd(&cursor[L], 1u)] = i / (uint32_t) npr;
+	}
+}
+
+#define SUBD_QREG 32			/* query elements a lane holds: dim <= 2048 */
+__global__ __launch_bounds__(256) void
+k_subdist_lists(const float *__restrict__ q, int dim, const uint32_t *__restrict__ lq_off, const uint32_t *__restrict__ lq,
+				const uint2 *__restrict__ units, uint32_t nunits, uint32_t unit_c, const uint32_t *__restrict__ uoff,
+				uint32_t *__restrict__ next, const uint32_t *__restrict__ sub_first, const int *__restrict__ sub_gidx,
+				const float *const *__restrict__ sub_cptr, float *__restrict__ subdist, uint32_t sstride)
+{
+	extern __shared__ __attribute__((aligned(16))) float s_c[];		/* [unit_c][dim] */
+	__shared__ uint32_t s_item;
+	__shared__ int s_g[16];
+	const int	tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t total = uoff[nunits];
+
+	for (;;)
+	{
+		__syncthreads();		/* (the tile and s_item of the item before) */
+		if (tid == 0)
+			s_item = atomicAdd(next, 1u);
+		__syncthreads();
+		const uint32_t item = s_item;
+
+		if (item >= total)
+			break;
+		/* the unit of this item: the last u with uoff[u] <= item */
+		uint32_t	lo = 0, hi = nunits;
+
+		while (hi - lo > 1)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+
+			if (uoff[mid] <= item)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		while (lo + 1 < nunits && uoff[lo + 1] <= item)
+			lo++;
+		const uint2 un = units[lo];
+		const uint32_t L = un.x, s0 = un.y, s1 = min(s0 + unit_c, sub_first[L + 1]);
+		const uint32_t q0 = lq_off[L] + ((item - uoff[lo]) << 8), q1 = min(q0 + 256u, lq_off[L + 1]);
+
+		/* the tile of centres (the sublists of the unit that have one) */
+		if (tid < 16)
+			s_g[tid] = s0 + (uint32_t) tid < s1 ? sub_gidx[s0 + tid] : -1;
+		for (uint32_t t = 0; s0 + t < s1; t++)
+		{
+			if (sub_gidx[s0 + t] < 0)		/* uniform */
+				continue;
+			const float *c = sub_cptr[s0 + t];
+
+			for (int i = tid; i < dim; i += 256)
+				s_c[(size_t) t * dim + i] = c[i];
+		}
+		__syncthreads();
+		for (uint32_t qi = q0 + (uint32_t) w; qi < q1; qi += 4)
+		{
+			const uint32_t qq = lq[qi];
+			const float *qv = q + (size_t) qq * dim;
+			float		qr[SUBD_QREG];
+
+#pragma unroll
+			for (int j = 0; j < SUBD_QREG; j++)
+				qr[j] = lane + 64 * j < dim ? qv[lane + 64 * j] : 0.0f;
+			for (uint32_t t = 0; s0 + t < s1; t++)
+			{
+				const int	gi = s_g[t];
+
+				if (gi < 0)				/* uniform */
+					continue;
+				const float *c = s_c + (size_t) t * dim;
+				float		p = 0.0f;
+
+#pragma unroll
+				for (int j = 0; j < SUBD_QREG; j++)
+					if (lane + 64 * j < dim)
+					{
+						const float d = qr[j] - c[lane + 64 * j];
+
+						p = p + d * d;
+					}
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1)
+					p = p + __shfl_xor(p, o, 64);
+				if (lane == 0)
+					subdist[(size_t) qq * sstride + (uint32_t) gi] = p;
+			}
+		}
+	}
+}
+
+static int
+ivf_s16_sub_distances_probed(ndbhip_ivf *ix, const float *d_q, int nq, const int *w_probes, int npr, uint32_t *sstride)
+{
+	const uint32_t st = (uint32_t) ((ix->nsub_g + 63) & ~63);
+	const int	nl = ix->ncent;
+	const uint32_t npairs = (uint32_t) nq * (uint32_t) npr;
+
+	if (ix->dim > 64 * SUBD_QREG)
+		return fail(NDBHIP_ERR_UNSUPPORTED, "ivf_s16_sub_distances_probed: dim <= %d", 64 * SUBD_QREG);
+	if (grow(ix->w_subdist, ix->w_subdist_n, (size_t) nq * st)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_lqoff, ix->w_lqoff_n, (size_t) 3 * (nl + 1))) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_lq, ix->w_lq_n, (size_t) npairs + 1)) return NDBHIP_ERR_HIP;
+	if (grow(ix->w_uoff, ix->w_uoff_n, (size_t) ix->nsub_units + 4)) return NDBHIP_ERR_HIP;
+	*sstride = st;
+	if (ix->nsub_units == 0 || npairs == 0)
+		return 0;
+	uint32_t   *cnt = ix->w_lqoff, *off = ix->w_lqoff + (nl + 1), *cursor = ix->w_lqoff + 2 * (nl + 1);
+
+	HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) (nl + 1) * 4, g.stream));
+	hipLaunchKernelGGL(k_lq_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, npairs, nl, cnt);
+	hipLaunchKernelGGL(k_lq_scan, dim3(1), dim3(1024), 0, g.stream, (const uint32_t *) cnt, nl, off, cursor,
+					   (const uint2 *) ix->d_sub_units, ix->nsub_units, ix->w_uoff);
+	hipLaunchKernelGGL(k_lq_fill, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, npairs, npr, nl, cursor, ix->w_lq);
+	const size_t smem = (size_t) ix->sub_unit_c * ix->dim * sizeof(float);
+
+	if (smem > 65536)
+	{
+		static bool attr = false;
+
+		if (!attr)
+		{
+			HIP_TRY(hipFuncSetAttribute((const void *) k_subdist_lists, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4));
+			attr = true;
+		}
+	}
+	hipLaunchKernelGGL(k_subdist_lists, dim3((unsigned) (g.num_cus * (smem > 49152 ? 2 : 3))), dim3(256), smem, g.stream, d_q, ix->dim,
+					   (const uint32_t *) off, (const uint32_t *) ix->w_lq, (const uint2 *) ix->d_sub_units, ix->nsub_units,
+					   ix->sub_unit_c, (const uint32_t *) ix->w_uoff, ix->w_uoff + ix->nsub_units + 1,
+					   (const uint32_t *) ix->d_sub_first, (const int *) ix->d_sub_gidx, (const float *const *) ix->d_sub_cptr,
+					   ix->w_subdist, st);
+	HIP_TRY(hipGetLastError());
+	return 0;
 }
 
 /* read the index image back (tests, bench cpu baseline, PostgreSQL page writer) */

@@ -809,3 +809,51 @@ def test_dense_tile_on_a_halfvec_mirror(strategy, lib):
         lib.check(L.ndbhip_set_option(b"screen16c_qb", 0))
         lib.check(L.ndbhip_set_option(b"screen16c_sample", 2048))
         ix.close()
+
+
+def test_centres_of_probed_lists_only_give_the_same_results_as_the_full_matrix():
+    """Round 6 (ivf_s16_sub_distances_probed, k_subdist_lists): a table with many regrouped lists scores, per batch, the
+    sublist centres of each query's PROBED lists (list-major, fp32) instead of multiplying every query by every centre on
+    the matrix cores.  The values only steer thresholds and pruning: results must be the oracle's either way — 256 lists
+    that mix clusters (regrouped from 300 rows up), L2 and inner product, a candidate cap, duplicate probes of list 0
+    (nprobe > lists is not possible here; list 0 is probed by many queries) — and `sub_restricted` must show which ran."""
+    from neurondb_amd import IvfIndex, _lib
+    from oracle import ndbo
+    L = _lib.lib()
+    rng = np.random.default_rng(606)
+    dim, nlists = 64, 256
+    comp = (rng.standard_normal((900, dim)) * 4).astype(np.float32)
+    rows, lens = [], []
+    for li in range(nlists):
+        mine = rng.choice(900, 2 + li % 3, replace=False)
+        n = 330 + 40 * (li % 7)
+        r = (comp[mine[rng.integers(0, len(mine), n)]] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+        rows.append(r)
+        lens.append(n)
+    rows = np.concatenate(rows)
+    cents = np.stack([rows[sum(lens[:li]):sum(lens[:li + 1])].mean(0) for li in range(nlists)]).astype(np.float32)
+    a = dict(centroids=cents, list_len=np.asarray(lens, np.int64), rows=rows, tids=ndbo.tids_from_rows(np.arange(len(rows))))
+    q = (comp[rng.integers(0, 900, 384)] + 0.05 * rng.standard_normal((384, dim))).astype(np.float32)
+    img = oracle_image(a)
+    _lib.check(L.ndbhip_set_option(b"screen16_sub_min", 300))
+    _lib.check(L.ndbhip_set_scan_mode(5))
+    try:
+        for strategy, cap in ((1, 0), (3, 0), (1, 60)):
+            et, ed, ec, _ = oracle_search_batch(img, q, strategy, 12, 10, cap)
+            for restrict, expect in ((1, True), (0, False)):
+                _lib.check(L.ndbhip_set_option(b"screen16_sub_restrict", restrict))
+                ix = IvfIndex(dim, nlists)
+                ix.set_centroids(a["centroids"])
+                ix.load(a["list_len"], a["rows"], a["tids"])
+                ix.search(q, strategy, 12, 10, cap)          # (the first batch lays the planes out; the second runs on them)
+                _lib.check(L.ndbhip_stats_reset())
+                t, d, c = ix.search(q, strategy, 12, 10, cap)
+                st = _lib.stats()
+                assert st["screen16_batches"] >= 1 and st["screen16_fallbacks"] == 0
+                assert (st["sub_restricted"] >= 1) == expect, (strategy, restrict, st)
+                assert_same_results(t, d, c, et, ed, ec)
+                ix.close()
+    finally:
+        _lib.check(L.ndbhip_set_option(b"screen16_sub_restrict", 0))
+        _lib.check(L.ndbhip_set_option(b"screen16_sub_min", 2048))
+        _lib.check(L.ndbhip_set_scan_mode(0))
