@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The `intended` HNSW at size: build rate, search rate, recall@10 against a float64 brute force.
-usage: tools/h2_bench.py N [DIM] [gauss|clustered] [EF ...]   (unit-norm rows, m = 16, ef_construction = 200)"""
+usage: tools/h2_bench.py N [DIM] [gauss|clustered] [EF ...]   (unit-norm rows, m = 16, ef_construction = 200;
+H2_STRATEGY = the operator class's strategy, default 2 = cosine like bench.py's C3 leg)"""
 import os
 import sys
 import time
@@ -23,6 +24,7 @@ def main():
     _lib.use_torch_stream()
     import ctypes as C
     nq = int(os.environ.get("H2_NQ", "8192"))
+    strategy = int(os.environ.get("H2_STRATEGY", "2"))
     x = torch.empty((n, dim), dtype=torch.float32, device=dev)
     q = torch.empty((nq, dim), dtype=torch.float32, device=dev)
     k1 = 1 if kind == "clustered" else 0
@@ -58,20 +60,20 @@ def main():
     sims = q[:nr].double() @ x.double().T
     gt = torch.topk(sims, 10, dim=1).indices.cpu().numpy() + 1
     for ef in efs:
-        ix.search_intended(q[:256], ef, 10)
+        ix.search_intended(q[:256], ef, 10, strategy=strategy)
         ph = (C.c_ulonglong * 8)()
         check(lib().ndbhip_debug_h2_phases(ph))               # (reset: what follows is the timed search alone)
         t0 = time.perf_counter()
-        ob, od, oc, oe = ix.search_intended(q, ef, 10)
+        ob, od, oc, oe = ix.search_intended(q, ef, 10, strategy=strategy)
         ts = time.perf_counter() - t0
         rec = float(np.mean([len(set(ob[i, :oc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nr)]))
-        print(f"search ef={ef}: {nq / ts:.0f} queries/s ({ts * 1e3:.1f} ms per {nq}), recall@10 {rec:.3f}, "
+        print(f"search ef={ef} strategy={strategy}: {nq / ts:.0f} queries/s ({ts * 1e3:.1f} ms per {nq}), recall@10 {rec:.3f}, "
               f"{oe.mean():.0f} evaluations/query")
         if dim % 4 == 0 and dim <= 1024:
             # the same with the walk on fp16 walk rows (ndbhip_hnsw_search_intended_w16_device)
-            ix.search_intended(q[:256], ef, 10, walk16=True)
+            ix.search_intended(q[:256], ef, 10, walk16=True, strategy=strategy)
             t0 = time.perf_counter()
-            wb, wd, wc, we = ix.search_intended(q, ef, 10, walk16=True)
+            wb, wd, wc, we = ix.search_intended(q, ef, 10, walk16=True, strategy=strategy)
             tw = time.perf_counter() - t0
             rec = float(np.mean([len(set(wb[i, :wc[i]].tolist()) & set(gt[i].tolist())) / 10 for i in range(nr)]))
             same = float(np.mean([np.array_equal(wb[i], ob[i]) for i in range(nq)]))

@@ -126,7 +126,10 @@ def main():
             a = a[3:]
             cf, cw = counters(hp + "_fetch.txt"), counters(hp + "_write.txt")
             # (round 5: k_h2_search<0> walks the float4 rows, k_h2_search<NG> the fp16 walk rows; older files: one kernel)
-            for needle, name in (("k_h2_search<0>", "k_h2_search"), ("k_h2_search<3>", "k_h2_search_w16"), ("k_h2_search(", "k_h2_search")):
+            # (round 6: the kernels carry the strategy too — k_h2_search<0, 1>, k_h2_search<3, 1>)
+            for needle, name in (("k_h2_search<0, 2>", "k_h2_search"), ("k_h2_search<3, 2>", "k_h2_search_w16"),
+                                 ("k_h2_search<0,", "k_h2_search"), ("k_h2_search<3,", "k_h2_search_w16"), ("k_h2_search<0>", "k_h2_search"),
+                                 ("k_h2_search<3>", "k_h2_search_w16"), ("k_h2_search(", "k_h2_search")):
                 f, w = pick(cf, needle), pick(cw, needle)
                 if f and w and name not in doc["kernels"]:
                     fk, n = f["FETCH_SIZE"]

@@ -53,7 +53,10 @@ def main():
     sync()
     pcn = pc.cpu().numpy()
     cnt = np.bincount(pcn[pcn >= 0].ravel(), minlength=nlists)
-    for world, how in ((2, "slices"), (4, "slices"), (8, "rows"), (8, "work"), (8, "slices")):
+    variants = ((2, "slices"), (4, "slices"), (8, "rows"), (8, "work"), (8, "slices"))
+    if os.environ.get("VARIANTS"):                       # e.g. VARIANTS=8:work,8:slices
+        variants = tuple((int(v.split(":")[0]), v.split(":")[1]) for v in os.environ["VARIANTS"].split(","))
+    for world, how in variants:
         if how == "slices":
             slo, sln, stl = partition_slices(ll, world, cnt)
             loads = sln.sum(1).astype(np.float64)
