@@ -610,9 +610,10 @@ def main():
                     mirrors[w].search_device(queries[s * nq:(s + 1) * nq], ln["t"], ln["d"], ln["c"], strategy, nprobe, k, 0)
                     ln["last"] = s
                 check(lib().ndbhip_synchronize())
-                check(lib().ndbhip_set_thread_stream(None))
             except Exception as e:              # (surfaced by the caller: a lane must not die silently)
                 err.append(e)
+            finally:
+                lib().ndbhip_set_thread_stream(None)
         th = [threading.Thread(target=lane, args=(w,)) for w in range(inflight)]
         for t in th:
             t.start()
@@ -1255,9 +1256,10 @@ def steps_in_flight(ix, nlanes, q, nq, first, count, strategy, P, K, dev, warm=2
                     handles[w].search_device(q[s_ * nq:(s_ + 1) * nq], *bufs[w], strategy, P, K, 0)
                     last[w] = s_
                 check(lib().ndbhip_synchronize())
-                check(lib().ndbhip_set_thread_stream(None))
             except Exception as e:          # noqa: BLE001
                 err.append(e)
+            finally:
+                lib().ndbhip_set_thread_stream(None)
         th = [threading.Thread(target=lane, args=(w,)) for w in range(nlanes)]
         for t_ in th:
             t_.start()
@@ -1782,9 +1784,10 @@ def hnsw_intended_leg(args, dev, m=16, efc=200, ef=64, nq=8192, strategy=2):
                     with torch.cuda.stream(streams[w]):
                         for _ in range(rp):
                             lastres[w] = handles[w].search_intended(q, ef, k, walk16=walk16, strategy=strategy)
-                    check(lib().ndbhip_set_thread_stream(None))
                 except Exception as ex:          # noqa: BLE001
                     errs.append(ex)
+                finally:
+                    lib().ndbhip_set_thread_stream(None)
 
             def go():
                 th = [threading.Thread(target=lane, args=(w,)) for w in range(nl)]

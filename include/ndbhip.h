@@ -86,7 +86,13 @@ int			ndbhip_set_stream(void *hip_stream);
 /* The CALLING THREAD's stream: every entry point this thread calls afterwards launches on it instead of the process-wide
  * one (NULL: back to that).  Two host threads, each with a stream and a mirror of its own, keep two batches in flight:
  * the per-query chains of one batch (round trips to memory) run under the other batch's sweep (profiles/r05_overlap.txt).
- * Handles are not shared between threads that search at the same time. */
+ * Handles are not shared between threads that search at the same time; ndbhip_ivf_share / ndbhip_hnsw_share and the
+ * destroy of a shared handle are made while no other thread searches on the source (a share copies the source's
+ * tables as they stand).
+ * GPU_MAX_HW_QUEUES: the HIP runtime maps a process's streams onto 4 hardware queues unless the environment says
+ * otherwise WHEN THE RUNTIME INITIALISES — two streams that land on one queue run one after the other and nothing
+ * overlaps.  A process that keeps batches in flight on streams of its own exports GPU_MAX_HW_QUEUES=8 before its first
+ * HIP call (bench.py sets it for itself; under rocprofv3 export it in the shell: tools/round_profiles.sh). */
 int			ndbhip_set_thread_stream(void *hip_stream);
 int			ndbhip_get_stream(void **out_hip_stream);	/* the stream every asynchronous entry point is ordered on */
 int			ndbhip_synchronize(void);

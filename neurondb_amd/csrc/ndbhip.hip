@@ -3540,6 +3540,9 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		}
 		ix->s16_valid = true;
 		ix->s16_bigk_off = false;		/* (a new layout: k > 64 gets another try) */
+		ix->s16w_off = false;			/* ... and so does the register-streaming sweep, with word arrays sized afresh */
+		ix->wc_words = 0;
+		ix->wc_mult = 4;
 	}
 	return 0;
 }
@@ -4413,7 +4416,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				 * the next batch gets planes twice as large */
 				if (ix->qc_mult < 16)
 					ix->qc_mult *= 2;
-				if (wd && ix->wc_mult < 4096)
+				/* (the word arrays only when THEY were what did not fit: f[7] = the words the batch needed — already remembered in
+				 * wc_words above, which sizes the next batch; a pair-plane overflow alone must not quadruple 256 bytes a word) */
+				if (wd && f[7] > wcap && ix->wc_mult < 4096)
 					ix->wc_mult *= 4;
 				break;
 			}

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -28,8 +29,15 @@ class HnswIndex:
         self._h = h
 
     def close(self):
+        """Destroys the handle; the shares made from it (share()) that are still open are closed first — the library refuses to
+        destroy a graph with live shares, and at interpreter exit the source may well be collected before them."""
+        for ref in getattr(self, "_shares", []):
+            sh = ref()
+            if sh is not None:
+                sh.close()
+        self._shares = []
         if getattr(self, "_h", None):
-            check(lib().ndbhip_hnsw_destroy(self._h))     # (refused while shares of this graph are alive: close them first)
+            check(lib().ndbhip_hnsw_destroy(self._h))
             self._h = None
 
     def share(self):
@@ -40,6 +48,9 @@ class HnswIndex:
         sub = HnswIndex.__new__(HnswIndex)
         sub.dim, sub.m, sub._h, sub._src = self.dim, self.m, h, self
         sub.nblocks = getattr(self, "nblocks", None)
+        if not hasattr(self, "_shares"):
+            self._shares = []
+        self._shares.append(weakref.ref(sub))
         return sub
 
     def __del__(self):

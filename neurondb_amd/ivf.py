@@ -10,6 +10,7 @@ IvfScan   ~ IndexScanDesc + IvfScanOpaqueData: rescan(query) / gettuple(),
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -36,8 +37,15 @@ class IvfIndex:
         self._keep = []          # device tensors adopted by load_device
 
     def close(self):
+        """Destroys the handle; the shares made from it (share()) that are still open are closed first — the library refuses to
+        destroy a mirror with live shares, and at interpreter exit the source may well be collected before them."""
+        for ref in getattr(self, "_shares", []):
+            sh = ref()
+            if sh is not None:
+                sh.close()
+        self._shares = []
         if getattr(self, "_h", None):
-            check(lib().ndbhip_ivf_destroy(self._h))      # (refused while shares of this mirror are alive: close them first)
+            check(lib().ndbhip_ivf_destroy(self._h))
             self._h = None
 
     def __del__(self):
@@ -157,6 +165,9 @@ class IvfIndex:
         sub = IvfIndex.__new__(IvfIndex)
         sub.dim, sub.nlists, sub._h, sub._keep = self.dim, self.nlists, h, [self]
         sub.ncent = getattr(self, "ncent", self.nlists)
+        if not hasattr(self, "_shares"):
+            self._shares = []
+        self._shares.append(weakref.ref(sub))
         return sub
 
     def to_f16(self, reference_encoder=True):

@@ -8,6 +8,7 @@ R=${1:-r06}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8     # (steps in flight need hardware queues of their own; rocprofv3's preloaded tool initialises the runtime before bench.py can set it)
 stats() { tag=$1; shift; rm -rf /tmp/ks_$tag; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks_$tag -o p -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > /tmp/ks_$tag.log 2>&1)
   f=$(find /tmp/ks_$tag -name "*.db" | head -1); [ -n "$f" ] && python3 tools/rocpd_summary.py $f 60 > gpurun_out/${R}_${tag}_kernel_stats.txt; grep -E "k_s16c_wsweep|k_s16w_collect|k_s16_finalize|k_s16c_seed" gpurun_out/${R}_${tag}_kernel_stats.txt | cut -c1-60,76-130; }
 LEGS0="--hnsw-nvec 0 --gauss-steps 0 --c5-nvec 0 --c4-nvec 0 --sigma-sweep 0 --cpu-seconds 0 --build-from-host 0 --recall-queries 0"
