@@ -222,8 +222,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="queries per step")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="default: 3 on clustered tables (and in the clustered legs), 1 on the i.i.d. table, whose dense sweep fills the "
-                         "device by itself.  N = 1, unsharded: steps in flight at once — that many mirrors of the index, each driven by a host thread "
+                    help="default: 3.  N = 1, unsharded: steps in flight at once — that many mirrors of the index, each driven by a host thread "
                          "with a stream of its own (ndbhip_set_thread_stream): a step's per-query chains (selection, seeds, pair "
                          "tables, finalize: waves waiting for memory) run under another step's sweep; the sweeps themselves queue "
                          "up.  1 = one step after the other (reported either way as `serial`)")
@@ -320,7 +319,9 @@ def main():
     lanes_legs = 3 if args.inflight is None else max(1, args.inflight)       # the clustered legs' steps in flight
     args.lanes_legs = lanes_legs
     if args.inflight is None:
-        args.inflight = 3 if args.data == "clustered" else 1
+        # (round 6: the i.i.d. table too — its dense sweep fills the device, but the 0.8 ms of chain kernels around it run under
+        # the next step's sweep: 6.10 -> 5.76 ms a step with three in flight, measured on one box)
+        args.inflight = 3
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -578,7 +579,8 @@ def main():
         # the other steps in flight search SHARES of the mirror (ndbhip_ivf_share: the same rows, planes and tables, scratch
         # of their own); a share builds nothing, so the source runs one batch first (matrices, samples, constants)
         import threading
-        step(queries[:nq])
+        for _ in range(2):              # (the second batch knows the first one's pairs per bucket: tile size, the rows' sample)
+            step(queries[:nq])
         torch.cuda.synchronize()
         for _ in range(inflight - 1):
             mirrors.append(ix.share())
