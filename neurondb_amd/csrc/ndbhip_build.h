@@ -1140,6 +1140,21 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 		HIP_TRY(hipMemsetAsync(acnt, 0, (size_t) ns * 4, g.stream));
 		hipLaunchKernelGGL(k_s16_row_prep<0>, dim3((unsigned) ((ns + 3) / 4)), dim3(256), 0, g.stream, (const void *) srows,
 						   ns, dim, dimp, (const int64_t *) (locoff + 2 * v), m32, 1, planes, rn2, rexp, xmax);
+		if (g_build_single_sweep)
+		{
+			/* round 6, ONE sweep (MODE 4): an item tests its elements against the row's minimum so far and the resolve kernel
+			 * applies the test again with the final one — the candidate sets of the two sweeps below, the matrix multiplied once */
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 4>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
+							   (const unsigned char *) planes, m32, (const float *) rn2, (const int16_t *) rexp,
+							   (const unsigned char *) qplanes, qrowbytes, (const float *) qn2, (const int *) qexp,
+							   (float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
+							   (const PairRec *) pairs, heads, m32 + 8, acnt, arec, 1u, rowmin, 0, dimp / S16_CH, nitems, 0u);
+			hipLaunchKernelGGL(k_s16_assign_resolve, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
+							   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
+							   (unsigned long long *) (over_n + 2), (const uint32_t *) rowmin, (const float *) rn2, (const float2 *) aux);
+		}
+		else
+		{
 		/* two sweeps over the same items: the minimum of every row, then the centroids within reach of it */
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16_sweep<R_IVF_L2, 0, 4, 2, 0, 1>), dim3(g.num_cus * 2), dim3(256), 0, g.stream, dv,
 						   (const unsigned char *) planes, m32, (const float *) rn2, (const int16_t *) rexp,
@@ -1154,7 +1169,8 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 						   dimp / S16_CH, nitems, 0u);
 		hipLaunchKernelGGL(k_s16_assign_resolve, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
 						   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
-						   (unsigned long long *) (over_n + 2));
+						   (unsigned long long *) (over_n + 2), (const uint32_t *) nullptr, (const float *) nullptr, (const float2 *) nullptr);
+		}
 		HIP_TRY(hipGetLastError());
 		if (!overlapped && while_running)
 		{

@@ -1803,7 +1803,13 @@ k_s16_items(const uint32_t *__restrict__ item_off, const uint32_t *__restrict__ 
  * MODE 2 records, per row, the centroids whose a lies within the error bound of that minimum: ecount[row] = how
  * many, erec[row][S16_ASSIGN_SLOTS] = (centroid, a).  qthr has one slot per centroid like in a search, of which
  * only qthr[0].x = the largest centroid norm is used. */
-#define S16_ASSIGN_SLOTS 8
+/* MODE 4 (round 6): both in ONE sweep.  An item first takes its tile's row minima (MODE 1), publishes them with a returning
+ * atomicMin on bmin[row] and tests its elements against the threshold of min(what bmin held, the tile's own) — the row's
+ * minimum SO FAR, never below the final one, so every centroid the final threshold admits is recorded (thresholds grow
+ * with the minimum they come from), along with a few the final one no longer admits: a row's tiles leave a record whenever
+ * they set a new low, 2.7 of 8 tiles on average.  k_s16_assign_resolve then applies MODE 2's test with the FINAL minimum to
+ * the records: the same candidate set as the two sweeps', hence the same lists; the matrix is multiplied once. */
+#define S16_ASSIGN_SLOTS 16
 
 template <int R, int H16, int NW, int NBUF, int DBG = 0, int MODE = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && NBUF == 2) ? 2 : 1) void
@@ -2310,10 +2316,58 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 					}
 			}
 		}
-		else if constexpr (MODE == 2)
+		else if constexpr (MODE == 2 || MODE == 4)
 		{
 			/* build, second sweep: every centroid within reach of the row's minimum, S16_ASSIGN_SLOTS records a row */
 			const float c2max = qthr[0].x;
+			__shared__ uint32_t s_rowlow[MODE == 4 ? G::RT : 1];
+
+			if constexpr (MODE == 4)
+			{
+				/* the tile's row minima (MODE 1's code), published; s_rowlow = the rows' minima so far, this tile included */
+				if (tid < G::RT)
+					s_rowlow[tid] = 0xFFFFFFFFu;
+				__syncthreads();
+#pragma unroll
+				for (int b = 0; b < 2; b++)
+				{
+					const uint32_t ridx = t2 * G::RT + (uint32_t) (32 * (2 * wr + b) + r32);
+					const size_t grow = (size_t) ix.loc_off[L] + (ridx < len ? ridx : len - 1);
+					const float x2 = rn2[grow];
+					const int	ex = (int) rexp[grow];
+					uint32_t	mn = 0xFFFFFFFFu;
+
+#pragma unroll
+					for (int a = 0; a < 2; a++)
+#pragma unroll
+						for (int reg = 0; reg < 16; reg++)
+						{
+							const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+							const S16Q	qi = qinfo[cur][m];
+
+							if (qi.nrow != 0)
+							{
+								const float dot = ldexpf(run[a][b][reg], qi.eq + ex - 28);
+								const float av = __builtin_fmaf(-2.0f, dot, qi.q2 + x2);
+
+								if (av == av)		/* (a NaN bounds nothing: left out of the minimum, emitted below) */
+									mn = min(mn, ndb_key_from_bits(__float_as_uint(av)));
+							}
+						}
+					mn = min(mn, (uint32_t) __shfl_xor((int) mn, 32, 64));
+					if (kh == 0 && ridx < len)
+						atomicMin(&s_rowlow[32 * (2 * wr + b) + r32], mn);
+				}
+				__syncthreads();
+				if (tid < G::RT && t2 * G::RT + (uint32_t) tid < len)
+				{
+					const uint32_t mine = s_rowlow[tid];
+					const uint32_t old = atomicMin(&bmin[(size_t) ix.loc_off[L] + t2 * G::RT + tid], mine);
+
+					s_rowlow[tid] = min(old, mine);
+				}
+				__syncthreads();
+			}
 
 #pragma unroll
 			for (int b = 0; b < 2; b++)
@@ -2325,7 +2379,7 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 				const size_t grow = (size_t) ix.loc_off[L] + ridx;
 				const float x2 = rn2[grow];
 				const int	ex = (int) rexp[grow];
-				const uint32_t gmin = bmin[grow];
+				const uint32_t gmin = MODE == 4 ? s_rowlow[32 * (2 * wr + b) + r32] : bmin[grow];
 				const uint32_t gb = (gmin & 0x80000000u) ? (gmin & 0x7FFFFFFFu) : ~gmin;
 				const float e_r = s16_e<R_IVF_L2>(ix.dim, x2, c2max, false);
 				const float thr = gmin == 0xFFFFFFFFu ? __uint_as_float(0x7F800000u) : s16_thr_from_a<R_IVF_L2>(__uint_as_float(gb), e_r, ix.dim);
@@ -2353,6 +2407,8 @@ k_s16_sweep(IvfDev ix, const unsigned char *__restrict__ planes, const uint32_t 
 						}
 					}
 			}
+			if constexpr (MODE == 4)
+				__syncthreads();		/* s_rowlow is reused by the next item */
 		}
 		else
 #pragma unroll
@@ -2748,17 +2804,43 @@ __global__ void __launch_bounds__(256)
 k_s16_assign_resolve(const float *__restrict__ rows, int64_t nrows, int dim, const float *__restrict__ cents,
 					 const unsigned int *__restrict__ acnt, const uint2 *__restrict__ arec,
 					 int *__restrict__ out_list, int64_t row_base, unsigned int *__restrict__ over_n,
-					 int64_t *__restrict__ over_rows, unsigned long long *__restrict__ multi_n)
+					 int64_t *__restrict__ over_rows, unsigned long long *__restrict__ multi_n,
+					 const uint32_t *__restrict__ rowmin = nullptr /* MODE 4's records: the rows' FINAL minima (keys), ... */ ,
+					 const float *__restrict__ rn2 = nullptr /* ... their norms ... */ ,
+					 const float2 *__restrict__ aux = nullptr /* ... and [0].x = the largest centroid norm: MODE 2's test is applied here */ )
 {
 	const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
 
 	if (r >= nrows)
 		return;
-	const uint32_t n = acnt[r];
+	uint32_t	n = acnt[r];
+	uint2		rec[S16_ASSIGN_SLOTS];
 
+	if (n >= 1 && n <= S16_ASSIGN_SLOTS)
+	{
+		uint32_t	nv = 0;
+		float		thr = __uint_as_float(0x7F800000u);
+
+		if (rowmin)
+		{
+			const uint32_t gmin = rowmin[r];
+			const uint32_t gb = (gmin & 0x80000000u) ? (gmin & 0x7FFFFFFFu) : ~gmin;
+
+			if (gmin != 0xFFFFFFFFu)
+				thr = s16_thr_from_a<R_IVF_L2>(__uint_as_float(gb), s16_e<R_IVF_L2>(dim, rn2[r], aux[0].x, false), dim);
+		}
+		for (uint32_t j = 0; j < n; j++)
+		{
+			const uint2 e = arec[(size_t) r * S16_ASSIGN_SLOTS + j];
+
+			if (!rowmin || !(__uint_as_float(e.y) > thr))
+				rec[nv++] = e;
+		}
+		n = nv;
+	}
 	if (n == 1)
 	{
-		out_list[r] = (int) arec[(size_t) r * S16_ASSIGN_SLOTS].x;
+		out_list[r] = (int) rec[0].x;
 		return;
 	}
 	if (n == 0 || n > S16_ASSIGN_SLOTS)
@@ -2775,7 +2857,7 @@ k_s16_assign_resolve(const float *__restrict__ rows, int64_t nrows, int dim, con
 	for (uint32_t j = 0; j < n; j++)
 	{
 		/* kept in centroid order (insertion: a handful of entries) */
-		const int	c = (int) arec[(size_t) r * S16_ASSIGN_SLOTS + j].x;
+		const int	c = (int) rec[j].x;
 		int			p = (int) j;
 
 		while (p > 0 && cand[p - 1] > c)
