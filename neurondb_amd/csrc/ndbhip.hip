@@ -3155,6 +3155,7 @@ k_ipc_qev(const float *__restrict__ qn2, const uint32_t *__restrict__ m2_bits, i
  * pass then serves batches of >= 128 queries); records a query may emit before the batch falls back */
 static int	g_s16_auto = 1;
 static int	g_build_s16 = 1;		/* ndbhip_set_option("build_screen16", 0): the build assigns on the vector ALU only */
+static int	g_kmeans_s16 = 1;		/* "kmeans_screen16": the Lloyd iterations' assignment through the screen too (0: the vector ALU, rounds 1-5) */
 static int	g_build_single_sweep = 1;	/* "build_single_sweep": the screened assignment multiplies the matrix once (k_s16_sweep MODE 4); 0 = two sweeps (rounds 2-5) */
 static int	g_s16_waves = 4;
 static int	g_s16_debug = 0;		/* timing experiments (wrong results): see k_s16_sweep's DBG */
@@ -4814,6 +4815,8 @@ ndbhip_set_option(const char *name, int value)
 			return fail(NDBHIP_ERR_INVALID, "screen16c_nbuf must be 0 (default), 2 or 3");
 		g_s16c_nbuf = value;
 	}
+	else if (!strcmp(name, "kmeans_screen16"))
+		g_kmeans_s16 = value != 0;
 	else if (!strcmp(name, "build_single_sweep"))
 		g_build_single_sweep = value != 0;
 	else if (!strcmp(name, "build_screen16"))

@@ -570,7 +570,7 @@ assign_rows(const float *d_rows, int64_t nrows, int dim, const float *d_cents, i
 
 static int	assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int k, int *d_out_list,
 							unsigned long long *stats, const std::function<int()> &while_running,
-							const std::function<int(int64_t)> &rows_until = nullptr);
+							const std::function<int(int64_t)> &rows_until = nullptr, bool use_sqrt = true);
 
 extern "C" int
 ndbhip_ivf_assign_device(const float *d_centroids, int ncentroids, int dim, const float *d_rows,
@@ -622,6 +622,8 @@ ndbhip_ivf_insert(ndbhip_ivf *ix, const float *vec, const uint8_t *tid6, int *li
 	return ndbhip_ivf_append(ix, list, vec, tid6);
 }
 
+__global__ void k_count_members(const int *__restrict__ idx, int n, int k, int *__restrict__ counts);
+
 extern "C" int
 ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter, float threshold,
 					 float *d_centroids, int *d_assign, int *d_counts, int *out_iters, float *out_cost)
@@ -650,7 +652,13 @@ ndbhip_kmeans_device(const float *d_samples, int n, int dim, int k, int max_iter
 		int			rc;
 
 		HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t) k * sizeof(int), g.stream));
-		rc = assign_rows(d_samples, n, dim, d_centroids, k, false, d_assign, d_counts, &ws);
+		/* round 6: the Lloyd assignment through the matrix-core screen too (kmeans_assign's squared distances decide among
+		 * the centroids inside the bound's window): 0.43 -> 0.2 ms an iteration at 10000 x 1024 x 768 */
+		rc = (g_build_s16 && g_kmeans_s16 && n >= 4096) ? assign_rows_s16(d_samples, n, dim, d_centroids, k, d_assign, nullptr, nullptr, nullptr, false) : 1;
+		if (rc == 0)
+			hipLaunchKernelGGL(k_count_members, dim3((n + 255) / 256), dim3(256), 0, g.stream, (const int *) d_assign, n, k, d_counts);
+		else if (rc == 1)
+			rc = assign_rows(d_samples, n, dim, d_centroids, k, false, d_assign, d_counts, &ws);
 		if (rc)
 			return rc;
 		hipLaunchKernelGGL(k_kmeans_update, dim3(k), dim3(256), (size_t) n * 4 + 64, g.stream, d_samples, n, dim,
@@ -1005,7 +1013,8 @@ static int
 assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cents, int k, int *d_out_list,
 				unsigned long long *stats /* host [2] or NULL: rows decided among several candidates, rows sent to the exact assignment */ ,
 				const std::function<int()> &while_running /* host work done while the kernels run */ ,
-				const std::function<int(int64_t)> &rows_until /* nullable: returns once rows [0, n) are on the device (a table still arriving) */ )
+				const std::function<int(int64_t)> &rows_until /* nullable: returns once rows [0, n) are on the device (a table still arriving) */ ,
+				bool use_sqrt /* true: the insert rule; false (round 6): kmeans_assign's squared distances — the Lloyd iterations */ )
 {
 	const int	dimp = (dim + 63) & ~63;
 	const uint32_t qrowbytes = (uint32_t) dimp * 4u;
@@ -1149,9 +1158,14 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 							   (const unsigned char *) qplanes, qrowbytes, (const float *) qn2, (const int *) qexp,
 							   (float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
 							   (const PairRec *) pairs, heads, m32 + 8, acnt, arec, 1u, rowmin, 0, dimp / S16_CH, nitems, 0u);
-			hipLaunchKernelGGL(k_s16_assign_resolve, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
-							   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
-							   (unsigned long long *) (over_n + 2), (const uint32_t *) rowmin, (const float *) rn2, (const float2 *) aux);
+			if (use_sqrt)
+				hipLaunchKernelGGL(k_s16_assign_resolve<true>, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
+								   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
+								   (unsigned long long *) (over_n + 2), (const uint32_t *) rowmin, (const float *) rn2, (const float2 *) aux);
+			else
+				hipLaunchKernelGGL(k_s16_assign_resolve<false>, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
+								   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
+								   (unsigned long long *) (over_n + 2), (const uint32_t *) rowmin, (const float *) rn2, (const float2 *) aux);
 		}
 		else
 		{
@@ -1167,9 +1181,14 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 						   (float2 *) aux, m32 + 17, 1, m32 + 3, m32 + 4, (const S16Desc *) (desc + (size_t) v * nitems),
 						   (const PairRec *) pairs, heads + 8 * NDB_QHEAD_STRIDE, m32 + 8, acnt, arec, 1u, rowmin, 0,
 						   dimp / S16_CH, nitems, 0u);
-		hipLaunchKernelGGL(k_s16_assign_resolve, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
-						   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
-						   (unsigned long long *) (over_n + 2), (const uint32_t *) nullptr, (const float *) nullptr, (const float2 *) nullptr);
+		if (use_sqrt)
+			hipLaunchKernelGGL(k_s16_assign_resolve<true>, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
+							   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
+							   (unsigned long long *) (over_n + 2), (const uint32_t *) nullptr, (const float *) nullptr, (const float2 *) nullptr);
+		else
+			hipLaunchKernelGGL(k_s16_assign_resolve<false>, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, g.stream, srows, ns, dim,
+							   d_cents, (const unsigned int *) acnt, (const uint2 *) arec, d_out_list + s0, s0, over_n, over_rows,
+							   (unsigned long long *) (over_n + 2), (const uint32_t *) nullptr, (const float *) nullptr, (const float2 *) nullptr);
 		}
 		HIP_TRY(hipGetLastError());
 		if (!overlapped && while_running)
@@ -1204,7 +1223,7 @@ assign_rows_s16(const float *d_rows, int64_t nrows, int dim, const float *d_cent
 		if (tmp.alloc(orows, (size_t) hs.over * dim * sizeof(float))) return NDBHIP_ERR_HIP;
 		if (tmp.alloc(olist, (size_t) hs.over * sizeof(int))) return NDBHIP_ERR_HIP;
 		hipLaunchKernelGGL(k_rows_gather, dim3(hs.over), dim3(256), 0, g.stream, d_rows, dim, (const int64_t *) over_rows, orows);
-		const int	rc = assign_rows(orows, (int64_t) hs.over, dim, d_cents, k, true, olist, nullptr);
+		const int	rc = assign_rows(orows, (int64_t) hs.over, dim, d_cents, k, use_sqrt, olist, nullptr);
 
 		if (rc != 0)
 			return rc;

@@ -2800,6 +2800,7 @@ k_s16_finalize(IvfDev ix, const float *__restrict__ queries, const int *__restri
  * the candidates in centroid order.  More than S16_ASSIGN_SLOTS (duplicated centroids, rows beyond fp32): the row
  * goes on the overflow list, which the host sends through the exact assignment.
  */
+template <bool SQRT>		/* true: the insert rule (sqrtf of the sum, ivf_am.c:905-935); false: kmeans_assign's squared distance (:2157-2180, 2255-2269) */
 __global__ void __launch_bounds__(256)
 k_s16_assign_resolve(const float *__restrict__ rows, int64_t nrows, int dim, const float *__restrict__ cents,
 					 const unsigned int *__restrict__ acnt, const uint2 *__restrict__ arec,
@@ -2877,10 +2878,10 @@ k_s16_assign_resolve(const float *__restrict__ rows, int64_t nrows, int dim, con
 		float		dv;
 
 		if ((dim & 3) == 0)
-			dv = scr_exact<R_IVF_L2>(x, cv, dim);	/* 16-byte pieces, 32 loads in flight, then the sequential chain */
+			dv = scr_exact<SQRT ? R_IVF_L2 : R_IVF_L2SQ>(x, cv, dim);	/* 16-byte pieces, 32 loads in flight, then the sequential chain */
 		else
 		{
-			Acc<R_IVF_L2> acc;
+			Acc<SQRT ? R_IVF_L2 : R_IVF_L2SQ> acc;
 
 			for (int d = 0; d < dim; d++)
 				acc.step(x[d], cv[d]);
