@@ -172,10 +172,12 @@ def test_two_batches_of_walks_in_flight_on_shares_of_one_graph():
                 assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
         with pytest.raises(NdbHipError):
             ix.build_intended(base, ndbo.tids_from_rows(np.arange(n)), levels, 64)      # frozen
-        with pytest.raises(NdbHipError):
-            ix.close()                                                                   # a share is alive
-        handles[1].close()
+        # (the library refuses to destroy a graph with live shares; HnswIndex.close() closes its shares first)
+        assert _lib.lib().ndbhip_hnsw_destroy(ix._h) < 0 and b"shares" in _lib.lib().ndbhip_last_error()
+        if not w16:
+            handles[1].close()
     ix.close()
+    assert handles[1]._h is None
 
 
 
