@@ -121,3 +121,58 @@ def test_round_5_artefacts_agree_with_each_other():
     traffic, source = bench.pmc_traffic(args, 1, "k_s16c_wsweep")
     assert traffic and abs(traffic - w["traffic_bytes_per_launch"]) < 0.02 * traffic and "profiles/r0" in source
 
+
+
+def test_round_6_artefacts_agree_with_each_other():
+    """profiles/r06_*: the line bench.py printed on the GPU box (what the driver parses) is under 8 KB, strict JSON, carries the
+    contract's fields with `roofline` and `cpu_baseline` as numbers, and is what driver_line() makes of the committed detail
+    file; the headline is the i.i.d. table with the clustered table beside it; the PMC traffic file is
+    what the committed summaries say and bench.py finds it for the kernel the headline runs."""
+    P = os.path.join(ROOT, "profiles")
+    raw = open(os.path.join(P, "r06_bench_line.json")).read().strip()
+    assert "\n" not in raw and len(raw) < 8192
+
+    def reject(tok):
+        raise AssertionError(tok)
+    d = json.loads(raw, parse_constant=reject)
+    full = json.load(open(os.path.join(P, "r06_bench_detail.json")))
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.driver_line(full) == d
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "value_clustered", "roofline_clustered", "c4", "c5", "sigma_sweep", "hnsw"):
+        assert key in d, key
+    assert "i.i.d." in d["metric"] and d["config"]["data"].startswith("i.i.d.") and d["vs_baseline"] is None
+    r, rc, c = d["roofline"], d["roofline_clustered"], d["cpu_baseline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "k_s16c_dense" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 0.7
+    assert rc["bound"] == "hbm" and rc["kernel"] == "k_s16c_wsweep" and 0.45 < rc["frac"] < 0.8
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["gpu_mismatches_on_sample"] == 0
+    assert d["value_clustered"] > 4 * d["value"] > 0 and d["recall_at_10"] > 0.85 and d["recall_at_10_clustered"] == 1.0
+    assert d["serial"]["lanes_identical_to_serial"] and d["step_latency_ms"] >= d["ms_per_step"]
+    for name, leg in d["sigma_sweep"].items():
+        assert leg["recall_at_10"] >= 0.99 and leg["oracle_mismatches"] == 0, name
+    # the middle of the sweep runs the dense tile now (round 6: from 48 pairs a bucket)
+    assert d["sigma_sweep"]["s1.0"]["kernel"] == "k_s16c_dense" and d["sigma_sweep"]["s1.0"]["queries_per_s"] > 1.2e6
+    h = d["hnsw"]
+    assert h["strategy"] == 2 and h["recall_at_10"] >= 0.90 and h["intended_oracle_parity_mismatches"] == 0 and h["queries_per_s"] > 2e6
+    assert h["ref_compat"]["oracle_mismatches"] == 0
+    b = full["build"]
+    assert b["lists_identical_to_exact_assignment"] and b["vectors_per_s"] > 3e7
+    kept = json.load(open(os.path.join(P, "r06_pmc_traffic.json")))["kernels"]
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "t.json")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_json.py"), out, "3",
+                               "--ivf", "clustered", os.path.join(P, "r06_pmc_clustered"), "--ivf", "gauss", os.path.join(P, "r06_pmc_gauss"),
+                               "--h2", os.path.join(P, "r06_pmc_h2"), "8192"], stdout=subprocess.DEVNULL)
+        fresh = json.load(open(out))["kernels"]
+    g, w = kept["k_s16c_dense"]["gauss"], kept["k_s16c_wsweep"]["clustered"]
+    assert fresh["k_s16c_dense"]["gauss"]["traffic_bytes_per_launch"] == g["traffic_bytes_per_launch"]
+    assert fresh["k_s16c_wsweep"]["clustered"]["traffic_bytes_per_launch"] == w["traffic_bytes_per_launch"]
+    assert 1.0e10 < g["traffic_bytes_per_launch"] < 2.5e10 and 0.4 < g["l2_hit_rate"] < 0.8 and 0.3 < g["mfma_busy"] < 0.8
+    assert r["traffic"] == g["traffic_bytes_per_launch"] and rc["traffic"] == w["traffic_bytes_per_launch"]
+    args = types.SimpleNamespace(data="gauss", nvec=1_000_000, dim=768, lists=1024, probes=32, batch=4096, k=10, rows="f32", strategy="l2")
+    t, src, busy = bench.pmc_traffic(args, 1, "k_s16c_dense", "gauss", want_busy=True)
+    assert t == g["traffic_bytes_per_launch"] and "profiles/r06" in src and busy == g["mfma_busy"]
+    w16 = kept["k_h2_search_w16"]["clustered_unit"]
+    assert 0.5 < w16["traffic_bytes_per_query"] / kept["k_h2_search"]["clustered_unit"]["traffic_bytes_per_query"] < 0.7
