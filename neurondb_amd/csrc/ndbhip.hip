@@ -3246,6 +3246,8 @@ static int	g_s16c_dense_min_sub = 100;	/* "screen16c_dense_min_sub": the same fo
 static int	g_sub_restrict = 0;
 static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold every this many records (power of two; "screen16c_tight") */
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
+static int	g_s16c_dense_spare = 0;	/* compute units k_s16c_dense leaves free on a mirror that has shares, i.e. steps in flight: the tile fills a CU's LDS and registers, so other steps' kernels run only where it is not ("screen16c_dense_spare") */
+static int	g_s16c_dense_split = 3;	/* 32-row blocks of a tile's eight that k_s16c_dense's loader waves multiply: 4 (as many as the multipliers) or 3 ("screen16c_dense_split") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_wave = 2;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
 static int	g_s16c_plseed = 1;	/* first thresholds from the sweep's own planes (block 0 of the nearest sublist) instead of float4 rows ("screen16c_plane_seeds") */
@@ -4155,6 +4157,68 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		else
 			hipLaunchKernelGGL(k_pair_count, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, w_probes, lco, npr,
 							   (uint32_t) nq, cnt, act, drop);
+#ifdef NDB_DEBUG_SUBPAIRS
+		if (sub && getenv("NDB_DEBUG_Q") && atoi(getenv("NDB_DEBUG_Q")) < nq)
+		{
+			/* (diagnostic builds only) what k_sub_pairs saw for one query */
+			const int	dq = atoi(getenv("NDB_DEBUG_Q"));
+			float2		th;
+			float		q2 = 0, xm = 0;
+			std::vector<int> pr(npr);
+			std::vector<uint32_t> lc(npr + 1), sf(nc + 1);
+
+			HIP_TRY(hipStreamSynchronize(g.stream));
+			HIP_TRY(hipMemcpy(&th, ix->w_qthr + dq, 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(&q2, ix->w_qn2 + dq, 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(&xm, sub_xmax, 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(pr.data(), w_probes + (size_t) dq * npr, 4 * npr, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(lc.data(), lco + (size_t) dq * (npr + 1), 4 * (npr + 1), hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(sf.data(), ix->d_sub_first, 4 * (nc + 1), hipMemcpyDeviceToHost));
+			float		ecd = (ndb_s16_cdot(dim) + NDB_S16_NORMS) * (q2 + xm) * 1.00001f;
+
+			ecd = ecd + fabsf(ecd) * 4.8e-7f + 1e-37f + NDB_S16_ABS;
+			fprintf(stderr, "DBG q %d: T %.9g  |q|^2 %.9g xmax %.9g ec %.9g prune %d cdist %d subdist %p sstride %u R %d\n", dq, th.x, q2, xm, ecd, (int) prune, cdist ? 1 : 0, (const void *) subdist, sstride, R);
+			for (int p = 0; p < npr; p++)
+			{
+				fprintf(stderr, "DBG  probe %d list %d visible %u\n", p, pr[p], lc[p + 1] - lc[p]);
+				if (pr[p] < 0 || pr[p] >= nc)
+					continue;
+				for (uint32_t s2 = sf[pr[p]]; s2 < sf[pr[p] + 1]; s2++)
+				{
+					uint32_t	sl = 0, sr = 0;
+					int			gi = 0;
+					float		a = -1.0f;
+					int64_t		po = 0;
+
+					HIP_TRY(hipMemcpy(&sl, ix->d_sub_len + s2, 4, hipMemcpyDeviceToHost));
+					HIP_TRY(hipMemcpy(&sr, ix->d_sub_rad + s2, 4, hipMemcpyDeviceToHost));
+					HIP_TRY(hipMemcpy(&gi, ix->d_sub_gidx + s2, 4, hipMemcpyDeviceToHost));
+					HIP_TRY(hipMemcpy(&po, ix->d_prow_off + s2, 8, hipMemcpyDeviceToHost));
+					if (gi >= 0 && subdist)
+						HIP_TRY(hipMemcpy(&a, subdist + (size_t) dq * sstride + gi, 4, hipMemcpyDeviceToHost));
+					float		rad;
+					memcpy(&rad, &sr, 4);
+					const double alo = (double) a - (double) ecd * (1.0 + 1e-6);
+					const double lb = sqrt(alo > 0.0 ? alo : 0.0) - (double) rad;
+					std::vector<uint32_t> pp(sl);
+					std::vector<float> cc(dim);
+					const float *cp = nullptr;
+
+					HIP_TRY(hipMemcpy(pp.data(), ix->d_pposof + po, 4 * sl, hipMemcpyDeviceToHost));
+					HIP_TRY(hipMemcpy(&cp, ix->d_sub_cptr + s2, sizeof(cp), hipMemcpyDeviceToHost));
+					HIP_TRY(hipMemcpy(cc.data(), cp, 4 * dim, hipMemcpyDeviceToHost));
+					fprintf(stderr, "DBG   sub %u len %u gi %d rad %.9g a %.9g lb^2 %.9g %s  pos:", s2, sl, gi, rad, a, lb > 0 ? lb * lb : 0.0,
+							(lb > 0.0 && lb * lb * (1.0 - 1e-9) > (double) th.x) ? "EXCLUDED" : "kept");
+					for (uint32_t r = 0; r < sl; r++)
+						fprintf(stderr, " %u", pp[r]);
+					fprintf(stderr, "\nDBG   centre:");
+					for (int i = 0; i < dim; i++)
+						fprintf(stderr, " %.9g", cc[i]);
+					fprintf(stderr, "\n");
+				}
+			}
+		}
+#endif
 		const bool	xsum_apart = sub && ncs > 8192;
 
 		if (xsum_apart)
@@ -4272,8 +4336,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0,                                       \
 							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, ipc ? (const float *) ix->w_qev : (const float *) nullptr)
-#define S16C_DENSE_L(DB)                                                                                             \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_dense<DB>), dim3(g.num_cus), dim3(512), 0, g.stream,                  \
+#define S16C_DENSE_L(DB) S16C_DENSE_LS(DB, 4)
+#define S16C_DENSE_LS(DB, NBLL)                                                                                      \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_dense<DB, NBLL>), dim3(dense_grid), dim3(512), 0, g.stream,           \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qc_plane * 2, \
@@ -4296,6 +4361,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (const uint32_t *) (grp_off + ncs), dimp / S16C_CH, desc_cap, (const uint32_t *) ix->d_pposof, cE, qc_cap, \
 							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, next_item)
 #define S16C_WSWEEP_D(DD, BLKK) do { if (ipc) S16C_WSWEEP_L(DD, true, BLKK); else S16C_WSWEEP_L(DD, false, BLKK); } while (0)
+			const unsigned dense_grid = (unsigned) std::max(8, g.num_cus - (ivf_frozen(ix) ? g_s16c_dense_spare : 0));
+
 			if (dense_k)
 				g.stats.dense_sweeps++;
 			/* (two chunks in flight: the 168-register form whatever the blocks — at two blocks a compute unit it leaves a
@@ -4312,6 +4379,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				S16C_DENSE_L(6);
 			else if (dense_k && g_s16_debug == 7)
 				S16C_DENSE_L(7);
+			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4) && g_s16c_dense_split == 3)
+				S16C_DENSE_LS(0, 3);
 			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4))
 				S16C_DENSE_L(0);
 			else if (dense_k && g_s16_debug == 1)
@@ -4769,6 +4838,18 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16c_dense"))
 		g_s16c_dense = value != 0;
+	else if (!strcmp(name, "screen16c_dense_split"))
+	{
+		if (value != 3 && value != 4)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_dense_split must be 3 or 4");
+		g_s16c_dense_split = value;
+	}
+	else if (!strcmp(name, "screen16c_dense_spare"))
+	{
+		if (value < 0 || value > 128)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_dense_spare must be 0..128");
+		g_s16c_dense_spare = value;
+	}
 	else if (!strcmp(name, "screen16c_pfd"))
 	{
 		if (value < 0 || value > 10)

@@ -565,7 +565,11 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 					/* (|q - c|^2 - |c|^2 orders the centres like -q.c does; any choice of seed rows is a valid one) */
 					dd -= gi < 0 ? (cn2_list ? cn2_list[probes[(size_t) q * npr + p0 + lo]] : 0.0f) : (cn2_sub ? cn2_sub[gi] : 0.0f);
 
-				if (dd < bd || (dd == bd && sx < bs))
+				/* (a total order, the probe included: a list probed twice — the reference's probe slots beyond nlists all
+				 * read list 0, ivf_am.c:1978 — offers the same sublist at the same distance under two probes with different
+				 * numbers of visible rows, and every lane of every wave has to end up with the SAME probe: round 6's fuzz
+				 * found lanes that disagreed on which seed rows are candidates, and a threshold of 0) */
+				if (dd < bd || (dd == bd && (sx < bs || (sx == bs && (uint32_t) (p0 + lo) < bp))))
 				{
 					bd = dd;
 					bs = sx;
@@ -580,7 +584,7 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			const float od = __shfl_xor(bd, off, 64);
 			const uint32_t os = (uint32_t) __shfl_xor((int) bs, off, 64), op = (uint32_t) __shfl_xor((int) bp, off, 64);
 
-			if (od < bd || (od == bd && os < bs))
+			if (od < bd || (od == bd && (os < bs || (os == bs && op < bp))))
 			{
 				bd = od;
 				bs = os;
@@ -600,7 +604,7 @@ k_s16c_seed(IvfDev ix, const float *__restrict__ queries, const int *__restrict_
 			const float od = s_bd[w];
 			const uint32_t os = s_bs[w], op = s_bp[w];
 
-			if (od < bd || (od == bd && os < bs))
+			if (od < bd || (od == bd && (os < bs || (os == bs && op < bp))))
 			{
 				bd = od;
 				bs = os;

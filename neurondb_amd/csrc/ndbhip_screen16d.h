@@ -48,7 +48,7 @@
 #define S16D_PH_FLUSH ((void) 0)
 #endif
 
-template <int DBG = 0>
+template <int DBG = 0, int NBL = 4 /* 32-row blocks of the tile's eight that a loader wave multiplies; its SIMD's multiplier takes the rest */>
 __global__ __launch_bounds__(512, 1) void
 k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
 			 const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
@@ -234,7 +234,6 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 	const int	sw = (r32 >> 1) & 7;
 	const int	qfrag = S16D_QOFF + (2 * wq) * 4096 + r32 * 128;
-	const int	rfrag = (4 * wr) * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
 
 	S16D_PH_DECL;
@@ -245,6 +244,16 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		for (int p = 0; p <= pfd; p++)
 			step();
 
+	/*
+	 * The items, for a wave that multiplies NB of the tile's eight 32-row blocks from block rb0 on (its SIMD's other wave
+	 * has the rest; both have the same 64 pairs).  NBL = 4: four and four.  NBL = 3: a loader's 16 requests per chunk cost
+	 * it ~1360 cycles in which it issues no matrix instruction, and its sibling's 32 are done after 1024 — with 24 for the
+	 * loader and 40 for the multiplier the pipe has work until the loader's requests are out.
+	 */
+	auto		run = [&](auto nbc, const int rb0) {
+	constexpr int NB = decltype(nbc)::value;
+	const int	rfrag = rb0 * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
+
 	for (;;)
 	{
 		/* the item being multiplied: its descriptor again (scalar cache) */
@@ -252,12 +261,12 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		const uint32_t L = dc.L, t2 = dc.t2;
 		const uint32_t nmem_cur = min((uint32_t) T, cnt[L] - dc.qt * T);
 		const uint32_t len = own_len[L];
-		ndb_f16acc	acc[2][4];
+		ndb_f16acc	acc[2][NB];
 
 #pragma unroll
 		for (int a = 0; a < 2; a++)
 #pragma unroll
-			for (int b = 0; b < 4; b++)
+			for (int b = 0; b < NB; b++)
 #pragma unroll
 				for (int i = 0; i < 16; i++)
 					acc[a][b][i] = 0.0f;
@@ -270,18 +279,18 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 #pragma unroll
 			for (int s = 0; s < 4; s++)
 			{
-				ndb_h8		ah[2], bh[4];
+				ndb_h8		ah[2], bh[NB];
 
 #pragma unroll
 				for (int a = 0; a < 2; a++)
 					ah[a] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + a * 4096 + (((2 * s + kh) ^ sw) * 16));
 #pragma unroll
-				for (int b = 0; b < 4; b++)
+				for (int b = 0; b < NB; b++)
 					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + s * 1024);
 #pragma unroll
 				for (int a = 0; a < 2; a++)
 #pragma unroll
-					for (int b = 0; b < 4; b++)
+					for (int b = 0; b < NB; b++)
 						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
 			}
 		};
@@ -308,37 +317,42 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			/* (thread = member: the loaders' 256 threads; a gather by LDS DMA like everything else — an ordinary load
 			 * would bring the compiler's own waits on the vector-memory counter into paths the prefetchers take too) */
 			s16_dma4(s16_uniform_ptr((const unsigned char *) qthr), 8u * s_qid[c_par][tid], tf_la + (uint32_t) lw * 256u);
-		for (int c = 1; c < nchunk; c++)
-			chunk();
-		if (nchunk == 1 && loader)
-			s16_wait_vm<0>();		/* (otherwise the later chunks' waits have covered the gather) */
-
-		/* does one of this lane's four rows (row 32 (4 wr + b) + r32 of the tile) have an exponent outside pass 0's range */
-		bool		wildrow = false;
+		/*
+		 * What the item's END needs besides the accumulators — the members' operands of pass 0's test instruction, whether
+		 * an exponent is outside its range — depends on nothing the chunks compute: the members' and rows' constants landed
+		 * with the first chunk, the thresholds with the second.  So from three chunks up it is made behind the SECOND chunk's
+		 * barrier, by the multiplier waves' threads (who wait for the loaders at every chunk anyway), and a wave goes from
+		 * its last matrix instruction straight into pass 0: no preparation and no block-wide barrier in the part of an item
+		 * where the matrix pipe idles (round 6; before, the loaders made it after the last chunk, a barrier behind it).
+		 */
+		const bool	early = nchunk >= 3;		/* uniform */
+		auto		wildcheck = [&]() {
+			/* does one of this lane's rows (row 32 (rb0 + b) + r32 of the tile) have an exponent outside pass 0's range */
+			bool		wildrow = false;
 
 #pragma unroll
-		for (int b = 0; b < 4; b++)
-		{
-			const int	ri = 32 * (4 * wr + b) + r32;
-			const int	ex = (int) reinterpret_cast<const int16_t *>(&s_exw[c_par][0])[(ri >> 6) * 128 + (ri & 63)];
+			for (int b = 0; b < NB; b++)
+			{
+				const int	ri = 32 * (rb0 + b) + r32;
+				const int	ex = (int) reinterpret_cast<const int16_t *>(&s_exw[c_par][0])[(ri >> 6) * 128 + (ri & 63)];
 
-			wildrow = wildrow || (t2 * T + (uint32_t) ri < len && (ex < -20 || ex > 20));
-		}
-		if (loader)
-		{
+				wildrow = wildrow || (t2 * T + (uint32_t) ri < len && (ex < -20 || ex > 20));
+			}
+			if (wildrow)
+				s_wild[c_par] = 1u;
+		};
+		auto		prep = [&](int tix /* the member */ ) {
 			/* what pass 1 subtracts: T rounded up with the slack its fused form needs; and the member's operands of the
 			 * test instruction (pass 0 — ndbhip_screen16c.h has the derivation): u = (KB Q2 - TB) 2^(27 - eq) and
 			 * v = KB 2^(27 - eq), negated.  A member the tile does not have never emits (u = +inf); a NaN — a norm that
 			 * is not a finite fp32, a threshold that is +inf — always does (u = -inf). */
 			/* (an index the compiler cannot see through: the kernel runs at the register file's limit, and an LDS address
 			 * computed in the prologue for this block would live — in scratch — across the whole sweep) */
-			int			tix = tid;
-
 			asm volatile("" : "+v"(tix));
 			const bool	valid = (uint32_t) tix < nmem_cur;
 			const int	eq = s_eq[c_par][tix];
 			const float KB = (1.0f - cE) * 0.9999962f;
-			const float tfresh = s_tf[tix];		/* (written by this wave's own DMA) */
+			const float tfresh = s_tf[tix];
 			const float TB = s16_up(tfresh * 1.000004f) + NDB_S16_ABS;
 			float		cm = __builtin_fmaf(s_q2[c_par][tix], KB, -TB);
 
@@ -349,12 +363,32 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			s_nuv[1][tix] = valid ? -ldexpf(cm, 27 - eq) : -__builtin_inff();
 			if (valid && (eq < -20 || eq > 20))
 				s_wild[c_par] = 1u;
+		};
+
+		for (int c = 1; c < nchunk; c++)
+		{
+			chunk();
+			if (c == 1 && early)
+			{
+				/* (behind the second chunk's barrier: the loaders waited for the thresholds' gather in front of it; the third
+				 * chunk's barrier, at least, comes before anybody looks) */
+				wildcheck();
+				if (!loader)
+					prep(tid - 256);
+			}
 		}
-		if (wildrow)
-			s_wild[c_par] = 1u;
+		if (nchunk == 1 && loader)
+			s16_wait_vm<0>();		/* (otherwise the later chunks' waits have covered the gather) */
+		if (!early)
+		{
+			wildcheck();
+			if (loader)
+				prep(tid);
+		}
 		if (tid == 0)
 			s_wild[c_par ^ 1u] = 0;		/* read by the item before this one, set next by the item after it */
-		__syncthreads();
+		if (!early)
+			__syncthreads();
 
 		const float K = (1.0f - cE) * 0.99999905f;
 		const bool	wild = s_wild[c_par] != 0;		/* uniform */
@@ -426,20 +460,36 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			__builtin_amdgcn_wave_barrier();
 			hq_n = 0;
 		};
-		auto		block = [&](auto ac, auto bc) {
-			constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
+		/* pass 0's operands, once per item: the rows' (w, 2^-ex) by row block, the members' (v, u) by pair block */
+		float		wbv[NB], uav[2];
+		uint32_t	deadm = 0;			/* bit b: this lane's row of row block b is no row (beyond the bucket, or a hole) */
 
-			if (a >= na)
-				return;				/* uniform */
-			const int	ri = 32 * (4 * wr + b) + r32;
+#pragma unroll
+		for (int b = 0; b < NB; b++)
+		{
+			const int	ri = 32 * (rb0 + b) + r32;
 			const int	ex = (int) reinterpret_cast<const int16_t *>(&s_exw[c_par][0])[(ri >> 6) * 128 + (ri & 63)];
 			const float x2 = s_x2[c_par][ri];
 			const bool	nan = !(x2 == x2);
 			const bool	dead = !(t2 * T + (uint32_t) ri < len) || s_por[c_par][ri] == 0xFFFFFFFFu;
 			const float w = dead ? __builtin_inff() : (nan ? -__builtin_inff() : ldexpf(x2, -ex));
-			const float wb = kh ? ldexpf(1.0f, -ex) : w;
-			const float ua = s_nuv[kh][32 * (2 * wq + a) + r32];
-			const ndb_f16acc fin = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, wb, acc[a][b], 0, 0, 0);
+
+			wbv[b] = kh ? ldexpf(1.0f, -ex) : w;
+			deadm |= dead ? 1u << b : 0u;
+		}
+#pragma unroll
+		for (int a = 0; a < 2; a++)
+			uav[a] = s_nuv[kh][32 * (2 * wq + a) + r32];
+		/* block n of the wave's 2 NB: pair block n & 1, row block n >> 1.  The test instruction of block n + 1 is issued
+		 * before block n's result is looked at (two result windows: the operand fragments' registers are free by now) */
+		auto		pass0 = [&](auto nc) {
+			constexpr int a = decltype(nc)::value & 1, b = decltype(nc)::value >> 1;
+
+			return __builtin_amdgcn_mfma_f32_32x32x2f32(uav[a], wbv[b], acc[a][b], 0, 0, 0);
+		};
+		auto		look = [&](auto nc, const ndb_f16acc &fin) {
+			constexpr int a = decltype(nc)::value & 1, b = decltype(nc)::value >> 1;
+			const int	ri = 32 * (rb0 + b) + r32;
 			int			mx = (int) 0x80000000;
 
 #pragma unroll
@@ -456,7 +506,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			uint32_t	mask = 0;
 
 			if (wild)
-				mask = dead ? 0u : 0xFFFFu;
+				mask = ((deadm >> b) & 1u) ? 0u : 0xFFFFu;
 			else
 			{
 #pragma unroll
@@ -492,10 +542,36 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				hq_n += cnt;
 			}
 		};
-#define S16D_BLK(A, B) block(std::integral_constant<int, A>{}, std::integral_constant<int, B>{})
-		S16D_BLK(0, 0); S16D_BLK(1, 0); S16D_BLK(0, 1); S16D_BLK(1, 1);
-		S16D_BLK(0, 2); S16D_BLK(1, 2); S16D_BLK(0, 3); S16D_BLK(1, 3);
-#undef S16D_BLK
+		{
+			ndb_f16acc	fin0, fin1;
+
+			/* (a = 1 blocks of a tile with <= 32 members here are not looked at: uniform) */
+#define S16D_P0(N, F) do { if constexpr ((N) < 2 * NB) { if (((N) & 1) < na) F = pass0(std::integral_constant<int, (N)>{}); } } while (0)
+#define S16D_LK(N, F) do { if constexpr ((N) < 2 * NB) { if (((N) & 1) < na) look(std::integral_constant<int, (N)>{}, F); } } while (0)
+			if constexpr (NB <= 4)
+			{
+				S16D_P0(0, fin0);
+				S16D_P0(1, fin1); S16D_LK(0, fin0);
+				S16D_P0(2, fin0); S16D_LK(1, fin1);
+				S16D_P0(3, fin1); S16D_LK(2, fin0);
+				S16D_P0(4, fin0); S16D_LK(3, fin1);
+				S16D_P0(5, fin1); S16D_LK(4, fin0);
+				S16D_P0(6, fin0); S16D_LK(5, fin1);
+				S16D_P0(7, fin1); S16D_LK(6, fin0);
+				S16D_LK(7, fin1);
+			}
+			else
+			{
+				/* (five row blocks: 160 accumulator registers leave room for one window) */
+				S16D_P0(0, fin0); S16D_LK(0, fin0); S16D_P0(1, fin0); S16D_LK(1, fin0);
+				S16D_P0(2, fin0); S16D_LK(2, fin0); S16D_P0(3, fin0); S16D_LK(3, fin0);
+				S16D_P0(4, fin0); S16D_LK(4, fin0); S16D_P0(5, fin0); S16D_LK(5, fin0);
+				S16D_P0(6, fin0); S16D_LK(6, fin0); S16D_P0(7, fin0); S16D_LK(7, fin0);
+				S16D_P0(8, fin0); S16D_LK(8, fin0); S16D_P0(9, fin0); S16D_LK(9, fin0);
+			}
+#undef S16D_P0
+#undef S16D_LK
+		}
 		if (hq_n != 0)
 			flush();
 		S16D_PH(4);
@@ -552,6 +628,13 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		/* (no barrier: the next item's first chunk starts with one, and the per-item arrays of parity c_par ^ 1 are
 		 * requested again only by an `enter` behind that barrier) */
 	}
+	};
+	if constexpr (NBL == 4)
+		run(std::integral_constant<int, 4>{}, 4 * wr);
+	else if (loader)
+		run(std::integral_constant<int, NBL>{}, 0);
+	else
+		run(std::integral_constant<int, 8 - NBL>{}, NBL);
 	S16D_PH_FLUSH;
 }
 

@@ -857,3 +857,34 @@ def test_centres_of_probed_lists_only_give_the_same_results_as_the_full_matrix()
         _lib.check(L.ndbhip_set_option(b"screen16_sub_restrict", 0))
         _lib.check(L.ndbhip_set_option(b"screen16_sub_min", 2048))
         _lib.check(L.ndbhip_set_scan_mode(0))
+
+
+def test_a_list_probed_twice_offers_its_sublists_under_two_probes_and_the_seeds_take_one(lib):
+    """Round 6's fuzz campaign (seed 81, case ~6000): nlists = 1 and nprobe = 2, so the reference scans list 0 again for the
+    second probe slot (ivf_am.c:1978) and, with a candidate cap of 500 over 2 x 373 rows, only 127 rows of the second pass
+    are candidates.  The seed kernel of the centred sweep (float4 seeds: the cosine path's, `screen16c_plane_seeds` 0 for L2)
+    found the nearest sublist under BOTH probes at the same distance; its lanes broke the tie differently, disagreed on which
+    seed rows are candidates, and one query got a threshold of 0 and lost its only neighbour.  The fixture is that case."""
+    import os
+    from tools.fuzz_replay import load_case
+    from neurondb_amd import _lib as L
+    z, ix, q, k, nprobe, cap, strategy, opts = load_case(os.path.join(os.path.dirname(__file__), "golden", "fuzz_r6_dup_probe_seed.npz"))
+    a = dict(centroids=z["centroids"], list_len=z["list_len"], rows=z["rows"], tids=z["tids"])
+    et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, strategy, nprobe, k, cap)
+    assert nprobe > len(a["list_len"]) and cap < 2 * len(a["rows"]) and ec.min() == 1
+    from tools.fuzz_scan import DEFAULT_OPTIONS, reset_options
+    try:
+        for name, value in opts.items():
+            L.check(L.lib().ndbhip_set_option(name.encode(), value))
+        for mode in (5, 0, 3):
+            L.check(L.lib().ndbhip_set_scan_mode(mode))
+            t, d, c = ix.search(q, strategy, nprobe, k, cap)
+            assert_same_results(t, d, c, et, ed, ec)
+        # ... and cosine, whose seeds are always the float4 rows'
+        et, ed, ec, _ = oracle_search_batch(oracle_image(a), q, 2, nprobe, k, cap)
+        L.check(L.lib().ndbhip_set_scan_mode(5))
+        t, d, c = ix.search(q, 2, nprobe, k, cap)
+        assert_same_results(t, d, c, et, ed, ec)
+    finally:
+        reset_options(L.lib(), L.check)
+        ix.close()

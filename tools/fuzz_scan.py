@@ -126,13 +126,13 @@ def one_case(rng, lib, IvfIndex, check):
     et, ed, ec, _ = oracle_search_batch(img, q, strategy, nprobe, k, cap)
     # the matrix-core screen's own variants: lists regrouped into sublists from 256 rows up (so that these small
     # tables have some), 32- to 256-row sublists, list-level exclusion and in-sweep tightening on or off
-    check(lib.ndbhip_set_option(b"screen16_sub_min", int(rng.choice([256, 256, 2048]))))
-    check(lib.ndbhip_set_option(b"screen16_sub_rows", int(rng.choice([32, 128, 256]))))
-    check(lib.ndbhip_set_option(b"screen16_sublists", int(rng.random() < 0.8)))
-    check(lib.ndbhip_set_option(b"screen16_prune", int(rng.random() < 0.8)))
-    check(lib.ndbhip_set_option(b"screen16_tighten", int(rng.random() < 0.8)))
-    # the centred sweep's tile: chosen by the library, or forced to 32 / 128 pairs x 128 rows, or 256 x 256
-    check(lib.ndbhip_set_option(b"screen16c_qb", int(rng.choice([0, 0, 1, 4, 8, 8]))))
+    sub_opts = [int(rng.choice([256, 256, 2048])), int(rng.choice([32, 128, 256])), int(rng.random() < 0.8),
+                int(rng.random() < 0.8), int(rng.random() < 0.8),
+                # the centred sweep's tile: chosen by the library, or forced to 32 / 128 pairs x 128 rows, or 256 x 256
+                int(rng.choice([0, 0, 1, 4, 8, 8]))]
+    for name, value in zip(("screen16_sub_min", "screen16_sub_rows", "screen16_sublists", "screen16_prune", "screen16_tighten",
+                            "screen16c_qb"), sub_opts):
+        check(lib.ndbhip_set_option(name.encode(), value))
     # round 4: the dense tile's own kernel or the older 8-wave sweep, sample-seeded thresholds on or off, how often the
     # dense kernel tightens, inner product on the centred planes or on two planes, rows streamed through LDS (ring depth)
     r4 = {"screen16c_dense": int(rng.random() < 0.75), "screen16c_sample": int(rng.choice([0, 256, 2048])),
@@ -159,6 +159,14 @@ def one_case(rng, lib, IvfIndex, check):
         except AssertionError:
             print("MISMATCH", dict(dim=dim, n=n, nlists=nlists, nq=nq, kind=kind, k=k, nprobe=nprobe, cap=cap,
                                    strategy=strategy, mode=mode), flush=True)
+            # the case itself, for tools/fuzz_replay.py (gpurun_out/ comes back from the GPU box)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            opts = dict(r4, screen16_sub_min=sub_opts[0], screen16_sub_rows=sub_opts[1], screen16_sublists=sub_opts[2],
+                        screen16_prune=sub_opts[3], screen16_tighten=sub_opts[4], screen16c_qb=sub_opts[5])
+            np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{int(time.time())}.npz"), centroids=a["centroids"],
+                     list_len=a["list_len"], rows=a["rows"], tids=a["tids"], q=q, half=half, k=k, nprobe=nprobe, cap=cap,
+                     strategy=strategy, mode=mode, opt_names=np.array(list(opts)), opt_values=np.array(list(opts.values())),
+                     rows_f16=h if half else np.zeros(0, np.uint16))
             raise
     if not half and rng.random() < 0.25:
         check(lib.ndbhip_set_scan_mode(3))
