@@ -509,34 +509,37 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				mask = ((deadm >> b) & 1u) ? 0u : 0xFFFFu;
 			else
 			{
+				/* the sixteen sign bits, one v_alignbit_b32 each: mk = (mk << 1) | sign, register 15 first */
+				uint32_t	mk = 0;
+
 #pragma unroll
-				for (int reg = 0; reg < 16; reg++)
-					mask |= (__float_as_int(fin[reg]) >= 0 ? 1u : 0u) << reg;
+				for (int reg = 15; reg >= 0; reg--)
+					mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(fin[reg]), 31);
+				mask = ~mk & 0xFFFFu;
 			}
 			for (;;)
 			{
-				const bool	has = mask != 0;
-				const unsigned long long bal = __ballot(has);
+				const unsigned long long any = __ballot(mask != 0);
 
-				if (bal == 0ull)
+				if (any == 0ull)
 					break;
+				/* the register of the first lane that has one (uniform: the accumulator is read by a relative move, no chain
+				 * of selects), and every lane that has an element in that register */
+				const int	reg = __builtin_amdgcn_readfirstlane(__ffs((int) __builtin_amdgcn_readlane((int) mask, __ffsll((long long) any) - 1)) - 1);
+				const bool	has = (mask >> reg) & 1u;
+				const unsigned long long bal = __ballot(has);
 				const uint32_t cnt = (uint32_t) __popcll(bal);
 
 				if (hq_n + cnt > 64u)
 					flush();
+				const float v = acc[a][b][reg];
+
 				if (has)
 				{
-					const int	reg = __ffs((int) mask) - 1;
-					float		v = acc[a][b][0];
-
-					mask &= mask - 1u;
-					/* (a chain of selects: an index known only at run time would send the accumulators to scratch) */
-#pragma unroll
-					for (int r = 1; r < 16; r++)
-						v = reg == r ? acc[a][b][r] : v;
 					const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
 					const uint32_t idx = hq_n + (uint32_t) __popcll(bal & ((1ull << lane) - 1ull));
 
+					mask &= ~(1u << reg);
 					s_hq[wave][idx] = make_uint2((uint32_t) m | ((uint32_t) ri << 8), __float_as_uint(v));
 				}
 				hq_n += cnt;
