@@ -37,4 +37,5 @@ timeout 300 python3 tools/latency.py 2>&1 | grep -v amdgpu.ids | tail -4 > gpuru
 for seed in 71 72; do
   timeout $((FZ+120)) python3 tools/fuzz_scan.py $FZ $seed 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-700 >> gpurun_out/${R}_fuzz_scan.txt
 done
+timeout $((FZ/2+120)) python3 tools/fuzz_hnsw.py $((FZ/2)) 73 2>&1 | grep -v amdgpu.ids | tail -2 | cut -c1-700 >> gpurun_out/${R}_fuzz_scan.txt
 cat gpurun_out/${R}_fuzz_scan.txt
