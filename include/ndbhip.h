@@ -335,7 +335,11 @@ int			ndbhip_ivf_shard_slices(const ndbhip_ivf *src, const int64_t *lo, const in
  * without a second copy of a mirror that is 1.55 x its table.  While a share lives both handles are FROZEN: loads,
  * appends, deletes, builds and anything that would lay the planes out again return NDBHIP_ERR_STATE, so run
  * ndbhip_ivf_prepare (or one batch of every kind the shares will serve) on the source first; ndbhip_ivf_destroy of the
- * source is refused until its shares are destroyed. */
+ * source is refused until its shares are destroyed.
+ * Threading: ndbhip_ivf_share copies the source's handle, and ndbhip_ivf_destroy of a share updates the source's count of
+ * shares: call both while NO search is running on the source (the bench and neurondb_amd/ivf.py create all shares before
+ * the lanes start and close them after the lanes have joined).  Searches on different handles of one mirror may run at the
+ * same time from different threads; searches on ONE handle may not. */
 int			ndbhip_ivf_share(ndbhip_ivf *src, ndbhip_ivf **out);
 /* A halfvec twin of a float4 mirror (same centroids, lists, TIDs): rows narrowed on the device with the
  * reference's own encoder float4_to_fp16 (src/types/quantization.c:141-168: mantissa truncated, subnormal
@@ -622,7 +626,8 @@ int			ndbhip_hnsw_search_intended(ndbhip_hnsw *g, const float *queries, int nq, 
  * maps, result blocks —: two batches of searches in flight, a host thread, a stream (ndbhip_set_thread_stream) and a handle
  * each (a batch ends with its longest walks; the next one's fill the device meanwhile).  Both handles are frozen while the
  * share lives (loads, inserts, builds, deletes: NDBHIP_ERR_STATE); ndbhip_hnsw_destroy of the source is refused until its
- * shares are gone.  Walk rows are made by the source's first ndbhip_hnsw_search_intended_w16_device, before sharing. */
+ * shares are gone.  Walk rows are made by the source's first ndbhip_hnsw_search_intended_w16_device, before sharing.
+ * Threading as for ndbhip_ivf_share: share and destroy while no search runs on the source. */
 int			ndbhip_hnsw_share(ndbhip_hnsw *src, ndbhip_hnsw **out);
 /* bit 0: the heuristic (else the nearest); bit 1: a new node takes up to 2m links at level 0 instead of m; bit 2 (with
  * bit 0): the places the heuristic leaves empty go to the nearest candidates it passed over (keepPrunedConnections). */

@@ -2996,7 +2996,7 @@ ndbhip_ivf_delete(ndbhip_ivf *ix, const uint8_t *tids6, int64_t n, int64_t *remo
 		ix->norm_valid = false;
 		ix->s16_valid = planes_stay;	/* (ivf_free_rows has just cleared it) */
 		if (planes_stay)
-			g.stats.prepare_updates++;
+			NDB_STAT_ADD(prepare_updates, 1);
 		rc = ivf_set_layout(ix, newlen.data(), nullptr, (int64_t) total);
 	}
 	if (removed)
@@ -3248,6 +3248,7 @@ static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold ever
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_dense_spare = 0;	/* compute units k_s16c_dense leaves free on a mirror that has shares, i.e. steps in flight: the tile fills a CU's LDS and registers, so other steps' kernels run only where it is not ("screen16c_dense_spare") */
 static int	g_s16c_dense_split = 3;	/* 32-row blocks of a tile's eight that k_s16c_dense's loader waves multiply: 4 (as many as the multipliers) or 3 ("screen16c_dense_split") */
+static int	g_s16c_dense_sync = 16;	/* k_s16c_dense: the blocks of an XCD meet before every this many-th item, so that the blocks sharing an operand tile ask for its chunks within the L2's memory (0: never; "screen16c_dense_sync") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_wave = 2;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
 static int	g_s16c_plseed = 1;	/* first thresholds from the sweep's own planes (block 0 of the nearest sublist) instead of float4 rows ("screen16c_plane_seeds") */
@@ -3339,7 +3340,7 @@ ivf_s16_prepare(ndbhip_ivf *ix, int R)
 		std::vector<uint32_t> bo;
 		uint64_t	nb = 0;
 
-		g.stats.prepares++;
+		NDB_STAT_ADD(prepares, 1);
 		ix->ipc_valid = false;		/* (the rows' constants are indexed by padded plane row) */
 		ix->s16_sub = false;
 		ix->s16_sub_cfg = lay_cfg;
@@ -3617,7 +3618,7 @@ ivf_s16c_append(ndbhip_ivf *ix, const std::vector<int64_t> &add, const std::vect
 					   (const uint32_t *) d_bidx, (const uint32_t *) d_bval, (uint32_t) bidx.size());
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(g.stream));		/* the host arrays are locals */
-	g.stats.prepare_updates++;
+	NDB_STAT_ADD(prepare_updates, 1);
 	return 0;
 }
 
@@ -3809,7 +3810,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 		/* 64 < k: thresholds come from the sublists' radii (k_s16c_thr_radius) — a layout without sublists, or not centred,
 		 * has nothing to take them from: this mirror's batches with k > 64 go to the fp32 screen, this one included */
 		ix->s16_bigk_off = true;
-		g.stats.screen16_fallbacks++;
+		NDB_STAT_ADD(screen16_fallbacks, 1);
 		return 1;
 	}
 	/* (centred path: upper bounds summed by the whole wave instead of the reference's chain per lane: k_s16c_seed) */
@@ -4072,7 +4073,7 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 
 					if (rc)
 						return rc;
-					g.stats.sub_restricted++;
+					NDB_STAT_ADD(sub_restricted, 1);
 					subdist = ix->w_subdist;
 					sub_xmax = ix->dm_all.xmax;
 					sub_rn2 = ix->dm_all.rn2 + ix->dm_all_ncmp;
@@ -4347,7 +4348,8 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   (float2 *) ix->w_qthr, (const uint32_t *) cnt, (const uint32_t *) pair_off,                    \
 							   (const S16Desc *) ix->w_s16desc, (const uint32_t *) runs, ecount, ix->w_erec, ix->w_eub, ecap, \
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
-							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight)
+							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0, g_s16c_pfd, g_s16c_rot, (uint32_t) g_s16c_tight,   \
+							   next_item, dense_sync)
 			/* chunks in flight per wave of the register-streaming sweep: the option's value if it divides the item's chunks */
 #define S16C_WSWEEP_L(DD, IPXX, BLKK)                                                                                   \
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_wsweep<DD, IPXX, BLKK>), dim3(g.num_cus * g_s16c_wblk), dim3(256), 0, g.stream, \
@@ -4363,12 +4365,21 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 #define S16C_WSWEEP_D(DD, BLKK) do { if (ipc) S16C_WSWEEP_L(DD, true, BLKK); else S16C_WSWEEP_L(DD, false, BLKK); } while (0)
 			const unsigned dense_grid = (unsigned) std::max(8, g.num_cus - (ivf_frozen(ix) ? g_s16c_dense_spare : 0));
 
+			/* the XCD's blocks meet only where the items are alike — whole lists probed by hundreds of queries, every tile
+			 * full: the i.i.d. table; on the middle of the sigma sweep (128 pairs a list, tiles of every size) the meetings
+			 * cost 9-12 % (measured) */
+			const uint32_t dense_sync = (dense_k && !sub && ix->s16c_density >= 400.0f) ? (uint32_t) g_s16c_dense_sync : 0u;
+
 			if (dense_k)
-				g.stats.dense_sweeps++;
+			{
+				NDB_STAT_ADD(dense_sweeps, 1);
+				if (dense_sync)
+					HIP_TRY(hipMemsetAsync(next_item, 0, (size_t) 8 * NDB_QHEAD_STRIDE * sizeof(unsigned int), g.stream));
+			}
 			/* (two chunks in flight: the 168-register form whatever the blocks — at two blocks a compute unit it leaves a
 			 * third of the register file to the other steps' kernels, see --inflight) */
 			if (wd)
-				g.stats.wave_sweeps++;
+				NDB_STAT_ADD(wave_sweeps, 1);
 			if (wd == 2)
 				S16C_WSWEEP_D(2, 3);
 			else if (wd == 3)
@@ -4554,13 +4565,13 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			ix->redo.resize(over_n);
 			HIP_TRY(hipMemcpyAsync(ix->redo.data(), ix->w_overq, (size_t) over_n * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
 			HIP_TRY(hipStreamSynchronize(g.stream));
-			g.stats.screen16_batches++;
+			NDB_STAT_ADD(screen16_batches, 1);
 			return 2;
 		}
-		g.stats.screen16_fallbacks++;
+		NDB_STAT_ADD(screen16_fallbacks, 1);
 		return 1;
 	}
-	g.stats.screen16_batches++;
+	NDB_STAT_ADD(screen16_batches, 1);
 	return 0;
 }
 
@@ -4838,6 +4849,12 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16c_dense"))
 		g_s16c_dense = value != 0;
+	else if (!strcmp(name, "screen16c_dense_sync"))
+	{
+		if (value < 0 || value > 1024)
+			return fail(NDBHIP_ERR_INVALID, "screen16c_dense_sync must be 0..1024");
+		g_s16c_dense_sync = value;
+	}
 	else if (!strcmp(name, "screen16c_dense_split"))
 	{
 		if (value != 3 && value != 4)
@@ -5176,7 +5193,7 @@ ivf_search_chunk(ndbhip_ivf *ix, const float *d_q, int nq, int strategy, int npr
 						   ncmp, ix->ncent, npr, (const uint32_t *) d.glob_len, d.own_lo, d.own_len,
 						   (uint64_t) (max_candidates > 0 ? max_candidates : 0), ix->dim * (ix->f16 ? 2 : 4),
 						   w_probes, ix->w_candoff, lco_w, g.d_counters, 1, (const uint8_t *) ix->w_cfull);
-		g.stats.cent_screen_batches++;
+		NDB_STAT_ADD(cent_screen_batches, 1);
 		cent_done = true;
 	}
 	if (!d_probes_in && !cent_done)
@@ -5739,7 +5756,7 @@ ivf_search_device_impl(ndbhip_ivf *ix, const float *d_queries, int nq, int strat
 		if (rc)
 			return rc;
 	}
-	g.stats.queries += (uint64_t) nq;
+	NDB_STAT_ADD(queries, (uint64_t) nq);
 	return NDBHIP_OK;
 }
 

@@ -3269,7 +3269,7 @@ ndbhip_hnsw_search_device(ndbhip_hnsw *h, const float *d_queries, int nq, int st
 #undef LAUNCH_HNSW_SEARCH
 	if (t.stop()) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipGetLastError());
-	g.stats.queries += (uint64_t) nq;
+	NDB_STAT_ADD(queries, (uint64_t) nq);
 	return NDBHIP_OK;
 }
 
@@ -3337,7 +3337,7 @@ ndbhip_hnsw_search_layer_device(ndbhip_hnsw *h, const float *d_queries, int nq, 
 					   d_out_count, d_out_tids, (long long *) d_out_scored);
 	if (t.stop()) return NDBHIP_ERR_HIP;
 	HIP_TRY(hipGetLastError());
-	g.stats.queries += (uint64_t) nq;
+	NDB_STAT_ADD(queries, (uint64_t) nq);
 	return NDBHIP_OK;
 }
 

@@ -92,6 +92,9 @@ struct Ctx
 	bool		big_cache_on = true;
 };
 extern Ctx	g;
+/* the library's counters are bumped by every thread that has a batch in flight (ndbhip_set_thread_stream: the bench's lanes,
+ * a service with several owner threads): relaxed atomic adds, read by ndbhip_stats_get as plain loads */
+#define NDB_STAT_ADD(FIELD, N) __atomic_fetch_add(&g.stats.FIELD, (uint64_t) (N), __ATOMIC_RELAXED)
 extern std::mutex ndbhip_g_mtx;		/* g's event pools and block cache, when several threads search at once */
 int			big_alloc(void **out, size_t bytes);
 void		big_free(void *p);
@@ -120,7 +123,7 @@ struct ScanTimer
 	{
 		std::lock_guard<std::mutex> lk(ndbhip_g_mtx);
 
-		g.stats.scan_launches++;
+		NDB_STAT_ADD(scan_launches, 1);
 		if (!g.profile)
 			return 0;
 		if (!g.pool.empty()) { ev = g.pool.back(); g.pool.pop_back(); }

@@ -62,7 +62,9 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			 uint32_t desc_cap, uint32_t topk, const uint32_t *__restrict__ pos_of, float cE,
 			 uint32_t qc_cap, int cosine, int pfd /* chunks the prefetch runs ahead of the operand stream (0: none) */,
 			 int rot /* 1: an item's chunks start at a rotation given by its row tile (see `enter`) */,
-			 uint32_t tight /* a query's threshold is tightened every time it has emitted this many more records (a power of two) */ )
+			 uint32_t tight /* a query's threshold is tightened every time it has emitted this many more records (a power of two) */,
+			 unsigned int *__restrict__ xsync = nullptr /* [8][NDB_QHEAD_STRIDE], zeroed: blocks of each XCD that have reached their next meeting */,
+			 uint32_t sync_every = 0 /* the blocks of an XCD meet before every this many-th item (0: never) */ )
 {
 	constexpr int T = S16D_T;
 	__shared__ uint32_t s_tn, s_tq[S16_TIGHT_Q], s_tkeys[S16_NB];
@@ -235,6 +237,8 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	const int	sw = (r32 >> 1) & 7;
 	const int	qfrag = S16D_QOFF + (2 * wq) * 4096 + r32 * 128;
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
+	uint32_t	n_item = 0;				/* items this block has begun */
+	bool		lonely = false;			/* (wave 0, lane 0) this block has given up waiting for its XCD's others */
 
 	S16D_PH_DECL;
 	enter(it_c, 0);
@@ -309,6 +313,44 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			g_c++;
 		};
 
+		/*
+		 * The 32 blocks of an XCD multiply 4 row tiles x 8 pair tiles at a time and a tile's chunk is asked for by the 8 (4)
+		 * blocks that share it; it is fetched from memory ONCE only if they ask within the few microseconds a line survives
+		 * in the 4 MB L2 under this stream.  Blocks start together and their items take the same time to within a
+		 * microsecond or two, but that drifts: every `sync_every` items the blocks of an XCD meet again (a counter in the
+		 * XCD's L2; the last generation's participants are the blocks that still have an item).  Wave 0 waits, the others
+		 * wait for it at the first chunk's barrier.  Measured on the i.i.d. table (PMC FETCH_SIZE, same box): never 19.1 GB a
+		 * launch, every item 9.8 GB (+ 9 % time), every 8th 10.3 GB (+ 1.2 %), every 16th 11.2 GB (no time), every 32nd
+		 * 12.6 GB (no time).
+		 */
+		if (sync_every != 0 && n_item % sync_every == 0 && wave == 0)
+		{
+			if (lane == 0)
+			{
+				const uint32_t base = it_c - (blockIdx.x >> 3);		/* the first item of this generation in the run */
+				const uint32_t part = min(stride, run_hi - base);
+				const uint32_t target = (n_item / sync_every) * stride + part;
+				unsigned int *ctr = xsync + xq * NDB_QHEAD_STRIDE;
+
+				atomicAdd(ctr, 1u);
+				/* (bounded: two sweeps of different processes — or of two streams with "screen16_sweep_queue" 0 — can each
+				 * hold part of the device and wait for blocks that cannot start; a block that has waited some milliseconds
+				 * goes on alone and from then on only reports its arrival) */
+				if (!lonely)
+				{
+					int			spins = 0;
+
+					while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < 8192)
+					{
+						__builtin_amdgcn_s_sleep(2);
+						spins++;
+					}
+					lonely = spins >= 8192;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+		n_item++;
 		chunk();
 		/* the members' thresholds as they stand now (in-sweep tightening; a stale value is a valid, looser bound): the one
 		 * ordinary vector-memory read of an item, by the loaders' threads, behind the first chunk's barrier (the member
