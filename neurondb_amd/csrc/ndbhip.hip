@@ -3248,6 +3248,7 @@ static int	g_s16c_tight = 128;	/* k_s16c_dense tightens a query's threshold ever
 static int	g_s16c_rot = 0;		/* k_s16c_dense takes an item's chunks in an order rotated by its row tile ("screen16c_rot") */
 static int	g_s16c_dense_spare = 0;	/* compute units k_s16c_dense leaves free on a mirror that has shares, i.e. steps in flight: the tile fills a CU's LDS and registers, so other steps' kernels run only where it is not ("screen16c_dense_spare") */
 static int	g_s16c_dense_split = 3;	/* 32-row blocks of a tile's eight that k_s16c_dense's loader waves multiply: 4 (as many as the multipliers) or 3 ("screen16c_dense_split") */
+static int	g_s16c_dense_small = 1;	/* k_s16c_dense: tiles of <= 128 members take the one-pair-block wave map ("screen16c_dense_small") */
 static int	g_s16c_dense_sync = 16;	/* k_s16c_dense: the blocks of an XCD meet before every this many-th item, so that the blocks sharing an operand tile ask for its chunks within the L2's memory (0: never; "screen16c_dense_sync") */
 static int	g_s16c_pfd = 0;		/* chunks k_s16c_dense's prefetchers run ahead of its loaders, 0 = no prefetch ("screen16c_pfd") */
 static int	g_s16c_wave = 2;	/* sparse pair tables (32-pair tiles): k_s16c_wsweep (ndbhip_screen16w.h: wave-autonomous register streams) with this many chunks a wave in flight (2 .. 4; at most the chunks of a row); 0: k_s16c_sweep<1, NBUF>, the LDS ring ("screen16c_wave") */
@@ -4337,9 +4338,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 							   ix->w_bmin, dimp / S16C_CH, desc_cap, g_s16_tighten ? (uint32_t) k : 0u,                       \
 							   (const uint32_t *) ix->d_pposof, cE, qc_cap, cosb ? 1 : 0,                                       \
 							   ipc ? (const float *) ix->d_rnx : (const float *) nullptr, ipc ? (const float *) ix->w_qev : (const float *) nullptr)
-#define S16C_DENSE_L(DB) S16C_DENSE_LS(DB, 4)
-#define S16C_DENSE_LS(DB, NBLL)                                                                                      \
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_dense<DB, NBLL>), dim3(dense_grid), dim3(512), 0, g.stream,           \
+#define S16C_DENSE_L(DB) S16C_DENSE_LS(DB, 4, false)
+#define S16C_DENSE_LS(DB, NBLL, SMALLL)                                                                              \
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s16c_dense<DB, NBLL, SMALLL>), dim3(dense_grid), dim3(512), 0, g.stream,   \
 							   dim, ncs, (const int64_t *) ix->d_prow_off, (const uint32_t *) ds.own_len,                     \
 							   (const unsigned char *) ix->d_planes, sub ? (const uint32_t *) ix->d_sub_blk : (const uint32_t *) ix->d_blkoff, \
 							   (const float *) ix->d_rn2, (const int16_t *) ix->d_rexp, (const unsigned char *) ix->w_qcplanes, qc_plane * 2, \
@@ -4369,6 +4370,9 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 			 * full: the i.i.d. table; on the middle of the sigma sweep (128 pairs a list, tiles of every size) the meetings
 			 * cost 9-12 % (measured) */
 			const uint32_t dense_sync = (dense_k && !sub && ix->s16c_density >= 400.0f) ? (uint32_t) g_s16c_dense_sync : 0u;
+			/* ... and where the buckets are probed by a hundred queries or two, most tiles have 128 members at most: the kernel
+			 * with the one-pair-block wave map for those (sigma 0.5: sweep 1.48 -> 1.40 ms, sigma 1.0: 1.98 -> 1.95) */
+			const bool	dense_small = dense_k && g_s16c_dense_small && ix->s16c_density < 400.0f;
 
 			if (dense_k)
 			{
@@ -4390,8 +4394,10 @@ ivf_s16_run(ndbhip_ivf *ix, const IvfDev &d, const float *d_q, int nq, int R, in
 				S16C_DENSE_L(6);
 			else if (dense_k && g_s16_debug == 7)
 				S16C_DENSE_L(7);
+			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4) && g_s16c_dense_split == 3 && dense_small)
+				S16C_DENSE_LS(0, 3, true);
 			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4) && g_s16c_dense_split == 3)
-				S16C_DENSE_LS(0, 3);
+				S16C_DENSE_LS(0, 3, false);
 			else if (dense_k && (g_s16_debug < 1 || g_s16_debug > 4))
 				S16C_DENSE_L(0);
 			else if (dense_k && g_s16_debug == 1)
@@ -4849,6 +4855,8 @@ ndbhip_set_option(const char *name, int value)
 	}
 	else if (!strcmp(name, "screen16c_dense"))
 		g_s16c_dense = value != 0;
+	else if (!strcmp(name, "screen16c_dense_small"))
+		g_s16c_dense_small = value != 0;
 	else if (!strcmp(name, "screen16c_dense_sync"))
 	{
 		if (value < 0 || value > 1024)

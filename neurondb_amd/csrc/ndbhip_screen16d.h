@@ -48,7 +48,9 @@
 #define S16D_PH_FLUSH ((void) 0)
 #endif
 
-template <int DBG = 0, int NBL = 4 /* 32-row blocks of the tile's eight that a loader wave multiplies; its SIMD's multiplier takes the rest */>
+template <int DBG = 0, int NBL = 4 /* 32-row blocks of the tile's eight that a loader wave multiplies; its SIMD's multiplier takes the rest */,
+		  bool SMALL = false /* tiles of <= 128 members take the one-pair-block wave map (a kernel of its own: the third copy of the item
+							  * costs the full tiles' path a few spilled registers, 1 % on the i.i.d. table, which has no such tile) */>
 __global__ __launch_bounds__(512, 1) void
 k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const uint32_t *__restrict__ own_len,
 			 const unsigned char *__restrict__ planes, const uint32_t *__restrict__ blk_off,
@@ -235,7 +237,6 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	};
 
 	const int	sw = (r32 >> 1) & 7;
-	const int	qfrag = S16D_QOFF + (2 * wq) * 4096 + r32 * 128;
 	uint32_t	c_par = 0, g_c = 0;		/* parity of the item being multiplied; chunks consumed so far */
 	uint32_t	n_item = 0;				/* items this block has begun */
 	bool		lonely = false;			/* (wave 0, lane 0) this block has given up waiting for its XCD's others */
@@ -254,10 +255,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 	 * it ~1360 cycles in which it issues no matrix instruction, and its sibling's 32 are done after 1024 — with 24 for the
 	 * loader and 40 for the multiplier the pipe has work until the loader's requests are out.
 	 */
-	auto		run = [&](auto nbc, const int rb0) {
-	constexpr int NB = decltype(nbc)::value;
-	const int	rfrag = rb0 * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
-
+	auto		run = [&](auto nbc0, const int rb00) {
 	for (;;)
 	{
 		/* the item being multiplied: its descriptor again (scalar cache) */
@@ -265,10 +263,22 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 		const uint32_t L = dc.L, t2 = dc.t2;
 		const uint32_t nmem_cur = min((uint32_t) T, cnt[L] - dc.qt * T);
 		const uint32_t len = own_len[L];
-		ndb_f16acc	acc[2][NB];
+
+		/*
+		 * One item for a wave that has NA pair blocks from block pb0 and NB row blocks from block rb0.  A tile with more than
+		 * 128 members: two pair blocks (its SIMD's pair of 64) and the role's row blocks.  A tile with 128 members at most
+		 * (SMALL; a bucket probed by a hundred queries — the middle of the sigma sweep — is mostly such tiles): the upper two
+		 * of the four 64-pair groups are empty, so every wave takes ONE 32-pair block and four row blocks — the eight
+		 * waves cover 4 x 8 blocks, nobody multiplies an empty block, the loaders skip the empty pair pieces as before.
+		 */
+		auto		item = [&](auto nac, auto nbc, const int pb0, const int rb0) {
+		constexpr int NA = decltype(nac)::value, NB = decltype(nbc)::value;
+		const int	rfrag = rb0 * 4096 + lane * 16;		/* (fragment-major row images: s16c_unit) */
+		const int	qfrag = S16D_QOFF + pb0 * 4096 + r32 * 128;
+		ndb_f16acc	acc[NA][NB];
 
 #pragma unroll
-		for (int a = 0; a < 2; a++)
+		for (int a = 0; a < NA; a++)
 #pragma unroll
 			for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -277,22 +287,22 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 		/* pair blocks of this wave that hold a member (wave-uniform; the empty ones are multiplied all the same: without
 		 * the test the k-steps are straight-line code, the next one's ds_reads issued under this one's MFMAs) */
-		const int	na = (nmem_cur > (uint32_t) (32 * (2 * wq)) ? 1 : 0) + (nmem_cur > (uint32_t) (32 * (2 * wq + 1)) ? 1 : 0);
+		const int	na = (nmem_cur > (uint32_t) (32 * pb0) ? 1 : 0) + ((NA > 1 && nmem_cur > (uint32_t) (32 * (pb0 + 1))) ? 1 : 0);
 
 		auto		compute = [&](const unsigned char *buf) {
 #pragma unroll
 			for (int s = 0; s < 4; s++)
 			{
-				ndb_h8		ah[2], bh[NB];
+				ndb_h8		ah[NA], bh[NB];
 
 #pragma unroll
-				for (int a = 0; a < 2; a++)
+				for (int a = 0; a < NA; a++)
 					ah[a] = *reinterpret_cast<const ndb_h8 *>(buf + qfrag + a * 4096 + (((2 * s + kh) ^ sw) * 16));
 #pragma unroll
 				for (int b = 0; b < NB; b++)
 					bh[b] = *reinterpret_cast<const ndb_h8 *>(buf + rfrag + b * 4096 + s * 1024);
 #pragma unroll
-				for (int a = 0; a < 2; a++)
+				for (int a = 0; a < NA; a++)
 #pragma unroll
 					for (int b = 0; b < NB; b++)
 						acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
@@ -503,7 +513,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			hq_n = 0;
 		};
 		/* pass 0's operands, once per item: the rows' (w, 2^-ex) by row block, the members' (v, u) by pair block */
-		float		wbv[NB], uav[2];
+		float		wbv[NB], uav[NA];
 		uint32_t	deadm = 0;			/* bit b: this lane's row of row block b is no row (beyond the bucket, or a hole) */
 
 #pragma unroll
@@ -520,17 +530,17 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			deadm |= dead ? 1u << b : 0u;
 		}
 #pragma unroll
-		for (int a = 0; a < 2; a++)
-			uav[a] = s_nuv[kh][32 * (2 * wq + a) + r32];
-		/* block n of the wave's 2 NB: pair block n & 1, row block n >> 1.  The test instruction of block n + 1 is issued
+		for (int a = 0; a < NA; a++)
+			uav[a] = s_nuv[kh][32 * (pb0 + a) + r32];
+		/* block n of the wave's NA NB: pair block n % NA, row block n / NA.  The test instruction of block n + 1 is issued
 		 * before block n's result is looked at (two result windows: the operand fragments' registers are free by now) */
 		auto		pass0 = [&](auto nc) {
-			constexpr int a = decltype(nc)::value & 1, b = decltype(nc)::value >> 1;
+			constexpr int a = decltype(nc)::value % NA, b = decltype(nc)::value / NA;
 
 			return __builtin_amdgcn_mfma_f32_32x32x2f32(uav[a], wbv[b], acc[a][b], 0, 0, 0);
 		};
 		auto		look = [&](auto nc, const ndb_f16acc &fin) {
-			constexpr int a = decltype(nc)::value & 1, b = decltype(nc)::value >> 1;
+			constexpr int a = decltype(nc)::value % NA, b = decltype(nc)::value / NA;
 			const int	ri = 32 * (rb0 + b) + r32;
 			int			mx = (int) 0x80000000;
 
@@ -578,7 +588,7 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 
 				if (has)
 				{
-					const int	m = 32 * (2 * wq + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+					const int	m = 32 * (pb0 + a) + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
 					const uint32_t idx = hq_n + (uint32_t) __popcll(bal & ((1ull << lane) - 1ull));
 
 					mask &= ~(1u << reg);
@@ -591,8 +601,8 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 			ndb_f16acc	fin0, fin1;
 
 			/* (a = 1 blocks of a tile with <= 32 members here are not looked at: uniform) */
-#define S16D_P0(N, F) do { if constexpr ((N) < 2 * NB) { if (((N) & 1) < na) F = pass0(std::integral_constant<int, (N)>{}); } } while (0)
-#define S16D_LK(N, F) do { if constexpr ((N) < 2 * NB) { if (((N) & 1) < na) look(std::integral_constant<int, (N)>{}, F); } } while (0)
+#define S16D_P0(N, F) do { if constexpr ((N) < NA * NB) { if (((N) % NA) < na) F = pass0(std::integral_constant<int, (N)>{}); } } while (0)
+#define S16D_LK(N, F) do { if constexpr ((N) < NA * NB) { if (((N) % NA) < na) look(std::integral_constant<int, (N)>{}, F); } } while (0)
 			if constexpr (NB <= 4)
 			{
 				S16D_P0(0, fin0);
@@ -666,6 +676,16 @@ k_s16c_dense(int dim, int nbuckets, const int64_t *__restrict__ loc_off, const u
 				s_tn = 0;
 		}
 		S16D_PH(5);
+		};		/* item */
+		if constexpr (SMALL)
+		{
+			if (nmem_cur <= 128u)
+				item(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, wave & 3, 4 * (wave >> 2));
+			else
+				item(std::integral_constant<int, 2>{}, nbc0, 2 * wq, rb00);
+		}
+		else
+			item(std::integral_constant<int, 2>{}, nbc0, 2 * wq, rb00);
 		it_c += stride;
 		if (it_c >= run_hi)
 			break;

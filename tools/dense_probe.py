@@ -38,7 +38,7 @@ def main():
     ref = None
     variants = sys.argv[1:] or [""]
     defaults = {}
-    default_of = {"screen16c_epi": 1, "screen16c_rot": 0, "screen16c_dense": 1, "screen16c_pfd": 0, "screen16c_sample": 2048, "screen16c_tight": 128, "screen16c_dense_split": 3, "screen16c_dense_sync": 16}
+    default_of = {"screen16c_epi": 1, "screen16c_rot": 0, "screen16c_dense": 1, "screen16c_pfd": 0, "screen16c_sample": 2048, "screen16c_tight": 128, "screen16c_dense_split": 3, "screen16c_dense_sync": 16, "screen16c_dense_small": 1}
     for v in variants:
         opts = dict(kv.split("=") for kv in v.split(",") if kv)
         for k in list(defaults):
