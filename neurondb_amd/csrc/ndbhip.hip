@@ -3232,8 +3232,11 @@ static int	g_s16c_sample = 2048;	/* rows of the mirror sampled for a dense batch
  * 0.82 against the ring's 0.86 ms, 74: 1.30 / 1.58, 133: 2.14 / 2.90 (25: 0.56 / 0.48 — the ring's); layouts with sublists
  * (buckets of ~128 rows fill half a row tile) 131: 1.56 / 1.79, 72: 1.04 / 1.01, 45: 0.76 / 0.59.  Until round 5 the rule
  * was 320 and whole lists only: a balanced table at 4096 queries (128 pairs a list) stayed on the 128 x 128 ring at 0.2 of
- * the matrix peak. */
-static int	g_s16c_dense_min = 48;		/* "screen16c_dense_min" */
+ * the matrix peak.  Later in round 6, with the kernel's one-pair-block map for tiles of <= 128 members (SMALL): whole lists
+ * at 24 / 32 / 48 pairs a bucket 0.60 / 0.75 / 0.96 against the ring's 0.66 / 0.83 / 1.18 ms — from 24 (where the 32-pair
+ * tile's sparse sweeps end); with sublists the two meet around 64 (0.94 / 0.97 ms) and the ring wins below (0.80 / 0.77 at
+ * 48): 100 stays. */
+static int	g_s16c_dense_min = 24;		/* "screen16c_dense_min" */
 static int	g_s16c_dense_min_sub = 100;	/* "screen16c_dense_min_sub": the same for regrouped planes (sublists); 0 = never */
 /* "screen16_sub_restrict": from this many regrouped-list centres on, a batch scores the centres of its PROBED lists only
  * (k_subdist_lists, list-major, fp32 vector ALU) instead of multiplying every query by every centre along with the

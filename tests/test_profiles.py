@@ -151,7 +151,7 @@ def test_round_6_artefacts_agree_with_each_other():
     assert d["serial"]["lanes_identical_to_serial"] and d["step_latency_ms"] >= d["ms_per_step"]
     for name, leg in d["sigma_sweep"].items():
         assert leg["recall_at_10"] >= 0.99 and leg["oracle_mismatches"] == 0, name
-    # the middle of the sweep runs the dense tile now (round 6: from 48 pairs a bucket)
+    # the middle of the sweep runs the dense tile now (round 6: from 48, later 24 pairs a bucket)
     assert d["sigma_sweep"]["s1.0"]["kernel"] == "k_s16c_dense" and d["sigma_sweep"]["s1.0"]["queries_per_s"] > 1.2e6
     h = d["hnsw"]
     assert h["strategy"] == 2 and h["recall_at_10"] >= 0.90 and h["intended_oracle_parity_mismatches"] == 0 and h["queries_per_s"] > 2e6
