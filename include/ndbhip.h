@@ -187,6 +187,22 @@ int			ndbhip_set_scan_mode(int mode);
  *   "screen16c_bigk"    1     64 < k <= 256 on the centred fp16 screen (L2, sublists): thresholds from the buckets' radii (k_s16c_thr_radius); 0: the fp32 screen serves k > 64
  *   "screen16c_sample"  2048  rows of the mirror sampled for the first thresholds of a batch on a table without cluster structure
  *                             (k_s16c_seed_sample: all queries x the sample as one matrix on the matrix cores); 0 = seeds only, 256..2048
+ *   "screen16c_dense_min" 24, "screen16c_dense_min_sub" 100  the dense tile's kernel from this many (query, bucket) pairs a bucket in the
+ *                             previous batch on this mirror: whole lists / layouts with sublists (0 = never); below: the 128-pair ring,
+ *                             below 24 the 32-pair tile (sparse tables)
+ *   "screen16c_wave"    2     the 32-pair tile as wave-autonomous register streams (k_s16c_wsweep): chunks in flight a wave, 2 | 3 | 4; 0 = the LDS ring
+ *   "screen16c_wave_blocks" 2 blocks of k_s16c_wsweep a compute unit (1 .. 3), "screen16c_wave_min_nq" 1024: batches below take the ring
+ *   "screen16c_plane_seeds" 1 L2 / inner product: a query's first threshold from block 0 of the nearest sublist's planes (0: from float4 rows)
+ *   "screen16_sweep_queue" 1  sweeps of different streams (steps in flight) take turns on the device; 0 = launched as they come
+ *   "screen16_sub_restrict" 0 from this many regrouped-list centres on a batch scores the centres of its PROBED lists only (0 = never)
+ *   "build_single_sweep" 1    build assignment: row minima and candidate records in ONE matrix sweep + a resolve kernel (0: two sweeps)
+ *   "kmeans_screen16"   1     k-means iterations assign on the matrix cores like the build does (0: exact kernels)
+ *   "slow_call_log"     0     a search call slower than this many microseconds reports its host-side phases on stderr
+ *   "screen16c_dense_split" 3  k_s16c_dense: 32-row blocks (of a tile's eight) a loader wave multiplies, its SIMD's multiplier the rest (3 | 4)
+ *   "screen16c_dense_sync" 16  k_s16c_dense on tables of whole full tiles: the blocks of an XCD meet before every this many-th item, so
+ *                             that the blocks sharing an operand tile ask for its chunks while the XCD's L2 still has them (0 = never)
+ *   "screen16c_dense_small" 1  tables below 400 pairs a bucket: the kernel whose tiles of <= 128 members run with one pair block a wave
+ *   "screen16c_dense_spare" 0  compute units k_s16c_dense leaves to other steps' kernels on a mirror with shares (measured: no gain)
  *   "screen16c_tight"   128   k_s16c_dense tightens a query's threshold every this many records (power of two, 8..1024)
  *   "screen16c_pfd"     0     chunks k_s16c_dense's prefetcher waves touch ahead of its loaders (0 = none: measured slower on MI355X), 0..10
  *   "screen16c_rot"     0     k_s16c_dense takes an item's chunks in an order rotated by its row tile (1) / pair tile (2); 0 = in order
