@@ -65,7 +65,11 @@ def test_every_documented_option_is_accepted_and_bad_ones_are_refused():
                 "screen16_sub_min": 256, "screen16_sub_rows": 128, "screen16_centered": 1, "cent_screen16": 1, "screen16_fin_threads": 64, "screen16_waves": 4,
                 "probe_select_threads": 256, "probe_select_radix": 0, "build_screen16": 1, "block_cache": 1, "gchunk": 32,
                 "scr_coop": 2, "scr_mfma": 1, "screen": 1, "screen16_slack": 1, "screen_min_nq": 5, "screen16_cosine": 1, "hnsw_intended_waves": 16, "screen16_cosine_centered": 1, "screen16_redo": 1,
-                "screen16c_dense": 1, "screen16c_sample": 2048, "screen16c_tight": 128, "screen16c_epi": 1, "screen16_stage": 1, "screen16_ip_centered": 1}
+                "screen16c_dense": 1, "screen16c_sample": 2048, "screen16c_tight": 128, "screen16c_epi": 1, "screen16_stage": 1, "screen16_ip_centered": 1,
+                "screen16c_dense_min": 24, "screen16c_dense_min_sub": 100, "screen16c_wave": 2, "screen16c_wave_blocks": 2,
+                "screen16c_wave_min_nq": 1024, "screen16c_plane_seeds": 1, "screen16_sweep_queue": 1, "screen16_sub_restrict": 0,
+                "build_single_sweep": 1, "kmeans_screen16": 1, "slow_call_log": 0, "screen16c_dense_split": 3,
+                "screen16c_dense_sync": 16, "screen16c_dense_small": 1, "screen16c_dense_spare": 0, "screen16c_bigk": 1, "scr_ch": 16}
     for n in sorted(names):
         rc = L.ndbhip_set_option(n.encode(), defaults.get(n, 0))
         assert rc == 0, (n, L.ndbhip_last_error().decode() if hasattr(L, "ndbhip_last_error") else rc)
