@@ -157,6 +157,30 @@ def test_c_oracle_equals_the_python_restatement_of_the_reference(kind, seed):
             assert np.array_equal(d.view(np.uint32), np.asarray(dist_p, np.float32).view(np.uint32)), (kind, strategy)
 
 
+def test_the_case_round_6_fuzz_found_is_pinned_by_both_restatements():
+    """tests/golden/fuzz_r6_dup_probe_seed.npz (the mirror and queries of the one mismatch round 6's long fuzz campaigns
+    found: nlists = 1, nprobe = 2 — list 0 scanned twice, ivf_am.c:1978 — candidate cap 500 over 2 x 373 rows, k = 1): the C
+    oracle and the Python restatement agree on it, every query has its neighbour, and the second pass of list 0 contributes
+    exactly cap - 373 = 127 candidates (what the device's seed kernel has to count rows against, tests/test_gpu_screen16.py)."""
+    import os
+    from tests.util import oracle_image
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz_r6_dup_probe_seed.npz"))
+    a = dict(centroids=z["centroids"], list_len=z["list_len"], rows=z["rows"], tids=z["tids"])
+    img = oracle_image(a)
+    q, k, nprobe, cap, strategy = z["q"], int(z["k"]), int(z["nprobe"]), int(z["cap"]), int(z["strategy"])
+    assert img.nlists == 1 and nprobe == 2 and cap == 500 and len(a["rows"]) == 373 and k == 1 and strategy == 1
+    for i in range(len(q)):
+        rows_p, dist_p = ref_search(img, q[i], strategy, nprobe, k, cap)
+        t, d, total = img.search(q[i], strategy, nprobe, k, cap)
+        assert len(t) == len(rows_p) == 1
+        assert np.array_equal(ndbo.tids_to_u64(t), ndbo.tids_to_u64(img.tids[np.asarray(rows_p, np.int64)]))
+        assert np.array_equal(d.view(np.uint32), np.asarray(dist_p, np.float32).view(np.uint32))
+        assert total == cap                                        # 373 rows of the first pass + 127 of the second
+        # the neighbour is the float64 nearest row (no tie anywhere near on this data)
+        d2 = ((a["rows"].astype(np.float64) - q[i].astype(np.float64)) ** 2).sum(1)
+        assert rows_p[0] == int(np.argmin(d2))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The build: kmeans_init / kmeans_run and their helpers (ivf_am.c:2070-2294) and the insert-time choice of a list
 # (:812-814, :905-935), restated the same way.
